@@ -1,0 +1,247 @@
+"""ctypes bindings for the oracle libraries (test infrastructure only)."""
+import ctypes as C
+import os
+import subprocess
+import threading
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "liboracle.so")
+REF_LIB = os.path.join(HERE, "_ref", "libstrawberry_ref.so")
+REF_BIN = os.path.join(HERE, "_ref", "strawberry_ref")
+SAM2BAM = os.path.join(HERE, "_ref", "sam2bam")
+REFERENCE_ROOT = "/root/reference"
+
+SBO_EM_OK, SBO_EM_INIT_EMPTY, SBO_EM_DENOM_ZERO, SBO_EM_MAXITER = 0, 1, 2, 3
+
+_p = np.ctypeslib.ndpointer
+_i32 = _p(np.int32, flags="C")
+_i64 = _p(np.int64, flags="C")
+_u32 = _p(np.uint32, flags="C")
+_f64 = _p(np.float64, flags="C")
+
+
+def build(with_ref=None):
+    """Compile liboracle.so; compile oracle/_ref too when /root/reference is mounted."""
+    subprocess.check_call(["make", "-s", "-C", HERE, "all"])
+    if with_ref is None:
+        with_ref = os.path.isdir(os.path.join(REFERENCE_ROOT, "src"))
+    if with_ref:
+        subprocess.check_call(["make", "-s", "-j4", "-C", HERE, "ref"])
+
+
+def have_ref():
+    return os.path.exists(REF_LIB)
+
+
+class sbo_insert_t(C.Structure):
+    _fields_ = [
+        ("mean", C.c_double),
+        ("sd", C.c_double),
+        ("use_emp", C.c_int32),
+        ("start_offset", C.c_int32),
+        ("end_offset", C.c_int32),
+        ("total_reads", C.c_int32),
+        ("emp_hist", C.POINTER(C.c_double)),
+    ]
+
+
+def _csr(row_off, iso_off, f_off, count, F):
+    return (
+        np.ascontiguousarray(row_off, np.int64),
+        np.ascontiguousarray(iso_off, np.int64),
+        np.ascontiguousarray(f_off, np.int64),
+        np.ascontiguousarray(count, np.int32),
+        np.ascontiguousarray(F, np.float64),
+    )
+
+
+def _run_threads(fn, n_loci, threads):
+    if threads <= 1 or n_loci < 2 * threads:
+        fn(0, n_loci)
+        return
+    # static contiguous partition (the analogue of `-p T`); ctypes
+    # releases the GIL for the duration of each foreign call
+    bounds = [n_loci * t // threads for t in range(threads + 1)]
+    ts = [threading.Thread(target=fn, args=(bounds[t], bounds[t + 1])) for t in range(threads)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+
+
+class OracleLib:
+    """liboracle.so -- the plain-C restatement."""
+
+    def __init__(self, path=LIB):
+        if not os.path.exists(path):
+            build(with_ref=False)
+        L = self.L = C.CDLL(path)
+        L.sbo_em_locus.argtypes = [C.c_int, C.c_int, _i32, _f64, _f64, C.POINTER(C.c_int32)]
+        L.sbo_em_locus.restype = C.c_int
+        L.sbo_em_batch.argtypes = [C.c_int64, C.c_int64, _i64, _i64, _i64, _i32, _f64, _f64, _i32, _i32]
+        L.sbo_em_batch.restype = None
+        L.sbo_abundance_locus.argtypes = [C.c_int, _f64, _i32, C.c_int32, C.c_int, C.c_double, C.c_int,
+                                          C.c_double, _f64, _f64, _i32]
+        L.sbo_abundance_locus.restype = C.c_double
+        L.sbo_tpm.argtypes = [C.c_int64, _f64, _i32, _f64]
+        L.sbo_tpm.restype = C.c_double
+        L.sbo_insert_pdf.argtypes = [C.POINTER(sbo_insert_t), C.c_uint32]
+        L.sbo_insert_pdf.restype = C.c_double
+        L.sbo_no_gap_ef.argtypes = [C.c_int] * 4
+        L.sbo_no_gap_ef.restype = C.c_int
+        L.sbo_gap_ef.argtypes = [C.c_int] * 5
+        L.sbo_gap_ef.restype = C.c_int
+        L.sbo_effective_len.argtypes = [C.c_int, _u32, C.c_int, _u32, C.c_int, C.c_int]
+        L.sbo_effective_len.restype = C.c_int
+        L.sbo_bin_weight.argtypes = [C.c_int, _u32, C.c_int, _u32, C.c_int, C.c_int, C.POINTER(sbo_insert_t)]
+        L.sbo_bin_weight.restype = C.c_double
+
+    # ---- EM
+    def em_locus(self, count, F):
+        """-> (theta[niso], status, iters) for one locus; F is (nrow, niso)."""
+        F = np.ascontiguousarray(F, np.float64)
+        nrow, niso = F.shape
+        count = np.ascontiguousarray(count, np.int32)
+        assert count.shape == (nrow,)
+        theta = np.zeros(niso, np.float64)
+        it = C.c_int32(0)
+        st = self.L.sbo_em_locus(nrow, niso, count, F.reshape(-1), theta, C.byref(it))
+        return theta, st, it.value
+
+    def em_batch(self, row_off, iso_off, f_off, count, F, threads=1):
+        row_off, iso_off, f_off, count, F = _csr(row_off, iso_off, f_off, count, F)
+        n = len(row_off) - 1
+        theta = np.zeros(int(iso_off[-1]), np.float64)
+        status = np.zeros(n, np.int32)
+        iters = np.zeros(n, np.int32)
+        _run_threads(
+            lambda lo, hi: self.L.sbo_em_batch(lo, hi, row_off, iso_off, f_off, count, F, theta, status, iters),
+            n, threads)
+        return theta, status, iters
+
+    # ---- epilogue
+    def abundance_locus(self, theta, length, total_mapped, effective_len_norm=False, insert_mean=0.0,
+                        filter_by_expression=True, min_isoform_frac=0.01):
+        theta = np.ascontiguousarray(theta, np.float64)
+        length = np.ascontiguousarray(length, np.int32)
+        n = len(theta)
+        fpkm, frac, keep = np.zeros(n), np.zeros(n), np.zeros(n, np.int32)
+        s = self.L.sbo_abundance_locus(n, theta, length, int(total_mapped), int(effective_len_norm),
+                                       float(insert_mean), int(filter_by_expression), float(min_isoform_frac),
+                                       fpkm, frac, keep)
+        return fpkm, frac, keep, s
+
+    def tpm(self, fpkm, keep):
+        fpkm = np.ascontiguousarray(fpkm, np.float64)
+        keep = np.ascontiguousarray(keep, np.int32)
+        out = np.zeros(len(fpkm))
+        total = self.L.sbo_tpm(len(fpkm), fpkm, keep, out)
+        return out, total
+
+    # ---- bin-weight model
+    @staticmethod
+    def make_insert(mean=0.0, sd=1.0, frag_lens=None):
+        """Gaussian when frag_lens is None, else the empirical law built like
+        InsertSize(vector<int>) (src/read.cpp:241-272, mean/sd via
+        mean_and_sd_insert_size)."""
+        ins = sbo_insert_t()
+        ins._keep = None
+        if frag_lens is None:
+            ins.mean, ins.sd, ins.use_emp = float(mean), float(sd), 0
+            return ins
+        fl = np.asarray(frag_lens, np.int64)
+        lo, hi = int(fl.min()), int(fl.max())
+        hist = np.bincount(fl - lo, minlength=hi - lo + 1).astype(np.float64)
+        ins._keep = hist
+        ins.mean, ins.sd, ins.use_emp = float(mean), float(sd), 1
+        ins.start_offset, ins.end_offset, ins.total_reads = lo, hi, len(fl)
+        ins.emp_hist = hist.ctypes.data_as(C.POINTER(C.c_double))
+        return ins
+
+    def insert_pdf(self, ins, fl):
+        return self.L.sbo_insert_pdf(C.byref(ins), int(fl))
+
+    def effective_len(self, seg_lens, implicit_idx, fl, rl):
+        s = np.ascontiguousarray(seg_lens, np.uint32)
+        m = np.ascontiguousarray(implicit_idx, np.uint32)
+        if len(m) == 0:
+            m = np.zeros(1, np.uint32)
+            nimp = 0
+        else:
+            nimp = len(m)
+        return self.L.sbo_effective_len(len(s), s, nimp, m, int(fl), int(rl))
+
+    def bin_weight(self, seg_lens, implicit_idx, iso_len, rl, ins):
+        s = np.ascontiguousarray(seg_lens, np.uint32)
+        m = np.ascontiguousarray(implicit_idx, np.uint32)
+        nimp = len(m)
+        if nimp == 0:
+            m = np.zeros(1, np.uint32)
+        return self.L.sbo_bin_weight(len(s), s, nimp, m, int(iso_len), int(rl), C.byref(ins))
+
+
+class RefLib:
+    """oracle/_ref/libstrawberry_ref.so -- the reference's own objects behind ref_shim.cpp."""
+
+    def __init__(self, path=REF_LIB):
+        if not os.path.exists(path):
+            raise FileNotFoundError(path + " (run `make -C oracle ref` where /root/reference is mounted)")
+        L = self.L = C.CDLL(path)
+        L.ref_em_locus.argtypes = [C.c_int, C.c_int, _i32, _f64, _f64]
+        L.ref_em_locus.restype = C.c_int
+        L.ref_em_batch.argtypes = [C.c_int64, C.c_int64, _i64, _i64, _i64, _i32, _f64, _f64, _i32]
+        L.ref_em_batch.restype = None
+        L.ref_effective_len.argtypes = [C.c_int, _u32, C.c_int, _u32, C.c_int, C.c_int]
+        L.ref_effective_len.restype = C.c_int
+        L.ref_insert_pdf.argtypes = [C.c_double, C.c_double, C.c_int, _i32, C.c_int, C.c_int, _f64, _f64]
+        L.ref_insert_pdf.restype = None
+        L.ref_bin_weight.argtypes = [C.c_int, _u32, C.c_int, _u32, C.c_int, C.c_int, C.c_double, C.c_double,
+                                     C.c_int, _i32]
+        L.ref_bin_weight.restype = C.c_double
+
+    def em_locus(self, count, F):
+        """-> (theta, init_ok, run_ok) from the reference's EmSolver."""
+        F = np.ascontiguousarray(F, np.float64)
+        nrow, niso = F.shape
+        count = np.ascontiguousarray(count, np.int32)
+        theta = np.zeros(niso, np.float64)
+        fl = self.L.ref_em_locus(nrow, niso, count, F.reshape(-1), theta)
+        return theta, bool(fl & 1), bool(fl & 2)
+
+    def em_batch(self, row_off, iso_off, f_off, count, F, threads=1):
+        row_off, iso_off, f_off, count, F = _csr(row_off, iso_off, f_off, count, F)
+        n = len(row_off) - 1
+        theta = np.zeros(int(iso_off[-1]), np.float64)
+        flags = np.zeros(n, np.int32)
+        _run_threads(
+            lambda lo, hi: self.L.ref_em_batch(lo, hi, row_off, iso_off, f_off, count, F, theta, flags),
+            n, threads)
+        return theta, flags
+
+    def effective_len(self, seg_lens, implicit_idx, fl, rl):
+        s = np.ascontiguousarray(seg_lens, np.uint32)
+        m = np.ascontiguousarray(implicit_idx, np.uint32)
+        nimp = len(m)
+        if nimp == 0:
+            m = np.zeros(1, np.uint32)
+        return self.L.ref_effective_len(len(s), s, nimp, m, int(fl), int(rl))
+
+    def insert_pdf(self, mean, sd, frag_lens, fl_lo, fl_hi):
+        fl = np.zeros(1, np.int32) if frag_lens is None else np.ascontiguousarray(frag_lens, np.int32)
+        n = 0 if frag_lens is None else len(fl)
+        out = np.zeros(fl_hi - fl_lo + 1)
+        info = np.zeros(4)
+        self.L.ref_insert_pdf(float(mean), float(sd), n, fl, int(fl_lo), int(fl_hi), out, info)
+        return out, info
+
+    def bin_weight(self, seg_lens, implicit_idx, iso_len, rl, mean, sd, frag_lens=None):
+        s = np.ascontiguousarray(seg_lens, np.uint32)
+        m = np.ascontiguousarray(implicit_idx, np.uint32)
+        nimp = len(m)
+        if nimp == 0:
+            m = np.zeros(1, np.uint32)
+        fl = np.zeros(1, np.int32) if frag_lens is None else np.ascontiguousarray(frag_lens, np.int32)
+        n = 0 if frag_lens is None else len(fl)
+        return self.L.ref_bin_weight(len(s), s, nimp, m, int(iso_len), int(rl), float(mean), float(sd), n, fl)

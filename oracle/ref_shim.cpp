@@ -1,0 +1,119 @@
+/*
+ * oracle/ref_shim.cpp -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Our own thin extern-"C" wrapper around the REFERENCE's unmodified classes.
+ * It contains no reference code: it #includes the reference's headers from
+ * /root/reference/include at build time and is linked (oracle/Makefile, target
+ * `ref`) against objects compiled straight from /root/reference/src/ *.cpp.
+ * The result, oracle/_ref/libstrawberry_ref.so, is git-ignored; it is used to
+ *   - pin oracle/em_oracle.c (tests/test_oracle_vs_ref.py),
+ *   - generate tests/golden/ vectors (tools/make_goldens.py),
+ *   - serve as bench.py's cpu_baseline of kind "reference".
+ */
+#include <limits>
+#include <vector>
+#include <cstdint>
+#include <numeric>
+#include <set>
+
+#include "estimate.hpp" /* /root/reference/include/estimate.hpp:230-257 (EmSolver) */
+
+extern "C" {
+
+/* EmSolver em; em.init(niso, n, alpha); if (ok) em.run();  -- exactly the call
+ * sequence of src/estimate.cpp:305-308.
+ * returns: bit0 = init() result, bit1 = run() result.                        */
+int ref_em_locus(int nrow, int niso, const int32_t *count, const double *F,
+                 double *theta_out)
+{
+   std::vector<int> n(count, count + nrow);
+   std::vector<std::vector<double>> alpha((size_t)nrow, std::vector<double>((size_t)niso));
+   for (int i = 0; i < nrow; ++i)
+      for (int j = 0; j < niso; ++j) alpha[i][j] = F[(size_t)i * niso + j];
+   EmSolver em;
+   bool ok = em.init(niso, n, alpha);
+   bool ran = false;
+   if (ok) ran = em.run();
+   for (int j = 0; j < niso; ++j) theta_out[j] = em._theta[j];
+   return (ok ? 1 : 0) | (ran ? 2 : 0);
+}
+
+/* Batch form over the CSR-of-loci layout (include/sbgpu.h), loci [lo,hi). */
+void ref_em_batch(int64_t lo, int64_t hi, const int64_t *row_off,
+                  const int64_t *iso_off, const int64_t *f_off,
+                  const int32_t *count, const double *F, double *theta_out,
+                  int32_t *flags_out)
+{
+   for (int64_t l = lo; l < hi; ++l) {
+      int nrow = (int)(row_off[l + 1] - row_off[l]);
+      int niso = (int)(iso_off[l + 1] - iso_off[l]);
+      int fl = ref_em_locus(nrow, niso, count + row_off[l], F + f_off[l],
+                            theta_out + iso_off[l]);
+      if (flags_out) flags_out[l] = fl;
+   }
+}
+
+/* ExonBin::effective_len, include/isoform.h:419-516 (state-independent: it only
+ * reads its arguments), called on a dummy one-segment bin.                   */
+int ref_effective_len(int nseg, const uint32_t *seg_lens, int nimp,
+                      const uint32_t *implicit_idx, int fl, int rl)
+{
+   std::set<std::pair<uint, uint>> coords;
+   coords.insert(std::make_pair(1u, 2u));
+   ExonBin eb(coords);
+   std::vector<uint> sl(seg_lens, seg_lens + nseg);
+   std::vector<uint> imp(implicit_idx, implicit_idx + nimp);
+   return eb.effective_len(sl, imp, fl, rl);
+}
+
+/* InsertSize::emp_dist_pdf, src/read.cpp:274-297.  n_frag_lens==0 -> the
+ * Gaussian object InsertSize(mean, sd); else the empirical object built from
+ * the fragment-length sample (src/read.cpp:241-272).                        */
+static InsertSize *make_insert(double mean, double sd, int n, const int32_t *frag_lens)
+{
+   if (n <= 0) return new InsertSize(mean, sd);
+   return new InsertSize(std::vector<int>(frag_lens, frag_lens + n));
+}
+
+void ref_insert_pdf(double mean, double sd, int n_frag_lens, const int32_t *frag_lens,
+                    int fl_lo, int fl_hi, double *pdf_out, double *mean_sd_off_out)
+{
+   InsertSize *is = make_insert(mean, sd, n_frag_lens, frag_lens);
+   for (int fl = fl_lo; fl <= fl_hi; ++fl) pdf_out[fl - fl_lo] = is->emp_dist_pdf((uint)fl);
+   if (mean_sd_off_out) {
+      mean_sd_off_out[0] = is->_mean;
+      mean_sd_off_out[1] = is->_sd;
+      mean_sd_off_out[2] = is->_use_emp ? is->_start_offset : 0;
+      mean_sd_off_out[3] = is->_use_emp ? is->_end_offset : 0;
+   }
+   delete is;
+}
+
+/* One (bin, isoform) weight: the loop of LocusContext::set_theory_bin_weight,
+ * src/estimate.cpp:209-230, driven with the reference's own effective_len and
+ * emp_dist_pdf (that member function is private, so its 10-line loop is
+ * re-driven here; the end-to-end goldens of tools/make_goldens.py pin the
+ * real one through the -f context TSV).                                      */
+double ref_bin_weight(int nseg, const uint32_t *seg_lens, int nimp,
+                      const uint32_t *implicit_idx, int iso_len, int rl,
+                      double mean, double sd, int n_frag_lens, const int32_t *frag_lens)
+{
+   InsertSize *is = make_insert(mean, sd, n_frag_lens, frag_lens);
+   std::set<std::pair<uint, uint>> coords;
+   coords.insert(std::make_pair(1u, 2u));
+   ExonBin eb(coords);
+   std::vector<uint> sl(seg_lens, seg_lens + nseg);
+   std::vector<uint> imp(implicit_idx, implicit_idx + nimp);
+   int lmax = std::accumulate(sl.begin(), sl.end(), 0);
+   int lmin = is->_use_emp ? is->_start_offset : rl;
+   if (sl.size() > 2) lmin = std::max(lmin, std::accumulate(sl.begin() + 1, sl.end() - 1, 0));
+   double weight = 0.0;
+   for (int fl = lmin; fl <= lmax; ++fl) {
+      double le_eff = eb.effective_len(sl, imp, fl, rl);
+      weight += is->emp_dist_pdf(fl) * le_eff / (iso_len - fl + 1);
+   }
+   delete is;
+   return weight;
+}
+
+} /* extern "C" */

@@ -1,0 +1,95 @@
+"""ctypes binding of libsbgpu.so (include/sbgpu.h).
+
+There is no fallback: if the shared library is missing or a call fails, an
+exception is raised.  Nothing here imports the oracle.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libsbgpu.so")
+
+SBGPU_OK = 0
+EM_OK, EM_INIT_EMPTY, EM_DENOM_ZERO, EM_MAXITER = 0, 1, 2, 3
+STATUS_NAMES = {0: "OK", 1: "INIT_EMPTY", 2: "DENOM_ZERO", 3: "MAXITER"}
+
+# every symbol include/sbgpu.h declares (tests check the .so exports all of them)
+SYMBOLS = [
+    "sbgpu_version", "sbgpu_last_error", "sbgpu_device_count", "sbgpu_init", "sbgpu_finalize",
+    "sbgpu_device_info", "sbgpu_synchronize", "sbgpu_plan_create", "sbgpu_plan_destroy", "sbgpu_plan_info",
+    "sbgpu_plan_classes", "sbgpu_em_run_device", "sbgpu_em_batch", "sbgpu_abundance_device", "sbgpu_tpm_device",
+]
+
+
+class SbgpuError(RuntimeError):
+    pass
+
+
+class sbgpu_batch_t(C.Structure):
+    _fields_ = [
+        ("n_loci", C.c_int64),
+        ("row_off", C.c_void_p),
+        ("iso_off", C.c_void_p),
+        ("f_off", C.c_void_p),
+        ("count", C.c_void_p),
+        ("F", C.c_void_p),
+    ]
+
+
+class sbgpu_abundance_params_t(C.Structure):
+    _fields_ = [
+        ("total_mapped_reads", C.c_int32),
+        ("effective_len_norm", C.c_int32),
+        ("filter_by_expression", C.c_int32),
+        ("reserved", C.c_int32),
+        ("insert_mean", C.c_double),
+        ("min_isoform_frac", C.c_double),
+    ]
+
+
+_lib = None
+
+
+def build():
+    """Compile libsbgpu.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "csrc")])
+
+
+def load():
+    """dlopen libsbgpu.so and declare prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SbgpuError(
+            "%s is missing: build it with `make -C strawberry_amd/csrc` (or __graft_entry__.build()). "
+            "There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i64p = C.c_void_p, C.POINTER(C.c_int64)
+    L.sbgpu_version.restype = C.c_char_p
+    L.sbgpu_last_error.restype = C.c_char_p
+    L.sbgpu_device_count.restype = C.c_int
+    L.sbgpu_init.argtypes = [C.c_int, C.POINTER(vp)]
+    L.sbgpu_finalize.argtypes = [vp]
+    L.sbgpu_device_info.argtypes = [vp, i64p]
+    L.sbgpu_synchronize.argtypes = [vp, vp]
+    L.sbgpu_plan_create.argtypes = [vp, C.c_int64, vp, vp, vp, C.POINTER(vp)]
+    L.sbgpu_plan_destroy.argtypes = [vp]
+    L.sbgpu_plan_info.argtypes = [vp, i64p]
+    L.sbgpu_plan_classes.argtypes = [vp, i64p, C.c_int]
+    L.sbgpu_em_run_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.sbgpu_em_batch.argtypes = [vp, C.POINTER(sbgpu_batch_t), vp, vp, vp]
+    L.sbgpu_abundance_device.argtypes = [vp, vp, vp, vp, vp, C.POINTER(sbgpu_abundance_params_t), vp, vp, vp, vp, vp]
+    L.sbgpu_tpm_device.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp]
+    for name in SYMBOLS:
+        f = getattr(L, name)
+        if f.restype is C.c_int and name not in ("sbgpu_device_count", "sbgpu_plan_classes"):
+            pass
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != SBGPU_OK:
+        raise SbgpuError("%s failed (%d): %s" % (what, rc, load().sbgpu_last_error().decode()))

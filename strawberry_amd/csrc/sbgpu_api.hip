@@ -1,0 +1,519 @@
+// strawberry_amd/csrc/sbgpu_api.hip -- the extern "C" surface of libsbgpu.so
+// (include/sbgpu.h): context, plan upload, kernel dispatch, abundance epilogue.
+// gfx950 only; there is no CPU fallback: every entry point fails with SBGPU_EHIP /
+// SBGPU_ENODEV when HIP or the device is unavailable.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/sbgpu.h"
+#include "em_device.h"
+#include "plan.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+   g_err = msg;
+   return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+   do {                                                                                       \
+      hipError_t e_ = (expr);                                                                 \
+      if (e_ != hipSuccess)                                                                   \
+         return fail(SBGPU_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+   } while (0)
+
+constexpr int kAuxStreams = 8;
+
+} // namespace
+
+struct sbgpu_ctx {
+   int device = 0;
+   int n_cu = 256;
+   hipDeviceProp_t prop;
+   hipStream_t stream = nullptr;            // the context's own stream
+   hipStream_t aux[kAuxStreams] = {};       // size classes run concurrently on these
+   hipEvent_t fork = nullptr;
+   hipEvent_t join[kAuxStreams] = {};
+};
+
+struct DeviceClass {
+   sb::SizeClass host; // loci vector kept for introspection
+   int32_t *d_loci = nullptr;
+   int cursor_index = 0;
+};
+
+struct sbgpu_plan {
+   sbgpu_ctx *ctx = nullptr;
+   sb::HostPlan host;
+   std::vector<DeviceClass> classes;
+   int64_t *d_row_off = nullptr, *d_iso_off = nullptr, *d_f_off = nullptr;
+   int32_t *d_loci_all = nullptr; // all class lists, concatenated
+   int32_t *d_cursors = nullptr;  // one per class
+   uint8_t *d_row_keep = nullptr; // streaming path: init() row flags
+   double *d_locus_sum = nullptr; // abundance epilogue: kept-FPKM sum per locus
+   size_t stream_lds_bytes = 0;
+};
+
+// ------------------------------------------------------------------ kernel dispatch
+namespace {
+
+template <int C, int G>
+hipError_t launch_tile_cg(const sb::EmArgs &a, const sb::ClassArgs &c, int n_blocks, hipStream_t s)
+{
+   constexpr int R = sb::kTileElems / C;
+   constexpr int threads = (G < 64) ? 64 : G;
+   hipLaunchKernelGGL((sb::em_tile_kernel<C, R, G>), dim3(n_blocks), dim3(threads), 0, s, a, c);
+   return hipGetLastError();
+}
+
+template <int C>
+hipError_t launch_tile_c(int G, const sb::EmArgs &a, const sb::ClassArgs &c, int n_blocks, hipStream_t s)
+{
+   switch (G) {
+   case 1: return launch_tile_cg<C, 1>(a, c, n_blocks, s);
+   case 2: return launch_tile_cg<C, 2>(a, c, n_blocks, s);
+   case 4: return launch_tile_cg<C, 4>(a, c, n_blocks, s);
+   case 8: return launch_tile_cg<C, 8>(a, c, n_blocks, s);
+   case 16: return launch_tile_cg<C, 16>(a, c, n_blocks, s);
+   case 32: return launch_tile_cg<C, 32>(a, c, n_blocks, s);
+   case 64: return launch_tile_cg<C, 64>(a, c, n_blocks, s);
+   case 256: return launch_tile_cg<C, 256>(a, c, n_blocks, s);
+   case 1024: return launch_tile_cg<C, 1024>(a, c, n_blocks, s);
+   default: return hipErrorInvalidValue;
+   }
+}
+
+hipError_t launch_tile(int C, int G, const sb::EmArgs &a, const sb::ClassArgs &c, int n_blocks, hipStream_t s)
+{
+   switch (C) {
+   case 2: return launch_tile_c<2>(G, a, c, n_blocks, s);
+   case 4: return launch_tile_c<4>(G, a, c, n_blocks, s);
+   case 8: return launch_tile_c<8>(G, a, c, n_blocks, s);
+   case 16: return launch_tile_c<16>(G, a, c, n_blocks, s);
+   case 32: return launch_tile_c<32>(G, a, c, n_blocks, s);
+   default: return hipErrorInvalidValue;
+   }
+}
+
+// ------------------------------------------------------------------ epilogue kernels
+// LocusContext::estimate_abundances, /root/reference/src/estimate.cpp:314-355.
+// One thread per locus; the per-locus FPKM sum runs in isoform order like the
+// reference's loop (:315-336).
+__global__ void abundance_kernel(int64_t n_loci, const int64_t *iso_off, const double *theta,
+                                 const int32_t *status, const int32_t *length,
+                                 sbgpu_abundance_params_t p, double *fpkm, double *frac,
+                                 int32_t *keep, double *locus_sum)
+{
+   const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (l >= n_loci) return;
+   const int64_t j0 = iso_off[l], j1 = iso_off[l + 1];
+   if (status[l] == sb::kStInitEmpty) {
+      // estimate_abundances() returns false: quantifyCluster returns no isoforms
+      // (/root/reference/src/alignments.cpp:1524-1545)
+      for (int64_t j = j0; j < j1; ++j) {
+         fpkm[j] = 0.0;
+         frac[j] = 0.0;
+         keep[j] = 0;
+      }
+      locus_sum[l] = 0.0;
+      return;
+   }
+   const double rpm = 1e6 / (double)p.total_mapped_reads; // :328
+   double sum_fpkm = 0.0;
+   for (int64_t j = j0; j < j1; ++j) {
+      double kb;
+      int32_t k = 1;
+      double f = 0.0;
+      if (p.effective_len_norm) { // :317-324
+         kb = (double)length[j] - p.insert_mean;
+         if (kb < 0) {
+            k = 2; // "NA"
+         } else {
+            kb = 1e3 / kb;
+         }
+      } else {
+         kb = 1e3 / (double)length[j]; // :326
+      }
+      if (k != 2) {
+         f = theta[j] * rpm * kb; // :329
+         sum_fpkm += f;
+      }
+      fpkm[j] = f;
+      keep[j] = k;
+   }
+   double kept_sum = 0.0;
+   for (int64_t j = j0; j < j1; ++j) {
+      double fr = 0.0;
+      int32_t k = keep[j];
+      if (k != 2) fr = fpkm[j] / sum_fpkm;                           // :342
+      if (p.filter_by_expression && fr < p.min_isoform_frac) k = 0;  // :346-355
+      frac[j] = fr;
+      keep[j] = k;
+      if (k) kept_sum += fpkm[j];
+   }
+   locus_sum[l] = kept_sum;
+}
+
+// Deterministic sum of locus_sum[0..n) in one workgroup (fixed strided order +
+// fixed tree), added to *out.  Sample::procSample, alignments.cpp:1821-1824.
+__global__ __launch_bounds__(1024) void sum_kernel(int64_t n, const double *x, double *out)
+{
+   __shared__ double s[1024];
+   double acc = 0.0;
+   for (int64_t i = threadIdx.x; i < n; i += 1024) acc += x[i];
+   s[threadIdx.x] = acc;
+   __syncthreads();
+   for (int w = 512; w > 0; w >>= 1) {
+      if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
+      __syncthreads();
+   }
+   if (threadIdx.x == 0) *out += s[0];
+}
+
+// alignments.cpp:1825-1829
+__global__ void tpm_kernel(int64_t n, const double *fpkm, const int32_t *keep, const double *total,
+                           double *tpm)
+{
+   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n) return;
+   const double t = *total;
+   tpm[i] = keep[i] ? 1e6 * fpkm[i] / t : 0.0;
+}
+
+} // namespace
+
+// ================================================================== C ABI
+extern "C" {
+
+const char *sbgpu_version(void) { return "libsbgpu 0.1 (gfx950, strawberry EM hot path)"; }
+
+const char *sbgpu_last_error(void) { return g_err.c_str(); }
+
+int sbgpu_device_count(void)
+{
+   int n = 0;
+   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+   return n;
+}
+
+int sbgpu_init(int device, sbgpu_ctx_t **ctx_out)
+{
+   if (!ctx_out) return fail(SBGPU_EINVAL, "sbgpu_init: null ctx_out");
+   *ctx_out = nullptr;
+   int n = 0;
+   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(SBGPU_ENODEV, "sbgpu_init: no HIP device");
+   if (device < 0 || device >= n) return fail(SBGPU_ENODEV, "sbgpu_init: device index out of range");
+   HIP_TRY(hipSetDevice(device));
+   sbgpu_ctx *c = new (std::nothrow) sbgpu_ctx();
+   if (!c) return fail(SBGPU_ENOMEM, "sbgpu_init: out of host memory");
+   c->device = device;
+   hipError_t e = hipGetDeviceProperties(&c->prop, device);
+   if (e != hipSuccess) {
+      delete c;
+      return fail(SBGPU_EHIP, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
+   }
+   if (std::strncmp(c->prop.gcnArchName, "gfx950", 6) != 0) {
+      std::string arch = c->prop.gcnArchName;
+      delete c;
+      return fail(SBGPU_ENODEV, "sbgpu_init: device is " + arch + ", libsbgpu is built for gfx950 only");
+   }
+   c->n_cu = c->prop.multiProcessorCount;
+   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+   for (int i = 0; e == hipSuccess && i < kAuxStreams; ++i) {
+      e = hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&c->join[i], hipEventDisableTiming);
+   }
+   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
+   if (e != hipSuccess) {
+      sbgpu_finalize(c);
+      return fail(SBGPU_EHIP, std::string("sbgpu_init: stream/event creation: ") + hipGetErrorString(e));
+   }
+   *ctx_out = c;
+   return SBGPU_OK;
+}
+
+int sbgpu_finalize(sbgpu_ctx_t *c)
+{
+   if (!c) return SBGPU_OK;
+   (void)hipSetDevice(c->device);
+   for (int i = 0; i < kAuxStreams; ++i) {
+      if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]);
+      if (c->join[i]) (void)hipEventDestroy(c->join[i]);
+   }
+   if (c->fork) (void)hipEventDestroy(c->fork);
+   if (c->stream) (void)hipStreamDestroy(c->stream);
+   delete c;
+   return SBGPU_OK;
+}
+
+int sbgpu_device_info(sbgpu_ctx_t *c, int64_t out[8])
+{
+   if (!c || !out) return fail(SBGPU_EINVAL, "sbgpu_device_info: null argument");
+   out[0] = c->prop.multiProcessorCount;
+   out[1] = c->prop.warpSize;
+   out[2] = (int64_t)c->prop.maxSharedMemoryPerMultiProcessor;
+   out[3] = c->prop.clockRate;
+   out[4] = (int64_t)(c->prop.totalGlobalMem >> 20);
+   out[5] = out[6] = out[7] = 0;
+   return SBGPU_OK;
+}
+
+int sbgpu_synchronize(sbgpu_ctx_t *c, void *stream)
+{
+   if (!c) return fail(SBGPU_EINVAL, "sbgpu_synchronize: null ctx");
+   HIP_TRY(hipStreamSynchronize(stream ? (hipStream_t)stream : c->stream));
+   return SBGPU_OK;
+}
+
+int sbgpu_plan_destroy(sbgpu_plan_t *p)
+{
+   if (!p) return SBGPU_OK;
+   if (p->ctx) (void)hipSetDevice(p->ctx->device);
+   (void)hipFree(p->d_row_off);
+   (void)hipFree(p->d_iso_off);
+   (void)hipFree(p->d_f_off);
+   (void)hipFree(p->d_loci_all);
+   (void)hipFree(p->d_cursors);
+   (void)hipFree(p->d_row_keep);
+   (void)hipFree(p->d_locus_sum);
+   delete p;
+   return SBGPU_OK;
+}
+
+int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, const int64_t *iso_off,
+                      const int64_t *f_off, sbgpu_plan_t **plan_out)
+{
+   if (!c || !plan_out) return fail(SBGPU_EINVAL, "sbgpu_plan_create: null argument");
+   *plan_out = nullptr;
+   sbgpu_plan *p = new (std::nothrow) sbgpu_plan();
+   if (!p) return fail(SBGPU_ENOMEM, "sbgpu_plan_create: out of host memory");
+   p->ctx = c;
+   const char *err = "";
+   int rc = sb::build_host_plan(n_loci, row_off, iso_off, f_off, c->n_cu, &p->host, &err);
+   if (rc != SBGPU_OK) {
+      delete p;
+      return fail(rc, err);
+   }
+   auto bail = [&](hipError_t e, const char *what) {
+      sbgpu_plan_destroy(p);
+      return fail(e == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+   };
+   hipError_t e = hipSetDevice(c->device);
+   if (e != hipSuccess) return bail(e, "hipSetDevice");
+   const size_t nb = (size_t)(n_loci + 1) * sizeof(int64_t);
+   if ((e = hipMalloc(&p->d_row_off, nb)) != hipSuccess) return bail(e, "hipMalloc(row_off)");
+   if ((e = hipMalloc(&p->d_iso_off, nb)) != hipSuccess) return bail(e, "hipMalloc(iso_off)");
+   if ((e = hipMalloc(&p->d_f_off, nb)) != hipSuccess) return bail(e, "hipMalloc(f_off)");
+   if ((e = hipMalloc(&p->d_loci_all, (size_t)(n_loci + 1) * sizeof(int32_t))) != hipSuccess) return bail(e, "hipMalloc(loci)");
+   if ((e = hipMalloc(&p->d_cursors, (p->host.classes.size() + 1) * sizeof(int32_t))) != hipSuccess) return bail(e, "hipMalloc(cursors)");
+   if ((e = hipMalloc(&p->d_row_keep, (size_t)p->host.n_rows + 1)) != hipSuccess) return bail(e, "hipMalloc(row_keep)");
+   if ((e = hipMalloc(&p->d_locus_sum, (size_t)(n_loci + 1) * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(locus_sum)");
+   if (n_loci > 0) {
+      if ((e = hipMemcpy(p->d_row_off, row_off, nb, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(row_off)");
+      if ((e = hipMemcpy(p->d_iso_off, iso_off, nb, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(iso_off)");
+      if ((e = hipMemcpy(p->d_f_off, f_off, nb, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(f_off)");
+   }
+   size_t off = 0;
+   int ci = 0;
+   size_t max_stream_iso = 0;
+   for (auto &sc : p->host.classes) {
+      DeviceClass dc;
+      dc.d_loci = p->d_loci_all + off;
+      dc.cursor_index = ci++;
+      if ((e = hipMemcpy(dc.d_loci, sc.loci.data(), sc.loci.size() * sizeof(int32_t), hipMemcpyHostToDevice)) != hipSuccess)
+         return bail(e, "hipMemcpy(class list)");
+      off += sc.loci.size();
+      if (sc.kind == sb::kStream) {
+         for (int32_t l : sc.loci) {
+            size_t k = (size_t)(iso_off[l + 1] - iso_off[l]);
+            if (k > max_stream_iso) max_stream_iso = k;
+         }
+      }
+      dc.host = sc;
+      p->classes.push_back(std::move(dc));
+   }
+   // streaming kernel LDS: (3 + NWAVE) * npad doubles, npad <= pow2ceil-padded niso
+   size_t npad = 1;
+   while (npad < max_stream_iso && npad < 64) npad <<= 1;
+   if (max_stream_iso > 64) npad = 64 * ((max_stream_iso + 63) / 64);
+   p->stream_lds_bytes = (3 + sb::kStreamThreads / 64) * npad * sizeof(double);
+   *plan_out = p;
+   return SBGPU_OK;
+}
+
+int sbgpu_plan_info(const sbgpu_plan_t *p, int64_t out[8])
+{
+   if (!p || !out) return fail(SBGPU_EINVAL, "sbgpu_plan_info: null argument");
+   out[0] = p->host.n_loci;
+   out[1] = p->host.n_rows;
+   out[2] = p->host.n_iso;
+   out[3] = p->host.n_elem;
+   out[4] = (int64_t)p->host.classes.size();
+   out[5] = p->host.n_stream_loci;
+   out[6] = p->host.algorithmic_bytes;
+   out[7] = 0;
+   return SBGPU_OK;
+}
+
+int sbgpu_plan_classes(const sbgpu_plan_t *p, int64_t *out, int cap)
+{
+   if (!p) return fail(SBGPU_EINVAL, "sbgpu_plan_classes: null plan");
+   int n = (int)p->classes.size();
+   for (int i = 0; i < n && i < cap && out; ++i) {
+      const sb::SizeClass &sc = p->classes[i].host;
+      out[i * 6 + 0] = sc.kind;
+      out[i * 6 + 1] = sc.C;
+      out[i * 6 + 2] = sc.R;
+      out[i * 6 + 3] = sc.G;
+      out[i * 6 + 4] = (int64_t)sc.loci.size();
+      out[i * 6 + 5] = (int64_t)sc.n_blocks * (sc.block_threads / 64);
+   }
+   return n;
+}
+
+int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_count, const double *d_F,
+                        double *d_theta, int32_t *d_status, int32_t *d_iters, void *stream)
+{
+   if (!c || !p) return fail(SBGPU_EINVAL, "sbgpu_em_run_device: null ctx/plan");
+   if (p->host.n_loci == 0) return SBGPU_OK;
+   if (!d_theta || !d_status || !d_iters || (!d_count && p->host.n_rows) || (!d_F && p->host.n_elem))
+      return fail(SBGPU_EINVAL, "sbgpu_em_run_device: null device pointer");
+   hipStream_t main = stream ? (hipStream_t)stream : c->stream;
+   sb::EmArgs a;
+   a.row_off = p->d_row_off;
+   a.iso_off = p->d_iso_off;
+   a.f_off = p->d_f_off;
+   a.count = d_count;
+   a.F = d_F;
+   a.theta = d_theta;
+   a.status = d_status;
+   a.iters = d_iters;
+   const int ncls = (int)p->classes.size();
+   HIP_TRY(hipMemsetAsync(p->d_cursors, 0, (size_t)(ncls + 1) * sizeof(int32_t), main));
+   // a single class runs on the caller's stream; several fork onto the aux streams
+   const bool fork = ncls > 1;
+   if (fork) {
+      HIP_TRY(hipEventRecord(c->fork, main));
+      for (int i = 0; i < kAuxStreams && i < ncls; ++i) HIP_TRY(hipStreamWaitEvent(c->aux[i], c->fork, 0));
+   }
+   for (int i = 0; i < ncls; ++i) {
+      const DeviceClass &dc = p->classes[i];
+      const sb::SizeClass &sc = dc.host;
+      hipStream_t s = fork ? c->aux[i % kAuxStreams] : main;
+      sb::ClassArgs ca;
+      ca.loci = dc.d_loci;
+      ca.n = (int32_t)sc.loci.size();
+      ca.cursor = p->d_cursors + dc.cursor_index;
+      if (sc.kind == sb::kTile) {
+         HIP_TRY(launch_tile(sc.C, sc.G, a, ca, sc.n_blocks, s));
+      } else {
+         hipLaunchKernelGGL(sb::em_stream_kernel, dim3(sc.n_blocks), dim3(sb::kStreamThreads),
+                            p->stream_lds_bytes, s, a, ca, p->d_row_keep);
+         HIP_TRY(hipGetLastError());
+      }
+   }
+   if (fork) {
+      for (int i = 0; i < kAuxStreams && i < ncls; ++i) {
+         HIP_TRY(hipEventRecord(c->join[i], c->aux[i]));
+         HIP_TRY(hipStreamWaitEvent(main, c->join[i], 0));
+      }
+   }
+   return SBGPU_OK;
+}
+
+int sbgpu_em_batch(sbgpu_ctx_t *c, const sbgpu_batch_t *b, double *theta_out, int32_t *status_out,
+                   int32_t *iters_out)
+{
+   if (!c || !b) return fail(SBGPU_EINVAL, "sbgpu_em_batch: null argument");
+   if (b->n_loci == 0) return SBGPU_OK;
+   if (!theta_out || !status_out) return fail(SBGPU_EINVAL, "sbgpu_em_batch: null output");
+   sbgpu_plan_t *p = nullptr;
+   int rc = sbgpu_plan_create(c, b->n_loci, b->row_off, b->iso_off, b->f_off, &p);
+   if (rc != SBGPU_OK) return rc;
+   const int64_t n_rows = p->host.n_rows, n_iso = p->host.n_iso, n_el = p->host.n_elem;
+   int32_t *d_count = nullptr, *d_status = nullptr, *d_iters = nullptr;
+   double *d_F = nullptr, *d_theta = nullptr;
+   auto cleanup = [&]() {
+      (void)hipFree(d_count);
+      (void)hipFree(d_status);
+      (void)hipFree(d_iters);
+      (void)hipFree(d_F);
+      (void)hipFree(d_theta);
+      sbgpu_plan_destroy(p);
+   };
+#define TRY_CLEAN(expr)                                                                       \
+   do {                                                                                       \
+      hipError_t e_ = (expr);                                                                 \
+      if (e_ != hipSuccess) {                                                                 \
+         cleanup();                                                                           \
+         return fail(e_ == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP,                   \
+                     std::string(#expr) + ": " + hipGetErrorString(e_));                      \
+      }                                                                                       \
+   } while (0)
+   TRY_CLEAN(hipMalloc(&d_count, (size_t)(n_rows + 1) * sizeof(int32_t)));
+   TRY_CLEAN(hipMalloc(&d_F, (size_t)(n_el + 1) * sizeof(double)));
+   TRY_CLEAN(hipMalloc(&d_theta, (size_t)(n_iso + 1) * sizeof(double)));
+   TRY_CLEAN(hipMalloc(&d_status, (size_t)b->n_loci * sizeof(int32_t)));
+   TRY_CLEAN(hipMalloc(&d_iters, (size_t)b->n_loci * sizeof(int32_t)));
+   if (n_rows) TRY_CLEAN(hipMemcpyAsync(d_count, b->count, (size_t)n_rows * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+   if (n_el) TRY_CLEAN(hipMemcpyAsync(d_F, b->F, (size_t)n_el * sizeof(double), hipMemcpyHostToDevice, c->stream));
+   rc = sbgpu_em_run_device(c, p, d_count, d_F, d_theta, d_status, d_iters, c->stream);
+   if (rc != SBGPU_OK) {
+      cleanup();
+      return rc;
+   }
+   TRY_CLEAN(hipMemcpyAsync(theta_out, d_theta, (size_t)n_iso * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+   TRY_CLEAN(hipMemcpyAsync(status_out, d_status, (size_t)b->n_loci * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+   if (iters_out)
+      TRY_CLEAN(hipMemcpyAsync(iters_out, d_iters, (size_t)b->n_loci * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+   TRY_CLEAN(hipStreamSynchronize(c->stream));
+#undef TRY_CLEAN
+   cleanup();
+   return SBGPU_OK;
+}
+
+int sbgpu_abundance_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const double *d_theta,
+                           const int32_t *d_status, const int32_t *d_length,
+                           const sbgpu_abundance_params_t *params, double *d_fpkm, double *d_frac,
+                           int32_t *d_keep, double *d_sum_fpkm, void *stream)
+{
+   if (!c || !p || !params) return fail(SBGPU_EINVAL, "sbgpu_abundance_device: null argument");
+   if (p->host.n_loci == 0) return SBGPU_OK;
+   if (!d_theta || !d_status || !d_length || !d_fpkm || !d_frac || !d_keep || !d_sum_fpkm)
+      return fail(SBGPU_EINVAL, "sbgpu_abundance_device: null device pointer");
+   if (params->total_mapped_reads <= 0) return fail(SBGPU_EINVAL, "sbgpu_abundance_device: total_mapped_reads must be > 0");
+   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+   const int64_t n = p->host.n_loci;
+   const int threads = 256;
+   hipLaunchKernelGGL(abundance_kernel, dim3((unsigned)((n + threads - 1) / threads)), dim3(threads), 0, s, n,
+                      p->d_iso_off, d_theta, d_status, d_length, *params, d_fpkm, d_frac, d_keep, p->d_locus_sum);
+   HIP_TRY(hipGetLastError());
+   hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, s, n, p->d_locus_sum, d_sum_fpkm);
+   HIP_TRY(hipGetLastError());
+   return SBGPU_OK;
+}
+
+int sbgpu_tpm_device(sbgpu_ctx_t *c, int64_t n_iso, const double *d_fpkm, const int32_t *d_keep,
+                     const double *d_total_fpkm, double *d_tpm, void *stream)
+{
+   if (!c) return fail(SBGPU_EINVAL, "sbgpu_tpm_device: null ctx");
+   if (n_iso == 0) return SBGPU_OK;
+   if (!d_fpkm || !d_keep || !d_total_fpkm || !d_tpm) return fail(SBGPU_EINVAL, "sbgpu_tpm_device: null device pointer");
+   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+   const int threads = 256;
+   hipLaunchKernelGGL(tpm_kernel, dim3((unsigned)((n_iso + threads - 1) / threads)), dim3(threads), 0, s, n_iso,
+                      d_fpkm, d_keep, d_total_fpkm, d_tpm);
+   HIP_TRY(hipGetLastError());
+   return SBGPU_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,81 @@
+"""CPU tests of the C-ABI library: it loads and exports every symbol
+include/sbgpu.h declares; without a GPU it fails loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from strawberry_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib.load()
+
+
+def test_exports_every_declared_symbol(lib):
+    from strawberry_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "sbgpu.h")).read()
+    declared = set(re.findall(r"\b(sbgpu_[a-z_]+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_version_and_constants(lib):
+    assert b"gfx950" in lib.sbgpu_version()
+    hdr = open(os.path.join(ROOT, "include", "sbgpu.h")).read()
+    assert "#define SBGPU_EM_MAX_ITER 1000" in hdr          # include/estimate.hpp:237
+    assert "#define SBGPU_EM_THETA_CHANGE_LIMIT 1e-2" in hdr  # include/estimate.hpp:241
+
+
+def test_no_cpu_fallback_without_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    rc = lib.sbgpu_init(0, C.byref(h))
+    assert rc < 0 and not h.value
+    assert b"device" in lib.sbgpu_last_error().lower()
+    from strawberry_amd import em, synth
+    with pytest.raises(Exception):
+        em.EmBatchSolver(synth.make_random(4))
+    with pytest.raises(Exception):
+        em.EmSolver().init(2, [1, 2], [[.1, .2], [.3, .1]])
+
+
+def test_product_does_not_import_oracle():
+    """The product path must never route through the oracle."""
+    pkg = os.path.join(ROOT, "strawberry_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", "Makefile")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), os.path.join(dirpath, f)
+                assert "liboracle" not in src and "em_oracle" not in src, os.path.join(dirpath, f)
+
+
+def test_synth_shapes_and_determinism():
+    from strawberry_amd import synth
+    a = synth.make_c2(n_loci=50)
+    b = synth.make_c2(n_loci=50)
+    np.testing.assert_array_equal(a.F, b.F)
+    np.testing.assert_array_equal(a.count, b.count)
+    assert (a.nrow == 32).all() and (a.niso == 8).all()
+    sums = np.add.reduceat(a.count.astype(np.int64), a.row_off[:-1])
+    assert (sums == 1000).all()
+    # >= 1 compatible isoform per bin and >= 1 bin per isoform
+    for l in range(a.n_loci):
+        n, F = a.locus(l)
+        assert (F > 0).any(axis=1).all() and (F > 0).any(axis=0).all()
+    assert a.algorithmic_bytes() == 50 * (32 * 8 * 8 + 32 * 4 + 8 * 8 + 24)
+    u = synth.make_c2(n_loci=5, unbinned=True)
+    assert (u.nrow == 1000).all() and (u.count == 1).all()
+    c3 = synth.make_c3(n_loci=300, total_frags=1e6)
+    assert c3.n_loci == 300 and c3.niso.min() >= 1 and c3.nrow.max() <= 2000
+    assert abs(c3.n_frags - 1e6) / 1e6 < 0.01

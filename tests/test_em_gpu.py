@@ -1,0 +1,164 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle and the
+reference goldens.  Tolerances: theta within 1e-9 relative (floor 1e-9 fragments)
+of the reference -- five orders tighter than the 1e-4 the north star asks of
+FPKM/TPM; status and iteration counts exact."""
+import numpy as np
+import pytest
+
+from conftest import ref_flags_to_status
+
+pytestmark = pytest.mark.gpu
+
+THETA_RTOL = 1e-9
+THETA_FLOOR = 1e-9
+
+
+def theta_err(theta, ref):
+    return np.abs(theta - ref) / np.maximum(np.abs(ref), THETA_FLOOR)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from strawberry_amd import em
+    return em.default_context(0)
+
+
+def solve(batch, ctx):
+    from strawberry_amd import em
+    s = em.EmBatchSolver(batch, ctx)
+    s.run_em()
+    return s, s.results()
+
+
+@pytest.mark.parametrize("name", ["em_edge", "em_random_256", "em_c2_64", "em_c3_400"])
+def test_gpu_matches_reference_goldens(ctx, oracle, golden, name):
+    b, ref_theta, ref_flags = golden(name)
+    _, r = solve(b, ctx)
+    o_theta, o_status, o_iters = oracle.em_batch(b.row_off, b.iso_off, b.f_off, b.count, b.F)
+    np.testing.assert_array_equal(r["status"], ref_flags_to_status(ref_flags, o_status))
+    np.testing.assert_array_equal(r["status"], o_status)
+    err = theta_err(r["theta"], ref_theta)
+    assert err.max() < THETA_RTOL, (name, err.max(), int(err.argmax()))
+    # iteration counts are part of the contract (absolute 1e-2 threshold, SURVEY "hard parts")
+    np.testing.assert_array_equal(r["iters"], o_iters)
+
+
+def test_gpu_known_answers_per_locus_adapter(ctx):
+    """EmSolver-shaped adapter: init()/run()/_theta like src/estimate.cpp:305-313."""
+    from strawberry_amd.em import EmSolver
+    from test_oracle import KATS
+    for name, n, F, status, theta in KATS:
+        em = EmSolver(ctx)
+        ok = em.init(len(F[0]), n, F)
+        ran = em.run()
+        assert ok == (status != 1), name
+        assert ran == (status in (0, 3)), name
+        np.testing.assert_allclose(em._theta, theta, rtol=2e-11, atol=1e-11, err_msg=name)
+
+
+def test_gpu_host_buffer_entry(ctx, oracle, golden):
+    """sbgpu_em_batch (host pointers in/out) == device-resident path."""
+    from strawberry_amd import em
+    b, ref_theta, _ = golden("em_random_256")
+    theta, status, iters = em.em_batch_host(b, ctx)
+    _, r = solve(b, ctx)
+    np.testing.assert_array_equal(theta, r["theta"])
+    np.testing.assert_array_equal(status, r["status"])
+    np.testing.assert_array_equal(iters, r["iters"])
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (1, 7), (7, 1), (5, 2), (33, 3), (64, 8), (65, 8), (200, 5),
+                                   (257, 8), (300, 16), (129, 32), (2000, 8), (5000, 2), (40, 33), (100, 64)])
+def test_gpu_every_size_class(ctx, oracle, shape):
+    """One batch per (nrow, niso) shape so that each tile / workgroup / streaming
+    class is exercised on its own, including its padding."""
+    from strawberry_amd import synth
+    nrow, niso = shape
+    rng = np.random.Generator(np.random.PCG64(nrow * 1000 + niso))
+    loci = []
+    for _ in range(6):
+        F = np.where(rng.random((nrow, niso)) < 0.5, rng.uniform(1e-3, .3, (nrow, niso)), 0.0)
+        loci.append((rng.integers(0, 50, nrow).astype(np.int32), F))
+    b = synth.from_loci(loci)
+    _, r = solve(b, ctx)
+    o_theta, o_status, o_iters = oracle.em_batch(b.row_off, b.iso_off, b.f_off, b.count, b.F)
+    np.testing.assert_array_equal(r["status"], o_status)
+    np.testing.assert_array_equal(r["iters"], o_iters)
+    assert theta_err(r["theta"], o_theta).max() < THETA_RTOL
+
+
+def test_gpu_empty_and_degenerate_batches(ctx):
+    from strawberry_amd import em, synth
+    # empty batch
+    b = synth.from_loci([])
+    theta, status, iters = em.em_batch_host(b, ctx)
+    assert len(theta) == 0 and len(status) == 0
+    # a locus with zero rows: init() false (no rows at all), theta0 = 0/niso
+    b = synth.LocusBatch(np.array([0, 0, 2], np.int64), np.array([0, 3, 5], np.int64), np.array([0, 0, 4], np.int64),
+                         np.array([4, 6], np.int32), np.array([.1, .2, .3, .1]), np.full(5, 1000, np.int32))
+    theta, status, iters = em.em_batch_host(b, ctx)
+    assert status[0] == 1 and iters[0] == 0 and (theta[:3] == 0).all()
+    assert status[1] in (0, 3)
+
+
+def test_gpu_c2_sample_against_oracle(ctx, oracle):
+    """A 2000-locus slice of config C2 (32 bins x 8 isoforms x 1000 fragments)."""
+    from strawberry_amd import synth
+    b = synth.make_c2(n_loci=2000)
+    _, r = solve(b, ctx)
+    o_theta, o_status, o_iters = oracle.em_batch(b.row_off, b.iso_off, b.f_off, b.count, b.F, threads=4)
+    np.testing.assert_array_equal(r["status"], o_status)
+    np.testing.assert_array_equal(r["iters"], o_iters)
+    assert theta_err(r["theta"], o_theta).max() < THETA_RTOL
+
+
+def test_gpu_full_size_properties(ctx):
+    """BASELINE-size runs checked through size-independent properties: mass
+    conservation (sum theta = kept counts after the first iteration), non-negativity,
+    determinism (bitwise identical re-run), TPM sums to 1e6."""
+    from strawberry_amd import synth, em
+    for b in (synth.make_c2(), synth.make_c3(n_loci=20000, total_frags=2e8 / 3)):
+        s = em.EmBatchSolver(b, ctx)
+        s.run_em()
+        r1 = s.results()
+        s.run_em()
+        s.run_abundance(total_mapped_reads=max(1, b.n_frags), min_isoform_frac=0.0)
+        s.run_tpm()
+        r2 = s.results()
+        np.testing.assert_array_equal(r1["theta"], r2["theta"])
+        np.testing.assert_array_equal(r1["iters"], r2["iters"])
+        assert (r2["status"] >= 0).all() and (r2["status"] <= 3).all()
+        assert (r2["theta"] >= 0).all() and np.isfinite(r2["theta"]).all()
+        tot_theta = np.add.reduceat(r2["theta"], b.iso_off[:-1])
+        tot_n = np.add.reduceat(b.count.astype(np.float64), b.row_off[:-1])
+        ok = np.isin(r2["status"], (0, 3)) & (r2["iters"] > 1)
+        # every synthetic row has a weight >= 1e-3, so no row is dropped
+        assert np.abs(tot_theta[ok] - tot_n[ok]).max() < 1e-6 * max(1.0, tot_n.max())
+        assert abs(r2["tpm"].sum() - 1e6) < 1e-3
+
+
+def test_gpu_abundance_and_tpm_match_oracle(ctx, oracle, golden):
+    from strawberry_amd import em
+    b, _, _ = golden("em_c3_400")
+    s = em.EmBatchSolver(b, ctx)
+    s.run_em()
+    total_mapped = 3_000_000
+    for kw in (dict(min_isoform_frac=0.01), dict(min_isoform_frac=0.0),
+               dict(effective_len_norm=True, insert_mean=700.0, min_isoform_frac=0.01)):
+        s.run_abundance(total_mapped, **kw)
+        s.run_tpm()
+        r = s.results()
+        fpkm, frac, keep = np.zeros_like(r["theta"]), np.zeros_like(r["theta"]), np.zeros(len(r["theta"]), np.int32)
+        for l in range(b.n_loci):
+            j0, j1 = b.iso_off[l], b.iso_off[l + 1]
+            if r["status"][l] == 1:
+                continue
+            f, fr, k, _ = oracle.abundance_locus(r["theta"][j0:j1], b.length[j0:j1], total_mapped,
+                                                 filter_by_expression=True, **kw)
+            fpkm[j0:j1], frac[j0:j1], keep[j0:j1] = f, fr, k
+        np.testing.assert_array_equal(r["keep"], keep)
+        np.testing.assert_allclose(r["fpkm"], fpkm, rtol=1e-14, atol=0)
+        np.testing.assert_allclose(r["frac"], frac, rtol=1e-14, atol=0)
+        tpm, tot = oracle.tpm(fpkm, keep)
+        assert abs(r["sum_fpkm"] - tot) / tot < 1e-12
+        np.testing.assert_allclose(r["tpm"], tpm, rtol=1e-12, atol=0)
