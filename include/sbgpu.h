@@ -21,7 +21,7 @@
  * text).  Per-locus outcomes are NOT errors, they are `status` values that
  * mirror the reference's bool returns.  "d_" pointers are device (HBM)
  * addresses, everything else is host memory.  `stream` is a hipStream_t passed
- * as void* (NULL = the context's own stream).  A context is used from one host
+ * as void* (NULL = HIP's null stream, as everywhere in HIP).  A context is used from one host
  * thread at a time (one process per GPU).
  */
 #ifndef SBGPU_H_

@@ -65,6 +65,13 @@ def load():
         raise SbgpuError(
             "%s is missing: build it with `make -C strawberry_amd/csrc` (or __graft_entry__.build()). "
             "There is no CPU fallback." % LIB_PATH)
+    # torch bundles its own libamdhip64.so.7; it must be the ONE HIP runtime of the
+    # process (device pointers and streams are shared with it), so it is loaded first
+    # and libsbgpu.so's NEEDED libamdhip64.so.7 then resolves to the same object.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i64p = C.c_void_p, C.POINTER(C.c_int64)
     L.sbgpu_version.restype = C.c_char_p

@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace sb {
 
 constexpr int kMaxIter = 1000;          // include/estimate.hpp:237
@@ -132,66 +134,134 @@ __device__ __forceinline__ double fast_div(double n, double d)
 }
 
 // ================================================================== tile kernel
-// A locus is owned by a GROUP of G lanes; lane g of the group keeps rows
-// g, g+G, g+2G, ... (R of them) of the locus' F in registers as an R x C tile,
-// plus a private copy of theta[C].  G <= 64: 64/G groups share a wave and run
-// independent loci; G > 64: the group is the whole workgroup (G threads) and the
-// cross-wave part of every reduction goes through LDS.
+// A locus is owned by a GROUP of G = CL x GR lanes laid out as a 2-D grid:
+//   gc = g % CL  "column lane": owns columns [gc*CPL, gc*CPL + CPL)
+//   gr = g / CL  "row lane":    owns rows gr, gr+GR, gr+2GR, ... (R of them)
+// so each lane keeps an R x CPL tile of F in registers for the whole solve, plus
+// theta for its own CPL columns.  Per iteration the group needs
+//   - the row denominators: all-reduce over the CL column lanes (low lane bits),
+//   - the weighted column sums: all-reduce over the GR row lanes (high lane bits;
+//     GR > 64/CL continues through LDS across the waves of the workgroup),
+// both as DPP butterflies; every lane of a group ends with bitwise identical sums,
+// so the convergence decision is group-uniform by construction.
 //
-// Groups pull loci from the class list through an atomic cursor and keep pulling
-// until it runs dry, so a wave stays busy while one of its groups is still
-// iterating (iteration counts range from 1 to the 1000 cap).
-template <int G>
-struct GroupComm {
-   static constexpr int GW = (G < 64) ? G : 64;   // lanes of the group inside one wave
-   static constexpr int NW = (G < 64) ? 1 : G / 64; // waves per group
-   double *lds;                                   // NW > 1: [2][NW] doubles per value slot
+// G <= 64: 64/G groups share a wave and run independent loci; G = 256/512: the
+// group is the whole workgroup.  Groups pull loci from the class list through an
+// atomic cursor until it runs dry (iteration counts range from 1 to the 1000 cap).
 
-   // all-reduce of V values at once (cross-wave: one LDS round for all of them)
-   template <int V>
-   __device__ __forceinline__ void sum(double (&x)[V], int wave_id, int &phase)
-   {
-#pragma unroll
-      for (int v = 0; v < V; ++v) x[v] = wave_group_sum<GW>(x[v]);
-      if (NW > 1) {
-         // double-buffered by phase so one barrier per round is enough
-         double *buf = lds + (size_t)phase * (V_MAX * NW);
-         if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-            for (int v = 0; v < V; ++v) buf[v * NW + wave_id] = x[v];
-         }
-         __syncthreads();
-#pragma unroll
-         for (int v = 0; v < V; ++v) {
-            double s = 0.0;
-            for (int w = 0; w < NW; ++w) s += buf[v * NW + w];
-            x[v] = s;
-         }
-         phase ^= 1;
-      }
+// value of lane (lane ^ MASK), true xor for every MASK
+template <int MASK>
+__device__ __forceinline__ int xor_get_i(int x)
+{
+   if (MASK == 1) return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);
+   if (MASK == 2) return __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true);
+   if (MASK == 4) {
+      // banks 0,2 (lanes 0-3, 8-11 of each row) read lane+4, banks 1,3 read lane-4
+      int t = __builtin_amdgcn_update_dpp(0, x, 0x104 /*row_shl:4*/, 0xF, 0x5, false);
+      return __builtin_amdgcn_update_dpp(t, x, 0x114 /*row_shr:4*/, 0xF, 0xA, false);
    }
-   static constexpr int V_MAX = 40; // >= C + 3 for the largest C (32)
-};
+   if (MASK == 8) return __builtin_amdgcn_update_dpp(0, x, 0x128 /*row_ror:8*/, 0xF, 0xF, true);
+   if (MASK == 16) return __builtin_amdgcn_ds_swizzle(x, 0x401F);
+   // MASK == 32
+   auto a = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+   return ((threadIdx.x & 32) ? a[0] : a[1]);
+}
+template <int MASK>
+__device__ __forceinline__ double xor_get(double x)
+{
+   return __hiloint2double(xor_get_i<MASK>(__double2hiint(x)), xor_get_i<MASK>(__double2loint(x)));
+}
+template <int MASK>
+__device__ __forceinline__ double xor_sum(double x)
+{
+   if (MASK == 32) return sum_xor32(x);
+   return x + xor_get<MASK>(x);
+}
 
-template <int C, int R, int G>
+// all-reduce over lane bits [LO, HI) (masks 2^LO .. 2^(HI-1)).  With LO == 0 the
+// cheaper mirror forms are valid for masks 4 and 8 (the lanes below are uniform).
+template <int LO, int HI>
+__device__ __forceinline__ double bits_sum(double x)
+{
+   if (LO == 0) {
+      if (HI >= 1) x += dpp_mov<kDppXor1>(x);
+      if (HI >= 2) x += dpp_mov<kDppXor2>(x);
+      if (HI >= 3) x += dpp_mov<kDppHalfMirror>(x);
+      if (HI >= 4) x += dpp_mov<kDppMirror>(x);
+      if (HI >= 5) x += swizzle_xor16(x);
+      if (HI >= 6) x = sum_xor32(x);
+      return x;
+   }
+   if (LO <= 0 && HI > 0) x = xor_sum<1>(x);
+   if (LO <= 1 && HI > 1) x = xor_sum<2>(x);
+   if (LO <= 2 && HI > 2) x = xor_sum<4>(x);
+   if (LO <= 3 && HI > 3) x = xor_sum<8>(x);
+   if (LO <= 4 && HI > 4) x = xor_sum<16>(x);
+   if (LO <= 5 && HI > 5) x = xor_sum<32>(x);
+   return x;
+}
+
+constexpr int ilog2(int x) { return x <= 1 ? 0 : 1 + ilog2(x / 2); }
+
+// fp64 denormals flush to zero inside the EM, like the reference build: it is
+// compiled -Ofast (CMakeLists.txt:84), whose crtfastmath.o sets FTZ/DAZ, and that
+// decides WHEN a decaying theta_j becomes exactly 0 and a row denominator trips
+// the `denom == 0` exit (estimate.cpp:451).  MODE.FP_DENORM[7:6] = 0.
+__device__ __forceinline__ void set_fp64_flush_denormals()
+{
+   __builtin_amdgcn_s_setreg(1 | (6 << 6) | ((2 - 1) << 11), 0);
+}
+
+template <int CPL, int CL, int R, int G>
 __global__ __launch_bounds__((G < 64) ? 64 : G) void em_tile_kernel(EmArgs a, ClassArgs cls)
 {
-   constexpr int GW = GroupComm<G>::GW;
-   constexpr int NW = GroupComm<G>::NW;
-   __shared__ double s_red[(NW > 1) ? 2 * GroupComm<G>::V_MAX * NW : 1];
+   constexpr int GW = (G < 64) ? G : 64;        // lanes of the group inside one wave
+   constexpr int NW = (G <= 64) ? 1 : G / 64;   // waves per group
+   constexpr int GR = G / CL;                   // row lanes per group
+   constexpr int LB_CL = ilog2(CL);
+   constexpr int LB_GW = ilog2(GW);
+   constexpr int NV = CPL + 1;                  // values in the per-iteration column reduce
+   static_assert(G >= CL && (G % CL) == 0, "group must hold all column lanes");
+   // cross-wave exchange: [2 phases][NW waves][CL column lanes][NV values]
+   __shared__ double s_red[(NW > 1) ? 2 * NW * CL * NV : 1];
    __shared__ int s_idx;
-   GroupComm<G> comm;
-   comm.lds = s_red;
    int phase = 0;
+
+   set_fp64_flush_denormals();
 
    const int lane = threadIdx.x & 63;
    const int wave_id = threadIdx.x >> 6;
-   const int g = (G < 64) ? (lane & (G - 1)) : (int)threadIdx.x; // index inside the group
+   const int g = (G <= 64) ? (lane & (GW - 1)) : (int)threadIdx.x; // index inside the group
+   const int gc = g & (CL - 1);
+   const int gr = g >> LB_CL;
 
-   double F[R][C];
-   double nn[R];      // n_i as double (obs_d, estimate.cpp:418-419)
-   bool act[R];       // row kept by init() (estimate.cpp:377-390) and inside the locus
-   double theta[C];
+   // all-reduce over the row lanes of the group of NVAL per-lane values
+   auto row_lane_sum = [&](double *x, auto nval_tag) {
+      constexpr int NVAL = decltype(nval_tag)::value;
+#pragma unroll
+      for (int v = 0; v < NVAL; ++v) x[v] = bits_sum<LB_CL, LB_GW>(x[v]);
+      if (NW > 1) {
+         double *buf = s_red + (size_t)phase * (NW * CL * NV);
+         if (lane < CL) {
+#pragma unroll
+            for (int v = 0; v < NVAL; ++v) buf[(wave_id * CL + lane) * NV + v] = x[v];
+         }
+         __syncthreads();
+#pragma unroll
+         for (int v = 0; v < NVAL; ++v) {
+            double s = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s += buf[(w * CL + gc) * NV + v];
+            x[v] = s;
+         }
+         phase ^= 1; // double-buffered: one barrier per round is enough
+      }
+   };
+
+   double F[R][CPL];
+   double nn[R];      // n_i as double (obs_d, estimate.cpp:418-419); 0 for dropped rows
+   bool act[R];       // row kept by init() (estimate.cpp:377-390)
+   double theta[CPL];
    double theta0 = 0.0;
    int it = 0;
    int niso = 0;
@@ -205,78 +275,100 @@ __global__ __launch_bounds__((G < 64) ? 64 : G) void em_tile_kernel(EmArgs a, Cl
       nn[r] = 0.0;
       act[r] = false;
 #pragma unroll
-      for (int j = 0; j < C; ++j) F[r][j] = 0.0;
+      for (int j = 0; j < CPL; ++j) F[r][j] = 0.0;
    }
 #pragma unroll
-   for (int j = 0; j < C; ++j) theta[j] = 0.0;
+   for (int j = 0; j < CPL; ++j) theta[j] = 0.0;
 
    for (;;) {
       // ---------------------------------------------------------------- refill
-      if (!have && !exhausted) {
-         int idx;
+      // Entered wave-uniformly when some group is idle; lanes of busy groups run
+      // it too (on locus 0's addresses, results discarded by selects) so that F,
+      // theta, ... are updated in place without per-lane control flow.
+      const bool need = !have && !exhausted;
+      if ((NW > 1) ? need : __any(need)) {
+         int idx = 0;
          if (NW > 1) {
             if (threadIdx.x == 0) s_idx = atomicAdd(cls.cursor, 1);
             __syncthreads();
             idx = s_idx;
             __syncthreads();
          } else {
-            idx = 0;
-            if (g == 0) idx = atomicAdd(cls.cursor, 1);
+            if (need && g == 0) idx = atomicAdd(cls.cursor, 1);
             idx = __shfl(idx, lane & ~(GW - 1));
          }
-         if (idx >= cls.n) {
-            exhausted = true;
-         } else {
-            locus = cls.loci[idx];
-            const int64_t r0 = a.row_off[locus];
-            const int nrow = (int)(a.row_off[locus + 1] - r0);
-            iso_base = a.iso_off[locus];
-            niso = (int)(a.iso_off[locus + 1] - iso_base);
-            const double *Fg = a.F + a.f_off[locus];
-            // EmSolver::init, estimate.cpp:366-391
-            double red[2];
-            red[0] = 0.0; // sum of ALL counts (theta0 precedes the row drop, :374-375)
-            red[1] = 0.0; // number of kept rows
+         const bool got = need && idx < cls.n;
+         exhausted = exhausted || (need && idx >= cls.n);
+         const int loc = got ? cls.loci[idx] : 0;
+         const int64_t r0 = a.row_off[loc];
+         const int nrow = (int)(a.row_off[loc + 1] - r0);
+         const int64_t ib = a.iso_off[loc];
+         const int ni = (int)(a.iso_off[loc + 1] - ib);
+         const double *Fg = a.F + a.f_off[loc];
+         // EmSolver::init, estimate.cpp:366-391
+         double red[2];
+         red[0] = 0.0; // sum of ALL counts (theta0 precedes the row drop, :374-375)
+         red[1] = 0.0; // number of kept rows
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-               const int i = r * G + g;
-               const bool valid = i < nrow;
-               nn[r] = valid ? (double)a.count[r0 + i] : 0.0;
-               red[0] += nn[r];
-               bool keep = false;
+         for (int r = 0; r < R; ++r) {
+            const int i = r * GR + gr;
+            const bool valid = got && i < nrow;
+            // clamped indices: loads stay inside the locus (or touch nothing when it
+            // has no rows), no per-element branches
+            const int ic = (i < nrow) ? i : (nrow > 0 ? nrow - 1 : 0);
+            double cnt = 0.0;
+            if (nrow > 0) cnt = (double)a.count[r0 + ic];
+            cnt = valid ? cnt : 0.0;
+            if (gc == 0) red[0] += cnt;
+            double v[CPL];
+            double mx = 0.0;
 #pragma unroll
-               for (int j = 0; j < C; ++j) {
-                  double v = (valid && j < niso) ? Fg[(int64_t)i * niso + j] : 0.0;
-                  keep = keep || (v > kRowEps); // :380
-                  F[r][j] = v;
-               }
-               act[r] = keep;
-               if (!keep) {
-                  nn[r] = 0.0;
-#pragma unroll
-                  for (int j = 0; j < C; ++j) F[r][j] = 0.0;
-               } else {
-                  red[1] += 1.0;
-               }
+            for (int jj = 0; jj < CPL; ++jj) {
+               const int j = gc * CPL + jj;
+               const int jc = (j < ni) ? j : ni - 1;
+               double x = 0.0;
+               if (nrow > 0) x = Fg[(int64_t)ic * ni + jc];
+               x = (valid && j < ni) ? x : 0.0;
+               mx = fmax(mx, x);
+               v[jj] = x;
             }
-            comm.template sum<2>(red, wave_id, phase);
-            theta0 = red[0] / (double)niso; // :375, IEEE division
+            // any weight of the row > 1e-5 (:380), over all column lanes
+            if (CL >= 2) mx = fmax(mx, xor_get<1>(mx));
+            if (CL >= 4) mx = fmax(mx, xor_get<2>(mx));
+            if (CL >= 8) mx = fmax(mx, xor_get<4>(mx));
+            const bool keep = mx > kRowEps;
+            if (gc == 0 && keep) red[1] += 1.0;
+            act[r] = got ? keep : act[r];
+            nn[r] = got ? (keep ? cnt : 0.0) : nn[r];
 #pragma unroll
-            for (int j = 0; j < C; ++j) theta[j] = (j < niso) ? theta0 : 0.0;
-            it = 0;
-            if (red[1] == 0.0) {
-               // init() == false (:391): theta = theta0, the caller drops the locus
-               if (g == 0) {
-                  a.status[locus] = kStInitEmpty;
-                  a.iters[locus] = 0;
-               }
+            for (int jj = 0; jj < CPL; ++jj) F[r][jj] = got ? (keep ? v[jj] : 0.0) : F[r][jj];
+         }
+         // group totals: over the column lanes, then over the row lanes
+         red[0] = bits_sum<0, LB_CL>(red[0]);
+         red[1] = bits_sum<0, LB_CL>(red[1]);
+         row_lane_sum(red, std::integral_constant<int, 2>());
+         const double t0 = red[0] / (double)ni; // :375, IEEE division
+         theta0 = got ? t0 : theta0;
 #pragma unroll
-               for (int j = 0; j < C; ++j)
-                  if (j < niso && (j % G) == g) a.theta[iso_base + j] = theta0;
-            } else {
-               have = true;
+         for (int jj = 0; jj < CPL; ++jj) theta[jj] = got ? ((gc * CPL + jj < ni) ? t0 : 0.0) : theta[jj];
+         it = got ? 0 : it;
+         locus = got ? loc : locus;
+         niso = got ? ni : niso;
+         iso_base = got ? ib : iso_base;
+         const bool empty = got && red[1] == 0.0;
+         if (empty) {
+            // init() == false (:391): theta = theta0, the caller drops the locus
+            if (g == 0) {
+               a.status[loc] = kStInitEmpty;
+               a.iters[loc] = 0;
+            }
+            if (gr == 0) {
+#pragma unroll
+               for (int jj = 0; jj < CPL; ++jj)
+                  if (gc * CPL + jj < ni) a.theta[ib + gc * CPL + jj] = t0;
             }
          }
+         have = have || (got && !empty);
       }
       if (NW > 1) {
          // have / exhausted are workgroup-uniform
@@ -291,77 +383,111 @@ __global__ __launch_bounds__((G < 64) ? 64 : G) void em_tile_kernel(EmArgs a, Cl
          }
       }
 
-      // ------------------------------------------------- one EM iteration (uniform)
-      // E-step denominators and the weighted column sums of the M-step.
-      double red[C + 1];
+      // ------------------------------------------------------ steady-state loop
+      // Runs until some group of the wave needs attention (first iteration's
+      // column normalisation, convergence, zero denominator, iteration cap).
+      // F is read-only in here.
+      double nt[NV]; // [0, CPL): next_theta of the own columns; [CPL]: zero-denominator flag
+      bool dz, conv, special;
+      do {
 #pragma unroll
-      for (int j = 0; j < C + 1; ++j) red[j] = 0.0;
-      int zero_flag = 0;
+         for (int v = 0; v < NV; ++v) nt[v] = 0.0;
+         int zero_flag = 0;
+         // rows in blocks of 4 to bound the live temporaries
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-         double d = 0.0;
+         for (int rb = 0; rb < R; rb += 4) {
+            double d[4];
 #pragma unroll
-         for (int j = 0; j < C; ++j) d = __builtin_fma(F[r][j], theta[j], d); // :450
-         zero_flag |= (act[r] && d == 0.0) ? 1 : 0;                          // :451
-         double w = fast_div(nn[r], d);
-         w = act[r] ? w : 0.0;
+            for (int q = 0; q < 4; ++q) {
+               if (rb + q < R) {
+                  double s = 0.0;
 #pragma unroll
-         for (int j = 0; j < C; ++j) red[j] = __builtin_fma(w, F[r][j], red[j]);
-      }
-      red[C] = (double)zero_flag;
-      comm.template sum<C + 1>(red, wave_id, phase);
-      const bool dz = red[C] != 0.0;
+                  for (int jj = 0; jj < CPL; ++jj) s = __builtin_fma(F[rb + q][jj], theta[jj], s); // :450
+                  d[q] = (CL > 1) ? bits_sum<0, LB_CL>(s) : s;
+               }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+               if (rb + q < R) {
+                  const int r = rb + q;
+                  zero_flag |= (act[r] && d[q] == 0.0) ? 1 : 0; // :451
+                  double w = fast_div(nn[r], d[q]);
+                  w = act[r] ? w : 0.0;
+#pragma unroll
+                  for (int jj = 0; jj < CPL; ++jj) nt[jj] = __builtin_fma(w, F[r][jj], nt[jj]);
+               }
+            }
+         }
+         nt[CPL] = (double)zero_flag;
+         row_lane_sum(nt, std::integral_constant<int, NV>());
+         dz = nt[CPL] != 0.0;
+         double p2 = 0.0;
+#pragma unroll
+         for (int jj = 0; jj < CPL; ++jj) {
+            nt[jj] = theta[jj] * nt[jj]; // next_theta_j = sum_i U_ij, :454-464
+            const double df = nt[jj] - theta[jj];
+            p2 = __builtin_fma(df, df, p2); // :479
+         }
+         const double d2 = bits_sum<0, LB_CL>(p2);
+         // ||next - theta||_2 < 1e-2 (:479-480) tested on the squares: sqrt is monotone, so
+         // the two tests can only differ for d2 within an ulp of 1e-4
+         conv = d2 < kThetaLimit * kThetaLimit;
+         special = have && (dz || conv || it == 0 || it + 1 == kMaxIter);
+         if (have && !special) {
+#pragma unroll
+            for (int jj = 0; jj < CPL; ++jj) theta[jj] = nt[jj]; // :481
+            ++it;
+         }
+      } while ((NW > 1) ? !special : !__any(special));
 
-      double next_theta[C];
-      double d2 = 0.0;
+      // ------------------------------------------------------- per-group events
+      // F <- column-normalised F after the first iteration (:466-478); a zero
+      // column stays zero.  Entered wave-uniformly; groups that are not at their
+      // first iteration scale by exactly 1.0, so F is updated in place for all.
+      const bool norm = special && !dz && it == 0;
+      {
+         double inv[CPL];
 #pragma unroll
-      for (int j = 0; j < C; ++j) {
-         next_theta[j] = theta[j] * red[j]; // = sum_i U_ij, :454-464
-         double df = next_theta[j] - theta[j];
-         d2 = __builtin_fma(df, df, d2);    // :479
+         for (int jj = 0; jj < CPL; ++jj) inv[jj] = 1.0;
+         if ((NW > 1) ? norm : __any(norm)) {
+            double cs[CPL];
+#pragma unroll
+            for (int jj = 0; jj < CPL; ++jj) {
+               double s = 0.0;
+#pragma unroll
+               for (int r = 0; r < R; ++r) s += F[r][jj];
+               cs[jj] = s;
+            }
+            row_lane_sum(cs, std::integral_constant<int, CPL>());
+#pragma unroll
+            for (int jj = 0; jj < CPL; ++jj) {
+               const double q = (cs[jj] == 0.0) ? 0.0 : 1.0 / cs[jj];
+               inv[jj] = norm ? q : 1.0;
+            }
+         }
+#pragma unroll
+         for (int jj = 0; jj < CPL; ++jj) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) F[r][jj] *= inv[jj];
+         }
       }
-
-      // ------------------------------------------------------- per-group epilogue
-      if (have) {
+      if (special) {
          bool finished = false;
          int32_t st = kStOk;
-         double out_scalar = 0.0;
-         bool out_is_theta0 = false;
          if (dz) {
             // run() returns false before touching _theta (:451-453): theta0 survives
             finished = true;
             st = kStDenomZero;
-            out_is_theta0 = true;
-            out_scalar = theta0;
+#pragma unroll
+            for (int jj = 0; jj < CPL; ++jj) theta[jj] = theta0;
+         } else if (conv) {
+            finished = true; // break before theta = next_theta (:480)
          } else {
-            if (it == 0) {
-               // F <- column-normalised F (:466-478); a zero column stays zero
-               double cs[C];
 #pragma unroll
-               for (int j = 0; j < C; ++j) {
-                  double s = 0.0;
-#pragma unroll
-                  for (int r = 0; r < R; ++r) s += F[r][j];
-                  cs[j] = s;
-               }
-               comm.template sum<C>(cs, wave_id, phase);
-#pragma unroll
-               for (int j = 0; j < C; ++j) {
-                  const double inv = (cs[j] == 0.0) ? 0.0 : 1.0 / cs[j];
-#pragma unroll
-                  for (int r = 0; r < R; ++r) F[r][j] *= inv;
-               }
-            }
-            if (sqrt(d2) < kThetaLimit) {
-               finished = true; // break before theta = next_theta (:480)
-               st = kStOk;
-            } else {
-#pragma unroll
-               for (int j = 0; j < C; ++j) theta[j] = next_theta[j]; // :481
-               if (it + 1 == kMaxIter) {
-                  finished = true;
-                  st = kStMaxIter;
-               }
+            for (int jj = 0; jj < CPL; ++jj) theta[jj] = nt[jj]; // :481
+            if (it + 1 == kMaxIter) {
+               finished = true;
+               st = kStMaxIter;
             }
          }
          ++it;
@@ -370,9 +496,10 @@ __global__ __launch_bounds__((G < 64) ? 64 : G) void em_tile_kernel(EmArgs a, Cl
                a.status[locus] = st;
                a.iters[locus] = it;
             }
+            if (gr == 0) {
 #pragma unroll
-            for (int j = 0; j < C; ++j) {
-               if (j < niso && (j % G) == g) a.theta[iso_base + j] = out_is_theta0 ? out_scalar : theta[j];
+               for (int jj = 0; jj < CPL; ++jj)
+                  if (gc * CPL + jj < niso) a.theta[iso_base + gc * CPL + jj] = theta[jj];
             }
             have = false;
          }
@@ -386,7 +513,7 @@ __global__ __launch_bounds__((G < 64) ? 64 : G) void em_tile_kernel(EmArgs a, Cl
 // the column normalisation is carried as a per-column scale s_j folded into
 // phi_j = s_j * theta_j.  LW lanes cooperate on one row (coalesced row reads),
 // 64/LW rows per wave-step.
-constexpr int kStreamThreads = 256;
+constexpr int kStreamThreads = 1024;
 constexpr int kStreamSlots = 8; // column slots per lane: niso <= LW * 8 <= 512
 
 __device__ __forceinline__ double wave_group_sum_rt(double x, int gw)
@@ -424,6 +551,7 @@ __global__ __launch_bounds__(kStreamThreads) void em_stream_kernel(EmArgs a, Cla
    const int lane = tid & 63;
    const int wave = tid >> 6;
    constexpr int NWAVE = kStreamThreads / 64;
+   set_fp64_flush_denormals();
 
    for (;;) {
       if (tid == 0) {
@@ -505,27 +633,40 @@ __global__ __launch_bounds__(kStreamThreads) void em_stream_kernel(EmArgs a, Cla
 #pragma unroll
          for (int k = 0; k < kStreamSlots; ++k) acc[k] = 0.0;
          int zf = 0;
-         for (int base = wave * rps; base < nrow; base += NWAVE * rps) {
-            const int i = base + rsub;
-            const bool valid = i < nrow;
-            double fv[kStreamSlots];
-            double part = 0.0;
+         constexpr int U = 4; // row-steps in flight per wave (independent loads first, then math)
+         for (int base = wave * rps; base < nrow; base += U * NWAVE * rps) {
+            double fv[U][kStreamSlots];
+            double cnt[U];
+            bool keepu[U];
 #pragma unroll
-            for (int k = 0; k < kStreamSlots; ++k) {
-               fv[k] = 0.0;
-               if (k < nslot) {
-                  const int j = c0 + k * lw;
-                  if (valid && j < niso) fv[k] = Fg[(int64_t)i * niso + j];
-                  part = __builtin_fma(fv[k], phi[j], part); // :450 with F' = F*scale
+            for (int u = 0; u < U; ++u) {
+               const int i = base + u * NWAVE * rps + rsub;
+               const bool valid = i < nrow;
+               const int ic = valid ? i : nrow - 1;
+               cnt[u] = valid ? (double)a.count[r0 + ic] : 0.0;
+               keepu[u] = valid && row_keep[r0 + ic] != 0;
+#pragma unroll
+               for (int k = 0; k < kStreamSlots; ++k) {
+                  fv[u][k] = 0.0;
+                  if (k < nslot) {
+                     const int j = c0 + k * lw;
+                     if (valid && j < niso) fv[u][k] = Fg[(int64_t)ic * niso + j];
+                  }
                }
             }
-            const double d = wave_group_sum_rt(part, lw);
-            const bool keep = valid && row_keep[r0 + i] != 0;
-            zf |= (keep && d == 0.0) ? 1 : 0;                 // :451
-            double w = fast_div(valid ? (double)a.count[r0 + i] : 0.0, d);
-            w = keep ? w : 0.0;
 #pragma unroll
-            for (int k = 0; k < kStreamSlots; ++k) acc[k] = __builtin_fma(w, fv[k], acc[k]);
+            for (int u = 0; u < U; ++u) {
+               double part = 0.0;
+#pragma unroll
+               for (int k = 0; k < kStreamSlots; ++k)
+                  if (k < nslot) part = __builtin_fma(fv[u][k], phi[c0 + k * lw], part); // :450 with F' = F*scale
+               const double d = wave_group_sum_rt(part, lw);
+               zf |= (keepu[u] && d == 0.0) ? 1 : 0; // :451
+               double w = fast_div(cnt[u], d);
+               w = keepu[u] ? w : 0.0;
+#pragma unroll
+               for (int k = 0; k < kStreamSlots; ++k) acc[k] = __builtin_fma(w, fv[u][k], acc[k]);
+            }
          }
          // column partials: over the row sub-groups of the wave, then one slot per wave
 #pragma unroll

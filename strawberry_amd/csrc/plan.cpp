@@ -49,33 +49,43 @@ int build_host_plan(int64_t n_loci, const int64_t *row_off, const int64_t *iso_o
          return SBGPU_ESHAPE;
       }
       p.algorithmic_bytes += nrow * niso * 8 + nrow * 4 + niso * 8 + 24;
-      int kind = kStream, C = 0, R = 0, G = 0;
+      int kind = kStream, CPL = 0, CL = 0, R = 0, G = 0;
       if (niso <= kMaxTileC) {
-         C = std::max(2, pow2ceil((int)niso));
-         R = kTileElems / C;
-         const int64_t lanes = std::max<int64_t>(1, (nrow + R - 1) / R);
+         const int C = std::max(2, pow2ceil((int)niso));
+         CPL = std::min(C, kMaxCPL);
+         CL = C / CPL;
+         R = kTileElems / CPL;
+         // row lanes needed with R rows each; the group is CL x (row lanes)
+         int64_t gr = std::max<int64_t>(1, (nrow + R - 1) / R);
+         int64_t lanes = (int64_t)pow2ceil((int)std::min<int64_t>(gr, 1 << 20)) * CL;
          if (lanes <= 64) {
             kind = kTile;
-            G = pow2ceil((int)lanes);
-         } else if (lanes <= 256) {
-            kind = kTile;
-            G = 256;
-         } else if (lanes <= 1024) {
-            kind = kTile;
-            G = 1024;
+            G = (int)lanes;
+         } else {
+            // one workgroup per locus: 256 or 512 lanes, R or 2R rows per row lane
+            for (int mult = 1; mult <= 2 && kind != kTile; ++mult) {
+               for (int gg = 256; gg <= 512 && kind != kTile; gg *= 2) {
+                  if ((int64_t)(gg / CL) * R * mult >= nrow) {
+                     kind = kTile;
+                     G = gg;
+                     R = R * mult;
+                  }
+               }
+            }
          }
       }
       if (kind == kStream) {
-         C = R = G = 0;
+         CPL = CL = R = G = 0;
          ++p.n_stream_loci;
       }
-      SizeClass &sc = by_key[std::make_tuple(kind, C, R, G)];
+      SizeClass &sc = by_key[std::make_tuple(kind, CPL * 16 + CL, R, G)];
       sc.kind = kind;
-      sc.C = C;
+      sc.CPL = CPL;
+      sc.CL = CL;
       sc.R = R;
       sc.G = G;
       sc.loci.push_back((int32_t)l);
-      sc.work += (kind == kTile) ? (int64_t)G * R * C : nrow * niso;
+      sc.work += (kind == kTile) ? (int64_t)(G / CL) * R * CPL * CL : nrow * niso;
    }
    p.n_rows = row_off[n_loci];
    p.n_iso = iso_off[n_loci];
@@ -104,9 +114,9 @@ int build_host_plan(int64_t n_loci, const int64_t *row_off, const int64_t *iso_o
             waves_wanted += (int64_t)sc.n_blocks * (sc.G / 64);
          }
       } else {
-         sc.block_threads = 256;
+         sc.block_threads = 1024;
          sc.n_blocks = (int)n;
-         waves_wanted += (int64_t)sc.n_blocks * 4;
+         waves_wanted += (int64_t)sc.n_blocks * 16;
       }
    }
    if (waves_wanted > wave_budget) {

@@ -16,7 +16,8 @@ enum ClassKind : int { kTile = 0, kStream = 1 };
 
 struct SizeClass {
    int kind;     // kTile / kStream
-   int C, R, G;  // tile: columns, rows per lane, lanes per locus (G > 64: one workgroup)
+   int CPL, CL;  // tile: columns per lane, column lanes (CPL*CL >= niso)
+   int R, G;     // tile: rows per row lane, lanes per locus = CL * row lanes (G > 64: one workgroup)
    std::vector<int32_t> loci; // ordered by decreasing nrow*niso
    int n_blocks = 0;          // launch grid
    int block_threads = 0;
@@ -30,8 +31,9 @@ struct HostPlan {
    std::vector<SizeClass> classes; // non-empty classes, heaviest first
 };
 
-constexpr int kTileElems = 32;    // R*C register tile per lane
-constexpr int kMaxTileC = 32;     // widest register tile; wider loci stream
+constexpr int kTileElems = 32;    // R*CPL register tile per lane (x2 for the tall workgroup variants)
+constexpr int kMaxCPL = 8;        // columns per lane
+constexpr int kMaxTileC = 64;     // 8 column lanes x 8 columns; wider loci stream
 constexpr int kMaxStreamIso = 512;
 
 // Returns 0, or a negative SBGPU_E* code with `err` filled.

@@ -66,42 +66,53 @@ struct sbgpu_plan {
 // ------------------------------------------------------------------ kernel dispatch
 namespace {
 
-template <int C, int G>
-hipError_t launch_tile_cg(const sb::EmArgs &a, const sb::ClassArgs &c, int n_blocks, hipStream_t s)
+template <int CPL, int CL, int R, int G>
+hipError_t launch_tile_inst(const sb::EmArgs &a, const sb::ClassArgs &c, int n_blocks, hipStream_t s)
 {
-   constexpr int R = sb::kTileElems / C;
    constexpr int threads = (G < 64) ? 64 : G;
-   hipLaunchKernelGGL((sb::em_tile_kernel<C, R, G>), dim3(n_blocks), dim3(threads), 0, s, a, c);
+   hipLaunchKernelGGL((sb::em_tile_kernel<CPL, CL, R, G>), dim3(n_blocks), dim3(threads), 0, s, a, c);
    return hipGetLastError();
 }
 
-template <int C>
-hipError_t launch_tile_c(int G, const sb::EmArgs &a, const sb::ClassArgs &c, int n_blocks, hipStream_t s)
+template <int CPL, int CL>
+hipError_t launch_tile_g(int R, int G, const sb::EmArgs &a, const sb::ClassArgs &c, int n_blocks, hipStream_t s)
 {
-   switch (G) {
-   case 1: return launch_tile_cg<C, 1>(a, c, n_blocks, s);
-   case 2: return launch_tile_cg<C, 2>(a, c, n_blocks, s);
-   case 4: return launch_tile_cg<C, 4>(a, c, n_blocks, s);
-   case 8: return launch_tile_cg<C, 8>(a, c, n_blocks, s);
-   case 16: return launch_tile_cg<C, 16>(a, c, n_blocks, s);
-   case 32: return launch_tile_cg<C, 32>(a, c, n_blocks, s);
-   case 64: return launch_tile_cg<C, 64>(a, c, n_blocks, s);
-   case 256: return launch_tile_cg<C, 256>(a, c, n_blocks, s);
-   case 1024: return launch_tile_cg<C, 1024>(a, c, n_blocks, s);
-   default: return hipErrorInvalidValue;
+   constexpr int R1 = sb::kTileElems / CPL;
+   if (R == R1) {
+      switch (G) {
+#define SB_CASE(GG)                                                                         \
+   case GG:                                                                                 \
+      if constexpr (GG >= CL) return launch_tile_inst<CPL, CL, R1, GG>(a, c, n_blocks, s);  \
+      break;
+         SB_CASE(1)
+         SB_CASE(2)
+         SB_CASE(4)
+         SB_CASE(8)
+         SB_CASE(16)
+         SB_CASE(32)
+         SB_CASE(64)
+         SB_CASE(256)
+         SB_CASE(512)
+#undef SB_CASE
+      default: break;
+      }
+   } else if (R == 2 * R1) {
+      if (G == 256) return launch_tile_inst<CPL, CL, 2 * R1, 256>(a, c, n_blocks, s);
+      if (G == 512) return launch_tile_inst<CPL, CL, 2 * R1, 512>(a, c, n_blocks, s);
    }
+   return hipErrorInvalidValue;
 }
 
-hipError_t launch_tile(int C, int G, const sb::EmArgs &a, const sb::ClassArgs &c, int n_blocks, hipStream_t s)
+hipError_t launch_tile(int CPL, int CL, int R, int G, const sb::EmArgs &a, const sb::ClassArgs &c, int n_blocks,
+                       hipStream_t s)
 {
-   switch (C) {
-   case 2: return launch_tile_c<2>(G, a, c, n_blocks, s);
-   case 4: return launch_tile_c<4>(G, a, c, n_blocks, s);
-   case 8: return launch_tile_c<8>(G, a, c, n_blocks, s);
-   case 16: return launch_tile_c<16>(G, a, c, n_blocks, s);
-   case 32: return launch_tile_c<32>(G, a, c, n_blocks, s);
-   default: return hipErrorInvalidValue;
-   }
+   if (CPL == 2 && CL == 1) return launch_tile_g<2, 1>(R, G, a, c, n_blocks, s);
+   if (CPL == 4 && CL == 1) return launch_tile_g<4, 1>(R, G, a, c, n_blocks, s);
+   if (CPL == 8 && CL == 1) return launch_tile_g<8, 1>(R, G, a, c, n_blocks, s);
+   if (CPL == 8 && CL == 2) return launch_tile_g<8, 2>(R, G, a, c, n_blocks, s);
+   if (CPL == 8 && CL == 4) return launch_tile_g<8, 4>(R, G, a, c, n_blocks, s);
+   if (CPL == 8 && CL == 8) return launch_tile_g<8, 8>(R, G, a, c, n_blocks, s);
+   return hipErrorInvalidValue;
 }
 
 // ------------------------------------------------------------------ epilogue kernels
@@ -270,7 +281,7 @@ int sbgpu_device_info(sbgpu_ctx_t *c, int64_t out[8])
 int sbgpu_synchronize(sbgpu_ctx_t *c, void *stream)
 {
    if (!c) return fail(SBGPU_EINVAL, "sbgpu_synchronize: null ctx");
-   HIP_TRY(hipStreamSynchronize(stream ? (hipStream_t)stream : c->stream));
+   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
    return SBGPU_OK;
 }
 
@@ -371,7 +382,7 @@ int sbgpu_plan_classes(const sbgpu_plan_t *p, int64_t *out, int cap)
    for (int i = 0; i < n && i < cap && out; ++i) {
       const sb::SizeClass &sc = p->classes[i].host;
       out[i * 6 + 0] = sc.kind;
-      out[i * 6 + 1] = sc.C;
+      out[i * 6 + 1] = sc.CPL * sc.CL;
       out[i * 6 + 2] = sc.R;
       out[i * 6 + 3] = sc.G;
       out[i * 6 + 4] = (int64_t)sc.loci.size();
@@ -387,7 +398,7 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
    if (p->host.n_loci == 0) return SBGPU_OK;
    if (!d_theta || !d_status || !d_iters || (!d_count && p->host.n_rows) || (!d_F && p->host.n_elem))
       return fail(SBGPU_EINVAL, "sbgpu_em_run_device: null device pointer");
-   hipStream_t main = stream ? (hipStream_t)stream : c->stream;
+   hipStream_t main = (hipStream_t)stream;
    sb::EmArgs a;
    a.row_off = p->d_row_off;
    a.iso_off = p->d_iso_off;
@@ -414,7 +425,7 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
       ca.n = (int32_t)sc.loci.size();
       ca.cursor = p->d_cursors + dc.cursor_index;
       if (sc.kind == sb::kTile) {
-         HIP_TRY(launch_tile(sc.C, sc.G, a, ca, sc.n_blocks, s));
+         HIP_TRY(launch_tile(sc.CPL, sc.CL, sc.R, sc.G, a, ca, sc.n_blocks, s));
       } else {
          hipLaunchKernelGGL(sb::em_stream_kernel, dim3(sc.n_blocks), dim3(sb::kStreamThreads),
                             p->stream_lds_bytes, s, a, ca, p->d_row_keep);
@@ -491,7 +502,7 @@ int sbgpu_abundance_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const double *
    if (!d_theta || !d_status || !d_length || !d_fpkm || !d_frac || !d_keep || !d_sum_fpkm)
       return fail(SBGPU_EINVAL, "sbgpu_abundance_device: null device pointer");
    if (params->total_mapped_reads <= 0) return fail(SBGPU_EINVAL, "sbgpu_abundance_device: total_mapped_reads must be > 0");
-   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+   hipStream_t s = (hipStream_t)stream;
    const int64_t n = p->host.n_loci;
    const int threads = 256;
    hipLaunchKernelGGL(abundance_kernel, dim3((unsigned)((n + threads - 1) / threads)), dim3(threads), 0, s, n,
@@ -508,7 +519,7 @@ int sbgpu_tpm_device(sbgpu_ctx_t *c, int64_t n_iso, const double *d_fpkm, const 
    if (!c) return fail(SBGPU_EINVAL, "sbgpu_tpm_device: null ctx");
    if (n_iso == 0) return SBGPU_OK;
    if (!d_fpkm || !d_keep || !d_total_fpkm || !d_tpm) return fail(SBGPU_EINVAL, "sbgpu_tpm_device: null device pointer");
-   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+   hipStream_t s = (hipStream_t)stream;
    const int threads = 256;
    hipLaunchKernelGGL(tpm_kernel, dim3((unsigned)((n_iso + threads - 1) / threads)), dim3(threads), 0, s, n_iso,
                       d_fpkm, d_keep, d_total_fpkm, d_tpm);

@@ -68,7 +68,8 @@ def test_gpu_host_buffer_entry(ctx, oracle, golden):
 
 
 @pytest.mark.parametrize("shape", [(1, 1), (1, 7), (7, 1), (5, 2), (33, 3), (64, 8), (65, 8), (200, 5),
-                                   (257, 8), (300, 16), (129, 32), (2000, 8), (5000, 2), (40, 33), (100, 64)])
+                                   (257, 8), (300, 16), (129, 32), (2000, 8), (5000, 2), (40, 33), (100, 64),
+                                   (9000, 2), (1000, 20), (3000, 20), (17, 13), (500, 40), (64, 65), (30, 200)])
 def test_gpu_every_size_class(ctx, oracle, shape):
     """One batch per (nrow, niso) shape so that each tile / workgroup / streaming
     class is exercised on its own, including its padding."""
@@ -144,7 +145,7 @@ def test_gpu_abundance_and_tpm_match_oracle(ctx, oracle, golden):
     s.run_em()
     total_mapped = 3_000_000
     for kw in (dict(min_isoform_frac=0.01), dict(min_isoform_frac=0.0),
-               dict(effective_len_norm=True, insert_mean=700.0, min_isoform_frac=0.01)):
+               dict(effective_len_norm=True, insert_mean=700.5, min_isoform_frac=0.01)):
         s.run_abundance(total_mapped, **kw)
         s.run_tpm()
         r = s.results()

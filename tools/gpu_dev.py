@@ -43,6 +43,12 @@ def bench(b, ctx, o, label, reps=5, check=True):
         print("   oracle %d thr: %.2fs (%.0f loci/s)  status_eq %s iters_eq %s (ndiff %d) max_rel_err %.2e" % (
             os.cpu_count(), dt, b.n_loci / dt, (r["status"] == status).all(), (r["iters"] == iters).all(),
             int((r["iters"] != iters).sum()), err.max()), flush=True)
+        bad = np.nonzero((r["status"] != status) | (r["iters"] != iters))[0]
+        errl = np.maximum.reduceat(np.nan_to_num(err, nan=1e9), b.iso_off[:-1])
+        bad = np.union1d(bad, np.nonzero(errl > 1e-9)[0])
+        for l in bad[:20]:
+            print("   BAD locus %d nrow %d niso %d: gpu st %d it %d | oracle st %d it %d | err %.2e" % (
+                l, b.nrow[l], b.niso[l], r["status"][l], r["iters"][l], status[l], iters[l], errl[l]))
 
 
 def main():
