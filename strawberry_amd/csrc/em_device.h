@@ -26,6 +26,7 @@ constexpr int kMaxIter = 1000;          // include/estimate.hpp:237
 constexpr double kThetaLimit = 1e-2;    // include/estimate.hpp:241
 constexpr double kRowEps = 1e-5;        // src/estimate.cpp:380
 
+constexpr int kMaxCPLv = 8;            // columns per lane of the widest register tile
 constexpr int32_t kStOk = 0, kStInitEmpty = 1, kStDenomZero = 2, kStMaxIter = 3;
 
 // Device view of a batch (CSR-of-loci, include/sbgpu.h) and its outputs.
@@ -141,13 +142,16 @@ __device__ __forceinline__ double fast_div(double n, double d)
 // theta for its own CPL columns.  Per iteration the group needs
 //   - the row denominators: all-reduce over the CL column lanes (low lane bits),
 //   - the weighted column sums: all-reduce over the GR row lanes (high lane bits;
-//     GR > 64/CL continues through LDS across the waves of the workgroup),
+//     in the workgroup form it continues through LDS across the waves),
 // both as DPP butterflies; every lane of a group ends with bitwise identical sums,
 // so the convergence decision is group-uniform by construction.
 //
-// G <= 64: 64/G groups share a wave and run independent loci; G = 256/512: the
-// group is the whole workgroup.  Groups pull loci from the class list through an
-// atomic cursor until it runs dry (iteration counts range from 1 to the 1000 cap).
+// Wave form  (BLOCK = false): G = 2^lbG <= 64 lanes, 64/G groups share a wave and
+//                             run independent loci; G is a run-time (wave-uniform)
+//                             value so that one kernel serves every size class.
+// Block form (BLOCK = true):  the group is the whole workgroup (256 or 512 lanes).
+// Groups pull loci from their class list through an atomic cursor until it runs
+// dry (iteration counts range from 1 to the 1000 cap).
 
 // value of lane (lane ^ MASK), true xor for every MASK
 template <int MASK>
@@ -171,37 +175,50 @@ __device__ __forceinline__ double xor_get(double x)
 {
    return __hiloint2double(xor_get_i<MASK>(__double2hiint(x)), xor_get_i<MASK>(__double2loint(x)));
 }
-template <int MASK>
+// x(lane) + x(lane ^ MASK).  LOW_UNIFORM: every lane below bit log2(MASK) of the
+// group already holds the same value, so the cheaper mirror forms are valid.
+template <int MASK, bool LOW_UNIFORM>
 __device__ __forceinline__ double xor_sum(double x)
 {
    if (MASK == 32) return sum_xor32(x);
+   if (MASK == 16) return x + swizzle_xor16(x);
+   if (LOW_UNIFORM && MASK == 4) return x + dpp_mov<kDppHalfMirror>(x);
+   if (LOW_UNIFORM && MASK == 8) return x + dpp_mov<kDppMirror>(x);
    return x + xor_get<MASK>(x);
 }
 
-// all-reduce over lane bits [LO, HI) (masks 2^LO .. 2^(HI-1)).  With LO == 0 the
-// cheaper mirror forms are valid for masks 4 and 8 (the lanes below are uniform).
-template <int LO, int HI>
-__device__ __forceinline__ double bits_sum(double x)
+constexpr int ilog2(int x) { return x <= 1 ? 0 : 1 + ilog2(x / 2); }
+
+// all-reduce over lane bits [0, HI) (compile-time)
+template <int HI>
+__device__ __forceinline__ double low_bits_sum(double x)
 {
-   if (LO == 0) {
-      if (HI >= 1) x += dpp_mov<kDppXor1>(x);
-      if (HI >= 2) x += dpp_mov<kDppXor2>(x);
-      if (HI >= 3) x += dpp_mov<kDppHalfMirror>(x);
-      if (HI >= 4) x += dpp_mov<kDppMirror>(x);
-      if (HI >= 5) x += swizzle_xor16(x);
-      if (HI >= 6) x = sum_xor32(x);
-      return x;
-   }
-   if (LO <= 0 && HI > 0) x = xor_sum<1>(x);
-   if (LO <= 1 && HI > 1) x = xor_sum<2>(x);
-   if (LO <= 2 && HI > 2) x = xor_sum<4>(x);
-   if (LO <= 3 && HI > 3) x = xor_sum<8>(x);
-   if (LO <= 4 && HI > 4) x = xor_sum<16>(x);
-   if (LO <= 5 && HI > 5) x = xor_sum<32>(x);
+   if (HI > 0) x = xor_sum<1, true>(x);
+   if (HI > 1) x = xor_sum<2, true>(x);
+   if (HI > 2) x = xor_sum<4, true>(x);
+   if (HI > 3) x = xor_sum<8, true>(x);
+   if (HI > 4) x = xor_sum<16, true>(x);
+   if (HI > 5) x = xor_sum<32, true>(x);
    return x;
 }
 
-constexpr int ilog2(int x) { return x <= 1 ? 0 : 1 + ilog2(x / 2); }
+// all-reduce of NVAL values over lane bits [LO, hi): LO compile-time, hi wave-uniform
+template <int LO, int NVAL>
+__device__ __forceinline__ void high_bits_sum(double (&x)[NVAL], int hi)
+{
+#define SB_STEP(BIT)                                                                \
+   if (LO <= BIT && hi > BIT) {                                                     \
+      _Pragma("unroll") for (int v = 0; v < NVAL; ++v)                              \
+         x[v] = xor_sum<(1 << BIT), (LO == 0)>(x[v]);                               \
+   }
+   SB_STEP(0)
+   SB_STEP(1)
+   SB_STEP(2)
+   SB_STEP(3)
+   SB_STEP(4)
+   SB_STEP(5)
+#undef SB_STEP
+}
 
 // fp64 denormals flush to zero inside the EM, like the reference build: it is
 // compiled -Ofast (CMakeLists.txt:84), whose crtfastmath.o sets FTZ/DAZ, and that
@@ -212,47 +229,56 @@ __device__ __forceinline__ void set_fp64_flush_denormals()
    __builtin_amdgcn_s_setreg(1 | (6 << 6) | ((2 - 1) << 11), 0);
 }
 
-template <int CPL, int CL, int R, int G>
-__global__ __launch_bounds__((G < 64) ? 64 : G) void em_tile_kernel(EmArgs a, ClassArgs cls)
+constexpr int kBlockWaves = 4; // block form: 256 lanes, one wave per SIMD, up to 512 VGPRs each
+
+// NWAVES = 0: wave form; NWAVES = 4: block form.  R is the register-tile capacity
+// in rows per row lane; the block form skips the row blocks a locus does not need.
+template <int CPL, int CL, int R, int NWAVES>
+__device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &cls, const int lbG,
+                                             double *s_red, int *s_idx)
 {
-   constexpr int GW = (G < 64) ? G : 64;        // lanes of the group inside one wave
-   constexpr int NW = (G <= 64) ? 1 : G / 64;   // waves per group
-   constexpr int GR = G / CL;                   // row lanes per group
+   constexpr bool BLOCK = NWAVES > 0;
+   constexpr int NW = BLOCK ? NWAVES : 1;                  // waves per group
    constexpr int LB_CL = ilog2(CL);
-   constexpr int LB_GW = ilog2(GW);
-   constexpr int NV = CPL + 1;                  // values in the per-iteration column reduce
-   static_assert(G >= CL && (G % CL) == 0, "group must hold all column lanes");
-   // cross-wave exchange: [2 phases][NW waves][CL column lanes][NV values]
-   __shared__ double s_red[(NW > 1) ? 2 * NW * CL * NV : 1];
-   __shared__ int s_idx;
-   int phase = 0;
-
-   set_fp64_flush_denormals();
-
+   constexpr int NV = CPL + 1; // values in the per-iteration column reduce
    const int lane = threadIdx.x & 63;
    const int wave_id = threadIdx.x >> 6;
-   const int g = (G <= 64) ? (lane & (GW - 1)) : (int)threadIdx.x; // index inside the group
+   const int GW = BLOCK ? 64 : (1 << lbG);                 // lanes of the group inside one wave
+   const int lbGW = BLOCK ? 6 : lbG;
+   const int G = BLOCK ? 64 * NW : GW;
+   const int GR = G >> LB_CL;                              // row lanes per group
+   const int g = BLOCK ? (int)threadIdx.x : (lane & (GW - 1)); // index inside the group
    const int gc = g & (CL - 1);
    const int gr = g >> LB_CL;
+   int phase = 0;
+   int r_used = R; // block form: rows per row lane the current locus needs (workgroup-uniform)
 
-   // all-reduce over the row lanes of the group of NVAL per-lane values
-   auto row_lane_sum = [&](double *x, auto nval_tag) {
+   // all-reduce over the row lanes of the group
+   auto row_lane_sum = [&](auto &x, auto nval_tag) {
       constexpr int NVAL = decltype(nval_tag)::value;
-#pragma unroll
-      for (int v = 0; v < NVAL; ++v) x[v] = bits_sum<LB_CL, LB_GW>(x[v]);
-      if (NW > 1) {
-         double *buf = s_red + (size_t)phase * (NW * CL * NV);
+      high_bits_sum<LB_CL, NVAL>(x, lbGW);
+      if (BLOCK) {
+         // cross-wave: [2 phases][NV values][CL column lanes][NW]; every lane then adds
+         // the NW partials in the same order
+         double *buf = s_red + (size_t)phase * (NV * CL * NW);
          if (lane < CL) {
 #pragma unroll
-            for (int v = 0; v < NVAL; ++v) buf[(wave_id * CL + lane) * NV + v] = x[v];
+            for (int v = 0; v < NVAL; ++v) buf[(v * CL + lane) * NW + wave_id] = x[v];
          }
          __syncthreads();
+         double part[NVAL][NW];
 #pragma unroll
          for (int v = 0; v < NVAL; ++v) {
-            double s = 0.0;
+            const double *p = buf + (v * CL + gc) * NW;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) s += buf[(w * CL + gc) * NV + v];
-            x[v] = s;
+            for (int w = 0; w < NW; ++w) part[v][w] = p[w];
+         }
+#pragma unroll
+         for (int v = 0; v < NVAL; ++v) {
+            double sum = part[v][0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) sum += part[v][w];
+            x[v] = sum;
          }
          phase ^= 1; // double-buffered: one barrier per round is enough
       }
@@ -262,10 +288,11 @@ __global__ __launch_bounds__((G < 64) ? 64 : G) void em_tile_kernel(EmArgs a, Cl
    double nn[R];      // n_i as double (obs_d, estimate.cpp:418-419); 0 for dropped rows
    bool act[R];       // row kept by init() (estimate.cpp:377-390)
    double theta[CPL];
+   double scale[CPL]; // 1, then 1/column-sum after the first iteration: F' = F * scale (:466-478)
    double theta0 = 0.0;
    int it = 0;
    int niso = 0;
-   int locus = -1;
+   int locus = 0;
    int64_t iso_base = 0;
    bool have = false;       // the group currently owns a locus
    bool exhausted = false;  // the class list ran dry for this group
@@ -278,7 +305,10 @@ __global__ __launch_bounds__((G < 64) ? 64 : G) void em_tile_kernel(EmArgs a, Cl
       for (int j = 0; j < CPL; ++j) F[r][j] = 0.0;
    }
 #pragma unroll
-   for (int j = 0; j < CPL; ++j) theta[j] = 0.0;
+   for (int j = 0; j < CPL; ++j) {
+      theta[j] = 0.0;
+      scale[j] = 1.0;
+   }
 
    for (;;) {
       // ---------------------------------------------------------------- refill
@@ -286,18 +316,19 @@ __global__ __launch_bounds__((G < 64) ? 64 : G) void em_tile_kernel(EmArgs a, Cl
       // it too (on locus 0's addresses, results discarded by selects) so that F,
       // theta, ... are updated in place without per-lane control flow.
       const bool need = !have && !exhausted;
-      if ((NW > 1) ? need : __any(need)) {
+      if (BLOCK ? need : __any(need)) {
          int idx = 0;
-         if (NW > 1) {
-            if (threadIdx.x == 0) s_idx = atomicAdd(cls.cursor, 1);
+         if (BLOCK) {
+            if (threadIdx.x == 0) *s_idx = atomicAdd(cls.cursor, 1);
             __syncthreads();
-            idx = s_idx;
+            idx = *s_idx;
             __syncthreads();
          } else {
             if (need && g == 0) idx = atomicAdd(cls.cursor, 1);
             idx = __shfl(idx, lane & ~(GW - 1));
          }
-         const bool got = need && idx < cls.n;
+         if (BLOCK && idx >= cls.n) break; // workgroup-uniform: the class list is dry
+         const bool got = BLOCK ? true : (need && idx < cls.n);
          exhausted = exhausted || (need && idx >= cls.n);
          const int loc = got ? cls.loci[idx] : 0;
          const int64_t r0 = a.row_off[loc];
@@ -305,12 +336,17 @@ __global__ __launch_bounds__((G < 64) ? 64 : G) void em_tile_kernel(EmArgs a, Cl
          const int64_t ib = a.iso_off[loc];
          const int ni = (int)(a.iso_off[loc + 1] - ib);
          const double *Fg = a.F + a.f_off[loc];
+         if (BLOCK) {
+            r_used = (nrow + GR - 1) / GR;
+            r_used = r_used < 1 ? 1 : (r_used > R ? R : r_used);
+         }
          // EmSolver::init, estimate.cpp:366-391
          double red[2];
          red[0] = 0.0; // sum of ALL counts (theta0 precedes the row drop, :374-375)
          red[1] = 0.0; // number of kept rows
 #pragma unroll
          for (int r = 0; r < R; ++r) {
+            if (BLOCK && (r & ~3) >= r_used) continue; // row block not needed by this locus
             const int i = r * GR + gr;
             const bool valid = got && i < nrow;
             // clamped indices: loads stay inside the locus (or touch nothing when it
@@ -338,19 +374,29 @@ __global__ __launch_bounds__((G < 64) ? 64 : G) void em_tile_kernel(EmArgs a, Cl
             if (CL >= 8) mx = fmax(mx, xor_get<4>(mx));
             const bool keep = mx > kRowEps;
             if (gc == 0 && keep) red[1] += 1.0;
-            act[r] = got ? keep : act[r];
-            nn[r] = got ? (keep ? cnt : 0.0) : nn[r];
+            if (BLOCK) {
+               act[r] = keep;
+               nn[r] = keep ? cnt : 0.0;
 #pragma unroll
-            for (int jj = 0; jj < CPL; ++jj) F[r][jj] = got ? (keep ? v[jj] : 0.0) : F[r][jj];
+               for (int jj = 0; jj < CPL; ++jj) F[r][jj] = keep ? v[jj] : 0.0;
+            } else {
+               act[r] = got ? keep : act[r];
+               nn[r] = got ? (keep ? cnt : 0.0) : nn[r];
+#pragma unroll
+               for (int jj = 0; jj < CPL; ++jj) F[r][jj] = got ? (keep ? v[jj] : 0.0) : F[r][jj];
+            }
          }
          // group totals: over the column lanes, then over the row lanes
-         red[0] = bits_sum<0, LB_CL>(red[0]);
-         red[1] = bits_sum<0, LB_CL>(red[1]);
+         red[0] = low_bits_sum<LB_CL>(red[0]);
+         red[1] = low_bits_sum<LB_CL>(red[1]);
          row_lane_sum(red, std::integral_constant<int, 2>());
          const double t0 = red[0] / (double)ni; // :375, IEEE division
          theta0 = got ? t0 : theta0;
 #pragma unroll
-         for (int jj = 0; jj < CPL; ++jj) theta[jj] = got ? ((gc * CPL + jj < ni) ? t0 : 0.0) : theta[jj];
+         for (int jj = 0; jj < CPL; ++jj) {
+            theta[jj] = got ? ((gc * CPL + jj < ni) ? t0 : 0.0) : theta[jj];
+            scale[jj] = got ? 1.0 : scale[jj];
+         }
          it = got ? 0 : it;
          locus = got ? loc : locus;
          niso = got ? ni : niso;
@@ -370,7 +416,7 @@ __global__ __launch_bounds__((G < 64) ? 64 : G) void em_tile_kernel(EmArgs a, Cl
          }
          have = have || (got && !empty);
       }
-      if (NW > 1) {
+      if (BLOCK) {
          // have / exhausted are workgroup-uniform
          if (!have) {
             if (exhausted) break;
@@ -392,18 +438,22 @@ __global__ __launch_bounds__((G < 64) ? 64 : G) void em_tile_kernel(EmArgs a, Cl
       do {
 #pragma unroll
          for (int v = 0; v < NV; ++v) nt[v] = 0.0;
+         double phi[CPL]; // theta of the column-normalised problem seen through the raw F
+#pragma unroll
+         for (int jj = 0; jj < CPL; ++jj) phi[jj] = theta[jj] * scale[jj];
          int zero_flag = 0;
          // rows in blocks of 4 to bound the live temporaries
 #pragma unroll
          for (int rb = 0; rb < R; rb += 4) {
+            if (BLOCK && rb >= r_used) continue;
             double d[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                if (rb + q < R) {
                   double s = 0.0;
 #pragma unroll
-                  for (int jj = 0; jj < CPL; ++jj) s = __builtin_fma(F[rb + q][jj], theta[jj], s); // :450
-                  d[q] = (CL > 1) ? bits_sum<0, LB_CL>(s) : s;
+                  for (int jj = 0; jj < CPL; ++jj) s = __builtin_fma(F[rb + q][jj], phi[jj], s); // :450
+                  d[q] = low_bits_sum<LB_CL>(s);
                }
             }
 #pragma unroll
@@ -424,11 +474,11 @@ __global__ __launch_bounds__((G < 64) ? 64 : G) void em_tile_kernel(EmArgs a, Cl
          double p2 = 0.0;
 #pragma unroll
          for (int jj = 0; jj < CPL; ++jj) {
-            nt[jj] = theta[jj] * nt[jj]; // next_theta_j = sum_i U_ij, :454-464
+            nt[jj] = phi[jj] * nt[jj]; // next_theta_j = sum_i U_ij, :454-464
             const double df = nt[jj] - theta[jj];
             p2 = __builtin_fma(df, df, p2); // :479
          }
-         const double d2 = bits_sum<0, LB_CL>(p2);
+         const double d2 = low_bits_sum<LB_CL>(p2);
          // ||next - theta||_2 < 1e-2 (:479-480) tested on the squares: sqrt is monotone, so
          // the two tests can only differ for d2 within an ulp of 1e-4
          conv = d2 < kThetaLimit * kThetaLimit;
@@ -438,37 +488,27 @@ __global__ __launch_bounds__((G < 64) ? 64 : G) void em_tile_kernel(EmArgs a, Cl
             for (int jj = 0; jj < CPL; ++jj) theta[jj] = nt[jj]; // :481
             ++it;
          }
-      } while ((NW > 1) ? !special : !__any(special));
+      } while (BLOCK ? !special : !__any(special));
 
       // ------------------------------------------------------- per-group events
-      // F <- column-normalised F after the first iteration (:466-478); a zero
-      // column stays zero.  Entered wave-uniformly; groups that are not at their
-      // first iteration scale by exactly 1.0, so F is updated in place for all.
+      // F <- column-normalised F after the first iteration (:466-478), a zero column
+      // stays zero: F itself is left untouched in registers, the column scale takes it.
       const bool norm = special && !dz && it == 0;
-      {
-         double inv[CPL];
-#pragma unroll
-         for (int jj = 0; jj < CPL; ++jj) inv[jj] = 1.0;
-         if ((NW > 1) ? norm : __any(norm)) {
-            double cs[CPL];
-#pragma unroll
-            for (int jj = 0; jj < CPL; ++jj) {
-               double s = 0.0;
-#pragma unroll
-               for (int r = 0; r < R; ++r) s += F[r][jj];
-               cs[jj] = s;
-            }
-            row_lane_sum(cs, std::integral_constant<int, CPL>());
-#pragma unroll
-            for (int jj = 0; jj < CPL; ++jj) {
-               const double q = (cs[jj] == 0.0) ? 0.0 : 1.0 / cs[jj];
-               inv[jj] = norm ? q : 1.0;
-            }
-         }
+      if (BLOCK ? norm : __any(norm)) {
+         double cs[CPL];
 #pragma unroll
          for (int jj = 0; jj < CPL; ++jj) {
+            double s = 0.0;
 #pragma unroll
-            for (int r = 0; r < R; ++r) F[r][jj] *= inv[jj];
+            for (int r = 0; r < R; ++r)
+               if (!BLOCK || (r & ~3) < r_used) s += F[r][jj];
+            cs[jj] = s;
+         }
+         row_lane_sum(cs, std::integral_constant<int, CPL>());
+#pragma unroll
+         for (int jj = 0; jj < CPL; ++jj) {
+            const double q = (cs[jj] == 0.0) ? 0.0 : 1.0 / cs[jj];
+            scale[jj] = norm ? q : scale[jj];
          }
       }
       if (special) {
@@ -504,6 +544,50 @@ __global__ __launch_bounds__((G < 64) ? 64 : G) void em_tile_kernel(EmArgs a, Cl
             have = false;
          }
       }
+   }
+}
+
+// One launch serves every size class of a batch: the workgroup looks its class
+// up in the descriptor table (sorted by first block) and jumps to the matching
+// instantiation.  `shape` packs (column-layout index, rows-per-lane multiplier,
+// log2 lanes per group).
+struct ClassDesc {
+   int32_t block_begin; // first blockIdx.x of this class
+   int32_t n;           // loci in the class
+   int32_t loci_off;    // offset of its list in the concatenated class lists
+   int32_t shape;       // layout | rmult << 8 | lbG << 16
+};
+constexpr int kLayouts = 6; // (CPL, CL): (2,1) (4,1) (8,1) (8,2) (8,4) (8,8)
+
+template <int NWAVES, int RMULT>
+__global__ __launch_bounds__(NWAVES > 0 ? 64 * NWAVES : 64) void em_fused_kernel(EmArgs a, const ClassDesc *table,
+                                                                                 int n_classes,
+                                                                                 const int32_t *loci_all,
+                                                                                 int32_t *cursors)
+{
+   __shared__ double s_red[NWAVES > 0 ? 2 * (kMaxCPLv + 1) * 8 * NWAVES : 1];
+   __shared__ int s_idx;
+   set_fp64_flush_denormals();
+   // wave-uniform class lookup
+   int c = 0;
+   const int b = (int)blockIdx.x;
+   for (int k = 1; k < n_classes; ++k)
+      if (table[k].block_begin <= b) c = k;
+   c = __builtin_amdgcn_readfirstlane(c);
+   const ClassDesc d = table[c];
+   ClassArgs cls;
+   cls.loci = loci_all + d.loci_off;
+   cls.n = d.n;
+   cls.cursor = cursors + c;
+   const int layout = d.shape & 0xFF;
+   const int lbG = (d.shape >> 16) & 0xFF;
+   switch (layout) {
+   case 0: em_tile_body<2, 1, 8 * RMULT, NWAVES>(a, cls, lbG, s_red, &s_idx); break;
+   case 1: em_tile_body<4, 1, 8 * RMULT, NWAVES>(a, cls, lbG, s_red, &s_idx); break;
+   case 2: em_tile_body<8, 1, 4 * RMULT, NWAVES>(a, cls, lbG, s_red, &s_idx); break;
+   case 3: em_tile_body<8, 2, 4 * RMULT, NWAVES>(a, cls, lbG, s_red, &s_idx); break;
+   case 4: em_tile_body<8, 4, 4 * RMULT, NWAVES>(a, cls, lbG, s_red, &s_idx); break;
+   default: em_tile_body<8, 8, 4 * RMULT, NWAVES>(a, cls, lbG, s_red, &s_idx); break;
    }
 }
 

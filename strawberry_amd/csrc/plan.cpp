@@ -9,15 +9,22 @@
 
 namespace sb {
 
-static int pow2ceil(int x)
+static int pow2ceil(int64_t x)
 {
    int p = 1;
    while (p < x) p <<= 1;
    return p;
 }
+static int ilog2i(int x)
+{
+   int l = 0;
+   while ((1 << l) < x) ++l;
+   return l;
+}
 
 int build_host_plan(int64_t n_loci, const int64_t *row_off, const int64_t *iso_off,
-                    const int64_t *f_off, int n_cu, HostPlan *out, const char **err)
+                    const int64_t *f_off, int n_cu, const PlanTuning &tune, HostPlan *out,
+                    const char **err)
 {
    *err = "";
    if (n_loci < 0 || (n_loci > 0 && (!row_off || !iso_off || !f_off))) {
@@ -36,11 +43,13 @@ int build_host_plan(int64_t n_loci, const int64_t *row_off, const int64_t *iso_o
       *err = "plan: offsets must start at 0";
       return SBGPU_EINVAL;
    }
-   std::map<std::tuple<int, int, int, int>, SizeClass> by_key;
+
+   // pass 1: validate, decide the wave-kind rows-per-lane multiplier from the load
+   int64_t wave_lanes_r1 = 0; // lanes the wave kind would occupy at rmult 1
    for (int64_t l = 0; l < n_loci; ++l) {
       const int64_t nrow = row_off[l + 1] - row_off[l];
       const int64_t niso = iso_off[l + 1] - iso_off[l];
-      if (nrow < 0 || niso < 1 || f_off[l + 1] - f_off[l] != nrow * niso || nrow > INT32_MAX / 2) {
+      if (nrow < 0 || niso < 1 || f_off[l + 1] - f_off[l] != nrow * niso || nrow > (1 << 28)) {
          *err = "plan: malformed locus (need niso >= 1, nrow >= 0, f_off step == nrow*niso)";
          return SBGPU_EINVAL;
       }
@@ -49,50 +58,81 @@ int build_host_plan(int64_t n_loci, const int64_t *row_off, const int64_t *iso_o
          return SBGPU_ESHAPE;
       }
       p.algorithmic_bytes += nrow * niso * 8 + nrow * 4 + niso * 8 + 24;
-      int kind = kStream, CPL = 0, CL = 0, R = 0, G = 0;
       if (niso <= kMaxTileC) {
-         const int C = std::max(2, pow2ceil((int)niso));
-         CPL = std::min(C, kMaxCPL);
-         CL = C / CPL;
-         R = kTileElems / CPL;
-         // row lanes needed with R rows each; the group is CL x (row lanes)
-         int64_t gr = std::max<int64_t>(1, (nrow + R - 1) / R);
-         int64_t lanes = (int64_t)pow2ceil((int)std::min<int64_t>(gr, 1 << 20)) * CL;
-         if (lanes <= 64) {
-            kind = kTile;
-            G = (int)lanes;
-         } else {
-            // one workgroup per locus: 256 or 512 lanes, R or 2R rows per row lane
-            for (int mult = 1; mult <= 2 && kind != kTile; ++mult) {
-               for (int gg = 256; gg <= 512 && kind != kTile; gg *= 2) {
-                  if ((int64_t)(gg / CL) * R * mult >= nrow) {
-                     kind = kTile;
-                     G = gg;
-                     R = R * mult;
-                  }
-               }
+         const int C = std::max(2, pow2ceil(niso));
+         const int CPL = std::min(C, 8), CL = C / CPL;
+         int R = 4;
+         for (int i = 0; i < kNumLayouts; ++i)
+            if (kLayoutCPL[i] == CPL && kLayoutCL[i] == CL) R = kLayoutR[i];
+         const int64_t lanes = (int64_t)pow2ceil(std::max<int64_t>(1, (nrow + R - 1) / R)) * CL;
+         if (lanes <= 64) wave_lanes_r1 += lanes;
+      }
+   }
+   const int64_t simd_lanes = (int64_t)n_cu * 4 * 64;
+   int wave_rmult = tune.wave_rmult;
+   if (wave_rmult != 1 && wave_rmult != 2) {
+      // one wave per SIMD keeps every iteration at full issue rate: fold rows
+      // (fewer, longer lanes) once the short-lane layout would oversubscribe the chip
+      wave_rmult = (wave_lanes_r1 > 2 * simd_lanes) ? 2 : 1;
+   }
+
+   std::map<std::tuple<int, int, int, int>, SizeClass> by_key;
+   for (int64_t l = 0; l < n_loci; ++l) {
+      const int64_t nrow = row_off[l + 1] - row_off[l];
+      const int64_t niso = iso_off[l + 1] - iso_off[l];
+      SizeClass k;
+      k.kind = kStream;
+      if (niso <= kMaxTileC) {
+         const int C = std::max(2, pow2ceil(niso));
+         k.CPL = std::min(C, 8);
+         k.CL = C / k.CPL;
+         for (int i = 0; i < kNumLayouts; ++i)
+            if (kLayoutCPL[i] == k.CPL && kLayoutCL[i] == k.CL) k.layout = i;
+         const int R1 = kLayoutR[k.layout];
+         // wave kind: smallest power-of-two group that holds the rows
+         bool placed = false;
+         {
+            const int R = R1 * wave_rmult;
+            const int64_t lanes = (int64_t)pow2ceil(std::max<int64_t>(1, (nrow + R - 1) / R)) * k.CL;
+            if (lanes <= 64) {
+               k.kind = (wave_rmult == 1) ? kWave1 : kWave2;
+               k.rmult = wave_rmult;
+               k.R = R;
+               k.G = (int)lanes;
+               k.lbG = ilog2i(k.G);
+               placed = true;
             }
          }
+         // block kind: the whole 256-lane workgroup is the group
+         if (!placed && (int64_t)(kBlockThreads / k.CL) * R1 * kBlockRmult >= nrow) {
+            k.kind = kBlock;
+            k.rmult = kBlockRmult;
+            k.R = R1 * kBlockRmult;
+            k.G = kBlockThreads;
+            k.lbG = 6;
+            placed = true;
+         }
       }
-      if (kind == kStream) {
-         CPL = CL = R = G = 0;
+      if (k.kind == kStream) {
+         k.layout = k.CPL = k.CL = k.R = k.G = k.lbG = 0;
+         k.rmult = 1;
          ++p.n_stream_loci;
       }
-      SizeClass &sc = by_key[std::make_tuple(kind, CPL * 16 + CL, R, G)];
-      sc.kind = kind;
-      sc.CPL = CPL;
-      sc.CL = CL;
-      sc.R = R;
-      sc.G = G;
+      SizeClass &sc = by_key[std::make_tuple(k.kind, k.layout, k.rmult, k.G)];
+      if (sc.loci.empty()) {
+         std::vector<int32_t> keep;
+         sc = k;
+      }
       sc.loci.push_back((int32_t)l);
-      sc.work += (kind == kTile) ? (int64_t)(G / CL) * R * CPL * CL : nrow * niso;
+      sc.work += (k.kind == kStream) ? nrow * niso : (int64_t)(k.G / std::max(1, k.CL)) * k.R * k.CPL * k.CL;
    }
    p.n_rows = row_off[n_loci];
    p.n_iso = iso_off[n_loci];
    p.n_elem = f_off[n_loci];
 
-   // resident-wave budget: 4 SIMDs per CU, a few waves each
-   const int64_t wave_budget = (int64_t)n_cu * 4 * 4;
+   // grids: one group per locus unless that exceeds the resident-wave budget, in
+   // which case every grid shrinks proportionally and groups keep pulling loci
+   const int64_t wave_budget = (int64_t)n_cu * 4 * std::max(1, tune.waves_per_simd);
    int64_t waves_wanted = 0;
    for (auto &kv : by_key) {
       SizeClass &sc = kv.second;
@@ -103,25 +143,19 @@ int build_host_plan(int64_t n_loci, const int64_t *row_off, const int64_t *iso_o
          return wx > wy;
       });
       const int64_t n = (int64_t)sc.loci.size();
-      if (sc.kind == kTile) {
-         if (sc.G <= 64) {
-            sc.block_threads = 64;
-            sc.n_blocks = (int)((n + (64 / sc.G) - 1) / (64 / sc.G));
-            waves_wanted += sc.n_blocks;
-         } else {
-            sc.block_threads = sc.G;
-            sc.n_blocks = (int)n;
-            waves_wanted += (int64_t)sc.n_blocks * (sc.G / 64);
-         }
-      } else {
+      if (sc.kind == kWave1 || sc.kind == kWave2) {
+         sc.block_threads = 64;
+         sc.n_blocks = (int)((n + (64 / sc.G) - 1) / (64 / sc.G));
+      } else if (sc.kind == kStream) {
          sc.block_threads = 1024;
          sc.n_blocks = (int)n;
-         waves_wanted += (int64_t)sc.n_blocks * 16;
+      } else {
+         sc.block_threads = sc.G;
+         sc.n_blocks = (int)n;
       }
+      waves_wanted += (int64_t)sc.n_blocks * (sc.block_threads / 64);
    }
    if (waves_wanted > wave_budget) {
-      // more groups than the chip can hold: shrink every grid proportionally and
-      // let the groups pull loci through the cursor until the list runs dry
       const double f = (double)wave_budget / (double)waves_wanted;
       for (auto &kv : by_key) {
          SizeClass &sc = kv.second;
@@ -129,11 +163,9 @@ int build_host_plan(int64_t n_loci, const int64_t *row_off, const int64_t *iso_o
       }
    }
    for (auto &kv : by_key) p.classes.push_back(std::move(kv.second));
-   std::sort(p.classes.begin(), p.classes.end(), [](const SizeClass &x, const SizeClass &y) {
-      // workgroup-per-locus classes first (longest iterations), then by total work
-      const int gx = x.kind == kStream ? 1 << 20 : x.G, gy = y.kind == kStream ? 1 << 20 : y.G;
-      if ((gx > 64) != (gy > 64)) return gx > 64;
-      return x.work > y.work;
+   std::stable_sort(p.classes.begin(), p.classes.end(), [](const SizeClass &x, const SizeClass &y) {
+      if (x.kind != y.kind) return x.kind < y.kind;
+      return x.work > y.work; // heaviest class gets the lowest block indices (dispatched first)
    });
    return SBGPU_OK;
 }

@@ -3,8 +3,9 @@
 // The reference solves one locus at a time on a CPU thread
 // (/root/reference/src/alignments.cpp:1782-1804).  On the GPU thousands of loci
 // are in flight at once and their shapes are ragged (1..~2000 bins x 1..~200
-// isoforms), so the batch is first sorted into size classes; each class is one
-// kernel instantiation (see em_device.h).
+// isoforms), so the batch is first sorted into size classes (register-tile
+// layout x lanes per locus, see em_device.h); all classes of one kind run in ONE
+// kernel launch whose workgroups look their class up in a descriptor table.
 #pragma once
 
 #include <cstdint>
@@ -12,32 +13,52 @@
 
 namespace sb {
 
-enum ClassKind : int { kTile = 0, kStream = 1 };
+// One kernel launch per kind (at most three per batch: one wave kind, the block
+// kind, the streaming kind -- the chip exposes four hardware queues).
+//  kWave1/kWave2  64/G groups per wave, rows-per-lane multiplier 1 or 2 (a plan uses one)
+//  kBlock         one 256-lane workgroup per locus, one wave per SIMD with the full
+//                 512-VGPR budget: register tiles up to kBlockRmult x the base rows
+//  kStream        anything larger: F re-read from L2 every iteration
+enum ClassKind : int { kWave1 = 0, kWave2, kBlock, kStream, kNumKinds };
+constexpr int kBlockThreads = 256;
+constexpr int kBlockRmult = 6;
 
 struct SizeClass {
-   int kind;     // kTile / kStream
-   int CPL, CL;  // tile: columns per lane, column lanes (CPL*CL >= niso)
-   int R, G;     // tile: rows per row lane, lanes per locus = CL * row lanes (G > 64: one workgroup)
+   int kind = kWave1;
+   int layout = 0;   // index into kLayoutCPL/kLayoutCL
+   int CPL = 0, CL = 0; // columns per lane, column lanes (CPL*CL >= niso)
+   int rmult = 1;    // rows per row lane = rmult * kLayoutR[layout]
+   int R = 0;
+   int G = 0;        // lanes per locus = CL * row lanes
+   int lbG = 0;      // log2(G) for the wave kind
    std::vector<int32_t> loci; // ordered by decreasing nrow*niso
-   int n_blocks = 0;          // launch grid
+   int n_blocks = 0;          // workgroups of this class inside its launch
    int block_threads = 0;
-   int64_t work = 0;          // sum of nrow*niso (padded) -- for ordering launches
+   int64_t work = 0;          // padded elements, for ordering
 };
 
 struct HostPlan {
    int64_t n_loci = 0, n_rows = 0, n_iso = 0, n_elem = 0;
    int64_t algorithmic_bytes = 0;
    int64_t n_stream_loci = 0;
-   std::vector<SizeClass> classes; // non-empty classes, heaviest first
+   std::vector<SizeClass> classes; // grouped by kind; inside a kind heaviest first
 };
 
-constexpr int kTileElems = 32;    // R*CPL register tile per lane (x2 for the tall workgroup variants)
-constexpr int kMaxCPL = 8;        // columns per lane
+constexpr int kNumLayouts = 6;
+constexpr int kLayoutCPL[kNumLayouts] = {2, 4, 8, 8, 8, 8};
+constexpr int kLayoutCL[kNumLayouts] = {1, 1, 1, 2, 4, 8};
+constexpr int kLayoutR[kNumLayouts] = {8, 8, 4, 4, 4, 4}; // rows per row lane at rmult 1
 constexpr int kMaxTileC = 64;     // 8 column lanes x 8 columns; wider loci stream
 constexpr int kMaxStreamIso = 512;
 
+struct PlanTuning {
+   int wave_rmult = 0;   // 0 = auto, 1 / 2 = force the rows-per-lane multiplier of the wave kind
+   int waves_per_simd = 2; // resident-wave budget used to size the grids
+};
+
 // Returns 0, or a negative SBGPU_E* code with `err` filled.
 int build_host_plan(int64_t n_loci, const int64_t *row_off, const int64_t *iso_off,
-                    const int64_t *f_off, int n_cu, HostPlan *out, const char **err);
+                    const int64_t *f_off, int n_cu, const PlanTuning &tune, HostPlan *out,
+                    const char **err);
 
 } // namespace sb

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -45,75 +46,28 @@ struct sbgpu_ctx {
    hipEvent_t join[kAuxStreams] = {};
 };
 
-struct DeviceClass {
-   sb::SizeClass host; // loci vector kept for introspection
-   int32_t *d_loci = nullptr;
-   int cursor_index = 0;
+struct KindLaunch {
+   int first_class = 0, n_classes = 0; // range in plan->host.classes
+   int n_blocks = 0;
+   int block_threads = 0;
+   sb::ClassDesc *d_table = nullptr;   // points into plan->d_tables
 };
 
 struct sbgpu_plan {
    sbgpu_ctx *ctx = nullptr;
    sb::HostPlan host;
-   std::vector<DeviceClass> classes;
+   KindLaunch launches[sb::kNumKinds];
    int64_t *d_row_off = nullptr, *d_iso_off = nullptr, *d_f_off = nullptr;
-   int32_t *d_loci_all = nullptr; // all class lists, concatenated
-   int32_t *d_cursors = nullptr;  // one per class
-   uint8_t *d_row_keep = nullptr; // streaming path: init() row flags
-   double *d_locus_sum = nullptr; // abundance epilogue: kept-FPKM sum per locus
+   int32_t *d_loci_all = nullptr;      // all class lists, concatenated
+   int32_t *d_cursors = nullptr;       // one per class
+   sb::ClassDesc *d_tables = nullptr;  // one descriptor per class
+   std::vector<int64_t> loci_off;      // per class: offset into d_loci_all
+   uint8_t *d_row_keep = nullptr;      // streaming path: init() row flags
+   double *d_locus_sum = nullptr;      // abundance epilogue: kept-FPKM sum per locus
    size_t stream_lds_bytes = 0;
 };
 
-// ------------------------------------------------------------------ kernel dispatch
 namespace {
-
-template <int CPL, int CL, int R, int G>
-hipError_t launch_tile_inst(const sb::EmArgs &a, const sb::ClassArgs &c, int n_blocks, hipStream_t s)
-{
-   constexpr int threads = (G < 64) ? 64 : G;
-   hipLaunchKernelGGL((sb::em_tile_kernel<CPL, CL, R, G>), dim3(n_blocks), dim3(threads), 0, s, a, c);
-   return hipGetLastError();
-}
-
-template <int CPL, int CL>
-hipError_t launch_tile_g(int R, int G, const sb::EmArgs &a, const sb::ClassArgs &c, int n_blocks, hipStream_t s)
-{
-   constexpr int R1 = sb::kTileElems / CPL;
-   if (R == R1) {
-      switch (G) {
-#define SB_CASE(GG)                                                                         \
-   case GG:                                                                                 \
-      if constexpr (GG >= CL) return launch_tile_inst<CPL, CL, R1, GG>(a, c, n_blocks, s);  \
-      break;
-         SB_CASE(1)
-         SB_CASE(2)
-         SB_CASE(4)
-         SB_CASE(8)
-         SB_CASE(16)
-         SB_CASE(32)
-         SB_CASE(64)
-         SB_CASE(256)
-         SB_CASE(512)
-#undef SB_CASE
-      default: break;
-      }
-   } else if (R == 2 * R1) {
-      if (G == 256) return launch_tile_inst<CPL, CL, 2 * R1, 256>(a, c, n_blocks, s);
-      if (G == 512) return launch_tile_inst<CPL, CL, 2 * R1, 512>(a, c, n_blocks, s);
-   }
-   return hipErrorInvalidValue;
-}
-
-hipError_t launch_tile(int CPL, int CL, int R, int G, const sb::EmArgs &a, const sb::ClassArgs &c, int n_blocks,
-                       hipStream_t s)
-{
-   if (CPL == 2 && CL == 1) return launch_tile_g<2, 1>(R, G, a, c, n_blocks, s);
-   if (CPL == 4 && CL == 1) return launch_tile_g<4, 1>(R, G, a, c, n_blocks, s);
-   if (CPL == 8 && CL == 1) return launch_tile_g<8, 1>(R, G, a, c, n_blocks, s);
-   if (CPL == 8 && CL == 2) return launch_tile_g<8, 2>(R, G, a, c, n_blocks, s);
-   if (CPL == 8 && CL == 4) return launch_tile_g<8, 4>(R, G, a, c, n_blocks, s);
-   if (CPL == 8 && CL == 8) return launch_tile_g<8, 8>(R, G, a, c, n_blocks, s);
-   return hipErrorInvalidValue;
-}
 
 // ------------------------------------------------------------------ epilogue kernels
 // LocusContext::estimate_abundances, /root/reference/src/estimate.cpp:314-355.
@@ -294,6 +248,7 @@ int sbgpu_plan_destroy(sbgpu_plan_t *p)
    (void)hipFree(p->d_f_off);
    (void)hipFree(p->d_loci_all);
    (void)hipFree(p->d_cursors);
+   (void)hipFree(p->d_tables);
    (void)hipFree(p->d_row_keep);
    (void)hipFree(p->d_locus_sum);
    delete p;
@@ -309,7 +264,10 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
    if (!p) return fail(SBGPU_ENOMEM, "sbgpu_plan_create: out of host memory");
    p->ctx = c;
    const char *err = "";
-   int rc = sb::build_host_plan(n_loci, row_off, iso_off, f_off, c->n_cu, &p->host, &err);
+   sb::PlanTuning tune;
+   if (const char *e = std::getenv("SBGPU_WAVE_RMULT")) tune.wave_rmult = std::atoi(e);
+   if (const char *e = std::getenv("SBGPU_WAVES_PER_SIMD")) tune.waves_per_simd = std::atoi(e);
+   int rc = sb::build_host_plan(n_loci, row_off, iso_off, f_off, c->n_cu, tune, &p->host, &err);
    if (rc != SBGPU_OK) {
       delete p;
       return fail(rc, err);
@@ -333,15 +291,28 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
       if ((e = hipMemcpy(p->d_iso_off, iso_off, nb, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(iso_off)");
       if ((e = hipMemcpy(p->d_f_off, f_off, nb, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(f_off)");
    }
+   if ((e = hipMalloc(&p->d_tables, (p->host.classes.size() + 1) * sizeof(sb::ClassDesc))) != hipSuccess) return bail(e, "hipMalloc(tables)");
    size_t off = 0;
-   int ci = 0;
    size_t max_stream_iso = 0;
-   for (auto &sc : p->host.classes) {
-      DeviceClass dc;
-      dc.d_loci = p->d_loci_all + off;
-      dc.cursor_index = ci++;
-      if ((e = hipMemcpy(dc.d_loci, sc.loci.data(), sc.loci.size() * sizeof(int32_t), hipMemcpyHostToDevice)) != hipSuccess)
+   std::vector<sb::ClassDesc> table(p->host.classes.size());
+   for (int k = 0; k < sb::kNumKinds; ++k) p->launches[k] = KindLaunch();
+   for (size_t ci = 0; ci < p->host.classes.size(); ++ci) {
+      const sb::SizeClass &sc = p->host.classes[ci];
+      KindLaunch &kl = p->launches[sc.kind];
+      if (kl.n_classes == 0) {
+         kl.first_class = (int)ci;
+         kl.d_table = p->d_tables + ci;
+         kl.block_threads = sc.block_threads;
+      }
+      table[ci].block_begin = kl.n_blocks;
+      table[ci].n = (int32_t)sc.loci.size();
+      table[ci].loci_off = (int32_t)off;
+      table[ci].shape = sc.layout | (sc.rmult << 8) | (sc.lbG << 16);
+      kl.n_blocks += sc.n_blocks;
+      kl.n_classes += 1;
+      if ((e = hipMemcpy(p->d_loci_all + off, sc.loci.data(), sc.loci.size() * sizeof(int32_t), hipMemcpyHostToDevice)) != hipSuccess)
          return bail(e, "hipMemcpy(class list)");
+      p->loci_off.push_back((int64_t)off);
       off += sc.loci.size();
       if (sc.kind == sb::kStream) {
          for (int32_t l : sc.loci) {
@@ -349,9 +320,10 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
             if (k > max_stream_iso) max_stream_iso = k;
          }
       }
-      dc.host = sc;
-      p->classes.push_back(std::move(dc));
    }
+   if (!table.empty() &&
+       (e = hipMemcpy(p->d_tables, table.data(), table.size() * sizeof(sb::ClassDesc), hipMemcpyHostToDevice)) != hipSuccess)
+      return bail(e, "hipMemcpy(tables)");
    // streaming kernel LDS: (3 + NWAVE) * npad doubles, npad <= pow2ceil-padded niso
    size_t npad = 1;
    while (npad < max_stream_iso && npad < 64) npad <<= 1;
@@ -378,9 +350,9 @@ int sbgpu_plan_info(const sbgpu_plan_t *p, int64_t out[8])
 int sbgpu_plan_classes(const sbgpu_plan_t *p, int64_t *out, int cap)
 {
    if (!p) return fail(SBGPU_EINVAL, "sbgpu_plan_classes: null plan");
-   int n = (int)p->classes.size();
+   int n = (int)p->host.classes.size();
    for (int i = 0; i < n && i < cap && out; ++i) {
-      const sb::SizeClass &sc = p->classes[i].host;
+      const sb::SizeClass &sc = p->host.classes[i];
       out[i * 6 + 0] = sc.kind;
       out[i * 6 + 1] = sc.CPL * sc.CL;
       out[i * 6 + 2] = sc.R;
@@ -408,34 +380,48 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
    a.theta = d_theta;
    a.status = d_status;
    a.iters = d_iters;
-   const int ncls = (int)p->classes.size();
+   const int ncls = (int)p->host.classes.size();
    HIP_TRY(hipMemsetAsync(p->d_cursors, 0, (size_t)(ncls + 1) * sizeof(int32_t), main));
-   // a single class runs on the caller's stream; several fork onto the aux streams
-   const bool fork = ncls > 1;
+   // one launch per kind (wave / block256 / block512 / stream); a single kind runs
+   // on the caller's stream, several fork onto the aux streams and join back
+   int kinds = 0;
+   for (int k = 0; k < sb::kNumKinds; ++k) kinds += p->launches[k].n_classes > 0;
+   const bool fork = kinds > 1;
    if (fork) {
       HIP_TRY(hipEventRecord(c->fork, main));
-      for (int i = 0; i < kAuxStreams && i < ncls; ++i) HIP_TRY(hipStreamWaitEvent(c->aux[i], c->fork, 0));
+      for (int k = 0; k < sb::kNumKinds; ++k)
+         if (p->launches[k].n_classes > 0) HIP_TRY(hipStreamWaitEvent(c->aux[k], c->fork, 0));
    }
-   for (int i = 0; i < ncls; ++i) {
-      const DeviceClass &dc = p->classes[i];
-      const sb::SizeClass &sc = dc.host;
-      hipStream_t s = fork ? c->aux[i % kAuxStreams] : main;
-      sb::ClassArgs ca;
-      ca.loci = dc.d_loci;
-      ca.n = (int32_t)sc.loci.size();
-      ca.cursor = p->d_cursors + dc.cursor_index;
-      if (sc.kind == sb::kTile) {
-         HIP_TRY(launch_tile(sc.CPL, sc.CL, sc.R, sc.G, a, ca, sc.n_blocks, s));
+   // heaviest per-iteration work first: stream, block512, block256, wave
+   for (int k = sb::kNumKinds - 1; k >= 0; --k) {
+      const KindLaunch &kl = p->launches[k];
+      if (kl.n_classes == 0) continue;
+      hipStream_t s = fork ? c->aux[k] : main;
+      int32_t *cursors = p->d_cursors + kl.first_class;
+      if (k == sb::kWave1) {
+         hipLaunchKernelGGL((sb::em_fused_kernel<0, 1>), dim3(kl.n_blocks), dim3(64), 0, s, a, kl.d_table,
+                            kl.n_classes, p->d_loci_all, cursors);
+      } else if (k == sb::kWave2) {
+         hipLaunchKernelGGL((sb::em_fused_kernel<0, 2>), dim3(kl.n_blocks), dim3(64), 0, s, a, kl.d_table,
+                            kl.n_classes, p->d_loci_all, cursors);
+      } else if (k == sb::kBlock) {
+         hipLaunchKernelGGL((sb::em_fused_kernel<sb::kBlockWaves, sb::kBlockRmult>), dim3(kl.n_blocks),
+                            dim3(sb::kBlockThreads), 0, s, a, kl.d_table, kl.n_classes, p->d_loci_all, cursors);
       } else {
-         hipLaunchKernelGGL(sb::em_stream_kernel, dim3(sc.n_blocks), dim3(sb::kStreamThreads),
+         sb::ClassArgs ca;
+         ca.loci = p->d_loci_all + p->loci_off[kl.first_class];
+         ca.n = (int32_t)p->host.classes[kl.first_class].loci.size();
+         ca.cursor = cursors;
+         hipLaunchKernelGGL(sb::em_stream_kernel, dim3(kl.n_blocks), dim3(sb::kStreamThreads),
                             p->stream_lds_bytes, s, a, ca, p->d_row_keep);
-         HIP_TRY(hipGetLastError());
       }
+      HIP_TRY(hipGetLastError());
    }
    if (fork) {
-      for (int i = 0; i < kAuxStreams && i < ncls; ++i) {
-         HIP_TRY(hipEventRecord(c->join[i], c->aux[i]));
-         HIP_TRY(hipStreamWaitEvent(main, c->join[i], 0));
+      for (int k = 0; k < sb::kNumKinds; ++k) {
+         if (p->launches[k].n_classes == 0) continue;
+         HIP_TRY(hipEventRecord(c->join[k], c->aux[k]));
+         HIP_TRY(hipStreamWaitEvent(main, c->join[k], 0));
       }
    }
    return SBGPU_OK;
