@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- EM-to-convergence throughput of the per-locus EM hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c2u]
+
+A step = one pass of the hot path over one batch of synthetic loci that is already
+resident in HBM: EM (init + run to convergence) for every locus, the FPKM/Frac
+epilogue, the TPM all-reduce (N > 1) and the TPM kernel.  N > 1 is launched by
+torchrun (one rank per GPU, RCCL); every rank holds its OWN full-size batch (weak
+scaling, seed + rank) and `value` is the loci all ranks processed per second.
+
+Prints ONE JSON line on rank 0.  Besides the driver's fields it carries
+  roofline     the dominant kernel against the HBM roofline (algorithmic bytes /
+               kernel time) and, because the loop runs on-chip, the
+               FP64-VALU view of the same kernel,
+  cpu_baseline the reference's EmSolver (oracle/_ref, kind "reference") or the C
+               restatement (kind "port") on this box's host cores, bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_VALU_PEAK_TF = 78.6     # vendor FP64 vector peak (256 CUs)
+
+WORKLOADS = {
+    "c3": "C3 human-scale synthetic: 60000 loci/GPU, niso~1+Geom(0.25), nrow~LogNormal(ln30,1), 2e8 fragments",
+    "c2": "C2 synthetic: 10000 loci x 8 isoforms x 1000 fragments, 32 exon bins",
+    "c2u": "C2-U synthetic: 2000 loci x 8 isoforms x 1000 un-binned fragments (1000 rows)",
+}
+
+
+def make_batch(name, rank):
+    from strawberry_amd import synth
+    if name == "c3":
+        return synth.make_c3(seed=0x5743 + rank)
+    if name == "c2":
+        return synth.make_c2(seed=0x5742 + rank)
+    if name == "c2u":
+        return synth.make_c2(n_loci=2000, seed=0x5742 + rank, unbinned=True)
+    raise SystemExit("unknown workload " + name)
+
+
+def cpu_baseline(batch, budget_s=12.0):
+    """Time the reference's EmSolver (or the port) on this box's host cores, on a
+    bounded prefix of the same batch: one thread (the reference's deterministic mode)
+    and all cores with a static locus partition (the analogue of `-p T`)."""
+    from oracle import OracleLib, RefLib, have_ref
+    kind = "reference" if have_ref() else "port"
+    lib = RefLib() if have_ref() else OracleLib()
+    cores = os.cpu_count() or 1
+
+    def run(n, threads):
+        sub = batch if n >= batch.n_loci else batch.select(np.arange(n))
+        t = time.perf_counter()
+        lib.em_batch(sub.row_off, sub.iso_off, sub.f_off, sub.count, sub.F, threads=threads)
+        return time.perf_counter() - t, sub
+
+    # calibrate on 2000 loci, then size the single-thread sample for ~budget/2 seconds
+    dt, _ = run(min(2000, batch.n_loci), 1)
+    rate1 = min(2000, batch.n_loci) / max(dt, 1e-9)
+    n1 = int(min(batch.n_loci, max(2000, rate1 * budget_s * 0.5)))
+    dt1, sub1 = run(n1, 1)
+    dtN, subN = run(batch.n_loci, cores)
+    return {
+        "value": n1 / dt1, "unit": "loci/s", "cores": 1, "kind": kind,
+        "sample": "first %d loci of the same batch, EmSolver init+run, 1 thread, %.2f s" % (n1, dt1),
+        "mfrags_per_s": sub1.n_frags / dt1 / 1e6,
+        "all_cores": {"value": batch.n_loci / dtN, "unit": "loci/s", "cores": cores,
+                      "sample": "whole batch (%d loci), static partition over %d threads, %.3f s" % (
+                          batch.n_loci, cores, dtN)},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from strawberry_amd import dist as sdist
+    from strawberry_amd import em
+
+    rank, world, local_rank = sdist.init_process_group()
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    batch = make_batch(args.workload, rank)
+    ctx = em.Context(local_rank)
+    solver = em.EmBatchSolver(batch, ctx)
+    # pass-1 normaliser (alignments.cpp:1372): global mapped fragments, one all-reduce at set-up
+    tot = torch.tensor([batch.n_frags], dtype=torch.int64, device=dev)
+    sdist.allreduce_sum_(tot)
+    total_mapped = int(min(int(tot.item()), 2**31 - 1))   # the reference holds it in an int
+    quant = sdist.ShardQuantifier(solver, total_mapped, min_isoform_frac=0.0)  # quant-only (-r): keep all
+
+    for _ in range(args.warmup):
+        quant.step()
+    torch.cuda.synchronize(dev)
+    sdist.barrier()
+    torch.cuda.synchronize(dev)
+
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    kern_ms = np.zeros(4)
+    t0 = time.perf_counter()
+    ev[0].record()
+    for _ in range(args.steps):
+        quant.step()
+    ev[1].record()
+    torch.cuda.synchronize(dev)
+    sdist.barrier()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    # per-kind EM kernel time: HIP events on the streams the kernels ran on (last step)
+    kern_ms = np.array(solver.last_kernel_ms())
+    gpu_ms = ev[0].elapsed_time(ev[1])
+
+    tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
+    sdist.allreduce_max_(tmax)
+    wall = float(tmax.item())
+    counts = torch.tensor([batch.n_loci, batch.n_frags], dtype=torch.int64, device=dev)
+    sdist.allreduce_sum_(counts)
+    n_loci_all, n_frags_all = int(counts[0].item()), int(counts[1].item())
+
+    if rank != 0:
+        return
+    res = solver.results()
+    ms_per_step = wall / args.steps * 1e3
+    value = n_loci_all * args.steps / wall
+
+    # ---- roofline of the dominant EM kernel (this rank's batch)
+    kinds = solver.plan.locus_kinds()
+    kind_names = ["em_fused_kernel<0,1> (wave form)", "em_fused_kernel<0,2> (wave form, 2x rows/lane)",
+                  "em_fused_kernel<4,6> (256-lane block form)", "em_stream_kernel"]
+    dom = int(np.argmax(kern_ms))
+    sel = kinds == dom
+    nrow, niso = batch.nrow, batch.niso
+    b_locus = nrow * niso * 8 + nrow * 4 + niso * 8 + 24
+    fl_locus = res["iters"].astype(np.int64) * (5 * nrow * niso + nrow + 3 * niso)
+    dom_s = kern_ms[dom] * 1e-3
+    ach_gbs = float(b_locus[sel].sum()) / dom_s / 1e9
+    roofline = {
+        "bound": "hbm", "kernel": kind_names[dom], "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
+        "kernel_ms": float(kern_ms[dom]), "kernel_loci": int(sel.sum()),
+        "algorithmic_bytes": int(b_locus[sel].sum()),
+        "note": "F stays in registers for all iterations: the loop is FP64-VALU/latency bound, see fp64_valu",
+        "fp64_valu": {"achieved": float(fl_locus[sel].sum()) / dom_s / 1e12, "peak": FP64_VALU_PEAK_TF,
+                      "unit": "TFLOP/s", "frac": float(fl_locus[sel].sum()) / dom_s / 1e12 / FP64_VALU_PEAK_TF,
+                      "algorithmic_flops": int(fl_locus[sel].sum())},
+        "all_kernels_ms": {kind_names[k]: float(kern_ms[k]) for k in range(4) if kern_ms[k] > 0},
+        "whole_batch": {"achieved": float(b_locus.sum()) / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
+                        "frac": float(b_locus.sum()) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+    }
+
+    out = {
+        "metric": "loci/s, EM-to-convergence (+ FPKM/TPM epilogue), %s" % args.workload.upper(),
+        "value": value, "unit": "loci/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "mfrags_per_s": n_frags_all * args.steps / wall / 1e6,
+        "config": {"workload": WORKLOADS[args.workload], "loci_per_gpu": batch.n_loci,
+                   "fragments_per_gpu": batch.n_frags, "sharding": "independent loci per rank, 1 all-reduce (8 B) per step",
+                   "size_classes": solver.plan.info()["n_classes"]},
+        "em_status": {"ok": int((res["status"] == 0).sum()), "init_empty": int((res["status"] == 1).sum()),
+                      "denom_zero": int((res["status"] == 2).sum()), "maxiter": int((res["status"] == 3).sum()),
+                      "mean_iters": float(res["iters"].mean())},
+        "gpu_event_ms_per_step": gpu_ms / args.steps,
+        "roofline": roofline,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(batch)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -17,7 +17,7 @@ STATUS_NAMES = {0: "OK", 1: "INIT_EMPTY", 2: "DENOM_ZERO", 3: "MAXITER"}
 SYMBOLS = [
     "sbgpu_version", "sbgpu_last_error", "sbgpu_device_count", "sbgpu_init", "sbgpu_finalize",
     "sbgpu_device_info", "sbgpu_synchronize", "sbgpu_plan_create", "sbgpu_plan_destroy", "sbgpu_plan_info",
-    "sbgpu_plan_classes", "sbgpu_em_run_device", "sbgpu_em_batch", "sbgpu_abundance_device", "sbgpu_tpm_device",
+    "sbgpu_plan_classes", "sbgpu_plan_locus_kinds", "sbgpu_em_run_device", "sbgpu_em_last_kernel_ms", "sbgpu_em_batch", "sbgpu_abundance_device", "sbgpu_tpm_device",
 ]
 
 
@@ -85,6 +85,8 @@ def load():
     L.sbgpu_plan_destroy.argtypes = [vp]
     L.sbgpu_plan_info.argtypes = [vp, i64p]
     L.sbgpu_plan_classes.argtypes = [vp, i64p, C.c_int]
+    L.sbgpu_plan_locus_kinds.argtypes = [vp, vp]
+    L.sbgpu_em_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.sbgpu_em_run_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.sbgpu_em_batch.argtypes = [vp, C.POINTER(sbgpu_batch_t), vp, vp, vp]
     L.sbgpu_abundance_device.argtypes = [vp, vp, vp, vp, vp, C.POINTER(sbgpu_abundance_params_t), vp, vp, vp, vp, vp]

@@ -150,8 +150,8 @@ __device__ __forceinline__ double fast_div(double n, double d)
 //                             run independent loci; G is a run-time (wave-uniform)
 //                             value so that one kernel serves every size class.
 // Block form (BLOCK = true):  the group is the whole workgroup (256 or 512 lanes).
-// Groups pull loci from their class list through an atomic cursor until it runs
-// dry (iteration counts range from 1 to the 1000 cap).
+// Waves pull loci from their class list through an atomic cursor, one per group,
+// whenever all their groups are idle, until the list runs dry.
 
 // value of lane (lane ^ MASK), true xor for every MASK
 template <int MASK>
@@ -295,7 +295,6 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
    int locus = 0;
    int64_t iso_base = 0;
    bool have = false;       // the group currently owns a locus
-   bool exhausted = false;  // the class list ran dry for this group
 
 #pragma unroll
    for (int r = 0; r < R; ++r) {
@@ -312,25 +311,24 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
 
    for (;;) {
       // ---------------------------------------------------------------- refill
-      // Entered wave-uniformly when some group is idle; lanes of busy groups run
-      // it too (on locus 0's addresses, results discarded by selects) so that F,
-      // theta, ... are updated in place without per-lane control flow.
-      const bool need = !have && !exhausted;
-      if (BLOCK ? need : __any(need)) {
+      // Wave-synchronous: when every group of the wave (block form: the workgroup)
+      // is idle, each group pulls its next locus from the class list.  All lanes
+      // load together, so F, theta, ... are simply overwritten.
+      if (BLOCK ? !have : !__any(have)) {
          int idx = 0;
          if (BLOCK) {
             if (threadIdx.x == 0) *s_idx = atomicAdd(cls.cursor, 1);
             __syncthreads();
             idx = *s_idx;
             __syncthreads();
+            if (idx >= cls.n) break; // workgroup-uniform: the class list is dry
          } else {
-            if (need && g == 0) idx = atomicAdd(cls.cursor, 1);
+            if (g == 0) idx = atomicAdd(cls.cursor, 1);
             idx = __shfl(idx, lane & ~(GW - 1));
+            if (!__any(idx < cls.n)) break; // nothing left for any group of this wave
          }
-         if (BLOCK && idx >= cls.n) break; // workgroup-uniform: the class list is dry
-         const bool got = BLOCK ? true : (need && idx < cls.n);
-         exhausted = exhausted || (need && idx >= cls.n);
-         const int loc = got ? cls.loci[idx] : 0;
+         const bool got = idx < cls.n;
+         const int loc = got ? cls.loci[idx] : 0; // idle groups shadow locus 0, results discarded
          const int64_t r0 = a.row_off[loc];
          const int nrow = (int)(a.row_off[loc + 1] - r0);
          const int64_t ib = a.iso_off[loc];
@@ -374,33 +372,25 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
             if (CL >= 8) mx = fmax(mx, xor_get<4>(mx));
             const bool keep = mx > kRowEps;
             if (gc == 0 && keep) red[1] += 1.0;
-            if (BLOCK) {
-               act[r] = keep;
-               nn[r] = keep ? cnt : 0.0;
+            act[r] = keep;
+            nn[r] = keep ? cnt : 0.0;
 #pragma unroll
-               for (int jj = 0; jj < CPL; ++jj) F[r][jj] = keep ? v[jj] : 0.0;
-            } else {
-               act[r] = got ? keep : act[r];
-               nn[r] = got ? (keep ? cnt : 0.0) : nn[r];
-#pragma unroll
-               for (int jj = 0; jj < CPL; ++jj) F[r][jj] = got ? (keep ? v[jj] : 0.0) : F[r][jj];
-            }
+            for (int jj = 0; jj < CPL; ++jj) F[r][jj] = keep ? v[jj] : 0.0;
          }
          // group totals: over the column lanes, then over the row lanes
          red[0] = low_bits_sum<LB_CL>(red[0]);
          red[1] = low_bits_sum<LB_CL>(red[1]);
          row_lane_sum(red, std::integral_constant<int, 2>());
-         const double t0 = red[0] / (double)ni; // :375, IEEE division
-         theta0 = got ? t0 : theta0;
+         theta0 = red[0] / (double)ni; // :375, IEEE division
 #pragma unroll
          for (int jj = 0; jj < CPL; ++jj) {
-            theta[jj] = got ? ((gc * CPL + jj < ni) ? t0 : 0.0) : theta[jj];
-            scale[jj] = got ? 1.0 : scale[jj];
+            theta[jj] = (gc * CPL + jj < ni) ? theta0 : 0.0;
+            scale[jj] = 1.0;
          }
-         it = got ? 0 : it;
-         locus = got ? loc : locus;
-         niso = got ? ni : niso;
-         iso_base = got ? ib : iso_base;
+         it = 0;
+         locus = loc;
+         niso = ni;
+         iso_base = ib;
          const bool empty = got && red[1] == 0.0;
          if (empty) {
             // init() == false (:391): theta = theta0, the caller drops the locus
@@ -411,23 +401,12 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
             if (gr == 0) {
 #pragma unroll
                for (int jj = 0; jj < CPL; ++jj)
-                  if (gc * CPL + jj < ni) a.theta[ib + gc * CPL + jj] = t0;
+                  if (gc * CPL + jj < ni) a.theta[ib + gc * CPL + jj] = theta0;
             }
          }
-         have = have || (got && !empty);
+         have = got && !empty;
       }
-      if (BLOCK) {
-         // have / exhausted are workgroup-uniform
-         if (!have) {
-            if (exhausted) break;
-            continue;
-         }
-      } else {
-         if (!__any(have)) {
-            if (__all(exhausted)) break;
-            continue;
-         }
-      }
+      if (BLOCK ? !have : !__any(have)) continue; // e.g. only init()==false loci: pull again
 
       // ------------------------------------------------------ steady-state loop
       // Runs until some group of the wave needs attention (first iteration's
@@ -559,8 +538,11 @@ struct ClassDesc {
 };
 constexpr int kLayouts = 6; // (CPL, CL): (2,1) (4,1) (8,1) (8,2) (8,4) (8,8)
 
+// Register budgets: the wave form asks for 3 (rows multiplier 1) or 2 (multiplier 2)
+// waves per SIMD, so that a whole human-scale batch is resident in one round; the
+// block form runs one wave per SIMD with all 512 VGPRs.
 template <int NWAVES, int RMULT>
-__global__ __launch_bounds__(NWAVES > 0 ? 64 * NWAVES : 64) void em_fused_kernel(EmArgs a, const ClassDesc *table,
+__global__ __launch_bounds__(NWAVES > 0 ? 64 * NWAVES : 64, NWAVES > 0 ? 1 : (RMULT == 1 ? 3 : 2)) void em_fused_kernel(EmArgs a, const ClassDesc *table,
                                                                                  int n_classes,
                                                                                  const int32_t *loci_all,
                                                                                  int32_t *cursors)

@@ -132,7 +132,8 @@ int build_host_plan(int64_t n_loci, const int64_t *row_off, const int64_t *iso_o
 
    // grids: one group per locus unless that exceeds the resident-wave budget, in
    // which case every grid shrinks proportionally and groups keep pulling loci
-   const int64_t wave_budget = (int64_t)n_cu * 4 * std::max(1, tune.waves_per_simd);
+   const int wps = tune.waves_per_simd > 0 ? tune.waves_per_simd : (wave_rmult == 1 ? 3 : 2);
+   const int64_t wave_budget = (int64_t)n_cu * 4 * wps;
    int64_t waves_wanted = 0;
    for (auto &kv : by_key) {
       SizeClass &sc = kv.second;
@@ -165,7 +166,10 @@ int build_host_plan(int64_t n_loci, const int64_t *row_off, const int64_t *iso_o
    for (auto &kv : by_key) p.classes.push_back(std::move(kv.second));
    std::stable_sort(p.classes.begin(), p.classes.end(), [](const SizeClass &x, const SizeClass &y) {
       if (x.kind != y.kind) return x.kind < y.kind;
-      return x.work > y.work; // heaviest class gets the lowest block indices (dispatched first)
+      // lowest block indices are dispatched first.  A wave lives as long as the slowest
+      // of its 64/G loci, so the classes with the most loci per wave go first.
+      if (x.G != y.G) return x.G < y.G;
+      return x.work > y.work;
    });
    return SBGPU_OK;
 }

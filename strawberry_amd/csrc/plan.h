@@ -53,7 +53,8 @@ constexpr int kMaxStreamIso = 512;
 
 struct PlanTuning {
    int wave_rmult = 0;   // 0 = auto, 1 / 2 = force the rows-per-lane multiplier of the wave kind
-   int waves_per_simd = 2; // resident-wave budget used to size the grids
+   int waves_per_simd = 0; // resident-wave budget used to size the grids; 0 = what the wave kernel's
+                           // register budget admits (3 at rows multiplier 1, 2 at multiplier 2)
 };
 
 // Returns 0, or a negative SBGPU_E* code with `err` filled.

@@ -44,6 +44,8 @@ struct sbgpu_ctx {
    hipStream_t aux[kAuxStreams] = {};       // size classes run concurrently on these
    hipEvent_t fork = nullptr;
    hipEvent_t join[kAuxStreams] = {};
+   hipEvent_t t0[sb::kNumKinds] = {}, t1[sb::kNumKinds] = {}; // per-kind kernel timing
+   bool timed[sb::kNumKinds] = {};
 };
 
 struct KindLaunch {
@@ -198,6 +200,10 @@ int sbgpu_init(int device, sbgpu_ctx_t **ctx_out)
       if (e == hipSuccess) e = hipEventCreateWithFlags(&c->join[i], hipEventDisableTiming);
    }
    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
+   for (int k = 0; e == hipSuccess && k < sb::kNumKinds; ++k) {
+      e = hipEventCreate(&c->t0[k]);
+      if (e == hipSuccess) e = hipEventCreate(&c->t1[k]);
+   }
    if (e != hipSuccess) {
       sbgpu_finalize(c);
       return fail(SBGPU_EHIP, std::string("sbgpu_init: stream/event creation: ") + hipGetErrorString(e));
@@ -215,6 +221,10 @@ int sbgpu_finalize(sbgpu_ctx_t *c)
       if (c->join[i]) (void)hipEventDestroy(c->join[i]);
    }
    if (c->fork) (void)hipEventDestroy(c->fork);
+   for (int k = 0; k < sb::kNumKinds; ++k) {
+      if (c->t0[k]) (void)hipEventDestroy(c->t0[k]);
+      if (c->t1[k]) (void)hipEventDestroy(c->t1[k]);
+   }
    if (c->stream) (void)hipStreamDestroy(c->stream);
    delete c;
    return SBGPU_OK;
@@ -393,11 +403,13 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
          if (p->launches[k].n_classes > 0) HIP_TRY(hipStreamWaitEvent(c->aux[k], c->fork, 0));
    }
    // heaviest per-iteration work first: stream, block512, block256, wave
+   for (int k = 0; k < sb::kNumKinds; ++k) c->timed[k] = false;
    for (int k = sb::kNumKinds - 1; k >= 0; --k) {
       const KindLaunch &kl = p->launches[k];
       if (kl.n_classes == 0) continue;
       hipStream_t s = fork ? c->aux[k] : main;
       int32_t *cursors = p->d_cursors + kl.first_class;
+      HIP_TRY(hipEventRecord(c->t0[k], s));
       if (k == sb::kWave1) {
          hipLaunchKernelGGL((sb::em_fused_kernel<0, 1>), dim3(kl.n_blocks), dim3(64), 0, s, a, kl.d_table,
                             kl.n_classes, p->d_loci_all, cursors);
@@ -416,6 +428,8 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
                             p->stream_lds_bytes, s, a, ca, p->d_row_keep);
       }
       HIP_TRY(hipGetLastError());
+      HIP_TRY(hipEventRecord(c->t1[k], s));
+      c->timed[k] = true;
    }
    if (fork) {
       for (int k = 0; k < sb::kNumKinds; ++k) {
@@ -424,6 +438,26 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
          HIP_TRY(hipStreamWaitEvent(main, c->join[k], 0));
       }
    }
+   return SBGPU_OK;
+}
+
+int sbgpu_em_last_kernel_ms(sbgpu_ctx_t *c, float ms[4])
+{
+   if (!c || !ms) return fail(SBGPU_EINVAL, "sbgpu_em_last_kernel_ms: null argument");
+   for (int k = 0; k < sb::kNumKinds && k < 4; ++k) {
+      ms[k] = 0.0f;
+      if (!c->timed[k]) continue;
+      HIP_TRY(hipEventSynchronize(c->t1[k]));
+      HIP_TRY(hipEventElapsedTime(&ms[k], c->t0[k], c->t1[k]));
+   }
+   return SBGPU_OK;
+}
+
+int sbgpu_plan_locus_kinds(const sbgpu_plan_t *p, int8_t *out)
+{
+   if (!p || (!out && p->host.n_loci)) return fail(SBGPU_EINVAL, "sbgpu_plan_locus_kinds: null argument");
+   for (const sb::SizeClass &sc : p->host.classes)
+      for (int32_t l : sc.loci) out[l] = (int8_t)sc.kind;
    return SBGPU_OK;
 }
 

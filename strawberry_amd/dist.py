@@ -1,0 +1,97 @@
+"""One process per GPU: locus sharding and the single collective of the path.
+
+Loci are independent (the reference runs them on detached threads,
+/root/reference/src/alignments.cpp:1782-1804), so ranks never exchange locus
+data.  The only cross-locus quantities are the two global normalisers of
+/root/reference/src/alignments.cpp:1372 (total mapped reads, before the EM) and
+:1821-1829 (sum of FPKM, after it): one all-reduce(sum) of a tiny buffer each --
+RCCL over xGMI on GPUs (`backend="nccl"` is RCCL on ROCm), gloo in the CPU tests.
+"""
+import os
+
+import numpy as np
+
+
+def env_world():
+    """(rank, world_size, local_rank) from the torchrun environment (1 process: 0,1,0)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def init_process_group(backend=None):
+    """Initialise torch.distributed from the environment when WORLD_SIZE > 1."""
+    import torch
+    import torch.distributed as dist
+    rank, world, local_rank = env_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def shard_loci(nrow, niso, world_size):
+    """Greedy LPT partition of loci over ranks by cost nrow*niso.
+
+    Returns a list of int64 index arrays, one per rank, each sorted ascending so a
+    rank's outputs stay in locus order.  Deterministic."""
+    cost = np.asarray(nrow, np.int64) * np.asarray(niso, np.int64) + 1
+    order = np.argsort(-cost, kind="stable")
+    load = np.zeros(world_size, np.int64)
+    owner = np.empty(len(cost), np.int64)
+    # LPT with a tie rule that is independent of the heap implementation
+    for l in order:
+        r = int(np.argmin(load))
+        owner[l] = r
+        load[r] += cost[l]
+    return [np.nonzero(owner == r)[0].astype(np.int64) for r in range(world_size)]
+
+
+def allreduce_sum_(tensor):
+    """In-place all-reduce(sum) over the default group; identity for one process."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
+    return tensor
+
+
+def allreduce_max_(tensor):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(tensor, op=dist.ReduceOp.MAX)
+    return tensor
+
+
+def barrier():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+class ShardQuantifier:
+    """A rank's share of the quantification: EM -> FPKM/Frac -> all-reduce -> TPM.
+
+    `solver` is an em.EmBatchSolver over this rank's loci.  `total_mapped_reads`
+    is the GLOBAL pass-1 count (alignments.cpp:1372), already all-reduced by the
+    caller (it precedes the EM: src/estimate.cpp:328)."""
+
+    def __init__(self, solver, total_mapped_reads, min_isoform_frac=0.01, effective_len_norm=False,
+                 insert_mean=0.0, filter_by_expression=True):
+        self.s = solver
+        self.kw = dict(total_mapped_reads=int(total_mapped_reads), min_isoform_frac=min_isoform_frac,
+                       effective_len_norm=effective_len_norm, insert_mean=insert_mean,
+                       filter_by_expression=filter_by_expression)
+
+    def step(self):
+        s = self.s
+        s.run_em()
+        s.run_abundance(**self.kw)          # leaves this rank's sum of kept FPKM in d_sum_fpkm
+        allreduce_sum_(s.d_sum_fpkm)        # the one collective: 8 bytes over xGMI
+        s.run_tpm(s.d_sum_fpkm)

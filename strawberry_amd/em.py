@@ -92,6 +92,12 @@ class Plan:
         keys = ("kind", "C", "R", "G", "n_loci", "n_waves")
         return [dict(zip(keys, out[i * 6:(i + 1) * 6])) for i in range(min(n, cap))]
 
+    def locus_kinds(self):
+        """int8[n_loci]: 0/1 wave kinds, 2 block kind, 3 streaming kind."""
+        out = np.zeros(max(self.n_loci, 1), np.int8)
+        _lib.check(self.ctx.L.sbgpu_plan_locus_kinds(self.h, out.ctypes.data), "sbgpu_plan_locus_kinds")
+        return out[:self.n_loci]
+
     def close(self):
         if self.h:
             self.ctx.L.sbgpu_plan_destroy(self.h)
@@ -137,6 +143,12 @@ class EmBatchSolver:
         _lib.check(L.sbgpu_em_run_device(self.ctx.h, self.plan.h, self.d_count.data_ptr(), self.d_F.data_ptr(),
                                          self.d_theta.data_ptr(), self.d_status.data_ptr(),
                                          self.d_iters.data_ptr(), self._stream()), "sbgpu_em_run_device")
+
+    def last_kernel_ms(self):
+        """Device time of the last run_em per kernel kind: [wave1, wave2, block, stream]."""
+        ms = (C.c_float * 4)()
+        _lib.check(self.ctx.L.sbgpu_em_last_kernel_ms(self.ctx.h, ms), "sbgpu_em_last_kernel_ms")
+        return [float(x) for x in ms]
 
     def run_abundance(self, total_mapped_reads, effective_len_norm=False, insert_mean=0.0,
                       filter_by_expression=True, min_isoform_frac=0.01):
