@@ -28,6 +28,7 @@ constexpr double kRowEps = 1e-5;        // src/estimate.cpp:380
 
 constexpr int kMaxCPLv = 8;            // columns per lane of the widest register tile
 constexpr int32_t kStOk = 0, kStInitEmpty = 1, kStDenomZero = 2, kStMaxIter = 3;
+constexpr int32_t kStRunning = 4; // transient: suspended at a phase limit, resumed by the next phase
 
 // Device view of a batch (CSR-of-loci, include/sbgpu.h) and its outputs.
 struct EmArgs {
@@ -47,6 +48,13 @@ struct ClassArgs {
    const int32_t *loci;
    int32_t n;
    int32_t *cursor;
+   // phased execution: a locus still running after `it_limit` iterations is suspended
+   // (theta and the iteration count are its whole state) and appended to `out`, the
+   // input list of the next phase, which packs the survivors densely again
+   int32_t *out;
+   int32_t *out_count;
+   int32_t it_limit;
+   int32_t resume; // this phase's loci carry state from the previous one
 };
 
 // ------------------------------------------------------------------ cross-lane
@@ -119,9 +127,9 @@ __device__ __forceinline__ int wave_group_or(int x)
 }
 
 // ------------------------------------------------------------------ arithmetic
-// n / d to <= 1 ulp without the IEEE div_scale/div_fixup tail: v_rcp_f64 seed,
-// two Newton steps, one residual correction.  Operands here are O(1e-6 .. 1e9);
-// d == 0 gives NaN, which callers mask or turn into DENOM_ZERO before use.
+// n / d without the IEEE div_scale / div_fixup tail: v_rcp_f64 seed (~2^-24 relative)
+// and two Newton steps (-> ~2^-52), then one multiply: <= 2 ulp.  Operands here are
+// O(1e-6 .. 1e9); d == 0 gives NaN, which callers mask or turn into DENOM_ZERO.
 __device__ __forceinline__ double fast_div(double n, double d)
 {
    double r = __builtin_amdgcn_rcp(d);
@@ -129,9 +137,7 @@ __device__ __forceinline__ double fast_div(double n, double d)
    r = __builtin_fma(r, e, r);
    e = __builtin_fma(-d, r, 1.0);
    r = __builtin_fma(r, e, r);
-   double q = n * r;
-   double rem = __builtin_fma(-d, q, n);
-   return __builtin_fma(rem, r, q);
+   return n * r;
 }
 
 // ================================================================== tile kernel
@@ -229,6 +235,15 @@ __device__ __forceinline__ void set_fp64_flush_denormals()
    __builtin_amdgcn_s_setreg(1 | (6 << 6) | ((2 - 1) << 11), 0);
 }
 
+#ifdef SB_STAMPS
+// Diagnostic build only (make stamps): per-wave cycle stamps, never compiled into the
+// product library.  [wave][8] = {start, after class lookup, first refill done, end,
+// batches, iterations, refill cycles total, events cycles total}
+constexpr int kStampWaves = 1 << 16;
+__device__ unsigned long long sb_debug_stamps[kStampWaves * 8];
+__device__ __forceinline__ unsigned long long sb_now() { return __builtin_readcyclecounter(); }
+#endif
+
 constexpr int kBlockWaves = 4; // block form: 256 lanes, one wave per SIMD, up to 512 VGPRs each
 
 // NWAVES = 0: wave form; NWAVES = 4: block form.  R is the register-tile capacity
@@ -252,6 +267,9 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
    const int gr = g >> LB_CL;
    int phase = 0;
    int r_used = R; // block form: rows per row lane the current locus needs (workgroup-uniform)
+#ifdef SB_STAMPS
+   unsigned long long st_refill = 0, st_events = 0, st_first = 0, st_batches = 0, st_iters = 0, st_t = 0;
+#endif
 
    // all-reduce over the row lanes of the group
    auto row_lane_sum = [&](auto &x, auto nval_tag) {
@@ -285,10 +303,26 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
    };
 
    double F[R][CPL];
+   double scale[CPL]; // 1, then 1/column-sum after the first iteration: F' = F * scale (:466-478)
+   // F <- column-normalised F (:466-478), a zero column stays zero: F itself is left
+   // untouched in registers, the column scale takes the normalisation
+   auto column_scale = [&]() {
+      double cs[CPL];
+#pragma unroll
+      for (int jj = 0; jj < CPL; ++jj) {
+         double sum = 0.0;
+#pragma unroll
+         for (int r = 0; r < R; ++r)
+            if (!BLOCK || (r & ~3) < r_used) sum += F[r][jj];
+         cs[jj] = sum;
+      }
+      row_lane_sum(cs, std::integral_constant<int, CPL>());
+#pragma unroll
+      for (int jj = 0; jj < CPL; ++jj) scale[jj] = (cs[jj] == 0.0) ? 0.0 : 1.0 / cs[jj];
+   };
    double nn[R];      // n_i as double (obs_d, estimate.cpp:418-419); 0 for dropped rows
    bool act[R];       // row kept by init() (estimate.cpp:377-390)
    double theta[CPL];
-   double scale[CPL]; // 1, then 1/column-sum after the first iteration: F' = F * scale (:466-478)
    double theta0 = 0.0;
    int it = 0;
    int niso = 0;
@@ -315,6 +349,9 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
       // is idle, each group pulls its next locus from the class list.  All lanes
       // load together, so F, theta, ... are simply overwritten.
       if (BLOCK ? !have : !__any(have)) {
+#ifdef SB_STAMPS
+         st_t = sb_now();
+#endif
          int idx = 0;
          if (BLOCK) {
             if (threadIdx.x == 0) *s_idx = atomicAdd(cls.cursor, 1);
@@ -335,6 +372,7 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
          const int ni = (int)(a.iso_off[loc + 1] - ib);
          const double *Fg = a.F + a.f_off[loc];
          if (BLOCK) {
+            // row blocks the locus does not reach are skipped (workgroup-uniform)
             r_used = (nrow + GR - 1) / GR;
             r_used = r_used < 1 ? 1 : (r_used > R ? R : r_used);
          }
@@ -391,6 +429,15 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
          locus = loc;
          niso = ni;
          iso_base = ib;
+         if (cls.resume) {
+            // state saved at the previous phase's limit: theta and the iteration count;
+            // the column scale is recomputed exactly as it was computed the first time
+            it = got ? a.iters[loc] : 0;
+#pragma unroll
+            for (int jj = 0; jj < CPL; ++jj)
+               theta[jj] = (gc * CPL + jj < ni) ? a.theta[ib + gc * CPL + jj] : 0.0;
+            column_scale();
+         }
          const bool empty = got && red[1] == 0.0;
          if (empty) {
             // init() == false (:391): theta = theta0, the caller drops the locus
@@ -405,6 +452,11 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
             }
          }
          have = got && !empty;
+#ifdef SB_STAMPS
+         st_refill += sb_now() - st_t;
+         st_batches += 1;
+         if (!st_first) st_first = sb_now();
+#endif
       }
       if (BLOCK ? !have : !__any(have)) continue; // e.g. only init()==false loci: pull again
 
@@ -461,34 +513,30 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
          // ||next - theta||_2 < 1e-2 (:479-480) tested on the squares: sqrt is monotone, so
          // the two tests can only differ for d2 within an ulp of 1e-4
          conv = d2 < kThetaLimit * kThetaLimit;
-         special = have && (dz || conv || it == 0 || it + 1 == kMaxIter);
+         special = have && (dz || conv || it == 0 || it + 1 == cls.it_limit);
          if (have && !special) {
 #pragma unroll
             for (int jj = 0; jj < CPL; ++jj) theta[jj] = nt[jj]; // :481
             ++it;
          }
+#ifdef SB_STAMPS
+         st_iters += 1;
+#endif
       } while (BLOCK ? !special : !__any(special));
+#ifdef SB_STAMPS
+      st_t = sb_now();
+#endif
 
       // ------------------------------------------------------- per-group events
-      // F <- column-normalised F after the first iteration (:466-478), a zero column
-      // stays zero: F itself is left untouched in registers, the column scale takes it.
+      // first iteration done: switch to the column-normalised problem (:466-478)
       const bool norm = special && !dz && it == 0;
       if (BLOCK ? norm : __any(norm)) {
-         double cs[CPL];
+         double keep_scale[CPL];
 #pragma unroll
-         for (int jj = 0; jj < CPL; ++jj) {
-            double s = 0.0;
+         for (int jj = 0; jj < CPL; ++jj) keep_scale[jj] = scale[jj];
+         column_scale();
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-               if (!BLOCK || (r & ~3) < r_used) s += F[r][jj];
-            cs[jj] = s;
-         }
-         row_lane_sum(cs, std::integral_constant<int, CPL>());
-#pragma unroll
-         for (int jj = 0; jj < CPL; ++jj) {
-            const double q = (cs[jj] == 0.0) ? 0.0 : 1.0 / cs[jj];
-            scale[jj] = norm ? q : scale[jj];
-         }
+         for (int jj = 0; jj < CPL; ++jj) scale[jj] = norm ? scale[jj] : keep_scale[jj];
       }
       if (special) {
          bool finished = false;
@@ -504,9 +552,11 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
          } else {
 #pragma unroll
             for (int jj = 0; jj < CPL; ++jj) theta[jj] = nt[jj]; // :481
-            if (it + 1 == kMaxIter) {
+            if (it + 1 == cls.it_limit) {
+               // the 1000-iteration cap (estimate.hpp:237), or only this phase's limit:
+               // then the locus is suspended and handed to the next phase
                finished = true;
-               st = kStMaxIter;
+               st = (cls.it_limit >= kMaxIter) ? kStMaxIter : kStRunning;
             }
          }
          ++it;
@@ -514,6 +564,7 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
             if (g == 0) {
                a.status[locus] = st;
                a.iters[locus] = it;
+               if (st == kStRunning) cls.out[atomicAdd(cls.out_count, 1)] = locus;
             }
             if (gr == 0) {
 #pragma unroll
@@ -523,7 +574,21 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
             have = false;
          }
       }
+#ifdef SB_STAMPS
+      st_events += sb_now() - st_t;
+#endif
    }
+#ifdef SB_STAMPS
+   if (lane == 0) {
+      const unsigned wg = (blockIdx.x * (blockDim.x >> 6) + wave_id) & (kStampWaves - 1);
+      sb_debug_stamps[wg * 8 + 2] = st_first;
+      sb_debug_stamps[wg * 8 + 3] = sb_now();
+      sb_debug_stamps[wg * 8 + 4] = st_batches;
+      sb_debug_stamps[wg * 8 + 5] = st_iters;
+      sb_debug_stamps[wg * 8 + 6] = st_refill;
+      sb_debug_stamps[wg * 8 + 7] = st_events;
+   }
+#endif
 }
 
 // One launch serves every size class of a batch: the workgroup looks its class
@@ -542,14 +607,17 @@ constexpr int kLayouts = 6; // (CPL, CL): (2,1) (4,1) (8,1) (8,2) (8,4) (8,8)
 // waves per SIMD, so that a whole human-scale batch is resident in one round; the
 // block form runs one wave per SIMD with all 512 VGPRs.
 template <int NWAVES, int RMULT>
-__global__ __launch_bounds__(NWAVES > 0 ? 64 * NWAVES : 64, NWAVES > 0 ? 1 : (RMULT == 1 ? 3 : 2)) void em_fused_kernel(EmArgs a, const ClassDesc *table,
-                                                                                 int n_classes,
-                                                                                 const int32_t *loci_all,
-                                                                                 int32_t *cursors)
+__global__ __launch_bounds__(NWAVES > 0 ? 64 * NWAVES : 64,
+                              NWAVES > 0 ? 1 : (RMULT == 1 ? 3 : 2)) void em_fused_kernel(
+   EmArgs a, const ClassDesc *table, int n_classes, const int32_t *lists_in, const int32_t *n_in,
+   int32_t *cursors, int32_t *lists_out, int32_t *n_out, int it_limit, int resume)
 {
    __shared__ double s_red[NWAVES > 0 ? 2 * (kMaxCPLv + 1) * 8 * NWAVES : 1];
    __shared__ int s_idx;
    set_fp64_flush_denormals();
+#ifdef SB_STAMPS
+   const unsigned long long st0 = sb_now();
+#endif
    // wave-uniform class lookup
    int c = 0;
    const int b = (int)blockIdx.x;
@@ -557,10 +625,21 @@ __global__ __launch_bounds__(NWAVES > 0 ? 64 * NWAVES : 64, NWAVES > 0 ? 1 : (RM
       if (table[k].block_begin <= b) c = k;
    c = __builtin_amdgcn_readfirstlane(c);
    const ClassDesc d = table[c];
+#ifdef SB_STAMPS
+   if ((threadIdx.x & 63) == 0) {
+      const unsigned wg = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (kStampWaves - 1);
+      sb_debug_stamps[wg * 8 + 0] = st0;
+      sb_debug_stamps[wg * 8 + 1] = sb_now();
+   }
+#endif
    ClassArgs cls;
-   cls.loci = loci_all + d.loci_off;
-   cls.n = d.n;
+   cls.loci = lists_in + d.loci_off;
+   cls.n = n_in[c];
    cls.cursor = cursors + c;
+   cls.out = lists_out + d.loci_off;
+   cls.out_count = n_out + c;
+   cls.it_limit = it_limit;
+   cls.resume = resume;
    const int layout = d.shape & 0xFF;
    const int lbG = (d.shape >> 16) & 0xFF;
    switch (layout) {

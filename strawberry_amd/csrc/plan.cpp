@@ -103,14 +103,17 @@ int build_host_plan(int64_t n_loci, const int64_t *row_off, const int64_t *iso_o
                placed = true;
             }
          }
-         // block kind: the whole 256-lane workgroup is the group
-         if (!placed && (int64_t)(kBlockThreads / k.CL) * R1 * kBlockRmult >= nrow) {
-            k.kind = kBlock;
-            k.rmult = kBlockRmult;
-            k.R = R1 * kBlockRmult;
-            k.G = kBlockThreads;
-            k.lbG = 6;
-            placed = true;
+         // block kinds: the whole 256-lane workgroup is the group
+         for (int tall = tune.light_block ? 0 : 1; tall < 2 && !placed; ++tall) {
+            const int rm = tall ? kBlockTallRmult : kBlockRmult;
+            if ((int64_t)(kBlockThreads / k.CL) * R1 * rm >= nrow) {
+               k.kind = tall ? kBlockTall : kBlock;
+               k.rmult = rm;
+               k.R = R1 * rm;
+               k.G = kBlockThreads;
+               k.lbG = 6;
+               placed = true;
+            }
          }
       }
       if (k.kind == kStream) {
@@ -130,10 +133,12 @@ int build_host_plan(int64_t n_loci, const int64_t *row_off, const int64_t *iso_o
    p.n_iso = iso_off[n_loci];
    p.n_elem = f_off[n_loci];
 
-   // grids: one group per locus unless that exceeds the resident-wave budget, in
-   // which case every grid shrinks proportionally and groups keep pulling loci
-   const int wps = tune.waves_per_simd > 0 ? tune.waves_per_simd : (wave_rmult == 1 ? 3 : 2);
-   const int64_t wave_budget = (int64_t)n_cu * 4 * wps;
+   // grids: one wave per batch of 64/G loci (one workgroup per locus in the block kind).
+   // More waves than the chip holds is fine: the dispatcher starts the next one as soon as
+   // a slot frees, and a wave that lives only as long as its own batch cannot chain several
+   // 1000-iteration batches back to back.  Only beyond `max_waves` do the grids shrink and
+   // waves pull further batches through the cursor.
+   const int64_t max_waves = tune.max_waves > 0 ? tune.max_waves : (int64_t)1 << 20;
    int64_t waves_wanted = 0;
    for (auto &kv : by_key) {
       SizeClass &sc = kv.second;
@@ -156,8 +161,8 @@ int build_host_plan(int64_t n_loci, const int64_t *row_off, const int64_t *iso_o
       }
       waves_wanted += (int64_t)sc.n_blocks * (sc.block_threads / 64);
    }
-   if (waves_wanted > wave_budget) {
-      const double f = (double)wave_budget / (double)waves_wanted;
+   if (waves_wanted > max_waves) {
+      const double f = (double)max_waves / (double)waves_wanted;
       for (auto &kv : by_key) {
          SizeClass &sc = kv.second;
          sc.n_blocks = std::max(1, (int)(sc.n_blocks * f + 0.5));

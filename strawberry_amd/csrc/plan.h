@@ -13,15 +13,17 @@
 
 namespace sb {
 
-// One kernel launch per kind (at most three per batch: one wave kind, the block
-// kind, the streaming kind -- the chip exposes four hardware queues).
+// One kernel launch per kind and phase (the chip exposes four hardware queues, and a
+// batch uses at most four kinds).
 //  kWave1/kWave2  64/G groups per wave, rows-per-lane multiplier 1 or 2 (a plan uses one)
-//  kBlock         one 256-lane workgroup per locus, one wave per SIMD with the full
-//                 512-VGPR budget: register tiles up to kBlockRmult x the base rows
+//  kBlock         one 256-lane workgroup per locus, register tile 2x the base rows, <= 256
+//                 VGPRs so that it shares a SIMD with wave-kind waves
+//  kBlockTall     same with 6x the base rows: one wave per SIMD, the full 512-VGPR budget
 //  kStream        anything larger: F re-read from L2 every iteration
-enum ClassKind : int { kWave1 = 0, kWave2, kBlock, kStream, kNumKinds };
+enum ClassKind : int { kWave1 = 0, kWave2, kBlock, kBlockTall, kStream, kNumKinds };
 constexpr int kBlockThreads = 256;
-constexpr int kBlockRmult = 6;
+constexpr int kBlockRmult = 2;
+constexpr int kBlockTallRmult = 6;
 
 struct SizeClass {
    int kind = kWave1;
@@ -53,8 +55,9 @@ constexpr int kMaxStreamIso = 512;
 
 struct PlanTuning {
    int wave_rmult = 0;   // 0 = auto, 1 / 2 = force the rows-per-lane multiplier of the wave kind
-   int waves_per_simd = 0; // resident-wave budget used to size the grids; 0 = what the wave kernel's
-                           // register budget admits (3 at rows multiplier 1, 2 at multiplier 2)
+   bool light_block = false; // also use the 2x-rows block kind (<= 256 VGPRs); off: it spills and
+                             // fights the wave kind for the same SIMDs (measured slower on C3)
+   int64_t max_waves = 0;  // grids shrink (waves pull several batches) only beyond this many waves; 0 = 2^20
 };
 
 // Returns 0, or a negative SBGPU_E* code with `err` filled.

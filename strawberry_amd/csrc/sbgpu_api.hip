@@ -60,8 +60,12 @@ struct sbgpu_plan {
    sb::HostPlan host;
    KindLaunch launches[sb::kNumKinds];
    int64_t *d_row_off = nullptr, *d_iso_off = nullptr, *d_f_off = nullptr;
-   int32_t *d_loci_all = nullptr;      // all class lists, concatenated
-   int32_t *d_cursors = nullptr;       // one per class
+   int32_t *d_loci_all = nullptr;      // all class lists, concatenated (input of phase 0)
+   int32_t *d_lists[2] = {nullptr, nullptr}; // survivor lists of the later phases (ping-pong)
+   int32_t *d_class_n = nullptr;       // loci per class (input count of phase 0)
+   int32_t *d_counts = nullptr;        // [phase][class] survivor counts, zeroed every run
+   int32_t *d_cursors = nullptr;       // [phase][class] dynamic-pull cursors, zeroed every run
+   std::vector<int> phase_limits;      // iteration limit of each phase, last = 1000
    sb::ClassDesc *d_tables = nullptr;  // one descriptor per class
    std::vector<int64_t> loci_off;      // per class: offset into d_loci_all
    uint8_t *d_row_keep = nullptr;      // streaming path: init() row flags
@@ -258,6 +262,10 @@ int sbgpu_plan_destroy(sbgpu_plan_t *p)
    (void)hipFree(p->d_f_off);
    (void)hipFree(p->d_loci_all);
    (void)hipFree(p->d_cursors);
+   (void)hipFree(p->d_counts);
+   (void)hipFree(p->d_class_n);
+   (void)hipFree(p->d_lists[0]);
+   (void)hipFree(p->d_lists[1]);
    (void)hipFree(p->d_tables);
    (void)hipFree(p->d_row_keep);
    (void)hipFree(p->d_locus_sum);
@@ -276,7 +284,8 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
    const char *err = "";
    sb::PlanTuning tune;
    if (const char *e = std::getenv("SBGPU_WAVE_RMULT")) tune.wave_rmult = std::atoi(e);
-   if (const char *e = std::getenv("SBGPU_WAVES_PER_SIMD")) tune.waves_per_simd = std::atoi(e);
+   if (const char *e = std::getenv("SBGPU_MAX_WAVES")) tune.max_waves = std::atoll(e);
+   if (const char *e = std::getenv("SBGPU_LIGHT_BLOCK")) tune.light_block = std::atoi(e) != 0;
    int rc = sb::build_host_plan(n_loci, row_off, iso_off, f_off, c->n_cu, tune, &p->host, &err);
    if (rc != SBGPU_OK) {
       delete p;
@@ -293,7 +302,32 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
    if ((e = hipMalloc(&p->d_iso_off, nb)) != hipSuccess) return bail(e, "hipMalloc(iso_off)");
    if ((e = hipMalloc(&p->d_f_off, nb)) != hipSuccess) return bail(e, "hipMalloc(f_off)");
    if ((e = hipMalloc(&p->d_loci_all, (size_t)(n_loci + 1) * sizeof(int32_t))) != hipSuccess) return bail(e, "hipMalloc(loci)");
-   if ((e = hipMalloc(&p->d_cursors, (p->host.classes.size() + 1) * sizeof(int32_t))) != hipSuccess) return bail(e, "hipMalloc(cursors)");
+   // phases: a single phase (the 1000 cap) by default; SBGPU_PHASES="64,256" suspends the loci
+   // still running at 64 and 256 iterations and re-packs them (measured: no gain on C2/C3)
+   {
+      std::string spec = "";
+      if (const char *ev = std::getenv("SBGPU_PHASES")) spec = ev;
+      int last = 1;
+      size_t pos = 0;
+      while (pos < spec.size()) {
+         size_t q = spec.find(',', pos);
+         if (q == std::string::npos) q = spec.size();
+         int v = std::atoi(spec.substr(pos, q - pos).c_str());
+         if (v > last && v < SBGPU_EM_MAX_ITER && p->phase_limits.size() < 6) {
+            p->phase_limits.push_back(v);
+            last = v;
+         }
+         pos = q + 1;
+      }
+      p->phase_limits.push_back(SBGPU_EM_MAX_ITER);
+   }
+   const size_t ncls_alloc = p->host.classes.size() + 1;
+   const size_t nph = p->phase_limits.size() + 1;
+   if ((e = hipMalloc(&p->d_cursors, nph * ncls_alloc * sizeof(int32_t))) != hipSuccess) return bail(e, "hipMalloc(cursors)");
+   if ((e = hipMalloc(&p->d_counts, nph * ncls_alloc * sizeof(int32_t))) != hipSuccess) return bail(e, "hipMalloc(counts)");
+   if ((e = hipMalloc(&p->d_class_n, ncls_alloc * sizeof(int32_t))) != hipSuccess) return bail(e, "hipMalloc(class_n)");
+   if ((e = hipMalloc(&p->d_lists[0], (size_t)(n_loci + 1) * sizeof(int32_t))) != hipSuccess) return bail(e, "hipMalloc(list0)");
+   if ((e = hipMalloc(&p->d_lists[1], (size_t)(n_loci + 1) * sizeof(int32_t))) != hipSuccess) return bail(e, "hipMalloc(list1)");
    if ((e = hipMalloc(&p->d_row_keep, (size_t)p->host.n_rows + 1)) != hipSuccess) return bail(e, "hipMalloc(row_keep)");
    if ((e = hipMalloc(&p->d_locus_sum, (size_t)(n_loci + 1) * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(locus_sum)");
    if (n_loci > 0) {
@@ -334,6 +368,12 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
    if (!table.empty() &&
        (e = hipMemcpy(p->d_tables, table.data(), table.size() * sizeof(sb::ClassDesc), hipMemcpyHostToDevice)) != hipSuccess)
       return bail(e, "hipMemcpy(tables)");
+   {
+      std::vector<int32_t> cn(table.size() + 1, 0);
+      for (size_t i = 0; i < table.size(); ++i) cn[i] = table[i].n;
+      if ((e = hipMemcpy(p->d_class_n, cn.data(), cn.size() * sizeof(int32_t), hipMemcpyHostToDevice)) != hipSuccess)
+         return bail(e, "hipMemcpy(class_n)");
+   }
    // streaming kernel LDS: (3 + NWAVE) * npad doubles, npad <= pow2ceil-padded niso
    size_t npad = 1;
    while (npad < max_stream_iso && npad < 64) npad <<= 1;
@@ -391,9 +431,12 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
    a.status = d_status;
    a.iters = d_iters;
    const int ncls = (int)p->host.classes.size();
-   HIP_TRY(hipMemsetAsync(p->d_cursors, 0, (size_t)(ncls + 1) * sizeof(int32_t), main));
-   // one launch per kind (wave / block256 / block512 / stream); a single kind runs
-   // on the caller's stream, several fork onto the aux streams and join back
+   const size_t ncls_alloc = (size_t)ncls + 1;
+   const int nph = (int)p->phase_limits.size();
+   HIP_TRY(hipMemsetAsync(p->d_cursors, 0, (size_t)(nph + 1) * ncls_alloc * sizeof(int32_t), main));
+   HIP_TRY(hipMemsetAsync(p->d_counts, 0, (size_t)(nph + 1) * ncls_alloc * sizeof(int32_t), main));
+   // one launch per kind and phase (wave / block / stream); a single kind runs on the
+   // caller's stream, several fork onto the aux streams and join back
    int kinds = 0;
    for (int k = 0; k < sb::kNumKinds; ++k) kinds += p->launches[k].n_classes > 0;
    const bool fork = kinds > 1;
@@ -402,32 +445,52 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
       for (int k = 0; k < sb::kNumKinds; ++k)
          if (p->launches[k].n_classes > 0) HIP_TRY(hipStreamWaitEvent(c->aux[k], c->fork, 0));
    }
-   // heaviest per-iteration work first: stream, block512, block256, wave
    for (int k = 0; k < sb::kNumKinds; ++k) c->timed[k] = false;
+   // longest iterations first: stream, block, wave
    for (int k = sb::kNumKinds - 1; k >= 0; --k) {
       const KindLaunch &kl = p->launches[k];
       if (kl.n_classes == 0) continue;
       hipStream_t s = fork ? c->aux[k] : main;
-      int32_t *cursors = p->d_cursors + kl.first_class;
       HIP_TRY(hipEventRecord(c->t0[k], s));
-      if (k == sb::kWave1) {
-         hipLaunchKernelGGL((sb::em_fused_kernel<0, 1>), dim3(kl.n_blocks), dim3(64), 0, s, a, kl.d_table,
-                            kl.n_classes, p->d_loci_all, cursors);
-      } else if (k == sb::kWave2) {
-         hipLaunchKernelGGL((sb::em_fused_kernel<0, 2>), dim3(kl.n_blocks), dim3(64), 0, s, a, kl.d_table,
-                            kl.n_classes, p->d_loci_all, cursors);
-      } else if (k == sb::kBlock) {
-         hipLaunchKernelGGL((sb::em_fused_kernel<sb::kBlockWaves, sb::kBlockRmult>), dim3(kl.n_blocks),
-                            dim3(sb::kBlockThreads), 0, s, a, kl.d_table, kl.n_classes, p->d_loci_all, cursors);
-      } else {
-         sb::ClassArgs ca;
+      if (k == sb::kStream) {
+         sb::ClassArgs ca = {};
          ca.loci = p->d_loci_all + p->loci_off[kl.first_class];
          ca.n = (int32_t)p->host.classes[kl.first_class].loci.size();
-         ca.cursor = cursors;
+         ca.cursor = p->d_cursors + kl.first_class;
          hipLaunchKernelGGL(sb::em_stream_kernel, dim3(kl.n_blocks), dim3(sb::kStreamThreads),
                             p->stream_lds_bytes, s, a, ca, p->d_row_keep);
+         HIP_TRY(hipGetLastError());
+      } else {
+         // phase ph runs the loci still alive up to phase_limits[ph] iterations and appends
+         // the unfinished ones to the next phase's list; later phases launch the same grid,
+         // waves whose class list is already dry leave after one atomic
+         for (int ph = 0; ph < nph; ++ph) {
+            const int32_t *lists_in = (ph == 0) ? p->d_loci_all : p->d_lists[(ph - 1) & 1];
+            const int32_t *n_in = (ph == 0) ? p->d_class_n + kl.first_class
+                                            : p->d_counts + (size_t)ph * ncls_alloc + kl.first_class;
+            int32_t *cursors = p->d_cursors + (size_t)ph * ncls_alloc + kl.first_class;
+            int32_t *lists_out = p->d_lists[ph & 1];
+            int32_t *n_out = p->d_counts + (size_t)(ph + 1) * ncls_alloc + kl.first_class;
+            const int limit = p->phase_limits[ph];
+            const int resume = ph > 0;
+            if (k == sb::kWave1) {
+               hipLaunchKernelGGL((sb::em_fused_kernel<0, 1>), dim3(kl.n_blocks), dim3(64), 0, s, a, kl.d_table,
+                                  kl.n_classes, lists_in, n_in, cursors, lists_out, n_out, limit, resume);
+            } else if (k == sb::kWave2) {
+               hipLaunchKernelGGL((sb::em_fused_kernel<0, 2>), dim3(kl.n_blocks), dim3(64), 0, s, a, kl.d_table,
+                                  kl.n_classes, lists_in, n_in, cursors, lists_out, n_out, limit, resume);
+            } else if (k == sb::kBlock) {
+               hipLaunchKernelGGL((sb::em_fused_kernel<sb::kBlockWaves, sb::kBlockRmult>), dim3(kl.n_blocks),
+                                  dim3(sb::kBlockThreads), 0, s, a, kl.d_table, kl.n_classes, lists_in, n_in,
+                                  cursors, lists_out, n_out, limit, resume);
+            } else {
+               hipLaunchKernelGGL((sb::em_fused_kernel<sb::kBlockWaves, sb::kBlockTallRmult>), dim3(kl.n_blocks),
+                                  dim3(sb::kBlockThreads), 0, s, a, kl.d_table, kl.n_classes, lists_in, n_in,
+                                  cursors, lists_out, n_out, limit, resume);
+            }
+            HIP_TRY(hipGetLastError());
+         }
       }
-      HIP_TRY(hipGetLastError());
       HIP_TRY(hipEventRecord(c->t1[k], s));
       c->timed[k] = true;
    }
@@ -441,10 +504,10 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
    return SBGPU_OK;
 }
 
-int sbgpu_em_last_kernel_ms(sbgpu_ctx_t *c, float ms[4])
+int sbgpu_em_last_kernel_ms(sbgpu_ctx_t *c, float ms[5])
 {
    if (!c || !ms) return fail(SBGPU_EINVAL, "sbgpu_em_last_kernel_ms: null argument");
-   for (int k = 0; k < sb::kNumKinds && k < 4; ++k) {
+   for (int k = 0; k < sb::kNumKinds && k < 5; ++k) {
       ms[k] = 0.0f;
       if (!c->timed[k]) continue;
       HIP_TRY(hipEventSynchronize(c->t1[k]));
@@ -452,6 +515,16 @@ int sbgpu_em_last_kernel_ms(sbgpu_ctx_t *c, float ms[4])
    }
    return SBGPU_OK;
 }
+
+#ifdef SB_STAMPS
+// diagnostic build only
+int sbgpu_debug_read_stamps(void *out, size_t bytes)
+{
+   HIP_TRY(hipDeviceSynchronize());
+   HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(sb::sb_debug_stamps), bytes));
+   return SBGPU_OK;
+}
+#endif
 
 int sbgpu_plan_locus_kinds(const sbgpu_plan_t *p, int8_t *out)
 {

@@ -163,3 +163,42 @@ def test_gpu_abundance_and_tpm_match_oracle(ctx, oracle, golden):
         tpm, tot = oracle.tpm(fpkm, keep)
         assert abs(r["sum_fpkm"] - tot) / tot < 1e-12
         np.testing.assert_allclose(r["tpm"], tpm, rtol=1e-12, atol=0)
+
+
+def test_gpu_phased_execution_is_bitwise_identical(ctx, monkeypatch):
+    """Suspending loci at iteration limits and resuming them in a later launch
+    (SBGPU_PHASES) must not change a single bit: theta and the iteration count are the
+    whole state, the column scale is recomputed in the same order."""
+    from strawberry_amd import em, synth
+    b = synth.make_c3(n_loci=6000, total_frags=2e7, seed=11)
+    monkeypatch.delenv("SBGPU_PHASES", raising=False)
+    s0 = em.EmBatchSolver(b, ctx)
+    s0.run_em()
+    r0 = s0.results()
+    for spec in ("8", "3,17,64,300", "64,256"):
+        monkeypatch.setenv("SBGPU_PHASES", spec)
+        s1 = em.EmBatchSolver(b, ctx)
+        s1.run_em()
+        r1 = s1.results()
+        np.testing.assert_array_equal(r0["status"], r1["status"])
+        np.testing.assert_array_equal(r0["iters"], r1["iters"])
+        np.testing.assert_array_equal(r0["theta"], r1["theta"])
+    assert (r0["status"] <= 3).all()
+
+
+@pytest.mark.parametrize("env", [{"SBGPU_WAVE_RMULT": "1"}, {"SBGPU_WAVE_RMULT": "2"},
+                                 {"SBGPU_LIGHT_BLOCK": "1"}, {"SBGPU_MAX_WAVES": "64"}])
+def test_gpu_every_schedule_gives_the_same_answer(ctx, oracle, monkeypatch, env):
+    """Size-class / grid tuning knobs change the schedule, never the result beyond
+    summation order (status and iteration counts stay exact)."""
+    from strawberry_amd import em, synth
+    b = synth.make_c3(n_loci=3000, total_frags=1e7, seed=5)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    s = em.EmBatchSolver(b, ctx)
+    s.run_em()
+    r = s.results()
+    o_theta, o_status, o_iters = oracle.em_batch(b.row_off, b.iso_off, b.f_off, b.count, b.F, threads=4)
+    np.testing.assert_array_equal(r["status"], o_status)
+    np.testing.assert_array_equal(r["iters"], o_iters)
+    assert theta_err(r["theta"], o_theta).max() < THETA_RTOL

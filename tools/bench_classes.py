@@ -50,5 +50,35 @@ def main():
                 r["iters"].mean(), best * 1e3 / max(1, r["iters"].max())), flush=True)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "mix"):
     main()
+
+
+def mix():
+    """Several shapes in ONE batch (one fused launch): does the mix slow the classes down?"""
+    ctx = em.default_context(0)
+    shapes = [(4, 2), (8, 4), (16, 4), (32, 8), (64, 8), (128, 8), (32, 16), (64, 16), (64, 32), (12, 3), (24, 6)]
+    for per in (16, 128):
+        parts = [make(nr, ni, per, seed=7 + i) for i, (nr, ni) in enumerate(shapes)]
+        loci = []
+        for b in parts:
+            for l in range(b.n_loci):
+                loci.append(b.locus(l))
+        b = synth.from_loci(loci)
+        s = em.EmBatchSolver(b, ctx)
+        s.run_em()
+        torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(3):
+            s.run_em()
+            torch.cuda.synchronize()
+            best = min(best, max(s.last_kernel_ms()))
+        r = s.results()
+        print("mix of %d shapes x %d loci: %d classes, %.3f ms, iters mean %.1f max %d" % (
+            len(shapes), per, s.plan.info()["n_classes"], best, r["iters"].mean(), r["iters"].max()), flush=True)
+        for c in s.plan.classes():
+            print("    ", c)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "mix":
+    mix()
