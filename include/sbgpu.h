@@ -168,6 +168,46 @@ int sbgpu_tpm_device(sbgpu_ctx_t *ctx, int64_t n_iso, const double *d_fpkm,
                      const int32_t *d_keep, const double *d_total_fpkm,
                      double *d_tpm, void *stream);
 
+/* ---- bin-weight model: what fills F ----------------------------
+ * Replaces LocusContext::set_theory_bin_weight, src/estimate.cpp:201-234, with
+ * ExonBin::effective_len (include/isoform.h:419-516) and InsertSize::emp_dist_pdf
+ * (src/read.cpp:274-297).  One work item per (exon bin, isoform) pair:
+ *   seg_lens[seg_off[p] .. seg_off[p+1])  lengths of the isoform's segments the bin
+ *                                         spans (<= 32), as returned through
+ *                                         ExonBin::bin_under_iso (isoform.h:363-411)
+ *   implicit_mask[p]                      bit k set: segment k is implicit (mate gap)
+ *   iso_len[p]                            exonic length L_j (estimate.hpp:98)
+ *   out_index[p]                          element of `F` that receives the weight
+ *                                         (NULL: F[p]) -- lets the kernel write
+ *                                         straight into an EM batch's F array      */
+typedef struct {
+   double mean, sd;        /* InsertSize::_mean, _sd                                   */
+   int32_t use_emp;        /* InsertSize::_use_emp                                     */
+   int32_t start_offset;   /* InsertSize::_start_offset (use_emp only)                 */
+   int32_t end_offset;     /* InsertSize::_end_offset                                  */
+   int32_t total_reads;    /* InsertSize::_total_reads                                 */
+   const double *emp_hist; /* InsertSize::_emp_dist[end_offset-start_offset+1], host   */
+   int32_t read_len;       /* ReadTable::read_len_mode(), include/read.hpp:150-160     */
+   int32_t long_read;      /* long_read_sample: F = 1/L_j (estimate.cpp:236-247)       */
+} sbgpu_insert_t;
+
+/* pdf_out[fl] = InsertSize::emp_dist_pdf(fl) for fl in [0, n) (host arrays).      */
+int sbgpu_insert_pdf_table(const sbgpu_insert_t *ins, int32_t n, double *pdf_out);
+
+/* Device-resident form.  d_pdf[pdf_len] must cover every fragment length up to
+ * the largest sum of a pair's segment lengths.  Asynchronous on `stream`.         */
+int sbgpu_binweight_device(sbgpu_ctx_t *ctx, int64_t n_pairs, const int64_t *d_seg_off,
+                           const uint32_t *d_seg_lens, const uint32_t *d_implicit_mask,
+                           const int32_t *d_iso_len, const int64_t *d_out_index,
+                           const double *d_pdf, int32_t pdf_len, int32_t read_len,
+                           int32_t lmin_base, int32_t long_read, double *d_F, void *stream);
+
+/* Host-buffer convenience form: builds the pdf table, uploads, runs, downloads
+ * weight_out[p] for every pair (out_index is not used), synchronises.            */
+int sbgpu_binweight_host(sbgpu_ctx_t *ctx, int64_t n_pairs, const int64_t *seg_off,
+                         const uint32_t *seg_lens, const uint32_t *implicit_mask,
+                         const int32_t *iso_len, const sbgpu_insert_t *ins, double *weight_out);
+
 #ifdef __cplusplus
 }
 #endif

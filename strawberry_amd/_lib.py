@@ -17,7 +17,8 @@ STATUS_NAMES = {0: "OK", 1: "INIT_EMPTY", 2: "DENOM_ZERO", 3: "MAXITER"}
 SYMBOLS = [
     "sbgpu_version", "sbgpu_last_error", "sbgpu_device_count", "sbgpu_init", "sbgpu_finalize",
     "sbgpu_device_info", "sbgpu_synchronize", "sbgpu_plan_create", "sbgpu_plan_destroy", "sbgpu_plan_info",
-    "sbgpu_plan_classes", "sbgpu_plan_locus_kinds", "sbgpu_em_run_device", "sbgpu_em_last_kernel_ms", "sbgpu_em_batch", "sbgpu_abundance_device", "sbgpu_tpm_device",
+    "sbgpu_plan_classes", "sbgpu_plan_locus_kinds", "sbgpu_em_run_device", "sbgpu_em_last_kernel_ms",
+    "sbgpu_insert_pdf_table", "sbgpu_binweight_device", "sbgpu_binweight_host", "sbgpu_em_batch", "sbgpu_abundance_device", "sbgpu_tpm_device",
 ]
 
 
@@ -44,6 +45,20 @@ class sbgpu_abundance_params_t(C.Structure):
         ("reserved", C.c_int32),
         ("insert_mean", C.c_double),
         ("min_isoform_frac", C.c_double),
+    ]
+
+
+class sbgpu_insert_t(C.Structure):
+    _fields_ = [
+        ("mean", C.c_double),
+        ("sd", C.c_double),
+        ("use_emp", C.c_int32),
+        ("start_offset", C.c_int32),
+        ("end_offset", C.c_int32),
+        ("total_reads", C.c_int32),
+        ("emp_hist", C.POINTER(C.c_double)),
+        ("read_len", C.c_int32),
+        ("long_read", C.c_int32),
     ]
 
 
@@ -91,6 +106,10 @@ def load():
     L.sbgpu_em_batch.argtypes = [vp, C.POINTER(sbgpu_batch_t), vp, vp, vp]
     L.sbgpu_abundance_device.argtypes = [vp, vp, vp, vp, vp, C.POINTER(sbgpu_abundance_params_t), vp, vp, vp, vp, vp]
     L.sbgpu_tpm_device.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp]
+    L.sbgpu_insert_pdf_table.argtypes = [C.POINTER(sbgpu_insert_t), C.c_int32, vp]
+    L.sbgpu_binweight_device.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32,
+                                         C.c_int32, vp, vp]
+    L.sbgpu_binweight_host.argtypes = [vp, C.c_int64, vp, vp, vp, vp, C.POINTER(sbgpu_insert_t), vp]
     for name in SYMBOLS:
         f = getattr(L, name)
         if f.restype is C.c_int and name not in ("sbgpu_device_count", "sbgpu_plan_classes"):

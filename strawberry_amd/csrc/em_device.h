@@ -20,6 +20,8 @@
 
 #include <type_traits>
 
+#include "device_common.h"
+
 namespace sb {
 
 constexpr int kMaxIter = 1000;          // include/estimate.hpp:237
@@ -224,15 +226,6 @@ __device__ __forceinline__ void high_bits_sum(double (&x)[NVAL], int hi)
    SB_STEP(4)
    SB_STEP(5)
 #undef SB_STEP
-}
-
-// fp64 denormals flush to zero inside the EM, like the reference build: it is
-// compiled -Ofast (CMakeLists.txt:84), whose crtfastmath.o sets FTZ/DAZ, and that
-// decides WHEN a decaying theta_j becomes exactly 0 and a row denominator trips
-// the `denom == 0` exit (estimate.cpp:451).  MODE.FP_DENORM[7:6] = 0.
-__device__ __forceinline__ void set_fp64_flush_denormals()
-{
-   __builtin_amdgcn_s_setreg(1 | (6 << 6) | ((2 - 1) << 11), 0);
 }
 
 #ifdef SB_STAMPS

@@ -6,12 +6,14 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <new>
 #include <string>
 #include <vector>
 
 #include "../../include/sbgpu.h"
+#include "binweight_device.h"
 #include "em_device.h"
 #include "plan.h"
 
@@ -617,6 +619,129 @@ int sbgpu_tpm_device(sbgpu_ctx_t *c, int64_t n_iso, const double *d_fpkm, const 
    hipLaunchKernelGGL(tpm_kernel, dim3((unsigned)((n_iso + threads - 1) / threads)), dim3(threads), 0, s, n_iso,
                       d_fpkm, d_keep, d_total_fpkm, d_tpm);
    HIP_TRY(hipGetLastError());
+   return SBGPU_OK;
+}
+
+// ---------------------------------------------------------------- bin-weight model
+int sbgpu_insert_pdf_table(const sbgpu_insert_t *ins, int32_t n, double *pdf_out)
+{
+   if (!ins || (n > 0 && !pdf_out)) return fail(SBGPU_EINVAL, "sbgpu_insert_pdf_table: null argument");
+   if (ins->use_emp && (!ins->emp_hist || ins->end_offset < ins->start_offset || ins->total_reads <= 0))
+      return fail(SBGPU_EINVAL, "sbgpu_insert_pdf_table: malformed empirical insert-size law");
+   // InsertSize::emp_dist_pdf, /root/reference/src/read.cpp:274-297; normal_pdf include/common.h:92-99
+   const double inv_sqrt_2pi = 0.3989422804014327;
+   for (int32_t fl = 0; fl < n; ++fl) {
+      double ret = 0.0;
+      if (ins->use_emp && fl >= ins->start_offset && fl <= ins->end_offset)
+         ret = ins->emp_hist[fl - ins->start_offset] / ins->total_reads;
+      if (ret == 0.0) {
+         const double a = ((double)fl - ins->mean) / ins->sd;
+         const double p = inv_sqrt_2pi / ins->sd * std::exp(-0.5 * a * a);
+         // the reference runs with FTZ/DAZ (-Ofast): a subnormal density is 0 there
+         ret = (p >= 2.2250738585072014e-308) ? p : 0.0;
+      }
+      pdf_out[fl] = ret;
+   }
+   return SBGPU_OK;
+}
+
+int sbgpu_binweight_device(sbgpu_ctx_t *c, int64_t n_pairs, const int64_t *d_seg_off, const uint32_t *d_seg_lens,
+                           const uint32_t *d_implicit_mask, const int32_t *d_iso_len, const int64_t *d_out_index,
+                           const double *d_pdf, int32_t pdf_len, int32_t read_len, int32_t lmin_base,
+                           int32_t long_read, double *d_F, void *stream)
+{
+   if (!c) return fail(SBGPU_EINVAL, "sbgpu_binweight_device: null ctx");
+   if (n_pairs == 0) return SBGPU_OK;
+   if (n_pairs < 0 || n_pairs > INT32_MAX) return fail(SBGPU_EINVAL, "sbgpu_binweight_device: bad n_pairs");
+   if (!d_seg_off || !d_seg_lens || !d_implicit_mask || !d_iso_len || !d_F || (!long_read && !d_pdf))
+      return fail(SBGPU_EINVAL, "sbgpu_binweight_device: null device pointer");
+   hipStream_t s = (hipStream_t)stream;
+   sb::BinWeightArgs a;
+   a.n_pairs = n_pairs;
+   a.seg_off = d_seg_off;
+   a.seg_lens = d_seg_lens;
+   a.implicit_mask = d_implicit_mask;
+   a.iso_len = d_iso_len;
+   a.out_index = d_out_index;
+   a.pdf = d_pdf;
+   a.out = d_F;
+   a.pdf_len = pdf_len;
+   a.read_len = read_len;
+   a.lmin_base = lmin_base;
+   a.long_read = long_read;
+   // one wave per pair; enough waves to fill the chip several times over
+   const int64_t want = n_pairs < (int64_t)c->n_cu * 64 ? n_pairs : (int64_t)c->n_cu * 64;
+   hipLaunchKernelGGL(sb::binweight_kernel, dim3((unsigned)want), dim3(64), 0, s, a);
+   HIP_TRY(hipGetLastError());
+   return SBGPU_OK;
+}
+
+int sbgpu_binweight_host(sbgpu_ctx_t *c, int64_t n_pairs, const int64_t *seg_off, const uint32_t *seg_lens,
+                         const uint32_t *implicit_mask, const int32_t *iso_len, const sbgpu_insert_t *ins,
+                         double *weight_out)
+{
+   if (!c || !ins) return fail(SBGPU_EINVAL, "sbgpu_binweight_host: null argument");
+   if (n_pairs == 0) return SBGPU_OK;
+   if (!seg_off || !seg_lens || !implicit_mask || !iso_len || !weight_out)
+      return fail(SBGPU_EINVAL, "sbgpu_binweight_host: null argument");
+   int64_t max_l = 1;
+   for (int64_t p = 0; p < n_pairs; ++p) {
+      const int64_t ns = seg_off[p + 1] - seg_off[p];
+      if (ns < 1 || ns > sb::kBinWeightMaxSeg)
+         return fail(SBGPU_ESHAPE, "sbgpu_binweight_host: a pair needs 1..32 segments");
+      int64_t l = 0;
+      for (int64_t k = seg_off[p]; k < seg_off[p + 1]; ++k) l += seg_lens[k];
+      if (l > max_l) max_l = l;
+   }
+   if (max_l > (1 << 26)) return fail(SBGPU_ESHAPE, "sbgpu_binweight_host: segment lengths out of range");
+   const int32_t pdf_len = (int32_t)max_l + 1;
+   std::vector<double> pdf((size_t)pdf_len);
+   int rc = sbgpu_insert_pdf_table(ins, pdf_len, pdf.data());
+   if (rc != SBGPU_OK) return rc;
+   const int64_t nseg_total = seg_off[n_pairs];
+   int64_t *d_off = nullptr;
+   uint32_t *d_seg = nullptr, *d_mask = nullptr;
+   int32_t *d_len = nullptr;
+   double *d_pdf = nullptr, *d_out = nullptr;
+   auto cleanup = [&]() {
+      (void)hipFree(d_off);
+      (void)hipFree(d_seg);
+      (void)hipFree(d_mask);
+      (void)hipFree(d_len);
+      (void)hipFree(d_pdf);
+      (void)hipFree(d_out);
+   };
+#define TRY_CLEAN(expr)                                                                       \
+   do {                                                                                       \
+      hipError_t e_ = (expr);                                                                 \
+      if (e_ != hipSuccess) {                                                                 \
+         cleanup();                                                                           \
+         return fail(e_ == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP,                   \
+                     std::string(#expr) + ": " + hipGetErrorString(e_));                      \
+      }                                                                                       \
+   } while (0)
+   TRY_CLEAN(hipMalloc(&d_off, (size_t)(n_pairs + 1) * sizeof(int64_t)));
+   TRY_CLEAN(hipMalloc(&d_seg, (size_t)(nseg_total + 1) * sizeof(uint32_t)));
+   TRY_CLEAN(hipMalloc(&d_mask, (size_t)n_pairs * sizeof(uint32_t)));
+   TRY_CLEAN(hipMalloc(&d_len, (size_t)n_pairs * sizeof(int32_t)));
+   TRY_CLEAN(hipMalloc(&d_pdf, (size_t)pdf_len * sizeof(double)));
+   TRY_CLEAN(hipMalloc(&d_out, (size_t)n_pairs * sizeof(double)));
+   TRY_CLEAN(hipMemcpyAsync(d_off, seg_off, (size_t)(n_pairs + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+   TRY_CLEAN(hipMemcpyAsync(d_seg, seg_lens, (size_t)nseg_total * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+   TRY_CLEAN(hipMemcpyAsync(d_mask, implicit_mask, (size_t)n_pairs * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+   TRY_CLEAN(hipMemcpyAsync(d_len, iso_len, (size_t)n_pairs * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+   TRY_CLEAN(hipMemcpyAsync(d_pdf, pdf.data(), (size_t)pdf_len * sizeof(double), hipMemcpyHostToDevice, c->stream));
+   const int32_t lmin_base = ins->use_emp ? ins->start_offset : ins->read_len;
+   rc = sbgpu_binweight_device(c, n_pairs, d_off, d_seg, d_mask, d_len, nullptr, d_pdf, pdf_len, ins->read_len,
+                               lmin_base, ins->long_read, d_out, c->stream);
+   if (rc != SBGPU_OK) {
+      cleanup();
+      return rc;
+   }
+   TRY_CLEAN(hipMemcpyAsync(weight_out, d_out, (size_t)n_pairs * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+   TRY_CLEAN(hipStreamSynchronize(c->stream));
+#undef TRY_CLEAN
+   cleanup();
    return SBGPU_OK;
 }
 
