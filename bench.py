@@ -97,6 +97,7 @@ def main():
         print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    local_rank = local_rank % torch.cuda.device_count()   # test rigs may run several ranks per GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 

@@ -25,10 +25,11 @@ def init_process_group(backend=None):
     rank, world, local_rank = env_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("SB_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
+            local_rank = local_rank % max(1, torch.cuda.device_count())
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
@@ -54,19 +55,29 @@ def shard_loci(nrow, niso, world_size):
     return [np.nonzero(owner == r)[0].astype(np.int64) for r in range(world_size)]
 
 
+def _allreduce_(tensor, op):
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return tensor
+    if tensor.is_cuda and dist.get_backend() == "gloo":
+        # test rigs only (several ranks sharing one GPU): gloo reduces a host copy
+        host = tensor.cpu()
+        dist.all_reduce(host, op=op)
+        tensor.copy_(host)
+    else:
+        dist.all_reduce(tensor, op=op)
+    return tensor
+
+
 def allreduce_sum_(tensor):
     """In-place all-reduce(sum) over the default group; identity for one process."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
-    return tensor
+    return _allreduce_(tensor, dist.ReduceOp.SUM)
 
 
 def allreduce_max_(tensor):
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(tensor, op=dist.ReduceOp.MAX)
-    return tensor
+    return _allreduce_(tensor, dist.ReduceOp.MAX)
 
 
 def barrier():

@@ -1,0 +1,142 @@
+"""End-to-end golden from the reference BINARY (tests/golden/e2e_toy, made by
+tools/make_e2e_golden.py): annotation -> bins -> weights -> EM -> FPKM/Frac/TPM.
+CPU part: the oracle against the reference's printed outputs.  GPU part (marked): the HIP
+kernels on the same inputs."""
+import numpy as np
+import pytest
+
+import e2e_util as U
+
+RL, MEAN, SD = 75, 250.0, 30.0
+
+
+@pytest.fixture(scope="module")
+def toy():
+    return U.load(U.E2E)
+
+
+@pytest.fixture(scope="module")
+def toy_long():
+    return U.load(U.E2E_LONG)
+
+
+def pairs_from_ctx(genes, rows):
+    """Every (bin, isoform) weight the reference printed, with the kernel inputs we derive."""
+    out = []
+    cache = {}
+    for r in rows:
+        g = r["gene"]
+        if g not in cache:
+            tx = genes[g]
+            segs = U.disjoint_segments([e for _, ex in tx for e in ex])
+            cache[g] = [(t, U.isoform_segments(segs, ex), sum(b - a + 1 for a, b in ex)) for t, ex in tx]
+        for j, (t, iso_segs, L) in enumerate(cache[g]):
+            assert r["transcripts"][j] == t
+            if r["F"][j] == 0.0:
+                continue
+            bu = U.bin_under_iso(r["coords"], iso_segs)
+            assert bu is not None, (g, t, r["coords"])
+            out.append((bu[0], bu[1], L, r["F"][j]))
+    return out
+
+
+def test_bin_weights_match_reference_context_table(toy, oracle):
+    """A4 end to end: disjoint segments + bin_under_iso + effective_len + pdf + sum reproduce
+    every nonzero weight of the reference's -f table (12 significant digits)."""
+    genes, rows, _, _ = toy
+    pairs = pairs_from_ctx(genes, rows)
+    assert len(pairs) > 150
+    ins = oracle.make_insert(MEAN, SD)
+    worst = 0.0
+    for segs, imp, L, ref in pairs:
+        w = oracle.bin_weight(segs, imp, L, RL, ins)
+        worst = max(worst, abs(w - ref) / ref)
+    assert worst < 5e-11, worst
+    assert max(len(p[0]) for p in pairs) >= 5  # the brute-force >= 5-segment branch is exercised
+
+
+def locus_inputs(rows, gene):
+    rs = [r for r in rows if r["gene"] == gene]
+    n = np.array([r["count"] for r in rs], np.int32)
+    F = np.array([r["F"] for r in rs], np.float64)
+    return n, F
+
+
+def test_em_reproduces_reference_theta_log(toy_long, oracle):
+    """A1/A2 end to end: the -f table's bins (count, weights at 12 digits) through the EM give
+    the theta the reference logged (`isoform k has %f raw read count`, src/estimate.cpp:312).
+    Uses the long-exon toy: there a bin's fragments all share one isoform compatibility, so the
+    table (which prints the weights seen by the LAST fragment of a bin, alignments.cpp:1556-1563)
+    is the complete EM input; fragments are unique, so the bin count equals n_i."""
+    genes, rows, _, theta_log = toy_long
+    assert len(theta_log) == len(genes)
+    long_run = 0
+    for (g, tx), ref_theta in zip(genes.items(), theta_log):
+        n, F = locus_inputs(rows, g)
+        theta, status, iters = oracle.em_locus(n, F)
+        assert status in (0, 3)
+        assert np.abs(theta - np.array(ref_theta)).max() < 1e-6, (g, theta, ref_theta)
+        long_run = max(long_run, iters)
+    assert long_run > 200  # a slowly converging locus is part of the fixture
+
+
+def test_abundance_and_tpm_reproduce_reference_gtf(toy_long, oracle):
+    """A3/A7/A9: theta (as logged, 6 decimals) -> FPKM/Frac/TPM agree with the GTF attributes to
+    the precision theta was logged with; Frac and TPM each sum to 1 / 1e6."""
+    genes, rows, gtf, theta_log = toy_long
+    total_mapped = rows[0]["total_mapped"]
+    fpkm_all, keep_all, names = [], [], []
+    for (g, tx), th in zip(genes.items(), theta_log):
+        length = [sum(b - a + 1 for a, b in ex) for _, ex in tx]
+        fpkm, frac, keep, _ = oracle.abundance_locus(th, length, total_mapped, min_isoform_frac=0.0)  # -r
+        for (t, _), f, fr in zip(tx, fpkm, frac):
+            ref_f, ref_fr, _ = gtf[t]
+            assert abs(f - float(ref_f)) <= 2e-6 * max(1.0, abs(f)) * 10, (t, f, ref_f)
+            assert abs(fr - float(ref_fr)) < 2e-6, (t, fr, ref_fr)
+            names.append(t)
+        fpkm_all += list(fpkm)
+        keep_all += list(keep)
+    tpm, _ = oracle.tpm(np.array(fpkm_all), np.array(keep_all, np.int32))
+    for t, v in zip(names, tpm):
+        assert abs(v - float(gtf[t][2])) <= 2e-5 * max(1.0, v), (t, v, gtf[t][2])
+    assert abs(tpm.sum() - 1e6) < 1e-3
+    # the GTF strings are the first 11 characters of to_string() (contig.cpp:678-700)
+    assert all(len(s) <= 11 for v in gtf.values() for s in v)
+
+
+@pytest.mark.gpu
+def test_gpu_pipeline_on_the_reference_toy(toy, toy_long, oracle):
+    """The HIP path on the same toy: bin-weight kernel vs the reference's table, then EM +
+    epilogue + TPM vs the reference's log / GTF."""
+    from strawberry_amd import em, synth
+    from strawberry_amd.binweight import InsertSize, bin_weights, pack_pairs
+    genes, rows, gtf, theta_log = toy
+    ctx = em.default_context(0)
+    pairs = pairs_from_ctx(genes, rows)
+    seg_off, seg_lens, mask = pack_pairs([p[0] for p in pairs], [p[1] for p in pairs])
+    w = bin_weights(seg_off, seg_lens, mask, [p[2] for p in pairs], InsertSize(MEAN, SD), RL, ctx=ctx)
+    ref = np.array([p[3] for p in pairs])
+    assert (np.abs(w - ref) / ref).max() < 5e-11
+    genes, rows, gtf, theta_log = toy_long
+    loci, lengths = [], []
+    for g, tx in genes.items():
+        loci.append(locus_inputs(rows, g))
+        lengths.append([sum(b - a + 1 for a, b in ex) for _, ex in tx])
+    b = synth.from_loci(loci, lengths)
+    s = em.EmBatchSolver(b, ctx)
+    s.run_em()
+    s.run_abundance(rows[0]["total_mapped"], min_isoform_frac=0.0)
+    s.run_tpm()
+    r = s.results()
+    for l, ref_theta in enumerate(theta_log):
+        th = r["theta"][b.iso_off[l]:b.iso_off[l + 1]]
+        assert np.abs(th - np.array(ref_theta)).max() < 1e-6
+    names = [t for _, tx in genes.items() for t, _ in tx]
+    for t, f, fr, tp in zip(names, r["fpkm"], r["frac"], r["tpm"]):
+        assert abs(f - float(gtf[t][0])) <= 1e-5 * max(1.0, f)
+        assert abs(fr - float(gtf[t][1])) < 2e-6
+        assert abs(tp - float(gtf[t][2])) <= 1e-5 * max(1.0, tp)
+    o_theta, o_status, o_iters = oracle.em_batch(b.row_off, b.iso_off, b.f_off, b.count, b.F)
+    np.testing.assert_array_equal(r["iters"], o_iters)
+    assert (np.abs(r["theta"] - o_theta) / np.maximum(np.abs(o_theta), 1e-9)).max() < 1e-9
+    assert abs(r["tpm"].sum() - 1e6) < 1e-3

@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""End-to-end golden from the REFERENCE BINARY (config C1 plumbing, SURVEY 8(c) `e2e_toy`).
+
+Runs only where /root/reference is mounted: builds oracle/_ref (the reference program
+compiled from its own sources, plus our sam2bam), simulates paired-end reads over a small
+synthetic annotation, runs
+
+    strawberry_ref toy.bam -g toy.gtf -r -i 250/30 -o out.gtf -T log.txt -f ctx.tsv
+
+and commits ONLY data: the annotation we wrote, and the reference's outputs (GTF attributes,
+theta log lines, the -f context table).  The SAM/BAM are regenerable and not committed.
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import build  # noqa: E402
+from oracle.lib import REF_BIN, SAM2BAM  # noqa: E402
+
+RL = 75
+MEAN, SD = 250.0, 30.0
+
+
+def make_annotation(rng, n_genes, ex_lo=60, ex_hi=400):
+    genes = []
+    pos = 1000
+    for g in range(n_genes):
+        n_ex = int(rng.integers(4, 9))
+        exons = []
+        for _ in range(n_ex):
+            ln = int(rng.integers(ex_lo, ex_hi))
+            exons.append((pos, pos + ln - 1))
+            pos += ln + int(rng.integers(80, 600))
+        n_iso = int(rng.integers(2, 5))
+        isos = [list(range(n_ex))]
+        tries = 0
+        while len(isos) < n_iso and tries < 50:
+            tries += 1
+            keep = [0] + [k for k in range(1, n_ex - 1) if rng.random() < 0.6] + [n_ex - 1]
+            if keep not in isos and len(keep) >= 2:
+                isos.append(keep)
+        genes.append({"id": "G%d" % (g + 1), "exons": exons, "isos": isos})
+        pos += 5000
+    return genes, pos + 1000
+
+
+def write_gtf(genes, path):
+    with open(path, "w") as f:
+        for g in genes:
+            for t, iso in enumerate(g["isos"]):
+                tid = "%s.%d" % (g["id"], t + 1)
+                ex = [g["exons"][k] for k in iso]
+                attr = 'gene_id "%s"; transcript_id "%s";' % (g["id"], tid)
+                f.write("chr1\tsynth\ttranscript\t%d\t%d\t.\t+\t.\t%s\n" % (ex[0][0], ex[-1][1], attr))
+                for (a, b) in ex:
+                    f.write("chr1\tsynth\texon\t%d\t%d\t.\t+\t.\t%s\n" % (a, b, attr))
+
+
+def tx_to_genome(ex, t0, t1):
+    """transcript interval [t0, t1) -> list of genomic blocks [(start, end)] (1-based closed)."""
+    blocks = []
+    off = 0
+    for (a, b) in ex:
+        ln = b - a + 1
+        lo, hi = max(t0, off), min(t1, off + ln)
+        if lo < hi:
+            blocks.append((a + lo - off, a + hi - off - 1))
+        off += ln
+    return blocks
+
+
+def cigar(blocks):
+    s = ""
+    for k, (a, b) in enumerate(blocks):
+        if k:
+            s += "%dN" % (a - blocks[k - 1][1] - 1)
+        s += "%dM" % (b - a + 1)
+    return s
+
+
+def simulate(rng, genes, frags_per_gene):
+    recs = []
+    seen = set()
+    rid = 0
+    for g in genes:
+        w = rng.dirichlet(np.ones(len(g["isos"])) * 0.8)
+        for _ in range(frags_per_gene):
+            t = int(rng.choice(len(g["isos"]), p=w))
+            ex = [g["exons"][k] for k in g["isos"][t]]
+            L = sum(b - a + 1 for a, b in ex)
+            fl = int(np.clip(np.rint(rng.normal(MEAN, SD)), 2 * RL + 1, L))
+            if fl > L:
+                continue
+            st = int(rng.integers(0, L - fl + 1))
+            left = tx_to_genome(ex, st, st + RL)
+            right = tx_to_genome(ex, st + fl - RL, st + fl)
+            sig = (tuple(left), tuple(right))
+            if sig in seen:     # no duplicate fragments: bin counts then equal uniq-hit counts
+                continue
+            seen.add(sig)
+            rid += 1
+            name = "r%06d" % rid
+            tlen = right[-1][1] - left[0][0] + 1
+            recs.append((left[0][0], "%s\t99\tchr1\t%d\t255\t%s\t=\t%d\t%d\t%s\t%s\tNH:i:1\tXS:A:+" % (
+                name, left[0][0], cigar(left), right[0][0], tlen, "A" * RL, "I" * RL)))
+            recs.append((right[0][0], "%s\t147\tchr1\t%d\t255\t%s\t=\t%d\t%d\t%s\t%s\tNH:i:1\tXS:A:+" % (
+                name, right[0][0], cigar(right), left[0][0], -tlen, "A" * RL, "I" * RL)))
+    recs.sort(key=lambda r: r[0])
+    return recs
+
+
+def main():
+    build(with_ref=True)
+    # e2e_toy: short exons -- bins spanning many segments, implicit (mate-gap) segments: pins the
+    #          bin-weight model.  e2e_toy_long: every exon longer than any mate gap, so a bin's
+    #          fragments all have the same isoform compatibility and the -f table shows the full
+    #          EM input: pins EmSolver / FPKM / TPM end to end.
+    make("e2e_toy", 4242, 60, 400)
+    make("e2e_toy_long", 4343, 420, 900)
+
+
+def make(name, seed, ex_lo, ex_hi):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    genes, chrom_len = make_annotation(rng, 6, ex_lo, ex_hi)
+    out_dir = os.path.join(ROOT, "tests", "golden", name)
+    os.makedirs(out_dir, exist_ok=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        gtf = os.path.join(tmp, "toy.gtf")
+        write_gtf(genes, gtf)
+        recs = simulate(rng, genes, 900)
+        sam = os.path.join(tmp, "toy.sam")
+        with open(sam, "w") as f:
+            f.write("@HD\tVN:1.0\tSO:coordinate\n@SQ\tSN:chr1\tLN:%d\n" % chrom_len)
+            for _, line in recs:
+                f.write(line + "\n")
+        bam = os.path.join(tmp, "toy.bam")
+        subprocess.check_call([SAM2BAM, sam, bam])
+        cmd = [REF_BIN, bam, "-g", gtf, "-r", "-i", "%d/%d" % (MEAN, SD), "-o", os.path.join(tmp, "out.gtf"),
+               "-T", os.path.join(tmp, "log.txt"), "-f", os.path.join(tmp, "ctx.tsv")]
+        r = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True)
+        print(r.stdout[-2000:])
+        print(r.stderr[-3000:])
+        r.check_returncode()
+        for name in ("toy.gtf", "out.gtf", "ctx.tsv"):
+            data = open(os.path.join(tmp, name)).read()
+            open(os.path.join(out_dir, name), "w").write(data)
+        with open(os.path.join(out_dir, "theta_log.txt"), "w") as f:
+            for line in open(os.path.join(tmp, "log.txt")):
+                if "raw read count" in line or "not compatible" in line:
+                    f.write(line)
+        with open(os.path.join(out_dir, "README.txt"), "w") as f:
+            f.write("Generated by tools/make_e2e_golden.py from the reference binary (oracle/_ref/strawberry_ref):\n"
+                    "  %s\n"
+                    "toy.gtf is our synthetic annotation; out.gtf, ctx.tsv and theta_log.txt are the reference's outputs.\n"
+                    "%d read records, read length %d, insert size -i %d/%d (Gaussian), %d genes.\n" % (
+                        " ".join(os.path.basename(c) if c.startswith("/") else c for c in cmd), len(recs), RL, MEAN, SD,
+                        len(genes)))
+    for name in sorted(os.listdir(out_dir)):
+        print(name, os.path.getsize(os.path.join(out_dir, name)))
+
+
+if __name__ == "__main__":
+    main()
