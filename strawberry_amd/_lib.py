@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libsbgpu.so")
+LIB_PATH = os.environ.get("SBGPU_LIB") or os.path.join(HERE, "lib", "libsbgpu.so")  # SBGPU_LIB: A/B builds
 
 SBGPU_OK = 0
 EM_OK, EM_INIT_EMPTY, EM_DENOM_ZERO, EM_MAXITER = 0, 1, 2, 3

@@ -234,7 +234,7 @@ __device__ __forceinline__ void high_bits_sum(double (&x)[NVAL], int hi)
 // batches, iterations, refill cycles total, events cycles total}
 constexpr int kStampWaves = 1 << 16;
 __device__ unsigned long long sb_debug_stamps[kStampWaves * 8];
-__device__ __forceinline__ unsigned long long sb_now() { return __builtin_readcyclecounter(); }
+__device__ __forceinline__ unsigned long long sb_now() { return __builtin_amdgcn_s_memrealtime(); } // 100 MHz, device-wide
 #endif
 
 constexpr int kBlockWaves = 4; // block form: 256 lanes, one wave per SIMD, up to 512 VGPRs each
@@ -248,7 +248,7 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
    constexpr bool BLOCK = NWAVES > 0;
    constexpr int NW = BLOCK ? NWAVES : 1;                  // waves per group
    constexpr int LB_CL = ilog2(CL);
-   constexpr int NV = CPL + 1; // values in the per-iteration column reduce
+   constexpr int NV = BLOCK ? CPL + 1 : CPL; // values in the per-iteration column reduce (+ zero flag)
    const int lane = threadIdx.x & 63;
    const int wave_id = threadIdx.x >> 6;
    const int GW = BLOCK ? 64 : (1 << lbG);                 // lanes of the group inside one wave
@@ -455,16 +455,20 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
 
       // ------------------------------------------------------ steady-state loop
       // Runs until some group of the wave needs attention (first iteration's
-      // column normalisation, convergence, zero denominator, iteration cap).
-      // F is read-only in here.
-      double nt[NV]; // [0, CPL): next_theta of the own columns; [CPL]: zero-denominator flag
+      // column normalisation, convergence, zero denominator, iteration limit).
+      // F is read-only in here and nothing touches memory.  Two iterations per
+      // trip, theta ping-ponging between `theta` and `nt`, so that no copy or
+      // select sits on the per-iteration path.
+      double nt[NV]; // [0, CPL): next_theta of the own columns; block form [CPL]: zero-denominator flag
       bool dz, conv, special;
-      do {
+      // one EM iteration: reads tin, writes tout (all lanes, no predication)
+      auto iterate = [&](const double *tin, double *tout) {
+         double acc[NV];
 #pragma unroll
-         for (int v = 0; v < NV; ++v) nt[v] = 0.0;
+         for (int v = 0; v < NV; ++v) acc[v] = 0.0;
          double phi[CPL]; // theta of the column-normalised problem seen through the raw F
 #pragma unroll
-         for (int jj = 0; jj < CPL; ++jj) phi[jj] = theta[jj] * scale[jj];
+         for (int jj = 0; jj < CPL; ++jj) phi[jj] = tin[jj] * scale[jj];
          int zero_flag = 0;
          // rows in blocks of 4 to bound the live temporaries
 #pragma unroll
@@ -474,10 +478,10 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                if (rb + q < R) {
-                  double s = 0.0;
+                  double sum = 0.0;
 #pragma unroll
-                  for (int jj = 0; jj < CPL; ++jj) s = __builtin_fma(F[rb + q][jj], phi[jj], s); // :450
-                  d[q] = low_bits_sum<LB_CL>(s);
+                  for (int jj = 0; jj < CPL; ++jj) sum = __builtin_fma(F[rb + q][jj], phi[jj], sum); // :450
+                  d[q] = low_bits_sum<LB_CL>(sum);
                }
             }
 #pragma unroll
@@ -488,37 +492,62 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
                   double w = fast_div(nn[r], d[q]);
                   w = act[r] ? w : 0.0;
 #pragma unroll
-                  for (int jj = 0; jj < CPL; ++jj) nt[jj] = __builtin_fma(w, F[r][jj], nt[jj]);
+                  for (int jj = 0; jj < CPL; ++jj) acc[jj] = __builtin_fma(w, F[r][jj], acc[jj]);
                }
             }
          }
-         nt[CPL] = (double)zero_flag;
-         row_lane_sum(nt, std::integral_constant<int, NV>());
-         dz = nt[CPL] != 0.0;
+         if (BLOCK) {
+            acc[NV - 1] = (double)zero_flag;
+            row_lane_sum(acc, std::integral_constant<int, NV>());
+            dz = acc[NV - 1] != 0.0;
+         } else {
+            row_lane_sum(acc, std::integral_constant<int, NV>());
+            // any zero denominator in the group: one ballot instead of a reduced value
+            const unsigned long long m = __ballot(zero_flag != 0);
+            const unsigned long long gm = (GW >= 64) ? ~0ull : (((1ull << GW) - 1ull) << (lane & ~(GW - 1)));
+            dz = (m & gm) != 0ull;
+         }
          double p2 = 0.0;
 #pragma unroll
          for (int jj = 0; jj < CPL; ++jj) {
-            nt[jj] = phi[jj] * nt[jj]; // next_theta_j = sum_i U_ij, :454-464
-            const double df = nt[jj] - theta[jj];
+            const double t = phi[jj] * acc[jj]; // next_theta_j = sum_i U_ij, :454-464
+            const double df = t - tin[jj];
             p2 = __builtin_fma(df, df, p2); // :479
+            tout[jj] = t;
          }
          const double d2 = low_bits_sum<LB_CL>(p2);
          // ||next - theta||_2 < 1e-2 (:479-480) tested on the squares: sqrt is monotone, so
          // the two tests can only differ for d2 within an ulp of 1e-4
          conv = d2 < kThetaLimit * kThetaLimit;
          special = have && (dz || conv || it == 0 || it + 1 == cls.it_limit);
-         if (have && !special) {
+      };
+      for (;;) {
+         iterate(theta, nt); // old in theta, new in nt
+         if (BLOCK ? special : __any(special)) {
+            // groups that simply finished an iteration move on (:481); the special ones keep
+            // (old, new) = (theta, nt) for the event handling below
+            const bool adv = have && !special;
 #pragma unroll
-            for (int jj = 0; jj < CPL; ++jj) theta[jj] = nt[jj]; // :481
-            ++it;
+            for (int jj = 0; jj < CPL; ++jj) theta[jj] = adv ? nt[jj] : theta[jj];
+            it += adv ? 1 : 0;
+            break;
          }
-#ifdef SB_STAMPS
-         st_iters += 1;
-#endif
-      } while (BLOCK ? !special : !__any(special));
-#ifdef SB_STAMPS
-      st_t = sb_now();
-#endif
+         ++it;
+         iterate(nt, theta); // old in nt, new in theta
+         if (BLOCK ? special : __any(special)) {
+            // special groups: bring (old, new) back to (theta, nt); the others already hold
+            // their new theta in `theta`
+#pragma unroll
+            for (int jj = 0; jj < CPL; ++jj) {
+               const double o = nt[jj], n2 = theta[jj];
+               theta[jj] = special ? o : n2;
+               nt[jj] = special ? n2 : o;
+            }
+            it += (have && !special) ? 1 : 0;
+            break;
+         }
+         ++it;
+      }
 
       // ------------------------------------------------------- per-group events
       // first iteration done: switch to the column-normalised problem (:466-478)
@@ -596,12 +625,18 @@ struct ClassDesc {
 };
 constexpr int kLayouts = 6; // (CPL, CL): (2,1) (4,1) (8,1) (8,2) (8,4) (8,8)
 
-// Register budgets: the wave form asks for 3 (rows multiplier 1) or 2 (multiplier 2)
-// waves per SIMD, so that a whole human-scale batch is resident in one round; the
-// block form runs one wave per SIMD with all 512 VGPRs.
+// Register budgets (waves per SIMD the wave form asks for, by rows multiplier); the block
+// form runs one wave per SIMD.  Forcing more waves than the body's natural register use
+// admits puts spills on the per-iteration path, which costs more than the occupancy buys.
+#ifndef SB_WAVE1_OCC
+#define SB_WAVE1_OCC 2
+#endif
+#ifndef SB_WAVE2_OCC
+#define SB_WAVE2_OCC 2
+#endif
 template <int NWAVES, int RMULT>
 __global__ __launch_bounds__(NWAVES > 0 ? 64 * NWAVES : 64,
-                              NWAVES > 0 ? 1 : (RMULT == 1 ? 3 : 2)) void em_fused_kernel(
+                              NWAVES > 0 ? 1 : (RMULT == 1 ? SB_WAVE1_OCC : SB_WAVE2_OCC)) void em_fused_kernel(
    EmArgs a, const ClassDesc *table, int n_classes, const int32_t *lists_in, const int32_t *n_in,
    int32_t *cursors, int32_t *lists_out, int32_t *n_out, int it_limit, int resume)
 {

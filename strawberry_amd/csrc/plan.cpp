@@ -171,9 +171,11 @@ int build_host_plan(int64_t n_loci, const int64_t *row_off, const int64_t *iso_o
    for (auto &kv : by_key) p.classes.push_back(std::move(kv.second));
    std::stable_sort(p.classes.begin(), p.classes.end(), [](const SizeClass &x, const SizeClass &y) {
       if (x.kind != y.kind) return x.kind < y.kind;
-      // lowest block indices are dispatched first.  A wave lives as long as the slowest
-      // of its 64/G loci, so the classes with the most loci per wave go first.
-      if (x.G != y.G) return x.G < y.G;
+      // Lowest block indices are dispatched first.  The makespan is set by the loci that run
+      // all 1000 iterations, and an iteration costs more the more lanes (and column lanes) a
+      // locus spans: those classes go first, the many short narrow ones fill in behind.
+      const int cx = x.lbG + 2 * x.layout, cy = y.lbG + 2 * y.layout;
+      if (cx != cy) return cx > cy;
       return x.work > y.work;
    });
    return SBGPU_OK;

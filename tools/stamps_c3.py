@@ -25,7 +25,7 @@ L.sbgpu_debug_read_stamps.argtypes = [C.c_void_p, C.c_size_t]
 assert L.sbgpu_debug_read_stamps(buf.ctypes.data, buf.nbytes) == 0
 st = buf.reshape(-1, 8)[:nw].astype(np.float64)
 t0 = st[:, 0].min()
-def us(x): return x / 100.0   # the cycle counter ticks at 100 MHz
+def us(x): return x / 100.0   # s_memrealtime ticks at 100 MHz
 print("waves", nw)
 print("start spread us: min %.1f med %.1f max %.1f" % (us(st[:,0].min()-t0), us(np.median(st[:,0])-t0), us(st[:,0].max()-t0)))
 print("lookup us: med %.2f max %.2f" % (us(np.median(st[:,1]-st[:,0])), us((st[:,1]-st[:,0]).max())))
@@ -37,6 +37,10 @@ life = us(st[:,3]-st[:,0])
 upi = life/np.maximum(st[:,5],1)
 print("life us: med %.1f max %.1f ; us/iter med %.3f p90 %.3f max %.3f" % (np.median(life), life.max(), np.median(upi), np.percentile(upi,90), upi.max()))
 off = 0
+print("waves still alive at t (us):", {t: int(((us(st[:,0]-t0) <= t) & (us(st[:,3]-t0) > t)).sum()) for t in (50,100,200,400,600,800,1000,1200,1400,1600,1800)})
+print("waves not yet started at t:", {t: int((us(st[:,0]-t0) > t).sum()) for t in (50,100,200,400,600,800,1000)})
+long = st[:,5] >= 900
+print("long waves (>=900 iters): %d ; their start us: med %.0f p90 %.0f max %.0f ; life med %.0f max %.0f" % (long.sum(), np.median(us(st[long,0]-t0)), np.percentile(us(st[long,0]-t0),90), us(st[long,0]-t0).max(), np.median(us(st[long,3]-st[long,0])), us(st[long,3]-st[long,0]).max()))
 for c in s.plan.classes():
     n = c["n_waves"]; x = st[off:off+n]; off += n
     lf = us(x[:,3]-x[:,0])
