@@ -117,7 +117,7 @@ def main():
     torch.cuda.synchronize(dev)
 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    kern_ms = np.zeros(5)
+    kern_ms = np.zeros(6)
     t0 = time.perf_counter()
     ev[0].record()
     for _ in range(args.steps):
@@ -146,9 +146,9 @@ def main():
 
     # ---- roofline of the dominant EM kernel (this rank's batch)
     kinds = solver.plan.locus_kinds()
-    kind_names = ["em_fused_kernel<0,1> (wave form)", "em_fused_kernel<0,2> (wave form, 2x rows/lane)",
-                  "em_fused_kernel<4,2> (256-lane block form)", "em_fused_kernel<4,6> (256-lane block form, tall tile)",
-                  "em_stream_kernel"]
+    kind_names = ["em_fused_kernel<0,1> (wave form, half tile)", "em_fused_kernel<0,2> (wave form, base tile)",
+                  "em_fused_kernel<0,4> (wave form, double tile)", "em_fused_kernel<4,4> (256-lane block form)",
+                  "em_fused_kernel<4,12> (256-lane block form, tall tile)", "em_stream_kernel"]
     dom = int(np.argmax(kern_ms))
     sel = kinds == dom
     nrow, niso = batch.nrow, batch.niso
@@ -165,7 +165,7 @@ def main():
         "fp64_valu": {"achieved": float(fl_locus[sel].sum()) / dom_s / 1e12, "peak": FP64_VALU_PEAK_TF,
                       "unit": "TFLOP/s", "frac": float(fl_locus[sel].sum()) / dom_s / 1e12 / FP64_VALU_PEAK_TF,
                       "algorithmic_flops": int(fl_locus[sel].sum())},
-        "all_kernels_ms": {kind_names[k]: float(kern_ms[k]) for k in range(5) if kern_ms[k] > 0},
+        "all_kernels_ms": {kind_names[k]: float(kern_ms[k]) for k in range(6) if kern_ms[k] > 0},
         "whole_batch": {"achieved": float(b_locus.sum()) / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
                         "frac": float(b_locus.sum()) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
     }

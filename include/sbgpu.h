@@ -119,8 +119,8 @@ int sbgpu_plan_info(const sbgpu_plan_t *plan, int64_t out[8]);
  * {kind (0 tile,1 stream), C, R, G, n_loci, n_waves}.  Returns #classes.          */
 int sbgpu_plan_classes(const sbgpu_plan_t *plan, int64_t *out, int cap);
 
-/* Which kernel serves each locus: out[l] = 0/1 wave kinds, 2 block, 3 tall block,
- * 4 streaming kind (profiling / roofline accounting only).                        */
+/* Which kernel serves each locus: out[l] = 0/1/2 wave kinds (half/base/double tile),
+ * 3 block, 4 tall block, 5 streaming kind (profiling / roofline accounting only).  */
 int sbgpu_plan_locus_kinds(const sbgpu_plan_t *plan, int8_t *out);
 
 /* ---- the hot path: EmSolver::init + run for every locus of the plan ----------
@@ -137,9 +137,9 @@ int sbgpu_em_run_device(sbgpu_ctx_t *ctx, const sbgpu_plan_t *plan,
 
 /* Device time of the last sbgpu_em_run_device per kernel kind (HIP events recorded
  * on the stream each kind was launched on, all phases of the kind included):
- * ms[5] = {wave (1x rows), wave (2x rows), block, tall block, stream}, 0 for kinds
- * not launched.  Synchronises with those events.                                 */
-int sbgpu_em_last_kernel_ms(sbgpu_ctx_t *ctx, float ms[5]);
+ * ms[6] = {wave half tile, wave base tile, wave double tile, block, tall block,
+ * stream}, 0 for kinds not launched.  Synchronises with those events.            */
+int sbgpu_em_last_kernel_ms(sbgpu_ctx_t *ctx, float ms[6]);
 
 /* Host-buffer convenience form (what a cgo/JNI/ctypes or the C++ driver binds
  * first): plans, uploads, solves, downloads, synchronises.                      */

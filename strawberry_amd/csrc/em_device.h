@@ -625,18 +625,23 @@ struct ClassDesc {
 };
 constexpr int kLayouts = 6; // (CPL, CL): (2,1) (4,1) (8,1) (8,2) (8,4) (8,8)
 
-// Register budgets (waves per SIMD the wave form asks for, by rows multiplier); the block
-// form runs one wave per SIMD.  Forcing more waves than the body's natural register use
-// admits puts spills on the per-iteration path, which costs more than the occupancy buys.
+// RH = rows per row lane in units of HALF the base tile (base: 8 rows for 2/4 columns per
+// lane, 4 rows for 8): 1 = half tile (shortest iteration, most lanes per locus), 2 = base,
+// 4 = double, 12 = the tall block tile.  Register budgets (waves per SIMD asked for): forcing
+// more waves than the body's natural register use admits puts spills on the per-iteration
+// path, which costs more than the occupancy buys.
+#ifndef SB_WAVEH_OCC
+#define SB_WAVEH_OCC 3
+#endif
 #ifndef SB_WAVE1_OCC
 #define SB_WAVE1_OCC 2
 #endif
 #ifndef SB_WAVE2_OCC
 #define SB_WAVE2_OCC 2
 #endif
-template <int NWAVES, int RMULT>
+template <int NWAVES, int RH>
 __global__ __launch_bounds__(NWAVES > 0 ? 64 * NWAVES : 64,
-                              NWAVES > 0 ? 1 : (RMULT == 1 ? SB_WAVE1_OCC : SB_WAVE2_OCC)) void em_fused_kernel(
+                              NWAVES > 0 ? 1 : (RH == 1 ? SB_WAVEH_OCC : (RH == 2 ? SB_WAVE1_OCC : SB_WAVE2_OCC))) void em_fused_kernel(
    EmArgs a, const ClassDesc *table, int n_classes, const int32_t *lists_in, const int32_t *n_in,
    int32_t *cursors, int32_t *lists_out, int32_t *n_out, int it_limit, int resume)
 {
@@ -671,12 +676,12 @@ __global__ __launch_bounds__(NWAVES > 0 ? 64 * NWAVES : 64,
    const int layout = d.shape & 0xFF;
    const int lbG = (d.shape >> 16) & 0xFF;
    switch (layout) {
-   case 0: em_tile_body<2, 1, 8 * RMULT, NWAVES>(a, cls, lbG, s_red, &s_idx); break;
-   case 1: em_tile_body<4, 1, 8 * RMULT, NWAVES>(a, cls, lbG, s_red, &s_idx); break;
-   case 2: em_tile_body<8, 1, 4 * RMULT, NWAVES>(a, cls, lbG, s_red, &s_idx); break;
-   case 3: em_tile_body<8, 2, 4 * RMULT, NWAVES>(a, cls, lbG, s_red, &s_idx); break;
-   case 4: em_tile_body<8, 4, 4 * RMULT, NWAVES>(a, cls, lbG, s_red, &s_idx); break;
-   default: em_tile_body<8, 8, 4 * RMULT, NWAVES>(a, cls, lbG, s_red, &s_idx); break;
+   case 0: em_tile_body<2, 1, 4 * RH, NWAVES>(a, cls, lbG, s_red, &s_idx); break;
+   case 1: em_tile_body<4, 1, 4 * RH, NWAVES>(a, cls, lbG, s_red, &s_idx); break;
+   case 2: em_tile_body<8, 1, 2 * RH, NWAVES>(a, cls, lbG, s_red, &s_idx); break;
+   case 3: em_tile_body<8, 2, 2 * RH, NWAVES>(a, cls, lbG, s_red, &s_idx); break;
+   case 4: em_tile_body<8, 4, 2 * RH, NWAVES>(a, cls, lbG, s_red, &s_idx); break;
+   default: em_tile_body<8, 8, 2 * RH, NWAVES>(a, cls, lbG, s_red, &s_idx); break;
    }
 }
 

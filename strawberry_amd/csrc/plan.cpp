@@ -44,8 +44,8 @@ int build_host_plan(int64_t n_loci, const int64_t *row_off, const int64_t *iso_o
       return SBGPU_EINVAL;
    }
 
-   // pass 1: validate, decide the wave-kind rows-per-lane multiplier from the load
-   int64_t wave_lanes_r1 = 0; // lanes the wave kind would occupy at rmult 1
+   // pass 1: validate, decide the wave-kind tile height from the load
+   int64_t wave_lanes_base = 0; // lanes the wave kind would occupy with the base tile (rh 2)
    for (int64_t l = 0; l < n_loci; ++l) {
       const int64_t nrow = row_off[l + 1] - row_off[l];
       const int64_t niso = iso_off[l + 1] - iso_off[l];
@@ -63,17 +63,18 @@ int build_host_plan(int64_t n_loci, const int64_t *row_off, const int64_t *iso_o
          const int CPL = std::min(C, 8), CL = C / CPL;
          int R = 4;
          for (int i = 0; i < kNumLayouts; ++i)
-            if (kLayoutCPL[i] == CPL && kLayoutCL[i] == CL) R = kLayoutR[i];
+            if (kLayoutCPL[i] == CPL && kLayoutCL[i] == CL) R = 2 * kLayoutRHalf[i];
          const int64_t lanes = (int64_t)pow2ceil(std::max<int64_t>(1, (nrow + R - 1) / R)) * CL;
-         if (lanes <= 64) wave_lanes_r1 += lanes;
+         if (lanes <= 64) wave_lanes_base += lanes;
       }
    }
    const int64_t simd_lanes = (int64_t)n_cu * 4 * 64;
    int wave_rmult = tune.wave_rmult;
-   if (wave_rmult != 1 && wave_rmult != 2) {
-      // one wave per SIMD keeps every iteration at full issue rate: fold rows
-      // (fewer, longer lanes) once the short-lane layout would oversubscribe the chip
-      wave_rmult = (wave_lanes_r1 > 2 * simd_lanes) ? 2 : 1;
+   if (wave_rmult != 1 && wave_rmult != 2 && wave_rmult != 4) {
+      // Base tile while the batch fits the two waves per SIMD its register budget admits,
+      // double tile (half the lanes per locus) beyond that.  The half tile (SBGPU_WAVE_RMULT=1)
+      // doubles the lanes for a ~10 % shorter iteration: measured no better on C2, worse on C3.
+      wave_rmult = (wave_lanes_base <= 2 * simd_lanes) ? 2 : 4;
    }
 
    std::map<std::tuple<int, int, int, int>, SizeClass> by_key;
@@ -88,14 +89,14 @@ int build_host_plan(int64_t n_loci, const int64_t *row_off, const int64_t *iso_o
          k.CL = C / k.CPL;
          for (int i = 0; i < kNumLayouts; ++i)
             if (kLayoutCPL[i] == k.CPL && kLayoutCL[i] == k.CL) k.layout = i;
-         const int R1 = kLayoutR[k.layout];
+         const int R1 = kLayoutRHalf[k.layout]; // half-tile rows
          // wave kind: smallest power-of-two group that holds the rows
          bool placed = false;
          {
             const int R = R1 * wave_rmult;
             const int64_t lanes = (int64_t)pow2ceil(std::max<int64_t>(1, (nrow + R - 1) / R)) * k.CL;
             if (lanes <= 64) {
-               k.kind = (wave_rmult == 1) ? kWave1 : kWave2;
+               k.kind = (wave_rmult == 1) ? kWaveH : (wave_rmult == 2 ? kWave1 : kWave2);
                k.rmult = wave_rmult;
                k.R = R;
                k.G = (int)lanes;
@@ -105,7 +106,7 @@ int build_host_plan(int64_t n_loci, const int64_t *row_off, const int64_t *iso_o
          }
          // block kinds: the whole 256-lane workgroup is the group
          for (int tall = tune.light_block ? 0 : 1; tall < 2 && !placed; ++tall) {
-            const int rm = tall ? kBlockTallRmult : kBlockRmult;
+            const int rm = tall ? kBlockTallRh : kBlockRh;
             if ((int64_t)(kBlockThreads / k.CL) * R1 * rm >= nrow) {
                k.kind = tall ? kBlockTall : kBlock;
                k.rmult = rm;
@@ -149,7 +150,7 @@ int build_host_plan(int64_t n_loci, const int64_t *row_off, const int64_t *iso_o
          return wx > wy;
       });
       const int64_t n = (int64_t)sc.loci.size();
-      if (sc.kind == kWave1 || sc.kind == kWave2) {
+      if (sc.kind == kWaveH || sc.kind == kWave1 || sc.kind == kWave2) {
          sc.block_threads = 64;
          sc.n_blocks = (int)((n + (64 / sc.G) - 1) / (64 / sc.G));
       } else if (sc.kind == kStream) {

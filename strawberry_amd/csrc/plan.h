@@ -13,23 +13,23 @@
 
 namespace sb {
 
-// One kernel launch per kind and phase (the chip exposes four hardware queues, and a
-// batch uses at most four kinds).
-//  kWave1/kWave2  64/G groups per wave, rows-per-lane multiplier 1 or 2 (a plan uses one)
-//  kBlock         one 256-lane workgroup per locus, register tile 2x the base rows, <= 256
-//                 VGPRs so that it shares a SIMD with wave-kind waves
-//  kBlockTall     same with 6x the base rows: one wave per SIMD, the full 512-VGPR budget
-//  kStream        anything larger: F re-read from L2 every iteration
-enum ClassKind : int { kWave1 = 0, kWave2, kBlock, kBlockTall, kStream, kNumKinds };
+// One kernel launch per kind and phase (a batch uses one wave kind, usually one block kind).
+// `rh` = rows per row lane in units of half the base tile (kLayoutRHalf).
+//  kWaveH/1/2   64/G groups per wave; rh = 1, 2, 4.  A plan uses ONE of them, chosen by load:
+//               the half tile has the shortest iteration but needs twice the lanes per locus
+//  kBlock       one 256-lane workgroup per locus, rh = 4 (optional, see PlanTuning)
+//  kBlockTall   same with rh = 12: tiles up to 6x the base rows
+//  kStream      anything larger: F re-read from L2 every iteration
+enum ClassKind : int { kWaveH = 0, kWave1, kWave2, kBlock, kBlockTall, kStream, kNumKinds };
 constexpr int kBlockThreads = 256;
-constexpr int kBlockRmult = 2;
-constexpr int kBlockTallRmult = 6;
+constexpr int kBlockRh = 4;
+constexpr int kBlockTallRh = 12;
 
 struct SizeClass {
    int kind = kWave1;
    int layout = 0;   // index into kLayoutCPL/kLayoutCL
    int CPL = 0, CL = 0; // columns per lane, column lanes (CPL*CL >= niso)
-   int rmult = 1;    // rows per row lane = rmult * kLayoutR[layout]
+   int rmult = 2;    // rh: rows per row lane = rh * kLayoutRHalf[layout]
    int R = 0;
    int G = 0;        // lanes per locus = CL * row lanes
    int lbG = 0;      // log2(G) for the wave kind
@@ -49,12 +49,12 @@ struct HostPlan {
 constexpr int kNumLayouts = 6;
 constexpr int kLayoutCPL[kNumLayouts] = {2, 4, 8, 8, 8, 8};
 constexpr int kLayoutCL[kNumLayouts] = {1, 1, 1, 2, 4, 8};
-constexpr int kLayoutR[kNumLayouts] = {8, 8, 4, 4, 4, 4}; // rows per row lane at rmult 1
+constexpr int kLayoutRHalf[kNumLayouts] = {4, 4, 2, 2, 2, 2}; // half of the base rows per row lane
 constexpr int kMaxTileC = 64;     // 8 column lanes x 8 columns; wider loci stream
 constexpr int kMaxStreamIso = 512;
 
 struct PlanTuning {
-   int wave_rmult = 0;   // 0 = auto, 1 / 2 = force the rows-per-lane multiplier of the wave kind
+   int wave_rmult = 0;   // 0 = auto, 1 / 2 / 4 = force rh of the wave kind (half / base / double tile)
    bool light_block = false; // also use the 2x-rows block kind (<= 256 VGPRs); off: it spills and
                              // fights the wave kind for the same SIMDs (measured slower on C3)
    int64_t max_waves = 0;  // grids shrink (waves pull several batches) only beyond this many waves; 0 = 2^20

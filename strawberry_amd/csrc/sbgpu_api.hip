@@ -475,18 +475,21 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
             int32_t *n_out = p->d_counts + (size_t)(ph + 1) * ncls_alloc + kl.first_class;
             const int limit = p->phase_limits[ph];
             const int resume = ph > 0;
-            if (k == sb::kWave1) {
+            if (k == sb::kWaveH) {
                hipLaunchKernelGGL((sb::em_fused_kernel<0, 1>), dim3(kl.n_blocks), dim3(64), 0, s, a, kl.d_table,
                                   kl.n_classes, lists_in, n_in, cursors, lists_out, n_out, limit, resume);
-            } else if (k == sb::kWave2) {
+            } else if (k == sb::kWave1) {
                hipLaunchKernelGGL((sb::em_fused_kernel<0, 2>), dim3(kl.n_blocks), dim3(64), 0, s, a, kl.d_table,
                                   kl.n_classes, lists_in, n_in, cursors, lists_out, n_out, limit, resume);
+            } else if (k == sb::kWave2) {
+               hipLaunchKernelGGL((sb::em_fused_kernel<0, 4>), dim3(kl.n_blocks), dim3(64), 0, s, a, kl.d_table,
+                                  kl.n_classes, lists_in, n_in, cursors, lists_out, n_out, limit, resume);
             } else if (k == sb::kBlock) {
-               hipLaunchKernelGGL((sb::em_fused_kernel<sb::kBlockWaves, sb::kBlockRmult>), dim3(kl.n_blocks),
+               hipLaunchKernelGGL((sb::em_fused_kernel<sb::kBlockWaves, sb::kBlockRh>), dim3(kl.n_blocks),
                                   dim3(sb::kBlockThreads), 0, s, a, kl.d_table, kl.n_classes, lists_in, n_in,
                                   cursors, lists_out, n_out, limit, resume);
             } else {
-               hipLaunchKernelGGL((sb::em_fused_kernel<sb::kBlockWaves, sb::kBlockTallRmult>), dim3(kl.n_blocks),
+               hipLaunchKernelGGL((sb::em_fused_kernel<sb::kBlockWaves, sb::kBlockTallRh>), dim3(kl.n_blocks),
                                   dim3(sb::kBlockThreads), 0, s, a, kl.d_table, kl.n_classes, lists_in, n_in,
                                   cursors, lists_out, n_out, limit, resume);
             }
@@ -506,10 +509,10 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
    return SBGPU_OK;
 }
 
-int sbgpu_em_last_kernel_ms(sbgpu_ctx_t *c, float ms[5])
+int sbgpu_em_last_kernel_ms(sbgpu_ctx_t *c, float ms[6])
 {
    if (!c || !ms) return fail(SBGPU_EINVAL, "sbgpu_em_last_kernel_ms: null argument");
-   for (int k = 0; k < sb::kNumKinds && k < 5; ++k) {
+   for (int k = 0; k < sb::kNumKinds && k < 6; ++k) {
       ms[k] = 0.0f;
       if (!c->timed[k]) continue;
       HIP_TRY(hipEventSynchronize(c->t1[k]));

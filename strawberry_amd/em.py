@@ -93,7 +93,7 @@ class Plan:
         return [dict(zip(keys, out[i * 6:(i + 1) * 6])) for i in range(min(n, cap))]
 
     def locus_kinds(self):
-        """int8[n_loci]: 0/1 wave kinds, 2 block, 3 tall block, 4 streaming kind."""
+        """int8[n_loci]: 0/1/2 wave kinds, 3 block, 4 tall block, 5 streaming kind."""
         out = np.zeros(max(self.n_loci, 1), np.int8)
         _lib.check(self.ctx.L.sbgpu_plan_locus_kinds(self.h, out.ctypes.data), "sbgpu_plan_locus_kinds")
         return out[:self.n_loci]
@@ -145,8 +145,9 @@ class EmBatchSolver:
                                          self.d_iters.data_ptr(), self._stream()), "sbgpu_em_run_device")
 
     def last_kernel_ms(self):
-        """Device time of the last run_em per kernel kind: [wave 1x, wave 2x, block, tall block, stream]."""
-        ms = (C.c_float * 5)()
+        """Device time of the last run_em per kernel kind:
+        [wave half tile, wave base tile, wave double tile, block, tall block, stream]."""
+        ms = (C.c_float * 6)()
         _lib.check(self.ctx.L.sbgpu_em_last_kernel_ms(self.ctx.h, ms), "sbgpu_em_last_kernel_ms")
         return [float(x) for x in ms]
 

@@ -79,3 +79,22 @@ def test_synth_shapes_and_determinism():
     c3 = synth.make_c3(n_loci=300, total_frags=1e6)
     assert c3.n_loci == 300 and c3.niso.min() >= 1 and c3.nrow.max() <= 2000
     assert abs(c3.n_frags - 1e6) / 1e6 < 0.01
+
+
+def test_header_is_plain_c_and_links(tmp_path, lib):
+    """include/sbgpu.h compiles as C99 (no C++/HIP/torch types in the signatures) and a C
+    program calling every entry point links against libsbgpu.so."""
+    import subprocess
+    from strawberry_amd import _lib
+    src = tmp_path / "abi.c"
+    calls = "\n".join("   p[%d] = (fn_t)%s;" % (i, name) for i, name in enumerate(_lib.SYMBOLS))
+    src.write_text('#include "sbgpu.h"\n#include <stdio.h>\ntypedef void (*fn_t)(void);\nint main(void) {\n   fn_t p[%d];\n%s\n'
+                   '   printf("%%s %%d\\n", sbgpu_version(), (int)(sizeof(p) / sizeof(p[0])));\n   return p[0] == 0;\n}\n'
+                   % (len(_lib.SYMBOLS), calls))
+    exe = tmp_path / "abi"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                           str(src), "-o", str(exe), "-L", libdir, "-lsbgpu", "-Wl,-rpath," + libdir,
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and "gfx950" in out.stdout, (out.stdout, out.stderr)

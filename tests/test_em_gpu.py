@@ -186,7 +186,7 @@ def test_gpu_phased_execution_is_bitwise_identical(ctx, monkeypatch):
     assert (r0["status"] <= 3).all()
 
 
-@pytest.mark.parametrize("env", [{"SBGPU_WAVE_RMULT": "1"}, {"SBGPU_WAVE_RMULT": "2"},
+@pytest.mark.parametrize("env", [{"SBGPU_WAVE_RMULT": "1"}, {"SBGPU_WAVE_RMULT": "2"}, {"SBGPU_WAVE_RMULT": "4"},
                                  {"SBGPU_LIGHT_BLOCK": "1"}, {"SBGPU_MAX_WAVES": "64"}])
 def test_gpu_every_schedule_gives_the_same_answer(ctx, oracle, monkeypatch, env):
     """Size-class / grid tuning knobs change the schedule, never the result beyond

@@ -22,7 +22,7 @@ ctx = em.default_context(0)
 b = synth.make_c3()
 s, r = run(b, ctx, "C3 full")
 it = r["iters"]; kinds = s.plan.locus_kinds()
-wave = kinds < 2
+wave = kinds < 3
 run(b.select(np.nonzero(wave)[0]), ctx, "C3 wave-kind loci only")
 run(b.select(np.nonzero(wave & (it == 1000))[0]), ctx, "wave-kind MAXITER loci")
 run(b.select(np.nonzero(wave & (it > 256))[0]), ctx, "wave-kind it>256")

@@ -11,7 +11,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     b = synth.make_c3()
     s = em.EmBatchSolver(b, ctx)
     kinds = s.plan.locus_kinds()
-    for name, sel in (("wave-kind only", kinds < 2), ("block-kind only", kinds >= 2), ("all", kinds >= 0)):
+    for name, sel in (("wave-kind only", kinds < 3), ("block-kind only", kinds >= 3), ("all", kinds >= 0)):
         sub = b.select(np.nonzero(sel)[0])
         s2 = em.EmBatchSolver(sub, ctx)
         s2.run_em(); torch.cuda.synchronize()
