@@ -197,6 +197,14 @@ __device__ __forceinline__ double xor_sum(double x)
 
 constexpr int ilog2(int x) { return x <= 1 ? 0 : 1 + ilog2(x / 2); }
 
+// rows per row lane of a register tile: rh halves of the base height, capped so that the
+// tile stays within the 256 VGPRs a VALU instruction can address (128 fp64 elements)
+constexpr int kMaxTileElems = 128;
+constexpr int tile_rows(int cpl, int rhalf, int rh)
+{
+   return (rhalf * rh * cpl > kMaxTileElems) ? kMaxTileElems / cpl : rhalf * rh;
+}
+
 // all-reduce over lane bits [0, HI) (compile-time)
 template <int HI>
 __device__ __forceinline__ double low_bits_sum(double x)
@@ -641,13 +649,17 @@ constexpr int kLayouts = 6; // (CPL, CL): (2,1) (4,1) (8,1) (8,2) (8,4) (8,8)
 #endif
 template <int NWAVES, int RH>
 __global__ __launch_bounds__(NWAVES > 0 ? 64 * NWAVES : 64,
-                              NWAVES > 0 ? 1 : (RH == 1 ? SB_WAVEH_OCC : (RH == 2 ? SB_WAVE1_OCC : SB_WAVE2_OCC))) void em_fused_kernel(
+                              NWAVES > 0 ? (RH <= 2 ? 2 : 1)
+                                         : (RH == 1 ? SB_WAVEH_OCC : (RH == 2 ? SB_WAVE1_OCC : SB_WAVE2_OCC))) void em_fused_kernel(
    EmArgs a, const ClassDesc *table, int n_classes, const int32_t *lists_in, const int32_t *n_in,
    int32_t *cursors, int32_t *lists_out, int32_t *n_out, int it_limit, int resume)
 {
    __shared__ double s_red[NWAVES > 0 ? 2 * (kMaxCPLv + 1) * 8 * NWAVES : 1];
    __shared__ int s_idx;
    set_fp64_flush_denormals();
+   // workgroup-per-locus waves have the longest iterations of the batch (LDS round + barrier):
+   // they go first whenever they share a SIMD with wave-form waves
+   if (NWAVES > 0) __builtin_amdgcn_s_setprio(3);
 #ifdef SB_STAMPS
    const unsigned long long st0 = sb_now();
 #endif
@@ -675,15 +687,60 @@ __global__ __launch_bounds__(NWAVES > 0 ? 64 * NWAVES : 64,
    cls.resume = resume;
    const int layout = d.shape & 0xFF;
    const int lbG = (d.shape >> 16) & 0xFF;
+   // layout = (CPL - 1) + 8 * log2(CL): exact columns per lane (no padding to a power of two),
+   // CL = 1 for up to 8 isoforms, else 2 / 4 / 8 column lanes of 5..8 columns each.
+   // Rows per row lane: RH halves of the base height (16, 8, 8, 8, 6, 6, 4, 4 for CPL = 1..8).
+#define SB_BODY(CPLV, CLV, RHALF)                                                                  \
+   case (CPLV - 1) + 8 * ilog2(CLV):                                                               \
+      em_tile_body<CPLV, CLV, tile_rows(CPLV, RHALF, RH), NWAVES>(a, cls, lbG, s_red, &s_idx);     \
+      break;
    switch (layout) {
-   case 0: em_tile_body<2, 1, 4 * RH, NWAVES>(a, cls, lbG, s_red, &s_idx); break;
-   case 1: em_tile_body<4, 1, 4 * RH, NWAVES>(a, cls, lbG, s_red, &s_idx); break;
-   case 2: em_tile_body<8, 1, 2 * RH, NWAVES>(a, cls, lbG, s_red, &s_idx); break;
-   case 3: em_tile_body<8, 2, 2 * RH, NWAVES>(a, cls, lbG, s_red, &s_idx); break;
-   case 4: em_tile_body<8, 4, 2 * RH, NWAVES>(a, cls, lbG, s_red, &s_idx); break;
-   default: em_tile_body<8, 8, 2 * RH, NWAVES>(a, cls, lbG, s_red, &s_idx); break;
+      SB_BODY(1, 1, 8)
+      SB_BODY(2, 1, 4)
+      SB_BODY(3, 1, 4)
+      SB_BODY(4, 1, 4)
+      SB_BODY(5, 1, 3)
+      SB_BODY(6, 1, 3)
+      SB_BODY(7, 1, 2)
+      SB_BODY(8, 1, 2)
+      SB_BODY(5, 2, 3)
+      SB_BODY(6, 2, 3)
+      SB_BODY(7, 2, 2)
+      SB_BODY(8, 2, 2)
+      SB_BODY(5, 4, 3)
+      SB_BODY(6, 4, 3)
+      SB_BODY(7, 4, 2)
+      SB_BODY(8, 4, 2)
+      SB_BODY(5, 8, 3)
+      SB_BODY(6, 8, 3)
+      SB_BODY(7, 8, 2)
+      SB_BODY(8, 8, 2)
+   default: break;
    }
+#undef SB_BODY
 }
+
+// host-callable launchers, one translation unit per instantiation (em_kernels_*.hip)
+struct FusedLaunch {
+   EmArgs a;
+   const ClassDesc *table;
+   int n_classes;
+   const int32_t *lists_in;
+   const int32_t *n_in;
+   int32_t *cursors;
+   int32_t *lists_out;
+   int32_t *n_out;
+   int it_limit;
+   int resume;
+   int n_blocks;
+};
+hipError_t launch_fused_wave_h(const FusedLaunch &l, hipStream_t s);
+hipError_t launch_fused_wave_1(const FusedLaunch &l, hipStream_t s);
+hipError_t launch_fused_wave_2(const FusedLaunch &l, hipStream_t s);
+hipError_t launch_fused_block(const FusedLaunch &l, hipStream_t s);
+hipError_t launch_fused_block_tall(const FusedLaunch &l, hipStream_t s);
+hipError_t launch_stream(const EmArgs &a, const ClassArgs &c, uint8_t *row_keep, int n_blocks, size_t lds_bytes,
+                         hipStream_t s);
 
 // ============================================================= streaming kernel
 // Any shape (niso <= 64*kStreamSlots): one 256-thread workgroup per locus, F is
@@ -717,6 +774,7 @@ __device__ __forceinline__ double wave_stride_sum_rt(double x, int lw)
    return x;
 }
 
+#ifdef SB_COMPILE_STREAM_KERNEL
 __global__ __launch_bounds__(kStreamThreads) void em_stream_kernel(EmArgs a, ClassArgs cls,
                                                                    uint8_t *row_keep /*[total rows]*/)
 {
@@ -929,5 +987,7 @@ __global__ __launch_bounds__(kStreamThreads) void em_stream_kernel(EmArgs a, Cla
       __syncthreads();
    }
 }
+
+#endif // SB_COMPILE_STREAM_KERNEL
 
 } // namespace sb

@@ -1,0 +1,12 @@
+// strawberry_amd/csrc/em_kernels_wave_1.hip -- one instantiation of the fused EM kernel per
+// translation unit (they compile in parallel); see em_device.h.
+#include "em_device.h"
+
+namespace sb {
+hipError_t launch_fused_wave_1(const FusedLaunch &l, hipStream_t s)
+{
+   hipLaunchKernelGGL((em_fused_kernel<0, 2>), dim3(l.n_blocks), dim3(64), 0, s, l.a, l.table, l.n_classes,
+                      l.lists_in, l.n_in, l.cursors, l.lists_out, l.n_out, l.it_limit, l.resume);
+   return hipGetLastError();
+}
+} // namespace sb

@@ -59,11 +59,9 @@ int build_host_plan(int64_t n_loci, const int64_t *row_off, const int64_t *iso_o
       }
       p.algorithmic_bytes += nrow * niso * 8 + nrow * 4 + niso * 8 + 24;
       if (niso <= kMaxTileC) {
-         const int C = std::max(2, pow2ceil(niso));
-         const int CPL = std::min(C, 8), CL = C / CPL;
-         int R = 4;
-         for (int i = 0; i < kNumLayouts; ++i)
-            if (kLayoutCPL[i] == CPL && kLayoutCL[i] == CL) R = 2 * kLayoutRHalf[i];
+         int CPL, CL;
+         layout_for(niso, &CPL, &CL);
+         const int R = tile_rows(CPL, 2);
          const int64_t lanes = (int64_t)pow2ceil(std::max<int64_t>(1, (nrow + R - 1) / R)) * CL;
          if (lanes <= 64) wave_lanes_base += lanes;
       }
@@ -71,10 +69,11 @@ int build_host_plan(int64_t n_loci, const int64_t *row_off, const int64_t *iso_o
    const int64_t simd_lanes = (int64_t)n_cu * 4 * 64;
    int wave_rmult = tune.wave_rmult;
    if (wave_rmult != 1 && wave_rmult != 2 && wave_rmult != 4) {
-      // Base tile while the batch fits the two waves per SIMD its register budget admits,
-      // double tile (half the lanes per locus) beyond that.  The half tile (SBGPU_WAVE_RMULT=1)
+      // Base tile up to 8x the lanes the two waves per SIMD of its register budget hold (the
+      // dispatcher back-fills as short waves retire: measured best on C2 and C3), double tile
+      // (half the lanes per locus) beyond that.  The half tile (SBGPU_WAVE_RMULT=1)
       // doubles the lanes for a ~10 % shorter iteration: measured no better on C2, worse on C3.
-      wave_rmult = (wave_lanes_base <= 2 * simd_lanes) ? 2 : 4;
+      wave_rmult = (wave_lanes_base <= 16 * simd_lanes) ? 2 : 4;
    }
 
    std::map<std::tuple<int, int, int, int>, SizeClass> by_key;
@@ -84,16 +83,12 @@ int build_host_plan(int64_t n_loci, const int64_t *row_off, const int64_t *iso_o
       SizeClass k;
       k.kind = kStream;
       if (niso <= kMaxTileC) {
-         const int C = std::max(2, pow2ceil(niso));
-         k.CPL = std::min(C, 8);
-         k.CL = C / k.CPL;
-         for (int i = 0; i < kNumLayouts; ++i)
-            if (kLayoutCPL[i] == k.CPL && kLayoutCL[i] == k.CL) k.layout = i;
-         const int R1 = kLayoutRHalf[k.layout]; // half-tile rows
+         layout_for(niso, &k.CPL, &k.CL);
+         k.layout = layout_id(k.CPL, k.CL);
          // wave kind: smallest power-of-two group that holds the rows
          bool placed = false;
          {
-            const int R = R1 * wave_rmult;
+            const int R = tile_rows(k.CPL, wave_rmult);
             const int64_t lanes = (int64_t)pow2ceil(std::max<int64_t>(1, (nrow + R - 1) / R)) * k.CL;
             if (lanes <= 64) {
                k.kind = (wave_rmult == 1) ? kWaveH : (wave_rmult == 2 ? kWave1 : kWave2);
@@ -107,10 +102,10 @@ int build_host_plan(int64_t n_loci, const int64_t *row_off, const int64_t *iso_o
          // block kinds: the whole 256-lane workgroup is the group
          for (int tall = tune.light_block ? 0 : 1; tall < 2 && !placed; ++tall) {
             const int rm = tall ? kBlockTallRh : kBlockRh;
-            if ((int64_t)(kBlockThreads / k.CL) * R1 * rm >= nrow) {
+            if ((int64_t)(kBlockThreads / k.CL) * tile_rows(k.CPL, rm) >= nrow) {
                k.kind = tall ? kBlockTall : kBlock;
                k.rmult = rm;
-               k.R = R1 * rm;
+               k.R = tile_rows(k.CPL, rm);
                k.G = kBlockThreads;
                k.lbG = 6;
                placed = true;
@@ -175,7 +170,7 @@ int build_host_plan(int64_t n_loci, const int64_t *row_off, const int64_t *iso_o
       // Lowest block indices are dispatched first.  The makespan is set by the loci that run
       // all 1000 iterations, and an iteration costs more the more lanes (and column lanes) a
       // locus spans: those classes go first, the many short narrow ones fill in behind.
-      const int cx = x.lbG + 2 * x.layout, cy = y.lbG + 2 * y.layout;
+      const int cx = x.lbG + x.CPL + 4 * (x.layout / 8), cy = y.lbG + y.CPL + 4 * (y.layout / 8);
       if (cx != cy) return cx > cy;
       return x.work > y.work;
    });

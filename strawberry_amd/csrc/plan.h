@@ -22,12 +22,12 @@ namespace sb {
 //  kStream      anything larger: F re-read from L2 every iteration
 enum ClassKind : int { kWaveH = 0, kWave1, kWave2, kBlock, kBlockTall, kStream, kNumKinds };
 constexpr int kBlockThreads = 256;
-constexpr int kBlockRh = 4;
+constexpr int kBlockRh = 2;
 constexpr int kBlockTallRh = 12;
 
 struct SizeClass {
    int kind = kWave1;
-   int layout = 0;   // index into kLayoutCPL/kLayoutCL
+   int layout = 0;   // layout_id(CPL, CL)
    int CPL = 0, CL = 0; // columns per lane, column lanes (CPL*CL >= niso)
    int rmult = 2;    // rh: rows per row lane = rh * kLayoutRHalf[layout]
    int R = 0;
@@ -46,17 +46,36 @@ struct HostPlan {
    std::vector<SizeClass> classes; // grouped by kind; inside a kind heaviest first
 };
 
-constexpr int kNumLayouts = 6;
-constexpr int kLayoutCPL[kNumLayouts] = {2, 4, 8, 8, 8, 8};
-constexpr int kLayoutCL[kNumLayouts] = {1, 1, 1, 2, 4, 8};
-constexpr int kLayoutRHalf[kNumLayouts] = {4, 4, 2, 2, 2, 2}; // half of the base rows per row lane
+// register-tile layouts: CPL exact columns per lane x CL column lanes (CPL*CL >= niso);
+// layout id = (CPL - 1) + 8 * log2(CL)
+constexpr int kLayoutRHalf[8] = {8, 4, 4, 4, 3, 3, 2, 2}; // half of the base rows per row lane, by CPL - 1
+// rows per row lane for a tile of rh halves (same cap as em_device.h::tile_rows)
+inline int tile_rows(int cpl, int rh)
+{
+   const int r = kLayoutRHalf[cpl - 1] * rh;
+   return (r * cpl > 128) ? 128 / cpl : r;
+}
+inline int layout_id(int cpl, int cl)
+{
+   int lb = 0;
+   while ((1 << lb) < cl) ++lb;
+   return (cpl - 1) + 8 * lb;
+}
+// niso -> (CPL, CL): one column lane up to 8 isoforms, then 2 / 4 / 8 lanes of 5..8 columns
+inline void layout_for(int64_t niso, int *cpl, int *cl)
+{
+   int c = 1;
+   while (niso > 8 * c) c *= 2;
+   *cl = c;
+   *cpl = (int)((niso + c - 1) / c);
+}
 constexpr int kMaxTileC = 64;     // 8 column lanes x 8 columns; wider loci stream
 constexpr int kMaxStreamIso = 512;
 
 struct PlanTuning {
    int wave_rmult = 0;   // 0 = auto, 1 / 2 / 4 = force rh of the wave kind (half / base / double tile)
-   bool light_block = false; // also use the 2x-rows block kind (<= 256 VGPRs); off: it spills and
-                             // fights the wave kind for the same SIMDs (measured slower on C3)
+   bool light_block = true;  // use the base-tile block kind (<= 256 VGPRs, shares SIMDs with wave-form
+                             // waves) for the loci it holds, the tall tile only for the rest
    int64_t max_waves = 0;  // grids shrink (waves pull several batches) only beyond this many waves; 0 = 2^20
 };
 

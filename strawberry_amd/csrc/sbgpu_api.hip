@@ -35,6 +35,12 @@ int fail(int code, const std::string &msg)
    } while (0)
 
 constexpr int kAuxStreams = 8;
+// Which aux stream each kernel kind runs on.  HIP folds streams onto a few hardware queues
+// (4 by default: GPU_MAX_HW_QUEUES) in creation order; measured on ROCm 7.2 the aux streams
+// land on queues {2,3,4,4,3,2,1,4} and the null stream on 3, so the three kinds that run
+// side by side (one wave kind, block, tall block) get streams 0, 2 and 6: three distinct queues
+// that also avoid the caller's.
+constexpr int kKindStream[sb::kNumKinds] = {0, 0, 0, 2, 6, 1};
 
 } // namespace
 
@@ -445,55 +451,45 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
    if (fork) {
       HIP_TRY(hipEventRecord(c->fork, main));
       for (int k = 0; k < sb::kNumKinds; ++k)
-         if (p->launches[k].n_classes > 0) HIP_TRY(hipStreamWaitEvent(c->aux[k], c->fork, 0));
+         if (p->launches[k].n_classes > 0) HIP_TRY(hipStreamWaitEvent(c->aux[kKindStream[k]], c->fork, 0));
    }
    for (int k = 0; k < sb::kNumKinds; ++k) c->timed[k] = false;
    // longest iterations first: stream, block, wave
    for (int k = sb::kNumKinds - 1; k >= 0; --k) {
       const KindLaunch &kl = p->launches[k];
       if (kl.n_classes == 0) continue;
-      hipStream_t s = fork ? c->aux[k] : main;
+      hipStream_t s = fork ? c->aux[kKindStream[k]] : main;
       HIP_TRY(hipEventRecord(c->t0[k], s));
       if (k == sb::kStream) {
          sb::ClassArgs ca = {};
          ca.loci = p->d_loci_all + p->loci_off[kl.first_class];
          ca.n = (int32_t)p->host.classes[kl.first_class].loci.size();
          ca.cursor = p->d_cursors + kl.first_class;
-         hipLaunchKernelGGL(sb::em_stream_kernel, dim3(kl.n_blocks), dim3(sb::kStreamThreads),
-                            p->stream_lds_bytes, s, a, ca, p->d_row_keep);
-         HIP_TRY(hipGetLastError());
+         HIP_TRY(sb::launch_stream(a, ca, p->d_row_keep, kl.n_blocks, p->stream_lds_bytes, s));
       } else {
          // phase ph runs the loci still alive up to phase_limits[ph] iterations and appends
          // the unfinished ones to the next phase's list; later phases launch the same grid,
          // waves whose class list is already dry leave after one atomic
          for (int ph = 0; ph < nph; ++ph) {
-            const int32_t *lists_in = (ph == 0) ? p->d_loci_all : p->d_lists[(ph - 1) & 1];
-            const int32_t *n_in = (ph == 0) ? p->d_class_n + kl.first_class
-                                            : p->d_counts + (size_t)ph * ncls_alloc + kl.first_class;
-            int32_t *cursors = p->d_cursors + (size_t)ph * ncls_alloc + kl.first_class;
-            int32_t *lists_out = p->d_lists[ph & 1];
-            int32_t *n_out = p->d_counts + (size_t)(ph + 1) * ncls_alloc + kl.first_class;
-            const int limit = p->phase_limits[ph];
-            const int resume = ph > 0;
-            if (k == sb::kWaveH) {
-               hipLaunchKernelGGL((sb::em_fused_kernel<0, 1>), dim3(kl.n_blocks), dim3(64), 0, s, a, kl.d_table,
-                                  kl.n_classes, lists_in, n_in, cursors, lists_out, n_out, limit, resume);
-            } else if (k == sb::kWave1) {
-               hipLaunchKernelGGL((sb::em_fused_kernel<0, 2>), dim3(kl.n_blocks), dim3(64), 0, s, a, kl.d_table,
-                                  kl.n_classes, lists_in, n_in, cursors, lists_out, n_out, limit, resume);
-            } else if (k == sb::kWave2) {
-               hipLaunchKernelGGL((sb::em_fused_kernel<0, 4>), dim3(kl.n_blocks), dim3(64), 0, s, a, kl.d_table,
-                                  kl.n_classes, lists_in, n_in, cursors, lists_out, n_out, limit, resume);
-            } else if (k == sb::kBlock) {
-               hipLaunchKernelGGL((sb::em_fused_kernel<sb::kBlockWaves, sb::kBlockRh>), dim3(kl.n_blocks),
-                                  dim3(sb::kBlockThreads), 0, s, a, kl.d_table, kl.n_classes, lists_in, n_in,
-                                  cursors, lists_out, n_out, limit, resume);
-            } else {
-               hipLaunchKernelGGL((sb::em_fused_kernel<sb::kBlockWaves, sb::kBlockTallRh>), dim3(kl.n_blocks),
-                                  dim3(sb::kBlockThreads), 0, s, a, kl.d_table, kl.n_classes, lists_in, n_in,
-                                  cursors, lists_out, n_out, limit, resume);
-            }
-            HIP_TRY(hipGetLastError());
+            sb::FusedLaunch fl;
+            fl.a = a;
+            fl.table = kl.d_table;
+            fl.n_classes = kl.n_classes;
+            fl.lists_in = (ph == 0) ? p->d_loci_all : p->d_lists[(ph - 1) & 1];
+            fl.n_in = (ph == 0) ? p->d_class_n + kl.first_class : p->d_counts + (size_t)ph * ncls_alloc + kl.first_class;
+            fl.cursors = p->d_cursors + (size_t)ph * ncls_alloc + kl.first_class;
+            fl.lists_out = p->d_lists[ph & 1];
+            fl.n_out = p->d_counts + (size_t)(ph + 1) * ncls_alloc + kl.first_class;
+            fl.it_limit = p->phase_limits[ph];
+            fl.resume = ph > 0;
+            fl.n_blocks = kl.n_blocks;
+            hipError_t e = hipErrorInvalidValue;
+            if (k == sb::kWaveH) e = sb::launch_fused_wave_h(fl, s);
+            else if (k == sb::kWave1) e = sb::launch_fused_wave_1(fl, s);
+            else if (k == sb::kWave2) e = sb::launch_fused_wave_2(fl, s);
+            else if (k == sb::kBlock) e = sb::launch_fused_block(fl, s);
+            else if (k == sb::kBlockTall) e = sb::launch_fused_block_tall(fl, s);
+            HIP_TRY(e);
          }
       }
       HIP_TRY(hipEventRecord(c->t1[k], s));
@@ -502,7 +498,7 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
    if (fork) {
       for (int k = 0; k < sb::kNumKinds; ++k) {
          if (p->launches[k].n_classes == 0) continue;
-         HIP_TRY(hipEventRecord(c->join[k], c->aux[k]));
+         HIP_TRY(hipEventRecord(c->join[k], c->aux[kKindStream[k]]));
          HIP_TRY(hipStreamWaitEvent(main, c->join[k], 0));
       }
    }
@@ -522,7 +518,20 @@ int sbgpu_em_last_kernel_ms(sbgpu_ctx_t *c, float ms[6])
 }
 
 #ifdef SB_STAMPS
-// diagnostic build only
+// diagnostic build only: one trivial launch per stream, to read the stream -> hardware queue
+// mapping off a rocprofv3 kernel trace (grid size = 64 * (index + 1) identifies the stream)
+int sbgpu_debug_touch_streams(sbgpu_ctx_t *c, double *d_buf)
+{
+   for (int i = 0; i < kAuxStreams; ++i) {
+      hipLaunchKernelGGL(sum_kernel, dim3(i + 1), dim3(1024), 0, c->aux[i], (int64_t)0, d_buf, d_buf + 1);
+      HIP_TRY(hipGetLastError());
+   }
+   hipLaunchKernelGGL(sum_kernel, dim3(20), dim3(1024), 0, c->stream, (int64_t)0, d_buf, d_buf + 1);
+   hipLaunchKernelGGL(sum_kernel, dim3(30), dim3(1024), 0, (hipStream_t)0, (int64_t)0, d_buf, d_buf + 1);
+   HIP_TRY(hipDeviceSynchronize());
+   return SBGPU_OK;
+}
+
 int sbgpu_debug_read_stamps(void *out, size_t bytes)
 {
    HIP_TRY(hipDeviceSynchronize());

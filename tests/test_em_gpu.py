@@ -69,7 +69,8 @@ def test_gpu_host_buffer_entry(ctx, oracle, golden):
 
 @pytest.mark.parametrize("shape", [(1, 1), (1, 7), (7, 1), (5, 2), (33, 3), (64, 8), (65, 8), (200, 5),
                                    (257, 8), (300, 16), (129, 32), (2000, 8), (5000, 2), (40, 33), (100, 64),
-                                   (9000, 2), (1000, 20), (3000, 20), (17, 13), (500, 40), (64, 65), (30, 200)])
+                                   (9000, 2), (1000, 20), (3000, 20), (17, 13), (500, 40), (64, 65), (30, 200),
+                                   (9, 4), (50, 6), (70, 12), (33, 24), (20, 48), (90, 28), (15, 56), (400, 6), (700, 11)])
 def test_gpu_every_size_class(ctx, oracle, shape):
     """One batch per (nrow, niso) shape so that each tile / workgroup / streaming
     class is exercised on its own, including its padding."""
