@@ -208,6 +208,23 @@ int sbgpu_binweight_host(sbgpu_ctx_t *ctx, int64_t n_pairs, const int64_t *seg_o
                          const uint32_t *seg_lens, const uint32_t *implicit_mask,
                          const int32_t *iso_len, const sbgpu_insert_t *ins, double *weight_out);
 
+/* ---- output formatting, host only -------------------------------
+ * The digits Strawberry prints for FPKM / Frac / TPM: std::to_string(double) (= "%f",
+ * src/estimate.cpp:335,344 and src/alignments.cpp:1827) copied into a char[12] by
+ * Contig::print2gtf (src/contig.cpp:678-700), i.e. the first 11 characters.           */
+int sbgpu_format_value(double v, char out[12]);
+
+/* One transcript block exactly as Contig::print2gtf writes it (src/contig.cpp:636-721):
+ * the `transcript` line then one `exon` line per exon; source "Strawberry", score 1000,
+ * attributes without a space after ';' and ` exon_id "k";` appended on exon lines.
+ * keep: 2 ("NA") prints NA for FPKM and Frac (src/estimate.cpp:321,339).  Writes at most
+ * cap-1 bytes + NUL into buf and returns the length needed (snprintf convention).       */
+int sbgpu_format_gtf_transcript(char *buf, int cap, const char *chrom, char strand, const char *gene_id,
+                                const char *transcript_id, const char *ref_gene_id,
+                                const char *ref_gene_name, int n_exons, const int32_t *exon_left,
+                                const int32_t *exon_right, double fpkm, double frac, double tpm,
+                                int32_t keep);
+
 #ifdef __cplusplus
 }
 #endif

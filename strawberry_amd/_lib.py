@@ -18,7 +18,8 @@ SYMBOLS = [
     "sbgpu_version", "sbgpu_last_error", "sbgpu_device_count", "sbgpu_init", "sbgpu_finalize",
     "sbgpu_device_info", "sbgpu_synchronize", "sbgpu_plan_create", "sbgpu_plan_destroy", "sbgpu_plan_info",
     "sbgpu_plan_classes", "sbgpu_plan_locus_kinds", "sbgpu_em_run_device", "sbgpu_em_last_kernel_ms",
-    "sbgpu_insert_pdf_table", "sbgpu_binweight_device", "sbgpu_binweight_host", "sbgpu_em_batch", "sbgpu_abundance_device", "sbgpu_tpm_device",
+    "sbgpu_insert_pdf_table", "sbgpu_binweight_device", "sbgpu_binweight_host",
+    "sbgpu_format_value", "sbgpu_format_gtf_transcript", "sbgpu_em_batch", "sbgpu_abundance_device", "sbgpu_tpm_device",
 ]
 
 
@@ -109,6 +110,10 @@ def load():
     L.sbgpu_insert_pdf_table.argtypes = [C.POINTER(sbgpu_insert_t), C.c_int32, vp]
     L.sbgpu_binweight_device.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32,
                                          C.c_int32, vp, vp]
+    L.sbgpu_format_value.argtypes = [C.c_double, C.c_char_p]
+    L.sbgpu_format_gtf_transcript.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_char, C.c_char_p, C.c_char_p,
+                                              C.c_char_p, C.c_char_p, C.c_int, vp, vp, C.c_double, C.c_double,
+                                              C.c_double, C.c_int32]
     L.sbgpu_binweight_host.argtypes = [vp, C.c_int64, vp, vp, vp, vp, C.POINTER(sbgpu_insert_t), vp]
     for name in SYMBOLS:
         f = getattr(L, name)

@@ -757,4 +757,51 @@ int sbgpu_binweight_host(sbgpu_ctx_t *c, int64_t n_pairs, const int64_t *seg_off
    return SBGPU_OK;
 }
 
+// ---------------------------------------------------------------- output formatting (A9)
+int sbgpu_format_value(double v, char out[12])
+{
+   if (!out) return fail(SBGPU_EINVAL, "sbgpu_format_value: null out");
+   char full[400];
+   std::snprintf(full, sizeof(full), "%f", v); // std::to_string(double)
+   std::strncpy(out, full, 12);                // print2gtf: strncpy into char[12] ...
+   out[11] = 0;                                // ... and terminate: first 11 characters
+   return SBGPU_OK;
+}
+
+int sbgpu_format_gtf_transcript(char *buf, int cap, const char *chrom, char strand, const char *gene_id,
+                                const char *transcript_id, const char *ref_gene_id, const char *ref_gene_name,
+                                int n_exons, const int32_t *exon_left, const int32_t *exon_right, double fpkm,
+                                double frac, double tpm, int32_t keep)
+{
+   if (!buf || cap < 1 || !chrom || !gene_id || !transcript_id || n_exons < 0 || (n_exons && (!exon_left || !exon_right)))
+      return fail(SBGPU_EINVAL, "sbgpu_format_gtf_transcript: bad argument");
+   char f[12], r[12], t[12];
+   sbgpu_format_value(fpkm, f);
+   sbgpu_format_value(frac, r);
+   sbgpu_format_value(tpm, t);
+   if (keep == 2) { // negative effective length: the strings are "NA" (estimate.cpp:321,339)
+      std::strcpy(f, "NA");
+      std::strcpy(r, "NA");
+   }
+   std::string attr = std::string("gene_id \"") + gene_id + "\";transcript_id \"" + transcript_id + "\";";
+   if (ref_gene_id && *ref_gene_id) attr += std::string("ref_gene_id \"") + ref_gene_id + "\";";
+   if (ref_gene_name && *ref_gene_name) attr += std::string("ref_gene_name \"") + ref_gene_name + "\";";
+   attr += std::string("FPKM \"") + f + "\";Frac \"" + r + "\";TPM \"" + t + "\";";
+   const int left = n_exons ? exon_left[0] : 0, right = n_exons ? exon_right[n_exons - 1] : 0;
+   std::string out;
+   char line[256];
+   std::snprintf(line, sizeof(line), "%s\tStrawberry\ttranscript\t%d\t%d\t%d\t%c\t%c\t", chrom, left, right, 1000,
+                 strand, '.');
+   out += line;
+   out += attr + "\n";
+   for (int k = 0; k < n_exons; ++k) {
+      std::snprintf(line, sizeof(line), "%s\tStrawberry\texon\t%d\t%d\t%d\t%c\t%c\t", chrom, exon_left[k],
+                    exon_right[k], 1000, strand, '.');
+      out += line;
+      out += attr + " exon_id \"" + std::to_string(k + 1) + "\";\n";
+   }
+   std::snprintf(buf, (size_t)cap, "%s", out.c_str());
+   return (int)out.size();
+}
+
 } // extern "C"

@@ -140,3 +140,51 @@ def test_gpu_pipeline_on_the_reference_toy(toy, toy_long, oracle):
     np.testing.assert_array_equal(r["iters"], o_iters)
     assert (np.abs(r["theta"] - o_theta) / np.maximum(np.abs(o_theta), 1e-9)).max() < 1e-9
     assert abs(r["tpm"].sum() - 1e6) < 1e-3
+
+
+def test_output_formatting_matches_reference_gtf(toy_long, oracle):
+    """A9: the strings Contig::print2gtf writes.  Known answers of the 11-character cut, then the
+    whole toy: our formatting of (theta as logged -> FPKM/Frac/TPM) reproduces the reference's
+    transcript lines -- theta is only known to its 6 logged decimals, so the last printed digit of a
+    value may differ; everything else must be byte-identical."""
+    from strawberry_amd.output import format_value, gtf_transcript
+    assert format_value(28404.567028) == "28404.56702"      # to_string -> 28404.567028, cut to 11
+    assert format_value(0.181426) == "0.181426"
+    assert format_value(1e6) == "1000000.000"
+    assert format_value(0.0) == "0.000000"
+    assert format_value(123456789.123) == "123456789.1"
+    genes, rows, gtf, theta_log = toy_long
+    ref_lines = {}
+    for line in open(U.E2E_LONG + "/out.gtf"):
+        if "\ttranscript\t" in line:
+            t = line.split('transcript_id "')[1].split('"')[0]
+            ref_lines[t] = line
+    total_mapped = rows[0]["total_mapped"]
+    fpkm_all, keep_all, info = [], [], []
+    for (g, tx), th in zip(genes.items(), theta_log):
+        length = [sum(b - a + 1 for a, b in ex) for _, ex in tx]
+        fpkm, frac, keep, _ = oracle.abundance_locus(th, length, total_mapped, min_isoform_frac=0.0)
+        for (t, ex), f, fr in zip(tx, fpkm, frac):
+            info.append((g, t, ex, f, fr))
+        fpkm_all += list(fpkm)
+        keep_all += list(keep)
+    tpm, _ = oracle.tpm(np.array(fpkm_all), np.array(keep_all, np.int32))
+    same = total = 0
+    for (g, t, ex, f, fr), tp in zip(info, tpm):
+        mine = gtf_transcript("chr1", "+", g, t, ex, f, fr, tp, ref_gene_id=g, ref_gene_name=g).split("\n")[0] + "\n"
+        ref = ref_lines[t]
+        # same structure byte for byte; the three numbers equal up to the digits theta was logged with
+        a, b = mine.split('"'), ref.split('"')
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            if x == y:
+                same += 1
+            else:
+                assert abs(float(x) - float(y)) <= 2e-5 * max(1.0, abs(float(y))), (x, y)
+            total += 1
+    assert same / total > 0.85  # all the text and most of the numbers are identical strings
+    # exon lines: ` exon_id "k";` appended, one per exon
+    g, t, ex, f, fr = info[0]
+    block = gtf_transcript("chr1", "+", g, t, ex, f, fr, tpm[0], ref_gene_id=g, ref_gene_name=g).split("\n")
+    assert len(block) == len(ex) + 2 and block[-1] == ""
+    assert block[1].endswith(' exon_id "1";') and "\texon\t%d\t%d\t1000\t+\t.\t" % ex[0] in block[1]
