@@ -208,6 +208,114 @@ int sbgpu_binweight_host(sbgpu_ctx_t *ctx, int64_t n_pairs, const int64_t *seg_o
                          const uint32_t *seg_lens, const uint32_t *implicit_mask,
                          const int32_t *iso_len, const sbgpu_insert_t *ins, double *weight_out);
 
+/* ---- exon-bin assignment, integer part --------------------------
+ * Replaces the two interval tests LocusContext::assign_exon_bin (src/estimate.cpp:135-198)
+ * makes for every (fragment, isoform) of a locus:
+ *   Contig::is_compatible(hit, isoform)      src/contig.cpp:547-599
+ *   LocusContext::overlap_exons(segs, hit)   src/estimate.cpp:115-131
+ * The bookkeeping on their results (LocusContext::set_maps, include/estimate.hpp:29-52:
+ * bins keyed by the set of touched segments) is host work in the caller.
+ *
+ * Annotation, CSR:  locus l owns isoforms iso_off[l]..iso_off[l+1]; isoform i owns exons
+ * exon_off[i]..exon_off[i+1] (closed coordinates, sorted: Contig::_genomic_feats' S_MATCH
+ * entries; its introns are the gaps between consecutive exons); locus l owns the disjoint
+ * exon segments seg_off[l]..seg_off[l+1] (LocusContext::_exon_segs, estimate.hpp:80-91).
+ * Hits, CSR: hit h belongs to locus hit_locus[h] and owns features feat_off[h]..feat_off[h+1]
+ * exactly as Contig::Contig(const PairedHit&) lays them out (src/contig.cpp:216-267):
+ * feat_code 0 = S_MATCH, 1 = S_INTRON, 2 = S_GAP (include/contig.h:26-31), closed
+ * feat_left..feat_right, sorted; first and last are S_MATCH.
+ * Results, bit words with a fixed stride per hit:
+ *   compat[h*compat_words + w] bit b  <=>  is_compatible(hit h, isoform 32*w+b of its locus)
+ *   key[h*key_words + w]       bit b  <=>  hit h overlaps segment 32*w+b of its locus
+ * compat_words / key_words must cover the widest locus (ceil(n/32)); bits past a locus' own
+ * isoforms / segments are 0.  A hit without features gets all-zero words.                 */
+typedef struct {
+   int64_t n_loci;
+   const int64_t *iso_off;     /* [n_loci + 1]                     */
+   const int64_t *exon_off;    /* [iso_off[n_loci] + 1]            */
+   const uint32_t *exon_left;  /* [exon_off[n_iso]]                */
+   const uint32_t *exon_right;
+   const int64_t *seg_off;     /* [n_loci + 1]                     */
+   const uint32_t *seg_left;   /* [seg_off[n_loci]]                */
+   const uint32_t *seg_right;
+} sbgpu_annotation_t;
+
+typedef struct {
+   int64_t n_hits;
+   const int32_t *hit_locus;   /* [n_hits]                         */
+   const int64_t *feat_off;    /* [n_hits + 1]                     */
+   const uint8_t *feat_code;   /* [feat_off[n_hits]]               */
+   const uint32_t *feat_left;
+   const uint32_t *feat_right;
+} sbgpu_hits_t;
+
+/* Device-resident form: every pointer inside the two structs and d_compat / d_key are device
+ * pointers (the structs themselves live on the host).  Asynchronous on `stream`.         */
+int sbgpu_exonbin_device(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *annot, const sbgpu_hits_t *hits,
+                         int32_t compat_words, int32_t key_words, uint32_t *d_compat,
+                         uint32_t *d_key, void *stream);
+
+/* Host-buffer convenience form: validates the CSR arrays (SBGPU_EINVAL / SBGPU_ESHAPE when
+ * the word counts do not cover a locus), uploads, runs, downloads, synchronises.         */
+int sbgpu_exonbin_host(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *annot, const sbgpu_hits_t *hits,
+                       int32_t compat_words, int32_t key_words, uint32_t *compat_out,
+                       uint32_t *key_out);
+
+/* ---- exon-bin bookkeeping on the host (the callers either side) --------
+ * Plain host code (no GPU work): what the reference does per locus with std::map / std::set
+ * between the interval tests above and the inputs of the bin-weight and EM kernels.        */
+
+/* The disjoint exon segments of every locus: sort + unique over the isoforms' exons, then
+ * IRanges::disjoint (include/estimate.hpp:80-91, include/interval.hpp:150-191).  Fills
+ * seg_off[n_loci+1] and up to `cap` entries of seg_left/seg_right (either may be NULL to
+ * size the arrays first); returns the total number of segments, or a negative SBGPU_E*.   */
+int64_t sbgpu_segments_host(int64_t n_loci, const int64_t *iso_off, const int64_t *exon_off,
+                            const uint32_t *exon_left, const uint32_t *exon_right, int64_t *seg_off,
+                            uint32_t *seg_left, uint32_t *seg_right, int64_t cap);
+
+/* The feature list of one fragment from its mates' features (each mate: its CIGAR as
+ * MATCH / INTRON features, readhit_2_genomicFeats, src/contig.cpp:12-53), as
+ * Contig::Contig(const PairedHit&) builds it (src/contig.cpp:216-267): a GAP feature when the
+ * mates are apart, sort + merge_genomicFeats (include/contig.h:111-137) when they touch or
+ * overlap; n_left or n_right may be 0 (single read).  The out arrays need room for
+ * n_left + n_right + 1 features.  Returns the number of features, 0 when the reference
+ * rejects the pair ("paired reads ... are not compatible", estimate.hpp:71-79), negative
+ * SBGPU_E* on a bad argument.                                                              */
+int sbgpu_hit_features(int n_left, const uint8_t *lcode, const uint32_t *lleft, const uint32_t *lright,
+                       int n_right, const uint8_t *rcode, const uint32_t *rleft, const uint32_t *rright,
+                       uint8_t *code_out, uint32_t *left_out, uint32_t *right_out);
+
+/* LocusContext::assign_exon_bin + set_maps (src/estimate.cpp:135-198, estimate.hpp:29-52)
+ * on the kernel's results (host copies of compat / key), hits visited in input order inside
+ * each locus (= HitCluster::uniq_hits() order):
+ *   - a hit with no compatible isoform is dropped;
+ *   - bins are keyed by `key` and numbered in order of first appearance
+ *     (UniqPushAndReturnIdx);
+ *   - a bin's count is ExonBin::read_count (include/isoform.h:285-296): fragments with the
+ *     same (offset, length) feature sequence count once (std::set<Contig>, first one wins),
+ *     masses are added in float in that set's order and truncated to int (estimate.cpp:288);
+ *   - a bin is paired with every isoform some hit of it is compatible with; for each pair
+ *     ExonBin::bin_under_iso (include/isoform.h:363-411) yields the bin-weight kernel's
+ *     segment lengths and implicit mask, and pair_out_index its element of the EM batch's F.
+ * hit_mass[h] = (float) PairedHit::collapse_mass().  The handle owns the results.          */
+typedef struct sbgpu_bins sbgpu_bins_t;
+int sbgpu_bins_create(const sbgpu_annotation_t *annot, const sbgpu_hits_t *hits, const float *hit_mass,
+                      int32_t compat_words, int32_t key_words, const uint32_t *compat,
+                      const uint32_t *key, sbgpu_bins_t **out);
+void sbgpu_bins_destroy(sbgpu_bins_t *bins);
+/* info: 0 n_loci, 1 n_iso, 2 n_bins, 3 n_elem (= f_off[n_loci]), 4 n_pairs, 5 total pair
+ * segments, 6 hits that landed in a bin, 7 key_words.                                      */
+int sbgpu_bins_info(const sbgpu_bins_t *bins, int64_t info[8]);
+/* Copies out what the caller asks for (NULL = skip).  The first five arrays are exactly an
+ * sbgpu_batch_t minus F (row_off/iso_off/f_off [n_loci+1], count [n_bins]) plus iso_len
+ * [n_iso]; bin_key [n_bins*key_words], bin_compat [n_bins*compat_words], hit_bin [n_hits]
+ * (global bin of each hit, -1 = dropped); the pair arrays are sbgpu_binweight_device's
+ * inputs ([n_pairs+1], [total pair segments], [n_pairs] x3).                               */
+int sbgpu_bins_export(const sbgpu_bins_t *bins, int64_t *row_off, int64_t *iso_off, int64_t *f_off,
+                      int32_t *count, int32_t *iso_len, uint32_t *bin_key, uint32_t *bin_compat,
+                      int64_t *hit_bin, int64_t *pair_seg_off, uint32_t *pair_seg_lens,
+                      uint32_t *pair_implicit_mask, int32_t *pair_iso_len, int64_t *pair_out_index);
+
 /* ---- output formatting, host only -------------------------------
  * The digits Strawberry prints for FPKM / Frac / TPM: std::to_string(double) (= "%f",
  * src/estimate.cpp:335,344 and src/alignments.cpp:1827) copied into a char[12] by

@@ -97,6 +97,14 @@ class OracleLib:
         L.sbo_effective_len.restype = C.c_int
         L.sbo_bin_weight.argtypes = [C.c_int, _u32, C.c_int, _u32, C.c_int, C.c_int, C.POINTER(sbo_insert_t)]
         L.sbo_bin_weight.restype = C.c_double
+        _u8 = _p(np.uint8, flags="C")
+        L.sbo_is_compatible.argtypes = [C.c_int, _u8, _u32, _u32, C.c_int, _u32, _u32]
+        L.sbo_is_compatible.restype = C.c_int
+        L.sbo_overlap_key.argtypes = [C.c_int, _u8, _u32, _u32, C.c_int, _u32, _u32, _u8]
+        L.sbo_overlap_key.restype = None
+        L.sbo_exonbin_batch.argtypes = [_i64, _i64, _u32, _u32, _i64, _u32, _u32, C.c_int64, _p(np.int32, flags="C"),
+                                        _i64, _u8, _u32, _u32, C.c_int32, C.c_int32, _u32, _u32]
+        L.sbo_exonbin_batch.restype = None
 
     # ---- EM
     def em_locus(self, count, F):
@@ -182,6 +190,40 @@ class OracleLib:
         return self.L.sbo_bin_weight(len(s), s, nimp, m, int(iso_len), int(rl), C.byref(ins))
 
 
+    # ---- exon-bin assignment, integer part
+    def is_compatible(self, code, left, right, exon_left, exon_right):
+        code = np.ascontiguousarray(code, np.uint8)
+        return bool(self.L.sbo_is_compatible(len(code), code, np.ascontiguousarray(left, np.uint32),
+                                             np.ascontiguousarray(right, np.uint32), len(exon_left),
+                                             np.ascontiguousarray(exon_left, np.uint32),
+                                             np.ascontiguousarray(exon_right, np.uint32)))
+
+    def overlap_key(self, code, left, right, seg_left, seg_right):
+        code = np.ascontiguousarray(code, np.uint8)
+        out = np.zeros(max(1, len(seg_left)), np.uint8)
+        self.L.sbo_overlap_key(len(code), code, np.ascontiguousarray(left, np.uint32),
+                               np.ascontiguousarray(right, np.uint32), len(seg_left),
+                               np.ascontiguousarray(seg_left, np.uint32), np.ascontiguousarray(seg_right, np.uint32), out)
+        return out[:len(seg_left)]
+
+
+    def exonbin_batch(self, annot, hits, compat_words=None, key_words=None):
+        """(compat, key) words for every hit; annot / hits carry the arrays of include/sbgpu.h's
+        sbgpu_annotation_t / sbgpu_hits_t as numpy attributes of the same names."""
+        cw = compat_words or annot.compat_words
+        kw = key_words or annot.key_words
+        compat = np.zeros((max(hits.n_hits, 1), cw), np.uint32)
+        key = np.zeros((max(hits.n_hits, 1), kw), np.uint32)
+        pad = lambda a, t: np.ascontiguousarray(a if len(a) else np.zeros(1, t), t)  # noqa: E731
+        self.L.sbo_exonbin_batch(
+            pad(annot.iso_off, np.int64), pad(annot.exon_off, np.int64), pad(annot.exon_left, np.uint32),
+            pad(annot.exon_right, np.uint32), pad(annot.seg_off, np.int64), pad(annot.seg_left, np.uint32),
+            pad(annot.seg_right, np.uint32), hits.n_hits, pad(hits.hit_locus, np.int32), pad(hits.feat_off, np.int64),
+            pad(hits.feat_code, np.uint8), pad(hits.feat_left, np.uint32), pad(hits.feat_right, np.uint32), cw, kw,
+            compat.reshape(-1), key.reshape(-1))
+        return compat[:hits.n_hits], key[:hits.n_hits]
+
+
 class RefLib:
     """oracle/_ref/libstrawberry_ref.so -- the reference's own objects behind ref_shim.cpp."""
 
@@ -200,6 +242,45 @@ class RefLib:
         L.ref_bin_weight.argtypes = [C.c_int, _u32, C.c_int, _u32, C.c_int, C.c_int, C.c_double, C.c_double,
                                      C.c_int, _i32]
         L.ref_bin_weight.restype = C.c_double
+        _u8 = _p(np.uint8, flags="C")
+        L.ref_is_compatible.argtypes = [C.c_int, _i32, _u32, _i32, C.c_int, _i32, _u32, _i32]
+        L.ref_is_compatible.restype = C.c_int
+        L.ref_overlap_key.argtypes = [C.c_int, _i32, _u32, _i32, C.c_int, _u32, _u32, _u8]
+        L.ref_overlap_key.restype = None
+        L.ref_pairedhit_features.argtypes = [C.c_int, _u32, _u32, C.c_int, _u32, _u32, _i32, _u32, _u32]
+        L.ref_pairedhit_features.restype = C.c_int
+
+    def is_compatible(self, code, left, right, exon_left, exon_right):
+        """Contig::is_compatible on Contigs built from flat features; the isoform from its exons."""
+        rc = np.ascontiguousarray(code, np.int32)
+        rl = np.ascontiguousarray(left, np.uint32)
+        rn = np.ascontiguousarray(np.asarray(right, np.int64) - np.asarray(left, np.int64) + 1, np.int32)
+        ic, il, iln = [], [], []
+        for k in range(len(exon_left)):
+            if k:
+                ic.append(1); il.append(exon_right[k - 1] + 1); iln.append(exon_left[k] - exon_right[k - 1] - 1)
+            ic.append(0); il.append(exon_left[k]); iln.append(exon_right[k] - exon_left[k] + 1)
+        return bool(self.L.ref_is_compatible(len(rc), rc, rl, rn, len(ic), np.ascontiguousarray(ic, np.int32),
+                                             np.ascontiguousarray(il, np.uint32), np.ascontiguousarray(iln, np.int32)))
+
+    def pairedhit_features(self, left_blocks, right_blocks):
+        """Contig(PairedHit) from the mates' aligned blocks -> (code, left, right) lists or None."""
+        def arr(blocks, k):
+            return np.ascontiguousarray([b[k] for b in blocks] or [0], np.uint32)
+        cap = 2 * (len(left_blocks) + len(right_blocks)) + 2
+        oc, ol, orr = np.zeros(cap, np.int32), np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
+        n = self.L.ref_pairedhit_features(len(left_blocks), arr(left_blocks, 0), arr(left_blocks, 1), len(right_blocks),
+                                          arr(right_blocks, 0), arr(right_blocks, 1), oc, ol, orr)
+        return None if n == 0 else (oc[:n].tolist(), ol[:n].tolist(), orr[:n].tolist())
+
+    def overlap_key(self, code, left, right, seg_left, seg_right):
+        rc = np.ascontiguousarray(code, np.int32)
+        rl = np.ascontiguousarray(left, np.uint32)
+        rn = np.ascontiguousarray(np.asarray(right, np.int64) - np.asarray(left, np.int64) + 1, np.int32)
+        out = np.zeros(max(1, len(seg_left)), np.uint8)
+        self.L.ref_overlap_key(len(rc), rc, rl, rn, len(seg_left), np.ascontiguousarray(seg_left, np.uint32),
+                               np.ascontiguousarray(seg_right, np.uint32), out)
+        return out[:len(seg_left)]
 
     def em_locus(self, count, F):
         """-> (theta, init_ok, run_ok) from the reference's EmSolver."""

@@ -116,4 +116,73 @@ double ref_bin_weight(int nseg, const uint32_t *seg_lens, int nimp,
    return weight;
 }
 
+/* ---- exon-bin assignment, integer part ---------------------------
+ * Contig::is_compatible(read, isoform), src/contig.cpp:547-599, on Contigs built with the
+ * reference's own public constructor (include/contig.h:165-182) from flat feature lists
+ * (code 0 MATCH / 1 INTRON / 2 GAP, left, length).                                       */
+static Contig make_contig(int n, const int32_t *code, const uint32_t *left, const int32_t *len, bool is_ref)
+{
+   std::vector<GenomicFeature> feats;
+   for (int k = 0; k < n; ++k) feats.push_back(GenomicFeature((Match_t)code[k], left[k], len[k]));
+   return Contig(0, 1, Strand_t::StrandPlus, 1.0, feats, is_ref);
+}
+
+int ref_is_compatible(int n_read, const int32_t *rcode, const uint32_t *rleft, const int32_t *rlen,
+                      int n_iso, const int32_t *icode, const uint32_t *ileft, const int32_t *ilen)
+{
+   Contig read = make_contig(n_read, rcode, rleft, rlen, false);
+   Contig iso = make_contig(n_iso, icode, ileft, ilen, true);
+   return Contig::is_compatible(read, iso) ? 1 : 0;
+}
+
+/* Bin key of a read: which disjoint exon segments any of its MATCH blocks overlaps --
+ * the double loop of LocusContext::overlap_exons (src/estimate.cpp:115-131, a member that
+ * needs a whole LocusContext, so its loop is re-driven here) over the reference's
+ * GenomicFeature::overlaps (src/contig.cpp:98-102).  key_out[k] = 1 if segment k is in. */
+void ref_overlap_key(int n_read, const int32_t *rcode, const uint32_t *rleft, const int32_t *rlen,
+                     int n_seg, const uint32_t *sleft, const uint32_t *sright, uint8_t *key_out)
+{
+   for (int k = 0; k < n_seg; ++k) {
+      GenomicFeature seg(Match_t::S_MATCH, sleft[k], (int)(sright[k] - sleft[k] + 1));
+      key_out[k] = 0;
+      for (int f = 0; f < n_read; ++f) {
+         if (rcode[f] != 0) continue;
+         GenomicFeature rf(Match_t::S_MATCH, rleft[f], rlen[f]);
+         if (GenomicFeature::overlaps(rf, seg)) key_out[k] = 1;
+      }
+   }
+}
+
+/* Contig::Contig(const PairedHit&), src/contig.cpp:216-267, on ReadHits built with the
+ * reference's public constructor (include/read.hpp:89-100) from aligned blocks (an M/N CIGAR).
+ * Returns the number of features (0: the reference marks the pair incompatible, ref_id -1). */
+static ReadHitPtr make_readhit(int n, const uint32_t *bl, const uint32_t *br, uint32_t flag)
+{
+   std::vector<CigarOp> cig;
+   for (int k = 0; k < n; ++k) {
+      if (k) cig.push_back(CigarOp(REF_SKIP, bl[k] - br[k - 1] - 1));
+      cig.push_back(CigarOp(MATCH, br[k] - bl[k] + 1));
+   }
+   GenomicInterval iv(0, bl[0], br[n - 1], Strand_t::StrandPlus);
+   return ReadHitPtr(new ReadHit(1, "r", iv, cig, 0, 0, 0, 1, flag, 1.0, NULL));
+}
+
+int ref_pairedhit_features(int n_left, const uint32_t *ll, const uint32_t *lr, int n_right, const uint32_t *rl,
+                           const uint32_t *rr, int32_t *code_out, uint32_t *left_out, uint32_t *right_out)
+{
+   ReadHitPtr L = n_left ? make_readhit(n_left, ll, lr, 99) : ReadHitPtr();
+   ReadHitPtr R = n_right ? make_readhit(n_right, rl, rr, 147) : ReadHitPtr();
+   PairedHit ph(L, R);
+   Contig c(ph);
+   if (c.ref_id() == -1) return 0;
+   int n = 0;
+   for (const auto &f : c._genomic_feats) {
+      code_out[n] = (int32_t)f._match_op._code;
+      left_out[n] = f.left();
+      right_out[n] = f.right();
+      ++n;
+   }
+   return n;
+}
+
 } /* extern "C" */

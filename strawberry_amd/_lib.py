@@ -19,6 +19,8 @@ SYMBOLS = [
     "sbgpu_device_info", "sbgpu_synchronize", "sbgpu_plan_create", "sbgpu_plan_destroy", "sbgpu_plan_info",
     "sbgpu_plan_classes", "sbgpu_plan_locus_kinds", "sbgpu_em_run_device", "sbgpu_em_last_kernel_ms",
     "sbgpu_insert_pdf_table", "sbgpu_binweight_device", "sbgpu_binweight_host",
+    "sbgpu_exonbin_device", "sbgpu_exonbin_host", "sbgpu_segments_host", "sbgpu_hit_features",
+    "sbgpu_bins_create", "sbgpu_bins_destroy", "sbgpu_bins_info", "sbgpu_bins_export",
     "sbgpu_format_value", "sbgpu_format_gtf_transcript", "sbgpu_em_batch", "sbgpu_abundance_device", "sbgpu_tpm_device",
 ]
 
@@ -60,6 +62,30 @@ class sbgpu_insert_t(C.Structure):
         ("emp_hist", C.POINTER(C.c_double)),
         ("read_len", C.c_int32),
         ("long_read", C.c_int32),
+    ]
+
+
+class sbgpu_annotation_t(C.Structure):
+    _fields_ = [
+        ("n_loci", C.c_int64),
+        ("iso_off", C.c_void_p),
+        ("exon_off", C.c_void_p),
+        ("exon_left", C.c_void_p),
+        ("exon_right", C.c_void_p),
+        ("seg_off", C.c_void_p),
+        ("seg_left", C.c_void_p),
+        ("seg_right", C.c_void_p),
+    ]
+
+
+class sbgpu_hits_t(C.Structure):
+    _fields_ = [
+        ("n_hits", C.c_int64),
+        ("hit_locus", C.c_void_p),
+        ("feat_off", C.c_void_p),
+        ("feat_code", C.c_void_p),
+        ("feat_left", C.c_void_p),
+        ("feat_right", C.c_void_p),
     ]
 
 
@@ -110,6 +136,19 @@ def load():
     L.sbgpu_insert_pdf_table.argtypes = [C.POINTER(sbgpu_insert_t), C.c_int32, vp]
     L.sbgpu_binweight_device.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32,
                                          C.c_int32, vp, vp]
+    L.sbgpu_exonbin_device.argtypes = [vp, C.POINTER(sbgpu_annotation_t), C.POINTER(sbgpu_hits_t), C.c_int32, C.c_int32,
+                                       vp, vp, vp]
+    L.sbgpu_exonbin_host.argtypes = [vp, C.POINTER(sbgpu_annotation_t), C.POINTER(sbgpu_hits_t), C.c_int32, C.c_int32,
+                                     vp, vp]
+    L.sbgpu_segments_host.argtypes = [C.c_int64, vp, vp, vp, vp, vp, vp, vp, C.c_int64]
+    L.sbgpu_segments_host.restype = C.c_int64
+    L.sbgpu_hit_features.argtypes = [C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
+    L.sbgpu_bins_create.argtypes = [C.POINTER(sbgpu_annotation_t), C.POINTER(sbgpu_hits_t), vp, C.c_int32, C.c_int32,
+                                    vp, vp, C.POINTER(vp)]
+    L.sbgpu_bins_destroy.argtypes = [vp]
+    L.sbgpu_bins_destroy.restype = None
+    L.sbgpu_bins_info.argtypes = [vp, i64p]
+    L.sbgpu_bins_export.argtypes = [vp] * 14
     L.sbgpu_format_value.argtypes = [C.c_double, C.c_char_p]
     L.sbgpu_format_gtf_transcript.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_char, C.c_char_p, C.c_char_p,
                                               C.c_char_p, C.c_char_p, C.c_int, vp, vp, C.c_double, C.c_double,

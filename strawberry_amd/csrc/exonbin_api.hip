@@ -1,0 +1,154 @@
+// strawberry_amd/csrc/exonbin_api.hip -- sbgpu_exonbin_device / sbgpu_exonbin_host
+// (include/sbgpu.h): launch of the per-hit compatibility + bin-key kernel.
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "../../include/sbgpu.h"
+#include "api_internal.h"
+#include "exonbin_device.h"
+
+using sb::api_fail;
+
+extern "C" {
+
+int sbgpu_exonbin_device(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgpu_hits_t *hits,
+                         int32_t compat_words, int32_t key_words, uint32_t *d_compat, uint32_t *d_key,
+                         void *stream)
+{
+   if (!c || !an || !hits) return api_fail(SBGPU_EINVAL, "sbgpu_exonbin_device: null argument");
+   if (hits->n_hits == 0) return SBGPU_OK;
+   if (hits->n_hits < 0 || an->n_loci < 1 || compat_words < 0 || key_words < 0)
+      return api_fail(SBGPU_EINVAL, "sbgpu_exonbin_device: bad counts");
+   if (!an->iso_off || !an->exon_off || !an->seg_off || !hits->hit_locus || !hits->feat_off ||
+       (compat_words && !d_compat) || (key_words && !d_key))
+      return api_fail(SBGPU_EINVAL, "sbgpu_exonbin_device: null device pointer");
+   sb::ExonBinArgs a;
+   a.iso_off = an->iso_off;
+   a.exon_off = an->exon_off;
+   a.exon_left = an->exon_left;
+   a.exon_right = an->exon_right;
+   a.seg_off = an->seg_off;
+   a.seg_left = an->seg_left;
+   a.seg_right = an->seg_right;
+   a.n_hits = hits->n_hits;
+   a.hit_locus = hits->hit_locus;
+   a.feat_off = hits->feat_off;
+   a.feat_code = hits->feat_code;
+   a.feat_left = hits->feat_left;
+   a.feat_right = hits->feat_right;
+   a.compat_words = compat_words;
+   a.key_words = key_words;
+   a.compat = d_compat;
+   a.key = d_key;
+   const int64_t blocks_wanted = (hits->n_hits + 255) / 256;
+   const int64_t cap = (int64_t)sb::ctx_cu_count(c) * 32;
+   const unsigned grid = (unsigned)(blocks_wanted < cap ? blocks_wanted : cap);
+   hipLaunchKernelGGL(sb::exonbin_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+   hipError_t e = hipGetLastError();
+   if (e != hipSuccess) return api_fail(SBGPU_EHIP, std::string("exonbin_kernel: ") + hipGetErrorString(e));
+   return SBGPU_OK;
+}
+
+int sbgpu_exonbin_host(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgpu_hits_t *hits,
+                       int32_t compat_words, int32_t key_words, uint32_t *compat_out, uint32_t *key_out)
+{
+   if (!c || !an || !hits) return api_fail(SBGPU_EINVAL, "sbgpu_exonbin_host: null argument");
+   const int64_t nh = hits->n_hits, nl = an->n_loci;
+   if (nh == 0) return SBGPU_OK;
+   if (nh < 0 || nl < 1 || compat_words < 0 || key_words < 0)
+      return api_fail(SBGPU_EINVAL, "sbgpu_exonbin_host: bad counts");
+   if (!an->iso_off || !an->exon_off || !an->seg_off || !hits->hit_locus || !hits->feat_off ||
+       (compat_words && !compat_out) || (key_words && !key_out))
+      return api_fail(SBGPU_EINVAL, "sbgpu_exonbin_host: null argument");
+   // ---- validate the CSR structure (the device form trusts it)
+   if (an->iso_off[0] != 0 || an->exon_off[0] != 0 || an->seg_off[0] != 0 || hits->feat_off[0] != 0)
+      return api_fail(SBGPU_EINVAL, "sbgpu_exonbin_host: offsets must start at 0");
+   for (int64_t l = 0; l < nl; ++l) {
+      const int64_t ni = an->iso_off[l + 1] - an->iso_off[l], ns = an->seg_off[l + 1] - an->seg_off[l];
+      if (ni < 0 || ns < 0) return api_fail(SBGPU_EINVAL, "sbgpu_exonbin_host: decreasing offsets");
+      if (ni > 32 * (int64_t)compat_words)
+         return api_fail(SBGPU_ESHAPE, "sbgpu_exonbin_host: compat_words does not cover a locus' isoforms");
+      if (ns > 32 * (int64_t)key_words)
+         return api_fail(SBGPU_ESHAPE, "sbgpu_exonbin_host: key_words does not cover a locus' segments");
+   }
+   const int64_t n_iso = an->iso_off[nl], n_seg = an->seg_off[nl];
+   for (int64_t i = 0; i < n_iso; ++i)
+      if (an->exon_off[i + 1] < an->exon_off[i]) return api_fail(SBGPU_EINVAL, "sbgpu_exonbin_host: decreasing exon_off");
+   const int64_t n_exon = an->exon_off[n_iso];
+   if ((n_exon && (!an->exon_left || !an->exon_right)) || (n_seg && (!an->seg_left || !an->seg_right)))
+      return api_fail(SBGPU_EINVAL, "sbgpu_exonbin_host: null coordinate array");
+   for (int64_t h = 0; h < nh; ++h) {
+      if (hits->hit_locus[h] < 0 || hits->hit_locus[h] >= nl)
+         return api_fail(SBGPU_EINVAL, "sbgpu_exonbin_host: hit_locus out of range");
+      if (hits->feat_off[h + 1] < hits->feat_off[h]) return api_fail(SBGPU_EINVAL, "sbgpu_exonbin_host: decreasing feat_off");
+   }
+   const int64_t n_feat = hits->feat_off[nh];
+   if (n_feat && (!hits->feat_code || !hits->feat_left || !hits->feat_right))
+      return api_fail(SBGPU_EINVAL, "sbgpu_exonbin_host: null feature array");
+
+   // ---- one device arena, one upload per array
+   struct Part {
+      const void *src;
+      size_t bytes, off;
+   };
+   Part parts[] = {
+      {an->iso_off, (size_t)(nl + 1) * 8, 0},     {an->exon_off, (size_t)(n_iso + 1) * 8, 0},
+      {an->seg_off, (size_t)(nl + 1) * 8, 0},     {hits->feat_off, (size_t)(nh + 1) * 8, 0},
+      {an->exon_left, (size_t)n_exon * 4, 0},     {an->exon_right, (size_t)n_exon * 4, 0},
+      {an->seg_left, (size_t)n_seg * 4, 0},       {an->seg_right, (size_t)n_seg * 4, 0},
+      {hits->hit_locus, (size_t)nh * 4, 0},       {hits->feat_left, (size_t)n_feat * 4, 0},
+      {hits->feat_right, (size_t)n_feat * 4, 0},  {hits->feat_code, (size_t)n_feat, 0},
+   };
+   size_t total = 0;
+   for (Part &p : parts) {
+      p.off = total;
+      total += (p.bytes + 255) & ~(size_t)255;
+   }
+   const size_t off_compat = total;
+   total += (((size_t)nh * compat_words * 4) + 255) & ~(size_t)255;
+   const size_t off_key = total;
+   total += (((size_t)nh * key_words * 4) + 255) & ~(size_t)255;
+   char *d = nullptr;
+   hipError_t e = hipMalloc(&d, total ? total : 256);
+   if (e != hipSuccess)
+      return api_fail(e == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+   hipStream_t s = sb::ctx_stream(c);
+   auto bail = [&](hipError_t err, const char *what) {
+      (void)hipFree(d);
+      return api_fail(SBGPU_EHIP, std::string(what) + ": " + hipGetErrorString(err));
+   };
+   for (Part &p : parts)
+      if (p.bytes && (e = hipMemcpyAsync(d + p.off, p.src, p.bytes, hipMemcpyHostToDevice, s)) != hipSuccess)
+         return bail(e, "hipMemcpyAsync(H2D)");
+   sbgpu_annotation_t dan = *an;
+   dan.iso_off = (const int64_t *)(d + parts[0].off);
+   dan.exon_off = (const int64_t *)(d + parts[1].off);
+   dan.seg_off = (const int64_t *)(d + parts[2].off);
+   dan.exon_left = (const uint32_t *)(d + parts[4].off);
+   dan.exon_right = (const uint32_t *)(d + parts[5].off);
+   dan.seg_left = (const uint32_t *)(d + parts[6].off);
+   dan.seg_right = (const uint32_t *)(d + parts[7].off);
+   sbgpu_hits_t dh = *hits;
+   dh.feat_off = (const int64_t *)(d + parts[3].off);
+   dh.hit_locus = (const int32_t *)(d + parts[8].off);
+   dh.feat_left = (const uint32_t *)(d + parts[9].off);
+   dh.feat_right = (const uint32_t *)(d + parts[10].off);
+   dh.feat_code = (const uint8_t *)(d + parts[11].off);
+   int rc = sbgpu_exonbin_device(c, &dan, &dh, compat_words, key_words, (uint32_t *)(d + off_compat),
+                                 (uint32_t *)(d + off_key), s);
+   if (rc != SBGPU_OK) {
+      (void)hipFree(d);
+      return rc;
+   }
+   if (compat_words &&
+       (e = hipMemcpyAsync(compat_out, d + off_compat, (size_t)nh * compat_words * 4, hipMemcpyDeviceToHost, s)) != hipSuccess)
+      return bail(e, "hipMemcpyAsync(D2H compat)");
+   if (key_words && (e = hipMemcpyAsync(key_out, d + off_key, (size_t)nh * key_words * 4, hipMemcpyDeviceToHost, s)) != hipSuccess)
+      return bail(e, "hipMemcpyAsync(D2H key)");
+   if ((e = hipStreamSynchronize(s)) != hipSuccess) return bail(e, "hipStreamSynchronize");
+   (void)hipFree(d);
+   return SBGPU_OK;
+}
+
+} // extern "C"

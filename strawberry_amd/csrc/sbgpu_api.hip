@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/sbgpu.h"
+#include "api_internal.h"
 #include "binweight_device.h"
 #include "em_device.h"
 #include "plan.h"
@@ -55,6 +56,12 @@ struct sbgpu_ctx {
    hipEvent_t t0[sb::kNumKinds] = {}, t1[sb::kNumKinds] = {}; // per-kind kernel timing
    bool timed[sb::kNumKinds] = {};
 };
+
+namespace sb {
+int api_fail(int code, const std::string &msg) { return fail(code, msg); }
+hipStream_t ctx_stream(const sbgpu_ctx_t *ctx) { return ctx->stream; }
+int ctx_cu_count(const sbgpu_ctx_t *ctx) { return ctx->n_cu; }
+} // namespace sb
 
 struct KindLaunch {
    int first_class = 0, n_classes = 0; // range in plan->host.classes

@@ -113,7 +113,9 @@ class Plan:
 class EmBatchSolver:
     """Device-resident batch: upload once, run the EM (and epilogue) many times."""
 
-    def __init__(self, batch, ctx=None, device=0):
+    def __init__(self, batch, ctx=None, device=0, d_F=None):
+        """d_F: F already on the device (float64[f_off[-1]], e.g. written by the bin-weight
+        kernel); batch.F is not read then."""
         torch = _torch()
         self.torch = torch
         self.ctx = ctx or default_context(device)
@@ -122,7 +124,7 @@ class EmBatchSolver:
         self.plan = Plan(self.ctx, batch.row_off, batch.iso_off, batch.f_off)
         n, n_iso = batch.n_loci, int(batch.iso_off[-1])
         self.d_count = torch.from_numpy(np.ascontiguousarray(batch.count, np.int32)).to(self.dev)
-        self.d_F = torch.from_numpy(np.ascontiguousarray(batch.F, np.float64)).to(self.dev)
+        self.d_F = d_F if d_F is not None else torch.from_numpy(np.ascontiguousarray(batch.F, np.float64)).to(self.dev)
         self.d_length = torch.from_numpy(np.ascontiguousarray(batch.length, np.int32)).to(self.dev)
         self.d_theta = torch.zeros(max(n_iso, 1), dtype=torch.float64, device=self.dev)
         self.d_status = torch.full((max(n, 1),), -1, dtype=torch.int32, device=self.dev)

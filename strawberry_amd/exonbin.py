@@ -1,0 +1,194 @@
+"""Host-side mirror of the reference's exon-bin assignment.
+
+Reference: LocusContext's constructor and assign_exon_bin, /root/reference/include/estimate.hpp:60-103
+and src/estimate.cpp:135-198.  The interval tests (Contig::is_compatible, overlap_exons) run in
+the HIP kernel behind sbgpu_exonbin_host / sbgpu_exonbin_device; the map/set bookkeeping around
+them is the C++ host code of libsbgpu.so (csrc/locus_bins.cpp).  Nothing here computes results in
+Python and nothing falls back to the CPU for the kernel's part.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .em import default_context
+
+MATCH, INTRON, GAP = 0, 1, 2
+
+
+def _ptr(a):
+    return a.ctypes.data if a.size else None
+
+
+class Annotation:
+    """Loci -> isoforms -> exons (closed, sorted) and the loci's disjoint exon segments."""
+
+    def __init__(self, loci):
+        """loci: list (per locus) of lists (per isoform) of (left, right) exons."""
+        iso_off, exon_off, xl, xr = [0], [0], [], []
+        for isos in loci:
+            for exons in isos:
+                for (a, b) in exons:
+                    xl.append(a)
+                    xr.append(b)
+                exon_off.append(len(xl))
+            iso_off.append(len(exon_off) - 1)
+        self.n_loci = len(loci)
+        self.iso_off = np.asarray(iso_off, np.int64)
+        self.exon_off = np.asarray(exon_off, np.int64)
+        self.exon_left = np.asarray(xl, np.uint32)
+        self.exon_right = np.asarray(xr, np.uint32)
+        L = _lib.load()
+        self.seg_off = np.zeros(self.n_loci + 1, np.int64)
+        n = L.sbgpu_segments_host(self.n_loci, _ptr(self.iso_off), _ptr(self.exon_off), _ptr(self.exon_left),
+                                  _ptr(self.exon_right), _ptr(self.seg_off), None, None, 0)
+        if n < 0:
+            _lib.check(int(n), "sbgpu_segments_host")
+        self.seg_left = np.zeros(n, np.uint32)
+        self.seg_right = np.zeros(n, np.uint32)
+        n2 = L.sbgpu_segments_host(self.n_loci, _ptr(self.iso_off), _ptr(self.exon_off), _ptr(self.exon_left),
+                                   _ptr(self.exon_right), _ptr(self.seg_off), _ptr(self.seg_left), _ptr(self.seg_right), n)
+        assert n2 == n
+        self.compat_words = max(1, int(-(-np.diff(self.iso_off).max(initial=0) // 32)))
+        self.key_words = max(1, int(-(-np.diff(self.seg_off).max(initial=0) // 32)))
+
+    def segments(self, locus):
+        s = slice(self.seg_off[locus], self.seg_off[locus + 1])
+        return list(zip(self.seg_left[s].tolist(), self.seg_right[s].tolist()))
+
+    def _struct(self):
+        s = _lib.sbgpu_annotation_t()
+        s.n_loci = self.n_loci
+        s.iso_off, s.exon_off, s.seg_off = _ptr(self.iso_off), _ptr(self.exon_off), _ptr(self.seg_off)
+        s.exon_left, s.exon_right = _ptr(self.exon_left), _ptr(self.exon_right)
+        s.seg_left, s.seg_right = _ptr(self.seg_left), _ptr(self.seg_right)
+        return s
+
+
+def mate_features(blocks):
+    """A mate's aligned blocks [(l, r), ...] -> (code, left, right) with the introns between them
+    (readhit_2_genomicFeats for an M/N CIGAR, src/contig.cpp:12-53)."""
+    code, left, right = [], [], []
+    for k, (a, b) in enumerate(blocks):
+        if k:
+            code.append(INTRON)
+            left.append(blocks[k - 1][1] + 1)
+            right.append(a - 1)
+        code.append(MATCH)
+        left.append(a)
+        right.append(b)
+    return code, left, right
+
+
+def hit_features(left_blocks, right_blocks):
+    """Contig(PairedHit): -> (code, left, right) lists, or None when the reference rejects the pair."""
+    L = _lib.load()
+    lc, ll, lr = (np.asarray(x, t) for x, t in zip(mate_features(left_blocks), (np.uint8, np.uint32, np.uint32)))
+    rc, rl, rr = (np.asarray(x, t) for x, t in zip(mate_features(right_blocks), (np.uint8, np.uint32, np.uint32)))
+    cap = len(lc) + len(rc) + 1
+    oc, ol, orr = np.zeros(cap, np.uint8), np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
+    n = L.sbgpu_hit_features(len(lc), _ptr(lc), _ptr(ll), _ptr(lr), len(rc), _ptr(rc), _ptr(rl), _ptr(rr),
+                             oc.ctypes.data, ol.ctypes.data, orr.ctypes.data)
+    if n < 0:
+        _lib.check(n, "sbgpu_hit_features")
+    if n == 0:
+        return None
+    return oc[:n].tolist(), ol[:n].tolist(), orr[:n].tolist()
+
+
+class Hits:
+    """Fragments of a batch of loci, CSR over features; `mass` = (float) collapse_mass."""
+
+    def __init__(self, hit_locus, feats, mass=None):
+        """feats: per hit (code, left, right) lists."""
+        self.n_hits = len(feats)
+        self.hit_locus = np.asarray(hit_locus, np.int32)
+        off = np.zeros(self.n_hits + 1, np.int64)
+        for h, f in enumerate(feats):
+            off[h + 1] = off[h] + len(f[0])
+        self.feat_off = off
+        self.feat_code = np.asarray([c for f in feats for c in f[0]], np.uint8)
+        self.feat_left = np.asarray([c for f in feats for c in f[1]], np.uint32)
+        self.feat_right = np.asarray([c for f in feats for c in f[2]], np.uint32)
+        self.mass = np.ones(self.n_hits, np.float32) if mass is None else np.asarray(mass, np.float32)
+
+    @classmethod
+    def from_arrays(cls, hit_locus, feat_off, feat_code, feat_left, feat_right, mass=None):
+        self = cls.__new__(cls)
+        self.n_hits = len(hit_locus)
+        self.hit_locus = np.ascontiguousarray(hit_locus, np.int32)
+        self.feat_off = np.ascontiguousarray(feat_off, np.int64)
+        self.feat_code = np.ascontiguousarray(feat_code, np.uint8)
+        self.feat_left = np.ascontiguousarray(feat_left, np.uint32)
+        self.feat_right = np.ascontiguousarray(feat_right, np.uint32)
+        self.mass = np.ones(self.n_hits, np.float32) if mass is None else np.ascontiguousarray(mass, np.float32)
+        return self
+
+    def _struct(self):
+        s = _lib.sbgpu_hits_t()
+        s.n_hits = self.n_hits
+        s.hit_locus, s.feat_off = _ptr(self.hit_locus), _ptr(self.feat_off)
+        s.feat_code, s.feat_left, s.feat_right = _ptr(self.feat_code), _ptr(self.feat_left), _ptr(self.feat_right)
+        return s
+
+
+def compat_and_keys(annot, hits, ctx=None, device=0, compat_words=None, key_words=None):
+    """-> (compat [n_hits, compat_words] uint32, key [n_hits, key_words] uint32) from the HIP kernel."""
+    ctx = ctx or default_context(device)
+    cw = annot.compat_words if compat_words is None else compat_words
+    kw = annot.key_words if key_words is None else key_words
+    compat = np.zeros((max(hits.n_hits, 1), max(cw, 1)), np.uint32)
+    key = np.zeros((max(hits.n_hits, 1), max(kw, 1)), np.uint32)
+    a, h = annot._struct(), hits._struct()
+    _lib.check(ctx.L.sbgpu_exonbin_host(ctx.h, C.byref(a), C.byref(h), cw, kw, compat.ctypes.data, key.ctypes.data),
+               "sbgpu_exonbin_host")
+    return compat[:hits.n_hits, :cw], key[:hits.n_hits, :kw]
+
+
+class LocusBins:
+    """The exon bins of a batch of loci: an EM batch minus F, and the bin-weight kernel's pairs."""
+
+    def __init__(self, annot, hits, compat, key):
+        L = _lib.load()
+        compat = np.ascontiguousarray(compat, np.uint32)
+        key = np.ascontiguousarray(key, np.uint32)
+        cw = compat.shape[1] if compat.ndim == 2 else annot.compat_words
+        kw = key.shape[1] if key.ndim == 2 else annot.key_words
+        a, h = annot._struct(), hits._struct()
+        handle = C.c_void_p()
+        _lib.check(L.sbgpu_bins_create(C.byref(a), C.byref(h), _ptr(hits.mass), cw, kw, _ptr(compat), _ptr(key),
+                                       C.byref(handle)), "sbgpu_bins_create")
+        try:
+            info = (C.c_int64 * 8)()
+            _lib.check(L.sbgpu_bins_info(handle, info), "sbgpu_bins_info")
+            (self.n_loci, self.n_iso, self.n_bins, self.n_elem, self.n_pairs, n_pair_segs, self.n_hits_used, _) = list(info)
+            self.row_off = np.zeros(self.n_loci + 1, np.int64)
+            self.iso_off = np.zeros(self.n_loci + 1, np.int64)
+            self.f_off = np.zeros(self.n_loci + 1, np.int64)
+            self.count = np.zeros(self.n_bins, np.int32)
+            self.iso_len = np.zeros(self.n_iso, np.int32)
+            self.bin_key = np.zeros((self.n_bins, kw), np.uint32)
+            self.bin_compat = np.zeros((self.n_bins, cw), np.uint32)
+            self.hit_bin = np.zeros(hits.n_hits, np.int64)
+            self.pair_seg_off = np.zeros(self.n_pairs + 1, np.int64)
+            self.pair_seg_lens = np.zeros(n_pair_segs, np.uint32)
+            self.pair_implicit_mask = np.zeros(self.n_pairs, np.uint32)
+            self.pair_iso_len = np.zeros(self.n_pairs, np.int32)
+            self.pair_out_index = np.zeros(self.n_pairs, np.int64)
+            _lib.check(L.sbgpu_bins_export(
+                handle, _ptr(self.row_off), _ptr(self.iso_off), _ptr(self.f_off), _ptr(self.count), _ptr(self.iso_len),
+                _ptr(self.bin_key), _ptr(self.bin_compat), _ptr(self.hit_bin), _ptr(self.pair_seg_off),
+                _ptr(self.pair_seg_lens), _ptr(self.pair_implicit_mask), _ptr(self.pair_iso_len),
+                _ptr(self.pair_out_index)), "sbgpu_bins_export")
+        finally:
+            L.sbgpu_bins_destroy(handle)
+        self._annot = annot
+
+    def bin_coords(self, locus):
+        """Per bin of the locus, the segments it spans [(l, r), ...] (ExonBin::_coords)."""
+        segs = self._annot.segments(locus)
+        out = []
+        for b in range(self.row_off[locus], self.row_off[locus + 1]):
+            words = self.bin_key[b]
+            out.append([s for k, s in enumerate(segs) if (int(words[k >> 5]) >> (k & 31)) & 1])
+        return out

@@ -1,0 +1,95 @@
+"""Fragments -> abundances for a batch of loci: the device-resident chain behind
+LocusContext's constructor + estimate_abundances (/root/reference/include/estimate.hpp:60-103,
+src/estimate.cpp:279-355) as Sample::quantifyCluster drives them (src/alignments.cpp:1505-1546).
+
+    hits --exonbin kernel--> compat/key words --host bookkeeping--> bins, counts, (bin, isoform) pairs
+         --bin-weight kernel--> F (written straight into the EM batch) --EM kernels--> theta
+         --epilogue kernels--> FPKM / Frac / TPM
+
+torch holds the device buffers; every number is produced by libsbgpu.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .binweight import InsertSize  # noqa: F401  (re-exported: the caller builds one)
+from .em import EmBatchSolver, _torch, default_context
+from .exonbin import LocusBins
+from .synth import LocusBatch
+
+
+class LocusQuantifier:
+    def __init__(self, annot, hits, insert, read_len, long_read=False, ctx=None, device=0):
+        self.torch = torch = _torch()
+        self.ctx = ctx or default_context(device)
+        self.dev = torch.device("cuda", self.ctx.device)
+        self.annot, self.hits = annot, hits
+        self.insert, self.read_len, self.long_read = insert, int(read_len), bool(long_read)
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)  # noqa: E731
+        # device copies of the kernel inputs (uint32 travels as int32 bit patterns)
+        self._d = {k: up(getattr(annot, k).view(np.int32) if getattr(annot, k).dtype == np.uint32 else getattr(annot, k))
+                   for k in ("iso_off", "exon_off", "exon_left", "exon_right", "seg_off", "seg_left", "seg_right")}
+        self._d.update({k: up(getattr(hits, k).view(np.int32) if getattr(hits, k).dtype == np.uint32 else getattr(hits, k))
+                        for k in ("hit_locus", "feat_off", "feat_code", "feat_left", "feat_right")})
+        self.bins = None
+        self.solver = None
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def _p(self, name):
+        t = self._d[name]
+        return t.data_ptr() if t.numel() else None
+
+    def assign_bins(self):
+        """A5: kernel for the interval tests, then the host bookkeeping.  -> LocusBins"""
+        torch, a, h = self.torch, self.annot, self.hits
+        cw, kw = a.compat_words, a.key_words
+        self.d_compat = torch.zeros((max(h.n_hits, 1), cw), dtype=torch.int32, device=self.dev)
+        self.d_key = torch.zeros((max(h.n_hits, 1), kw), dtype=torch.int32, device=self.dev)
+        an = _lib.sbgpu_annotation_t(a.n_loci, self._p("iso_off"), self._p("exon_off"), self._p("exon_left"),
+                                     self._p("exon_right"), self._p("seg_off"), self._p("seg_left"), self._p("seg_right"))
+        ht = _lib.sbgpu_hits_t(h.n_hits, self._p("hit_locus"), self._p("feat_off"), self._p("feat_code"),
+                               self._p("feat_left"), self._p("feat_right"))
+        _lib.check(self.ctx.L.sbgpu_exonbin_device(self.ctx.h, C.byref(an), C.byref(ht), cw, kw, self.d_compat.data_ptr(),
+                                                   self.d_key.data_ptr(), self._stream()), "sbgpu_exonbin_device")
+        compat = self.d_compat[:h.n_hits].cpu().numpy().view(np.uint32)
+        key = self.d_key[:h.n_hits].cpu().numpy().view(np.uint32)
+        self.bins = LocusBins(a, h, compat, key)
+        return self.bins
+
+    def bin_weights(self):
+        """A4: one weight per (bin, isoform) pair, scattered into the EM batch's F on the device."""
+        torch, b = self.torch, self.bins
+        up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(self.dev)  # noqa: E731
+        self.d_F = torch.zeros(max(b.n_elem, 1), dtype=torch.float64, device=self.dev)
+        if b.n_pairs == 0:
+            return self.d_F
+        max_l = int(np.add.reduceat(b.pair_seg_lens.astype(np.int64), b.pair_seg_off[:-1]).max())
+        pdf = self.insert.pdf_table(max_l + 1, self.read_len)
+        d_off, d_seg = up(b.pair_seg_off), up(b.pair_seg_lens.view(np.int32))
+        d_mask, d_len = up(b.pair_implicit_mask.view(np.int32)), up(b.pair_iso_len)
+        d_idx, d_pdf = up(b.pair_out_index), up(pdf)
+        lmin_base = self.insert.start_offset if self.insert.use_emp else self.read_len
+        _lib.check(self.ctx.L.sbgpu_binweight_device(
+            self.ctx.h, b.n_pairs, d_off.data_ptr(), d_seg.data_ptr(), d_mask.data_ptr(), d_len.data_ptr(),
+            d_idx.data_ptr(), d_pdf.data_ptr(), len(pdf), self.read_len, lmin_base, int(self.long_read),
+            self.d_F.data_ptr(), self._stream()), "sbgpu_binweight_device")
+        self.torch.cuda.current_stream(self.dev).synchronize()  # the inputs above go out of scope
+        return self.d_F
+
+    def solve(self, total_mapped_reads, **abundance_kw):
+        """A1-A3, A7: EM + abundance epilogue + TPM over all loci.  -> results dict (host arrays)."""
+        b = self.bins
+        batch = LocusBatch(b.row_off, b.iso_off, b.f_off, b.count, None, b.iso_len, "hits")
+        self.solver = s = EmBatchSolver(batch, self.ctx, d_F=self.d_F)
+        s.run_em()
+        s.run_abundance(total_mapped_reads, **abundance_kw)
+        s.run_tpm()
+        return s.results()
+
+    def run(self, total_mapped_reads, **abundance_kw):
+        self.assign_bins()
+        self.bin_weights()
+        return self.solve(total_mapped_reads, **abundance_kw)

@@ -211,3 +211,86 @@ def make_random(n_loci=256, max_nrow=64, max_niso=12, density=0.4, max_count=60,
         n = rng.integers(0, max_count, nrow).astype(np.int32)
         loci.append((n, F))
     return from_loci(loci, name="random")
+
+
+# ---------------------------------------------------------------------------------------------
+# Synthetic annotation + fragments for the exon-bin path (A5).  Gene models and read pairs of our
+# own making, shaped like the reference's inputs: loci of alternatively spliced isoforms, paired
+# reads sampled from them, plus fragments that fit no isoform (unspliced, shifted, novel junctions).
+def make_gene_models(n_loci, seed=7, max_exons=12, max_isoforms=6, ex_lo=60, ex_hi=400, in_lo=80, in_hi=600):
+    """-> list (per locus) of lists (per isoform) of sorted closed exons [(l, r), ...]."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    loci = []
+    pos = 1000
+    for _ in range(n_loci):
+        n_ex = int(rng.integers(1, max_exons + 1))
+        exons = []
+        for _ in range(n_ex):
+            ln = int(rng.integers(ex_lo, ex_hi + 1))
+            exons.append((pos, pos + ln - 1))
+            pos += ln + int(rng.integers(in_lo, in_hi + 1))
+        n_iso = int(rng.integers(1, max_isoforms + 1))
+        isos = []
+        seen = set()
+        for k in range(n_iso):
+            if k == 0 or n_ex < 3:
+                use = list(range(n_ex))
+            else:
+                use = [e for e in range(n_ex) if e in (0, n_ex - 1) or rng.random() < 0.7]
+            ex = [exons[e] for e in use]
+            # alternative 5'/3' ends: shorten an exon now and then (creates sub-exon segments)
+            if k and rng.random() < 0.5:
+                e = int(rng.integers(0, len(ex)))
+                a, b = ex[e]
+                cut = int(rng.integers(5, max(6, (b - a) // 2)))
+                ex[e] = (a + cut, b) if rng.random() < 0.5 else (a, b - cut)
+            if tuple(ex) in seen:
+                continue
+            seen.add(tuple(ex))
+            isos.append(ex)
+        loci.append(isos)
+        pos += 5000
+    return loci
+
+
+def _tx_blocks(ex, t0, t1):
+    """transcript interval [t0, t1) -> genomic blocks."""
+    out, off = [], 0
+    for (a, b) in ex:
+        ln = b - a + 1
+        lo, hi = max(t0, off), min(t1, off + ln)
+        if lo < hi:
+            out.append((a + lo - off, a + hi - off - 1))
+        off += ln
+    return out
+
+
+def make_fragments(loci, hits_per_locus, seed=11, read_len=75, mean=250.0, sd=30.0, noise=0.15, single=0.05):
+    """-> (hit_locus list, [(left_blocks, right_blocks), ...]) in (locus, left, right) order.
+    `noise`: share of pairs that are shifted / unspliced so that they fit fewer (or no) isoforms;
+    `single`: share of single-end fragments (right mate missing)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = []
+    for l, isos in enumerate(loci):
+        for _ in range(hits_per_locus):
+            ex = isos[int(rng.integers(0, len(isos)))]
+            L = sum(b - a + 1 for a, b in ex)
+            rl = min(read_len, L)
+            fl = int(np.clip(np.rint(rng.normal(mean, sd)), rl, L))
+            st = int(rng.integers(0, L - fl + 1))
+            left = _tx_blocks(ex, st, st + rl)
+            right = _tx_blocks(ex, st + fl - rl, st + fl)
+            u = rng.random()
+            if u < noise / 3:            # genomic (unspliced) read: runs into the intron
+                left = [(left[0][0], left[0][0] + rl - 1)]
+            elif u < 2 * noise / 3:      # shifted by a few bases: junctions no longer match
+                d = int(rng.integers(1, 9))
+                right = [(a + d, b + d) for a, b in right]
+            elif u < noise:              # novel junction: skip from the first block to the last
+                if len(right) > 1:
+                    right = [right[0], right[-1]]
+            if rng.random() < single:
+                right = []
+            out.append((l, left[0][0], (right or left)[-1][1], left, right))
+    out.sort(key=lambda r: (r[0], r[1], r[2]))
+    return [r[0] for r in out], [(r[3], r[4]) for r in out]

@@ -1,0 +1,166 @@
+"""A5 on the GPU: the exon-bin kernel (sbgpu_exonbin_host / _device) against the reference's
+answers (tests/golden/exonbin_cases.npz), against the oracle on larger seeded inputs, and the
+whole hits -> abundances chain against the reference binary's outputs (tests/golden/e2e_toy*).
+Integer work: every comparison is bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+import e2e_util as U
+import exonbin_util as XU
+from test_exonbin_oracle import GOLD, annotation_from_arrays
+
+pytestmark = pytest.mark.gpu
+
+RL, MEAN, SD = 75, 250.0, 30.0
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from strawberry_amd import em
+    return em.default_context(0)
+
+
+def test_kernel_reproduces_reference_words(ctx):
+    from strawberry_amd import exonbin as eb
+    z = dict(np.load(GOLD))
+    annot, _ = annotation_from_arrays(z)
+    hits = eb.Hits.from_arrays(z["hit_locus"], z["feat_off"], z["feat_code"], z["feat_left"], z["feat_right"])
+    compat, key = eb.compat_and_keys(annot, hits, ctx)
+    np.testing.assert_array_equal(compat, z["compat"])
+    np.testing.assert_array_equal(key, z["key"])
+
+
+def synth_case(n_loci, per_locus, seed, **kw):
+    from strawberry_amd import exonbin as eb
+    from strawberry_amd import synth
+    loci = synth.make_gene_models(n_loci, seed=seed, **{k: v for k, v in kw.items() if k.startswith(("max_", "ex_", "in_"))})
+    hl, pairs = synth.make_fragments(loci, per_locus, seed=seed + 1, **{k: v for k, v in kw.items() if not k.startswith(("max_", "ex_", "in_"))})
+    feats, loc = [], []
+    for l, (lb, rb) in zip(hl, pairs):
+        f = eb.hit_features(lb, rb)
+        if f is not None:
+            feats.append(f)
+            loc.append(l)
+    return loci, eb.Annotation(loci), eb.Hits(loc, feats)
+
+
+@pytest.mark.parametrize("name,args", [
+    ("typical", dict(n_loci=300, per_locus=150, seed=1)),
+    ("noisy_overlapping_mates", dict(n_loci=200, per_locus=100, seed=2, noise=0.5, mean=150.0, sd=15.0)),
+    ("many_blocks", dict(n_loci=60, per_locus=200, seed=3, max_exons=40, ex_lo=15, ex_hi=50, read_len=150, mean=400.0, sd=50.0)),
+    ("wide_loci", dict(n_loci=12, per_locus=300, seed=4, max_exons=60, max_isoforms=50, ex_lo=70, ex_hi=200)),
+    ("single_exon_genes", dict(n_loci=100, per_locus=50, seed=5, max_exons=1, max_isoforms=1, ex_lo=300, ex_hi=900)),
+])
+def test_kernel_matches_oracle(ctx, oracle, name, args):
+    from strawberry_amd import exonbin as eb
+    loci, annot, hits = synth_case(**args)
+    compat, key = eb.compat_and_keys(annot, hits, ctx)
+    o_compat, o_key = oracle.exonbin_batch(annot, hits)
+    np.testing.assert_array_equal(compat, o_compat)
+    np.testing.assert_array_equal(key, o_key)
+    assert hits.n_hits > 1000 and (compat != 0).any()
+    if name == "many_blocks":
+        assert np.diff(hits.feat_off).max() > 8      # the from-memory path of the kernel
+    if name == "wide_loci":
+        assert annot.compat_words > 1 or annot.key_words > 1
+
+
+def test_kernel_edge_cases(ctx, oracle):
+    from strawberry_amd import exonbin as eb
+    from strawberry_amd._lib import SbgpuError
+    annot = eb.Annotation([[[(100, 199), (300, 399)], [(100, 199), (500, 599)], []],
+                           [[(1000, 1099)]]])
+    m = lambda l, r: ([0], [l], [r])  # noqa: E731
+    feats = [m(100, 199),                       # exactly an exon
+             m(99, 150),                        # one base outside
+             ([0, 1, 0], [150, 200, 300], [199, 299, 350]),   # junction of isoform 0 only
+             ([0, 1, 0], [150, 200, 500], [199, 499, 550]),   # junction of isoform 1 only
+             ([0, 2, 0], [150, 200, 500], [199, 499, 550]),   # same span through a mate gap
+             ([0, 1, 0], [150, 200, 301], [199, 300, 350]),   # intron off by one
+             ([], [], []),                      # a hit without features
+             m(350, 520),                       # block over two segments of different isoforms
+             m(1000, 1099)]
+    hits = eb.Hits([0, 0, 0, 0, 0, 0, 0, 0, 1], feats)
+    compat, key = eb.compat_and_keys(annot, hits, ctx)
+    assert compat[:, 0].tolist() == [3, 0, 1, 2, 2, 0, 0, 0, 1]
+    assert key[:, 0].tolist() == [1, 1, 3, 5, 5, 3, 0, 6, 1]
+    o = oracle.exonbin_batch(annot, hits)
+    np.testing.assert_array_equal(compat, o[0])
+    np.testing.assert_array_equal(key, o[1])
+    # no hits: nothing to do; too few words: refused
+    eb.compat_and_keys(annot, eb.Hits([], []), ctx)
+    wide = eb.Annotation([[[(k * 100, k * 100 + 50)] for k in range(1, 40)]])
+    with pytest.raises(SbgpuError):
+        eb.compat_and_keys(wide, eb.Hits([0], [m(100, 120)]), ctx, compat_words=1)
+    with pytest.raises(SbgpuError):
+        eb.compat_and_keys(annot, eb.Hits([7], [m(100, 120)]), ctx)   # hit_locus out of range
+
+
+def test_large_batch_properties(ctx, oracle):
+    """BASELINE-scale hit counts through size-independent properties: tiling the loci along the genome
+    must tile the answers; a fragment sampled from an isoform without noise is compatible with it."""
+    from strawberry_amd import exonbin as eb
+    from strawberry_amd import synth
+    loci = synth.make_gene_models(400, seed=21)
+    hl, pairs = synth.make_fragments(loci, 100, seed=22, noise=0.0, single=0.0)
+    feats, loc = [], []
+    for l, (lb, rb) in zip(hl, pairs):
+        f = eb.hit_features(lb, rb)
+        if f is not None:
+            feats.append(f)
+            loc.append(l)
+    annot, hits = eb.Annotation(loci), eb.Hits(loc, feats)
+    compat, key = eb.compat_and_keys(annot, hits, ctx)
+    assert (compat != 0).any(1).all() and (key != 0).any(1).all()
+    big_annot, big_hits = XU.tile(annot, hits, 64)
+    assert big_hits.n_hits == 64 * hits.n_hits > 2_000_000
+    c2, k2 = eb.compat_and_keys(big_annot, big_hits, ctx)
+    np.testing.assert_array_equal(c2.reshape(64, hits.n_hits, -1), np.broadcast_to(compat, (64,) + compat.shape))
+    np.testing.assert_array_equal(k2.reshape(64, hits.n_hits, -1), np.broadcast_to(key, (64,) + key.shape))
+
+
+@pytest.mark.parametrize("which", ["E2E", "E2E_LONG"])
+def test_chain_from_fragments_reproduces_reference_run(ctx, oracle, which):
+    """Our simulated fragments (reads.npz, the BAM the reference binary was run on) through the whole
+    device chain: bins and counts == the -f table; every nonzero weight of the table == F (12 digits);
+    theta == the reference's log; FPKM / Frac / TPM == its GTF."""
+    from strawberry_amd.quantify import InsertSize, LocusQuantifier
+    d = getattr(U, which)
+    ordered, rows, gtf, theta_log = U.load(d)
+    annot, hits, names, _ = XU.e2e_inputs(d, ordered)
+    q = LocusQuantifier(annot, hits, InsertSize(MEAN, SD), RL, ctx=ctx)
+    bins = q.assign_bins()
+    o_compat, o_key = oracle.exonbin_batch(annot, hits)
+    np.testing.assert_array_equal(q.d_compat.cpu().numpy().view(np.uint32)[:hits.n_hits], o_compat)
+    np.testing.assert_array_equal(q.d_key.cpu().numpy().view(np.uint32)[:hits.n_hits], o_key)
+    F = q.bin_weights().cpu().numpy()
+    n_checked = 0
+    for l, g in enumerate(names):
+        coords = [tuple(c) for c in bins.bin_coords(l)]
+        niso = int(bins.iso_off[l + 1] - bins.iso_off[l])
+        Fl = F[bins.f_off[l]:bins.f_off[l + 1]].reshape(len(coords), niso)
+        ref_rows = [r for r in rows if r["gene"] == g]
+        assert sorted(coords) == sorted(tuple(r["coords"]) for r in ref_rows)
+        for r in ref_rows:
+            b = coords.index(tuple(r["coords"]))
+            assert bins.count[bins.row_off[l] + b] == r["count"]
+            for j, f in enumerate(r["F"]):
+                if f != 0.0:
+                    assert abs(Fl[b, j] - f) <= 5e-11 * f, (g, r["coords"], j)
+                    n_checked += 1
+    assert n_checked > 100
+    res = q.solve(rows[0]["total_mapped"], min_isoform_frac=0.0)   # the golden run used -r: kMinIsoformFrac = 0 (Strawberry.cpp:158-161)
+    for l, ref_theta in enumerate(theta_log):
+        th = res["theta"][bins.iso_off[l]:bins.iso_off[l + 1]]
+        assert np.abs(th - np.array(ref_theta)).max() < 1e-6, (names[l], th, ref_theta)
+    tx_names = [t for g in names for t, _ in ordered[g]]
+    for t, f, fr, tp in zip(tx_names, res["fpkm"], res["frac"], res["tpm"]):
+        assert abs(f - float(gtf[t][0])) <= 1e-5 * max(1.0, f), t       # FPKM/TPM: 1e-4 rel is the bar; we are tighter
+        assert abs(fr - float(gtf[t][1])) < 2e-6, t
+        assert abs(tp - float(gtf[t][2])) <= 1e-5 * max(1.0, tp), t
+    # and the EM input we built equals what the oracle gets from the same F
+    o_theta, o_status, o_iters = oracle.em_batch(bins.row_off, bins.iso_off, bins.f_off, bins.count, F)
+    np.testing.assert_array_equal(res["iters"], o_iters)
+    np.testing.assert_array_equal(res["status"], o_status)

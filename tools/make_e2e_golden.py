@@ -85,9 +85,10 @@ def cigar(blocks):
 
 def simulate(rng, genes, frags_per_gene):
     recs = []
+    frags = []
     seen = set()
     rid = 0
-    for g in genes:
+    for gi, g in enumerate(genes):
         w = rng.dirichlet(np.ones(len(g["isos"])) * 0.8)
         for _ in range(frags_per_gene):
             t = int(rng.choice(len(g["isos"]), p=w))
@@ -106,12 +107,29 @@ def simulate(rng, genes, frags_per_gene):
             rid += 1
             name = "r%06d" % rid
             tlen = right[-1][1] - left[0][0] + 1
+            frags.append((gi, left, right))
             recs.append((left[0][0], "%s\t99\tchr1\t%d\t255\t%s\t=\t%d\t%d\t%s\t%s\tNH:i:1\tXS:A:+" % (
                 name, left[0][0], cigar(left), right[0][0], tlen, "A" * RL, "I" * RL)))
             recs.append((right[0][0], "%s\t147\tchr1\t%d\t255\t%s\t=\t%d\t%d\t%s\t%s\tNH:i:1\tXS:A:+" % (
                 name, right[0][0], cigar(right), left[0][0], -tlen, "A" * RL, "I" * RL)))
     recs.sort(key=lambda r: r[0])
-    return recs
+    return recs, frags
+
+
+def save_frags(frags, path):
+    """reads.npz: our simulated fragments (inputs of the golden run) as aligned blocks, 1-based closed."""
+    def csr(which):
+        off, bl, br = [0], [], []
+        for f in frags:
+            for (a, b) in f[which]:
+                bl.append(a)
+                br.append(b)
+            off.append(len(bl))
+        return np.asarray(off, np.int64), np.asarray(bl, np.uint32), np.asarray(br, np.uint32)
+    lo, ll, lr = csr(1)
+    ro, rl, rr = csr(2)
+    np.savez_compressed(path, gene=np.asarray([f[0] for f in frags], np.int32), left_off=lo, left_l=ll, left_r=lr,
+                        right_off=ro, right_l=rl, right_r=rr)
 
 
 def main():
@@ -132,7 +150,8 @@ def make(name, seed, ex_lo, ex_hi):
     with tempfile.TemporaryDirectory() as tmp:
         gtf = os.path.join(tmp, "toy.gtf")
         write_gtf(genes, gtf)
-        recs = simulate(rng, genes, 900)
+        recs, frags = simulate(rng, genes, 900)
+        save_frags(frags, os.path.join(out_dir, "reads.npz"))
         sam = os.path.join(tmp, "toy.sam")
         with open(sam, "w") as f:
             f.write("@HD\tVN:1.0\tSO:coordinate\n@SQ\tSN:chr1\tLN:%d\n" % chrom_len)
