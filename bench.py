@@ -110,23 +110,32 @@ def main():
     total_mapped = int(min(int(tot.item()), 2**31 - 1))   # the reference holds it in an int
     quant = sdist.ShardQuantifier(solver, total_mapped, min_isoform_frac=0.0)  # quant-only (-r): keep all
 
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     for _ in range(args.warmup):
         quant.step()
+    ev[0].record()   # first use of a timing event on this stream happens here, not inside the timed region
     torch.cuda.synchronize(dev)
     sdist.barrier()
     torch.cuda.synchronize(dev)
 
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     kern_ms = np.zeros(6)
     t0 = time.perf_counter()
     ev[0].record()
+    trace = [] if os.environ.get("SB_BENCH_TRACE") else None   # diagnostic: host time of every call
     for _ in range(args.steps):
         quant.step()
+        if trace is not None:
+            trace.append(time.perf_counter() - t0)
     ev[1].record()
     torch.cuda.synchronize(dev)
+    if trace is not None:
+        trace.append(time.perf_counter() - t0)
     sdist.barrier()
     torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t0
+    if trace is not None:
+        print("trace (ms since t0): " + " ".join("%.2f" % (x * 1e3) for x in trace) + " | end %.2f" % (wall * 1e3),
+              file=sys.stderr)
     gpu_ms = ev[0].elapsed_time(ev[1])
     # per-kind EM kernel time: HIP events on the streams the kernels run on, averaged over a few
     # extra (untimed) steps -- reading them synchronises, so it stays out of the timed region

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 
 namespace sb {
 
@@ -13,6 +14,45 @@ namespace sb {
 __device__ __forceinline__ void set_fp64_flush_denormals()
 {
    __builtin_amdgcn_s_setreg(1 | (6 << 6) | ((2 - 1) << 11), 0);
+}
+
+// value of lane (lane ^ MASK), true xor for every MASK
+template <int MASK>
+__device__ __forceinline__ int xor_get_i(int x)
+{
+   if (MASK == 1) return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);
+   if (MASK == 2) return __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true);
+   if (MASK == 4) {
+      // banks 0,2 (lanes 0-3, 8-11 of each row) read lane+4, banks 1,3 read lane-4
+      int t = __builtin_amdgcn_update_dpp(0, x, 0x104 /*row_shl:4*/, 0xF, 0x5, false);
+      return __builtin_amdgcn_update_dpp(t, x, 0x114 /*row_shr:4*/, 0xF, 0xA, false);
+   }
+   if (MASK == 8) return __builtin_amdgcn_update_dpp(0, x, 0x128 /*row_ror:8*/, 0xF, 0xF, true);
+   if (MASK == 16) return __builtin_amdgcn_ds_swizzle(x, 0x401F);
+   // MASK == 32
+   auto a = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+   return ((threadIdx.x & 32) ? a[0] : a[1]);
+}
+// all-lanes min / max of a 32-bit value over the wave, as a uniform (SGPR) result
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+   v = min(v, (uint32_t)xor_get_i<1>((int)v));
+   v = min(v, (uint32_t)xor_get_i<2>((int)v));
+   v = min(v, (uint32_t)xor_get_i<4>((int)v));
+   v = min(v, (uint32_t)xor_get_i<8>((int)v));
+   v = min(v, (uint32_t)xor_get_i<16>((int)v));
+   v = min(v, (uint32_t)xor_get_i<32>((int)v));
+   return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+   v = max(v, (uint32_t)xor_get_i<1>((int)v));
+   v = max(v, (uint32_t)xor_get_i<2>((int)v));
+   v = max(v, (uint32_t)xor_get_i<4>((int)v));
+   v = max(v, (uint32_t)xor_get_i<8>((int)v));
+   v = max(v, (uint32_t)xor_get_i<16>((int)v));
+   v = max(v, (uint32_t)xor_get_i<32>((int)v));
+   return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
 
 } // namespace sb

@@ -161,23 +161,6 @@ __device__ __forceinline__ double fast_div(double n, double d)
 // Waves pull loci from their class list through an atomic cursor, one per group,
 // whenever all their groups are idle, until the list runs dry.
 
-// value of lane (lane ^ MASK), true xor for every MASK
-template <int MASK>
-__device__ __forceinline__ int xor_get_i(int x)
-{
-   if (MASK == 1) return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);
-   if (MASK == 2) return __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true);
-   if (MASK == 4) {
-      // banks 0,2 (lanes 0-3, 8-11 of each row) read lane+4, banks 1,3 read lane-4
-      int t = __builtin_amdgcn_update_dpp(0, x, 0x104 /*row_shl:4*/, 0xF, 0x5, false);
-      return __builtin_amdgcn_update_dpp(t, x, 0x114 /*row_shr:4*/, 0xF, 0xA, false);
-   }
-   if (MASK == 8) return __builtin_amdgcn_update_dpp(0, x, 0x128 /*row_ror:8*/, 0xF, 0xF, true);
-   if (MASK == 16) return __builtin_amdgcn_ds_swizzle(x, 0x401F);
-   // MASK == 32
-   auto a = __builtin_amdgcn_permlane32_swap(x, x, false, false);
-   return ((threadIdx.x & 32) ? a[0] : a[1]);
-}
 template <int MASK>
 __device__ __forceinline__ double xor_get(double x)
 {

@@ -2,6 +2,7 @@
 // (include/sbgpu.h): launch of the per-hit compatibility + bin-key kernel.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <string>
 
 #include "../../include/sbgpu.h"
@@ -42,9 +43,15 @@ int sbgpu_exonbin_device(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
    a.compat = d_compat;
    a.key = d_key;
    const int64_t blocks_wanted = (hits->n_hits + 255) / 256;
-   const int64_t cap = (int64_t)sb::ctx_cu_count(c) * 32;
-   const unsigned grid = (unsigned)(blocks_wanted < cap ? blocks_wanted : cap);
-   hipLaunchKernelGGL(sb::exonbin_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+   if (blocks_wanted > 0x7fffffff) return api_fail(SBGPU_ESHAPE, "sbgpu_exonbin_device: more than 2^39 hits in one call");
+   static const bool lane_form = std::getenv("SBGPU_EXONBIN_LANE") && std::atoi(std::getenv("SBGPU_EXONBIN_LANE")) != 0;
+   if (lane_form) { // per-lane kernel only (A/B measurements)
+      const int64_t cap = (int64_t)sb::ctx_cu_count(c) * 32;
+      hipLaunchKernelGGL(sb::exonbin_lane_kernel, dim3((unsigned)(blocks_wanted < cap ? blocks_wanted : cap)), dim3(256), 0,
+                         (hipStream_t)stream, a);
+   } else {
+      hipLaunchKernelGGL(sb::exonbin_kernel, dim3((unsigned)blocks_wanted), dim3(256), 0, (hipStream_t)stream, a);
+   }
    hipError_t e = hipGetLastError();
    if (e != hipSuccess) return api_fail(SBGPU_EHIP, std::string("exonbin_kernel: ") + hipGetErrorString(e));
    return SBGPU_OK;

@@ -98,6 +98,49 @@ def test_kernel_edge_cases(ctx, oracle):
         eb.compat_and_keys(annot, eb.Hits([7], [m(100, 120)]), ctx)   # hit_locus out of range
 
 
+def test_irregular_feature_lists(ctx, oracle):
+    """Feature lists that are not MATCH (connector MATCH)*: the kernel's per-lane walk must take them
+    and agree with the oracle bit for bit, mixed into waves of regular hits."""
+    from strawberry_amd import exonbin as eb
+    from strawberry_amd import synth
+    loci = synth.make_gene_models(20, seed=8)
+    hl, pairs = synth.make_fragments(loci, 120, seed=9)
+    rng = np.random.default_rng(10)
+    feats, loc = [], []
+    n_irregular = 0
+    for l, (lb, rb) in zip(hl, pairs):
+        f = eb.hit_features(lb, rb)
+        if f is None:
+            continue
+        c, le, ri = [list(x) for x in f]
+        u = rng.random()
+        if u < 0.10 and len(c) >= 3:        # drop a connector: two MATCH blocks in a row
+            k = 1 + 2 * int(rng.integers(0, len(c) // 2))
+            del c[k], le[k], ri[k]
+            n_irregular += 1
+        elif u < 0.20 and len(c) >= 3:      # double connector: GAP then INTRON
+            k = 1 + 2 * int(rng.integers(0, len(c) // 2))
+            mid = (le[k] + ri[k]) // 2
+            c[k:k + 1] = [2, 1]
+            le[k:k + 1] = [le[k], mid + 1]
+            ri[k:k + 1] = [mid, ri[k]]
+            n_irregular += 1
+        elif u < 0.25:                      # a connector first
+            c, le, ri = [1] + c, [le[0] - 50] + le, [le[0] - 1] + ri
+            n_irregular += 1
+        elif u < 0.30 and len(c) >= 3:      # an INTRON turned MATCH
+            c[1] = 0
+            n_irregular += 1
+        feats.append((c, le, ri))
+        loc.append(l)
+    annot, hits = eb.Annotation(loci), eb.Hits(loc, feats)
+    assert n_irregular > 300
+    compat, key = eb.compat_and_keys(annot, hits, ctx)
+    o_compat, o_key = oracle.exonbin_batch(annot, hits)
+    np.testing.assert_array_equal(compat, o_compat)
+    np.testing.assert_array_equal(key, o_key)
+
+
 def test_large_batch_properties(ctx, oracle):
     """BASELINE-scale hit counts through size-independent properties: tiling the loci along the genome
     must tile the answers; a fragment sampled from an isoform without noise is compatible with it."""

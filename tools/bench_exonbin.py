@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--only", choices=["compat", "key"], help="diagnostic: run only one of the two tests")
     a = ap.parse_args()
     import torch
     import exonbin_util as XU
@@ -46,11 +47,15 @@ def main():
     q = LocusQuantifier(annot, hits, InsertSize(250.0, 30.0), 75, ctx=ctx)
     cw, kw = annot.compat_words, annot.key_words
     n_feat = int(hits.feat_off[-1])
+    if a.only == "compat":
+        kw = 0
+    if a.only == "key":
+        cw = 0
     # algorithmic bytes per hit: its features (1 + 4 + 4 B each), its offset and locus, its words out
     alg_bytes = n_feat * 9 + hits.n_hits * (8 + 4 + 4 * (cw + kw))
     dev = torch.device("cuda", 0)
-    d_compat = torch.zeros((hits.n_hits, cw), dtype=torch.int32, device=dev)
-    d_key = torch.zeros((hits.n_hits, kw), dtype=torch.int32, device=dev)
+    d_compat = torch.zeros((hits.n_hits, max(cw, 1)), dtype=torch.int32, device=dev)
+    d_key = torch.zeros((hits.n_hits, max(kw, 1)), dtype=torch.int32, device=dev)
     an = _lib.sbgpu_annotation_t(annot.n_loci, q._p("iso_off"), q._p("exon_off"), q._p("exon_left"), q._p("exon_right"),
                                  q._p("seg_off"), q._p("seg_left"), q._p("seg_right"))
     ht = _lib.sbgpu_hits_t(hits.n_hits, q._p("hit_locus"), q._p("feat_off"), q._p("feat_code"), q._p("feat_left"),
@@ -80,7 +85,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": alg_bytes / (kern_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                      "frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / 8000.0, "traffic": None, "kernel_ms": kern_ms},
     }
-    if not a.no_cpu_baseline:
+    if not a.no_cpu_baseline and not a.only:
         from oracle import OracleLib
         orc = OracleLib()
         n = min(hits.n_hits, 2_000_000)
