@@ -333,6 +333,22 @@ int sbgpu_format_gtf_transcript(char *buf, int cap, const char *chrom, char stra
                                 const int32_t *exon_right, double fpkm, double frac, double tpm,
                                 int32_t keep);
 
+/* One row of the `-f` context table exactly as Sample::printContext writes it
+ * (src/alignments.cpp:1549-1639, columns 1-10; the six sequence columns exist only with
+ * BIAS_CORRECTION and a genome FASTA and are not produced): tab-separated
+ *   sample, sample_frag_count (total mapped reads), gene_id, gene_frag_count, transcripts (comma
+ *   list), FPKMs (std::to_string each), conditional_probabilities (the bin's weight per isoform,
+ *   to_string_with_precision(.,12) = "%.12g", include/common.h:366-372; 0 for an isoform the bin's
+ *   last fragment is not compatible with), class_probabilities (Frac, std::to_string),
+ *   path_symbol ("[l-r]" per segment of the bin), path_count (unique hits in the bin), newline.
+ * Rows of a locus come in std::map order of the bins' coordinate sets (:1552-1563).  snprintf
+ * convention like sbgpu_format_gtf_transcript.                                                */
+int sbgpu_format_context_row(char *buf, int cap, const char *sample, int32_t sample_frag_count,
+                             const char *gene_id, uint32_t gene_frag_count, int n_iso,
+                             const char *const *transcript_ids, const double *fpkm,
+                             const double *cond_prob, const double *frac, int n_seg,
+                             const uint32_t *seg_left, const uint32_t *seg_right, uint32_t path_count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,7 +21,7 @@ SYMBOLS = [
     "sbgpu_insert_pdf_table", "sbgpu_binweight_device", "sbgpu_binweight_host",
     "sbgpu_exonbin_device", "sbgpu_exonbin_host", "sbgpu_segments_host", "sbgpu_hit_features",
     "sbgpu_bins_create", "sbgpu_bins_destroy", "sbgpu_bins_info", "sbgpu_bins_export",
-    "sbgpu_format_value", "sbgpu_format_gtf_transcript", "sbgpu_em_batch", "sbgpu_abundance_device", "sbgpu_tpm_device",
+    "sbgpu_format_value", "sbgpu_format_gtf_transcript", "sbgpu_format_context_row", "sbgpu_em_batch", "sbgpu_abundance_device", "sbgpu_tpm_device",
 ]
 
 
@@ -153,6 +153,8 @@ def load():
     L.sbgpu_format_gtf_transcript.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_char, C.c_char_p, C.c_char_p,
                                               C.c_char_p, C.c_char_p, C.c_int, vp, vp, C.c_double, C.c_double,
                                               C.c_double, C.c_int32]
+    L.sbgpu_format_context_row.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int32, C.c_char_p, C.c_uint32, C.c_int,
+                                           C.POINTER(C.c_char_p), vp, vp, vp, C.c_int, vp, vp, C.c_uint32]
     L.sbgpu_binweight_host.argtypes = [vp, C.c_int64, vp, vp, vp, vp, C.POINTER(sbgpu_insert_t), vp]
     for name in SYMBOLS:
         f = getattr(L, name)

@@ -811,4 +811,32 @@ int sbgpu_format_gtf_transcript(char *buf, int cap, const char *chrom, char stra
    return (int)out.size();
 }
 
+int sbgpu_format_context_row(char *buf, int cap, const char *sample, int32_t sample_frag_count, const char *gene_id,
+                             uint32_t gene_frag_count, int n_iso, const char *const *transcript_ids, const double *fpkm,
+                             const double *cond_prob, const double *frac, int n_seg, const uint32_t *seg_left,
+                             const uint32_t *seg_right, uint32_t path_count)
+{
+   if (!buf || cap < 1 || !sample || !gene_id || n_iso < 1 || !transcript_ids || !fpkm || !cond_prob || !frac || n_seg < 0 ||
+       (n_seg && (!seg_left || !seg_right)))
+      return fail(SBGPU_EINVAL, "sbgpu_format_context_row: bad argument");
+   std::string out = std::string(sample) + "\t" + std::to_string(sample_frag_count) + "\t" + gene_id + "\t" +
+                     std::to_string(gene_frag_count) + "\t";
+   char num[64];
+   for (int j = 0; j < n_iso; ++j) out += std::string(j ? "," : "") + (transcript_ids[j] ? transcript_ids[j] : "");
+   out += "\t";
+   for (int j = 0; j < n_iso; ++j) out += std::string(j ? "," : "") + std::to_string(fpkm[j]);
+   out += "\t";
+   for (int j = 0; j < n_iso; ++j) {
+      std::snprintf(num, sizeof(num), "%.12g", cond_prob[j]); // ostream << setprecision(12)
+      out += std::string(j ? "," : "") + num;
+   }
+   out += "\t";
+   for (int j = 0; j < n_iso; ++j) out += std::string(j ? "," : "") + std::to_string(frac[j]);
+   out += "\t";
+   for (int k = 0; k < n_seg; ++k) out += "[" + std::to_string(seg_left[k]) + "-" + std::to_string(seg_right[k]) + "]";
+   out += "\t" + std::to_string(path_count) + "\n";
+   std::snprintf(buf, (size_t)cap, "%s", out.c_str());
+   return (int)out.size();
+}
+
 } // extern "C"

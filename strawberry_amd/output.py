@@ -33,3 +33,59 @@ def gtf_transcript(chrom, strand, gene_id, transcript_id, exons, fpkm, frac, tpm
     if n < 0:
         _lib.check(n, "sbgpu_format_gtf_transcript")
     return buf.value.decode()
+
+
+CONTEXT_HEADER = "\t".join([
+    "sample", "sample_frag_count", "gene_id", "gene_frag_count", "transcripts", "FPKMs", "conditional_probabilities",
+    "class_probabilities", "path_symbol", "path_count", "path_gc_content", "path_hexmer_entropy", "gc_stretch_0.8_20",
+    "gc_stretch_0.9_20", "gc_stretch_0.8_40", "gc_stretch_0.9_40"]) + "\n"   # alignments.cpp:1746-1752
+
+
+def context_row(sample, sample_frag_count, gene_id, gene_frag_count, transcript_ids, fpkm, cond_prob, frac, segs,
+                path_count):
+    """One row of the `-f` table (Sample::printContext, alignments.cpp:1549-1639, columns 1-10)."""
+    L = _lib.load()
+    n = len(transcript_ids)
+    names = (C.c_char_p * n)(*[t.encode() for t in transcript_ids])
+    fpkm = np.ascontiguousarray(fpkm, np.float64)
+    cond = np.ascontiguousarray(cond_prob, np.float64)
+    frac = np.ascontiguousarray(frac, np.float64)
+    sl = np.ascontiguousarray([s[0] for s in segs], np.uint32)
+    sr = np.ascontiguousarray([s[1] for s in segs], np.uint32)
+    cap = 512 + 64 * n * 4 + 32 * len(segs) + sum(len(t) for t in transcript_ids)
+    buf = C.create_string_buffer(cap)
+    r = L.sbgpu_format_context_row(buf, cap, sample.encode(), int(sample_frag_count), gene_id.encode(),
+                                   int(gene_frag_count), n, names, fpkm.ctypes.data, cond.ctypes.data, frac.ctypes.data,
+                                   len(segs), sl.ctypes.data if len(segs) else None, sr.ctypes.data if len(segs) else None,
+                                   int(path_count))
+    if r < 0:
+        _lib.check(r, "sbgpu_format_context_row")
+    return buf.value.decode()
+
+
+def context_table(sample, total_mapped, gene_ids, transcript_ids, bins, compat, F, fpkm, frac):
+    """The whole `-f` table of a batch of loci from the chain's results.
+
+    bins: exonbin.LocusBins; compat: the kernel's words per hit [n_hits, cw]; F: the EM batch's weights
+    (host copy); fpkm / frac per isoform; transcript_ids[l] the isoform names of locus l in batch order.
+    Per bin the reference prints the weights of the isoforms its LAST fragment is compatible with and
+    the number of unique hits in it, bins in std::map order of their coordinate sets."""
+    out = [CONTEXT_HEADER]
+    hit_bin = np.asarray(bins.hit_bin)
+    used = hit_bin >= 0
+    n_in_bin = np.bincount(hit_bin[used], minlength=bins.n_bins)
+    last_hit = np.full(bins.n_bins, -1, np.int64)
+    last_hit[hit_bin[used]] = np.nonzero(used)[0]          # later hits overwrite earlier ones
+    for l, gene in enumerate(gene_ids):
+        b0, b1 = int(bins.row_off[l]), int(bins.row_off[l + 1])
+        i0, i1 = int(bins.iso_off[l]), int(bins.iso_off[l + 1])
+        niso = i1 - i0
+        coords = bins.bin_coords(l)
+        gene_frags = int(n_in_bin[b0:b1].sum())
+        Fl = np.asarray(F[bins.f_off[l]:bins.f_off[l + 1]]).reshape(b1 - b0, niso)
+        for b in sorted(range(b1 - b0), key=lambda k: coords[k]):
+            words = compat[last_hit[b0 + b]]
+            mask = np.array([(int(words[j >> 5]) >> (j & 31)) & 1 for j in range(niso)], bool)
+            out.append(context_row(sample, total_mapped, gene, gene_frags, transcript_ids[l], fpkm[i0:i1],
+                                   np.where(mask, Fl[b], 0.0), frac[i0:i1], coords[b], n_in_bin[b0 + b]))
+    return "".join(out)

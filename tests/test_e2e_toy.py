@@ -188,3 +188,19 @@ def test_output_formatting_matches_reference_gtf(toy_long, oracle):
     block = gtf_transcript("chr1", "+", g, t, ex, f, fr, tpm[0], ref_gene_id=g, ref_gene_name=g).split("\n")
     assert len(block) == len(ex) + 2 and block[-1] == ""
     assert block[1].endswith(' exon_id "1";') and "\texon\t%d\t%d\t1000\t+\t.\t" % ex[0] in block[1]
+
+
+@pytest.mark.parametrize("which", ["E2E", "E2E_LONG"])
+def test_context_row_formatting_round_trips_reference_table(which):
+    """sbgpu_format_context_row (host code): parsing a row of the reference's -f table and printing it
+    again gives the same bytes -- to_string for FPKM/Frac, 12 significant digits for the weights."""
+    from strawberry_amd.output import CONTEXT_HEADER, context_row
+    d = getattr(U, which)
+    lines = open(d + "/ctx.tsv").read().splitlines(keepends=True)
+    assert lines[0] == CONTEXT_HEADER
+    for line in lines[1:]:
+        f = line.rstrip("\n").split("\t")
+        coords = [(int(a), int(b)) for a, b in __import__("re").findall(r"\[(\d+)-(\d+)\]", f[8])]
+        again = context_row(f[0], int(f[1]), f[2], int(f[3]), f[4].split(","), [float(x) for x in f[5].split(",")],
+                            [float(x) for x in f[6].split(",")], [float(x) for x in f[7].split(",")], coords, int(f[9]))
+        assert again == line

@@ -207,3 +207,20 @@ def test_chain_from_fragments_reproduces_reference_run(ctx, oracle, which):
     o_theta, o_status, o_iters = oracle.em_batch(bins.row_off, bins.iso_off, bins.f_off, bins.count, F)
     np.testing.assert_array_equal(res["iters"], o_iters)
     np.testing.assert_array_equal(res["status"], o_status)
+
+    # the reference's two output FILES, byte for byte, from the fragments alone
+    from strawberry_amd.output import context_table, gtf_transcript
+    compat = q.d_compat.cpu().numpy().view(np.uint32)[:hits.n_hits]
+    table = context_table("toy", rows[0]["total_mapped"], names, [[t for t, _ in ordered[g]] for g in names], bins,
+                          compat, F, res["fpkm"], res["frac"])
+    assert table == open(os.path.join(d, "ctx.tsv")).read()
+    gtf_text = []
+    k = 0
+    for g in names:
+        for t, ex in ordered[g]:
+            gtf_text.append(gtf_transcript("chr1", "+", g, t, ex, res["fpkm"][k], res["frac"][k], res["tpm"][k],
+                                           ref_gene_id=g, ref_gene_name=g))
+            k += 1
+    ref_gtf = open(os.path.join(d, "out.gtf")).read().split("\n", 2)
+    assert ref_gtf[0].startswith("#") and ref_gtf[1].startswith("#")   # command line + rule: not data
+    assert "".join(gtf_text) == ref_gtf[2]
