@@ -48,6 +48,32 @@ def make_batch(name, rank):
     raise SystemExit("unknown workload " + name)
 
 
+def pmc_traffic(workload, kind):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
+    very command (tools/profile_round.sh: separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` runs,
+    summarised in profiles/rNN_<workload>_pmc_summary.json).  A counter pass cannot run inside the
+    bench itself, so the number is read back; None when no summary for this workload is committed.
+    Unit and correction per MI355X_MICROARCH.md (HBM): the counters are in KB and on gfx950 FETCH_SIZE
+    tallies 128-B requests at 64 B, so it is doubled before it is compared with a byte count."""
+    import glob
+    import json
+    key = ["em_fused_kernel<0, 1>", "em_fused_kernel<0, 2>", "em_fused_kernel<0, 4>", "em_fused_kernel<4, 2>",
+           "em_fused_kernel<4, 12>", "em_stream_kernel"][kind]
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "profiles", "r*_%s_pmc_summary.json" % workload)))
+    if not files:
+        return None, "no PMC summary committed for this workload"
+    try:
+        d = json.load(open(files[-1]))
+        c = next(v for k, v in d.items() if key in k)
+        fetch_kb, write_kb = c["FETCH_SIZE"]["mean_per_dispatch"], c["WRITE_SIZE"]["mean_per_dispatch"]
+    except (StopIteration, KeyError, ValueError):
+        return None, "PMC summary %s has no FETCH_SIZE/WRITE_SIZE for %s" % (os.path.basename(files[-1]), key)
+    return (int((2.0 * fetch_kb + write_kb) * 1024),
+            "%s: 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE = 2 x %.0f KB + %.0f KB per launch" % (
+                os.path.basename(files[-1]), fetch_kb, write_kb))
+
+
 def cpu_baseline(batch, budget_s=12.0):
     """Time the reference's EmSolver (or the port) on this box's host cores, on a
     bounded prefix of the same batch: one thread (the reference's deterministic mode)
@@ -161,7 +187,7 @@ def main():
     # ---- roofline of the dominant EM kernel (this rank's batch)
     kinds = solver.plan.locus_kinds()
     kind_names = ["em_fused_kernel<0,1> (wave form, half tile)", "em_fused_kernel<0,2> (wave form, base tile)",
-                  "em_fused_kernel<0,4> (wave form, double tile)", "em_fused_kernel<4,4> (256-lane block form)",
+                  "em_fused_kernel<0,4> (wave form, double tile)", "em_fused_kernel<4,2> (256-lane block form)",
                   "em_fused_kernel<4,12> (256-lane block form, tall tile)", "em_stream_kernel"]
     dom = int(np.argmax(kern_ms))
     sel = kinds == dom
@@ -170,9 +196,10 @@ def main():
     fl_locus = res["iters"].astype(np.int64) * (5 * nrow * niso + nrow + 3 * niso)
     dom_s = kern_ms[dom] * 1e-3
     ach_gbs = float(b_locus[sel].sum()) / dom_s / 1e9
+    traffic, traffic_note = pmc_traffic(args.workload, dom)
     roofline = {
         "bound": "hbm", "kernel": kind_names[dom], "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
+        "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
         "kernel_ms": float(kern_ms[dom]), "kernel_loci": int(sel.sum()),
         "algorithmic_bytes": int(b_locus[sel].sum()),
         "note": "F stays in registers for all iterations: the loop is FP64-VALU/latency bound, see fp64_valu",

@@ -12,6 +12,11 @@
 //
 // Plain host C++: no HIP calls.  All arithmetic on the results happens in the kernels.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -166,11 +171,26 @@ int sbgpu_bins_create(const sbgpu_annotation_t *an, const sbgpu_hits_t *hits, co
    if (nl && (!an->iso_off || !an->exon_off || !an->seg_off)) return api_fail(SBGPU_EINVAL, "sbgpu_bins_create: null annotation");
    if (nh && (!hits->hit_locus || !hits->feat_off || !hit_mass || !compat || !key))
       return api_fail(SBGPU_EINVAL, "sbgpu_bins_create: null hits");
+   for (int64_t h = 0; h < nh; ++h)
+      if (hits->hit_locus[h] < 0 || hits->hit_locus[h] >= nl) return api_fail(SBGPU_EINVAL, "sbgpu_bins_create: hit_locus out of range");
+   for (int64_t l = 0; l < nl; ++l)
+      if (an->iso_off[l + 1] - an->iso_off[l] > 32 * (int64_t)compat_words || an->seg_off[l + 1] - an->seg_off[l] > 32 * (int64_t)key_words)
+         return api_fail(SBGPU_ESHAPE, "sbgpu_bins_create: word counts do not cover a locus");
    sbgpu_bins *B = new (std::nothrow) sbgpu_bins();
    if (!B) return api_fail(SBGPU_ENOMEM, "sbgpu_bins_create: out of memory");
    auto bail = [&](int code, const char *msg) {
       delete B;
       return api_fail(code, msg);
+   };
+   const bool timing = std::getenv("SBGPU_HOST_TIMING") != nullptr; // diagnostic: stage times on stderr
+   auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+   double t_stage = now();
+   auto stage = [&](const char *name) {
+      if (timing) {
+         const double t = now();
+         std::fprintf(stderr, "sbgpu_bins_create: %-10s %.1f ms\n", name, (t - t_stage) * 1e3);
+         t_stage = t;
+      }
    };
    try {
       B->n_loci = nl;
@@ -178,8 +198,8 @@ int sbgpu_bins_create(const sbgpu_annotation_t *an, const sbgpu_hits_t *hits, co
       B->compat_words = compat_words;
       const int64_t n_iso = nl ? an->iso_off[nl] : 0;
       B->n_iso = n_iso;
-      B->iso_off.assign(an->iso_off, an->iso_off + nl + 1);
-      if (nl == 0) B->iso_off.assign(1, 0);
+      if (nl) B->iso_off.assign(an->iso_off, an->iso_off + nl + 1);
+      else B->iso_off.assign(1, 0);
       B->iso_len.resize((size_t)n_iso);
       for (int64_t i = 0; i < n_iso; ++i) { // Contig::exonic_length, src/contig.cpp:436-445
          int64_t len = 0;
@@ -188,119 +208,251 @@ int sbgpu_bins_create(const sbgpu_annotation_t *an, const sbgpu_hits_t *hits, co
       }
       // hits of each locus, in input order
       std::vector<int64_t> loc_start((size_t)nl + 1, 0), order((size_t)nh);
-      for (int64_t h = 0; h < nh; ++h) {
-         if (hits->hit_locus[h] < 0 || hits->hit_locus[h] >= nl) return bail(SBGPU_EINVAL, "sbgpu_bins_create: hit_locus out of range");
-         ++loc_start[(size_t)hits->hit_locus[h] + 1];
-      }
+      for (int64_t h = 0; h < nh; ++h) ++loc_start[(size_t)hits->hit_locus[h] + 1];
       for (int64_t l = 0; l < nl; ++l) loc_start[(size_t)l + 1] += loc_start[(size_t)l];
       {
          std::vector<int64_t> fill(loc_start.begin(), loc_start.end() - 1);
          for (int64_t h = 0; h < nh; ++h) order[(size_t)fill[(size_t)hits->hit_locus[h]]++] = h;
       }
       B->hit_bin.assign((size_t)nh, -1);
-      B->row_off.assign(1, 0);
-      B->f_off.assign(1, 0);
-      B->pair_seg_off.assign(1, 0);
+      stage("setup");
 
-      typedef std::vector<uint32_t> Key;
-      typedef std::vector<uint64_t> Frag; // (offset << 32 | length) per feature: Contig::operator<, contig.cpp:342-347
-      struct Bin {
-         std::map<Frag, float> frags; // ExonBin::_frags (a std::set<Contig>): first insertion wins
-         Key compat;
+      // ---- per locus, independent of every other locus: worker threads pull loci from a counter
+      struct LocusOut {
+         int64_t nb = 0, used = 0;
+         std::vector<int32_t> count;
+         std::vector<uint32_t> key, compat;          // nb * kw, nb * cw
+         std::vector<uint32_t> pair_seg_lens, pair_mask;
+         std::vector<int32_t> pair_nseg, pair_iso;    // per pair: segments, isoform (local index)
+         std::vector<int64_t> pair_bin;               // per pair: local bin
+         int err = 0;
+         const char *msg = nullptr;
       };
-      std::vector<Iv> iso_segs, bin_segs;
-      for (int64_t l = 0; l < nl; ++l) {
+      std::vector<LocusOut> res((size_t)nl);
+      const uint32_t *fl = hits->feat_left, *fr = hits->feat_right;
+      const int64_t *fo = hits->feat_off;
+      // Contig::operator< (contig.cpp:342-347): features compared by (offset, length), lexicographic,
+      // a proper prefix first; equal sequences are one std::set element and the first inserted stays
+      auto frag_cmp = [&](int64_t x, int64_t y) {
+         const int64_t nx = fo[x + 1] - fo[x], ny = fo[y + 1] - fo[y], n = nx < ny ? nx : ny;
+         for (int64_t i = 0; i < n; ++i) {
+            const uint32_t lx = fl[fo[x] + i], ly = fl[fo[y] + i];
+            if (lx != ly) return lx < ly ? -1 : 1;
+            const uint32_t wx = fr[fo[x] + i] - lx, wy = fr[fo[y] + i] - ly;
+            if (wx != wy) return wx < wy ? -1 : 1;
+         }
+         return nx == ny ? 0 : (nx < ny ? -1 : 1);
+      };
+      auto do_locus = [&](int64_t l) {
+         LocusOut &R = res[(size_t)l];
          const int64_t i0 = an->iso_off[l], niso = an->iso_off[l + 1] - i0;
          const int64_t s0 = an->seg_off[l], nseg = an->seg_off[l + 1] - s0;
-         if (niso > 32 * (int64_t)compat_words || nseg > 32 * (int64_t)key_words)
-            return bail(SBGPU_ESHAPE, "sbgpu_bins_create: word counts do not cover a locus");
-         std::map<Key, int> index; // UniqPushAndReturnIdx: bins in order of first appearance
-         std::vector<Bin> bins;
-         std::vector<const Key *> bin_keys;
-         for (int64_t q = loc_start[(size_t)l]; q < loc_start[(size_t)l + 1]; ++q) {
-            const int64_t h = order[(size_t)q];
-            const uint32_t *cw = compat + h * compat_words, *kw = key + h * key_words;
-            bool any_c = false, any_k = false;
-            for (int w = 0; w < compat_words; ++w) any_c |= cw[w] != 0;
-            for (int w = 0; w < key_words; ++w) any_k |= kw[w] != 0;
-            if (!any_c || !any_k) continue; // no compatible isoform / set_maps: coords.empty()
-            Key k(kw, kw + key_words);
-            auto ins = index.emplace(k, (int)bins.size());
-            if (ins.second) {
-               bins.emplace_back();
-               bins.back().compat.assign((size_t)compat_words, 0);
-               bin_keys.push_back(&ins.first->first);
+         const int64_t q0 = loc_start[(size_t)l], nq = loc_start[(size_t)l + 1] - q0;
+         const int cw = compat_words, kw = key_words;
+         // bins keyed by the key words, numbered in order of first appearance (UniqPushAndReturnIdx):
+         // open-addressing table of bin ids, a bin's key = the words of its first hit
+         size_t cap = 16;
+         while (cap < (size_t)nq * 2) cap <<= 1;
+         std::vector<int32_t> table(cap, -1);
+         std::vector<int64_t> first_hit;      // per bin
+         std::vector<int32_t> local((size_t)nq, -1), n_in_bin;
+         for (int64_t q = 0; q < nq; ++q) {
+            const int64_t h = order[(size_t)(q0 + q)];
+            const uint32_t *cwp = compat + h * cw, *kwp = key + h * kw;
+            uint32_t any_c = 0, any_k = 0;
+            uint64_t hash = 1469598103934665603ull;
+            for (int w = 0; w < cw; ++w) any_c |= cwp[w];
+            for (int w = 0; w < kw; ++w) {
+               any_k |= kwp[w];
+               hash = (hash ^ kwp[w]) * 1099511628211ull;
             }
-            Bin &b = bins[(size_t)ins.first->second];
-            for (int w = 0; w < compat_words; ++w) b.compat[(size_t)w] |= cw[w];
-            Frag fr;
-            for (int64_t f = hits->feat_off[h]; f < hits->feat_off[h + 1]; ++f)
-               fr.push_back(((uint64_t)hits->feat_left[f] << 32) | (uint64_t)(hits->feat_right[f] - hits->feat_left[f] + 1));
-            b.frags.emplace(std::move(fr), hit_mass[h]);
-            B->hit_bin[(size_t)h] = B->n_bins + ins.first->second;
-            ++B->n_hits_used;
+            if (!any_c || !any_k) continue; // no compatible isoform / set_maps: coords.empty()
+            size_t slot = (size_t)(hash ^ (hash >> 29)) & (cap - 1);
+            int32_t b;
+            for (;;) {
+               b = table[slot];
+               if (b < 0 || std::memcmp(key + first_hit[(size_t)b] * kw, kwp, (size_t)kw * 4) == 0) break;
+               slot = (slot + 1) & (cap - 1);
+            }
+            if (b < 0) {
+               b = (int32_t)first_hit.size();
+               table[slot] = b;
+               first_hit.push_back(h);
+               n_in_bin.push_back(0);
+               R.compat.insert(R.compat.end(), (size_t)cw, 0u);
+            }
+            for (int w = 0; w < cw; ++w) R.compat[(size_t)b * cw + w] |= cwp[w];
+            local[(size_t)q] = b;
+            ++n_in_bin[(size_t)b];
+            ++R.used;
          }
-         const int64_t nb = (int64_t)bins.size();
+         const int64_t nb = R.nb = (int64_t)first_hit.size();
+         R.key.resize((size_t)nb * kw);
+         for (int64_t b = 0; b < nb; ++b) std::memcpy(&R.key[(size_t)b * kw], key + first_hit[(size_t)b] * kw, (size_t)kw * 4);
+         // members of each bin, then ExonBin::read_count (isoform.h:285-296): distinct fragments in the
+         // std::set's order, float accumulation, truncated to int at estimate.cpp:288
+         std::vector<int64_t> start((size_t)nb + 1, 0), members((size_t)R.used);
+         for (int64_t b = 0; b < nb; ++b) start[(size_t)b + 1] = start[(size_t)b] + n_in_bin[(size_t)b];
+         {
+            std::vector<int64_t> fill(start.begin(), start.end() - 1);
+            for (int64_t q = 0; q < nq; ++q)
+               if (local[(size_t)q] >= 0) {
+                  const int64_t h = order[(size_t)(q0 + q)];
+                  members[(size_t)fill[(size_t)local[(size_t)q]]++] = h;
+                  B->hit_bin[(size_t)h] = local[(size_t)q]; // local id for now; made global below
+               }
+         }
+         R.count.resize((size_t)nb);
          for (int64_t b = 0; b < nb; ++b) {
-            float sum = 0.0f; // ExonBin::read_count, isoform.h:285-296: float accumulation in set order
-            for (const auto &kv : bins[(size_t)b].frags) sum += kv.second;
-            B->count.push_back((int32_t)sum); // n[i] = bin.read_count(), estimate.cpp:288
-            B->bin_key.insert(B->bin_key.end(), bin_keys[(size_t)b]->begin(), bin_keys[(size_t)b]->end());
-            B->bin_compat.insert(B->bin_compat.end(), bins[(size_t)b].compat.begin(), bins[(size_t)b].compat.end());
+            int64_t *m0 = members.data() + start[(size_t)b], *m1 = members.data() + start[(size_t)b + 1];
+            // input order breaks ties, so of equal fragments the first inserted comes first
+            std::stable_sort(m0, m1, [&](int64_t x, int64_t y) { return frag_cmp(x, y) < 0; });
+            float sum = 0.0f;
+            for (int64_t *m = m0; m < m1; ++m)
+               if (m == m0 || frag_cmp(m[-1], m[0]) != 0) sum += hit_mass[*m];
+            R.count[(size_t)b] = (int32_t)sum;
          }
-         // (bin, isoform) pairs of set_theory_bin_weight with ExonBin::bin_under_iso
-         const int64_t f0 = B->f_off.back();
+         // (bin, isoform) pairs of set_theory_bin_weight with ExonBin::bin_under_iso.
+         // Isoform::_exon_segs (isoform.h:59-71): the locus' segments inside one of its exons
+         std::vector<std::vector<int32_t>> iso_segs((size_t)niso);
          for (int64_t j = 0; j < niso; ++j) {
             const int64_t iso = i0 + j, e0 = an->exon_off[iso], ne = an->exon_off[iso + 1] - e0;
-            // Isoform::_exon_segs (isoform.h:59-71): the locus' segments inside one of its exons
-            iso_segs.clear();
-            for (int64_t s = 0; s < nseg; ++s) {
-               const uint32_t sl = an->seg_left[s0 + s], sr = an->seg_right[s0 + s];
-               int64_t e = 0;
-               while (e < ne && an->exon_right[e0 + e] < sl) ++e; // contig.cpp:615-634
-               if (e < ne && an->exon_left[e0 + e] <= sl && an->exon_right[e0 + e] >= sr) iso_segs.push_back({sl, sr});
+            int64_t e = 0;
+            for (int64_t sidx = 0; sidx < nseg; ++sidx) {
+               const uint32_t sl = an->seg_left[s0 + sidx], sr = an->seg_right[s0 + sidx];
+               while (e < ne && an->exon_right[e0 + e] < sl) ++e; // contig.cpp:615-634; segments ascend
+               if (e < ne && an->exon_left[e0 + e] <= sl && an->exon_right[e0 + e] >= sr) iso_segs[(size_t)j].push_back((int32_t)sidx);
             }
+         }
+         std::vector<int32_t> bin_segs;
+         for (int64_t j = 0; j < niso; ++j) {
+            const std::vector<int32_t> &is = iso_segs[(size_t)j];
             for (int64_t b = 0; b < nb; ++b) {
-               if (!((bins[(size_t)b].compat[(size_t)(j >> 5)] >> (j & 31)) & 1u)) continue;
+               if (!((R.compat[(size_t)b * cw + (size_t)(j >> 5)] >> (j & 31)) & 1u)) continue;
                bin_segs.clear();
-               const Key &k = *bin_keys[(size_t)b];
-               for (int64_t s = 0; s < nseg; ++s)
-                  if ((k[(size_t)(s >> 5)] >> (s & 31)) & 1u) bin_segs.push_back({an->seg_left[s0 + s], an->seg_right[s0 + s]});
-               // isoform.h:381-391: isoform segments from the bin's first to its last
-               auto lb = [&](uint32_t v) {
-                  size_t p = 0;
-                  while (p < iso_segs.size() && iso_segs[p].l < v) ++p;
-                  return p;
-               };
-               const size_t low = lb(bin_segs.front().l), up = lb(bin_segs.back().l);
-               if (low >= iso_segs.size() || up >= iso_segs.size() || up < low)
-                  return bail(SBGPU_ESHAPE, "sbgpu_bins_create: a bin is not under an isoform it is compatible with");
+               const uint32_t *k = &R.key[(size_t)b * kw];
+               for (int w = 0; w < kw; ++w)
+                  for (uint32_t bits = k[w]; bits; bits &= bits - 1) bin_segs.push_back(32 * w + __builtin_ctz(bits));
+               // isoform.h:381-391: the isoform's segments from the bin's first to its last.  Segment
+               // indices ascend with their left ends, so lower_bound on start positions = on indices
+               const size_t low = std::lower_bound(is.begin(), is.end(), bin_segs.front()) - is.begin();
+               const size_t up = std::lower_bound(is.begin(), is.end(), bin_segs.back()) - is.begin();
+               if (low >= is.size() || up >= is.size() || up < low) {
+                  R.err = SBGPU_ESHAPE;
+                  R.msg = "sbgpu_bins_create: a bin is not under an isoform it is compatible with";
+                  return;
+               }
                const size_t n = up - low + 1;
-               if (n > 32) return bail(SBGPU_ESHAPE, "sbgpu_bins_create: a bin spans more than 32 isoform segments");
+               if (n > 32) {
+                  R.err = SBGPU_ESHAPE;
+                  R.msg = "sbgpu_bins_create: a bin spans more than 32 isoform segments";
+                  return;
+               }
                uint32_t mask = 0;
                size_t c = 1, i = 1; // :393-409
                while (i + 1 < n) {
-                  if (c >= bin_segs.size() || iso_segs[low + i].l < bin_segs[c].l) {
+                  if (c >= bin_segs.size() || is[low + i] < bin_segs[c]) {
                      mask |= 1u << i;
                      ++i;
-                  } else if (iso_segs[low + i].l == bin_segs[c].l) {
+                  } else if (is[low + i] == bin_segs[c]) {
                      ++i;
                      ++c;
                   } else {
-                     return bail(SBGPU_ESHAPE, "sbgpu_bins_create: a bin holds a segment its isoform lacks");
+                     R.err = SBGPU_ESHAPE;
+                     R.msg = "sbgpu_bins_create: a bin holds a segment its isoform lacks";
+                     return;
                   }
                }
-               for (size_t q = 0; q < n; ++q) B->pair_seg_lens.push_back(iso_segs[low + q].r - iso_segs[low + q].l + 1);
-               B->pair_seg_off.push_back((int64_t)B->pair_seg_lens.size());
-               B->pair_mask.push_back(mask);
-               B->pair_iso_len.push_back(B->iso_len[(size_t)iso]);
-               B->pair_out_index.push_back(f0 + b * niso + j);
+               for (size_t q = 0; q < n; ++q) {
+                  const int32_t sidx = is[low + q];
+                  R.pair_seg_lens.push_back(an->seg_right[s0 + sidx] - an->seg_left[s0 + sidx] + 1);
+               }
+               R.pair_nseg.push_back((int32_t)n);
+               R.pair_mask.push_back(mask);
+               R.pair_iso.push_back((int32_t)j);
+               R.pair_bin.push_back(b);
             }
          }
-         B->n_bins += nb;
-         B->row_off.push_back(B->n_bins);
-         B->f_off.push_back(f0 + nb * niso);
+      };
+      unsigned nt = std::thread::hardware_concurrency();
+      if (const char *e = std::getenv("SBGPU_HOST_THREADS")) nt = (unsigned)std::atoi(e);
+      if (nt < 1) nt = 1;
+      if (nt > 64) nt = 64;
+      if ((int64_t)nt > nl) nt = (unsigned)(nl > 0 ? nl : 1);
+      std::atomic<bool> oom(false);
+      // run f(l) for every locus on nt threads, 16 loci at a time
+      auto for_each_locus = [&](auto f) {
+         std::atomic<int64_t> next(0);
+         auto worker = [&]() {
+            try {
+               for (;;) {
+                  const int64_t l0 = next.fetch_add(16);
+                  if (l0 >= nl) break;
+                  for (int64_t l = l0; l < nl && l < l0 + 16; ++l) f(l);
+               }
+            } catch (const std::bad_alloc &) {
+               oom = true;
+            }
+         };
+         if (nt == 1) {
+            worker();
+         } else {
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < nt; ++t) pool.emplace_back(worker);
+            for (auto &t : pool) t.join();
+         }
+      };
+      for_each_locus(do_locus);
+      if (oom) return bail(SBGPU_ENOMEM, "sbgpu_bins_create: out of memory");
+      stage("loci");
+      // ---- stitch the loci together, in locus order: offsets first, then every locus copies its part
+      B->row_off.assign((size_t)nl + 1, 0);
+      B->f_off.assign((size_t)nl + 1, 0);
+      std::vector<int64_t> pair0((size_t)nl + 1, 0), pseg0((size_t)nl + 1, 0);
+      for (int64_t l = 0; l < nl; ++l) {
+         const LocusOut &R = res[(size_t)l];
+         if (R.err) return bail(R.err, R.msg);
+         const int64_t niso = an->iso_off[l + 1] - an->iso_off[l];
+         B->row_off[(size_t)l + 1] = B->row_off[(size_t)l] + R.nb;
+         B->f_off[(size_t)l + 1] = B->f_off[(size_t)l] + R.nb * niso;
+         pair0[(size_t)l + 1] = pair0[(size_t)l] + (int64_t)R.pair_mask.size();
+         pseg0[(size_t)l + 1] = pseg0[(size_t)l] + (int64_t)R.pair_seg_lens.size();
+         B->n_hits_used += R.used;
       }
+      B->n_bins = B->row_off[(size_t)nl];
+      const int64_t n_pairs = pair0[(size_t)nl];
+      B->count.resize((size_t)B->n_bins);
+      B->bin_key.resize((size_t)B->n_bins * key_words);
+      B->bin_compat.resize((size_t)B->n_bins * compat_words);
+      B->pair_seg_lens.resize((size_t)pseg0[(size_t)nl]);
+      B->pair_mask.resize((size_t)n_pairs);
+      B->pair_iso_len.resize((size_t)n_pairs);
+      B->pair_out_index.resize((size_t)n_pairs);
+      B->pair_seg_off.assign((size_t)n_pairs + 1, 0);
+      for_each_locus([&](int64_t l) {
+         LocusOut &R = res[(size_t)l];
+         const int64_t niso = an->iso_off[l + 1] - an->iso_off[l], f0 = B->f_off[(size_t)l], b0 = B->row_off[(size_t)l];
+         std::copy(R.count.begin(), R.count.end(), B->count.begin() + b0);
+         std::copy(R.key.begin(), R.key.end(), B->bin_key.begin() + b0 * key_words);
+         std::copy(R.compat.begin(), R.compat.end(), B->bin_compat.begin() + b0 * compat_words);
+         std::copy(R.pair_seg_lens.begin(), R.pair_seg_lens.end(), B->pair_seg_lens.begin() + pseg0[(size_t)l]);
+         std::copy(R.pair_mask.begin(), R.pair_mask.end(), B->pair_mask.begin() + pair0[(size_t)l]);
+         int64_t so = pseg0[(size_t)l];
+         for (size_t p = 0; p < R.pair_mask.size(); ++p) {
+            const size_t g = (size_t)pair0[(size_t)l] + p;
+            so += R.pair_nseg[p];
+            B->pair_seg_off[g + 1] = so;
+            B->pair_iso_len[g] = B->iso_len[(size_t)(an->iso_off[l] + R.pair_iso[p])];
+            B->pair_out_index[g] = f0 + R.pair_bin[p] * niso + R.pair_iso[p];
+         }
+         for (int64_t q = loc_start[(size_t)l]; q < loc_start[(size_t)l + 1]; ++q) {
+            int64_t &hb = B->hit_bin[(size_t)order[(size_t)q]];
+            if (hb >= 0) hb += b0;
+         }
+         R = LocusOut(); // release
+      });
+      if (oom) return bail(SBGPU_ENOMEM, "sbgpu_bins_create: out of memory");
+      stage("stitch");
       B->n_elem = B->f_off.back();
       B->n_pairs = (int64_t)B->pair_mask.size();
       B->n_pair_segs = (int64_t)B->pair_seg_lens.size();
