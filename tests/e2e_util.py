@@ -14,6 +14,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 E2E = os.path.join(HERE, "golden", "e2e_toy")            # short exons: bins over many segments
 E2E_LONG = os.path.join(HERE, "golden", "e2e_toy_long")  # exons longer than any mate gap
+E2E_MASS = os.path.join(HERE, "golden", "e2e_toy_mass")  # PCR duplicates + multi-mapped pairs (masses 1, 1/2, 1/3)
 
 
 def load(directory):

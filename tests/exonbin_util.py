@@ -11,32 +11,43 @@ def load_reads(directory):
     """reads.npz (our simulated fragments, tools/make_e2e_golden.py) -> [(gene index, left blocks, right blocks)]."""
     z = dict(np.load(os.path.join(directory, "reads.npz")))
     out = []
+    nh_off, nh = z["nh_off"], z["nh"]
     for k in range(len(z["gene"])):
         lb = [(int(a), int(b)) for a, b in zip(z["left_l"][z["left_off"][k]:z["left_off"][k + 1]],
                                                z["left_r"][z["left_off"][k]:z["left_off"][k + 1]])]
         rb = [(int(a), int(b)) for a, b in zip(z["right_l"][z["right_off"][k]:z["right_off"][k + 1]],
                                                z["right_r"][z["right_off"][k]:z["right_off"][k + 1]])]
-        out.append((int(z["gene"][k]), lb, rb))
+        # PairedHit mass = 0.5/NH per mate (src/read.cpp:49-53,734-741), collapsed over the copies of the
+        # fragment (src/alignments.cpp:683-696), all in double
+        mass = 0.0
+        for n in nh[nh_off[k]:nh_off[k + 1]]:
+            mass += 0.5 / int(n) + 0.5 / int(n)
+        out.append((int(z["gene"][k]), lb, rb, mass))
     return out
 
 
 def e2e_inputs(directory, ordered_genes):
     """-> (Annotation, Hits, gene names, rejected pair count).  Loci in gene order with the reference's
     isoform order; hits as HitCluster::collapseAndFilterHits leaves them: sorted by (left, right) of
-    the pair (src/alignments.cpp:660, src/read.cpp:917-923), rejected pairs dropped."""
+    the pair (src/alignments.cpp:660, src/read.cpp:917-923), rejected pairs dropped.  Hits.mass is
+    (float) collapse mass; Hits.total_mapped the reference's _total_mapped_reads: the int-truncated
+    raw mass of every cluster, summed (src/alignments.cpp:1372)."""
     names = list(ordered_genes)
     annot = eb.Annotation([[ex for _, ex in ordered_genes[g]] for g in names])
     # reads.npz numbers genes in annotation-file order G1..Gn, the same as `names`
     rows = []
     rejected = 0
-    for gi, lb, rb in load_reads(directory):
+    cluster_mass = [0.0] * len(names)
+    for gi, lb, rb, mass in load_reads(directory):
+        cluster_mass[gi] += mass
         f = eb.hit_features(lb, rb)
         if f is None:
             rejected += 1
             continue
-        rows.append((gi, lb[0][0], rb[-1][1], f))
+        rows.append((gi, lb[0][0], rb[-1][1], f, mass))
     rows.sort(key=lambda r: (r[0], r[1], r[2]))
-    hits = eb.Hits([r[0] for r in rows], [r[3] for r in rows])
+    hits = eb.Hits([r[0] for r in rows], [r[3] for r in rows], mass=[r[4] for r in rows])
+    hits.total_mapped = sum(int(m) for m in cluster_mass)
     return annot, hits, names, rejected
 
 

@@ -106,7 +106,7 @@ def test_segments_host_is_the_disjoint_cut():
     assert eb.Annotation([]).n_loci == 0
 
 
-@pytest.mark.parametrize("which", ["E2E", "E2E_LONG"])
+@pytest.mark.parametrize("which", ["E2E", "E2E_LONG", "E2E_MASS"])
 def test_bins_reproduce_reference_context_table(which, oracle):
     """The reference binary's -f table lists every exon bin (its segments) with the number of
     fragments in it; hits -> (oracle words) -> sbgpu_bins_create must give the same bins and counts."""
@@ -117,10 +117,16 @@ def test_bins_reproduce_reference_context_table(which, oracle):
     compat, key = oracle.exonbin_batch(annot, hits)
     bins = eb.LocusBins(annot, hits, compat, key)
     assert bins.n_bins == len(rows)
+    assert hits.total_mapped == rows[0]["total_mapped"]
+    hits_in_bin = np.bincount(bins.hit_bin[bins.hit_bin >= 0], minlength=bins.n_bins)
     for l, g in enumerate(names):
+        # the table's path_count is the number of unique hits of the bin; with unit masses and no
+        # duplicates (the two plain toys) that is also the bin's count n_i
         ref = sorted((tuple(r["coords"]), r["count"]) for r in rows if r["gene"] == g)
-        got = sorted(zip([tuple(c) for c in bins.bin_coords(l)], bins.count[bins.row_off[l]:bins.row_off[l + 1]].tolist()))
+        got = sorted(zip([tuple(c) for c in bins.bin_coords(l)], hits_in_bin[bins.row_off[l]:bins.row_off[l + 1]].tolist()))
         assert got == ref, g
+        if which != "E2E_MASS":
+            assert hits_in_bin[bins.row_off[l]:bins.row_off[l + 1]].tolist() == bins.count[bins.row_off[l]:bins.row_off[l + 1]].tolist()
         # a nonzero weight in the table is a (bin, isoform) pair of ours (the table prints, per bin, the
         # weights of the isoforms its LAST fragment is compatible with, alignments.cpp:1556-1563)
         by_coords = {tuple(c): b for b, c in zip(range(bins.row_off[l], bins.row_off[l + 1]), bins.bin_coords(l))}
@@ -133,6 +139,40 @@ def test_bins_reproduce_reference_context_table(which, oracle):
     assert bins.f_off[-1] == bins.n_elem == int((np.diff(bins.row_off) * np.diff(bins.iso_off)).sum())
     assert bins.pair_out_index.max() < bins.n_elem and len(np.unique(bins.pair_out_index)) == bins.n_pairs
     assert (bins.hit_bin >= 0).sum() == bins.n_hits_used
+
+
+def test_fractional_masses_reproduce_reference_theta(oracle):
+    """PCR duplicates and multi-mapped pairs (tests/golden/e2e_toy_mass): hit masses are sums of 1, 1/2
+    and 1/3; the bin counts n_i = (int) float-sum of them (ExonBin::read_count) feed the EM, whose theta
+    the reference logged.  Our bins + the oracle's weights + the oracle's EM must land on that theta."""
+    d = U.E2E_MASS
+    ordered, rows, gtf, theta_log = U.load(d)
+    annot, hits, names, _ = XU.e2e_inputs(d, ordered)
+    assert len(np.unique(hits.mass)) > 10 and np.abs(hits.mass - np.rint(hits.mass)).max() > 0.3
+    compat, key = oracle.exonbin_batch(annot, hits)
+    bins = eb.LocusBins(annot, hits, compat, key)
+    # counts differ from the plain number of hits in most bins -- the masses matter
+    hits_in_bin = np.bincount(bins.hit_bin[bins.hit_bin >= 0], minlength=bins.n_bins)
+    assert (hits_in_bin != bins.count).mean() > 0.5
+    ins = oracle.make_insert(250.0, 30.0)
+    F = np.zeros(bins.n_elem)
+    for p in range(bins.n_pairs):
+        s = slice(bins.pair_seg_off[p], bins.pair_seg_off[p + 1])
+        imp = [k for k in range(32) if (int(bins.pair_implicit_mask[p]) >> k) & 1]
+        F[bins.pair_out_index[p]] = oracle.bin_weight(bins.pair_seg_lens[s], imp, int(bins.pair_iso_len[p]), 75, ins)
+    theta, status, iters = oracle.em_batch(bins.row_off, bins.iso_off, bins.f_off, bins.count, F)
+    for l, ref_theta in enumerate(theta_log):
+        th = theta[bins.iso_off[l]:bins.iso_off[l + 1]]
+        assert np.abs(th - np.array(ref_theta)).max() < 1e-6, (names[l], th, ref_theta)
+    # and FPKM through the oracle's epilogue with the reference's mapped-read total
+    k = 0
+    for l, g in enumerate(names):
+        th = theta[bins.iso_off[l]:bins.iso_off[l + 1]]
+        fpkm, frac, keep, _ = oracle.abundance_locus(th, bins.iso_len[bins.iso_off[l]:bins.iso_off[l + 1]],
+                                                     hits.total_mapped, min_isoform_frac=0.0)
+        for (t, _), f, fr in zip(ordered[g], fpkm, frac):
+            assert abs(f - float(gtf[t][0])) <= 1e-6 * max(1.0, f), t
+            assert abs(fr - float(gtf[t][1])) < 2e-6, t
 
 
 def test_bins_bookkeeping_rules():

@@ -83,10 +83,15 @@ def cigar(blocks):
     return s
 
 
-def simulate(rng, genes, frags_per_gene):
+def simulate(rng, genes, frags_per_gene, dup=0.0, multi=0.0):
+    """dup: chance that a fragment is sequenced again (1-3 PCR duplicates: same alignments, other read
+    names); multi: chance that a pair is multi-mapped (NH 2 or 3 on both mates).  With either, two
+    different fragments never share (left end, right end): the reference sorts hits by that pair only
+    (src/read.cpp:917-923) before collapsing neighbours, and the order of ties is std::sort's business."""
     recs = []
     frags = []
     seen = set()
+    spans = set()
     rid = 0
     for gi, g in enumerate(genes):
         w = rng.dirichlet(np.ones(len(g["isos"])) * 0.8)
@@ -103,15 +108,24 @@ def simulate(rng, genes, frags_per_gene):
             sig = (tuple(left), tuple(right))
             if sig in seen:     # no duplicate fragments: bin counts then equal uniq-hit counts
                 continue
+            if dup or multi:
+                if (left[0][0], right[-1][1]) in spans:
+                    continue
+                spans.add((left[0][0], right[-1][1]))
             seen.add(sig)
-            rid += 1
-            name = "r%06d" % rid
+            copies = 1 + (int(rng.integers(1, 4)) if dup and rng.random() < dup else 0)
+            nhs = []
             tlen = right[-1][1] - left[0][0] + 1
-            frags.append((gi, left, right))
-            recs.append((left[0][0], "%s\t99\tchr1\t%d\t255\t%s\t=\t%d\t%d\t%s\t%s\tNH:i:1\tXS:A:+" % (
-                name, left[0][0], cigar(left), right[0][0], tlen, "A" * RL, "I" * RL)))
-            recs.append((right[0][0], "%s\t147\tchr1\t%d\t255\t%s\t=\t%d\t%d\t%s\t%s\tNH:i:1\tXS:A:+" % (
-                name, right[0][0], cigar(right), left[0][0], -tlen, "A" * RL, "I" * RL)))
+            for _ in range(copies):
+                nh = int(rng.integers(2, 4)) if multi and rng.random() < multi else 1
+                nhs.append(nh)
+                rid += 1
+                name = "r%06d" % rid
+                recs.append((left[0][0], "%s\t99\tchr1\t%d\t255\t%s\t=\t%d\t%d\t%s\t%s\tNH:i:%d\tXS:A:+" % (
+                    name, left[0][0], cigar(left), right[0][0], tlen, "A" * RL, "I" * RL, nh)))
+                recs.append((right[0][0], "%s\t147\tchr1\t%d\t255\t%s\t=\t%d\t%d\t%s\t%s\tNH:i:%d\tXS:A:+" % (
+                    name, right[0][0], cigar(right), left[0][0], -tlen, "A" * RL, "I" * RL, nh)))
+            frags.append((gi, left, right, nhs))
     recs.sort(key=lambda r: r[0])
     return recs, frags
 
@@ -128,8 +142,11 @@ def save_frags(frags, path):
         return np.asarray(off, np.int64), np.asarray(bl, np.uint32), np.asarray(br, np.uint32)
     lo, ll, lr = csr(1)
     ro, rl, rr = csr(2)
+    # per fragment the NH tags of its copies (one copy with NH 1 in the plain toys)
+    nh_off = np.concatenate([[0], np.cumsum([len(f[3]) for f in frags])]).astype(np.int64)
     np.savez_compressed(path, gene=np.asarray([f[0] for f in frags], np.int32), left_off=lo, left_l=ll, left_r=lr,
-                        right_off=ro, right_l=rl, right_r=rr)
+                        right_off=ro, right_l=rl, right_r=rr, nh_off=nh_off,
+                        nh=np.asarray([n for f in frags for n in f[3]], np.int32))
 
 
 def main():
@@ -140,9 +157,13 @@ def main():
     #          EM input: pins EmSolver / FPKM / TPM end to end.
     make("e2e_toy", 4242, 60, 400)
     make("e2e_toy_long", 4343, 420, 900)
+    # e2e_toy_mass: PCR duplicates and multi-mapped pairs (NH 2 / 3, --allow-multimapped-hits): hit masses
+    #          are sums of 1, 1/2, 1/3 -- pins the collapse mass, the float accumulation of
+    #          ExonBin::read_count with its int truncation, and the int-truncated mapped-read total.
+    make("e2e_toy_mass", 4444, 200, 700, dup=0.3, multi=0.35, extra=["--allow-multimapped-hits"])
 
 
-def make(name, seed, ex_lo, ex_hi):
+def make(name, seed, ex_lo, ex_hi, dup=0.0, multi=0.0, extra=()):
     rng = np.random.Generator(np.random.PCG64(seed))
     genes, chrom_len = make_annotation(rng, 6, ex_lo, ex_hi)
     out_dir = os.path.join(ROOT, "tests", "golden", name)
@@ -150,7 +171,7 @@ def make(name, seed, ex_lo, ex_hi):
     with tempfile.TemporaryDirectory() as tmp:
         gtf = os.path.join(tmp, "toy.gtf")
         write_gtf(genes, gtf)
-        recs, frags = simulate(rng, genes, 900)
+        recs, frags = simulate(rng, genes, 900, dup, multi)
         save_frags(frags, os.path.join(out_dir, "reads.npz"))
         sam = os.path.join(tmp, "toy.sam")
         with open(sam, "w") as f:
@@ -160,7 +181,7 @@ def make(name, seed, ex_lo, ex_hi):
         bam = os.path.join(tmp, "toy.bam")
         subprocess.check_call([SAM2BAM, sam, bam])
         cmd = [REF_BIN, bam, "-g", gtf, "-r", "-i", "%d/%d" % (MEAN, SD), "-o", os.path.join(tmp, "out.gtf"),
-               "-T", os.path.join(tmp, "log.txt"), "-f", os.path.join(tmp, "ctx.tsv")]
+               "-T", os.path.join(tmp, "log.txt"), "-f", os.path.join(tmp, "ctx.tsv")] + list(extra)
         r = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True)
         print(r.stdout[-2000:])
         print(r.stderr[-3000:])
