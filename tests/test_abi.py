@@ -98,3 +98,53 @@ def test_header_is_plain_c_and_links(tmp_path, lib):
                            "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0 and "gfx950" in out.stdout, (out.stdout, out.stderr)
+
+
+def test_host_entry_points_reject_bad_arguments(lib):
+    """The host-only entry points (no GPU needed) validate their arguments and say why."""
+    from strawberry_amd import _lib
+    SBGPU_EINVAL = -1
+    assert lib.sbgpu_bins_create(None, None, None, 1, 1, None, None, None) == SBGPU_EINVAL
+    assert b"null" in lib.sbgpu_last_error()
+    assert lib.sbgpu_bins_info(None, None) == SBGPU_EINVAL
+    assert lib.sbgpu_format_context_row(None, 0, None, 0, None, 0, 0, None, None, None, None, 0, None, None, 0) == SBGPU_EINVAL
+    out = (C.c_uint8 * 4)()
+    assert lib.sbgpu_hit_features(-1, None, None, None, 0, None, None, None, out, None, None) == SBGPU_EINVAL
+    # an exon with right < left is refused by the segment builder
+    iso_off, exon_off = np.array([0, 1], np.int64), np.array([0, 1], np.int64)
+    xl, xr = np.array([100], np.uint32), np.array([50], np.uint32)
+    seg_off = np.zeros(2, np.int64)
+    assert lib.sbgpu_segments_host(1, iso_off.ctypes.data, exon_off.ctypes.data, xl.ctypes.data, xr.ctypes.data,
+                                   seg_off.ctypes.data, None, None, 0) == SBGPU_EINVAL
+    # without a GPU the kernel-backed forms fail before touching anything
+    import torch
+    if not torch.cuda.is_available():
+        an, ht = _lib.sbgpu_annotation_t(), _lib.sbgpu_hits_t()
+        assert lib.sbgpu_exonbin_host(None, C.byref(an), C.byref(ht), 1, 1, None, None) == SBGPU_EINVAL
+
+
+def test_bins_are_independent_of_host_thread_count(monkeypatch):
+    """sbgpu_bins_create runs loci on host threads; the result must not depend on how many."""
+    from oracle import OracleLib
+    from strawberry_amd import exonbin as eb
+    from strawberry_amd import synth
+    loci = synth.make_gene_models(60, seed=14)
+    hl, pairs = synth.make_fragments(loci, 40, seed=15, noise=0.3)
+    feats = [(l, eb.hit_features(lb, rb)) for l, (lb, rb) in zip(hl, pairs)]
+    feats = [(l, f) for l, f in feats if f is not None]
+    rng = np.random.default_rng(3)
+    annot = eb.Annotation(loci)
+    hits = eb.Hits([l for l, _ in feats], [f for _, f in feats], mass=rng.choice([1.0, 0.5, 1 / 3, 2.0, 1.5], len(feats)))
+    compat, key = OracleLib().exonbin_batch(annot, hits)
+    ref = None
+    for nt in ("1", "3", "16"):
+        monkeypatch.setenv("SBGPU_HOST_THREADS", nt)
+        b = eb.LocusBins(annot, hits, compat, key)
+        got = [b.row_off, b.f_off, b.count, b.bin_key, b.bin_compat, b.hit_bin, b.pair_seg_off, b.pair_seg_lens,
+               b.pair_implicit_mask, b.pair_iso_len, b.pair_out_index]
+        if ref is None:
+            ref = got
+            assert b.n_bins > 300 and b.n_pairs > 500
+        else:
+            for x, y in zip(ref, got):
+                np.testing.assert_array_equal(x, y)
