@@ -1,0 +1,218 @@
+// examples/quantify_fragments.cpp -- a C++14 driver over include/sbgpu_host.hpp, the way
+// Strawberry's own Sample::procSample would use libsbgpu.so: read an annotation
+// and read pairs, quantify every locus in one batch on the GPU, write the reference's two output
+// files (GTF and the -f context table).  Used by tests/test_cpp_driver.py, which checks the files
+// byte for byte against what the reference binary wrote for the same input.
+//
+//   g++ -std=c++14 -O2 -Iinclude examples/quantify_fragments.cpp -Lstrawberry_amd/lib -lsbgpu
+//       -Wl,-rpath,$PWD/strawberry_amd/lib -o quantify_fragments
+//   ./quantify_fragments input.txt out.gtf ctx.tsv
+//
+// Input (plain text, whitespace separated):
+//   sample <name>  chrom <name>  strand <+|->  insert <mean> <sd>  read_len <n>  min_isoform_frac <x>
+//   loci <L>
+//     locus <gene_id> <n_isoforms>
+//       iso <transcript_id> <n_exons> <left> <right> ...          (the reference's isoform order)
+//   pairs <P>
+//     pair <locus> <mass> <n_left_blocks> <l> <r> ... <n_right_blocks> <l> <r> ...
+//         (aligned blocks of each mate; mass = the pair's collapse mass, alignments.cpp:683-696)
+#include <algorithm>
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "sbgpu_host.hpp"
+
+namespace {
+
+struct Pair {
+   int locus;
+   double mass;
+   std::vector<std::pair<uint32_t, uint32_t>> left, right;
+};
+
+// readhit_2_genomicFeats for an M/N CIGAR (src/contig.cpp:12-53): blocks with the introns between them
+void mate_features(const std::vector<std::pair<uint32_t, uint32_t>> &blocks, std::vector<uint8_t> &c, std::vector<uint32_t> &l,
+                   std::vector<uint32_t> &r)
+{
+   for (size_t k = 0; k < blocks.size(); ++k) {
+      if (k) {
+         c.push_back(1);
+         l.push_back(blocks[k - 1].second + 1);
+         r.push_back(blocks[k].first - 1);
+      }
+      c.push_back(0);
+      l.push_back(blocks[k].first);
+      r.push_back(blocks[k].second);
+   }
+}
+
+} // namespace
+
+int main(int argc, char **argv)
+{
+   if (argc != 4) {
+      std::fprintf(stderr, "usage: %s input.txt out.gtf ctx.tsv\n", argv[0]);
+      return 2;
+   }
+   std::ifstream in(argv[1]);
+   std::string tok, sample, chrom, strand;
+   double ins_mean = 0, ins_sd = 0, min_frac = 0;
+   int read_len = 0;
+   in >> tok >> sample >> tok >> chrom >> tok >> strand >> tok >> ins_mean >> ins_sd >> tok >> read_len >> tok >> min_frac;
+   int64_t L = 0, P = 0;
+   in >> tok >> L;
+   sbgpu::LocusBatch batch;
+   std::vector<std::string> gene_id;
+   std::vector<std::vector<std::string>> tx_id;
+   std::vector<std::vector<std::vector<std::pair<uint32_t, uint32_t>>>> tx_exons;
+   for (int64_t l = 0; l < L; ++l) {
+      std::string g;
+      int niso;
+      in >> tok >> g >> niso;
+      gene_id.push_back(g);
+      tx_id.emplace_back();
+      tx_exons.emplace_back();
+      for (int j = 0; j < niso; ++j) {
+         std::string t;
+         int ne;
+         in >> tok >> t >> ne;
+         std::vector<std::pair<uint32_t, uint32_t>> ex((size_t)ne);
+         for (auto &e : ex) in >> e.first >> e.second;
+         tx_id.back().push_back(t);
+         tx_exons.back().push_back(ex);
+      }
+      batch.add_locus(tx_exons.back());
+   }
+   in >> tok >> P;
+   std::vector<Pair> pairs((size_t)P);
+   for (auto &p : pairs) {
+      int nl, nr;
+      in >> tok >> p.locus >> p.mass >> nl;
+      p.left.resize((size_t)nl);
+      for (auto &b : p.left) in >> b.first >> b.second;
+      in >> nr;
+      p.right.resize((size_t)nr);
+      for (auto &b : p.right) in >> b.first >> b.second;
+   }
+   if (!in) {
+      std::fprintf(stderr, "malformed input\n");
+      return 2;
+   }
+   // HitCluster::collapseAndFilterHits: hits sorted by (left end, right end) of the pair
+   // (src/alignments.cpp:660, src/read.cpp:917-923); stable here, the input holds no ties
+   std::stable_sort(pairs.begin(), pairs.end(), [](const Pair &a, const Pair &b) {
+      if (a.locus != b.locus) return a.locus < b.locus;
+      const uint32_t al = a.left.front().first, bl = b.left.front().first;
+      if (al != bl) return al < bl;
+      return (a.right.empty() ? a.left : a.right).back().second < (b.right.empty() ? b.left : b.right).back().second;
+   });
+   // _total_mapped_reads += (int) cluster->weighted_mass(), src/alignments.cpp:1372
+   std::vector<double> cluster_mass((size_t)L, 0.0);
+   for (const Pair &p : pairs) {
+      cluster_mass[(size_t)p.locus] += p.mass;
+      std::vector<uint8_t> lc, rc;
+      std::vector<uint32_t> ll, lr, rl, rr;
+      mate_features(p.left, lc, ll, lr);
+      mate_features(p.right, rc, rl, rr);
+      batch.add_pair(p.locus, lc, ll, lr, rc, rl, rr, (float)p.mass); // Contig::mass() is a float
+   }
+   int total_mapped = 0;
+   for (double m : cluster_mass) total_mapped += (int)m;
+
+   try {
+      sbgpu::Context ctx(0);
+      sbgpu::InsertSize ins;
+      ins.mean = ins_mean;
+      ins.sd = ins_sd;
+      sbgpu_abundance_params_t par = {};
+      par.total_mapped_reads = total_mapped;
+      par.filter_by_expression = 1;
+      par.min_isoform_frac = min_frac;
+      batch.quantify(ctx, ins, read_len, par);
+      sbgpu::finalize_tpm(batch.isoforms, sbgpu::sum_fpkm(batch.isoforms));
+   } catch (const std::exception &e) {
+      std::fprintf(stderr, "error: %s\n", e.what());
+      return 1;
+   }
+
+   // ---- GTF: Contig::print2gtf for every kept isoform, locus by locus (src/alignments.cpp:1831-1834)
+   std::ofstream gtf(argv[2]);
+   std::vector<char> buf(1 << 20);
+   for (int64_t l = 0; l < L; ++l) {
+      for (size_t j = 0; j < tx_id[(size_t)l].size(); ++j) {
+         const sbgpu::Isoform &t = batch.isoforms[(size_t)batch.iso_off[(size_t)l] + j];
+         if (!t.kept) continue;
+         std::vector<int32_t> el, er;
+         for (const auto &e : tx_exons[(size_t)l][j]) {
+            el.push_back((int32_t)e.first);
+            er.push_back((int32_t)e.second);
+         }
+         const int n = sbgpu_format_gtf_transcript(buf.data(), (int)buf.size(), chrom.c_str(), strand[0], gene_id[(size_t)l].c_str(),
+                                                   tx_id[(size_t)l][j].c_str(), gene_id[(size_t)l].c_str(), gene_id[(size_t)l].c_str(),
+                                                   (int)el.size(), el.data(), er.data(), t.FPKM, t.frac, t.TPM,
+                                                   t.FPKM_s == "NA" ? 2 : 1);
+         sbgpu::check(n, "sbgpu_format_gtf_transcript");
+         gtf.write(buf.data(), n);
+      }
+   }
+   // ---- the -f table: Sample::printContext (src/alignments.cpp:1549-1639)
+   std::ofstream ctxf(argv[3]);
+   ctxf << "sample\tsample_frag_count\tgene_id\tgene_frag_count\ttranscripts\tFPKMs\tconditional_probabilities\t"
+           "class_probabilities\tpath_symbol\tpath_count\tpath_gc_content\tpath_hexmer_entropy\tgc_stretch_0.8_20\t"
+           "gc_stretch_0.9_20\tgc_stretch_0.8_40\tgc_stretch_0.9_40\n";
+   const int64_t n_bins = batch.row_off.back();
+   std::vector<int64_t> last_hit((size_t)n_bins, -1), n_in_bin((size_t)n_bins, 0);
+   for (int64_t h = 0; h < batch.n_hits(); ++h)
+      if (batch.hit_bin[(size_t)h] >= 0) {
+         last_hit[(size_t)batch.hit_bin[(size_t)h]] = h;
+         ++n_in_bin[(size_t)batch.hit_bin[(size_t)h]];
+      }
+   for (int64_t l = 0; l < L; ++l) {
+      const int64_t b0 = batch.row_off[(size_t)l], b1 = batch.row_off[(size_t)l + 1];
+      const int64_t j0 = batch.iso_off[(size_t)l], niso = batch.iso_off[(size_t)l + 1] - j0;
+      const int64_t s0 = batch.seg_off[(size_t)l], nseg = batch.seg_off[(size_t)l + 1] - s0;
+      uint32_t gene_frags = 0;
+      // bins in std::map order of their coordinate sets (:1552-1563)
+      std::map<std::vector<std::pair<uint32_t, uint32_t>>, int64_t> by_coords;
+      for (int64_t b = b0; b < b1; ++b) {
+         std::vector<std::pair<uint32_t, uint32_t>> coords;
+         for (int64_t s = 0; s < nseg; ++s)
+            if ((batch.bin_key[(size_t)(b * batch.key_words + (s >> 5))] >> (s & 31)) & 1u)
+               coords.emplace_back(batch.seg_left[(size_t)(s0 + s)], batch.seg_right[(size_t)(s0 + s)]);
+         by_coords[coords] = b;
+         gene_frags += (uint32_t)n_in_bin[(size_t)b];
+      }
+      std::vector<const char *> names;
+      std::vector<double> fpkm, frac;
+      for (int64_t j = 0; j < niso; ++j) {
+         names.push_back(tx_id[(size_t)l][(size_t)j].c_str());
+         fpkm.push_back(batch.isoforms[(size_t)(j0 + j)].FPKM);
+         frac.push_back(batch.isoforms[(size_t)(j0 + j)].frac);
+      }
+      for (const auto &kv : by_coords) {
+         const int64_t b = kv.second, h = last_hit[(size_t)b];
+         std::vector<double> prob((size_t)niso, 0.0);
+         std::vector<uint32_t> sl, sr;
+         for (int64_t j = 0; j < niso; ++j) // the weights of the isoforms the bin's LAST fragment fits (:1556-1563)
+            if ((batch.compat[(size_t)(h * batch.compat_words + (j >> 5))] >> (j & 31)) & 1u)
+               prob[(size_t)j] = batch.F[(size_t)(batch.f_off[(size_t)l] + (b - b0) * niso + j)];
+         for (const auto &c : kv.first) {
+            sl.push_back(c.first);
+            sr.push_back(c.second);
+         }
+         const int n = sbgpu_format_context_row(buf.data(), (int)buf.size(), sample.c_str(), total_mapped, gene_id[(size_t)l].c_str(),
+                                                gene_frags, (int)niso, names.data(), fpkm.data(), prob.data(), frac.data(),
+                                                (int)sl.size(), sl.data(), sr.data(), (uint32_t)n_in_bin[(size_t)b]);
+         sbgpu::check(n, "sbgpu_format_context_row");
+         ctxf.write(buf.data(), n);
+      }
+   }
+   std::fprintf(stderr, "%lld loci, %lld hits, %lld bins, %d mapped reads\n", (long long)L, (long long)batch.n_hits(), (long long)n_bins,
+                total_mapped);
+   return 0;
+}

@@ -1,0 +1,103 @@
+"""The host side in the reference's own language: include/sbgpu_host.hpp (C++14) and the two example
+programs over it.  CPU: they compile with g++ -std=c++14 (the reference's standard) against the
+C ABI and, without a GPU, fail loudly.  GPU: the driver turns the toy inputs into the reference
+binary's two output files byte for byte, entirely from C++; sbgpu::EmSolver reproduces the
+reference's known answers at its own call-site shape."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import e2e_util as U
+import exonbin_util as XU
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIBDIR = os.path.join(ROOT, "strawberry_amd", "lib")
+
+
+def build(tmp_path_factory, name):
+    from strawberry_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    out = str(tmp_path_factory.mktemp("cpp") / name)
+    cmd = ["g++", "-std=c++14", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", name + ".cpp"), "-L" + LIBDIR, "-lsbgpu", "-Wl,-rpath," + LIBDIR, "-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return out
+
+
+@pytest.fixture(scope="module")
+def driver(tmp_path_factory):
+    return build(tmp_path_factory, "quantify_fragments")
+
+
+@pytest.fixture(scope="module")
+def kat(tmp_path_factory):
+    return build(tmp_path_factory, "em_solver_kat")
+
+
+def write_input(directory, path):
+    ordered, rows, _, _ = U.load(directory)
+    names = list(ordered)
+    with open(path, "w") as f:
+        f.write("sample toy chrom chr1 strand + insert 250 30 read_len 75 min_isoform_frac 0\n")
+        f.write("loci %d\n" % len(names))
+        for g in names:
+            f.write("locus %s %d\n" % (g, len(ordered[g])))
+            for t, ex in ordered[g]:
+                f.write("iso %s %d %s\n" % (t, len(ex), " ".join("%d %d" % e for e in ex)))
+        reads = XU.load_reads(directory)
+        f.write("pairs %d\n" % len(reads))
+        for gi, lb, rb, mass in reads:   # in simulation order: the driver sorts them itself
+            f.write("pair %d %.17g %d %s %d %s\n" % (gi, mass, len(lb), " ".join("%d %d" % b for b in lb), len(rb),
+                                                    " ".join("%d %d" % b for b in rb)))
+    return rows
+
+
+def test_examples_compile_as_cxx14_and_refuse_to_run_without_a_gpu(driver, kat, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    inp = str(tmp_path / "in.txt")
+    write_input(U.E2E_LONG, inp)
+    r = subprocess.run([driver, inp, str(tmp_path / "o.gtf"), str(tmp_path / "c.tsv")], capture_output=True, text=True)
+    assert r.returncode == 1 and "sbgpu_init" in r.stderr      # no CPU fallback
+    r = subprocess.run([kat], capture_output=True, text=True)
+    assert r.returncode == 1 and "sbgpu_init" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["E2E", "E2E_LONG", "E2E_MASS"])
+def test_cxx_driver_reproduces_reference_files(driver, tmp_path, which):
+    d = getattr(U, which)
+    inp, gtf, ctx = str(tmp_path / "in.txt"), str(tmp_path / "out.gtf"), str(tmp_path / "ctx.tsv")
+    write_input(d, inp)
+    r = subprocess.run([driver, inp, gtf, ctx], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(ctx).read() == open(os.path.join(d, "ctx.tsv")).read()
+    ref = open(os.path.join(d, "out.gtf")).read().split("\n", 2)
+    assert ref[0].startswith("#") and ref[1].startswith("#")
+    assert open(gtf).read() == ref[2]
+
+
+@pytest.mark.gpu
+def test_cxx_emsolver_known_answers(kat):
+    """EmSolver results captured from the reference (%.12g)."""
+    r = subprocess.run([kat], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = {l.split()[0]: l.split()[1:] for l in r.stdout.strip().splitlines()}
+    ref = {
+        "toy": ("init=1", "run=1", [136.1126370333, 43.8873629667]),
+        "denom_zero": ("init=1", "run=0", [2.5, 2.5]),
+        "all_dropped": ("init=0", "run=0", [3.5, 3.5]),
+        "zero_col": ("init=1", "run=1", [4.58515682744, 25.4148431726, 0]),
+        "row_dropped": ("init=1", "run=1", [4.58515682744, 25.4148431726]),
+        "single_iso": ("init=1", "run=1", [30]),
+        "single_row": ("init=1", "run=1", [2.57142857143, 1.28571428571, 5.14285714286]),
+    }
+    assert set(got) == set(ref)
+    for k, (i, rn, th) in ref.items():
+        assert got[k][0] == i and got[k][1] == rn, (k, got[k])
+        np.testing.assert_allclose([float(x) for x in got[k][2:]], th, rtol=1e-11, atol=1e-12)
