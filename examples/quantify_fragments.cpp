@@ -165,13 +165,21 @@ int main(int argc, char **argv)
    ctxf << "sample\tsample_frag_count\tgene_id\tgene_frag_count\ttranscripts\tFPKMs\tconditional_probabilities\t"
            "class_probabilities\tpath_symbol\tpath_count\tpath_gc_content\tpath_hexmer_entropy\tgc_stretch_0.8_20\t"
            "gc_stretch_0.9_20\tgc_stretch_0.8_40\tgc_stretch_0.9_40\n";
+   // printContext runs after the expression filter, over the surviving isoforms only: a hit counts when
+   // it is compatible with one of them (get_frag_info, include/estimate.hpp:173-196)
    const int64_t n_bins = batch.row_off.back();
    std::vector<int64_t> last_hit((size_t)n_bins, -1), n_in_bin((size_t)n_bins, 0);
-   for (int64_t h = 0; h < batch.n_hits(); ++h)
-      if (batch.hit_bin[(size_t)h] >= 0) {
-         last_hit[(size_t)batch.hit_bin[(size_t)h]] = h;
-         ++n_in_bin[(size_t)batch.hit_bin[(size_t)h]];
-      }
+   for (int64_t h = 0; h < batch.n_hits(); ++h) {
+      const int64_t b = batch.hit_bin[(size_t)h];
+      if (b < 0) continue;
+      const int64_t l = batch.hit_locus[(size_t)h], j0 = batch.iso_off[(size_t)l], niso = batch.iso_off[(size_t)l + 1] - j0;
+      bool any = false;
+      for (int64_t j = 0; j < niso; ++j)
+         any |= ((batch.compat[(size_t)(h * batch.compat_words + (j >> 5))] >> (j & 31)) & 1u) && batch.isoforms[(size_t)(j0 + j)].kept;
+      if (!any) continue;
+      last_hit[(size_t)b] = h;
+      ++n_in_bin[(size_t)b];
+   }
    for (int64_t l = 0; l < L; ++l) {
       const int64_t b0 = batch.row_off[(size_t)l], b1 = batch.row_off[(size_t)l + 1];
       const int64_t j0 = batch.iso_off[(size_t)l], niso = batch.iso_off[(size_t)l + 1] - j0;
@@ -180,6 +188,7 @@ int main(int argc, char **argv)
       // bins in std::map order of their coordinate sets (:1552-1563)
       std::map<std::vector<std::pair<uint32_t, uint32_t>>, int64_t> by_coords;
       for (int64_t b = b0; b < b1; ++b) {
+         if (n_in_bin[(size_t)b] == 0) continue;
          std::vector<std::pair<uint32_t, uint32_t>> coords;
          for (int64_t s = 0; s < nseg; ++s)
             if ((batch.bin_key[(size_t)(b * batch.key_words + (s >> 5))] >> (s & 31)) & 1u)
@@ -187,26 +196,31 @@ int main(int argc, char **argv)
          by_coords[coords] = b;
          gene_frags += (uint32_t)n_in_bin[(size_t)b];
       }
+      std::vector<int64_t> kept;
       std::vector<const char *> names;
       std::vector<double> fpkm, frac;
       for (int64_t j = 0; j < niso; ++j) {
+         if (!batch.isoforms[(size_t)(j0 + j)].kept) continue;
+         kept.push_back(j);
          names.push_back(tx_id[(size_t)l][(size_t)j].c_str());
          fpkm.push_back(batch.isoforms[(size_t)(j0 + j)].FPKM);
          frac.push_back(batch.isoforms[(size_t)(j0 + j)].frac);
       }
+      if (kept.empty()) continue;
       for (const auto &kv : by_coords) {
          const int64_t b = kv.second, h = last_hit[(size_t)b];
-         std::vector<double> prob((size_t)niso, 0.0);
+         std::vector<double> prob;
          std::vector<uint32_t> sl, sr;
-         for (int64_t j = 0; j < niso; ++j) // the weights of the isoforms the bin's LAST fragment fits (:1556-1563)
-            if ((batch.compat[(size_t)(h * batch.compat_words + (j >> 5))] >> (j & 31)) & 1u)
-               prob[(size_t)j] = batch.F[(size_t)(batch.f_off[(size_t)l] + (b - b0) * niso + j)];
+         for (int64_t j : kept) // the weights of the isoforms the bin's LAST fragment fits (:1556-1563)
+            prob.push_back(((batch.compat[(size_t)(h * batch.compat_words + (j >> 5))] >> (j & 31)) & 1u)
+                              ? batch.F[(size_t)(batch.f_off[(size_t)l] + (b - b0) * niso + j)]
+                              : 0.0);
          for (const auto &c : kv.first) {
             sl.push_back(c.first);
             sr.push_back(c.second);
          }
          const int n = sbgpu_format_context_row(buf.data(), (int)buf.size(), sample.c_str(), total_mapped, gene_id[(size_t)l].c_str(),
-                                                gene_frags, (int)niso, names.data(), fpkm.data(), prob.data(), frac.data(),
+                                                gene_frags, (int)kept.size(), names.data(), fpkm.data(), prob.data(), frac.data(),
                                                 (int)sl.size(), sl.data(), sr.data(), (uint32_t)n_in_bin[(size_t)b]);
          sbgpu::check(n, "sbgpu_format_context_row");
          ctxf.write(buf.data(), n);

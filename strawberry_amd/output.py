@@ -63,29 +63,43 @@ def context_row(sample, sample_frag_count, gene_id, gene_frag_count, transcript_
     return buf.value.decode()
 
 
-def context_table(sample, total_mapped, gene_ids, transcript_ids, bins, compat, F, fpkm, frac):
+def context_table(sample, total_mapped, gene_ids, transcript_ids, bins, compat, F, fpkm, frac, keep=None):
     """The whole `-f` table of a batch of loci from the chain's results.
 
     bins: exonbin.LocusBins; compat: the kernel's words per hit [n_hits, cw]; F: the EM batch's weights
-    (host copy); fpkm / frac per isoform; transcript_ids[l] the isoform names of locus l in batch order.
-    Per bin the reference prints the weights of the isoforms its LAST fragment is compatible with and
-    the number of unique hits in it, bins in std::map order of their coordinate sets."""
+    (host copy); fpkm / frac per isoform; transcript_ids[l] the isoform names of locus l in batch order;
+    keep: per isoform, False for the ones the expression filter erased (estimate.cpp:346-355).
+    Sample::printContext runs after the filter, over the surviving isoforms only: a hit counts if it is
+    compatible with one of them, per bin the reference prints the weights of the isoforms its LAST such
+    hit is compatible with and the number of such hits, bins in std::map order of their coordinate sets."""
     out = [CONTEXT_HEADER]
     hit_bin = np.asarray(bins.hit_bin)
-    used = hit_bin >= 0
-    n_in_bin = np.bincount(hit_bin[used], minlength=bins.n_bins)
+    keep = np.ones(int(bins.iso_off[-1]), bool) if keep is None else np.asarray(keep) != 0
+    n_in_bin = np.zeros(bins.n_bins, np.int64)
     last_hit = np.full(bins.n_bins, -1, np.int64)
-    last_hit[hit_bin[used]] = np.nonzero(used)[0]          # later hits overwrite earlier ones
+    hit_locus = np.searchsorted(bins.row_off, hit_bin, side="right") - 1
+    for h in np.nonzero(hit_bin >= 0)[0]:
+        l = hit_locus[h]
+        i0, niso = int(bins.iso_off[l]), int(bins.iso_off[l + 1] - bins.iso_off[l])
+        if any((int(compat[h][j >> 5]) >> (j & 31)) & 1 and keep[i0 + j] for j in range(niso)):
+            n_in_bin[hit_bin[h]] += 1
+            last_hit[hit_bin[h]] = h                      # later hits overwrite earlier ones
     for l, gene in enumerate(gene_ids):
         b0, b1 = int(bins.row_off[l]), int(bins.row_off[l + 1])
         i0, i1 = int(bins.iso_off[l]), int(bins.iso_off[l + 1])
         niso = i1 - i0
+        kept = [j for j in range(niso) if keep[i0 + j]]
+        if not kept:
+            continue
         coords = bins.bin_coords(l)
         gene_frags = int(n_in_bin[b0:b1].sum())
         Fl = np.asarray(F[bins.f_off[l]:bins.f_off[l + 1]]).reshape(b1 - b0, niso)
         for b in sorted(range(b1 - b0), key=lambda k: coords[k]):
+            if n_in_bin[b0 + b] == 0:
+                continue
             words = compat[last_hit[b0 + b]]
-            mask = np.array([(int(words[j >> 5]) >> (j & 31)) & 1 for j in range(niso)], bool)
-            out.append(context_row(sample, total_mapped, gene, gene_frags, transcript_ids[l], fpkm[i0:i1],
-                                   np.where(mask, Fl[b], 0.0), frac[i0:i1], coords[b], n_in_bin[b0 + b]))
+            prob = [Fl[b, j] if (int(words[j >> 5]) >> (j & 31)) & 1 else 0.0 for j in kept]
+            out.append(context_row(sample, total_mapped, gene, gene_frags, [transcript_ids[l][j] for j in kept],
+                                   [fpkm[i0 + j] for j in kept], prob, [frac[i0 + j] for j in kept], coords[b],
+                                   n_in_bin[b0 + b]))
     return "".join(out)

@@ -15,6 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 E2E = os.path.join(HERE, "golden", "e2e_toy")            # short exons: bins over many segments
 E2E_LONG = os.path.join(HERE, "golden", "e2e_toy_long")  # exons longer than any mate gap
 E2E_MASS = os.path.join(HERE, "golden", "e2e_toy_mass")  # PCR duplicates + multi-mapped pairs (masses 1, 1/2, 1/3)
+E2E_FILTER = os.path.join(HERE, "golden", "e2e_toy_filter")  # e2e_toy_long's reads with -e 0.05: isoforms erased
 
 
 def load(directory):
@@ -22,9 +23,12 @@ def load(directory):
     genes = parse_annotation(os.path.join(directory, "toy.gtf"))
     rows = parse_ctx(os.path.join(directory, "ctx.tsv"))
     # the reference orders a locus' isoforms its own way (sorted by position); the -f table's
-    # `transcripts` column is that order, and the theta log follows it
+    # `transcripts` column is that order, and the theta log follows it.  With the expression filter on,
+    # the table only lists the surviving isoforms: the order then comes from the unfiltered run of the
+    # same annotation (e2e_toy_long).
+    order_rows = parse_ctx(os.path.join(E2E_LONG, "ctx.tsv")) if directory == E2E_FILTER else rows
     ordered = {}
-    for r in rows:
+    for r in order_rows:
         if r["gene"] not in ordered:
             by_name = dict(genes[r["gene"]])
             ordered[r["gene"]] = [(t, by_name[t]) for t in r["transcripts"]]

@@ -204,3 +204,30 @@ def test_context_row_formatting_round_trips_reference_table(which):
         again = context_row(f[0], int(f[1]), f[2], int(f[3]), f[4].split(","), [float(x) for x in f[5].split(",")],
                             [float(x) for x in f[6].split(",")], [float(x) for x in f[7].split(",")], coords, int(f[9]))
         assert again == line
+
+
+def test_expression_filter_reproduces_reference_gtf(oracle):
+    """A3 filter + A7: the reference run with `-r -e 0.05` (tests/golden/e2e_toy_filter) erases the
+    isoforms below 5 % of their locus after the EM (estimate.cpp:346-355) and takes TPM over the
+    survivors; the oracle's epilogue on the logged theta must keep exactly the transcripts the GTF
+    holds and agree with its numbers."""
+    genes, rows, gtf, theta_log = U.load(U.E2E_FILTER)
+    total_mapped = rows[0]["total_mapped"]
+    fpkm_all, keep_all, names = [], [], []
+    for (g, tx), th in zip(genes.items(), theta_log):
+        length = [sum(b - a + 1 for a, b in ex) for _, ex in tx]
+        fpkm, frac, keep, _ = oracle.abundance_locus(th, length, total_mapped, min_isoform_frac=0.05)
+        for (t, _), f, fr, k in zip(tx, fpkm, frac, keep):
+            assert bool(k) == (t in gtf), (t, fr)
+            if k:
+                assert abs(f - float(gtf[t][0])) <= 2e-5 * max(1.0, abs(f))
+                assert abs(fr - float(gtf[t][1])) < 2e-6
+            names.append(t)
+        fpkm_all += list(fpkm)
+        keep_all += list(keep)
+    assert 0 < sum(1 for k in keep_all if not k) < len(keep_all)
+    tpm, _ = oracle.tpm(np.array(fpkm_all), np.array(keep_all, np.int32))
+    for t, v, k in zip(names, tpm, keep_all):
+        if k:
+            assert abs(v - float(gtf[t][2])) <= 2e-5 * max(1.0, v), (t, v, gtf[t][2])
+    assert abs(tpm[np.array(keep_all) != 0].sum() - 1e6) < 1e-3

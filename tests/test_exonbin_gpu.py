@@ -164,7 +164,7 @@ def test_large_batch_properties(ctx, oracle):
     np.testing.assert_array_equal(k2.reshape(64, hits.n_hits, -1), np.broadcast_to(key, (64,) + key.shape))
 
 
-@pytest.mark.parametrize("which", ["E2E", "E2E_LONG", "E2E_MASS"])
+@pytest.mark.parametrize("which", ["E2E", "E2E_LONG", "E2E_MASS", "E2E_FILTER"])
 def test_chain_from_fragments_reproduces_reference_run(ctx, oracle, which):
     """Our simulated fragments (reads.npz, the BAM the reference binary was run on) through the whole
     device chain: bins and counts == the -f table; every nonzero weight of the table == F (12 digits);
@@ -185,6 +185,10 @@ def test_chain_from_fragments_reproduces_reference_run(ctx, oracle, which):
         niso = int(bins.iso_off[l + 1] - bins.iso_off[l])
         Fl = F[bins.f_off[l]:bins.f_off[l + 1]].reshape(len(coords), niso)
         ref_rows = [r for r in rows if r["gene"] == g]
+        if which == "E2E_FILTER":   # the table lost the erased isoforms' columns (and some bins): compared as a file below
+            assert set(tuple(r["coords"]) for r in ref_rows) <= set(coords)
+            n_checked += len(ref_rows)
+            continue
         assert sorted(coords) == sorted(tuple(r["coords"]) for r in ref_rows)
         for r in ref_rows:
             b = coords.index(tuple(r["coords"]))
@@ -194,14 +198,19 @@ def test_chain_from_fragments_reproduces_reference_run(ctx, oracle, which):
                 if f != 0.0:
                     assert abs(Fl[b, j] - f) <= 5e-11 * f, (g, r["coords"], j)
                     n_checked += 1
-    assert n_checked > 100
+    assert n_checked > (50 if which == "E2E_FILTER" else 100)
     assert hits.total_mapped == rows[0]["total_mapped"]
-    res = q.solve(hits.total_mapped, min_isoform_frac=0.0)   # the golden run used -r: kMinIsoformFrac = 0 (Strawberry.cpp:158-161)
+    min_frac = 0.05 if which == "E2E_FILTER" else 0.0   # -r: kMinIsoformFrac = 0; -r -e 0.05: 0.05 (Strawberry.cpp:158-177)
+    res = q.solve(hits.total_mapped, min_isoform_frac=min_frac)
+    assert (res["keep"] == 0).sum() == (5 if which == "E2E_FILTER" else 0)
     for l, ref_theta in enumerate(theta_log):
         th = res["theta"][bins.iso_off[l]:bins.iso_off[l + 1]]
         assert np.abs(th - np.array(ref_theta)).max() < 1e-6, (names[l], th, ref_theta)
     tx_names = [t for g in names for t, _ in ordered[g]]
-    for t, f, fr, tp in zip(tx_names, res["fpkm"], res["frac"], res["tpm"]):
+    assert set(gtf) == set(t for t, k in zip(tx_names, res["keep"]) if k)   # exactly the survivors are written
+    for t, f, fr, tp, k in zip(tx_names, res["fpkm"], res["frac"], res["tpm"], res["keep"]):
+        if not k:
+            continue
         assert abs(f - float(gtf[t][0])) <= 1e-5 * max(1.0, f), t       # FPKM/TPM: 1e-4 rel is the bar; we are tighter
         assert abs(fr - float(gtf[t][1])) < 2e-6, t
         assert abs(tp - float(gtf[t][2])) <= 1e-5 * max(1.0, tp), t
@@ -214,14 +223,15 @@ def test_chain_from_fragments_reproduces_reference_run(ctx, oracle, which):
     from strawberry_amd.output import context_table, gtf_transcript
     compat = q.d_compat.cpu().numpy().view(np.uint32)[:hits.n_hits]
     table = context_table("toy", rows[0]["total_mapped"], names, [[t for t, _ in ordered[g]] for g in names], bins,
-                          compat, F, res["fpkm"], res["frac"])
+                          compat, F, res["fpkm"], res["frac"], keep=res["keep"])
     assert table == open(os.path.join(d, "ctx.tsv")).read()
     gtf_text = []
     k = 0
     for g in names:
         for t, ex in ordered[g]:
-            gtf_text.append(gtf_transcript("chr1", "+", g, t, ex, res["fpkm"][k], res["frac"][k], res["tpm"][k],
-                                           ref_gene_id=g, ref_gene_name=g))
+            if res["keep"][k]:
+                gtf_text.append(gtf_transcript("chr1", "+", g, t, ex, res["fpkm"][k], res["frac"][k], res["tpm"][k],
+                                               ref_gene_id=g, ref_gene_name=g))
             k += 1
     ref_gtf = open(os.path.join(d, "out.gtf")).read().split("\n", 2)
     assert ref_gtf[0].startswith("#") and ref_gtf[1].startswith("#")   # command line + rule: not data

@@ -161,6 +161,10 @@ def main():
     #          are sums of 1, 1/2, 1/3 -- pins the collapse mass, the float accumulation of
     #          ExonBin::read_count with its int truncation, and the int-truncated mapped-read total.
     make("e2e_toy_mass", 4444, 200, 700, dup=0.3, multi=0.35, extra=["--allow-multimapped-hits"])
+    # e2e_toy_filter: the reads of e2e_toy_long with `-e 0.05` after `-r` (kMinIsoformFrac = 0.05,
+    #          Strawberry.cpp:158-177): isoforms below 5 % of their locus are erased after the EM
+    #          (estimate.cpp:346-355), TPM is taken over the survivors, the -f table loses their columns.
+    make("e2e_toy_filter", 4343, 420, 900, extra=["-e", "0.05"])
 
 
 def make(name, seed, ex_lo, ex_hi, dup=0.0, multi=0.0, extra=()):
