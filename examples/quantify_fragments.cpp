@@ -126,14 +126,12 @@ int main(int argc, char **argv)
 
    try {
       sbgpu::Context ctx(0);
-      sbgpu::InsertSize ins;
-      ins.mean = ins_mean;
-      ins.sd = ins_sd;
+      sbgpu::InsertSize ins(ins_mean, ins_sd); // `insert 0 0`: no -i, build the empirical distribution
       sbgpu_abundance_params_t par = {};
       par.total_mapped_reads = total_mapped;
       par.filter_by_expression = 1;
       par.min_isoform_frac = min_frac;
-      batch.quantify(ctx, ins, read_len, par);
+      batch.quantify(ctx, (ins_mean != 0 && ins_sd != 0) ? &ins : nullptr, read_len, par); // Strawberry.cpp:339-356
       sbgpu::finalize_tpm(batch.isoforms, sbgpu::sum_fpkm(batch.isoforms));
    } catch (const std::exception &e) {
       std::fprintf(stderr, "error: %s\n", e.what());

@@ -285,6 +285,14 @@ int sbgpu_hit_features(int n_left, const uint8_t *lcode, const uint32_t *lleft, 
                        int n_right, const uint8_t *rcode, const uint32_t *rleft, const uint32_t *rright,
                        uint8_t *code_out, uint32_t *left_out, uint32_t *right_out);
 
+/* The sample of the empirical insert-size distribution, Sample::fragLenDist's inner loop
+ * (src/alignments.cpp:1381-1407): frag_len_out[h] = Contig::exonic_overlaps_len(t, hit.left(),
+ * hit.right()) (src/contig.cpp:412-426) when hit h is compatible with exactly ONE transcript t of
+ * its locus, else -1.  `compat` is the kernel's result (host copy).  Returns how many hits got a
+ * length; InsertSize(frag_lens) (src/read.cpp:238-262) takes them in hit order.              */
+int64_t sbgpu_frag_lens_host(const sbgpu_annotation_t *annot, const sbgpu_hits_t *hits,
+                             int32_t compat_words, const uint32_t *compat, int32_t *frag_len_out);
+
 /* LocusContext::assign_exon_bin + set_maps (src/estimate.cpp:135-198, estimate.hpp:29-52)
  * on the kernel's results (host copies of compat / key), hits visited in input order inside
  * each locus (= HitCluster::uniq_hits() order):

@@ -18,6 +18,7 @@
 #ifndef SBGPU_HOST_HPP_
 #define SBGPU_HOST_HPP_
 
+#include <cmath>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -126,6 +127,28 @@ struct InsertSize { /* include/read.hpp:176-192 */
    bool use_emp = false;
    int start_offset = 0, end_offset = 0, total_reads = 0;
    std::vector<double> emp_dist;
+   InsertSize() = default;
+   InsertSize(double m, double s) : mean(m), sd(s) {}
+   /* InsertSize(const vector<int> frag_lens), src/read.cpp:238-262 (+ mean_and_sd_insert_size, :14-20) */
+   explicit InsertSize(const std::vector<int> &frag_lens) : use_emp(true)
+   {
+      total_reads = (int)frag_lens.size();
+      if (total_reads < 1) throw std::runtime_error("Not enough reads");
+      double sum = 0.0, sq = 0.0;
+      int lo = frag_lens[0], hi = frag_lens[0];
+      for (int v : frag_lens) {
+         sum += v;
+         lo = v < lo ? v : lo;
+         hi = v > hi ? v : hi;
+      }
+      for (int v : frag_lens) sq += (double)v * v;
+      mean = sum / frag_lens.size();
+      sd = std::sqrt(sq / frag_lens.size() - mean * mean);
+      start_offset = lo;
+      end_offset = hi;
+      emp_dist.assign((size_t)(hi - lo + 1), 0.0);
+      for (int v : frag_lens) emp_dist[(size_t)(v - lo)] += 1.0;
+   }
 };
 
 struct Isoform { /* what the epilogue fills: include/isoform.h:40-58 */
@@ -210,9 +233,13 @@ public:
       return h;
    }
 
+   InsertSize insert; /* the distribution quantify() used (the empirical one when it was asked to build it) */
+
    /* LocusContext ctor + estimate_abundances for every locus.  total_mapped_reads, min_isoform_frac
-    * etc. are the globals the reference reads (sbgpu_abundance_params_t).                          */
-   void quantify(const Context &ctx, const InsertSize &ins, int read_len, const sbgpu_abundance_params_t &par,
+    * etc. are the globals the reference reads (sbgpu_abundance_params_t).  ins_in == nullptr: no -i was
+    * given, the empirical insert-size distribution is built from the hits first (Sample::fragLenDist,
+    * src/alignments.cpp:1363-1407 + Strawberry.cpp:345-355).                                       */
+   void quantify(const Context &ctx, const InsertSize *ins_in, int read_len, const sbgpu_abundance_params_t &par,
                  bool long_read = false)
    {
       const int64_t nl = n_loci();
@@ -239,6 +266,18 @@ public:
       sbgpu_annotation_t an = annotation();
       sbgpu_hits_t ht = hits();
       check(sbgpu_exonbin_host(ctx.get(), &an, &ht, compat_words, key_words, compat.data(), key.data()), "sbgpu_exonbin_host");
+      if (ins_in) {
+         insert = *ins_in;
+      } else {
+         std::vector<int32_t> fl((size_t)nh + 1, -1);
+         const int64_t n = sbgpu_frag_lens_host(&an, &ht, compat_words, compat.data(), fl.data());
+         check((int)(n < 0 ? n : 0), "sbgpu_frag_lens_host");
+         std::vector<int> lens;
+         for (int64_t h = 0; h < nh; ++h)
+            if (fl[(size_t)h] >= 0) lens.push_back(fl[(size_t)h]);
+         insert = InsertSize(lens);
+      }
+      const InsertSize &ins = insert;
       sbgpu_bins_t *bins = nullptr;
       check(sbgpu_bins_create(&an, &ht, hit_mass.data(), compat_words, key_words, compat.data(), key.data(), &bins),
             "sbgpu_bins_create");

@@ -19,7 +19,7 @@ SYMBOLS = [
     "sbgpu_device_info", "sbgpu_synchronize", "sbgpu_plan_create", "sbgpu_plan_destroy", "sbgpu_plan_info",
     "sbgpu_plan_classes", "sbgpu_plan_locus_kinds", "sbgpu_em_run_device", "sbgpu_em_last_kernel_ms",
     "sbgpu_insert_pdf_table", "sbgpu_binweight_device", "sbgpu_binweight_host",
-    "sbgpu_exonbin_device", "sbgpu_exonbin_host", "sbgpu_segments_host", "sbgpu_hit_features",
+    "sbgpu_exonbin_device", "sbgpu_exonbin_host", "sbgpu_segments_host", "sbgpu_hit_features", "sbgpu_frag_lens_host",
     "sbgpu_bins_create", "sbgpu_bins_destroy", "sbgpu_bins_info", "sbgpu_bins_export",
     "sbgpu_format_value", "sbgpu_format_gtf_transcript", "sbgpu_format_context_row", "sbgpu_em_batch", "sbgpu_abundance_device", "sbgpu_tpm_device",
 ]
@@ -142,6 +142,8 @@ def load():
                                      vp, vp]
     L.sbgpu_segments_host.argtypes = [C.c_int64, vp, vp, vp, vp, vp, vp, vp, C.c_int64]
     L.sbgpu_segments_host.restype = C.c_int64
+    L.sbgpu_frag_lens_host.argtypes = [C.POINTER(sbgpu_annotation_t), C.POINTER(sbgpu_hits_t), C.c_int32, vp, vp]
+    L.sbgpu_frag_lens_host.restype = C.c_int64
     L.sbgpu_hit_features.argtypes = [C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.sbgpu_bins_create.argtypes = [C.POINTER(sbgpu_annotation_t), C.POINTER(sbgpu_hits_t), vp, C.c_int32, C.c_int32,
                                     vp, vp, C.POINTER(vp)]

@@ -160,6 +160,42 @@ int sbgpu_hit_features(int n_left, const uint8_t *lcode, const uint32_t *lleft, 
    return (int)g.size();
 }
 
+int64_t sbgpu_frag_lens_host(const sbgpu_annotation_t *an, const sbgpu_hits_t *hits, int32_t compat_words,
+                             const uint32_t *compat, int32_t *frag_len_out)
+{
+   if (!an || !hits || (hits->n_hits && (!compat || !frag_len_out || !hits->hit_locus || !hits->feat_off)) || compat_words < 1)
+      return api_fail(SBGPU_EINVAL, "sbgpu_frag_lens_host: bad argument");
+   int64_t n = 0;
+   for (int64_t h = 0; h < hits->n_hits; ++h) {
+      frag_len_out[h] = -1;
+      const int32_t loc = hits->hit_locus[h];
+      if (loc < 0 || loc >= an->n_loci) return api_fail(SBGPU_EINVAL, "sbgpu_frag_lens_host: hit_locus out of range");
+      const int64_t f0 = hits->feat_off[h], f1 = hits->feat_off[h + 1];
+      if (f1 <= f0) continue;
+      // compatible with exactly one transcript (alignments.cpp:1383-1392)
+      int counter = 0;
+      int64_t mark = 0;
+      const int64_t niso = an->iso_off[loc + 1] - an->iso_off[loc];
+      for (int64_t j = 0; j < niso && j < 32 * (int64_t)compat_words; ++j)
+         if ((compat[h * compat_words + (j >> 5)] >> (j & 31)) & 1u) {
+            ++counter;
+            mark = j;
+         }
+      if (counter != 1) continue;
+      // Contig::exonic_overlaps_len(transcript, hit.left(), hit.right()), src/contig.cpp:412-426
+      const uint32_t left = hits->feat_left[f0], right = hits->feat_right[f1 - 1];
+      const int64_t iso = an->iso_off[loc] + mark;
+      int64_t len = 0;
+      for (int64_t e = an->exon_off[iso]; e < an->exon_off[iso + 1]; ++e) {
+         const uint32_t xl = an->exon_left[e], xr = an->exon_right[e];
+         if (xl <= right && left <= xr) len += (int64_t)std::min(xr, right) - (int64_t)std::max(xl, left) + 1; // :118-125
+      }
+      frag_len_out[h] = (int32_t)len;
+      ++n;
+   }
+   return n;
+}
+
 int sbgpu_bins_create(const sbgpu_annotation_t *an, const sbgpu_hits_t *hits, const float *hit_mass,
                       int32_t compat_words, int32_t key_words, const uint32_t *compat, const uint32_t *key,
                       sbgpu_bins_t **out)

@@ -145,6 +145,20 @@ def compat_and_keys(annot, hits, ctx=None, device=0, compat_words=None, key_word
     return compat[:hits.n_hits, :cw], key[:hits.n_hits, :kw]
 
 
+def frag_lens(annot, hits, compat):
+    """The empirical insert-size sample (Sample::fragLenDist): the exonic span of every hit that is
+    compatible with exactly one transcript, in hit order.  -> int array (only those hits)."""
+    L = _lib.load()
+    compat = np.ascontiguousarray(compat, np.uint32)
+    out = np.full(max(hits.n_hits, 1), -1, np.int32)
+    a, h = annot._struct(), hits._struct()
+    n = L.sbgpu_frag_lens_host(C.byref(a), C.byref(h), compat.shape[1], _ptr(compat), out.ctypes.data)
+    if n < 0:
+        _lib.check(int(n), "sbgpu_frag_lens_host")
+    out = out[:hits.n_hits]
+    return out[out >= 0]
+
+
 class LocusBins:
     """The exon bins of a batch of loci: an EM batch minus F, and the bin-weight kernel's pairs."""
 

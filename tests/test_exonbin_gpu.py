@@ -164,7 +164,7 @@ def test_large_batch_properties(ctx, oracle):
     np.testing.assert_array_equal(k2.reshape(64, hits.n_hits, -1), np.broadcast_to(key, (64,) + key.shape))
 
 
-@pytest.mark.parametrize("which", ["E2E", "E2E_LONG", "E2E_MASS", "E2E_FILTER"])
+@pytest.mark.parametrize("which", ["E2E", "E2E_LONG", "E2E_MASS", "E2E_FILTER", "E2E_EMP"])
 def test_chain_from_fragments_reproduces_reference_run(ctx, oracle, which):
     """Our simulated fragments (reads.npz, the BAM the reference binary was run on) through the whole
     device chain: bins and counts == the -f table; every nonzero weight of the table == F (12 digits);
@@ -178,6 +178,10 @@ def test_chain_from_fragments_reproduces_reference_run(ctx, oracle, which):
     o_compat, o_key = oracle.exonbin_batch(annot, hits)
     np.testing.assert_array_equal(q.d_compat.cpu().numpy().view(np.uint32)[:hits.n_hits], o_compat)
     np.testing.assert_array_equal(q.d_key.cpu().numpy().view(np.uint32)[:hits.n_hits], o_key)
+    if which == "E2E_EMP":   # no -i: the empirical insert-size distribution, built from the hits (pass 1)
+        from strawberry_amd import exonbin as eb
+        q.insert = InsertSize.from_frag_lens(eb.frag_lens(annot, hits, o_compat))
+        assert q.insert.use_emp and q.insert.total_reads > 1000 and abs(q.insert.mean - MEAN) < 5
     F = q.bin_weights().cpu().numpy()
     n_checked = 0
     for l, g in enumerate(names):

@@ -203,3 +203,44 @@ def test_bins_bookkeeping_rules():
     wide = eb.Annotation([[[(k * 100, k * 100 + 50)] for k in range(1, 40)]])
     with pytest.raises(SbgpuError):
         eb.LocusBins(wide, eb.Hits([0], [m(100, 120)]), np.zeros((1, 1), np.uint32), np.zeros((1, 2), np.uint32))
+
+
+def test_empirical_insert_size_reproduces_reference_weights(oracle):
+    """No -i (tests/golden/e2e_toy_emp): the reference builds the empirical insert-size distribution from
+    every unique hit that fits exactly one transcript (fragLenDist) and the bin weights use it.
+    sbgpu_frag_lens_host + InsertSize(frag_lens) + the oracle's weight model must reproduce every nonzero
+    weight of the reference's -f table (12 digits) and, through the oracle's EM, the logged theta."""
+    from strawberry_amd.binweight import InsertSize
+    d = U.E2E_EMP
+    ordered, rows, gtf, theta_log = U.load(d)
+    annot, hits, names, _ = XU.e2e_inputs(d, ordered)
+    compat, key = oracle.exonbin_batch(annot, hits)
+    fl = eb.frag_lens(annot, hits, compat)
+    popc = np.array([bin(int(w)).count("1") for w in compat[:, 0]])
+    assert len(fl) == (popc == 1).sum() > 1000
+    ins = InsertSize.from_frag_lens(fl)
+    assert ins.use_emp and ins.start_offset == fl.min() and ins.end_offset == fl.max()
+    oi = oracle.make_insert(ins.mean, ins.sd, frag_lens=fl)
+    bins = eb.LocusBins(annot, hits, compat, key)
+    F = np.zeros(bins.n_elem)
+    for p in range(bins.n_pairs):
+        s = slice(bins.pair_seg_off[p], bins.pair_seg_off[p + 1])
+        imp = [k for k in range(32) if (int(bins.pair_implicit_mask[p]) >> k) & 1]
+        F[bins.pair_out_index[p]] = oracle.bin_weight(bins.pair_seg_lens[s], imp, int(bins.pair_iso_len[p]), 75, oi)
+    n = 0
+    for l, g in enumerate(names):
+        coords = [tuple(c) for c in bins.bin_coords(l)]
+        niso = int(bins.iso_off[l + 1] - bins.iso_off[l])
+        Fl = F[bins.f_off[l]:bins.f_off[l + 1]].reshape(len(coords), niso)
+        for r in rows:
+            if r["gene"] == g:
+                b = coords.index(tuple(r["coords"]))
+                for j, f in enumerate(r["F"]):
+                    if f != 0.0:
+                        assert abs(Fl[b, j] - f) <= 5e-11 * f, (g, r["coords"], j, Fl[b, j], f)
+                        n += 1
+    assert n > 150
+    theta, status, iters = oracle.em_batch(bins.row_off, bins.iso_off, bins.f_off, bins.count, F)
+    for l, ref_theta in enumerate(theta_log):
+        th = theta[bins.iso_off[l]:bins.iso_off[l + 1]]
+        assert np.abs(th - np.array(ref_theta)).max() < 1e-6, (names[l], th, ref_theta)

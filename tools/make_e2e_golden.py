@@ -165,9 +165,13 @@ def main():
     #          Strawberry.cpp:158-177): isoforms below 5 % of their locus are erased after the EM
     #          (estimate.cpp:346-355), TPM is taken over the survivors, the -f table loses their columns.
     make("e2e_toy_filter", 4343, 420, 900, extra=["-e", "0.05"])
+    # e2e_toy_emp: the reads of e2e_toy WITHOUT -i: the reference then builds the empirical insert-size
+    #          distribution in its first pass (fragLenDist, alignments.cpp:1363-1407: the exonic span of every
+    #          unique hit that fits exactly one transcript) and the bin weights use it (read.cpp:274-297).
+    make("e2e_toy_emp", 4242, 60, 400, insert=False)
 
 
-def make(name, seed, ex_lo, ex_hi, dup=0.0, multi=0.0, extra=()):
+def make(name, seed, ex_lo, ex_hi, dup=0.0, multi=0.0, extra=(), insert=True):
     rng = np.random.Generator(np.random.PCG64(seed))
     genes, chrom_len = make_annotation(rng, 6, ex_lo, ex_hi)
     out_dir = os.path.join(ROOT, "tests", "golden", name)
@@ -184,7 +188,7 @@ def make(name, seed, ex_lo, ex_hi, dup=0.0, multi=0.0, extra=()):
                 f.write(line + "\n")
         bam = os.path.join(tmp, "toy.bam")
         subprocess.check_call([SAM2BAM, sam, bam])
-        cmd = [REF_BIN, bam, "-g", gtf, "-r", "-i", "%d/%d" % (MEAN, SD), "-o", os.path.join(tmp, "out.gtf"),
+        cmd = [REF_BIN, bam, "-g", gtf, "-r"] + (["-i", "%d/%d" % (MEAN, SD)] if insert else []) + ["-o", os.path.join(tmp, "out.gtf"),
                "-T", os.path.join(tmp, "log.txt"), "-f", os.path.join(tmp, "ctx.tsv")] + list(extra)
         r = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True)
         print(r.stdout[-2000:])
@@ -201,8 +205,10 @@ def make(name, seed, ex_lo, ex_hi, dup=0.0, multi=0.0, extra=()):
             f.write("Generated by tools/make_e2e_golden.py from the reference binary (oracle/_ref/strawberry_ref):\n"
                     "  %s\n"
                     "toy.gtf is our synthetic annotation; out.gtf, ctx.tsv and theta_log.txt are the reference's outputs.\n"
-                    "%d read records, read length %d, insert size -i %d/%d (Gaussian), %d genes.\n" % (
-                        " ".join(os.path.basename(c) if c.startswith("/") else c for c in cmd), len(recs), RL, MEAN, SD,
+                    "%d read records, read length %d, %s, %d genes.\n" % (
+                        " ".join(os.path.basename(c) if c.startswith("/") else c for c in cmd), len(recs), RL,
+                        ("insert size -i %d/%d (Gaussian)" % (MEAN, SD)) if insert else
+                        "no -i: empirical insert-size distribution (fragments simulated from N(%d, %d))" % (MEAN, SD),
                         len(genes)))
     for name in sorted(os.listdir(out_dir)):
         print(name, os.path.getsize(os.path.join(out_dir, name)))
