@@ -44,7 +44,7 @@ def e2e_inputs(directory, ordered_genes):
         if f is None:
             rejected += 1
             continue
-        rows.append((gi, lb[0][0], rb[-1][1], f, mass))
+        rows.append((gi, lb[0][0], (rb or lb)[-1][1], f, mass))
     rows.sort(key=lambda r: (r[0], r[1], r[2]))
     hits = eb.Hits([r[0] for r in rows], [r[3] for r in rows], mass=[r[4] for r in rows])
     hits.total_mapped = sum(int(m) for m in cluster_mass)

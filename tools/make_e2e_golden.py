@@ -83,7 +83,7 @@ def cigar(blocks):
     return s
 
 
-def simulate(rng, genes, frags_per_gene, dup=0.0, multi=0.0):
+def simulate(rng, genes, frags_per_gene, dup=0.0, multi=0.0, single=False):
     """dup: chance that a fragment is sequenced again (1-3 PCR duplicates: same alignments, other read
     names); multi: chance that a pair is multi-mapped (NH 2 or 3 on both mates).  With either, two
     different fragments never share (left end, right end): the reference sorts hits by that pair only
@@ -107,6 +107,18 @@ def simulate(rng, genes, frags_per_gene, dup=0.0, multi=0.0):
             right = tx_to_genome(ex, st + fl - RL, st + fl)
             sig = (tuple(left), tuple(right))
             if sig in seen:     # no duplicate fragments: bin counts then equal uniq-hit counts
+                continue
+            if single:          # single-end library: only the first mate is sequenced, unpaired (flag 0)
+                right = []
+                sig = (tuple(left), ())
+                if sig in seen or (left[0][0], left[-1][1]) in spans:
+                    continue
+                spans.add((left[0][0], left[-1][1]))
+                seen.add(sig)
+                rid += 1
+                recs.append((left[0][0], "r%06d\t0\tchr1\t%d\t255\t%s\t*\t0\t0\t%s\t%s\tNH:i:1\tXS:A:+" % (
+                    rid, left[0][0], cigar(left), "A" * RL, "I" * RL)))
+                frags.append((gi, left, right, [1]))
                 continue
             if dup or multi:
                 if (left[0][0], right[-1][1]) in spans:
@@ -169,9 +181,12 @@ def main():
     #          distribution in its first pass (fragLenDist, alignments.cpp:1363-1407: the exonic span of every
     #          unique hit that fits exactly one transcript) and the bin weights use it (read.cpp:274-297).
     make("e2e_toy_emp", 4242, 60, 400, insert=False)
+    # e2e_toy_single: a single-end library (unpaired reads).  The reference then forces the insert size to
+    #          N(200, 80) whatever -i says (Strawberry.cpp:329-333) and every hit is a single read.
+    make("e2e_toy_single", 4545, 60, 400, single=True)
 
 
-def make(name, seed, ex_lo, ex_hi, dup=0.0, multi=0.0, extra=(), insert=True):
+def make(name, seed, ex_lo, ex_hi, dup=0.0, multi=0.0, extra=(), insert=True, single=False):
     rng = np.random.Generator(np.random.PCG64(seed))
     genes, chrom_len = make_annotation(rng, 6, ex_lo, ex_hi)
     out_dir = os.path.join(ROOT, "tests", "golden", name)
@@ -179,7 +194,7 @@ def make(name, seed, ex_lo, ex_hi, dup=0.0, multi=0.0, extra=(), insert=True):
     with tempfile.TemporaryDirectory() as tmp:
         gtf = os.path.join(tmp, "toy.gtf")
         write_gtf(genes, gtf)
-        recs, frags = simulate(rng, genes, 900, dup, multi)
+        recs, frags = simulate(rng, genes, 900, dup, multi, single)
         save_frags(frags, os.path.join(out_dir, "reads.npz"))
         sam = os.path.join(tmp, "toy.sam")
         with open(sam, "w") as f:
