@@ -9,7 +9,9 @@
 //   ./quantify_fragments input.txt out.gtf ctx.tsv
 //
 // Input (plain text, whitespace separated):
-//   sample <name>  chrom <name>  strand <+|->  insert <mean> <sd>  read_len <n>  min_isoform_frac <x>
+//   sample <name>  chrom <name>  strand <+|->  insert <mean> <sd>  read_len <n>  min_isoform_frac <x>  long_read <0|1>
+//         (insert 0 0: no -i, empirical distribution; long_read: the reference's long-read workflow,
+//          Strawberry.cpp:292-303, decided by the caller from the read lengths)
 //   loci <L>
 //     locus <gene_id> <n_isoforms>
 //       iso <transcript_id> <n_exons> <left> <right> ...          (the reference's isoform order)
@@ -63,7 +65,9 @@ int main(int argc, char **argv)
    std::string tok, sample, chrom, strand;
    double ins_mean = 0, ins_sd = 0, min_frac = 0;
    int read_len = 0;
-   in >> tok >> sample >> tok >> chrom >> tok >> strand >> tok >> ins_mean >> ins_sd >> tok >> read_len >> tok >> min_frac;
+   int long_read = 0;
+   in >> tok >> sample >> tok >> chrom >> tok >> strand >> tok >> ins_mean >> ins_sd >> tok >> read_len >> tok >> min_frac >> tok >>
+      long_read;
    int64_t L = 0, P = 0;
    in >> tok >> L;
    sbgpu::LocusBatch batch;
@@ -131,7 +135,7 @@ int main(int argc, char **argv)
       par.total_mapped_reads = total_mapped;
       par.filter_by_expression = 1;
       par.min_isoform_frac = min_frac;
-      batch.quantify(ctx, (ins_mean != 0 && ins_sd != 0) ? &ins : nullptr, read_len, par); // Strawberry.cpp:339-356
+      batch.quantify(ctx, (ins_mean != 0 && ins_sd != 0) ? &ins : nullptr, read_len, par, long_read != 0); // Strawberry.cpp:339-356
       sbgpu::finalize_tpm(batch.isoforms, sbgpu::sum_fpkm(batch.isoforms));
    } catch (const std::exception &e) {
       std::fprintf(stderr, "error: %s\n", e.what());

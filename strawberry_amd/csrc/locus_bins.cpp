@@ -378,11 +378,16 @@ int sbgpu_bins_create(const sbgpu_annotation_t *an, const sbgpu_hits_t *hits, co
                   R.msg = "sbgpu_bins_create: a bin is not under an isoform it is compatible with";
                   return;
                }
-               const size_t n = up - low + 1;
+               size_t n = up - low + 1;
                if (n > 32) {
-                  R.err = SBGPU_ESHAPE;
-                  R.msg = "sbgpu_bins_create: a bin spans more than 32 isoform segments";
-                  return;
+                  // the bin-weight model's masks stop at 32 segments (as the reference's `1u << idx` do); the
+                  // pair is still a pair -- the long-read workflow weighs it 1/L without looking at segments --
+                  // so it is emitted without segments and sbgpu_binweight_* refuses it in the short-read model
+                  R.pair_nseg.push_back(0);
+                  R.pair_mask.push_back(0);
+                  R.pair_iso.push_back((int32_t)j);
+                  R.pair_bin.push_back(b);
+                  continue;
                }
                uint32_t mask = 0;
                size_t c = 1, i = 1; // :393-409

@@ -706,6 +706,7 @@ int sbgpu_binweight_host(sbgpu_ctx_t *c, int64_t n_pairs, const int64_t *seg_off
    int64_t max_l = 1;
    for (int64_t p = 0; p < n_pairs; ++p) {
       const int64_t ns = seg_off[p + 1] - seg_off[p];
+      if (ins->long_read) continue; // F = 1/L: the segments are not looked at (estimate.cpp:236-247)
       if (ns < 1 || ns > sb::kBinWeightMaxSeg)
          return fail(SBGPU_ESHAPE, "sbgpu_binweight_host: a pair needs 1..32 segments");
       int64_t l = 0;

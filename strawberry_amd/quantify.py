@@ -66,8 +66,11 @@ class LocusQuantifier:
         self.d_F = torch.zeros(max(b.n_elem, 1), dtype=torch.float64, device=self.dev)
         if b.n_pairs == 0:
             return self.d_F
-        max_l = int(np.add.reduceat(b.pair_seg_lens.astype(np.int64), b.pair_seg_off[:-1]).max())
-        pdf = self.insert.pdf_table(max_l + 1, self.read_len)
+        if self.long_read:      # F = 1/L_j: neither the segments nor the pdf are looked at
+            pdf = np.zeros(2, np.float64)
+        else:
+            span = np.diff(np.concatenate([[0], np.cumsum(b.pair_seg_lens.astype(np.int64))])[b.pair_seg_off])
+            pdf = self.insert.pdf_table(int(span.max()) + 1, self.read_len)
         d_off, d_seg = up(b.pair_seg_off), up(b.pair_seg_lens.view(np.int32))
         d_mask, d_len = up(b.pair_implicit_mask.view(np.int32)), up(b.pair_iso_len)
         d_idx, d_pdf = up(b.pair_out_index), up(pdf)

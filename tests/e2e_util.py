@@ -17,6 +17,7 @@ E2E_LONG = os.path.join(HERE, "golden", "e2e_toy_long")  # exons longer than any
 E2E_MASS = os.path.join(HERE, "golden", "e2e_toy_mass")  # PCR duplicates + multi-mapped pairs (masses 1, 1/2, 1/3)
 E2E_EMP = os.path.join(HERE, "golden", "e2e_toy_emp")     # e2e_toy's reads without -i: empirical insert-size distribution
 E2E_SINGLE = os.path.join(HERE, "golden", "e2e_toy_single")  # single-end library: unpaired reads, insert size forced to N(200, 80)
+E2E_LONGREAD = os.path.join(HERE, "golden", "e2e_toy_longread")  # unpaired reads of 1001-2600 bases: long-read workflow, F = 1/L
 E2E_FILTER = os.path.join(HERE, "golden", "e2e_toy_filter")  # e2e_toy_long's reads with -e 0.05: isoforms erased
 
 

@@ -43,10 +43,10 @@ def write_input(directory, path):
     names = list(ordered)
     with open(path, "w") as f:
         # the golden runs used -r (kMinIsoformFrac = 0), the filter toy -r -e 0.05
-        f.write("sample toy chrom chr1 strand + insert %s read_len 75 min_isoform_frac %s\n" % (
+        f.write("sample toy chrom chr1 strand + insert %s read_len 75 min_isoform_frac %s long_read %d\n" % (
             # single-end library: the reference overrides -i with N(200, 80) (Strawberry.cpp:329-333)
-            "0 0" if directory == U.E2E_EMP else ("200 80" if directory == U.E2E_SINGLE else "250 30"),
-            "0.05" if directory == U.E2E_FILTER else "0"))
+            "0 0" if directory == U.E2E_EMP else ("200 80" if directory in (U.E2E_SINGLE, U.E2E_LONGREAD) else "250 30"),
+            "0.05" if directory == U.E2E_FILTER else "0", directory == U.E2E_LONGREAD))
         f.write("loci %d\n" % len(names))
         for g in names:
             f.write("locus %s %d\n" % (g, len(ordered[g])))
@@ -73,7 +73,7 @@ def test_examples_compile_as_cxx14_and_refuse_to_run_without_a_gpu(driver, kat, 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which", ["E2E", "E2E_LONG", "E2E_MASS", "E2E_FILTER", "E2E_EMP", "E2E_SINGLE"])
+@pytest.mark.parametrize("which", ["E2E", "E2E_LONG", "E2E_MASS", "E2E_FILTER", "E2E_EMP", "E2E_SINGLE", "E2E_LONGREAD"])
 def test_cxx_driver_reproduces_reference_files(driver, tmp_path, which):
     d = getattr(U, which)
     inp, gtf, ctx = str(tmp_path / "in.txt"), str(tmp_path / "out.gtf"), str(tmp_path / "ctx.tsv")

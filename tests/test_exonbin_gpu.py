@@ -164,7 +164,7 @@ def test_large_batch_properties(ctx, oracle):
     np.testing.assert_array_equal(k2.reshape(64, hits.n_hits, -1), np.broadcast_to(key, (64,) + key.shape))
 
 
-@pytest.mark.parametrize("which", ["E2E", "E2E_LONG", "E2E_MASS", "E2E_FILTER", "E2E_EMP", "E2E_SINGLE"])
+@pytest.mark.parametrize("which", ["E2E", "E2E_LONG", "E2E_MASS", "E2E_FILTER", "E2E_EMP", "E2E_SINGLE", "E2E_LONGREAD"])
 def test_chain_from_fragments_reproduces_reference_run(ctx, oracle, which):
     """Our simulated fragments (reads.npz, the BAM the reference binary was run on) through the whole
     device chain: bins and counts == the -f table; every nonzero weight of the table == F (12 digits);
@@ -174,8 +174,11 @@ def test_chain_from_fragments_reproduces_reference_run(ctx, oracle, which):
     ordered, rows, gtf, theta_log = U.load(d)
     annot, hits, names, _ = XU.e2e_inputs(d, ordered)
     # single-end library: the reference forces the insert size to N(200, 80) (Strawberry.cpp:329-333)
-    q = LocusQuantifier(annot, hits, InsertSize(200.0, 80.0) if which == "E2E_SINGLE" else InsertSize(MEAN, SD), RL, ctx=ctx)
-    if which == "E2E_SINGLE":
+    # long reads (more than ten read lengths above 1000, Strawberry.cpp:292-303): every weight is 1/L_j
+    unpaired = which in ("E2E_SINGLE", "E2E_LONGREAD")
+    q = LocusQuantifier(annot, hits, InsertSize(200.0, 80.0) if unpaired else InsertSize(MEAN, SD), RL,
+                        long_read=(which == "E2E_LONGREAD"), ctx=ctx)
+    if unpaired:
         assert (hits.feat_code != 2).all()      # no mate gaps: every hit is a single read
     bins = q.assign_bins()
     o_compat, o_key = oracle.exonbin_batch(annot, hits)

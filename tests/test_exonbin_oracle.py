@@ -106,7 +106,7 @@ def test_segments_host_is_the_disjoint_cut():
     assert eb.Annotation([]).n_loci == 0
 
 
-@pytest.mark.parametrize("which", ["E2E", "E2E_LONG", "E2E_MASS", "E2E_EMP", "E2E_SINGLE"])
+@pytest.mark.parametrize("which", ["E2E", "E2E_LONG", "E2E_MASS", "E2E_EMP", "E2E_SINGLE", "E2E_LONGREAD"])
 def test_bins_reproduce_reference_context_table(which, oracle):
     """The reference binary's -f table lists every exon bin (its segments) with the number of
     fragments in it; hits -> (oracle words) -> sbgpu_bins_create must give the same bins and counts."""

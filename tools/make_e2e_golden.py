@@ -83,7 +83,7 @@ def cigar(blocks):
     return s
 
 
-def simulate(rng, genes, frags_per_gene, dup=0.0, multi=0.0, single=False):
+def simulate(rng, genes, frags_per_gene, dup=0.0, multi=0.0, single=False, long_reads=False):
     """dup: chance that a fragment is sequenced again (1-3 PCR duplicates: same alignments, other read
     names); multi: chance that a pair is multi-mapped (NH 2 or 3 on both mates).  With either, two
     different fragments never share (left end, right end): the reference sorts hits by that pair only
@@ -108,7 +108,14 @@ def simulate(rng, genes, frags_per_gene, dup=0.0, multi=0.0, single=False):
             sig = (tuple(left), tuple(right))
             if sig in seen:     # no duplicate fragments: bin counts then equal uniq-hit counts
                 continue
-            if single:          # single-end library: only the first mate is sequenced, unpaired (flag 0)
+            if long_reads:      # long-read library: one unpaired read of 1001..2600 bases of the transcript
+                if L < 1100:
+                    continue
+                rlen = int(rng.integers(1001, min(L, 2600) + 1))
+                st = int(rng.integers(0, L - rlen + 1))
+                left = tx_to_genome(ex, st, st + rlen)
+            if single or long_reads:  # single-end library: only the first mate is sequenced, unpaired (flag 0)
+                rlen = sum(b - a + 1 for a, b in left)
                 right = []
                 sig = (tuple(left), ())
                 if sig in seen or (left[0][0], left[-1][1]) in spans:
@@ -117,7 +124,7 @@ def simulate(rng, genes, frags_per_gene, dup=0.0, multi=0.0, single=False):
                 seen.add(sig)
                 rid += 1
                 recs.append((left[0][0], "r%06d\t0\tchr1\t%d\t255\t%s\t*\t0\t0\t%s\t%s\tNH:i:1\tXS:A:+" % (
-                    rid, left[0][0], cigar(left), "A" * RL, "I" * RL)))
+                    rid, left[0][0], cigar(left), "A" * rlen, "I" * rlen)))
                 frags.append((gi, left, right, [1]))
                 continue
             if dup or multi:
@@ -184,9 +191,13 @@ def main():
     # e2e_toy_single: a single-end library (unpaired reads).  The reference then forces the insert size to
     #          N(200, 80) whatever -i says (Strawberry.cpp:329-333) and every hit is a single read.
     make("e2e_toy_single", 4545, 60, 400, single=True)
+    # e2e_toy_longread: unpaired reads of 1001-2600 bases.  More than ten read lengths above 1000 switch the
+    #          reference to its long-read workflow (Strawberry.cpp:292-303): every bin weight is 1/L_j
+    #          (set_bin_weight_without_frag_dist, estimate.cpp:236-247).
+    make("e2e_toy_longread", 4646, 300, 700, long_reads=True, n_frags=400)
 
 
-def make(name, seed, ex_lo, ex_hi, dup=0.0, multi=0.0, extra=(), insert=True, single=False):
+def make(name, seed, ex_lo, ex_hi, dup=0.0, multi=0.0, extra=(), insert=True, single=False, long_reads=False, n_frags=900):
     rng = np.random.Generator(np.random.PCG64(seed))
     genes, chrom_len = make_annotation(rng, 6, ex_lo, ex_hi)
     out_dir = os.path.join(ROOT, "tests", "golden", name)
@@ -194,7 +205,7 @@ def make(name, seed, ex_lo, ex_hi, dup=0.0, multi=0.0, extra=(), insert=True, si
     with tempfile.TemporaryDirectory() as tmp:
         gtf = os.path.join(tmp, "toy.gtf")
         write_gtf(genes, gtf)
-        recs, frags = simulate(rng, genes, 900, dup, multi, single)
+        recs, frags = simulate(rng, genes, n_frags, dup, multi, single, long_reads)
         save_frags(frags, os.path.join(out_dir, "reads.npz"))
         sam = os.path.join(tmp, "toy.sam")
         with open(sam, "w") as f:
