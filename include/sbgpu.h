@@ -43,6 +43,7 @@ extern "C" {
 #define SBGPU_ENODEV (-3)   /* no gfx950 device / device index out of range       */
 #define SBGPU_ENOMEM (-4)   /* host or device allocation failed                   */
 #define SBGPU_ESHAPE (-5)   /* a locus exceeds the supported shape (niso > 512)   */
+#define SBGPU_EUNSUPPORTED (-6) /* the device form does not cover this input: use the host form (see the call) */
 
 /* ---- per-locus status: the reference's two bools, src/estimate.cpp:305-308 - */
 #define SBGPU_EM_OK 0          /* init()==true,  run()==true, converged (estimate.cpp:480 break) */
@@ -310,6 +311,23 @@ typedef struct sbgpu_bins sbgpu_bins_t;
 int sbgpu_bins_create(const sbgpu_annotation_t *annot, const sbgpu_hits_t *hits, const float *hit_mass,
                       int32_t compat_words, int32_t key_words, const uint32_t *compat,
                       const uint32_t *key, sbgpu_bins_t **out);
+/* The same bins with the per-hit work on the GPU (csrc/bins_device.h): one workgroup per locus
+ * groups its hits through a hash table in LDS, ranks the bins by first appearance, accumulates
+ * compat unions and masses; only the per-bin arrays come back to the host, where the (bin, isoform)
+ * pairs are made as in sbgpu_bins_create.  `annot` holds HOST pointers (the pairs need the
+ * annotation on the host); d_hits' pointers, d_hit_mass, d_compat and d_key are DEVICE pointers
+ * (the kernel's inputs and results never leave HBM); locus_hit_off[n_loci+1] (host) says where each
+ * locus' hits start -- hits must be grouped by locus.  d_hit_bin (device, [n_hits], may be NULL)
+ * receives the global bin of every hit; the handle's own hit_bin stays empty.
+ * The device form is exact only where the order of the reference's float accumulation cannot
+ * matter, and it checks that: hits of a locus sorted by (left end, right end) (HitCluster's order),
+ * whole-number masses below 2^24 per bin (the reference's default: no multi-mapped reads), at most
+ * 2800 bins per locus.  Otherwise it returns SBGPU_EUNSUPPORTED and the caller uses
+ * sbgpu_bins_create.  Synchronises on `stream`.                                                  */
+int sbgpu_bins_create_device(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *annot, const sbgpu_hits_t *d_hits,
+                             const float *d_hit_mass, const int64_t *locus_hit_off, int32_t compat_words,
+                             int32_t key_words, const uint32_t *d_compat, const uint32_t *d_key,
+                             int64_t *d_hit_bin, void *stream, sbgpu_bins_t **out);
 void sbgpu_bins_destroy(sbgpu_bins_t *bins);
 /* info: 0 n_loci, 1 n_iso, 2 n_bins, 3 n_elem (= f_off[n_loci]), 4 n_pairs, 5 total pair
  * segments, 6 hits that landed in a bin, 7 key_words.                                      */

@@ -10,6 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SBGPU_LIB") or os.path.join(HERE, "lib", "libsbgpu.so")  # SBGPU_LIB: A/B builds
 
 SBGPU_OK = 0
+SBGPU_EUNSUPPORTED = -6
 EM_OK, EM_INIT_EMPTY, EM_DENOM_ZERO, EM_MAXITER = 0, 1, 2, 3
 STATUS_NAMES = {0: "OK", 1: "INIT_EMPTY", 2: "DENOM_ZERO", 3: "MAXITER"}
 
@@ -20,7 +21,7 @@ SYMBOLS = [
     "sbgpu_plan_classes", "sbgpu_plan_locus_kinds", "sbgpu_em_run_device", "sbgpu_em_last_kernel_ms",
     "sbgpu_insert_pdf_table", "sbgpu_binweight_device", "sbgpu_binweight_host",
     "sbgpu_exonbin_device", "sbgpu_exonbin_host", "sbgpu_segments_host", "sbgpu_hit_features", "sbgpu_frag_lens_host",
-    "sbgpu_bins_create", "sbgpu_bins_destroy", "sbgpu_bins_info", "sbgpu_bins_export",
+    "sbgpu_bins_create", "sbgpu_bins_create_device", "sbgpu_bins_destroy", "sbgpu_bins_info", "sbgpu_bins_export",
     "sbgpu_format_value", "sbgpu_format_gtf_transcript", "sbgpu_format_context_row", "sbgpu_em_batch", "sbgpu_abundance_device", "sbgpu_tpm_device",
 ]
 
@@ -147,6 +148,8 @@ def load():
     L.sbgpu_hit_features.argtypes = [C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.sbgpu_bins_create.argtypes = [C.POINTER(sbgpu_annotation_t), C.POINTER(sbgpu_hits_t), vp, C.c_int32, C.c_int32,
                                     vp, vp, C.POINTER(vp)]
+    L.sbgpu_bins_create_device.argtypes = [vp, C.POINTER(sbgpu_annotation_t), C.POINTER(sbgpu_hits_t), vp, vp, C.c_int32,
+                                           C.c_int32, vp, vp, vp, vp, C.POINTER(vp)]
     L.sbgpu_bins_destroy.argtypes = [vp]
     L.sbgpu_bins_destroy.restype = None
     L.sbgpu_bins_info.argtypes = [vp, i64p]

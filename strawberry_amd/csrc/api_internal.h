@@ -12,4 +12,8 @@ namespace sb {
 int api_fail(int code, const std::string &msg); // records sbgpu_last_error(), returns code
 hipStream_t ctx_stream(const sbgpu_ctx_t *ctx); // the context's own stream
 int ctx_cu_count(const sbgpu_ctx_t *ctx);
+// locus_bins.cpp: finish bins that were grouped on the device (host copies of the per-bin arrays)
+int bins_from_groups(const sbgpu_annotation_t *annot, int32_t compat_words, int32_t key_words, const int64_t *row_off,
+                     const int32_t *count, const uint32_t *key, const uint32_t *compat, int64_t n_hits_used,
+                     sbgpu_bins_t **out);
 } // namespace sb

@@ -1,0 +1,243 @@
+// strawberry_amd/csrc/bins_device.h -- grouping the hits of a locus into exon bins on the GPU
+// (SURVEY 8(a) A5): LocusContext::set_maps (/root/reference/include/estimate.hpp:29-52) and
+// ExonBin::read_count (include/isoform.h:285-296) for the common case.
+//
+// One workgroup per locus.  A hash table in LDS maps a hit's key words (the set of exon segments
+// it touches, exonbin_device.h) to a bin; bins are then ranked by their first hit (the reference
+// numbers them in order of first appearance, UniqPushAndReturnIdx), every hit gets its bin, and
+// the bin's compat union and mass are accumulated with atomics.
+//
+// Exactness.  The reference keeps a bin's fragments in a std::set<Contig> ordered by the
+// (offset, length) feature sequence and adds their float masses in that order.  Two things make
+// the order irrelevant here, and the kernel VERIFIES both and reports when they do not hold
+// (the caller then groups on the host, locus_bins.cpp):
+//   - hits of a locus come sorted by (left end, right end) -- HitCluster's own order -- so equal
+//     feature sequences are neighbours: a hit is dropped as a duplicate iff an earlier hit of its
+//     (left, right) run has the same sequence and the same bin;
+//   - all masses are whole numbers below 2^24 per bin (no multi-mapped reads: the reference's
+//     default), so the float accumulation is exact in any order.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sb {
+
+constexpr int kBinsSlots = 4096;            // LDS table: 16 B per slot + 4 B per listed bin
+constexpr int kBinsMaxPerLocus = 2800;      // ~0.7 load
+constexpr int kBinsThreads = 256;
+enum : int32_t { kBinsUnsorted = 1, kBinsFractional = 2, kBinsTableFull = 4, kBinsMassOverflow = 8 };
+
+struct BinsArgs {
+   int64_t n_loci;
+   const int64_t *locus_hit_off; // [n_loci + 1]: hits are grouped by locus
+   const int64_t *feat_off;
+   const uint32_t *feat_left, *feat_right;
+   const float *mass;
+   int32_t compat_words, key_words;
+   const uint32_t *compat, *key;
+   // hit-indexed scratch: bin b of locus l lives at index locus_hit_off[l] + b
+   int32_t *hit_bin_local;  // [n_hits] rank of the hit's bin inside its locus, -1: dropped
+   int32_t *bin_rep;        // [n_hits] a member hit of the bin (its key words are the bin's)
+   int32_t *bin_count;      // [n_hits] zeroed by the caller
+   uint32_t *bin_compat;    // [n_hits * compat_words] zeroed by the caller
+   int32_t *n_bins;         // [n_loci]
+   int32_t *n_used;         // [n_loci] hits that landed in a bin
+   int32_t *flags;          // [1] OR of kBins*
+};
+
+__device__ __forceinline__ uint32_t bins_hash(const uint32_t *k, int kw)
+{
+   uint64_t h = 1469598103934665603ull;
+   for (int w = 0; w < kw; ++w) h = (h ^ k[w]) * 1099511628211ull;
+   h ^= h >> 29;
+   return (uint32_t)h | 1u; // never 0: a zero tag means "free"
+}
+
+// slot of the bin with these key words; INSERT: claim a free slot if there is none.
+// A slot's tag = hash << 32 | (member hit - first hit of the locus + 1), written by one atomicCAS, so a
+// reader never sees a claimed slot without its member.
+template <bool INSERT>
+__device__ __forceinline__ int bins_find(unsigned long long *tag, const BinsArgs &a, int64_t q0, int64_t h, const uint32_t *kh)
+{
+   const int kw = a.key_words;
+   const uint32_t hv = bins_hash(kh, kw);
+   const unsigned long long mine = ((unsigned long long)hv << 32) | (unsigned long long)(h - q0 + 1);
+   int slot = (int)(hv >> 1) & (kBinsSlots - 1);
+   for (int probe = 0; probe < kBinsSlots; ++probe) {
+      unsigned long long t = tag[slot];
+      if (t == 0ull && INSERT) {
+         t = atomicCAS(&tag[slot], 0ull, mine);
+         if (t == 0ull) return slot; // claimed
+      }
+      if (t == 0ull) return -1;
+      if ((uint32_t)(t >> 32) == hv) {
+         const uint32_t *kr = a.key + (q0 + (int64_t)(uint32_t)t - 1) * kw;
+         bool same = true;
+         for (int w = 0; w < kw; ++w) same &= kr[w] == kh[w];
+         if (same) return slot;
+      }
+      slot = (slot + 1) & (kBinsSlots - 1);
+   }
+   return -1;
+}
+
+__device__ __forceinline__ bool bins_same_fragment(const BinsArgs &a, int64_t x, int64_t y)
+{
+   const int64_t fx = a.feat_off[x], fy = a.feat_off[y];
+   const int64_t n = a.feat_off[x + 1] - fx;
+   if (a.feat_off[y + 1] - fy != n) return false;
+   for (int64_t i = 0; i < n; ++i)
+      if (a.feat_left[fx + i] != a.feat_left[fy + i] || a.feat_right[fx + i] != a.feat_right[fy + i]) return false;
+   return true;
+}
+
+__global__ __launch_bounds__(kBinsThreads) void bins_locus_kernel(BinsArgs a)
+{
+   __shared__ unsigned long long tag[kBinsSlots];
+   __shared__ int first[kBinsSlots]; // first hit of the bin (min), later its rank
+   __shared__ int used[kBinsMaxPerLocus], used_rank[kBinsMaxPerLocus];
+   __shared__ int n_used_slots, n_hits_in, bad;
+   const int tid = threadIdx.x;
+   for (int64_t l = blockIdx.x; l < a.n_loci; l += gridDim.x) {
+      const int64_t q0 = a.locus_hit_off[l], q1 = a.locus_hit_off[l + 1];
+      for (int s = tid; s < kBinsSlots; s += kBinsThreads) {
+         tag[s] = 0ull;
+         first[s] = 0x7fffffff;
+      }
+      if (tid == 0) n_used_slots = 0, n_hits_in = 0, bad = 0;
+      __syncthreads();
+      const int cw = a.compat_words, kw = a.key_words;
+      // ---- pass 1: every hit that has a compatible isoform enters the table
+      int my_bad = 0;
+      for (int64_t h = q0 + tid; h < q1; h += kBinsThreads) {
+         const int64_t f0 = a.feat_off[h], f1 = a.feat_off[h + 1];
+         if (h > q0 && f1 > f0) { // sorted by (left, right)?  (empty hits carry no position)
+            const int64_t g0 = a.feat_off[h - 1], g1 = f0;
+            if (g1 > g0) {
+               const uint32_t pl = a.feat_left[g0], pr = a.feat_right[g1 - 1], cl = a.feat_left[f0], cr = a.feat_right[f1 - 1];
+               if (pl > cl || (pl == cl && pr > cr)) my_bad |= kBinsUnsorted;
+            }
+         }
+         uint32_t any_c = 0, any_k = 0;
+         for (int w = 0; w < cw; ++w) any_c |= a.compat[h * cw + w];
+         for (int w = 0; w < kw; ++w) any_k |= a.key[h * kw + w];
+         if (!any_c || !any_k) continue;
+         const float m = a.mass[h];
+         if (!(m >= 0.0f && m < 16777216.0f && (float)(int)m == m)) my_bad |= kBinsFractional;
+         const int slot = bins_find<true>(tag, a, q0, h, a.key + h * kw);
+         if (slot < 0) {
+            my_bad |= kBinsTableFull;
+            continue;
+         }
+         atomicMin(&first[slot], (int)(h - q0));
+      }
+      if (my_bad) atomicOr(&bad, my_bad);
+      __syncthreads();
+      // ---- the bins, ranked by their first hit
+      for (int s = tid; s < kBinsSlots; s += kBinsThreads)
+         if (tag[s] != 0ull) {
+            const int k = atomicAdd(&n_used_slots, 1);
+            if (k < kBinsMaxPerLocus) used[k] = s;
+         }
+      __syncthreads();
+      int nb = n_used_slots;
+      if (nb > kBinsMaxPerLocus) {
+         if (tid == 0) atomicOr(&bad, (int)kBinsTableFull);
+         nb = 0; // the locus is not written; the flag sends the whole batch to the host
+      }
+      for (int k = tid; k < nb; k += kBinsThreads) {
+         const int fk = first[used[k]];
+         int r = 0;
+         for (int v = 0; v < nb; ++v) r += first[used[v]] < fk; // first hits are distinct: ranks are a permutation
+         used_rank[k] = r;
+      }
+      __syncthreads();
+      for (int k = tid; k < nb; k += kBinsThreads) {
+         const int s = used[k];
+         a.bin_rep[q0 + used_rank[k]] = (int32_t)(uint32_t)tag[s] - 1; // a member hit, relative to q0
+         first[s] = used_rank[k];                                      // from now on: the bin's rank
+      }
+      __syncthreads();
+      // ---- pass 2: every hit learns its bin; the first of equal fragments adds its mass
+      int my_used = 0;
+      for (int64_t h = q0 + tid; h < q1 && nb > 0; h += kBinsThreads) {
+         a.hit_bin_local[h] = -1;
+         uint32_t any_c = 0, any_k = 0;
+         for (int w = 0; w < cw; ++w) any_c |= a.compat[h * cw + w];
+         for (int w = 0; w < kw; ++w) any_k |= a.key[h * kw + w];
+         if (!any_c || !any_k) continue;
+         const int slot = bins_find<false>(tag, a, q0, h, a.key + h * kw);
+         if (slot < 0) continue; // table was full
+         const int b = first[slot];
+         a.hit_bin_local[h] = b;
+         ++my_used;
+         for (int w = 0; w < cw; ++w)
+            if (a.compat[h * cw + w]) atomicOr(&a.bin_compat[(q0 + b) * cw + w], a.compat[h * cw + w]);
+         // std::set<Contig>: an equal fragment already in this bin?  Only its (left, right) run can hold one.
+         const int64_t f0 = a.feat_off[h], f1 = a.feat_off[h + 1];
+         const uint32_t cl = a.feat_left[f0], cr = a.feat_right[f1 - 1];
+         bool dup = false;
+         for (int64_t p = h - 1; p >= q0 && !dup; --p) {
+            const int64_t g0 = a.feat_off[p], g1 = a.feat_off[p + 1];
+            if (g1 <= g0) continue;
+            if (a.feat_left[g0] != cl || a.feat_right[g1 - 1] != cr) break;
+            if (!bins_same_fragment(a, p, h)) continue;
+            uint32_t pc = 0, pk = 0;
+            for (int w = 0; w < cw; ++w) pc |= a.compat[p * cw + w];
+            for (int w = 0; w < kw; ++w) pk |= a.key[p * kw + w];
+            if (!pc || !pk) continue;
+            const int ps = bins_find<false>(tag, a, q0, p, a.key + p * kw);
+            dup = ps >= 0 && first[ps] == b;
+         }
+         if (!dup) atomicAdd(&a.bin_count[q0 + b], (int)a.mass[h]);
+      }
+      if (nb == 0)
+         for (int64_t h = q0 + tid; h < q1; h += kBinsThreads) a.hit_bin_local[h] = -1;
+      if (my_used) atomicAdd(&n_hits_in, my_used);
+      __syncthreads();
+      if (tid == 0) {
+         a.n_bins[l] = nb;
+         a.n_used[l] = n_hits_in;
+         if (bad) atomicOr(a.flags, bad);
+      }
+      __syncthreads();
+   }
+}
+
+// bins of all loci into their final, dense arrays (row_off = scan of n_bins, done on the host)
+struct BinsPackArgs {
+   int64_t n_loci;
+   const int64_t *locus_hit_off, *row_off;
+   int32_t compat_words, key_words;
+   const uint32_t *key;
+   const int32_t *hit_bin_local, *bin_rep, *bin_count_in;
+   const uint32_t *bin_compat_in;
+   int32_t *count;       // [n_bins]
+   uint32_t *bin_key;    // [n_bins * key_words]
+   uint32_t *bin_compat; // [n_bins * compat_words]
+   int64_t *hit_bin;     // [n_hits] global bin or -1 (may be null)
+   int32_t *flags;
+};
+
+__global__ __launch_bounds__(256) void bins_pack_kernel(BinsPackArgs a)
+{
+   for (int64_t l = blockIdx.x; l < a.n_loci; l += gridDim.x) {
+      const int64_t q0 = a.locus_hit_off[l], q1 = a.locus_hit_off[l + 1], b0 = a.row_off[l];
+      const int nb = (int)(a.row_off[l + 1] - b0);
+      for (int b = threadIdx.x; b < nb; b += blockDim.x) {
+         const int32_t c = a.bin_count_in[q0 + b];
+         if (c >= 16777216) atomicOr(a.flags, (int)kBinsMassOverflow);
+         a.count[b0 + b] = c;
+         const int64_t rep = q0 + a.bin_rep[q0 + b];
+         for (int w = 0; w < a.key_words; ++w) a.bin_key[(b0 + b) * a.key_words + w] = a.key[rep * a.key_words + w];
+         for (int w = 0; w < a.compat_words; ++w)
+            a.bin_compat[(b0 + b) * a.compat_words + w] = a.bin_compat_in[(q0 + b) * a.compat_words + w];
+      }
+      if (a.hit_bin)
+         for (int64_t h = q0 + threadIdx.x; h < q1; h += blockDim.x)
+            a.hit_bin[h] = a.hit_bin_local[h] < 0 ? -1 : b0 + a.hit_bin_local[h];
+   }
+}
+
+} // namespace sb

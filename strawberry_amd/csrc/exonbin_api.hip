@@ -4,9 +4,11 @@
 
 #include <cstdlib>
 #include <string>
+#include <vector>
 
 #include "../../include/sbgpu.h"
 #include "api_internal.h"
+#include "bins_device.h"
 #include "exonbin_device.h"
 
 using sb::api_fail;
@@ -156,6 +158,139 @@ int sbgpu_exonbin_host(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgpu
    if ((e = hipStreamSynchronize(s)) != hipSuccess) return bail(e, "hipStreamSynchronize");
    (void)hipFree(d);
    return SBGPU_OK;
+}
+
+int sbgpu_bins_create_device(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgpu_hits_t *dh, const float *d_mass,
+                             const int64_t *locus_hit_off, int32_t compat_words, int32_t key_words, const uint32_t *d_compat,
+                             const uint32_t *d_key, int64_t *d_hit_bin, void *stream, sbgpu_bins_t **out)
+{
+   if (!c || !an || !dh || !locus_hit_off || !out) return api_fail(SBGPU_EINVAL, "sbgpu_bins_create_device: null argument");
+   *out = nullptr;
+   const int64_t nl = an->n_loci, nh = dh->n_hits;
+   if (nl < 1 || nh < 0 || compat_words < 1 || key_words < 1) return api_fail(SBGPU_EINVAL, "sbgpu_bins_create_device: bad counts");
+   if (nh > 0x7fffffff) return api_fail(SBGPU_ESHAPE, "sbgpu_bins_create_device: more than 2^31 hits in one call");
+   if (nh && (!dh->feat_off || !dh->feat_left || !dh->feat_right || !d_mass || !d_compat || !d_key))
+      return api_fail(SBGPU_EINVAL, "sbgpu_bins_create_device: null device pointer");
+   if (locus_hit_off[0] != 0 || locus_hit_off[nl] != nh) return api_fail(SBGPU_EINVAL, "sbgpu_bins_create_device: locus_hit_off does not span the hits");
+   for (int64_t l = 0; l < nl; ++l) {
+      if (locus_hit_off[l + 1] < locus_hit_off[l]) return api_fail(SBGPU_EINVAL, "sbgpu_bins_create_device: decreasing locus_hit_off");
+      if (an->iso_off[l + 1] - an->iso_off[l] > 32 * (int64_t)compat_words || an->seg_off[l + 1] - an->seg_off[l] > 32 * (int64_t)key_words)
+         return api_fail(SBGPU_ESHAPE, "sbgpu_bins_create_device: word counts do not cover a locus");
+   }
+   hipStream_t s = (hipStream_t)stream;
+   // one arena for the scratch: [hit_bin_local | bin_rep | bin_count | bin_compat | n_bins | n_used | flags | offsets x2]
+   const size_t nh1 = (size_t)(nh > 0 ? nh : 1);
+   auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+   size_t off = 0;
+   const size_t o_local = off; off += up(nh1 * 4);
+   const size_t o_rep = off; off += up(nh1 * 4);
+   const size_t o_zero = off; // bin_count + bin_compat are zeroed together
+   const size_t o_cnt = off; off += up(nh1 * 4);
+   const size_t o_cmp = off; off += up(nh1 * 4 * (size_t)compat_words);
+   const size_t zero_bytes = off - o_zero;
+   const size_t o_nb = off; off += up((size_t)nl * 4);
+   const size_t o_nu = off; off += up((size_t)nl * 4);
+   const size_t o_flag = off; off += 256;
+   const size_t o_hoff = off; off += up((size_t)(nl + 1) * 8);
+   const size_t o_roff = off; off += up((size_t)(nl + 1) * 8);
+   char *d = nullptr, *d2 = nullptr;
+   hipError_t e = hipMalloc(&d, off);
+   if (e != hipSuccess) return api_fail(e == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+   auto bail = [&](int code, const std::string &msg) {
+      (void)hipFree(d);
+      (void)hipFree(d2);
+      return api_fail(code, msg);
+   };
+#define SB_TRY(expr)                                                                        \
+   do {                                                                                     \
+      hipError_t e_ = (expr);                                                               \
+      if (e_ != hipSuccess) return bail(SBGPU_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+   } while (0)
+   SB_TRY(hipMemsetAsync(d + o_zero, 0, zero_bytes, s));
+   SB_TRY(hipMemsetAsync(d + o_flag, 0, 256, s));
+   SB_TRY(hipMemcpyAsync(d + o_hoff, locus_hit_off, (size_t)(nl + 1) * 8, hipMemcpyHostToDevice, s));
+   sb::BinsArgs a;
+   a.n_loci = nl;
+   a.locus_hit_off = (const int64_t *)(d + o_hoff);
+   a.feat_off = dh->feat_off;
+   a.feat_left = dh->feat_left;
+   a.feat_right = dh->feat_right;
+   a.mass = d_mass;
+   a.compat_words = compat_words;
+   a.key_words = key_words;
+   a.compat = d_compat;
+   a.key = d_key;
+   a.hit_bin_local = (int32_t *)(d + o_local);
+   a.bin_rep = (int32_t *)(d + o_rep);
+   a.bin_count = (int32_t *)(d + o_cnt);
+   a.bin_compat = (uint32_t *)(d + o_cmp);
+   a.n_bins = (int32_t *)(d + o_nb);
+   a.n_used = (int32_t *)(d + o_nu);
+   a.flags = (int32_t *)(d + o_flag);
+   const int64_t cap = (int64_t)sb::ctx_cu_count(c) * 8;
+   hipLaunchKernelGGL(sb::bins_locus_kernel, dim3((unsigned)(nl < cap ? nl : cap)), dim3(sb::kBinsThreads), 0, s, a);
+   SB_TRY(hipGetLastError());
+   std::vector<int32_t> nb((size_t)nl), nu((size_t)nl);
+   int32_t flags = 0;
+   SB_TRY(hipMemcpyAsync(nb.data(), d + o_nb, (size_t)nl * 4, hipMemcpyDeviceToHost, s));
+   SB_TRY(hipMemcpyAsync(nu.data(), d + o_nu, (size_t)nl * 4, hipMemcpyDeviceToHost, s));
+   SB_TRY(hipMemcpyAsync(&flags, d + o_flag, 4, hipMemcpyDeviceToHost, s));
+   SB_TRY(hipStreamSynchronize(s));
+   if (flags) {
+      std::string why = "sbgpu_bins_create_device: not covered by the device form:";
+      if (flags & sb::kBinsUnsorted) why += " hits of a locus are not sorted by (left, right);";
+      if (flags & sb::kBinsFractional) why += " fractional hit masses;";
+      if (flags & sb::kBinsTableFull) why += " a locus has more bins than the LDS table holds;";
+      return bail(SBGPU_EUNSUPPORTED, why + " use sbgpu_bins_create");
+   }
+   std::vector<int64_t> row_off((size_t)nl + 1, 0);
+   int64_t used = 0;
+   for (int64_t l = 0; l < nl; ++l) {
+      row_off[(size_t)l + 1] = row_off[(size_t)l] + nb[(size_t)l];
+      used += nu[(size_t)l];
+   }
+   const int64_t n_bins = row_off[(size_t)nl];
+   const size_t nb1 = (size_t)(n_bins > 0 ? n_bins : 1);
+   size_t off2 = 0;
+   const size_t p_cnt = off2; off2 += up(nb1 * 4);
+   const size_t p_key = off2; off2 += up(nb1 * 4 * (size_t)key_words);
+   const size_t p_cmp = off2; off2 += up(nb1 * 4 * (size_t)compat_words);
+   e = hipMalloc(&d2, off2);
+   if (e != hipSuccess) return bail(e == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+   SB_TRY(hipMemcpyAsync(d + o_roff, row_off.data(), (size_t)(nl + 1) * 8, hipMemcpyHostToDevice, s));
+   sb::BinsPackArgs pk;
+   pk.n_loci = nl;
+   pk.locus_hit_off = a.locus_hit_off;
+   pk.row_off = (const int64_t *)(d + o_roff);
+   pk.compat_words = compat_words;
+   pk.key_words = key_words;
+   pk.key = d_key;
+   pk.hit_bin_local = a.hit_bin_local;
+   pk.bin_rep = a.bin_rep;
+   pk.bin_count_in = a.bin_count;
+   pk.bin_compat_in = a.bin_compat;
+   pk.count = (int32_t *)(d2 + p_cnt);
+   pk.bin_key = (uint32_t *)(d2 + p_key);
+   pk.bin_compat = (uint32_t *)(d2 + p_cmp);
+   pk.hit_bin = d_hit_bin;
+   pk.flags = a.flags;
+   hipLaunchKernelGGL(sb::bins_pack_kernel, dim3((unsigned)(nl < cap ? nl : cap)), dim3(256), 0, s, pk);
+   SB_TRY(hipGetLastError());
+   std::vector<int32_t> count(nb1);
+   std::vector<uint32_t> key(nb1 * (size_t)key_words), compat(nb1 * (size_t)compat_words);
+   if (n_bins) {
+      SB_TRY(hipMemcpyAsync(count.data(), d2 + p_cnt, (size_t)n_bins * 4, hipMemcpyDeviceToHost, s));
+      SB_TRY(hipMemcpyAsync(key.data(), d2 + p_key, (size_t)n_bins * 4 * key_words, hipMemcpyDeviceToHost, s));
+      SB_TRY(hipMemcpyAsync(compat.data(), d2 + p_cmp, (size_t)n_bins * 4 * compat_words, hipMemcpyDeviceToHost, s));
+   }
+   SB_TRY(hipMemcpyAsync(&flags, d + o_flag, 4, hipMemcpyDeviceToHost, s));
+   SB_TRY(hipStreamSynchronize(s));
+#undef SB_TRY
+   (void)hipFree(d);
+   (void)hipFree(d2);
+   if (flags & sb::kBinsMassOverflow)
+      return api_fail(SBGPU_EUNSUPPORTED, "sbgpu_bins_create_device: a bin's mass reaches 2^24; use sbgpu_bins_create");
+   return sb::bins_from_groups(an, compat_words, key_words, row_off.data(), count.data(), key.data(), compat.data(), used, out);
 }
 
 } // extern "C"

@@ -196,10 +196,24 @@ int64_t sbgpu_frag_lens_host(const sbgpu_annotation_t *an, const sbgpu_hits_t *h
    return n;
 }
 
-int sbgpu_bins_create(const sbgpu_annotation_t *an, const sbgpu_hits_t *hits, const float *hit_mass,
-                      int32_t compat_words, int32_t key_words, const uint32_t *compat, const uint32_t *key,
-                      sbgpu_bins_t **out)
+} // extern "C"
+
+namespace {
+// Bins that were already grouped (on the device, bins_device.h): per locus their number, and per bin
+// the count, key words and compat union, in first-appearance order.  Only the pairs are left to do.
+struct PreGrouped {
+   const int64_t *row_off;
+   const int32_t *count;
+   const uint32_t *key, *compat;
+   int64_t n_hits_used;
+};
+
+int bins_create_impl(const sbgpu_annotation_t *an, const sbgpu_hits_t *hits, const float *hit_mass,
+                     int32_t compat_words, int32_t key_words, const uint32_t *compat, const uint32_t *key,
+                     const PreGrouped *pre, sbgpu_bins_t **out)
 {
+   static const sbgpu_hits_t no_hits = {0, nullptr, nullptr, nullptr, nullptr, nullptr};
+   if (pre) hits = &no_hits;
    if (!an || !hits || !out) return api_fail(SBGPU_EINVAL, "sbgpu_bins_create: null argument");
    *out = nullptr;
    const int64_t nl = an->n_loci, nh = hits->n_hits;
@@ -285,6 +299,13 @@ int sbgpu_bins_create(const sbgpu_annotation_t *an, const sbgpu_hits_t *hits, co
          const int64_t s0 = an->seg_off[l], nseg = an->seg_off[l + 1] - s0;
          const int64_t q0 = loc_start[(size_t)l], nq = loc_start[(size_t)l + 1] - q0;
          const int cw = compat_words, kw = key_words;
+         if (pre) { // grouped on the device: take the bins as they are
+            const int64_t b0 = pre->row_off[l], pnb = pre->row_off[l + 1] - b0;
+            R.nb = pnb;
+            R.count.assign(pre->count + b0, pre->count + b0 + pnb);
+            R.key.assign(pre->key + b0 * kw, pre->key + (b0 + pnb) * kw);
+            R.compat.assign(pre->compat + b0 * cw, pre->compat + (b0 + pnb) * cw);
+         } else {
          // bins keyed by the key words, numbered in order of first appearance (UniqPushAndReturnIdx):
          // open-addressing table of bin ids, a bin's key = the words of its first hit
          size_t cap = 16;
@@ -348,6 +369,8 @@ int sbgpu_bins_create(const sbgpu_annotation_t *an, const sbgpu_hits_t *hits, co
                if (m == m0 || frag_cmp(m[-1], m[0]) != 0) sum += hit_mass[*m];
             R.count[(size_t)b] = (int32_t)sum;
          }
+         } // host grouping
+         const int64_t nb = R.nb;
          // (bin, isoform) pairs of set_theory_bin_weight with ExonBin::bin_under_iso.
          // Isoform::_exon_segs (isoform.h:59-71): the locus' segments inside one of its exons
          std::vector<std::vector<int32_t>> iso_segs((size_t)niso);
@@ -500,8 +523,29 @@ int sbgpu_bins_create(const sbgpu_annotation_t *an, const sbgpu_hits_t *hits, co
    } catch (const std::bad_alloc &) {
       return bail(SBGPU_ENOMEM, "sbgpu_bins_create: out of memory");
    }
+   if (pre) B->n_hits_used = pre->n_hits_used;
    *out = B;
    return SBGPU_OK;
+}
+
+} // namespace
+
+namespace sb {
+int bins_from_groups(const sbgpu_annotation_t *an, int32_t compat_words, int32_t key_words, const int64_t *row_off,
+                     const int32_t *count, const uint32_t *key, const uint32_t *compat, int64_t n_hits_used, sbgpu_bins_t **out)
+{
+   const PreGrouped pre = {row_off, count, key, compat, n_hits_used};
+   return bins_create_impl(an, nullptr, nullptr, compat_words, key_words, nullptr, nullptr, &pre, out);
+}
+} // namespace sb
+
+extern "C" {
+
+int sbgpu_bins_create(const sbgpu_annotation_t *an, const sbgpu_hits_t *hits, const float *hit_mass,
+                      int32_t compat_words, int32_t key_words, const uint32_t *compat, const uint32_t *key,
+                      sbgpu_bins_t **out)
+{
+   return bins_create_impl(an, hits, hit_mass, compat_words, key_words, compat, key, nullptr, out);
 }
 
 void sbgpu_bins_destroy(sbgpu_bins_t *b) { delete b; }

@@ -163,6 +163,7 @@ class LocusBins:
     """The exon bins of a batch of loci: an EM batch minus F, and the bin-weight kernel's pairs."""
 
     def __init__(self, annot, hits, compat, key):
+        """Host grouping (sbgpu_bins_create) from host copies of the kernel's words."""
         L = _lib.load()
         compat = np.ascontiguousarray(compat, np.uint32)
         key = np.ascontiguousarray(key, np.uint32)
@@ -172,6 +173,29 @@ class LocusBins:
         handle = C.c_void_p()
         _lib.check(L.sbgpu_bins_create(C.byref(a), C.byref(h), _ptr(hits.mass), cw, kw, _ptr(compat), _ptr(key),
                                        C.byref(handle)), "sbgpu_bins_create")
+        self._export(L, annot, handle, hits.n_hits, cw, kw, with_hit_bin=True)
+
+    @classmethod
+    def on_device(cls, ctx, annot, hits, d_hits_struct, d_mass_ptr, cw, kw, d_compat_ptr, d_key_ptr, d_hit_bin_ptr, stream):
+        """Device grouping (sbgpu_bins_create_device): the words stay in HBM.  Returns None when the device
+        form does not cover the input (unsorted hits, fractional masses, a locus with thousands of bins);
+        the caller then uses the host form."""
+        L = _lib.load()
+        if hits.n_hits and np.any(np.diff(hits.hit_locus) < 0):
+            return None
+        off = np.searchsorted(hits.hit_locus, np.arange(annot.n_loci + 1), side="left").astype(np.int64)
+        a = annot._struct()
+        handle = C.c_void_p()
+        rc = L.sbgpu_bins_create_device(ctx.h, C.byref(a), C.byref(d_hits_struct), d_mass_ptr, off.ctypes.data, cw, kw,
+                                        d_compat_ptr, d_key_ptr, d_hit_bin_ptr, stream, C.byref(handle))
+        if rc == _lib.SBGPU_EUNSUPPORTED:
+            return None
+        _lib.check(rc, "sbgpu_bins_create_device")
+        self = cls.__new__(cls)
+        self._export(L, annot, handle, hits.n_hits, cw, kw, with_hit_bin=False)
+        return self
+
+    def _export(self, L, annot, handle, n_hits, cw, kw, with_hit_bin):
         try:
             info = (C.c_int64 * 8)()
             _lib.check(L.sbgpu_bins_info(handle, info), "sbgpu_bins_info")
@@ -183,7 +207,7 @@ class LocusBins:
             self.iso_len = np.zeros(self.n_iso, np.int32)
             self.bin_key = np.zeros((self.n_bins, kw), np.uint32)
             self.bin_compat = np.zeros((self.n_bins, cw), np.uint32)
-            self.hit_bin = np.zeros(hits.n_hits, np.int64)
+            self.hit_bin = np.zeros(n_hits, np.int64) if with_hit_bin else None   # device form: see d_hit_bin
             self.pair_seg_off = np.zeros(self.n_pairs + 1, np.int64)
             self.pair_seg_lens = np.zeros(n_pair_segs, np.uint32)
             self.pair_implicit_mask = np.zeros(self.n_pairs, np.uint32)
@@ -191,8 +215,8 @@ class LocusBins:
             self.pair_out_index = np.zeros(self.n_pairs, np.int64)
             _lib.check(L.sbgpu_bins_export(
                 handle, _ptr(self.row_off), _ptr(self.iso_off), _ptr(self.f_off), _ptr(self.count), _ptr(self.iso_len),
-                _ptr(self.bin_key), _ptr(self.bin_compat), _ptr(self.hit_bin), _ptr(self.pair_seg_off),
-                _ptr(self.pair_seg_lens), _ptr(self.pair_implicit_mask), _ptr(self.pair_iso_len),
+                _ptr(self.bin_key), _ptr(self.bin_compat), _ptr(self.hit_bin) if with_hit_bin else None,
+                _ptr(self.pair_seg_off), _ptr(self.pair_seg_lens), _ptr(self.pair_implicit_mask), _ptr(self.pair_iso_len),
                 _ptr(self.pair_out_index)), "sbgpu_bins_export")
         finally:
             L.sbgpu_bins_destroy(handle)

@@ -19,8 +19,25 @@ from .exonbin import LocusBins
 from .synth import LocusBatch
 
 
+class _LazyHitBin:
+    """hit -> bin of the device grouping: stays in HBM until somebody asks for it as an array."""
+
+    def __init__(self, d):
+        self._d, self._h = d, None
+
+    def __array__(self, dtype=None, copy=None):
+        if self._h is None:
+            self._h = self._d.cpu().numpy()
+        return self._h if dtype is None else self._h.astype(dtype)
+
+    def __getitem__(self, k):
+        return np.asarray(self)[k]
+
+
 class LocusQuantifier:
-    def __init__(self, annot, hits, insert, read_len, long_read=False, ctx=None, device=0):
+    def __init__(self, annot, hits, insert, read_len, long_read=False, ctx=None, device=0, device_bins=True):
+        """device_bins: group the hits into bins on the GPU when the input allows it (sorted hits, whole-number
+        masses; sbgpu_bins_create_device), else -- or when False -- on the host."""
         self.torch = torch = _torch()
         self.ctx = ctx or default_context(device)
         self.dev = torch.device("cuda", self.ctx.device)
@@ -32,6 +49,9 @@ class LocusQuantifier:
                    for k in ("iso_off", "exon_off", "exon_left", "exon_right", "seg_off", "seg_left", "seg_right")}
         self._d.update({k: up(getattr(hits, k).view(np.int32) if getattr(hits, k).dtype == np.uint32 else getattr(hits, k))
                         for k in ("hit_locus", "feat_off", "feat_code", "feat_left", "feat_right")})
+        self._d["mass"] = up(hits.mass)
+        self.device_bins = bool(device_bins)
+        self.bins_on_device = False
         self.bins = None
         self.solver = None
 
@@ -54,9 +74,18 @@ class LocusQuantifier:
                                self._p("feat_left"), self._p("feat_right"))
         _lib.check(self.ctx.L.sbgpu_exonbin_device(self.ctx.h, C.byref(an), C.byref(ht), cw, kw, self.d_compat.data_ptr(),
                                                    self.d_key.data_ptr(), self._stream()), "sbgpu_exonbin_device")
-        compat = self.d_compat[:h.n_hits].cpu().numpy().view(np.uint32)
-        key = self.d_key[:h.n_hits].cpu().numpy().view(np.uint32)
-        self.bins = LocusBins(a, h, compat, key)
+        self.bins = None
+        if self.device_bins and h.n_hits:
+            self.d_hit_bin = torch.zeros(h.n_hits, dtype=torch.int64, device=self.dev)
+            self.bins = LocusBins.on_device(self.ctx, a, h, ht, self._p("mass"), cw, kw, self.d_compat.data_ptr(),
+                                            self.d_key.data_ptr(), self.d_hit_bin.data_ptr(), self._stream())
+            if self.bins is not None:
+                self.bins.hit_bin = _LazyHitBin(self.d_hit_bin)
+        self.bins_on_device = self.bins is not None
+        if self.bins is None:   # host form: bring the words back
+            compat = self.d_compat[:h.n_hits].cpu().numpy().view(np.uint32)
+            key = self.d_key[:h.n_hits].cpu().numpy().view(np.uint32)
+            self.bins = LocusBins(a, h, compat, key)
         return self.bins
 
     def bin_weights(self):

@@ -141,6 +141,79 @@ def test_irregular_feature_lists(ctx, oracle):
     np.testing.assert_array_equal(key, o_key)
 
 
+def bins_arrays(b):
+    return [b.row_off, b.f_off, b.count, b.bin_key, b.bin_compat, np.asarray(b.hit_bin), b.pair_seg_off, b.pair_seg_lens,
+            b.pair_implicit_mask, b.pair_iso_len, b.pair_out_index]
+
+
+def test_device_grouping_equals_host_grouping(ctx, oracle):
+    """sbgpu_bins_create_device vs sbgpu_bins_create on the same words: every array identical.  The input has
+    duplicate fragments (equal feature sequences: counted once, the first one's mass), masses above 1, hits
+    without a compatible isoform, empty loci."""
+    from strawberry_amd import exonbin as eb
+    from strawberry_amd import synth
+    from strawberry_amd.quantify import InsertSize, LocusQuantifier
+    loci = synth.make_gene_models(150, seed=41)
+    hl, pairs = synth.make_fragments(loci, 120, seed=42, noise=0.3)
+    rng = np.random.default_rng(43)
+    rows = []
+    for l, (lb, rb) in zip(hl, pairs):
+        if l % 17 == 3:
+            continue                                  # some loci get no hits at all
+        f = eb.hit_features(lb, rb)
+        if f is None:
+            continue
+        rows.append((l, f[1][0], f[2][-1], f, float(rng.integers(1, 5))))
+        if rng.random() < 0.15:                       # an equal fragment later in the same (left, right) run
+            rows.append((l, f[1][0], f[2][-1], f, float(rng.integers(1, 9))))
+        if rng.random() < 0.05:                       # same coordinates, GAP turned INTRON: another Contig code-wise,
+            c2 = [1 if c == 2 else c for c in f[0]]   # the SAME std::set element (compared by offset and length only)
+            rows.append((l, f[1][0], f[2][-1], (c2, f[1], f[2]), 3.0))
+    rows.sort(key=lambda r: (r[0], r[1], r[2]))
+    annot = eb.Annotation(loci)
+    hits = eb.Hits([r[0] for r in rows], [r[3] for r in rows], mass=[r[4] for r in rows])
+    qd = LocusQuantifier(annot, hits, InsertSize(250.0, 30.0), 75, ctx=ctx, device_bins=True)
+    qh = LocusQuantifier(annot, hits, InsertSize(250.0, 30.0), 75, ctx=ctx, device_bins=False)
+    bd, bh = qd.assign_bins(), qh.assign_bins()
+    assert qd.bins_on_device and not qh.bins_on_device
+    assert bh.n_bins > 2000 and bh.n_hits_used < hits.n_hits and (np.diff(bh.row_off) == 0).any()
+    assert bd.n_hits_used == bh.n_hits_used
+    for x, y in zip(bins_arrays(bd), bins_arrays(bh)):
+        np.testing.assert_array_equal(x, y)
+    # the duplicates mattered: counting every hit's mass would give other counts
+    naive = np.bincount(bh.hit_bin[bh.hit_bin >= 0], weights=hits.mass[bh.hit_bin >= 0], minlength=bh.n_bins)
+    assert (naive != bh.count).sum() > 50
+
+
+def test_device_grouping_declines_what_it_cannot_do_exactly(ctx):
+    from strawberry_amd import exonbin as eb
+    from strawberry_amd import synth
+    from strawberry_amd.quantify import InsertSize, LocusQuantifier
+    loci = synth.make_gene_models(20, seed=51)
+    hl, pairs = synth.make_fragments(loci, 60, seed=52)
+    rows = [(l, eb.hit_features(lb, rb)) for l, (lb, rb) in zip(hl, pairs)]
+    rows = [(l, f) for l, f in rows if f is not None]
+    annot = eb.Annotation(loci)
+    ok = eb.Hits([l for l, _ in rows], [f for _, f in rows])
+    q = LocusQuantifier(annot, ok, InsertSize(250.0, 30.0), 75, ctx=ctx)
+    q.assign_bins()
+    assert q.bins_on_device
+    ref = bins_arrays(q.bins)
+    # fractional masses: the float accumulation order matters -> host
+    frac = eb.Hits([l for l, _ in rows], [f for _, f in rows], mass=[0.5] * len(rows))
+    q = LocusQuantifier(annot, frac, InsertSize(250.0, 30.0), 75, ctx=ctx)
+    q.assign_bins()
+    assert not q.bins_on_device
+    # hits of a locus not in (left, right) order: equal fragments need not be neighbours -> host, same bins as sets
+    rev = list(reversed(rows))
+    rev.sort(key=lambda r: r[0])
+    unsorted = eb.Hits([l for l, _ in rev], [f for _, f in rev])
+    q = LocusQuantifier(annot, unsorted, InsertSize(250.0, 30.0), 75, ctx=ctx)
+    b = q.assign_bins()
+    assert not q.bins_on_device and b.n_bins == q.bins.n_bins == len(ref[2])
+    assert sorted(b.count.tolist()) == sorted(ref[2].tolist())
+
+
 def test_large_batch_properties(ctx, oracle):
     """BASELINE-scale hit counts through size-independent properties: tiling the loci along the genome
     must tile the answers; a fragment sampled from an isoform without noise is compatible with it."""
@@ -181,6 +254,8 @@ def test_chain_from_fragments_reproduces_reference_run(ctx, oracle, which):
     if unpaired:
         assert (hits.feat_code != 2).all()      # no mate gaps: every hit is a single read
     bins = q.assign_bins()
+    # grouped on the device wherever the order of the float accumulation cannot matter (whole-number masses)
+    assert q.bins_on_device == (which != "E2E_MASS")
     o_compat, o_key = oracle.exonbin_batch(annot, hits)
     np.testing.assert_array_equal(q.d_compat.cpu().numpy().view(np.uint32)[:hits.n_hits], o_compat)
     np.testing.assert_array_equal(q.d_key.cpu().numpy().view(np.uint32)[:hits.n_hits], o_key)
