@@ -2,6 +2,9 @@
 #include "plan.h"
 
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <thread>
 #include <map>
 #include <tuple>
 
@@ -15,6 +18,30 @@ static int pow2ceil(int64_t x)
    while (p < x) p <<= 1;
    return p;
 }
+// host threads for the per-locus passes (SBGPU_HOST_THREADS, default min(16, hardware threads))
+static unsigned plan_threads(int64_t n_items)
+{
+   unsigned nt = std::thread::hardware_concurrency();
+   if (nt > 16) nt = 16;
+   if (const char *e = std::getenv("SBGPU_HOST_THREADS")) nt = (unsigned)std::atoi(e);
+   if (nt < 1) nt = 1;
+   if (nt > 64) nt = 64;
+   if ((int64_t)nt * 8192 > n_items) nt = (unsigned)std::max<int64_t>(1, n_items / 8192); // not worth a thread below 8192 loci
+   return nt;
+}
+// f(begin, end, t) over [0, n) split into nt contiguous ranges
+template <class F>
+static void parallel_ranges(int64_t n, unsigned nt, F f)
+{
+   if (nt <= 1) {
+      f((int64_t)0, n, 0u);
+      return;
+   }
+   std::vector<std::thread> pool;
+   for (unsigned t = 0; t < nt; ++t) pool.emplace_back([=]() { f(n * t / nt, n * (t + 1) / nt, t); });
+   for (auto &th : pool) th.join();
+}
+
 static int ilog2i(int x)
 {
    int l = 0;
@@ -45,25 +72,51 @@ int build_host_plan(int64_t n_loci, const int64_t *row_off, const int64_t *iso_o
    }
 
    // pass 1: validate, decide the wave-kind tile height from the load
+   const unsigned nt = plan_threads(n_loci);
    int64_t wave_lanes_base = 0; // lanes the wave kind would occupy with the base tile (rh 2)
-   for (int64_t l = 0; l < n_loci; ++l) {
-      const int64_t nrow = row_off[l + 1] - row_off[l];
-      const int64_t niso = iso_off[l + 1] - iso_off[l];
-      if (nrow < 0 || niso < 1 || f_off[l + 1] - f_off[l] != nrow * niso || nrow > (1 << 28)) {
+   {
+      std::vector<int64_t> lanes_t(nt, 0), bytes_t(nt, 0);
+      std::vector<int> bad_t(nt, 0);
+      parallel_ranges(n_loci, nt, [&](int64_t b, int64_t e, unsigned t) {
+         int64_t lanes_sum = 0, bytes = 0;
+         int bad = 0;
+         for (int64_t l = b; l < e; ++l) {
+            const int64_t nrow = row_off[l + 1] - row_off[l];
+            const int64_t niso = iso_off[l + 1] - iso_off[l];
+            if (nrow < 0 || niso < 1 || f_off[l + 1] - f_off[l] != nrow * niso || nrow > (1 << 28)) {
+               bad |= 1;
+               continue;
+            }
+            if (niso > kMaxStreamIso) {
+               bad |= 2;
+               continue;
+            }
+            bytes += nrow * niso * 8 + nrow * 4 + niso * 8 + 24;
+            if (niso <= kMaxTileC) {
+               int CPL, CL;
+               layout_for(niso, &CPL, &CL);
+               const int R = tile_rows(CPL, 2);
+               const int64_t lanes = (int64_t)pow2ceil(std::max<int64_t>(1, (nrow + R - 1) / R)) * CL;
+               if (lanes <= 64) lanes_sum += lanes;
+            }
+         }
+         lanes_t[t] = lanes_sum;
+         bytes_t[t] = bytes;
+         bad_t[t] = bad;
+      });
+      int bad = 0;
+      for (unsigned t = 0; t < nt; ++t) {
+         wave_lanes_base += lanes_t[t];
+         p.algorithmic_bytes += bytes_t[t];
+         bad |= bad_t[t];
+      }
+      if (bad & 1) {
          *err = "plan: malformed locus (need niso >= 1, nrow >= 0, f_off step == nrow*niso)";
          return SBGPU_EINVAL;
       }
-      if (niso > kMaxStreamIso) {
+      if (bad & 2) {
          *err = "plan: a locus has more than 512 isoforms";
          return SBGPU_ESHAPE;
-      }
-      p.algorithmic_bytes += nrow * niso * 8 + nrow * 4 + niso * 8 + 24;
-      if (niso <= kMaxTileC) {
-         int CPL, CL;
-         layout_for(niso, &CPL, &CL);
-         const int R = tile_rows(CPL, 2);
-         const int64_t lanes = (int64_t)pow2ceil(std::max<int64_t>(1, (nrow + R - 1) / R)) * CL;
-         if (lanes <= 64) wave_lanes_base += lanes;
       }
    }
    const int64_t simd_lanes = (int64_t)n_cu * 4 * 64;
@@ -76,55 +129,98 @@ int build_host_plan(int64_t n_loci, const int64_t *row_off, const int64_t *iso_o
       wave_rmult = (wave_lanes_base <= 16 * simd_lanes) ? 2 : 4;
    }
 
-   std::map<std::tuple<int, int, int, int>, SizeClass> by_key;
-   for (int64_t l = 0; l < n_loci; ++l) {
-      const int64_t nrow = row_off[l + 1] - row_off[l];
-      const int64_t niso = iso_off[l + 1] - iso_off[l];
-      SizeClass k;
-      k.kind = kStream;
-      if (niso <= kMaxTileC) {
-         layout_for(niso, &k.CPL, &k.CL);
-         k.layout = layout_id(k.CPL, k.CL);
-         // wave kind: smallest power-of-two group that holds the rows
-         bool placed = false;
-         {
-            const int R = tile_rows(k.CPL, wave_rmult);
-            const int64_t lanes = (int64_t)pow2ceil(std::max<int64_t>(1, (nrow + R - 1) / R)) * k.CL;
-            if (lanes <= 64) {
-               k.kind = (wave_rmult == 1) ? kWaveH : (wave_rmult == 2 ? kWave1 : kWave2);
-               k.rmult = wave_rmult;
-               k.R = R;
-               k.G = (int)lanes;
-               k.lbG = ilog2i(k.G);
-               placed = true;
+   // Classes are few (kinds x layouts x group sizes).  Each host thread classifies a contiguous range of
+   // loci into its own table; the tables are merged in range order, so a class list stays in locus order.
+   typedef std::tuple<int, int, int, int> ClassKey;
+   struct Local {
+      std::map<ClassKey, int> slot_of;
+      std::vector<SizeClass> found;
+      int64_t n_stream = 0;
+   };
+   std::vector<Local> local(nt);
+   std::vector<int64_t> work_of((size_t)n_loci);
+   parallel_ranges(n_loci, nt, [&](int64_t lb, int64_t le, unsigned t) {
+      Local &L = local[t];
+      int last_slot = -1;
+      ClassKey last_key(-1, -1, -1, -1);
+      for (int64_t l = lb; l < le; ++l) {
+         const int64_t nrow = row_off[l + 1] - row_off[l];
+         const int64_t niso = iso_off[l + 1] - iso_off[l];
+         work_of[(size_t)l] = nrow * niso;
+         int kind = kStream, layout = 0, CPL = 0, CL = 0, rmult = 1, R = 0, G = 0, lbG = 0;
+         if (niso <= kMaxTileC) {
+            layout_for(niso, &CPL, &CL);
+            layout = layout_id(CPL, CL);
+            // wave kind: smallest power-of-two group that holds the rows
+            bool placed = false;
+            {
+               const int Rw = tile_rows(CPL, wave_rmult);
+               const int64_t lanes = (int64_t)pow2ceil(std::max<int64_t>(1, (nrow + Rw - 1) / Rw)) * CL;
+               if (lanes <= 64) {
+                  kind = (wave_rmult == 1) ? kWaveH : (wave_rmult == 2 ? kWave1 : kWave2);
+                  rmult = wave_rmult;
+                  R = Rw;
+                  G = (int)lanes;
+                  lbG = ilog2i(G);
+                  placed = true;
+               }
+            }
+            // block kinds: the whole 256-lane workgroup is the group
+            for (int tall = tune.light_block ? 0 : 1; tall < 2 && !placed; ++tall) {
+               const int rm = tall ? kBlockTallRh : kBlockRh;
+               if ((int64_t)(kBlockThreads / CL) * tile_rows(CPL, rm) >= nrow) {
+                  kind = tall ? kBlockTall : kBlock;
+                  rmult = rm;
+                  R = tile_rows(CPL, rm);
+                  G = kBlockThreads;
+                  lbG = 6;
+                  placed = true;
+               }
             }
          }
-         // block kinds: the whole 256-lane workgroup is the group
-         for (int tall = tune.light_block ? 0 : 1; tall < 2 && !placed; ++tall) {
-            const int rm = tall ? kBlockTallRh : kBlockRh;
-            if ((int64_t)(kBlockThreads / k.CL) * tile_rows(k.CPL, rm) >= nrow) {
-               k.kind = tall ? kBlockTall : kBlock;
-               k.rmult = rm;
-               k.R = tile_rows(k.CPL, rm);
-               k.G = kBlockThreads;
-               k.lbG = 6;
-               placed = true;
+         if (kind == kStream) {
+            layout = CPL = CL = R = G = lbG = 0;
+            rmult = 1;
+            ++L.n_stream;
+         }
+         const ClassKey key(kind, layout, rmult, G);
+         int slot;
+         if (key == last_key) {
+            slot = last_slot; // neighbouring loci are often of one class
+         } else {
+            auto it = L.slot_of.find(key);
+            if (it == L.slot_of.end()) {
+               it = L.slot_of.emplace(key, (int)L.found.size()).first;
+               SizeClass k;
+               k.kind = kind, k.layout = layout, k.CPL = CPL, k.CL = CL, k.rmult = rmult, k.R = R, k.G = G, k.lbG = lbG;
+               L.found.push_back(std::move(k));
             }
+            slot = it->second;
+            last_key = key;
+            last_slot = slot;
+         }
+         SizeClass &sc = L.found[(size_t)slot];
+         sc.loci.push_back((int32_t)l);
+         sc.work += (kind == kStream) ? nrow * niso : (int64_t)(G / std::max(1, CL)) * R * CPL * CL;
+      }
+   });
+   // merge in range order; the rest of the function walks the classes in key order
+   std::map<ClassKey, SizeClass> merged;
+   for (unsigned t = 0; t < nt; ++t) {
+      p.n_stream_loci += local[t].n_stream;
+      for (auto &kv : local[t].slot_of) {
+         SizeClass &src = local[t].found[(size_t)kv.second];
+         auto it = merged.find(kv.first);
+         if (it == merged.end()) {
+            merged.emplace(kv.first, std::move(src));
+         } else {
+            it->second.loci.insert(it->second.loci.end(), src.loci.begin(), src.loci.end());
+            it->second.work += src.work;
          }
       }
-      if (k.kind == kStream) {
-         k.layout = k.CPL = k.CL = k.R = k.G = k.lbG = 0;
-         k.rmult = 1;
-         ++p.n_stream_loci;
-      }
-      SizeClass &sc = by_key[std::make_tuple(k.kind, k.layout, k.rmult, k.G)];
-      if (sc.loci.empty()) {
-         std::vector<int32_t> keep;
-         sc = k;
-      }
-      sc.loci.push_back((int32_t)l);
-      sc.work += (k.kind == kStream) ? nrow * niso : (int64_t)(k.G / std::max(1, k.CL)) * k.R * k.CPL * k.CL;
    }
+   std::vector<std::pair<ClassKey, SizeClass>> by_key;
+   for (auto &kv : merged) by_key.emplace_back(kv.first, std::move(kv.second));
    p.n_rows = row_off[n_loci];
    p.n_iso = iso_off[n_loci];
    p.n_elem = f_off[n_loci];
@@ -136,14 +232,31 @@ int build_host_plan(int64_t n_loci, const int64_t *row_off, const int64_t *iso_o
    // waves pull further batches through the cursor.
    const int64_t max_waves = tune.max_waves > 0 ? tune.max_waves : (int64_t)1 << 20;
    int64_t waves_wanted = 0;
+   {
+      // heaviest loci first inside a class: they are the likeliest stragglers (LPT order); ties keep
+      // locus order.  Classes are independent: host threads take them one at a time.
+      std::atomic<size_t> next(0);
+      auto sorter = [&]() {
+         for (;;) {
+            const size_t ci = next.fetch_add(1);
+            if (ci >= by_key.size()) break;
+            std::vector<int32_t> &loci = by_key[ci].second.loci;
+            std::sort(loci.begin(), loci.end(), [&](int32_t x, int32_t y) {
+               const int64_t wx = work_of[(size_t)x], wy = work_of[(size_t)y];
+               return wx != wy ? wx > wy : x < y;
+            });
+         }
+      };
+      if (nt <= 1) {
+         sorter();
+      } else {
+         std::vector<std::thread> pool;
+         for (unsigned t = 0; t < nt; ++t) pool.emplace_back(sorter);
+         for (auto &th : pool) th.join();
+      }
+   }
    for (auto &kv : by_key) {
       SizeClass &sc = kv.second;
-      // heaviest loci first: they are the likeliest stragglers (LPT order)
-      std::stable_sort(sc.loci.begin(), sc.loci.end(), [&](int32_t x, int32_t y) {
-         const int64_t wx = (row_off[x + 1] - row_off[x]) * (iso_off[x + 1] - iso_off[x]);
-         const int64_t wy = (row_off[y + 1] - row_off[y]) * (iso_off[y + 1] - iso_off[y]);
-         return wx > wy;
-      });
       const int64_t n = (int64_t)sc.loci.size();
       if (sc.kind == kWaveH || sc.kind == kWave1 || sc.kind == kWave2) {
          sc.block_threads = 64;

@@ -6,6 +6,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -74,6 +75,7 @@ struct sbgpu_plan {
    sbgpu_ctx *ctx = nullptr;
    sb::HostPlan host;
    KindLaunch launches[sb::kNumKinds];
+   char *d_arena = nullptr;            // one allocation, one upload: the arrays below point into it
    int64_t *d_row_off = nullptr, *d_iso_off = nullptr, *d_f_off = nullptr;
    int32_t *d_loci_all = nullptr;      // all class lists, concatenated (input of phase 0)
    int32_t *d_lists[2] = {nullptr, nullptr}; // survivor lists of the later phases (ping-pong)
@@ -272,18 +274,7 @@ int sbgpu_plan_destroy(sbgpu_plan_t *p)
 {
    if (!p) return SBGPU_OK;
    if (p->ctx) (void)hipSetDevice(p->ctx->device);
-   (void)hipFree(p->d_row_off);
-   (void)hipFree(p->d_iso_off);
-   (void)hipFree(p->d_f_off);
-   (void)hipFree(p->d_loci_all);
-   (void)hipFree(p->d_cursors);
-   (void)hipFree(p->d_counts);
-   (void)hipFree(p->d_class_n);
-   (void)hipFree(p->d_lists[0]);
-   (void)hipFree(p->d_lists[1]);
-   (void)hipFree(p->d_tables);
-   (void)hipFree(p->d_row_keep);
-   (void)hipFree(p->d_locus_sum);
+   (void)hipFree(p->d_arena); // every device array of the plan lives in this one allocation
    delete p;
    return SBGPU_OK;
 }
@@ -301,7 +292,18 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
    if (const char *e = std::getenv("SBGPU_WAVE_RMULT")) tune.wave_rmult = std::atoi(e);
    if (const char *e = std::getenv("SBGPU_MAX_WAVES")) tune.max_waves = std::atoll(e);
    if (const char *e = std::getenv("SBGPU_LIGHT_BLOCK")) tune.light_block = std::atoi(e) != 0;
+   const bool timing = std::getenv("SBGPU_HOST_TIMING") != nullptr; // diagnostic: stage times on stderr
+   auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+   double t_stage = now();
+   auto stage = [&](const char *name) {
+      if (timing) {
+         const double t = now();
+         std::fprintf(stderr, "sbgpu_plan_create: %-12s %.2f ms\n", name, (t - t_stage) * 1e3);
+         t_stage = t;
+      }
+   };
    int rc = sb::build_host_plan(n_loci, row_off, iso_off, f_off, c->n_cu, tune, &p->host, &err);
+   stage("size classes");
    if (rc != SBGPU_OK) {
       delete p;
       return fail(rc, err);
@@ -313,10 +315,6 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
    hipError_t e = hipSetDevice(c->device);
    if (e != hipSuccess) return bail(e, "hipSetDevice");
    const size_t nb = (size_t)(n_loci + 1) * sizeof(int64_t);
-   if ((e = hipMalloc(&p->d_row_off, nb)) != hipSuccess) return bail(e, "hipMalloc(row_off)");
-   if ((e = hipMalloc(&p->d_iso_off, nb)) != hipSuccess) return bail(e, "hipMalloc(iso_off)");
-   if ((e = hipMalloc(&p->d_f_off, nb)) != hipSuccess) return bail(e, "hipMalloc(f_off)");
-   if ((e = hipMalloc(&p->d_loci_all, (size_t)(n_loci + 1) * sizeof(int32_t))) != hipSuccess) return bail(e, "hipMalloc(loci)");
    // phases: a single phase (the 1000 cap) by default; SBGPU_PHASES="64,256" suspends the loci
    // still running at 64 and 256 iterations and re-packs them (measured: no gain on C2/C3)
    {
@@ -336,26 +334,53 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
       }
       p->phase_limits.push_back(SBGPU_EM_MAX_ITER);
    }
-   const size_t ncls_alloc = p->host.classes.size() + 1;
+   const size_t ncls = p->host.classes.size();
+   const size_t ncls_alloc = ncls + 1;
    const size_t nph = p->phase_limits.size() + 1;
-   if ((e = hipMalloc(&p->d_cursors, nph * ncls_alloc * sizeof(int32_t))) != hipSuccess) return bail(e, "hipMalloc(cursors)");
-   if ((e = hipMalloc(&p->d_counts, nph * ncls_alloc * sizeof(int32_t))) != hipSuccess) return bail(e, "hipMalloc(counts)");
-   if ((e = hipMalloc(&p->d_class_n, ncls_alloc * sizeof(int32_t))) != hipSuccess) return bail(e, "hipMalloc(class_n)");
-   if ((e = hipMalloc(&p->d_lists[0], (size_t)(n_loci + 1) * sizeof(int32_t))) != hipSuccess) return bail(e, "hipMalloc(list0)");
-   if ((e = hipMalloc(&p->d_lists[1], (size_t)(n_loci + 1) * sizeof(int32_t))) != hipSuccess) return bail(e, "hipMalloc(list1)");
-   if ((e = hipMalloc(&p->d_row_keep, (size_t)p->host.n_rows + 1)) != hipSuccess) return bail(e, "hipMalloc(row_keep)");
-   if ((e = hipMalloc(&p->d_locus_sum, (size_t)(n_loci + 1) * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(locus_sum)");
+   // ---- one device arena; its head (offsets, class lists, tables, class sizes) is staged on the host
+   // and uploaded with a single copy, the rest is workspace
+   auto up = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
+   size_t at = 0;
+   const size_t o_row = at; at += up(nb);
+   const size_t o_iso = at; at += up(nb);
+   const size_t o_f = at; at += up(nb);
+   const size_t o_loci = at; at += up((size_t)(n_loci + 1) * sizeof(int32_t));
+   const size_t o_tab = at; at += up(ncls_alloc * sizeof(sb::ClassDesc));
+   const size_t o_cn = at; at += up(ncls_alloc * sizeof(int32_t));
+   const size_t staged = at;
+   const size_t o_cur = at; at += up(nph * ncls_alloc * sizeof(int32_t));
+   const size_t o_cnt = at; at += up(nph * ncls_alloc * sizeof(int32_t));
+   const size_t o_l0 = at; at += up((size_t)(n_loci + 1) * sizeof(int32_t));
+   const size_t o_l1 = at; at += up((size_t)(n_loci + 1) * sizeof(int32_t));
+   const size_t o_keep = at; at += up((size_t)p->host.n_rows + 1);
+   const size_t o_sum = at; at += up((size_t)(n_loci + 1) * sizeof(double));
+   if ((e = hipMalloc(&p->d_arena, at)) != hipSuccess) return bail(e, "hipMalloc(plan arena)");
+   stage("hipMalloc");
+   p->d_row_off = (int64_t *)(p->d_arena + o_row);
+   p->d_iso_off = (int64_t *)(p->d_arena + o_iso);
+   p->d_f_off = (int64_t *)(p->d_arena + o_f);
+   p->d_loci_all = (int32_t *)(p->d_arena + o_loci);
+   p->d_tables = (sb::ClassDesc *)(p->d_arena + o_tab);
+   p->d_class_n = (int32_t *)(p->d_arena + o_cn);
+   p->d_cursors = (int32_t *)(p->d_arena + o_cur);
+   p->d_counts = (int32_t *)(p->d_arena + o_cnt);
+   p->d_lists[0] = (int32_t *)(p->d_arena + o_l0);
+   p->d_lists[1] = (int32_t *)(p->d_arena + o_l1);
+   p->d_row_keep = (uint8_t *)(p->d_arena + o_keep);
+   p->d_locus_sum = (double *)(p->d_arena + o_sum);
+   std::vector<char> stage_buf(staged, 0);
    if (n_loci > 0) {
-      if ((e = hipMemcpy(p->d_row_off, row_off, nb, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(row_off)");
-      if ((e = hipMemcpy(p->d_iso_off, iso_off, nb, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(iso_off)");
-      if ((e = hipMemcpy(p->d_f_off, f_off, nb, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(f_off)");
+      std::memcpy(stage_buf.data() + o_row, row_off, nb);
+      std::memcpy(stage_buf.data() + o_iso, iso_off, nb);
+      std::memcpy(stage_buf.data() + o_f, f_off, nb);
    }
-   if ((e = hipMalloc(&p->d_tables, (p->host.classes.size() + 1) * sizeof(sb::ClassDesc))) != hipSuccess) return bail(e, "hipMalloc(tables)");
+   int32_t *h_loci = (int32_t *)(stage_buf.data() + o_loci);
+   sb::ClassDesc *table = (sb::ClassDesc *)(stage_buf.data() + o_tab);
+   int32_t *h_cn = (int32_t *)(stage_buf.data() + o_cn);
    size_t off = 0;
    size_t max_stream_iso = 0;
-   std::vector<sb::ClassDesc> table(p->host.classes.size());
    for (int k = 0; k < sb::kNumKinds; ++k) p->launches[k] = KindLaunch();
-   for (size_t ci = 0; ci < p->host.classes.size(); ++ci) {
+   for (size_t ci = 0; ci < ncls; ++ci) {
       const sb::SizeClass &sc = p->host.classes[ci];
       KindLaunch &kl = p->launches[sc.kind];
       if (kl.n_classes == 0) {
@@ -367,10 +392,10 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
       table[ci].n = (int32_t)sc.loci.size();
       table[ci].loci_off = (int32_t)off;
       table[ci].shape = sc.layout | (sc.rmult << 8) | (sc.lbG << 16);
+      h_cn[ci] = table[ci].n;
       kl.n_blocks += sc.n_blocks;
       kl.n_classes += 1;
-      if ((e = hipMemcpy(p->d_loci_all + off, sc.loci.data(), sc.loci.size() * sizeof(int32_t), hipMemcpyHostToDevice)) != hipSuccess)
-         return bail(e, "hipMemcpy(class list)");
+      std::memcpy(h_loci + off, sc.loci.data(), sc.loci.size() * sizeof(int32_t));
       p->loci_off.push_back((int64_t)off);
       off += sc.loci.size();
       if (sc.kind == sb::kStream) {
@@ -380,15 +405,9 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
          }
       }
    }
-   if (!table.empty() &&
-       (e = hipMemcpy(p->d_tables, table.data(), table.size() * sizeof(sb::ClassDesc), hipMemcpyHostToDevice)) != hipSuccess)
-      return bail(e, "hipMemcpy(tables)");
-   {
-      std::vector<int32_t> cn(table.size() + 1, 0);
-      for (size_t i = 0; i < table.size(); ++i) cn[i] = table[i].n;
-      if ((e = hipMemcpy(p->d_class_n, cn.data(), cn.size() * sizeof(int32_t), hipMemcpyHostToDevice)) != hipSuccess)
-         return bail(e, "hipMemcpy(class_n)");
-   }
+   stage("staging");
+   if ((e = hipMemcpy(p->d_arena, stage_buf.data(), staged, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(plan)");
+   stage("upload");
    // streaming kernel LDS: (3 + NWAVE) * npad doubles, npad <= pow2ceil-padded niso
    size_t npad = 1;
    while (npad < max_stream_iso && npad < 64) npad <<= 1;

@@ -14,6 +14,8 @@ for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ
   tag=$(echo $pmc | cut -d' ' -f1)
   timeout 600 rocprofv3 --pmc $pmc --output-format csv -d $OUT/pmc_$tag -o eb -- python3 $REPO/tools/bench_exonbin.py --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_$tag.log 2>&1
 done
+# the grouping kernels (bins_locus_kernel, bins_pack_kernel) are timed inside the chain
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/chain_stats -o ch -- python3 $REPO/tools/bench_chain.py > $OUT/chain.json 2>$OUT/chain.log
 cd $REPO
 python3 - "$OUT" <<'PY'
 import collections, csv, glob, json, sys
@@ -32,6 +34,17 @@ for f in glob.glob(out + '/stats/**/*kernel_stats.csv', recursive=True):
         if 'exonbin' in r['Name']:
             stats = r
 bench = json.loads(open(out + '/bench_exonbin.json').read().strip().splitlines()[-1])
-json.dump({"bench": bench, "rocprof_kernel_stats": stats, "pmc": pmc}, open(out + '/summary.json', 'w'), indent=1)
+grouping = []
+for f in glob.glob(out + '/chain_stats/**/*kernel_stats.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        if 'bins_' in r['Name']:
+            grouping.append(r)
+chain = None
+try:
+    chain = json.loads(open(out + '/chain.json').read().strip().splitlines()[-1])
+except Exception:
+    pass
+json.dump({"bench": bench, "rocprof_kernel_stats": stats, "pmc": pmc,
+           "grouping_kernels_in_chain_4M_hits": grouping, "chain_bench": chain}, open(out + '/summary.json', 'w'), indent=1)
 print(open(out + '/summary.json').read())
 PY
