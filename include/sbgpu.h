@@ -342,6 +342,31 @@ int sbgpu_bins_export(const sbgpu_bins_t *bins, int64_t *row_off, int64_t *iso_o
                       int64_t *hit_bin, int64_t *pair_seg_off, uint32_t *pair_seg_lens,
                       uint32_t *pair_implicit_mask, int32_t *pair_iso_len, int64_t *pair_out_index);
 
+/* ---- the whole path in one call: fragments -> exon bins -> bin weights -> EM ------------------
+ * LocusContext's constructor + the EM of estimate_abundances for every locus of a batch
+ * (include/estimate.hpp:60-103, src/estimate.cpp:279-308), host buffers in, host buffers out:
+ * uploads the annotation and the hits once, runs sbgpu_exonbin_device, groups the hits into bins
+ * on the device (on the host when sbgpu_bins_create_device declines), builds the pairs, runs
+ * sbgpu_binweight_device straight into the EM batch's F, plans and runs sbgpu_em_run_device.
+ * Nothing but the per-bin arrays, theta and (on request) F comes back over PCIe.
+ *   annot          host arrays incl. the segments (sbgpu_segments_host)
+ *   hits, hit_mass host arrays; hits grouped by locus and, inside a locus, in uniq_hits() order
+ *   insert         the insert-size law (-i); NULL = none given: the empirical distribution is built
+ *                  from the hits first (Sample::fragLenDist, src/alignments.cpp:1363-1407,
+ *                  Strawberry.cpp:345-355) and written to *insert_used with emp_hist pointing into
+ *                  the returned handle
+ *   theta_out [n_iso], status_out / iters_out [n_loci]   as sbgpu_em_batch
+ *   compat_out [n_hits * ceil(max isoforms / 32)]  optional (NULL): the kernel's compat words
+ *   *bins_out      the bins (sbgpu_bins_info / _export, incl. hit_bin; sbgpu_bins_export_weights
+ *                  for F); destroy with sbgpu_bins_destroy
+ * The caller applies the reference's own epilogue to theta (src/estimate.cpp:310-355).          */
+int sbgpu_quantify_host(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *annot, const sbgpu_hits_t *hits,
+                        const float *hit_mass, const sbgpu_insert_t *insert, int32_t read_len,
+                        int32_t long_read, double *theta_out, int32_t *status_out, int32_t *iters_out,
+                        uint32_t *compat_out, sbgpu_insert_t *insert_used, sbgpu_bins_t **bins_out);
+/* F of the EM batch a handle from sbgpu_quantify_host holds: F_out[info[3]] (row-major per locus). */
+int sbgpu_bins_export_weights(const sbgpu_bins_t *bins, double *F_out);
+
 /* ---- output formatting, host only -------------------------------
  * The digits Strawberry prints for FPKM / Frac / TPM: std::to_string(double) (= "%f",
  * src/estimate.cpp:335,344 and src/alignments.cpp:1827) copied into a char[12] by

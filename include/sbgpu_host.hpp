@@ -259,67 +259,58 @@ public:
       }
       compat_words = (int32_t)((max_iso + 31) / 32);
       key_words = (int32_t)((max_seg + 31) / 32);
-      /* assign_exon_bin: the interval tests on the GPU, set_maps on the host */
+      /* assign_exon_bin + set_theory_bin_weight + EmSolver for all loci: one call, everything between the
+       * hits and theta stays on the device (sbgpu_quantify_host) */
       const int64_t nh = n_hits();
+      const int64_t n_iso = iso_off[(size_t)nl];
       compat.assign((size_t)nh * compat_words + 1, 0);
-      key.assign((size_t)nh * key_words + 1, 0);
-      sbgpu_annotation_t an = annotation();
-      sbgpu_hits_t ht = hits();
-      check(sbgpu_exonbin_host(ctx.get(), &an, &ht, compat_words, key_words, compat.data(), key.data()), "sbgpu_exonbin_host");
-      if (ins_in) {
-         insert = *ins_in;
-      } else {
-         std::vector<int32_t> fl((size_t)nh + 1, -1);
-         const int64_t n = sbgpu_frag_lens_host(&an, &ht, compat_words, compat.data(), fl.data());
-         check((int)(n < 0 ? n : 0), "sbgpu_frag_lens_host");
-         std::vector<int> lens;
-         for (int64_t h = 0; h < nh; ++h)
-            if (fl[(size_t)h] >= 0) lens.push_back(fl[(size_t)h]);
-         insert = InsertSize(lens);
-      }
-      const InsertSize &ins = insert;
-      sbgpu_bins_t *bins = nullptr;
-      check(sbgpu_bins_create(&an, &ht, hit_mass.data(), compat_words, key_words, compat.data(), key.data(), &bins),
-            "sbgpu_bins_create");
-      int64_t info[8];
-      sbgpu_bins_info(bins, info);
-      const int64_t n_iso = info[1], n_bins = info[2], n_elem = info[3], n_pairs = info[4], n_psegs = info[5];
-      row_off.assign((size_t)nl + 1, 0);
-      f_off.assign((size_t)nl + 1, 0);
-      std::vector<int64_t> iso_off2((size_t)nl + 1, 0), pair_seg_off((size_t)n_pairs + 1, 0), pair_out((size_t)n_pairs + 1, 0);
-      count.assign((size_t)n_bins + 1, 0);
-      std::vector<int32_t> iso_len((size_t)n_iso + 1, 0), pair_len((size_t)n_pairs + 1, 0);
-      bin_key.assign((size_t)n_bins * key_words + 1, 0);
-      hit_bin.assign((size_t)nh + 1, -1);
-      std::vector<uint32_t> pair_segs((size_t)n_psegs + 1, 0), pair_mask((size_t)n_pairs + 1, 0);
-      check(sbgpu_bins_export(bins, row_off.data(), iso_off2.data(), f_off.data(), count.data(), iso_len.data(), bin_key.data(),
-                              nullptr, hit_bin.data(), pair_seg_off.data(), pair_segs.data(), pair_mask.data(),
-                              pair_len.data(), pair_out.data()),
-            "sbgpu_bins_export");
-      sbgpu_bins_destroy(bins);
-      /* set_theory_bin_weight: one kernel call for all (bin, isoform) pairs, scattered into alpha */
-      sbgpu_insert_t si;
-      si.mean = ins.mean;
-      si.sd = ins.sd;
-      si.use_emp = ins.use_emp;
-      si.start_offset = ins.start_offset;
-      si.end_offset = ins.end_offset;
-      si.total_reads = ins.total_reads;
-      si.emp_hist = ins.emp_dist.empty() ? nullptr : ins.emp_dist.data();
-      si.read_len = read_len;
-      si.long_read = long_read;
-      std::vector<double> w((size_t)n_pairs + 1, 0.0);
-      check(sbgpu_binweight_host(ctx.get(), n_pairs, pair_seg_off.data(), pair_segs.data(), pair_mask.data(), pair_len.data(), &si,
-                                 w.data()),
-            "sbgpu_binweight_host");
-      F.assign((size_t)n_elem + 1, 0.0);
-      for (int64_t p = 0; p < n_pairs; ++p) F[(size_t)pair_out[(size_t)p]] = w[(size_t)p];
-      /* EmSolver::init + run for all loci */
       theta.assign((size_t)n_iso + 1, 0.0);
       status.assign((size_t)nl + 1, 0);
       iters.assign((size_t)nl + 1, 0);
-      sbgpu_batch_t b = {nl, row_off.data(), iso_off.data(), f_off.data(), count.data(), F.data()};
-      check(sbgpu_em_batch(ctx.get(), &b, theta.data(), status.data(), iters.data()), "sbgpu_em_batch");
+      sbgpu_annotation_t an = annotation();
+      sbgpu_hits_t ht = hits();
+      sbgpu_insert_t si, used;
+      if (ins_in) {
+         insert = *ins_in;
+         si.mean = insert.mean;
+         si.sd = insert.sd;
+         si.use_emp = insert.use_emp;
+         si.start_offset = insert.start_offset;
+         si.end_offset = insert.end_offset;
+         si.total_reads = insert.total_reads;
+         si.emp_hist = insert.emp_dist.empty() ? nullptr : insert.emp_dist.data();
+         si.read_len = read_len;
+         si.long_read = long_read;
+      }
+      sbgpu_bins_t *bins = nullptr;
+      check(sbgpu_quantify_host(ctx.get(), &an, &ht, hit_mass.data(), ins_in ? &si : nullptr, read_len, long_read, theta.data(),
+                                status.data(), iters.data(), compat.data(), &used, &bins),
+            "sbgpu_quantify_host");
+      if (!ins_in) { /* the empirical law the library built (Sample::fragLenDist + InsertSize(frag_lens)) */
+         insert = InsertSize();
+         insert.mean = used.mean;
+         insert.sd = used.sd;
+         insert.use_emp = true;
+         insert.start_offset = used.start_offset;
+         insert.end_offset = used.end_offset;
+         insert.total_reads = used.total_reads;
+         insert.emp_dist.assign(used.emp_hist, used.emp_hist + (used.end_offset - used.start_offset + 1));
+      }
+      int64_t info[8];
+      sbgpu_bins_info(bins, info);
+      const int64_t n_bins = info[2], n_elem = info[3];
+      row_off.assign((size_t)nl + 1, 0);
+      f_off.assign((size_t)nl + 1, 0);
+      count.assign((size_t)n_bins + 1, 0);
+      std::vector<int32_t> iso_len((size_t)n_iso + 1, 0);
+      bin_key.assign((size_t)n_bins * key_words + 1, 0);
+      hit_bin.assign((size_t)nh + 1, -1);
+      F.assign((size_t)n_elem + 1, 0.0);
+      int rc = sbgpu_bins_export(bins, row_off.data(), nullptr, f_off.data(), count.data(), iso_len.data(), bin_key.data(), nullptr,
+                                 hit_bin.data(), nullptr, nullptr, nullptr, nullptr, nullptr);
+      if (rc == SBGPU_OK) rc = sbgpu_bins_export_weights(bins, F.data());
+      sbgpu_bins_destroy(bins);
+      check(rc, "sbgpu_bins_export");
       /* the reference's own epilogue, src/estimate.cpp:310-355 */
       isoforms.assign((size_t)n_iso, Isoform());
       for (int64_t l = 0; l < nl; ++l) {

@@ -21,7 +21,8 @@ SYMBOLS = [
     "sbgpu_plan_classes", "sbgpu_plan_locus_kinds", "sbgpu_em_run_device", "sbgpu_em_last_kernel_ms",
     "sbgpu_insert_pdf_table", "sbgpu_binweight_device", "sbgpu_binweight_host",
     "sbgpu_exonbin_device", "sbgpu_exonbin_host", "sbgpu_segments_host", "sbgpu_hit_features", "sbgpu_frag_lens_host",
-    "sbgpu_bins_create", "sbgpu_bins_create_device", "sbgpu_bins_destroy", "sbgpu_bins_info", "sbgpu_bins_export",
+    "sbgpu_bins_create", "sbgpu_bins_create_device", "sbgpu_bins_destroy", "sbgpu_quantify_host",
+    "sbgpu_bins_export_weights", "sbgpu_bins_info", "sbgpu_bins_export",
     "sbgpu_format_value", "sbgpu_format_gtf_transcript", "sbgpu_format_context_row", "sbgpu_em_batch", "sbgpu_abundance_device", "sbgpu_tpm_device",
 ]
 
@@ -150,6 +151,9 @@ def load():
                                     vp, vp, C.POINTER(vp)]
     L.sbgpu_bins_create_device.argtypes = [vp, C.POINTER(sbgpu_annotation_t), C.POINTER(sbgpu_hits_t), vp, vp, C.c_int32,
                                            C.c_int32, vp, vp, vp, vp, C.POINTER(vp)]
+    L.sbgpu_quantify_host.argtypes = [vp, C.POINTER(sbgpu_annotation_t), C.POINTER(sbgpu_hits_t), vp, C.POINTER(sbgpu_insert_t),
+                                      C.c_int32, C.c_int32, vp, vp, vp, vp, C.POINTER(sbgpu_insert_t), C.POINTER(vp)]
+    L.sbgpu_bins_export_weights.argtypes = [vp, vp]
     L.sbgpu_bins_destroy.argtypes = [vp]
     L.sbgpu_bins_destroy.restype = None
     L.sbgpu_bins_info.argtypes = [vp, i64p]

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <vector>
 
 #include "../../include/sbgpu.h"
 
@@ -16,4 +17,7 @@ int ctx_cu_count(const sbgpu_ctx_t *ctx);
 int bins_from_groups(const sbgpu_annotation_t *annot, int32_t compat_words, int32_t key_words, const int64_t *row_off,
                      const int32_t *count, const uint32_t *key, const uint32_t *compat, int64_t n_hits_used,
                      sbgpu_bins_t **out);
+void bins_set_weights(sbgpu_bins_t *bins, std::vector<double> &&F);
+void bins_set_hit_bin(sbgpu_bins_t *bins, std::vector<int64_t> &&hit_bin);
+const double *bins_weights_tail(const sbgpu_bins_t *bins, size_t at); // F.data() + at (the empirical histogram lives there)
 } // namespace sb

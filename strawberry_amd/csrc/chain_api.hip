@@ -1,0 +1,292 @@
+// strawberry_amd/csrc/chain_api.hip -- sbgpu_quantify_host (include/sbgpu.h): the path's entry points
+// chained on one stream with the intermediate results resident in HBM.  No torch, no Python: this is
+// what a C / C++ driver calls (include/sbgpu_host.hpp wraps it).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sbgpu.h"
+#include "api_internal.h"
+
+using sb::api_fail;
+
+namespace {
+
+// the empirical insert-size law of a handle: kept alive with the handle through its weights' tail
+struct DeviceBuf {
+   char *p = nullptr;
+   ~DeviceBuf() { (void)hipFree(p); }
+};
+
+size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+} // namespace
+
+extern "C" {
+
+int sbgpu_quantify_host(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgpu_hits_t *hits, const float *hit_mass,
+                        const sbgpu_insert_t *insert, int32_t read_len, int32_t long_read, double *theta_out,
+                        int32_t *status_out, int32_t *iters_out, uint32_t *compat_out, sbgpu_insert_t *insert_used,
+                        sbgpu_bins_t **bins_out)
+{
+   if (!c || !an || !hits || !theta_out || !status_out || !iters_out || !bins_out)
+      return api_fail(SBGPU_EINVAL, "sbgpu_quantify_host: null argument");
+   *bins_out = nullptr;
+   const int64_t nl = an->n_loci, nh = hits->n_hits;
+   if (nl < 1 || nh < 0) return api_fail(SBGPU_EINVAL, "sbgpu_quantify_host: bad counts");
+   if (!an->iso_off || !an->exon_off || !an->seg_off || (nh && (!hits->hit_locus || !hits->feat_off || !hit_mass)))
+      return api_fail(SBGPU_EINVAL, "sbgpu_quantify_host: null array");
+   if (!insert && !insert_used) return api_fail(SBGPU_EINVAL, "sbgpu_quantify_host: insert_used is needed when no insert-size law is given");
+   const int64_t n_iso = an->iso_off[nl], n_exon = an->exon_off[n_iso], n_seg = an->seg_off[nl];
+   const int64_t n_feat = nh ? hits->feat_off[nh] : 0;
+   int64_t max_iso = 1, max_seg = 1;
+   for (int64_t l = 0; l < nl; ++l) {
+      max_iso = std::max(max_iso, an->iso_off[l + 1] - an->iso_off[l]);
+      max_seg = std::max(max_seg, an->seg_off[l + 1] - an->seg_off[l]);
+   }
+   const int32_t cw = (int32_t)((max_iso + 31) / 32), kw = (int32_t)((max_seg + 31) / 32);
+   // hits grouped by locus?  (the device grouping needs it; the host one does not)
+   bool grouped = true;
+   std::vector<int64_t> locus_hit_off((size_t)nl + 1, 0);
+   for (int64_t h = 0; h < nh; ++h) {
+      const int32_t l = hits->hit_locus[h];
+      if (l < 0 || l >= nl) return api_fail(SBGPU_EINVAL, "sbgpu_quantify_host: hit_locus out of range");
+      if (h && l < hits->hit_locus[h - 1]) grouped = false;
+      ++locus_hit_off[(size_t)l + 1];
+   }
+   for (int64_t l = 0; l < nl; ++l) locus_hit_off[(size_t)l + 1] += locus_hit_off[(size_t)l];
+
+   hipStream_t s = sb::ctx_stream(c);
+   // ---- inputs: one arena, one copy per array
+   struct Part {
+      const void *src;
+      size_t bytes, off;
+   };
+   const size_t nh1 = (size_t)std::max<int64_t>(nh, 1);
+   Part parts[] = {
+      {an->iso_off, (size_t)(nl + 1) * 8, 0},    {an->exon_off, (size_t)(n_iso + 1) * 8, 0},
+      {an->seg_off, (size_t)(nl + 1) * 8, 0},    {hits->feat_off, nh ? (size_t)(nh + 1) * 8 : 0, 0},
+      {an->exon_left, (size_t)n_exon * 4, 0},    {an->exon_right, (size_t)n_exon * 4, 0},
+      {an->seg_left, (size_t)n_seg * 4, 0},      {an->seg_right, (size_t)n_seg * 4, 0},
+      {hits->hit_locus, (size_t)nh * 4, 0},      {hits->feat_left, (size_t)n_feat * 4, 0},
+      {hits->feat_right, (size_t)n_feat * 4, 0}, {hits->feat_code, (size_t)n_feat, 0},
+      {hit_mass, (size_t)nh * 4, 0},
+   };
+   size_t total = 0;
+   for (Part &p : parts) {
+      p.off = total;
+      total += up256(p.bytes ? p.bytes : 8);
+   }
+   const size_t o_compat = total; total += up256(nh1 * 4 * (size_t)cw);
+   const size_t o_key = total; total += up256(nh1 * 4 * (size_t)kw);
+   const size_t o_hbin = total; total += up256(nh1 * 8);
+   DeviceBuf in;
+   hipError_t e = hipMalloc(&in.p, total);
+   if (e != hipSuccess) return api_fail(e == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+#define SB_TRY(expr)                                                                                          \
+   do {                                                                                                       \
+      hipError_t e_ = (expr);                                                                                 \
+      if (e_ != hipSuccess) return api_fail(SBGPU_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+   } while (0)
+#define SB_RC(expr)                      \
+   do {                                  \
+      const int rc_ = (expr);            \
+      if (rc_ != SBGPU_OK) return rc_;   \
+   } while (0)
+   for (Part &p : parts)
+      if (p.bytes) SB_TRY(hipMemcpyAsync(in.p + p.off, p.src, p.bytes, hipMemcpyHostToDevice, s));
+   sbgpu_annotation_t dan = *an;
+   dan.iso_off = (const int64_t *)(in.p + parts[0].off);
+   dan.exon_off = (const int64_t *)(in.p + parts[1].off);
+   dan.seg_off = (const int64_t *)(in.p + parts[2].off);
+   dan.exon_left = (const uint32_t *)(in.p + parts[4].off);
+   dan.exon_right = (const uint32_t *)(in.p + parts[5].off);
+   dan.seg_left = (const uint32_t *)(in.p + parts[6].off);
+   dan.seg_right = (const uint32_t *)(in.p + parts[7].off);
+   sbgpu_hits_t dh = *hits;
+   dh.feat_off = (const int64_t *)(in.p + parts[3].off);
+   dh.hit_locus = (const int32_t *)(in.p + parts[8].off);
+   dh.feat_left = (const uint32_t *)(in.p + parts[9].off);
+   dh.feat_right = (const uint32_t *)(in.p + parts[10].off);
+   dh.feat_code = (const uint8_t *)(in.p + parts[11].off);
+   const float *d_mass = (const float *)(in.p + parts[12].off);
+   uint32_t *d_compat = (uint32_t *)(in.p + o_compat), *d_key = (uint32_t *)(in.p + o_key);
+   int64_t *d_hit_bin = (int64_t *)(in.p + o_hbin);
+
+   // ---- A5: the interval tests
+   if (nh) SB_RC(sbgpu_exonbin_device(c, &dan, &dh, cw, kw, d_compat, d_key, s));
+   std::vector<uint32_t> compat_h, key_h;
+   auto need_compat = [&]() -> int {
+      if (compat_h.empty() && nh) {
+         compat_h.resize((size_t)nh * cw);
+         SB_TRY(hipMemcpyAsync(compat_h.data(), d_compat, compat_h.size() * 4, hipMemcpyDeviceToHost, s));
+         SB_TRY(hipStreamSynchronize(s));
+      }
+      return SBGPU_OK;
+   };
+   // ---- the insert-size law: given, or the empirical one from the hits (pass 1 of the reference)
+   sbgpu_insert_t ins;
+   std::vector<double> emp_hist;
+   if (insert) {
+      ins = *insert;
+      ins.read_len = read_len;
+      ins.long_read = long_read;
+   } else {
+      SB_RC(need_compat());
+      std::vector<int32_t> fl(nh1, -1);
+      const int64_t n = sbgpu_frag_lens_host(an, hits, cw, compat_h.data(), fl.data());
+      if (n < 0) return (int)n;
+      if (n < 1) return api_fail(SBGPU_EINVAL, "sbgpu_quantify_host: no hit fits exactly one transcript: no empirical insert-size law (\"Not enough reads\")");
+      // InsertSize(const vector<int> frag_lens), src/read.cpp:238-262; mean_and_sd_insert_size :14-20
+      double sum = 0.0, sq = 0.0;
+      int32_t lo = 0x7fffffff, hi = -1;
+      for (int64_t h = 0; h < nh; ++h)
+         if (fl[(size_t)h] >= 0) {
+            sum += fl[(size_t)h];
+            lo = std::min(lo, fl[(size_t)h]);
+            hi = std::max(hi, fl[(size_t)h]);
+         }
+      for (int64_t h = 0; h < nh; ++h)
+         if (fl[(size_t)h] >= 0) sq += (double)fl[(size_t)h] * fl[(size_t)h];
+      emp_hist.assign((size_t)(hi - lo + 1), 0.0);
+      for (int64_t h = 0; h < nh; ++h)
+         if (fl[(size_t)h] >= 0) emp_hist[(size_t)(fl[(size_t)h] - lo)] += 1.0;
+      ins.mean = sum / (double)n;
+      ins.sd = std::sqrt(sq / (double)n - ins.mean * ins.mean);
+      ins.use_emp = 1;
+      ins.start_offset = lo;
+      ins.end_offset = hi;
+      ins.total_reads = (int32_t)n;
+      ins.emp_hist = emp_hist.data();
+      ins.read_len = read_len;
+      ins.long_read = long_read;
+   }
+   // ---- A5: bins (device; host when the device form declines)
+   sbgpu_bins_t *bins = nullptr;
+   int rc = SBGPU_EUNSUPPORTED;
+   if (grouped && nh) rc = sbgpu_bins_create_device(c, an, &dh, d_mass, locus_hit_off.data(), cw, kw, d_compat, d_key, d_hit_bin, s, &bins);
+   const bool on_device = rc == SBGPU_OK;
+   if (rc == SBGPU_EUNSUPPORTED) {
+      SB_RC(need_compat());
+      key_h.resize(nh1 * (size_t)kw);
+      if (nh) {
+         SB_TRY(hipMemcpyAsync(key_h.data(), d_key, (size_t)nh * kw * 4, hipMemcpyDeviceToHost, s));
+         SB_TRY(hipStreamSynchronize(s));
+      }
+      if (compat_h.empty()) compat_h.resize((size_t)cw);
+      rc = sbgpu_bins_create(an, hits, hit_mass, cw, kw, compat_h.data(), key_h.data(), &bins);
+   }
+   if (rc != SBGPU_OK) return rc;
+   struct BinsGuard {
+      sbgpu_bins_t *b;
+      ~BinsGuard() { sbgpu_bins_destroy(b); }
+   } guard = {bins};
+   int64_t info[8];
+   SB_RC(sbgpu_bins_info(bins, info));
+   const int64_t n_bins = info[2], n_elem = info[3], n_pairs = info[4], n_psegs = info[5];
+   std::vector<int64_t> row_off((size_t)nl + 1), iso_off((size_t)nl + 1), f_off((size_t)nl + 1), pair_seg_off((size_t)n_pairs + 1),
+      pair_out((size_t)n_pairs + 1);
+   std::vector<int32_t> count((size_t)n_bins + 1), pair_len((size_t)n_pairs + 1);
+   std::vector<uint32_t> pair_segs((size_t)n_psegs + 1), pair_mask((size_t)n_pairs + 1);
+   SB_RC(sbgpu_bins_export(bins, row_off.data(), iso_off.data(), f_off.data(), count.data(), nullptr, nullptr, nullptr, nullptr,
+                           pair_seg_off.data(), pair_segs.data(), pair_mask.data(), pair_len.data(), pair_out.data()));
+   // ---- A4: weights straight into the EM batch's F
+   int64_t max_l = 1;
+   if (!long_read)
+      for (int64_t p = 0; p < n_pairs; ++p) {
+         int64_t l = 0;
+         for (int64_t k = pair_seg_off[(size_t)p]; k < pair_seg_off[(size_t)p + 1]; ++k) l += pair_segs[(size_t)k];
+         if (pair_seg_off[(size_t)p + 1] == pair_seg_off[(size_t)p])
+            return api_fail(SBGPU_ESHAPE, "sbgpu_quantify_host: a bin spans more than 32 isoform segments");
+         max_l = std::max(max_l, l);
+      }
+   if (max_l > (1 << 26)) return api_fail(SBGPU_ESHAPE, "sbgpu_quantify_host: segment lengths out of range");
+   const int32_t pdf_len = (int32_t)max_l + 1;
+   std::vector<double> pdf((size_t)pdf_len);
+   SB_RC(sbgpu_insert_pdf_table(&ins, pdf_len, pdf.data()));
+   const size_t np1 = (size_t)std::max<int64_t>(n_pairs, 1), ne1 = (size_t)std::max<int64_t>(n_elem, 1), nb1 = (size_t)std::max<int64_t>(n_bins, 1);
+   size_t t2 = 0;
+   const size_t q_off = t2; t2 += up256((np1 + 1) * 8);
+   const size_t q_idx = t2; t2 += up256(np1 * 8);
+   const size_t q_seg = t2; t2 += up256((size_t)(n_psegs + 1) * 4);
+   const size_t q_mask = t2; t2 += up256(np1 * 4);
+   const size_t q_len = t2; t2 += up256(np1 * 4);
+   const size_t q_pdf = t2; t2 += up256((size_t)pdf_len * 8);
+   const size_t q_cnt = t2; t2 += up256(nb1 * 4);
+   const size_t q_F = t2; t2 += up256(ne1 * 8);
+   const size_t q_theta = t2; t2 += up256((size_t)(n_iso + 1) * 8);
+   const size_t q_st = t2; t2 += up256((size_t)(nl + 1) * 4);
+   const size_t q_it = t2; t2 += up256((size_t)(nl + 1) * 4);
+   DeviceBuf w;
+   e = hipMalloc(&w.p, t2);
+   if (e != hipSuccess) return api_fail(e == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+   SB_TRY(hipMemsetAsync(w.p + q_F, 0, ne1 * 8, s));
+   if (n_pairs) {
+      SB_TRY(hipMemcpyAsync(w.p + q_off, pair_seg_off.data(), (size_t)(n_pairs + 1) * 8, hipMemcpyHostToDevice, s));
+      SB_TRY(hipMemcpyAsync(w.p + q_idx, pair_out.data(), (size_t)n_pairs * 8, hipMemcpyHostToDevice, s));
+      if (n_psegs) SB_TRY(hipMemcpyAsync(w.p + q_seg, pair_segs.data(), (size_t)n_psegs * 4, hipMemcpyHostToDevice, s));
+      SB_TRY(hipMemcpyAsync(w.p + q_mask, pair_mask.data(), (size_t)n_pairs * 4, hipMemcpyHostToDevice, s));
+      SB_TRY(hipMemcpyAsync(w.p + q_len, pair_len.data(), (size_t)n_pairs * 4, hipMemcpyHostToDevice, s));
+      SB_TRY(hipMemcpyAsync(w.p + q_pdf, pdf.data(), (size_t)pdf_len * 8, hipMemcpyHostToDevice, s));
+      const int32_t lmin_base = ins.use_emp ? ins.start_offset : ins.read_len;
+      SB_RC(sbgpu_binweight_device(c, n_pairs, (const int64_t *)(w.p + q_off), (const uint32_t *)(w.p + q_seg),
+                                   (const uint32_t *)(w.p + q_mask), (const int32_t *)(w.p + q_len), (const int64_t *)(w.p + q_idx),
+                                   (const double *)(w.p + q_pdf), pdf_len, ins.read_len, lmin_base, ins.long_read,
+                                   (double *)(w.p + q_F), s));
+   }
+   // ---- A1/A2: the EM
+   if (n_bins) SB_TRY(hipMemcpyAsync(w.p + q_cnt, count.data(), (size_t)n_bins * 4, hipMemcpyHostToDevice, s));
+   sbgpu_plan_t *plan = nullptr;
+   SB_RC(sbgpu_plan_create(c, nl, row_off.data(), iso_off.data(), f_off.data(), &plan));
+   rc = sbgpu_em_run_device(c, plan, (const int32_t *)(w.p + q_cnt), (const double *)(w.p + q_F), (double *)(w.p + q_theta),
+                            (int32_t *)(w.p + q_st), (int32_t *)(w.p + q_it), s);
+   if (rc != SBGPU_OK) {
+      sbgpu_plan_destroy(plan);
+      return rc;
+   }
+   std::vector<double> F((size_t)n_elem);
+   std::vector<int64_t> hit_bin;
+   hipError_t e1 = hipMemcpyAsync(theta_out, w.p + q_theta, (size_t)n_iso * 8, hipMemcpyDeviceToHost, s);
+   hipError_t e2 = hipMemcpyAsync(status_out, w.p + q_st, (size_t)nl * 4, hipMemcpyDeviceToHost, s);
+   hipError_t e3 = hipMemcpyAsync(iters_out, w.p + q_it, (size_t)nl * 4, hipMemcpyDeviceToHost, s);
+   hipError_t e4 = n_elem ? hipMemcpyAsync(F.data(), w.p + q_F, (size_t)n_elem * 8, hipMemcpyDeviceToHost, s) : hipSuccess;
+   hipError_t e5 = hipSuccess;
+   if (on_device && nh) {
+      hit_bin.resize((size_t)nh);
+      e5 = hipMemcpyAsync(hit_bin.data(), d_hit_bin, (size_t)nh * 8, hipMemcpyDeviceToHost, s);
+   }
+   hipError_t e6 = hipStreamSynchronize(s);
+   sbgpu_plan_destroy(plan);
+   for (hipError_t x : {e1, e2, e3, e4, e5, e6})
+      if (x != hipSuccess) return api_fail(SBGPU_EHIP, std::string("sbgpu_quantify_host: download: ") + hipGetErrorString(x));
+   if (compat_out) {
+      SB_RC(need_compat());
+      if (nh) std::memcpy(compat_out, compat_h.data(), (size_t)nh * cw * 4);
+   }
+   if (on_device && nh) sb::bins_set_hit_bin(bins, std::move(hit_bin));
+   if (insert_used) {
+      *insert_used = ins;
+      if (!insert) {
+         // the histogram lives on with the handle: behind the weights
+         const size_t at = F.size();
+         F.insert(F.end(), emp_hist.begin(), emp_hist.end());
+         sb::bins_set_weights(bins, std::move(F));
+         insert_used->emp_hist = sb::bins_weights_tail(bins, at);
+      } else {
+         sb::bins_set_weights(bins, std::move(F));
+      }
+   } else {
+      sb::bins_set_weights(bins, std::move(F));
+   }
+#undef SB_TRY
+#undef SB_RC
+   guard.b = nullptr;
+   *bins_out = bins;
+   return SBGPU_OK;
+}
+
+} // extern "C"

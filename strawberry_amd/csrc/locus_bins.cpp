@@ -40,6 +40,7 @@ struct sbgpu_bins {
    std::vector<int64_t> pair_seg_off, pair_out_index;
    std::vector<uint32_t> pair_seg_lens, pair_mask;
    std::vector<int32_t> pair_iso_len;
+   std::vector<double> F; // the EM batch's weights, when the handle comes from sbgpu_quantify_host
 };
 
 namespace {
@@ -531,6 +532,9 @@ int bins_create_impl(const sbgpu_annotation_t *an, const sbgpu_hits_t *hits, con
 } // namespace
 
 namespace sb {
+void bins_set_weights(sbgpu_bins_t *b, std::vector<double> &&F) { b->F = std::move(F); }
+void bins_set_hit_bin(sbgpu_bins_t *b, std::vector<int64_t> &&hb) { b->hit_bin = std::move(hb); }
+const double *bins_weights_tail(const sbgpu_bins_t *b, size_t at) { return b->F.data() + at; }
 int bins_from_groups(const sbgpu_annotation_t *an, int32_t compat_words, int32_t key_words, const int64_t *row_off,
                      const int32_t *count, const uint32_t *key, const uint32_t *compat, int64_t n_hits_used, sbgpu_bins_t **out)
 {
@@ -549,6 +553,15 @@ int sbgpu_bins_create(const sbgpu_annotation_t *an, const sbgpu_hits_t *hits, co
 }
 
 void sbgpu_bins_destroy(sbgpu_bins_t *b) { delete b; }
+
+int sbgpu_bins_export_weights(const sbgpu_bins_t *b, double *F_out)
+{
+   if (!b || !F_out) return api_fail(SBGPU_EINVAL, "sbgpu_bins_export_weights: null argument");
+   if ((int64_t)b->F.size() < b->n_elem || (b->F.empty() && b->n_elem == 0 && b->n_bins > 0))
+      return api_fail(SBGPU_EINVAL, "sbgpu_bins_export_weights: this handle holds no weights");
+   if (b->n_elem) std::memcpy(F_out, b->F.data(), (size_t)b->n_elem * sizeof(double));
+   return SBGPU_OK;
+}
 
 int sbgpu_bins_info(const sbgpu_bins_t *b, int64_t info[8])
 {

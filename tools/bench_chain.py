@@ -62,10 +62,29 @@ def main():
     stages["bin_weights (upload pairs + A4 kernel)"], _ = timed(q.bin_weights)
     stages["solve (plan + EM + epilogue + D2H)"], res = timed(lambda: q.solve(hits.n_hits, min_isoform_frac=0.0))
     total = sum(stages.values())
+    # the same chain as ONE C-ABI call with host buffers in and out (what a C/C++ driver uses)
+    import ctypes as C
+    from strawberry_amd import _lib
+    an, ht = annot._struct(), hits._struct()
+    ins = InsertSize(250.0, 30.0)._struct(75)
+    n_iso = int(annot.iso_off[-1])
+    theta = np.zeros(n_iso + 1); status = np.zeros(annot.n_loci + 1, np.int32); iters = np.zeros(annot.n_loci + 1, np.int32)
+    used = _lib.sbgpu_insert_t()
+
+    def one_call():
+        h = C.c_void_p()
+        _lib.check(ctx.L.sbgpu_quantify_host(ctx.h, C.byref(an), C.byref(ht), hits.mass.ctypes.data, C.byref(ins), 75, 0,
+                                             theta.ctypes.data, status.ctypes.data, iters.ctypes.data, None, C.byref(used),
+                                             C.byref(h)), "sbgpu_quantify_host")
+        ctx.L.sbgpu_bins_destroy(h)
+    one_call()
+    one_ms = min(timed(one_call)[0] for _ in range(3))
+    assert np.allclose(theta[:n_iso], res["theta"], rtol=1e-12, atol=1e-12)
     print(json.dumps({
         "metric": "fragments/s, fragments -> abundances chain", "value": hits.n_hits / total * 1e3, "unit": "fragments/s",
         "hits": hits.n_hits, "loci": annot.n_loci, "bins": int(bins.n_bins), "pairs": int(bins.n_pairs),
-        "stage_ms": stages, "total_ms": total, "assign_bins_ms_with_host_grouping_by_threads": host, "host_cores": os.cpu_count(),
+        "stage_ms": stages, "total_ms": total, "sbgpu_quantify_host_ms": one_ms,
+        "sbgpu_quantify_host_fragments_per_s": hits.n_hits / one_ms * 1e3, "assign_bins_ms_with_host_grouping_by_threads": host, "host_cores": os.cpu_count(),
         "em_mean_iters": float(res["iters"].mean())}))
 
 
