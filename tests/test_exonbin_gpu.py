@@ -185,6 +185,73 @@ def test_device_grouping_equals_host_grouping(ctx, oracle):
     assert (naive != bh.count).sum() > 50
 
 
+def group_both_ways(ctx, annot, hits, compat, key):
+    """(device bins or None, host bins) for arbitrary word arrays (they need not come from the kernel)."""
+    import ctypes as C
+    import torch
+    from strawberry_amd import exonbin as eb
+    dev = torch.device("cuda", ctx.device)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    d = {k: up(getattr(hits, k).view(np.int32) if getattr(hits, k).dtype == np.uint32 else getattr(hits, k))
+         for k in ("hit_locus", "feat_off", "feat_code", "feat_left", "feat_right")}
+    d_mass, d_compat, d_key = up(hits.mass), up(compat.view(np.int32)), up(key.view(np.int32))
+    d_hit_bin = torch.zeros(hits.n_hits, dtype=torch.int64, device=dev)
+    from strawberry_amd import _lib
+    ht = _lib.sbgpu_hits_t(hits.n_hits, d["hit_locus"].data_ptr(), d["feat_off"].data_ptr(), d["feat_code"].data_ptr(),
+                           d["feat_left"].data_ptr(), d["feat_right"].data_ptr())
+    bd = eb.LocusBins.on_device(ctx, annot, hits, ht, d_mass.data_ptr(), compat.shape[1], key.shape[1], d_compat.data_ptr(),
+                                d_key.data_ptr(), d_hit_bin.data_ptr(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if bd is not None:
+        bd.hit_bin = d_hit_bin.cpu().numpy()
+    return bd, eb.LocusBins(annot, hits, compat, key)
+
+
+def test_device_grouping_multiword_keys_and_table_limit(ctx):
+    """Keys of several words (loci with more than 32 segments), compat of several words, many small loci in
+    one call -- and a locus with more bins than the LDS table holds, which the device form must decline."""
+    from strawberry_amd import exonbin as eb
+    rng = np.random.default_rng(77)
+    # 30 loci of 71 isoforms that all hold the same 130 exons (= 130 segments): any set of segments is under any
+    # isoform, so arbitrary key / compat words are consistent input.  3 compat words, 5 key words.
+    loci = [[[(1000 * (l + 1) * 200 + 100 * k, 1000 * (l + 1) * 200 + 100 * k + 49) for k in range(130)]] * 71 for l in range(30)]
+    annot = eb.Annotation(loci)
+    assert annot.compat_words == 3 and annot.key_words == 5
+    def make(n_keys_per_locus, n_hits_per_locus, n_loci=30):
+        loc, feats, masses, compat, key = [], [], [], [], []
+        for l in range(n_loci):
+            base = 1000 * (l + 1) * 200
+            keys = rng.integers(1, 2 ** 32, (n_keys_per_locus, 5), dtype=np.uint64).astype(np.uint32)
+            keys[:, 4] &= 3                      # 130 segments: two bits in the last word
+            comps = rng.integers(0, 2 ** 32, (n_keys_per_locus, 3), dtype=np.uint64).astype(np.uint32)
+            comps[:, 2] &= (1 << 7) - 1          # 71 isoforms
+            pick = np.sort(rng.integers(0, n_keys_per_locus, n_hits_per_locus))
+            lefts = np.sort(rng.integers(base, base + 12000, n_hits_per_locus))
+            for q in range(n_hits_per_locus):
+                loc.append(l)
+                feats.append(([0], [int(lefts[q])], [int(lefts[q]) + 74]))
+                masses.append(float(rng.integers(1, 4)))
+                key.append(keys[pick[q]])
+                c = comps[pick[q]].copy()
+                if rng.random() < 0.1:
+                    c[:] = 0                      # a hit without a compatible isoform
+                compat.append(c)
+        return eb.Hits(loc, feats, mass=masses), np.array(compat, np.uint32), np.array(key, np.uint32)
+    hits, compat, key = make(40, 400)
+    bd, bh = group_both_ways(ctx, annot, hits, compat, key)
+    assert bd is not None and bh.n_bins > 1000
+    for x, y in zip(bins_arrays_no_pairs(bd), bins_arrays_no_pairs(bh)):
+        np.testing.assert_array_equal(x, y)
+    # ~5000 different keys in one locus: more than the table holds -> declined, the host form does it
+    hits, compat, key = make(6000, 14000, n_loci=1)
+    annot1 = eb.Annotation(loci[:1])
+    bd, bh = group_both_ways(ctx, annot1, hits, compat, key)
+    assert bd is None and bh.n_bins > 2800
+
+
+def bins_arrays_no_pairs(b):
+    return [b.row_off, b.f_off, b.count, b.bin_key, b.bin_compat, np.asarray(b.hit_bin)]
+
+
 def test_device_grouping_declines_what_it_cannot_do_exactly(ctx):
     from strawberry_amd import exonbin as eb
     from strawberry_amd import synth
