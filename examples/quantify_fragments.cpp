@@ -17,7 +17,8 @@
 //       iso <transcript_id> <n_exons> <left> <right> ...          (the reference's isoform order)
 //   pairs <P>
 //     pair <locus> <mass> <n_left_blocks> <l> <r> ... <n_right_blocks> <l> <r> ...
-//         (aligned blocks of each mate; mass = the pair's collapse mass, alignments.cpp:683-696)
+//         (every sequenced read pair, in any order: aligned blocks of each mate; mass = the pair's raw
+//          mass, 1 / NH -- duplicates are collapsed by the library like the reference does)
 #include <algorithm>
 #include <cstdio>
 #include <fstream>
@@ -107,26 +108,30 @@ int main(int argc, char **argv)
       std::fprintf(stderr, "malformed input\n");
       return 2;
    }
-   // HitCluster::collapseAndFilterHits: hits sorted by (left end, right end) of the pair
-   // (src/alignments.cpp:660, src/read.cpp:917-923); stable here, the input holds no ties
-   std::stable_sort(pairs.begin(), pairs.end(), [](const Pair &a, const Pair &b) {
-      if (a.locus != b.locus) return a.locus < b.locus;
-      const uint32_t al = a.left.front().first, bl = b.left.front().first;
-      if (al != bl) return al < bl;
-      return (a.right.empty() ? a.left : a.right).back().second < (b.right.empty() ? b.left : b.right).back().second;
-   });
-   // _total_mapped_reads += (int) cluster->weighted_mass(), src/alignments.cpp:1372
-   std::vector<double> cluster_mass((size_t)L, 0.0);
+   // every sequenced copy goes in as it is; the library does HitCluster::collapseAndFilterHits
+   // (sort by the pair's ends, span filter, collapse of equal pairs) and Contig(PairedHit)
+   std::vector<int32_t> p_locus;
+   std::vector<double> p_mass;
+   std::vector<int64_t> lo{0}, ro{0};
+   std::vector<uint8_t> lc, rc;
+   std::vector<uint32_t> ll, lr, rl, rr;
    for (const Pair &p : pairs) {
-      cluster_mass[(size_t)p.locus] += p.mass;
-      std::vector<uint8_t> lc, rc;
-      std::vector<uint32_t> ll, lr, rl, rr;
+      p_locus.push_back(p.locus);
+      p_mass.push_back(p.mass);
       mate_features(p.left, lc, ll, lr);
       mate_features(p.right, rc, rl, rr);
-      batch.add_pair(p.locus, lc, ll, lr, rc, rl, rr, (float)p.mass); // Contig::mass() is a float
+      lo.push_back((int64_t)lc.size());
+      ro.push_back((int64_t)rc.size());
    }
+   const sbgpu_pairs_t raw = {(int64_t)pairs.size(), p_locus.data(), p_mass.data(), lo.data(), lc.data(), ll.data(), lr.data(),
+                              ro.data(), rc.data(), rl.data(), rr.data()};
    int total_mapped = 0;
-   for (double m : cluster_mass) total_mapped += (int)m;
+   try {
+      total_mapped = batch.set_hits_from_pairs(raw);
+   } catch (const std::exception &e) {
+      std::fprintf(stderr, "error: %s\n", e.what());
+      return 1;
+   }
 
    try {
       sbgpu::Context ctx(0);

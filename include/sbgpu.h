@@ -294,6 +294,44 @@ int sbgpu_hit_features(int n_left, const uint8_t *lcode, const uint32_t *lleft, 
 int64_t sbgpu_frag_lens_host(const sbgpu_annotation_t *annot, const sbgpu_hits_t *hits,
                              int32_t compat_words, const uint32_t *compat, int32_t *frag_len_out);
 
+/* ---- from aligned read pairs to unique hits (host code) ----------------------
+ * HitCluster::collapseAndFilterHits (src/alignments.cpp:656-703) followed by Contig(PairedHit) for
+ * every unique hit, for the clusters (loci) of a batch:
+ *   - pairs of a locus are ordered by (left end, right end) of the pair (src/read.cpp:917-923); the
+ *     reference uses std::sort there, ties keep their input order here;
+ *   - a pair one of whose mates spans more than mean + 15.45 sd of the locus' mate spans is skipped
+ *     (phi((len - mean) / (5 sd)) > 0.999, :667-682; spans of all mates, population sd, common.h:100-110);
+ *   - the others add their raw mass to the cluster's mass (:683-684) and are collapsed with the
+ *     previous unique hit when both mates are equal -- same start, same CIGAR (:685-697,
+ *     src/read.cpp:196-207,897-910) -- summing the masses in double;
+ *   - every unique hit becomes features through sbgpu_hit_features; a rejected one (0 features) is
+ *     dropped, its mass stays in the cluster's mass.
+ * A mate is its MATCH / INTRON features (readhit_2_genomicFeats); a missing mate has no features.
+ * pair_mass[p] is the pair's raw mass: 0.5 / NH per mate of a proper pair, 1 / NH for a singleton
+ * (src/read.cpp:49-53,116-123).                                                                  */
+typedef struct {
+   int64_t n_pairs;
+   const int32_t *pair_locus;  /* [n_pairs]                                  */
+   const double *pair_mass;    /* [n_pairs]                                  */
+   const int64_t *left_off;    /* [n_pairs + 1] into the left mates' features  */
+   const uint8_t *left_code;
+   const uint32_t *left_left, *left_right;
+   const int64_t *right_off;   /* [n_pairs + 1] into the right mates' features */
+   const uint8_t *right_code;
+   const uint32_t *right_left, *right_right;
+} sbgpu_pairs_t;
+typedef struct sbgpu_uniq sbgpu_uniq_t;
+int sbgpu_collapse_pairs_host(int64_t n_loci, const sbgpu_pairs_t *pairs, sbgpu_uniq_t **out);
+void sbgpu_uniq_destroy(sbgpu_uniq_t *u);
+/* info: 0 unique hits kept, 1 their features, 2 pairs skipped by the span filter, 3 unique hits
+ * rejected by Contig(PairedHit), 4 total mapped reads = sum over loci of (int) cluster mass
+ * (src/alignments.cpp:1372).                                                                 */
+int sbgpu_uniq_info(const sbgpu_uniq_t *u, int64_t info[8]);
+/* The unique hits as an sbgpu_hits_t's arrays (+ hit_mass = (float) collapse mass, cluster_mass
+ * [n_loci] in double); NULL = skip.                                                           */
+int sbgpu_uniq_export(const sbgpu_uniq_t *u, int32_t *hit_locus, int64_t *feat_off, uint8_t *feat_code,
+                      uint32_t *feat_left, uint32_t *feat_right, float *hit_mass, double *cluster_mass);
+
 /* LocusContext::assign_exon_bin + set_maps (src/estimate.cpp:135-198, estimate.hpp:29-52)
  * on the kernel's results (host copies of compat / key), hits visited in input order inside
  * each locus (= HitCluster::uniq_hits() order):

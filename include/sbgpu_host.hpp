@@ -221,6 +221,28 @@ public:
       return true;
    }
 
+   /* All aligned read pairs of the batch at once: HitCluster::collapseAndFilterHits + Contig(PairedHit)
+    * (sbgpu_collapse_pairs_host).  Replaces the hits added so far; returns the reference's
+    * _total_mapped_reads (sum over loci of the int-truncated cluster mass, src/alignments.cpp:1372).   */
+   int set_hits_from_pairs(const sbgpu_pairs_t &pairs)
+   {
+      sbgpu_uniq_t *u = nullptr;
+      check(sbgpu_collapse_pairs_host(n_loci(), &pairs, &u), "sbgpu_collapse_pairs_host");
+      int64_t info[8];
+      sbgpu_uniq_info(u, info);
+      hit_locus.assign((size_t)info[0], 0);
+      feat_off.assign((size_t)info[0] + 1, 0);
+      feat_code.assign((size_t)info[1], 0);
+      feat_left.assign((size_t)info[1], 0);
+      feat_right.assign((size_t)info[1], 0);
+      hit_mass.assign((size_t)info[0], 0.0f);
+      const int rc = sbgpu_uniq_export(u, hit_locus.data(), feat_off.data(), feat_code.data(), feat_left.data(), feat_right.data(),
+                                       hit_mass.data(), nullptr);
+      sbgpu_uniq_destroy(u);
+      check(rc, "sbgpu_uniq_export");
+      return (int)info[4];
+   }
+
    sbgpu_annotation_t annotation() const
    {
       sbgpu_annotation_t a = {n_loci(), iso_off.data(), exon_off.data(), exon_left.data(), exon_right.data(),

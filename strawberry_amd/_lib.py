@@ -22,7 +22,7 @@ SYMBOLS = [
     "sbgpu_insert_pdf_table", "sbgpu_binweight_device", "sbgpu_binweight_host",
     "sbgpu_exonbin_device", "sbgpu_exonbin_host", "sbgpu_segments_host", "sbgpu_hit_features", "sbgpu_frag_lens_host",
     "sbgpu_bins_create", "sbgpu_bins_create_device", "sbgpu_bins_destroy", "sbgpu_quantify_host",
-    "sbgpu_bins_export_weights", "sbgpu_bins_info", "sbgpu_bins_export",
+    "sbgpu_bins_export_weights", "sbgpu_collapse_pairs_host", "sbgpu_uniq_destroy", "sbgpu_uniq_info", "sbgpu_uniq_export", "sbgpu_bins_info", "sbgpu_bins_export",
     "sbgpu_format_value", "sbgpu_format_gtf_transcript", "sbgpu_format_context_row", "sbgpu_em_batch", "sbgpu_abundance_device", "sbgpu_tpm_device",
 ]
 
@@ -78,6 +78,12 @@ class sbgpu_annotation_t(C.Structure):
         ("seg_left", C.c_void_p),
         ("seg_right", C.c_void_p),
     ]
+
+
+class sbgpu_pairs_t(C.Structure):
+    _fields_ = [(n, C.c_int64 if n == "n_pairs" else C.c_void_p) for n in (
+        "n_pairs", "pair_locus", "pair_mass", "left_off", "left_code", "left_left", "left_right", "right_off", "right_code",
+        "right_left", "right_right")]
 
 
 class sbgpu_hits_t(C.Structure):
@@ -154,6 +160,11 @@ def load():
     L.sbgpu_quantify_host.argtypes = [vp, C.POINTER(sbgpu_annotation_t), C.POINTER(sbgpu_hits_t), vp, C.POINTER(sbgpu_insert_t),
                                       C.c_int32, C.c_int32, vp, vp, vp, vp, C.POINTER(sbgpu_insert_t), C.POINTER(vp)]
     L.sbgpu_bins_export_weights.argtypes = [vp, vp]
+    L.sbgpu_collapse_pairs_host.argtypes = [C.c_int64, C.POINTER(sbgpu_pairs_t), C.POINTER(vp)]
+    L.sbgpu_uniq_destroy.argtypes = [vp]
+    L.sbgpu_uniq_destroy.restype = None
+    L.sbgpu_uniq_info.argtypes = [vp, i64p]
+    L.sbgpu_uniq_export.argtypes = [vp] * 8
     L.sbgpu_bins_destroy.argtypes = [vp]
     L.sbgpu_bins_destroy.restype = None
     L.sbgpu_bins_info.argtypes = [vp, i64p]

@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <thread>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -598,6 +599,197 @@ int sbgpu_bins_export(const sbgpu_bins_t *b, int64_t *row_off, int64_t *iso_off,
    SB_COPY(pair_implicit_mask, b->pair_mask);
    SB_COPY(pair_iso_len, b->pair_iso_len);
    SB_COPY(pair_out_index, b->pair_out_index);
+#undef SB_COPY
+   return SBGPU_OK;
+}
+
+// ---------------------------------------------------------------- pairs -> unique hits
+} // extern "C"
+
+struct sbgpu_uniq {
+   int64_t n_loci = 0, n_filtered = 0, n_rejected = 0, total_mapped = 0;
+   std::vector<int32_t> hit_locus;
+   std::vector<int64_t> feat_off{0};
+   std::vector<uint8_t> feat_code;
+   std::vector<uint32_t> feat_left, feat_right;
+   std::vector<float> hit_mass;
+   std::vector<double> cluster_mass;
+};
+
+namespace {
+// include/common.h:112-134
+double ref_phi(double x)
+{
+   const double a1 = 0.254829592, a2 = -0.284496736, a3 = 1.421413741, a4 = -1.453152027, a5 = 1.061405429, p = 0.3275911;
+   int sign = 1;
+   if (x < 0) sign = -1;
+   x = std::fabs(x) / std::sqrt(2.0);
+   const double t = 1.0 / (1.0 + p * x);
+   const double y = 1.0 - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * std::exp(-x * x);
+   return 0.5 * (1.0 + sign * y);
+}
+} // namespace
+
+extern "C" {
+
+int sbgpu_collapse_pairs_host(int64_t n_loci, const sbgpu_pairs_t *pr, sbgpu_uniq_t **out)
+{
+   if (!pr || !out || n_loci < 0) return api_fail(SBGPU_EINVAL, "sbgpu_collapse_pairs_host: bad argument");
+   *out = nullptr;
+   const int64_t np = pr->n_pairs;
+   if (np < 0 || (np && (!pr->pair_locus || !pr->pair_mass || !pr->left_off || !pr->right_off)))
+      return api_fail(SBGPU_EINVAL, "sbgpu_collapse_pairs_host: null array");
+   sbgpu_uniq *U = new (std::nothrow) sbgpu_uniq();
+   if (!U) return api_fail(SBGPU_ENOMEM, "sbgpu_collapse_pairs_host: out of memory");
+   try {
+      U->n_loci = n_loci;
+      U->cluster_mass.assign((size_t)n_loci, 0.0);
+      // pairs of each locus, input order
+      std::vector<int64_t> start((size_t)n_loci + 1, 0), order((size_t)np);
+      for (int64_t p = 0; p < np; ++p) {
+         if (pr->pair_locus[p] < 0 || pr->pair_locus[p] >= n_loci) {
+            delete U;
+            return api_fail(SBGPU_EINVAL, "sbgpu_collapse_pairs_host: pair_locus out of range");
+         }
+         if (pr->left_off[p + 1] == pr->left_off[p] && pr->right_off[p + 1] == pr->right_off[p]) {
+            delete U;
+            return api_fail(SBGPU_EINVAL, "sbgpu_collapse_pairs_host: a pair without mates");
+         }
+         ++start[(size_t)pr->pair_locus[p] + 1];
+      }
+      for (int64_t l = 0; l < n_loci; ++l) start[(size_t)l + 1] += start[(size_t)l];
+      {
+         std::vector<int64_t> fill(start.begin(), start.end() - 1);
+         for (int64_t p = 0; p < np; ++p) order[(size_t)fill[(size_t)pr->pair_locus[p]]++] = p;
+      }
+      struct Mate {
+         const uint8_t *c;
+         const uint32_t *l, *r;
+         int64_t n;
+      };
+      auto left_mate = [&](int64_t p) { const int64_t o = pr->left_off[p]; return Mate{pr->left_code + o, pr->left_left + o, pr->left_right + o, pr->left_off[p + 1] - o}; };
+      auto right_mate = [&](int64_t p) { const int64_t o = pr->right_off[p]; return Mate{pr->right_code + o, pr->right_left + o, pr->right_right + o, pr->right_off[p + 1] - o}; };
+      auto mate_equal = [](const Mate &a, const Mate &b) { // ReadHit::operator==: same start, same CIGAR
+         if (a.n != b.n) return false;
+         for (int64_t i = 0; i < a.n; ++i)
+            if (a.c[i] != b.c[i] || a.l[i] != b.l[i] || a.r[i] != b.r[i]) return false;
+         return true;
+      };
+      auto left_pos = [&](int64_t p) { // PairedHit::left_pos / right_pos, src/read.cpp:797-819
+         const Mate a = left_mate(p), b = right_mate(p);
+         if (a.n && b.n) return std::min(a.l[0], b.l[0]);
+         return a.n ? a.l[0] : b.l[0];
+      };
+      auto right_pos = [&](int64_t p) {
+         const Mate a = left_mate(p), b = right_mate(p);
+         if (a.n && b.n) return std::max(a.r[a.n - 1], b.r[b.n - 1]);
+         return b.n ? b.r[b.n - 1] : a.r[a.n - 1];
+      };
+      std::vector<uint8_t> oc;
+      std::vector<uint32_t> ol, orr;
+      for (int64_t l = 0; l < n_loci; ++l) {
+         int64_t *q0 = order.data() + start[(size_t)l], *q1 = order.data() + start[(size_t)l + 1];
+         if (q0 == q1) continue;
+         // spans of all mates of the cluster (HitCluster::_read_ref_span), getMeanAndSd (common.h:100-110)
+         double sum = 0.0;
+         int64_t n_mates = 0;
+         for (int64_t *q = q0; q < q1; ++q)
+            for (const Mate &m : {left_mate(*q), right_mate(*q)})
+               if (m.n) {
+                  sum += (double)(int)(m.r[m.n - 1] - m.l[0] + 1);
+                  ++n_mates;
+               }
+         const double mean = sum / (double)n_mates;
+         double sq = 0.0;
+         for (int64_t *q = q0; q < q1; ++q)
+            for (const Mate &m : {left_mate(*q), right_mate(*q)})
+               if (m.n) {
+                  const double d = (double)(int)(m.r[m.n - 1] - m.l[0] + 1) - mean;
+                  sq += d * d;
+               }
+         const double sd = std::sqrt(sq / (double)n_mates) * 5;
+         std::stable_sort(q0, q1, [&](int64_t x, int64_t y) {
+            const uint32_t lx = left_pos(x), ly = left_pos(y);
+            return lx != ly ? lx < ly : right_pos(x) < right_pos(y);
+         });
+         int64_t last = -1; // the pair the latest unique hit was made of
+         double mass = 0.0;
+         auto flush = [&]() {
+            if (last < 0) return;
+            const Mate a = left_mate(last), b = right_mate(last);
+            oc.resize((size_t)(a.n + b.n + 1));
+            ol.resize(oc.size());
+            orr.resize(oc.size());
+            const int n = sbgpu_hit_features((int)a.n, a.c, a.l, a.r, (int)b.n, b.c, b.l, b.r, oc.data(), ol.data(), orr.data());
+            if (n <= 0) {
+               ++U->n_rejected;
+               return;
+            }
+            U->hit_locus.push_back((int32_t)l);
+            U->feat_code.insert(U->feat_code.end(), oc.begin(), oc.begin() + n);
+            U->feat_left.insert(U->feat_left.end(), ol.begin(), ol.begin() + n);
+            U->feat_right.insert(U->feat_right.end(), orr.begin(), orr.begin() + n);
+            U->feat_off.push_back((int64_t)U->feat_code.size());
+            U->hit_mass.push_back((float)mass); // Contig::mass() returns float
+         };
+         for (int64_t *q = q0; q < q1; ++q) {
+            const Mate a = left_mate(*q), b = right_mate(*q);
+            bool skip = false;
+            for (const Mate &m : {a, b})
+               if (m.n && ref_phi(((double)(uint32_t)(m.r[m.n - 1] - m.l[0] + 1) - mean) / sd) > 0.999) skip = true;
+            if (skip) {
+               ++U->n_filtered;
+               continue;
+            }
+            U->cluster_mass[(size_t)l] += pr->pair_mass[*q];
+            const bool same = last >= 0 && mate_equal(left_mate(last), a) && mate_equal(right_mate(last), b);
+            if (same) {
+               mass += pr->pair_mass[*q];
+            } else {
+               flush();
+               last = *q;
+               mass = pr->pair_mass[*q];
+            }
+         }
+         flush();
+         U->total_mapped += (int64_t)(int)U->cluster_mass[(size_t)l];
+      }
+   } catch (const std::bad_alloc &) {
+      delete U;
+      return api_fail(SBGPU_ENOMEM, "sbgpu_collapse_pairs_host: out of memory");
+   }
+   *out = U;
+   return SBGPU_OK;
+}
+
+void sbgpu_uniq_destroy(sbgpu_uniq_t *u) { delete u; }
+
+int sbgpu_uniq_info(const sbgpu_uniq_t *u, int64_t info[8])
+{
+   if (!u || !info) return api_fail(SBGPU_EINVAL, "sbgpu_uniq_info: null argument");
+   info[0] = (int64_t)u->hit_locus.size();
+   info[1] = (int64_t)u->feat_code.size();
+   info[2] = u->n_filtered;
+   info[3] = u->n_rejected;
+   info[4] = u->total_mapped;
+   info[5] = u->n_loci;
+   info[6] = info[7] = 0;
+   return SBGPU_OK;
+}
+
+int sbgpu_uniq_export(const sbgpu_uniq_t *u, int32_t *hit_locus, int64_t *feat_off, uint8_t *feat_code, uint32_t *feat_left,
+                      uint32_t *feat_right, float *hit_mass, double *cluster_mass)
+{
+   if (!u) return api_fail(SBGPU_EINVAL, "sbgpu_uniq_export: null argument");
+#define SB_COPY(dst, vec)                                                              \
+   if (dst && !(vec).empty()) std::memcpy(dst, (vec).data(), (vec).size() * sizeof((vec)[0]))
+   SB_COPY(hit_locus, u->hit_locus);
+   SB_COPY(feat_off, u->feat_off);
+   SB_COPY(feat_code, u->feat_code);
+   SB_COPY(feat_left, u->feat_left);
+   SB_COPY(feat_right, u->feat_right);
+   SB_COPY(hit_mass, u->hit_mass);
+   SB_COPY(cluster_mass, u->cluster_mass);
 #undef SB_COPY
    return SBGPU_OK;
 }

@@ -96,6 +96,44 @@ def hit_features(left_blocks, right_blocks):
     return oc[:n].tolist(), ol[:n].tolist(), orr[:n].tolist()
 
 
+def collapse_pairs(n_loci, pair_locus, pair_mass, left_blocks, right_blocks):
+    """Aligned read pairs -> unique hits: HitCluster::collapseAndFilterHits + Contig(PairedHit)
+    (sbgpu_collapse_pairs_host).  left_blocks / right_blocks: per pair the mate's aligned blocks [(l, r), ...]
+    ([] for a missing mate); pair_mass: the pair's raw mass.  -> (Hits, cluster_mass[n_loci], info dict)"""
+    L = _lib.load()
+    def csr(blocks_list):
+        off, c, l, r = [0], [], [], []
+        for b in blocks_list:
+            cc, ll, rr = mate_features(b)
+            c += cc
+            l += ll
+            r += rr
+            off.append(len(c))
+        return (np.asarray(off, np.int64), np.asarray(c, np.uint8), np.asarray(l, np.uint32), np.asarray(r, np.uint32))
+    lo, lc, ll, lr = csr(left_blocks)
+    ro, rc, rl, rr = csr(right_blocks)
+    loc = np.ascontiguousarray(pair_locus, np.int32)
+    mass = np.ascontiguousarray(pair_mass, np.float64)
+    p = _lib.sbgpu_pairs_t(len(loc), _ptr(loc), _ptr(mass), _ptr(lo), _ptr(lc), _ptr(ll), _ptr(lr), _ptr(ro), _ptr(rc),
+                           _ptr(rl), _ptr(rr))
+    handle = C.c_void_p()
+    _lib.check(L.sbgpu_collapse_pairs_host(n_loci, C.byref(p), C.byref(handle)), "sbgpu_collapse_pairs_host")
+    try:
+        info = (C.c_int64 * 8)()
+        _lib.check(L.sbgpu_uniq_info(handle, info), "sbgpu_uniq_info")
+        nh, nf = int(info[0]), int(info[1])
+        hit_locus, feat_off = np.zeros(nh, np.int32), np.zeros(nh + 1, np.int64)
+        code, left, right = np.zeros(nf, np.uint8), np.zeros(nf, np.uint32), np.zeros(nf, np.uint32)
+        hmass, cmass = np.zeros(nh, np.float32), np.zeros(n_loci, np.float64)
+        _lib.check(L.sbgpu_uniq_export(handle, _ptr(hit_locus), feat_off.ctypes.data, _ptr(code), _ptr(left), _ptr(right),
+                                       _ptr(hmass), _ptr(cmass)), "sbgpu_uniq_export")
+    finally:
+        L.sbgpu_uniq_destroy(handle)
+    hits = Hits.from_arrays(hit_locus, feat_off, code, left, right, hmass)
+    hits.total_mapped = int(info[4])
+    return hits, cmass, {"filtered": int(info[2]), "rejected": int(info[3]), "total_mapped": int(info[4])}
+
+
 class Hits:
     """Fragments of a batch of loci, CSR over features; `mass` = (float) collapse_mass."""
 

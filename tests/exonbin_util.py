@@ -26,6 +26,17 @@ def load_reads(directory):
     return out
 
 
+def load_read_copies(directory):
+    """Every sequenced copy of every fragment as its own pair: [(gene, left blocks, right blocks, raw mass)]
+    -- what a driver reads from the BAM before HitCluster::collapseAndFilterHits."""
+    z = dict(np.load(os.path.join(directory, "reads.npz")))
+    out = []
+    for k, (gi, lb, rb, _) in enumerate(load_reads(directory)):
+        for n in z["nh"][z["nh_off"][k]:z["nh_off"][k + 1]]:
+            out.append((gi, lb, rb, 0.5 / int(n) + 0.5 / int(n)))   # src/read.cpp:49-53; 1/NH for an unpaired read
+    return out
+
+
 def e2e_inputs(directory, ordered_genes):
     """-> (Annotation, Hits, gene names, rejected pair count).  Loci in gene order with the reference's
     isoform order; hits as HitCluster::collapseAndFilterHits leaves them: sorted by (left, right) of

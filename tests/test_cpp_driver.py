@@ -52,9 +52,9 @@ def write_input(directory, path):
             f.write("locus %s %d\n" % (g, len(ordered[g])))
             for t, ex in ordered[g]:
                 f.write("iso %s %d %s\n" % (t, len(ex), " ".join("%d %d" % e for e in ex)))
-        reads = XU.load_reads(directory)
+        reads = XU.load_read_copies(directory)   # every sequenced copy, in simulation order: the library sorts and collapses
         f.write("pairs %d\n" % len(reads))
-        for gi, lb, rb, mass in reads:   # in simulation order: the driver sorts them itself
+        for gi, lb, rb, mass in reads:
             f.write("pair %d %.17g %d %s %d %s\n" % (gi, mass, len(lb), " ".join("%d %d" % b for b in lb), len(rb),
                                                     " ".join("%d %d" % b for b in rb)))
     return rows

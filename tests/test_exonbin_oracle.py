@@ -175,6 +175,45 @@ def test_fractional_masses_reproduce_reference_theta(oracle):
             assert abs(fr - float(gtf[t][1])) < 2e-6, t
 
 
+@pytest.mark.parametrize("which", ["E2E", "E2E_MASS", "E2E_SINGLE", "E2E_LONGREAD"])
+def test_collapse_pairs_gives_the_unique_hits(which):
+    """sbgpu_collapse_pairs_host on every sequenced copy (shuffled) == the unique hits the other tests build by
+    hand: same order, features, float masses, and the reference's mapped-read total (the -f table's column 2)."""
+    d = getattr(U, which)
+    ordered, rows, _, _ = U.load(d)
+    annot, hits, names, rejected = XU.e2e_inputs(d, ordered)
+    copies = XU.load_read_copies(d)
+    rng = np.random.default_rng(5)
+    copies = [copies[i] for i in rng.permutation(len(copies))]
+    got, cluster_mass, info = eb.collapse_pairs(len(names), [c[0] for c in copies], [c[3] for c in copies],
+                                                [c[1] for c in copies], [c[2] for c in copies])
+    assert info["total_mapped"] == rows[0]["total_mapped"] == hits.total_mapped
+    assert info["rejected"] == rejected and info["filtered"] == 0
+    for a in ("hit_locus", "feat_off", "feat_code", "feat_left", "feat_right", "mass"):
+        np.testing.assert_array_equal(getattr(got, a), getattr(hits, a), err_msg=a)
+    if which == "E2E_MASS":
+        assert len(copies) > got.n_hits * 1.3 and len(np.unique(got.mass)) > 10
+
+
+def test_collapse_pairs_span_filter_and_equality():
+    """The span filter (a mate far longer than the cluster's mates is skipped, its mass not counted) and
+    what "equal" means when collapsing (both mates: same start and same blocks)."""
+    left = [[(1000 + 3 * k, 1074 + 3 * k)] for k in range(200)]
+    right = [[(1300 + 3 * k, 1374 + 3 * k)] for k in range(200)]
+    left.append([(1500, 1574)]); right.append([(1700, 1710), (30000, 30063)])      # a mate spanning 28 kb
+    left.append([(1003, 1077)]); right.append([(1303, 1377)])                      # a second copy of pair 1
+    left.append([(1003, 1077)]); right.append([(1303, 1340), (1400, 1436)])        # same ends... no: spliced, not equal
+    hits, cm, info = eb.collapse_pairs(1, [0] * 203, [1.0] * 201 + [0.5, 1.0], left, right)
+    assert info["filtered"] == 1 and info["rejected"] == 0
+    assert hits.n_hits == 201 and abs(cm[0] - 201.5) < 1e-12 and info["total_mapped"] == 201
+    k = int(np.nonzero(hits.feat_left[hits.feat_off[:-1]] == 1003)[0][0])
+    assert hits.mass[k] == 1.5 or hits.mass[k + 1] == 1.5   # the copy was collapsed into its twin
+    # single reads (no right mate) and a pair whose mates abut (rejected, but counted in the cluster mass)
+    hits, cm, info = eb.collapse_pairs(2, [0, 0, 1], [1.0, 1.0, 1.0], [[(10, 84)], [(10, 84)], [(500, 574)]],
+                                       [[], [], [(575, 649)]])
+    assert hits.n_hits == 1 and hits.mass[0] == 2.0 and info["rejected"] == 1 and cm.tolist() == [2.0, 1.0]
+
+
 def test_bins_bookkeeping_rules():
     """set_maps / read_count details: first-appearance order, duplicate fragments count once,
     float masses truncate, hits without a compatible isoform are dropped."""
