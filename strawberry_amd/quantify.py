@@ -125,3 +125,40 @@ class LocusQuantifier:
         self.assign_bins()
         self.bin_weights()
         return self.solve(total_mapped_reads, **abundance_kw)
+
+
+def quantify_host(annot, hits, insert, read_len, long_read=False, ctx=None, device=0):
+    """sbgpu_quantify_host: the whole chain as one C-ABI call on host arrays (what a C / C++ driver uses).
+    insert=None: build the empirical insert-size distribution from the hits.
+    -> dict(theta, status, iters, compat, bins (LocusBins incl. hit_bin), F, insert (mean, sd, use_emp, ...))"""
+    from .exonbin import LocusBins
+    ctx = ctx or default_context(device)
+    L = ctx.L
+    a, h = annot._struct(), hits._struct()
+    n_iso = int(annot.iso_off[-1])
+    theta = np.zeros(n_iso + 1, np.float64)
+    status = np.zeros(annot.n_loci + 1, np.int32)
+    iters = np.zeros(annot.n_loci + 1, np.int32)
+    cw, kw = annot.compat_words, annot.key_words
+    compat = np.zeros((max(hits.n_hits, 1), cw), np.uint32)
+    used = _lib.sbgpu_insert_t()
+    ins = insert._struct(read_len, long_read) if insert is not None else None
+    handle = C.c_void_p()
+    _lib.check(L.sbgpu_quantify_host(ctx.h, C.byref(a), C.byref(h), hits.mass.ctypes.data if hits.n_hits else None,
+                                     C.byref(ins) if ins is not None else None, int(read_len), int(long_read),
+                                     theta.ctypes.data, status.ctypes.data, iters.ctypes.data, compat.ctypes.data,
+                                     C.byref(used), C.byref(handle)), "sbgpu_quantify_host")
+    info = (C.c_int64 * 8)()
+    _lib.check(L.sbgpu_bins_info(handle, info), "sbgpu_bins_info")
+    F = np.zeros(max(int(info[3]), 1), np.float64)
+    _lib.check(L.sbgpu_bins_export_weights(handle, F.ctypes.data), "sbgpu_bins_export_weights")
+    emp = None
+    if used.use_emp:
+        n = used.end_offset - used.start_offset + 1
+        emp = np.ctypeslib.as_array(used.emp_hist, shape=(n,)).copy()
+    bins = LocusBins.__new__(LocusBins)
+    bins._export(L, annot, handle, hits.n_hits, cw, kw, with_hit_bin=True)   # destroys the handle
+    return {"theta": theta[:n_iso], "status": status[:annot.n_loci], "iters": iters[:annot.n_loci],
+            "compat": compat[:hits.n_hits], "bins": bins, "F": F[:int(info[3])],
+            "insert": {"mean": used.mean, "sd": used.sd, "use_emp": bool(used.use_emp), "start_offset": used.start_offset,
+                       "end_offset": used.end_offset, "total_reads": used.total_reads, "emp_hist": emp}}

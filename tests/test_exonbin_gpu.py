@@ -281,6 +281,47 @@ def test_device_grouping_declines_what_it_cannot_do_exactly(ctx):
     assert sorted(b.count.tolist()) == sorted(ref[2].tolist())
 
 
+def test_one_call_chain_equals_the_staged_chain(ctx):
+    """sbgpu_quantify_host vs LocusQuantifier (the same kernels driven stage by stage): identical theta, F, bins --
+    with hits grouped by locus (device grouping), with hits of different loci interleaved (host grouping),
+    with the empirical insert size, and with no hits at all."""
+    from strawberry_amd import exonbin as eb
+    from strawberry_amd import synth
+    from strawberry_amd.quantify import InsertSize, LocusQuantifier, quantify_host
+    loci = synth.make_gene_models(60, seed=61)
+    hl, pairs = synth.make_fragments(loci, 90, seed=62, noise=0.2)
+    rows = [(l, eb.hit_features(lb, rb)) for l, (lb, rb) in zip(hl, pairs)]
+    rows = [(l, f) for l, f in rows if f is not None]
+    annot = eb.Annotation(loci)
+    hits = eb.Hits([l for l, _ in rows], [f for _, f in rows])
+    q = LocusQuantifier(annot, hits, InsertSize(250.0, 30.0), 75, ctx=ctx)
+    ref = q.run(hits.n_hits, min_isoform_frac=0.0)
+    one = quantify_host(annot, hits, InsertSize(250.0, 30.0), 75, ctx=ctx)
+    np.testing.assert_array_equal(one["theta"], ref["theta"])
+    np.testing.assert_array_equal(one["iters"], ref["iters"])
+    np.testing.assert_array_equal(one["F"], q.d_F.cpu().numpy()[:len(one["F"])])
+    for x, y in zip(bins_arrays(one["bins"]), bins_arrays(q.bins)):
+        np.testing.assert_array_equal(x, y)
+    # hits of different loci interleaved: grouping falls back to the host, results are the same per locus
+    perm = np.argsort(np.arange(hits.n_hits) % 7, kind="stable")
+    mixed = eb.Hits([rows[i][0] for i in perm], [rows[i][1] for i in perm])
+    two = quantify_host(annot, mixed, InsertSize(250.0, 30.0), 75, ctx=ctx)
+    assert two["bins"].n_bins == one["bins"].n_bins
+    assert abs(two["theta"].sum() - one["theta"].sum()) < 1e-6 * one["theta"].sum()
+    # empirical insert size built by the library = built by hand from the same words
+    emp = quantify_host(annot, hits, None, 75, ctx=ctx)
+    fl = eb.frag_lens(annot, hits, one["compat"])
+    byhand = InsertSize.from_frag_lens(fl)
+    assert emp["insert"]["use_emp"] and emp["insert"]["total_reads"] == len(fl)
+    assert emp["insert"]["mean"] == byhand.mean and emp["insert"]["sd"] == byhand.sd
+    np.testing.assert_array_equal(emp["insert"]["emp_hist"], byhand.emp_hist)
+    q2 = LocusQuantifier(annot, hits, byhand, 75, ctx=ctx)
+    np.testing.assert_array_equal(emp["theta"], q2.run(hits.n_hits, min_isoform_frac=0.0)["theta"])
+    # no hits: every locus is INIT_EMPTY, nothing breaks
+    none = quantify_host(annot, eb.Hits([], []), InsertSize(250.0, 30.0), 75, ctx=ctx)
+    assert none["bins"].n_bins == 0 and (none["status"] == 1).all()
+
+
 def test_large_batch_properties(ctx, oracle):
     """BASELINE-scale hit counts through size-independent properties: tiling the loci along the genome
     must tile the answers; a fragment sampled from an isoform without noise is compatible with it."""
