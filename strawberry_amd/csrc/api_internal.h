@@ -10,13 +10,28 @@
 #include "../../include/sbgpu.h"
 
 namespace sb {
+// (bin, isoform) pairs made on the device (bins_device.h): sbgpu_binweight_device's inputs in one arena.
+// A bins handle that holds them downloads them only when somebody exports the pair arrays.
+struct DevicePairs {
+   char *arena = nullptr; // hipMalloc'ed; owned by the handle it is attached to
+   int64_t n_pairs = 0, n_pair_segs = 0;
+   bool any_wide = false; // some pair spans more than 32 segments and carries none (fine for long reads only)
+   size_t o_seg_off = 0, o_seg_lens = 0, o_mask = 0, o_iso_len = 0, o_out_index = 0;
+   const int64_t *seg_off() const { return (const int64_t *)(arena + o_seg_off); }
+   const uint32_t *seg_lens() const { return (const uint32_t *)(arena + o_seg_lens); }
+   const uint32_t *mask() const { return (const uint32_t *)(arena + o_mask); }
+   const int32_t *iso_len() const { return (const int32_t *)(arena + o_iso_len); }
+   const int64_t *out_index() const { return (const int64_t *)(arena + o_out_index); }
+};
 int api_fail(int code, const std::string &msg); // records sbgpu_last_error(), returns code
 hipStream_t ctx_stream(const sbgpu_ctx_t *ctx); // the context's own stream
 int ctx_cu_count(const sbgpu_ctx_t *ctx);
 // locus_bins.cpp: finish bins that were grouped on the device (host copies of the per-bin arrays)
+// `pairs`: made on the device already (the handle takes the arena over); nullptr: make them here, on the host
 int bins_from_groups(const sbgpu_annotation_t *annot, int32_t compat_words, int32_t key_words, const int64_t *row_off,
                      const int32_t *count, const uint32_t *key, const uint32_t *compat, int64_t n_hits_used,
-                     sbgpu_bins_t **out);
+                     const DevicePairs *pairs, sbgpu_bins_t **out);
+const DevicePairs *bins_device_pairs(const sbgpu_bins_t *bins); // nullptr when the pairs live on the host
 void bins_set_weights(sbgpu_bins_t *bins, std::vector<double> &&F);
 void bins_set_hit_bin(sbgpu_bins_t *bins, std::vector<int64_t> &&hit_bin);
 const double *bins_weights_tail(const sbgpu_bins_t *bins, size_t at); // F.data() + at (the empirical histogram lives there)

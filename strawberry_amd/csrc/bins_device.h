@@ -240,4 +240,122 @@ __global__ __launch_bounds__(256) void bins_pack_kernel(BinsPackArgs a)
    }
 }
 
+// ------------------------------------------------------------------ (bin, isoform) pairs
+// ExonBin::bin_under_iso (/root/reference/include/isoform.h:363-411) for every pair LocusContext::
+// set_theory_bin_weight visits (src/estimate.cpp:203-213): the isoform's segments from the bin's first to
+// its last, and which of the inner ones the bin does not hold ("implicit": under the mate gap).
+// One lane per isoform, walking the bins of its locus: the pairs come out ordered by (isoform, bin), the
+// order of the host code.  Pass 1 counts, pass 2 (after the host's scan) fills.
+enum : int32_t { kPairsNotUnder = 16, kPairsForeignSegment = 32, kPairsWide = 64 };
+
+struct PairsArgs {
+   int64_t n_iso;
+   const int32_t *iso_locus;      // [n_iso]
+   const int64_t *iso_off;        // [n_loci + 1]
+   const int64_t *row_off, *f_off; // [n_loci + 1]
+   const int64_t *seg_off;        // [n_loci + 1]
+   const uint32_t *seg_left, *seg_right;
+   const int64_t *iso_seg_off;    // [n_iso + 1]: Isoform::_exon_segs as local segment indices
+   const int32_t *iso_seg_idx;
+   const int32_t *iso_len;        // [n_iso]
+   int32_t compat_words, key_words;
+   const uint32_t *bin_key, *bin_compat;
+   int32_t *pair_cnt, *seg_cnt;        // pass 1: [n_iso]
+   const int64_t *pair_off, *pseg_off; // pass 2: their exclusive scans, [n_iso + 1]
+   int64_t *pair_seg_off;
+   uint32_t *pair_seg_lens, *pair_mask;
+   int32_t *pair_iso_len;
+   int64_t *pair_out_index;
+   int32_t *flags;
+};
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void bins_pairs_kernel(PairsArgs a)
+{
+   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_iso; i += stride) {
+      const int l = a.iso_locus[i];
+      const int64_t i0 = a.iso_off[l];
+      const int j = (int)(i - i0), niso = (int)(a.iso_off[l + 1] - i0);
+      const int64_t b0 = a.row_off[l], b1 = a.row_off[l + 1], s0 = a.seg_off[l];
+      const int32_t *is = a.iso_seg_idx + a.iso_seg_off[i];
+      const int nis = (int)(a.iso_seg_off[i + 1] - a.iso_seg_off[i]);
+      const int cw = a.compat_words, kw = a.key_words;
+      int np = 0, ns = 0, bad = 0;
+      int64_t p = FILL ? a.pair_off[i] : 0, so = FILL ? a.pseg_off[i] : 0;
+      for (int64_t b = b0; b < b1; ++b) {
+         if (!((a.bin_compat[b * cw + (j >> 5)] >> (j & 31)) & 1u)) continue;
+         const uint32_t *key = a.bin_key + b * kw;
+         int bf = -1, bl = -1, nbits = 0; // first / last segment of the bin, number of its segments
+         for (int w = 0; w < kw; ++w) {
+            const uint32_t k = key[w];
+            if (!k) continue;
+            if (bf < 0) bf = 32 * w + __ffs(k) - 1;
+            bl = 32 * w + 31 - __clz(k);
+            nbits += __popc(k);
+         }
+         // isoform.h:381-391: lower_bound of the bin's first and last segment among the isoform's
+         int low = 0, up = 0;
+         {
+            int lo = 0, hi = nis;
+            while (lo < hi) {
+               const int mid = (lo + hi) >> 1;
+               if (is[mid] < bf) lo = mid + 1;
+               else hi = mid;
+            }
+            low = lo;
+            hi = nis;
+            while (lo < hi) {
+               const int mid = (lo + hi) >> 1;
+               if (is[mid] < bl) lo = mid + 1;
+               else hi = mid;
+            }
+            up = lo;
+         }
+         if (low >= nis || up >= nis || up < low) {
+            bad |= kPairsNotUnder;
+            continue;
+         }
+         const int n = up - low + 1;
+         uint32_t mask = 0;
+         int n_eff = n;
+         if (n > 32) {
+            n_eff = 0; // see locus_bins.cpp: such a pair carries no segments (long-read workflow only)
+            bad |= kPairsWide;
+         } else {
+            // :393-409: an inner isoform segment the bin does not hold is implicit; every segment the bin
+            // holds between its ends must be one of the isoform's
+            int inside = 0;
+            for (int q = 1; q + 1 < n; ++q) {
+               const int sidx = is[low + q];
+               if ((key[sidx >> 5] >> (sidx & 31)) & 1u) ++inside;
+               else mask |= 1u << q;
+            }
+            // the bin's other segments (all but its first and last) must be the ones counted: a mismatch is
+            // either the reference's assert(false) or a case its walk lets pass -- the host code decides
+            if (nbits >= 2 && inside != nbits - 2) bad |= kPairsForeignSegment;
+         }
+         if (FILL) {
+            a.pair_seg_off[p] = so;
+            for (int q = 0; q < n_eff; ++q) {
+               const int sidx = is[low + q];
+               a.pair_seg_lens[so + q] = a.seg_right[s0 + sidx] - a.seg_left[s0 + sidx] + 1;
+            }
+            a.pair_mask[p] = mask;
+            a.pair_iso_len[p] = a.iso_len[i];
+            a.pair_out_index[p] = a.f_off[l] + (b - b0) * niso + j;
+            ++p;
+            so += n_eff;
+         }
+         ++np;
+         ns += n_eff;
+      }
+      if (!FILL) {
+         a.pair_cnt[i] = np;
+         a.seg_cnt[i] = ns;
+      }
+      if (bad) atomicOr(a.flags, bad);
+   }
+}
+
 } // namespace sb

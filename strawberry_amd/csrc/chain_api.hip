@@ -4,6 +4,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -61,6 +64,17 @@ int sbgpu_quantify_host(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgp
    for (int64_t l = 0; l < nl; ++l) locus_hit_off[(size_t)l + 1] += locus_hit_off[(size_t)l];
 
    hipStream_t s = sb::ctx_stream(c);
+   const bool timing = std::getenv("SBGPU_HOST_TIMING") != nullptr; // diagnostic: stage times on stderr (each stage synchronises)
+   auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+   double t_stage = now();
+   auto stage = [&](const char *name) {
+      if (timing) {
+         (void)hipStreamSynchronize(s);
+         const double t = now();
+         std::fprintf(stderr, "sbgpu_quantify_host: %-18s %.2f ms\n", name, (t - t_stage) * 1e3);
+         t_stage = t;
+      }
+   };
    // ---- inputs: one arena, one copy per array
    struct Part {
       const void *src;
@@ -117,8 +131,10 @@ int sbgpu_quantify_host(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgp
    uint32_t *d_compat = (uint32_t *)(in.p + o_compat), *d_key = (uint32_t *)(in.p + o_key);
    int64_t *d_hit_bin = (int64_t *)(in.p + o_hbin);
 
+   stage("upload");
    // ---- A5: the interval tests
    if (nh) SB_RC(sbgpu_exonbin_device(c, &dan, &dh, cw, kw, d_compat, d_key, s));
+   stage("exonbin kernel");
    std::vector<uint32_t> compat_h, key_h;
    auto need_compat = [&]() -> int {
       if (compat_h.empty() && nh) {
@@ -165,6 +181,7 @@ int sbgpu_quantify_host(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgp
       ins.read_len = read_len;
       ins.long_read = long_read;
    }
+   stage("insert size");
    // ---- A5: bins (device; host when the device form declines)
    sbgpu_bins_t *bins = nullptr;
    int rc = SBGPU_EUNSUPPORTED;
@@ -185,34 +202,57 @@ int sbgpu_quantify_host(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgp
       sbgpu_bins_t *b;
       ~BinsGuard() { sbgpu_bins_destroy(b); }
    } guard = {bins};
+   stage("bins + pairs");
    int64_t info[8];
    SB_RC(sbgpu_bins_info(bins, info));
    const int64_t n_bins = info[2], n_elem = info[3], n_pairs = info[4], n_psegs = info[5];
-   std::vector<int64_t> row_off((size_t)nl + 1), iso_off((size_t)nl + 1), f_off((size_t)nl + 1), pair_seg_off((size_t)n_pairs + 1),
-      pair_out((size_t)n_pairs + 1);
-   std::vector<int32_t> count((size_t)n_bins + 1), pair_len((size_t)n_pairs + 1);
-   std::vector<uint32_t> pair_segs((size_t)n_psegs + 1), pair_mask((size_t)n_pairs + 1);
+   const sb::DevicePairs *dpairs = sb::bins_device_pairs(bins); // made on the device: used where they are
+   std::vector<int64_t> row_off((size_t)nl + 1), iso_off((size_t)nl + 1), f_off((size_t)nl + 1), pair_seg_off, pair_out;
+   std::vector<int32_t> count((size_t)n_bins + 1), pair_len;
+   std::vector<uint32_t> pair_segs, pair_mask;
+   if (!dpairs) {
+      pair_seg_off.resize((size_t)n_pairs + 1);
+      pair_out.resize((size_t)n_pairs + 1);
+      pair_len.resize((size_t)n_pairs + 1);
+      pair_segs.resize((size_t)n_psegs + 1);
+      pair_mask.resize((size_t)n_pairs + 1);
+   }
    SB_RC(sbgpu_bins_export(bins, row_off.data(), iso_off.data(), f_off.data(), count.data(), nullptr, nullptr, nullptr, nullptr,
-                           pair_seg_off.data(), pair_segs.data(), pair_mask.data(), pair_len.data(), pair_out.data()));
+                           dpairs ? nullptr : pair_seg_off.data(), dpairs ? nullptr : pair_segs.data(),
+                           dpairs ? nullptr : pair_mask.data(), dpairs ? nullptr : pair_len.data(),
+                           dpairs ? nullptr : pair_out.data()));
+   stage("export");
    // ---- A4: weights straight into the EM batch's F
    int64_t max_l = 1;
-   if (!long_read)
-      for (int64_t p = 0; p < n_pairs; ++p) {
-         int64_t l = 0;
-         for (int64_t k = pair_seg_off[(size_t)p]; k < pair_seg_off[(size_t)p + 1]; ++k) l += pair_segs[(size_t)k];
-         if (pair_seg_off[(size_t)p + 1] == pair_seg_off[(size_t)p])
-            return api_fail(SBGPU_ESHAPE, "sbgpu_quantify_host: a bin spans more than 32 isoform segments");
-         max_l = std::max(max_l, l);
+   if (!long_read) {
+      if (dpairs) {
+         if (dpairs->any_wide) return api_fail(SBGPU_ESHAPE, "sbgpu_quantify_host: a bin spans more than 32 isoform segments");
+         // no pair spans more than its locus' segments together
+         for (int64_t l = 0; l < nl; ++l) {
+            int64_t tot = 0;
+            for (int64_t k = an->seg_off[l]; k < an->seg_off[l + 1]; ++k) tot += (int64_t)an->seg_right[k] - an->seg_left[k] + 1;
+            max_l = std::max(max_l, tot);
+         }
+      } else {
+         for (int64_t p = 0; p < n_pairs; ++p) {
+            int64_t l = 0;
+            for (int64_t k = pair_seg_off[(size_t)p]; k < pair_seg_off[(size_t)p + 1]; ++k) l += pair_segs[(size_t)k];
+            if (pair_seg_off[(size_t)p + 1] == pair_seg_off[(size_t)p])
+               return api_fail(SBGPU_ESHAPE, "sbgpu_quantify_host: a bin spans more than 32 isoform segments");
+            max_l = std::max(max_l, l);
+         }
       }
+   }
    if (max_l > (1 << 26)) return api_fail(SBGPU_ESHAPE, "sbgpu_quantify_host: segment lengths out of range");
    const int32_t pdf_len = (int32_t)max_l + 1;
    std::vector<double> pdf((size_t)pdf_len);
    SB_RC(sbgpu_insert_pdf_table(&ins, pdf_len, pdf.data()));
-   const size_t np1 = (size_t)std::max<int64_t>(n_pairs, 1), ne1 = (size_t)std::max<int64_t>(n_elem, 1), nb1 = (size_t)std::max<int64_t>(n_bins, 1);
+   const size_t np1 = (size_t)std::max<int64_t>(dpairs ? 1 : n_pairs, 1), ne1 = (size_t)std::max<int64_t>(n_elem, 1),
+                nb1 = (size_t)std::max<int64_t>(n_bins, 1), ns1 = (size_t)(dpairs ? 1 : n_psegs + 1);
    size_t t2 = 0;
    const size_t q_off = t2; t2 += up256((np1 + 1) * 8);
    const size_t q_idx = t2; t2 += up256(np1 * 8);
-   const size_t q_seg = t2; t2 += up256((size_t)(n_psegs + 1) * 4);
+   const size_t q_seg = t2; t2 += up256(ns1 * 4);
    const size_t q_mask = t2; t2 += up256(np1 * 4);
    const size_t q_len = t2; t2 += up256(np1 * 4);
    const size_t q_pdf = t2; t2 += up256((size_t)pdf_len * 8);
@@ -226,18 +266,24 @@ int sbgpu_quantify_host(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgp
    if (e != hipSuccess) return api_fail(e == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e));
    SB_TRY(hipMemsetAsync(w.p + q_F, 0, ne1 * 8, s));
    if (n_pairs) {
-      SB_TRY(hipMemcpyAsync(w.p + q_off, pair_seg_off.data(), (size_t)(n_pairs + 1) * 8, hipMemcpyHostToDevice, s));
-      SB_TRY(hipMemcpyAsync(w.p + q_idx, pair_out.data(), (size_t)n_pairs * 8, hipMemcpyHostToDevice, s));
-      if (n_psegs) SB_TRY(hipMemcpyAsync(w.p + q_seg, pair_segs.data(), (size_t)n_psegs * 4, hipMemcpyHostToDevice, s));
-      SB_TRY(hipMemcpyAsync(w.p + q_mask, pair_mask.data(), (size_t)n_pairs * 4, hipMemcpyHostToDevice, s));
-      SB_TRY(hipMemcpyAsync(w.p + q_len, pair_len.data(), (size_t)n_pairs * 4, hipMemcpyHostToDevice, s));
+      const int64_t *d_off = dpairs ? dpairs->seg_off() : (const int64_t *)(w.p + q_off);
+      const uint32_t *d_seg = dpairs ? dpairs->seg_lens() : (const uint32_t *)(w.p + q_seg);
+      const uint32_t *d_msk = dpairs ? dpairs->mask() : (const uint32_t *)(w.p + q_mask);
+      const int32_t *d_len = dpairs ? dpairs->iso_len() : (const int32_t *)(w.p + q_len);
+      const int64_t *d_idx = dpairs ? dpairs->out_index() : (const int64_t *)(w.p + q_idx);
+      if (!dpairs) {
+         SB_TRY(hipMemcpyAsync(w.p + q_off, pair_seg_off.data(), (size_t)(n_pairs + 1) * 8, hipMemcpyHostToDevice, s));
+         SB_TRY(hipMemcpyAsync(w.p + q_idx, pair_out.data(), (size_t)n_pairs * 8, hipMemcpyHostToDevice, s));
+         if (n_psegs) SB_TRY(hipMemcpyAsync(w.p + q_seg, pair_segs.data(), (size_t)n_psegs * 4, hipMemcpyHostToDevice, s));
+         SB_TRY(hipMemcpyAsync(w.p + q_mask, pair_mask.data(), (size_t)n_pairs * 4, hipMemcpyHostToDevice, s));
+         SB_TRY(hipMemcpyAsync(w.p + q_len, pair_len.data(), (size_t)n_pairs * 4, hipMemcpyHostToDevice, s));
+      }
       SB_TRY(hipMemcpyAsync(w.p + q_pdf, pdf.data(), (size_t)pdf_len * 8, hipMemcpyHostToDevice, s));
       const int32_t lmin_base = ins.use_emp ? ins.start_offset : ins.read_len;
-      SB_RC(sbgpu_binweight_device(c, n_pairs, (const int64_t *)(w.p + q_off), (const uint32_t *)(w.p + q_seg),
-                                   (const uint32_t *)(w.p + q_mask), (const int32_t *)(w.p + q_len), (const int64_t *)(w.p + q_idx),
-                                   (const double *)(w.p + q_pdf), pdf_len, ins.read_len, lmin_base, ins.long_read,
-                                   (double *)(w.p + q_F), s));
+      SB_RC(sbgpu_binweight_device(c, n_pairs, d_off, d_seg, d_msk, d_len, d_idx, (const double *)(w.p + q_pdf), pdf_len,
+                                   ins.read_len, lmin_base, ins.long_read, (double *)(w.p + q_F), s));
    }
+   stage("bin weights");
    // ---- A1/A2: the EM
    if (n_bins) SB_TRY(hipMemcpyAsync(w.p + q_cnt, count.data(), (size_t)n_bins * 4, hipMemcpyHostToDevice, s));
    sbgpu_plan_t *plan = nullptr;
@@ -261,6 +307,7 @@ int sbgpu_quantify_host(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgp
    }
    hipError_t e6 = hipStreamSynchronize(s);
    sbgpu_plan_destroy(plan);
+   stage("plan + EM + download");
    for (hipError_t x : {e1, e2, e3, e4, e5, e6})
       if (x != hipSuccess) return api_fail(SBGPU_EHIP, std::string("sbgpu_quantify_host: download: ") + hipGetErrorString(x));
    if (compat_out) {

@@ -2,6 +2,9 @@
 // (include/sbgpu.h): launch of the per-hit compatibility + bin-key kernel.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -178,6 +181,17 @@ int sbgpu_bins_create_device(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const
          return api_fail(SBGPU_ESHAPE, "sbgpu_bins_create_device: word counts do not cover a locus");
    }
    hipStream_t s = (hipStream_t)stream;
+   const bool timing = std::getenv("SBGPU_HOST_TIMING") != nullptr; // diagnostic: stage times on stderr
+   auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+   double t_stage = now();
+   auto stage = [&](const char *name) {
+      if (timing) {
+         (void)hipStreamSynchronize(s);
+         const double t = now();
+         std::fprintf(stderr, "  bins_create_device: %-16s %.2f ms\n", name, (t - t_stage) * 1e3);
+         t_stage = t;
+      }
+   };
    // one arena for the scratch: [hit_bin_local | bin_rep | bin_count | bin_compat | n_bins | n_used | flags | offsets x2]
    const size_t nh1 = (size_t)(nh > 0 ? nh : 1);
    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -243,6 +257,7 @@ int sbgpu_bins_create_device(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const
       if (flags & sb::kBinsTableFull) why += " a locus has more bins than the LDS table holds;";
       return bail(SBGPU_EUNSUPPORTED, why + " use sbgpu_bins_create");
    }
+   stage("group kernel");
    std::vector<int64_t> row_off((size_t)nl + 1, 0);
    int64_t used = 0;
    for (int64_t l = 0; l < nl; ++l) {
@@ -283,14 +298,151 @@ int sbgpu_bins_create_device(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const
       SB_TRY(hipMemcpyAsync(key.data(), d2 + p_key, (size_t)n_bins * 4 * key_words, hipMemcpyDeviceToHost, s));
       SB_TRY(hipMemcpyAsync(compat.data(), d2 + p_cmp, (size_t)n_bins * 4 * compat_words, hipMemcpyDeviceToHost, s));
    }
-   SB_TRY(hipMemcpyAsync(&flags, d + o_flag, 4, hipMemcpyDeviceToHost, s));
-   SB_TRY(hipStreamSynchronize(s));
+   stage("pack + D2H");
+   // ---- the (bin, isoform) pairs, on the device too (bins_pairs_kernel): the isoforms' segment lists
+   // (Isoform::_exon_segs, include/isoform.h:59-71) come from the host annotation
+   const int64_t n_iso = an->iso_off[nl];
+   std::vector<int64_t> iso_seg_off((size_t)n_iso + 1, 0), f_off((size_t)nl + 1, 0);
+   std::vector<int32_t> iso_locus((size_t)(n_iso > 0 ? n_iso : 1)), iso_len((size_t)(n_iso > 0 ? n_iso : 1));
+   std::vector<int32_t> iso_seg_idx;
+   for (int64_t l = 0; l < nl; ++l) {
+      const int64_t s0 = an->seg_off[l], nseg = an->seg_off[l + 1] - s0, niso = an->iso_off[l + 1] - an->iso_off[l];
+      f_off[(size_t)l + 1] = f_off[(size_t)l] + (row_off[(size_t)l + 1] - row_off[(size_t)l]) * niso;
+      for (int64_t iso = an->iso_off[l]; iso < an->iso_off[l + 1]; ++iso) {
+         const int64_t e0 = an->exon_off[iso], ne = an->exon_off[iso + 1] - e0;
+         int64_t e = 0, len = 0;
+         for (int64_t x = 0; x < ne; ++x) len += (int64_t)an->exon_right[e0 + x] - an->exon_left[e0 + x] + 1;
+         for (int64_t sidx = 0; sidx < nseg; ++sidx) {
+            const uint32_t sl = an->seg_left[s0 + sidx], sr = an->seg_right[s0 + sidx];
+            while (e < ne && an->exon_right[e0 + e] < sl) ++e; // contig.cpp:615-634; segments ascend
+            if (e < ne && an->exon_left[e0 + e] <= sl && an->exon_right[e0 + e] >= sr) iso_seg_idx.push_back((int32_t)sidx);
+         }
+         iso_seg_off[(size_t)iso + 1] = (int64_t)iso_seg_idx.size();
+         iso_locus[(size_t)iso] = (int32_t)l;
+         iso_len[(size_t)iso] = (int32_t)len;
+      }
+   }
+   stage("iso segments");
+   const size_t ni1 = (size_t)(n_iso > 0 ? n_iso : 1), nsi1 = iso_seg_idx.empty() ? 1 : iso_seg_idx.size();
+   const int64_t n_seg = an->seg_off[nl];
+   size_t off3 = 0;
+   const size_t r_isoff = off3; off3 += up((size_t)(nl + 1) * 8);
+   const size_t r_foff = off3; off3 += up((size_t)(nl + 1) * 8);
+   const size_t r_segoff = off3; off3 += up((size_t)(nl + 1) * 8);
+   const size_t r_segl = off3; off3 += up((size_t)(n_seg + 1) * 4);
+   const size_t r_segr = off3; off3 += up((size_t)(n_seg + 1) * 4);
+   const size_t r_isegoff = off3; off3 += up((ni1 + 1) * 8);
+   const size_t r_isegidx = off3; off3 += up(nsi1 * 4);
+   const size_t r_isoloc = off3; off3 += up(ni1 * 4);
+   const size_t r_isolen = off3; off3 += up(ni1 * 4);
+   const size_t r_pcnt = off3; off3 += up(ni1 * 4);
+   const size_t r_scnt = off3; off3 += up(ni1 * 4);
+   const size_t r_poff = off3; off3 += up((ni1 + 1) * 8);
+   const size_t r_soff = off3; off3 += up((ni1 + 1) * 8);
+   char *d3 = nullptr;
+   e = hipMalloc(&d3, off3);
+   if (e != hipSuccess) return bail(e == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+   sb::DevicePairs dp;
+   auto bail3 = [&](int code, const std::string &msg) {
+      (void)hipFree(d3);
+      (void)hipFree(dp.arena);
+      return bail(code, msg);
+   };
+#define SB_TRY3(expr)                                                                          \
+   do {                                                                                        \
+      hipError_t e_ = (expr);                                                                  \
+      if (e_ != hipSuccess) return bail3(SBGPU_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+   } while (0)
+   SB_TRY3(hipMemcpyAsync(d3 + r_isoff, an->iso_off, (size_t)(nl + 1) * 8, hipMemcpyHostToDevice, s));
+   SB_TRY3(hipMemcpyAsync(d3 + r_foff, f_off.data(), (size_t)(nl + 1) * 8, hipMemcpyHostToDevice, s));
+   SB_TRY3(hipMemcpyAsync(d3 + r_segoff, an->seg_off, (size_t)(nl + 1) * 8, hipMemcpyHostToDevice, s));
+   if (n_seg) {
+      SB_TRY3(hipMemcpyAsync(d3 + r_segl, an->seg_left, (size_t)n_seg * 4, hipMemcpyHostToDevice, s));
+      SB_TRY3(hipMemcpyAsync(d3 + r_segr, an->seg_right, (size_t)n_seg * 4, hipMemcpyHostToDevice, s));
+   }
+   SB_TRY3(hipMemcpyAsync(d3 + r_isegoff, iso_seg_off.data(), (size_t)(n_iso + 1) * 8, hipMemcpyHostToDevice, s));
+   if (!iso_seg_idx.empty()) SB_TRY3(hipMemcpyAsync(d3 + r_isegidx, iso_seg_idx.data(), iso_seg_idx.size() * 4, hipMemcpyHostToDevice, s));
+   if (n_iso) {
+      SB_TRY3(hipMemcpyAsync(d3 + r_isoloc, iso_locus.data(), (size_t)n_iso * 4, hipMemcpyHostToDevice, s));
+      SB_TRY3(hipMemcpyAsync(d3 + r_isolen, iso_len.data(), (size_t)n_iso * 4, hipMemcpyHostToDevice, s));
+   }
+   sb::PairsArgs pa;
+   pa.n_iso = n_iso;
+   pa.iso_locus = (const int32_t *)(d3 + r_isoloc);
+   pa.iso_off = (const int64_t *)(d3 + r_isoff);
+   pa.row_off = pk.row_off;
+   pa.f_off = (const int64_t *)(d3 + r_foff);
+   pa.seg_off = (const int64_t *)(d3 + r_segoff);
+   pa.seg_left = (const uint32_t *)(d3 + r_segl);
+   pa.seg_right = (const uint32_t *)(d3 + r_segr);
+   pa.iso_seg_off = (const int64_t *)(d3 + r_isegoff);
+   pa.iso_seg_idx = (const int32_t *)(d3 + r_isegidx);
+   pa.iso_len = (const int32_t *)(d3 + r_isolen);
+   pa.compat_words = compat_words;
+   pa.key_words = key_words;
+   pa.bin_key = pk.bin_key;
+   pa.bin_compat = pk.bin_compat;
+   pa.pair_cnt = (int32_t *)(d3 + r_pcnt);
+   pa.seg_cnt = (int32_t *)(d3 + r_scnt);
+   pa.pair_off = (const int64_t *)(d3 + r_poff);
+   pa.pseg_off = (const int64_t *)(d3 + r_soff);
+   pa.pair_seg_off = nullptr;
+   pa.pair_seg_lens = pa.pair_mask = nullptr;
+   pa.pair_iso_len = nullptr;
+   pa.pair_out_index = nullptr;
+   pa.flags = a.flags;
+   const unsigned pgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_iso + 255) / 256, cap * 4));
+   hipLaunchKernelGGL(sb::bins_pairs_kernel<false>, dim3(pgrid), dim3(256), 0, s, pa);
+   SB_TRY3(hipGetLastError());
+   std::vector<int32_t> pcnt(ni1), scnt(ni1);
+   if (n_iso) {
+      SB_TRY3(hipMemcpyAsync(pcnt.data(), d3 + r_pcnt, (size_t)n_iso * 4, hipMemcpyDeviceToHost, s));
+      SB_TRY3(hipMemcpyAsync(scnt.data(), d3 + r_scnt, (size_t)n_iso * 4, hipMemcpyDeviceToHost, s));
+   }
+   SB_TRY3(hipMemcpyAsync(&flags, d + o_flag, 4, hipMemcpyDeviceToHost, s));
+   SB_TRY3(hipStreamSynchronize(s));
+   if (flags & sb::kBinsMassOverflow) return bail3(SBGPU_EUNSUPPORTED, "sbgpu_bins_create_device: a bin's mass reaches 2^24; use sbgpu_bins_create");
+   if (flags & (sb::kPairsNotUnder | sb::kPairsForeignSegment))
+      return bail3(SBGPU_EUNSUPPORTED, "sbgpu_bins_create_device: a bin does not sit under an isoform it is compatible with; sbgpu_bins_create reports the details");
+   stage("pairs count");
+   std::vector<int64_t> poff((size_t)n_iso + 1, 0), soff((size_t)n_iso + 1, 0);
+   for (int64_t i = 0; i < n_iso; ++i) {
+      poff[(size_t)i + 1] = poff[(size_t)i] + pcnt[(size_t)i];
+      soff[(size_t)i + 1] = soff[(size_t)i] + scnt[(size_t)i];
+   }
+   dp.any_wide = (flags & sb::kPairsWide) != 0;
+   dp.n_pairs = poff[(size_t)n_iso];
+   dp.n_pair_segs = soff[(size_t)n_iso];
+   size_t off4 = 0;
+   dp.o_seg_off = off4; off4 += up(((size_t)dp.n_pairs + 1) * 8);
+   dp.o_out_index = off4; off4 += up(((size_t)dp.n_pairs + 1) * 8);
+   dp.o_seg_lens = off4; off4 += up(((size_t)dp.n_pair_segs + 1) * 4);
+   dp.o_mask = off4; off4 += up(((size_t)dp.n_pairs + 1) * 4);
+   dp.o_iso_len = off4; off4 += up(((size_t)dp.n_pairs + 1) * 4);
+   e = hipMalloc(&dp.arena, off4);
+   if (e != hipSuccess) return bail3(e == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+   SB_TRY3(hipMemcpyAsync(d3 + r_poff, poff.data(), (size_t)(n_iso + 1) * 8, hipMemcpyHostToDevice, s));
+   SB_TRY3(hipMemcpyAsync(d3 + r_soff, soff.data(), (size_t)(n_iso + 1) * 8, hipMemcpyHostToDevice, s));
+   SB_TRY3(hipMemcpyAsync(dp.arena + dp.o_seg_off + (size_t)dp.n_pairs * 8, &dp.n_pair_segs, 8, hipMemcpyHostToDevice, s)); // the CSR's last entry
+   pa.pair_seg_off = (int64_t *)(dp.arena + dp.o_seg_off);
+   pa.pair_seg_lens = (uint32_t *)(dp.arena + dp.o_seg_lens);
+   pa.pair_mask = (uint32_t *)(dp.arena + dp.o_mask);
+   pa.pair_iso_len = (int32_t *)(dp.arena + dp.o_iso_len);
+   pa.pair_out_index = (int64_t *)(dp.arena + dp.o_out_index);
+   hipLaunchKernelGGL(sb::bins_pairs_kernel<true>, dim3(pgrid), dim3(256), 0, s, pa);
+   SB_TRY3(hipGetLastError());
+   SB_TRY3(hipStreamSynchronize(s));
+#undef SB_TRY3
 #undef SB_TRY
+   stage("pairs fill");
    (void)hipFree(d);
    (void)hipFree(d2);
-   if (flags & sb::kBinsMassOverflow)
-      return api_fail(SBGPU_EUNSUPPORTED, "sbgpu_bins_create_device: a bin's mass reaches 2^24; use sbgpu_bins_create");
-   return sb::bins_from_groups(an, compat_words, key_words, row_off.data(), count.data(), key.data(), compat.data(), used, out);
+   (void)hipFree(d3);
+   stage("free");
+   const int rc = sb::bins_from_groups(an, compat_words, key_words, row_off.data(), count.data(), key.data(), compat.data(), used, &dp, out);
+   if (rc != SBGPU_OK) (void)hipFree(dp.arena);
+   stage("handle");
+   return rc;
 }
 
 } // extern "C"

@@ -42,6 +42,9 @@ struct sbgpu_bins {
    std::vector<uint32_t> pair_seg_lens, pair_mask;
    std::vector<int32_t> pair_iso_len;
    std::vector<double> F; // the EM batch's weights, when the handle comes from sbgpu_quantify_host
+   sb::DevicePairs dev;   // pairs made on the device: downloaded into the vectors above on first export
+   bool pairs_on_device = false, pairs_downloaded = false;
+   ~sbgpu_bins() { (void)hipFree(dev.arena); }
 };
 
 namespace {
@@ -208,6 +211,7 @@ struct PreGrouped {
    const int32_t *count;
    const uint32_t *key, *compat;
    int64_t n_hits_used;
+   const sb::DevicePairs *dev; // the pairs too were made on the device
 };
 
 int bins_create_impl(const sbgpu_annotation_t *an, const sbgpu_hits_t *hits, const float *hit_mass,
@@ -257,6 +261,26 @@ int bins_create_impl(const sbgpu_annotation_t *an, const sbgpu_hits_t *hits, con
          int64_t len = 0;
          for (int64_t e = an->exon_off[i]; e < an->exon_off[i + 1]; ++e) len += (int64_t)an->exon_right[e] - an->exon_left[e] + 1;
          B->iso_len[(size_t)i] = (int32_t)len;
+      }
+      if (pre && pre->dev) {
+         // bins and pairs both come from the device: the handle only takes the arrays over
+         B->row_off.assign(pre->row_off, pre->row_off + nl + 1);
+         B->n_bins = B->row_off[(size_t)nl];
+         B->f_off.assign((size_t)nl + 1, 0);
+         for (int64_t l = 0; l < nl; ++l)
+            B->f_off[(size_t)l + 1] = B->f_off[(size_t)l] + (B->row_off[(size_t)l + 1] - B->row_off[(size_t)l]) * (an->iso_off[l + 1] - an->iso_off[l]);
+         B->n_elem = B->f_off[(size_t)nl];
+         B->count.assign(pre->count, pre->count + B->n_bins);
+         B->bin_key.assign(pre->key, pre->key + B->n_bins * key_words);
+         B->bin_compat.assign(pre->compat, pre->compat + B->n_bins * compat_words);
+         B->n_hits_used = pre->n_hits_used;
+         B->dev = *pre->dev;
+         B->pairs_on_device = true;
+         B->n_pairs = pre->dev->n_pairs;
+         B->n_pair_segs = pre->dev->n_pair_segs;
+         stage("take over");
+         *out = B;
+         return SBGPU_OK;
       }
       // hits of each locus, in input order
       std::vector<int64_t> loc_start((size_t)nl + 1, 0), order((size_t)nh);
@@ -372,6 +396,7 @@ int bins_create_impl(const sbgpu_annotation_t *an, const sbgpu_hits_t *hits, con
             R.count[(size_t)b] = (int32_t)sum;
          }
          } // host grouping
+         if (pre && pre->dev) return; // ... and so were the pairs
          const int64_t nb = R.nb;
          // (bin, isoform) pairs of set_theory_bin_weight with ExonBin::bin_under_iso.
          // Isoform::_exon_segs (isoform.h:59-71): the locus' segments inside one of its exons
@@ -526,6 +551,12 @@ int bins_create_impl(const sbgpu_annotation_t *an, const sbgpu_hits_t *hits, con
       return bail(SBGPU_ENOMEM, "sbgpu_bins_create: out of memory");
    }
    if (pre) B->n_hits_used = pre->n_hits_used;
+   if (pre && pre->dev) {
+      B->dev = *pre->dev;
+      B->pairs_on_device = true;
+      B->n_pairs = pre->dev->n_pairs;
+      B->n_pair_segs = pre->dev->n_pair_segs;
+   }
    *out = B;
    return SBGPU_OK;
 }
@@ -536,10 +567,12 @@ namespace sb {
 void bins_set_weights(sbgpu_bins_t *b, std::vector<double> &&F) { b->F = std::move(F); }
 void bins_set_hit_bin(sbgpu_bins_t *b, std::vector<int64_t> &&hb) { b->hit_bin = std::move(hb); }
 const double *bins_weights_tail(const sbgpu_bins_t *b, size_t at) { return b->F.data() + at; }
+const DevicePairs *bins_device_pairs(const sbgpu_bins_t *b) { return b && b->pairs_on_device ? &b->dev : nullptr; }
 int bins_from_groups(const sbgpu_annotation_t *an, int32_t compat_words, int32_t key_words, const int64_t *row_off,
-                     const int32_t *count, const uint32_t *key, const uint32_t *compat, int64_t n_hits_used, sbgpu_bins_t **out)
+                     const int32_t *count, const uint32_t *key, const uint32_t *compat, int64_t n_hits_used,
+                     const DevicePairs *pairs, sbgpu_bins_t **out)
 {
-   const PreGrouped pre = {row_off, count, key, compat, n_hits_used};
+   const PreGrouped pre = {row_off, count, key, compat, n_hits_used, pairs};
    return bins_create_impl(an, nullptr, nullptr, compat_words, key_words, nullptr, nullptr, &pre, out);
 }
 } // namespace sb
@@ -584,6 +617,24 @@ int sbgpu_bins_export(const sbgpu_bins_t *b, int64_t *row_off, int64_t *iso_off,
                       int32_t *pair_iso_len, int64_t *pair_out_index)
 {
    if (!b) return api_fail(SBGPU_EINVAL, "sbgpu_bins_export: null argument");
+   if (b->pairs_on_device && !b->pairs_downloaded &&
+       (pair_seg_off || pair_seg_lens || pair_implicit_mask || pair_iso_len || pair_out_index)) {
+      // pairs made on the device: bring them over once, now that somebody wants them on the host
+      sbgpu_bins *m = const_cast<sbgpu_bins *>(b);
+      const sb::DevicePairs &d = b->dev;
+      m->pair_seg_off.assign((size_t)d.n_pairs + 1, 0);
+      m->pair_seg_lens.assign((size_t)d.n_pair_segs, 0);
+      m->pair_mask.assign((size_t)d.n_pairs, 0);
+      m->pair_iso_len.assign((size_t)d.n_pairs, 0);
+      m->pair_out_index.assign((size_t)d.n_pairs, 0);
+      hipError_t e = hipMemcpy(m->pair_seg_off.data(), d.seg_off(), ((size_t)d.n_pairs + 1) * 8, hipMemcpyDeviceToHost);
+      if (e == hipSuccess && d.n_pair_segs) e = hipMemcpy(m->pair_seg_lens.data(), d.seg_lens(), (size_t)d.n_pair_segs * 4, hipMemcpyDeviceToHost);
+      if (e == hipSuccess && d.n_pairs) e = hipMemcpy(m->pair_mask.data(), d.mask(), (size_t)d.n_pairs * 4, hipMemcpyDeviceToHost);
+      if (e == hipSuccess && d.n_pairs) e = hipMemcpy(m->pair_iso_len.data(), d.iso_len(), (size_t)d.n_pairs * 4, hipMemcpyDeviceToHost);
+      if (e == hipSuccess && d.n_pairs) e = hipMemcpy(m->pair_out_index.data(), d.out_index(), (size_t)d.n_pairs * 8, hipMemcpyDeviceToHost);
+      if (e != hipSuccess) return api_fail(SBGPU_EHIP, std::string("sbgpu_bins_export: download of the pairs: ") + hipGetErrorString(e));
+      m->pairs_downloaded = true;
+   }
 #define SB_COPY(dst, vec)                                                              \
    if (dst && !(vec).empty()) std::memcpy(dst, (vec).data(), (vec).size() * sizeof((vec)[0]))
    SB_COPY(row_off, b->row_off);
