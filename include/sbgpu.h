@@ -360,7 +360,7 @@ int sbgpu_bins_create(const sbgpu_annotation_t *annot, const sbgpu_hits_t *hits,
  * The device form is exact only where the order of the reference's float accumulation cannot
  * matter, and it checks that: hits of a locus sorted by (left end, right end) (HitCluster's order),
  * whole-number masses below 2^24 per bin (the reference's default: no multi-mapped reads), at most
- * 2800 bins per locus.  Otherwise it returns SBGPU_EUNSUPPORTED and the caller uses
+ * 5600 bins per locus.  Otherwise it returns SBGPU_EUNSUPPORTED and the caller uses
  * sbgpu_bins_create.  Synchronises on `stream`.                                                  */
 int sbgpu_bins_create_device(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *annot, const sbgpu_hits_t *d_hits,
                              const float *d_hit_mass, const int64_t *locus_hit_off, int32_t compat_words,

@@ -23,14 +23,18 @@
 
 namespace sb {
 
-constexpr int kBinsSlots = 4096;            // LDS table: 16 B per slot + 4 B per listed bin
-constexpr int kBinsMaxPerLocus = 2800;      // ~0.7 load
+// Two table sizes: loci of up to 256 hits (most of them) take 1024 slots -- 18 KB of LDS, so that many
+// workgroups share a CU and hide each other's memory latency -- the others 8192 (140 KB, one per CU).
+constexpr int kBinsSlotsSmall = 1024, kBinsMaxSmall = 256;   // at most one bin per hit
+constexpr int kBinsSlotsBig = 8192, kBinsMaxBig = 5600;      // ~0.7 load
+constexpr int kBinsSmallHits = 256;
 constexpr int kBinsThreads = 256;
 enum : int32_t { kBinsUnsorted = 1, kBinsFractional = 2, kBinsTableFull = 4, kBinsMassOverflow = 8 };
 
 struct BinsArgs {
-   int64_t n_loci;
-   const int64_t *locus_hit_off; // [n_loci + 1]: hits are grouped by locus
+   int64_t n_loci;               // loci in `loci`
+   const int32_t *loci;          // the loci this launch serves (small or big ones)
+   const int64_t *locus_hit_off; // [all loci + 1]: hits are grouped by locus
    const int64_t *feat_off;
    const uint32_t *feat_left, *feat_right;
    const float *mass;
@@ -58,13 +62,14 @@ __device__ __forceinline__ uint32_t bins_hash(const uint32_t *k, int kw)
 // A slot's tag = hash << 32 | (member hit - first hit of the locus + 1), written by one atomicCAS, so a
 // reader never sees a claimed slot without its member.
 template <bool INSERT>
-__device__ __forceinline__ int bins_find(unsigned long long *tag, const BinsArgs &a, int64_t q0, int64_t h, const uint32_t *kh)
+__device__ __forceinline__ int bins_find(unsigned long long *tag, int slots, const BinsArgs &a, int64_t q0, int64_t h,
+                                         const uint32_t *kh)
 {
    const int kw = a.key_words;
    const uint32_t hv = bins_hash(kh, kw);
    const unsigned long long mine = ((unsigned long long)hv << 32) | (unsigned long long)(h - q0 + 1);
-   int slot = (int)(hv >> 1) & (kBinsSlots - 1);
-   for (int probe = 0; probe < kBinsSlots; ++probe) {
+   int slot = (int)(hv >> 1) & (slots - 1);
+   for (int probe = 0; probe < slots; ++probe) {
       unsigned long long t = tag[slot];
       if (t == 0ull && INSERT) {
          t = atomicCAS(&tag[slot], 0ull, mine);
@@ -77,7 +82,7 @@ __device__ __forceinline__ int bins_find(unsigned long long *tag, const BinsArgs
          for (int w = 0; w < kw; ++w) same &= kr[w] == kh[w];
          if (same) return slot;
       }
-      slot = (slot + 1) & (kBinsSlots - 1);
+      slot = (slot + 1) & (slots - 1);
    }
    return -1;
 }
@@ -92,6 +97,7 @@ __device__ __forceinline__ bool bins_same_fragment(const BinsArgs &a, int64_t x,
    return true;
 }
 
+template <int kBinsSlots, int kBinsMaxPerLocus>
 __global__ __launch_bounds__(kBinsThreads) void bins_locus_kernel(BinsArgs a)
 {
    __shared__ unsigned long long tag[kBinsSlots];
@@ -99,9 +105,14 @@ __global__ __launch_bounds__(kBinsThreads) void bins_locus_kernel(BinsArgs a)
    __shared__ int used[kBinsMaxPerLocus], used_rank[kBinsMaxPerLocus];
    __shared__ int n_used_slots, n_hits_in, bad;
    const int tid = threadIdx.x;
-   for (int64_t l = blockIdx.x; l < a.n_loci; l += gridDim.x) {
+   for (int64_t li = blockIdx.x; li < a.n_loci; li += gridDim.x) {
+      const int64_t l = a.loci[li];
       const int64_t q0 = a.locus_hit_off[l], q1 = a.locus_hit_off[l + 1];
-      for (int s = tid; s < kBinsSlots; s += kBinsThreads) {
+      // the table is as large as the locus needs (at most one bin per hit, load <= 1/4): small loci neither
+      // clear nor scan 4096 slots
+      int slots = 64;
+      while (slots < kBinsSlots && slots < 4 * (q1 - q0)) slots <<= 1;
+      for (int s = tid; s < slots; s += kBinsThreads) {
          tag[s] = 0ull;
          first[s] = 0x7fffffff;
       }
@@ -125,7 +136,7 @@ __global__ __launch_bounds__(kBinsThreads) void bins_locus_kernel(BinsArgs a)
          if (!any_c || !any_k) continue;
          const float m = a.mass[h];
          if (!(m >= 0.0f && m < 16777216.0f && (float)(int)m == m)) my_bad |= kBinsFractional;
-         const int slot = bins_find<true>(tag, a, q0, h, a.key + h * kw);
+         const int slot = bins_find<true>(tag, slots, a, q0, h, a.key + h * kw);
          if (slot < 0) {
             my_bad |= kBinsTableFull;
             continue;
@@ -135,7 +146,7 @@ __global__ __launch_bounds__(kBinsThreads) void bins_locus_kernel(BinsArgs a)
       if (my_bad) atomicOr(&bad, my_bad);
       __syncthreads();
       // ---- the bins, ranked by their first hit
-      for (int s = tid; s < kBinsSlots; s += kBinsThreads)
+      for (int s = tid; s < slots; s += kBinsThreads)
          if (tag[s] != 0ull) {
             const int k = atomicAdd(&n_used_slots, 1);
             if (k < kBinsMaxPerLocus) used[k] = s;
@@ -167,7 +178,7 @@ __global__ __launch_bounds__(kBinsThreads) void bins_locus_kernel(BinsArgs a)
          for (int w = 0; w < cw; ++w) any_c |= a.compat[h * cw + w];
          for (int w = 0; w < kw; ++w) any_k |= a.key[h * kw + w];
          if (!any_c || !any_k) continue;
-         const int slot = bins_find<false>(tag, a, q0, h, a.key + h * kw);
+         const int slot = bins_find<false>(tag, slots, a, q0, h, a.key + h * kw);
          if (slot < 0) continue; // table was full
          const int b = first[slot];
          a.hit_bin_local[h] = b;
@@ -187,7 +198,7 @@ __global__ __launch_bounds__(kBinsThreads) void bins_locus_kernel(BinsArgs a)
             for (int w = 0; w < cw; ++w) pc |= a.compat[p * cw + w];
             for (int w = 0; w < kw; ++w) pk |= a.key[p * kw + w];
             if (!pc || !pk) continue;
-            const int ps = bins_find<false>(tag, a, q0, p, a.key + p * kw);
+            const int ps = bins_find<false>(tag, slots, a, q0, p, a.key + p * kw);
             dup = ps >= 0 && first[ps] == b;
          }
          if (!dup) atomicAdd(&a.bin_count[q0 + b], (int)a.mass[h]);

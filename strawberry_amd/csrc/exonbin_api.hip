@@ -207,6 +207,7 @@ int sbgpu_bins_create_device(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const
    const size_t o_flag = off; off += 256;
    const size_t o_hoff = off; off += up((size_t)(nl + 1) * 8);
    const size_t o_roff = off; off += up((size_t)(nl + 1) * 8);
+   const size_t o_order = off; off += up((size_t)nl * 4);
    char *d = nullptr, *d2 = nullptr;
    hipError_t e = hipMalloc(&d, off);
    if (e != hipSuccess) return api_fail(e == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e));
@@ -242,7 +243,28 @@ int sbgpu_bins_create_device(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const
    a.n_used = (int32_t *)(d + o_nu);
    a.flags = (int32_t *)(d + o_flag);
    const int64_t cap = (int64_t)sb::ctx_cu_count(c) * 8;
-   hipLaunchKernelGGL(sb::bins_locus_kernel, dim3((unsigned)(nl < cap ? nl : cap)), dim3(sb::kBinsThreads), 0, s, a);
+   // small and big loci in two launches (two LDS table sizes)
+   std::vector<int32_t> order((size_t)nl);
+   int64_t n_small = 0;
+   for (int64_t l = 0; l < nl; ++l)
+      if (locus_hit_off[l + 1] - locus_hit_off[l] <= sb::kBinsSmallHits) order[(size_t)n_small++] = (int32_t)l;
+   int64_t n_big = 0;
+   for (int64_t l = 0; l < nl; ++l)
+      if (locus_hit_off[l + 1] - locus_hit_off[l] > sb::kBinsSmallHits) order[(size_t)(n_small + n_big++)] = (int32_t)l;
+   SB_TRY(hipMemcpyAsync(d + o_order, order.data(), (size_t)nl * 4, hipMemcpyHostToDevice, s));
+   if (n_small) {
+      a.n_loci = n_small;
+      a.loci = (const int32_t *)(d + o_order);
+      hipLaunchKernelGGL((sb::bins_locus_kernel<sb::kBinsSlotsSmall, sb::kBinsMaxSmall>), dim3((unsigned)std::min<int64_t>(n_small, cap * 4)),
+                         dim3(sb::kBinsThreads), 0, s, a);
+      SB_TRY(hipGetLastError());
+   }
+   if (n_big) {
+      a.n_loci = n_big;
+      a.loci = (const int32_t *)(d + o_order) + n_small;
+      hipLaunchKernelGGL((sb::bins_locus_kernel<sb::kBinsSlotsBig, sb::kBinsMaxBig>), dim3((unsigned)std::min<int64_t>(n_big, cap)),
+                         dim3(sb::kBinsThreads), 0, s, a);
+   }
    SB_TRY(hipGetLastError());
    std::vector<int32_t> nb((size_t)nl), nu((size_t)nl);
    int32_t flags = 0;

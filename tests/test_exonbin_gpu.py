@@ -241,11 +241,18 @@ def test_device_grouping_multiword_keys_and_table_limit(ctx):
     assert bd is not None and bh.n_bins > 1000
     for x, y in zip(bins_arrays_no_pairs(bd), bins_arrays_no_pairs(bh)):
         np.testing.assert_array_equal(x, y)
-    # ~5000 different keys in one locus: more than the table holds -> declined, the host form does it
-    hits, compat, key = make(6000, 14000, n_loci=1)
+    # a locus with ~4000 bins goes through the big table
+    hits, compat, key = make(5000, 12000, n_loci=1)
     annot1 = eb.Annotation(loci[:1])
     bd, bh = group_both_ways(ctx, annot1, hits, compat, key)
-    assert bd is None and bh.n_bins > 2800
+    assert bd is not None and bh.n_bins > 3000
+    for x, y in zip(bins_arrays_no_pairs(bd), bins_arrays_no_pairs(bh)):
+        np.testing.assert_array_equal(x, y)
+    # ~12000 different keys in one locus: more than the (big) table holds -> declined, the host form does it
+    hits, compat, key = make(14000, 36000, n_loci=1)
+    annot1 = eb.Annotation(loci[:1])
+    bd, bh = group_both_ways(ctx, annot1, hits, compat, key)
+    assert bd is None and bh.n_bins > 8192
 
 
 def bins_arrays_no_pairs(b):
