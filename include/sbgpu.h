@@ -13,8 +13,14 @@
  * One call per locus would serialise the GPU, so the boundary is BATCHED: the
  * host collects the (n, alpha) of many loci into a CSR-of-loci arena, one call
  * solves them all, and the per-locus result is (theta, status, iters).  The
- * per-locus EmSolver-shaped adapter lives above this ABI (strawberry_amd/em.py,
- * INTEGRATION.md shows the C++ one).
+ * per-locus EmSolver-shaped adapter lives above this ABI (include/sbgpu_host.hpp in
+ * C++14, strawberry_amd/em.py for the Python harness).
+ *
+ * Around that seam the same batching covers what feeds it: read pairs ->
+ * unique hits (sbgpu_collapse_pairs_host), hit x isoform compatibility and exon bins
+ * (sbgpu_exonbin_*, sbgpu_bins_create*), bin weights (sbgpu_binweight_*), and what follows it:
+ * FPKM / Frac / TPM (sbgpu_abundance_device, sbgpu_tpm_device) and the reference's two output
+ * formats (sbgpu_format_*).  sbgpu_quantify_host chains them in one call.
  *
  * Conventions: plain pointers and sizes only; every function returns 0 on
  * success and a negative SBGPU_E* code on failure (sbgpu_last_error() has the
