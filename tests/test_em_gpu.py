@@ -203,3 +203,33 @@ def test_gpu_every_schedule_gives_the_same_answer(ctx, oracle, monkeypatch, env)
     np.testing.assert_array_equal(r["status"], o_status)
     np.testing.assert_array_equal(r["iters"], o_iters)
     assert theta_err(r["theta"], o_theta).max() < THETA_RTOL
+
+
+@pytest.mark.gpu
+def test_plan_is_independent_of_host_thread_count(monkeypatch):
+    """sbgpu_plan_create classifies and sorts the loci on host threads; the plan (classes, their loci, the
+    kernel kind of every locus) and hence the results must not depend on how many."""
+    from strawberry_amd import em, synth
+    b = synth.make_c3(n_loci=40000)
+    ctx = em.default_context(0)
+    ref = None
+    for nt in ("1", "3", "16"):
+        monkeypatch.setenv("SBGPU_HOST_THREADS", nt)
+        p = em.Plan(ctx, b.row_off, b.iso_off, b.f_off)
+        got = (p.info(), p.classes(), p.locus_kinds().tolist())
+        p.close()
+        if ref is None:
+            ref = got
+            assert got[0]["n_classes"] > 50
+        else:
+            assert got == ref
+    monkeypatch.setenv("SBGPU_HOST_THREADS", "16")
+    s16 = em.EmBatchSolver(b, ctx)
+    s16.run_em()
+    r16 = s16.results()
+    monkeypatch.setenv("SBGPU_HOST_THREADS", "1")
+    s1 = em.EmBatchSolver(b, ctx)
+    s1.run_em()
+    r1 = s1.results()
+    np.testing.assert_array_equal(r1["theta"], r16["theta"])
+    np.testing.assert_array_equal(r1["iters"], r16["iters"])
