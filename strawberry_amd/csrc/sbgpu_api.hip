@@ -467,8 +467,8 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
    const int ncls = (int)p->host.classes.size();
    const size_t ncls_alloc = (size_t)ncls + 1;
    const int nph = (int)p->phase_limits.size();
-   HIP_TRY(hipMemsetAsync(p->d_cursors, 0, (size_t)(nph + 1) * ncls_alloc * sizeof(int32_t), main));
-   HIP_TRY(hipMemsetAsync(p->d_counts, 0, (size_t)(nph + 1) * ncls_alloc * sizeof(int32_t), main));
+   // cursors and counts sit next to each other in the plan's arena: one memset clears both
+   HIP_TRY(hipMemsetAsync(p->d_cursors, 0, (size_t)((char *)p->d_counts - (char *)p->d_cursors) + (size_t)(nph + 1) * ncls_alloc * sizeof(int32_t), main));
    // one launch per kind and phase (wave / block / stream); a single kind runs on the
    // caller's stream, several fork onto the aux streams and join back
    int kinds = 0;
