@@ -188,7 +188,7 @@ def main():
     kinds = solver.plan.locus_kinds()
     kind_names = ["em_fused_kernel<0,1> (wave form, half tile)", "em_fused_kernel<0,2> (wave form, base tile)",
                   "em_fused_kernel<0,4> (wave form, double tile)", "em_fused_kernel<4,2> (256-lane block form)",
-                  "em_fused_kernel<4,12> (256-lane block form, tall tile)", "em_stream_kernel"]
+                  "em_fused_kernel<4,12> (256-lane block form, tall tile)", "em_wide_kernel (several workgroups per locus) + em_stream_kernel"]
     dom = int(np.argmax(kern_ms))
     sel = kinds == dom
     nrow, niso = batch.nrow, batch.niso

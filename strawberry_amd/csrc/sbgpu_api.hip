@@ -17,6 +17,7 @@
 #include "api_internal.h"
 #include "binweight_device.h"
 #include "em_device.h"
+#include "em_wide.h"
 #include "plan.h"
 
 namespace {
@@ -56,6 +57,7 @@ struct sbgpu_ctx {
    hipEvent_t join[kAuxStreams] = {};
    hipEvent_t t0[sb::kNumKinds] = {}, t1[sb::kNumKinds] = {}; // per-kind kernel timing
    bool timed[sb::kNumKinds] = {};
+   int32_t *wide_error = nullptr; // pinned host word the wide-locus kernel raises when a barrier times out
 };
 
 namespace sb {
@@ -88,6 +90,16 @@ struct sbgpu_plan {
    uint8_t *d_row_keep = nullptr;      // streaming path: init() row flags
    double *d_locus_sum = nullptr;      // abundance epilogue: kept-FPKM sum per locus
    size_t stream_lds_bytes = 0;
+   // wide loci (kStream class) served by the cooperative multi-workgroup kernel, in launches ("rounds")
+   struct WideRound {
+      int nslot = 2, first_desc = 0, n_desc = 0, n_blocks = 0;
+      size_t lds_bytes = 0;
+   };
+   std::vector<WideRound> wide_rounds;
+   sb::WideDesc *d_wide_table = nullptr; // all rounds' descriptors
+   double *d_wide_bufs = nullptr;
+   unsigned *d_wide_barriers = nullptr;
+   int32_t n_wide_desc = 0, n_wide_loci = 0; // the first n_wide_loci of the stream class' list go to the wide kernel
 };
 
 namespace {
@@ -221,6 +233,8 @@ int sbgpu_init(int device, sbgpu_ctx_t **ctx_out)
       if (e == hipSuccess) e = hipEventCreateWithFlags(&c->join[i], hipEventDisableTiming);
    }
    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
+   if (e == hipSuccess) e = hipHostMalloc((void **)&c->wide_error, sizeof(int32_t), hipHostMallocDefault);
+   if (e == hipSuccess) *c->wide_error = 0;
    for (int k = 0; e == hipSuccess && k < sb::kNumKinds; ++k) {
       e = hipEventCreate(&c->t0[k]);
       if (e == hipSuccess) e = hipEventCreate(&c->t1[k]);
@@ -247,6 +261,7 @@ int sbgpu_finalize(sbgpu_ctx_t *c)
       if (c->t1[k]) (void)hipEventDestroy(c->t1[k]);
    }
    if (c->stream) (void)hipStreamDestroy(c->stream);
+   if (c->wide_error) (void)hipHostFree(c->wide_error);
    delete c;
    return SBGPU_OK;
 }
@@ -267,6 +282,10 @@ int sbgpu_synchronize(sbgpu_ctx_t *c, void *stream)
 {
    if (!c) return fail(SBGPU_EINVAL, "sbgpu_synchronize: null ctx");
    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+   if (c->wide_error && *c->wide_error) {
+      *c->wide_error = 0;
+      return fail(SBGPU_EHIP, "a barrier of the wide-locus EM kernel timed out: the loci it served have no result");
+   }
    return SBGPU_OK;
 }
 
@@ -334,6 +353,61 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
       }
       p->phase_limits.push_back(SBGPU_EM_MAX_ITER);
    }
+   // ---- wide loci: the streaming class is served by the multi-workgroup kernel wherever a locus' rows fit
+   // into n_cu workgroups; such loci move to the front of the class list, the rest keeps the streaming kernel
+   std::vector<sb::WideDesc> wide_table;
+   size_t wide_buf_doubles = 0;
+   for (sb::SizeClass &sc : p->host.classes) {
+      if (sc.kind != sb::kStream) continue;
+      std::vector<int32_t> wide_loci[3], rest; // by template: 2, 4, 8 columns per lane
+      for (int32_t l : sc.loci) {
+         const int64_t nrow = row_off[l + 1] - row_off[l], niso = iso_off[l + 1] - iso_off[l];
+         const int need = (int)((niso + 63) / 64);
+         const int t = need <= 2 ? 0 : (need <= 4 ? 1 : 2);
+         const int ns = 2 << t;
+         const int64_t rpb = (int64_t)sb::kWideWaves * sb::wide_rows(ns);
+         const int64_t G = std::max<int64_t>(1, (nrow + rpb - 1) / rpb);
+         if (need <= 8 && G <= c->n_cu && !std::getenv("SBGPU_NO_WIDE")) wide_loci[t].push_back(l);
+         else rest.push_back(l);
+      }
+      sc.loci.clear();
+      for (int t = 0; t < 3; ++t) {
+         const int ns = 2 << t;
+         const int64_t rpb = (int64_t)sb::kWideWaves * sb::wide_rows(ns);
+         sbgpu_plan::WideRound round;
+         round.nslot = ns;
+         round.first_desc = (int)wide_table.size();
+         for (int32_t l : wide_loci[t]) {
+            const int64_t nrow = row_off[l + 1] - row_off[l], niso = iso_off[l + 1] - iso_off[l];
+            const int G = (int)std::max<int64_t>(1, (nrow + rpb - 1) / rpb);
+            if (round.n_blocks + G > c->n_cu) { // this launch is full: all its workgroups must be resident
+               p->wide_rounds.push_back(round);
+               round = sbgpu_plan::WideRound();
+               round.nslot = ns;
+               round.first_desc = (int)wide_table.size();
+            }
+            sb::WideDesc d;
+            d.locus = l;
+            d.first_block = round.n_blocks;
+            d.n_blocks = G;
+            d.rows_per_block = (int32_t)rpb;
+            d.npad = 64 * (int32_t)((niso + 63) / 64);
+            d.buf_off = (int64_t)wide_buf_doubles;
+            d.barrier = (int32_t)wide_table.size();
+            wide_buf_doubles += (size_t)2 * G * (d.npad + 2);
+            round.n_blocks += G;
+            round.n_desc += 1;
+            round.lds_bytes = std::max(round.lds_bytes, (size_t)(3 * d.npad + sb::kWideWaves * (d.npad + 2)) * sizeof(double));
+            wide_table.push_back(d);
+            sc.loci.push_back(l);
+         }
+         if (round.n_desc) p->wide_rounds.push_back(round);
+      }
+      p->n_wide_loci = (int32_t)sc.loci.size();
+      sc.loci.insert(sc.loci.end(), rest.begin(), rest.end());
+      sc.n_blocks = (int)rest.size(); // what is left for the streaming kernel
+   }
+   p->n_wide_desc = (int32_t)wide_table.size();
    const size_t ncls = p->host.classes.size();
    const size_t ncls_alloc = ncls + 1;
    const size_t nph = p->phase_limits.size() + 1;
@@ -347,6 +421,7 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
    const size_t o_loci = at; at += up((size_t)(n_loci + 1) * sizeof(int32_t));
    const size_t o_tab = at; at += up(ncls_alloc * sizeof(sb::ClassDesc));
    const size_t o_cn = at; at += up(ncls_alloc * sizeof(int32_t));
+   const size_t o_wtab = at; at += up((wide_table.size() + 1) * sizeof(sb::WideDesc));
    const size_t staged = at;
    const size_t o_cur = at; at += up(nph * ncls_alloc * sizeof(int32_t));
    const size_t o_cnt = at; at += up(nph * ncls_alloc * sizeof(int32_t));
@@ -354,6 +429,8 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
    const size_t o_l1 = at; at += up((size_t)(n_loci + 1) * sizeof(int32_t));
    const size_t o_keep = at; at += up((size_t)p->host.n_rows + 1);
    const size_t o_sum = at; at += up((size_t)(n_loci + 1) * sizeof(double));
+   const size_t o_wbar = at; at += up((wide_table.size() + 1) * sizeof(unsigned));
+   const size_t o_wbuf = at; at += up((wide_buf_doubles + 1) * sizeof(double));
    if ((e = hipMalloc(&p->d_arena, at)) != hipSuccess) return bail(e, "hipMalloc(plan arena)");
    stage("hipMalloc");
    p->d_row_off = (int64_t *)(p->d_arena + o_row);
@@ -368,6 +445,9 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
    p->d_lists[1] = (int32_t *)(p->d_arena + o_l1);
    p->d_row_keep = (uint8_t *)(p->d_arena + o_keep);
    p->d_locus_sum = (double *)(p->d_arena + o_sum);
+   p->d_wide_table = (sb::WideDesc *)(p->d_arena + o_wtab);
+   p->d_wide_barriers = (unsigned *)(p->d_arena + o_wbar);
+   p->d_wide_bufs = (double *)(p->d_arena + o_wbuf);
    std::vector<char> stage_buf(staged, 0);
    if (n_loci > 0) {
       std::memcpy(stage_buf.data() + o_row, row_off, nb);
@@ -377,6 +457,7 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
    int32_t *h_loci = (int32_t *)(stage_buf.data() + o_loci);
    sb::ClassDesc *table = (sb::ClassDesc *)(stage_buf.data() + o_tab);
    int32_t *h_cn = (int32_t *)(stage_buf.data() + o_cn);
+   if (!wide_table.empty()) std::memcpy(stage_buf.data() + o_wtab, wide_table.data(), wide_table.size() * sizeof(sb::WideDesc));
    size_t off = 0;
    size_t max_stream_iso = 0;
    for (int k = 0; k < sb::kNumKinds; ++k) p->launches[k] = KindLaunch();
@@ -487,11 +568,30 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
       hipStream_t s = fork ? c->aux[kKindStream[k]] : main;
       HIP_TRY(hipEventRecord(c->t0[k], s));
       if (k == sb::kStream) {
-         sb::ClassArgs ca = {};
-         ca.loci = p->d_loci_all + p->loci_off[kl.first_class];
-         ca.n = (int32_t)p->host.classes[kl.first_class].loci.size();
-         ca.cursor = p->d_cursors + kl.first_class;
-         HIP_TRY(sb::launch_stream(a, ca, p->d_row_keep, kl.n_blocks, p->stream_lds_bytes, s));
+         // wide loci: cooperative launches, one per round (all workgroups of a launch are resident)
+         if (p->n_wide_desc) {
+            HIP_TRY(hipMemsetAsync(p->d_wide_barriers, 0, (size_t)p->n_wide_desc * sizeof(unsigned), s));
+            int32_t *d_err = nullptr;
+            HIP_TRY(hipHostGetDevicePointer((void **)&d_err, c->wide_error, 0));
+            for (const sbgpu_plan::WideRound &r : p->wide_rounds) {
+               sb::WideArgs wa;
+               wa.a = a;
+               wa.table = p->d_wide_table + r.first_desc;
+               wa.n_desc = r.n_desc;
+               wa.bufs = p->d_wide_bufs;
+               wa.barriers = p->d_wide_barriers;
+               wa.error = d_err;
+               HIP_TRY(sb::launch_wide(r.nslot, wa, r.n_blocks, r.lds_bytes, s));
+            }
+         }
+         const int32_t n_all = (int32_t)p->host.classes[kl.first_class].loci.size();
+         if (n_all > p->n_wide_loci) { // the rest: one workgroup per locus, F streamed from L2
+            sb::ClassArgs ca = {};
+            ca.loci = p->d_loci_all + p->loci_off[kl.first_class] + p->n_wide_loci;
+            ca.n = n_all - p->n_wide_loci;
+            ca.cursor = p->d_cursors + kl.first_class;
+            HIP_TRY(sb::launch_stream(a, ca, p->d_row_keep, ca.n, p->stream_lds_bytes, s));
+         }
       } else {
          // phase ph runs the loci still alive up to phase_limits[ph] iterations and appends
          // the unfinished ones to the next phase's list; later phases launch the same grid,
@@ -622,6 +722,10 @@ int sbgpu_em_batch(sbgpu_ctx_t *c, const sbgpu_batch_t *b, double *theta_out, in
    TRY_CLEAN(hipStreamSynchronize(c->stream));
 #undef TRY_CLEAN
    cleanup();
+   if (c->wide_error && *c->wide_error) {
+      *c->wide_error = 0;
+      return fail(SBGPU_EHIP, "sbgpu_em_batch: a barrier of the wide-locus EM kernel timed out");
+   }
    return SBGPU_OK;
 }
 

@@ -233,3 +233,38 @@ def test_plan_is_independent_of_host_thread_count(monkeypatch):
     r1 = s1.results()
     np.testing.assert_array_equal(r1["theta"], r16["theta"])
     np.testing.assert_array_equal(r1["iters"], r16["iters"])
+
+
+@pytest.mark.gpu
+def test_wide_loci_multi_workgroup_kernel(oracle, monkeypatch):
+    """Loci with more than 64 isoforms (or more rows than a workgroup's tile) run on the cooperative
+    multi-workgroup kernel: several workgroups per locus, one exchange per iteration.  All three template
+    widths (<= 128, <= 256, <= 512 isoforms), single- and multi-workgroup loci, next to ordinary loci in the
+    same batch; status and iteration counts exact, theta to 1e-9 -- and the same through the streaming
+    kernel (SBGPU_NO_WIDE=1), which stays the fallback."""
+    from strawberry_amd import em, synth
+    from strawberry_amd.synth import _generate
+    rng = np.random.Generator(np.random.PCG64(2024))
+    niso = np.array([65, 100, 128, 129, 200, 256, 300, 420, 70, 90], np.int64)
+    nrow = np.array([40, 700, 1500, 90, 1100, 300, 900, 200, 3, 2500], np.int64)
+    wide = _generate(rng, nrow, niso, (nrow * 40).astype(np.int64), name="wide")
+    small = synth.make_random(n_loci=200, seed=77)
+    loci = [wide.locus(l) for l in range(wide.n_loci)] + [small.locus(l) for l in range(small.n_loci)]
+    b = synth.from_loci(loci)
+    o_theta, o_status, o_iters = oracle.em_batch(b.row_off, b.iso_off, b.f_off, b.count, b.F, threads=8)
+    ctx = em.default_context(0)
+    for no_wide in ("", "1"):
+        if no_wide:
+            monkeypatch.setenv("SBGPU_NO_WIDE", "1")
+        else:
+            monkeypatch.delenv("SBGPU_NO_WIDE", raising=False)
+        s = em.EmBatchSolver(b, ctx)
+        kinds = s.plan.locus_kinds()
+        assert (kinds[:10] == 5).all()
+        s.run_em()
+        r = s.results()
+        np.testing.assert_array_equal(r["status"], o_status)
+        np.testing.assert_array_equal(r["iters"], o_iters)
+        err = np.abs(r["theta"] - o_theta) / np.maximum(np.abs(o_theta), 1e-9)
+        assert err.max() < 1e-9, (no_wide, err.max())
+    assert o_iters[:10].max() > 100

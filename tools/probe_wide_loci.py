@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""GPU box: what do a few very wide loci (more than 64 isoforms: the streaming kernel) cost next to C3?"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from strawberry_amd import em, synth
+from strawberry_amd.synth import _generate
+ctx = em.default_context(0)
+def run(b, label):
+    s = em.EmBatchSolver(b, ctx)
+    s.run_em(); torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        s.run_em(); torch.cuda.synchronize()
+        ms = s.last_kernel_ms()
+        best = min(best, max(ms))
+    r = s.results()
+    print("%-34s %6d loci  max kernel %.3f ms  per kind %s  iters max %d" % (label, b.n_loci, best, ["%.2f" % x for x in ms], r["iters"].max()), flush=True)
+    return r
+rng = np.random.Generator(np.random.PCG64(99))
+for n_wide in (1, 20):
+    niso = rng.integers(70, 200, n_wide).astype(np.int64)
+    nrow = rng.integers(300, 2000, n_wide).astype(np.int64)
+    nfr = (nrow * 50).astype(np.int64)
+    wide = _generate(rng, nrow, niso, nfr, name="wide")
+    r = run(wide, "%d wide loci alone" % n_wide)
+    for l in range(min(n_wide, 4)):
+        print("    locus %d: %d x %d, %d iterations" % (l, nrow[l], niso[l], r["iters"][l]))
