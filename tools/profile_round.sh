@@ -39,4 +39,7 @@ cp $OUT/exonbin/stats/eb_kernel_stats.csv $SUM/${R}_exonbin_kernel_stats.csv
 bash tools/profile_binweight.sh $R > /dev/null 2>&1
 cp $OUT/binweight/summary.json $SUM/${R}_binweight_summary.json
 cp $OUT/binweight/bench_binweight.json $SUM/${R}_bench_binweight.json
+# wide loci (> 64 isoforms): multi-workgroup kernel vs the streaming fallback
+(echo "em_wide_kernel (default):"; timeout 300 python tools/probe_wide_loci.py 2>/dev/null | grep "wide loci alone"; \
+ echo "em_stream_kernel only (SBGPU_NO_WIDE=1):"; SBGPU_NO_WIDE=1 timeout 300 python tools/probe_wide_loci.py 2>/dev/null | grep "wide loci alone") > $SUM/${R}_wide_loci.txt
 cat $SUM/${R}_pytest_gpu.txt; cat $SUM/${R}_bench_c3.json; echo; cat $SUM/${R}_bench_c2.json; echo; ls -la $SUM
