@@ -58,6 +58,7 @@ struct sbgpu_ctx {
    hipEvent_t t0[sb::kNumKinds] = {}, t1[sb::kNumKinds] = {}; // per-kind kernel timing
    bool timed[sb::kNumKinds] = {};
    int32_t *wide_error = nullptr; // pinned host word the wide-locus kernel raises when a barrier times out
+   hipEvent_t wide_fork = nullptr, wide_join[2] = {}; // rounds of the wide-locus kernel overlap on three streams
 };
 
 namespace sb {
@@ -233,6 +234,8 @@ int sbgpu_init(int device, sbgpu_ctx_t **ctx_out)
       if (e == hipSuccess) e = hipEventCreateWithFlags(&c->join[i], hipEventDisableTiming);
    }
    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
+   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->wide_fork, hipEventDisableTiming);
+   for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->wide_join[i], hipEventDisableTiming);
    if (e == hipSuccess) e = hipHostMalloc((void **)&c->wide_error, sizeof(int32_t), hipHostMallocDefault);
    if (e == hipSuccess) *c->wide_error = 0;
    for (int k = 0; e == hipSuccess && k < sb::kNumKinds; ++k) {
@@ -262,6 +265,9 @@ int sbgpu_finalize(sbgpu_ctx_t *c)
    }
    if (c->stream) (void)hipStreamDestroy(c->stream);
    if (c->wide_error) (void)hipHostFree(c->wide_error);
+   if (c->wide_fork) (void)hipEventDestroy(c->wide_fork);
+   for (int i = 0; i < 2; ++i)
+      if (c->wide_join[i]) (void)hipEventDestroy(c->wide_join[i]);
    delete c;
    return SBGPU_OK;
 }
@@ -573,6 +579,17 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
             HIP_TRY(hipMemsetAsync(p->d_wide_barriers, 0, (size_t)p->n_wide_desc * sizeof(unsigned), s));
             int32_t *d_err = nullptr;
             HIP_TRY(hipHostGetDevicePointer((void **)&d_err, c->wide_error, 0));
+            // Rounds go to three streams in turn: a round's workgroups start as soon as CUs free up, so the tail
+            // of one round (its slowest locus) overlaps the next.  No round waits on another, every round fits the
+            // chip by itself: no deadlock among the counter barriers.
+            hipStream_t lanes[3] = {s, c->aux[3], c->aux[5]};
+            const bool spread = p->wide_rounds.size() > 1;
+            if (spread) {
+               HIP_TRY(hipEventRecord(c->wide_fork, s));
+               HIP_TRY(hipStreamWaitEvent(lanes[1], c->wide_fork, 0));
+               HIP_TRY(hipStreamWaitEvent(lanes[2], c->wide_fork, 0));
+            }
+            size_t ri = 0;
             for (const sbgpu_plan::WideRound &r : p->wide_rounds) {
                sb::WideArgs wa;
                wa.a = a;
@@ -581,8 +598,14 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
                wa.bufs = p->d_wide_bufs;
                wa.barriers = p->d_wide_barriers;
                wa.error = d_err;
-               HIP_TRY(sb::launch_wide(r.nslot, wa, r.n_blocks, r.lds_bytes, s));
+               HIP_TRY(sb::launch_wide(r.nslot, wa, r.n_blocks, r.lds_bytes, spread ? lanes[ri % 3] : s));
+               ++ri;
             }
+            if (spread)
+               for (int x = 0; x < 2; ++x) {
+                  HIP_TRY(hipEventRecord(c->wide_join[x], lanes[x + 1]));
+                  HIP_TRY(hipStreamWaitEvent(s, c->wide_join[x], 0));
+               }
          }
          const int32_t n_all = (int32_t)p->host.classes[kl.first_class].loci.size();
          if (n_all > p->n_wide_loci) { // the rest: one workgroup per locus, F streamed from L2
