@@ -411,6 +411,35 @@ int sbgpu_quantify_host(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *annot, const
 /* F of the EM batch a handle from sbgpu_quantify_host holds: F_out[info[3]] (row-major per locus). */
 int sbgpu_bins_export_weights(const sbgpu_bins_t *bins, double *F_out);
 
+/* ---- per-bin sequence statistics ---------------------------------------
+ * What the reference's "bias" option (-b genome.fa) adds to the `-f` table and nothing else
+ * (src/bias.cpp holds no code): for every exon bin, over the bases of its segments concatenated
+ * (ExonBin::bin_dnaseq, include/isoform.h:173-182; FaSeqGetter::fetchSeq, src/fasta.cpp:195-200),
+ *   gc[b]       Kmer<string>::GCRatio            include/kmer.h:67-76    (C c G g count; exact)
+ *   entropy[b]  Kmer<string>::Entropy(seq, 6)    include/kmer.h:46-65    (natural log; bytes other
+ *               than ACGTacgt code as A, :106-124; fp64, ~1e-15 relative to the reference)
+ *   flags[b]    bit 0..3 = Kmer<string>::HighGCStrech(seq, 20, 0.8), (20, 0.9), (40, 0.8), (40, 0.9)
+ *               include/kmer.h:78-88, in the order of src/alignments.cpp:1626-1629         (exact)
+ * genome[0] is base `genome_start` (1-based, the coordinates of the segments) of the chromosome,
+ * genome_len bytes as they stand in the FASTA (either case, N, ...).  Bin b = segments
+ * seg_off[b] .. seg_off[b+1]-1, closed coordinates, in the bin's own (sorted) order.
+ * The reference aborts on bins of 40 bases or fewer (live asserts, kmer.h:20,82); here a window
+ * that does not fit gives flag 0, fewer than 6 bases give entropy 0, an empty bin gives gc NaN.
+ *
+ * Device form: all pointers are device pointers; *d_error (caller zeroes it) gets a non-zero
+ * value if a segment lies outside the genome window (that bin's outputs are then 0).
+ * Asynchronous on `stream`.                                                                  */
+int sbgpu_binseq_device(sbgpu_ctx_t *ctx, const uint8_t *d_genome, int64_t genome_start, int64_t genome_len,
+                        int64_t n_bins, const int64_t *d_seg_off, const uint32_t *d_seg_left,
+                        const uint32_t *d_seg_right, double *d_gc, double *d_entropy, uint8_t *d_flags,
+                        int32_t *d_error, void *stream);
+
+/* Host-buffer form: validates (SBGPU_EINVAL for a segment outside the window), uploads, runs,
+ * downloads, synchronises.                                                                   */
+int sbgpu_binseq_host(sbgpu_ctx_t *ctx, const uint8_t *genome, int64_t genome_start, int64_t genome_len,
+                      int64_t n_bins, const int64_t *seg_off, const uint32_t *seg_left,
+                      const uint32_t *seg_right, double *gc_out, double *entropy_out, uint8_t *flags_out);
+
 /* ---- output formatting, host only -------------------------------
  * The digits Strawberry prints for FPKM / Frac / TPM: std::to_string(double) (= "%f",
  * src/estimate.cpp:335,344 and src/alignments.cpp:1827) copied into a char[12] by
@@ -430,7 +459,7 @@ int sbgpu_format_gtf_transcript(char *buf, int cap, const char *chrom, char stra
 
 /* One row of the `-f` context table exactly as Sample::printContext writes it
  * (src/alignments.cpp:1549-1639, columns 1-10; the six sequence columns exist only with
- * BIAS_CORRECTION and a genome FASTA and are not produced): tab-separated
+ * BIAS_CORRECTION and a genome FASTA: sbgpu_format_context_row_seq below): tab-separated
  *   sample, sample_frag_count (total mapped reads), gene_id, gene_frag_count, transcripts (comma
  *   list), FPKMs (std::to_string each), conditional_probabilities (the bin's weight per isoform,
  *   to_string_with_precision(.,12) = "%.12g", include/common.h:366-372; 0 for an isoform the bin's
@@ -443,6 +472,16 @@ int sbgpu_format_context_row(char *buf, int cap, const char *sample, int32_t sam
                              const char *const *transcript_ids, const double *fpkm,
                              const double *cond_prob, const double *frac, int n_seg,
                              const uint32_t *seg_left, const uint32_t *seg_right, uint32_t path_count);
+
+/* The same row of a run with `-b genome.fa`: six more columns (src/alignments.cpp:1622-1636) --
+ * path_gc_content and path_hexmer_entropy (std::to_string, six decimals) and the four stretch flags
+ * (std::to_string(bool): 0 / 1), from sbgpu_binseq_*'s outputs for the bin.                   */
+int sbgpu_format_context_row_seq(char *buf, int cap, const char *sample, int32_t sample_frag_count,
+                                 const char *gene_id, uint32_t gene_frag_count, int n_iso,
+                                 const char *const *transcript_ids, const double *fpkm,
+                                 const double *cond_prob, const double *frac, int n_seg,
+                                 const uint32_t *seg_left, const uint32_t *seg_right, uint32_t path_count,
+                                 double gc, double entropy, uint32_t flags);
 
 #ifdef __cplusplus
 }

@@ -105,6 +105,14 @@ class OracleLib:
         L.sbo_exonbin_batch.argtypes = [_i64, _i64, _u32, _u32, _i64, _u32, _u32, C.c_int64, _p(np.int32, flags="C"),
                                         _i64, _u8, _u32, _u32, C.c_int32, C.c_int32, _u32, _u32]
         L.sbo_exonbin_batch.restype = None
+        L.sbo_gc_ratio.argtypes = [_u8, C.c_int64]
+        L.sbo_gc_ratio.restype = C.c_double
+        L.sbo_kmer_entropy.argtypes = [_u8, C.c_int64, C.c_int]
+        L.sbo_kmer_entropy.restype = C.c_double
+        L.sbo_high_gc_stretch.argtypes = [_u8, C.c_int64, C.c_int, C.c_double]
+        L.sbo_high_gc_stretch.restype = C.c_int
+        L.sbo_binseq_batch.argtypes = [_u8, C.c_int64, C.c_int64, _i64, _u32, _u32, _f64, _f64, _u8]
+        L.sbo_binseq_batch.restype = None
 
     # ---- EM
     def em_locus(self, count, F):
@@ -224,6 +232,27 @@ class OracleLib:
         return compat[:hits.n_hits], key[:hits.n_hits]
 
 
+    # ---- per-bin sequence statistics (A8)
+    def seq_stats(self, seq):
+        """(gc, entropy, flags) of one sequence given as bytes."""
+        a = np.frombuffer(bytes(seq), np.uint8).copy() if len(seq) else np.zeros(1, np.uint8)
+        n = len(seq)
+        flags = 0
+        for q, (w, cut) in enumerate(((20, 0.8), (20, 0.9), (40, 0.8), (40, 0.9))):
+            flags |= self.L.sbo_high_gc_stretch(a, n, w, cut) << q
+        return self.L.sbo_gc_ratio(a, n), self.L.sbo_kmer_entropy(a, n, 6), flags
+
+    def binseq_batch(self, genome, genome_start, seg_off, seg_left, seg_right):
+        """The six `-f` columns of every bin: (gc[n], entropy[n], flags[n])."""
+        seg_off = np.ascontiguousarray(seg_off, np.int64)
+        n = len(seg_off) - 1
+        gc, ent, fl = np.zeros(max(n, 1)), np.zeros(max(n, 1)), np.zeros(max(n, 1), np.uint8)
+        pad = lambda a, t: np.ascontiguousarray(a if len(a) else np.zeros(1, t), t)  # noqa: E731
+        self.L.sbo_binseq_batch(pad(np.frombuffer(bytes(genome), np.uint8), np.uint8), genome_start, n, seg_off,
+                                pad(seg_left, np.uint32), pad(seg_right, np.uint32), gc, ent, fl)
+        return gc[:n], ent[:n], fl[:n]
+
+
 class RefLib:
     """oracle/_ref/libstrawberry_ref.so -- the reference's own objects behind ref_shim.cpp."""
 
@@ -249,6 +278,15 @@ class RefLib:
         L.ref_overlap_key.restype = None
         L.ref_pairedhit_features.argtypes = [C.c_int, _u32, _u32, C.c_int, _u32, _u32, _i32, _u32, _u32]
         L.ref_pairedhit_features.restype = C.c_int
+        L.ref_kmer_stats.argtypes = [C.c_char_p, C.c_int, _f64]
+        L.ref_kmer_stats.restype = None
+
+    def kmer_stats(self, seq):
+        """(gc, entropy, flags) by the reference's own Kmer<string> templates; len(seq) > 40."""
+        assert len(seq) > 40, "the reference asserts w < len (kmer.h:82)"
+        out = np.zeros(6)
+        self.L.ref_kmer_stats(bytes(seq), len(seq), out)
+        return out[0], out[1], int(out[2]) | int(out[3]) << 1 | int(out[4]) << 2 | int(out[5]) << 3
 
     def is_compatible(self, code, left, right, exon_left, exon_right):
         """Contig::is_compatible on Contigs built from flat features; the isoform from its exons."""

@@ -17,6 +17,9 @@
 #include <set>
 
 #include "estimate.hpp" /* /root/reference/include/estimate.hpp:230-257 (EmSolver) */
+#include <cassert>
+#include <string>
+#include "kmer.h"     /* /root/reference/include/kmer.h:14-135 (Kmer<string>) */
 
 extern "C" {
 
@@ -183,6 +186,20 @@ int ref_pairedhit_features(int n_left, const uint32_t *ll, const uint32_t *lr, i
       ++n;
    }
    return n;
+}
+
+/* The six per-bin sequence statistics of the `-f` table, by the reference's own templates
+ * exactly as src/alignments.cpp:1623-1629 calls them.  out6 = gc, entropy, 4 flags (0/1).
+ * The caller keeps to len > 40: the reference's live asserts abort below that.           */
+void ref_kmer_stats(const char *seq, int len, double *out6)
+{
+   std::string s(seq, seq + len);
+   out6[0] = Kmer<std::string>::GCRatio(s.begin(), s.end());
+   out6[1] = Kmer<std::string>::Entropy(s, 6);
+   out6[2] = Kmer<std::string>::HighGCStrech(s.begin(), s.end(), 20, 0.8);
+   out6[3] = Kmer<std::string>::HighGCStrech(s.begin(), s.end(), 20, 0.9);
+   out6[4] = Kmer<std::string>::HighGCStrech(s.begin(), s.end(), 40, 0.8);
+   out6[5] = Kmer<std::string>::HighGCStrech(s.begin(), s.end(), 40, 0.9);
 }
 
 } /* extern "C" */

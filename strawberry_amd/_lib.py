@@ -23,7 +23,8 @@ SYMBOLS = [
     "sbgpu_exonbin_device", "sbgpu_exonbin_host", "sbgpu_segments_host", "sbgpu_hit_features", "sbgpu_frag_lens_host",
     "sbgpu_bins_create", "sbgpu_bins_create_device", "sbgpu_bins_destroy", "sbgpu_quantify_host",
     "sbgpu_bins_export_weights", "sbgpu_collapse_pairs_host", "sbgpu_uniq_destroy", "sbgpu_uniq_info", "sbgpu_uniq_export", "sbgpu_bins_info", "sbgpu_bins_export",
-    "sbgpu_format_value", "sbgpu_format_gtf_transcript", "sbgpu_format_context_row", "sbgpu_em_batch", "sbgpu_abundance_device", "sbgpu_tpm_device",
+    "sbgpu_format_value", "sbgpu_format_gtf_transcript", "sbgpu_format_context_row", "sbgpu_format_context_row_seq",
+    "sbgpu_binseq_device", "sbgpu_binseq_host", "sbgpu_em_batch", "sbgpu_abundance_device", "sbgpu_tpm_device",
 ]
 
 
@@ -175,6 +176,9 @@ def load():
                                               C.c_double, C.c_int32]
     L.sbgpu_format_context_row.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int32, C.c_char_p, C.c_uint32, C.c_int,
                                            C.POINTER(C.c_char_p), vp, vp, vp, C.c_int, vp, vp, C.c_uint32]
+    L.sbgpu_format_context_row_seq.argtypes = L.sbgpu_format_context_row.argtypes + [C.c_double, C.c_double, C.c_uint32]
+    L.sbgpu_binseq_device.argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.sbgpu_binseq_host.argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int64, vp, vp, vp, vp, vp, vp]
     L.sbgpu_binweight_host.argtypes = [vp, C.c_int64, vp, vp, vp, vp, C.POINTER(sbgpu_insert_t), vp]
     for name in SYMBOLS:
         f = getattr(L, name)

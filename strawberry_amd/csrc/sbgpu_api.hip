@@ -958,14 +958,14 @@ int sbgpu_format_gtf_transcript(char *buf, int cap, const char *chrom, char stra
    return (int)out.size();
 }
 
-int sbgpu_format_context_row(char *buf, int cap, const char *sample, int32_t sample_frag_count, const char *gene_id,
-                             uint32_t gene_frag_count, int n_iso, const char *const *transcript_ids, const double *fpkm,
-                             const double *cond_prob, const double *frac, int n_seg, const uint32_t *seg_left,
-                             const uint32_t *seg_right, uint32_t path_count)
+static int context_row(const char *who, char *buf, int cap, const char *sample, int32_t sample_frag_count, const char *gene_id,
+                       uint32_t gene_frag_count, int n_iso, const char *const *transcript_ids, const double *fpkm,
+                       const double *cond_prob, const double *frac, int n_seg, const uint32_t *seg_left,
+                       const uint32_t *seg_right, uint32_t path_count, const double *seq_stats, uint32_t flags)
 {
    if (!buf || cap < 1 || !sample || !gene_id || n_iso < 1 || !transcript_ids || !fpkm || !cond_prob || !frac || n_seg < 0 ||
        (n_seg && (!seg_left || !seg_right)))
-      return fail(SBGPU_EINVAL, "sbgpu_format_context_row: bad argument");
+      return fail(SBGPU_EINVAL, std::string(who) + ": bad argument");
    std::string out = std::string(sample) + "\t" + std::to_string(sample_frag_count) + "\t" + gene_id + "\t" +
                      std::to_string(gene_frag_count) + "\t";
    char num[64];
@@ -981,9 +981,33 @@ int sbgpu_format_context_row(char *buf, int cap, const char *sample, int32_t sam
    for (int j = 0; j < n_iso; ++j) out += std::string(j ? "," : "") + std::to_string(frac[j]);
    out += "\t";
    for (int k = 0; k < n_seg; ++k) out += "[" + std::to_string(seg_left[k]) + "-" + std::to_string(seg_right[k]) + "]";
-   out += "\t" + std::to_string(path_count) + "\n";
+   out += "\t" + std::to_string(path_count);
+   if (seq_stats) { // src/alignments.cpp:1630-1635
+      out += "\t" + std::to_string(seq_stats[0]) + "\t" + std::to_string(seq_stats[1]);
+      for (int q = 0; q < 4; ++q) out += "\t" + std::to_string((bool)((flags >> q) & 1u));
+   }
+   out += "\n";
    std::snprintf(buf, (size_t)cap, "%s", out.c_str());
    return (int)out.size();
+}
+
+int sbgpu_format_context_row(char *buf, int cap, const char *sample, int32_t sample_frag_count, const char *gene_id,
+                             uint32_t gene_frag_count, int n_iso, const char *const *transcript_ids, const double *fpkm,
+                             const double *cond_prob, const double *frac, int n_seg, const uint32_t *seg_left,
+                             const uint32_t *seg_right, uint32_t path_count)
+{
+   return context_row("sbgpu_format_context_row", buf, cap, sample, sample_frag_count, gene_id, gene_frag_count, n_iso,
+                      transcript_ids, fpkm, cond_prob, frac, n_seg, seg_left, seg_right, path_count, nullptr, 0);
+}
+
+int sbgpu_format_context_row_seq(char *buf, int cap, const char *sample, int32_t sample_frag_count, const char *gene_id,
+                                 uint32_t gene_frag_count, int n_iso, const char *const *transcript_ids, const double *fpkm,
+                                 const double *cond_prob, const double *frac, int n_seg, const uint32_t *seg_left,
+                                 const uint32_t *seg_right, uint32_t path_count, double gc, double entropy, uint32_t flags)
+{
+   const double st[2] = {gc, entropy};
+   return context_row("sbgpu_format_context_row_seq", buf, cap, sample, sample_frag_count, gene_id, gene_frag_count, n_iso,
+                      transcript_ids, fpkm, cond_prob, frac, n_seg, seg_left, seg_right, path_count, st, flags);
 }
 
 } // extern "C"

@@ -42,8 +42,10 @@ CONTEXT_HEADER = "\t".join([
 
 
 def context_row(sample, sample_frag_count, gene_id, gene_frag_count, transcript_ids, fpkm, cond_prob, frac, segs,
-                path_count):
-    """One row of the `-f` table (Sample::printContext, alignments.cpp:1549-1639, columns 1-10)."""
+                path_count, seq_stats=None):
+    """One row of the `-f` table (Sample::printContext, alignments.cpp:1549-1639, columns 1-10).
+    seq_stats = (gc, entropy, flags) of the bin (binseq.bin_sequence_stats) adds the six columns of a run
+    with `-b genome.fa` (alignments.cpp:1622-1636)."""
     L = _lib.load()
     n = len(transcript_ids)
     names = (C.c_char_p * n)(*[t.encode() for t in transcript_ids])
@@ -54,16 +56,19 @@ def context_row(sample, sample_frag_count, gene_id, gene_frag_count, transcript_
     sr = np.ascontiguousarray([s[1] for s in segs], np.uint32)
     cap = 512 + 64 * n * 4 + 32 * len(segs) + sum(len(t) for t in transcript_ids)
     buf = C.create_string_buffer(cap)
-    r = L.sbgpu_format_context_row(buf, cap, sample.encode(), int(sample_frag_count), gene_id.encode(),
-                                   int(gene_frag_count), n, names, fpkm.ctypes.data, cond.ctypes.data, frac.ctypes.data,
-                                   len(segs), sl.ctypes.data if len(segs) else None, sr.ctypes.data if len(segs) else None,
-                                   int(path_count))
+    args = (buf, cap, sample.encode(), int(sample_frag_count), gene_id.encode(),
+            int(gene_frag_count), n, names, fpkm.ctypes.data, cond.ctypes.data, frac.ctypes.data,
+            len(segs), sl.ctypes.data if len(segs) else None, sr.ctypes.data if len(segs) else None, int(path_count))
+    if seq_stats is None:
+        r = L.sbgpu_format_context_row(*args)
+    else:
+        r = L.sbgpu_format_context_row_seq(*args, float(seq_stats[0]), float(seq_stats[1]), int(seq_stats[2]))
     if r < 0:
         _lib.check(r, "sbgpu_format_context_row")
     return buf.value.decode()
 
 
-def context_table(sample, total_mapped, gene_ids, transcript_ids, bins, compat, F, fpkm, frac, keep=None):
+def context_table(sample, total_mapped, gene_ids, transcript_ids, bins, compat, F, fpkm, frac, keep=None, seq_stats=None):
     """The whole `-f` table of a batch of loci from the chain's results.
 
     bins: exonbin.LocusBins; compat: the kernel's words per hit [n_hits, cw]; F: the EM batch's weights
@@ -71,7 +76,8 @@ def context_table(sample, total_mapped, gene_ids, transcript_ids, bins, compat, 
     keep: per isoform, False for the ones the expression filter erased (estimate.cpp:346-355).
     Sample::printContext runs after the filter, over the surviving isoforms only: a hit counts if it is
     compatible with one of them, per bin the reference prints the weights of the isoforms its LAST such
-    hit is compatible with and the number of such hits, bins in std::map order of their coordinate sets."""
+    hit is compatible with and the number of such hits, bins in std::map order of their coordinate sets.
+    seq_stats: (gc[n_bins], entropy[n_bins], flags[n_bins]) from binseq.bin_sequence_stats for a `-b` run."""
     out = [CONTEXT_HEADER]
     hit_bin = np.asarray(bins.hit_bin)
     keep = np.ones(int(bins.iso_off[-1]), bool) if keep is None else np.asarray(keep) != 0
@@ -101,5 +107,6 @@ def context_table(sample, total_mapped, gene_ids, transcript_ids, bins, compat, 
             prob = [Fl[b, j] if (int(words[j >> 5]) >> (j & 31)) & 1 else 0.0 for j in kept]
             out.append(context_row(sample, total_mapped, gene, gene_frags, [transcript_ids[l][j] for j in kept],
                                    [fpkm[i0 + j] for j in kept], prob, [frac[i0 + j] for j in kept], coords[b],
-                                   n_in_bin[b0 + b]))
+                                   n_in_bin[b0 + b],
+                                   None if seq_stats is None else tuple(x[b0 + b] for x in seq_stats)))
     return "".join(out)

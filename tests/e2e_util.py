@@ -18,6 +18,7 @@ E2E_MASS = os.path.join(HERE, "golden", "e2e_toy_mass")  # PCR duplicates + mult
 E2E_EMP = os.path.join(HERE, "golden", "e2e_toy_emp")     # e2e_toy's reads without -i: empirical insert-size distribution
 E2E_SINGLE = os.path.join(HERE, "golden", "e2e_toy_single")  # single-end library: unpaired reads, insert size forced to N(200, 80)
 E2E_LONGREAD = os.path.join(HERE, "golden", "e2e_toy_longread")  # unpaired reads of 1001-2600 bases: long-read workflow, F = 1/L
+E2E_BIAS = os.path.join(HERE, "golden", "e2e_toy_bias")     # -b genome.fa: six sequence columns per bin in the -f table
 E2E_FILTER = os.path.join(HERE, "golden", "e2e_toy_filter")  # e2e_toy_long's reads with -e 0.05: isoforms erased
 
 
@@ -105,7 +106,8 @@ def parse_ctx(path=os.path.join(E2E, "ctx.tsv")):
             "total_mapped": int(f[1]), "gene": f[2], "transcripts": f[4].split(","),
             "fpkm": [float(x) for x in f[5].split(",")], "F": [float(x) for x in f[6].split(",")],
             "frac": [float(x) for x in f[7].split(",")],
-            "coords": [(int(a), int(b)) for a, b in re.findall(r"\[(\d+)-(\d+)\]", f[8])], "count": int(f[9])})
+            "coords": [(int(a), int(b)) for a, b in re.findall(r"\[(\d+)-(\d+)\]", f[8])], "count": int(f[9]),
+            "seq": f[10:]})     # with -b: gc, entropy (six decimals) and four 0 / 1 flags
     return rows
 
 

@@ -1,0 +1,157 @@
+"""A8 on the GPU: binseq_kernel (sbgpu_binseq_host / _device) against the reference's answers
+(tests/golden/binseq_cases.npz), against the oracle on shapes the goldens do not hold (bins over many
+segments, bins longer than one 4096-base chunk, bins shorter than the windows), and the `-f` table of
+the reference binary's `-b genome.fa` run byte for byte.
+
+GC ratio and the four flags are integer work: exact.  The entropy is fp64 through the device's log()
+and a different (per position) summation order than the reference's: tolerance 1e-12 relative
+(|d| <= 1e-12 * max(1, |x|)); the six-decimal strings of the table must be identical."""
+import os
+
+import numpy as np
+import pytest
+
+import e2e_util as U
+import exonbin_util as XU
+from test_binseq_oracle import cases, load_bias_run
+
+pytestmark = pytest.mark.gpu
+
+ENT_TOL = 1e-12
+
+
+def close(a, b):
+    return abs(a - b) <= ENT_TOL * max(1.0, abs(b))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from strawberry_amd import em
+    return em.default_context(0)
+
+
+def test_kernel_reproduces_reference_goldens(ctx):
+    from strawberry_amd.binseq import bin_sequence_stats
+    cs = cases()
+    genome = b"".join(c[0] for c in cs)
+    off = np.cumsum([0] + [len(c[0]) for c in cs])
+    gc, ent, fl = bin_sequence_stats(genome, np.arange(len(cs) + 1), off[:-1] + 1, off[1:])   # one segment per bin
+    for k, (seq, rgc, rent, rfl) in enumerate(cs):
+        assert gc[k] == rgc and int(fl[k]) == rfl, (k, len(seq))
+        assert close(ent[k], rent), (k, len(seq), ent[k], rent)
+        assert "%f" % ent[k] == "%f" % rent
+
+
+def test_kernel_matches_oracle_on_segmented_and_long_bins(ctx, oracle):
+    from strawberry_amd.binseq import bin_sequence_stats
+    rng = np.random.Generator(np.random.PCG64(0xB1))
+    n = 300000
+    gcp = np.repeat(rng.choice([0.2, 0.5, 0.8, 0.93], size=n // 100), 100)
+    u = rng.random(n)
+    genome = np.where(u < gcp / 2, ord("C"), np.where(u < gcp, ord("G"), np.where(u < gcp + (1 - gcp) / 2, ord("A"), ord("T")))).astype(np.uint8)
+    genome[rng.random(n) < 0.05] |= 0x20
+    genome[rng.random(n) < 0.01] = ord("N")
+    genome[rng.random(n) < 0.002] = 1
+    genome = genome.tobytes()
+    start = 5001
+    bins = []
+    for L in (1, 2, 5, 6, 7, 19, 20, 21, 39, 40, 41, 63, 64, 65, 127, 128, 129, 4090, 4095, 4096, 4097, 4101, 4102, 4159, 4160, 4161,
+              8191, 8192, 8193, 12288, 20000, 100000):                       # one segment, lengths around every boundary
+        a = int(rng.integers(start, start + n - L))
+        bins.append([(a, a + L - 1)])
+    for t in range(300):                                                       # 2-40 segments of 1-400 bases, ascending
+        k = int(rng.integers(2, 40))
+        a = int(rng.integers(start, start + n - 40 * 900))
+        segs = []
+        for _ in range(k):
+            ln = int(rng.integers(1, 400)) if t % 3 else int(rng.integers(1, 4))
+            segs.append((a, a + ln - 1))
+            a += ln + int(rng.integers(1, 500))
+        bins.append(segs)
+    bins.append([(start + 3 * i, start + 3 * i) for i in range(5000)])           # 5000 one-base segments (two chunks)
+    bins.append([(start + n - 50, start + n - 1)])                             # the window's last base
+    off = np.cumsum([0] + [len(b) for b in bins])
+    sl = np.array([a for b in bins for a, _ in b], np.uint32)
+    sr = np.array([c for b in bins for _, c in b], np.uint32)
+    gc, ent, fl = bin_sequence_stats(genome, off, sl, sr, genome_start=start)
+    ogc, oent, ofl = oracle.binseq_batch(genome, start, off, sl, sr)
+    np.testing.assert_array_equal(gc, ogc)
+    np.testing.assert_array_equal(fl, ofl)
+    assert len(set(ofl.tolist())) >= 5
+    for k in range(len(bins)):
+        assert close(ent[k], oent[k]), (k, bins[k][:3], ent[k], oent[k])
+
+
+def test_rejects_a_segment_outside_the_genome_window(ctx):
+    from strawberry_amd import _lib
+    from strawberry_amd.binseq import bin_sequence_stats
+    genome = b"ACGT" * 100
+    for segs in ([(390, 401)], [(0, 50)], [(50, 40)]):
+        with pytest.raises(_lib.SbgpuError):
+            bin_sequence_stats(genome, [0, 1], [segs[0][0]], [segs[0][1]])
+    gc, ent, fl = bin_sequence_stats(genome, [0], [], [])                     # no bins: nothing to do
+    assert len(gc) == 0
+
+
+def test_device_form_and_its_error_flag(ctx):
+    import torch
+    from strawberry_amd.binseq import bin_sequence_stats, bin_sequence_stats_device
+    rng = np.random.Generator(np.random.PCG64(3))
+    genome = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=100000)
+    left = np.sort(rng.integers(1, 99000, size=2000)).astype(np.uint32)
+    right = (left + rng.integers(41, 900, size=2000)).astype(np.uint32)
+    off = np.arange(0, 2001, 2)                                                # two segments per bin
+    h = bin_sequence_stats(genome.tobytes(), off, left, right)
+    dev = torch.device("cuda", 0)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)   # noqa: E731
+    gc, ent, fl, err = bin_sequence_stats_device(t(genome, np.uint8), 1, t(off.astype(np.int64), np.int64), t(left, np.int32), t(right, np.int32))
+    torch.cuda.synchronize()
+    assert int(err.item()) == 0
+    np.testing.assert_array_equal(gc.cpu().numpy(), h[0])
+    np.testing.assert_array_equal(ent.cpu().numpy(), h[1])                       # same kernel, same inputs: same bits
+    np.testing.assert_array_equal(fl.cpu().numpy(), h[2])
+    right[7] = 100001                                                          # past the window: flagged, outputs zeroed
+    gc, ent, fl, err = bin_sequence_stats_device(t(genome, np.uint8), 1, t(off.astype(np.int64), np.int64), t(left, np.int32), t(right, np.int32))
+    torch.cuda.synchronize()
+    assert int(err.item()) != 0 and gc[3].item() == 0.0 and (gc.cpu().numpy()[:3] == h[0][:3]).all()
+
+
+def test_large_batch_properties(ctx):
+    """200 000 bins over a 20 Mbase window: properties that need no oracle."""
+    from strawberry_amd.binseq import bin_sequence_stats
+    rng = np.random.Generator(np.random.PCG64(11))
+    n = 20_000_000
+    genome = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=n, p=[0.2, 0.3, 0.3, 0.2])
+    isgc = np.concatenate([[0], np.cumsum((genome == ord("C")) | (genome == ord("G")))])
+    left = rng.integers(1, n - 3000, size=200_000).astype(np.uint32)
+    right = (left + rng.integers(45, 2500, size=200_000)).astype(np.uint32)
+    gc, ent, fl = bin_sequence_stats(genome.tobytes(), np.arange(200_001), left, right)
+    L = right.astype(np.int64) - left + 1
+    np.testing.assert_array_equal(gc, (isgc[right] - isgc[left - 1]) / L)       # exact: an integer count over the length
+    assert (ent > 0).all() and (ent <= np.log(np.minimum(L - 5, 4096)) + 1e-12).all()
+    f = fl.astype(np.int64)
+    assert (((f >> 1) & 1) <= (f & 1)).all() and (((f >> 3) & 1) <= ((f >> 2) & 1)).all()   # above 0.9 implies above 0.8
+    assert (((f >> 3) & 1) <= ((f >> 1) & 1)).all()        # a 40-window above 0.9 holds a 20-window above 0.9
+    dup = bin_sequence_stats(genome.tobytes(), np.arange(200_001), left, right)
+    assert all((a == b).all() for a, b in zip((gc, ent, fl), dup))             # deterministic
+
+
+def test_context_table_of_the_bias_run_byte_for_byte(ctx):
+    """tests/golden/e2e_toy_bias: the reference binary run with -b genome.fa.  The whole chain from the
+    fragments, plus the sequence statistics of every bin, gives its -f table byte for byte."""
+    from strawberry_amd.binseq import bin_segments, bin_sequence_stats
+    from strawberry_amd.output import context_table
+    from strawberry_amd.quantify import InsertSize, LocusQuantifier
+    d = U.E2E_BIAS
+    ordered, rows, gtf, theta_log = U.load(d)
+    genome, _ = load_bias_run()
+    annot, hits, names, _ = XU.e2e_inputs(d, ordered)
+    q = LocusQuantifier(annot, hits, InsertSize(250.0, 30.0), 75, ctx=ctx)
+    bins = q.assign_bins()
+    F = q.bin_weights().cpu().numpy()
+    res = q.solve(hits.total_mapped, min_isoform_frac=0.0)
+    stats = bin_sequence_stats(genome, *bin_segments(bins))
+    compat = q.d_compat.cpu().numpy().view(np.uint32)[:hits.n_hits]
+    table = context_table("toy", hits.total_mapped, names, [[t for t, _ in ordered[g]] for g in names], bins, compat, F,
+                          res["fpkm"], res["frac"], keep=res["keep"], seq_stats=stats)
+    assert table == open(os.path.join(d, "ctx.tsv")).read()

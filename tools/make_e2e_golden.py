@@ -168,8 +168,35 @@ def save_frags(frags, path):
                         nh=np.asarray([n for f in frags for n in f[3]], np.int32))
 
 
+def write_genome(rng, length, out_dir):
+    """genome.fa (60 bases per line) + genome.fa.fai (the reference cannot build the index, fasta.cpp:89-91)."""
+    seq = np.empty(length, np.uint8)
+    at = 0
+    while at < length:                       # stretches of 30-300 bases, each with its own GC content
+        n = int(rng.integers(30, 300))
+        gc = float(rng.choice([0.15, 0.35, 0.5, 0.65, 0.85, 0.95]))
+        p = np.array([(1 - gc) / 2, gc / 2, gc / 2, (1 - gc) / 2])
+        seq[at:at + n] = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=n, p=p)[:length - at]
+        at += n
+    lower = rng.random(length) < 0.08
+    seq[lower] |= 0x20
+    seq[rng.random(length) < 0.01] = ord("N")
+    text = seq.tobytes().decode()
+    with open(os.path.join(out_dir, "genome.fa"), "w") as f:
+        f.write(">chr1\n")
+        for i in range(0, length, 60):
+            f.write(text[i:i + 60] + "\n")
+    with open(os.path.join(out_dir, "genome.fa.fai"), "w") as f:
+        f.write("chr1\t%d\t6\t60\t61\n" % length)
+
+
 def main():
     build(with_ref=True)
+    only = sys.argv[1:]
+    if only:                                  # regenerate the named runs only
+        global make
+        _make = make
+        make = lambda name, *a, **k: _make(name, *a, **k) if name in only else None  # noqa: E731
     # e2e_toy: short exons -- bins spanning many segments, implicit (mate-gap) segments: pins the
     #          bin-weight model.  e2e_toy_long: every exon longer than any mate gap, so a bin's
     #          fragments all have the same isoform compatibility and the -f table shows the full
@@ -195,9 +222,16 @@ def main():
     #          reference to its long-read workflow (Strawberry.cpp:292-303): every bin weight is 1/L_j
     #          (set_bin_weight_without_frag_dist, estimate.cpp:236-247).
     make("e2e_toy_longread", 4646, 300, 700, long_reads=True, n_frags=400)
+    # e2e_toy_bias: `-b genome.fa` -- the reference's bias option.  It changes no abundance (src/bias.cpp holds
+    #          no code); it appends six columns to the -f table: GC ratio, hexamer entropy and four high-GC-stretch
+    #          flags of every bin's sequence (alignments.cpp:1622-1636, kmer.h).  The genome is ours: random bases
+    #          with GC-rich and GC-poor stretches, some lower case, some N.  Exons of 60+ bases: the reference
+    #          aborts on a bin of 40 bases or fewer (kmer.h:82, asserts are live in its release build).
+    make("e2e_toy_bias", 4747, 60, 400, genome=True)
 
 
-def make(name, seed, ex_lo, ex_hi, dup=0.0, multi=0.0, extra=(), insert=True, single=False, long_reads=False, n_frags=900):
+def make(name, seed, ex_lo, ex_hi, dup=0.0, multi=0.0, extra=(), insert=True, single=False, long_reads=False, n_frags=900,
+         genome=False):
     rng = np.random.Generator(np.random.PCG64(seed))
     genes, chrom_len = make_annotation(rng, 6, ex_lo, ex_hi)
     out_dir = os.path.join(ROOT, "tests", "golden", name)
@@ -214,13 +248,17 @@ def make(name, seed, ex_lo, ex_hi, dup=0.0, multi=0.0, extra=(), insert=True, si
                 f.write(line + "\n")
         bam = os.path.join(tmp, "toy.bam")
         subprocess.check_call([SAM2BAM, sam, bam])
+        extra = list(extra)
+        if genome:
+            write_genome(rng, chrom_len + 500, tmp)
+            extra += ["-b", "genome.fa"]
         cmd = [REF_BIN, bam, "-g", gtf, "-r"] + (["-i", "%d/%d" % (MEAN, SD)] if insert else []) + ["-o", os.path.join(tmp, "out.gtf"),
                "-T", os.path.join(tmp, "log.txt"), "-f", os.path.join(tmp, "ctx.tsv")] + list(extra)
         r = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True)
         print(r.stdout[-2000:])
         print(r.stderr[-3000:])
         r.check_returncode()
-        for name in ("toy.gtf", "out.gtf", "ctx.tsv"):
+        for name in ("toy.gtf", "out.gtf", "ctx.tsv") + (("genome.fa",) if genome else ()):
             data = open(os.path.join(tmp, name)).read()
             open(os.path.join(out_dir, name), "w").write(data)
         with open(os.path.join(out_dir, "theta_log.txt"), "w") as f:
