@@ -56,7 +56,7 @@ def test_kernel_matches_oracle_on_segmented_and_long_bins(ctx, oracle):
     start = 5001
     bins = []
     for L in (1, 2, 5, 6, 7, 19, 20, 21, 39, 40, 41, 63, 64, 65, 127, 128, 129, 4090, 4095, 4096, 4097, 4101, 4102, 4159, 4160, 4161,
-              8191, 8192, 8193, 12288, 20000, 100000):                       # one segment, lengths around every boundary
+              8191, 8192, 8193, 12288, 20000, 65540, 65541, 100000):   # 65540 bases = 65535 hexamers: the last packed one                       # one segment, lengths around every boundary
         a = int(rng.integers(start, start + n - L))
         bins.append([(a, a + L - 1)])
     for t in range(300):                                                       # 2-40 segments of 1-400 bases, ascending
@@ -69,6 +69,7 @@ def test_kernel_matches_oracle_on_segmented_and_long_bins(ctx, oracle):
             a += ln + int(rng.integers(1, 500))
         bins.append(segs)
     bins.append([(start + 3 * i, start + 3 * i) for i in range(5000)])           # 5000 one-base segments (two chunks)
+    bins.append([(start + 1100 * i, start + 1100 * i + 999) for i in range(70)])   # 70 000 bases over 70 segments: two passes, list in global memory
     bins.append([(start + n - 50, start + n - 1)])                             # the window's last base
     off = np.cumsum([0] + [len(b) for b in bins])
     sl = np.array([a for b in bins for a, _ in b], np.uint32)
