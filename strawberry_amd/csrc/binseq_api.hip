@@ -2,13 +2,43 @@
 // launch of the per-bin sequence statistics kernel (binseq_device.h).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+#include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/sbgpu.h"
 #include "api_internal.h"
 #include "binseq_device.h"
 
 using sb::api_fail;
+
+namespace {
+// g_binseq_log_n on the current device, once per device and process: log(n) by the host's libm
+std::mutex g_log_mutex;
+uint64_t g_log_done = 0; // bit d: device d has its table
+int ensure_log_table()
+{
+   int dev = 0;
+   hipError_t e = hipGetDevice(&dev);
+   if (e != hipSuccess) return api_fail(SBGPU_EHIP, std::string("hipGetDevice: ") + hipGetErrorString(e));
+   std::lock_guard<std::mutex> lock(g_log_mutex);
+   if (dev < 64 && ((g_log_done >> dev) & 1)) return SBGPU_OK;
+   std::vector<double> t(sb::kBinSeqChunk + 1, 0.0);
+   for (int n = 1; n <= sb::kBinSeqChunk; ++n) t[n] = std::log((double)n);
+   e = hipMemcpyToSymbol(HIP_SYMBOL(sb::g_binseq_log_n), t.data(), t.size() * sizeof(double));
+   if (e != hipSuccess) return api_fail(SBGPU_EHIP, std::string("hipMemcpyToSymbol(log table): ") + hipGetErrorString(e));
+   uint8_t lut[256] = {0}; // include/kmer.h:91-124 (ToDna2, ToDna)
+   lut['C'] = lut['c'] = 1 | 4;
+   lut['G'] = lut['g'] = 2 | 4;
+   lut['T'] = lut['t'] = 3;
+   lut[1] = lut[2] = 4;
+   e = hipMemcpyToSymbol(HIP_SYMBOL(sb::g_binseq_lut), lut, sizeof(lut));
+   if (e != hipSuccess) return api_fail(SBGPU_EHIP, std::string("hipMemcpyToSymbol(base table): ") + hipGetErrorString(e));
+   if (dev < 64) g_log_done |= 1ull << dev;
+   return SBGPU_OK;
+}
+} // namespace
 
 extern "C" {
 
@@ -22,6 +52,8 @@ int sbgpu_binseq_device(sbgpu_ctx_t *c, const uint8_t *d_genome, int64_t genome_
    if (!d_genome || !d_seg_off || !d_seg_left || !d_seg_right || !d_gc || !d_entropy || !d_flags || !d_error)
       return api_fail(SBGPU_EINVAL, "sbgpu_binseq_device: null device pointer");
    if (n_bins > 0x7fffffff) return api_fail(SBGPU_ESHAPE, "sbgpu_binseq_device: more than 2^31 - 1 bins in one call");
+   if (genome_len > 0xffffffffll) return api_fail(SBGPU_ESHAPE, "sbgpu_binseq_device: a genome window of 2^32 bases or more");
+   if (int rc = ensure_log_table()) return rc;
    sb::BinSeqArgs a;
    a.genome = d_genome;
    a.genome_start = genome_start;

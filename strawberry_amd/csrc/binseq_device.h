@@ -63,20 +63,20 @@ __device__ __forceinline__ uint32_t plane_bits32(const uint32_t *plane, int word
 // One batch of the fetch: kBinSeqBatch words (64 positions each) starting at word w0 of the chunk at p0.  All the
 // byte loads of a batch are issued before the first one is used (the ballots come in a second loop), so a lane has
 // up to kBinSeqBatch loads in flight -- the kernel is otherwise bound by the latency of one dependent load per word.
-// TABLE: the bin's segment list lives in LDS (tbl_end / tbl_base, <= 64 segments) and a lane's cursor walks it
+// TABLE: the bin's segment list lives in LDS (tbl_end / tbl_shift, <= 64 segments) and a lane's cursor walks it
 // there; otherwise the cursor walks the list in global memory (any number of segments).
-constexpr int kBinSeqBatch = 16;
+constexpr int kBinSeqBatch = 8;
 
 struct SegCursor {
-   int64_t seg;   // index of the segment (into the bin's list when TABLE, global otherwise)
-   int begin, end; // concatenated positions [begin, end) are that segment
-   int64_t base;  // index into genome[] of the segment's first base
+   int64_t seg;    // index of the segment (into the bin's list when TABLE, global otherwise)
+   int end;        // the segment ends before concatenated position `end`
+   uint32_t shift; // index into genome[] of concatenated position p while in this segment: p + shift (mod 2^32)
 };
 
 template <bool TABLE>
-__device__ __forceinline__ void fetch_batch(const BinSeqArgs &a, SegCursor &cur, const int *tbl_end, const int64_t *tbl_base,
-                                            int p0, int w0, int w1, int L, int lane, uint64_t *plane_lo, uint64_t *plane_hi,
-                                            uint64_t *plane_gc)
+__device__ __forceinline__ void fetch_batch(const BinSeqArgs &a, SegCursor &cur, const int *tbl_end, const uint32_t *tbl_shift,
+                                            const uint8_t *lut, int p0, int w0, int w1, int L, int lane, uint64_t *plane_lo,
+                                            uint64_t *plane_hi, uint64_t *plane_gc)
 {
    uint32_t c[kBinSeqBatch];
 #pragma unroll
@@ -86,25 +86,25 @@ __device__ __forceinline__ void fetch_batch(const BinSeqArgs &a, SegCursor &cur,
       if (w0 + i < w1 && p < L) {
          while (p >= cur.end) {
             ++cur.seg;
-            cur.begin = cur.end;
+            const int begin = cur.end;
             if (TABLE) {
                cur.end = tbl_end[cur.seg];
-               cur.base = tbl_base[cur.seg];
+               cur.shift = tbl_shift[cur.seg];
             } else {
                cur.end += (int)(a.seg_right[cur.seg] - a.seg_left[cur.seg] + 1);
-               cur.base = (int64_t)a.seg_left[cur.seg] - a.genome_start;
+               cur.shift = (uint32_t)(a.seg_left[cur.seg] - (uint32_t)a.genome_start) - (uint32_t)begin;
             }
          }
-         c[i] = a.genome[cur.base + (p - cur.begin)];
+         c[i] = a.genome[(uint32_t)p + cur.shift]; // genome_len < 2^32 (checked by the launcher): a 32-bit offset
       }
    }
 #pragma unroll
    for (int i = 0; i < kBinSeqBatch; ++i) {
       if (w0 + i < w1) { // wave-uniform
-         // a position past the bin's end holds c = 0: no bit in any plane
-         const uint32_t u = c[i] & 0xDFu; // upper case
-         const bool isC = u == 'C', isG = u == 'G', isT = u == 'T';
-         const uint64_t lo = __ballot(isC | isT), hi = __ballot(isG | isT), g = __ballot(isC | isG | (c[i] - 1u < 2u));
+         // lut[byte]: bit 0 / 1 = the base code's low / high bit, bit 2 = counts as GC (kmer.h:91-124).  A position
+         // past the bin's end holds byte 0: no bit in any plane.
+         const uint32_t t = lut[c[i]];
+         const uint64_t lo = __ballot(t & 1u), hi = __ballot(t & 2u), g = __ballot(t & 4u);
          if (lane == 0) {
             plane_lo[w0 + i] = lo;
             plane_hi[w0 + i] = hi;
@@ -120,13 +120,21 @@ __device__ __forceinline__ void fetch_batch(const BinSeqArgs &a, SegCursor &cur,
 //   larger bins      two passes over the bin, pass q counting the hexamers with idx >> 11 == q in 2048 32-bit counters.
 constexpr int kBinSeqPackedMax = 65535;
 
+// log(n) for n = 0 .. 4096 (entry 0 unused), filled once per device by the host with its own libm -- the one the
+// reference calls (binseq_api.hip).  A one-chunk bin takes log(total) and the log of every count from here.
+__device__ double g_binseq_log_n[kBinSeqChunk + 1];
+// byte -> bit 0 / 1: low / high bit of the base code (C = 1, G = 2, T = 3, anything else 0; either case),
+// bit 2: counts as GC (C c G g and the bytes 1, 2).  Filled with the log table.
+__device__ uint8_t g_binseq_lut[256];
+
 __global__ __launch_bounds__(64) void binseq_kernel(BinSeqArgs a)
 {
    __shared__ uint32_t hist[2048];
    // one spare 32-bit half after the look-ahead word: plane_bits32(.., more = 1) reads it (and masks it away)
    __shared__ uint64_t plane_lo[kBinSeqWords + 2], plane_hi[kBinSeqWords + 2], plane_gc[kBinSeqWords + 2];
    __shared__ int tbl_end[64];
-   __shared__ int64_t tbl_base[64];
+   __shared__ uint32_t tbl_shift[64];
+   __shared__ uint8_t lut[256];
    __shared__ double log_tbl[64]; // log(1 .. 64)
    const uint32_t *lo32 = (const uint32_t *)plane_lo, *hi32 = (const uint32_t *)plane_hi, *gc32 = (const uint32_t *)plane_gc;
    const int lane = threadIdx.x;
@@ -138,13 +146,13 @@ __global__ __launch_bounds__(64) void binseq_kernel(BinSeqArgs a)
    int64_t len = 0;
    bool bad = false;
    int my_len = 0;
-   int64_t my_base = 0; // lane k: segment k (table form)
+   uint32_t my_base = 0; // lane k: segment k (table form)
    for (int64_t s = s0 + lane; s < s1; s += 64) {
       const int64_t l = a.seg_left[s], r = a.seg_right[s];
       bad |= (r < l) | (l < a.genome_start) | (r - a.genome_start >= a.genome_len);
       len += r - l + 1;
       my_len = (int)(r - l + 1);
-      my_base = l - a.genome_start;
+      my_base = (uint32_t)(l - a.genome_start);
    }
    for (int m = 1; m < 64; m <<= 1) len += __shfl_xor(len, m);
    if (__ballot(bad) != 0 || len > 0x7fffffff) {
@@ -156,7 +164,7 @@ __global__ __launch_bounds__(64) void binseq_kernel(BinSeqArgs a)
       }
       return;
    }
-   const int L = (int)len;
+   const int L = __builtin_amdgcn_readfirstlane((int)len); // wave-uniform: loop counts stay in SGPRs
    const int total = L - 5; // hexamers (kmer.h:19-41); <= 0: none
    if (table) {
       int scan = my_len; // inclusive prefix sum over lanes: the end position of lane k's segment
@@ -165,29 +173,29 @@ __global__ __launch_bounds__(64) void binseq_kernel(BinSeqArgs a)
          if (lane >= m) scan += up;
       }
       tbl_end[lane] = scan;
-      tbl_base[lane] = my_base;
+      tbl_shift[lane] = my_base - (uint32_t)(scan - my_len);
    }
-   log_tbl[lane] = log((double)(lane + 1));
+   log_tbl[lane] = g_binseq_log_n[lane + 1];
+   ((uint32_t *)lut)[lane] = ((const uint32_t *)g_binseq_lut)[lane];
    for (int i = lane; i < 2048 / 4; i += 64) ((uint4 *)hist)[i] = make_uint4(0, 0, 0, 0);
    if (lane == 0) plane_lo[kBinSeqWords + 1] = plane_hi[kBinSeqWords + 1] = plane_gc[kBinSeqWords + 1] = 0;
 
-   int gc_count = 0;
-   uint32_t flag_bits = 0;
+   int gc_count = 0; // per lane, summed at the end
+   int max20 = 0, max40 = 0;
    double acc = 0.0;
    const bool one_chunk = L <= kBinSeqChunk;
    const bool packed = total <= kBinSeqPackedMax;
-   const double log_total = total > 0 ? log((double)total) : 0.0;
+   const double log_total = (one_chunk && total > 0) ? g_binseq_log_n[total] : 0.0; // only the one-chunk form uses it
 
    for (int pass = 0; pass < (packed ? 1 : 2); ++pass) {
       // per-lane cursor into the segment list: the segment holding this lane's next position
       SegCursor cur;
       cur.seg = table ? 0 : s0;
-      cur.begin = 0;
       cur.end = 0;
-      cur.base = 0;
+      cur.shift = 0;
       if (s1 > s0) {
          cur.end = (int)(a.seg_right[s0] - a.seg_left[s0] + 1);
-         cur.base = (int64_t)a.seg_left[s0] - a.genome_start;
+         cur.shift = (uint32_t)(a.seg_left[s0] - (uint32_t)a.genome_start);
       }
       for (int p0 = 0; p0 < L; p0 += kBinSeqChunk) {
          __syncthreads(); // the previous chunk's readers are done with the planes (first chunk: the tables are written)
@@ -202,9 +210,9 @@ __global__ __launch_bounds__(64) void binseq_kernel(BinSeqArgs a)
          }
          for (int w0 = p0 > 0 ? 1 : 0; w0 < n_words; w0 += kBinSeqBatch) {
             if (table)
-               fetch_batch<true>(a, cur, tbl_end, tbl_base, p0, w0, n_words, L, lane, plane_lo, plane_hi, plane_gc);
+               fetch_batch<true>(a, cur, tbl_end, tbl_shift, lut, p0, w0, n_words, L, lane, plane_lo, plane_hi, plane_gc);
             else
-               fetch_batch<false>(a, cur, tbl_end, tbl_base, p0, w0, n_words, L, lane, plane_lo, plane_hi, plane_gc);
+               fetch_batch<false>(a, cur, tbl_end, tbl_shift, lut, p0, w0, n_words, L, lane, plane_lo, plane_hi, plane_gc);
          }
          if (n_words <= kBinSeqWords && lane == 0) { // the word after the last one is read as look-ahead: zero
             plane_lo[n_words] = 0;
@@ -212,25 +220,30 @@ __global__ __launch_bounds__(64) void binseq_kernel(BinSeqArgs a)
             plane_gc[n_words] = 0;
          }
          __syncthreads();
-         // ---- count
+         // ---- count.  Window flags: a lane keeps the largest GC count of the 20- and 40-base windows starting at its
+         // positions.  A window running past the bin's end only sees zero bits there, and the last full window
+         // contains whatever it does see -- so it cannot raise the maximum above a full window's unless the bin
+         // is shorter than the window, which the final test excludes.
          const int own_words = min(kBinSeqWords, n_words);
-         for (int w = 0; w < own_words; ++w) {
-            const int p = p0 + 64 * w + lane;
-            if (p < total) {
+         if (packed) {
+            for (int w = 0; w < own_words; ++w) {
+               const uint32_t lo = plane_bits32(lo32, w, lane), hi = plane_bits32(hi32, w, lane);
+               // counter (lo6 | hi6 << 6): 16-bit half (lo & 1) of the 32-bit word (lo6 >> 1) | hi6 << 5
+               if (p0 + 64 * w + lane < total) atomicAdd(&hist[((lo & 62u) >> 1) | ((hi & 63u) << 5)], (lo & 1u) ? 0x10000u : 1u);
+            }
+         } else {
+            for (int w = 0; w < own_words; ++w) {
                const uint32_t idx = (plane_bits32(lo32, w, lane) & 63u) | ((plane_bits32(hi32, w, lane) & 63u) << 6);
-               if (packed)
-                  atomicAdd(&hist[idx >> 1], 1u << ((idx & 1u) * 16u));
-               else if ((int)(idx >> 11) == pass)
-                  atomicAdd(&hist[idx & 2047u], 1u);
+               if (p0 + 64 * w + lane < total && (int)(idx >> 11) == pass) atomicAdd(&hist[idx & 2047u], 1u);
             }
-            if (pass == 0) {
-               if (lane == 0) gc_count += __popcll(plane_gc[w]);
+         }
+         if (pass == 0) {
+            for (int w = 0; w < own_words; ++w) {
                const uint32_t g0 = plane_bits32(gc32, w, lane), g1 = plane_bits32(gc32, w, lane, 1);
-               const int g20 = __popc(g0 & 0xFFFFFu), g40 = __popc(g0) + __popc(g1 & 0xFFu);
-               const bool w20 = p + 20 <= L, w40 = p + 40 <= L;
-               flag_bits |= (uint32_t)(w20 & (g20 > 16)) | ((uint32_t)(w20 & (g20 > 18)) << 1) | ((uint32_t)(w40 & (g40 > 32)) << 2) |
-                            ((uint32_t)(w40 & (g40 > 36)) << 3);
+               max20 = max(max20, (int)__popc(g0 & 0xFFFFFu));
+               max40 = max(max40, (int)(__popc(g0) + __popc(g1 & 0xFFu)));
             }
+            if (lane < own_words) gc_count += __popcll(plane_gc[lane]); // lane w: word w's GC bits
          }
          if (one_chunk) {
             // ---- entropy per position while the planes are still here (one chunk: every count is final).  A position
@@ -239,9 +252,10 @@ __global__ __launch_bounds__(64) void binseq_kernel(BinSeqArgs a)
             for (int w = 0; w < own_words; ++w) {
                const int p = 64 * w + lane;
                if (p < total) {
-                  const uint32_t idx = (plane_bits32(lo32, w, lane) & 63u) | ((plane_bits32(hi32, w, lane) & 63u) << 6);
-                  const uint32_t c = (hist[idx >> 1] >> ((idx & 1u) * 16u)) & 0xFFFFu;
-                  acc += log_total - (c <= 64 ? log_tbl[c - 1] : log((double)c));
+                  const uint32_t lo = plane_bits32(lo32, w, lane), hi = plane_bits32(hi32, w, lane);
+                  const uint32_t v = hist[((lo & 62u) >> 1) | ((hi & 63u) << 5)];
+                  const uint32_t c = (lo & 1u) ? v >> 16 : v & 0xFFFFu;
+                  acc += log_total - (c <= 64 ? log_tbl[c - 1] : g_binseq_log_n[c]);
                }
             }
          }
@@ -265,12 +279,14 @@ __global__ __launch_bounds__(64) void binseq_kernel(BinSeqArgs a)
    }
    for (int m = 1; m < 64; m <<= 1) {
       acc += __shfl_xor(acc, m);
-      flag_bits |= (uint32_t)__shfl_xor((int)flag_bits, m);
+      gc_count += __shfl_xor(gc_count, m);
    }
+   const uint32_t m20 = wave_max_u32((uint32_t)max20), m40 = wave_max_u32((uint32_t)max40);
    if (lane == 0) {
       a.gc[bin] = (double)gc_count / (double)L; // 0/0 = NaN for an empty bin (the reference asserts there)
       a.entropy[bin] = total > 0 ? (one_chunk ? acc / (double)total : acc) : 0.0;
-      a.flags[bin] = (uint8_t)flag_bits;
+      a.flags[bin] = (uint8_t)((L >= 20 ? (uint32_t)(m20 > 16) | ((uint32_t)(m20 > 18) << 1) : 0u) |
+                               (L >= 40 ? ((uint32_t)(m40 > 32) << 2) | ((uint32_t)(m40 > 36) << 3) : 0u));
    }
 }
 
