@@ -6,7 +6,9 @@
 //
 //   g++ -std=c++14 -O2 -Iinclude examples/quantify_fragments.cpp -Lstrawberry_amd/lib -lsbgpu
 //       -Wl,-rpath,$PWD/strawberry_amd/lib -o quantify_fragments
-//   ./quantify_fragments input.txt out.gtf ctx.tsv
+//   ./quantify_fragments input.txt out.gtf ctx.tsv [genome.fa]
+//         (genome.fa: the reference's `-b` option -- six sequence columns per bin in the -f table,
+//          src/alignments.cpp:1622-1636)
 //
 // Input (plain text, whitespace separated):
 //   sample <name>  chrom <name>  strand <+|->  insert <mean> <sd>  read_len <n>  min_isoform_frac <x>  long_read <0|1>
@@ -58,8 +60,8 @@ void mate_features(const std::vector<std::pair<uint32_t, uint32_t>> &blocks, std
 
 int main(int argc, char **argv)
 {
-   if (argc != 4) {
-      std::fprintf(stderr, "usage: %s input.txt out.gtf ctx.tsv\n", argv[0]);
+   if (argc != 4 && argc != 5) {
+      std::fprintf(stderr, "usage: %s input.txt out.gtf ctx.tsv [genome.fa]\n", argv[0]);
       return 2;
    }
    std::ifstream in(argv[1]);
@@ -187,6 +189,49 @@ int main(int argc, char **argv)
       last_hit[(size_t)b] = h;
       ++n_in_bin[(size_t)b];
    }
+   // -b genome.fa: GC ratio, hexamer entropy and high-GC-stretch flags of every bin's sequence, one kernel launch
+   std::vector<double> bin_gc, bin_entropy;
+   std::vector<uint8_t> bin_flags;
+   if (argc == 5) {
+      std::ifstream fa(argv[4]);
+      if (!fa) {
+         std::fprintf(stderr, "cannot open %s\n", argv[4]);
+         return 2;
+      }
+      std::string genome, line;
+      bool mine = false;
+      while (std::getline(fa, line)) {
+         if (!line.empty() && line[0] == '>')
+            mine = line.substr(1, line.find_first_of(" \t") == std::string::npos ? std::string::npos : line.find_first_of(" \t") - 1) == chrom;
+         else if (mine)
+            genome += line;
+      }
+      std::vector<int64_t> off(1, 0);
+      std::vector<uint32_t> sl, sr;
+      for (int64_t l = 0; l < L; ++l) {
+         const int64_t s0 = batch.seg_off[(size_t)l], nseg = batch.seg_off[(size_t)l + 1] - s0;
+         for (int64_t b = batch.row_off[(size_t)l]; b < batch.row_off[(size_t)l + 1]; ++b) {
+            for (int64_t s = 0; s < nseg; ++s)
+               if ((batch.bin_key[(size_t)(b * batch.key_words + (s >> 5))] >> (s & 31)) & 1u) {
+                  sl.push_back(batch.seg_left[(size_t)(s0 + s)]);
+                  sr.push_back(batch.seg_right[(size_t)(s0 + s)]);
+               }
+            off.push_back((int64_t)sl.size());
+         }
+      }
+      bin_gc.resize((size_t)n_bins);
+      bin_entropy.resize((size_t)n_bins);
+      bin_flags.resize((size_t)n_bins);
+      try {
+         sbgpu::Context ctx(0);
+         sbgpu::check(sbgpu_binseq_host(ctx.get(), (const uint8_t *)genome.data(), 1, (int64_t)genome.size(), n_bins, off.data(),
+                                        sl.data(), sr.data(), bin_gc.data(), bin_entropy.data(), bin_flags.data()),
+                      "sbgpu_binseq_host");
+      } catch (const std::exception &e) {
+         std::fprintf(stderr, "error: %s\n", e.what());
+         return 1;
+      }
+   }
    for (int64_t l = 0; l < L; ++l) {
       const int64_t b0 = batch.row_off[(size_t)l], b1 = batch.row_off[(size_t)l + 1];
       const int64_t j0 = batch.iso_off[(size_t)l], niso = batch.iso_off[(size_t)l + 1] - j0;
@@ -226,9 +271,15 @@ int main(int argc, char **argv)
             sl.push_back(c.first);
             sr.push_back(c.second);
          }
-         const int n = sbgpu_format_context_row(buf.data(), (int)buf.size(), sample.c_str(), total_mapped, gene_id[(size_t)l].c_str(),
-                                                gene_frags, (int)kept.size(), names.data(), fpkm.data(), prob.data(), frac.data(),
-                                                (int)sl.size(), sl.data(), sr.data(), (uint32_t)n_in_bin[(size_t)b]);
+         const int n =
+            bin_gc.empty()
+               ? sbgpu_format_context_row(buf.data(), (int)buf.size(), sample.c_str(), total_mapped, gene_id[(size_t)l].c_str(),
+                                          gene_frags, (int)kept.size(), names.data(), fpkm.data(), prob.data(), frac.data(),
+                                          (int)sl.size(), sl.data(), sr.data(), (uint32_t)n_in_bin[(size_t)b])
+               : sbgpu_format_context_row_seq(buf.data(), (int)buf.size(), sample.c_str(), total_mapped, gene_id[(size_t)l].c_str(),
+                                              gene_frags, (int)kept.size(), names.data(), fpkm.data(), prob.data(), frac.data(),
+                                              (int)sl.size(), sl.data(), sr.data(), (uint32_t)n_in_bin[(size_t)b], bin_gc[(size_t)b],
+                                              bin_entropy[(size_t)b], bin_flags[(size_t)b]);
          sbgpu::check(n, "sbgpu_format_context_row");
          ctxf.write(buf.data(), n);
       }

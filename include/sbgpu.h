@@ -428,7 +428,8 @@ int sbgpu_bins_export_weights(const sbgpu_bins_t *bins, double *F_out);
  *
  * Device form: all pointers are device pointers; *d_error (caller zeroes it) gets a non-zero
  * value if a segment lies outside the genome window (that bin's outputs are then 0).
- * Asynchronous on `stream`.                                                                  */
+ * genome_len must be below 2^32 (SBGPU_ESHAPE otherwise).  The first call on a device uploads two
+ * small tables (synchronous); after that the call is asynchronous on `stream`.              */
 int sbgpu_binseq_device(sbgpu_ctx_t *ctx, const uint8_t *d_genome, int64_t genome_start, int64_t genome_len,
                         int64_t n_bins, const int64_t *d_seg_off, const uint32_t *d_seg_left,
                         const uint32_t *d_seg_right, double *d_gc, double *d_entropy, uint8_t *d_flags,

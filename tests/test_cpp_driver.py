@@ -87,6 +87,18 @@ def test_cxx_driver_reproduces_reference_files(driver, tmp_path, which):
 
 
 @pytest.mark.gpu
+def test_cxx_driver_with_a_genome_reproduces_the_bias_run(driver, tmp_path):
+    """`-b genome.fa` (tests/golden/e2e_toy_bias): the -f table with its six sequence columns per bin, byte for byte."""
+    d = U.E2E_BIAS
+    inp, gtf, ctx = str(tmp_path / "in.txt"), str(tmp_path / "out.gtf"), str(tmp_path / "ctx.tsv")
+    write_input(d, inp)
+    r = subprocess.run([driver, inp, gtf, ctx, os.path.join(d, "genome.fa")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(ctx).read() == open(os.path.join(d, "ctx.tsv")).read()
+    assert open(gtf).read() == open(os.path.join(d, "out.gtf")).read().split("\n", 2)[2]
+
+
+@pytest.mark.gpu
 def test_cxx_emsolver_known_answers(kat):
     """EmSolver results captured from the reference (%.12g)."""
     r = subprocess.run([kat], capture_output=True, text=True)

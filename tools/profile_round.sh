@@ -39,6 +39,9 @@ cp $OUT/exonbin/stats/eb_kernel_stats.csv $SUM/${R}_exonbin_kernel_stats.csv
 bash tools/profile_binweight.sh $R > /dev/null 2>&1
 cp $OUT/binweight/summary.json $SUM/${R}_binweight_summary.json
 cp $OUT/binweight/bench_binweight.json $SUM/${R}_bench_binweight.json
+bash tools/profile_binseq.sh $R > /dev/null 2>&1
+cp $OUT/binseq/summary.json $SUM/${R}_binseq_summary.json
+cp $OUT/binseq/stats/bs_kernel_stats.csv $SUM/${R}_binseq_kernel_stats.csv
 # wide loci (> 64 isoforms): multi-workgroup kernel vs the streaming fallback
 (echo "em_wide_kernel (default):"; timeout 300 python tools/probe_wide_loci.py 2>/dev/null | grep "wide loci alone"; \
  echo "em_stream_kernel only (SBGPU_NO_WIDE=1):"; SBGPU_NO_WIDE=1 timeout 300 python tools/probe_wide_loci.py 2>/dev/null | grep "wide loci alone") > $SUM/${R}_wide_loci.txt
