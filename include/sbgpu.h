@@ -159,9 +159,8 @@ int sbgpu_em_batch(sbgpu_ctx_t *ctx, const sbgpu_batch_t *host_batch,
  *   d_fpkm, d_frac   [n_iso] doubles
  *   d_keep[n_iso]    0 erased (Frac < min_isoform_frac, or locus INIT_EMPTY),
  *                    1 kept, 2 kept but "NA" (effective length < 0)
- *   d_sum_fpkm[1]    += sum of FPKM over kept isoforms of this rank (the operand
- *                    of the TPM all-reduce, alignments.cpp:1821-1824); the caller
- *                    zeroes it.                                                  */
+ *   d_sum_fpkm[1]    = sum of FPKM over kept isoforms of this rank (the operand
+ *                    of the TPM all-reduce, alignments.cpp:1821-1824); overwritten. */
 int sbgpu_abundance_device(sbgpu_ctx_t *ctx, const sbgpu_plan_t *plan,
                            const double *d_theta, const int32_t *d_status,
                            const int32_t *d_length,

@@ -37,6 +37,7 @@ struct SizeClass {
    int n_blocks = 0;          // workgroups of this class inside its launch
    int block_threads = 0;
    int64_t work = 0;          // padded elements, for ordering
+   int64_t pred = 0;          // largest predicted iteration count among its loci (plan.cpp), for ordering
 };
 
 struct HostPlan {
@@ -77,6 +78,10 @@ struct PlanTuning {
    bool light_block = true;  // use the base-tile block kind (<= 256 VGPRs, shares SIMDs with wave-form
                              // waves) for the loci it holds, the tall tile only for the rest
    int64_t max_waves = 0;  // grids shrink (waves pull several batches) only beyond this many waves; 0 = 2^20
+   bool classes_by_prediction = true; // dispatch the classes with the largest predicted iteration counts first
+                                      // (SBGPU_CLASS_ORDER=cost: by the cost of an iteration only; A/B measurements)
+   bool order_by_work = false; // order a class by nrow * niso only (SBGPU_ORDER=work; A/B measurements) instead of
+                               // by the iteration count predicted from the shape
 };
 
 // Returns 0, or a negative SBGPU_E* code with `err` filled.

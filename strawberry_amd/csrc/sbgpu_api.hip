@@ -108,14 +108,11 @@ namespace {
 // ------------------------------------------------------------------ epilogue kernels
 // LocusContext::estimate_abundances, /root/reference/src/estimate.cpp:314-355.
 // One thread per locus; the per-locus FPKM sum runs in isoform order like the
-// reference's loop (:315-336).
-__global__ void abundance_kernel(int64_t n_loci, const int64_t *iso_off, const double *theta,
-                                 const int32_t *status, const int32_t *length,
-                                 sbgpu_abundance_params_t p, double *fpkm, double *frac,
-                                 int32_t *keep, double *locus_sum)
+// reference's loop (:315-336).  Returns the sum of the locus' kept FPKM.
+__device__ double abundance_locus(int64_t l, const int64_t *iso_off, const double *theta, const int32_t *status,
+                                  const int32_t *length, const sbgpu_abundance_params_t &p, double *fpkm, double *frac,
+                                  int32_t *keep)
 {
-   const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-   if (l >= n_loci) return;
    const int64_t j0 = iso_off[l], j1 = iso_off[l + 1];
    if (status[l] == sb::kStInitEmpty) {
       // estimate_abundances() returns false: quantifyCluster returns no isoforms
@@ -125,8 +122,7 @@ __global__ void abundance_kernel(int64_t n_loci, const int64_t *iso_off, const d
          frac[j] = 0.0;
          keep[j] = 0;
       }
-      locus_sum[l] = 0.0;
-      return;
+      return 0.0;
    }
    const double rpm = 1e6 / (double)p.total_mapped_reads; // :328
    double sum_fpkm = 0.0;
@@ -161,11 +157,28 @@ __global__ void abundance_kernel(int64_t n_loci, const int64_t *iso_off, const d
       keep[j] = k;
       if (k) kept_sum += fpkm[j];
    }
-   locus_sum[l] = kept_sum;
+   return kept_sum;
 }
 
-// Deterministic sum of locus_sum[0..n) in one workgroup (fixed strided order +
-// fixed tree), added to *out.  Sample::procSample, alignments.cpp:1821-1824.
+__global__ void abundance_kernel(int64_t n_loci, const int64_t *iso_off, const double *theta,
+                                 const int32_t *status, const int32_t *length,
+                                 sbgpu_abundance_params_t p, double *fpkm, double *frac,
+                                 int32_t *keep, double *block_sum)
+{
+   const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   __shared__ double part[256];
+   part[threadIdx.x] = l < n_loci ? abundance_locus(l, iso_off, theta, status, length, p, fpkm, frac, keep) : 0.0;
+   __syncthreads();
+   // this workgroup's 256 loci summed in a fixed tree: the global sum is deterministic
+   for (int w = 128; w > 0; w >>= 1) {
+      if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+      __syncthreads();
+   }
+   if (threadIdx.x == 0) block_sum[blockIdx.x] = part[0];
+}
+
+// Deterministic sum of x[0..n) (the abundance kernel's per-workgroup sums) in one workgroup (fixed strided
+// order + fixed tree), written to *out.  Sample::procSample, alignments.cpp:1821-1824.
 __global__ __launch_bounds__(1024) void sum_kernel(int64_t n, const double *x, double *out)
 {
    __shared__ double s[1024];
@@ -177,7 +190,7 @@ __global__ __launch_bounds__(1024) void sum_kernel(int64_t n, const double *x, d
       if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
       __syncthreads();
    }
-   if (threadIdx.x == 0) *out += s[0];
+   if (threadIdx.x == 0) *out = s[0];
 }
 
 // alignments.cpp:1825-1829
@@ -229,8 +242,15 @@ int sbgpu_init(int device, sbgpu_ctx_t **ctx_out)
    }
    c->n_cu = c->prop.multiProcessorCount;
    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+   // The few workgroups of the block and stream kinds run the longest loci: their streams get the higher queue
+   // priority, so that they take their slots before the thousands of short wave-form workgroups do
+   // (SBGPU_STREAM_PRIORITY=0 turns that off; A/B measurements).
+   int prio_least = 0, prio_greatest = 0;
+   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+   const bool use_prio = !(std::getenv("SBGPU_STREAM_PRIORITY") && std::atoi(std::getenv("SBGPU_STREAM_PRIORITY")) == 0);
    for (int i = 0; e == hipSuccess && i < kAuxStreams; ++i) {
-      e = hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
+      const bool long_kind = i == kKindStream[sb::kNumKinds - 1] || i == kKindStream[sb::kNumKinds - 2] || i == kKindStream[sb::kNumKinds - 3];
+      e = hipStreamCreateWithPriority(&c->aux[i], hipStreamNonBlocking, (use_prio && long_kind) ? prio_greatest : 0);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&c->join[i], hipEventDisableTiming);
    }
    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
@@ -317,6 +337,8 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
    if (const char *e = std::getenv("SBGPU_WAVE_RMULT")) tune.wave_rmult = std::atoi(e);
    if (const char *e = std::getenv("SBGPU_MAX_WAVES")) tune.max_waves = std::atoll(e);
    if (const char *e = std::getenv("SBGPU_LIGHT_BLOCK")) tune.light_block = std::atoi(e) != 0;
+   if (const char *e = std::getenv("SBGPU_ORDER")) tune.order_by_work = std::string(e) == "work";
+   if (const char *e = std::getenv("SBGPU_CLASS_ORDER")) tune.classes_by_prediction = std::string(e) != "cost";
    const bool timing = std::getenv("SBGPU_HOST_TIMING") != nullptr; // diagnostic: stage times on stderr
    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
    double t_stage = now();
@@ -765,10 +787,11 @@ int sbgpu_abundance_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const double *
    hipStream_t s = (hipStream_t)stream;
    const int64_t n = p->host.n_loci;
    const int threads = 256;
-   hipLaunchKernelGGL(abundance_kernel, dim3((unsigned)((n + threads - 1) / threads)), dim3(threads), 0, s, n,
-                      p->d_iso_off, d_theta, d_status, d_length, *params, d_fpkm, d_frac, d_keep, p->d_locus_sum);
+   const int64_t blocks = (n + threads - 1) / threads;
+   hipLaunchKernelGGL(abundance_kernel, dim3((unsigned)blocks), dim3(threads), 0, s, n, p->d_iso_off, d_theta, d_status,
+                      d_length, *params, d_fpkm, d_frac, d_keep, p->d_locus_sum);
    HIP_TRY(hipGetLastError());
-   hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, s, n, p->d_locus_sum, d_sum_fpkm);
+   hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, s, blocks, p->d_locus_sum, d_sum_fpkm);
    HIP_TRY(hipGetLastError());
    return SBGPU_OK;
 }

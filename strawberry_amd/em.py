@@ -159,7 +159,6 @@ class EmBatchSolver:
         p = _lib.sbgpu_abundance_params_t(int(total_mapped_reads), int(effective_len_norm),
                                           int(filter_by_expression), 0, float(insert_mean),
                                           float(min_isoform_frac))
-        self.d_sum_fpkm.zero_()
         _lib.check(self.ctx.L.sbgpu_abundance_device(
             self.ctx.h, self.plan.h, self.d_theta.data_ptr(), self.d_status.data_ptr(), self.d_length.data_ptr(),
             C.byref(p), self.d_fpkm.data_ptr(), self.d_frac.data_ptr(), self.d_keep.data_ptr(),
