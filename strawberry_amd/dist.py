@@ -38,8 +38,18 @@ def init_process_group(backend=None):
     return rank, world, local_rank
 
 
+def predicted_iterations(nrow, niso):
+    """The plan's shape-only estimate of a locus' EM iteration count (csrc/plan.cpp::predicted_iterations,
+    tools/probe_iteration_shape.py): slow when a locus has about as many bins as isoforms, slower with more isoforms."""
+    nrow, niso = np.asarray(nrow, np.float64), np.asarray(niso, np.float64)
+    r = nrow / np.maximum(niso, 1)
+    w = np.select([r < 0.5, r < 0.75, r < 1.25, r < 1.5, r < 2, r < 3, r < 5, r < 10],
+                  [0.10, 0.60, 1.00, 0.80, 0.55, 0.35, 0.27, 0.20], 0.17)
+    return np.minimum(80.0 * w * np.minimum(niso, 24), 1000.0).astype(np.int64)
+
+
 def shard_loci(nrow, niso, world_size):
-    """Greedy LPT partition of loci over ranks by cost nrow*niso.
+    """Greedy LPT partition of loci over ranks by cost = elements x predicted iterations.
 
     Loci with more than 64 isoforms run on the multi-workgroup kernel, whose iterations cost about
     50x more per element (an exchange between workgroups every iteration): their cost is weighted
@@ -47,7 +57,7 @@ def shard_loci(nrow, niso, world_size):
     Returns a list of int64 index arrays, one per rank, each sorted ascending so a
     rank's outputs stay in locus order.  Deterministic."""
     nrow, niso = np.asarray(nrow, np.int64), np.asarray(niso, np.int64)
-    cost = nrow * niso * np.where(niso > 64, 50, 1) + 1
+    cost = nrow * niso * np.where(niso > 64, 50, 1) * np.maximum(predicted_iterations(nrow, niso), 1) + 1
     order = np.argsort(-cost, kind="stable")
     load = np.zeros(world_size, np.int64)
     owner = np.empty(len(cost), np.int64)
