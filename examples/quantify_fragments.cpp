@@ -15,7 +15,7 @@
 //         (insert 0 0: no -i, empirical distribution; long_read: the reference's long-read workflow,
 //          Strawberry.cpp:292-303, decided by the caller from the read lengths)
 //   loci <L>
-//     locus <gene_id> <n_isoforms>
+//     locus <gene_id> <n_isoforms> <+|->                        (the gene's strand)
 //       iso <transcript_id> <n_exons> <left> <right> ...          (the reference's isoform order)
 //   pairs <P>
 //     pair <locus> <mass> <n_left_blocks> <l> <r> ... <n_right_blocks> <l> <r> ...
@@ -74,14 +74,15 @@ int main(int argc, char **argv)
    int64_t L = 0, P = 0;
    in >> tok >> L;
    sbgpu::LocusBatch batch;
-   std::vector<std::string> gene_id;
+   std::vector<std::string> gene_id, gene_strand;
    std::vector<std::vector<std::string>> tx_id;
    std::vector<std::vector<std::vector<std::pair<uint32_t, uint32_t>>>> tx_exons;
    for (int64_t l = 0; l < L; ++l) {
-      std::string g;
+      std::string g, gs;
       int niso;
-      in >> tok >> g >> niso;
+      in >> tok >> g >> niso >> gs;
       gene_id.push_back(g);
+      gene_strand.push_back(gs);
       tx_id.emplace_back();
       tx_exons.emplace_back();
       for (int j = 0; j < niso; ++j) {
@@ -161,7 +162,7 @@ int main(int argc, char **argv)
             el.push_back((int32_t)e.first);
             er.push_back((int32_t)e.second);
          }
-         const int n = sbgpu_format_gtf_transcript(buf.data(), (int)buf.size(), chrom.c_str(), strand[0], gene_id[(size_t)l].c_str(),
+         const int n = sbgpu_format_gtf_transcript(buf.data(), (int)buf.size(), chrom.c_str(), gene_strand[(size_t)l][0], gene_id[(size_t)l].c_str(),
                                                    tx_id[(size_t)l][j].c_str(), gene_id[(size_t)l].c_str(), gene_id[(size_t)l].c_str(),
                                                    (int)el.size(), el.data(), er.data(), t.FPKM, t.frac, t.TPM,
                                                    t.FPKM_s == "NA" ? 2 : 1);

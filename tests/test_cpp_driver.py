@@ -48,8 +48,9 @@ def write_input(directory, path):
             "0 0" if directory == U.E2E_EMP else ("200 80" if directory in (U.E2E_SINGLE, U.E2E_LONGREAD) else "250 30"),
             "0.05" if directory == U.E2E_FILTER else "0", directory == U.E2E_LONGREAD))
         f.write("loci %d\n" % len(names))
+        strands = U.gene_strands(directory)
         for g in names:
-            f.write("locus %s %d\n" % (g, len(ordered[g])))
+            f.write("locus %s %d %s\n" % (g, len(ordered[g]), strands[g]))
             for t, ex in ordered[g]:
                 f.write("iso %s %d %s\n" % (t, len(ex), " ".join("%d %d" % e for e in ex)))
         reads = XU.load_read_copies(directory)   # every sequenced copy, in simulation order: the library sorts and collapses
@@ -73,7 +74,7 @@ def test_examples_compile_as_cxx14_and_refuse_to_run_without_a_gpu(driver, kat, 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which", ["E2E", "E2E_LONG", "E2E_MASS", "E2E_FILTER", "E2E_EMP", "E2E_SINGLE", "E2E_LONGREAD"])
+@pytest.mark.parametrize("which", ["E2E", "E2E_LONG", "E2E_MASS", "E2E_FILTER", "E2E_EMP", "E2E_SINGLE", "E2E_LONGREAD", "E2E_MINUS"])
 def test_cxx_driver_reproduces_reference_files(driver, tmp_path, which):
     d = getattr(U, which)
     inp, gtf, ctx = str(tmp_path / "in.txt"), str(tmp_path / "out.gtf"), str(tmp_path / "ctx.tsv")

@@ -44,7 +44,7 @@ def make_annotation(rng, n_genes, ex_lo=60, ex_hi=400):
             keep = [0] + [k for k in range(1, n_ex - 1) if rng.random() < 0.6] + [n_ex - 1]
             if keep not in isos and len(keep) >= 2:
                 isos.append(keep)
-        genes.append({"id": "G%d" % (g + 1), "exons": exons, "isos": isos})
+        genes.append({"id": "G%d" % (g + 1), "exons": exons, "isos": isos, "strand": "+"})
         pos += 5000
     return genes, pos + 1000
 
@@ -56,9 +56,9 @@ def write_gtf(genes, path):
                 tid = "%s.%d" % (g["id"], t + 1)
                 ex = [g["exons"][k] for k in iso]
                 attr = 'gene_id "%s"; transcript_id "%s";' % (g["id"], tid)
-                f.write("chr1\tsynth\ttranscript\t%d\t%d\t.\t+\t.\t%s\n" % (ex[0][0], ex[-1][1], attr))
+                f.write("chr1\tsynth\ttranscript\t%d\t%d\t.\t%s\t.\t%s\n" % (ex[0][0], ex[-1][1], g["strand"], attr))
                 for (a, b) in ex:
-                    f.write("chr1\tsynth\texon\t%d\t%d\t.\t+\t.\t%s\n" % (a, b, attr))
+                    f.write("chr1\tsynth\texon\t%d\t%d\t.\t%s\t.\t%s\n" % (a, b, g["strand"], attr))
 
 
 def tx_to_genome(ex, t0, t1):
@@ -123,8 +123,8 @@ def simulate(rng, genes, frags_per_gene, dup=0.0, multi=0.0, single=False, long_
                 spans.add((left[0][0], left[-1][1]))
                 seen.add(sig)
                 rid += 1
-                recs.append((left[0][0], "r%06d\t0\tchr1\t%d\t255\t%s\t*\t0\t0\t%s\t%s\tNH:i:1\tXS:A:+" % (
-                    rid, left[0][0], cigar(left), "A" * rlen, "I" * rlen)))
+                recs.append((left[0][0], "r%06d\t0\tchr1\t%d\t255\t%s\t*\t0\t0\t%s\t%s\tNH:i:1\tXS:A:%s" % (
+                    rid, left[0][0], cigar(left), "A" * rlen, "I" * rlen, g["strand"])))
                 frags.append((gi, left, right, [1]))
                 continue
             if dup or multi:
@@ -140,10 +140,10 @@ def simulate(rng, genes, frags_per_gene, dup=0.0, multi=0.0, single=False, long_
                 nhs.append(nh)
                 rid += 1
                 name = "r%06d" % rid
-                recs.append((left[0][0], "%s\t99\tchr1\t%d\t255\t%s\t=\t%d\t%d\t%s\t%s\tNH:i:%d\tXS:A:+" % (
-                    name, left[0][0], cigar(left), right[0][0], tlen, "A" * RL, "I" * RL, nh)))
-                recs.append((right[0][0], "%s\t147\tchr1\t%d\t255\t%s\t=\t%d\t%d\t%s\t%s\tNH:i:%d\tXS:A:+" % (
-                    name, right[0][0], cigar(right), left[0][0], -tlen, "A" * RL, "I" * RL, nh)))
+                recs.append((left[0][0], "%s\t99\tchr1\t%d\t255\t%s\t=\t%d\t%d\t%s\t%s\tNH:i:%d\tXS:A:%s" % (
+                    name, left[0][0], cigar(left), right[0][0], tlen, "A" * RL, "I" * RL, nh, g["strand"])))
+                recs.append((right[0][0], "%s\t147\tchr1\t%d\t255\t%s\t=\t%d\t%d\t%s\t%s\tNH:i:%d\tXS:A:%s" % (
+                    name, right[0][0], cigar(right), left[0][0], -tlen, "A" * RL, "I" * RL, nh, g["strand"])))
             frags.append((gi, left, right, nhs))
     recs.sort(key=lambda r: r[0])
     return recs, frags
@@ -228,12 +228,18 @@ def main():
     #          with GC-rich and GC-poor stretches, some lower case, some N.  Exons of 60+ bases: the reference
     #          aborts on a bin of 40 bases or fewer (kmer.h:82, asserts are live in its release build).
     make("e2e_toy_bias", 4747, 60, 400, genome=True)
+    # e2e_toy_minus: every other gene on the minus strand (GTF strand column, XS:A:- on its reads): pins the
+    #          strand handling of the output (Contig::print2gtf's strand column and exon numbering).
+    make("e2e_toy_minus", 4848, 150, 500, minus=True)
 
 
 def make(name, seed, ex_lo, ex_hi, dup=0.0, multi=0.0, extra=(), insert=True, single=False, long_reads=False, n_frags=900,
-         genome=False):
+         genome=False, minus=False):
     rng = np.random.Generator(np.random.PCG64(seed))
     genes, chrom_len = make_annotation(rng, 6, ex_lo, ex_hi)
+    if minus:
+        for g in genes[1::2]:
+            g["strand"] = "-"
     out_dir = os.path.join(ROOT, "tests", "golden", name)
     os.makedirs(out_dir, exist_ok=True)
     with tempfile.TemporaryDirectory() as tmp:
