@@ -193,6 +193,13 @@ __global__ __launch_bounds__(1024) void sum_kernel(int64_t n, const double *x, d
    if (threadIdx.x == 0) *out = s[0];
 }
 
+// Holds a stream back for `ticks` of the 100 MHz device clock (one wave, asleep most of the time).
+__global__ void delay_kernel(unsigned long long ticks)
+{
+   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+   while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 // alignments.cpp:1825-1829
 __global__ void tpm_kernel(int64_t n, const double *fpkm, const int32_t *keep, const double *total,
                            double *tpm)
@@ -594,6 +601,15 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
       const KindLaunch &kl = p->launches[k];
       if (kl.n_classes == 0) continue;
       hipStream_t s = fork ? c->aux[kKindStream[k]] : main;
+      // The block kinds' workgroups need a whole CU's registers (tall tile) or half of them: once the thousands of
+      // wave-form workgroups have filled the chip they wait for a CU to drain.  The wave kind therefore starts a
+      // few microseconds after them (SBGPU_WAVE_DELAY_US, 0 = off; C3: 1.49 -> 1.45 ms per step at 5, no better
+      // at 10-40).
+      static const int wave_delay_us = std::getenv("SBGPU_WAVE_DELAY_US") ? std::atoi(std::getenv("SBGPU_WAVE_DELAY_US")) : 5;
+      if (fork && kKindStream[k] == 0 && wave_delay_us > 0) {
+         hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, s, (unsigned long long)wave_delay_us * 100ull);
+         HIP_TRY(hipGetLastError());
+      }
       HIP_TRY(hipEventRecord(c->t0[k], s));
       if (k == sb::kStream) {
          // wide loci: cooperative launches, one per round (all workgroups of a launch are resident)
