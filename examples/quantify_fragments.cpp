@@ -207,27 +207,12 @@ int main(int argc, char **argv)
          else if (mine)
             genome += line;
       }
-      std::vector<int64_t> off(1, 0);
-      std::vector<uint32_t> sl, sr;
-      for (int64_t l = 0; l < L; ++l) {
-         const int64_t s0 = batch.seg_off[(size_t)l], nseg = batch.seg_off[(size_t)l + 1] - s0;
-         for (int64_t b = batch.row_off[(size_t)l]; b < batch.row_off[(size_t)l + 1]; ++b) {
-            for (int64_t s = 0; s < nseg; ++s)
-               if ((batch.bin_key[(size_t)(b * batch.key_words + (s >> 5))] >> (s & 31)) & 1u) {
-                  sl.push_back(batch.seg_left[(size_t)(s0 + s)]);
-                  sr.push_back(batch.seg_right[(size_t)(s0 + s)]);
-               }
-            off.push_back((int64_t)sl.size());
-         }
-      }
-      bin_gc.resize((size_t)n_bins);
-      bin_entropy.resize((size_t)n_bins);
-      bin_flags.resize((size_t)n_bins);
       try {
          sbgpu::Context ctx(0);
-         sbgpu::check(sbgpu_binseq_host(ctx.get(), (const uint8_t *)genome.data(), 1, (int64_t)genome.size(), n_bins, off.data(),
-                                        sl.data(), sr.data(), bin_gc.data(), bin_entropy.data(), bin_flags.data()),
-                      "sbgpu_binseq_host");
+         sbgpu::BinSequenceStats st = sbgpu::bin_sequence_stats(ctx, batch, genome);
+         bin_gc.swap(st.gc);
+         bin_entropy.swap(st.entropy);
+         bin_flags.swap(st.flags);
       } catch (const std::exception &e) {
          std::fprintf(stderr, "error: %s\n", e.what());
          return 1;

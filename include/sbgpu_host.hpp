@@ -396,5 +396,38 @@ inline void finalize_tpm(std::vector<Isoform> &isoforms, double total_fpkm)
    }
 }
 
+/* The six sequence columns of the `-f` table under `-b genome.fa` (src/alignments.cpp:1622-1636) for every bin of
+ * a quantified batch: ExonBin::bin_dnaseq + Kmer<string>::GCRatio / Entropy / HighGCStrech, one kernel launch.
+ * `chrom_seq` holds the chromosome's bases as load_chrom_fasta keeps them (base 1 first).                      */
+struct BinSequenceStats {
+   std::vector<double> gc, entropy; /* per bin, batch order                                     */
+   std::vector<uint8_t> flags;      /* bit 0..3 = stretch (20, 0.8), (20, 0.9), (40, 0.8), (40, 0.9) */
+};
+inline BinSequenceStats bin_sequence_stats(const Context &ctx, const LocusBatch &batch, const std::string &chrom_seq)
+{
+   const int64_t n_loci = (int64_t)batch.row_off.size() - 1, n_bins = batch.row_off.back();
+   std::vector<int64_t> off(1, 0);
+   std::vector<uint32_t> sl, sr;
+   for (int64_t l = 0; l < n_loci; ++l) {
+      const int64_t s0 = batch.seg_off[(size_t)l], nseg = batch.seg_off[(size_t)l + 1] - s0;
+      for (int64_t b = batch.row_off[(size_t)l]; b < batch.row_off[(size_t)l + 1]; ++b) {
+         for (int64_t s = 0; s < nseg; ++s)
+            if ((batch.bin_key[(size_t)(b * batch.key_words + (s >> 5))] >> (s & 31)) & 1u) {
+               sl.push_back(batch.seg_left[(size_t)(s0 + s)]);
+               sr.push_back(batch.seg_right[(size_t)(s0 + s)]);
+            }
+         off.push_back((int64_t)sl.size());
+      }
+   }
+   BinSequenceStats out;
+   out.gc.resize((size_t)n_bins);
+   out.entropy.resize((size_t)n_bins);
+   out.flags.resize((size_t)n_bins);
+   check(sbgpu_binseq_host(ctx.get(), (const uint8_t *)chrom_seq.data(), 1, (int64_t)chrom_seq.size(), n_bins, off.data(), sl.data(),
+                           sr.data(), out.gc.data(), out.entropy.data(), out.flags.data()),
+         "sbgpu_binseq_host");
+   return out;
+}
+
 } // namespace sbgpu
 #endif /* SBGPU_HOST_HPP_ */
