@@ -11,6 +11,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/sbgpu.h"
@@ -741,10 +742,14 @@ int sbgpu_em_batch(sbgpu_ctx_t *c, const sbgpu_batch_t *b, double *theta_out, in
    if (!c || !b) return fail(SBGPU_EINVAL, "sbgpu_em_batch: null argument");
    if (b->n_loci == 0) return SBGPU_OK;
    if (!theta_out || !status_out) return fail(SBGPU_EINVAL, "sbgpu_em_batch: null output");
+   if (b->n_loci < 0 || !b->row_off || !b->iso_off || !b->f_off) return fail(SBGPU_EINVAL, "sbgpu_em_batch: bad n_loci or null offset array");
+   // The batch's sizes are its last offsets: the uploads (2.5 ms for C3 from pageable memory) start at once on a
+   // helper thread while this thread sorts the loci into size classes (2.3 ms) -- sbgpu_plan_create validates the
+   // offsets and reports what is wrong with them.
+   const int64_t n_rows = b->row_off[b->n_loci], n_iso = b->iso_off[b->n_loci], n_el = b->f_off[b->n_loci];
+   if (n_rows < 0 || n_iso < 0 || n_el < 0 || (n_rows && !b->count) || (n_el && !b->F))
+      return fail(SBGPU_EINVAL, "sbgpu_em_batch: negative size or null count / F array");
    sbgpu_plan_t *p = nullptr;
-   int rc = sbgpu_plan_create(c, b->n_loci, b->row_off, b->iso_off, b->f_off, &p);
-   if (rc != SBGPU_OK) return rc;
-   const int64_t n_rows = p->host.n_rows, n_iso = p->host.n_iso, n_el = p->host.n_elem;
    int32_t *d_count = nullptr, *d_status = nullptr, *d_iters = nullptr;
    double *d_F = nullptr, *d_theta = nullptr;
    auto cleanup = [&]() {
@@ -769,8 +774,23 @@ int sbgpu_em_batch(sbgpu_ctx_t *c, const sbgpu_batch_t *b, double *theta_out, in
    TRY_CLEAN(hipMalloc(&d_theta, (size_t)(n_iso + 1) * sizeof(double)));
    TRY_CLEAN(hipMalloc(&d_status, (size_t)b->n_loci * sizeof(int32_t)));
    TRY_CLEAN(hipMalloc(&d_iters, (size_t)b->n_loci * sizeof(int32_t)));
-   if (n_rows) TRY_CLEAN(hipMemcpyAsync(d_count, b->count, (size_t)n_rows * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-   if (n_el) TRY_CLEAN(hipMemcpyAsync(d_F, b->F, (size_t)n_el * sizeof(double), hipMemcpyHostToDevice, c->stream));
+   hipError_t up_err = hipSuccess;
+   std::thread uploader([&]() {
+      up_err = hipSetDevice(c->device);
+      if (up_err == hipSuccess && n_rows)
+         up_err = hipMemcpyAsync(d_count, b->count, (size_t)n_rows * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
+      if (up_err == hipSuccess && n_el)
+         up_err = hipMemcpyAsync(d_F, b->F, (size_t)n_el * sizeof(double), hipMemcpyHostToDevice, c->stream);
+   });
+   int rc = sbgpu_plan_create(c, b->n_loci, b->row_off, b->iso_off, b->f_off, &p);
+   uploader.join();
+   if (rc != SBGPU_OK) {
+      const std::string why = g_err; // cleanup() must not lose the planner's message
+      (void)hipStreamSynchronize(c->stream);
+      cleanup();
+      return fail(rc, why);
+   }
+   TRY_CLEAN(up_err);
    rc = sbgpu_em_run_device(c, p, d_count, d_F, d_theta, d_status, d_iters, c->stream);
    if (rc != SBGPU_OK) {
       cleanup();
