@@ -23,6 +23,16 @@ struct DevicePairs {
    const int32_t *iso_len() const { return (const int32_t *)(arena + o_iso_len); }
    const int64_t *out_index() const { return (const int64_t *)(arena + o_out_index); }
 };
+// exonbin_api.hip: the isoforms' segment lists of an annotation (host data; depends on the annotation only)
+struct IsoSegments {
+   std::vector<int64_t> seg_off;           // [n_iso + 1]
+   std::vector<int32_t> seg_idx, locus, len; // segment indices within the locus; the isoform's locus; its exonic length
+};
+void iso_segments(const sbgpu_annotation_t *annot, IsoSegments *out);
+// sbgpu_bins_create_device with the segment lists made beforehand (nullptr: made inside)
+int bins_create_device_impl(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *annot, const sbgpu_hits_t *d_hits, const float *d_mass,
+                            const int64_t *locus_hit_off, int32_t compat_words, int32_t key_words, const uint32_t *d_compat,
+                            const uint32_t *d_key, int64_t *d_hit_bin, void *stream, const IsoSegments *iso_pre, sbgpu_bins_t **out);
 int api_fail(int code, const std::string &msg); // records sbgpu_last_error(), returns code
 hipStream_t ctx_stream(const sbgpu_ctx_t *ctx); // the context's own stream
 int ctx_cu_count(const sbgpu_ctx_t *ctx);

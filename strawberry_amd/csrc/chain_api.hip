@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/sbgpu.h"
@@ -111,6 +112,17 @@ int sbgpu_quantify_host(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgp
       const int rc_ = (expr);            \
       if (rc_ != SBGPU_OK) return rc_;   \
    } while (0)
+   // The isoforms' segment lists depend on the annotation only: a helper thread makes them (1 ms of host work for
+   // 20 000 loci) while this one feeds the uploads.
+   struct Joiner {
+      std::thread t;
+      ~Joiner()
+      {
+         if (t.joinable()) t.join();
+      }
+   } iso_worker;
+   sb::IsoSegments iso_pre;
+   if (grouped && nh) iso_worker.t = std::thread([&]() { sb::iso_segments(an, &iso_pre); });
    for (Part &p : parts)
       if (p.bytes) SB_TRY(hipMemcpyAsync(in.p + p.off, p.src, p.bytes, hipMemcpyHostToDevice, s));
    sbgpu_annotation_t dan = *an;
@@ -185,7 +197,10 @@ int sbgpu_quantify_host(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgp
    // ---- A5: bins (device; host when the device form declines)
    sbgpu_bins_t *bins = nullptr;
    int rc = SBGPU_EUNSUPPORTED;
-   if (grouped && nh) rc = sbgpu_bins_create_device(c, an, &dh, d_mass, locus_hit_off.data(), cw, kw, d_compat, d_key, d_hit_bin, s, &bins);
+   if (grouped && nh) {
+      iso_worker.t.join();
+      rc = sb::bins_create_device_impl(c, an, &dh, d_mass, locus_hit_off.data(), cw, kw, d_compat, d_key, d_hit_bin, s, &iso_pre, &bins);
+   }
    const bool on_device = rc == SBGPU_OK;
    if (rc == SBGPU_EUNSUPPORTED) {
       SB_RC(need_compat());

@@ -164,9 +164,72 @@ int sbgpu_exonbin_host(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgpu
    return SBGPU_OK;
 }
 
-int sbgpu_bins_create_device(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgpu_hits_t *dh, const float *d_mass,
-                             const int64_t *locus_hit_off, int32_t compat_words, int32_t key_words, const uint32_t *d_compat,
-                             const uint32_t *d_key, int64_t *d_hit_bin, void *stream, sbgpu_bins_t **out)
+} // extern "C"
+
+namespace sb {
+// The isoforms' segment lists (Isoform::_exon_segs, include/isoform.h:59-71; contig.cpp:615-634), their loci and
+// exonic lengths, from the host annotation: two passes over the loci on host threads (count, then write).
+void iso_segments(const sbgpu_annotation_t *an, IsoSegments *out)
+{
+   const int64_t nl = an->n_loci, n_iso = an->iso_off[nl];
+   std::vector<int64_t> &iso_seg_off = out->seg_off;
+   std::vector<int32_t> &iso_seg_idx = out->seg_idx, &iso_locus = out->locus, &iso_len = out->len;
+   iso_seg_off.assign((size_t)n_iso + 1, 0);
+   iso_locus.assign((size_t)(n_iso > 0 ? n_iso : 1), 0);
+   iso_len.assign((size_t)(n_iso > 0 ? n_iso : 1), 0);
+   iso_seg_idx.clear();
+   {
+      // two passes over the loci on host threads: count the segments of every isoform, then write them
+      unsigned nt = std::thread::hardware_concurrency();
+      if (nt > 16) nt = 16;
+      if (const char *ev = std::getenv("SBGPU_HOST_THREADS")) nt = (unsigned)std::atoi(ev);
+      if (nt < 1) nt = 1;
+      if ((int64_t)nt * 2048 > nl) nt = (unsigned)std::max<int64_t>(1, nl / 2048);
+      auto walk = [&](int64_t l, bool fill) {
+         const int64_t s0 = an->seg_off[l], nseg = an->seg_off[l + 1] - s0;
+         for (int64_t iso = an->iso_off[l]; iso < an->iso_off[l + 1]; ++iso) {
+            const int64_t e0 = an->exon_off[iso], ne = an->exon_off[iso + 1] - e0;
+            int64_t e = 0, n = 0;
+            int32_t *dst = fill ? iso_seg_idx.data() + iso_seg_off[(size_t)iso] : nullptr;
+            for (int64_t sidx = 0; sidx < nseg; ++sidx) {
+               const uint32_t sl = an->seg_left[s0 + sidx], sr = an->seg_right[s0 + sidx];
+               while (e < ne && an->exon_right[e0 + e] < sl) ++e; // contig.cpp:615-634; segments ascend
+               if (e < ne && an->exon_left[e0 + e] <= sl && an->exon_right[e0 + e] >= sr) {
+                  if (fill) dst[n] = (int32_t)sidx;
+                  ++n;
+               }
+            }
+            if (!fill) {
+               int64_t len = 0;
+               for (int64_t x = 0; x < ne; ++x) len += (int64_t)an->exon_right[e0 + x] - an->exon_left[e0 + x] + 1;
+               iso_seg_off[(size_t)iso + 1] = n; // a count for now
+               iso_locus[(size_t)iso] = (int32_t)l;
+               iso_len[(size_t)iso] = (int32_t)len;
+            }
+         }
+      };
+      auto run = [&](bool fill) {
+         if (nt <= 1) {
+            for (int64_t l = 0; l < nl; ++l) walk(l, fill);
+            return;
+         }
+         std::vector<std::thread> pool;
+         for (unsigned t = 0; t < nt; ++t)
+            pool.emplace_back([&, t]() {
+               for (int64_t l = nl * t / nt; l < nl * (t + 1) / nt; ++l) walk(l, fill);
+            });
+         for (auto &th : pool) th.join();
+      };
+      run(false);
+      for (int64_t i = 0; i < n_iso; ++i) iso_seg_off[(size_t)i + 1] += iso_seg_off[(size_t)i];
+      iso_seg_idx.resize((size_t)iso_seg_off[(size_t)n_iso]);
+      run(true);
+   }
+}
+
+int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgpu_hits_t *dh, const float *d_mass,
+                            const int64_t *locus_hit_off, int32_t compat_words, int32_t key_words, const uint32_t *d_compat,
+                            const uint32_t *d_key, int64_t *d_hit_bin, void *stream, const IsoSegments *iso_pre, sbgpu_bins_t **out)
 {
    if (!c || !an || !dh || !locus_hit_off || !out) return api_fail(SBGPU_EINVAL, "sbgpu_bins_create_device: null argument");
    *out = nullptr;
@@ -325,58 +388,16 @@ int sbgpu_bins_create_device(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const
    // ---- the (bin, isoform) pairs, on the device too (bins_pairs_kernel): the isoforms' segment lists
    // (Isoform::_exon_segs, include/isoform.h:59-71) come from the host annotation
    const int64_t n_iso = an->iso_off[nl];
-   std::vector<int64_t> iso_seg_off((size_t)n_iso + 1, 0), f_off((size_t)nl + 1, 0);
-   std::vector<int32_t> iso_locus((size_t)(n_iso > 0 ? n_iso : 1)), iso_len((size_t)(n_iso > 0 ? n_iso : 1));
-   std::vector<int32_t> iso_seg_idx;
-   {
-      // two passes over the loci on host threads: count the segments of every isoform, then write them
-      unsigned nt = std::thread::hardware_concurrency();
-      if (nt > 16) nt = 16;
-      if (const char *ev = std::getenv("SBGPU_HOST_THREADS")) nt = (unsigned)std::atoi(ev);
-      if (nt < 1) nt = 1;
-      if ((int64_t)nt * 2048 > nl) nt = (unsigned)std::max<int64_t>(1, nl / 2048);
-      auto walk = [&](int64_t l, bool fill) {
-         const int64_t s0 = an->seg_off[l], nseg = an->seg_off[l + 1] - s0;
-         for (int64_t iso = an->iso_off[l]; iso < an->iso_off[l + 1]; ++iso) {
-            const int64_t e0 = an->exon_off[iso], ne = an->exon_off[iso + 1] - e0;
-            int64_t e = 0, n = 0;
-            int32_t *dst = fill ? iso_seg_idx.data() + iso_seg_off[(size_t)iso] : nullptr;
-            for (int64_t sidx = 0; sidx < nseg; ++sidx) {
-               const uint32_t sl = an->seg_left[s0 + sidx], sr = an->seg_right[s0 + sidx];
-               while (e < ne && an->exon_right[e0 + e] < sl) ++e; // contig.cpp:615-634; segments ascend
-               if (e < ne && an->exon_left[e0 + e] <= sl && an->exon_right[e0 + e] >= sr) {
-                  if (fill) dst[n] = (int32_t)sidx;
-                  ++n;
-               }
-            }
-            if (!fill) {
-               int64_t len = 0;
-               for (int64_t x = 0; x < ne; ++x) len += (int64_t)an->exon_right[e0 + x] - an->exon_left[e0 + x] + 1;
-               iso_seg_off[(size_t)iso + 1] = n; // a count for now
-               iso_locus[(size_t)iso] = (int32_t)l;
-               iso_len[(size_t)iso] = (int32_t)len;
-            }
-         }
-      };
-      auto run = [&](bool fill) {
-         if (nt <= 1) {
-            for (int64_t l = 0; l < nl; ++l) walk(l, fill);
-            return;
-         }
-         std::vector<std::thread> pool;
-         for (unsigned t = 0; t < nt; ++t)
-            pool.emplace_back([&, t]() {
-               for (int64_t l = nl * t / nt; l < nl * (t + 1) / nt; ++l) walk(l, fill);
-            });
-         for (auto &th : pool) th.join();
-      };
-      run(false);
-      for (int64_t l = 0; l < nl; ++l)
-         f_off[(size_t)l + 1] = f_off[(size_t)l] + (row_off[(size_t)l + 1] - row_off[(size_t)l]) * (an->iso_off[l + 1] - an->iso_off[l]);
-      for (int64_t i = 0; i < n_iso; ++i) iso_seg_off[(size_t)i + 1] += iso_seg_off[(size_t)i];
-      iso_seg_idx.resize((size_t)iso_seg_off[(size_t)n_iso]);
-      run(true);
+   std::vector<int64_t> f_off((size_t)nl + 1, 0);
+   sb::IsoSegments own_segments;
+   if (!iso_pre) { // a caller that knows the annotation earlier makes them while something else runs (chain_api.hip)
+      sb::iso_segments(an, &own_segments);
+      iso_pre = &own_segments;
    }
+   const std::vector<int64_t> &iso_seg_off = iso_pre->seg_off;
+   const std::vector<int32_t> &iso_seg_idx = iso_pre->seg_idx, &iso_locus = iso_pre->locus, &iso_len = iso_pre->len;
+   for (int64_t l = 0; l < nl; ++l)
+      f_off[(size_t)l + 1] = f_off[(size_t)l] + (row_off[(size_t)l + 1] - row_off[(size_t)l]) * (an->iso_off[l + 1] - an->iso_off[l]);
    stage("iso segments");
    const size_t ni1 = (size_t)(n_iso > 0 ? n_iso : 1), nsi1 = iso_seg_idx.empty() ? 1 : iso_seg_idx.size();
    const int64_t n_seg = an->seg_off[nl];
@@ -498,6 +519,17 @@ int sbgpu_bins_create_device(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const
    if (rc != SBGPU_OK) (void)hipFree(dp.arena);
    stage("handle");
    return rc;
+}
+} // namespace sb
+
+extern "C" {
+
+int sbgpu_bins_create_device(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgpu_hits_t *dh, const float *d_mass,
+                             const int64_t *locus_hit_off, int32_t compat_words, int32_t key_words, const uint32_t *d_compat,
+                             const uint32_t *d_key, int64_t *d_hit_bin, void *stream, sbgpu_bins_t **out)
+{
+   return sb::bins_create_device_impl(c, an, dh, d_mass, locus_hit_off, compat_words, key_words, d_compat, d_key, d_hit_bin, stream,
+                                      nullptr, out);
 }
 
 } // extern "C"
