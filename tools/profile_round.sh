@@ -8,8 +8,6 @@ SUM=$OUT/summary
 mkdir -p $SUM
 cd $REPO
 (timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -4) > $SUM/${R}_pytest_gpu.txt
-(timeout 900 python bench.py 2>/dev/null) > $SUM/${R}_bench_c3.json
-(timeout 600 python bench.py --workload c2 2>/dev/null) > $SUM/${R}_bench_c2.json
 cd /tmp && export TMPDIR=/tmp
 # kernel trace + stats in their own runs; every PMC group in its own run, never with a trace domain
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3 -o em -- python3 $REPO/bench.py --no-cpu-baseline --steps 10 > $OUT/stats_c3.log 2>&1
@@ -17,6 +15,8 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_c3 -o em -- python3 $REPO/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_c3 -o em -- python3 $REPO/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_write.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_sq_c3 -o em -- python3 $REPO/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_sq.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_c2 -o em -- python3 $REPO/bench.py --workload c2 --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_fetch_c2.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_c2 -o em -- python3 $REPO/bench.py --workload c2 --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_write_c2.log 2>&1
 cd $REPO
 python3 - "$OUT" "$SUM" "$R" <<'PY'
 import collections, csv, glob, json, shutil, sys
@@ -24,15 +24,20 @@ out, summ, r = sys.argv[1:4]
 for w in ("c3", "c2"):
     for f in glob.glob("%s/stats_%s/**/*kernel_stats.csv" % (out, w), recursive=True):
         shutil.copy(f, "%s/%s_%s_kernel_stats.csv" % (summ, r, w))
-acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(out + "/pmc_*_c3/**/*counter_collection.csv", recursive=True):
-    for row in csv.DictReader(open(f)):
-        k = row["Kernel_Name"]
-        if "sb::" in k:
-            acc[k.split("(")[0]][row["Counter_Name"]].append(float(row["Counter_Value"]))
-json.dump({k: {c: {"mean_per_dispatch": sum(v) / len(v), "dispatches": len(v)} for c, v in cs.items()} for k, cs in acc.items()},
-          open("%s/%s_c3_pmc_summary.json" % (summ, r), "w"), indent=1)
+for w in ("c3", "c2"):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(out + "/pmc_*_%s/**/*counter_collection.csv" % w, recursive=True):
+        for row in csv.DictReader(open(f)):
+            k = row["Kernel_Name"]
+            if "sb::" in k:
+                acc[k.split("(")[0]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    json.dump({k: {c: {"mean_per_dispatch": sum(v) / len(v), "dispatches": len(v)} for c, v in cs.items()} for k, cs in acc.items()},
+              open("%s/%s_%s_pmc_summary.json" % (summ, r, w), "w"), indent=1)
 PY
+# the bench lines come after the counter passes: bench.py reads roofline.traffic from profiles/*_pmc_summary.json
+cp $SUM/${R}_c3_pmc_summary.json $SUM/${R}_c2_pmc_summary.json $REPO/profiles/ 2>/dev/null
+(timeout 900 python bench.py 2>/dev/null) > $SUM/${R}_bench_c3.json
+(timeout 600 python bench.py --workload c2 2>/dev/null) > $SUM/${R}_bench_c2.json
 bash tools/profile_exonbin.sh $R > /dev/null 2>&1
 cp $OUT/exonbin/summary.json $SUM/${R}_exonbin_summary.json
 cp $OUT/exonbin/stats/eb_kernel_stats.csv $SUM/${R}_exonbin_kernel_stats.csv
