@@ -15,7 +15,7 @@
 //         (insert 0 0: no -i, empirical distribution; long_read: the reference's long-read workflow,
 //          Strawberry.cpp:292-303, decided by the caller from the read lengths)
 //   loci <L>
-//     locus <gene_id> <n_isoforms> <+|->                        (the gene's strand)
+//     locus <gene_id> <n_isoforms> <+|-> <chrom>                (the gene's strand and chromosome)
 //       iso <transcript_id> <n_exons> <left> <right> ...          (the reference's isoform order)
 //   pairs <P>
 //     pair <locus> <mass> <n_left_blocks> <l> <r> ... <n_right_blocks> <l> <r> ...
@@ -74,15 +74,16 @@ int main(int argc, char **argv)
    int64_t L = 0, P = 0;
    in >> tok >> L;
    sbgpu::LocusBatch batch;
-   std::vector<std::string> gene_id, gene_strand;
+   std::vector<std::string> gene_id, gene_strand, gene_chrom;
    std::vector<std::vector<std::string>> tx_id;
    std::vector<std::vector<std::vector<std::pair<uint32_t, uint32_t>>>> tx_exons;
    for (int64_t l = 0; l < L; ++l) {
-      std::string g, gs;
+      std::string g, gs, gc;
       int niso;
-      in >> tok >> g >> niso >> gs;
+      in >> tok >> g >> niso >> gs >> gc;
       gene_id.push_back(g);
       gene_strand.push_back(gs);
+      gene_chrom.push_back(gc);
       tx_id.emplace_back();
       tx_exons.emplace_back();
       for (int j = 0; j < niso; ++j) {
@@ -162,7 +163,7 @@ int main(int argc, char **argv)
             el.push_back((int32_t)e.first);
             er.push_back((int32_t)e.second);
          }
-         const int n = sbgpu_format_gtf_transcript(buf.data(), (int)buf.size(), chrom.c_str(), gene_strand[(size_t)l][0], gene_id[(size_t)l].c_str(),
+         const int n = sbgpu_format_gtf_transcript(buf.data(), (int)buf.size(), gene_chrom[(size_t)l].c_str(), gene_strand[(size_t)l][0], gene_id[(size_t)l].c_str(),
                                                    tx_id[(size_t)l][j].c_str(), gene_id[(size_t)l].c_str(), gene_id[(size_t)l].c_str(),
                                                    (int)el.size(), el.data(), er.data(), t.FPKM, t.frac, t.TPM,
                                                    t.FPKM_s == "NA" ? 2 : 1);
@@ -194,6 +195,11 @@ int main(int argc, char **argv)
    std::vector<double> bin_gc, bin_entropy;
    std::vector<uint8_t> bin_flags;
    if (argc == 5) {
+      for (const std::string &gc : gene_chrom)
+         if (gc != chrom) {
+            std::fprintf(stderr, "genome.fa: this driver takes one chromosome per run (header `chrom %s`, a locus on %s)\n", chrom.c_str(), gc.c_str());
+            return 2;
+         }
       std::ifstream fa(argv[4]);
       if (!fa) {
          std::fprintf(stderr, "cannot open %s\n", argv[4]);

@@ -20,6 +20,7 @@ E2E_SINGLE = os.path.join(HERE, "golden", "e2e_toy_single")  # single-end librar
 E2E_LONGREAD = os.path.join(HERE, "golden", "e2e_toy_longread")  # unpaired reads of 1001-2600 bases: long-read workflow, F = 1/L
 E2E_BIAS = os.path.join(HERE, "golden", "e2e_toy_bias")     # -b genome.fa: six sequence columns per bin in the -f table
 E2E_MINUS = os.path.join(HERE, "golden", "e2e_toy_minus")   # every other gene on the minus strand
+E2E_CHROMS = os.path.join(HERE, "golden", "e2e_toy_chroms")  # genes alternating between two chromosomes
 E2E_FILTER = os.path.join(HERE, "golden", "e2e_toy_filter")  # e2e_toy_long's reads with -e 0.05: isoforms erased
 
 
@@ -57,14 +58,19 @@ def parse_annotation(path=os.path.join(E2E, "toy.gtf")):
     return genes
 
 
-def gene_strands(directory):
+def gene_strands(directory, column=6):
     """-> {gene: '+' / '-'} from the annotation's strand column."""
     out = {}
     for line in open(os.path.join(directory, "toy.gtf")):
         f = line.rstrip("\n").split("\t")
         if len(f) >= 9 and f[2] == "exon":
-            out[re.search(r'gene_id "([^"]+)"', f[8]).group(1)] = f[6]
+            out[re.search(r'gene_id "([^"]+)"', f[8]).group(1)] = f[column]
     return out
+
+
+def gene_chroms(directory):
+    """-> {gene: chromosome name} from the annotation."""
+    return gene_strands(directory, column=0)
 
 
 def disjoint_segments(exons):

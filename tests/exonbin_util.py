@@ -37,6 +37,14 @@ def load_read_copies(directory):
     return out
 
 
+def locus_of_gene_index(directory, names):
+    """reads.npz numbers genes in annotation-file order; `names` is the reference's output order (chromosome by
+    chromosome, the order of its -f table): annotation index -> locus index."""
+    import e2e_util as U
+    ann = list(U.parse_annotation(os.path.join(directory, "toy.gtf")))
+    return [names.index(g) for g in ann]
+
+
 def e2e_inputs(directory, ordered_genes):
     """-> (Annotation, Hits, gene names, rejected pair count).  Loci in gene order with the reference's
     isoform order; hits as HitCluster::collapseAndFilterHits leaves them: sorted by (left, right) of
@@ -45,11 +53,12 @@ def e2e_inputs(directory, ordered_genes):
     raw mass of every cluster, summed (src/alignments.cpp:1372)."""
     names = list(ordered_genes)
     annot = eb.Annotation([[ex for _, ex in ordered_genes[g]] for g in names])
-    # reads.npz numbers genes in annotation-file order G1..Gn, the same as `names`
+    locus_of = locus_of_gene_index(directory, names)
     rows = []
     rejected = 0
     cluster_mass = [0.0] * len(names)
     for gi, lb, rb, mass in load_reads(directory):
+        gi = locus_of[gi]
         cluster_mass[gi] += mass
         f = eb.hit_features(lb, rb)
         if f is None:

@@ -48,14 +48,16 @@ def write_input(directory, path):
             "0 0" if directory == U.E2E_EMP else ("200 80" if directory in (U.E2E_SINGLE, U.E2E_LONGREAD) else "250 30"),
             "0.05" if directory == U.E2E_FILTER else "0", directory == U.E2E_LONGREAD))
         f.write("loci %d\n" % len(names))
-        strands = U.gene_strands(directory)
+        strands, chroms = U.gene_strands(directory), U.gene_chroms(directory)
         for g in names:
-            f.write("locus %s %d %s\n" % (g, len(ordered[g]), strands[g]))
+            f.write("locus %s %d %s %s\n" % (g, len(ordered[g]), strands[g], chroms[g]))
             for t, ex in ordered[g]:
                 f.write("iso %s %d %s\n" % (t, len(ex), " ".join("%d %d" % e for e in ex)))
         reads = XU.load_read_copies(directory)   # every sequenced copy, in simulation order: the library sorts and collapses
         f.write("pairs %d\n" % len(reads))
+        locus_of = XU.locus_of_gene_index(directory, names)
         for gi, lb, rb, mass in reads:
+            gi = locus_of[gi]
             f.write("pair %d %.17g %d %s %d %s\n" % (gi, mass, len(lb), " ".join("%d %d" % b for b in lb), len(rb),
                                                     " ".join("%d %d" % b for b in rb)))
     return rows
@@ -74,7 +76,7 @@ def test_examples_compile_as_cxx14_and_refuse_to_run_without_a_gpu(driver, kat, 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which", ["E2E", "E2E_LONG", "E2E_MASS", "E2E_FILTER", "E2E_EMP", "E2E_SINGLE", "E2E_LONGREAD", "E2E_MINUS"])
+@pytest.mark.parametrize("which", ["E2E", "E2E_LONG", "E2E_MASS", "E2E_FILTER", "E2E_EMP", "E2E_SINGLE", "E2E_LONGREAD", "E2E_MINUS", "E2E_CHROMS"])
 def test_cxx_driver_reproduces_reference_files(driver, tmp_path, which):
     d = getattr(U, which)
     inp, gtf, ctx = str(tmp_path / "in.txt"), str(tmp_path / "out.gtf"), str(tmp_path / "ctx.tsv")

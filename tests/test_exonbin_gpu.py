@@ -352,7 +352,7 @@ def test_large_batch_properties(ctx, oracle):
     np.testing.assert_array_equal(k2.reshape(64, hits.n_hits, -1), np.broadcast_to(key, (64,) + key.shape))
 
 
-@pytest.mark.parametrize("which", ["E2E", "E2E_LONG", "E2E_MASS", "E2E_FILTER", "E2E_EMP", "E2E_SINGLE", "E2E_LONGREAD", "E2E_MINUS"])
+@pytest.mark.parametrize("which", ["E2E", "E2E_LONG", "E2E_MASS", "E2E_FILTER", "E2E_EMP", "E2E_SINGLE", "E2E_LONGREAD", "E2E_MINUS", "E2E_CHROMS"])
 def test_chain_from_fragments_reproduces_reference_run(ctx, oracle, which):
     """Our simulated fragments (reads.npz, the BAM the reference binary was run on) through the whole
     device chain: bins and counts == the -f table; every nonzero weight of the table == F (12 digits);
@@ -427,11 +427,11 @@ def test_chain_from_fragments_reproduces_reference_run(ctx, oracle, which):
     assert table == open(os.path.join(d, "ctx.tsv")).read()
     gtf_text = []
     k = 0
-    strands = U.gene_strands(d)
+    strands, chroms = U.gene_strands(d), U.gene_chroms(d)
     for g in names:
         for t, ex in ordered[g]:
             if res["keep"][k]:
-                gtf_text.append(gtf_transcript("chr1", strands[g], g, t, ex, res["fpkm"][k], res["frac"][k], res["tpm"][k],
+                gtf_text.append(gtf_transcript(chroms[g], strands[g], g, t, ex, res["fpkm"][k], res["frac"][k], res["tpm"][k],
                                                ref_gene_id=g, ref_gene_name=g))
             k += 1
     ref_gtf = open(os.path.join(d, "out.gtf")).read().split("\n", 2)

@@ -44,7 +44,7 @@ def make_annotation(rng, n_genes, ex_lo=60, ex_hi=400):
             keep = [0] + [k for k in range(1, n_ex - 1) if rng.random() < 0.6] + [n_ex - 1]
             if keep not in isos and len(keep) >= 2:
                 isos.append(keep)
-        genes.append({"id": "G%d" % (g + 1), "exons": exons, "isos": isos, "strand": "+"})
+        genes.append({"id": "G%d" % (g + 1), "exons": exons, "isos": isos, "strand": "+", "chrom": "chr1"})
         pos += 5000
     return genes, pos + 1000
 
@@ -56,9 +56,9 @@ def write_gtf(genes, path):
                 tid = "%s.%d" % (g["id"], t + 1)
                 ex = [g["exons"][k] for k in iso]
                 attr = 'gene_id "%s"; transcript_id "%s";' % (g["id"], tid)
-                f.write("chr1\tsynth\ttranscript\t%d\t%d\t.\t%s\t.\t%s\n" % (ex[0][0], ex[-1][1], g["strand"], attr))
+                f.write("%s\tsynth\ttranscript\t%d\t%d\t.\t%s\t.\t%s\n" % (g["chrom"], ex[0][0], ex[-1][1], g["strand"], attr))
                 for (a, b) in ex:
-                    f.write("chr1\tsynth\texon\t%d\t%d\t.\t%s\t.\t%s\n" % (a, b, g["strand"], attr))
+                    f.write("%s\tsynth\texon\t%d\t%d\t.\t%s\t.\t%s\n" % (g["chrom"], a, b, g["strand"], attr))
 
 
 def tx_to_genome(ex, t0, t1):
@@ -123,7 +123,7 @@ def simulate(rng, genes, frags_per_gene, dup=0.0, multi=0.0, single=False, long_
                 spans.add((left[0][0], left[-1][1]))
                 seen.add(sig)
                 rid += 1
-                recs.append((left[0][0], "r%06d\t0\tchr1\t%d\t255\t%s\t*\t0\t0\t%s\t%s\tNH:i:1\tXS:A:%s" % (
+                recs.append(((g["chrom"], left[0][0]), "r%06d\t0\t@CHROM@\t%d\t255\t%s\t*\t0\t0\t%s\t%s\tNH:i:1\tXS:A:%s" % (
                     rid, left[0][0], cigar(left), "A" * rlen, "I" * rlen, g["strand"])))
                 frags.append((gi, left, right, [1]))
                 continue
@@ -140,11 +140,12 @@ def simulate(rng, genes, frags_per_gene, dup=0.0, multi=0.0, single=False, long_
                 nhs.append(nh)
                 rid += 1
                 name = "r%06d" % rid
-                recs.append((left[0][0], "%s\t99\tchr1\t%d\t255\t%s\t=\t%d\t%d\t%s\t%s\tNH:i:%d\tXS:A:%s" % (
+                recs.append(((g["chrom"], left[0][0]), "%s\t99\t@CHROM@\t%d\t255\t%s\t=\t%d\t%d\t%s\t%s\tNH:i:%d\tXS:A:%s" % (
                     name, left[0][0], cigar(left), right[0][0], tlen, "A" * RL, "I" * RL, nh, g["strand"])))
-                recs.append((right[0][0], "%s\t147\tchr1\t%d\t255\t%s\t=\t%d\t%d\t%s\t%s\tNH:i:%d\tXS:A:%s" % (
+                recs.append(((g["chrom"], right[0][0]), "%s\t147\t@CHROM@\t%d\t255\t%s\t=\t%d\t%d\t%s\t%s\tNH:i:%d\tXS:A:%s" % (
                     name, right[0][0], cigar(right), left[0][0], -tlen, "A" * RL, "I" * RL, nh, g["strand"])))
             frags.append((gi, left, right, nhs))
+    recs = [(k, line.replace("@CHROM@", k[0])) for k, line in recs]
     recs.sort(key=lambda r: r[0])
     return recs, frags
 
@@ -231,15 +232,21 @@ def main():
     # e2e_toy_minus: every other gene on the minus strand (GTF strand column, XS:A:- on its reads): pins the
     #          strand handling of the output (Contig::print2gtf's strand column and exon numbering).
     make("e2e_toy_minus", 4848, 150, 500, minus=True)
+    # e2e_toy_chroms: the genes alternate between two chromosomes: the mapped-read total runs over both
+    #          (alignments.cpp:1372) and the output is written chromosome by chromosome.
+    make("e2e_toy_chroms", 4949, 150, 500, chroms=2)
 
 
 def make(name, seed, ex_lo, ex_hi, dup=0.0, multi=0.0, extra=(), insert=True, single=False, long_reads=False, n_frags=900,
-         genome=False, minus=False):
+         genome=False, minus=False, chroms=1):
     rng = np.random.Generator(np.random.PCG64(seed))
     genes, chrom_len = make_annotation(rng, 6, ex_lo, ex_hi)
     if minus:
         for g in genes[1::2]:
             g["strand"] = "-"
+    if chroms == 2:
+        for g in genes[1::2]:
+            g["chrom"] = "chr2"
     out_dir = os.path.join(ROOT, "tests", "golden", name)
     os.makedirs(out_dir, exist_ok=True)
     with tempfile.TemporaryDirectory() as tmp:
@@ -249,7 +256,7 @@ def make(name, seed, ex_lo, ex_hi, dup=0.0, multi=0.0, extra=(), insert=True, si
         save_frags(frags, os.path.join(out_dir, "reads.npz"))
         sam = os.path.join(tmp, "toy.sam")
         with open(sam, "w") as f:
-            f.write("@HD\tVN:1.0\tSO:coordinate\n@SQ\tSN:chr1\tLN:%d\n" % chrom_len)
+            f.write("@HD\tVN:1.0\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % (c, chrom_len) for c in sorted(set(g["chrom"] for g in genes))))
             for _, line in recs:
                 f.write(line + "\n")
         bam = os.path.join(tmp, "toy.bam")
