@@ -29,15 +29,16 @@ def read_fasta(path):
 
 
 def bin_segments(bins):
-    """(seg_off, seg_left, seg_right) of every bin of an exonbin.LocusBins, bins in batch order."""
-    off, sl, sr = [0], [], []
-    for l in range(len(bins.row_off) - 1):
-        for coords in bins.bin_coords(l):
-            for (a, b) in coords:
-                sl.append(a)
-                sr.append(b)
-            off.append(len(sl))
-    return np.asarray(off, np.int64), np.asarray(sl, np.uint32), np.asarray(sr, np.uint32)
+    """(seg_off, seg_left, seg_right) of every bin of an exonbin.LocusBins, bins in batch order: the set bits of
+    the bins' key words, as coordinates of the loci's disjoint segments (ascending, like ExonBin::_coords)."""
+    annot = bins._annot
+    key = np.ascontiguousarray(bins.bin_key, np.uint32).reshape(bins.n_bins, -1)
+    bits = np.unpackbits(key.view(np.uint8), axis=1, bitorder="little")      # [n_bins, 32 * key_words]
+    b, k = np.nonzero(bits)                                                  # by bin, then by segment
+    locus = np.searchsorted(np.asarray(bins.row_off), b, side="right") - 1
+    seg = np.asarray(annot.seg_off)[locus] + k
+    off = np.concatenate([[0], np.cumsum(bits.sum(axis=1, dtype=np.int64))]).astype(np.int64)
+    return off, np.asarray(annot.seg_left)[seg].astype(np.uint32), np.asarray(annot.seg_right)[seg].astype(np.uint32)
 
 
 def bin_sequence_stats(genome, seg_off, seg_left, seg_right, genome_start=1, device=0):

@@ -118,6 +118,11 @@ def test_bins_reproduce_reference_context_table(which, oracle):
     bins = eb.LocusBins(annot, hits, compat, key)
     assert bins.n_bins == len(rows)
     assert hits.total_mapped == rows[0]["total_mapped"]
+    from strawberry_amd.binseq import bin_segments     # the bins' segment lists as flat arrays == bin_coords
+    off, sl, sr = bin_segments(bins)
+    flat = [c for l in range(len(names)) for c in bins.bin_coords(l)]
+    assert off.tolist() == np.concatenate([[0], np.cumsum([len(c) for c in flat])]).tolist()
+    assert list(zip(sl.tolist(), sr.tolist())) == [s for c in flat for s in c]
     hits_in_bin = np.bincount(bins.hit_bin[bins.hit_bin >= 0], minlength=bins.n_bins)
     for l, g in enumerate(names):
         # the table's path_count is the number of unique hits of the bin; with unit masses and no
