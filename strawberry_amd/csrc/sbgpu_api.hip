@@ -126,37 +126,63 @@ __device__ double abundance_locus(int64_t l, const int64_t *iso_off, const doubl
       return 0.0;
    }
    const double rpm = 1e6 / (double)p.total_mapped_reads; // :328
+   // Both passes go four isoforms at a time: the loads of a group are issued together (a locus of 200 isoforms
+   // otherwise pays one memory round trip per isoform and pass), the arithmetic stays in isoform order.
    double sum_fpkm = 0.0;
-   for (int64_t j = j0; j < j1; ++j) {
-      double kb;
-      int32_t k = 1;
-      double f = 0.0;
-      if (p.effective_len_norm) { // :317-324
-         kb = (double)length[j] - p.insert_mean;
-         if (kb < 0) {
-            k = 2; // "NA"
+   for (int64_t jb = j0; jb < j1; jb += 4) {
+      int32_t len[4];
+      double th[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+         const bool in = jb + u < j1;
+         len[u] = in ? length[jb + u] : 1;
+         th[u] = in ? theta[jb + u] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+         if (jb + u >= j1) break;
+         double kb;
+         int32_t k = 1;
+         double f = 0.0;
+         if (p.effective_len_norm) { // :317-324
+            kb = (double)len[u] - p.insert_mean;
+            if (kb < 0) {
+               k = 2; // "NA"
+            } else {
+               kb = 1e3 / kb;
+            }
          } else {
-            kb = 1e3 / kb;
+            kb = 1e3 / (double)len[u]; // :326
          }
-      } else {
-         kb = 1e3 / (double)length[j]; // :326
+         if (k != 2) {
+            f = th[u] * rpm * kb; // :329
+            sum_fpkm += f;
+         }
+         fpkm[jb + u] = f;
+         keep[jb + u] = k;
       }
-      if (k != 2) {
-         f = theta[j] * rpm * kb; // :329
-         sum_fpkm += f;
-      }
-      fpkm[j] = f;
-      keep[j] = k;
    }
    double kept_sum = 0.0;
-   for (int64_t j = j0; j < j1; ++j) {
-      double fr = 0.0;
-      int32_t k = keep[j];
-      if (k != 2) fr = fpkm[j] / sum_fpkm;                           // :342
-      if (p.filter_by_expression && fr < p.min_isoform_frac) k = 0;  // :346-355
-      frac[j] = fr;
-      keep[j] = k;
-      if (k) kept_sum += fpkm[j];
+   for (int64_t jb = j0; jb < j1; jb += 4) {
+      double f[4];
+      int32_t kk[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+         const bool in = jb + u < j1;
+         f[u] = in ? fpkm[jb + u] : 0.0;
+         kk[u] = in ? keep[jb + u] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+         if (jb + u >= j1) break;
+         double fr = 0.0;
+         int32_t k = kk[u];
+         if (k != 2) fr = f[u] / sum_fpkm;                              // :342
+         if (p.filter_by_expression && fr < p.min_isoform_frac) k = 0;  // :346-355
+         frac[jb + u] = fr;
+         keep[jb + u] = k;
+         if (k) kept_sum += f[u];
+      }
    }
    return kept_sum;
 }
