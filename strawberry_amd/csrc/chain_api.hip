@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstring>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -122,7 +123,13 @@ int sbgpu_quantify_host(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgp
       }
    } iso_worker;
    sb::IsoSegments iso_pre;
-   if (grouped && nh) iso_worker.t = std::thread([&]() { sb::iso_segments(an, &iso_pre); });
+   if (grouped && nh) {
+      try {
+         iso_worker.t = std::thread([&]() { sb::iso_segments(an, &iso_pre); });
+      } catch (const std::system_error &) { // no thread to be had: make them here
+         sb::iso_segments(an, &iso_pre);
+      }
+   }
    for (Part &p : parts)
       if (p.bytes) SB_TRY(hipMemcpyAsync(in.p + p.off, p.src, p.bytes, hipMemcpyHostToDevice, s));
    sbgpu_annotation_t dan = *an;
@@ -198,7 +205,7 @@ int sbgpu_quantify_host(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgp
    sbgpu_bins_t *bins = nullptr;
    int rc = SBGPU_EUNSUPPORTED;
    if (grouped && nh) {
-      iso_worker.t.join();
+      if (iso_worker.t.joinable()) iso_worker.t.join();
       rc = sb::bins_create_device_impl(c, an, &dh, d_mass, locus_hit_off.data(), cw, kw, d_compat, d_key, d_hit_bin, s, &iso_pre, &bins);
    }
    const bool on_device = rc == SBGPU_OK;

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -801,15 +802,21 @@ int sbgpu_em_batch(sbgpu_ctx_t *c, const sbgpu_batch_t *b, double *theta_out, in
    TRY_CLEAN(hipMalloc(&d_status, (size_t)b->n_loci * sizeof(int32_t)));
    TRY_CLEAN(hipMalloc(&d_iters, (size_t)b->n_loci * sizeof(int32_t)));
    hipError_t up_err = hipSuccess;
-   std::thread uploader([&]() {
+   auto upload = [&]() {
       up_err = hipSetDevice(c->device);
       if (up_err == hipSuccess && n_rows)
          up_err = hipMemcpyAsync(d_count, b->count, (size_t)n_rows * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
       if (up_err == hipSuccess && n_el)
          up_err = hipMemcpyAsync(d_F, b->F, (size_t)n_el * sizeof(double), hipMemcpyHostToDevice, c->stream);
-   });
+   };
+   std::thread uploader;
+   try {
+      uploader = std::thread(upload);
+   } catch (const std::system_error &) { // no thread to be had: upload here, then plan
+      upload();
+   }
    int rc = sbgpu_plan_create(c, b->n_loci, b->row_off, b->iso_off, b->f_off, &p);
-   uploader.join();
+   if (uploader.joinable()) uploader.join();
    if (rc != SBGPU_OK) {
       const std::string why = g_err; // cleanup() must not lose the planner's message
       (void)hipStreamSynchronize(c->stream);
