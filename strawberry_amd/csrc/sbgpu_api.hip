@@ -629,13 +629,20 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
       const KindLaunch &kl = p->launches[k];
       if (kl.n_classes == 0) continue;
       hipStream_t s = fork ? c->aux[kKindStream[k]] : main;
-      // The block kinds' workgroups need a whole CU's registers (tall tile) or half of them: once the thousands of
-      // wave-form workgroups have filled the chip they wait for a CU to drain.  The wave kind therefore starts a
-      // few microseconds after them (SBGPU_WAVE_DELAY_US, 0 = off; C3: 1.49 -> 1.45 ms per step at 5, no better
-      // at 10-40).
+      // Start order.  A tall-tile workgroup needs a whole CU's registers, a block-kind one half of them: once the
+      // workgroups of a lighter kind have spread over the chip, a heavier one waits for a CU to drain -- the 9
+      // tall workgroups of C3 then finish at 1.48 ms instead of 0.65 ms, behind everything else (they start within a
+      // few microseconds of the block kind, in either order).  So every kind is held back a few microseconds behind
+      // the next heavier one: tall, block (+SBGPU_BLOCK_DELAY_US), wave (+SBGPU_WAVE_DELAY_US more); 0 = off.
+      // C3: 1.49 -> 1.45 ms per step with the wave delay at 5 (no better at 10-40).
       static const int wave_delay_us = std::getenv("SBGPU_WAVE_DELAY_US") ? std::atoi(std::getenv("SBGPU_WAVE_DELAY_US")) : 5;
-      if (fork && kKindStream[k] == 0 && wave_delay_us > 0) {
-         hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, s, (unsigned long long)wave_delay_us * 100ull);
+      static const int block_delay_us = std::getenv("SBGPU_BLOCK_DELAY_US") ? std::atoi(std::getenv("SBGPU_BLOCK_DELAY_US")) : 5;
+      const bool tall_runs = p->launches[sb::kBlockTall].n_classes > 0;
+      int hold_us = 0;
+      if (fork && k == sb::kBlock && tall_runs) hold_us = block_delay_us;
+      if (fork && kKindStream[k] == 0) hold_us = wave_delay_us + ((tall_runs && p->launches[sb::kBlock].n_classes > 0) ? block_delay_us : 0);
+      if (hold_us > 0) {
+         hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, s, (unsigned long long)hold_us * 100ull);
          HIP_TRY(hipGetLastError());
       }
       HIP_TRY(hipEventRecord(c->t0[k], s));
