@@ -226,6 +226,18 @@ __device__ __forceinline__ void high_bits_sum(double (&x)[NVAL], int hi)
 constexpr int kStampWaves = 1 << 16;
 __device__ unsigned long long sb_debug_stamps[kStampWaves * 8];
 __device__ __forceinline__ unsigned long long sb_now() { return __builtin_amdgcn_s_memrealtime(); } // 100 MHz, device-wide
+// every translation unit has its own copy of the stamp buffer: each kernel file exports a reader of its copy and
+// sbgpu_debug_read_stamps merges them (a wave slot is written by one kernel only)
+#define SB_DEFINE_STAMP_READER(NAME)                                                        \
+   hipError_t read_stamps_##NAME(void *out, size_t bytes)                                   \
+   {                                                                                        \
+      return hipMemcpyFromSymbol(out, HIP_SYMBOL(sb_debug_stamps), bytes);                  \
+   }
+hipError_t read_stamps_wave_h(void *out, size_t bytes);
+hipError_t read_stamps_wave_1(void *out, size_t bytes);
+hipError_t read_stamps_wave_2(void *out, size_t bytes);
+hipError_t read_stamps_block(void *out, size_t bytes);
+hipError_t read_stamps_block_tall(void *out, size_t bytes);
 #endif
 
 constexpr int kBlockWaves = 4; // block form: 256 lanes, one wave per SIMD, up to 512 VGPRs each
@@ -514,6 +526,9 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
       };
       for (;;) {
          iterate(theta, nt); // old in theta, new in nt
+#ifdef SB_STAMPS
+         st_iters += 1;
+#endif
          if (BLOCK ? special : __any(special)) {
             // groups that simply finished an iteration move on (:481); the special ones keep
             // (old, new) = (theta, nt) for the event handling below
@@ -525,6 +540,9 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
          }
          ++it;
          iterate(nt, theta); // old in nt, new in theta
+#ifdef SB_STAMPS
+         st_iters += 1;
+#endif
          if (BLOCK ? special : __any(special)) {
             // special groups: bring (old, new) back to (theta, nt); the others already hold
             // their new theta in `theta`

@@ -9,4 +9,7 @@ hipError_t launch_fused_wave_1(const FusedLaunch &l, hipStream_t s)
                       l.lists_in, l.n_in, l.cursors, l.lists_out, l.n_out, l.it_limit, l.resume);
    return hipGetLastError();
 }
+#ifdef SB_STAMPS
+SB_DEFINE_STAMP_READER(wave_1)
+#endif
 } // namespace sb

@@ -757,7 +757,15 @@ int sbgpu_debug_touch_streams(sbgpu_ctx_t *c, double *d_buf)
 int sbgpu_debug_read_stamps(void *out, size_t bytes)
 {
    HIP_TRY(hipDeviceSynchronize());
-   HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(sb::sb_debug_stamps), bytes));
+   // the kernels' translation units each hold their own copy of the buffer: merge them (unwritten slots are 0)
+   std::vector<unsigned long long> part(bytes / 8), all(bytes / 8, 0ull);
+   hipError_t (*readers[])(void *, size_t) = {sb::read_stamps_wave_h, sb::read_stamps_wave_1, sb::read_stamps_wave_2,
+                                              sb::read_stamps_block, sb::read_stamps_block_tall};
+   for (auto rd : readers) {
+      HIP_TRY(rd(part.data(), part.size() * 8));
+      for (size_t i = 0; i < all.size(); ++i) all[i] = std::max(all[i], part[i]);
+   }
+   std::memcpy(out, all.data(), all.size() * 8);
    return SBGPU_OK;
 }
 #endif

@@ -39,8 +39,8 @@ print("life us: med %.1f max %.1f ; us/iter med %.3f p90 %.3f max %.3f" % (np.me
 off = 0
 print("waves still alive at t (us):", {t: int(((us(st[:,0]-t0) <= t) & (us(st[:,3]-t0) > t)).sum()) for t in (50,100,200,400,600,800,1000,1200,1400,1600,1800)})
 print("waves not yet started at t:", {t: int((us(st[:,0]-t0) > t).sum()) for t in (50,100,200,400,600,800,1000)})
-long = st[:,5] >= 900
-print("long waves (>=900 iters): %d ; their start us: med %.0f p90 %.0f max %.0f ; life med %.0f max %.0f" % (long.sum(), np.median(us(st[long,0]-t0)), np.percentile(us(st[long,0]-t0),90), us(st[long,0]-t0).max(), np.median(us(st[long,3]-st[long,0])), us(st[long,3]-st[long,0]).max()))
+long = (st[:,5] >= 900) if st[:,5].max() > 0 else (life >= 500.0)   # no iteration counts in the stamps: by lifetime
+print("long waves (>=900 iters or >= 500 us): %d ; their start us: med %.0f p90 %.0f max %.0f ; life med %.0f max %.0f" % (long.sum(), np.median(us(st[long,0]-t0)), np.percentile(us(st[long,0]-t0),90), us(st[long,0]-t0).max(), np.median(us(st[long,3]-st[long,0])), us(st[long,3]-st[long,0]).max()))
 for c in s.plan.classes():
     n = c["n_waves"]; x = st[off:off+n]; off += n
     lf = us(x[:,3]-x[:,0])
