@@ -17,11 +17,11 @@ namespace {
 // g_binseq_log_n on the current device, once per device and process: log(n) by the host's libm
 std::mutex g_log_mutex;
 uint64_t g_log_done = 0; // bit d: device d has its table
-int ensure_log_table()
+int ensure_log_table(const sbgpu_ctx_t *c)
 {
-   int dev = 0;
-   hipError_t e = hipGetDevice(&dev);
-   if (e != hipSuccess) return api_fail(SBGPU_EHIP, std::string("hipGetDevice: ") + hipGetErrorString(e));
+   const int dev = sb::ctx_device(c); // the tables live on the context's device, whatever the caller's current one is
+   hipError_t e = hipSetDevice(dev);
+   if (e != hipSuccess) return api_fail(SBGPU_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
    std::lock_guard<std::mutex> lock(g_log_mutex);
    if (dev < 64 && ((g_log_done >> dev) & 1)) return SBGPU_OK;
    std::vector<double> t(sb::kBinSeqChunk + 1, 0.0);
@@ -53,7 +53,7 @@ int sbgpu_binseq_device(sbgpu_ctx_t *c, const uint8_t *d_genome, int64_t genome_
       return api_fail(SBGPU_EINVAL, "sbgpu_binseq_device: null device pointer");
    if (n_bins > 0x7fffffff) return api_fail(SBGPU_ESHAPE, "sbgpu_binseq_device: more than 2^31 - 1 bins in one call");
    if (genome_len > 0xffffffffll) return api_fail(SBGPU_ESHAPE, "sbgpu_binseq_device: a genome window of 2^32 bases or more");
-   if (int rc = ensure_log_table()) return rc;
+   if (int rc = ensure_log_table(c)) return rc;
    sb::BinSeqArgs a;
    a.genome = d_genome;
    a.genome_start = genome_start;

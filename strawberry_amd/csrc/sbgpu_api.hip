@@ -67,6 +67,7 @@ namespace sb {
 int api_fail(int code, const std::string &msg) { return fail(code, msg); }
 hipStream_t ctx_stream(const sbgpu_ctx_t *ctx) { return ctx->stream; }
 int ctx_cu_count(const sbgpu_ctx_t *ctx) { return ctx->n_cu; }
+int ctx_device(const sbgpu_ctx_t *ctx) { return ctx->device; }
 } // namespace sb
 
 struct KindLaunch {
