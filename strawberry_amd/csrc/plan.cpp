@@ -16,7 +16,7 @@ namespace sb {
 // depend on it).  The EM converges slowly when a locus has about as many bins as isoforms (the likelihood is
 // nearly flat along some direction of theta) and the slower the more isoforms it has; with many more bins than
 // isoforms it converges in a few dozen steps.  Numbers: mean iteration counts of the reference's EmSolver on
-// the C3 batch by nrow / niso, relative to the peak at nrow ~ niso, times niso (tools/probe_iteration_shape.py:
+// the C3 batch by nrow / niso, relative to the peak at nrow ~ niso, times (niso + 18) (tools/probe_iteration_shape.py:
 // the loci that run all 1000 iterations are 97 % within the top 10 % of this score).
 static int64_t predicted_iterations(int64_t nrow, int64_t niso)
 {
@@ -24,7 +24,10 @@ static int64_t predicted_iterations(int64_t nrow, int64_t niso)
    const double r = (double)nrow / (double)niso;
    const double w = r < 0.5 ? 0.10 : r < 0.75 ? 0.60 : r < 1.25 ? 1.00 : r < 1.5 ? 0.80 : r < 2 ? 0.55 : r < 3 ? 0.35 : r < 5 ? 0.27
                   : r < 10 ? 0.20 : 0.17;
-   const double it = 80.0 * w * (double)(niso < 24 ? niso : 24);
+   // What orders the classes is the LARGEST count among a class's loci, and loci of few isoforms with nrow ~ niso reach
+   // the cap far more often than their mean suggests: hence the constant beside niso.  Measured on C3 (ms per step,
+   // tools/probe_order.sh): + 0 1.40, + 6 1.38, + 12 1.36, + 18 1.32, + 24 1.32, + 30 1.34, + 45 1.42, + 150 1.62.
+   const double it = 80.0 * w * (double)((niso < 24 ? niso : 24) + 18);
    return (int64_t)(it < 1000.0 ? it : 1000.0);
 }
 

@@ -45,7 +45,7 @@ def predicted_iterations(nrow, niso):
     r = nrow / np.maximum(niso, 1)
     w = np.select([r < 0.5, r < 0.75, r < 1.25, r < 1.5, r < 2, r < 3, r < 5, r < 10],
                   [0.10, 0.60, 1.00, 0.80, 0.55, 0.35, 0.27, 0.20], 0.17)
-    return np.minimum(80.0 * w * np.minimum(niso, 24), 1000.0).astype(np.int64)
+    return np.minimum(80.0 * w * (np.minimum(niso, 24) + 18), 1000.0).astype(np.int64)
 
 
 def shard_loci(nrow, niso, world_size):

@@ -22,7 +22,7 @@ def main():
     print("%d loci, %d at the iteration cap, mean %.1f iterations" % (len(iters), (iters >= 1000).sum(), iters.mean()))
     w = np.select([r < 0.5, r < 0.75, r < 1.25, r < 1.5, r < 2, r < 3, r < 5, r < 10], [0.10, 0.60, 1.00, 0.80, 0.55, 0.35, 0.27, 0.20], 0.17)
     for name, x in (("nrow * niso (the old order)", (nrow * niso).astype(float)), ("niso", niso.astype(float)),
-                    ("niso / nrow", niso / nrow), ("plan.cpp: w(nrow / niso) * min(niso, 24)", w * np.minimum(niso, 24))):
+                    ("niso / nrow", niso / nrow), ("plan.cpp: w(nrow / niso) * (min(niso, 24) + 18)", w * (np.minimum(niso, 24) + 18))):
         order = np.argsort(-x, kind="stable")
         capped = iters[order] >= 1000
         print("%-44s top 5 / 10 / 20 %% hold %5.1f / %5.1f / %5.1f %% of the capped loci" % (
