@@ -149,6 +149,26 @@ class OracleLib:
                                        fpkm, frac, keep)
         return fpkm, frac, keep, s
 
+    def abundance(self, iso_off, theta, status, length, total_mapped_reads, effective_len_norm=False,
+                  insert_mean=0.0, filter_by_expression=True, min_isoform_frac=0.01):
+        """The epilogue for a whole batch: sbo_abundance_locus per locus (loci whose init() failed are
+        dropped: quantifyCluster returns nothing for them, src/alignments.cpp:1524-1545), then sbo_tpm
+        over the survivors.  -> dict(fpkm, frac, keep, tpm, sum_fpkm)."""
+        iso_off = np.ascontiguousarray(iso_off, np.int64)
+        theta = np.ascontiguousarray(theta, np.float64)
+        length = np.ascontiguousarray(length, np.int32)
+        n = len(theta)
+        fpkm, frac, keep = np.zeros(n), np.zeros(n), np.zeros(n, np.int32)
+        for l in range(len(iso_off) - 1):
+            if status[l] == 1:
+                continue
+            j0, j1 = int(iso_off[l]), int(iso_off[l + 1])
+            self.L.sbo_abundance_locus(j1 - j0, theta[j0:j1], length[j0:j1], int(total_mapped_reads),
+                                       int(effective_len_norm), float(insert_mean), int(filter_by_expression),
+                                       float(min_isoform_frac), fpkm[j0:j1], frac[j0:j1], keep[j0:j1])
+        tpm, total = self.tpm(fpkm, keep)
+        return {"fpkm": fpkm, "frac": frac, "keep": keep, "tpm": tpm, "sum_fpkm": total}
+
     def tpm(self, fpkm, keep):
         fpkm = np.ascontiguousarray(fpkm, np.float64)
         keep = np.ascontiguousarray(keep, np.int32)

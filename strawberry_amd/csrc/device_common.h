@@ -28,7 +28,11 @@ __device__ __forceinline__ int xor_get_i(int x)
       return __builtin_amdgcn_update_dpp(t, x, 0x114 /*row_shr:4*/, 0xF, 0xA, false);
    }
    if (MASK == 8) return __builtin_amdgcn_update_dpp(0, x, 0x128 /*row_ror:8*/, 0xF, 0xF, true);
-   if (MASK == 16) return __builtin_amdgcn_ds_swizzle(x, 0x401F);
+   if (MASK == 16) {
+      // v_permlane16_swap: even 16-lane rows end up twice in a[0], odd rows twice in a[1]
+      auto a = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+      return ((threadIdx.x & 16) ? a[0] : a[1]);
+   }
    // MASK == 32
    auto a = __builtin_amdgcn_permlane32_swap(x, x, false, false);
    return ((threadIdx.x & 32) ? a[0] : a[1]);

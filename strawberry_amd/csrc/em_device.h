@@ -80,12 +80,15 @@ constexpr int kDppXor2 = 0x4E;        // quad_perm:[2,3,0,1]
 constexpr int kDppHalfMirror = 0x141; // lane i <- 7-i   (other quad of the 8-lane group)
 constexpr int kDppMirror = 0x140;     // lane i <- 15-i  (other half of the 16-lane row)
 
-__device__ __forceinline__ double swizzle_xor16(double x)
+// x(lane) + x(lane^16) with v_permlane16_swap (gfx950): the swap leaves the even rows (16 lanes each) twice in
+// one register and the odd rows twice in the other.  13 cycles per swap against 56 for a ds_swizzle round trip
+// (tools/microbench.hip).
+__device__ __forceinline__ double sum_xor16(double x)
 {
    int lo = __double2loint(x), hi = __double2hiint(x);
-   lo = __builtin_amdgcn_ds_swizzle(lo, 0x401F); // bitmask mode: xor 0x10, and 0x1F
-   hi = __builtin_amdgcn_ds_swizzle(hi, 0x401F);
-   return __hiloint2double(hi, lo);
+   auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+   auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+   return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
 }
 
 // x(lane) + x(lane^32) with v_permlane32_swap (gfx950): after the swap one
@@ -108,7 +111,7 @@ __device__ __forceinline__ double wave_group_sum(double x)
    if (GW >= 4) x += dpp_mov<kDppXor2>(x);
    if (GW >= 8) x += dpp_mov<kDppHalfMirror>(x);
    if (GW >= 16) x += dpp_mov<kDppMirror>(x);
-   if (GW >= 32) x += swizzle_xor16(x);
+   if (GW >= 32) x = sum_xor16(x);
    if (GW >= 64) x = sum_xor32(x);
    return x;
 }
@@ -166,13 +169,26 @@ __device__ __forceinline__ double xor_get(double x)
 {
    return __hiloint2double(xor_get_i<MASK>(__double2hiint(x)), xor_get_i<MASK>(__double2loint(x)));
 }
+// Sum over lane bits 4 and 5 -- x(l) + x(l^16) + x(l^32) + x(l^48), in every lane -- with ONE matrix
+// instruction: v_mfma_f64_4x4x4_4b with A = 1 and B = x gives D(lane) = sum over k of x(16 k + lane % 16)
+// (layout probed by tools/microbench.hip).  19-22 cycles on the matrix pipe (which the vector instructions of the
+// other waves do not wait for) against ~50 for the two lane-swap steps; every lane of a column adds the same four
+// values in the same order, so the sums are bitwise identical across the lanes, as the butterflies' are.
+__device__ __forceinline__ double sum_bits45(double x)
+{
+   return __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, x, 0.0, 0, 0, 0);
+}
+// value of lane (l - 4) mod 16 / (l - 8) mod 16 of the own 16-lane row
+__device__ __forceinline__ double row_ror4(double x) { return dpp_mov<0x124>(x); }
+__device__ __forceinline__ double row_ror8(double x) { return dpp_mov<0x128>(x); }
+
 // x(lane) + x(lane ^ MASK).  LOW_UNIFORM: every lane below bit log2(MASK) of the
 // group already holds the same value, so the cheaper mirror forms are valid.
 template <int MASK, bool LOW_UNIFORM>
 __device__ __forceinline__ double xor_sum(double x)
 {
    if (MASK == 32) return sum_xor32(x);
-   if (MASK == 16) return x + swizzle_xor16(x);
+   if (MASK == 16) return sum_xor16(x);
    if (LOW_UNIFORM && MASK == 4) return x + dpp_mov<kDppHalfMirror>(x);
    if (LOW_UNIFORM && MASK == 8) return x + dpp_mov<kDppMirror>(x);
    return x + xor_get<MASK>(x);
@@ -201,21 +217,35 @@ __device__ __forceinline__ double low_bits_sum(double x)
    return x;
 }
 
-// all-reduce of NVAL values over lane bits [LO, hi): LO compile-time, hi wave-uniform
+// all-reduce of NVAL values over lane bits [LO, hi): LO compile-time, hi wave-uniform.
+// Bits 4 and 5 together go through the matrix pipe (sum_bits45).  Bits 2 and 3 together, when the lanes below are
+// not uniform, go as a rotate butterfly inside the 16-lane row -- y = x + ror8(x), z = y + ror4(y): the second
+// step needs one DPP move per half where a true xor 4 needs two, and every lane still adds the same pairs.
 template <int LO, int NVAL>
 __device__ __forceinline__ void high_bits_sum(double (&x)[NVAL], int hi)
 {
 #define SB_STEP(BIT)                                                                \
-   if (LO <= BIT && hi > BIT) {                                                     \
+   {                                                                                \
       _Pragma("unroll") for (int v = 0; v < NVAL; ++v)                              \
          x[v] = xor_sum<(1 << BIT), (LO == 0)>(x[v]);                               \
    }
-   SB_STEP(0)
-   SB_STEP(1)
-   SB_STEP(2)
-   SB_STEP(3)
-   SB_STEP(4)
-   SB_STEP(5)
+   if (LO <= 0 && hi > 0) SB_STEP(0)
+   if (LO <= 1 && hi > 1) SB_STEP(1)
+   if (LO > 0 && LO <= 2 && hi > 3) {
+      SB_STEP(3)
+#pragma unroll
+      for (int v = 0; v < NVAL; ++v) x[v] += row_ror4(x[v]);
+   } else {
+      if (LO <= 2 && hi > 2) SB_STEP(2)
+      if (LO <= 3 && hi > 3) SB_STEP(3)
+   }
+   if (LO <= 4 && hi > 5) {
+#pragma unroll
+      for (int v = 0; v < NVAL; ++v) x[v] = sum_bits45(x[v]);
+   } else {
+      if (LO <= 4 && hi > 4) SB_STEP(4)
+      if (LO <= 5 && hi > 5) SB_STEP(5)
+   }
 #undef SB_STEP
 }
 
@@ -759,7 +789,7 @@ __device__ __forceinline__ double wave_group_sum_rt(double x, int gw)
    if (gw >= 4) x += dpp_mov<kDppXor2>(x);
    if (gw >= 8) x += dpp_mov<kDppHalfMirror>(x);
    if (gw >= 16) x += dpp_mov<kDppMirror>(x);
-   if (gw >= 32) x += swizzle_xor16(x);
+   if (gw >= 32) x = sum_xor16(x);
    if (gw >= 64) x = sum_xor32(x);
    return x;
 }

@@ -114,6 +114,31 @@ def test_gpu_c2_sample_against_oracle(ctx, oracle):
     assert theta_err(r["theta"], o_theta).max() < THETA_RTOL
 
 
+@pytest.mark.parametrize("config", ["c2", "c3"])
+def test_gpu_full_size_configs_against_oracle(ctx, oracle, config):
+    """BASELINE.json's configurations at FULL size -- C2: 10 000 loci x 8 isoforms x 1000 fragments,
+    C3: 60 000 loci, 2e8 fragments -- through sbgpu_em_run_device, every locus compared with the
+    oracle (a few seconds of CPU on 8 threads): status and iteration counts exact, theta to 1e-9,
+    TPM (after the epilogue) to 1e-9 -- the north star asks 1e-4."""
+    from strawberry_amd import synth, em
+    b = synth.make_c2() if config == "c2" else synth.make_c3()
+    assert b.n_loci == (10000 if config == "c2" else 60000)
+    s = em.EmBatchSolver(b, ctx)
+    s.run_em()
+    s.run_abundance(total_mapped_reads=min(b.n_frags, 2**31 - 1), min_isoform_frac=0.0)
+    s.run_tpm()
+    r = s.results()
+    o_theta, o_status, o_iters = oracle.em_batch(b.row_off, b.iso_off, b.f_off, b.count, b.F, threads=8)
+    np.testing.assert_array_equal(r["status"], o_status)
+    np.testing.assert_array_equal(r["iters"], o_iters)
+    err = theta_err(r["theta"], o_theta)
+    assert err.max() < THETA_RTOL, (config, err.max(), int(err.argmax()))
+    o = oracle.abundance(b.iso_off, o_theta, o_status, b.length, total_mapped_reads=min(b.n_frags, 2**31 - 1),
+                         min_isoform_frac=0.0)
+    tpm_err = np.abs(r["tpm"] - o["tpm"]) / np.maximum(np.abs(o["tpm"]), 1e-6)
+    assert tpm_err.max() < 1e-9, (config, tpm_err.max())
+
+
 def test_gpu_full_size_properties(ctx):
     """BASELINE-size runs checked through size-independent properties: mass
     conservation (sum theta = kept counts after the first iteration), non-negativity,
