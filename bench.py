@@ -165,11 +165,15 @@ def main():
     gpu_ms = ev[0].elapsed_time(ev[1])
     # per-kind EM kernel time: HIP events on the streams the kernels run on, averaged over a few
     # extra (untimed) steps -- reading them synchronises, so it stays out of the timed region
-    probe = []
+    probe, phase_probe = [], []
+    solver.set_timing(True)
     for _ in range(5):
         quant.step()
         probe.append(solver.last_kernel_ms())
+        phase_probe.append(solver.last_phase_ms())
+    solver.set_timing(False)
     kern_ms = np.mean(np.array(probe), axis=0)
+    phase_ms = [float(x) for x in np.mean(np.array(phase_probe), axis=0)] if phase_probe and phase_probe[0] else []
 
     tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
     sdist.allreduce_max_(tmax)
@@ -224,6 +228,7 @@ def main():
                       "denom_zero": int((res["status"] == 2).sum()), "maxiter": int((res["status"] == 3).sum()),
                       "mean_iters": float(res["iters"].mean())},
         "gpu_event_ms_per_step": gpu_ms / args.steps,
+        "wave_phase_ms": phase_ms,
         "roofline": roofline,
     }
     if world == 1 and not args.no_cpu_baseline:

@@ -58,6 +58,10 @@ extern "C" {
 #define SBGPU_EM_DENOM_ZERO 2  /* run()==false: a row denominator was 0 (estimate.cpp:451-453);
                                   theta = theta0; the caller proceeds (bool ignored, estimate.cpp:308) */
 #define SBGPU_EM_MAXITER 3     /* run()==true after all 1000 iterations (estimate.hpp:237)         */
+#define SBGPU_EM_UNSOLVED (-1) /* no kernel wrote a result for the locus: what sbgpu_em_run_device sets every status
+                                  to before it launches; only seen together with an SBGPU_EHIP from
+                                  sbgpu_synchronize / sbgpu_em_batch / sbgpu_quantify_host (a wide-locus
+                                  barrier timed out)                                                */
 
 /* EmSolver constants, include/estimate.hpp:237,241 and src/estimate.cpp:380 */
 #define SBGPU_EM_MAX_ITER 1000
@@ -142,11 +146,22 @@ int sbgpu_em_run_device(sbgpu_ctx_t *ctx, const sbgpu_plan_t *plan,
                         double *d_theta, int32_t *d_status, int32_t *d_iters,
                         void *stream);
 
+/* Timing events around the EM kernels are off by default (they cost a few microseconds
+ * per call); sbgpu_set_timing(ctx, 1) turns them on for the calls that follow.       */
+int sbgpu_set_timing(sbgpu_ctx_t *ctx, int on);
+
 /* Device time of the last sbgpu_em_run_device per kernel kind (HIP events recorded
  * on the stream each kind was launched on, all phases of the kind included):
  * ms[6] = {wave half tile, wave base tile, wave double tile, block, tall block,
- * stream}, 0 for kinds not launched.  Synchronises with those events.            */
+ * stream}, 0 for kinds not launched or when timing is off.  Synchronises with those
+ * events.                                                                          */
 int sbgpu_em_last_kernel_ms(sbgpu_ctx_t *ctx, float ms[6]);
+
+/* The wave kind runs in phases: phase 0 takes every locus up to a first iteration
+ * limit, each later phase continues the loci still running in layouts with more lanes
+ * per locus.  Fills ms[0 .. n) with the device time of each phase of the
+ * last sbgpu_em_run_device (timing on) and returns n (0: one phase or timing off).   */
+int sbgpu_em_last_phase_ms(sbgpu_ctx_t *ctx, float *ms, int cap);
 
 /* Host-buffer convenience form (what a cgo/JNI/ctypes or the C++ driver binds
  * first): plans, uploads, solves, downloads, synchronises.                      */

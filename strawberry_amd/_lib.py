@@ -19,6 +19,7 @@ SYMBOLS = [
     "sbgpu_version", "sbgpu_last_error", "sbgpu_device_count", "sbgpu_init", "sbgpu_finalize",
     "sbgpu_device_info", "sbgpu_synchronize", "sbgpu_plan_create", "sbgpu_plan_destroy", "sbgpu_plan_info",
     "sbgpu_plan_classes", "sbgpu_plan_locus_kinds", "sbgpu_em_run_device", "sbgpu_em_last_kernel_ms",
+    "sbgpu_set_timing", "sbgpu_em_last_phase_ms",
     "sbgpu_insert_pdf_table", "sbgpu_binweight_device", "sbgpu_binweight_host",
     "sbgpu_exonbin_device", "sbgpu_exonbin_host", "sbgpu_segments_host", "sbgpu_hit_features", "sbgpu_frag_lens_host",
     "sbgpu_bins_create", "sbgpu_bins_create_device", "sbgpu_bins_destroy", "sbgpu_quantify_host",
@@ -138,6 +139,8 @@ def load():
     L.sbgpu_plan_classes.argtypes = [vp, i64p, C.c_int]
     L.sbgpu_plan_locus_kinds.argtypes = [vp, vp]
     L.sbgpu_em_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.sbgpu_set_timing.argtypes = [vp, C.c_int]
+    L.sbgpu_em_last_phase_ms.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
     L.sbgpu_em_run_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.sbgpu_em_batch.argtypes = [vp, C.POINTER(sbgpu_batch_t), vp, vp, vp]
     L.sbgpu_abundance_device.argtypes = [vp, vp, vp, vp, vp, C.POINTER(sbgpu_abundance_params_t), vp, vp, vp, vp, vp]

@@ -37,6 +37,7 @@ int api_fail(int code, const std::string &msg); // records sbgpu_last_error(), r
 hipStream_t ctx_stream(const sbgpu_ctx_t *ctx); // the context's own stream
 int ctx_cu_count(const sbgpu_ctx_t *ctx);
 int ctx_device(const sbgpu_ctx_t *ctx);        // the HIP device the context was made on
+bool ctx_take_wide_error(sbgpu_ctx_t *ctx);    // true once if a wide-locus barrier timed out since the last call (clears the flag)
 // locus_bins.cpp: finish bins that were grouped on the device (host copies of the per-bin arrays)
 // `pairs`: made on the device already (the handle takes the arena over); nullptr: make them here, on the host
 int bins_from_groups(const sbgpu_annotation_t *annot, int32_t compat_words, int32_t key_words, const int64_t *row_off,

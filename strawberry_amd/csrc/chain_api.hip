@@ -115,6 +115,7 @@ int sbgpu_quantify_host(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgp
    } while (0)
    // The isoforms' segment lists depend on the annotation only: a helper thread makes them (1 ms of host work for
    // 20 000 loci) while this one feeds the uploads.
+   sb::IsoSegments iso_pre; // declared BEFORE the worker: on an early return the thread is joined while its output still lives
    struct Joiner {
       std::thread t;
       ~Joiner()
@@ -122,7 +123,6 @@ int sbgpu_quantify_host(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgp
          if (t.joinable()) t.join();
       }
    } iso_worker;
-   sb::IsoSegments iso_pre;
    if (grouped && nh) {
       try {
          iso_worker.t = std::thread([&]() { sb::iso_segments(an, &iso_pre); });
@@ -332,6 +332,9 @@ int sbgpu_quantify_host(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgp
    stage("plan + EM + download");
    for (hipError_t x : {e1, e2, e3, e4, e5, e6})
       if (x != hipSuccess) return api_fail(SBGPU_EHIP, std::string("sbgpu_quantify_host: download: ") + hipGetErrorString(x));
+   // a wide-locus barrier that timed out leaves its loci unsolved (status SBGPU_EM_UNSOLVED): that is a failed call
+   if (sb::ctx_take_wide_error(c))
+      return api_fail(SBGPU_EHIP, "sbgpu_quantify_host: a barrier of the wide-locus EM kernel timed out: the loci it served have no result");
    if (compat_out) {
       SB_RC(need_compat());
       if (nh) std::memcpy(compat_out, compat_h.data(), (size_t)nh * cw * 4);

@@ -44,19 +44,31 @@ struct EmArgs {
    int32_t *iters;
 };
 
+// Descriptor of a size class inside a launch's table (sorted by first block).
+struct ClassDesc {
+   int32_t block_begin; // first blockIdx.x of this class (later phases: written on the device, phase_prepare_kernel)
+   int32_t n;           // loci in the class (later phases: its capacity -- every locus that could reach it)
+   int32_t loci_off;    // offset of its list in the concatenated class lists
+   int32_t shape;       // layout | rmult << 8 | lbG << 16
+};
+
 // One size class: the loci it holds (ordered by decreasing work) and the
 // dynamic-pull cursor.
 struct ClassArgs {
    const int32_t *loci;
    int32_t n;
    int32_t *cursor;
-   // phased execution: a locus still running after `it_limit` iterations is suspended
-   // (theta and the iteration count are its whole state) and appended to `out`, the
-   // input list of the next phase, which packs the survivors densely again
-   int32_t *out;
-   int32_t *out_count;
+   // phased execution: a locus still running after `it_limit` iterations is suspended (theta and the
+   // iteration count are its whole state) and appended to the list of ITS class of the next phase
+   // (`route[locus]`, an index into `next_table`): the next phase gives the survivors layouts with more
+   // lanes per locus -- fewer instructions per iteration -- now that fewer loci are alive
+   int32_t *out;                 // the next phase's class lists (one array, next_table[c].loci_off)
+   int32_t *out_count;           // [class of the next phase]
+   const int32_t *route;         // [locus] -> class of the next phase
+   const ClassDesc *next_table;
    int32_t it_limit;
    int32_t resume; // this phase's loci carry state from the previous one
+   int32_t batch;  // >= 0: the workgroup serves exactly this batch of the class (loci batch * per-wave ...), no cursor
 };
 
 // ------------------------------------------------------------------ cross-lane
@@ -249,6 +261,40 @@ __device__ __forceinline__ void high_bits_sum(double (&x)[NVAL], int hi)
 #undef SB_STEP
 }
 
+// all-reduce of NVAL values over the TOP `lb` lane bits [6 - lb, 6) (lb wave-uniform): bits 4 and 5 through the
+// matrix pipe, the ones below as steps inside the 16-lane row (bit 3: rotate by 8 = xor 8; bit 2: rotate by 4
+// of the result, which is symmetric under the rotation by 8 by then; bits 1 and 0: quad permutes).  The lanes
+// below bit 6 - lb hold different data throughout.
+template <int NVAL>
+__device__ __forceinline__ void top_bits_sum(double (&x)[NVAL], int lb)
+{
+   if (lb == 1) {
+#pragma unroll
+      for (int v = 0; v < NVAL; ++v) x[v] = sum_xor32(x[v]);
+      return;
+   }
+   if (lb >= 3) {
+#pragma unroll
+      for (int v = 0; v < NVAL; ++v) x[v] += row_ror8(x[v]);
+   }
+   if (lb >= 4) {
+#pragma unroll
+      for (int v = 0; v < NVAL; ++v) x[v] += row_ror4(x[v]);
+   }
+   if (lb >= 5) {
+#pragma unroll
+      for (int v = 0; v < NVAL; ++v) x[v] = xor_sum<2, false>(x[v]);
+   }
+   if (lb >= 6) {
+#pragma unroll
+      for (int v = 0; v < NVAL; ++v) x[v] = xor_sum<1, false>(x[v]);
+   }
+   if (lb >= 2) {
+#pragma unroll
+      for (int v = 0; v < NVAL; ++v) x[v] = sum_bits45(x[v]);
+   }
+}
+
 #ifdef SB_STAMPS
 // Diagnostic build only (make stamps): per-wave cycle stamps, never compiled into the
 // product library.  [wave][8] = {start, after class lookup, first refill done, end,
@@ -274,10 +320,15 @@ constexpr int kBlockWaves = 4; // block form: 256 lanes, one wave per SIMD, up t
 
 // NWAVES = 0: wave form; NWAVES = 4: block form.  R is the register-tile capacity
 // in rows per row lane; the block form skips the row blocks a locus does not need.
-template <int CPL, int CL, int R, int NWAVES>
+// HIMAP (wave form only): the row lanes of a group are the TOP lane bits and the groups of a wave are
+// interleaved between them and the column lanes -- lane = gc | group << log2(CL) | gr << (6 - log2(GR)) -- so that
+// the all-reduce over the row lanes runs over lane bits 4 and 5 first, which one matrix instruction covers
+// (sum_bits45), then 3, 2, ... as rotate steps inside the 16-lane rows.
+template <int CPL, int CL, int R, int NWAVES, bool HIMAP = false>
 __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &cls, const int lbG,
                                              double *s_red, int *s_idx)
 {
+   static_assert(!(HIMAP && NWAVES > 0), "the high-bit lane map is a wave form");
    constexpr bool BLOCK = NWAVES > 0;
    constexpr int NW = BLOCK ? NWAVES : 1;                  // waves per group
    constexpr int LB_CL = ilog2(CL);
@@ -288,9 +339,23 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
    const int lbGW = BLOCK ? 6 : lbG;
    const int G = BLOCK ? 64 * NW : GW;
    const int GR = G >> LB_CL;                              // row lanes per group
-   const int g = BLOCK ? (int)threadIdx.x : (lane & (GW - 1)); // index inside the group
-   const int gc = g & (CL - 1);
-   const int gr = g >> LB_CL;
+   const int lbGR = lbGW - LB_CL;                          // (wave form) log2 of the row lanes
+   const int grp = HIMAP ? ((lane >> LB_CL) & ((64 >> lbGW) - 1)) : (lane >> lbGW); // (wave form) group inside the wave
+   const int gc = HIMAP ? (lane & (CL - 1)) : ((BLOCK ? (int)threadIdx.x : (lane & (GW - 1))) & (CL - 1));
+   const int gr = HIMAP ? (lane >> (6 - lbGR)) : ((BLOCK ? (int)threadIdx.x : (lane & (GW - 1))) >> LB_CL);
+   const int g = gc | (gr << LB_CL);                       // index inside the group; 0 = its leader
+   const int leader_lane = HIMAP ? (grp << LB_CL) : (lane & ~(GW - 1));
+   // the lanes of this lane's group, for ballots
+   unsigned long long group_mask = ~0ull;
+   if (!BLOCK) {
+      if (HIMAP) {
+         group_mask = ((1ull << CL) - 1ull) << (grp << LB_CL);
+         for (int k = 6 - lbGR; k < 6; ++k) group_mask |= group_mask << (1 << k);
+      } else if (GW < 64) {
+         group_mask = ((1ull << GW) - 1ull) << (lane & ~(GW - 1));
+      }
+   }
+   bool batch_taken = false; // static-batch mode (cls.batch >= 0): the one refill has happened
    int phase = 0;
    int r_used = R; // block form: rows per row lane the current locus needs (workgroup-uniform)
 #ifdef SB_STAMPS
@@ -300,7 +365,8 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
    // all-reduce over the row lanes of the group
    auto row_lane_sum = [&](auto &x, auto nval_tag) {
       constexpr int NVAL = decltype(nval_tag)::value;
-      high_bits_sum<LB_CL, NVAL>(x, lbGW);
+      if (HIMAP) top_bits_sum<NVAL>(x, lbGR);
+      else high_bits_sum<LB_CL, NVAL>(x, lbGW);
       if (BLOCK) {
          // cross-wave: [2 phases][NV values][CL column lanes][NW]; every lane then adds
          // the NW partials in the same order
@@ -379,7 +445,13 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
          st_t = sb_now();
 #endif
          int idx = 0;
-         if (BLOCK) {
+         if (cls.batch >= 0) {
+            // static assignment: this workgroup serves batch `cls.batch` of its class and nothing else
+            if (batch_taken) break;
+            batch_taken = true;
+            idx = BLOCK ? cls.batch : cls.batch * (64 >> lbGW) + grp;
+            if (BLOCK ? (idx >= cls.n) : !__any(idx < cls.n)) break;
+         } else if (BLOCK) {
             if (threadIdx.x == 0) *s_idx = atomicAdd(cls.cursor, 1);
             __syncthreads();
             idx = *s_idx;
@@ -387,7 +459,7 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
             if (idx >= cls.n) break; // workgroup-uniform: the class list is dry
          } else {
             if (g == 0) idx = atomicAdd(cls.cursor, 1);
-            idx = __shfl(idx, lane & ~(GW - 1));
+            idx = __shfl(idx, leader_lane);
             if (!__any(idx < cls.n)) break; // nothing left for any group of this wave
          }
          const bool got = idx < cls.n;
@@ -434,6 +506,7 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
             if (CL >= 2) mx = fmax(mx, xor_get<1>(mx));
             if (CL >= 4) mx = fmax(mx, xor_get<2>(mx));
             if (CL >= 8) mx = fmax(mx, xor_get<4>(mx));
+            if (CL >= 16) mx = fmax(mx, xor_get<8>(mx));
             const bool keep = mx > kRowEps;
             if (gc == 0 && keep) red[1] += 1.0;
             act[r] = keep;
@@ -537,8 +610,7 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
             row_lane_sum(acc, std::integral_constant<int, NV>());
             // any zero denominator in the group: one ballot instead of a reduced value
             const unsigned long long m = __ballot(zero_flag != 0);
-            const unsigned long long gm = (GW >= 64) ? ~0ull : (((1ull << GW) - 1ull) << (lane & ~(GW - 1)));
-            dz = (m & gm) != 0ull;
+            dz = (m & group_mask) != 0ull;
          }
          double p2 = 0.0;
 #pragma unroll
@@ -625,7 +697,10 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
             if (g == 0) {
                a.status[locus] = st;
                a.iters[locus] = it;
-               if (st == kStRunning) cls.out[atomicAdd(cls.out_count, 1)] = locus;
+               if (st == kStRunning) {
+                  const int c2 = cls.route[locus];
+                  cls.out[cls.next_table[c2].loci_off + atomicAdd(cls.out_count + c2, 1)] = locus;
+               }
             }
             if (gr == 0) {
 #pragma unroll
@@ -656,13 +731,36 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
 // up in the descriptor table (sorted by first block) and jumps to the matching
 // instantiation.  `shape` packs (column-layout index, rows-per-lane multiplier,
 // log2 lanes per group).
-struct ClassDesc {
-   int32_t block_begin; // first blockIdx.x of this class
-   int32_t n;           // loci in the class
-   int32_t loci_off;    // offset of its list in the concatenated class lists
-   int32_t shape;       // layout | rmult << 8 | lbG << 16
-};
 constexpr int kLayouts = 6; // (CPL, CL): (2,1) (4,1) (8,1) (8,2) (8,4) (8,8)
+
+// class of workgroup b: the last descriptor whose first block is <= b (wave-uniform binary search; empty classes
+// share their successor's first block and are skipped that way)
+__device__ __forceinline__ int find_class(const ClassDesc *table, int n_classes, int b)
+{
+   int lo = 0, hi = n_classes - 1;
+   while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (table[mid].block_begin <= b) lo = mid;
+      else hi = mid - 1;
+   }
+   return __builtin_amdgcn_readfirstlane(lo);
+}
+
+// what a kernel of phase p needs besides the batch (one struct, passed by value)
+struct PhaseArgs {
+   const ClassDesc *table;       // this launch's classes
+   int32_t n_classes;
+   const int32_t *lists_in;      // class lists (table[c].loci_off)
+   const int32_t *n_in;          // [class] loci in the list
+   int32_t *cursors;             // [class] dynamic-pull cursors (phase 0)
+   const int32_t *total_blocks;  // later phases: number of batches, computed on the device; nullptr: the grid
+   int32_t *lists_out;           // next phase
+   int32_t *n_out;
+   const int32_t *route;
+   const ClassDesc *next_table;
+   int32_t it_limit;
+   int32_t resume;
+};
 
 // RH = rows per row lane in units of HALF the base tile (base: 8 rows for 2/4 columns per
 // lane, 4 rows for 8): 1 = half tile (shortest iteration, most lanes per locus), 2 = base,
@@ -682,8 +780,7 @@ template <int NWAVES, int RH>
 __global__ __launch_bounds__(NWAVES > 0 ? 64 * NWAVES : 64,
                               NWAVES > 0 ? (RH <= 2 ? 2 : 1)
                                          : (RH == 1 ? SB_WAVEH_OCC : (RH == 2 ? SB_WAVE1_OCC : SB_WAVE2_OCC))) void em_fused_kernel(
-   EmArgs a, const ClassDesc *table, int n_classes, const int32_t *lists_in, const int32_t *n_in,
-   int32_t *cursors, int32_t *lists_out, int32_t *n_out, int it_limit, int resume)
+   EmArgs a, PhaseArgs ph)
 {
    __shared__ double s_red[NWAVES > 0 ? 2 * (kMaxCPLv + 1) * 8 * NWAVES : 1];
    __shared__ int s_idx;
@@ -694,13 +791,8 @@ __global__ __launch_bounds__(NWAVES > 0 ? 64 * NWAVES : 64,
 #ifdef SB_STAMPS
    const unsigned long long st0 = sb_now();
 #endif
-   // wave-uniform class lookup
-   int c = 0;
-   const int b = (int)blockIdx.x;
-   for (int k = 1; k < n_classes; ++k)
-      if (table[k].block_begin <= b) c = k;
-   c = __builtin_amdgcn_readfirstlane(c);
-   const ClassDesc d = table[c];
+   const int c = find_class(ph.table, ph.n_classes, (int)blockIdx.x);
+   const ClassDesc d = ph.table[c];
 #ifdef SB_STAMPS
    if ((threadIdx.x & 63) == 0) {
       const unsigned wg = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (kStampWaves - 1);
@@ -709,13 +801,16 @@ __global__ __launch_bounds__(NWAVES > 0 ? 64 * NWAVES : 64,
    }
 #endif
    ClassArgs cls;
-   cls.loci = lists_in + d.loci_off;
-   cls.n = n_in[c];
-   cls.cursor = cursors + c;
-   cls.out = lists_out + d.loci_off;
-   cls.out_count = n_out + c;
-   cls.it_limit = it_limit;
-   cls.resume = resume;
+   cls.loci = ph.lists_in + d.loci_off;
+   cls.n = ph.n_in[c];
+   cls.cursor = ph.cursors + c;
+   cls.out = ph.lists_out;
+   cls.out_count = ph.n_out;
+   cls.route = ph.route;
+   cls.next_table = ph.next_table;
+   cls.it_limit = ph.it_limit;
+   cls.resume = ph.resume;
+   cls.batch = -1;
    const int layout = d.shape & 0xFF;
    const int lbG = (d.shape >> 16) & 0xFF;
    // layout = (CPL - 1) + 8 * log2(CL): exact columns per lane (no padding to a power of two),
@@ -751,18 +846,101 @@ __global__ __launch_bounds__(NWAVES > 0 ? 64 * NWAVES : 64,
 #undef SB_BODY
 }
 
+// ------------------------------------------------------------------ the later phases' kernel
+// "Lane-rich" wave layouts for the loci that are still running when most of the batch has converged: few
+// columns per lane (1..4) on 1..16 column lanes, few rows per lane (1..8), the row lanes in the top lane bits
+// (HIMAP).  An iteration then is a few dozen instructions instead of ~200, at the price of more lanes per locus
+// -- which are free by then.  shape = (CPL - 1) | log2(CL) << 2 | R << 8 | lbG << 16.
+// A workgroup (one wave) serves the batches b = blockIdx.x, + gridDim.x, ... of the table; in the later phases
+// the table's first-block column and the number of batches are computed on the device from the survivor counts.
+#ifndef SB_LAT_MAXTILE
+#define SB_LAT_MAXTILE 32
+#endif
+constexpr int kLatMaxTile = SB_LAT_MAXTILE; // R * CPL: elements of F a lane holds at most
+constexpr int lat_shape(int cpl, int lb_cl, int r) { return (cpl - 1) | (lb_cl << 2) | (r << 8); }
+#ifndef SB_LAT_OCC
+#define SB_LAT_OCC 2
+#endif
+#ifdef SB_COMPILE_LAT_KERNEL
+__global__ __launch_bounds__(64, SB_LAT_OCC) void em_lat_kernel(EmArgs a, PhaseArgs ph)
+{
+   set_fp64_flush_denormals();
+   const int n_batches = ph.total_blocks ? *ph.total_blocks : (int)gridDim.x;
+   for (int b = (int)blockIdx.x; b < n_batches; b += (int)gridDim.x) {
+      const int c = find_class(ph.table, ph.n_classes, b);
+      const ClassDesc d = ph.table[c];
+      ClassArgs cls;
+      cls.loci = ph.lists_in + d.loci_off;
+      cls.n = ph.n_in[c];
+      cls.cursor = nullptr;
+      cls.out = ph.lists_out;
+      cls.out_count = ph.n_out;
+      cls.route = ph.route;
+      cls.next_table = ph.next_table;
+      cls.it_limit = ph.it_limit;
+      cls.resume = ph.resume;
+      cls.batch = b - d.block_begin;
+      // every lane-rich class gives a locus the whole wave (lbG = 6, a literal below: the reductions' step
+      // selection folds at compile time)
+#define SB_LAT(CPLV, CLV, RV)                                                             \
+   case lat_shape(CPLV, ilog2(CLV), RV):                                                  \
+      if constexpr (CPLV * RV <= kLatMaxTile)                                             \
+         em_tile_body<CPLV, CLV, RV, 0, true>(a, cls, 6, nullptr, nullptr);               \
+      break;
+#define SB_LAT_ROWS(CPLV, CLV)                                                            \
+   SB_LAT(CPLV, CLV, 1) SB_LAT(CPLV, CLV, 2) SB_LAT(CPLV, CLV, 3) SB_LAT(CPLV, CLV, 4)    \
+   SB_LAT(CPLV, CLV, 6) SB_LAT(CPLV, CLV, 8)
+#define SB_LAT_COLS(CLV) SB_LAT_ROWS(1, CLV) SB_LAT_ROWS(2, CLV) SB_LAT_ROWS(3, CLV) SB_LAT_ROWS(4, CLV)
+      switch (d.shape & 0xFFFF) {
+         SB_LAT_COLS(1)
+         SB_LAT_COLS(2)
+         SB_LAT_COLS(4)
+         SB_LAT_COLS(8)
+         SB_LAT_COLS(16)
+      default: break;
+      }
+#undef SB_LAT_COLS
+#undef SB_LAT_ROWS
+#undef SB_LAT
+   }
+}
+
+// First blocks of a later phase's classes from the survivor counts the previous phase left: one workgroup.
+// A class needs ceil(survivors / loci per wave) batches, loci per wave = 64 >> lbG.
+__global__ __launch_bounds__(256) void phase_prepare_kernel(ClassDesc *table, const int32_t *n_in, int n_classes,
+                                                            int32_t *total_blocks)
+{
+   __shared__ int s_scan[256];
+   int carry = 0;
+   for (int base = 0; base < n_classes; base += 256) {
+      const int c = base + (int)threadIdx.x;
+      int nb = 0;
+      if (c < n_classes) {
+         const int lbG = (table[c].shape >> 16) & 0xFF;
+         const int lpw = 64 >> lbG;
+         nb = (n_in[c] + lpw - 1) / lpw;
+      }
+      s_scan[threadIdx.x] = nb;
+      __syncthreads();
+      for (int w = 1; w < 256; w <<= 1) {
+         const int v = (int)threadIdx.x >= w ? s_scan[threadIdx.x - w] : 0;
+         __syncthreads();
+         s_scan[threadIdx.x] += v;
+         __syncthreads();
+      }
+      if (c < n_classes) table[c].block_begin = carry + s_scan[threadIdx.x] - nb;
+      carry += s_scan[255];
+      __syncthreads();
+   }
+   if (threadIdx.x == 0) *total_blocks = carry;
+}
+
+#endif // SB_COMPILE_LAT_KERNEL
+
 // host-callable launchers, one translation unit per instantiation (em_kernels_*.hip)
 struct FusedLaunch {
    EmArgs a;
-   const ClassDesc *table;
-   int n_classes;
-   const int32_t *lists_in;
-   const int32_t *n_in;
-   int32_t *cursors;
-   int32_t *lists_out;
-   int32_t *n_out;
-   int it_limit;
-   int resume;
+   PhaseArgs ph;
    int n_blocks;
 };
 hipError_t launch_fused_wave_h(const FusedLaunch &l, hipStream_t s);
@@ -770,6 +948,8 @@ hipError_t launch_fused_wave_1(const FusedLaunch &l, hipStream_t s);
 hipError_t launch_fused_wave_2(const FusedLaunch &l, hipStream_t s);
 hipError_t launch_fused_block(const FusedLaunch &l, hipStream_t s);
 hipError_t launch_fused_block_tall(const FusedLaunch &l, hipStream_t s);
+hipError_t launch_lat(const FusedLaunch &l, hipStream_t s);
+hipError_t launch_phase_prepare(ClassDesc *table, const int32_t *n_in, int n_classes, int32_t *total_blocks, hipStream_t s);
 hipError_t launch_stream(const EmArgs &a, const ClassArgs &c, uint8_t *row_keep, int n_blocks, size_t lds_bytes,
                          hipStream_t s);
 

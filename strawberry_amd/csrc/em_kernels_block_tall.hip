@@ -5,8 +5,7 @@
 namespace sb {
 hipError_t launch_fused_block_tall(const FusedLaunch &l, hipStream_t s)
 {
-   hipLaunchKernelGGL((em_fused_kernel<kBlockWaves, 12>), dim3(l.n_blocks), dim3(64 * kBlockWaves), 0, s, l.a, l.table, l.n_classes,
-                      l.lists_in, l.n_in, l.cursors, l.lists_out, l.n_out, l.it_limit, l.resume);
+   hipLaunchKernelGGL((em_fused_kernel<kBlockWaves, 12>), dim3(l.n_blocks), dim3(64 * kBlockWaves), 0, s, l.a, l.ph);
    return hipGetLastError();
 }
 #ifdef SB_STAMPS

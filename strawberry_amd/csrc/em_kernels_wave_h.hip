@@ -5,8 +5,7 @@
 namespace sb {
 hipError_t launch_fused_wave_h(const FusedLaunch &l, hipStream_t s)
 {
-   hipLaunchKernelGGL((em_fused_kernel<0, 1>), dim3(l.n_blocks), dim3(64), 0, s, l.a, l.table, l.n_classes,
-                      l.lists_in, l.n_in, l.cursors, l.lists_out, l.n_out, l.it_limit, l.resume);
+   hipLaunchKernelGGL((em_fused_kernel<0, 1>), dim3(l.n_blocks), dim3(64), 0, s, l.a, l.ph);
    return hipGetLastError();
 }
 #ifdef SB_STAMPS

@@ -69,6 +69,44 @@ static int ilog2i(int x)
    return l;
 }
 
+// Modelled latency (cycles, one wave alone on its SIMD) of one EM iteration in a lane-rich layout, from the
+// instruction costs tools/microbench.hip measures on MI355X (profiles/r02_microbench.txt): ~6 cycles per fp64 or DPP
+// instruction, 62 per row for the division (v_rcp_f64 alone is 18) with its zero test, 18 per value and
+// butterfly step, 19 for the matrix-pipe sum over lane bits 4-5, 32 for a lone permlane32 step.
+static double lat_cycles(int cpl, int lb_cl, int r, int lb_gr)
+{
+   const double row_reduce = lb_gr == 0 ? 0.0 : lb_gr == 1 ? 32.0 : 18.0 * (lb_gr - 2) + 19.0;
+   return 6.0 * cpl + 12.0 * r * cpl + 18.0 * r * lb_cl + 62.0 * r + cpl * row_reduce + 18.0 * cpl + 21.0 * lb_cl + 60.0;
+}
+
+bool lat_layout_for(int64_t nrow, int64_t niso, double lambda, LatLayout *out)
+{
+   bool found = false;
+   double best = 0.0;
+   for (int lb_cl = 0; lb_cl <= 4; ++lb_cl) {
+      const int cl = 1 << lb_cl;
+      const int64_t cpl = (niso + cl - 1) / cl;
+      if (cpl > 4 || cpl < 1) continue;
+      if (lb_cl > 0 && (niso + cl / 2 - 1) / (cl / 2) <= 1) continue; // half the column lanes already hold it with one column each
+      for (int r : kLatRows) {
+         if (r * cpl > kLatMaxTileElems) continue;
+         // a locus gets the whole wave: 64 / cl row lanes (lanes are what the later phases have to spare, and a
+         // compile-time lane count keeps the reductions free of branches)
+         const int gr = 64 / cl;
+         if ((std::max<int64_t>(nrow, 1) + r - 1) / r > gr) continue;
+         const int lb_gr = ilog2i(gr);
+         const double cyc = lat_cycles((int)cpl, lb_cl, r, lb_gr);
+         const double score = cyc * (1.0 + lambda * (double)(gr * cl) / 64.0);
+         if (!found || score < best) {
+            found = true;
+            best = score;
+            out->cpl = (int)cpl, out->lb_cl = lb_cl, out->r = r, out->lbG = lb_gr + lb_cl, out->cycles = cyc;
+         }
+      }
+   }
+   return found;
+}
+
 int build_host_plan(int64_t n_loci, const int64_t *row_off, const int64_t *iso_off,
                     const int64_t *f_off, int n_cu, const PlanTuning &tune, HostPlan *out,
                     const char **err)
@@ -149,6 +187,23 @@ int build_host_plan(int64_t n_loci, const int64_t *row_off, const int64_t *iso_o
       wave_rmult = (wave_lanes_base <= 16 * simd_lanes) ? 2 : 4;
    }
 
+   // Phases of the wave kind (plan.h: LatPhase).  Defaults, for batches that fill the chip: suspend at 32, 128 and
+   // 512 iterations; the later phases weigh a layout's lanes 8, 2 and 0.25 times its latency.
+   std::vector<int> limits = tune.phase_limits;
+   std::vector<double> lambdas = tune.phase_lambda;
+   if (limits.empty() && tune.phases_auto && n_loci >= 4096) {
+      limits = {32, 128, 512};
+      lambdas = {8.0, 2.0, 0.25};
+   }
+   {
+      std::vector<int> ok;
+      for (int v : limits)
+         if (v > (ok.empty() ? 1 : ok.back()) && v < SBGPU_EM_MAX_ITER && ok.size() < 6) ok.push_back(v);
+      limits = ok;
+      while (lambdas.size() < limits.size()) lambdas.push_back(lambdas.empty() ? 1.0 : lambdas.back());
+   }
+   const bool phased = !limits.empty();
+
    // Classes are few (kinds x layouts x group sizes).  Each host thread classifies a contiguous range of
    // loci into its own table; the tables are merged in range order, so a class list stays in locus order.
    typedef std::tuple<int, int, int, int> ClassKey;
@@ -176,7 +231,9 @@ int build_host_plan(int64_t n_loci, const int64_t *row_off, const int64_t *iso_o
             {
                const int Rw = tile_rows(CPL, wave_rmult);
                const int64_t lanes = (int64_t)pow2ceil(std::max<int64_t>(1, (nrow + Rw - 1) / Rw)) * CL;
-               if (lanes <= 64) {
+               LatLayout ll;
+               // a phased locus must fit a lane-rich layout too (the few that do not go to the workgroup kinds)
+               if (lanes <= 64 && (!phased || lat_layout_for(nrow, niso, 0.0, &ll))) {
                   kind = (wave_rmult == 1) ? kWaveH : (wave_rmult == 2 ? kWave1 : kWave2);
                   rmult = wave_rmult;
                   R = Rw;
@@ -314,6 +371,72 @@ int build_host_plan(int64_t n_loci, const int64_t *row_off, const int64_t *iso_o
       if (cx != cy) return cx > cy;
       return x.work > y.work;
    });
+
+   // ---- later phases of the wave kind: every phased locus gets its class in each of them
+   p.first_limit = SBGPU_EM_MAX_ITER;
+   if (phased) {
+      std::vector<int32_t> wave_loci;
+      for (const SizeClass &sc : p.classes)
+         if (sc.kind == kWaveH || sc.kind == kWave1 || sc.kind == kWave2) wave_loci.insert(wave_loci.end(), sc.loci.begin(), sc.loci.end());
+      if (!wave_loci.empty()) {
+         p.first_limit = limits[0];
+         p.lat.resize(limits.size());
+         for (size_t ph = 0; ph < limits.size(); ++ph) {
+            LatPhase &lp = p.lat[ph];
+            lp.it_limit = ph + 1 < limits.size() ? limits[ph + 1] : SBGPU_EM_MAX_ITER;
+            lp.route.assign((size_t)n_loci, -1);
+            const double lambda = lambdas[ph];
+            // layouts in parallel, classes serially (they are few)
+            std::vector<LatLayout> lay(wave_loci.size());
+            parallel_ranges((int64_t)wave_loci.size(), nt, [&](int64_t b, int64_t e, unsigned) {
+               for (int64_t k = b; k < e; ++k) {
+                  const int32_t l = wave_loci[(size_t)k];
+                  lat_layout_for(row_off[l + 1] - row_off[l], iso_off[l + 1] - iso_off[l], lambda, &lay[(size_t)k]);
+               }
+            });
+            std::map<ClassKey, int> slot;
+            std::vector<double> cyc;
+            for (size_t k = 0; k < wave_loci.size(); ++k) {
+               const LatLayout &ll = lay[k];
+               const ClassKey key(ll.cpl, ll.lb_cl, ll.r, ll.lbG);
+               auto it = slot.find(key);
+               if (it == slot.end()) {
+                  it = slot.emplace(key, (int)lp.classes.size()).first;
+                  SizeClass sc;
+                  sc.kind = kLat;
+                  sc.CPL = ll.cpl, sc.CL = 1 << ll.lb_cl, sc.R = ll.r, sc.rmult = ll.r;
+                  sc.layout = (ll.cpl - 1) | (ll.lb_cl << 2);
+                  sc.lbG = ll.lbG, sc.G = 1 << ll.lbG;
+                  sc.block_threads = 64;
+                  lp.classes.push_back(sc);
+                  lp.capacity.push_back(0);
+                  cyc.push_back(ll.cycles);
+               }
+               lp.capacity[(size_t)it->second] += 1;
+               lp.route[(size_t)wave_loci[k]] = it->second;
+            }
+            // slowest iterations first (lowest block indices are dispatched first); routes follow the permutation
+            std::vector<int> order(lp.classes.size()), where(lp.classes.size());
+            for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+            std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cyc[(size_t)x] > cyc[(size_t)y]; });
+            std::vector<SizeClass> cls2;
+            std::vector<int32_t> cap2;
+            for (size_t i = 0; i < order.size(); ++i) {
+               where[(size_t)order[i]] = (int)i;
+               cls2.push_back(lp.classes[(size_t)order[i]]);
+               cap2.push_back(lp.capacity[(size_t)order[i]]);
+            }
+            lp.classes.swap(cls2);
+            lp.capacity.swap(cap2);
+            for (int32_t l : wave_loci) lp.route[(size_t)l] = where[(size_t)lp.route[(size_t)l]];
+            lp.max_blocks = 0;
+            for (size_t i = 0; i < lp.classes.size(); ++i) {
+               const int lpw = 64 >> lp.classes[i].lbG;
+               lp.max_blocks += (lp.capacity[i] + lpw - 1) / lpw;
+            }
+         }
+      }
+   }
    return SBGPU_OK;
 }
 

@@ -21,6 +21,7 @@ namespace sb {
 //  kBlockTall   same with rh = 12: tiles up to 6x the base rows
 //  kStream      anything larger: F re-read from L2 every iteration
 enum ClassKind : int { kWaveH = 0, kWave1, kWave2, kBlock, kBlockTall, kStream, kNumKinds };
+constexpr int kLat = kNumKinds; // the later phases' lane-rich wave layouts (their own tables; never a phase-0 kind)
 constexpr int kBlockThreads = 256;
 constexpr int kBlockRh = 2;
 constexpr int kBlockTallRh = 12;
@@ -40,11 +41,25 @@ struct SizeClass {
    int64_t pred = 0;          // largest predicted iteration count among its loci (plan.cpp), for ordering
 };
 
+// A later phase of the wave kind: the loci still running at the previous phase's iteration limit continue in
+// lane-rich layouts (em_device.h: em_lat_kernel).  `route[l]` is the class of locus l in THIS phase (-1: the
+// locus is not of the phased wave kind); a class's `loci` is empty on the host -- the lists are filled on the
+// device -- and `capacity` says how many loci could reach it.
+struct LatPhase {
+   int it_limit = 0;                 // iterations (total) at which this phase suspends its loci; 1000 = the last phase
+   std::vector<SizeClass> classes;
+   std::vector<int32_t> capacity;    // per class
+   std::vector<int32_t> route;       // [n_loci]
+   int64_t max_blocks = 0;           // batches if every locus that can reach the phase does
+};
+
 struct HostPlan {
    int64_t n_loci = 0, n_rows = 0, n_iso = 0, n_elem = 0;
    int64_t algorithmic_bytes = 0;
    int64_t n_stream_loci = 0;
-   std::vector<SizeClass> classes; // grouped by kind; inside a kind heaviest first
+   std::vector<SizeClass> classes; // phase 0; grouped by kind; inside a kind heaviest first
+   int first_limit = 1000;         // iteration limit of phase 0 for the wave kind (1000: no later phases)
+   std::vector<LatPhase> lat;      // phases 1, 2, ...
 };
 
 // register-tile layouts: CPL exact columns per lane x CL column lanes (CPL*CL >= niso);
@@ -82,7 +97,23 @@ struct PlanTuning {
                                       // (SBGPU_CLASS_ORDER=cost: by the cost of an iteration only; A/B measurements)
    bool order_by_work = false; // order a class by nrow * niso only (SBGPU_ORDER=work; A/B measurements) instead of
                                // by the iteration count predicted from the shape
+   // Phases of the wave kind: iteration limits of all phases but the last (empty: one phase) and, per later phase,
+   // the weight of a layout's lane count against its iteration latency (large early, when many loci are alive and
+   // lanes are dear; ~0 in the last phase, when the chip is nearly empty and only the latency counts).
+   bool phases_auto = true;          // use the defaults below for batches that fill the chip
+   std::vector<int> phase_limits;
+   std::vector<double> phase_lambda; // [phase - 1]
 };
+
+// lane-rich layouts (em_device.h, em_lat_kernel): rows per lane on offer and the tile bound
+constexpr int kLatRows[6] = {1, 2, 3, 4, 6, 8};
+constexpr int kLatMaxTileElems = 32;
+struct LatLayout {
+   int cpl = 0, lb_cl = 0, r = 0, lbG = 0;
+   double cycles = 0.0; // modelled latency of one iteration
+};
+// best lane-rich layout of a locus under the lane weight `lambda`; false when none holds it
+bool lat_layout_for(int64_t nrow, int64_t niso, double lambda, LatLayout *out);
 
 // Returns 0, or a negative SBGPU_E* code with `err` filled.
 int build_host_plan(int64_t n_loci, const int64_t *row_off, const int64_t *iso_off,

@@ -40,6 +40,7 @@ int fail(int code, const std::string &msg)
    } while (0)
 
 constexpr int kAuxStreams = 8;
+constexpr int kMaxPhaseEvents = 6; // later phases of the wave kind that get timing events
 // Which aux stream each kernel kind runs on.  HIP folds streams onto a few hardware queues
 // (4 by default: GPU_MAX_HW_QUEUES) in creation order; measured on ROCm 7.2 the aux streams
 // land on queues {2,3,4,4,3,2,1,4} and the null stream on 3, so the three kinds that run
@@ -57,8 +58,11 @@ struct sbgpu_ctx {
    hipStream_t aux[kAuxStreams] = {};       // size classes run concurrently on these
    hipEvent_t fork = nullptr;
    hipEvent_t join[kAuxStreams] = {};
-   hipEvent_t t0[sb::kNumKinds] = {}, t1[sb::kNumKinds] = {}; // per-kind kernel timing
+   hipEvent_t t0[sb::kNumKinds] = {}, t1[sb::kNumKinds] = {}; // per-kind kernel timing (sbgpu_set_timing)
+   hipEvent_t tp[kMaxPhaseEvents + 1] = {};                   // ends of the wave kind's phases
    bool timed[sb::kNumKinds] = {};
+   bool timing = false; // record the timing events (off by default: they cost a few microseconds per step)
+   int n_phase_timed = 0;
    int32_t *wide_error = nullptr; // pinned host word the wide-locus kernel raises when a barrier times out
    hipEvent_t wide_fork = nullptr, wide_join[2] = {}; // rounds of the wide-locus kernel overlap on three streams
 };
@@ -68,6 +72,12 @@ int api_fail(int code, const std::string &msg) { return fail(code, msg); }
 hipStream_t ctx_stream(const sbgpu_ctx_t *ctx) { return ctx->stream; }
 int ctx_cu_count(const sbgpu_ctx_t *ctx) { return ctx->n_cu; }
 int ctx_device(const sbgpu_ctx_t *ctx) { return ctx->device; }
+bool ctx_take_wide_error(sbgpu_ctx_t *ctx)
+{
+   if (!ctx->wide_error || !*ctx->wide_error) return false;
+   *ctx->wide_error = 0;
+   return true;
+}
 } // namespace sb
 
 struct KindLaunch {
@@ -84,11 +94,17 @@ struct sbgpu_plan {
    char *d_arena = nullptr;            // one allocation, one upload: the arrays below point into it
    int64_t *d_row_off = nullptr, *d_iso_off = nullptr, *d_f_off = nullptr;
    int32_t *d_loci_all = nullptr;      // all class lists, concatenated (input of phase 0)
-   int32_t *d_lists[2] = {nullptr, nullptr}; // survivor lists of the later phases (ping-pong)
    int32_t *d_class_n = nullptr;       // loci per class (input count of phase 0)
-   int32_t *d_counts = nullptr;        // [phase][class] survivor counts, zeroed every run
-   int32_t *d_cursors = nullptr;       // [phase][class] dynamic-pull cursors, zeroed every run
-   std::vector<int> phase_limits;      // iteration limit of each phase, last = 1000
+   int32_t *d_cursors = nullptr;       // [class] dynamic-pull cursors of phase 0; zeroed every run together with
+   size_t zero_bytes = 0;              //   the later phases' survivor counts and batch totals behind them
+   // later phases of the wave kind (plan.h: LatPhase): class table (first blocks filled on the device), survivor
+   // counts, number of batches, survivor lists, and the route INTO the phase
+   struct LatDev {
+      sb::ClassDesc *d_table = nullptr;
+      int32_t *d_counts = nullptr, *d_total = nullptr, *d_lists = nullptr, *d_route = nullptr;
+      int n_classes = 0, it_limit = 0, grid = 0;
+   };
+   std::vector<LatDev> lat;
    sb::ClassDesc *d_tables = nullptr;  // one descriptor per class
    std::vector<int64_t> loci_off;      // per class: offset into d_loci_all
    uint8_t *d_row_keep = nullptr;      // streaming path: init() row flags
@@ -298,6 +314,7 @@ int sbgpu_init(int device, sbgpu_ctx_t **ctx_out)
       e = hipEventCreate(&c->t0[k]);
       if (e == hipSuccess) e = hipEventCreate(&c->t1[k]);
    }
+   for (int i = 0; e == hipSuccess && i <= kMaxPhaseEvents; ++i) e = hipEventCreate(&c->tp[i]);
    if (e != hipSuccess) {
       sbgpu_finalize(c);
       return fail(SBGPU_EHIP, std::string("sbgpu_init: stream/event creation: ") + hipGetErrorString(e));
@@ -319,6 +336,8 @@ int sbgpu_finalize(sbgpu_ctx_t *c)
       if (c->t0[k]) (void)hipEventDestroy(c->t0[k]);
       if (c->t1[k]) (void)hipEventDestroy(c->t1[k]);
    }
+   for (int i = 0; i <= kMaxPhaseEvents; ++i)
+      if (c->tp[i]) (void)hipEventDestroy(c->tp[i]);
    if (c->stream) (void)hipStreamDestroy(c->stream);
    if (c->wide_error) (void)hipHostFree(c->wide_error);
    if (c->wide_fork) (void)hipEventDestroy(c->wide_fork);
@@ -375,6 +394,23 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
    if (const char *e = std::getenv("SBGPU_LIGHT_BLOCK")) tune.light_block = std::atoi(e) != 0;
    if (const char *e = std::getenv("SBGPU_ORDER")) tune.order_by_work = std::string(e) == "work";
    if (const char *e = std::getenv("SBGPU_CLASS_ORDER")) tune.classes_by_prediction = std::string(e) != "cost";
+   // SBGPU_PHASES="32,128,512": iteration limits at which the wave kind's loci are suspended and continue in
+   // lane-rich layouts ("0" or "": one phase); SBGPU_PHASE_LAMBDA="8,2,0.25": the later phases' lane weights
+   auto parse_list = [](const char *ev, auto conv, auto *out) {
+      std::string spec = ev;
+      size_t pos = 0;
+      while (pos < spec.size()) {
+         size_t q = spec.find(',', pos);
+         if (q == std::string::npos) q = spec.size();
+         out->push_back(conv(spec.substr(pos, q - pos)));
+         pos = q + 1;
+      }
+   };
+   if (const char *e = std::getenv("SBGPU_PHASES")) {
+      tune.phases_auto = false;
+      parse_list(e, [](const std::string &t) { return std::atoi(t.c_str()); }, &tune.phase_limits);
+   }
+   if (const char *e = std::getenv("SBGPU_PHASE_LAMBDA")) parse_list(e, [](const std::string &t) { return std::atof(t.c_str()); }, &tune.phase_lambda);
    const bool timing = std::getenv("SBGPU_HOST_TIMING") != nullptr; // diagnostic: stage times on stderr
    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
    double t_stage = now();
@@ -398,25 +434,6 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
    hipError_t e = hipSetDevice(c->device);
    if (e != hipSuccess) return bail(e, "hipSetDevice");
    const size_t nb = (size_t)(n_loci + 1) * sizeof(int64_t);
-   // phases: a single phase (the 1000 cap) by default; SBGPU_PHASES="64,256" suspends the loci
-   // still running at 64 and 256 iterations and re-packs them (measured: no gain on C2/C3)
-   {
-      std::string spec = "";
-      if (const char *ev = std::getenv("SBGPU_PHASES")) spec = ev;
-      int last = 1;
-      size_t pos = 0;
-      while (pos < spec.size()) {
-         size_t q = spec.find(',', pos);
-         if (q == std::string::npos) q = spec.size();
-         int v = std::atoi(spec.substr(pos, q - pos).c_str());
-         if (v > last && v < SBGPU_EM_MAX_ITER && p->phase_limits.size() < 6) {
-            p->phase_limits.push_back(v);
-            last = v;
-         }
-         pos = q + 1;
-      }
-      p->phase_limits.push_back(SBGPU_EM_MAX_ITER);
-   }
    // ---- wide loci: the streaming class is served by the multi-workgroup kernel wherever a locus' rows fit
    // into n_cu workgroups; such loci move to the front of the class list, the rest keeps the streaming kernel
    std::vector<sb::WideDesc> wide_table;
@@ -474,7 +491,10 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
    p->n_wide_desc = (int32_t)wide_table.size();
    const size_t ncls = p->host.classes.size();
    const size_t ncls_alloc = ncls + 1;
-   const size_t nph = p->phase_limits.size() + 1;
+   const size_t nlat = p->host.lat.size();
+   int64_t n_phased = 0; // loci of the phased wave kind = capacity of every later phase's lists
+   if (nlat)
+      for (int32_t cap : p->host.lat[0].capacity) n_phased += cap;
    // ---- one device arena; its head (offsets, class lists, tables, class sizes) is staged on the host
    // and uploaded with a single copy, the rest is workspace
    auto up = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
@@ -486,11 +506,22 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
    const size_t o_tab = at; at += up(ncls_alloc * sizeof(sb::ClassDesc));
    const size_t o_cn = at; at += up(ncls_alloc * sizeof(int32_t));
    const size_t o_wtab = at; at += up((wide_table.size() + 1) * sizeof(sb::WideDesc));
+   std::vector<size_t> o_ltab(nlat), o_lroute(nlat), o_lcnt(nlat), o_ltot(nlat), o_llist(nlat);
+   for (size_t i = 0; i < nlat; ++i) {
+      o_ltab[i] = at; at += up((p->host.lat[i].classes.size() + 1) * sizeof(sb::ClassDesc));
+      o_lroute[i] = at; at += up((size_t)(n_loci + 1) * sizeof(int32_t));
+   }
    const size_t staged = at;
-   const size_t o_cur = at; at += up(nph * ncls_alloc * sizeof(int32_t));
-   const size_t o_cnt = at; at += up(nph * ncls_alloc * sizeof(int32_t));
-   const size_t o_l0 = at; at += up((size_t)(n_loci + 1) * sizeof(int32_t));
-   const size_t o_l1 = at; at += up((size_t)(n_loci + 1) * sizeof(int32_t));
+   // zeroed before every run: phase-0 cursors, then every later phase's survivor counts and batch total
+   const size_t o_cur = at; at += up(ncls_alloc * sizeof(int32_t));
+   for (size_t i = 0; i < nlat; ++i) {
+      o_lcnt[i] = at; at += up((p->host.lat[i].classes.size() + 1) * sizeof(int32_t));
+      o_ltot[i] = at; at += up(sizeof(int32_t));
+   }
+   p->zero_bytes = at - o_cur;
+   for (size_t i = 0; i < nlat; ++i) {
+      o_llist[i] = at; at += up((size_t)(n_phased + 1) * sizeof(int32_t));
+   }
    const size_t o_keep = at; at += up((size_t)p->host.n_rows + 1);
    const size_t o_sum = at; at += up((size_t)(n_loci + 1) * sizeof(double));
    const size_t o_wbar = at; at += up((wide_table.size() + 1) * sizeof(unsigned));
@@ -504,9 +535,20 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
    p->d_tables = (sb::ClassDesc *)(p->d_arena + o_tab);
    p->d_class_n = (int32_t *)(p->d_arena + o_cn);
    p->d_cursors = (int32_t *)(p->d_arena + o_cur);
-   p->d_counts = (int32_t *)(p->d_arena + o_cnt);
-   p->d_lists[0] = (int32_t *)(p->d_arena + o_l0);
-   p->d_lists[1] = (int32_t *)(p->d_arena + o_l1);
+   p->lat.resize(nlat);
+   for (size_t i = 0; i < nlat; ++i) {
+      sbgpu_plan::LatDev &ld = p->lat[i];
+      const sb::LatPhase &lp = p->host.lat[i];
+      ld.d_table = (sb::ClassDesc *)(p->d_arena + o_ltab[i]);
+      ld.d_route = (int32_t *)(p->d_arena + o_lroute[i]);
+      ld.d_counts = (int32_t *)(p->d_arena + o_lcnt[i]);
+      ld.d_total = (int32_t *)(p->d_arena + o_ltot[i]);
+      ld.d_lists = (int32_t *)(p->d_arena + o_llist[i]);
+      ld.n_classes = (int)lp.classes.size();
+      ld.it_limit = lp.it_limit;
+      // every batch gets a wave of its own up to 32768 waves; beyond that the waves stride over the batches
+      ld.grid = (int)std::min<int64_t>(std::max<int64_t>(lp.max_blocks, 1), 32768);
+   }
    p->d_row_keep = (uint8_t *)(p->d_arena + o_keep);
    p->d_locus_sum = (double *)(p->d_arena + o_sum);
    p->d_wide_table = (sb::WideDesc *)(p->d_arena + o_wtab);
@@ -522,6 +564,20 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
    sb::ClassDesc *table = (sb::ClassDesc *)(stage_buf.data() + o_tab);
    int32_t *h_cn = (int32_t *)(stage_buf.data() + o_cn);
    if (!wide_table.empty()) std::memcpy(stage_buf.data() + o_wtab, wide_table.data(), wide_table.size() * sizeof(sb::WideDesc));
+   for (size_t i = 0; i < nlat; ++i) {
+      const sb::LatPhase &lp = p->host.lat[i];
+      sb::ClassDesc *lt = (sb::ClassDesc *)(stage_buf.data() + o_ltab[i]);
+      int32_t loff = 0;
+      for (size_t ci = 0; ci < lp.classes.size(); ++ci) {
+         const sb::SizeClass &sc = lp.classes[ci];
+         lt[ci].block_begin = 0; // phase_prepare_kernel fills it from the survivor counts
+         lt[ci].n = lp.capacity[ci];
+         lt[ci].loci_off = loff;
+         lt[ci].shape = sc.layout | (sc.rmult << 8) | (sc.lbG << 16);
+         loff += lp.capacity[ci];
+      }
+      std::memcpy(stage_buf.data() + o_lroute[i], lp.route.data(), lp.route.size() * sizeof(int32_t));
+   }
    size_t off = 0;
    size_t max_stream_iso = 0;
    for (int k = 0; k < sb::kNumKinds; ++k) p->launches[k] = KindLaunch();
@@ -609,12 +665,12 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
    a.theta = d_theta;
    a.status = d_status;
    a.iters = d_iters;
-   const int ncls = (int)p->host.classes.size();
-   const size_t ncls_alloc = (size_t)ncls + 1;
-   const int nph = (int)p->phase_limits.size();
-   // cursors and counts sit next to each other in the plan's arena: one memset clears both
-   HIP_TRY(hipMemsetAsync(p->d_cursors, 0, (size_t)((char *)p->d_counts - (char *)p->d_cursors) + (size_t)(nph + 1) * ncls_alloc * sizeof(int32_t), main));
-   // one launch per kind and phase (wave / block / stream); a single kind runs on the
+   // phase-0 cursors and the later phases' survivor counts / batch totals sit next to each other: one memset
+   HIP_TRY(hipMemsetAsync(p->d_cursors, 0, p->zero_bytes, main));
+   // a locus the kernels never reach (a wide-locus barrier that timed out) must not look solved: status starts
+   // at -1 = SBGPU_EM_UNSOLVED (0xFF bytes)
+   HIP_TRY(hipMemsetAsync(d_status, 0xFF, (size_t)p->host.n_loci * sizeof(int32_t), main));
+   // one launch per kind (wave / block / stream); a single kind runs on the
    // caller's stream, several fork onto the aux streams and join back
    int kinds = 0;
    for (int k = 0; k < sb::kNumKinds; ++k) kinds += p->launches[k].n_classes > 0;
@@ -625,6 +681,8 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
          if (p->launches[k].n_classes > 0) HIP_TRY(hipStreamWaitEvent(c->aux[kKindStream[k]], c->fork, 0));
    }
    for (int k = 0; k < sb::kNumKinds; ++k) c->timed[k] = false;
+   c->n_phase_timed = 0;
+   const bool timing = c->timing;
    // longest iterations first: stream, block, wave
    for (int k = sb::kNumKinds - 1; k >= 0; --k) {
       const KindLaunch &kl = p->launches[k];
@@ -646,25 +704,43 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
          hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, s, (unsigned long long)hold_us * 100ull);
          HIP_TRY(hipGetLastError());
       }
-      HIP_TRY(hipEventRecord(c->t0[k], s));
+      if (timing) HIP_TRY(hipEventRecord(c->t0[k], s));
       if (k == sb::kStream) {
          // wide loci: cooperative launches, one per round (all workgroups of a launch are resident)
          if (p->n_wide_desc) {
             HIP_TRY(hipMemsetAsync(p->d_wide_barriers, 0, (size_t)p->n_wide_desc * sizeof(unsigned), s));
             int32_t *d_err = nullptr;
             HIP_TRY(hipHostGetDevicePointer((void **)&d_err, c->wide_error, 0));
-            // Rounds go to three streams in turn: a round's workgroups start as soon as CUs free up, so the tail
-            // of one round (its slowest locus) overlaps the next.  No round waits on another, every round fits the
-            // chip by itself: no deadlock among the counter barriers.
+            // Rounds may overlap on three streams -- the tail of one round (its slowest locus) then runs beside the
+            // next -- but ONLY while the rounds in flight fit the chip together: a cooperative launch is promised
+            // residency on an otherwise free device, so two rounds that each need most of the CUs could both end up
+            // half resident and spin in their barriers until the timeout.  A round that does not fit beside the ones
+            // in flight first joins them all.
             hipStream_t lanes[3] = {s, c->aux[3], c->aux[5]};
-            const bool spread = p->wide_rounds.size() > 1;
-            if (spread) {
-               HIP_TRY(hipEventRecord(c->wide_fork, s));
-               HIP_TRY(hipStreamWaitEvent(lanes[1], c->wide_fork, 0));
-               HIP_TRY(hipStreamWaitEvent(lanes[2], c->wide_fork, 0));
-            }
-            size_t ri = 0;
+            int in_flight_blocks = 0, lane = 0;
+            bool used[3] = {false, false, false};
+            auto join_lanes = [&]() -> int {
+               for (int x = 1; x < 3; ++x) {
+                  if (!used[x]) continue;
+                  HIP_TRY(hipEventRecord(c->wide_join[x - 1], lanes[x]));
+                  HIP_TRY(hipStreamWaitEvent(s, c->wide_join[x - 1], 0));
+                  used[x] = false;
+               }
+               return SBGPU_OK;
+            };
             for (const sbgpu_plan::WideRound &r : p->wide_rounds) {
+               if (in_flight_blocks > 0 && (in_flight_blocks + r.n_blocks > c->n_cu || lane == 3)) {
+                  const int rc = join_lanes();
+                  if (rc != SBGPU_OK) return rc;
+                  in_flight_blocks = 0;
+                  lane = 0;
+               }
+               if (lane > 0) {
+                  // the side stream starts behind everything the round stream has done so far
+                  HIP_TRY(hipEventRecord(c->wide_fork, s));
+                  HIP_TRY(hipStreamWaitEvent(lanes[lane], c->wide_fork, 0));
+                  used[lane] = true;
+               }
                sb::WideArgs wa;
                wa.a = a;
                wa.table = p->d_wide_table + r.first_desc;
@@ -672,14 +748,12 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
                wa.bufs = p->d_wide_bufs;
                wa.barriers = p->d_wide_barriers;
                wa.error = d_err;
-               HIP_TRY(sb::launch_wide(r.nslot, wa, r.n_blocks, r.lds_bytes, spread ? lanes[ri % 3] : s));
-               ++ri;
+               HIP_TRY(sb::launch_wide(r.nslot, wa, r.n_blocks, r.lds_bytes, lanes[lane]));
+               in_flight_blocks += r.n_blocks;
+               ++lane;
             }
-            if (spread)
-               for (int x = 0; x < 2; ++x) {
-                  HIP_TRY(hipEventRecord(c->wide_join[x], lanes[x + 1]));
-                  HIP_TRY(hipStreamWaitEvent(s, c->wide_join[x], 0));
-               }
+            const int rc = join_lanes();
+            if (rc != SBGPU_OK) return rc;
          }
          const int32_t n_all = (int32_t)p->host.classes[kl.first_class].loci.size();
          if (n_all > p->n_wide_loci) { // the rest: one workgroup per locus, F streamed from L2
@@ -687,36 +761,65 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
             ca.loci = p->d_loci_all + p->loci_off[kl.first_class] + p->n_wide_loci;
             ca.n = n_all - p->n_wide_loci;
             ca.cursor = p->d_cursors + kl.first_class;
+            ca.batch = -1;
             HIP_TRY(sb::launch_stream(a, ca, p->d_row_keep, ca.n, p->stream_lds_bytes, s));
          }
       } else {
-         // phase ph runs the loci still alive up to phase_limits[ph] iterations and appends
-         // the unfinished ones to the next phase's list; later phases launch the same grid,
-         // waves whose class list is already dry leave after one atomic
-         for (int ph = 0; ph < nph; ++ph) {
-            sb::FusedLaunch fl;
-            fl.a = a;
-            fl.table = kl.d_table;
-            fl.n_classes = kl.n_classes;
-            fl.lists_in = (ph == 0) ? p->d_loci_all : p->d_lists[(ph - 1) & 1];
-            fl.n_in = (ph == 0) ? p->d_class_n + kl.first_class : p->d_counts + (size_t)ph * ncls_alloc + kl.first_class;
-            fl.cursors = p->d_cursors + (size_t)ph * ncls_alloc + kl.first_class;
-            fl.lists_out = p->d_lists[ph & 1];
-            fl.n_out = p->d_counts + (size_t)(ph + 1) * ncls_alloc + kl.first_class;
-            fl.it_limit = p->phase_limits[ph];
-            fl.resume = ph > 0;
-            fl.n_blocks = kl.n_blocks;
-            hipError_t e = hipErrorInvalidValue;
-            if (k == sb::kWaveH) e = sb::launch_fused_wave_h(fl, s);
-            else if (k == sb::kWave1) e = sb::launch_fused_wave_1(fl, s);
-            else if (k == sb::kWave2) e = sb::launch_fused_wave_2(fl, s);
-            else if (k == sb::kBlock) e = sb::launch_fused_block(fl, s);
-            else if (k == sb::kBlockTall) e = sb::launch_fused_block_tall(fl, s);
-            HIP_TRY(e);
+         const bool wave_kind = k == sb::kWaveH || k == sb::kWave1 || k == sb::kWave2;
+         const bool phased = wave_kind && !p->lat.empty();
+         sb::FusedLaunch fl;
+         fl.a = a;
+         fl.ph.table = kl.d_table;
+         fl.ph.n_classes = kl.n_classes;
+         fl.ph.lists_in = p->d_loci_all;
+         fl.ph.n_in = p->d_class_n + kl.first_class;
+         fl.ph.cursors = p->d_cursors + kl.first_class;
+         fl.ph.total_blocks = nullptr;
+         fl.ph.lists_out = phased ? p->lat[0].d_lists : nullptr;
+         fl.ph.n_out = phased ? p->lat[0].d_counts : nullptr;
+         fl.ph.route = phased ? p->lat[0].d_route : nullptr;
+         fl.ph.next_table = phased ? p->lat[0].d_table : nullptr;
+         fl.ph.it_limit = phased ? p->host.first_limit : SBGPU_EM_MAX_ITER;
+         fl.ph.resume = 0;
+         fl.n_blocks = kl.n_blocks;
+         hipError_t e = hipErrorInvalidValue;
+         if (k == sb::kWaveH) e = sb::launch_fused_wave_h(fl, s);
+         else if (k == sb::kWave1) e = sb::launch_fused_wave_1(fl, s);
+         else if (k == sb::kWave2) e = sb::launch_fused_wave_2(fl, s);
+         else if (k == sb::kBlock) e = sb::launch_fused_block(fl, s);
+         else if (k == sb::kBlockTall) e = sb::launch_fused_block_tall(fl, s);
+         HIP_TRY(e);
+         // later phases: the loci still running continue in lane-rich layouts; a one-workgroup kernel turns the
+         // survivor counts into the next launch's block table in between
+         for (size_t i = 0; phased && i < p->lat.size(); ++i) {
+            const sbgpu_plan::LatDev &ld = p->lat[i];
+            const bool last = i + 1 == p->lat.size();
+            if (timing && i < (size_t)kMaxPhaseEvents) HIP_TRY(hipEventRecord(c->tp[i], s));
+            HIP_TRY(sb::launch_phase_prepare(ld.d_table, ld.d_counts, ld.n_classes, ld.d_total, s));
+            sb::FusedLaunch ll;
+            ll.a = a;
+            ll.ph.table = ld.d_table;
+            ll.ph.n_classes = ld.n_classes;
+            ll.ph.lists_in = ld.d_lists;
+            ll.ph.n_in = ld.d_counts;
+            ll.ph.cursors = nullptr;
+            ll.ph.total_blocks = ld.d_total;
+            ll.ph.lists_out = last ? nullptr : p->lat[i + 1].d_lists;
+            ll.ph.n_out = last ? nullptr : p->lat[i + 1].d_counts;
+            ll.ph.route = last ? nullptr : p->lat[i + 1].d_route;
+            ll.ph.next_table = last ? nullptr : p->lat[i + 1].d_table;
+            ll.ph.it_limit = ld.it_limit;
+            ll.ph.resume = 1;
+            ll.n_blocks = ld.grid;
+            HIP_TRY(sb::launch_lat(ll, s));
+            if (timing) c->n_phase_timed = (int)std::min<size_t>(i + 1, kMaxPhaseEvents);
          }
+         if (timing && phased && p->lat.size() <= (size_t)kMaxPhaseEvents) HIP_TRY(hipEventRecord(c->tp[p->lat.size()], s));
       }
-      HIP_TRY(hipEventRecord(c->t1[k], s));
-      c->timed[k] = true;
+      if (timing) {
+         HIP_TRY(hipEventRecord(c->t1[k], s));
+         c->timed[k] = true;
+      }
    }
    if (fork) {
       for (int k = 0; k < sb::kNumKinds; ++k) {
@@ -726,6 +829,30 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
       }
    }
    return SBGPU_OK;
+}
+
+int sbgpu_set_timing(sbgpu_ctx_t *c, int on)
+{
+   if (!c) return fail(SBGPU_EINVAL, "sbgpu_set_timing: null ctx");
+   c->timing = on != 0;
+   return SBGPU_OK;
+}
+
+int sbgpu_em_last_phase_ms(sbgpu_ctx_t *c, float *ms, int cap)
+{
+   if (!c || (!ms && cap > 0)) return fail(SBGPU_EINVAL, "sbgpu_em_last_phase_ms: null argument");
+   // tp[0] = end of phase 0, tp[i] = end of later phase i; t0[wave kind] = start of phase 0
+   int wave = -1;
+   for (int k = 0; k <= sb::kWave2; ++k)
+      if (c->timed[k]) wave = k;
+   if (wave < 0 || c->n_phase_timed == 0) return 0;
+   int n = 0;
+   for (int i = 0; i <= c->n_phase_timed && n < cap; ++i) {
+      HIP_TRY(hipEventSynchronize(c->tp[i]));
+      HIP_TRY(hipEventElapsedTime(&ms[n], i == 0 ? c->t0[wave] : c->tp[i - 1], c->tp[i]));
+      ++n;
+   }
+   return n;
 }
 
 int sbgpu_em_last_kernel_ms(sbgpu_ctx_t *c, float ms[6])

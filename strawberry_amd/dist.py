@@ -120,3 +120,7 @@ class ShardQuantifier:
         s.run_abundance(**self.kw)          # leaves this rank's sum of kept FPKM in d_sum_fpkm
         allreduce_sum_(s.d_sum_fpkm)        # the one collective: 8 bytes over xGMI
         s.run_tpm(s.d_sum_fpkm)
+
+    def finish(self):
+        """Wait for the step(s) issued so far; raises if a run failed on the device (SbgpuError)."""
+        self.s.synchronize()

@@ -146,6 +146,23 @@ class EmBatchSolver:
                                          self.d_theta.data_ptr(), self.d_status.data_ptr(),
                                          self.d_iters.data_ptr(), self._stream()), "sbgpu_em_run_device")
 
+    def set_timing(self, on=True):
+        """Timing events around the EM kernels (off by default; bench.py turns them on for its probe steps)."""
+        _lib.check(self.ctx.L.sbgpu_set_timing(self.ctx.h, int(bool(on))), "sbgpu_set_timing")
+
+    def last_phase_ms(self):
+        """Device time of each phase of the wave kind in the last run_em (timing on); [] for one phase."""
+        ms = (C.c_float * 8)()
+        n = self.ctx.L.sbgpu_em_last_phase_ms(self.ctx.h, ms, 8)
+        if n < 0:
+            _lib.check(n, "sbgpu_em_last_phase_ms")
+        return [float(ms[i]) for i in range(n)]
+
+    def synchronize(self):
+        """Wait for this solver's stream and report a failed run (a wide-locus barrier that timed out leaves
+        loci unsolved: that must raise, not hand stale theta to FPKM/TPM and the all-reduce)."""
+        _lib.check(self.ctx.L.sbgpu_synchronize(self.ctx.h, self._stream()), "sbgpu_synchronize")
+
     def last_kernel_ms(self):
         """Device time of the last run_em per kernel kind:
         [wave half tile, wave base tile, wave double tile, block, tall block, stream]."""
@@ -172,7 +189,8 @@ class EmBatchSolver:
                                                self._stream()), "sbgpu_tpm_device")
 
     def results(self):
-        """-> dict of host numpy arrays (synchronises)."""
+        """-> dict of host numpy arrays (synchronises; raises if the last run failed)."""
+        self.synchronize()
         self.torch.cuda.synchronize(self.dev)
         n, k = self.batch.n_loci, self.n_iso
         return {

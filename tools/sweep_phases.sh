@@ -1,0 +1,17 @@
+#!/bin/bash
+# tools/sweep_phases.sh -- C3 step time under different phase limits / lane weights (diagnostic)
+cd "$(dirname "$0")/.."
+run() {
+  SBGPU_PHASES="$1" SBGPU_PHASE_LAMBDA="$2" python bench.py --steps 20 --warmup 5 --no-cpu-baseline --workload ${3:-c3} 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('phases %-18s lambda %-14s ms/step %.3f  kinds %s  phases_ms %s' % ('$1','$2',d['ms_per_step'],' '.join('%.3f'%v for v in d['roofline']['all_kernels_ms'].values()),' '.join('%.3f'%v for v in d.get('wave_phase_ms',[]))))"
+}
+if [ $# -gt 0 ]; then run "$@"; exit; fi
+run 0 ""
+run 32,128,512 8,2,0.25
+run 32,128,512 4,1,0.1
+run 24,96,384 8,2,0.25
+run 48,256 4,0.25
+run 16,64,256 16,4,0.5
+run 32,128,512 16,4,0.5
