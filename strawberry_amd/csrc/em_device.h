@@ -791,7 +791,13 @@ __global__ __launch_bounds__(NWAVES > 0 ? 64 * NWAVES : 64,
 #ifdef SB_STAMPS
    const unsigned long long st0 = sb_now();
 #endif
-   const int c = find_class(ph.table, ph.n_classes, (int)blockIdx.x);
+   // Phase 0: one workgroup per batch, loci pulled through the class cursors.  A later phase that re-packs its
+   // survivors into the same layouts (ph.total_blocks set): batches b = blockIdx.x, + gridDim.x, ... of the table
+   // whose first-block column phase_prepare_kernel has written from the survivor counts.
+   const bool fixed_batches = ph.total_blocks != nullptr;
+   const int n_batches = fixed_batches ? *ph.total_blocks : (int)gridDim.x;
+   for (int b = (int)blockIdx.x; b < n_batches; b += (int)gridDim.x) {
+   const int c = find_class(ph.table, ph.n_classes, b);
    const ClassDesc d = ph.table[c];
 #ifdef SB_STAMPS
    if ((threadIdx.x & 63) == 0) {
@@ -810,7 +816,7 @@ __global__ __launch_bounds__(NWAVES > 0 ? 64 * NWAVES : 64,
    cls.next_table = ph.next_table;
    cls.it_limit = ph.it_limit;
    cls.resume = ph.resume;
-   cls.batch = -1;
+   cls.batch = fixed_batches ? b - d.block_begin : -1;
    const int layout = d.shape & 0xFF;
    const int lbG = (d.shape >> 16) & 0xFF;
    // layout = (CPL - 1) + 8 * log2(CL): exact columns per lane (no padding to a power of two),
@@ -844,6 +850,7 @@ __global__ __launch_bounds__(NWAVES > 0 ? 64 * NWAVES : 64,
    default: break;
    }
 #undef SB_BODY
+   } // batches
 }
 
 // ------------------------------------------------------------------ the later phases' kernel

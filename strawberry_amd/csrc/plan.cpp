@@ -386,6 +386,20 @@ int build_host_plan(int64_t n_loci, const int64_t *row_off, const int64_t *iso_o
             lp.it_limit = ph + 1 < limits.size() ? limits[ph + 1] : SBGPU_EM_MAX_ITER;
             lp.route.assign((size_t)n_loci, -1);
             const double lambda = lambdas[ph];
+            if (lambda < 0.0) {
+               // re-pack: the phase's classes are the wave kind's phase-0 classes, in their order
+               lp.repack = true;
+               for (const SizeClass &sc : p.classes) {
+                  if (!(sc.kind == kWaveH || sc.kind == kWave1 || sc.kind == kWave2)) continue;
+                  SizeClass c2 = sc;
+                  c2.loci.clear();
+                  for (int32_t l : sc.loci) lp.route[(size_t)l] = (int32_t)lp.classes.size();
+                  lp.capacity.push_back((int32_t)sc.loci.size());
+                  lp.max_blocks += sc.n_blocks;
+                  lp.classes.push_back(std::move(c2));
+               }
+               continue;
+            }
             // layouts in parallel, classes serially (they are few)
             std::vector<LatLayout> lay(wave_loci.size());
             parallel_ranges((int64_t)wave_loci.size(), nt, [&](int64_t b, int64_t e, unsigned) {

@@ -46,6 +46,7 @@ struct SizeClass {
 // locus is not of the phased wave kind); a class's `loci` is empty on the host -- the lists are filled on the
 // device -- and `capacity` says how many loci could reach it.
 struct LatPhase {
+   bool repack = false;              // true: the survivors are re-packed into their phase-0 layouts (the wave kind's own kernel)
    int it_limit = 0;                 // iterations (total) at which this phase suspends its loci; 1000 = the last phase
    std::vector<SizeClass> classes;
    std::vector<int32_t> capacity;    // per class
@@ -100,9 +101,10 @@ struct PlanTuning {
    // Phases of the wave kind: iteration limits of all phases but the last (empty: one phase) and, per later phase,
    // the weight of a layout's lane count against its iteration latency (large early, when many loci are alive and
    // lanes are dear; ~0 in the last phase, when the chip is nearly empty and only the latency counts).
-   bool phases_auto = true;          // use the defaults below for batches that fill the chip
+   bool phases_auto = false;         // use default limits for batches that fill the chip.  OFF: measured on C3 (profiles/
+                                     // r02_phase_sweep_*.txt) every phase schedule is slower than one phase -- see DESIGN.md 3.1
    std::vector<int> phase_limits;
-   std::vector<double> phase_lambda; // [phase - 1]
+   std::vector<double> phase_lambda; // [phase - 1]; negative: the phase re-packs the survivors into their phase-0 layouts instead
 };
 
 // lane-rich layouts (em_device.h, em_lat_kernel): rows per lane on offer and the tile bound

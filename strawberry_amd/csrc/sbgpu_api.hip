@@ -103,6 +103,7 @@ struct sbgpu_plan {
       sb::ClassDesc *d_table = nullptr;
       int32_t *d_counts = nullptr, *d_total = nullptr, *d_lists = nullptr, *d_route = nullptr;
       int n_classes = 0, it_limit = 0, grid = 0;
+      bool repack = false;
    };
    std::vector<LatDev> lat;
    sb::ClassDesc *d_tables = nullptr;  // one descriptor per class
@@ -410,7 +411,9 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
       tune.phases_auto = false;
       parse_list(e, [](const std::string &t) { return std::atoi(t.c_str()); }, &tune.phase_limits);
    }
-   if (const char *e = std::getenv("SBGPU_PHASE_LAMBDA")) parse_list(e, [](const std::string &t) { return std::atof(t.c_str()); }, &tune.phase_lambda);
+   // a lane weight "t" makes the phase re-pack its survivors into their phase-0 layouts instead ("tile" phases)
+   if (const char *e = std::getenv("SBGPU_PHASE_LAMBDA"))
+      parse_list(e, [](const std::string &t) { return (!t.empty() && (t[0] == 't' || t[0] == 'T')) ? -1.0 : std::atof(t.c_str()); }, &tune.phase_lambda);
    const bool timing = std::getenv("SBGPU_HOST_TIMING") != nullptr; // diagnostic: stage times on stderr
    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
    double t_stage = now();
@@ -546,6 +549,7 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
       ld.d_lists = (int32_t *)(p->d_arena + o_llist[i]);
       ld.n_classes = (int)lp.classes.size();
       ld.it_limit = lp.it_limit;
+      ld.repack = lp.repack;
       // every batch gets a wave of its own up to 32768 waves; beyond that the waves stride over the batches
       ld.grid = (int)std::min<int64_t>(std::max<int64_t>(lp.max_blocks, 1), 32768);
    }
@@ -811,7 +815,12 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
             ll.ph.it_limit = ld.it_limit;
             ll.ph.resume = 1;
             ll.n_blocks = ld.grid;
-            HIP_TRY(sb::launch_lat(ll, s));
+            hipError_t el = hipErrorInvalidValue;
+            if (!ld.repack) el = sb::launch_lat(ll, s);
+            else if (k == sb::kWaveH) el = sb::launch_fused_wave_h(ll, s);
+            else if (k == sb::kWave1) el = sb::launch_fused_wave_1(ll, s);
+            else el = sb::launch_fused_wave_2(ll, s);
+            HIP_TRY(el);
             if (timing) c->n_phase_timed = (int)std::min<size_t>(i + 1, kMaxPhaseEvents);
          }
          if (timing && phased && p->lat.size() <= (size_t)kMaxPhaseEvents) HIP_TRY(hipEventRecord(c->tp[p->lat.size()], s));

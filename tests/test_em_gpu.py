@@ -200,7 +200,7 @@ def test_gpu_phased_execution_matches_oracle(ctx, oracle, monkeypatch):
     b = synth.make_c3(n_loci=6000, total_frags=2e7, seed=11)
     o_theta, o_status, o_iters = oracle.em_batch(b.row_off, b.iso_off, b.f_off, b.count, b.F, threads=4)
     for spec, lam in (("0", None), ("8", "0"), ("3,17,64,300", "16,4,1,0"), ("64,256", "2,0.25"), ("32,128,512", None),
-                      ("1000", None), ("2", "100")):
+                      ("1000", None), ("2", "100"), ("8,64", "t,t"), ("16,100,400", "t,1,t"), ("5,50", "0,t")):
         monkeypatch.setenv("SBGPU_PHASES", spec)
         if lam is None:
             monkeypatch.delenv("SBGPU_PHASE_LAMBDA", raising=False)

@@ -9,9 +9,14 @@ print('phases %-18s lambda %-14s ms/step %.3f  kinds %s  phases_ms %s' % ('$1','
 }
 if [ $# -gt 0 ]; then run "$@"; exit; fi
 run 0 ""
-run 32,128,512 8,2,0.25
-run 32,128,512 4,1,0.1
-run 24,96,384 8,2,0.25
-run 48,256 4,0.25
-run 16,64,256 16,4,0.5
-run 32,128,512 16,4,0.5
+run 32 t
+run 32,128 t,t
+run 32,128,512 t,t,t
+run 16,64,256 t,t,t
+run 32,128,384 t,t,0.25
+run 32,128,512 t,t,0.25
+run 32,128,256 t,t,0.25
+run 64,256 t,0.25
+run 32,256 t,0.25
+run 32,128,256,512 t,t,t,0.25
+run 16,48,128,320 t,t,t,0.25
