@@ -26,6 +26,7 @@ namespace sb {
 
 constexpr int kMaxIter = 1000;          // include/estimate.hpp:237
 constexpr double kThetaLimit = 1e-2;    // include/estimate.hpp:241
+constexpr double kThetaLimitSq = 0x1.a36e2eb1c432bp-14; // 9.999999999999998e-05: sqrt(x) < 1e-2  <=>  x <= this
 constexpr double kRowEps = 1e-5;        // src/estimate.cpp:380
 
 constexpr int kMaxCPLv = 8;            // columns per lane of the widest register tile
@@ -332,7 +333,7 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
    constexpr bool BLOCK = NWAVES > 0;
    constexpr int NW = BLOCK ? NWAVES : 1;                  // waves per group
    constexpr int LB_CL = ilog2(CL);
-   constexpr int NV = BLOCK ? CPL + 1 : CPL; // values in the per-iteration column reduce (+ zero flag)
+   constexpr int NV = CPL; // values in the per-iteration column reduce
    const int lane = threadIdx.x & 63;
    const int wave_id = threadIdx.x >> 6;
    const int GW = BLOCK ? 64 : (1 << lbG);                 // lanes of the group inside one wave
@@ -565,7 +566,7 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
       // F is read-only in here and nothing touches memory.  Two iterations per
       // trip, theta ping-ponging between `theta` and `nt`, so that no copy or
       // select sits on the per-iteration path.
-      double nt[NV]; // [0, CPL): next_theta of the own columns; block form [CPL]: zero-denominator flag
+      double nt[NV]; // next_theta of the own columns
       bool dz, conv, special;
       // one EM iteration: reads tin, writes tout (all lanes, no predication)
       auto iterate = [&](const double *tin, double *tout) {
@@ -575,7 +576,11 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
          double phi[CPL]; // theta of the column-normalised problem seen through the raw F
 #pragma unroll
          for (int jj = 0; jj < CPL; ++jj) phi[jj] = tin[jj] * scale[jj];
-         int zero_flag = 0;
+         // A zero denominator of a kept row (:451) is not tested row by row: 1 / 0 is infinite, the Newton steps turn
+         // it into a NaN, the row's weight n * NaN is a NaN whatever n is, NaN * F poisons every column sum of the
+         // lane -- and the same row denominator is seen by all column lanes -- so every next_theta of the group and
+         // with them ||next - theta||^2 come out as NaN, which is tested once per iteration below.  Nothing else
+         // makes a NaN here: denominators are sums of products of non-negative finite numbers.
          // rows in blocks of 4 to bound the live temporaries
 #pragma unroll
          for (int rb = 0; rb < R; rb += 4) {
@@ -594,7 +599,6 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
             for (int q = 0; q < 4; ++q) {
                if (rb + q < R) {
                   const int r = rb + q;
-                  zero_flag |= (act[r] && d[q] == 0.0) ? 1 : 0; // :451
                   double w = fast_div(nn[r], d[q]);
                   w = act[r] ? w : 0.0;
 #pragma unroll
@@ -602,16 +606,7 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
                }
             }
          }
-         if (BLOCK) {
-            acc[NV - 1] = (double)zero_flag;
-            row_lane_sum(acc, std::integral_constant<int, NV>());
-            dz = acc[NV - 1] != 0.0;
-         } else {
-            row_lane_sum(acc, std::integral_constant<int, NV>());
-            // any zero denominator in the group: one ballot instead of a reduced value
-            const unsigned long long m = __ballot(zero_flag != 0);
-            dz = (m & group_mask) != 0ull;
-         }
+         row_lane_sum(acc, std::integral_constant<int, NV>());
          double p2 = 0.0;
 #pragma unroll
          for (int jj = 0; jj < CPL; ++jj) {
@@ -621,9 +616,11 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
             tout[jj] = t;
          }
          const double d2 = low_bits_sum<LB_CL>(p2);
-         // ||next - theta||_2 < 1e-2 (:479-480) tested on the squares: sqrt is monotone, so
-         // the two tests can only differ for d2 within an ulp of 1e-4
-         conv = d2 < kThetaLimit * kThetaLimit;
+         // ||next - theta||_2 < 1e-2 (:479-480) tested on the square: kThetaLimitSq is the largest double whose
+         // (correctly rounded) square root is below 1e-2, so this is the same predicate as sqrt(d2) < 1e-2 of the
+         // reference, the oracle and the streaming / wide kernels, for every d2
+         conv = d2 <= kThetaLimitSq;
+         dz = __builtin_isnan(d2); // some kept row had a zero denominator (:451), see above
          special = have && (dz || conv || it == 0 || it + 1 == cls.it_limit);
       };
       for (;;) {
