@@ -1,20 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- EM-to-convergence throughput of the per-locus EM hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c2u]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c2u] [--scaling weak|strong]
 
 A step = one pass of the hot path over one batch of synthetic loci that is already
 resident in HBM: EM (init + run to convergence) for every locus, the FPKM/Frac
 epilogue, the TPM all-reduce (N > 1) and the TPM kernel.  N > 1 is launched by
-torchrun (one rank per GPU, RCCL); every rank holds its OWN full-size batch (weak
-scaling, seed + rank) and `value` is the loci all ranks processed per second.
+torchrun (one rank per GPU, RCCL).  Two measurements, both in the line:
+  weak_scaling    every rank holds its OWN full-size batch (seed + rank); value = the loci
+                  all ranks processed per second (the headline `value` by default);
+  strong_scaling  BASELINE config 3, "loci sharded 1 -> 2 -> 4 -> 8": ONE batch, its loci
+                  dealt to the ranks by dist.shard_loci, one all-reduce per step; value =
+                  that batch's loci per second (`--scaling strong` makes it the headline).
+At N = 1 the two are the same run.
 
 Prints ONE JSON line on rank 0.  Besides the driver's fields it carries
   roofline     the dominant kernel against the HBM roofline (algorithmic bytes /
                kernel time) and, because the loop runs on-chip, the
                FP64-VALU view of the same kernel,
   cpu_baseline the reference's EmSolver (oracle/_ref, kind "reference") or the C
-               restatement (kind "port") on this box's host cores, bounded sample.
+               restatement (kind "port") on this box's host cores, bounded sample,
+  parity       the timed batch's GPU result against that CPU run (every locus); a mismatch fails the bench.
 """
 import argparse
 import json
@@ -74,10 +80,12 @@ def pmc_traffic(workload, kind):
                 os.path.basename(files[-1]), fetch_kb, write_kb))
 
 
-def cpu_baseline(batch, budget_s=12.0):
+def cpu_baseline(batch, gpu, budget_s=12.0):
     """Time the reference's EmSolver (or the port) on this box's host cores, on a
     bounded prefix of the same batch: one thread (the reference's deterministic mode)
-    and all cores with a static locus partition (the analogue of `-p T`)."""
+    and all cores with a static locus partition (the analogue of `-p T`).  The all-core
+    run solves the WHOLE batch, so it doubles as the parity check of what was just timed
+    on the GPU (`gpu` = its results): status and iteration counts exact, theta to 1e-9."""
     from oracle import OracleLib, RefLib, have_ref
     kind = "reference" if have_ref() else "port"
     lib = RefLib() if have_ref() else OracleLib()
@@ -86,16 +94,23 @@ def cpu_baseline(batch, budget_s=12.0):
     def run(n, threads):
         sub = batch if n >= batch.n_loci else batch.select(np.arange(n))
         t = time.perf_counter()
-        lib.em_batch(sub.row_off, sub.iso_off, sub.f_off, sub.count, sub.F, threads=threads)
-        return time.perf_counter() - t, sub
+        out = lib.em_batch(sub.row_off, sub.iso_off, sub.f_off, sub.count, sub.F, threads=threads)
+        return time.perf_counter() - t, sub, out
 
     # calibrate on 2000 loci, then size the single-thread sample for ~budget/2 seconds
-    dt, _ = run(min(2000, batch.n_loci), 1)
+    dt, _, _ = run(min(2000, batch.n_loci), 1)
     rate1 = min(2000, batch.n_loci) / max(dt, 1e-9)
     n1 = int(min(batch.n_loci, max(2000, rate1 * budget_s * 0.5)))
-    dt1, sub1 = run(n1, 1)
-    dtN, subN = run(batch.n_loci, cores)
-    return {
+    dt1, sub1, _ = run(n1, 1)
+    dtN, subN, cpu = run(batch.n_loci, cores)
+    if kind == "reference":
+        # EmSolver exposes two bools (init, run): MAXITER is not observable, both 0 and 3 read "ran"
+        theta, flags = cpu
+        status = np.where((flags & 1) == 0, 1, np.where((flags & 2) == 0, 2, 0)).astype(np.int32)
+        iters = None
+    else:
+        theta, status, iters = cpu
+    out = {
         "value": n1 / dt1, "unit": "loci/s", "cores": 1, "kind": kind,
         "sample": "first %d loci of the same batch, EmSolver init+run, 1 thread, %.2f s" % (n1, dt1),
         "mfrags_per_s": sub1.n_frags / dt1 / 1e6,
@@ -103,6 +118,42 @@ def cpu_baseline(batch, budget_s=12.0):
                       "sample": "whole batch (%d loci), static partition over %d threads, %.3f s" % (
                           batch.n_loci, cores, dtN)},
     }
+    # parity of the timed GPU result with this CPU run
+    g_st = np.where(gpu["status"] == 3, 0, gpu["status"]) if kind == "reference" else gpu["status"]
+    c_st = status
+    err = np.abs(gpu["theta"] - theta) / np.maximum(np.abs(theta), 1e-9)
+    parity = {"checked_loci": int(batch.n_loci), "against": kind, "status_mismatches": int((g_st != c_st).sum()),
+              "theta_max_rel_err": float(err.max()) if len(err) else 0.0, "tolerance": 1e-9}
+    if iters is not None:
+        parity["iteration_count_mismatches"] = int((gpu["iters"] != iters).sum())
+    parity["ok"] = bool(parity["status_mismatches"] == 0 and parity["theta_max_rel_err"] < 1e-9 and
+                        parity.get("iteration_count_mismatches", 0) == 0)
+    return out, parity
+
+
+def timed_steps(quant, steps, warmup, dev, sdist, torch):
+    """W untimed steps, then exactly K steps bracketed by barrier + synchronize on both sides; -> (wall seconds,
+    max over ranks; device milliseconds between two events on torch's stream)."""
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    for _ in range(warmup):
+        quant.step()
+    ev[0].record()   # first use of a timing event on this stream happens here, not inside the timed region
+    torch.cuda.synchronize(dev)
+    sdist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    ev[0].record()
+    for _ in range(steps):
+        quant.step()
+    ev[1].record()
+    torch.cuda.synchronize(dev)
+    sdist.barrier()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    quant.finish()   # raises if a run failed on the device
+    tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
+    sdist.allreduce_max_(tmax)
+    return float(tmax.item()), ev[0].elapsed_time(ev[1])
 
 
 def main():
@@ -111,6 +162,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank its own full batch (the headline line); strong: ONE batch, loci sharded "
+                         "over the ranks (BASELINE config 3) -- measured either way and reported under `strong_scaling`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -126,43 +180,43 @@ def main():
     local_rank = local_rank % torch.cuda.device_count()   # test rigs may run several ranks per GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-
-    batch = make_batch(args.workload, rank)
     ctx = em.Context(local_rank)
-    solver = em.EmBatchSolver(batch, ctx)
-    # pass-1 normaliser (alignments.cpp:1372): global mapped fragments, one all-reduce at set-up
-    tot = torch.tensor([batch.n_frags], dtype=torch.int64, device=dev)
-    sdist.allreduce_sum_(tot)
-    total_mapped = int(min(int(tot.item()), 2**31 - 1))   # the reference holds it in an int
-    quant = sdist.ShardQuantifier(solver, total_mapped, min_isoform_frac=0.0)  # quant-only (-r): keep all
+    # the per-step collective: torch.distributed (RCCL) by default, the C ABI's own RCCL binding with SB_COMM=abi
+    comm = sdist.AbiComm(ctx) if os.environ.get("SB_COMM") == "abi" and world > 1 else None
 
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    for _ in range(args.warmup):
-        quant.step()
-    ev[0].record()   # first use of a timing event on this stream happens here, not inside the timed region
-    torch.cuda.synchronize(dev)
-    sdist.barrier()
-    torch.cuda.synchronize(dev)
+    def make_quant(b):
+        solver = em.EmBatchSolver(b, ctx)
+        # pass-1 normaliser (alignments.cpp:1372): global mapped fragments, one all-reduce at set-up
+        tot = torch.tensor([b.n_frags], dtype=torch.int64, device=dev)
+        (comm.allreduce_sum_(tot) if comm is not None else sdist.allreduce_sum_(tot))
+        total_mapped = int(min(int(tot.item()), 2**31 - 1))   # the reference holds it in an int
+        return solver, sdist.ShardQuantifier(solver, total_mapped, min_isoform_frac=0.0, comm=comm)  # quant-only (-r): keep all
 
-    kern_ms = np.zeros(6)
-    t0 = time.perf_counter()
-    ev[0].record()
-    trace = [] if os.environ.get("SB_BENCH_TRACE") else None   # diagnostic: host time of every call
-    for _ in range(args.steps):
-        quant.step()
-        if trace is not None:
-            trace.append(time.perf_counter() - t0)
-    ev[1].record()
-    torch.cuda.synchronize(dev)
-    if trace is not None:
-        trace.append(time.perf_counter() - t0)
-    sdist.barrier()
-    torch.cuda.synchronize(dev)
-    wall = time.perf_counter() - t0
-    if trace is not None:
-        print("trace (ms since t0): " + " ".join("%.2f" % (x * 1e3) for x in trace) + " | end %.2f" % (wall * 1e3),
-              file=sys.stderr)
-    gpu_ms = ev[0].elapsed_time(ev[1])
+    # ---- weak scaling: every rank holds its OWN full-size batch
+    batch = make_batch(args.workload, rank)
+    solver, quant = make_quant(batch)
+    wall, gpu_ms = timed_steps(quant, args.steps, args.warmup, dev, sdist, torch)
+    counts = torch.tensor([batch.n_loci, batch.n_frags], dtype=torch.int64, device=dev)
+    sdist.allreduce_sum_(counts)
+    n_loci_all, n_frags_all = int(counts[0].item()), int(counts[1].item())
+    weak = {"value": n_loci_all * args.steps / wall, "ms_per_step": wall / args.steps * 1e3,
+            "mfrags_per_s": n_frags_all * args.steps / wall / 1e6, "loci": n_loci_all}
+
+    # ---- strong scaling (BASELINE config 3: "loci sharded 1 -> 2 -> 4 -> 8"): ONE batch, LPT shards, one all-reduce
+    if world > 1:
+        whole = make_batch(args.workload, 0)
+        shard = whole.select(sdist.shard_loci(whole.nrow, whole.niso, world)[rank])
+        _, squant = make_quant(shard)
+        swall, _ = timed_steps(squant, args.steps, args.warmup, dev, sdist, torch)
+        strong = {"value": whole.n_loci * args.steps / swall, "ms_per_step": swall / args.steps * 1e3,
+                  "mfrags_per_s": whole.n_frags * args.steps / swall / 1e6, "loci": whole.n_loci,
+                  "loci_this_rank": shard.n_loci}
+        del squant
+    else:
+        strong = dict(weak, loci_this_rank=batch.n_loci)   # one rank: the same run
+    strong["sharding"] = "one %d-locus batch, LPT shards by elements x predicted iterations (dist.shard_loci), " \
+                         "no locus data crosses ranks, 1 all-reduce (8 B) per step" % strong["loci"]
+
     # per-kind EM kernel time: HIP events on the streams the kernels run on, averaged over a few
     # extra (untimed) steps -- reading them synchronises, so it stays out of the timed region
     probe, phase_probe = [], []
@@ -175,18 +229,11 @@ def main():
     kern_ms = np.mean(np.array(probe), axis=0)
     phase_ms = [float(x) for x in np.mean(np.array(phase_probe), axis=0)] if phase_probe and phase_probe[0] else []
 
-    tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
-    sdist.allreduce_max_(tmax)
-    wall = float(tmax.item())
-    counts = torch.tensor([batch.n_loci, batch.n_frags], dtype=torch.int64, device=dev)
-    sdist.allreduce_sum_(counts)
-    n_loci_all, n_frags_all = int(counts[0].item()), int(counts[1].item())
-
     if rank != 0:
         return
     res = solver.results()
-    ms_per_step = wall / args.steps * 1e3
-    value = n_loci_all * args.steps / wall
+    head = strong if args.scaling == "strong" else weak
+    ms_per_step = head["ms_per_step"]
 
     # ---- roofline of the dominant EM kernel (this rank's batch)
     kinds = solver.plan.locus_kinds()
@@ -201,6 +248,7 @@ def main():
     dom_s = kern_ms[dom] * 1e-3
     ach_gbs = float(b_locus[sel].sum()) / dom_s / 1e9
     traffic, traffic_note = pmc_traffic(args.workload, dom)
+    weak_ms = weak["ms_per_step"]
     roofline = {
         "bound": "hbm", "kernel": kind_names[dom], "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
@@ -211,28 +259,36 @@ def main():
                       "unit": "TFLOP/s", "frac": float(fl_locus[sel].sum()) / dom_s / 1e12 / FP64_VALU_PEAK_TF,
                       "algorithmic_flops": int(fl_locus[sel].sum())},
         "all_kernels_ms": {kind_names[k]: float(kern_ms[k]) for k in range(6) if kern_ms[k] > 0},
-        "whole_batch": {"achieved": float(b_locus.sum()) / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
-                        "frac": float(b_locus.sum()) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        "whole_batch": {"achieved": float(b_locus.sum()) / (weak_ms * 1e-3) / 1e9, "unit": "GB/s",
+                        "frac": float(b_locus.sum()) / (weak_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
     }
 
     out = {
         "metric": "loci/s, EM-to-convergence (+ FPKM/TPM epilogue), %s" % args.workload.upper(),
-        "value": value, "unit": "loci/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": head["value"], "unit": "loci/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "mfrags_per_s": n_frags_all * args.steps / wall / 1e6,
-        "config": {"workload": WORKLOADS[args.workload], "loci_per_gpu": batch.n_loci,
-                   "fragments_per_gpu": batch.n_frags, "sharding": "independent loci per rank, 1 all-reduce (8 B) per step",
+        "mfrags_per_s": head["mfrags_per_s"],
+        "config": {"workload": WORKLOADS[args.workload], "loci_per_gpu": batch.n_loci if args.scaling == "weak" else strong["loci_this_rank"],
+                   "fragments_per_gpu": batch.n_frags,
+                   "sharding": "independent loci per rank (own batch each), 1 all-reduce (8 B) per step" if args.scaling == "weak" else strong["sharding"],
+                   "collective": "C ABI (sbgpu_allreduce_sum_f64, RCCL)" if comm is not None else "torch.distributed (RCCL)",
                    "size_classes": solver.plan.info()["n_classes"]},
         "em_status": {"ok": int((res["status"] == 0).sum()), "init_empty": int((res["status"] == 1).sum()),
                       "denom_zero": int((res["status"] == 2).sum()), "maxiter": int((res["status"] == 3).sum()),
                       "mean_iters": float(res["iters"].mean())},
         "gpu_event_ms_per_step": gpu_ms / args.steps,
         "wave_phase_ms": phase_ms,
+        "weak_scaling": weak,
+        "strong_scaling": strong,
         "roofline": roofline,
     }
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(batch)
+        out["cpu_baseline"], out["parity"] = cpu_baseline(batch, res)
+        if not out["parity"]["ok"]:
+            print(json.dumps(out))
+            raise SystemExit("bench.py: the GPU result of the timed batch does not match the CPU %s: %r" % (
+                out["parity"]["against"], out["parity"]))
     print(json.dumps(out))
 
 

@@ -6,9 +6,13 @@
 //
 //   g++ -std=c++14 -O2 -Iinclude examples/quantify_fragments.cpp -Lstrawberry_amd/lib -lsbgpu
 //       -Wl,-rpath,$PWD/strawberry_amd/lib -o quantify_fragments
-//   ./quantify_fragments input.txt out.gtf ctx.tsv [genome.fa]
+//   ./quantify_fragments input.txt out.gtf ctx.tsv [genome.fa] [--rank R --world W --comm-id FILE]
 //         (genome.fa: the reference's `-b` option -- six sequence columns per bin in the -f table,
 //          src/alignments.cpp:1622-1636)
+//   Several GPUs: one process per GPU, rank R of W on GPU R; locus l belongs to rank l mod W.  Every rank reads
+//   the whole input, keeps its loci and their pairs, and writes out.gtf / ctx.tsv with the suffix ".rank<R>";
+//   the two sums over all loci -- mapped reads before the EM, FPKM after it (src/alignments.cpp:1372, :1821-1824)
+//   -- are all-reduced over RCCL (sbgpu::Comm; rank 0 leaves the RCCL id in FILE for the others).
 //
 // Input (plain text, whitespace separated):
 //   sample <name>  chrom <name>  strand <+|->  insert <mean> <sd>  read_len <n>  min_isoform_frac <x>  long_read <0|1>
@@ -60,10 +64,30 @@ void mate_features(const std::vector<std::pair<uint32_t, uint32_t>> &blocks, std
 
 int main(int argc, char **argv)
 {
-   if (argc != 4 && argc != 5) {
-      std::fprintf(stderr, "usage: %s input.txt out.gtf ctx.tsv [genome.fa]\n", argv[0]);
+   int rank = 0, world = 1;
+   std::string comm_id_file;
+   {
+      // trailing options; what is left are the positional arguments
+      int n = argc;
+      for (int i = 1; i + 1 < n;) {
+         const std::string a = argv[i];
+         if (a == "--rank" || a == "--world" || a == "--comm-id") {
+            if (a == "--rank") rank = std::atoi(argv[i + 1]);
+            else if (a == "--world") world = std::atoi(argv[i + 1]);
+            else comm_id_file = argv[i + 1];
+            for (int k = i; k + 2 < n; ++k) argv[k] = argv[k + 2];
+            n -= 2;
+         } else {
+            ++i;
+         }
+      }
+      argc = n;
+   }
+   if ((argc != 4 && argc != 5) || world < 1 || rank < 0 || rank >= world) {
+      std::fprintf(stderr, "usage: %s input.txt out.gtf ctx.tsv [genome.fa] [--rank R --world W --comm-id FILE]\n", argv[0]);
       return 2;
    }
+   const std::string part = world > 1 ? ".rank" + std::to_string(rank) : std::string();
    std::ifstream in(argv[1]);
    std::string tok, sample, chrom, strand;
    double ins_mean = 0, ins_sd = 0, min_frac = 0;
@@ -120,6 +144,7 @@ int main(int argc, char **argv)
    std::vector<uint8_t> lc, rc;
    std::vector<uint32_t> ll, lr, rl, rr;
    for (const Pair &p : pairs) {
+      if (p.locus % world != rank) continue; // another rank's locus
       p_locus.push_back(p.locus);
       p_mass.push_back(p.mass);
       mate_features(p.left, lc, ll, lr);
@@ -127,7 +152,7 @@ int main(int argc, char **argv)
       lo.push_back((int64_t)lc.size());
       ro.push_back((int64_t)rc.size());
    }
-   const sbgpu_pairs_t raw = {(int64_t)pairs.size(), p_locus.data(), p_mass.data(), lo.data(), lc.data(), ll.data(), lr.data(),
+   const sbgpu_pairs_t raw = {(int64_t)p_locus.size(), p_locus.data(), p_mass.data(), lo.data(), lc.data(), ll.data(), lr.data(),
                               ro.data(), rc.data(), rl.data(), rr.data()};
    int total_mapped = 0;
    try {
@@ -138,21 +163,29 @@ int main(int argc, char **argv)
    }
 
    try {
-      sbgpu::Context ctx(0);
+      sbgpu::Context ctx(rank % std::max(1, sbgpu_device_count()));
+      sbgpu::Comm comm(ctx, rank, world, comm_id_file);
+      // Sample::_total_mapped_reads counts the whole sample (src/alignments.cpp:1372): sum over the ranks
+      total_mapped = (int)comm.allreduce_sum((int64_t)total_mapped);
       sbgpu::InsertSize ins(ins_mean, ins_sd); // `insert 0 0`: no -i, build the empirical distribution
       sbgpu_abundance_params_t par = {};
       par.total_mapped_reads = total_mapped;
       par.filter_by_expression = 1;
       par.min_isoform_frac = min_frac;
       batch.quantify(ctx, (ins_mean != 0 && ins_sd != 0) ? &ins : nullptr, read_len, par, long_read != 0); // Strawberry.cpp:339-356
-      sbgpu::finalize_tpm(batch.isoforms, sbgpu::sum_fpkm(batch.isoforms));
+      // loci of other ranks hold no hits here: they are not this rank's to report
+      for (int64_t l = 0; l < L; ++l)
+         if (l % world != rank)
+            for (int64_t j = batch.iso_off[(size_t)l]; j < batch.iso_off[(size_t)l + 1]; ++j) batch.isoforms[(size_t)j].kept = false;
+      // the FPKM total runs over every isoform of the sample (src/alignments.cpp:1821-1824): sum over the ranks
+      sbgpu::finalize_tpm(batch.isoforms, comm.allreduce_sum(sbgpu::sum_fpkm(batch.isoforms)));
    } catch (const std::exception &e) {
       std::fprintf(stderr, "error: %s\n", e.what());
       return 1;
    }
 
    // ---- GTF: Contig::print2gtf for every kept isoform, locus by locus (src/alignments.cpp:1831-1834)
-   std::ofstream gtf(argv[2]);
+   std::ofstream gtf(std::string(argv[2]) + part);
    std::vector<char> buf(1 << 20);
    for (int64_t l = 0; l < L; ++l) {
       for (size_t j = 0; j < tx_id[(size_t)l].size(); ++j) {
@@ -172,7 +205,7 @@ int main(int argc, char **argv)
       }
    }
    // ---- the -f table: Sample::printContext (src/alignments.cpp:1549-1639)
-   std::ofstream ctxf(argv[3]);
+   std::ofstream ctxf(std::string(argv[3]) + part);
    ctxf << "sample\tsample_frag_count\tgene_id\tgene_frag_count\ttranscripts\tFPKMs\tconditional_probabilities\t"
            "class_probabilities\tpath_symbol\tpath_count\tpath_gc_content\tpath_hexmer_entropy\tgc_stretch_0.8_20\t"
            "gc_stretch_0.9_20\tgc_stretch_0.8_40\tgc_stretch_0.9_40\n";
@@ -214,7 +247,7 @@ int main(int argc, char **argv)
             genome += line;
       }
       try {
-         sbgpu::Context ctx(0);
+         sbgpu::Context ctx(rank % std::max(1, sbgpu_device_count()));
          sbgpu::BinSequenceStats st = sbgpu::bin_sequence_stats(ctx, batch, genome);
          bin_gc.swap(st.gc);
          bin_entropy.swap(st.entropy);

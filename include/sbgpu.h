@@ -50,6 +50,7 @@ extern "C" {
 #define SBGPU_ENOMEM (-4)   /* host or device allocation failed                   */
 #define SBGPU_ESHAPE (-5)   /* a locus exceeds the supported shape (niso > 512)   */
 #define SBGPU_EUNSUPPORTED (-6) /* the device form does not cover this input: use the host form (see the call) */
+#define SBGPU_ERCCL (-7)    /* RCCL could not be loaded or one of its calls failed    */
 
 /* ---- per-locus status: the reference's two bools, src/estimate.cpp:305-308 - */
 #define SBGPU_EM_OK 0          /* init()==true,  run()==true, converged (estimate.cpp:480 break) */
@@ -188,6 +189,32 @@ int sbgpu_abundance_device(sbgpu_ctx_t *ctx, const sbgpu_plan_t *plan,
 int sbgpu_tpm_device(sbgpu_ctx_t *ctx, int64_t n_iso, const double *d_fpkm,
                      const int32_t *d_keep, const double *d_total_fpkm,
                      double *d_tpm, void *stream);
+
+/* ---- the collective: loci sharded over one process per GPU -------------------------------
+ * Replaces the two cross-locus sums of the reference -- `_total_mapped_reads +=`
+ * (src/alignments.cpp:1372, an atomic<int> the locus threads add to) and the FPKM total
+ * of Sample::procSample (src/alignments.cpp:1821-1824) -- by all-reduce(sum) over the
+ * ranks: RCCL over xGMI, a few bytes, once before and once after the EM.  No locus data
+ * ever crosses ranks.  Bootstrapping is the caller's (no MPI in the library): rank 0
+ * makes an id with sbgpu_comm_unique_id and hands its 128 bytes to the other ranks by
+ * whatever channel the driver has (a file, a socket, argv); every rank then calls
+ * sbgpu_comm_init(ctx, rank, world, id) -- a collective call -- on the GPU of its ctx.
+ * world == 1 needs no id (NULL) and no RCCL: its all-reduce is the identity.
+ * The all-reduces are in place, on device buffers, asynchronous on `stream`.             */
+#define SBGPU_COMM_ID_BYTES 128
+typedef struct sbgpu_comm sbgpu_comm_t;
+int sbgpu_comm_unique_id(uint8_t id_out[SBGPU_COMM_ID_BYTES]);
+int sbgpu_comm_init(sbgpu_ctx_t *ctx, int rank, int world, const uint8_t id[SBGPU_COMM_ID_BYTES],
+                    sbgpu_comm_t **comm_out);
+int sbgpu_comm_info(const sbgpu_comm_t *comm, int *rank, int *world);
+int sbgpu_comm_destroy(sbgpu_comm_t *comm);
+int sbgpu_allreduce_sum_f64(sbgpu_comm_t *comm, double *d_buf, int64_t n, void *stream);
+int sbgpu_allreduce_sum_i64(sbgpu_comm_t *comm, int64_t *d_buf, int64_t n, void *stream);
+/* The same for HOST buffers of up to 512 values (what a driver that keeps its totals on the
+ * host calls: `_total_mapped_reads`, the FPKM total): staged through device memory on the
+ * context's stream; returns when the result is in `buf`.                                 */
+int sbgpu_allreduce_sum_f64_host(sbgpu_comm_t *comm, double *buf, int64_t n);
+int sbgpu_allreduce_sum_i64_host(sbgpu_comm_t *comm, int64_t *buf, int64_t n);
 
 /* ---- bin-weight model: what fills F ----------------------------
  * Replaces LocusContext::set_theory_bin_weight, src/estimate.cpp:201-234, with

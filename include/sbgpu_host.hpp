@@ -20,6 +20,8 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <ctime>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -376,6 +378,58 @@ public:
                if (isoforms[(size_t)j].frac < par.min_isoform_frac) isoforms[(size_t)j].kept = false;
       }
    }
+};
+
+/* The collective of a multi-GPU run (one process per GPU, loci sharded over the ranks): the two cross-locus
+ * sums of the reference, `_total_mapped_reads` (src/alignments.cpp:1372) and the FPKM total (:1821-1824).
+ * Rank 0 makes the RCCL id and leaves it in `id_file` (written under a temporary name and renamed, so a reader
+ * never sees half of it); the other ranks wait for the file.  world == 1 needs no file and no RCCL.         */
+class Comm {
+ public:
+   Comm(const Context &ctx, int rank, int world, const std::string &id_file = std::string()) : h_(nullptr)
+   {
+      uint8_t id[SBGPU_COMM_ID_BYTES] = {0};
+      if (world > 1) {
+         if (id_file.empty()) throw Error(SBGPU_EINVAL, "sbgpu::Comm: a world of several ranks needs an id file");
+         if (rank == 0) {
+            check(sbgpu_comm_unique_id(id), "sbgpu_comm_unique_id");
+            const std::string tmp = id_file + ".tmp";
+            FILE *f = std::fopen(tmp.c_str(), "wb");
+            if (!f || std::fwrite(id, 1, sizeof(id), f) != sizeof(id) || std::fclose(f) != 0 || std::rename(tmp.c_str(), id_file.c_str()) != 0)
+               throw Error(SBGPU_EINVAL, "sbgpu::Comm: cannot write " + id_file);
+         } else {
+            for (int tries = 0;; ++tries) {
+               FILE *f = std::fopen(id_file.c_str(), "rb");
+               if (f) {
+                  const size_t n = std::fread(id, 1, sizeof(id), f);
+                  std::fclose(f);
+                  if (n == sizeof(id)) break;
+               }
+               if (tries > 6000) throw Error(SBGPU_ERCCL, "sbgpu::Comm: no id in " + id_file + " after 60 s");
+               struct timespec ts = {0, 10 * 1000 * 1000};
+               nanosleep(&ts, nullptr);
+            }
+         }
+      }
+      check(sbgpu_comm_init(ctx.get(), rank, world, world > 1 ? id : nullptr, &h_), "sbgpu_comm_init");
+   }
+   ~Comm() { sbgpu_comm_destroy(h_); }
+   Comm(const Comm &) = delete;
+   Comm &operator=(const Comm &) = delete;
+   double allreduce_sum(double x) const
+   {
+      check(sbgpu_allreduce_sum_f64_host(h_, &x, 1), "sbgpu_allreduce_sum_f64_host");
+      return x;
+   }
+   int64_t allreduce_sum(int64_t x) const
+   {
+      check(sbgpu_allreduce_sum_i64_host(h_, &x, 1), "sbgpu_allreduce_sum_i64_host");
+      return x;
+   }
+   sbgpu_comm_t *get() const { return h_; }
+
+ private:
+   sbgpu_comm_t *h_;
 };
 
 /* Sample::procSample's tail (src/alignments.cpp:1821-1829) over every isoform that is written.

@@ -10,7 +10,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SBGPU_LIB") or os.path.join(HERE, "lib", "libsbgpu.so")  # SBGPU_LIB: A/B builds
 
 SBGPU_OK = 0
+SBGPU_EINVAL = -1
 SBGPU_EUNSUPPORTED = -6
+SBGPU_ERCCL = -7
+EM_UNSOLVED = -1
 EM_OK, EM_INIT_EMPTY, EM_DENOM_ZERO, EM_MAXITER = 0, 1, 2, 3
 STATUS_NAMES = {0: "OK", 1: "INIT_EMPTY", 2: "DENOM_ZERO", 3: "MAXITER"}
 
@@ -20,6 +23,8 @@ SYMBOLS = [
     "sbgpu_device_info", "sbgpu_synchronize", "sbgpu_plan_create", "sbgpu_plan_destroy", "sbgpu_plan_info",
     "sbgpu_plan_classes", "sbgpu_plan_locus_kinds", "sbgpu_em_run_device", "sbgpu_em_last_kernel_ms",
     "sbgpu_set_timing", "sbgpu_em_last_phase_ms",
+    "sbgpu_comm_unique_id", "sbgpu_comm_init", "sbgpu_comm_info", "sbgpu_comm_destroy",
+    "sbgpu_allreduce_sum_f64", "sbgpu_allreduce_sum_i64", "sbgpu_allreduce_sum_f64_host", "sbgpu_allreduce_sum_i64_host",
     "sbgpu_insert_pdf_table", "sbgpu_binweight_device", "sbgpu_binweight_host",
     "sbgpu_exonbin_device", "sbgpu_exonbin_host", "sbgpu_segments_host", "sbgpu_hit_features", "sbgpu_frag_lens_host",
     "sbgpu_bins_create", "sbgpu_bins_create_device", "sbgpu_bins_destroy", "sbgpu_quantify_host",
@@ -140,6 +145,14 @@ def load():
     L.sbgpu_plan_locus_kinds.argtypes = [vp, vp]
     L.sbgpu_em_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.sbgpu_set_timing.argtypes = [vp, C.c_int]
+    L.sbgpu_comm_unique_id.argtypes = [vp]
+    L.sbgpu_comm_init.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
+    L.sbgpu_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.sbgpu_comm_destroy.argtypes = [vp]
+    L.sbgpu_allreduce_sum_f64.argtypes = [vp, vp, C.c_int64, vp]
+    L.sbgpu_allreduce_sum_i64.argtypes = [vp, vp, C.c_int64, vp]
+    L.sbgpu_allreduce_sum_f64_host.argtypes = [vp, vp, C.c_int64]
+    L.sbgpu_allreduce_sum_i64_host.argtypes = [vp, vp, C.c_int64]
     L.sbgpu_em_last_phase_ms.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
     L.sbgpu_em_run_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.sbgpu_em_batch.argtypes = [vp, C.POINTER(sbgpu_batch_t), vp, vp, vp]

@@ -100,6 +100,64 @@ def barrier():
         dist.barrier()
 
 
+class AbiComm:
+    """The collective behind the C ABI (include/sbgpu.h: sbgpu_comm_*, sbgpu_allreduce_sum_*): RCCL without
+    torch.distributed in the data path -- what a C++14 Strawberry driver uses.  Rank 0's id reaches the other ranks
+    through `broadcast_id` (a callable bytes -> bytes; default: torch.distributed's object broadcast when a
+    process group exists)."""
+
+    def __init__(self, ctx, rank=None, world=None, broadcast_id=None):
+        import ctypes as C
+        from . import _lib
+        self.ctx, self.L = ctx, _lib.load()
+        r, w, _ = env_world()
+        self.rank = r if rank is None else rank
+        self.world = w if world is None else world
+        ident = None
+        if self.world > 1:
+            buf = (C.c_uint8 * 128)()
+            if self.rank == 0:
+                _lib.check(self.L.sbgpu_comm_unique_id(buf), "sbgpu_comm_unique_id")
+            raw = bytes(buf)
+            if broadcast_id is None:
+                import torch.distributed as dist
+                box = [raw]
+                dist.broadcast_object_list(box, src=0)
+                raw = box[0]
+            else:
+                raw = broadcast_id(raw)
+            ident = (C.c_uint8 * 128).from_buffer_copy(raw)
+        h = C.c_void_p()
+        _lib.check(self.L.sbgpu_comm_init(ctx.h, self.rank, self.world, ident, C.byref(h)), "sbgpu_comm_init")
+        self.h = h
+
+    def allreduce_sum_(self, tensor):
+        """In place, on the tensor's device buffer, asynchronous on torch's current stream."""
+        import ctypes as C
+        import torch
+        from . import _lib
+        stream = C.c_void_p(torch.cuda.current_stream(tensor.device).cuda_stream)
+        if tensor.dtype == torch.float64:
+            fn, name = self.L.sbgpu_allreduce_sum_f64, "sbgpu_allreduce_sum_f64"
+        elif tensor.dtype == torch.int64:
+            fn, name = self.L.sbgpu_allreduce_sum_i64, "sbgpu_allreduce_sum_i64"
+        else:
+            raise TypeError("AbiComm reduces float64 or int64 buffers")
+        _lib.check(fn(self.h, tensor.data_ptr(), tensor.numel(), stream), name)
+        return tensor
+
+    def close(self):
+        if self.h:
+            self.L.sbgpu_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ShardQuantifier:
     """A rank's share of the quantification: EM -> FPKM/Frac -> all-reduce -> TPM.
 
@@ -108,8 +166,10 @@ class ShardQuantifier:
     caller (it precedes the EM: src/estimate.cpp:328)."""
 
     def __init__(self, solver, total_mapped_reads, min_isoform_frac=0.01, effective_len_norm=False,
-                 insert_mean=0.0, filter_by_expression=True):
+                 insert_mean=0.0, filter_by_expression=True, comm=None):
+        """comm: an AbiComm (the C-ABI collective); None: torch.distributed's default group."""
         self.s = solver
+        self.comm = comm
         self.kw = dict(total_mapped_reads=int(total_mapped_reads), min_isoform_frac=min_isoform_frac,
                        effective_len_norm=effective_len_norm, insert_mean=insert_mean,
                        filter_by_expression=filter_by_expression)
@@ -118,7 +178,11 @@ class ShardQuantifier:
         s = self.s
         s.run_em()
         s.run_abundance(**self.kw)          # leaves this rank's sum of kept FPKM in d_sum_fpkm
-        allreduce_sum_(s.d_sum_fpkm)        # the one collective: 8 bytes over xGMI
+        # the one collective: 8 bytes over xGMI
+        if self.comm is not None:
+            self.comm.allreduce_sum_(s.d_sum_fpkm)
+        else:
+            allreduce_sum_(s.d_sum_fpkm)
         s.run_tpm(s.d_sum_fpkm)
 
     def finish(self):

@@ -21,7 +21,7 @@ def lib():
 def test_exports_every_declared_symbol(lib):
     from strawberry_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "sbgpu.h")).read()
-    declared = set(re.findall(r"\b(sbgpu_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(sbgpu_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name

@@ -1,0 +1,93 @@
+"""GPU tests of the N > 1 path through the HIP kernels: two ranks (two processes) sharing the one GPU of the
+test box, each solving ITS shard of a C3 slice with ShardQuantifier.step -- EM, epilogue, the all-reduce, TPM --
+against the single-rank HIP result; and the C-ABI collective (sbgpu_comm_*) at world size 1.  RCCL refuses two
+ranks on one device, so the two-rank test reduces through gloo (dist._allreduce_'s host-copy path); the RCCL
+calls themselves run in the driver's multi-GPU bench (`SB_COMM=abi`) and in examples/quantify_fragments.cpp."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    import numpy as np
+    import torch
+    sys.path.insert(0, %(root)r)
+    from strawberry_amd import dist, em, synth
+    rank, world, _ = dist.init_process_group("gloo")
+    torch.cuda.set_device(0)
+    b = synth.make_c3(n_loci=4000, total_frags=2e6, seed=78)
+    parts = dist.shard_loci(b.nrow, b.niso, world)
+    mine = b.select(parts[rank])
+    ctx = em.Context(0)
+    solver = em.EmBatchSolver(mine, ctx)
+    tot = torch.tensor([mine.n_frags], dtype=torch.int64, device="cuda:0")
+    dist.allreduce_sum_(tot)                 # pass-1 normaliser (alignments.cpp:1372)
+    q = dist.ShardQuantifier(solver, int(tot.item()), min_isoform_frac=0.0)
+    q.step()
+    q.step()
+    q.finish()
+    r = solver.results()
+    np.savez(os.path.join(%(out)r, "rank%%d.npz" %% rank), idx=parts[rank], iso_off=mine.iso_off, tpm=r["tpm"],
+             fpkm=r["fpkm"], status=r["status"], iters=r["iters"], total_mapped=int(tot.item()))
+    dist.barrier()
+""")
+
+
+def test_two_ranks_on_one_gpu_equal_single_rank(tmp_path):
+    from strawberry_amd import em, synth
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT, "out": str(tmp_path)})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", SB_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29641", str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    b = synth.make_c3(n_loci=4000, total_frags=2e6, seed=78)
+    s = em.EmBatchSolver(b, em.default_context(0))
+    s.run_em()
+    s.run_abundance(total_mapped_reads=b.n_frags, min_isoform_frac=0.0)
+    s.run_tpm()
+    ref = s.results()
+    got_tpm = np.full(len(ref["tpm"]), np.nan)
+    got_it = np.full(b.n_loci, -1)
+    for rank in range(2):
+        z = np.load(tmp_path / ("rank%d.npz" % rank))
+        assert int(z["total_mapped"]) == b.n_frags
+        for pos, l in enumerate(z["idx"]):
+            n = b.iso_off[l + 1] - b.iso_off[l]
+            got_tpm[b.iso_off[l]:b.iso_off[l + 1]] = z["tpm"][z["iso_off"][pos]:z["iso_off"][pos] + n]
+            got_it[l] = z["iters"][pos]
+    assert not np.isnan(got_tpm).any()
+    np.testing.assert_array_equal(got_it, ref["iters"])
+    # the shard changes which loci share a wave, never a locus' arithmetic; the FPKM total is summed in another order
+    np.testing.assert_allclose(got_tpm, ref["tpm"], rtol=1e-12, atol=0)
+
+
+def test_abi_comm_world_of_one_and_bad_arguments():
+    import ctypes as C
+    import torch
+    from strawberry_amd import _lib, dist, em
+    ctx = em.default_context(0)
+    comm = dist.AbiComm(ctx, rank=0, world=1)
+    x = torch.tensor([1.5, 2.5], dtype=torch.float64, device="cuda:0")
+    n = torch.tensor([7], dtype=torch.int64, device="cuda:0")
+    comm.allreduce_sum_(x)
+    comm.allreduce_sum_(n)
+    torch.cuda.synchronize()
+    assert x.tolist() == [1.5, 2.5] and n.item() == 7      # the sum over one rank
+    L = _lib.load()
+    rank, world = C.c_int(-1), C.c_int(-1)
+    assert L.sbgpu_comm_info(comm.h, C.byref(rank), C.byref(world)) == 0 and (rank.value, world.value) == (0, 1)
+    h = C.c_void_p()
+    assert L.sbgpu_comm_init(ctx.h, 2, 2, None, C.byref(h)) == _lib.SBGPU_EINVAL      # rank out of range
+    assert L.sbgpu_comm_init(ctx.h, 0, 2, None, C.byref(h)) == _lib.SBGPU_EINVAL      # world > 1 without an id
+    buf = (C.c_uint8 * 128)()
+    assert L.sbgpu_comm_unique_id(buf) == 0 and any(buf)
+    comm.close()
