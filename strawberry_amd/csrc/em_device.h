@@ -53,12 +53,11 @@ struct ClassDesc {
    int32_t shape;       // layout | rmult << 8 | lbG << 16
 };
 
-// One size class: the loci it holds (ordered by decreasing work) and the
-// dynamic-pull cursor.
+// One size class as a workgroup sees it: the loci it holds (likeliest stragglers first) and the batch of them
+// this workgroup serves.
 struct ClassArgs {
    const int32_t *loci;
    int32_t n;
-   int32_t *cursor;
    // phased execution: a locus still running after `it_limit` iterations is suspended (theta and the
    // iteration count are its whole state) and appended to the list of ITS class of the next phase
    // (`route[locus]`, an index into `next_table`): the next phase gives the survivors layouts with more
@@ -69,7 +68,7 @@ struct ClassArgs {
    const ClassDesc *next_table;
    int32_t it_limit;
    int32_t resume; // this phase's loci carry state from the previous one
-   int32_t batch;  // >= 0: the workgroup serves exactly this batch of the class (loci batch * per-wave ...), no cursor
+   int32_t batch;  // the workgroup serves exactly this batch of the class: loci [batch * k, batch * k + k), k = loci per workgroup
 };
 
 // ------------------------------------------------------------------ cross-lane
@@ -345,18 +344,7 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
    const int gc = HIMAP ? (lane & (CL - 1)) : ((BLOCK ? (int)threadIdx.x : (lane & (GW - 1))) & (CL - 1));
    const int gr = HIMAP ? (lane >> (6 - lbGR)) : ((BLOCK ? (int)threadIdx.x : (lane & (GW - 1))) >> LB_CL);
    const int g = gc | (gr << LB_CL);                       // index inside the group; 0 = its leader
-   const int leader_lane = HIMAP ? (grp << LB_CL) : (lane & ~(GW - 1));
-   // the lanes of this lane's group, for ballots
-   unsigned long long group_mask = ~0ull;
-   if (!BLOCK) {
-      if (HIMAP) {
-         group_mask = ((1ull << CL) - 1ull) << (grp << LB_CL);
-         for (int k = 6 - lbGR; k < 6; ++k) group_mask |= group_mask << (1 << k);
-      } else if (GW < 64) {
-         group_mask = ((1ull << GW) - 1ull) << (lane & ~(GW - 1));
-      }
-   }
-   bool batch_taken = false; // static-batch mode (cls.batch >= 0): the one refill has happened
+   bool batch_taken = false; // the one refill has happened
    int phase = 0;
    int r_used = R; // block form: rows per row lane the current locus needs (workgroup-uniform)
 #ifdef SB_STAMPS
@@ -445,24 +433,12 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
 #ifdef SB_STAMPS
          st_t = sb_now();
 #endif
-         int idx = 0;
-         if (cls.batch >= 0) {
-            // static assignment: this workgroup serves batch `cls.batch` of its class and nothing else
-            if (batch_taken) break;
-            batch_taken = true;
-            idx = BLOCK ? cls.batch : cls.batch * (64 >> lbGW) + grp;
-            if (BLOCK ? (idx >= cls.n) : !__any(idx < cls.n)) break;
-         } else if (BLOCK) {
-            if (threadIdx.x == 0) *s_idx = atomicAdd(cls.cursor, 1);
-            __syncthreads();
-            idx = *s_idx;
-            __syncthreads();
-            if (idx >= cls.n) break; // workgroup-uniform: the class list is dry
-         } else {
-            if (g == 0) idx = atomicAdd(cls.cursor, 1);
-            idx = __shfl(idx, leader_lane);
-            if (!__any(idx < cls.n)) break; // nothing left for any group of this wave
-         }
+         // static assignment: this workgroup serves batch `cls.batch` of its class and nothing else (no cursor to
+         // pull from, hence nothing to zero between runs)
+         if (batch_taken) break;
+         batch_taken = true;
+         const int idx = BLOCK ? cls.batch : cls.batch * (64 >> lbGW) + grp;
+         if (BLOCK ? (idx >= cls.n) : !__any(idx < cls.n)) break;
          const bool got = idx < cls.n;
          const int loc = got ? cls.loci[idx] : 0; // idle groups shadow locus 0, results discarded
          const int64_t r0 = a.row_off[loc];
@@ -749,8 +725,8 @@ struct PhaseArgs {
    int32_t n_classes;
    const int32_t *lists_in;      // class lists (table[c].loci_off)
    const int32_t *n_in;          // [class] loci in the list
-   int32_t *cursors;             // [class] dynamic-pull cursors (phase 0)
-   const int32_t *total_blocks;  // later phases: number of batches, computed on the device; nullptr: the grid
+   int32_t n_batches;            // phase 0: batches of this launch (the table's first-batch column is the host's)
+   const int32_t *total_blocks;  // later phases: number of batches, computed on the device; nullptr: n_batches
    int32_t *lists_out;           // next phase
    int32_t *n_out;
    const int32_t *route;
@@ -788,11 +764,10 @@ __global__ __launch_bounds__(NWAVES > 0 ? 64 * NWAVES : 64,
 #ifdef SB_STAMPS
    const unsigned long long st0 = sb_now();
 #endif
-   // Phase 0: one workgroup per batch, loci pulled through the class cursors.  A later phase that re-packs its
-   // survivors into the same layouts (ph.total_blocks set): batches b = blockIdx.x, + gridDim.x, ... of the table
-   // whose first-block column phase_prepare_kernel has written from the survivor counts.
-   const bool fixed_batches = ph.total_blocks != nullptr;
-   const int n_batches = fixed_batches ? *ph.total_blocks : (int)gridDim.x;
+   // A workgroup serves the batches b = blockIdx.x, + gridDim.x, ... of the table (normally exactly one: the grid
+   // is the number of batches).  Phase 0: the table's first-batch column comes from the host; a later phase that
+   // re-packs its survivors into the same layouts: phase_prepare_kernel has written it from the survivor counts.
+   const int n_batches = ph.total_blocks ? *ph.total_blocks : ph.n_batches;
    for (int b = (int)blockIdx.x; b < n_batches; b += (int)gridDim.x) {
    const int c = find_class(ph.table, ph.n_classes, b);
    const ClassDesc d = ph.table[c];
@@ -806,14 +781,13 @@ __global__ __launch_bounds__(NWAVES > 0 ? 64 * NWAVES : 64,
    ClassArgs cls;
    cls.loci = ph.lists_in + d.loci_off;
    cls.n = ph.n_in[c];
-   cls.cursor = ph.cursors + c;
    cls.out = ph.lists_out;
    cls.out_count = ph.n_out;
    cls.route = ph.route;
    cls.next_table = ph.next_table;
    cls.it_limit = ph.it_limit;
    cls.resume = ph.resume;
-   cls.batch = fixed_batches ? b - d.block_begin : -1;
+   cls.batch = b - d.block_begin;
    const int layout = d.shape & 0xFF;
    const int lbG = (d.shape >> 16) & 0xFF;
    // layout = (CPL - 1) + 8 * log2(CL): exact columns per lane (no padding to a power of two),
@@ -869,14 +843,13 @@ constexpr int lat_shape(int cpl, int lb_cl, int r) { return (cpl - 1) | (lb_cl <
 __global__ __launch_bounds__(64, SB_LAT_OCC) void em_lat_kernel(EmArgs a, PhaseArgs ph)
 {
    set_fp64_flush_denormals();
-   const int n_batches = ph.total_blocks ? *ph.total_blocks : (int)gridDim.x;
+   const int n_batches = ph.total_blocks ? *ph.total_blocks : ph.n_batches;
    for (int b = (int)blockIdx.x; b < n_batches; b += (int)gridDim.x) {
       const int c = find_class(ph.table, ph.n_classes, b);
       const ClassDesc d = ph.table[c];
       ClassArgs cls;
       cls.loci = ph.lists_in + d.loci_off;
       cls.n = ph.n_in[c];
-      cls.cursor = nullptr;
       cls.out = ph.lists_out;
       cls.out_count = ph.n_out;
       cls.route = ph.route;
@@ -997,21 +970,15 @@ __global__ __launch_bounds__(kStreamThreads) void em_stream_kernel(EmArgs a, Cla
    extern __shared__ double s_dyn[];
    __shared__ double s_part[kStreamThreads / 64];
    __shared__ int s_flag;
-   __shared__ int s_idx;
    const int tid = threadIdx.x;
    const int lane = tid & 63;
    const int wave = tid >> 6;
    constexpr int NWAVE = kStreamThreads / 64;
    set_fp64_flush_denormals();
 
-   for (;;) {
-      if (tid == 0) {
-         s_idx = atomicAdd(cls.cursor, 1);
-         s_flag = 0;
-      }
+   for (int idx = (int)blockIdx.x; idx < cls.n; idx += (int)gridDim.x) {
+      if (tid == 0) s_flag = 0;
       __syncthreads();
-      const int idx = s_idx;
-      if (idx >= cls.n) break;
       const int locus = cls.loci[idx];
       const int64_t r0 = a.row_off[locus];
       const int nrow = (int)(a.row_off[locus + 1] - r0);

@@ -350,13 +350,9 @@ int build_host_plan(int64_t n_loci, const int64_t *row_off, const int64_t *iso_o
       }
       waves_wanted += (int64_t)sc.n_blocks * (sc.block_threads / 64);
    }
-   if (waves_wanted > max_waves) {
-      const double f = (double)max_waves / (double)waves_wanted;
-      for (auto &kv : by_key) {
-         SizeClass &sc = kv.second;
-         sc.n_blocks = std::max(1, (int)(sc.n_blocks * f + 0.5));
-      }
-   }
+   // (a class's n_blocks stays its number of batches; when a kind wants more waves than `max_waves` the launch's
+   // grid is cut instead and its workgroups stride over the batches)
+   p.grid_scale = waves_wanted > max_waves ? (double)max_waves / (double)waves_wanted : 1.0;
    for (auto &kv : by_key) p.classes.push_back(std::move(kv.second));
    const bool by_pred = tune.classes_by_prediction;
    std::stable_sort(p.classes.begin(), p.classes.end(), [by_pred](const SizeClass &x, const SizeClass &y) {

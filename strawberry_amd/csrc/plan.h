@@ -60,6 +60,7 @@ struct HostPlan {
    int64_t n_stream_loci = 0;
    std::vector<SizeClass> classes; // phase 0; grouped by kind; inside a kind heaviest first
    int first_limit = 1000;         // iteration limit of phase 0 for the wave kind (1000: no later phases)
+   double grid_scale = 1.0;        // < 1: every launch's grid is this share of its batches (PlanTuning::max_waves)
    std::vector<LatPhase> lat;      // phases 1, 2, ...
 };
 

@@ -95,8 +95,8 @@ struct sbgpu_plan {
    int64_t *d_row_off = nullptr, *d_iso_off = nullptr, *d_f_off = nullptr;
    int32_t *d_loci_all = nullptr;      // all class lists, concatenated (input of phase 0)
    int32_t *d_class_n = nullptr;       // loci per class (input count of phase 0)
-   int32_t *d_cursors = nullptr;       // [class] dynamic-pull cursors of phase 0; zeroed every run together with
-   size_t zero_bytes = 0;              //   the later phases' survivor counts and batch totals behind them
+   char *d_zero = nullptr;             // the later phases' survivor counts and batch totals: zeroed before every run
+   size_t zero_bytes = 0;
    // later phases of the wave kind (plan.h: LatPhase): class table (first blocks filled on the device), survivor
    // counts, number of batches, survivor lists, and the route INTO the phase
    struct LatDev {
@@ -109,7 +109,8 @@ struct sbgpu_plan {
    sb::ClassDesc *d_tables = nullptr;  // one descriptor per class
    std::vector<int64_t> loci_off;      // per class: offset into d_loci_all
    uint8_t *d_row_keep = nullptr;      // streaming path: init() row flags
-   double *d_locus_sum = nullptr;      // abundance epilogue: kept-FPKM sum per locus
+   double *d_locus_sum = nullptr;      // abundance epilogue: kept-FPKM sum per workgroup of 256 loci
+   unsigned *d_epi_ticket = nullptr;   // abundance epilogue: finished workgroups (the last one sums; it leaves 0 behind)
    size_t stream_lds_bytes = 0;
    // wide loci (kStream class) served by the cooperative multi-workgroup kernel, in launches ("rounds")
    struct WideRound {
@@ -206,13 +207,19 @@ __device__ double abundance_locus(int64_t l, const int64_t *iso_off, const doubl
    return kept_sum;
 }
 
-__global__ void abundance_kernel(int64_t n_loci, const int64_t *iso_off, const double *theta,
-                                 const int32_t *status, const int32_t *length,
-                                 sbgpu_abundance_params_t p, double *fpkm, double *frac,
-                                 int32_t *keep, double *block_sum)
+// The workgroup that finishes LAST adds the per-workgroup sums (fixed strided order + fixed tree: deterministic,
+// whichever workgroup it is) and writes the total -- Sample::procSample's FPKM sum, alignments.cpp:1821-1824 --
+// so no second launch is needed.  Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility): the sums are
+// stored and loaded with agent-scope (sc1) accesses, the storing lane waits for its store before it takes its
+// ticket, and the workgroup whose ticket is the last one reads only after its add has returned.
+__global__ __launch_bounds__(256) void abundance_kernel(int64_t n_loci, const int64_t *iso_off, const double *theta,
+                                                        const int32_t *status, const int32_t *length,
+                                                        sbgpu_abundance_params_t p, double *fpkm, double *frac,
+                                                        int32_t *keep, double *block_sum, unsigned *ticket, double *total)
 {
    const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
    __shared__ double part[256];
+   __shared__ int s_last;
    part[threadIdx.x] = l < n_loci ? abundance_locus(l, iso_off, theta, status, length, p, fpkm, frac, keep) : 0.0;
    __syncthreads();
    // this workgroup's 256 loci summed in a fixed tree: the global sum is deterministic
@@ -220,7 +227,27 @@ __global__ void abundance_kernel(int64_t n_loci, const int64_t *iso_off, const d
       if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
       __syncthreads();
    }
-   if (threadIdx.x == 0) block_sum[blockIdx.x] = part[0];
+   if (threadIdx.x == 0) {
+      __hip_atomic_store(&block_sum[blockIdx.x], part[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = t == gridDim.x - 1;
+   }
+   __syncthreads();
+   if (!s_last) return;
+   double acc = 0.0;
+   for (unsigned i = threadIdx.x; i < gridDim.x; i += 256)
+      acc += __hip_atomic_load(&block_sum[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+   part[threadIdx.x] = acc;
+   __syncthreads();
+   for (int w = 128; w > 0; w >>= 1) {
+      if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+      __syncthreads();
+   }
+   if (threadIdx.x == 0) {
+      *total = part[0];
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch
+   }
 }
 
 // Deterministic sum of x[0..n) (the abundance kernel's per-workgroup sums) in one workgroup (fixed strided
@@ -515,8 +542,8 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
       o_lroute[i] = at; at += up((size_t)(n_loci + 1) * sizeof(int32_t));
    }
    const size_t staged = at;
-   // zeroed before every run: phase-0 cursors, then every later phase's survivor counts and batch total
-   const size_t o_cur = at; at += up(ncls_alloc * sizeof(int32_t));
+   // zeroed before every run: every later phase's survivor counts and batch total
+   const size_t o_cur = at;
    for (size_t i = 0; i < nlat; ++i) {
       o_lcnt[i] = at; at += up((p->host.lat[i].classes.size() + 1) * sizeof(int32_t));
       o_ltot[i] = at; at += up(sizeof(int32_t));
@@ -527,6 +554,7 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
    }
    const size_t o_keep = at; at += up((size_t)p->host.n_rows + 1);
    const size_t o_sum = at; at += up((size_t)(n_loci + 1) * sizeof(double));
+   const size_t o_tick = at; at += up(sizeof(unsigned));
    const size_t o_wbar = at; at += up((wide_table.size() + 1) * sizeof(unsigned));
    const size_t o_wbuf = at; at += up((wide_buf_doubles + 1) * sizeof(double));
    if ((e = hipMalloc(&p->d_arena, at)) != hipSuccess) return bail(e, "hipMalloc(plan arena)");
@@ -537,7 +565,7 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
    p->d_loci_all = (int32_t *)(p->d_arena + o_loci);
    p->d_tables = (sb::ClassDesc *)(p->d_arena + o_tab);
    p->d_class_n = (int32_t *)(p->d_arena + o_cn);
-   p->d_cursors = (int32_t *)(p->d_arena + o_cur);
+   p->d_zero = p->d_arena + o_cur;
    p->lat.resize(nlat);
    for (size_t i = 0; i < nlat; ++i) {
       sbgpu_plan::LatDev &ld = p->lat[i];
@@ -555,6 +583,7 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
    }
    p->d_row_keep = (uint8_t *)(p->d_arena + o_keep);
    p->d_locus_sum = (double *)(p->d_arena + o_sum);
+   p->d_epi_ticket = (unsigned *)(p->d_arena + o_tick);
    p->d_wide_table = (sb::WideDesc *)(p->d_arena + o_wtab);
    p->d_wide_barriers = (unsigned *)(p->d_arena + o_wbar);
    p->d_wide_bufs = (double *)(p->d_arena + o_wbuf);
@@ -612,6 +641,7 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
    }
    stage("staging");
    if ((e = hipMemcpy(p->d_arena, stage_buf.data(), staged, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(plan)");
+   if ((e = hipMemset(p->d_epi_ticket, 0, sizeof(unsigned))) != hipSuccess) return bail(e, "hipMemset(plan)");
    stage("upload");
    // streaming kernel LDS: (3 + NWAVE) * npad doubles, npad <= pow2ceil-padded niso
    size_t npad = 1;
@@ -669,11 +699,12 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
    a.theta = d_theta;
    a.status = d_status;
    a.iters = d_iters;
-   // phase-0 cursors and the later phases' survivor counts / batch totals sit next to each other: one memset
-   HIP_TRY(hipMemsetAsync(p->d_cursors, 0, p->zero_bytes, main));
-   // a locus the kernels never reach (a wide-locus barrier that timed out) must not look solved: status starts
-   // at -1 = SBGPU_EM_UNSOLVED (0xFF bytes)
-   HIP_TRY(hipMemsetAsync(d_status, 0xFF, (size_t)p->host.n_loci * sizeof(int32_t), main));
+   // Batches are dealt to the workgroups statically: nothing to reset between runs but the later phases' survivor
+   // counts (only when the plan has phases)
+   if (p->zero_bytes) HIP_TRY(hipMemsetAsync(p->d_zero, 0, p->zero_bytes, main));
+   // a locus the kernels never reach (a wide-locus barrier that timed out) must not look solved: with wide loci in
+   // the plan, status starts at -1 = SBGPU_EM_UNSOLVED (0xFF bytes); every other kernel writes all its loci
+   if (p->n_wide_desc) HIP_TRY(hipMemsetAsync(d_status, 0xFF, (size_t)p->host.n_loci * sizeof(int32_t), main));
    // one launch per kind (wave / block / stream); a single kind runs on the
    // caller's stream, several fork onto the aux streams and join back
    int kinds = 0;
@@ -764,8 +795,7 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
             sb::ClassArgs ca = {};
             ca.loci = p->d_loci_all + p->loci_off[kl.first_class] + p->n_wide_loci;
             ca.n = n_all - p->n_wide_loci;
-            ca.cursor = p->d_cursors + kl.first_class;
-            ca.batch = -1;
+            ca.batch = 0;
             HIP_TRY(sb::launch_stream(a, ca, p->d_row_keep, ca.n, p->stream_lds_bytes, s));
          }
       } else {
@@ -777,7 +807,7 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
          fl.ph.n_classes = kl.n_classes;
          fl.ph.lists_in = p->d_loci_all;
          fl.ph.n_in = p->d_class_n + kl.first_class;
-         fl.ph.cursors = p->d_cursors + kl.first_class;
+         fl.ph.n_batches = kl.n_blocks;
          fl.ph.total_blocks = nullptr;
          fl.ph.lists_out = phased ? p->lat[0].d_lists : nullptr;
          fl.ph.n_out = phased ? p->lat[0].d_counts : nullptr;
@@ -785,7 +815,7 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
          fl.ph.next_table = phased ? p->lat[0].d_table : nullptr;
          fl.ph.it_limit = phased ? p->host.first_limit : SBGPU_EM_MAX_ITER;
          fl.ph.resume = 0;
-         fl.n_blocks = kl.n_blocks;
+         fl.n_blocks = std::max(1, (int)(kl.n_blocks * p->host.grid_scale + 0.5));
          hipError_t e = hipErrorInvalidValue;
          if (k == sb::kWaveH) e = sb::launch_fused_wave_h(fl, s);
          else if (k == sb::kWave1) e = sb::launch_fused_wave_1(fl, s);
@@ -806,7 +836,7 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
             ll.ph.n_classes = ld.n_classes;
             ll.ph.lists_in = ld.d_lists;
             ll.ph.n_in = ld.d_counts;
-            ll.ph.cursors = nullptr;
+            ll.ph.n_batches = 0;
             ll.ph.total_blocks = ld.d_total;
             ll.ph.lists_out = last ? nullptr : p->lat[i + 1].d_lists;
             ll.ph.n_out = last ? nullptr : p->lat[i + 1].d_counts;
@@ -1010,9 +1040,7 @@ int sbgpu_abundance_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const double *
    const int threads = 256;
    const int64_t blocks = (n + threads - 1) / threads;
    hipLaunchKernelGGL(abundance_kernel, dim3((unsigned)blocks), dim3(threads), 0, s, n, p->d_iso_off, d_theta, d_status,
-                      d_length, *params, d_fpkm, d_frac, d_keep, p->d_locus_sum);
-   HIP_TRY(hipGetLastError());
-   hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, s, blocks, p->d_locus_sum, d_sum_fpkm);
+                      d_length, *params, d_fpkm, d_frac, d_keep, p->d_locus_sum, p->d_epi_ticket, d_sum_fpkm);
    HIP_TRY(hipGetLastError());
    return SBGPU_OK;
 }
