@@ -40,6 +40,8 @@ WORKLOADS = {
     "c3": "C3 human-scale synthetic: 60000 loci/GPU, niso~1+Geom(0.25), nrow~LogNormal(ln30,1), 2e8 fragments",
     "c2": "C2 synthetic: 10000 loci x 8 isoforms x 1000 fragments, 32 exon bins",
     "c2u": "C2-U synthetic: 2000 loci x 8 isoforms x 1000 un-binned fragments (1000 rows)",
+    "c5": "C5 synthetic: the C3 law at 4e8 fragments, bias factors 2^U(-1,1) on the weights; fp32 variant of the EM "
+          "timed next to the fp64 path (tolerance sweep: tools/c5_sweep.py)",
 }
 
 
@@ -51,6 +53,8 @@ def make_batch(name, rank):
         return synth.make_c2(seed=0x5742 + rank)
     if name == "c2u":
         return synth.make_c2(n_loci=2000, seed=0x5742 + rank, unbinned=True)
+    if name == "c5":
+        return synth.make_c5(seed=0x5745 + rank)
     raise SystemExit("unknown workload " + name)
 
 
@@ -184,13 +188,13 @@ def main():
     # the per-step collective: torch.distributed (RCCL) by default, the C ABI's own RCCL binding with SB_COMM=abi
     comm = sdist.AbiComm(ctx) if os.environ.get("SB_COMM") == "abi" and world > 1 else None
 
-    def make_quant(b):
-        solver = em.EmBatchSolver(b, ctx)
+    def make_quant(b, f32=False, solver=None):
+        solver = solver or em.EmBatchSolver(b, ctx)
         # pass-1 normaliser (alignments.cpp:1372): global mapped fragments, one all-reduce at set-up
         tot = torch.tensor([b.n_frags], dtype=torch.int64, device=dev)
         (comm.allreduce_sum_(tot) if comm is not None else sdist.allreduce_sum_(tot))
         total_mapped = int(min(int(tot.item()), 2**31 - 1))   # the reference holds it in an int
-        return solver, sdist.ShardQuantifier(solver, total_mapped, min_isoform_frac=0.0, comm=comm)  # quant-only (-r): keep all
+        return solver, sdist.ShardQuantifier(solver, total_mapped, min_isoform_frac=0.0, comm=comm, f32=f32)  # quant-only (-r): keep all
 
     # ---- weak scaling: every rank holds its OWN full-size batch
     batch = make_batch(args.workload, rank)
@@ -228,6 +232,26 @@ def main():
     solver.set_timing(False)
     kern_ms = np.mean(np.array(probe), axis=0)
     phase_ms = [float(x) for x in np.mean(np.array(phase_probe), axis=0)] if phase_probe and phase_probe[0] else []
+
+    # ---- C5: the fp32 variant next to the fp64 path just timed (same batch, same plan)
+    c5 = None
+    if args.workload == "c5":
+        quant.step()
+        res64 = solver.results()
+        _, q32 = make_quant(batch, f32=True, solver=solver)
+        wall32, _ = timed_steps(q32, args.steps, args.warmup, dev, sdist, torch)
+        res32 = solver.results()
+        ok = np.isin(res64["status"], (0, 3)) & np.isin(res32["status"], (0, 3))
+        m = ok[np.repeat(np.arange(batch.n_loci), batch.niso)]
+        tpm_rel = np.abs(res32["tpm"] - res64["tpm"])[m] / np.maximum(res64["tpm"][m], 1e-3)
+        c5 = {"f32": {"value": n_loci_all * args.steps / wall32, "ms_per_step": wall32 / args.steps * 1e3},
+              "f64": {"value": weak["value"], "ms_per_step": weak["ms_per_step"]},
+              "tolerance": {"isoforms_within_1e-4_relative_tpm": float((tpm_rel < 1e-4).mean()),
+                            "tpm_rel_err_p99": float(np.percentile(tpm_rel, 99)), "tpm_rel_err_max": float(tpm_rel.max()),
+                            "loci_status_changed": int((res64["status"] != res32["status"]).sum()),
+                            "loci_iteration_count_changed": int((res64["iters"] != res32["iters"]).sum()),
+                            "histogram": "profiles/r02_c5_sweep.json (tools/c5_sweep.py)"}}
+        quant.step()   # leave the fp64 result in place for the roofline / parity legs below
 
     if rank != 0:
         return
@@ -283,6 +307,11 @@ def main():
         "strong_scaling": strong,
         "roofline": roofline,
     }
+    if c5 is not None:
+        # the headline of this workload is the fp32 variant; the fp64 numbers of the same run sit beside it
+        out.update({"value": c5["f32"]["value"], "ms_per_step": c5["f32"]["ms_per_step"], "dtype": "f32",
+                    "mfrags_per_s": n_frags_all / (c5["f32"]["ms_per_step"] * 1e-3) / 1e6, "c5": c5})
+        out["roofline"]["note"] += "; roofline figures are the fp64 path's (kernel_ms, algorithmic bytes with s = 8)"
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"], out["parity"] = cpu_baseline(batch, res)
         if not out["parity"]["ok"]:

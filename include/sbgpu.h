@@ -147,6 +147,15 @@ int sbgpu_em_run_device(sbgpu_ctx_t *ctx, const sbgpu_plan_t *plan,
                         double *d_theta, int32_t *d_status, int32_t *d_iters,
                         void *stream);
 
+/* The fp32 variant (BASELINE config 5, "fp32 vs fp64 tolerance sweep"): the same kernels with F, theta and all
+ * arithmetic in fp32 (d_F, d_theta are float arrays; fp32 denormals flush too).  It exists to measure what
+ * fp32 costs in accuracy and buys in speed; it is NOT a parity path: results differ from the reference's fp64
+ * EmSolver (tools/c5_sweep.py).  Loci of up to 64 isoforms only (else SBGPU_EUNSUPPORTED).        */
+int sbgpu_em_run_device_f32(sbgpu_ctx_t *ctx, const sbgpu_plan_t *plan,
+                            const int32_t *d_count, const float *d_F,
+                            float *d_theta, int32_t *d_status, int32_t *d_iters,
+                            void *stream);
+
 /* Timing events around the EM kernels are off by default (they cost a few microseconds
  * per call); sbgpu_set_timing(ctx, 1) turns them on for the calls that follow.       */
 int sbgpu_set_timing(sbgpu_ctx_t *ctx, int on);

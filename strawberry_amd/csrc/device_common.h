@@ -16,6 +16,18 @@ __device__ __forceinline__ void set_fp64_flush_denormals()
    __builtin_amdgcn_s_setreg(1 | (6 << 6) | ((2 - 1) << 11), 0);
 }
 
+// fp32 variant (BASELINE config 5): flush fp32 denormals as well (MODE.FP_DENORM[5:4] = 0), like -Ofast would
+__device__ __forceinline__ void set_all_flush_denormals()
+{
+   __builtin_amdgcn_s_setreg(1 | (4 << 6) | ((4 - 1) << 11), 0);
+}
+template <class T>
+__device__ __forceinline__ void set_flush_denormals()
+{
+   if (sizeof(T) == 4) set_all_flush_denormals();
+   else set_fp64_flush_denormals();
+}
+
 // value of lane (lane ^ MASK), true xor for every MASK
 template <int MASK>
 __device__ __forceinline__ int xor_get_i(int x)

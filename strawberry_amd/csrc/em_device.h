@@ -34,16 +34,20 @@ constexpr int32_t kStOk = 0, kStInitEmpty = 1, kStDenomZero = 2, kStMaxIter = 3;
 constexpr int32_t kStRunning = 4; // transient: suspended at a phase limit, resumed by the next phase
 
 // Device view of a batch (CSR-of-loci, include/sbgpu.h) and its outputs.
-struct EmArgs {
+// T = double: the reference's arithmetic (every parity claim is about this instantiation).  T = float: the fp32
+// variant of BASELINE config 5 (F, theta and all arithmetic in fp32), for the tolerance sweep -- not a parity target.
+template <class T>
+struct EmArgsT {
    const int64_t *row_off;
    const int64_t *iso_off;
    const int64_t *f_off;
    const int32_t *count;
-   const double *F;
-   double *theta;
+   const T *F;
+   T *theta;
    int32_t *status;
    int32_t *iters;
 };
+typedef EmArgsT<double> EmArgs;
 
 // Descriptor of a size class inside a launch's table (sorted by first block).
 struct ClassDesc {
@@ -82,6 +86,11 @@ __device__ __forceinline__ double dpp_mov(double x)
    return __hiloint2double(hi, lo);
 }
 template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x)
+{
+   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
 __device__ __forceinline__ int dpp_mov_i(int x)
 {
    return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true);
@@ -101,6 +110,17 @@ __device__ __forceinline__ double sum_xor16(double x)
    auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
    auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+
+__device__ __forceinline__ float sum_xor16(float x)
+{
+   auto a = __builtin_amdgcn_permlane16_swap(__float_as_int(x), __float_as_int(x), false, false);
+   return __int_as_float(a[0]) + __int_as_float(a[1]);
+}
+__device__ __forceinline__ float sum_xor32(float x)
+{
+   auto a = __builtin_amdgcn_permlane32_swap(__float_as_int(x), __float_as_int(x), false, false);
+   return __int_as_float(a[0]) + __int_as_float(a[1]);
 }
 
 // x(lane) + x(lane^32) with v_permlane32_swap (gfx950): after the swap one
@@ -157,6 +177,20 @@ __device__ __forceinline__ double fast_div(double n, double d)
    return n * r;
 }
 
+// fp32: v_rcp_f32 is good to 1 ulp; one Newton step on the quotient keeps n / d within ~1 ulp
+__device__ __forceinline__ float fast_div(float n, float d)
+{
+   const float r = __builtin_amdgcn_rcpf(d);
+   const float q = n * r;
+   return __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
+}
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+// squared convergence threshold: largest value whose correctly rounded square root is below 1e-2
+template <class T> struct ThetaLimitSq;
+template <> struct ThetaLimitSq<double> { static constexpr double value = 0x1.a36e2eb1c432bp-14; };
+template <> struct ThetaLimitSq<float> { static constexpr float value = 0x1.a36e2ap-14f; };
+
 // ================================================================== tile kernel
 // A locus is owned by a GROUP of G = CL x GR lanes laid out as a 2-D grid:
 //   gc = g % CL  "column lane": owns columns [gc*CPL, gc*CPL + CPL)
@@ -181,6 +215,11 @@ __device__ __forceinline__ double xor_get(double x)
 {
    return __hiloint2double(xor_get_i<MASK>(__double2hiint(x)), xor_get_i<MASK>(__double2loint(x)));
 }
+template <int MASK>
+__device__ __forceinline__ float xor_get(float x)
+{
+   return __int_as_float(xor_get_i<MASK>(__float_as_int(x)));
+}
 // Sum over lane bits 4 and 5 -- x(l) + x(l^16) + x(l^32) + x(l^48), in every lane -- with ONE matrix
 // instruction: v_mfma_f64_4x4x4_4b with A = 1 and B = x gives D(lane) = sum over k of x(16 k + lane % 16)
 // (layout probed by tools/microbench.hip).  19-22 cycles on the matrix pipe (which the vector instructions of the
@@ -190,14 +229,18 @@ __device__ __forceinline__ double sum_bits45(double x)
 {
    return __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, x, 0.0, 0, 0, 0);
 }
+// fp32: the two lane-swap steps (the fp32-input matrix instructions have no 4-deep form to sum with)
+__device__ __forceinline__ float sum_bits45(float x) { return sum_xor32(sum_xor16(x)); }
 // value of lane (l - 4) mod 16 / (l - 8) mod 16 of the own 16-lane row
-__device__ __forceinline__ double row_ror4(double x) { return dpp_mov<0x124>(x); }
-__device__ __forceinline__ double row_ror8(double x) { return dpp_mov<0x128>(x); }
+template <class T>
+__device__ __forceinline__ T row_ror4(T x) { return dpp_mov<0x124>(x); }
+template <class T>
+__device__ __forceinline__ T row_ror8(T x) { return dpp_mov<0x128>(x); }
 
 // x(lane) + x(lane ^ MASK).  LOW_UNIFORM: every lane below bit log2(MASK) of the
 // group already holds the same value, so the cheaper mirror forms are valid.
-template <int MASK, bool LOW_UNIFORM>
-__device__ __forceinline__ double xor_sum(double x)
+template <int MASK, bool LOW_UNIFORM, class T>
+__device__ __forceinline__ T xor_sum(T x)
 {
    if (MASK == 32) return sum_xor32(x);
    if (MASK == 16) return sum_xor16(x);
@@ -217,8 +260,8 @@ constexpr int tile_rows(int cpl, int rhalf, int rh)
 }
 
 // all-reduce over lane bits [0, HI) (compile-time)
-template <int HI>
-__device__ __forceinline__ double low_bits_sum(double x)
+template <int HI, class T>
+__device__ __forceinline__ T low_bits_sum(T x)
 {
    if (HI > 0) x = xor_sum<1, true>(x);
    if (HI > 1) x = xor_sum<2, true>(x);
@@ -233,8 +276,8 @@ __device__ __forceinline__ double low_bits_sum(double x)
 // Bits 4 and 5 together go through the matrix pipe (sum_bits45).  Bits 2 and 3 together, when the lanes below are
 // not uniform, go as a rotate butterfly inside the 16-lane row -- y = x + ror8(x), z = y + ror4(y): the second
 // step needs one DPP move per half where a true xor 4 needs two, and every lane still adds the same pairs.
-template <int LO, int NVAL>
-__device__ __forceinline__ void high_bits_sum(double (&x)[NVAL], int hi)
+template <int LO, int NVAL, class T>
+__device__ __forceinline__ void high_bits_sum(T (&x)[NVAL], int hi)
 {
 #define SB_STEP(BIT)                                                                \
    {                                                                                \
@@ -265,8 +308,8 @@ __device__ __forceinline__ void high_bits_sum(double (&x)[NVAL], int hi)
 // matrix pipe, the ones below as steps inside the 16-lane row (bit 3: rotate by 8 = xor 8; bit 2: rotate by 4
 // of the result, which is symmetric under the rotation by 8 by then; bits 1 and 0: quad permutes).  The lanes
 // below bit 6 - lb hold different data throughout.
-template <int NVAL>
-__device__ __forceinline__ void top_bits_sum(double (&x)[NVAL], int lb)
+template <int NVAL, class T>
+__device__ __forceinline__ void top_bits_sum(T (&x)[NVAL], int lb)
 {
    if (lb == 1) {
 #pragma unroll
@@ -324,9 +367,8 @@ constexpr int kBlockWaves = 4; // block form: 256 lanes, one wave per SIMD, up t
 // interleaved between them and the column lanes -- lane = gc | group << log2(CL) | gr << (6 - log2(GR)) -- so that
 // the all-reduce over the row lanes runs over lane bits 4 and 5 first, which one matrix instruction covers
 // (sum_bits45), then 3, 2, ... as rotate steps inside the 16-lane rows.
-template <int CPL, int CL, int R, int NWAVES, bool HIMAP = false>
-__device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &cls, const int lbG,
-                                             double *s_red, int *s_idx)
+template <class T, int CPL, int CL, int R, int NWAVES, bool HIMAP = false>
+__device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArgs &cls, const int lbG, T *s_red)
 {
    static_assert(!(HIMAP && NWAVES > 0), "the high-bit lane map is a wave form");
    constexpr bool BLOCK = NWAVES > 0;
@@ -359,39 +401,39 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
       if (BLOCK) {
          // cross-wave: [2 phases][NV values][CL column lanes][NW]; every lane then adds
          // the NW partials in the same order
-         double *buf = s_red + (size_t)phase * (NV * CL * NW);
+         T *buf = s_red + (size_t)phase * (NV * CL * NW);
          if (lane < CL) {
 #pragma unroll
             for (int v = 0; v < NVAL; ++v) buf[(v * CL + lane) * NW + wave_id] = x[v];
          }
          __syncthreads();
-         double part[NVAL][NW];
+         T part[NVAL][NW];
 #pragma unroll
          for (int v = 0; v < NVAL; ++v) {
-            const double *p = buf + (v * CL + gc) * NW;
+            const T *p = buf + (v * CL + gc) * NW;
 #pragma unroll
             for (int w = 0; w < NW; ++w) part[v][w] = p[w];
          }
 #pragma unroll
          for (int v = 0; v < NVAL; ++v) {
-            double sum = part[v][0];
+            T sum = part[v][0];
 #pragma unroll
             for (int w = 1; w < NW; ++w) sum += part[v][w];
             x[v] = sum;
          }
-         phase ^= 1; // double-buffered: one barrier per round is enough
+         phase ^= 1; // T-buffered: one barrier per round is enough
       }
    };
 
-   double F[R][CPL];
-   double scale[CPL]; // 1, then 1/column-sum after the first iteration: F' = F * scale (:466-478)
+   T F[R][CPL];
+   T scale[CPL]; // 1, then 1/column-sum after the first iteration: F' = F * scale (:466-478)
    // F <- column-normalised F (:466-478), a zero column stays zero: F itself is left
    // untouched in registers, the column scale takes the normalisation
    auto column_scale = [&]() {
-      double cs[CPL];
+      T cs[CPL];
 #pragma unroll
       for (int jj = 0; jj < CPL; ++jj) {
-         double sum = 0.0;
+         T sum = T(0);
 #pragma unroll
          for (int r = 0; r < R; ++r)
             if (!BLOCK || (r & ~3) < r_used) sum += F[r][jj];
@@ -399,12 +441,12 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
       }
       row_lane_sum(cs, std::integral_constant<int, CPL>());
 #pragma unroll
-      for (int jj = 0; jj < CPL; ++jj) scale[jj] = (cs[jj] == 0.0) ? 0.0 : 1.0 / cs[jj];
+      for (int jj = 0; jj < CPL; ++jj) scale[jj] = (cs[jj] == T(0)) ? T(0) : T(1) / cs[jj];
    };
-   double nn[R];      // n_i as double (obs_d, estimate.cpp:418-419); 0 for dropped rows
+   T nn[R];      // n_i as T (obs_d, estimate.cpp:418-419); 0 for dropped rows
    bool act[R];       // row kept by init() (estimate.cpp:377-390)
-   double theta[CPL];
-   double theta0 = 0.0;
+   T theta[CPL];
+   T theta0 = T(0);
    int it = 0;
    int niso = 0;
    int locus = 0;
@@ -413,15 +455,15 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
 
 #pragma unroll
    for (int r = 0; r < R; ++r) {
-      nn[r] = 0.0;
+      nn[r] = T(0);
       act[r] = false;
 #pragma unroll
-      for (int j = 0; j < CPL; ++j) F[r][j] = 0.0;
+      for (int j = 0; j < CPL; ++j) F[r][j] = T(0);
    }
 #pragma unroll
    for (int j = 0; j < CPL; ++j) {
-      theta[j] = 0.0;
-      scale[j] = 1.0;
+      theta[j] = T(0);
+      scale[j] = T(1);
    }
 
    for (;;) {
@@ -445,16 +487,16 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
          const int nrow = (int)(a.row_off[loc + 1] - r0);
          const int64_t ib = a.iso_off[loc];
          const int ni = (int)(a.iso_off[loc + 1] - ib);
-         const double *Fg = a.F + a.f_off[loc];
+         const T *Fg = a.F + a.f_off[loc];
          if (BLOCK) {
             // row blocks the locus does not reach are skipped (workgroup-uniform)
             r_used = (nrow + GR - 1) / GR;
             r_used = r_used < 1 ? 1 : (r_used > R ? R : r_used);
          }
          // EmSolver::init, estimate.cpp:366-391
-         double red[2];
-         red[0] = 0.0; // sum of ALL counts (theta0 precedes the row drop, :374-375)
-         red[1] = 0.0; // number of kept rows
+         T red[2];
+         red[0] = T(0); // sum of ALL counts (theta0 precedes the row drop, :374-375)
+         red[1] = T(0); // number of kept rows
 #pragma unroll
          for (int r = 0; r < R; ++r) {
             if (BLOCK && (r & ~3) >= r_used) continue; // row block not needed by this locus
@@ -463,19 +505,19 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
             // clamped indices: loads stay inside the locus (or touch nothing when it
             // has no rows), no per-element branches
             const int ic = (i < nrow) ? i : (nrow > 0 ? nrow - 1 : 0);
-            double cnt = 0.0;
-            if (nrow > 0) cnt = (double)a.count[r0 + ic];
-            cnt = valid ? cnt : 0.0;
+            T cnt = T(0);
+            if (nrow > 0) cnt = (T)a.count[r0 + ic];
+            cnt = valid ? cnt : T(0);
             if (gc == 0) red[0] += cnt;
-            double v[CPL];
-            double mx = 0.0;
+            T v[CPL];
+            T mx = T(0);
 #pragma unroll
             for (int jj = 0; jj < CPL; ++jj) {
                const int j = gc * CPL + jj;
                const int jc = (j < ni) ? j : ni - 1;
-               double x = 0.0;
+               T x = T(0);
                if (nrow > 0) x = Fg[(int64_t)ic * ni + jc];
-               x = (valid && j < ni) ? x : 0.0;
+               x = (valid && j < ni) ? x : T(0);
                mx = fmax(mx, x);
                v[jj] = x;
             }
@@ -484,22 +526,22 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
             if (CL >= 4) mx = fmax(mx, xor_get<2>(mx));
             if (CL >= 8) mx = fmax(mx, xor_get<4>(mx));
             if (CL >= 16) mx = fmax(mx, xor_get<8>(mx));
-            const bool keep = mx > kRowEps;
-            if (gc == 0 && keep) red[1] += 1.0;
+            const bool keep = mx > (T)kRowEps;
+            if (gc == 0 && keep) red[1] += T(1);
             act[r] = keep;
-            nn[r] = keep ? cnt : 0.0;
+            nn[r] = keep ? cnt : T(0);
 #pragma unroll
-            for (int jj = 0; jj < CPL; ++jj) F[r][jj] = keep ? v[jj] : 0.0;
+            for (int jj = 0; jj < CPL; ++jj) F[r][jj] = keep ? v[jj] : T(0);
          }
          // group totals: over the column lanes, then over the row lanes
          red[0] = low_bits_sum<LB_CL>(red[0]);
          red[1] = low_bits_sum<LB_CL>(red[1]);
          row_lane_sum(red, std::integral_constant<int, 2>());
-         theta0 = red[0] / (double)ni; // :375, IEEE division
+         theta0 = red[0] / (T)ni; // :375, IEEE division
 #pragma unroll
          for (int jj = 0; jj < CPL; ++jj) {
-            theta[jj] = (gc * CPL + jj < ni) ? theta0 : 0.0;
-            scale[jj] = 1.0;
+            theta[jj] = (gc * CPL + jj < ni) ? theta0 : T(0);
+            scale[jj] = T(1);
          }
          it = 0;
          locus = loc;
@@ -511,10 +553,10 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
             it = got ? a.iters[loc] : 0;
 #pragma unroll
             for (int jj = 0; jj < CPL; ++jj)
-               theta[jj] = (gc * CPL + jj < ni) ? a.theta[ib + gc * CPL + jj] : 0.0;
+               theta[jj] = (gc * CPL + jj < ni) ? a.theta[ib + gc * CPL + jj] : T(0);
             column_scale();
          }
-         const bool empty = got && red[1] == 0.0;
+         const bool empty = got && red[1] == T(0);
          if (empty) {
             // init() == false (:391): theta = theta0, the caller drops the locus
             if (g == 0) {
@@ -542,14 +584,14 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
       // F is read-only in here and nothing touches memory.  Two iterations per
       // trip, theta ping-ponging between `theta` and `nt`, so that no copy or
       // select sits on the per-iteration path.
-      double nt[NV]; // next_theta of the own columns
+      T nt[NV]; // next_theta of the own columns
       bool dz, conv, special;
       // one EM iteration: reads tin, writes tout (all lanes, no predication)
-      auto iterate = [&](const double *tin, double *tout) {
-         double acc[NV];
+      auto iterate = [&](const T *tin, T *tout) {
+         T acc[NV];
 #pragma unroll
-         for (int v = 0; v < NV; ++v) acc[v] = 0.0;
-         double phi[CPL]; // theta of the column-normalised problem seen through the raw F
+         for (int v = 0; v < NV; ++v) acc[v] = T(0);
+         T phi[CPL]; // theta of the column-normalised problem seen through the raw F
 #pragma unroll
          for (int jj = 0; jj < CPL; ++jj) phi[jj] = tin[jj] * scale[jj];
          // A zero denominator of a kept row (:451) is not tested row by row: 1 / 0 is infinite, the Newton steps turn
@@ -561,13 +603,13 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
 #pragma unroll
          for (int rb = 0; rb < R; rb += 4) {
             if (BLOCK && rb >= r_used) continue;
-            double d[4];
+            T d[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                if (rb + q < R) {
-                  double sum = 0.0;
+                  T sum = T(0);
 #pragma unroll
-                  for (int jj = 0; jj < CPL; ++jj) sum = __builtin_fma(F[rb + q][jj], phi[jj], sum); // :450
+                  for (int jj = 0; jj < CPL; ++jj) sum = fma_t(F[rb + q][jj], phi[jj], sum); // :450
                   d[q] = low_bits_sum<LB_CL>(sum);
                }
             }
@@ -575,27 +617,27 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
             for (int q = 0; q < 4; ++q) {
                if (rb + q < R) {
                   const int r = rb + q;
-                  double w = fast_div(nn[r], d[q]);
-                  w = act[r] ? w : 0.0;
+                  T w = fast_div(nn[r], d[q]);
+                  w = act[r] ? w : T(0);
 #pragma unroll
-                  for (int jj = 0; jj < CPL; ++jj) acc[jj] = __builtin_fma(w, F[r][jj], acc[jj]);
+                  for (int jj = 0; jj < CPL; ++jj) acc[jj] = fma_t(w, F[r][jj], acc[jj]);
                }
             }
          }
          row_lane_sum(acc, std::integral_constant<int, NV>());
-         double p2 = 0.0;
+         T p2 = T(0);
 #pragma unroll
          for (int jj = 0; jj < CPL; ++jj) {
-            const double t = phi[jj] * acc[jj]; // next_theta_j = sum_i U_ij, :454-464
-            const double df = t - tin[jj];
-            p2 = __builtin_fma(df, df, p2); // :479
+            const T t = phi[jj] * acc[jj]; // next_theta_j = sum_i U_ij, :454-464
+            const T df = t - tin[jj];
+            p2 = fma_t(df, df, p2); // :479
             tout[jj] = t;
          }
-         const double d2 = low_bits_sum<LB_CL>(p2);
-         // ||next - theta||_2 < 1e-2 (:479-480) tested on the square: kThetaLimitSq is the largest double whose
+         const T d2 = low_bits_sum<LB_CL>(p2);
+         // ||next - theta||_2 < 1e-2 (:479-480) tested on the square: kThetaLimitSq is the largest T whose
          // (correctly rounded) square root is below 1e-2, so this is the same predicate as sqrt(d2) < 1e-2 of the
          // reference, the oracle and the streaming / wide kernels, for every d2
-         conv = d2 <= kThetaLimitSq;
+         conv = d2 <= ThetaLimitSq<T>::value;
          dz = __builtin_isnan(d2); // some kept row had a zero denominator (:451), see above
          special = have && (dz || conv || it == 0 || it + 1 == cls.it_limit);
       };
@@ -623,7 +665,7 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
             // their new theta in `theta`
 #pragma unroll
             for (int jj = 0; jj < CPL; ++jj) {
-               const double o = nt[jj], n2 = theta[jj];
+               const T o = nt[jj], n2 = theta[jj];
                theta[jj] = special ? o : n2;
                nt[jj] = special ? n2 : o;
             }
@@ -637,7 +679,7 @@ __device__ __forceinline__ void em_tile_body(const EmArgs &a, const ClassArgs &c
       // first iteration done: switch to the column-normalised problem (:466-478)
       const bool norm = special && !dz && it == 0;
       if (BLOCK ? norm : __any(norm)) {
-         double keep_scale[CPL];
+         T keep_scale[CPL];
 #pragma unroll
          for (int jj = 0; jj < CPL; ++jj) keep_scale[jj] = scale[jj];
          column_scale();
@@ -749,15 +791,14 @@ struct PhaseArgs {
 #ifndef SB_WAVE2_OCC
 #define SB_WAVE2_OCC 2
 #endif
-template <int NWAVES, int RH>
+template <int NWAVES, int RH, class T = double>
 __global__ __launch_bounds__(NWAVES > 0 ? 64 * NWAVES : 64,
                               NWAVES > 0 ? (RH <= 2 ? 2 : 1)
                                          : (RH == 1 ? SB_WAVEH_OCC : (RH == 2 ? SB_WAVE1_OCC : SB_WAVE2_OCC))) void em_fused_kernel(
-   EmArgs a, PhaseArgs ph)
+   EmArgsT<T> a, PhaseArgs ph)
 {
-   __shared__ double s_red[NWAVES > 0 ? 2 * (kMaxCPLv + 1) * 8 * NWAVES : 1];
-   __shared__ int s_idx;
-   set_fp64_flush_denormals();
+   __shared__ T s_red[NWAVES > 0 ? 2 * (kMaxCPLv + 1) * 8 * NWAVES : 1];
+   set_flush_denormals<T>();
    // workgroup-per-locus waves have the longest iterations of the batch (LDS round + barrier):
    // they go first whenever they share a SIMD with wave-form waves
    if (NWAVES > 0) __builtin_amdgcn_s_setprio(3);
@@ -795,7 +836,7 @@ __global__ __launch_bounds__(NWAVES > 0 ? 64 * NWAVES : 64,
    // Rows per row lane: RH halves of the base height (16, 8, 8, 8, 6, 6, 4, 4 for CPL = 1..8).
 #define SB_BODY(CPLV, CLV, RHALF)                                                                  \
    case (CPLV - 1) + 8 * ilog2(CLV):                                                               \
-      em_tile_body<CPLV, CLV, tile_rows(CPLV, RHALF, RH), NWAVES>(a, cls, lbG, s_red, &s_idx);     \
+      em_tile_body<T, CPLV, CLV, tile_rows(CPLV, RHALF, RH), NWAVES>(a, cls, lbG, s_red);          \
       break;
    switch (layout) {
       SB_BODY(1, 1, 8)
@@ -862,7 +903,7 @@ __global__ __launch_bounds__(64, SB_LAT_OCC) void em_lat_kernel(EmArgs a, PhaseA
 #define SB_LAT(CPLV, CLV, RV)                                                             \
    case lat_shape(CPLV, ilog2(CLV), RV):                                                  \
       if constexpr (CPLV * RV <= kLatMaxTile)                                             \
-         em_tile_body<CPLV, CLV, RV, 0, true>(a, cls, 6, nullptr, nullptr);               \
+         em_tile_body<double, CPLV, CLV, RV, 0, true>(a, cls, 6, nullptr);                \
       break;
 #define SB_LAT_ROWS(CPLV, CLV)                                                            \
    SB_LAT(CPLV, CLV, 1) SB_LAT(CPLV, CLV, 2) SB_LAT(CPLV, CLV, 3) SB_LAT(CPLV, CLV, 4)    \
@@ -920,6 +961,12 @@ struct FusedLaunch {
    PhaseArgs ph;
    int n_blocks;
 };
+struct FusedLaunchF32 {
+   EmArgsT<float> a;
+   PhaseArgs ph;
+   int n_blocks;
+};
+hipError_t launch_fused_f32(int kind, const FusedLaunchF32 &l, hipStream_t s); // kind: plan.h ClassKind (wave base / double tile, block, tall block)
 hipError_t launch_fused_wave_h(const FusedLaunch &l, hipStream_t s);
 hipError_t launch_fused_wave_1(const FusedLaunch &l, hipStream_t s);
 hipError_t launch_fused_wave_2(const FusedLaunch &l, hipStream_t s);

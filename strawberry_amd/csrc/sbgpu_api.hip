@@ -682,23 +682,31 @@ int sbgpu_plan_classes(const sbgpu_plan_t *p, int64_t *out, int cap)
    return n;
 }
 
-int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_count, const double *d_F,
-                        double *d_theta, int32_t *d_status, int32_t *d_iters, void *stream)
+} // extern "C"
+
+// fp64 (the product path) and fp32 (BASELINE config 5's tolerance sweep) share the launch structure
+static int em_run_impl(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_count, const void *d_F_any, void *d_theta_any,
+                       int32_t *d_status, int32_t *d_iters, void *stream, const bool f32)
 {
    if (!c || !p) return fail(SBGPU_EINVAL, "sbgpu_em_run_device: null ctx/plan");
    if (p->host.n_loci == 0) return SBGPU_OK;
-   if (!d_theta || !d_status || !d_iters || (!d_count && p->host.n_rows) || (!d_F && p->host.n_elem))
+   if (!d_theta_any || !d_status || !d_iters || (!d_count && p->host.n_rows) || (!d_F_any && p->host.n_elem))
       return fail(SBGPU_EINVAL, "sbgpu_em_run_device: null device pointer");
+   if (f32 && (p->launches[sb::kStream].n_classes > 0 || p->launches[sb::kWaveH].n_classes > 0))
+      return fail(SBGPU_EUNSUPPORTED, "sbgpu_em_run_device_f32: the fp32 variant covers loci of up to 64 isoforms in the tile kernels only");
    hipStream_t main = (hipStream_t)stream;
    sb::EmArgs a;
    a.row_off = p->d_row_off;
    a.iso_off = p->d_iso_off;
    a.f_off = p->d_f_off;
    a.count = d_count;
-   a.F = d_F;
-   a.theta = d_theta;
+   a.F = (const double *)d_F_any;
+   a.theta = (double *)d_theta_any;
    a.status = d_status;
    a.iters = d_iters;
+   sb::EmArgsT<float> a32;
+   a32.row_off = a.row_off, a32.iso_off = a.iso_off, a32.f_off = a.f_off, a32.count = a.count;
+   a32.F = (const float *)d_F_any, a32.theta = (float *)d_theta_any, a32.status = d_status, a32.iters = d_iters;
    // Batches are dealt to the workgroups statically: nothing to reset between runs but the later phases' survivor
    // counts (only when the plan has phases)
    if (p->zero_bytes) HIP_TRY(hipMemsetAsync(p->d_zero, 0, p->zero_bytes, main));
@@ -800,7 +808,7 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
          }
       } else {
          const bool wave_kind = k == sb::kWaveH || k == sb::kWave1 || k == sb::kWave2;
-         const bool phased = wave_kind && !p->lat.empty();
+         const bool phased = wave_kind && !p->lat.empty() && !f32;
          sb::FusedLaunch fl;
          fl.a = a;
          fl.ph.table = kl.d_table;
@@ -817,7 +825,11 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
          fl.ph.resume = 0;
          fl.n_blocks = std::max(1, (int)(kl.n_blocks * p->host.grid_scale + 0.5));
          hipError_t e = hipErrorInvalidValue;
-         if (k == sb::kWaveH) e = sb::launch_fused_wave_h(fl, s);
+         if (f32) {
+            sb::FusedLaunchF32 f;
+            f.a = a32, f.ph = fl.ph, f.n_blocks = fl.n_blocks;
+            e = sb::launch_fused_f32(k, f, s);
+         } else if (k == sb::kWaveH) e = sb::launch_fused_wave_h(fl, s);
          else if (k == sb::kWave1) e = sb::launch_fused_wave_1(fl, s);
          else if (k == sb::kWave2) e = sb::launch_fused_wave_2(fl, s);
          else if (k == sb::kBlock) e = sb::launch_fused_block(fl, s);
@@ -868,6 +880,20 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
       }
    }
    return SBGPU_OK;
+}
+
+extern "C" {
+
+int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_count, const double *d_F,
+                        double *d_theta, int32_t *d_status, int32_t *d_iters, void *stream)
+{
+   return em_run_impl(c, p, d_count, d_F, d_theta, d_status, d_iters, stream, false);
+}
+
+int sbgpu_em_run_device_f32(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_count, const float *d_F,
+                            float *d_theta, int32_t *d_status, int32_t *d_iters, void *stream)
+{
+   return em_run_impl(c, p, d_count, d_F, d_theta, d_status, d_iters, stream, true);
 }
 
 int sbgpu_set_timing(sbgpu_ctx_t *c, int on)

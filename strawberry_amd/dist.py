@@ -166,17 +166,23 @@ class ShardQuantifier:
     caller (it precedes the EM: src/estimate.cpp:328)."""
 
     def __init__(self, solver, total_mapped_reads, min_isoform_frac=0.01, effective_len_norm=False,
-                 insert_mean=0.0, filter_by_expression=True, comm=None):
-        """comm: an AbiComm (the C-ABI collective); None: torch.distributed's default group."""
+                 insert_mean=0.0, filter_by_expression=True, comm=None, f32=False):
+        """comm: an AbiComm (the C-ABI collective); None: torch.distributed's default group.
+        f32: run the EM's fp32 variant (BASELINE config 5; not a parity path), the epilogue stays fp64."""
         self.s = solver
         self.comm = comm
+        self.f32 = f32
         self.kw = dict(total_mapped_reads=int(total_mapped_reads), min_isoform_frac=min_isoform_frac,
                        effective_len_norm=effective_len_norm, insert_mean=insert_mean,
                        filter_by_expression=filter_by_expression)
 
     def step(self):
         s = self.s
-        s.run_em()
+        if self.f32:
+            s.run_em_f32()
+            s.theta32_as_f64()
+        else:
+            s.run_em()
         s.run_abundance(**self.kw)          # leaves this rank's sum of kept FPKM in d_sum_fpkm
         # the one collective: 8 bytes over xGMI
         if self.comm is not None:

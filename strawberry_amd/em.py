@@ -146,6 +146,21 @@ class EmBatchSolver:
                                          self.d_theta.data_ptr(), self.d_status.data_ptr(),
                                          self.d_iters.data_ptr(), self._stream()), "sbgpu_em_run_device")
 
+    def run_em_f32(self):
+        """The fp32 variant (BASELINE config 5's tolerance sweep; not a parity path): F and theta in fp32.
+        Results land in d_theta32 / d_status / d_iters; theta32_as_f64() feeds the fp64 epilogue."""
+        torch = self.torch
+        if getattr(self, "d_F32", None) is None:
+            self.d_F32 = self.d_F.to(torch.float32)
+            self.d_theta32 = torch.zeros(max(self.n_iso, 1), dtype=torch.float32, device=self.dev)
+        _lib.check(self.ctx.L.sbgpu_em_run_device_f32(self.ctx.h, self.plan.h, self.d_count.data_ptr(), self.d_F32.data_ptr(),
+                                                     self.d_theta32.data_ptr(), self.d_status.data_ptr(),
+                                                     self.d_iters.data_ptr(), self._stream()), "sbgpu_em_run_device_f32")
+
+    def theta32_as_f64(self):
+        """Copy the fp32 run's theta into d_theta (fp64) so that the epilogue kernels can follow."""
+        self.d_theta.copy_(self.d_theta32)
+
     def set_timing(self, on=True):
         """Timing events around the EM kernels (off by default; bench.py turns them on for its probe steps)."""
         _lib.check(self.ctx.L.sbgpu_set_timing(self.ctx.h, int(bool(on))), "sbgpu_set_timing")

@@ -198,6 +198,16 @@ def make_c3(n_loci=60000, total_frags=2e8, seed=0x5743, max_niso=200, max_nrow=2
     return _generate(rng, nrow, niso, n_frags, name="C3")
 
 
+def make_c5(n_loci=60000, total_frags=4e8, seed=0x5745):
+    """Config C5: the C3 law at 4e8 fragments with every weight multiplied by a bias factor
+    b_ij in [0.5, 2] (log-uniform; the reference itself has no bias arithmetic, so the factors are ours).  The
+    input of the fp32-vs-fp64 tolerance sweep."""
+    b = make_c3(n_loci=n_loci, total_frags=total_frags, seed=seed)
+    rng = np.random.Generator(np.random.PCG64(seed ^ 0xB1A5))
+    F = b.F * np.exp2(rng.uniform(-1.0, 1.0, b.F.shape)) * (b.F != 0)
+    return LocusBatch(b.row_off, b.iso_off, b.f_off, b.count, np.ascontiguousarray(F), b.length, "C5")
+
+
 def make_random(n_loci=256, max_nrow=64, max_niso=12, density=0.4, max_count=60, seed=12345):
     """The survey's ``em_random`` law: nrow in [1,max_nrow], niso in [1,max_niso],
     weights mask*U(1e-3,0.3) (no >=1 guarantees, so dropped rows / zero columns occur),
