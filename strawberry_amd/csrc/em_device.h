@@ -136,6 +136,7 @@ __device__ __forceinline__ double sum_xor32(double x)
 // All-reduce (sum) over the GW consecutive lanes of a wave that form one group
 // (GW = 1,2,4,...,64).  Every step adds a value to its butterfly partner's, so all
 // lanes of a group end with bitwise identical sums.
+__device__ __forceinline__ double sum_bits45(double x); // below: lane bits 4 and 5 through the matrix pipe
 template <int GW>
 __device__ __forceinline__ double wave_group_sum(double x)
 {
@@ -143,8 +144,8 @@ __device__ __forceinline__ double wave_group_sum(double x)
    if (GW >= 4) x += dpp_mov<kDppXor2>(x);
    if (GW >= 8) x += dpp_mov<kDppHalfMirror>(x);
    if (GW >= 16) x += dpp_mov<kDppMirror>(x);
+   if (GW >= 64) return sum_bits45(x);
    if (GW >= 32) x = sum_xor16(x);
-   if (GW >= 64) x = sum_xor32(x);
    return x;
 }
 

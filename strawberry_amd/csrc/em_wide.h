@@ -3,16 +3,15 @@
 //
 // The streaming kernel (em_device.h) gives such a locus one workgroup and re-reads F from L2 in every
 // iteration: ~90 us per iteration for a 1160 x 194 locus, i.e. 90 ms for the 1000-iteration cap, and a
-// human annotation has tens of such loci.  Here the rows of the locus are dealt to G workgroups (CUs);
-// each keeps its rows of F in registers for all iterations -- F is read from HBM once -- and an iteration
-// costs one exchange: every workgroup writes its partial column sums (niso doubles) to a small buffer in
-// global memory, a counter barrier among the G workgroups of the locus, every workgroup adds the G
-// partials in the same order.  All G workgroups thus hold bitwise identical theta and take identical
-// decisions (convergence, zero denominator), so no second barrier is needed; two buffers alternate.
+// human annotation has tens to hundreds of such loci.  Here the rows of the locus are dealt to G workgroups
+// (CUs); each keeps its rows of F in registers for all iterations -- F is read from HBM once -- and an iteration
+// costs one exchange: every workgroup publishes its partial column sums (niso doubles) as tagged 16-byte
+// granules in global memory, every workgroup sweeps all G partials into LDS (re-reading what has not arrived
+// yet) and adds them in the same order.  All G workgroups thus hold bitwise identical theta and take identical
+// decisions (convergence, zero denominator); two buffers alternate, there is no barrier object at all.
 //
-// Launched cooperatively (hipLaunchCooperativeKernel): the barrier needs all workgroups of a locus
-// resident.  A barrier that does not complete within kWideSpinLimit polls gives up and raises an error
-// flag instead of hanging the GPU.
+// Launched cooperatively (hipLaunchCooperativeKernel): the exchange needs all workgroups of a locus resident.
+// A partial that does not arrive within kWideSpinLimit sweeps raises an error flag instead of hanging the GPU.
 //
 // Same arithmetic as the other kernels: F' = F * scale through phi, fast_div, fp64 flush mode.
 #pragma once
@@ -23,17 +22,20 @@ namespace sb {
 
 constexpr int kWideThreads = 512;              // 8 waves, 2 per SIMD: up to 256 VGPRs each
 constexpr int kWideWaves = kWideThreads / 64;
-// rows of F a wave keeps in registers (x NSLOT columns per lane): bounded by 256 VGPRs with n_i, flags, temporaries
-constexpr int wide_rows(int nslot) { return nslot <= 2 ? 16 : (nslot <= 4 ? 12 : 8); }
-constexpr unsigned kWideSpinLimit = 1u << 24;  // polls of a barrier before giving up (~ seconds)
+// rows of F a wave keeps in registers (x NSLOT columns per lane): the most that leaves the kernel free of spills
+// (the unrolled row loop's temporaries and the gather's granules share the 256 VGPRs with the tile)
+constexpr int wide_rows(int nslot) { return nslot <= 2 ? 20 : (nslot <= 4 ? 12 : 8); }
+constexpr unsigned kWideSpinLimit = 1u << 20;  // sweeps of a round's partials before giving up (~ seconds)
+constexpr int kWideSweep = 4;                  // granules a thread has in flight per sweep
+constexpr int kWideStageDoubles = 8 * kWideThreads; // LDS staging area of the gather: 32 KB
 
 struct WideDesc {
    int32_t locus;
    int32_t first_block; // in this launch
    int32_t n_blocks;    // G
    int32_t rows_per_block;
-   int64_t buf_off;     // doubles: start of this locus' 2 x G x (npad + 2) exchange buffers
-   int32_t barrier;     // index of its counter
+   int64_t buf_off;     // doubles: start of this locus' 2 x G x (npad + 2) exchange granules (16 bytes each)
+   int32_t unused;
    int32_t npad;
 };
 
@@ -41,47 +43,39 @@ struct WideArgs {
    EmArgs a;
    const WideDesc *table;
    int32_t n_desc;
-   double *bufs;
-   unsigned *barriers; // zeroed before the launch
-   int32_t *error;     // set to 1 when a barrier timed out
+   double *bufs;       // zeroed when the plan is made
+   unsigned epoch;     // distinguishes this run's granules from those an earlier run left in the buffers
+   int32_t *error;     // set to 1 when a partial never arrived
 };
 
-// All G workgroups of the locus have written exchange number `round` (1-based).
-// Hand-off form (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility", first
-// row of the sc1 table): every byte of the partials is stored with an agent-scope relaxed atomic store
-// (global_store sc1: write-through, no line kept in this XCD's non-coherent L2) and loaded with an agent-scope
-// relaxed atomic load (sc1: never served from the vector L1); every storing wave waits for its stores
-// (s_waitcnt vmcnt(0)), a workgroup barrier, ONE lane adds to the locus' counter (agent-scope atomic) and polls
-// it with sc1 loads, a workgroup barrier, then the loads.  No L2 write-back / invalidate fences: those cost
-// more than the whole iteration (measured 10 of 13.5 us with release / acquire fences).
-__device__ __forceinline__ bool wide_barrier(unsigned *counter, unsigned G, unsigned round, int32_t *error)
+// The exchange of partial column sums among the G workgroups of a locus, once per iteration.
+// Every partial travels as a 16-byte granule {value, tag, ~tag} written by ONE global_store_dwordx4 sc1
+// (write-through: nothing stays in this XCD's non-coherent L2) and read by global_load_dwordx4 sc1 (never served
+// from the vector L1): a reader that finds the current exchange's tag beside a value has the value -- no counter,
+// no flag, no second round trip (MI355X_MICROARCH.md: "handoff-1to1", data-tagged granules, 0.8-1.0 us against
+// 1.7-2.5x that for a separate flag; 16-byte sc1 granules are observed untorn on gfx950 -- and a torn one would
+// fail the tag / ~tag test and be read again).  tag = run epoch * 2048 + exchange number, so nothing an earlier
+// run left in the buffers can pass.  Two buffers alternate by the exchange's parity: a workgroup can run at most
+// one exchange ahead of the slowest one, because it needs everyone's partials of an exchange to leave it.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void granule_store(void *p, double v, unsigned round)
 {
-   asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's partial stores have left
-   __syncthreads();
-   __shared__ int ok;
-   if (threadIdx.x == 0) {
-      __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      unsigned spins = 0;
-      const unsigned target = G * round;
-      while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-         __builtin_amdgcn_s_sleep(1);
-         if (++spins > kWideSpinLimit || __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-            __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-         }
-      }
-      ok = __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
-   }
-   __syncthreads();
-   return ok != 0;
+   u32x4 g;
+   g.x = (unsigned)__double2loint(v);
+   g.y = (unsigned)__double2hiint(v);
+   g.z = round;
+   g.w = ~round;
+   asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(g) : "memory");
 }
+__device__ __forceinline__ bool granule_ready(const u32x4 &g, unsigned round) { return g.z == round && g.w == ~round; }
+__device__ __forceinline__ double granule_value(const u32x4 &g) { return __hiloint2double((int)g.y, (int)g.x); }
 
 // NSLOT columns per lane (64 lanes per row): niso <= 64 * NSLOT; R = wide_rows(NSLOT) rows per wave
 template <int NSLOT>
 __global__ __launch_bounds__(kWideThreads) void em_wide_kernel(WideArgs g)
 {
    constexpr int R = wide_rows(NSLOT);
-   extern __shared__ double s_dyn[]; // phi[npad] | theta[npad] | scale[npad] | accw[kWideWaves][npad + 2]
+   extern __shared__ double s_dyn[]; // phi[npad] | theta[npad] | scale[npad] | accw[kWideWaves][npad + 2] | stage[kWideStageDoubles]
    const EmArgs &a = g.a;
    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
    set_fp64_flush_denormals();
@@ -99,15 +93,19 @@ __global__ __launch_bounds__(kWideThreads) void em_wide_kernel(WideArgs g)
    const double *Fg = a.F + a.f_off[locus];
    const int npad = d.npad, nv = npad + 2; // exchanged vector: npad column values + 2 scalars
    double *phi = s_dyn, *theta = s_dyn + npad, *scale = s_dyn + 2 * npad, *accw = s_dyn + 3 * npad;
+   double *stage = accw + kWideWaves * nv; // [chunk of producers][nv]
    double *bufs = g.bufs + d.buf_off;
-   unsigned *counter = g.barriers + d.barrier;
-   unsigned round = 0;
+   int32_t *g_err = g.error;
+   unsigned round = g.epoch << 11; // tags = epoch * 2048 + exchange number (at most 1002 exchanges per run)
 
    // ---- my rows: block w owns rows [w * rows_per_block, ...), wave v of it the rows v, v + 16, ...
    const int row_lo = w * d.rows_per_block;
    const int row_hi = min(nrow, row_lo + d.rows_per_block);
-   double F[R][NSLOT], nn[R];
-   bool act[R];
+   double F[R][NSLOT];
+   // a wave's 64 lanes share their rows, so a row's count and its "kept" flag are wave-uniform: they live in
+   // scalar registers (the count as the int it is), which leaves the vector registers to the tile
+   int nn_i[R];
+   unsigned act_mask = 0;
    double tot = 0.0;
    int kept = 0;
 #pragma unroll
@@ -132,8 +130,8 @@ __global__ __launch_bounds__(kWideThreads) void em_wide_kernel(WideArgs g)
       mx = fmax(mx, xor_get<16>(mx));
       mx = fmax(mx, xor_get<32>(mx));
       const bool keep = valid && mx > kRowEps; // estimate.cpp:380
-      act[r] = keep;
-      nn[r] = keep ? cnt : 0.0;
+      if (__builtin_amdgcn_readfirstlane(keep ? 1 : 0)) act_mask |= 1u << r;
+      nn_i[r] = __builtin_amdgcn_readfirstlane(keep ? (int)cnt : 0);
       if (!keep) {
 #pragma unroll
          for (int k = 0; k < NSLOT; ++k) F[r][k] = 0.0;
@@ -143,7 +141,9 @@ __global__ __launch_bounds__(kWideThreads) void em_wide_kernel(WideArgs g)
    }
    // exchange: every lane contributes NSLOT column values + 2 scalars through accw, then the blocks
    // through `bufs`; returns the sums in accw[0 .. npad + 2) of wave slot 0 (identical in all blocks)
-   auto exchange = [&](const double (&col)[NSLOT], double s0, double s1) -> bool {
+   // tot[q] = the locus-wide sum of value j = tid + q * kWideThreads (also left in accw[j], wave 0's slot -- NOT yet
+   // visible to the other threads: the caller synchronises before anybody reads another thread's value)
+   auto exchange = [&](const double (&col)[NSLOT], double s0, double s1, double (&tot)[2]) -> bool {
       double *mine = accw + wave * nv;
 #pragma unroll
       for (int k = 0; k < NSLOT; ++k)
@@ -154,25 +154,70 @@ __global__ __launch_bounds__(kWideThreads) void em_wide_kernel(WideArgs g)
       }
       __syncthreads();
       ++round;
-      double *out = bufs + ((size_t)(round & 1) * G + w) * nv;
-      for (int j = tid; j < nv; j += kWideThreads) {
-         double s = 0.0;
-         for (int v = 0; v < kWideWaves; ++v) s += accw[v * nv + j];
-         if (G > 1) __hip_atomic_store(out + j, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // sc1 store
-         else accw[j] = s; // (wave 0's slot; safe: every thread owns its j)
+      char *out = (char *)bufs + ((size_t)(round & 1) * G + w) * nv * 16;
+      {
+         int q = 0;
+         for (int j = tid; j < nv; j += kWideThreads, ++q) {
+            double s = 0.0;
+            for (int v = 0; v < kWideWaves; ++v) s += accw[v * nv + j];
+            if (G > 1) granule_store(out + (size_t)j * 16, s, round);
+            tot[q] = s;
+         }
       }
       if (G == 1) {
-         __syncthreads();
+         int q = 0;
+         for (int j = tid; j < nv; j += kWideThreads, ++q) accw[j] = tot[q]; // (wave 0's slot; every thread owns its j)
          return true;
       }
-      if (!wide_barrier(counter, (unsigned)G, round, g.error)) return false;
-      const double *in = bufs + (size_t)(round & 1) * G * nv;
-      for (int j = tid; j < nv; j += kWideThreads) {
-         double s = 0.0;
-         for (int v = 0; v < G; ++v) s += __hip_atomic_load(in + (size_t)v * nv + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // sc1 load
-         accw[j] = s;
+      // gather: ALL threads sweep the G x nv granules of the exchange into LDS (kWideSweep granules per thread and
+      // pass, loads issued together; a granule that still carries an older tag is read again in the next pass),
+      // producers in chunks that fit the staging area; then thread j adds the staged partials of value j in
+      // workgroup order -- every workgroup the same order, so all hold bitwise identical sums
+      const char *in = (const char *)bufs + (size_t)(round & 1) * G * nv * 16;
+      const int chunk_g = max(1, (kWideSweep * kWideThreads) / nv); // producers per chunk (one pass covers a chunk)
+      double run[2] = {0.0, 0.0};                                    // running sums of the (at most 2) values this thread owns
+      for (int v0 = 0; v0 < G; v0 += chunk_g) {
+         const int n = min(chunk_g, G - v0) * nv;                    // granules of this chunk: [v0 * nv, v0 * nv + n)
+         unsigned pending = 0;
+#pragma unroll
+         for (int k = 0; k < kWideSweep; ++k)
+            if (tid + k * kWideThreads < n) pending |= 1u << k;
+         for (unsigned spins = 0;; ++spins) {
+            u32x4 gr[kWideSweep];
+#pragma unroll
+            for (int k = 0; k < kWideSweep; ++k)
+               if (pending & (1u << k))
+                  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(gr[k]) : "v"(in + ((size_t)v0 * nv + tid + k * kWideThreads) * 16) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < kWideSweep; ++k)
+               if ((pending & (1u << k)) && granule_ready(gr[k], round)) {
+                  stage[tid + k * kWideThreads] = granule_value(gr[k]);
+                  pending &= ~(1u << k);
+               }
+            if (!__syncthreads_or((int)pending)) break; // also publishes the staged values to the workgroup
+            // give up together: one thread looks at the error word every 64th sweep (it lives in host memory)
+            int bad = spins > kWideSpinLimit;
+            if ((spins & 63) == 63 && tid == 0) bad |= __hip_atomic_load(g_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            if ((spins > kWideSpinLimit || (spins & 63) == 63) && __syncthreads_or(bad)) {
+               if (tid == 0) __hip_atomic_store(g_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+               return false;
+            }
+            __builtin_amdgcn_s_sleep(2);
+         }
+         const int gc = min(chunk_g, G - v0);
+         int q = 0;
+         for (int j = tid; j < nv; j += kWideThreads, ++q) {
+            double sum = run[q];
+            for (int v = 0; v < gc; ++v) sum += stage[v * nv + j];
+            run[q] = sum;
+         }
+         if (v0 + chunk_g < G) __syncthreads(); // the staging area is free for the next chunk
       }
-      __syncthreads();
+      {
+         int q = 0;
+         for (int j = tid; j < nv; j += kWideThreads, ++q) accw[j] = tot[q] = run[q];
+      }
       return true;
    };
 
@@ -183,8 +228,10 @@ __global__ __launch_bounds__(kWideThreads) void em_wide_kernel(WideArgs g)
       for (int k = 0; k < NSLOT; ++k) col[k] = 0.0;
       // per-wave scalars: lane 0 carries the wave's totals
       double t = tot; // every lane of the wave holds the same tot (rows are per wave)
-      if (!exchange(col, t, (double)kept)) return;
+      double unused[2];
+      if (!exchange(col, t, (double)kept, unused)) return;
    }
+   __syncthreads();
    const double theta0 = accw[npad] / (double)niso; // :375
    const bool any_kept = accw[npad + 1] != 0.0;
    __syncthreads();
@@ -216,32 +263,49 @@ __global__ __launch_bounds__(kWideThreads) void em_wide_kernel(WideArgs g)
          acc[k] = 0.0;
       }
       int zf = 0;
+      // rows four at a time: their dot products, the four 64-lane sums step by step side by side, the four
+      // divisions, the four updates
+      static_assert(R % 4 == 0, "rows per wave come in fours");
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-         double part = 0.0;
+      for (int rb = 0; rb < R; rb += 4) {
+         double dd[4];
 #pragma unroll
-         for (int k = 0; k < NSLOT; ++k) part = __builtin_fma(F[r][k], ph[k], part); // :450
-         const double dd = wave_group_sum<64>(part);
-         zf |= (act[r] && dd == 0.0) ? 1 : 0; // :451
-         double wgt = fast_div(nn[r], dd);
-         wgt = act[r] ? wgt : 0.0;
+         for (int q = 0; q < 4; ++q) {
+            double part = 0.0;
 #pragma unroll
-         for (int k = 0; k < NSLOT; ++k) acc[k] = __builtin_fma(wgt, F[r][k], acc[k]);
+            for (int k = 0; k < NSLOT; ++k) part = __builtin_fma(F[rb + q][k], ph[k], part); // :450
+            dd[q] = part;
+         }
+         high_bits_sum<0, 4>(dd, 6); // all-reduce over the 64 lanes (bits 4 and 5 through the matrix pipe)
+#pragma unroll
+         for (int q = 0; q < 4; ++q) {
+            const int r = rb + q;
+            const bool act = (act_mask >> r) & 1u; // compile-time r: one scalar bit test
+            zf |= (act && dd[q] == 0.0) ? 1 : 0; // :451
+            double wgt = fast_div((double)nn_i[r], dd[q]);
+            wgt = act ? wgt : 0.0;
+#pragma unroll
+            for (int k = 0; k < NSLOT; ++k) acc[k] = __builtin_fma(wgt, F[r][k], acc[k]);
+         }
       }
-      if (!exchange(acc, (double)zf, 0.0)) return;
-      const bool dz = accw[npad] != 0.0;
-      // next_theta, identical in every block; column j is owned by thread j (and j + 1024 ...)
+      double tot[2];
+      if (!exchange(acc, (double)zf, 0.0, tot)) return;
+      // next_theta of the columns this thread owns (j = tid, tid + 512), identical in every workgroup
+      double nt[2] = {0.0, 0.0};
       double d2 = 0.0;
-      for (int j = tid; j < niso; j += kWideThreads) {
-         const double nt = phi[j] * accw[j]; // :454-464
-         const double df = nt - theta[j];
-         d2 = __builtin_fma(df, df, d2);
-         accw[nv + j] = nt; // wave 1's slot is free now: next_theta
+      {
+         int q = 0;
+         for (int j = tid; j < niso; j += kWideThreads, ++q) {
+            nt[q] = phi[j] * tot[q]; // :454-464
+            const double df = nt[q] - theta[j];
+            d2 = __builtin_fma(df, df, d2);
+         }
       }
       d2 = wave_group_sum<64>(d2);
       __shared__ double s_part[kWideWaves];
       if (lane == 0) s_part[wave] = d2;
-      __syncthreads();
+      __syncthreads(); // the zero flag (accw[npad]) and the waves' shares of ||next - theta||^2 are visible
+      const bool dz = accw[npad] != 0.0;
       d2 = 0.0;
       for (int v = 0; v < kWideWaves; ++v) d2 += s_part[v];
       ++it;
@@ -259,28 +323,26 @@ __global__ __launch_bounds__(kWideThreads) void em_wide_kernel(WideArgs g)
 #pragma unroll
             for (int r = 0; r < R; ++r) cs[k] += F[r][k];
          }
-         // next_theta lives in wave 1's slot of accw, which the exchange overwrites: park it in theta's
-         // shadow (scale[] is free until we set it below)
-         for (int j = tid; j < niso; j += kWideThreads) scale[j] = accw[nv + j];
-         __syncthreads();
-         if (!exchange(cs, 0.0, 0.0)) return;
-         for (int j = tid; j < niso; j += kWideThreads) {
-            const double nt = scale[j];
-            const double s = accw[j];
-            scale[j] = (s == 0.0) ? 0.0 : 1.0 / s;
-            accw[nv + j] = nt;
-         }
-         __syncthreads();
+         __syncthreads(); // everybody has read the zero flag before the exchange reuses accw
+         double cst[2];
+         if (!exchange(cs, 0.0, 0.0, cst)) return;
+         int q = 0;
+         for (int j = tid; j < niso; j += kWideThreads, ++q) scale[j] = (cst[q] == 0.0) ? 0.0 : 1.0 / cst[q];
       }
-      if (sqrt(d2) < kThetaLimit) { // :479-480, theta NOT updated
+      if (d2 <= kThetaLimitSq) { // sqrt(d2) < 1e-2 (:479-480), theta NOT updated
          st = kStOk;
          break;
       }
-      for (int j = tid; j < niso; j += kWideThreads) theta[j] = accw[nv + j]; // :481
-      __syncthreads();
-      for (int j = tid; j < npad; j += kWideThreads) phi[j] = (j < niso) ? theta[j] * scale[j] : 0.0;
-      __syncthreads();
+      {
+         int q = 0;
+         for (int j = tid; j < niso; j += kWideThreads, ++q) {
+            theta[j] = nt[q];            // :481
+            phi[j] = nt[q] * scale[j];   // (phi of the padding columns stays 0)
+         }
+      }
+      __syncthreads(); // phi is complete for the next iteration; accw and s_part may be reused
    }
+   __syncthreads(); // (the threads that broke out read theta below)
    if (w == 0) {
       if (tid == 0) {
          a.status[locus] = st;

@@ -120,7 +120,7 @@ struct sbgpu_plan {
    std::vector<WideRound> wide_rounds;
    sb::WideDesc *d_wide_table = nullptr; // all rounds' descriptors
    double *d_wide_bufs = nullptr;
-   unsigned *d_wide_barriers = nullptr;
+   mutable unsigned wide_epoch = 0;    // bumped by every run: the tag space of its exchange granules
    int32_t n_wide_desc = 0, n_wide_loci = 0; // the first n_wide_loci of the stream class' list go to the wide kernel
 };
 
@@ -504,11 +504,11 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
             d.rows_per_block = (int32_t)rpb;
             d.npad = 64 * (int32_t)((niso + 63) / 64);
             d.buf_off = (int64_t)wide_buf_doubles;
-            d.barrier = (int32_t)wide_table.size();
-            wide_buf_doubles += (size_t)2 * G * (d.npad + 2);
+            d.unused = 0;
+            wide_buf_doubles += (size_t)4 * G * (d.npad + 2); // two buffers of G x (npad + 2) 16-byte granules
             round.n_blocks += G;
             round.n_desc += 1;
-            round.lds_bytes = std::max(round.lds_bytes, (size_t)(3 * d.npad + sb::kWideWaves * (d.npad + 2)) * sizeof(double));
+            round.lds_bytes = std::max(round.lds_bytes, (size_t)(3 * d.npad + sb::kWideWaves * (d.npad + 2) + sb::kWideStageDoubles) * sizeof(double));
             wide_table.push_back(d);
             sc.loci.push_back(l);
          }
@@ -555,7 +555,6 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
    const size_t o_keep = at; at += up((size_t)p->host.n_rows + 1);
    const size_t o_sum = at; at += up((size_t)(n_loci + 1) * sizeof(double));
    const size_t o_tick = at; at += up(sizeof(unsigned));
-   const size_t o_wbar = at; at += up((wide_table.size() + 1) * sizeof(unsigned));
    const size_t o_wbuf = at; at += up((wide_buf_doubles + 1) * sizeof(double));
    if ((e = hipMalloc(&p->d_arena, at)) != hipSuccess) return bail(e, "hipMalloc(plan arena)");
    stage("hipMalloc");
@@ -585,7 +584,6 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
    p->d_locus_sum = (double *)(p->d_arena + o_sum);
    p->d_epi_ticket = (unsigned *)(p->d_arena + o_tick);
    p->d_wide_table = (sb::WideDesc *)(p->d_arena + o_wtab);
-   p->d_wide_barriers = (unsigned *)(p->d_arena + o_wbar);
    p->d_wide_bufs = (double *)(p->d_arena + o_wbuf);
    std::vector<char> stage_buf(staged, 0);
    if (n_loci > 0) {
@@ -642,6 +640,8 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
    stage("staging");
    if ((e = hipMemcpy(p->d_arena, stage_buf.data(), staged, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(plan)");
    if ((e = hipMemset(p->d_epi_ticket, 0, sizeof(unsigned))) != hipSuccess) return bail(e, "hipMemset(plan)");
+   // the wide kernel's exchange granules carry a per-run tag: start from a state no tag matches
+   if (wide_buf_doubles && (e = hipMemset(p->d_wide_bufs, 0, wide_buf_doubles * sizeof(double))) != hipSuccess) return bail(e, "hipMemset(plan)");
    stage("upload");
    // streaming kernel LDS: (3 + NWAVE) * npad doubles, npad <= pow2ceil-padded niso
    size_t npad = 1;
@@ -751,7 +751,7 @@ static int em_run_impl(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_c
       if (k == sb::kStream) {
          // wide loci: cooperative launches, one per round (all workgroups of a launch are resident)
          if (p->n_wide_desc) {
-            HIP_TRY(hipMemsetAsync(p->d_wide_barriers, 0, (size_t)p->n_wide_desc * sizeof(unsigned), s));
+            p->wide_epoch = (p->wide_epoch % 0x1FFFFFu) + 1; // 1 .. 2^21 - 1: epoch * 2048 + round fits 32 bits
             int32_t *d_err = nullptr;
             HIP_TRY(hipHostGetDevicePointer((void **)&d_err, c->wide_error, 0));
             // Rounds may overlap on three streams -- the tail of one round (its slowest locus) then runs beside the
@@ -789,7 +789,7 @@ static int em_run_impl(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_c
                wa.table = p->d_wide_table + r.first_desc;
                wa.n_desc = r.n_desc;
                wa.bufs = p->d_wide_bufs;
-               wa.barriers = p->d_wide_barriers;
+               wa.epoch = p->wide_epoch;
                wa.error = d_err;
                HIP_TRY(sb::launch_wide(r.nslot, wa, r.n_blocks, r.lds_bytes, lanes[lane]));
                in_flight_blocks += r.n_blocks;

@@ -198,6 +198,39 @@ def make_c3(n_loci=60000, total_frags=2e8, seed=0x5743, max_niso=200, max_nrow=2
     return _generate(rng, nrow, niso, n_frags, name="C3")
 
 
+def make_c3t(n_loci=60000, total_frags=2e8, seed=0x5743, n_tail=300):
+    """C3-T: C3 plus a human-annotation-shaped TAIL the C3 law (niso ~ 1 + Geom(0.25), at most ~36) never draws --
+    `n_tail` loci of 65..400 isoforms and 200..3000 bins (both log-uniform), 50 fragments per bin.  These are the
+    loci of a GENCODE-size annotation that do not fit a workgroup's registers (em_wide_kernel / em_stream_kernel).
+    The tail loci are spread evenly through the batch."""
+    base = make_c3(n_loci=n_loci, total_frags=total_frags, seed=seed)
+    rng = np.random.Generator(np.random.PCG64(seed ^ 0x7A11))
+    niso = np.exp(rng.uniform(np.log(65), np.log(400), n_tail)).astype(np.int64)
+    nrow = np.exp(rng.uniform(np.log(200), np.log(3000), n_tail)).astype(np.int64)
+    tail = _generate(rng, nrow, niso, nrow * 50, name="tail")
+    # interleave: tail locus k goes in front of base locus pos[k]
+    pos = np.linspace(0, n_loci, n_tail, endpoint=False).astype(np.int64)
+    parts, prev = [], 0
+    for k in range(n_tail):
+        if pos[k] > prev:
+            parts.append(base.select(np.arange(prev, pos[k])))
+        parts.append(tail.select(np.array([k])))
+        prev = pos[k]
+    if prev < n_loci:
+        parts.append(base.select(np.arange(prev, n_loci)))
+    return concat_batches(parts, "C3-T")
+
+
+def concat_batches(parts, name="batch"):
+    """Concatenate LocusBatches (loci keep their order)."""
+    row_off = np.concatenate([[0]] + [p.row_off[1:] + o for p, o in zip(parts, np.cumsum([0] + [int(p.row_off[-1]) for p in parts[:-1]]))])
+    iso_off = np.concatenate([[0]] + [p.iso_off[1:] + o for p, o in zip(parts, np.cumsum([0] + [int(p.iso_off[-1]) for p in parts[:-1]]))])
+    f_off = np.concatenate([[0]] + [p.f_off[1:] + o for p, o in zip(parts, np.cumsum([0] + [int(p.f_off[-1]) for p in parts[:-1]]))])
+    return LocusBatch(row_off.astype(np.int64), iso_off.astype(np.int64), f_off.astype(np.int64),
+                      np.concatenate([p.count for p in parts]), np.concatenate([p.F for p in parts]),
+                      np.concatenate([p.length for p in parts]), name)
+
+
 def make_c5(n_loci=60000, total_frags=4e8, seed=0x5745):
     """Config C5: the C3 law at 4e8 fragments with every weight multiplied by a bias factor
     b_ij in [0.5, 2] (log-uniform; the reference itself has no bias arithmetic, so the factors are ours).  The

@@ -36,6 +36,7 @@ def main():
                 continue
             b = make(nrow, niso, n_loci)
             s = em.EmBatchSolver(b, ctx)
+            s.set_timing(True)
             s.run_em()
             torch.cuda.synchronize()
             best = 1e9
@@ -66,6 +67,7 @@ def mix():
                 loci.append(b.locus(l))
         b = synth.from_loci(loci)
         s = em.EmBatchSolver(b, ctx)
+        s.set_timing(True)
         s.run_em()
         torch.cuda.synchronize()
         best = 1e9

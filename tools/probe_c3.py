@@ -9,6 +9,7 @@ from strawberry_amd import em, synth
 
 def run(b, ctx, label):
     s = em.EmBatchSolver(b, ctx)
+    s.set_timing(True)
     s.run_em(); torch.cuda.synchronize()
     best = 1e9
     for _ in range(3):

@@ -10,10 +10,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     ctx = em.default_context(0)
     b = synth.make_c3()
     s = em.EmBatchSolver(b, ctx)
+    s.set_timing(True)
     kinds = s.plan.locus_kinds()
     for name, sel in (("wave-kind only", kinds < 3), ("block-kind only", kinds >= 3), ("all", kinds >= 0)):
         sub = b.select(np.nonzero(sel)[0])
         s2 = em.EmBatchSolver(sub, ctx)
+        s2.set_timing(True)
         s2.run_em(); torch.cuda.synchronize()
         best = 1e9
         for _ in range(4):

@@ -10,6 +10,7 @@ from strawberry_amd.synth import _generate
 ctx = em.default_context(0)
 def run(b, label):
     s = em.EmBatchSolver(b, ctx)
+    s.set_timing(True)
     s.run_em(); torch.cuda.synchronize()
     best = 1e9
     for _ in range(3):

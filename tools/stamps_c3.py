@@ -13,9 +13,11 @@ from strawberry_amd import em, synth
 ctx = em.default_context(0)
 b = synth.make_c3()
 s = em.EmBatchSolver(b, ctx); s.run_em(); r = s.results()
+s.set_timing(True)
 kinds = s.plan.locus_kinds()
 sub = b.select(np.nonzero(kinds < 3)[0])
 s = em.EmBatchSolver(sub, ctx)
+s.set_timing(True)
 s.run_em(); torch.cuda.synchronize(); s.run_em(); torch.cuda.synchronize()
 print("kernel ms", s.last_kernel_ms())
 nw = sum(c["n_waves"] for c in s.plan.classes())
