@@ -40,6 +40,8 @@ WORKLOADS = {
     "c3": "C3 human-scale synthetic: 60000 loci/GPU, niso~1+Geom(0.25), nrow~LogNormal(ln30,1), 2e8 fragments",
     "c2": "C2 synthetic: 10000 loci x 8 isoforms x 1000 fragments, 32 exon bins",
     "c2u": "C2-U synthetic: 2000 loci x 8 isoforms x 1000 un-binned fragments (1000 rows)",
+    "c3t": "C3-T synthetic: C3 plus a human-annotation-shaped tail of 300 loci with 65-400 isoforms and 200-3000 bins "
+           "(the loci a workgroup's registers do not hold: em_wide_kernel)",
     "c5": "C5 synthetic: the C3 law at 4e8 fragments, bias factors 2^U(-1,1) on the weights; fp32 variant of the EM "
           "timed next to the fp64 path (tolerance sweep: tools/c5_sweep.py)",
 }
@@ -55,6 +57,8 @@ def make_batch(name, rank):
         return synth.make_c2(n_loci=2000, seed=0x5742 + rank, unbinned=True)
     if name == "c5":
         return synth.make_c5(seed=0x5745 + rank)
+    if name == "c3t":
+        return synth.make_c3t(seed=0x5743 + rank)
     raise SystemExit("unknown workload " + name)
 
 

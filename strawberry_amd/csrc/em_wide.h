@@ -35,7 +35,7 @@ struct WideDesc {
    int32_t n_blocks;    // G
    int32_t rows_per_block;
    int64_t buf_off;     // doubles: start of this locus' 2 x G x (npad + 2) exchange granules (16 bytes each)
-   int32_t unused;
+   int32_t nslot;       // columns per lane of the instantiation that serves it: 2, 4 or 8
    int32_t npad;
 };
 
@@ -72,17 +72,13 @@ __device__ __forceinline__ double granule_value(const u32x4 &g) { return __hiloi
 
 // NSLOT columns per lane (64 lanes per row): niso <= 64 * NSLOT; R = wide_rows(NSLOT) rows per wave
 template <int NSLOT>
-__global__ __launch_bounds__(kWideThreads) void em_wide_kernel(WideArgs g)
+__device__ __forceinline__ void em_wide_body(const WideArgs &g, const int di)
 {
    constexpr int R = wide_rows(NSLOT);
    extern __shared__ double s_dyn[]; // phi[npad] | theta[npad] | scale[npad] | accw[kWideWaves][npad + 2] | stage[kWideStageDoubles]
    const EmArgs &a = g.a;
    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
    set_fp64_flush_denormals();
-   // my locus
-   int di = 0;
-   for (int k = 1; k < g.n_desc; ++k)
-      if (g.table[k].first_block <= (int)blockIdx.x) di = k;
    const WideDesc d = g.table[di];
    const int w = (int)blockIdx.x - d.first_block, G = d.n_blocks;
    const int locus = d.locus;
@@ -352,6 +348,23 @@ __global__ __launch_bounds__(kWideThreads) void em_wide_kernel(WideArgs g)
    }
 }
 
-hipError_t launch_wide(int nslot, const WideArgs &g, int n_blocks, size_t lds_bytes, hipStream_t s);
+// One launch serves loci of all three widths (a round's workgroups must all be resident together, and cooperative
+// launches do not overlap, so rounds should be few and full): the workgroup looks up its locus and jumps to the
+// instantiation its width needs.
+#ifdef SB_COMPILE_WIDE_KERNEL
+__global__ __launch_bounds__(kWideThreads) void em_wide_kernel(WideArgs g)
+{
+   int di = 0;
+   for (int k = 1; k < g.n_desc; ++k)
+      if (g.table[k].first_block <= (int)blockIdx.x) di = k;
+   di = __builtin_amdgcn_readfirstlane(di);
+   const int nslot = g.table[di].nslot;
+   if (nslot <= 2) em_wide_body<2>(g, di);
+   else if (nslot <= 4) em_wide_body<4>(g, di);
+   else em_wide_body<8>(g, di);
+}
+#endif
+
+hipError_t launch_wide(const WideArgs &g, int n_blocks, size_t lds_bytes, hipStream_t s);
 
 } // namespace sb

@@ -114,7 +114,7 @@ struct sbgpu_plan {
    size_t stream_lds_bytes = 0;
    // wide loci (kStream class) served by the cooperative multi-workgroup kernel, in launches ("rounds")
    struct WideRound {
-      int nslot = 2, first_desc = 0, n_desc = 0, n_blocks = 0;
+      int first_desc = 0, n_desc = 0, n_blocks = 0;
       size_t lds_bytes = 0;
    };
    std::vector<WideRound> wide_rounds;
@@ -470,50 +470,48 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
    size_t wide_buf_doubles = 0;
    for (sb::SizeClass &sc : p->host.classes) {
       if (sc.kind != sb::kStream) continue;
-      std::vector<int32_t> wide_loci[3], rest; // by template: 2, 4, 8 columns per lane
+      // (workgroups, locus): a round's time is its slowest locus', and an iteration costs the more the more
+      // workgroups exchange partials, so loci of like workgroup counts share rounds: largest first
+      std::vector<std::pair<int, int32_t>> wide;
+      std::vector<int32_t> rest;
+      auto slots_of = [](int64_t niso) { const int need = (int)((niso + 63) / 64); return need <= 2 ? 2 : (need <= 4 ? 4 : 8); };
       for (int32_t l : sc.loci) {
          const int64_t nrow = row_off[l + 1] - row_off[l], niso = iso_off[l + 1] - iso_off[l];
-         const int need = (int)((niso + 63) / 64);
-         const int t = need <= 2 ? 0 : (need <= 4 ? 1 : 2);
-         const int ns = 2 << t;
-         const int64_t rpb = (int64_t)sb::kWideWaves * sb::wide_rows(ns);
+         const int64_t rpb = (int64_t)sb::kWideWaves * sb::wide_rows(slots_of(niso));
          const int64_t G = std::max<int64_t>(1, (nrow + rpb - 1) / rpb);
-         if (need <= 8 && G <= c->n_cu && !std::getenv("SBGPU_NO_WIDE")) wide_loci[t].push_back(l);
+         if (niso <= 512 && G <= c->n_cu && !std::getenv("SBGPU_NO_WIDE")) wide.emplace_back((int)G, l);
          else rest.push_back(l);
       }
+      std::stable_sort(wide.begin(), wide.end(), [](const std::pair<int, int32_t> &x, const std::pair<int, int32_t> &y) { return x.first > y.first; });
       sc.loci.clear();
-      for (int t = 0; t < 3; ++t) {
-         const int ns = 2 << t;
-         const int64_t rpb = (int64_t)sb::kWideWaves * sb::wide_rows(ns);
-         sbgpu_plan::WideRound round;
-         round.nslot = ns;
-         round.first_desc = (int)wide_table.size();
-         for (int32_t l : wide_loci[t]) {
-            const int64_t nrow = row_off[l + 1] - row_off[l], niso = iso_off[l + 1] - iso_off[l];
-            const int G = (int)std::max<int64_t>(1, (nrow + rpb - 1) / rpb);
-            if (round.n_blocks + G > c->n_cu) { // this launch is full: all its workgroups must be resident
-               p->wide_rounds.push_back(round);
-               round = sbgpu_plan::WideRound();
-               round.nslot = ns;
-               round.first_desc = (int)wide_table.size();
-            }
-            sb::WideDesc d;
-            d.locus = l;
-            d.first_block = round.n_blocks;
-            d.n_blocks = G;
-            d.rows_per_block = (int32_t)rpb;
-            d.npad = 64 * (int32_t)((niso + 63) / 64);
-            d.buf_off = (int64_t)wide_buf_doubles;
-            d.unused = 0;
-            wide_buf_doubles += (size_t)4 * G * (d.npad + 2); // two buffers of G x (npad + 2) 16-byte granules
-            round.n_blocks += G;
-            round.n_desc += 1;
-            round.lds_bytes = std::max(round.lds_bytes, (size_t)(3 * d.npad + sb::kWideWaves * (d.npad + 2) + sb::kWideStageDoubles) * sizeof(double));
-            wide_table.push_back(d);
-            sc.loci.push_back(l);
+      sbgpu_plan::WideRound round;
+      round.first_desc = (int)wide_table.size();
+      for (const auto &gl : wide) {
+         const int32_t l = gl.second;
+         const int G = gl.first;
+         const int64_t niso = iso_off[l + 1] - iso_off[l];
+         const int ns = slots_of(niso);
+         if (round.n_blocks + G > c->n_cu) { // this launch is full: all its workgroups must be resident
+            p->wide_rounds.push_back(round);
+            round = sbgpu_plan::WideRound();
+            round.first_desc = (int)wide_table.size();
          }
-         if (round.n_desc) p->wide_rounds.push_back(round);
+         sb::WideDesc d;
+         d.locus = l;
+         d.first_block = round.n_blocks;
+         d.n_blocks = G;
+         d.rows_per_block = (int32_t)(sb::kWideWaves * sb::wide_rows(ns));
+         d.npad = 64 * (int32_t)((niso + 63) / 64);
+         d.buf_off = (int64_t)wide_buf_doubles;
+         d.nslot = ns;
+         wide_buf_doubles += (size_t)4 * G * (d.npad + 2); // two buffers of G x (npad + 2) 16-byte granules
+         round.n_blocks += G;
+         round.n_desc += 1;
+         round.lds_bytes = std::max(round.lds_bytes, (size_t)(3 * d.npad + sb::kWideWaves * (d.npad + 2) + sb::kWideStageDoubles) * sizeof(double));
+         wide_table.push_back(d);
+         sc.loci.push_back(l);
       }
+      if (round.n_desc) p->wide_rounds.push_back(round);
       p->n_wide_loci = (int32_t)sc.loci.size();
       sc.loci.insert(sc.loci.end(), rest.begin(), rest.end());
       sc.n_blocks = (int)rest.size(); // what is left for the streaming kernel
@@ -791,7 +789,7 @@ static int em_run_impl(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_c
                wa.bufs = p->d_wide_bufs;
                wa.epoch = p->wide_epoch;
                wa.error = d_err;
-               HIP_TRY(sb::launch_wide(r.nslot, wa, r.n_blocks, r.lds_bytes, lanes[lane]));
+               HIP_TRY(sb::launch_wide(wa, r.n_blocks, r.lds_bytes, lanes[lane]));
                in_flight_blocks += r.n_blocks;
                ++lane;
             }
