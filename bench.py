@@ -42,6 +42,9 @@ WORKLOADS = {
     "c2u": "C2-U synthetic: 2000 loci x 8 isoforms x 1000 un-binned fragments (1000 rows)",
     "c3t": "C3-T synthetic: C3 plus a human-annotation-shaped tail of 300 loci with 65-400 isoforms and 200-3000 bins "
            "(the loci a workgroup's registers do not hold: em_wide_kernel)",
+    "c3-chain": "C3-scale chain: 60000 loci (100 gene models laid out 600 times), 2e8 read pairs resident in HBM, through "
+                "fragment x isoform compatibility + bin keys -> bins -> (bin, isoform) pairs -> bin weights -> EM -> theta "
+                "(sbgpu_quantify_device), FPKM / TPM on the host",
     "c5": "C5 synthetic: the C3 law at 4e8 fragments, bias factors 2^U(-1,1) on the weights; fp32 variant of the EM "
           "timed next to the fp64 path (tolerance sweep: tools/c5_sweep.py)",
 }
@@ -164,6 +167,40 @@ def timed_steps(quant, steps, warmup, dev, sdist, torch):
     return float(tmax.item()), ev[0].elapsed_time(ev[1])
 
 
+def chain_main(args, ctx, dev, rank, world, sdist, torch):
+    """--workload c3-chain: the whole path from fragments, hits resident in HBM.  Ranks hold their own sample each
+    (weak scaling); no collective inside the step (the FPKM total is summed on the host arrays)."""
+    from strawberry_amd import chain
+    n_frags = float(os.environ.get("SB_CHAIN_FRAGS", "2e8"))
+    q = chain.ChainQuantifier(ctx, n_loci=60000, n_frags=n_frags, seed=31 + rank)
+    wall, _ = timed_steps(q, args.steps, args.warmup, dev, sdist, torch)
+    counts = torch.tensor([q.n_loci, q.n_frags], dtype=torch.int64, device=dev)
+    sdist.allreduce_sum_(counts)
+    # per-stage device time of one more step (the library prints it on stderr when SBGPU_HOST_TIMING is set)
+    if rank != 0:
+        return
+    ms = wall / args.steps * 1e3
+    b_hit = 9.0 * q.hits.n_features / q.n_frags + 12.0 + 4.0 * (q.annot.compat_words + q.annot.key_words)   # DESIGN 3.5
+    out = {
+        "metric": "loci/s and Mfrags/s, fragments -> abundances chain (C3-scale)", "value": int(counts[0]) * args.steps / wall,
+        "unit": "loci/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 intervals + f64", "data": "synthetic",
+        "mfrags_per_s": int(counts[1]) * args.steps / wall / 1e6,
+        "config": {"workload": WORKLOADS["c3-chain"], "loci_per_gpu": q.n_loci, "fragments_per_gpu": q.n_frags,
+                   "features_per_fragment": q.hits.n_features / q.n_frags, **(q.info or {})},
+        "em_status": {"ok": int((q.status[:q.n_loci] == 0).sum()), "init_empty": int((q.status[:q.n_loci] == 1).sum()),
+                      "denom_zero": int((q.status[:q.n_loci] == 2).sum()), "maxiter": int((q.status[:q.n_loci] == 3).sum()),
+                      "mean_iters": float(q.iters[:q.n_loci].mean())},
+        "roofline": {"bound": "hbm", "kernel": "whole chain (exonbin_kernel + bins_locus_kernel dominate)",
+                     "achieved": b_hit * q.n_frags / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": b_hit * q.n_frags / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes": int(b_hit * q.n_frags),
+                     "note": "algorithmic bytes = the exon-bin kernel's per-hit figure (DESIGN 3.5): features, offsets, words; "
+                             "the step also holds host work (plan, pairs' prefix sums, pdf table): see stage times with SBGPU_HOST_TIMING=1"},
+    }
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,6 +228,9 @@ def main():
     ctx = em.Context(local_rank)
     # the per-step collective: torch.distributed (RCCL) by default, the C ABI's own RCCL binding with SB_COMM=abi
     comm = sdist.AbiComm(ctx) if os.environ.get("SB_COMM") == "abi" and world > 1 else None
+
+    if args.workload == "c3-chain":
+        return chain_main(args, ctx, dev, rank, world, sdist, torch)
 
     def make_quant(b, f32=False, solver=None):
         solver = solver or em.EmBatchSolver(b, ctx)

@@ -458,6 +458,17 @@ int sbgpu_quantify_host(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *annot, const
                         const float *hit_mass, const sbgpu_insert_t *insert, int32_t read_len,
                         int32_t long_read, double *theta_out, int32_t *status_out, int32_t *iters_out,
                         uint32_t *compat_out, sbgpu_insert_t *insert_used, sbgpu_bins_t **bins_out);
+/* The same chain for hits that are in HBM already (a driver that decodes or collapses on the device, or
+ * that quantifies the same fragments again): d_hits' arrays and d_hit_mass are DEVICE pointers, grouped by
+ * locus as locus_hit_off[n_loci + 1] (host) says and sorted inside a locus like HitCluster's uniq_hits();
+ * `annot` holds host pointers; the insert-size law must be given.  The hits take the device grouping
+ * (sbgpu_bins_create_device) -- where that declines (fractional masses, ...) the call returns
+ * SBGPU_EUNSUPPORTED and the caller uses sbgpu_quantify_host.  theta_out / status_out / iters_out are host
+ * arrays; the handle holds the bins (no per-hit bin indices: those stay on the device side).          */
+int sbgpu_quantify_device(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *annot, const sbgpu_hits_t *d_hits,
+                          const float *d_hit_mass, const int64_t *locus_hit_off, const sbgpu_insert_t *insert,
+                          int32_t read_len, int32_t long_read, double *theta_out, int32_t *status_out,
+                          int32_t *iters_out, sbgpu_bins_t **bins_out);
 /* F of the EM batch a handle from sbgpu_quantify_host holds: F_out[info[3]] (row-major per locus). */
 int sbgpu_bins_export_weights(const sbgpu_bins_t *bins, double *F_out);
 

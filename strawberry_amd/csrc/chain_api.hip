@@ -31,13 +31,14 @@ size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 } // namespace
 
-extern "C" {
-
-int sbgpu_quantify_host(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgpu_hits_t *hits, const float *hit_mass,
-                        const sbgpu_insert_t *insert, int32_t read_len, int32_t long_read, double *theta_out,
-                        int32_t *status_out, int32_t *iters_out, uint32_t *compat_out, sbgpu_insert_t *insert_used,
-                        sbgpu_bins_t **bins_out)
+// `dev_hit_off` != nullptr: the hits (hits->..., hit_mass) are DEVICE arrays already, grouped by locus as
+// dev_hit_off[n_loci + 1] (host) says -- sbgpu_quantify_device; else host arrays -- sbgpu_quantify_host.
+static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgpu_hits_t *hits, const float *hit_mass,
+                         const int64_t *dev_hit_off, const sbgpu_insert_t *insert, int32_t read_len, int32_t long_read,
+                         double *theta_out, int32_t *status_out, int32_t *iters_out, uint32_t *compat_out,
+                         sbgpu_insert_t *insert_used, sbgpu_bins_t **bins_out)
 {
+   const bool on_dev = dev_hit_off != nullptr;
    if (!c || !an || !hits || !theta_out || !status_out || !iters_out || !bins_out)
       return api_fail(SBGPU_EINVAL, "sbgpu_quantify_host: null argument");
    *bins_out = nullptr;
@@ -46,8 +47,10 @@ int sbgpu_quantify_host(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgp
    if (!an->iso_off || !an->exon_off || !an->seg_off || (nh && (!hits->hit_locus || !hits->feat_off || !hit_mass)))
       return api_fail(SBGPU_EINVAL, "sbgpu_quantify_host: null array");
    if (!insert && !insert_used) return api_fail(SBGPU_EINVAL, "sbgpu_quantify_host: insert_used is needed when no insert-size law is given");
+   if (on_dev && (!insert || compat_out)) return api_fail(SBGPU_EINVAL, "sbgpu_quantify_device: needs an insert-size law and returns no compat words");
    const int64_t n_iso = an->iso_off[nl], n_exon = an->exon_off[n_iso], n_seg = an->seg_off[nl];
-   const int64_t n_feat = nh ? hits->feat_off[nh] : 0;
+   int64_t n_feat = 0;
+   if (nh && !on_dev) n_feat = hits->feat_off[nh];
    int64_t max_iso = 1, max_seg = 1;
    for (int64_t l = 0; l < nl; ++l) {
       max_iso = std::max(max_iso, an->iso_off[l + 1] - an->iso_off[l]);
@@ -57,13 +60,18 @@ int sbgpu_quantify_host(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgp
    // hits grouped by locus?  (the device grouping needs it; the host one does not)
    bool grouped = true;
    std::vector<int64_t> locus_hit_off((size_t)nl + 1, 0);
-   for (int64_t h = 0; h < nh; ++h) {
+   if (on_dev) {
+      locus_hit_off.assign(dev_hit_off, dev_hit_off + nl + 1);
+      if (locus_hit_off[0] != 0 || locus_hit_off[(size_t)nl] != nh) return api_fail(SBGPU_EINVAL, "sbgpu_quantify_device: locus_hit_off does not cover the hits");
+   }
+   for (int64_t h = 0; h < (on_dev ? 0 : nh); ++h) {
       const int32_t l = hits->hit_locus[h];
       if (l < 0 || l >= nl) return api_fail(SBGPU_EINVAL, "sbgpu_quantify_host: hit_locus out of range");
       if (h && l < hits->hit_locus[h - 1]) grouped = false;
       ++locus_hit_off[(size_t)l + 1];
    }
-   for (int64_t l = 0; l < nl; ++l) locus_hit_off[(size_t)l + 1] += locus_hit_off[(size_t)l];
+   if (!on_dev)
+      for (int64_t l = 0; l < nl; ++l) locus_hit_off[(size_t)l + 1] += locus_hit_off[(size_t)l];
 
    hipStream_t s = sb::ctx_stream(c);
    const bool timing = std::getenv("SBGPU_HOST_TIMING") != nullptr; // diagnostic: stage times on stderr (each stage synchronises)
@@ -92,6 +100,8 @@ int sbgpu_quantify_host(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgp
       {hits->feat_right, (size_t)n_feat * 4, 0}, {hits->feat_code, (size_t)n_feat, 0},
       {hit_mass, (size_t)nh * 4, 0},
    };
+   if (on_dev)
+      for (int k : {3, 8, 9, 10, 11, 12}) parts[k].bytes = 0; // the hits are in HBM already
    size_t total = 0;
    for (Part &p : parts) {
       p.off = total;
@@ -141,12 +151,15 @@ int sbgpu_quantify_host(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgp
    dan.seg_left = (const uint32_t *)(in.p + parts[6].off);
    dan.seg_right = (const uint32_t *)(in.p + parts[7].off);
    sbgpu_hits_t dh = *hits;
-   dh.feat_off = (const int64_t *)(in.p + parts[3].off);
-   dh.hit_locus = (const int32_t *)(in.p + parts[8].off);
-   dh.feat_left = (const uint32_t *)(in.p + parts[9].off);
-   dh.feat_right = (const uint32_t *)(in.p + parts[10].off);
-   dh.feat_code = (const uint8_t *)(in.p + parts[11].off);
-   const float *d_mass = (const float *)(in.p + parts[12].off);
+   const float *d_mass = hit_mass;
+   if (!on_dev) {
+      dh.feat_off = (const int64_t *)(in.p + parts[3].off);
+      dh.hit_locus = (const int32_t *)(in.p + parts[8].off);
+      dh.feat_left = (const uint32_t *)(in.p + parts[9].off);
+      dh.feat_right = (const uint32_t *)(in.p + parts[10].off);
+      dh.feat_code = (const uint8_t *)(in.p + parts[11].off);
+      d_mass = (const float *)(in.p + parts[12].off);
+   }
    uint32_t *d_compat = (uint32_t *)(in.p + o_compat), *d_key = (uint32_t *)(in.p + o_key);
    int64_t *d_hit_bin = (int64_t *)(in.p + o_hbin);
 
@@ -209,6 +222,8 @@ int sbgpu_quantify_host(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgp
       rc = sb::bins_create_device_impl(c, an, &dh, d_mass, locus_hit_off.data(), cw, kw, d_compat, d_key, d_hit_bin, s, &iso_pre, &bins);
    }
    const bool on_device = rc == SBGPU_OK;
+   if (rc == SBGPU_EUNSUPPORTED && on_dev)
+      return api_fail(rc, "sbgpu_quantify_device: the device grouping does not cover these hits (unsorted, fractional masses or a locus of thousands of bins): use sbgpu_quantify_host");
    if (rc == SBGPU_EUNSUPPORTED) {
       SB_RC(need_compat());
       key_h.resize(nh1 * (size_t)kw);
@@ -323,7 +338,7 @@ int sbgpu_quantify_host(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgp
    hipError_t e3 = hipMemcpyAsync(iters_out, w.p + q_it, (size_t)nl * 4, hipMemcpyDeviceToHost, s);
    hipError_t e4 = n_elem ? hipMemcpyAsync(F.data(), w.p + q_F, (size_t)n_elem * 8, hipMemcpyDeviceToHost, s) : hipSuccess;
    hipError_t e5 = hipSuccess;
-   if (on_device && nh) {
+   if (on_device && nh && !on_dev) { // (device hits: the caller did not ask for 8 bytes per hit over PCIe)
       hit_bin.resize((size_t)nh);
       e5 = hipMemcpyAsync(hit_bin.data(), d_hit_bin, (size_t)nh * 8, hipMemcpyDeviceToHost, s);
    }
@@ -339,7 +354,7 @@ int sbgpu_quantify_host(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgp
       SB_RC(need_compat());
       if (nh) std::memcpy(compat_out, compat_h.data(), (size_t)nh * cw * 4);
    }
-   if (on_device && nh) sb::bins_set_hit_bin(bins, std::move(hit_bin));
+   if (on_device && nh && !on_dev) sb::bins_set_hit_bin(bins, std::move(hit_bin));
    if (insert_used) {
       *insert_used = ins;
       if (!insert) {
@@ -359,6 +374,27 @@ int sbgpu_quantify_host(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgp
    guard.b = nullptr;
    *bins_out = bins;
    return SBGPU_OK;
+}
+
+extern "C" {
+
+int sbgpu_quantify_host(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgpu_hits_t *hits, const float *hit_mass,
+                        const sbgpu_insert_t *insert, int32_t read_len, int32_t long_read, double *theta_out,
+                        int32_t *status_out, int32_t *iters_out, uint32_t *compat_out, sbgpu_insert_t *insert_used,
+                        sbgpu_bins_t **bins_out)
+{
+   return quantify_impl(c, an, hits, hit_mass, nullptr, insert, read_len, long_read, theta_out, status_out, iters_out, compat_out,
+                        insert_used, bins_out);
+}
+
+int sbgpu_quantify_device(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgpu_hits_t *d_hits, const float *d_hit_mass,
+                          const int64_t *locus_hit_off, const sbgpu_insert_t *insert, int32_t read_len, int32_t long_read,
+                          double *theta_out, int32_t *status_out, int32_t *iters_out, sbgpu_bins_t **bins_out)
+{
+   if (!locus_hit_off) return api_fail(SBGPU_EINVAL, "sbgpu_quantify_device: null locus_hit_off");
+   sbgpu_insert_t used;
+   return quantify_impl(c, an, d_hits, d_hit_mass, locus_hit_off, insert, read_len, long_read, theta_out, status_out, iters_out,
+                        nullptr, &used, bins_out);
 }
 
 } // extern "C"

@@ -437,3 +437,35 @@ def test_chain_from_fragments_reproduces_reference_run(ctx, oracle, which):
     ref_gtf = open(os.path.join(d, "out.gtf")).read().split("\n", 2)
     assert ref_gtf[0].startswith("#") and ref_gtf[1].startswith("#")   # command line + rule: not data
     assert "".join(gtf_text) == ref_gtf[2]
+
+
+def test_quantify_device_equals_quantify_host_on_tiled_sample():
+    """sbgpu_quantify_device (hits resident in HBM, laid out by torch on the device: strawberry_amd/chain.py) gives
+    the same theta, status and iteration counts as sbgpu_quantify_host on the same hits built on the host."""
+    import torch
+    from strawberry_amd import chain, em, exonbin as eb, synth
+    from strawberry_amd.quantify import InsertSize, quantify_host
+    import exonbin_util as XU
+    ctx = em.default_context(0)
+    q = chain.ChainQuantifier(ctx, n_loci=300, n_frags=300 * 150, base_loci=30, seed=5)
+    q.step()
+    # the same sample on the host: the 30 gene models and their pairs tiled with the tests' own helper
+    loci = synth.make_gene_models(30, seed=5)
+    hl, pairs = synth.make_fragments(loci, 150, seed=6, single=0.0)
+    feats, loc = [], []
+    for l, (lb, rb) in zip(hl, pairs):
+        f = eb.hit_features(lb, rb)
+        if f is not None:
+            feats.append(f)
+            loc.append(l)
+    a0, h0 = eb.Annotation(loci), eb.Hits(loc, feats)
+    stride = int(max(a0.exon_right.max(), h0.feat_right.max()) + 100000)
+    annot, hits = XU.tile(a0, h0, 10, stride=stride)
+    assert hits.n_hits == q.n_frags and annot.n_loci == q.n_loci
+    np.testing.assert_array_equal(q.hits.feat_left.cpu().numpy().view(np.uint32), hits.feat_left)
+    np.testing.assert_array_equal(q.hits.feat_off.cpu().numpy(), hits.feat_off)
+    np.testing.assert_array_equal(q.hits.hit_locus.cpu().numpy(), hits.hit_locus)
+    r = quantify_host(annot, hits, InsertSize(250.0, 30.0), 75, ctx=ctx)
+    np.testing.assert_array_equal(q.status[:q.n_loci], r["status"])
+    np.testing.assert_array_equal(q.iters[:q.n_loci], r["iters"])
+    np.testing.assert_array_equal(q.theta[:q.n_iso], r["theta"])
