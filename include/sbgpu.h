@@ -464,7 +464,8 @@ int sbgpu_quantify_host(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *annot, const
  * `annot` holds host pointers; the insert-size law must be given.  The hits take the device grouping
  * (sbgpu_bins_create_device) -- where that declines (fractional masses, ...) the call returns
  * SBGPU_EUNSUPPORTED and the caller uses sbgpu_quantify_host.  theta_out / status_out / iters_out are host
- * arrays; the handle holds the bins (no per-hit bin indices: those stay on the device side).          */
+ * arrays; the handle holds the bins (no per-hit bin indices and no weights: sbgpu_bins_export_weights on it
+ * fails with SBGPU_EINVAL -- a caller that wants F uses sbgpu_quantify_host).                                       */
 int sbgpu_quantify_device(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *annot, const sbgpu_hits_t *d_hits,
                           const float *d_hit_mass, const int64_t *locus_hit_off, const sbgpu_insert_t *insert,
                           int32_t read_len, int32_t long_read, double *theta_out, int32_t *status_out,

@@ -26,9 +26,13 @@ namespace sb {
 // Two table sizes: loci of up to 256 hits (most of them) take 1024 slots -- 18 KB of LDS, so that many
 // workgroups share a CU and hide each other's memory latency -- the others 8192 (140 KB, one per CU).
 constexpr int kBinsSlotsSmall = 1024, kBinsMaxSmall = 256;   // at most one bin per hit
+constexpr int kBinsSlotsMid = 2048, kBinsMaxMid = 1400;      // larger loci first try this one (36 KB: four workgroups per CU);
+                                                             // a locus with more bins than that is redone with the big table
 constexpr int kBinsSlotsBig = 8192, kBinsMaxBig = 5600;      // ~0.7 load
 constexpr int kBinsSmallHits = 256;
-constexpr int kBinsThreads = 256;
+constexpr int kBinsThreads = 256;      // the small table's workgroup
+constexpr int kBinsThreadsMid = 512;
+constexpr int kBinsThreadsBig = 1024;  // the big table fills a CU's LDS: one workgroup per CU, so it brings 16 waves
 enum : int32_t { kBinsUnsorted = 1, kBinsFractional = 2, kBinsTableFull = 4, kBinsMassOverflow = 8 };
 
 struct BinsArgs {
@@ -97,12 +101,20 @@ __device__ __forceinline__ bool bins_same_fragment(const BinsArgs &a, int64_t x,
    return true;
 }
 
-template <int kBinsSlots, int kBinsMaxPerLocus>
-__global__ __launch_bounds__(kBinsThreads) void bins_locus_kernel(BinsArgs a)
+// RETRY: a locus whose bins do not fit this table is not an error -- it is marked (n_bins = -1, nothing else
+// written that the retry does not overwrite) and the caller runs it again with the next larger table.
+template <int kBinsSlots, int kBinsMaxPerLocus, int kThreads, bool RETRY = false>
+__global__ __launch_bounds__(kThreads) void bins_locus_kernel(BinsArgs a)
 {
    __shared__ unsigned long long tag[kBinsSlots];
    __shared__ int first[kBinsSlots]; // first hit of the bin (min), later its rank
    __shared__ int used[kBinsMaxPerLocus], used_rank[kBinsMaxPerLocus];
+   // A bin's mass and compat union are accumulated in LDS and written once (hundreds of hits of a locus add to the
+   // same few bins: as global atomics those adds serialise at the memory side).  The big table leaves no LDS for
+   // this, and compat unions of more than two words do not fit either: those cases keep the global atomics.
+   constexpr bool kLdsAcc = kBinsSlots <= kBinsSlotsMid;
+   __shared__ int acc_count[kLdsAcc ? kBinsMaxPerLocus : 1];
+   __shared__ unsigned acc_compat[kLdsAcc ? 2 * kBinsMaxPerLocus : 1];
    __shared__ int n_used_slots, n_hits_in, bad;
    const int tid = threadIdx.x;
    for (int64_t li = blockIdx.x; li < a.n_loci; li += gridDim.x) {
@@ -112,7 +124,7 @@ __global__ __launch_bounds__(kBinsThreads) void bins_locus_kernel(BinsArgs a)
       // clear nor scan 4096 slots
       int slots = 64;
       while (slots < kBinsSlots && slots < 4 * (q1 - q0)) slots <<= 1;
-      for (int s = tid; s < slots; s += kBinsThreads) {
+      for (int s = tid; s < slots; s += kThreads) {
          tag[s] = 0ull;
          first[s] = 0x7fffffff;
       }
@@ -121,7 +133,7 @@ __global__ __launch_bounds__(kBinsThreads) void bins_locus_kernel(BinsArgs a)
       const int cw = a.compat_words, kw = a.key_words;
       // ---- pass 1: every hit that has a compatible isoform enters the table
       int my_bad = 0;
-      for (int64_t h = q0 + tid; h < q1; h += kBinsThreads) {
+      for (int64_t h = q0 + tid; h < q1; h += kThreads) {
          const int64_t f0 = a.feat_off[h], f1 = a.feat_off[h + 1];
          if (h > q0 && f1 > f0) { // sorted by (left, right)?  (empty hits carry no position)
             const int64_t g0 = a.feat_off[h - 1], g1 = f0;
@@ -146,33 +158,39 @@ __global__ __launch_bounds__(kBinsThreads) void bins_locus_kernel(BinsArgs a)
       if (my_bad) atomicOr(&bad, my_bad);
       __syncthreads();
       // ---- the bins, ranked by their first hit
-      for (int s = tid; s < slots; s += kBinsThreads)
+      for (int s = tid; s < slots; s += kThreads)
          if (tag[s] != 0ull) {
             const int k = atomicAdd(&n_used_slots, 1);
             if (k < kBinsMaxPerLocus) used[k] = s;
          }
       __syncthreads();
       int nb = n_used_slots;
-      if (nb > kBinsMaxPerLocus) {
-         if (tid == 0) atomicOr(&bad, (int)kBinsTableFull);
-         nb = 0; // the locus is not written; the flag sends the whole batch to the host
+      bool overflow = nb > kBinsMaxPerLocus || (bad & kBinsTableFull);
+      if (overflow) {
+         if (tid == 0 && !RETRY) atomicOr(&bad, (int)kBinsTableFull);
+         nb = 0; // the locus is not written; the flag sends the whole batch to the host (or, RETRY, to the next table)
       }
-      for (int k = tid; k < nb; k += kBinsThreads) {
+      for (int k = tid; k < nb; k += kThreads) {
          const int fk = first[used[k]];
          int r = 0;
          for (int v = 0; v < nb; ++v) r += first[used[v]] < fk; // first hits are distinct: ranks are a permutation
          used_rank[k] = r;
       }
       __syncthreads();
-      for (int k = tid; k < nb; k += kBinsThreads) {
+      const bool lds_acc = kLdsAcc && cw <= 2;
+      for (int k = tid; k < nb; k += kThreads) {
          const int s = used[k];
          a.bin_rep[q0 + used_rank[k]] = (int32_t)(uint32_t)tag[s] - 1; // a member hit, relative to q0
          first[s] = used_rank[k];                                      // from now on: the bin's rank
+         if (lds_acc) {
+            acc_count[k] = 0;
+            acc_compat[2 * k] = acc_compat[2 * k + 1] = 0u;
+         }
       }
       __syncthreads();
       // ---- pass 2: every hit learns its bin; the first of equal fragments adds its mass
       int my_used = 0;
-      for (int64_t h = q0 + tid; h < q1 && nb > 0; h += kBinsThreads) {
+      for (int64_t h = q0 + tid; h < q1 && nb > 0; h += kThreads) {
          a.hit_bin_local[h] = -1;
          uint32_t any_c = 0, any_k = 0;
          for (int w = 0; w < cw; ++w) any_c |= a.compat[h * cw + w];
@@ -183,8 +201,15 @@ __global__ __launch_bounds__(kBinsThreads) void bins_locus_kernel(BinsArgs a)
          const int b = first[slot];
          a.hit_bin_local[h] = b;
          ++my_used;
-         for (int w = 0; w < cw; ++w)
-            if (a.compat[h * cw + w]) atomicOr(&a.bin_compat[(q0 + b) * cw + w], a.compat[h * cw + w]);
+         for (int w = 0; w < cw; ++w) {
+            const uint32_t cv = a.compat[h * cw + w];
+            if (!cv) continue;
+            if (lds_acc) {
+               if ((acc_compat[2 * b + w] & cv) != cv) atomicOr(&acc_compat[2 * b + w], cv);
+            } else {
+               atomicOr(&a.bin_compat[(q0 + b) * cw + w], cv);
+            }
+         }
          // std::set<Contig>: an equal fragment already in this bin?  Only its (left, right) run can hold one.
          const int64_t f0 = a.feat_off[h], f1 = a.feat_off[h + 1];
          const uint32_t cl = a.feat_left[f0], cr = a.feat_right[f1 - 1];
@@ -201,15 +226,26 @@ __global__ __launch_bounds__(kBinsThreads) void bins_locus_kernel(BinsArgs a)
             const int ps = bins_find<false>(tag, slots, a, q0, p, a.key + p * kw);
             dup = ps >= 0 && first[ps] == b;
          }
-         if (!dup) atomicAdd(&a.bin_count[q0 + b], (int)a.mass[h]);
+         if (!dup) {
+            if (lds_acc) atomicAdd(&acc_count[b], (int)a.mass[h]);
+            else atomicAdd(&a.bin_count[q0 + b], (int)a.mass[h]);
+         }
+      }
+      if (lds_acc) {
+         __syncthreads();
+         for (int b = tid; b < nb; b += kThreads) {
+            a.bin_count[q0 + b] = acc_count[b];
+            for (int w = 0; w < cw; ++w) a.bin_compat[(q0 + b) * cw + w] = acc_compat[2 * b + w];
+         }
       }
       if (nb == 0)
-         for (int64_t h = q0 + tid; h < q1; h += kBinsThreads) a.hit_bin_local[h] = -1;
+         for (int64_t h = q0 + tid; h < q1; h += kThreads) a.hit_bin_local[h] = -1;
       if (my_used) atomicAdd(&n_hits_in, my_used);
       __syncthreads();
       if (tid == 0) {
-         a.n_bins[l] = nb;
+         a.n_bins[l] = (RETRY && overflow) ? -1 : nb;
          a.n_used[l] = n_hits_in;
+         if (RETRY && overflow) bad &= ~(int)kBinsTableFull;
          if (bad) atomicOr(a.flags, bad);
       }
       __syncthreads();

@@ -331,12 +331,12 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
       sbgpu_plan_destroy(plan);
       return rc;
    }
-   std::vector<double> F((size_t)n_elem);
+   std::vector<double> F(on_dev ? (size_t)0 : (size_t)n_elem); // (device entry: the weights are not brought back)
    std::vector<int64_t> hit_bin;
    hipError_t e1 = hipMemcpyAsync(theta_out, w.p + q_theta, (size_t)n_iso * 8, hipMemcpyDeviceToHost, s);
    hipError_t e2 = hipMemcpyAsync(status_out, w.p + q_st, (size_t)nl * 4, hipMemcpyDeviceToHost, s);
    hipError_t e3 = hipMemcpyAsync(iters_out, w.p + q_it, (size_t)nl * 4, hipMemcpyDeviceToHost, s);
-   hipError_t e4 = n_elem ? hipMemcpyAsync(F.data(), w.p + q_F, (size_t)n_elem * 8, hipMemcpyDeviceToHost, s) : hipSuccess;
+   hipError_t e4 = (n_elem && !on_dev) ? hipMemcpyAsync(F.data(), w.p + q_F, (size_t)n_elem * 8, hipMemcpyDeviceToHost, s) : hipSuccess;
    hipError_t e5 = hipSuccess;
    if (on_device && nh && !on_dev) { // (device hits: the caller did not ask for 8 bytes per hit over PCIe)
       hit_bin.resize((size_t)nh);

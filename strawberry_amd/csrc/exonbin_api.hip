@@ -319,15 +319,16 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
    if (n_small) {
       a.n_loci = n_small;
       a.loci = (const int32_t *)(d + o_order);
-      hipLaunchKernelGGL((sb::bins_locus_kernel<sb::kBinsSlotsSmall, sb::kBinsMaxSmall>), dim3((unsigned)std::min<int64_t>(n_small, cap * 4)),
+      hipLaunchKernelGGL((sb::bins_locus_kernel<sb::kBinsSlotsSmall, sb::kBinsMaxSmall, sb::kBinsThreads>), dim3((unsigned)std::min<int64_t>(n_small, cap * 4)),
                          dim3(sb::kBinsThreads), 0, s, a);
       SB_TRY(hipGetLastError());
    }
    if (n_big) {
+      // first the middle table (four workgroups per CU); whatever has more bins than it holds is redone below
       a.n_loci = n_big;
       a.loci = (const int32_t *)(d + o_order) + n_small;
-      hipLaunchKernelGGL((sb::bins_locus_kernel<sb::kBinsSlotsBig, sb::kBinsMaxBig>), dim3((unsigned)std::min<int64_t>(n_big, cap)),
-                         dim3(sb::kBinsThreads), 0, s, a);
+      hipLaunchKernelGGL((sb::bins_locus_kernel<sb::kBinsSlotsMid, sb::kBinsMaxMid, sb::kBinsThreadsMid, true>),
+                         dim3((unsigned)std::min<int64_t>(n_big, cap * 4)), dim3(sb::kBinsThreadsMid), 0, s, a);
    }
    SB_TRY(hipGetLastError());
    std::vector<int32_t> nb((size_t)nl), nu((size_t)nl);
@@ -336,6 +337,24 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
    SB_TRY(hipMemcpyAsync(nu.data(), d + o_nu, (size_t)nl * 4, hipMemcpyDeviceToHost, s));
    SB_TRY(hipMemcpyAsync(&flags, d + o_flag, 4, hipMemcpyDeviceToHost, s));
    SB_TRY(hipStreamSynchronize(s));
+   {
+      // loci the middle table could not hold: again, with the big one
+      std::vector<int32_t> redo;
+      for (int64_t l = 0; l < nl; ++l)
+         if (nb[(size_t)l] < 0) redo.push_back((int32_t)l);
+      if (!redo.empty()) {
+         SB_TRY(hipMemcpyAsync(d + o_order, redo.data(), redo.size() * 4, hipMemcpyHostToDevice, s));
+         a.n_loci = (int64_t)redo.size();
+         a.loci = (const int32_t *)(d + o_order);
+         hipLaunchKernelGGL((sb::bins_locus_kernel<sb::kBinsSlotsBig, sb::kBinsMaxBig, sb::kBinsThreadsBig>),
+                            dim3((unsigned)std::min<int64_t>((int64_t)redo.size(), cap)), dim3(sb::kBinsThreadsBig), 0, s, a);
+         SB_TRY(hipGetLastError());
+         SB_TRY(hipMemcpyAsync(nb.data(), d + o_nb, (size_t)nl * 4, hipMemcpyDeviceToHost, s));
+         SB_TRY(hipMemcpyAsync(nu.data(), d + o_nu, (size_t)nl * 4, hipMemcpyDeviceToHost, s));
+         SB_TRY(hipMemcpyAsync(&flags, d + o_flag, 4, hipMemcpyDeviceToHost, s));
+         SB_TRY(hipStreamSynchronize(s));
+      }
+   }
    if (flags) {
       std::string why = "sbgpu_bins_create_device: not covered by the device form:";
       if (flags & sb::kBinsUnsorted) why += " hits of a locus are not sorted by (left, right);";
