@@ -33,7 +33,7 @@ constexpr int kBinsSmallHits = 256;
 constexpr int kBinsThreads = 256;      // the small table's workgroup
 constexpr int kBinsThreadsMid = 512;
 constexpr int kBinsThreadsBig = 1024;  // the big table fills a CU's LDS: one workgroup per CU, so it brings 16 waves
-enum : int32_t { kBinsUnsorted = 1, kBinsFractional = 2, kBinsTableFull = 4, kBinsMassOverflow = 8 };
+enum : int32_t { kBinsUnsorted = 1, kBinsFractional = 2, kBinsTableFull = 4, kBinsMassOverflow = 8, kBinsRunTooLong = 128 };
 
 struct BinsArgs {
    int64_t n_loci;               // loci in `loci`
@@ -49,6 +49,7 @@ struct BinsArgs {
    int32_t *bin_rep;        // [n_hits] a member hit of the bin (its key words are the bin's)
    int32_t *bin_count;      // [n_hits] zeroed by the caller
    uint32_t *bin_compat;    // [n_hits * compat_words] zeroed by the caller
+   uint8_t *dup;            // [n_hits] 1: an equal fragment of the same bin came earlier (std::set keeps that one)
    int32_t *n_bins;         // [n_loci]
    int32_t *n_used;         // [n_loci] hits that landed in a bin
    int32_t *flags;          // [1] OR of kBins*
@@ -226,6 +227,7 @@ __global__ __launch_bounds__(kThreads) void bins_locus_kernel(BinsArgs a)
             const int ps = bins_find<false>(tag, slots, a, q0, p, a.key + p * kw);
             dup = ps >= 0 && first[ps] == b;
          }
+         a.dup[h] = dup ? 1 : 0;
          if (!dup) {
             if (lds_acc) atomicAdd(&acc_count[b], (int)a.mass[h]);
             else atomicAdd(&a.bin_count[q0 + b], (int)a.mass[h]);
@@ -249,6 +251,76 @@ __global__ __launch_bounds__(kThreads) void bins_locus_kernel(BinsArgs a)
          if (bad) atomicOr(a.flags, bad);
       }
       __syncthreads();
+   }
+}
+
+// ------------------------------------------------------------------ fractional masses
+// With multi-mapped reads (--allow-multimapped-hits) a hit's mass is a sum of 1, 1/2, 1/3, ...; ExonBin::read_count
+// (/root/reference/include/isoform.h:285-296) adds the masses of a bin's distinct fragments IN FLOAT, in the order
+// of its std::set<Contig> -- Contig::operator< (src/contig.cpp:342-347): the feature lists compared (offset, length)
+// by (offset, length), a proper prefix first -- and LocusContext truncates the sum to int (src/estimate.cpp:288).
+// Float addition is not associative and the truncation can turn a last-bit difference into a different count, so
+// the order is reproduced: hits come sorted by their left end, which is also the set order's leading key, so the
+// set order differs from the hit order only INSIDE a run of hits with the same left end.  One thread per bin walks
+// the locus' hits (every thread of the workgroup reads the same hit at the same time: the loads broadcast),
+// keeps the members of its bin of the current run, and when the run ends sorts those few by the set's order and
+// adds their masses.  A bin with more than kBinsRunCap members in one run raises a flag (the caller then groups on
+// the host).
+constexpr int kBinsRunCap = 48;
+
+__device__ __forceinline__ int bins_frag_cmp(const BinsArgs &a, int64_t x, int64_t y)
+{
+   const int64_t fx = a.feat_off[x], fy = a.feat_off[y];
+   const int64_t nx = a.feat_off[x + 1] - fx, ny = a.feat_off[y + 1] - fy, n = nx < ny ? nx : ny;
+   for (int64_t i = 0; i < n; ++i) {
+      const uint32_t lx = a.feat_left[fx + i], ly = a.feat_left[fy + i];
+      if (lx != ly) return lx < ly ? -1 : 1;
+      const uint32_t wx = a.feat_right[fx + i] - lx, wy = a.feat_right[fy + i] - ly;
+      if (wx != wy) return wx < wy ? -1 : 1;
+   }
+   return nx == ny ? 0 : (nx < ny ? -1 : 1);
+}
+
+__global__ __launch_bounds__(256) void bins_ordered_mass_kernel(BinsArgs a)
+{
+   for (int64_t li = blockIdx.x; li < a.n_loci; li += gridDim.x) {
+      const int64_t l = a.loci[li];
+      const int64_t q0 = a.locus_hit_off[l], q1 = a.locus_hit_off[l + 1];
+      const int nb = a.n_bins[l];
+      for (int b0 = 0; b0 < nb; b0 += 256) {
+         const int b = b0 + (int)threadIdx.x; // this thread's bin (threads beyond nb walk along idle)
+         int run[kBinsRunCap];
+         int n_run = 0, too_long = 0;
+         uint32_t run_left = 0;
+         float sum = 0.0f;
+         auto flush = [&]() {
+            for (int k = 0; k < n_run; ++k) sum += a.mass[q0 + run[k]]; // the set's order inside the run
+            n_run = 0;
+         };
+         for (int64_t h = q0; h < q1; ++h) {
+            const int hb = a.hit_bin_local[h]; // workgroup-uniform loads: every thread looks at the same hit
+            if (hb < 0 || a.dup[h]) continue;
+            if (hb != b) continue;
+            const uint32_t left = a.feat_left[a.feat_off[h]];
+            if (n_run && left != run_left) flush();
+            run_left = left;
+            if (n_run == kBinsRunCap) {
+               too_long = 1;
+               continue;
+            }
+            // stable insertion by Contig::operator<: behind every member that is not greater
+            int pos = n_run;
+            while (pos > 0 && bins_frag_cmp(a, q0 + run[pos - 1], h) > 0) {
+               run[pos] = run[pos - 1];
+               --pos;
+            }
+            run[pos] = (int)(h - q0);
+            ++n_run;
+         }
+         flush();
+         if (b < nb) a.bin_count[q0 + b] = (int)sum; // (int) float: estimate.cpp:288
+         if (too_long) atomicOr(a.flags, (int)kBinsRunTooLong);
+      }
    }
 }
 

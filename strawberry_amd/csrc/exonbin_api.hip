@@ -272,6 +272,7 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
    const size_t o_hoff = off; off += up((size_t)(nl + 1) * 8);
    const size_t o_roff = off; off += up((size_t)(nl + 1) * 8);
    const size_t o_order = off; off += up((size_t)nl * 4);
+   const size_t o_dup = off; off += up(nh1);
    char *d = nullptr, *d2 = nullptr;
    hipError_t e = hipMalloc(&d, off);
    if (e != hipSuccess) return api_fail(e == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e));
@@ -303,6 +304,7 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
    a.bin_rep = (int32_t *)(d + o_rep);
    a.bin_count = (int32_t *)(d + o_cnt);
    a.bin_compat = (uint32_t *)(d + o_cmp);
+   a.dup = (uint8_t *)(d + o_dup);
    a.n_bins = (int32_t *)(d + o_nb);
    a.n_used = (int32_t *)(d + o_nu);
    a.flags = (int32_t *)(d + o_flag);
@@ -355,11 +357,26 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
          SB_TRY(hipStreamSynchronize(s));
       }
    }
+   if (flags == sb::kBinsFractional) {
+      // fractional masses (multi-mapped reads): the bins stand, their masses are summed again in float, in the
+      // order of the reference's std::set (bins_device.h)
+      std::vector<int32_t> all((size_t)nl);
+      for (int64_t l = 0; l < nl; ++l) all[(size_t)l] = (int32_t)l;
+      SB_TRY(hipMemcpyAsync(d + o_order, all.data(), (size_t)nl * 4, hipMemcpyHostToDevice, s));
+      SB_TRY(hipMemsetAsync(d + o_flag, 0, 4, s));
+      a.n_loci = nl;
+      a.loci = (const int32_t *)(d + o_order);
+      hipLaunchKernelGGL(sb::bins_ordered_mass_kernel, dim3((unsigned)std::min<int64_t>(nl, cap * 4)), dim3(256), 0, s, a);
+      SB_TRY(hipGetLastError());
+      SB_TRY(hipMemcpyAsync(&flags, d + o_flag, 4, hipMemcpyDeviceToHost, s));
+      SB_TRY(hipStreamSynchronize(s));
+   }
    if (flags) {
       std::string why = "sbgpu_bins_create_device: not covered by the device form:";
       if (flags & sb::kBinsUnsorted) why += " hits of a locus are not sorted by (left, right);";
-      if (flags & sb::kBinsFractional) why += " fractional hit masses;";
+      if (flags & sb::kBinsFractional) why += " fractional hit masses next to another obstacle;";
       if (flags & sb::kBinsTableFull) why += " a locus has more bins than the LDS table holds;";
+      if (flags & sb::kBinsRunTooLong) why += " fractional masses and more than 48 fragments of one bin starting at one position;";
       return bail(SBGPU_EUNSUPPORTED, why + " use sbgpu_bins_create");
    }
    stage("group kernel");
