@@ -388,6 +388,29 @@ int sbgpu_uniq_info(const sbgpu_uniq_t *u, int64_t info[8]);
 int sbgpu_uniq_export(const sbgpu_uniq_t *u, int32_t *hit_locus, int64_t *feat_off, uint8_t *feat_code,
                       uint32_t *feat_left, uint32_t *feat_right, float *hit_mass, double *cluster_mass);
 
+/* The same on the GPU (csrc/collapse_device.h): the pairs' arrays of `d_pairs` are DEVICE pointers (pair_locus is
+ * not read), grouped by locus as locus_pair_off[n_loci + 1] (host) says; the unique hits stay in HBM in
+ * sbgpu_hits_t layout -- sbgpu_uniq_dev_hits hands them to sbgpu_exonbin_device / sbgpu_quantify_device -- and
+ * only the per-locus counts and cluster masses come back.  One workgroup per locus sorts its pairs in LDS
+ * ((left, right), ties in input order), applies the span filter, collapses equal neighbours (masses added in
+ * double, in that order) and builds Contig(PairedHit)'s features.  Covers loci of up to 4096 pairs and mates of up
+ * to 24 features; otherwise SBGPU_EUNSUPPORTED (use sbgpu_collapse_pairs_host).  Synchronises on `stream`.
+ * The span filter evaluates phi() with the device's exp(): a pair exactly on the 0.999 boundary could fall on the
+ * other side than with the host's libm (not observed).                                                        */
+typedef struct sbgpu_uniq_dev sbgpu_uniq_dev_t;
+int sbgpu_collapse_pairs_device(sbgpu_ctx_t *ctx, int64_t n_loci, const sbgpu_pairs_t *d_pairs,
+                                const int64_t *locus_pair_off, void *stream, sbgpu_uniq_dev_t **out);
+void sbgpu_uniq_dev_destroy(sbgpu_uniq_dev_t *u);
+/* info as sbgpu_uniq_info */
+int sbgpu_uniq_dev_info(const sbgpu_uniq_dev_t *u, int64_t info[8]);
+/* The unique hits where they are: *d_hits gets device pointers, *d_hit_mass the (float) collapse masses
+ * (device), *locus_hit_off [n_loci + 1] (host): the arguments of sbgpu_quantify_device.  Owned by the handle. */
+int sbgpu_uniq_dev_hits(const sbgpu_uniq_dev_t *u, sbgpu_hits_t *d_hits, const float **d_hit_mass,
+                        const int64_t **locus_hit_off);
+/* Host copies (as sbgpu_uniq_export; NULL = skip). */
+int sbgpu_uniq_dev_export(const sbgpu_uniq_dev_t *u, int32_t *hit_locus, int64_t *feat_off, uint8_t *feat_code,
+                          uint32_t *feat_left, uint32_t *feat_right, float *hit_mass, double *cluster_mass);
+
 /* LocusContext::assign_exon_bin + set_maps (src/estimate.cpp:135-198, estimate.hpp:29-52)
  * on the kernel's results (host copies of compat / key), hits visited in input order inside
  * each locus (= HitCluster::uniq_hits() order):

@@ -28,7 +28,8 @@ SYMBOLS = [
     "sbgpu_insert_pdf_table", "sbgpu_binweight_device", "sbgpu_binweight_host",
     "sbgpu_exonbin_device", "sbgpu_exonbin_host", "sbgpu_segments_host", "sbgpu_hit_features", "sbgpu_frag_lens_host",
     "sbgpu_bins_create", "sbgpu_bins_create_device", "sbgpu_bins_destroy", "sbgpu_quantify_host", "sbgpu_quantify_device",
-    "sbgpu_bins_export_weights", "sbgpu_collapse_pairs_host", "sbgpu_uniq_destroy", "sbgpu_uniq_info", "sbgpu_uniq_export", "sbgpu_bins_info", "sbgpu_bins_export",
+    "sbgpu_bins_export_weights", "sbgpu_collapse_pairs_host", "sbgpu_uniq_destroy", "sbgpu_uniq_info", "sbgpu_uniq_export",
+    "sbgpu_collapse_pairs_device", "sbgpu_uniq_dev_destroy", "sbgpu_uniq_dev_info", "sbgpu_uniq_dev_hits", "sbgpu_uniq_dev_export", "sbgpu_bins_info", "sbgpu_bins_export",
     "sbgpu_format_value", "sbgpu_format_gtf_transcript", "sbgpu_format_context_row", "sbgpu_format_context_row_seq",
     "sbgpu_binseq_device", "sbgpu_binseq_host", "sbgpu_em_batch", "sbgpu_abundance_device", "sbgpu_tpm_device",
 ]
@@ -181,6 +182,12 @@ def load():
                                         C.c_int32, C.c_int32, vp, vp, vp, C.POINTER(vp)]
     L.sbgpu_bins_export_weights.argtypes = [vp, vp]
     L.sbgpu_collapse_pairs_host.argtypes = [C.c_int64, C.POINTER(sbgpu_pairs_t), C.POINTER(vp)]
+    L.sbgpu_collapse_pairs_device.argtypes = [vp, C.c_int64, C.POINTER(sbgpu_pairs_t), vp, vp, C.POINTER(vp)]
+    L.sbgpu_uniq_dev_destroy.argtypes = [vp]
+    L.sbgpu_uniq_dev_destroy.restype = None
+    L.sbgpu_uniq_dev_info.argtypes = [vp, i64p]
+    L.sbgpu_uniq_dev_hits.argtypes = [vp, C.POINTER(sbgpu_hits_t), C.POINTER(vp), C.POINTER(vp)]
+    L.sbgpu_uniq_dev_export.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.sbgpu_uniq_destroy.argtypes = [vp]
     L.sbgpu_uniq_destroy.restype = None
     L.sbgpu_uniq_info.argtypes = [vp, i64p]

@@ -1,0 +1,228 @@
+// strawberry_amd/csrc/collapse_api.hip -- sbgpu_collapse_pairs_device (include/sbgpu.h): read pairs resident in
+// HBM -> unique hits resident in HBM (HitCluster::collapseAndFilterHits + Contig(PairedHit),
+// /root/reference/src/alignments.cpp:656-703, src/contig.cpp:216-267).  Kernels: collapse_device.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/sbgpu.h"
+#include "api_internal.h"
+#include "collapse_device.h"
+
+using sb::api_fail;
+
+struct sbgpu_uniq_dev {
+   int device = 0;
+   char *arena = nullptr; // the unique hits (sbgpu_hits_t layout) + their masses
+   int64_t n_loci = 0, n_hits = 0, n_feat = 0, n_filtered = 0, n_rejected = 0, total_mapped = 0;
+   int32_t *d_hit_locus = nullptr;
+   int64_t *d_feat_off = nullptr;
+   uint8_t *d_feat_code = nullptr;
+   uint32_t *d_feat_left = nullptr, *d_feat_right = nullptr;
+   float *d_mass = nullptr;
+   std::vector<int64_t> locus_hit_off; // host
+   std::vector<double> cluster_mass;   // host
+};
+
+namespace {
+size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
+} // namespace
+
+extern "C" {
+
+void sbgpu_uniq_dev_destroy(sbgpu_uniq_dev_t *u)
+{
+   if (!u) return;
+   (void)hipSetDevice(u->device);
+   (void)hipFree(u->arena);
+   delete u;
+}
+
+int sbgpu_collapse_pairs_device(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_pairs_t *dp, const int64_t *locus_pair_off,
+                                void *stream, sbgpu_uniq_dev_t **out)
+{
+   if (!c || !dp || !out || !locus_pair_off || n_loci < 0) return api_fail(SBGPU_EINVAL, "sbgpu_collapse_pairs_device: bad argument");
+   *out = nullptr;
+   const int64_t np = dp->n_pairs;
+   if (np < 0 || locus_pair_off[0] != 0 || locus_pair_off[n_loci] != np)
+      return api_fail(SBGPU_EINVAL, "sbgpu_collapse_pairs_device: locus_pair_off does not cover the pairs");
+   if (np && (!dp->pair_mass || !dp->left_off || !dp->right_off)) return api_fail(SBGPU_EINVAL, "sbgpu_collapse_pairs_device: null array");
+   for (int64_t l = 0; l < n_loci; ++l)
+      if (locus_pair_off[l + 1] < locus_pair_off[l]) return api_fail(SBGPU_EINVAL, "sbgpu_collapse_pairs_device: locus_pair_off must ascend");
+   hipStream_t s = (hipStream_t)stream;
+   sbgpu_uniq_dev *U = new (std::nothrow) sbgpu_uniq_dev();
+   if (!U) return api_fail(SBGPU_ENOMEM, "sbgpu_collapse_pairs_device: out of host memory");
+   U->device = sb::ctx_device(c);
+   U->n_loci = n_loci;
+   U->locus_hit_off.assign((size_t)n_loci + 1, 0);
+   U->cluster_mass.assign((size_t)n_loci, 0.0);
+   char *w = nullptr; // scratch
+   auto bail = [&](int code, const std::string &msg) {
+      (void)hipFree(w);
+      sbgpu_uniq_dev_destroy(U);
+      return api_fail(code, msg);
+   };
+#define SB_TRY(expr)                                                                                     \
+   do {                                                                                                  \
+      hipError_t e_ = (expr);                                                                            \
+      if (e_ != hipSuccess) return bail(e_ == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+   } while (0)
+   if (np == 0 || n_loci == 0) {
+      *out = U;
+      return SBGPU_OK;
+   }
+   SB_TRY(hipSetDevice(U->device));
+   const size_t np1 = (size_t)np, nl1 = (size_t)n_loci + 1;
+   size_t off = 0;
+   const size_t o_poff = off; off += up256(nl1 * 8);
+   const size_t o_order = off; off += up256(np1 * 4);
+   const size_t o_nfeat = off; off += up256(np1 * 4);
+   const size_t o_mass = off; off += up256(np1 * 4);
+   const size_t o_cm = off; off += up256(nl1 * 8);
+   const size_t o_nh = off; off += up256(nl1 * 4);
+   const size_t o_nf = off; off += up256(nl1 * 4);
+   const size_t o_nfi = off; off += up256(nl1 * 4);
+   const size_t o_nr = off; off += up256(nl1 * 4);
+   const size_t o_flag = off; off += 256;
+   const size_t o_hoff = off; off += up256(nl1 * 8);
+   const size_t o_fbase = off; off += up256(nl1 * 8);
+   SB_TRY(hipMalloc(&w, off));
+   SB_TRY(hipMemsetAsync(w + o_flag, 0, 256, s));
+   SB_TRY(hipMemcpyAsync(w + o_poff, locus_pair_off, nl1 * 8, hipMemcpyHostToDevice, s));
+   sb::CollapseArgs a = {};
+   a.n_loci = n_loci;
+   a.locus_pair_off = (const int64_t *)(w + o_poff);
+   a.pair_mass = dp->pair_mass;
+   a.left_off = dp->left_off, a.right_off = dp->right_off;
+   a.left_code = dp->left_code, a.right_code = dp->right_code;
+   a.left_left = dp->left_left, a.left_right = dp->left_right;
+   a.right_left = dp->right_left, a.right_right = dp->right_right;
+   a.order = (int32_t *)(w + o_order);
+   a.nfeat = (int32_t *)(w + o_nfeat);
+   a.mass = (float *)(w + o_mass);
+   a.cluster_mass = (double *)(w + o_cm);
+   a.n_hits = (int32_t *)(w + o_nh);
+   a.n_feats = (int32_t *)(w + o_nf);
+   a.n_filtered = (int32_t *)(w + o_nfi);
+   a.n_rejected = (int32_t *)(w + o_nr);
+   a.flags = (int32_t *)(w + o_flag);
+   const unsigned grid = (unsigned)std::min<int64_t>(n_loci, (int64_t)sb::ctx_cu_count(c) * 8);
+   hipLaunchKernelGGL(sb::collapse_locus_kernel, dim3(grid), dim3(sb::kCollapseThreads), 0, s, a);
+   SB_TRY(hipGetLastError());
+   std::vector<int32_t> nh((size_t)n_loci), nf((size_t)n_loci), nfi((size_t)n_loci), nr((size_t)n_loci);
+   int32_t flags = 0;
+   SB_TRY(hipMemcpyAsync(nh.data(), w + o_nh, (size_t)n_loci * 4, hipMemcpyDeviceToHost, s));
+   SB_TRY(hipMemcpyAsync(nf.data(), w + o_nf, (size_t)n_loci * 4, hipMemcpyDeviceToHost, s));
+   SB_TRY(hipMemcpyAsync(nfi.data(), w + o_nfi, (size_t)n_loci * 4, hipMemcpyDeviceToHost, s));
+   SB_TRY(hipMemcpyAsync(nr.data(), w + o_nr, (size_t)n_loci * 4, hipMemcpyDeviceToHost, s));
+   SB_TRY(hipMemcpyAsync(U->cluster_mass.data(), w + o_cm, (size_t)n_loci * 8, hipMemcpyDeviceToHost, s));
+   SB_TRY(hipMemcpyAsync(&flags, w + o_flag, 4, hipMemcpyDeviceToHost, s));
+   SB_TRY(hipStreamSynchronize(s));
+   if (flags) {
+      std::string why = "sbgpu_collapse_pairs_device: not covered by the device form:";
+      if (flags & sb::kCollapseTooMany) why += " a locus has more than 4096 read pairs;";
+      if (flags & sb::kCollapseLongMate) why += " a mate has more than 24 features;";
+      if (flags & sb::kCollapseNoMates) return bail(SBGPU_EINVAL, "sbgpu_collapse_pairs_device: a pair without mates");
+      return bail(SBGPU_EUNSUPPORTED, why + " use sbgpu_collapse_pairs_host");
+   }
+   std::vector<int64_t> feat_base((size_t)n_loci + 1, 0);
+   for (int64_t l = 0; l < n_loci; ++l) {
+      U->locus_hit_off[(size_t)l + 1] = U->locus_hit_off[(size_t)l] + nh[(size_t)l];
+      feat_base[(size_t)l + 1] = feat_base[(size_t)l] + nf[(size_t)l];
+      U->n_filtered += nfi[(size_t)l];
+      U->n_rejected += nr[(size_t)l];
+      U->total_mapped += (int64_t)(int)U->cluster_mass[(size_t)l]; // src/alignments.cpp:1372
+   }
+   U->n_hits = U->locus_hit_off[(size_t)n_loci];
+   U->n_feat = feat_base[(size_t)n_loci];
+   // ---- the unique hits' own arena
+   const size_t nh1 = (size_t)U->n_hits + 1, nfe1 = (size_t)U->n_feat + 1;
+   size_t t = 0;
+   const size_t u_off = t; t += up256(nh1 * 8);
+   const size_t u_loc = t; t += up256(nh1 * 4);
+   const size_t u_mass = t; t += up256(nh1 * 4);
+   const size_t u_left = t; t += up256(nfe1 * 4);
+   const size_t u_right = t; t += up256(nfe1 * 4);
+   const size_t u_code = t; t += up256(nfe1);
+   SB_TRY(hipMalloc(&U->arena, t));
+   U->d_feat_off = (int64_t *)(U->arena + u_off);
+   U->d_hit_locus = (int32_t *)(U->arena + u_loc);
+   U->d_mass = (float *)(U->arena + u_mass);
+   U->d_feat_left = (uint32_t *)(U->arena + u_left);
+   U->d_feat_right = (uint32_t *)(U->arena + u_right);
+   U->d_feat_code = (uint8_t *)(U->arena + u_code);
+   SB_TRY(hipMemcpyAsync(w + o_hoff, U->locus_hit_off.data(), nl1 * 8, hipMemcpyHostToDevice, s));
+   SB_TRY(hipMemcpyAsync(w + o_fbase, feat_base.data(), nl1 * 8, hipMemcpyHostToDevice, s));
+   SB_TRY(hipMemcpyAsync(U->d_feat_off + U->n_hits, &U->n_feat, 8, hipMemcpyHostToDevice, s));
+   a.hit_off = (const int64_t *)(w + o_hoff);
+   a.feat_base = (const int64_t *)(w + o_fbase);
+   a.hit_locus = U->d_hit_locus;
+   a.feat_off = U->d_feat_off;
+   a.feat_code = U->d_feat_code;
+   a.feat_left = U->d_feat_left;
+   a.feat_right = U->d_feat_right;
+   a.hit_mass = U->d_mass;
+   hipLaunchKernelGGL(sb::collapse_fill_kernel, dim3(grid), dim3(sb::kCollapseThreads), 0, s, a);
+   SB_TRY(hipGetLastError());
+   SB_TRY(hipStreamSynchronize(s)); // the scratch goes away
+#undef SB_TRY
+   (void)hipFree(w);
+   *out = U;
+   return SBGPU_OK;
+}
+
+int sbgpu_uniq_dev_info(const sbgpu_uniq_dev_t *u, int64_t info[8])
+{
+   if (!u || !info) return api_fail(SBGPU_EINVAL, "sbgpu_uniq_dev_info: null argument");
+   info[0] = u->n_hits;
+   info[1] = u->n_feat;
+   info[2] = u->n_filtered;
+   info[3] = u->n_rejected;
+   info[4] = u->total_mapped;
+   info[5] = u->n_loci;
+   info[6] = info[7] = 0;
+   return SBGPU_OK;
+}
+
+int sbgpu_uniq_dev_hits(const sbgpu_uniq_dev_t *u, sbgpu_hits_t *d_hits, const float **d_hit_mass, const int64_t **locus_hit_off)
+{
+   if (!u || !d_hits) return api_fail(SBGPU_EINVAL, "sbgpu_uniq_dev_hits: null argument");
+   d_hits->n_hits = u->n_hits;
+   d_hits->hit_locus = u->d_hit_locus;
+   d_hits->feat_off = u->d_feat_off;
+   d_hits->feat_code = u->d_feat_code;
+   d_hits->feat_left = u->d_feat_left;
+   d_hits->feat_right = u->d_feat_right;
+   if (d_hit_mass) *d_hit_mass = u->d_mass;
+   if (locus_hit_off) *locus_hit_off = u->locus_hit_off.data();
+   return SBGPU_OK;
+}
+
+int sbgpu_uniq_dev_export(const sbgpu_uniq_dev_t *u, int32_t *hit_locus, int64_t *feat_off, uint8_t *feat_code, uint32_t *feat_left,
+                          uint32_t *feat_right, float *hit_mass, double *cluster_mass)
+{
+   if (!u) return api_fail(SBGPU_EINVAL, "sbgpu_uniq_dev_export: null argument");
+   hipError_t e = hipSetDevice(u->device);
+   auto get = [&](void *dst, const void *src, size_t bytes) {
+      if (e == hipSuccess && dst && bytes) e = hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
+   };
+   if (u->arena) {
+      get(hit_locus, u->d_hit_locus, (size_t)u->n_hits * 4);
+      get(feat_off, u->d_feat_off, (size_t)(u->n_hits + 1) * 8);
+      get(feat_code, u->d_feat_code, (size_t)u->n_feat);
+      get(feat_left, u->d_feat_left, (size_t)u->n_feat * 4);
+      get(feat_right, u->d_feat_right, (size_t)u->n_feat * 4);
+      get(hit_mass, u->d_mass, (size_t)u->n_hits * 4);
+   } else if (feat_off) {
+      feat_off[0] = 0;
+   }
+   if (cluster_mass && !u->cluster_mass.empty()) std::memcpy(cluster_mass, u->cluster_mass.data(), u->cluster_mass.size() * 8);
+   if (e != hipSuccess) return api_fail(SBGPU_EHIP, std::string("sbgpu_uniq_dev_export: ") + hipGetErrorString(e));
+   return SBGPU_OK;
+}
+
+} // extern "C"

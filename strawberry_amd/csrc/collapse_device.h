@@ -1,0 +1,381 @@
+// strawberry_amd/csrc/collapse_device.h -- HitCluster::collapseAndFilterHits on the GPU.
+//
+// /root/reference/src/alignments.cpp:656-703: the read pairs of a cluster are sorted by (left end, right end),
+// pairs with a mate whose reference span is an outlier are skipped, the others add their raw mass to the
+// cluster's mass and are collapsed with the previous unique hit when both mates are equal; every unique hit
+// then becomes a Contig (src/contig.cpp:216-267).  One workgroup per locus:
+//   1. sort keys (left << 32 | right) and the pairs' input indices go to LDS; a bitonic sort on (key, index)
+//      gives the reference's order with ties in input order (what sbgpu_collapse_pairs_host's stable sort gives);
+//   2. the mates' spans are integers, so their sum -- and the mean -- are exact in any order; the sum of squared
+//      deviations is not, so one thread adds it in input order, as std::inner_product does (common.h:100-110);
+//   3. the filter, "equal to the previous kept pair" and Contig(PairedHit)'s feature count are per-pair work;
+//      the cluster's mass is one sequential double sum in sorted order, a unique hit's mass one per group;
+//   4. after the host has turned the per-locus counts into offsets, a second kernel writes the unique hits
+//      (sbgpu_hits_t layout) where the exon-bin kernel reads them.
+// Limits, each reported through a flag (the caller then uses sbgpu_collapse_pairs_host): at most 4096 pairs per
+// locus, at most 24 features per mate.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sb {
+
+constexpr int kCollapseMax = 4096;   // pairs of one locus (LDS sort)
+constexpr int kCollapseThreads = 256;
+constexpr int kMateFeatMax = 24;     // features of one mate the device form handles
+enum : int32_t { kCollapseTooMany = 1, kCollapseLongMate = 2, kCollapseNoMates = 4 };
+
+struct CollapseArgs {
+   int64_t n_loci;
+   const int64_t *locus_pair_off; // [n_loci + 1] pairs are grouped by locus
+   const double *pair_mass;
+   const int64_t *left_off, *right_off;
+   const uint8_t *left_code, *right_code;
+   const uint32_t *left_left, *left_right, *right_left, *right_right;
+   // per sorted position of a locus (index locus_pair_off[l] + i)
+   int32_t *order;   // input index (inside the locus) of the pair at sorted position i
+   int32_t *nfeat;   // > 0: a unique hit with that many features starts here; 0: none
+   float *mass;      // its collapse mass
+   // per locus
+   double *cluster_mass;
+   int32_t *n_hits, *n_feats, *n_filtered, *n_rejected;
+   int32_t *flags;
+   // pass 2
+   const int64_t *hit_off, *feat_base; // [n_loci + 1]: first unique hit / first feature of each locus
+   int32_t *hit_locus;
+   int64_t *feat_off; // [n_hits + 1]
+   uint8_t *feat_code;
+   uint32_t *feat_left, *feat_right;
+   float *hit_mass;
+};
+
+struct MateRef {
+   const uint8_t *c;
+   const uint32_t *l, *r;
+   int n;
+};
+__device__ __forceinline__ MateRef left_mate(const CollapseArgs &a, int64_t p)
+{
+   const int64_t o = a.left_off[p];
+   return MateRef{a.left_code + o, a.left_left + o, a.left_right + o, (int)(a.left_off[p + 1] - o)};
+}
+__device__ __forceinline__ MateRef right_mate(const CollapseArgs &a, int64_t p)
+{
+   const int64_t o = a.right_off[p];
+   return MateRef{a.right_code + o, a.right_left + o, a.right_right + o, (int)(a.right_off[p + 1] - o)};
+}
+// ReadHit::operator== (src/read.cpp:196-207): same start, same CIGAR
+__device__ __forceinline__ bool mate_equal(const MateRef &x, const MateRef &y)
+{
+   if (x.n != y.n) return false;
+   for (int i = 0; i < x.n; ++i)
+      if (x.c[i] != y.c[i] || x.l[i] != y.l[i] || x.r[i] != y.r[i]) return false;
+   return true;
+}
+// include/common.h:112-134
+__device__ __forceinline__ double ref_phi_dev(double x)
+{
+   const double a1 = 0.254829592, a2 = -0.284496736, a3 = 1.421413741, a4 = -1.453152027, a5 = 1.061405429, p = 0.3275911;
+   const int sign = x < 0 ? -1 : 1;
+   x = fabs(x) / sqrt(2.0);
+   const double t = 1.0 / (1.0 + p * x);
+   const double y = 1.0 - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * exp(-x * x);
+   return 0.5 * (1.0 + sign * y);
+}
+
+// Contig(PairedHit), src/contig.cpp:216-267, as sbgpu_hit_features (locus_bins.cpp) does it: a GAP between
+// mates that are apart; else the features of both sorted by (offset, length) and merged (contig.h:111-137):
+// equal introns fuse, overlapping blocks fuse, two different introns or blocks that merely abut reject the pair.
+// Returns the number of features (0: rejected); writes them when `out_*` are given.
+struct Feat {
+   uint32_t l, r;
+   uint8_t c;
+};
+__device__ __forceinline__ bool feat_less(const Feat &x, const Feat &y) { return x.l != y.l ? x.l < y.l : (x.r - x.l) < (y.r - y.l); }
+__device__ inline int hit_features_dev(const MateRef &a, const MateRef &b, uint8_t *out_c, uint32_t *out_l, uint32_t *out_r)
+{
+   Feat g[2 * kMateFeatMax + 1];
+   int n = 0;
+   auto push_sorted = [&](const Feat &f) { // insertion keeps g sorted by (offset, length)
+      int pos = n++;
+      while (pos > 0 && feat_less(f, g[pos - 1])) {
+         g[pos] = g[pos - 1];
+         --pos;
+      }
+      g[pos] = f;
+   };
+   for (int i = 0; i < a.n; ++i) push_sorted(Feat{a.l[i], a.r[i], a.c[i]});
+   for (int i = 0; i < b.n; ++i) push_sorted(Feat{b.l[i], b.r[i], b.c[i]});
+   if (a.n && b.n) {
+      const int64_t gap = (int64_t)b.l[0] - (int64_t)a.r[a.n - 1] - 1; // :234
+      if (gap > 0) {
+         push_sorted(Feat{a.r[a.n - 1] + 1, (uint32_t)(a.r[a.n - 1] + gap), 2});
+      } else {
+         int m = 0;
+         for (int i = 0; i < n; ++i) {
+            Feat f = g[i];
+            while (i + 1 < n && f.c == g[i + 1].c) {
+               if (f.c == 1) {
+                  if (!(f.l == g[i + 1].l && f.r == g[i + 1].r)) return 0; // two different introns
+               } else {
+                  if (f.r < g[i + 1].l) return 0; // blocks that do not overlap (abutting included)
+                  f.r = max(f.r, g[i + 1].r);
+               }
+               ++i;
+            }
+            g[m++] = f;
+         }
+         n = m;
+         // merged blocks keep their offsets, so the (offset, length) order can only change among equal offsets
+         for (int i = 1; i < n; ++i) {
+            const Feat f = g[i];
+            int pos = i;
+            while (pos > 0 && feat_less(f, g[pos - 1])) {
+               g[pos] = g[pos - 1];
+               --pos;
+            }
+            g[pos] = f;
+         }
+      }
+   }
+   if (out_c)
+      for (int i = 0; i < n; ++i) {
+         out_c[i] = g[i].c;
+         out_l[i] = g[i].l;
+         out_r[i] = g[i].r;
+      }
+   return n;
+}
+
+__device__ __forceinline__ uint32_t pair_left_pos(const MateRef &a, const MateRef &b)
+{
+   if (a.n && b.n) return min(a.l[0], b.l[0]); // PairedHit::left_pos, src/read.cpp:797-807
+   return a.n ? a.l[0] : b.l[0];
+}
+__device__ __forceinline__ uint32_t pair_right_pos(const MateRef &a, const MateRef &b)
+{
+   if (a.n && b.n) return max(a.r[a.n - 1], b.r[b.n - 1]);
+   return b.n ? b.r[b.n - 1] : a.r[a.n - 1];
+}
+
+__global__ __launch_bounds__(kCollapseThreads) void collapse_locus_kernel(CollapseArgs a)
+{
+   __shared__ unsigned long long key[kCollapseMax]; // sort keys; afterwards the pairs' masses (as doubles)
+   __shared__ int idx[kCollapseMax];
+   __shared__ int span_l[kCollapseMax], span_r[kCollapseMax]; // by input index; -1: no such mate
+   __shared__ unsigned char skip[kCollapseMax];               // by sorted position
+   __shared__ double red[kCollapseThreads];
+   __shared__ double s_mean, s_sd5;
+   __shared__ int s_nmates, c_hits, c_feats, c_filt, c_rej, s_bad;
+   const int tid = threadIdx.x;
+   for (int64_t l = blockIdx.x; l < a.n_loci; l += gridDim.x) {
+      const int64_t q0 = a.locus_pair_off[l];
+      const int np = (int)min<int64_t>(a.locus_pair_off[l + 1] - q0, (int64_t)kCollapseMax + 1);
+      if (tid == 0) {
+         a.cluster_mass[l] = 0.0;
+         a.n_hits[l] = a.n_feats[l] = a.n_filtered[l] = a.n_rejected[l] = 0;
+         c_hits = c_feats = c_filt = c_rej = s_bad = 0;
+      }
+      if (np == 0) continue;
+      if (np > kCollapseMax) {
+         if (tid == 0) atomicOr(a.flags, (int)kCollapseTooMany);
+         continue;
+      }
+      __syncthreads();
+      int n2 = 1;
+      while (n2 < np) n2 <<= 1;
+      // ---- keys, spans
+      int bad = 0;
+      double span_sum = 0.0;
+      int n_mates = 0;
+      for (int i = tid; i < n2; i += kCollapseThreads) {
+         unsigned long long k = ~0ull;
+         if (i < np) {
+            const MateRef x = left_mate(a, q0 + i), y = right_mate(a, q0 + i);
+            if (x.n > kMateFeatMax || y.n > kMateFeatMax) bad |= kCollapseLongMate;
+            if (x.n == 0 && y.n == 0) {
+               bad |= kCollapseNoMates;
+            } else {
+               k = ((unsigned long long)pair_left_pos(x, y) << 32) | pair_right_pos(x, y);
+            }
+            span_l[i] = x.n ? (int)(x.r[x.n - 1] - x.l[0] + 1) : -1;
+            span_r[i] = y.n ? (int)(y.r[y.n - 1] - y.l[0] + 1) : -1;
+            if (x.n) span_sum += (double)span_l[i], ++n_mates;
+            if (y.n) span_sum += (double)span_r[i], ++n_mates;
+         }
+         key[i] = k;
+         idx[i] = i;
+      }
+      if (bad) atomicOr(&s_bad, bad);
+      // the spans are whole numbers: their sum is exact whatever the order
+      red[tid] = span_sum;
+      __syncthreads();
+      for (int w = kCollapseThreads / 2; w > 0; w >>= 1) {
+         if (tid < w) red[tid] += red[tid + w];
+         __syncthreads();
+      }
+      const double total_span = red[0];
+      __syncthreads();
+      red[tid] = (double)n_mates;
+      __syncthreads();
+      for (int w = kCollapseThreads / 2; w > 0; w >>= 1) {
+         if (tid < w) red[tid] += red[tid + w];
+         __syncthreads();
+      }
+      if (tid == 0) {
+         s_nmates = (int)red[0];
+         s_mean = total_span / red[0];
+      }
+      __syncthreads();
+      if (s_bad) {
+         if (tid == 0) atomicOr(a.flags, s_bad);
+         __syncthreads();
+         continue;
+      }
+      // ---- bitonic sort of (key, input index)
+      for (int k2 = 2; k2 <= n2; k2 <<= 1)
+         for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < n2; i += kCollapseThreads) {
+               const int p = i ^ j;
+               if (p > i) {
+                  const bool up = (i & k2) == 0;
+                  const unsigned long long ki = key[i], kp = key[p];
+                  const int ii = idx[i], ip = idx[p];
+                  const bool greater = ki > kp || (ki == kp && ii > ip);
+                  if (greater == up) {
+                     key[i] = kp, key[p] = ki;
+                     idx[i] = ip, idx[p] = ii;
+                  }
+               }
+            }
+            __syncthreads();
+         }
+      // ---- sd: the squared deviations added in INPUT order (left mate, then right mate of each pair), by one thread
+      if (tid == 0) {
+         const double mean = s_mean;
+         double sq = 0.0;
+         for (int i = 0; i < np; ++i) {
+            if (span_l[i] >= 0) {
+               const double d = (double)span_l[i] - mean;
+               sq += d * d;
+            }
+            if (span_r[i] >= 0) {
+               const double d = (double)span_r[i] - mean;
+               sq += d * d;
+            }
+         }
+         s_sd5 = sqrt(sq / (double)s_nmates) * 5;
+      }
+      __syncthreads();
+      // ---- the span filter (:670-682), and the masses into LDS in sorted order
+      double *pmass = (double *)key;
+      for (int i = tid; i < np; i += kCollapseThreads) {
+         const int p = idx[i];
+         a.order[q0 + i] = p;
+         bool sk = false;
+         if (span_l[p] >= 0 && ref_phi_dev(((double)(uint32_t)span_l[p] - s_mean) / s_sd5) > 0.999) sk = true;
+         if (span_r[p] >= 0 && ref_phi_dev(((double)(uint32_t)span_r[p] - s_mean) / s_sd5) > 0.999) sk = true;
+         skip[i] = sk ? 1 : 0;
+      }
+      __syncthreads(); // everybody is done with key[] as keys
+      for (int i = tid; i < np; i += kCollapseThreads) pmass[i] = a.pair_mass[q0 + idx[i]];
+      __syncthreads();
+      // ---- the cluster's mass: kept pairs in sorted order, one running double (:683-684)
+      if (tid == 0) {
+         double m = 0.0;
+         for (int i = 0; i < np; ++i)
+            if (!skip[i]) m += pmass[i];
+         a.cluster_mass[l] = m;
+      }
+      // ---- unique hits: a kept pair that differs from the previous kept pair (:685-697)
+      int my_hits = 0, my_feats = 0, my_filt = 0, my_rej = 0;
+      for (int i = tid; i < np; i += kCollapseThreads) {
+         a.nfeat[q0 + i] = 0;
+         a.mass[q0 + i] = 0.0f;
+         if (skip[i]) {
+            ++my_filt;
+            continue;
+         }
+         const MateRef x = left_mate(a, q0 + idx[i]), y = right_mate(a, q0 + idx[i]);
+         int prev = i - 1;
+         while (prev >= 0 && skip[prev]) --prev;
+         if (prev >= 0 && mate_equal(left_mate(a, q0 + idx[prev]), x) && mate_equal(right_mate(a, q0 + idx[prev]), y)) continue;
+         // head of a group: its mass = the members' masses added in order, in double; stored as float (Contig::mass())
+         double m = pmass[i];
+         for (int k = i + 1; k < np; ++k) {
+            if (skip[k]) continue;
+            if (!(mate_equal(left_mate(a, q0 + idx[k]), x) && mate_equal(right_mate(a, q0 + idx[k]), y))) break;
+            m += pmass[k];
+         }
+         const int nf = hit_features_dev(x, y, nullptr, nullptr, nullptr);
+         if (nf <= 0) {
+            ++my_rej; // Contig(PairedHit) rejects the pair: no hit, its mass stays in the cluster's
+            continue;
+         }
+         a.nfeat[q0 + i] = nf;
+         a.mass[q0 + i] = (float)m;
+         ++my_hits;
+         my_feats += nf;
+      }
+      if (my_hits) atomicAdd(&c_hits, my_hits);
+      if (my_feats) atomicAdd(&c_feats, my_feats);
+      if (my_filt) atomicAdd(&c_filt, my_filt);
+      if (my_rej) atomicAdd(&c_rej, my_rej);
+      __syncthreads();
+      if (tid == 0) {
+         a.n_hits[l] = c_hits;
+         a.n_feats[l] = c_feats;
+         a.n_filtered[l] = c_filt;
+         a.n_rejected[l] = c_rej;
+      }
+      __syncthreads();
+   }
+}
+
+// pass 2: the unique hits of every locus at their final places
+__global__ __launch_bounds__(kCollapseThreads) void collapse_fill_kernel(CollapseArgs a)
+{
+   __shared__ int cnt_h[kCollapseThreads], cnt_f[kCollapseThreads];
+   const int tid = threadIdx.x;
+   for (int64_t l = blockIdx.x; l < a.n_loci; l += gridDim.x) {
+      const int64_t q0 = a.locus_pair_off[l];
+      const int np = (int)(a.locus_pair_off[l + 1] - q0);
+      const int64_t h0 = a.hit_off[l], f0 = a.feat_base[l];
+      // thread t owns the sorted positions [t * per, t * per + per): hits come out in sorted order
+      const int per = (np + kCollapseThreads - 1) / kCollapseThreads;
+      int nh = 0, nf = 0;
+      for (int i = tid * per; i < min(np, tid * per + per); ++i)
+         if (a.nfeat[q0 + i] > 0) {
+            ++nh;
+            nf += a.nfeat[q0 + i];
+         }
+      cnt_h[tid] = nh;
+      cnt_f[tid] = nf;
+      __syncthreads();
+      if (tid == 0) {
+         int sh = 0, sf = 0;
+         for (int t = 0; t < kCollapseThreads; ++t) {
+            const int ch = cnt_h[t], cf = cnt_f[t];
+            cnt_h[t] = sh, cnt_f[t] = sf;
+            sh += ch, sf += cf;
+         }
+      }
+      __syncthreads();
+      int64_t h = h0 + cnt_h[tid], f = f0 + cnt_f[tid];
+      for (int i = tid * per; i < min(np, tid * per + per); ++i) {
+         const int n = a.nfeat[q0 + i];
+         if (n <= 0) continue;
+         const int64_t p = q0 + a.order[q0 + i];
+         a.hit_locus[h] = (int32_t)l;
+         a.feat_off[h] = f;
+         a.hit_mass[h] = a.mass[q0 + i];
+         hit_features_dev(left_mate(a, p), right_mate(a, p), a.feat_code + f, a.feat_left + f, a.feat_right + f);
+         ++h;
+         f += n;
+      }
+      __syncthreads();
+   }
+}
+
+} // namespace sb

@@ -96,11 +96,20 @@ def hit_features(left_blocks, right_blocks):
     return oc[:n].tolist(), ol[:n].tolist(), orr[:n].tolist()
 
 
-def collapse_pairs(n_loci, pair_locus, pair_mass, left_blocks, right_blocks):
+def collapse_pairs(n_loci, pair_locus, pair_mass, left_blocks, right_blocks, device=None):
     """Aligned read pairs -> unique hits: HitCluster::collapseAndFilterHits + Contig(PairedHit)
     (sbgpu_collapse_pairs_host).  left_blocks / right_blocks: per pair the mate's aligned blocks [(l, r), ...]
-    ([] for a missing mate); pair_mass: the pair's raw mass.  -> (Hits, cluster_mass[n_loci], info dict)"""
+    ([] for a missing mate); pair_mass: the pair's raw mass.  -> (Hits, cluster_mass[n_loci], info dict)
+    device: an em.Context -- the pairs (grouped by locus here) are uploaded and collapsed on the GPU
+    (sbgpu_collapse_pairs_device); the result comes back as host arrays for comparison."""
     L = _lib.load()
+    if device is not None:
+        # group by locus, keeping the input order inside a locus (what the host form does internally)
+        order = np.argsort(np.asarray(pair_locus), kind="stable")
+        pair_locus = [pair_locus[i] for i in order]
+        pair_mass = [pair_mass[i] for i in order]
+        left_blocks = [left_blocks[i] for i in order]
+        right_blocks = [right_blocks[i] for i in order]
     def csr(blocks_list):
         off, c, l, r = [0], [], [], []
         for b in blocks_list:
@@ -117,6 +126,30 @@ def collapse_pairs(n_loci, pair_locus, pair_mass, left_blocks, right_blocks):
     p = _lib.sbgpu_pairs_t(len(loc), _ptr(loc), _ptr(mass), _ptr(lo), _ptr(lc), _ptr(ll), _ptr(lr), _ptr(ro), _ptr(rc),
                            _ptr(rl), _ptr(rr))
     handle = C.c_void_p()
+    if device is not None:
+        import torch
+        dev = torch.device("cuda", device.device)
+        keep = [torch.from_numpy(x.view(np.int32) if x.dtype == np.uint32 else x).to(dev) if x.size else torch.zeros(1, dtype=torch.int64, device=dev)
+                for x in (mass, lo, lc, ll, lr, ro, rc, rl, rr)]
+        dp = _lib.sbgpu_pairs_t(len(loc), None, *[t.data_ptr() for t in keep])
+        poff = np.searchsorted(loc, np.arange(n_loci + 1), side="left").astype(np.int64)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(L.sbgpu_collapse_pairs_device(device.h, n_loci, C.byref(dp), poff.ctypes.data, stream, C.byref(handle)),
+                   "sbgpu_collapse_pairs_device")
+        try:
+            info = (C.c_int64 * 8)()
+            _lib.check(L.sbgpu_uniq_dev_info(handle, info), "sbgpu_uniq_dev_info")
+            nh, nf = int(info[0]), int(info[1])
+            hit_locus, feat_off = np.zeros(nh, np.int32), np.zeros(nh + 1, np.int64)
+            code, left, right = np.zeros(nf, np.uint8), np.zeros(nf, np.uint32), np.zeros(nf, np.uint32)
+            hmass, cmass = np.zeros(nh, np.float32), np.zeros(n_loci, np.float64)
+            _lib.check(L.sbgpu_uniq_dev_export(handle, _ptr(hit_locus), feat_off.ctypes.data, _ptr(code), _ptr(left), _ptr(right),
+                                               _ptr(hmass), _ptr(cmass)), "sbgpu_uniq_dev_export")
+        finally:
+            L.sbgpu_uniq_dev_destroy(handle)
+        hits = Hits.from_arrays(hit_locus, feat_off, code, left, right, hmass)
+        hits.total_mapped = int(info[4])
+        return hits, cmass, {"filtered": int(info[2]), "rejected": int(info[3]), "total_mapped": int(info[4])}
     _lib.check(L.sbgpu_collapse_pairs_host(n_loci, C.byref(p), C.byref(handle)), "sbgpu_collapse_pairs_host")
     try:
         info = (C.c_int64 * 8)()

@@ -1,0 +1,162 @@
+"""GPU tests of sbgpu_collapse_pairs_device (HitCluster::collapseAndFilterHits + Contig(PairedHit) on the GPU,
+/root/reference/src/alignments.cpp:656-703, src/contig.cpp:216-267) against sbgpu_collapse_pairs_host, which is
+itself pinned to the reference binary's runs (tests/test_exonbin_oracle.py): unique hits, features, float masses,
+cluster masses and the int-truncated mapped-read total must be identical."""
+import numpy as np
+import pytest
+
+import e2e_util as U
+import exonbin_util as XU
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from strawberry_amd import em
+    return em.default_context(0)
+
+
+def same(got, ref, gcm, rcm, ginfo, rinfo):
+    assert ginfo == rinfo
+    for a in ("hit_locus", "feat_off", "feat_code", "feat_left", "feat_right", "mass"):
+        np.testing.assert_array_equal(getattr(got, a), getattr(ref, a), err_msg=a)
+    np.testing.assert_array_equal(gcm, rcm)
+
+
+@pytest.mark.parametrize("which", ["E2E", "E2E_MASS", "E2E_SINGLE", "E2E_LONGREAD"])
+def test_device_collapse_equals_host_on_the_reference_runs(ctx, which):
+    """Every sequenced copy of the toy runs (shuffled): PCR duplicates, NH 2/3 masses, single-end and long reads."""
+    from strawberry_amd import exonbin as eb
+    d = getattr(U, which)
+    ordered, rows, _, _ = U.load(d)
+    annot, hits, names, rejected = XU.e2e_inputs(d, ordered)
+    copies = XU.load_read_copies(d)
+    rng = np.random.default_rng(5)
+    copies = [copies[i] for i in rng.permutation(len(copies))]
+    args = (len(names), [c[0] for c in copies], [c[3] for c in copies], [c[1] for c in copies], [c[2] for c in copies])
+    ref, rcm, rinfo = eb.collapse_pairs(*args)
+    if which == "E2E_LONGREAD":
+        # reads of up to 11 blocks = 21 features per mate: inside the device form's 24
+        pass
+    got, gcm, ginfo = eb.collapse_pairs(*args, device=ctx)
+    same(got, ref, gcm, rcm, ginfo, rinfo)
+    assert ginfo["total_mapped"] == rows[0]["total_mapped"] == hits.total_mapped
+
+
+def test_device_collapse_filter_equality_and_rejects(ctx):
+    from strawberry_amd import exonbin as eb
+    left = [[(1000 + 3 * k, 1074 + 3 * k)] for k in range(200)]
+    right = [[(1300 + 3 * k, 1374 + 3 * k)] for k in range(200)]
+    left.append([(1500, 1574)]); right.append([(1700, 1710), (30000, 30063)])      # a mate spanning 28 kb: filtered
+    left.append([(1003, 1077)]); right.append([(1303, 1377)])                      # a second copy of pair 1
+    left.append([(1003, 1077)]); right.append([(1303, 1340), (1400, 1436)])        # spliced: not equal
+    args = (1, [0] * 203, [1.0] * 201 + [0.5, 1.0], left, right)
+    g, r = eb.collapse_pairs(*args, device=ctx), eb.collapse_pairs(*args)
+    same(g[0], r[0], g[1], r[1], g[2], r[2])
+    assert g[2]["filtered"] == 1 and g[0].n_hits == 201
+    # single reads, abutting mates (rejected but counted), overlapping mates (merged), an empty locus in between
+    args = (4, [0, 0, 1, 3, 3], [1.0, 1.0, 1.0, 0.5, 1.0 / 3],
+            [[(10, 84)], [(10, 84)], [(500, 574)], [(900, 974)], [(900, 950), (1000, 1023)]],
+            [[], [], [(575, 649)], [(950, 1024)], [(1010, 1084)]])
+    g, r = eb.collapse_pairs(*args, device=ctx), eb.collapse_pairs(*args)
+    same(g[0], r[0], g[1], r[1], g[2], r[2])
+    assert g[2]["rejected"] == 1 and g[0].n_hits == 3
+
+
+def test_device_collapse_random_stress(ctx):
+    """Random clusters: many duplicates, fractional masses (sums whose float / int truncation depends on the order),
+    equal (left, right) ends with different blocks, single reads, spliced mates, up to 4000 pairs in a locus."""
+    from strawberry_amd import exonbin as eb
+    rng = np.random.default_rng(123)
+    for trial in range(4):
+        n_loci = int(rng.integers(3, 40))
+        loc, mass, left, right = [], [], [], []
+        for l in range(n_loci):
+            n = int(rng.integers(0, 4000 if l == 0 else 300))
+            base = 100000 * (l + 1)
+            starts = rng.integers(base, base + 400, n)
+            for k in range(n):
+                s = int(starts[k])
+                rl = 75
+                lb = [(s, s + rl - 1)]
+                if rng.random() < 0.3:                       # spliced left mate
+                    cut = int(rng.integers(10, 60))
+                    gap = int(rng.choice([200, 350]))
+                    lb = [(s, s + cut - 1), (s + cut + gap, s + gap + rl - 1)]
+                u = rng.random()
+                if u < 0.1:
+                    rb = []                                   # single read
+                else:
+                    ins = int(rng.choice([180, 200, 230, 75, 40]))   # apart, abutting (75) and overlapping (40) mates
+                    rs = lb[-1][1] + 1 + ins - rl if ins > rl else lb[0][0] + ins
+                    rb = [(rs, rs + rl - 1)]
+                loc.append(l)
+                mass.append(float(rng.choice([1.0, 0.5, 1.0 / 3.0, 0.25])))
+                left.append(lb)
+                right.append(rb)
+        perm = rng.permutation(len(loc))
+        args = (n_loci, [loc[i] for i in perm], [mass[i] for i in perm], [left[i] for i in perm], [right[i] for i in perm])
+        g, r = eb.collapse_pairs(*args, device=ctx), eb.collapse_pairs(*args)
+        same(g[0], r[0], g[1], r[1], g[2], r[2])
+        assert r[0].n_hits < len(loc) * 0.9      # the stress does collapse
+
+
+def test_device_collapse_declines_what_it_does_not_cover(ctx):
+    from strawberry_amd import _lib, exonbin as eb
+    n = 4097
+    left = [[(1000 + k, 1074 + k)] for k in range(n)]
+    with pytest.raises(_lib.SbgpuError, match="4096"):
+        eb.collapse_pairs(1, [0] * n, [1.0] * n, left, [[] for _ in range(n)], device=ctx)
+    long_mate = [[(1000 + 100 * k, 1040 + 100 * k) for k in range(13)]]      # 25 features
+    with pytest.raises(_lib.SbgpuError, match="24 features"):
+        eb.collapse_pairs(1, [0], [1.0], long_mate, [[]], device=ctx)
+
+
+def test_collapsed_hits_feed_the_chain_without_leaving_the_device(ctx):
+    """pairs (device) -> sbgpu_collapse_pairs_device -> sbgpu_uniq_dev_hits -> sbgpu_quantify_device == the host chain on
+    the host-collapsed hits."""
+    import ctypes as C
+    import torch
+    from strawberry_amd import _lib, exonbin as eb
+    from strawberry_amd.quantify import InsertSize, quantify_host
+    d = U.E2E
+    ordered, rows, _, _ = U.load(d)
+    annot, hits, names, rejected = XU.e2e_inputs(d, ordered)
+    copies = XU.load_read_copies(d)
+    order = np.argsort([c[0] for c in copies], kind="stable")
+    copies = [copies[i] for i in order]
+    L = _lib.load()
+    dev = torch.device("cuda", 0)
+    def csr(blocks_list):
+        off, c, l, r = [0], [], [], []
+        for b in blocks_list:
+            cc, ll, rr = eb.mate_features(b)
+            c += cc; l += ll; r += rr
+            off.append(len(c))
+        return (np.asarray(off, np.int64), np.asarray(c, np.uint8), np.asarray(l, np.uint32), np.asarray(r, np.uint32))
+    lo, lc, ll, lr = csr([c[1] for c in copies])
+    ro, rc, rl, rr = csr([c[2] for c in copies])
+    mass = np.asarray([c[3] for c in copies], np.float64)
+    loc = np.asarray([c[0] for c in copies], np.int32)
+    keep = [torch.from_numpy(x.view(np.int32) if x.dtype == np.uint32 else x).to(dev) if x.size else torch.zeros(1, dtype=torch.int64, device=dev)
+            for x in (mass, lo, lc, ll, lr, ro, rc, rl, rr)]
+    dp = _lib.sbgpu_pairs_t(len(loc), None, *[t.data_ptr() for t in keep])
+    poff = np.searchsorted(loc, np.arange(len(names) + 1), side="left").astype(np.int64)
+    h = C.c_void_p()
+    _lib.check(L.sbgpu_collapse_pairs_device(ctx.h, len(names), C.byref(dp), poff.ctypes.data, None, C.byref(h)), "collapse")
+    dh = _lib.sbgpu_hits_t()
+    d_mass, hoff = C.c_void_p(), C.c_void_p()
+    _lib.check(L.sbgpu_uniq_dev_hits(h, C.byref(dh), C.byref(d_mass), C.byref(hoff)), "uniq_dev_hits")
+    n_iso = int(annot.iso_off[-1])
+    theta = np.zeros(n_iso + 1); status = np.zeros(annot.n_loci + 1, np.int32); iters = np.zeros(annot.n_loci + 1, np.int32)
+    ins = InsertSize(250.0, 30.0)._struct(75)
+    an = annot._struct()
+    bh = C.c_void_p()
+    _lib.check(L.sbgpu_quantify_device(ctx.h, C.byref(an), C.byref(dh), d_mass, hoff, C.byref(ins), 75, 0, theta.ctypes.data,
+                                       status.ctypes.data, iters.ctypes.data, C.byref(bh)), "sbgpu_quantify_device")
+    L.sbgpu_bins_destroy(bh)
+    L.sbgpu_uniq_dev_destroy(h)
+    r = quantify_host(annot, hits, InsertSize(250.0, 30.0), 75, ctx=ctx)
+    np.testing.assert_array_equal(theta[:n_iso], r["theta"])
+    np.testing.assert_array_equal(iters[:annot.n_loci], r["iters"])
