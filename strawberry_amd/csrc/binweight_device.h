@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "em_device.h" // wave_group_sum: the 64-lane sum by DPP steps and one matrix instruction
+
 namespace sb {
 
 struct BinWeightArgs {
@@ -28,6 +30,7 @@ struct BinWeightArgs {
    const double *pdf;             // pdf[fl], fl in [0, pdf_len)
    double *out;
    int32_t pdf_len;
+   const int32_t *pdf_support;    // [2] first and last fl with pdf[fl] != 0 (pdf_support_kernel): the terms outside are exact zeros and are skipped
    int32_t read_len;              // rl = read_len_mode()
    int32_t lmin_base;             // _use_emp ? _start_offset : rl   (estimate.cpp:214-219)
    int32_t long_read;             // set_bin_weight_without_frag_dist: F = 1/L (estimate.cpp:236-247)
@@ -54,7 +57,8 @@ __device__ __forceinline__ int gap_ef(int l_left, int l_right, int l_int, int rl
 
 // include/isoform.h:419-516.  s = segment lengths (LDS), nseg >= 1.
 // SL[m] / SR[m]: total length of the m leftmost / rightmost INNER segments (m = 0..nseg-2).
-__device__ __forceinline__ int effective_len(const uint32_t *s, const int *SL, const int *SR, int nseg,
+template <class SegPtr>
+__device__ __forceinline__ int effective_len(SegPtr s, const int *SL, const int *SR, int nseg,
                                              uint32_t imask, int nimp, int inner, int fl, int rl)
 {
    const int gap = fl - 2 * rl;
@@ -146,6 +150,29 @@ __device__ __forceinline__ double bw_div(double n, double d)
    return __builtin_fma(__builtin_fma(-d, q, n), r, q);
 }
 
+// first and last index of a non-zero density (one workgroup); an all-zero table gives the empty range [1, 0]
+__global__ __launch_bounds__(256) void pdf_support_kernel(const double *pdf, int n, int32_t *out)
+{
+   __shared__ int lo, hi;
+   if (threadIdx.x == 0) lo = 0x7fffffff, hi = -1;
+   __syncthreads();
+   int mylo = 0x7fffffff, myhi = -1;
+   for (int i = threadIdx.x; i < n; i += 256)
+      if (pdf[i] != 0.0) {
+         mylo = min(mylo, i);
+         myhi = max(myhi, i);
+      }
+   if (myhi >= 0) {
+      atomicMin(&lo, mylo);
+      atomicMax(&hi, myhi);
+   }
+   __syncthreads();
+   if (threadIdx.x == 0) {
+      out[0] = hi >= 0 ? lo : 1;
+      out[1] = hi >= 0 ? hi : 0;
+   }
+}
+
 constexpr int kBinWeightMaxSeg = 32; // the reference's `1u << idx` masks stop at 32 segments too
 
 __global__ __launch_bounds__(64) void binweight_kernel(BinWeightArgs a)
@@ -166,6 +193,25 @@ __global__ __launch_bounds__(64) void binweight_kernel(BinWeightArgs a)
       double acc = 0.0;
       if (a.long_read) { // estimate.cpp:236-247
          acc = 1.0 / (double)L;
+      } else if (nseg <= 4) {
+         // closed forms (1-4 segments, nearly all pairs): the segment lengths are wave-uniform scalars, no LDS,
+         // no barrier
+         uint32_t s4[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+         for (int k = 0; k < 4; ++k)
+            if (k < nseg) s4[k] = a.seg_lens[off + k];
+         const uint32_t imask = a.implicit_mask[p];
+         const int nimp = __popc(imask);
+         const int lmax = (int)(s4[0] + s4[1] + s4[2] + s4[3]);
+         const int inner = nseg > 2 ? lmax - (int)s4[0] - (int)s4[nseg - 1] : 0;
+         int lmin = a.lmin_base;                // estimate.cpp:214-219
+         if (nseg > 2) lmin = max(lmin, inner); // :220-221
+         const int f0 = max(lmin, a.pdf_support[0]), f1 = min(lmax, a.pdf_support[1]);
+         for (int fl = f0 + lane; fl <= f1; fl += 64) { // :223-227, lanes over fl
+            const int e = effective_len(s4, (const int *)nullptr, (const int *)nullptr, nseg, imask, nimp, inner, fl, a.read_len);
+            acc += bw_div(a.pdf[fl] * (double)e, (double)(L - fl + 1));
+         }
+         acc = wave_group_sum<64>(acc);
       } else {
          __syncthreads(); // the previous pair's readers are done with s_seg
          if (lane < nseg) s_seg[lane] = a.seg_lens[off + lane];
@@ -190,13 +236,13 @@ __global__ __launch_bounds__(64) void binweight_kernel(BinWeightArgs a)
          }
          int lmin = a.lmin_base;                // estimate.cpp:214-219
          if (nseg > 2) lmin = max(lmin, inner); // :220-221
-         for (int fl = lmin + lane; fl <= lmax; fl += 64) { // :223-227, lanes over fl
-            const int e = effective_len(s_seg, s_SL, s_SR, nseg, imask, nimp, inner, fl, a.read_len);
-            const double pdfv = (fl >= 0 && fl < a.pdf_len) ? a.pdf[fl] : 0.0;
-            acc += bw_div(pdfv * (double)e, (double)(L - fl + 1));
+         const int f0 = max(lmin, a.pdf_support[0]), f1 = min(lmax, a.pdf_support[1]);
+         for (int fl = f0 + lane; fl <= f1; fl += 64) { // :223-227, lanes over fl
+            const int e = effective_len((const uint32_t *)s_seg, s_SL, s_SR, nseg, imask, nimp, inner, fl, a.read_len);
+            acc += bw_div(a.pdf[fl] * (double)e, (double)(L - fl + 1));
          }
          // wave sum (order differs from the reference's sequential loop by rounding only)
-         for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+         acc = wave_group_sum<64>(acc);
       }
       if (lane == 0) a.out[dst] = acc;
    }

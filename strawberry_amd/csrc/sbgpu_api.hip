@@ -63,6 +63,7 @@ struct sbgpu_ctx {
    bool timed[sb::kNumKinds] = {};
    bool timing = false; // record the timing events (off by default: they cost a few microseconds per step)
    int n_phase_timed = 0;
+   int32_t *d_pdf_support = nullptr; // [2] device: support of the insert-size table of the bin-weight launch in flight
    int32_t *wide_error = nullptr; // pinned host word the wide-locus kernel raises when a barrier times out
    hipEvent_t wide_fork = nullptr, wide_join[2] = {}; // rounds of the wide-locus kernel overlap on three streams
 };
@@ -336,6 +337,7 @@ int sbgpu_init(int device, sbgpu_ctx_t **ctx_out)
    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->wide_fork, hipEventDisableTiming);
    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->wide_join[i], hipEventDisableTiming);
+   if (e == hipSuccess) e = hipMalloc((void **)&c->d_pdf_support, 2 * sizeof(int32_t));
    if (e == hipSuccess) e = hipHostMalloc((void **)&c->wide_error, sizeof(int32_t), hipHostMallocDefault);
    if (e == hipSuccess) *c->wide_error = 0;
    for (int k = 0; e == hipSuccess && k < sb::kNumKinds; ++k) {
@@ -368,6 +370,7 @@ int sbgpu_finalize(sbgpu_ctx_t *c)
       if (c->tp[i]) (void)hipEventDestroy(c->tp[i]);
    if (c->stream) (void)hipStreamDestroy(c->stream);
    if (c->wide_error) (void)hipHostFree(c->wide_error);
+   if (c->d_pdf_support) (void)hipFree(c->d_pdf_support);
    if (c->wide_fork) (void)hipEventDestroy(c->wide_fork);
    for (int i = 0; i < 2; ++i)
       if (c->wide_join[i]) (void)hipEventDestroy(c->wide_join[i]);
@@ -1127,6 +1130,11 @@ int sbgpu_binweight_device(sbgpu_ctx_t *c, int64_t n_pairs, const int64_t *d_seg
    a.pdf = d_pdf;
    a.out = d_F;
    a.pdf_len = pdf_len;
+   a.pdf_support = c->d_pdf_support;
+   if (!long_read) {
+      hipLaunchKernelGGL(sb::pdf_support_kernel, dim3(1), dim3(256), 0, s, d_pdf, pdf_len, c->d_pdf_support);
+      HIP_TRY(hipGetLastError());
+   }
    a.read_len = read_len;
    a.lmin_base = lmin_base;
    a.long_read = long_read;
