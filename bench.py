@@ -74,8 +74,8 @@ def pmc_traffic(workload, kind):
     tallies 128-B requests at 64 B, so it is doubled before it is compared with a byte count."""
     import glob
     import json
-    key = ["em_fused_kernel<0, 1>", "em_fused_kernel<0, 2>", "em_fused_kernel<0, 4>", "em_fused_kernel<4, 2>",
-           "em_fused_kernel<4, 12>", "em_stream_kernel"][kind]
+    key = ["em_fused_kernel<0, 1,", "em_fused_kernel<0, 2,", "em_fused_kernel<0, 4,", "em_fused_kernel<4, 2,",
+           "em_fused_kernel<4, 12,", "em_wide_kernel"][kind]
     here = os.path.dirname(os.path.abspath(__file__))
     files = sorted(glob.glob(os.path.join(here, "profiles", "r*_%s_pmc_summary.json" % workload)))
     if not files:

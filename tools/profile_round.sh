@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: the round's evidence.  Usage (repo root): bash tools/profile_round.sh r01
 # Everything judged is collected under gpurun_out/$R/summary/ -- copy that directory's files into profiles/.
-R=${1:-r01}
+R=${1:-r02}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/$R
 SUM=$OUT/summary
@@ -38,6 +38,13 @@ PY
 cp $SUM/${R}_c3_pmc_summary.json $SUM/${R}_c2_pmc_summary.json $REPO/profiles/ 2>/dev/null
 (timeout 900 python bench.py 2>/dev/null) > $SUM/${R}_bench_c3.json
 (timeout 600 python bench.py --workload c2 2>/dev/null) > $SUM/${R}_bench_c2.json
+(timeout 900 python bench.py --workload c5 --no-cpu-baseline 2>/dev/null) > $SUM/${R}_bench_c5.json
+(timeout 900 python bench.py --workload c3t --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null) > $SUM/${R}_bench_c3t.json
+(timeout 900 python bench.py --workload c3-chain --steps 5 --warmup 2 2>/dev/null) > $SUM/${R}_bench_c3chain.json
+cd /tmp
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_chain -o ch -- python3 $REPO/bench.py --workload c3-chain --steps 3 --warmup 1 > $OUT/stats_chain.log 2>&1
+cd $REPO
+for f in $(find $OUT/stats_chain -name "*kernel_stats.csv"); do cp $f $SUM/${R}_c3chain_kernel_stats.csv; done
 bash tools/profile_exonbin.sh $R > /dev/null 2>&1
 cp $OUT/exonbin/summary.json $SUM/${R}_exonbin_summary.json
 cp $OUT/exonbin/stats/eb_kernel_stats.csv $SUM/${R}_exonbin_kernel_stats.csv
@@ -47,7 +54,8 @@ cp $OUT/binweight/bench_binweight.json $SUM/${R}_bench_binweight.json
 bash tools/profile_binseq.sh $R > /dev/null 2>&1
 cp $OUT/binseq/summary.json $SUM/${R}_binseq_summary.json
 cp $OUT/binseq/stats/bs_kernel_stats.csv $SUM/${R}_binseq_kernel_stats.csv
-# wide loci (> 64 isoforms): multi-workgroup kernel vs the streaming fallback
-(echo "em_wide_kernel (default):"; timeout 300 python tools/probe_wide_loci.py 2>/dev/null | grep "wide loci alone"; \
- echo "em_stream_kernel only (SBGPU_NO_WIDE=1):"; SBGPU_NO_WIDE=1 timeout 300 python tools/probe_wide_loci.py 2>/dev/null | grep "wide loci alone") > $SUM/${R}_wide_loci.txt
+# wide loci (> 64 isoforms): multi-workgroup kernel, by shape and on C3-T
+(timeout 600 python tools/probe_c3t.py; timeout 300 python tools/probe_wide_loci.py; timeout 300 python tools/probe_wide_shapes.py) 2>/dev/null > $SUM/${R}_wide_loci.txt
+timeout 600 python tools/c5_sweep.py $SUM/${R}_c5_sweep.json > /dev/null 2>&1
+timeout 120 ./tools/bin/microbench > $SUM/${R}_microbench.txt 2>&1
 cat $SUM/${R}_pytest_gpu.txt; cat $SUM/${R}_bench_c3.json; echo; cat $SUM/${R}_bench_c2.json; echo; ls -la $SUM
