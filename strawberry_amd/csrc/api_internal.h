@@ -37,6 +37,9 @@ int api_fail(int code, const std::string &msg); // records sbgpu_last_error(), r
 hipStream_t ctx_stream(const sbgpu_ctx_t *ctx); // the context's own stream
 int ctx_cu_count(const sbgpu_ctx_t *ctx);
 int ctx_device(const sbgpu_ctx_t *ctx);        // the HIP device the context was made on
+// device scratch that lives with the context (slot 0..7, grows on demand, never shrinks): valid until the next
+// request for the same slot; one host thread per context
+hipError_t ctx_scratch(sbgpu_ctx_t *ctx, int slot, size_t bytes, char **out);
 bool ctx_take_wide_error(sbgpu_ctx_t *ctx);    // true once if a wide-locus barrier timed out since the last call (clears the flag)
 // locus_bins.cpp: finish bins that were grouped on the device (host copies of the per-bin arrays)
 // `pairs`: made on the device already (the handle takes the arena over); nullptr: make them here, on the host

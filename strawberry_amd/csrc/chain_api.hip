@@ -23,8 +23,7 @@ namespace {
 
 // the empirical insert-size law of a handle: kept alive with the handle through its weights' tail
 struct DeviceBuf {
-   char *p = nullptr;
-   ~DeviceBuf() { (void)hipFree(p); }
+   char *p = nullptr; // the context's scratch (sb::ctx_scratch): not freed here
 };
 
 size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
@@ -111,7 +110,7 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
    const size_t o_key = total; total += up256(nh1 * 4 * (size_t)kw);
    const size_t o_hbin = total; total += up256(nh1 * 8);
    DeviceBuf in;
-   hipError_t e = hipMalloc(&in.p, total);
+   hipError_t e = sb::ctx_scratch(c, 0, total, &in.p);
    if (e != hipSuccess) return api_fail(e == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e));
 #define SB_TRY(expr)                                                                                          \
    do {                                                                                                       \
@@ -299,7 +298,7 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
    const size_t q_st = t2; t2 += up256((size_t)(nl + 1) * 4);
    const size_t q_it = t2; t2 += up256((size_t)(nl + 1) * 4);
    DeviceBuf w;
-   e = hipMalloc(&w.p, t2);
+   e = sb::ctx_scratch(c, 1, t2, &w.p);
    if (e != hipSuccess) return api_fail(e == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e));
    SB_TRY(hipMemsetAsync(w.p + q_F, 0, ne1 * 8, s));
    if (n_pairs) {

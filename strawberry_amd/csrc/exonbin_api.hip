@@ -273,14 +273,11 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
    const size_t o_roff = off; off += up((size_t)(nl + 1) * 8);
    const size_t o_order = off; off += up((size_t)nl * 4);
    const size_t o_dup = off; off += up(nh1);
+   // the scratch arenas live with the context (sb::ctx_scratch): nothing to free here
    char *d = nullptr, *d2 = nullptr;
-   hipError_t e = hipMalloc(&d, off);
+   hipError_t e = sb::ctx_scratch(c, 2, off, &d);
    if (e != hipSuccess) return api_fail(e == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e));
-   auto bail = [&](int code, const std::string &msg) {
-      (void)hipFree(d);
-      (void)hipFree(d2);
-      return api_fail(code, msg);
-   };
+   auto bail = [&](int code, const std::string &msg) { return api_fail(code, msg); };
 #define SB_TRY(expr)                                                                        \
    do {                                                                                     \
       hipError_t e_ = (expr);                                                               \
@@ -392,7 +389,7 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
    const size_t p_cnt = off2; off2 += up(nb1 * 4);
    const size_t p_key = off2; off2 += up(nb1 * 4 * (size_t)key_words);
    const size_t p_cmp = off2; off2 += up(nb1 * 4 * (size_t)compat_words);
-   e = hipMalloc(&d2, off2);
+   e = sb::ctx_scratch(c, 3, off2, &d2);
    if (e != hipSuccess) return bail(e == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e));
    SB_TRY(hipMemcpyAsync(d + o_roff, row_off.data(), (size_t)(nl + 1) * 8, hipMemcpyHostToDevice, s));
    sb::BinsPackArgs pk;
@@ -452,11 +449,10 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
    const size_t r_poff = off3; off3 += up((ni1 + 1) * 8);
    const size_t r_soff = off3; off3 += up((ni1 + 1) * 8);
    char *d3 = nullptr;
-   e = hipMalloc(&d3, off3);
+   e = sb::ctx_scratch(c, 4, off3, &d3);
    if (e != hipSuccess) return bail(e == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e));
    sb::DevicePairs dp;
    auto bail3 = [&](int code, const std::string &msg) {
-      (void)hipFree(d3);
       (void)hipFree(dp.arena);
       return bail(code, msg);
    };
@@ -547,10 +543,6 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
 #undef SB_TRY3
 #undef SB_TRY
    stage("pairs fill");
-   (void)hipFree(d);
-   (void)hipFree(d2);
-   (void)hipFree(d3);
-   stage("free");
    const int rc = sb::bins_from_groups(an, compat_words, key_words, row_off.data(), count.data(), key.data(), compat.data(), used, &dp, out);
    if (rc != SBGPU_OK) (void)hipFree(dp.arena);
    stage("handle");

@@ -63,6 +63,10 @@ struct sbgpu_ctx {
    bool timed[sb::kNumKinds] = {};
    bool timing = false; // record the timing events (off by default: they cost a few microseconds per step)
    int n_phase_timed = 0;
+   // grow-only device scratch of the multi-stage entry points (a hipMalloc / hipFree pair of a few GB per call costs
+   // tens to hundreds of milliseconds): sb::ctx_scratch
+   char *scratch[8] = {};
+   size_t scratch_bytes[8] = {};
    int32_t *d_pdf_support = nullptr; // [2] device: support of the insert-size table of the bin-weight launch in flight
    int32_t *wide_error = nullptr; // pinned host word the wide-locus kernel raises when a barrier times out
    hipEvent_t wide_fork = nullptr, wide_join[2] = {}; // rounds of the wide-locus kernel overlap on three streams
@@ -73,6 +77,28 @@ int api_fail(int code, const std::string &msg) { return fail(code, msg); }
 hipStream_t ctx_stream(const sbgpu_ctx_t *ctx) { return ctx->stream; }
 int ctx_cu_count(const sbgpu_ctx_t *ctx) { return ctx->n_cu; }
 int ctx_device(const sbgpu_ctx_t *ctx) { return ctx->device; }
+hipError_t ctx_scratch(sbgpu_ctx_t *ctx, int slot, size_t bytes, char **out)
+{
+   *out = nullptr;
+   if (slot < 0 || slot >= 8) return hipErrorInvalidValue;
+   if (bytes < 256) bytes = 256;
+   if (ctx->scratch_bytes[slot] < bytes) {
+      if (ctx->scratch[slot]) (void)hipFree(ctx->scratch[slot]);
+      ctx->scratch[slot] = nullptr;
+      ctx->scratch_bytes[slot] = 0;
+      const size_t want = bytes + bytes / 4; // head-room: the next call is often a little larger
+      hipError_t e = hipMalloc(&ctx->scratch[slot], want);
+      if (e != hipSuccess) {
+         e = hipMalloc(&ctx->scratch[slot], bytes);
+         if (e != hipSuccess) return e;
+         ctx->scratch_bytes[slot] = bytes;
+      } else {
+         ctx->scratch_bytes[slot] = want;
+      }
+   }
+   *out = ctx->scratch[slot];
+   return hipSuccess;
+}
 bool ctx_take_wide_error(sbgpu_ctx_t *ctx)
 {
    if (!ctx->wide_error || !*ctx->wide_error) return false;
@@ -371,6 +397,8 @@ int sbgpu_finalize(sbgpu_ctx_t *c)
    if (c->stream) (void)hipStreamDestroy(c->stream);
    if (c->wide_error) (void)hipHostFree(c->wide_error);
    if (c->d_pdf_support) (void)hipFree(c->d_pdf_support);
+   for (int i = 0; i < 8; ++i)
+      if (c->scratch[i]) (void)hipFree(c->scratch[i]);
    if (c->wide_fork) (void)hipEventDestroy(c->wide_fork);
    for (int i = 0; i < 2; ++i)
       if (c->wide_join[i]) (void)hipEventDestroy(c->wide_join[i]);
