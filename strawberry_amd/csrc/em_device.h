@@ -408,19 +408,29 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
             for (int v = 0; v < NVAL; ++v) buf[(v * CL + lane) * NW + wave_id] = x[v];
          }
          __syncthreads();
-         T part[NVAL][NW];
+         // the partials of a few values at a time: all NVAL x NW of them in flight together cost the block
+         // kernels their last free registers (and then some: scratch spills inside the iteration)
+         constexpr int kChunk = NVAL < 2 ? NVAL : 2;
 #pragma unroll
-         for (int v = 0; v < NVAL; ++v) {
-            const T *p = buf + (v * CL + gc) * NW;
+         for (int v0 = 0; v0 < NVAL; v0 += kChunk) {
+            T part[kChunk][NW];
 #pragma unroll
-            for (int w = 0; w < NW; ++w) part[v][w] = p[w];
-         }
+            for (int u = 0; u < kChunk; ++u) {
+               if (v0 + u < NVAL) {
+                  const T *p = buf + ((v0 + u) * CL + gc) * NW;
 #pragma unroll
-         for (int v = 0; v < NVAL; ++v) {
-            T sum = part[v][0];
+                  for (int w = 0; w < NW; ++w) part[u][w] = p[w];
+               }
+            }
 #pragma unroll
-            for (int w = 1; w < NW; ++w) sum += part[v][w];
-            x[v] = sum;
+            for (int u = 0; u < kChunk; ++u) {
+               if (v0 + u < NVAL) {
+                  T sum = part[u][0];
+#pragma unroll
+                  for (int w = 1; w < NW; ++w) sum += part[u][w];
+                  x[v0 + u] = sum;
+               }
+            }
          }
          phase ^= 1; // T-buffered: one barrier per round is enough
       }
