@@ -178,6 +178,55 @@ __device__ __forceinline__ double fast_div(double n, double d)
    return n * r;
 }
 
+// Reciprocals of N = 1..4 denominators from ONE v_rcp_f64 (the instruction occupies the pipe four times as long as an
+// FMA, and each of its results wants two Newton steps): invert the product and multiply the other factors back in
+// (a * b inverted gives 1/a = r * b, 1/b = r * a; four go as a tree of two pairs).  <= 5 roundings per result instead
+// of 3.  A zero among the denominators makes ALL results NaN (0 * inf) -- callers only ever ask whether any
+// denominator was zero.  The product of N numbers can leave the exponent range where no single one does: an underflow
+// (flushed to zero) also gives NaN -- callers confirm a NaN with exact_reciprocal-based arithmetic before they
+// believe it; denominators here are <= ~1e10, so no overflow.
+__device__ __forceinline__ double newton_rcp(double p)
+{
+   double r = __builtin_amdgcn_rcp(p);
+   double e = __builtin_fma(-p, r, 1.0);
+   r = __builtin_fma(r, e, r);
+   e = __builtin_fma(-p, r, 1.0);
+   return __builtin_fma(r, e, r);
+}
+template <int N>
+__device__ __forceinline__ void batch_reciprocals(const double (&d)[4], double (&inv)[4])
+{
+   if (N == 1) {
+      inv[0] = newton_rcp(d[0]);
+   } else if (N == 2) {
+      const double r = newton_rcp(d[0] * d[1]);
+      inv[0] = r * d[1];
+      inv[1] = r * d[0];
+   } else if (N == 3) {
+      const double a = d[0] * d[1];
+      const double r = newton_rcp(a * d[2]);
+      const double ra = r * d[2]; // 1 / (d0 d1)
+      inv[0] = ra * d[1];
+      inv[1] = ra * d[0];
+      inv[2] = r * a;
+   } else {
+      const double a = d[0] * d[1], b = d[2] * d[3];
+      const double r = newton_rcp(a * b);
+      const double ra = r * b, rb = r * a;
+      inv[0] = ra * d[1];
+      inv[1] = ra * d[0];
+      inv[2] = rb * d[3];
+      inv[3] = rb * d[2];
+   }
+}
+// the high word of 1.0: OR-ed into the high word of a denominator that is +0.0 by construction (a row that is not part
+// of the problem), it makes the denominator 1.0
+constexpr uint32_t kOneHi = 0x3FF00000u;
+__device__ __forceinline__ double or_high_word(double x, uint32_t hi)
+{
+   return __longlong_as_double(__double_as_longlong(x) | (long long)((unsigned long long)hi << 32));
+}
+
 // fp32: v_rcp_f32 is good to 1 ulp; one Newton step on the quotient keeps n / d within ~1 ulp
 __device__ __forceinline__ float fast_div(float n, float d)
 {
@@ -339,6 +388,105 @@ __device__ __forceinline__ void top_bits_sum(T (&x)[NVAL], int lb)
    }
 }
 
+// ------------------------------------------------------------------ the matrix lane map
+// Where the lanes of a group sit inside the wave decides what its all-reduces cost.  One v_mfma_f64_4x4x4_4b sums
+// over lane bits 4 and 5 (A = 1, B = x), and a PAIR of them -- x as A against B = 1, which also moves lane bits 0,1
+// of the source to bits 4,5 of the result, then that result as B against A = 1 -- sums over lane bits 0, 1, 4 and 5:
+// sixteen lanes for the issue time of six vector instructions, where four butterfly steps take twelve to twenty
+// (layouts: tools/probe_mfma_layout.hip).  So the ROW lanes of a group -- the wide reduction: CPL values over up to 64
+// lanes, every iteration -- take the lane bits in the order 4, 5, 0, 1 and only then the rest, and the COLUMN lanes
+// (at most 8, one value per row) sit on bits 3, 2, 1, where xor 8 and the pair (8, 4) are single rotations of the
+// 16-lane row:
+//      CL   column-lane bits    row-lane bits, in order     (the bits a group does not use number its wave's groups)
+//       1   -                   4 5 0 1 3 2
+//       2   3                   4 5 0 1 2
+//       4   3 2                 4 5 0 1
+//       8   3 2 1               4 5 0
+// except that TWO row lanes are bit 0 (one quad permute).  (One matrix instruction could sum over bit 4 alone, with
+// zeros in A where bit 5 differs -- but 0 times a NaN of the other half's group is a NaN.)
+// Every lane of a group still ends with bitwise identical sums: a matrix instruction adds its four terms in one
+// order for all of its results, and a butterfly step adds the same two numbers in both partners.
+template <int LB_CL>
+__device__ __forceinline__ int row_rank(int lane, int lbGR) // the lane's row-order bits, compressed: bit t = lane bit order[t]
+{
+   int r = (lane >> 4) & 3;
+   if (LB_CL <= 2) r |= (lane & 3) << 2;
+   else r |= (lane & 1) << 2;
+   if (LB_CL == 0) r |= (((lane >> 3) & 1) << 4) | (((lane >> 2) & 1) << 5);
+   if (LB_CL == 1) r |= ((lane >> 2) & 1) << 4;
+   if (lbGR == 1) r = ((r >> 2) & 1) | ((r & 3) << 1) | (r & ~7); // two row lanes: order 0 4 5 ...
+   return r;
+}
+template <int LB_CL>
+__device__ __forceinline__ int column_lane(int lane) { return (lane >> (4 - LB_CL)) & ((1 << LB_CL) - 1); }
+
+// all-reduce over the column lanes
+template <int LB_CL, class T>
+__device__ __forceinline__ T col_lanes_sum(T x)
+{
+   if (LB_CL >= 1) x += row_ror8(x);
+   if (LB_CL >= 2) x += row_ror4(x); // symmetric under the rotation by 8 by now: this adds the xor-4 partner's pair
+   if (LB_CL >= 3) x = xor_sum<2, false>(x);
+   return x;
+}
+template <int LB_CL, class T>
+__device__ __forceinline__ T col_lanes_max(T x)
+{
+   if (LB_CL >= 1) x = fmax(x, row_ror8(x));
+   if (LB_CL >= 2) x = fmax(x, row_ror4(x));
+   if (LB_CL >= 3) x = fmax(x, xor_get<2>(x));
+   return x;
+}
+
+// all-reduce of NVAL values over the first lbGR row-lane bits (lbGR wave-uniform)
+template <int LB_CL, int NVAL>
+__device__ __forceinline__ void row_lanes_sum(double (&x)[NVAL], int lbGR)
+{
+   static_assert(LB_CL <= 3, "the matrix lane map has at most 8 column lanes");
+   if (lbGR >= 4) {
+#pragma unroll
+      for (int v = 0; v < NVAL; ++v) x[v] = __builtin_amdgcn_mfma_f64_4x4x4f64(x[v], 1.0, 0.0, 0, 0, 0);
+#pragma unroll
+      for (int v = 0; v < NVAL; ++v) x[v] = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, x[v], 0.0, 0, 0, 0);
+   } else if (lbGR >= 2) {
+#pragma unroll
+      for (int v = 0; v < NVAL; ++v) x[v] = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, x[v], 0.0, 0, 0, 0);
+   }
+   if (lbGR == 3 || lbGR == 1) {
+#pragma unroll
+      for (int v = 0; v < NVAL; ++v) x[v] = xor_sum<1, false>(x[v]);
+   }
+   if (LB_CL == 0 && lbGR >= 5) {
+#pragma unroll
+      for (int v = 0; v < NVAL; ++v) x[v] += row_ror8(x[v]);
+   }
+   if (LB_CL == 0 && lbGR >= 6) {
+#pragma unroll
+      for (int v = 0; v < NVAL; ++v) x[v] += row_ror4(x[v]);
+   }
+   if (LB_CL == 1 && lbGR >= 5) {
+#pragma unroll
+      for (int v = 0; v < NVAL; ++v) x[v] = xor_sum<4, false>(x[v]);
+   }
+}
+// fp32 has no matrix instruction that sums: the same bits as butterfly steps
+template <int LB_CL, int NVAL>
+__device__ __forceinline__ void row_lanes_sum(float (&x)[NVAL], int lbGR)
+{
+#define SB_STEP(MASKV)                                                                          \
+   {                                                                                            \
+      _Pragma("unroll") for (int v = 0; v < NVAL; ++v) x[v] = xor_sum<MASKV, false>(x[v]);      \
+   }
+   if (lbGR >= 2) SB_STEP(16)
+   if (lbGR >= 2) SB_STEP(32)
+   if (lbGR >= 3 || lbGR == 1) SB_STEP(1)
+   if (lbGR >= 4) SB_STEP(2)
+   if (LB_CL == 0 && lbGR >= 5) SB_STEP(8)
+   if (LB_CL == 0 && lbGR >= 6) SB_STEP(4)
+   if (LB_CL == 1 && lbGR >= 5) SB_STEP(4)
+#undef SB_STEP
+}
+
 #ifdef SB_STAMPS
 // Diagnostic build only (make stamps): per-wave cycle stamps, never compiled into the
 // product library.  [wave][8] = {start, after class lookup, first refill done, end,
@@ -383,10 +531,18 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
    const int G = BLOCK ? 64 * NW : GW;
    const int GR = G >> LB_CL;                              // row lanes per group
    const int lbGR = lbGW - LB_CL;                          // (wave form) log2 of the row lanes
-   const int grp = HIMAP ? ((lane >> LB_CL) & ((64 >> lbGW) - 1)) : (lane >> lbGW); // (wave form) group inside the wave
-   const int gc = HIMAP ? (lane & (CL - 1)) : ((BLOCK ? (int)threadIdx.x : (lane & (GW - 1))) & (CL - 1));
-   const int gr = HIMAP ? (lane >> (6 - lbGR)) : ((BLOCK ? (int)threadIdx.x : (lane & (GW - 1))) >> LB_CL);
+   // HIMAP: the later phases' map; else the matrix lane map (see row_rank)
+   constexpr int LB_MM = HIMAP ? 0 : LB_CL; // (the matrix map's helpers are not instantiated for HIMAP's 16 column lanes)
+   const int rrank = row_rank<LB_MM>(lane, lbGR);
+   const int grp = HIMAP ? ((lane >> LB_CL) & ((64 >> lbGW) - 1)) : (rrank >> lbGR); // (wave form) group inside the wave
+   const int gc = HIMAP ? (lane & (CL - 1)) : column_lane<LB_MM>(lane);
+   const int gr = HIMAP ? (lane >> (6 - lbGR)) : (BLOCK ? (rrank | (wave_id << lbGR)) : (rrank & ((1 << lbGR) - 1)));
    const int g = gc | (gr << LB_CL);                       // index inside the group; 0 = its leader
+   // all-reduce over the column lanes of the group
+   auto col_sum = [&](T x) -> T {
+      if constexpr (HIMAP) return low_bits_sum<LB_CL>(x);
+      else return col_lanes_sum<LB_MM>(x);
+   };
    bool batch_taken = false; // the one refill has happened
    int phase = 0;
    int r_used = R; // block form: rows per row lane the current locus needs (workgroup-uniform)
@@ -397,15 +553,15 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
    // all-reduce over the row lanes of the group
    auto row_lane_sum = [&](auto &x, auto nval_tag) {
       constexpr int NVAL = decltype(nval_tag)::value;
-      if (HIMAP) top_bits_sum<NVAL>(x, lbGR);
-      else high_bits_sum<LB_CL, NVAL>(x, lbGW);
+      if constexpr (HIMAP) top_bits_sum<NVAL>(x, lbGR);
+      else row_lanes_sum<LB_MM, NVAL>(x, lbGR);
       if (BLOCK) {
          // cross-wave: [2 phases][NV values][CL column lanes][NW]; every lane then adds
          // the NW partials in the same order
          T *buf = s_red + (size_t)phase * (NV * CL * NW);
-         if (lane < CL) {
+         if (rrank == 0) { // one lane per column lane
 #pragma unroll
-            for (int v = 0; v < NVAL; ++v) buf[(v * CL + lane) * NW + wave_id] = x[v];
+            for (int v = 0; v < NVAL; ++v) buf[(v * CL + gc) * NW + wave_id] = x[v];
          }
          __syncthreads();
          // the partials of a few values at a time: all NVAL x NW of them in flight together cost the block
@@ -455,7 +611,13 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
       for (int jj = 0; jj < CPL; ++jj) scale[jj] = (cs[jj] == T(0)) ? T(0) : T(1) / cs[jj];
    };
    T nn[R];      // n_i as T (obs_d, estimate.cpp:418-419); 0 for dropped rows
-   bool act[R];       // row kept by init() (estimate.cpp:377-390)
+   // a row that init() dropped (estimate.cpp:377-390), or that lies beyond the locus, has F = 0 and n = 0 here, hence
+   // the denominator +0.0.  fp64: `fix` carries the high word that turns exactly that into 1.0 (weight 0 / 1 = 0);
+   // fp32: the weight is selected away
+   // (not for the tall tile: it has no registers to spare for the block's reciprocals)
+   constexpr bool kBatchDiv = std::is_same<T, double>::value && R * CPL <= 64;
+   uint32_t fix[R];
+   bool act[R];
    T theta[CPL];
    T theta0 = T(0);
    int it = 0;
@@ -468,6 +630,7 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
    for (int r = 0; r < R; ++r) {
       nn[r] = T(0);
       act[r] = false;
+      fix[r] = kOneHi;
 #pragma unroll
       for (int j = 0; j < CPL; ++j) F[r][j] = T(0);
    }
@@ -533,20 +696,25 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
                v[jj] = x;
             }
             // any weight of the row > 1e-5 (:380), over all column lanes
-            if (CL >= 2) mx = fmax(mx, xor_get<1>(mx));
-            if (CL >= 4) mx = fmax(mx, xor_get<2>(mx));
-            if (CL >= 8) mx = fmax(mx, xor_get<4>(mx));
-            if (CL >= 16) mx = fmax(mx, xor_get<8>(mx));
+            if constexpr (HIMAP) {
+               if (CL >= 2) mx = fmax(mx, xor_get<1>(mx));
+               if (CL >= 4) mx = fmax(mx, xor_get<2>(mx));
+               if (CL >= 8) mx = fmax(mx, xor_get<4>(mx));
+               if (CL >= 16) mx = fmax(mx, xor_get<8>(mx));
+            } else {
+               mx = col_lanes_max<LB_MM>(mx);
+            }
             const bool keep = mx > (T)kRowEps;
             if (gc == 0 && keep) red[1] += T(1);
             act[r] = keep;
+            fix[r] = keep ? 0u : kOneHi;
             nn[r] = keep ? cnt : T(0);
 #pragma unroll
             for (int jj = 0; jj < CPL; ++jj) F[r][jj] = keep ? v[jj] : T(0);
          }
          // group totals: over the column lanes, then over the row lanes
-         red[0] = low_bits_sum<LB_CL>(red[0]);
-         red[1] = low_bits_sum<LB_CL>(red[1]);
+         red[0] = col_sum(red[0]);
+         red[1] = col_sum(red[1]);
          row_lane_sum(red, std::integral_constant<int, 2>());
          theta0 = red[0] / (T)ni; // :375, IEEE division
 #pragma unroll
@@ -598,7 +766,8 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
       T nt[NV]; // next_theta of the own columns
       bool dz, conv, special;
       // one EM iteration: reads tin, writes tout (all lanes, no predication)
-      auto iterate = [&](const T *tin, T *tout) {
+      auto iterate = [&](const T *tin, T *tout, auto exact_tag) {
+         constexpr bool kExact = decltype(exact_tag)::value;
          T acc[NV];
 #pragma unroll
          for (int v = 0; v < NV; ++v) acc[v] = T(0);
@@ -621,17 +790,42 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
                   T sum = T(0);
 #pragma unroll
                   for (int jj = 0; jj < CPL; ++jj) sum = fma_t(F[rb + q][jj], phi[jj], sum); // :450
-                  d[q] = low_bits_sum<LB_CL>(sum);
+                  d[q] = col_sum(sum);
                }
             }
+            if constexpr (kBatchDiv && !kExact) {
+               // the block's reciprocals from one v_rcp_f64 (see batch_reciprocals)
+               const int nb = R - rb < 4 ? R - rb : 4; // a constant once the loop is unrolled
+               double dd[4], inv[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-               if (rb + q < R) {
+               for (int q = 0; q < 4; ++q) dd[q] = q < nb ? or_high_word(d[q], fix[rb + q]) : 1.0;
+               if (nb == 4) batch_reciprocals<4>(dd, inv);
+               else if (nb == 3) batch_reciprocals<3>(dd, inv);
+               else if (nb == 2) batch_reciprocals<2>(dd, inv);
+               else batch_reciprocals<1>(dd, inv);
+#pragma unroll
+               for (int q = 0; q < 4; ++q) {
+                  if (q >= nb) continue;
                   const int r = rb + q;
-                  T w = fast_div(nn[r], d[q]);
-                  w = act[r] ? w : T(0);
+                  const T w = nn[r] * inv[q];
 #pragma unroll
                   for (int jj = 0; jj < CPL; ++jj) acc[jj] = fma_t(w, F[r][jj], acc[jj]);
+               }
+            } else {
+#pragma unroll
+               for (int q = 0; q < 4; ++q) {
+                  if (rb + q < R) {
+                     const int r = rb + q;
+                     T w;
+                     if constexpr (kBatchDiv) {
+                        w = fast_div(nn[r], or_high_word(d[q], fix[r])); // a row outside the problem: 0 / 1
+                     } else {
+                        w = fast_div(nn[r], d[q]);
+                        w = act[r] ? w : T(0);
+                     }
+#pragma unroll
+                     for (int jj = 0; jj < CPL; ++jj) acc[jj] = fma_t(w, F[r][jj], acc[jj]);
+                  }
                }
             }
          }
@@ -644,7 +838,7 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
             p2 = fma_t(df, df, p2); // :479
             tout[jj] = t;
          }
-         const T d2 = low_bits_sum<LB_CL>(p2);
+         const T d2 = col_sum(p2);
          // ||next - theta||_2 < 1e-2 (:479-480) tested on the square: kThetaLimitSq is the largest T whose
          // (correctly rounded) square root is below 1e-2, so this is the same predicate as sqrt(d2) < 1e-2 of the
          // reference, the oracle and the streaming / wide kernels, for every d2
@@ -653,7 +847,7 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
          special = have && (dz || conv || it == 0 || it + 1 == cls.it_limit);
       };
       for (;;) {
-         iterate(theta, nt); // old in theta, new in nt
+         iterate(theta, nt, std::false_type()); // old in theta, new in nt
 #ifdef SB_STAMPS
          st_iters += 1;
 #endif
@@ -667,7 +861,7 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
             break;
          }
          ++it;
-         iterate(nt, theta); // old in nt, new in theta
+         iterate(nt, theta, std::false_type()); // old in nt, new in theta
 #ifdef SB_STAMPS
          st_iters += 1;
 #endif
@@ -687,6 +881,24 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
       }
 
       // ------------------------------------------------------- per-group events
+      if constexpr (kBatchDiv) {
+         // a NaN of the batched reciprocals is a zero denominator -- or a product of several tiny ones that left the
+         // exponent range: the groups that saw one repeat the iteration with a division per row and take ITS
+         // verdict and thetas (the other groups keep what they have: their results never depend on their neighbours)
+         const bool suspect = special && dz;
+         if (BLOCK ? suspect : __any(suspect)) {
+            T keep_nt[CPL];
+            const bool keep_conv = conv, keep_special = special;
+#pragma unroll
+            for (int jj = 0; jj < CPL; ++jj) keep_nt[jj] = nt[jj];
+            iterate(theta, nt, std::true_type());
+#pragma unroll
+            for (int jj = 0; jj < CPL; ++jj) nt[jj] = suspect ? nt[jj] : keep_nt[jj];
+            conv = suspect ? conv : keep_conv;
+            dz = suspect && dz;
+            special = keep_special;
+         }
+      }
       // first iteration done: switch to the column-normalised problem (:466-478)
       const bool norm = special && !dz && it == 0;
       if (BLOCK ? norm : __any(norm)) {
@@ -741,13 +953,12 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
 #endif
    }
 #ifdef SB_STAMPS
-   if (lane == 0) {
+   if (lane == 0 && !BLOCK) {
       const unsigned wg = (blockIdx.x * (blockDim.x >> 6) + wave_id) & (kStampWaves - 1);
       sb_debug_stamps[wg * 8 + 2] = st_first;
       sb_debug_stamps[wg * 8 + 3] = sb_now();
       sb_debug_stamps[wg * 8 + 4] = st_batches;
       sb_debug_stamps[wg * 8 + 5] = st_iters;
-      sb_debug_stamps[wg * 8 + 6] = st_refill;
       sb_debug_stamps[wg * 8 + 7] = st_events;
    }
 #endif
@@ -824,10 +1035,13 @@ __global__ __launch_bounds__(NWAVES > 0 ? 64 * NWAVES : 64,
    const int c = find_class(ph.table, ph.n_classes, b);
    const ClassDesc d = ph.table[c];
 #ifdef SB_STAMPS
-   if ((threadIdx.x & 63) == 0) {
+   if ((threadIdx.x & 63) == 0 && NWAVES == 0) { // wave kind only: the kinds share the stamp array
       const unsigned wg = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (kStampWaves - 1);
       sb_debug_stamps[wg * 8 + 0] = st0;
       sb_debug_stamps[wg * 8 + 1] = sb_now();
+      // which SIMD the wave runs on: HW_ID simd 5:4, cu 11:8, sh 12, se 15:13; XCC_ID 3:0
+      const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+      sb_debug_stamps[wg * 8 + 6] = ((xcc & 7u) << 10) | (((hw >> 8) & 0xFFu) << 2) | ((hw >> 4) & 3u);
    }
 #endif
    ClassArgs cls;
