@@ -86,7 +86,7 @@ class Plan:
                 "n_stream_loci": out[5], "algorithmic_bytes": out[6]}
 
     def classes(self):
-        cap = 128
+        cap = 1024
         out = (C.c_int64 * (6 * cap))()
         n = self.ctx.L.sbgpu_plan_classes(self.h, out, cap)
         keys = ("kind", "C", "R", "G", "n_loci", "n_waves")
