@@ -114,6 +114,33 @@ def test_gpu_c2_sample_against_oracle(ctx, oracle):
     assert theta_err(r["theta"], o_theta).max() < THETA_RTOL
 
 
+def test_gpu_tiny_denominators_are_not_zero_denominators(ctx, oracle):
+    """The tile kernels invert the PRODUCT of up to four row denominators (one v_rcp_f64 for four rows): the product
+    of two tiny denominators underflows long before either is zero, and that must not be taken for the reference's
+    `denom == 0` (estimate.cpp:451).  Isoform B below loses its reads to A and decays by a factor 5 per iteration;
+    bins that fit only B and hold no reads then have denominators 0.4 theta_B: their pairwise product leaves the
+    exponent range after ~220 iterations, theta_B itself flushes to zero -- the real zero denominator -- after 326 to
+    650, depending on the locus; two nearly equal isoforms C, D keep the EM running that long."""
+    from strawberry_amd import synth
+    def locus(decay_rows):
+        rows, cnt = [[1.0, 0.5, 0, 0], [1.0, 0.0, 0, 0]], [100, 100]
+        for _ in range(decay_rows):
+            rows.append([0.0, 1.0, 0, 0]); cnt.append(0)
+        for k in range(6):
+            a = 0.5 + 0.05 * k
+            rows.append([0, 0, a, a * (1 + 1e-3 * (k - 2.5))]); cnt.append(50 + k)
+        return np.array(cnt, np.int32), np.array(rows)
+    # alone, eight to a wave, and with enough rows for several row lanes
+    loci = [locus(2), locus(4), locus(1), locus(9), locus(30), locus(70)] + [locus(2 + k % 3) for k in range(40)]
+    b = synth.from_loci(loci)
+    _, r = solve(b, ctx)
+    o_theta, o_status, o_iters = oracle.em_batch(b.row_off, b.iso_off, b.f_off, b.count, b.F, threads=2)
+    assert (o_status == 2).all() and o_iters[:3].min() > 300   # DENOM_ZERO, long after the products underflow
+    np.testing.assert_array_equal(r["status"], o_status)
+    np.testing.assert_array_equal(r["iters"], o_iters)
+    assert theta_err(r["theta"], o_theta).max() < THETA_RTOL
+
+
 @pytest.mark.parametrize("config", ["c2", "c3"])
 def test_gpu_full_size_configs_against_oracle(ctx, oracle, config):
     """BASELINE.json's configurations at FULL size -- C2: 10 000 loci x 8 isoforms x 1000 fragments,
