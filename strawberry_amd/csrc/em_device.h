@@ -524,7 +524,12 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
    constexpr int NW = BLOCK ? NWAVES : 1;                  // waves per group
    constexpr int LB_CL = ilog2(CL);
    constexpr int NV = CPL; // values in the per-iteration column reduce
-   const int lane = threadIdx.x & 63;
+   // (the lane id goes through an empty asm: one kernel holds twenty instantiations of this body behind a switch, and
+   // the compiler otherwise hoists every instantiation's lane-derived addresses in front of the switch -- dozens of
+   // live registers that it then spills)
+   int lane_opaque = threadIdx.x & 63;
+   asm volatile("" : "+v"(lane_opaque));
+   const int lane = lane_opaque;
    const int wave_id = threadIdx.x >> 6;
    const int GW = BLOCK ? 64 : (1 << lbG);                 // lanes of the group inside one wave
    const int lbGW = BLOCK ? 6 : lbG;
