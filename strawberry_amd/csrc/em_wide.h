@@ -26,7 +26,7 @@ constexpr int kWideWaves = kWideThreads / 64;
 // (the unrolled row loop's temporaries and the gather's granules share the 256 VGPRs with the tile)
 constexpr int wide_rows(int nslot) { return nslot <= 2 ? 20 : (nslot <= 4 ? 12 : 8); }
 constexpr unsigned kWideSpinLimit = 1u << 20;  // sweeps of a round's partials before giving up (~ seconds)
-constexpr int kWideSweep = 4;                  // granules a thread has in flight per sweep
+constexpr int kWideSweep = 8;                  // granules a thread has in flight per sweep (8: a 13-workgroup locus of 256 columns in one pass)
 constexpr int kWideStageDoubles = 8 * kWideThreads; // LDS staging area of the gather: 32 KB
 
 struct WideDesc {
@@ -172,6 +172,9 @@ __device__ __forceinline__ void em_wide_body(const WideArgs &g, const int di)
       const char *in = (const char *)bufs + (size_t)(round & 1) * G * nv * 16;
       const int chunk_g = max(1, (kWideSweep * kWideThreads) / nv); // producers per chunk (one pass covers a chunk)
       double run[2] = {0.0, 0.0};                                    // running sums of the (at most 2) values this thread owns
+      // the others' granules take ~0.5 us to become visible: a sweep issued right behind the own stores mostly
+      // comes back empty and costs a memory round trip (measured: 5.0 -> 4.75 us per iteration at two workgroups)
+      __builtin_amdgcn_s_sleep(8);
       for (int v0 = 0; v0 < G; v0 += chunk_g) {
          const int n = min(chunk_g, G - v0) * nv;                    // granules of this chunk: [v0 * nv, v0 * nv + n)
          unsigned pending = 0;
@@ -273,13 +276,28 @@ __device__ __forceinline__ void em_wide_body(const WideArgs &g, const int di)
             dd[q] = part;
          }
          high_bits_sum<0, 4>(dd, 6); // all-reduce over the 64 lanes (bits 4 and 5 through the matrix pipe)
+         // the four reciprocals from one v_rcp_f64 (em_device.h: batch_reciprocals) -- the denominators are the same
+         // in all 64 lanes, so whether their product stays inside the exponent range is a wave-uniform question,
+         // asked before the fact: if it does not (tiny denominators of a dying isoform's bins, or a zero, which the
+         // flag above reports anyway), every row gets its own reciprocal
+         double de[4], inv[4];
+#pragma unroll
+         for (int q = 0; q < 4; ++q) {
+            const bool act = (act_mask >> (rb + q)) & 1u; // compile-time row: one scalar bit test
+            zf |= (act && dd[q] == 0.0) ? 1 : 0;          // :451
+            de[q] = act ? dd[q] : 1.0;                    // a row outside the problem: n = 0, weight 0 / 1
+         }
+         const double prod = (de[0] * de[1]) * (de[2] * de[3]);
+         if (prod >= 0x1p-960) {
+            batch_reciprocals<4>(de, inv);
+         } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) inv[q] = newton_rcp(de[q]);
+         }
 #pragma unroll
          for (int q = 0; q < 4; ++q) {
             const int r = rb + q;
-            const bool act = (act_mask >> r) & 1u; // compile-time r: one scalar bit test
-            zf |= (act && dd[q] == 0.0) ? 1 : 0; // :451
-            double wgt = fast_div((double)nn_i[r], dd[q]);
-            wgt = act ? wgt : 0.0;
+            const double wgt = (double)nn_i[r] * inv[q];
 #pragma unroll
             for (int k = 0; k < NSLOT; ++k) acc[k] = __builtin_fma(wgt, F[r][k], acc[k]);
          }
