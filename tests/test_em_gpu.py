@@ -218,6 +218,36 @@ def test_gpu_abundance_and_tpm_match_oracle(ctx, oracle, golden):
         np.testing.assert_allclose(r["tpm"], tpm, rtol=1e-12, atol=0)
 
 
+def test_wide_kernel_tiny_denominators_are_not_zero_denominators(ctx, oracle):
+    """The same on the multi-workgroup kernel for loci of more than 64 isoforms (it checks the product's range
+    before it inverts it): rows 2 and 10 -- both bins of the dying isoform -- share a wave's block of four."""
+    from strawberry_amd import synth
+    def wide_locus(decay_rows, extra=66):
+        niso = 4 + extra
+        rows, cnt = [], []
+        def row(d, n):
+            r = np.zeros(niso)
+            for k, v in d.items():
+                r[k] = v
+            rows.append(r); cnt.append(n)
+        row({0: 1.0, 1: 0.5}, 100); row({0: 1.0}, 100)
+        for _ in range(decay_rows):
+            row({1: 1.0}, 0)
+        for k in range(6):
+            a = 0.5 + 0.05 * k
+            row({2: a, 3: a * (1 + 1e-3 * (k - 2.5))}, 50 + k)
+        for k in range(extra):
+            row({4 + k: 1.0}, 10 + k % 7)
+        return np.array(cnt, np.int32), np.array(rows)
+    b = synth.from_loci([wide_locus(9), wide_locus(12), wide_locus(40, extra=130)])
+    _, r = solve(b, ctx)
+    o_theta, o_status, o_iters = oracle.em_batch(b.row_off, b.iso_off, b.f_off, b.count, b.F, threads=2)
+    assert (o_status == 2).all() and o_iters.min() > 150
+    np.testing.assert_array_equal(r["status"], o_status)
+    np.testing.assert_array_equal(r["iters"], o_iters)
+    assert theta_err(r["theta"], o_theta).max() < THETA_RTOL
+
+
 def test_gpu_phased_execution_matches_oracle(ctx, oracle, monkeypatch):
     """Phases of the wave kind: loci still running at an iteration limit are suspended (theta and the iteration
     count are their whole state) and continue in a later launch with MORE lanes per locus (lane-rich layouts,
