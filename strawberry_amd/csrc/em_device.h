@@ -243,22 +243,22 @@ template <> struct ThetaLimitSq<float> { static constexpr float value = 0x1.a36e
 
 // ================================================================== tile kernel
 // A locus is owned by a GROUP of G = CL x GR lanes laid out as a 2-D grid:
-//   gc = g % CL  "column lane": owns columns [gc*CPL, gc*CPL + CPL)
-//   gr = g / CL  "row lane":    owns rows gr, gr+GR, gr+2GR, ... (R of them)
+//   gc  "column lane": owns columns [gc*CPL, gc*CPL + CPL)
+//   gr  "row lane":    owns rows gr, gr+GR, gr+2GR, ... (R of them)
 // so each lane keeps an R x CPL tile of F in registers for the whole solve, plus
 // theta for its own CPL columns.  Per iteration the group needs
-//   - the row denominators: all-reduce over the CL column lanes (low lane bits),
-//   - the weighted column sums: all-reduce over the GR row lanes (high lane bits;
-//     in the workgroup form it continues through LDS across the waves),
-// both as DPP butterflies; every lane of a group ends with bitwise identical sums,
-// so the convergence decision is group-uniform by construction.
+//   - the row denominators: all-reduce over the CL column lanes,
+//   - the weighted column sums: all-reduce over the GR row lanes (in the workgroup
+//     form it continues through LDS across the waves);
+// which lane bits carry gc and gr -- and hence what these reductions cost -- is the "matrix lane map" below
+// (row_rank).  Every lane of a group ends with bitwise identical sums, so the convergence decision is
+// group-uniform by construction.
 //
 // Wave form  (BLOCK = false): G = 2^lbG <= 64 lanes, 64/G groups share a wave and
 //                             run independent loci; G is a run-time (wave-uniform)
 //                             value so that one kernel serves every size class.
-// Block form (BLOCK = true):  the group is the whole workgroup (256 or 512 lanes).
-// Waves pull loci from their class list through an atomic cursor, one per group,
-// whenever all their groups are idle, until the list runs dry.
+// Block form (BLOCK = true):  the group is the whole workgroup (256 lanes).
+// A workgroup serves exactly one batch of its class (64/G loci; one locus in the block form).
 
 template <int MASK>
 __device__ __forceinline__ double xor_get(double x)
