@@ -508,6 +508,10 @@ hipError_t read_stamps_block(void *out, size_t bytes);
 hipError_t read_stamps_block_tall(void *out, size_t bytes);
 #endif
 
+// any lane of the wave: the lane mask itself compared with zero (one scalar instruction; __any goes through a
+// v_cndmask / v_cmp pair)
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
 constexpr int kBlockWaves = 4; // block form: 256 lanes, one wave per SIMD, up to 512 VGPRs each
 
 // NWAVES = 0: wave form; NWAVES = 4: block form.  R is the register-tile capacity
@@ -625,7 +629,7 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
    bool act[R];
    T theta[CPL];
    T theta0 = T(0);
-   int it = 0;
+   int it = 0; // iterations done; wave-uniform: the groups of a wave (the one batch it serves) start together
    int niso = 0;
    int locus = 0;
    int64_t iso_base = 0;
@@ -650,7 +654,7 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
       // Wave-synchronous: when every group of the wave (block form: the workgroup)
       // is idle, each group pulls its next locus from the class list.  All lanes
       // load together, so F, theta, ... are simply overwritten.
-      if (BLOCK ? !have : !__any(have)) {
+      if (BLOCK ? !have : !wave_any(have)) {
 #ifdef SB_STAMPS
          st_t = sb_now();
 #endif
@@ -659,7 +663,7 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
          if (batch_taken) break;
          batch_taken = true;
          const int idx = BLOCK ? cls.batch : cls.batch * (64 >> lbGW) + grp;
-         if (BLOCK ? (idx >= cls.n) : !__any(idx < cls.n)) break;
+         if (BLOCK ? (idx >= cls.n) : !wave_any(idx < cls.n)) break;
          const bool got = idx < cls.n;
          const int loc = got ? cls.loci[idx] : 0; // idle groups shadow locus 0, results discarded
          const int64_t r0 = a.row_off[loc];
@@ -734,7 +738,8 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
          if (cls.resume) {
             // state saved at the previous phase's limit: theta and the iteration count;
             // the column scale is recomputed exactly as it was computed the first time
-            it = got ? a.iters[loc] : 0;
+            // (the same for every locus of the wave: they were all suspended at the previous phase's limit)
+            it = __builtin_amdgcn_readfirstlane(got ? a.iters[loc] : 0);
 #pragma unroll
             for (int jj = 0; jj < CPL; ++jj)
                theta[jj] = (gc * CPL + jj < ni) ? a.theta[ib + gc * CPL + jj] : T(0);
@@ -760,7 +765,7 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
          if (!st_first) st_first = sb_now();
 #endif
       }
-      if (BLOCK ? !have : !__any(have)) continue; // e.g. only init()==false loci: pull again
+      if (BLOCK ? !have : !wave_any(have)) continue; // e.g. only init()==false loci: pull again
 
       // ------------------------------------------------------ steady-state loop
       // Runs until some group of the wave needs attention (first iteration's
@@ -770,6 +775,9 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
       // select sits on the per-iteration path.
       T nt[NV]; // next_theta of the own columns
       bool dz, conv, special;
+      unsigned long long special_mask = 0;
+      const unsigned long long have_mask = __builtin_amdgcn_ballot_w64(have); // (have changes only outside the loop)
+      T d2_last; // ||next - theta||^2 of the iteration just done
       // one EM iteration: reads tin, writes tout (all lanes, no predication)
       auto iterate = [&](const T *tin, T *tout, auto exact_tag) {
          constexpr bool kExact = decltype(exact_tag)::value;
@@ -847,22 +855,32 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
          // ||next - theta||_2 < 1e-2 (:479-480) tested on the square: kThetaLimitSq is the largest T whose
          // (correctly rounded) square root is below 1e-2, so this is the same predicate as sqrt(d2) < 1e-2 of the
          // reference, the oracle and the streaming / wide kernels, for every d2
-         conv = d2 <= ThetaLimitSq<T>::value;
-         dz = __builtin_isnan(d2); // some kept row had a zero denominator (:451), see above
-         special = have && (dz || conv || it == 0 || it + 1 == cls.it_limit);
+         // One compare on the per-iteration path: "not above the limit" is converged OR NaN -- some kept row had a
+         // zero denominator (:451), see above; the event code tells the two apart.  The iteration count is a scalar.
+         // The groups that need attention are kept as a lane MASK in scalar registers (the compare writes one; the
+         // rest is scalar arithmetic, and "any?" is one scalar compare with zero).
+         d2_last = d2;
+         const bool edge = (unsigned)(it - 1) >= (unsigned)(cls.it_limit - 2); // it == 0 or it + 1 == limit, one compare
+         const unsigned long long stop_mask = __builtin_amdgcn_ballot_w64(!(d2 > ThetaLimitSq<T>::value));
+         special_mask = have_mask & (edge ? ~0ull : stop_mask);
+      };
+      auto lane_of = [&](unsigned long long m) -> bool { return (m >> lane) & 1ull; };
+      auto classify = [&]() {
+         conv = d2_last <= ThetaLimitSq<T>::value;
+         dz = __builtin_isnan(d2_last);
       };
       for (;;) {
          iterate(theta, nt, std::false_type()); // old in theta, new in nt
 #ifdef SB_STAMPS
          st_iters += 1;
 #endif
-         if (BLOCK ? special : __any(special)) {
+         if (special_mask != 0ull) {
             // groups that simply finished an iteration move on (:481); the special ones keep
             // (old, new) = (theta, nt) for the event handling below
+            special = lane_of(special_mask);
             const bool adv = have && !special;
 #pragma unroll
             for (int jj = 0; jj < CPL; ++jj) theta[jj] = adv ? nt[jj] : theta[jj];
-            it += adv ? 1 : 0;
             break;
          }
          ++it;
@@ -870,43 +888,48 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
 #ifdef SB_STAMPS
          st_iters += 1;
 #endif
-         if (BLOCK ? special : __any(special)) {
+         if (special_mask != 0ull) {
             // special groups: bring (old, new) back to (theta, nt); the others already hold
             // their new theta in `theta`
+            special = lane_of(special_mask);
 #pragma unroll
             for (int jj = 0; jj < CPL; ++jj) {
                const T o = nt[jj], n2 = theta[jj];
                theta[jj] = special ? o : n2;
                nt[jj] = special ? n2 : o;
             }
-            it += (have && !special) ? 1 : 0;
             break;
          }
          ++it;
       }
 
       // ------------------------------------------------------- per-group events
+      // (`it` still counts the iterations BEFORE the one whose results are looked at here)
+      classify();
       if constexpr (kBatchDiv) {
          // a NaN of the batched reciprocals is a zero denominator -- or a product of several tiny ones that left the
          // exponent range: the groups that saw one repeat the iteration with a division per row and take ITS
          // verdict and thetas (the other groups keep what they have: their results never depend on their neighbours)
          const bool suspect = special && dz;
-         if (BLOCK ? suspect : __any(suspect)) {
+         if (BLOCK ? suspect : wave_any(suspect)) {
             T keep_nt[CPL];
             const bool keep_conv = conv, keep_special = special;
+            const unsigned long long keep_mask = special_mask;
 #pragma unroll
             for (int jj = 0; jj < CPL; ++jj) keep_nt[jj] = nt[jj];
             iterate(theta, nt, std::true_type());
+            classify();
 #pragma unroll
             for (int jj = 0; jj < CPL; ++jj) nt[jj] = suspect ? nt[jj] : keep_nt[jj];
             conv = suspect ? conv : keep_conv;
             dz = suspect && dz;
             special = keep_special;
+            special_mask = keep_mask;
          }
       }
       // first iteration done: switch to the column-normalised problem (:466-478)
       const bool norm = special && !dz && it == 0;
-      if (BLOCK ? norm : __any(norm)) {
+      if (BLOCK ? norm : wave_any(norm)) {
          T keep_scale[CPL];
 #pragma unroll
          for (int jj = 0; jj < CPL; ++jj) keep_scale[jj] = scale[jj];
@@ -935,11 +958,10 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
                st = (cls.it_limit >= kMaxIter) ? kStMaxIter : kStRunning;
             }
          }
-         ++it;
          if (finished) {
             if (g == 0) {
                a.status[locus] = st;
-               a.iters[locus] = it;
+               a.iters[locus] = it + 1;
                if (st == kStRunning) {
                   const int c2 = cls.route[locus];
                   cls.out[cls.next_table[c2].loci_off + atomicAdd(cls.out_count + c2, 1)] = locus;
@@ -953,6 +975,7 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
             have = false;
          }
       }
+      ++it; // the iteration that ended the loop is done, for every group
 #ifdef SB_STAMPS
       st_events += sb_now() - st_t;
 #endif
