@@ -560,10 +560,14 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
 #endif
 
    // all-reduce over the row lanes of the group
-   auto row_lane_sum = [&](auto &x, auto nval_tag) {
+   // (lb_tag: the number of row-lane bits as a compile-time constant where the caller has one -- the steady-state
+   // loop is instantiated for the common values, so that no branch on it is left inside -- else -1: use lbGR)
+   auto row_lane_sum = [&](auto &x, auto nval_tag, auto lb_tag) {
       constexpr int NVAL = decltype(nval_tag)::value;
-      if constexpr (HIMAP) top_bits_sum<NVAL>(x, lbGR);
-      else row_lanes_sum<LB_MM, NVAL>(x, lbGR);
+      constexpr int LBC = decltype(lb_tag)::value;
+      const int lb = LBC >= 0 ? LBC : lbGR;
+      if constexpr (HIMAP) top_bits_sum<NVAL>(x, lb);
+      else row_lanes_sum<LB_MM, NVAL>(x, lb);
       if (BLOCK) {
          // cross-wave: [2 phases][NV values][CL column lanes][NW]; every lane then adds
          // the NW partials in the same order
@@ -615,7 +619,7 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
             if (!BLOCK || (r & ~3) < r_used) sum += F[r][jj];
          cs[jj] = sum;
       }
-      row_lane_sum(cs, std::integral_constant<int, CPL>());
+      row_lane_sum(cs, std::integral_constant<int, CPL>(), std::integral_constant<int, -1>());
 #pragma unroll
       for (int jj = 0; jj < CPL; ++jj) scale[jj] = (cs[jj] == T(0)) ? T(0) : T(1) / cs[jj];
    };
@@ -724,7 +728,7 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
          // group totals: over the column lanes, then over the row lanes
          red[0] = col_sum(red[0]);
          red[1] = col_sum(red[1]);
-         row_lane_sum(red, std::integral_constant<int, 2>());
+         row_lane_sum(red, std::integral_constant<int, 2>(), std::integral_constant<int, -1>());
          theta0 = red[0] / (T)ni; // :375, IEEE division
 #pragma unroll
          for (int jj = 0; jj < CPL; ++jj) {
@@ -779,7 +783,7 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
       const unsigned long long have_mask = __builtin_amdgcn_ballot_w64(have); // (have changes only outside the loop)
       T d2_last; // ||next - theta||^2 of the iteration just done
       // one EM iteration: reads tin, writes tout (all lanes, no predication)
-      auto iterate = [&](const T *tin, T *tout, auto exact_tag) {
+      auto iterate = [&](const T *tin, T *tout, auto exact_tag, auto lb_tag) {
          constexpr bool kExact = decltype(exact_tag)::value;
          T acc[NV];
 #pragma unroll
@@ -842,7 +846,7 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
                }
             }
          }
-         row_lane_sum(acc, std::integral_constant<int, NV>());
+         row_lane_sum(acc, std::integral_constant<int, NV>(), lb_tag);
          T p2 = T(0);
 #pragma unroll
          for (int jj = 0; jj < CPL; ++jj) {
@@ -869,8 +873,9 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
          conv = d2_last <= ThetaLimitSq<T>::value;
          dz = __builtin_isnan(d2_last);
       };
+      auto run = [&](auto lb_tag) {
       for (;;) {
-         iterate(theta, nt, std::false_type()); // old in theta, new in nt
+         iterate(theta, nt, std::false_type(), lb_tag); // old in theta, new in nt
 #ifdef SB_STAMPS
          st_iters += 1;
 #endif
@@ -884,7 +889,7 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
             break;
          }
          ++it;
-         iterate(nt, theta, std::false_type()); // old in nt, new in theta
+         iterate(nt, theta, std::false_type(), lb_tag); // old in nt, new in theta
 #ifdef SB_STAMPS
          st_iters += 1;
 #endif
@@ -902,6 +907,14 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
          }
          ++it;
       }
+      };
+      // the loop once per common group height (wave form; the block form's is a constant anyway)
+      if (BLOCK || HIMAP) run(std::integral_constant<int, -1>());
+      else if (lbGR == 4 && LB_CL <= 2) run(std::integral_constant<int, (LB_CL <= 2 ? 4 : -1)>());
+      else if (lbGR == 3) run(std::integral_constant<int, 3>());
+      else if (lbGR == 5 && LB_CL <= 1) run(std::integral_constant<int, (LB_CL <= 1 ? 5 : -1)>());
+      else if (lbGR == 2) run(std::integral_constant<int, 2>());
+      else run(std::integral_constant<int, -1>());
 
       // ------------------------------------------------------- per-group events
       // (`it` still counts the iterations BEFORE the one whose results are looked at here)
@@ -917,7 +930,7 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
             const unsigned long long keep_mask = special_mask;
 #pragma unroll
             for (int jj = 0; jj < CPL; ++jj) keep_nt[jj] = nt[jj];
-            iterate(theta, nt, std::true_type());
+            iterate(theta, nt, std::true_type(), std::integral_constant<int, -1>());
             classify();
 #pragma unroll
             for (int jj = 0; jj < CPL; ++jj) nt[jj] = suspect ? nt[jj] : keep_nt[jj];
