@@ -606,9 +606,7 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
    };
 
    T F[R][CPL];
-   T scale[CPL]; // 1, then 1/column-sum after the first iteration: F' = F * scale (:466-478)
-   // F <- column-normalised F (:466-478), a zero column stays zero: F itself is left
-   // untouched in registers, the column scale takes the normalisation
+   T scale[CPL]; // 1 / column sum over the kept rows (:466-478), a zero column stays zero; used once, by normalise_tile
    auto column_scale = [&]() {
       T cs[CPL];
 #pragma unroll
@@ -622,6 +620,16 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
       row_lane_sum(cs, std::integral_constant<int, CPL>(), std::integral_constant<int, -1>());
 #pragma unroll
       for (int jj = 0; jj < CPL; ++jj) scale[jj] = (cs[jj] == T(0)) ? T(0) : T(1) / cs[jj];
+   };
+   // F <- F * scale, once, when the first iteration is over (all groups of a wave reach that point together): what the
+   // reference does (:466-478), and it keeps a multiply per column off the per-iteration path
+   auto normalise_tile = [&](bool mine) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+         if (BLOCK && (r & ~3) >= r_used) continue;
+#pragma unroll
+         for (int jj = 0; jj < CPL; ++jj) F[r][jj] = mine ? F[r][jj] * scale[jj] : F[r][jj];
+      }
    };
    T nn[R];      // n_i as T (obs_d, estimate.cpp:418-419); 0 for dropped rows
    // a row that init() dropped (estimate.cpp:377-390), or that lies beyond the locus, has F = 0 and n = 0 here, hence
@@ -748,6 +756,7 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
             for (int jj = 0; jj < CPL; ++jj)
                theta[jj] = (gc * CPL + jj < ni) ? a.theta[ib + gc * CPL + jj] : T(0);
             column_scale();
+            normalise_tile(true);
          }
          const bool empty = got && red[1] == T(0);
          if (empty) {
@@ -788,9 +797,6 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
          T acc[NV];
 #pragma unroll
          for (int v = 0; v < NV; ++v) acc[v] = T(0);
-         T phi[CPL]; // theta of the column-normalised problem seen through the raw F
-#pragma unroll
-         for (int jj = 0; jj < CPL; ++jj) phi[jj] = tin[jj] * scale[jj];
          // A zero denominator of a kept row (:451) is not tested row by row: 1 / 0 is infinite, the Newton steps turn
          // it into a NaN, the row's weight n * NaN is a NaN whatever n is, NaN * F poisons every column sum of the
          // lane -- and the same row denominator is seen by all column lanes -- so every next_theta of the group and
@@ -806,7 +812,7 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
                if (rb + q < R) {
                   T sum = T(0);
 #pragma unroll
-                  for (int jj = 0; jj < CPL; ++jj) sum = fma_t(F[rb + q][jj], phi[jj], sum); // :450
+                  for (int jj = 0; jj < CPL; ++jj) sum = fma_t(F[rb + q][jj], tin[jj], sum); // :450
                   d[q] = col_sum(sum);
                }
             }
@@ -850,7 +856,7 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
          T p2 = T(0);
 #pragma unroll
          for (int jj = 0; jj < CPL; ++jj) {
-            const T t = phi[jj] * acc[jj]; // next_theta_j = sum_i U_ij, :454-464
+            const T t = tin[jj] * acc[jj]; // next_theta_j = sum_i U_ij, :454-464
             const T df = t - tin[jj];
             p2 = fma_t(df, df, p2); // :479
             tout[jj] = t;
@@ -949,6 +955,7 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
          column_scale();
 #pragma unroll
          for (int jj = 0; jj < CPL; ++jj) scale[jj] = norm ? scale[jj] : keep_scale[jj];
+         normalise_tile(norm);
       }
       if (special) {
          bool finished = false;
