@@ -219,14 +219,6 @@ __device__ __forceinline__ void batch_reciprocals(const double (&d)[4], double (
       inv[3] = rb * d[2];
    }
 }
-// the high word of 1.0: OR-ed into the high word of a denominator that is +0.0 by construction (a row that is not part
-// of the problem), it makes the denominator 1.0
-constexpr uint32_t kOneHi = 0x3FF00000u;
-__device__ __forceinline__ double or_high_word(double x, uint32_t hi)
-{
-   return __longlong_as_double(__double_as_longlong(x) | (long long)((unsigned long long)hi << 32));
-}
-
 // fp32: v_rcp_f32 is good to 1 ulp; one Newton step on the quotient keeps n / d within ~1 ulp
 __device__ __forceinline__ float fast_div(float n, float d)
 {
@@ -632,12 +624,15 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
       }
    };
    T nn[R];      // n_i as T (obs_d, estimate.cpp:418-419); 0 for dropped rows
-   // a row that init() dropped (estimate.cpp:377-390), or that lies beyond the locus, has F = 0 and n = 0 here, hence
-   // the denominator +0.0.  fp64: `fix` carries the high word that turns exactly that into 1.0 (weight 0 / 1 = 0);
-   // fp32: the weight is selected away
-   // (not for the tall tile: it has no registers to spare for the block's reciprocals)
+   // A row that init() dropped (estimate.cpp:377-390), or that lies beyond the locus, has F = 0 and n = 0 here, hence
+   // the denominator +0.0 -- which must not look like the reference's `denom == 0` of a KEPT row.  Its dot product
+   // starts from dfix = 1 instead of 0 (the first FMA's addend: no instruction), so its denominator is CL and its
+   // weight 0 / CL = 0.
+   // (batched reciprocals: not for the tall tile, which has no registers to spare for a block's)
    constexpr bool kBatchDiv = std::is_same<T, double>::value && R * CPL <= 64;
-   uint32_t fix[R];
+   // (the tall tile has no registers for dfix either: it selects the weight of such a row away)
+   constexpr bool kDfix = R * CPL <= 64;
+   T dfix[kDfix ? R : 1];
    bool act[R];
    T theta[CPL];
    T theta0 = T(0);
@@ -650,8 +645,8 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
 #pragma unroll
    for (int r = 0; r < R; ++r) {
       nn[r] = T(0);
+      if (kDfix) dfix[r] = T(1);
       act[r] = false;
-      fix[r] = kOneHi;
 #pragma unroll
       for (int j = 0; j < CPL; ++j) F[r][j] = T(0);
    }
@@ -727,8 +722,8 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
             }
             const bool keep = mx > (T)kRowEps;
             if (gc == 0 && keep) red[1] += T(1);
+            if (kDfix) dfix[r] = keep ? T(0) : T(1);
             act[r] = keep;
-            fix[r] = keep ? 0u : kOneHi;
             nn[r] = keep ? cnt : T(0);
 #pragma unroll
             for (int jj = 0; jj < CPL; ++jj) F[r][jj] = keep ? v[jj] : T(0);
@@ -810,7 +805,7 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                if (rb + q < R) {
-                  T sum = T(0);
+                  T sum = kDfix ? dfix[rb + q] : T(0);
 #pragma unroll
                   for (int jj = 0; jj < CPL; ++jj) sum = fma_t(F[rb + q][jj], tin[jj], sum); // :450
                   d[q] = col_sum(sum);
@@ -821,7 +816,7 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
                const int nb = R - rb < 4 ? R - rb : 4; // a constant once the loop is unrolled
                double dd[4], inv[4];
 #pragma unroll
-               for (int q = 0; q < 4; ++q) dd[q] = q < nb ? or_high_word(d[q], fix[rb + q]) : 1.0;
+               for (int q = 0; q < 4; ++q) dd[q] = q < nb ? d[q] : 1.0;
                if (nb == 4) batch_reciprocals<4>(dd, inv);
                else if (nb == 3) batch_reciprocals<3>(dd, inv);
                else if (nb == 2) batch_reciprocals<2>(dd, inv);
@@ -839,13 +834,8 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
                for (int q = 0; q < 4; ++q) {
                   if (rb + q < R) {
                      const int r = rb + q;
-                     T w;
-                     if constexpr (kBatchDiv) {
-                        w = fast_div(nn[r], or_high_word(d[q], fix[r])); // a row outside the problem: 0 / 1
-                     } else {
-                        w = fast_div(nn[r], d[q]);
-                        w = act[r] ? w : T(0);
-                     }
+                     T w = fast_div(nn[r], d[q]);
+                     if (!kDfix) w = act[r] ? w : T(0);
 #pragma unroll
                      for (int jj = 0; jj < CPL; ++jj) acc[jj] = fma_t(w, F[r][jj], acc[jj]);
                   }
