@@ -910,6 +910,9 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
       else if (lbGR == 3) run(std::integral_constant<int, 3>());
       else if (lbGR == 5 && LB_CL <= 1) run(std::integral_constant<int, (LB_CL <= 1 ? 5 : -1)>());
       else if (lbGR == 2) run(std::integral_constant<int, 2>());
+      else if (lbGR == 1) run(std::integral_constant<int, 1>());
+      else if (lbGR == 6 && LB_CL == 0) run(std::integral_constant<int, (LB_CL == 0 ? 6 : -1)>());
+      else if (lbGR == 0) run(std::integral_constant<int, 0>()); // (a group of CL lanes: no row lanes to sum over)
       else run(std::integral_constant<int, -1>());
 
       // ------------------------------------------------------- per-group events
