@@ -1,3 +1,4 @@
+"""GPU box: solve C3 and list the loci whose status or iteration count differs from the oracle (diagnostic)."""
 import sys, os, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from strawberry_amd import em, synth
