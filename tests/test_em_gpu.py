@@ -384,6 +384,27 @@ def test_wide_loci_multi_workgroup_kernel(oracle, monkeypatch):
     assert o_iters[:10].max() > 100
 
 
+def test_c3t_tail_every_wide_locus_against_oracle(oracle):
+    """The tail of bench.py's C3-T workload at full size -- 300 loci of 65..400 isoforms and 200..3000 bins, all of them
+    on em_wide_kernel, about twenty cooperative rounds -- locus by locus against the oracle (it takes the CPU a few
+    seconds on the GPU box's cores): status and iteration counts exact, theta to 1e-9."""
+    import os
+    from strawberry_amd import em, synth
+    b = synth.make_c3t(n_loci=300, total_frags=1e6, n_tail=300)
+    assert b.n_loci == 600
+    threads = max(4, min(32, os.cpu_count() or 4))
+    o_theta, o_status, o_iters = oracle.em_batch(b.row_off, b.iso_off, b.f_off, b.count, b.F, threads=threads)
+    ctx = em.default_context(0)
+    s = em.EmBatchSolver(b, ctx)
+    assert (s.plan.locus_kinds() == 5).sum() == 300
+    s.run_em()
+    r = s.results()
+    np.testing.assert_array_equal(r["status"], o_status)
+    np.testing.assert_array_equal(r["iters"], o_iters)
+    err = np.abs(r["theta"] - o_theta) / np.maximum(np.abs(o_theta), 1e-9)
+    assert err.max() < 1e-9, err.max()
+
+
 def test_gpu_fp32_variant_is_close_and_leaves_fp64_untouched(ctx, oracle):
     """BASELINE config 5: the fp32 instantiation of the tile kernels (sbgpu_em_run_device_f32).  Not a parity path
     -- it is compared loosely (most loci keep their status, theta within 1e-3 of a fragment-floor relative error
