@@ -201,6 +201,44 @@ def chain_main(args, ctx, dev, rank, world, sdist, torch):
     print(json.dumps(out))
 
 
+def self_launch(args):
+    """`--gpus N` (N > 1) without a torchrun environment: start the N ranks ourselves, one process per GPU, with the
+    driver's own command line (`python -m torch.distributed.run --nproc-per-node N bench.py ...`).  This process has
+    not touched the GPU (no HIP call, no torch.cuda query besides the device count) and never does: it waits for
+    the ranks, whose rank 0 prints the JSON line on the stdout they inherit, and exits with their return code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args):
+    """SB_BENCH_DRY_RUN=1: the launch and the collectives of a run without its GPU work -- what the CPU test of the
+    self-launch drives (gloo, no device).  Every rank goes through the same rendezvous, barrier, max-over-ranks and
+    sum-over-ranks calls as a real run; rank 0 prints a line that says it measured nothing."""
+    import torch
+    from strawberry_amd import dist as sdist
+    rank, world, _ = sdist.init_process_group("gloo")
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    sdist.barrier()
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    sdist.allreduce_max_(t)
+    n = torch.tensor([1, rank], dtype=torch.int64)
+    sdist.allreduce_sum_(n)
+    sdist.barrier()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": int(n[0]), "rank_sum": int(n[1]),
+                          "max_over_ranks": float(t.item()), "steps": args.steps, "warmup": args.warmup,
+                          "workload": args.workload, "scaling": args.scaling,
+                          "note": "SB_BENCH_DRY_RUN: launch + collectives only, nothing measured"}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -212,22 +250,56 @@ def main():
                          "over the ranks (BASELINE config 3) -- measured either way and reported under `strong_scaling`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))       # before anything here has touched the GPU
+    if os.environ.get("SB_BENCH_DRY_RUN") == "1":
+        return dry_run(args)
 
     import torch
     from strawberry_amd import dist as sdist
     from strawberry_amd import em
 
-    rank, world, local_rank = sdist.init_process_group()
-    if world != args.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    # One rank per GPU over RCCL.  A box with fewer devices than ranks (the 1-GPU test box with --gpus 2) still runs
+    # all ranks, several per device: RCCL refuses two ranks on one device, so the collective is then gloo on a host
+    # copy, and the line says so (`oversubscribed`).
+    n_dev = torch.cuda.device_count()             # does not initialise the GPU
+    if n_dev < 1:
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    want_world = int(os.environ.get("WORLD_SIZE", "1"))
+    oversub = want_world > n_dev
+    rank, world, local_rank = sdist.init_process_group("gloo" if oversub else None)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    local_rank = local_rank % torch.cuda.device_count()   # test rigs may run several ranks per GPU
+    local_rank = local_rank % n_dev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     ctx = em.Context(local_rank)
-    # the per-step collective: torch.distributed (RCCL) by default, the C ABI's own RCCL binding with SB_COMM=abi
-    comm = sdist.AbiComm(ctx) if os.environ.get("SB_COMM") == "abi" and world > 1 else None
+    # the per-step collective: the C ABI's own RCCL binding (sbgpu_allreduce_sum_*) whenever there is more than one
+    # rank; SB_COMM=torch selects torch.distributed's all-reduce instead.  All ranks take the same one.
+    comm, comm_note = None, None
+    if world > 1 and not oversub and os.environ.get("SB_COMM", "abi") == "abi":
+        try:
+            comm = sdist.AbiComm(ctx)
+            ok = 1
+        except Exception as e:   # noqa: BLE001 -- reported in the line, and the ranks agree on what to use
+            comm_note, ok = "C-ABI communicator failed (%s); torch.distributed used" % e, 0
+        flag = torch.tensor([ok], dtype=torch.int64, device=dev)
+        sdist.allreduce_sum_(flag)
+        if int(flag.item()) != world:
+            comm = None
+            comm_note = comm_note or "C-ABI communicator failed on another rank; torch.distributed used"
+    collective = ("C ABI (sbgpu_allreduce_sum_f64 over RCCL)" if comm is not None else
+                  "gloo on a host copy (%d ranks share %d device(s): RCCL refuses two ranks per device)" % (world, n_dev)
+                  if oversub else "torch.distributed (RCCL)" if world > 1 else "none (one rank)")
+    launch = {"world_size": world, "devices": n_dev, "collective": collective}
+    if oversub:
+        launch["oversubscribed"] = True
+    if comm_note:
+        launch["collective_note"] = comm_note
 
     if args.workload == "c3-chain":
         return chain_main(args, ctx, dev, rank, world, sdist, torch)
@@ -340,8 +412,8 @@ def main():
         "config": {"workload": WORKLOADS[args.workload], "loci_per_gpu": batch.n_loci if args.scaling == "weak" else strong["loci_this_rank"],
                    "fragments_per_gpu": batch.n_frags,
                    "sharding": "independent loci per rank (own batch each), 1 all-reduce (8 B) per step" if args.scaling == "weak" else strong["sharding"],
-                   "collective": "C ABI (sbgpu_allreduce_sum_f64, RCCL)" if comm is not None else "torch.distributed (RCCL)",
-                   "size_classes": solver.plan.info()["n_classes"]},
+                   "collective": collective, "size_classes": solver.plan.info()["n_classes"]},
+        "launch": launch,
         "em_status": {"ok": int((res["status"] == 0).sum()), "init_empty": int((res["status"] == 1).sum()),
                       "denom_zero": int((res["status"] == 2).sum()), "maxiter": int((res["status"] == 3).sum()),
                       "mean_iters": float(res["iters"].mean())},

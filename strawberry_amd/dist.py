@@ -116,9 +116,11 @@ class AbiComm:
         ident = None
         if self.world > 1:
             buf = (C.c_uint8 * 128)()
+            raw = b""
             if self.rank == 0:
-                _lib.check(self.L.sbgpu_comm_unique_id(buf), "sbgpu_comm_unique_id")
-            raw = bytes(buf)
+                # a failure here must still reach the broadcast below, or the other ranks wait for it forever
+                rc = self.L.sbgpu_comm_unique_id(buf)
+                raw = bytes(buf) if rc == 0 else b"!" + (self.L.sbgpu_last_error() or b"sbgpu_comm_unique_id failed")
             if broadcast_id is None:
                 import torch.distributed as dist
                 box = [raw]
@@ -126,6 +128,8 @@ class AbiComm:
                 raw = box[0]
             else:
                 raw = broadcast_id(raw)
+            if len(raw) != 128:
+                raise _lib.SbgpuError("rank 0 could not make an RCCL id: " + raw[1:].decode(errors="replace"))
             ident = (C.c_uint8 * 128).from_buffer_copy(raw)
         h = C.c_void_p()
         _lib.check(self.L.sbgpu_comm_init(ctx.h, self.rank, self.world, ident, C.byref(h)), "sbgpu_comm_init")
