@@ -69,7 +69,6 @@ struct sbgpu_ctx {
    size_t scratch_bytes[8] = {};
    int32_t *d_pdf_support = nullptr; // [2] device: support of the insert-size table of the bin-weight launch in flight
    int32_t *wide_error = nullptr; // pinned host word the wide-locus kernel raises when a barrier times out
-   hipEvent_t wide_fork = nullptr, wide_join[2] = {}; // rounds of the wide-locus kernel overlap on three streams
 };
 
 namespace sb {
@@ -361,8 +360,6 @@ int sbgpu_init(int device, sbgpu_ctx_t **ctx_out)
       if (e == hipSuccess) e = hipEventCreateWithFlags(&c->join[i], hipEventDisableTiming);
    }
    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
-   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->wide_fork, hipEventDisableTiming);
-   for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->wide_join[i], hipEventDisableTiming);
    if (e == hipSuccess) e = hipMalloc((void **)&c->d_pdf_support, 2 * sizeof(int32_t));
    if (e == hipSuccess) e = hipHostMalloc((void **)&c->wide_error, sizeof(int32_t), hipHostMallocDefault);
    if (e == hipSuccess) *c->wide_error = 0;
@@ -399,9 +396,6 @@ int sbgpu_finalize(sbgpu_ctx_t *c)
    if (c->d_pdf_support) (void)hipFree(c->d_pdf_support);
    for (int i = 0; i < 8; ++i)
       if (c->scratch[i]) (void)hipFree(c->scratch[i]);
-   if (c->wide_fork) (void)hipEventDestroy(c->wide_fork);
-   for (int i = 0; i < 2; ++i)
-      if (c->wide_join[i]) (void)hipEventDestroy(c->wide_join[i]);
    delete c;
    return SBGPU_OK;
 }
@@ -505,12 +499,20 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
       // workgroups exchange partials, so loci of like workgroup counts share rounds: largest first
       std::vector<std::pair<int, int32_t>> wide;
       std::vector<int32_t> rest;
-      auto slots_of = [](int64_t niso) { const int need = (int)((niso + 63) / 64); return need <= 2 ? 2 : (need <= 4 ? 4 : 8); };
-      for (int32_t l : sc.loci) {
+      // a locus' layout follows from its isoform count (em_wide.h: 16 / 32 / 64 column lanes x 4-8 columns), the
+      // number of workgroups from its rows; the rows are then dealt evenly
+      auto groups_of = [&](int32_t l, int &layout) -> int64_t {
          const int64_t nrow = row_off[l + 1] - row_off[l], niso = iso_off[l + 1] - iso_off[l];
-         const int64_t rpb = (int64_t)sb::kWideWaves * sb::wide_rows(slots_of(niso));
-         const int64_t G = std::max<int64_t>(1, (nrow + rpb - 1) / rpb);
-         if (niso <= 512 && G <= c->n_cu && !std::getenv("SBGPU_NO_WIDE")) wide.emplace_back((int)G, l);
+         layout = sb::wide_layout_for(niso);
+         if (layout < 0) return -1;
+         const int64_t rpb = sb::wide_rows_per_block(layout);
+         return std::max<int64_t>(1, (nrow + rpb - 1) / rpb);
+      };
+      static const bool no_wide = std::getenv("SBGPU_NO_WIDE") != nullptr;
+      for (int32_t l : sc.loci) {
+         int layout;
+         const int64_t G = groups_of(l, layout);
+         if (G > 0 && G <= c->n_cu && row_off[l + 1] > row_off[l] && !no_wide) wide.emplace_back((int)G, l);
          else rest.push_back(l);
       }
       std::stable_sort(wide.begin(), wide.end(), [](const std::pair<int, int32_t> &x, const std::pair<int, int32_t> &y) { return x.first > y.first; });
@@ -520,8 +522,9 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
       for (const auto &gl : wide) {
          const int32_t l = gl.second;
          const int G = gl.first;
-         const int64_t niso = iso_off[l + 1] - iso_off[l];
-         const int ns = slots_of(niso);
+         const int64_t nrow = row_off[l + 1] - row_off[l];
+         int layout;
+         (void)groups_of(l, layout);
          if (round.n_blocks + G > c->n_cu) { // this launch is full: all its workgroups must be resident
             p->wide_rounds.push_back(round);
             round = sbgpu_plan::WideRound();
@@ -531,14 +534,16 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
          d.locus = l;
          d.first_block = round.n_blocks;
          d.n_blocks = G;
-         d.rows_per_block = (int32_t)(sb::kWideWaves * sb::wide_rows(ns));
-         d.npad = 64 * (int32_t)((niso + 63) / 64);
+         d.rows_per_block = (int32_t)std::max<int64_t>(1, (nrow + G - 1) / G);
+         d.npad = sb::wide_cols(layout);
          d.buf_off = (int64_t)wide_buf_doubles;
-         d.nslot = ns;
-         wide_buf_doubles += (size_t)4 * G * (d.npad + 2); // two buffers of G x (npad + 2) 16-byte granules
+         d.layout = layout;
+         d.lb_slice = sb::wide_lb_slice(d.npad, G);
+         d.pad_ = 0;
+         wide_buf_doubles += (size_t)4 * G * d.npad + (size_t)4 * d.npad; // two buffers of G x npad 16-byte granules (partials) + two of npad (totals)
          round.n_blocks += G;
          round.n_desc += 1;
-         round.lds_bytes = std::max(round.lds_bytes, (size_t)(3 * d.npad + sb::kWideWaves * (d.npad + 2) + sb::kWideStageDoubles) * sizeof(double));
+         round.lds_bytes = std::max(round.lds_bytes, sb::wide_lds_bytes(layout));
          wide_table.push_back(d);
          sc.loci.push_back(l);
       }
@@ -783,36 +788,11 @@ static int em_run_impl(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_c
             p->wide_epoch = (p->wide_epoch % 0x1FFFFFu) + 1; // 1 .. 2^21 - 1: epoch * 2048 + round fits 32 bits
             int32_t *d_err = nullptr;
             HIP_TRY(hipHostGetDevicePointer((void **)&d_err, c->wide_error, 0));
-            // Rounds may overlap on three streams -- the tail of one round (its slowest locus) then runs beside the
-            // next -- but ONLY while the rounds in flight fit the chip together: a cooperative launch is promised
-            // residency on an otherwise free device, so two rounds that each need most of the CUs could both end up
-            // half resident and spin in their barriers until the timeout.  A round that does not fit beside the ones
-            // in flight first joins them all.
-            hipStream_t lanes[3] = {s, c->aux[3], c->aux[5]};
-            int in_flight_blocks = 0, lane = 0;
-            bool used[3] = {false, false, false};
-            auto join_lanes = [&]() -> int {
-               for (int x = 1; x < 3; ++x) {
-                  if (!used[x]) continue;
-                  HIP_TRY(hipEventRecord(c->wide_join[x - 1], lanes[x]));
-                  HIP_TRY(hipStreamWaitEvent(s, c->wide_join[x - 1], 0));
-                  used[x] = false;
-               }
-               return SBGPU_OK;
-            };
+            // Rounds run one after the other on this kind's stream: a round fills the chip (one workgroup per CU, all
+            // registers), its loci run the same number of exchanges give or take, and a cooperative launch is only
+            // promised residency on an otherwise free device -- two rounds in flight could both end up half resident
+            // and spin in their exchanges until the timeout.
             for (const sbgpu_plan::WideRound &r : p->wide_rounds) {
-               if (in_flight_blocks > 0 && (in_flight_blocks + r.n_blocks > c->n_cu || lane == 3)) {
-                  const int rc = join_lanes();
-                  if (rc != SBGPU_OK) return rc;
-                  in_flight_blocks = 0;
-                  lane = 0;
-               }
-               if (lane > 0) {
-                  // the side stream starts behind everything the round stream has done so far
-                  HIP_TRY(hipEventRecord(c->wide_fork, s));
-                  HIP_TRY(hipStreamWaitEvent(lanes[lane], c->wide_fork, 0));
-                  used[lane] = true;
-               }
                sb::WideArgs wa;
                wa.a = a;
                wa.table = p->d_wide_table + r.first_desc;
@@ -820,12 +800,8 @@ static int em_run_impl(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_c
                wa.bufs = p->d_wide_bufs;
                wa.epoch = p->wide_epoch;
                wa.error = d_err;
-               HIP_TRY(sb::launch_wide(wa, r.n_blocks, r.lds_bytes, lanes[lane]));
-               in_flight_blocks += r.n_blocks;
-               ++lane;
+               HIP_TRY(sb::launch_wide(wa, r.n_blocks, r.lds_bytes, s));
             }
-            const int rc = join_lanes();
-            if (rc != SBGPU_OK) return rc;
          }
          const int32_t n_all = (int32_t)p->host.classes[kl.first_class].loci.size();
          if (n_all > p->n_wide_loci) { // the rest: one workgroup per locus, F streamed from L2
