@@ -33,7 +33,7 @@
 
 namespace sb {
 
-constexpr int kWideWaves = 8;                  // 2 per SIMD: up to 256 VGPRs each
+constexpr int kWideWaves = 8;                  // 2 per SIMD: up to 256 VGPRs each (the sums over the waves are written as trees of 8)
 constexpr int kWideThreads = 64 * kWideWaves;
 constexpr unsigned kWideSpinLimit = 1u << 20;  // sweeps of an exchange's partials before giving up (~ seconds)
 constexpr int kWideSweep = 8;                  // granules a thread has in flight per sweep
@@ -60,12 +60,12 @@ inline int wide_layout_for(int64_t niso)
       if (niso <= wide_cols(id)) return id;
    return -1;
 }
-// dynamic LDS of a workgroup: phi[npad] | accw[waves][npad] | part[waves] | misc[8] | zf[16 ints] | counts[R][threads] ints
+// dynamic LDS of a workgroup: phi[npad] | accw[waves][npad] | part[waves] | misc[8] | zf[16 ints] | counts[R][threads] doubles
 // | stage[2 npad] granules (the two-level exchange)
 constexpr size_t wide_lds_bytes(int id)
 {
    return (size_t)(wide_cols(id) * (1 + kWideWaves) + kWideWaves + 8) * sizeof(double) + 16 * sizeof(int) +
-          (size_t)wide_layout(id).r * kWideThreads * sizeof(int) + (size_t)2 * wide_cols(id) * 16;
+          (size_t)wide_layout(id).r * kWideThreads * sizeof(double) + (size_t)2 * wide_cols(id) * 16;
 }
 // columns per slice of the two-level exchange: the smallest power of two m with m * G >= npad (m * G < 2 npad)
 inline int wide_lb_slice(int npad, int G)
@@ -174,9 +174,9 @@ __device__ __forceinline__ void em_wide_body(const WideArgs &g, const int di)
    double *phi = s_dyn;                       // [NPAD] theta_j * scale_j of the iteration about to run
    double *accw = phi + NPAD;                 // [kWideWaves][NPAD] the waves' partial column sums
    double *s_part = accw + kWideWaves * NPAD; // [kWideWaves] the owner waves' shares of ||next - theta||^2
-   double *s_misc = s_part + kWideWaves;      // 0: total count, 1: rows kept, 2: zero-denominator flag, 3: abort
+   double *s_misc = s_part + kWideWaves;      // 0: total count, 1: rows kept, 3: abort, 4 + parity: zero-denominator flag of an iteration
    int *s_zf = (int *)(s_misc + 8);           // [kWideWaves] "a kept row of this wave had a zero denominator"
-   int *s_cnt = s_zf + 16;                    // [R][kWideThreads] counts of the lanes' rows (0 for rows not kept)
+   double *s_cnt = (double *)(s_zf + 16);     // [R][kWideThreads] counts of the lanes' rows as doubles (0 for rows not kept)
    const EmArgs &a = g.a;
    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
    set_fp64_flush_denormals();
@@ -230,7 +230,7 @@ __device__ __forceinline__ void em_wide_body(const WideArgs &g, const int di)
 #pragma unroll
          for (int k = 0; k < CPL; ++k) F[r][k] = 0.0;
       }
-      s_cnt[r * kWideThreads + tid] = keep[r] ? cnt : 0;
+      s_cnt[r * kWideThreads + tid] = keep[r] ? (double)cnt : 0.0;
       if (c == 0) tot += (double)cnt; // theta_0 counts ALL rows (:374-375); one lane per row
       kept |= keep[r] ? 1 : 0;
 #pragma unroll
@@ -368,8 +368,10 @@ __device__ __forceinline__ void em_wide_body(const WideArgs &g, const int di)
       __syncthreads();
       double s = 0.0;
       if (tid < 2) {
+         double p[kWideWaves];
 #pragma unroll
-         for (int v = 0; v < kWideWaves; ++v) s += accw[v * NPAD + tid];
+         for (int v = 0; v < kWideWaves; ++v) p[v] = accw[v * NPAD + tid];
+         s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
       }
       unsigned fo;
       s = exchange(s, 0u, 2, fo);
@@ -406,8 +408,10 @@ __device__ __forceinline__ void em_wide_body(const WideArgs &g, const int di)
    {
       double s = 0.0;
       if (tid < NPAD) {
+         double p[kWideWaves];
 #pragma unroll
-         for (int v = 0; v < kWideWaves; ++v) s += accw[v * NPAD + tid];
+         for (int v = 0; v < kWideWaves; ++v) p[v] = accw[v * NPAD + tid];
+         s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
       }
       unsigned fo;
       s = exchange(s, 0u, NPAD, fo);
@@ -425,24 +429,56 @@ __device__ __forceinline__ void em_wide_body(const WideArgs &g, const int di)
       return;
    }
 
+   // The loop is pipelined by one decision: pass `it` runs iteration `it`'s E- and M-step and update, and -- behind
+   // its first barrier -- decides on iteration it - 1, whose shares of ||next - theta||^2 the owner waves reduce at
+   // the top of the pass, off the critical path (the old order reduced, synchronised and summed between the update
+   // and the next E-step: half of an iteration's cycles were waves parked at barriers and LDS waits).  theta's
+   // update is therefore written before anybody knows whether the iteration converged; the owner thread keeps
+   // the value of before (th_prev), which is what the reference returns then (estimate.cpp:479-481).  Pass
+   // kMaxIter + 1 only decides.
    int32_t st = kStMaxIter;
-   int it = 0;
-   bool theta0_out = false;
-   for (;;) {
+   int it_done = 0;
+   bool theta0_out = false, prev_out = false;
+   double th_prev = 0.0, q_prev = 0.0;
+   for (int it = 1;; ++it) {
+      if (it > 1) {
+         const double x = wave_group_sum<64>(q_prev);
+         if (lane == 0 && wave < (NPAD + 63) / 64) s_part[wave] = x;
+      }
+      if (it > kMaxIter) { // the pass that only decides on iteration kMaxIter
+         __syncthreads();
+         if (s_misc[3] != 0.0) {
+            if (tid == 0) __hip_atomic_store(g_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+         }
+         double p[kWideWaves];
+#pragma unroll
+         for (int v = 0; v < kWideWaves; ++v) p[v] = s_part[v];
+         const double dsum = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+         it_done = kMaxIter;
+         if (s_misc[4 + ((it - 1) & 1)] != 0.0) {
+            st = kStDenomZero;
+            theta0_out = true;
+         } else if (dsum <= kThetaLimitSq) {
+            st = kStOk;
+            prev_out = true;
+         }
+         break;
+      }
       // ---- E-step and M-step over my tile
       double ph[CPL], acc[CPL];
 #pragma unroll
-      for (int k = 0; k < CPL; ++k) {
-         ph[k] = phi[k * CL + c];
-         acc[k] = 0.0;
-      }
+      for (int k = 0; k < CPL; ++k) ph[k] = phi[k * CL + c];
       bool zf = false;
+#ifdef SB_WIDE_DIAG
+      if (!(SB_WIDE_DIAG & 1))
+#endif
 #pragma unroll
       for (int rb = 0; rb < R; rb += RBLK) {
          constexpr int NB = RBLK; // rows of this block (R is a multiple of RBLK)
          const int kind = blk_kind[rb / RBLK];
-         if (kind == 0) continue; // no lane of this wave has a kept row in these slots: nothing to add
-         int cnt[NB];
+         if (rb > 0 && kind == 0) continue; // no lane of this wave has a kept row in these slots: nothing to add
+         double cnt[NB];
 #pragma unroll
          for (int q = 0; q < NB; ++q) cnt[q] = s_cnt[(rb + q) * kWideThreads + tid];
          double dd[4];
@@ -454,38 +490,41 @@ __device__ __forceinline__ void em_wide_body(const WideArgs &g, const int di)
             dd[q] = part;
          }
          wide_col_lanes_sum<LB_CL, NB>(dd);
-         // the block's reciprocals from one v_rcp_f64 (em_device.h: batch_reciprocals) unless their product leaves the
-         // exponent range in some lane of the wave (tiny denominators of a dying isoform's bins, or a zero, which
-         // the flag reports anyway): then every row gets its own reciprocal
          double de[4], inv[4];
          double prod = 1.0;
          if (kind == 1) { // every lane's row is a kept one
 #pragma unroll
-            for (int q = 0; q < NB; ++q) {
-               zf |= dd[q] == 0.0; // :451
-               de[q] = dd[q];
-            }
+            for (int q = 0; q < NB; ++q) de[q] = dd[q];
          } else {
 #pragma unroll
-            for (int q = 0; q < NB; ++q) {
-               zf |= keep[rb + q] && dd[q] == 0.0;      // :451
-               de[q] = keep[rb + q] ? dd[q] : 1.0;      // a row outside the problem: n = 0, weight 0 / 1
-            }
+            for (int q = 0; q < NB; ++q) de[q] = keep[rb + q] ? dd[q] : 1.0; // a row outside the problem: n = 0, weight 0 / 1
          }
          if (NB == 4) prod = (de[0] * de[1]) * (de[2] * de[3]);
          else if (NB == 2) prod = de[0] * de[1];
          else prod = de[0];
+         // the block's reciprocals from one v_rcp_f64 (em_device.h: batch_reciprocals) unless their product leaves the
+         // exponent range in some lane of the wave (tiny denominators of a dying isoform's bins -- or a zero: a
+         // product in range has no zero factor, so the test for zero denominators, estimate.cpp:451, lives on the
+         // slow side only): then every row gets its own reciprocal
          if (!wave_any(!(prod >= 0x1p-960))) {
             batch_reciprocals<NB>(de, inv);
          } else {
 #pragma unroll
-            for (int q = 0; q < NB; ++q) inv[q] = newton_rcp(de[q]);
+            for (int q = 0; q < NB; ++q) {
+               zf |= keep[rb + q] && dd[q] == 0.0; // :451
+               inv[q] = newton_rcp(de[q]);
+            }
          }
 #pragma unroll
          for (int q = 0; q < NB; ++q) {
-            const double wgt = (double)cnt[q] * inv[q];
+            const double wgt = cnt[q] * inv[q];
+            if (rb == 0 && q == 0) { // the first row starts the column partials
 #pragma unroll
-            for (int k = 0; k < CPL; ++k) acc[k] = __builtin_fma(wgt, F[rb + q][k], acc[k]);
+               for (int k = 0; k < CPL; ++k) acc[k] = wgt * F[0][k];
+            } else {
+#pragma unroll
+               for (int k = 0; k < CPL; ++k) acc[k] = __builtin_fma(wgt, F[rb + q][k], acc[k]);
+            }
          }
          // one block's temporaries at a time (the tile leaves few registers): the empty asm pins the column partials
          // here, so the block's updates cannot be sunk behind the later blocks' reciprocals
@@ -501,62 +540,82 @@ __device__ __forceinline__ void em_wide_body(const WideArgs &g, const int di)
          const int zw = wave_any(zf) ? 1 : 0;
          if (lane == 0) s_zf[wave] = zw;
       }
-      __syncthreads(); // (A) the waves' partial column sums and flags are visible
-      // ---- the owner of column tid: the locus-wide sum, next_theta, its share of ||next - theta||^2
-      double nt = 0.0, d2 = 0.0;
+#ifdef SB_WIDE_DIAG
+      if (!(SB_WIDE_DIAG & 2))
+#endif
+      __syncthreads(); // (A) the waves' partial column sums and flags (and the previous iteration's shares) are visible
+      if (s_misc[3] != 0.0) {
+         if (tid == 0) __hip_atomic_store(g_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+         return;
+      }
+      if (it > 1) { // ---- the decision on iteration it - 1
+         double p[kWideWaves];
+#pragma unroll
+         for (int v = 0; v < kWideWaves; ++v) p[v] = s_part[v];
+         const double dsum = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+#ifdef SB_WIDE_DIAG
+         if (false)
+#endif
+         if (s_misc[4 + ((it - 1) & 1)] != 0.0) { // run() == false, _theta untouched (:451-453)
+            st = kStDenomZero;
+            theta0_out = true;
+            it_done = it - 1;
+            break;
+         }
+#ifdef SB_WIDE_DIAG
+         if (false)
+#endif
+         if (dsum <= kThetaLimitSq) { // sqrt(d2) < 1e-2 (:479-480), theta NOT updated: the value of before
+            st = kStOk;
+            prev_out = true;
+            it_done = it - 1;
+            break;
+         }
+      }
+      // ---- the owner of column tid: the locus-wide sum, next_theta (:454-464), its share of ||next - theta||^2
+#ifdef SB_WIDE_DIAG
+      if (!(SB_WIDE_DIAG & 8))
+#endif
       {
          double s = 0.0;
          unsigned flag = 0;
          if (tid < NPAD) {
+            double p[kWideWaves];
 #pragma unroll
-            for (int v = 0; v < kWideWaves; ++v) s += accw[v * NPAD + tid];
+            for (int v = 0; v < kWideWaves; ++v) p[v] = accw[v * NPAD + tid];
+            s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
 #pragma unroll
             for (int v = 0; v < kWideWaves; ++v) flag |= (unsigned)s_zf[v];
          }
          unsigned fo;
          s = exchange(s, flag, NPAD, fo);
          if (tid < NPAD) {
+            double nt = 0.0;
+            q_prev = 0.0;
             if (tid < niso) {
-               nt = ph_own * s; // :454-464
+               nt = ph_own * s;
                const double df = nt - th;
-               d2 = df * df;
+               q_prev = df * df;
             }
+            th_prev = th;
+            th = nt;          // :481 (undone by prev_out when the iteration turns out to have converged)
             ph_own = nt * sc; // (phi of the padding columns stays 0)
             phi[tid] = ph_own;
-            if (tid == 0) s_misc[2] = fo ? 1.0 : 0.0;
+            if (tid == 0) s_misc[4 + (it & 1)] = fo ? 1.0 : 0.0;
             if (aborted) s_misc[3] = 1.0;
          }
       }
-      d2 = wave_group_sum<64>(d2);
-      if (lane == 0 && wave < (NPAD + 63) / 64) s_part[wave] = d2;
-      __syncthreads(); // (B) phi, the flag and the waves' shares are visible
-      if (s_misc[3] != 0.0) {
-         if (tid == 0) __hip_atomic_store(g_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-         return;
-      }
-      const bool dz = s_misc[2] != 0.0;
-      double dsum = 0.0;
-#pragma unroll
-      for (int v = 0; v < kWideWaves; ++v) dsum += s_part[v];
-      ++it;
-      if (dz) { // run() == false, _theta untouched (:451-453)
-         st = kStDenomZero;
-         theta0_out = true;
-         break;
-      }
-      if (dsum <= kThetaLimitSq) { // sqrt(d2) < 1e-2 (:479-480), theta NOT updated
-         st = kStOk;
-         break;
-      }
-      th = nt; // :481
-      if (it >= kMaxIter) break;
+#ifdef SB_WIDE_DIAG
+      if (!(SB_WIDE_DIAG & 4))
+#endif
+      __syncthreads(); // (B) phi is complete
    }
    if (w == 0) {
       if (tid == 0) {
          a.status[locus] = st;
-         a.iters[locus] = it;
+         a.iters[locus] = it_done;
       }
-      if (tid < niso) a.theta[iso_base + tid] = theta0_out ? theta0 : th;
+      if (tid < niso) a.theta[iso_base + tid] = theta0_out ? theta0 : (prev_out ? th_prev : th);
    }
 }
 

@@ -761,9 +761,22 @@ static int em_run_impl(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_c
    c->n_phase_timed = 0;
    const bool timing = c->timing;
    // longest iterations first: stream, block, wave
+   // The wide-locus rounds are cooperative launches that want the chip to themselves (one 512-lane workgroup with all
+   // of a CU's registers and up to 94 KB of its LDS per CU): beside the tile kinds' workgroups their residency is not
+   // assured and the rounds take twice as long (measured: C3-T 44 -> 79 ms).  They run when the tile kinds are done.
+   const bool wide_last = fork && p->n_wide_desc > 0;
+   for (int pass = 0; pass < 2; ++pass)
    for (int k = sb::kNumKinds - 1; k >= 0; --k) {
       const KindLaunch &kl = p->launches[k];
       if (kl.n_classes == 0) continue;
+      if ((pass == 1) != (wide_last && k == sb::kStream)) continue; // pass 0: everything but a deferred stream kind
+      if (pass == 1) {
+         for (int o = 0; o < sb::kNumKinds; ++o) {
+            if (o == k || p->launches[o].n_classes == 0) continue;
+            HIP_TRY(hipEventRecord(c->join[o], c->aux[kKindStream[o]]));
+            HIP_TRY(hipStreamWaitEvent(c->aux[kKindStream[k]], c->join[o], 0));
+         }
+      }
       hipStream_t s = fork ? c->aux[kKindStream[k]] : main;
       // Start order.  A tall-tile workgroup needs a whole CU's registers, a block-kind one half of them: once the
       // workgroups of a lighter kind have spread over the chip, a heavier one waits for a CU to drain -- the 9
