@@ -1,0 +1,119 @@
+"""The drop-in, proven with the reference's OWN driver (north star: "drops in under the existing Strawberry.cpp
+driver").  oracle/_ref/strawberry_sbgpu is the reference program linked from its unmodified objects -- main, BAM
+decode, clustering, LocusContext, GTF / table output -- with exactly the two functions of the seam replaced:
+EmSolver::init and EmSolver::run (/root/reference/src/estimate.cpp:366-488, called at :305-308) are weakened in a
+copy of estimate.o and defined by oracle/sbgpu_em_shim.cpp over sbgpu::EmSolver (include/sbgpu_host.hpp), i.e. the
+HIP kernels behind the C ABI.  The toy BAMs are regenerated from the committed fragments (tests/golden/*/reads.npz,
+the simulation's own order and read names) with oracle/_ref/sam2bam; the program runs with the golden runs'
+command lines; its out.gtf and -f table must equal the reference binary's committed outputs byte for byte.
+
+Test infrastructure only: nothing under strawberry_amd/ refers to the binary or the shim.  Skipped where oracle/_ref
+was not built (it needs /root/reference at build time; the built files travel to the GPU box)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import e2e_util as U
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_DIR = os.path.join(ROOT, "oracle", "_ref")
+DRIVER = os.path.join(REF_DIR, "strawberry_sbgpu")
+SAM2BAM = os.path.join(REF_DIR, "sam2bam")
+RL = 75
+
+# (golden directory, extra command-line arguments of its golden run, -i given?)
+RUNS = {
+    "E2E": (U.E2E, [], True),
+    "E2E_LONG": (U.E2E_LONG, [], True),
+    "E2E_MASS": (U.E2E_MASS, ["--allow-multimapped-hits"], True),
+    "E2E_FILTER": (U.E2E_FILTER, ["-e", "0.05"], True),
+    "E2E_EMP": (U.E2E_EMP, [], False),
+    "E2E_MINUS": (U.E2E_MINUS, [], True),
+    "E2E_CHROMS": (U.E2E_CHROMS, [], True),
+}
+
+
+def need_driver():
+    if not (os.path.exists(DRIVER) and os.path.exists(SAM2BAM)):
+        pytest.skip("oracle/_ref/strawberry_sbgpu not built (`make -C oracle ref` where /root/reference is mounted)")
+
+
+def cigar(blocks):
+    s = ""
+    for k, (a, b) in enumerate(blocks):
+        if k:
+            s += "%dN" % (a - blocks[k - 1][1] - 1)
+        s += "%dM" % (b - a + 1)
+    return s
+
+
+def write_sam(directory, path):
+    """The SAM of the golden run, rebuilt from reads.npz: one pair of records per sequenced copy, names in simulation
+    order, NH and XS tags as simulated, records sorted by (chromosome, position) -- stable, like the generator's sort."""
+    z = dict(np.load(os.path.join(directory, "reads.npz")))
+    genes = list(U.parse_annotation(os.path.join(directory, "toy.gtf")))
+    strands, chroms = U.gene_strands(directory), U.gene_chroms(directory)
+    recs, rid, top = [], 0, 0
+    for k in range(len(z["gene"])):
+        g = genes[int(z["gene"][k])]
+        left = [(int(a), int(b)) for a, b in zip(z["left_l"][z["left_off"][k]:z["left_off"][k + 1]], z["left_r"][z["left_off"][k]:z["left_off"][k + 1]])]
+        right = [(int(a), int(b)) for a, b in zip(z["right_l"][z["right_off"][k]:z["right_off"][k + 1]], z["right_r"][z["right_off"][k]:z["right_off"][k + 1]])]
+        assert right, "paired-end runs only"
+        tlen = right[-1][1] - left[0][0] + 1
+        top = max(top, right[-1][1])
+        for nh in z["nh"][z["nh_off"][k]:z["nh_off"][k + 1]]:
+            rid += 1
+            name = "r%06d" % rid
+            c = chroms[g]
+            recs.append(((c, left[0][0]), "%s\t99\t%s\t%d\t255\t%s\t=\t%d\t%d\t%s\t%s\tNH:i:%d\tXS:A:%s" % (
+                name, c, left[0][0], cigar(left), right[0][0], tlen, "A" * RL, "I" * RL, nh, strands[g])))
+            recs.append(((c, right[0][0]), "%s\t147\t%s\t%d\t255\t%s\t=\t%d\t%d\t%s\t%s\tNH:i:%d\tXS:A:%s" % (
+                name, c, right[0][0], cigar(right), left[0][0], -tlen, "A" * RL, "I" * RL, nh, strands[g])))
+    recs.sort(key=lambda r: r[0])
+    with open(path, "w") as f:
+        f.write("@HD\tVN:1.0\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % (c, top + 10000) for c in sorted(set(chroms.values()))))
+        for _, line in recs:
+            f.write(line + "\n")
+    return len(recs)
+
+
+def run_driver(which, tmp_path):
+    directory, extra, insert = RUNS[which]
+    sam, bam = str(tmp_path / "toy.sam"), str(tmp_path / "toy.bam")
+    n = write_sam(directory, sam)
+    assert ("%d read records" % n) in open(os.path.join(directory, "README.txt")).read()     # the golden run's input
+    subprocess.check_call([SAM2BAM, sam, bam])
+    cmd = [DRIVER, bam, "-g", os.path.join(directory, "toy.gtf"), "-r"] + (["-i", "250/30"] if insert else []) + [
+        "-o", str(tmp_path / "out.gtf"), "-T", str(tmp_path / "log.txt"), "-f", str(tmp_path / "ctx.tsv")] + extra
+    return subprocess.run(cmd, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+
+
+def test_reference_driver_over_libsbgpu_has_no_cpu_path(tmp_path):
+    """Without a GPU the linked program must fail in sbgpu_init -- the proof that the reference's call site reaches the
+    library and that nothing of the reference's own EmSolver is left on the path."""
+    need_driver()
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = run_driver("E2E_LONG", tmp_path)
+    assert r.returncode != 0 and "sbgpu_init" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", sorted(RUNS))
+def test_reference_driver_over_libsbgpu_reproduces_reference_files(which, tmp_path):
+    need_driver()
+    directory = RUNS[which][0]
+    r = run_driver(which, tmp_path)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    for name in ("out.gtf", "ctx.tsv"):
+        # (the GTF's first line is a comment holding the program's own command line, temporary paths included)
+        got = [l for l in open(str(tmp_path / name), "rb").read().split(b"\n") if not l.startswith(b"#/")]
+        want = [l for l in open(os.path.join(directory, name), "rb").read().split(b"\n") if not l.startswith(b"#/")]
+        assert got == want, "%s of %s differs from the reference binary's" % (name, which)
+    # the theta lines of the reference's log (estimate.cpp:312) as well
+    want = open(os.path.join(directory, "theta_log.txt")).read()
+    got = "".join(l for l in open(str(tmp_path / "log.txt")) if "raw read count" in l or "not compatible" in l)
+    assert got == want
