@@ -42,9 +42,10 @@ WORKLOADS = {
     "c2u": "C2-U synthetic: 2000 loci x 8 isoforms x 1000 un-binned fragments (1000 rows)",
     "c3t": "C3-T synthetic: C3 plus a human-annotation-shaped tail of 300 loci with 65-400 isoforms and 200-3000 bins "
            "(the loci a workgroup's registers do not hold: em_wide_kernel)",
-    "c3-chain": "C3-scale chain: 60000 loci (100 gene models laid out 600 times), 2e8 read pairs resident in HBM, through "
-                "fragment x isoform compatibility + bin keys -> bins -> (bin, isoform) pairs -> bin weights -> EM -> theta "
-                "(sbgpu_quantify_device), FPKM / TPM on the host",
+    "c3-chain": "C3-scale chain: 60000 DISTINCT gene models (1-12 exons, 1-6 isoforms), ~2e8 read pairs drawn on the device "
+                "(log-normal share per locus, expression per isoform, N(250,30) fragments, 10% pairs that fit fewer isoforms or none), "
+                "resident in HBM, through fragment x isoform compatibility + bin keys -> bins -> (bin, isoform) pairs -> bin weights "
+                "-> EM -> theta (sbgpu_quantify_device)",
     "c5": "C5 synthetic: the C3 law at 4e8 fragments, bias factors 2^U(-1,1) on the weights; fp32 variant of the EM "
           "timed next to the fp64 path (tolerance sweep: tools/c5_sweep.py)",
 }
@@ -167,38 +168,168 @@ def timed_steps(quant, steps, warmup, dev, sdist, torch):
     return float(tmax.item()), ev[0].elapsed_time(ev[1])
 
 
-def chain_main(args, ctx, dev, rank, world, sdist, torch):
-    """--workload c3-chain: the whole path from fragments, hits resident in HBM.  Ranks hold their own sample each
-    (weak scaling); no collective inside the step (the FPKM total is summed on the host arrays)."""
+def chain_cpu_baseline(q, budget_frags=3.5e5):
+    """The reference PROGRAM (oracle/_ref/strawberry_ref: Strawberry's own main, BAM decode, clustering, LocusContext,
+    EmSolver, output -- compiled from /root/reference) on the first loci of the chain sample, one thread, timed on
+    this box's host; and the GPU chain's theta of those loci against the theta lines of its log (estimate.cpp:312).
+    The sample's hits are turned back into a coordinate-sorted BAM (our sam2bam) and a GTF of its gene models.
+    -> (cpu_baseline dict, parity dict), or (None, None) where oracle/_ref is not built."""
+    import re
+    import subprocess
+    import tempfile
+    ref_dir = os.path.join(ROOT, "oracle", "_ref")
+    ref_bin, sam2bam = os.path.join(ref_dir, "strawberry_ref"), os.path.join(ref_dir, "sam2bam")
+    if not (os.path.exists(ref_bin) and os.path.exists(sam2bam)):
+        return None, None
+    a = q.annot
+    K = int(np.searchsorted(q.hits.locus_hit_off, budget_frags, side="right"))
+    K = max(1, min(K, q.n_loci))
+    h = q.hits.host_hits(K)
+    with tempfile.TemporaryDirectory() as tmp:
+        gtf, sam, bam = (os.path.join(tmp, n) for n in ("s.gtf", "s.sam", "s.bam"))
+        with open(gtf, "w") as f:
+            for l in range(K):
+                for j, i in enumerate(range(int(a.iso_off[l]), int(a.iso_off[l + 1]))):
+                    e0, e1 = int(a.exon_off[i]), int(a.exon_off[i + 1])
+                    attr = 'gene_id "G%d"; transcript_id "G%d.%d";' % (l, l, j + 1)
+                    f.write("chr1\tsynth\ttranscript\t%d\t%d\t.\t+\t.\t%s\n" % (a.exon_left[e0], a.exon_right[e1 - 1], attr))
+                    for e in range(e0, e1):
+                        f.write("chr1\tsynth\texon\t%d\t%d\t.\t+\t.\t%s\n" % (a.exon_left[e], a.exon_right[e], attr))
+        # hits -> read pairs: the features before the GAP are the left mate's, those behind it the right mate's
+        off, code, fl, fr = h.feat_off, h.feat_code, h.feat_left.astype(np.int64), h.feat_right.astype(np.int64)
+        recs, pos = [], []
+        for k in range(h.n_hits):
+            f0, f1 = int(off[k]), int(off[k + 1])
+            g = f0 + int(np.nonzero(code[f0:f1] == 2)[0][0])
+
+            def mate(x0, x1):
+                c, n = "", 0
+                for i in range(x0, x1):
+                    ln = int(fr[i] - fl[i] + 1)
+                    c += "%d%s" % (ln, "M" if code[i] == 0 else "N")
+                    n += ln if code[i] == 0 else 0
+                return c, n
+            (cl, nl), (cr, nr) = mate(f0, g), mate(g + 1, f1)
+            pl, pr = int(fl[f0]), int(fl[g + 1])
+            tlen = int(fr[f1 - 1]) - pl + 1
+            for c in range(int(h.mass[k])):      # every read pair behind the unique hit
+                recs.append("r%d_%d\t99\tchr1\t%d\t255\t%s\t=\t%d\t%d\t%s\t%s\tNH:i:1\tXS:A:+" % (k, c, pl, cl, pr, tlen, "A" * nl, "I" * nl))
+                recs.append("r%d_%d\t147\tchr1\t%d\t255\t%s\t=\t%d\t%d\t%s\t%s\tNH:i:1\tXS:A:+" % (k, c, pr, cr, pl, -tlen, "A" * nr, "I" * nr))
+                pos += [pl, pr]
+        order = np.argsort(np.asarray(pos), kind="stable")
+        with open(sam, "w") as f:
+            f.write("@HD\tVN:1.0\tSO:coordinate\n@SQ\tSN:chr1\tLN:%d\n" % (int(fr.max()) + 10000))
+            f.write("\n".join(recs[i] for i in order) + "\n")
+        subprocess.check_call([sam2bam, sam, bam], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        cmd = [ref_bin, bam, "-g", gtf, "-r", "-i", "250/30", "-o", os.path.join(tmp, "out.gtf"), "-T", os.path.join(tmp, "log.txt"),
+               "-f", os.path.join(tmp, "ctx.tsv")]
+        t = time.perf_counter()
+        r = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True)
+        dt = time.perf_counter() - t
+        if r.returncode != 0:
+            return {"error": "strawberry_ref failed: " + r.stderr[-300:]}, None
+        # theta per locus from the log, loci and isoform order from the -f table
+        thetas = []
+        for line in open(os.path.join(tmp, "log.txt")):
+            m = re.match(r"isoform (\d+) has ([0-9.eE+-]+) raw read count", line)
+            if m:
+                if int(m.group(1)) == 1:
+                    thetas.append([])
+                thetas[-1].append(float(m.group(2)))
+        genes = []
+        for k, line in enumerate(open(os.path.join(tmp, "ctx.tsv"))):
+            f = line.rstrip("\n").split("\t")
+            if k and len(f) >= 10 and (not genes or genes[-1][0] != f[2]):
+                genes.append((f[2], f[4].split(",")))
+    n_pairs = int(h.mass.sum())
+    base = {"value": n_pairs / dt, "unit": "fragments/s", "cores": 1, "kind": "reference",
+            "sample": "the first %d loci of the same sample (%d read pairs, %d unique hits) as a BAM + GTF through the reference program "
+                      "(strawberry_ref -g -r -i 250/30: two BAM passes, clustering, bins, weights, EM, output), 1 thread, %.2f s" % (K, n_pairs, h.n_hits, dt),
+            "loci_per_s": K / dt}
+    worst, checked = 0.0, 0
+    ok = len(genes) == len(thetas)
+    for (gid, tx), th in zip(genes, thetas):
+        l = int(gid[1:])
+        for t, v in zip(tx, th):
+            j = int(t.split(".")[1]) - 1
+            mine = float(q.theta[int(a.iso_off[l]) + j])
+            worst = max(worst, abs(mine - v) / max(abs(v), 1.0))
+            checked += 1
+        ok &= int(q.status[l]) in (0, 2, 3)
+    parity = {"against": "reference program's theta log (printed %f)", "loci_checked": len(genes), "isoforms_checked": checked,
+              "theta_max_err": worst, "tolerance": 2e-6, "ok": bool(ok and checked > 0 and worst < 2e-6)}
+    return base, parity
+
+
+def chain_leg(args, ctx, dev, rank, world, sdist, torch, strong=False, with_cpu=True):
+    """The fragments -> abundances chain (sbgpu_quantify_device) on the chain sample (strawberry_amd/chain.py): 60 000
+    distinct gene models, ~2e8 read pairs resident in HBM.  Weak scaling: every rank its own sample; strong: ONE
+    sample, locus l on rank l mod world (no locus data crosses ranks; the caller's FPKM total is the one collective).
+    -> dict for the JSON line (rank 0), None on the other ranks."""
     from strawberry_amd import chain
     n_frags = float(os.environ.get("SB_CHAIN_FRAGS", "2e8"))
-    q = chain.ChainQuantifier(ctx, n_loci=60000, n_frags=n_frags, seed=31 + rank)
+    n_loci = int(float(os.environ.get("SB_CHAIN_LOCI", "60000")))
+    sub = (rank, world) if (strong and world > 1) else None
+    q = chain.ChainQuantifier(ctx, n_loci=n_loci, n_frags=n_frags, seed=31 + (0 if strong else rank), loci_subset=sub)
     wall, _ = timed_steps(q, args.steps, args.warmup, dev, sdist, torch)
-    counts = torch.tensor([q.n_loci, q.n_frags], dtype=torch.int64, device=dev)
+    counts = torch.tensor([q.n_loci, q.n_frags, q.n_hits], dtype=torch.int64, device=dev)
     sdist.allreduce_sum_(counts)
-    # per-stage device time of one more step (the library prints it on stderr when SBGPU_HOST_TIMING is set)
     if rank != 0:
-        return
+        return None
     ms = wall / args.steps * 1e3
-    b_hit = 9.0 * q.hits.n_features / q.n_frags + 12.0 + 4.0 * (q.annot.compat_words + q.annot.key_words)   # DESIGN 3.5
+    stage = q.stage_ms()
+    feats = q.hits.n_features / max(q.n_hits, 1)
+    cw, kw = q.annot.compat_words, q.annot.key_words
+    info = q.info or {}
+    # algorithmic bytes of the kernel stages (DESIGN 3.5 / 3.9): what each must read and write once
+    alg = {
+        "exonbin_kernel": q.n_hits * (9.0 * feats + 12.0 + 4.0 * (cw + kw) + 12.0),      # features, offsets, locus; words, span + hash out
+        "bins_accum_kernel": q.n_hits * (4.0 * (cw + kw) + 4.0 + 8.0 + 4.0 + 1.0) + info.get("n_bins", 0) * (8.0 + 4.0 * cw),
+        "binweight_kernel": info.get("n_pairs", 0) * (8.0 + 4.0 + 4.0 + 8.0 + 8.0 + 4.0 * 3.0),  # offsets, mask, length, index, F out, ~3 segments
+    }
+    dom = max((k for k in stage if k in alg), key=lambda k: stage[k], default=None)
+    roof = None
+    if dom:
+        ach = alg[dom] / (stage[dom] * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": None, "kernel_ms": stage[dom], "algorithmic_bytes": int(alg[dom]),
+                "note": "kernel time from HIP events on the kernels' stream (sbgpu_last_stage_ms); PMC traffic of this kernel: profiles/r03_c3chain_pmc_summary.json"}
     out = {
-        "metric": "loci/s and Mfrags/s, fragments -> abundances chain (C3-scale)", "value": int(counts[0]) * args.steps / wall,
-        "unit": "loci/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 intervals + f64", "data": "synthetic",
-        "mfrags_per_s": int(counts[1]) * args.steps / wall / 1e6,
-        "config": {"workload": WORKLOADS["c3-chain"], "loci_per_gpu": q.n_loci, "fragments_per_gpu": q.n_frags,
-                   "features_per_fragment": q.hits.n_features / q.n_frags, **(q.info or {})},
+        "workload": WORKLOADS["c3-chain"], "scaling": "strong" if strong else "weak",
+        "loci": int(counts[0]), "fragments": int(counts[1]), "unique_hits": int(counts[2]), "features_per_hit": feats,
+        "ms_per_step": ms, "loci_per_s": int(counts[0]) * args.steps / wall, "gfrags_per_s": int(counts[1]) * args.steps / wall / 1e9,
+        "kernel_ms": stage, "kernels_sum_ms": float(sum(stage.values())),
+        "host_and_gaps_ms": ms - float(sum(stage.values())),
+        "shape": info,
         "em_status": {"ok": int((q.status[:q.n_loci] == 0).sum()), "init_empty": int((q.status[:q.n_loci] == 1).sum()),
                       "denom_zero": int((q.status[:q.n_loci] == 2).sum()), "maxiter": int((q.status[:q.n_loci] == 3).sum()),
                       "mean_iters": float(q.iters[:q.n_loci].mean())},
-        "roofline": {"bound": "hbm", "kernel": "whole chain (exonbin_kernel + bins_locus_kernel dominate)",
-                     "achieved": b_hit * q.n_frags / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": b_hit * q.n_frags / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                     "algorithmic_bytes": int(b_hit * q.n_frags),
-                     "note": "algorithmic bytes = the exon-bin kernel's per-hit figure (DESIGN 3.5): features, offsets, words; "
-                             "the step also holds host work (plan, pairs' prefix sums, pdf table): see stage times with SBGPU_HOST_TIMING=1"},
+        "roofline": roof,
     }
+    if with_cpu and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"], out["parity"] = chain_cpu_baseline(q)
+    return out
+
+
+def chain_main(args, ctx, dev, rank, world, sdist, torch, launch):
+    """--workload c3-chain: the chain is the headline of the line."""
+    c = chain_leg(args, ctx, dev, rank, world, sdist, torch, strong=args.scaling == "strong")
+    if rank != 0:
+        return
+    out = {
+        "metric": "loci/s and G fragments/s, fragments -> abundances chain (C3-scale)", "value": c["loci_per_s"],
+        "unit": "loci/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": c["ms_per_step"],
+        "higher_is_better": True, "scaling": c["scaling"], "vs_baseline": None, "dtype": "u32 intervals + f64", "data": "synthetic",
+        "mfrags_per_s": c["gfrags_per_s"] * 1e3,
+        "config": {"workload": WORKLOADS["c3-chain"], "loci": c["loci"], "fragments": c["fragments"],
+                   "sharding": "locus l on rank l mod N of ONE sample" if c["scaling"] == "strong" else "every rank its own sample"},
+        "launch": launch, "chain": c, "roofline": c["roofline"],
+    }
+    if c.get("cpu_baseline"):
+        out["cpu_baseline"], out["parity"] = c["cpu_baseline"], c.get("parity")
     print(json.dumps(out))
+    if c.get("parity") and not c["parity"]["ok"]:
+        raise SystemExit("bench.py: the chain's theta does not match the reference program's: %r" % c["parity"])
 
 
 def self_launch(args):
@@ -249,6 +380,7 @@ def main():
                     help="weak: every rank its own full batch (the headline line); strong: ONE batch, loci sharded "
                          "over the ranks (BASELINE config 3) -- measured either way and reported under `strong_scaling`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-chain", action="store_true", help="default workload: leave the fragments -> abundances leg out of the line")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
@@ -302,7 +434,7 @@ def main():
         launch["collective_note"] = comm_note
 
     if args.workload == "c3-chain":
-        return chain_main(args, ctx, dev, rank, world, sdist, torch)
+        return chain_main(args, ctx, dev, rank, world, sdist, torch, launch)
 
     def make_quant(b, f32=False, solver=None):
         solver = solver or em.EmBatchSolver(b, ctx)
@@ -369,9 +501,15 @@ def main():
                             "histogram": "profiles/r02_c5_sweep.json (tools/c5_sweep.py)"}}
         quant.step()   # leave the fp64 result in place for the roofline / parity legs below
 
+    # ---- the chain leg of the default line: fragments -> abundances on 2e8 read pairs in HBM (every rank takes part:
+    # its collectives are collective); --no-chain leaves it out
+    chain_obj = None
+    if args.workload == "c3" and not args.no_chain:
+        res_keep = solver.results() if rank == 0 else None       # (the chain reuses the context's scratch; results first)
+        chain_obj = chain_leg(args, ctx, dev, rank, world, sdist, torch, strong=args.scaling == "strong")
     if rank != 0:
         return
-    res = solver.results()
+    res = res_keep if chain_obj is not None else solver.results()
     head = strong if args.scaling == "strong" else weak
     ms_per_step = head["ms_per_step"]
 
@@ -423,6 +561,8 @@ def main():
         "strong_scaling": strong,
         "roofline": roofline,
     }
+    if chain_obj is not None:
+        out["chain"] = chain_obj
     if c5 is not None:
         # the headline of this workload is the fp32 variant; the fp64 numbers of the same run sit beside it
         out.update({"value": c5["f32"]["value"], "ms_per_step": c5["f32"]["ms_per_step"], "dtype": "f32",

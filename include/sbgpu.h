@@ -159,6 +159,11 @@ int sbgpu_em_run_device_f32(sbgpu_ctx_t *ctx, const sbgpu_plan_t *plan,
 /* Timing events around the EM kernels are off by default (they cost a few microseconds
  * per call); sbgpu_set_timing(ctx, 1) turns them on for the calls that follow.       */
 int sbgpu_set_timing(sbgpu_ctx_t *ctx, int on);
+/* With timing on, sbgpu_quantify_host / _device bracket each of their kernel stages (exon bins, grouping, packing,
+ * pairs, bin weights, EM) with HIP events on the stream the kernels run on.  Reads the stages of the last such call
+ * (waits for them): fills ms[i] / names[i] (static strings) for up to `cap` stages, returns their number or a
+ * negative SBGPU_E* code.  The times are the kernels' own: host work between the stages is not in them.       */
+int sbgpu_last_stage_ms(sbgpu_ctx_t *ctx, int cap, float *ms, const char **names);
 
 /* Device time of the last sbgpu_em_run_device per kernel kind (HIP events recorded
  * on the stream each kind was launched on, all phases of the kind included):

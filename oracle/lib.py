@@ -113,6 +113,16 @@ class OracleLib:
         L.sbo_high_gc_stretch.restype = C.c_int
         L.sbo_binseq_batch.argtypes = [_u8, C.c_int64, C.c_int64, _i64, _u32, _u32, _f64, _f64, _u8]
         L.sbo_binseq_batch.restype = None
+        L.sbo_collapse_cluster.argtypes = [C.c_int, _i64, _u32, _u32, _i64, _u32, _u32, _i32, _i32, _f64, _f64, _i32]
+        L.sbo_collapse_cluster.restype = C.c_int
+        L.sbo_phi.argtypes = [C.c_double]
+        L.sbo_phi.restype = C.c_double
+
+    # ---- duplicate collapse (HitCluster::collapseAndFilterHits)
+    def collapse_cluster(self, left_blocks, right_blocks, nh):
+        """One cluster: per pair the mates' aligned blocks [(l, r), ...] ([] = no such mate) and the NH tag.
+        -> (uniq_pair int32[n_uniq], uniq_mass float64[n_uniq], cluster_mass, n_filtered)"""
+        return _collapse_call(self.L.sbo_collapse_cluster, left_blocks, right_blocks, nh, with_filtered=True)
 
     # ---- EM
     def em_locus(self, count, F):
@@ -273,6 +283,31 @@ class OracleLib:
         return gc[:n], ent[:n], fl[:n]
 
 
+def _blocks_csr(blocks_list):
+    off, l, r = [0], [], []
+    for b in blocks_list:
+        for (x, y) in b:
+            l.append(x)
+            r.append(y)
+        off.append(len(l))
+    pad = lambda v: np.asarray(v if v else [0], np.uint32)  # noqa: E731
+    return np.asarray(off, np.int64), pad(l), pad(r)
+
+
+def _collapse_call(fn, left_blocks, right_blocks, nh, with_filtered):
+    n = len(left_blocks)
+    lo, ll, lr = _blocks_csr(left_blocks)
+    ro, rl, rr = _blocks_csr(right_blocks)
+    nh = np.ascontiguousarray(nh, np.int32)
+    up, um = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.float64)
+    cm, nf = np.zeros(1, np.float64), np.zeros(1, np.int32)
+    args = [n, lo, ll, lr, ro, rl, rr, nh, up, um, cm] + ([nf] if with_filtered else [])
+    k = fn(*args)
+    if k < 0:
+        raise ValueError("collapse: malformed cluster")
+    return up[:k].copy(), um[:k].copy(), float(cm[0]), int(nf[0])
+
+
 class RefLib:
     """oracle/_ref/libstrawberry_ref.so -- the reference's own objects behind ref_shim.cpp."""
 
@@ -300,6 +335,15 @@ class RefLib:
         L.ref_pairedhit_features.restype = C.c_int
         L.ref_kmer_stats.argtypes = [C.c_char_p, C.c_int, _f64]
         L.ref_kmer_stats.restype = None
+        if hasattr(L, "ref_collapse_cluster"):
+            L.ref_collapse_cluster.argtypes = [C.c_int, _i64, _u32, _u32, _i64, _u32, _u32, _i32, _i32, _f64, _f64]
+            L.ref_collapse_cluster.restype = C.c_int
+
+    def collapse_cluster(self, left_blocks, right_blocks, nh):
+        """The reference's own HitCluster (addOpenHit for every read, then collapseAndFilterHits).
+        -> (uniq_pair, uniq_mass, cluster_mass, None)"""
+        up, um, cm, _ = _collapse_call(self.L.ref_collapse_cluster, left_blocks, right_blocks, nh, with_filtered=False)
+        return up, um, cm, None
 
     def kmer_stats(self, seq):
         """(gc, entropy, flags) by the reference's own Kmer<string> templates; len(seq) > 40."""

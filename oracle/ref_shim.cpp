@@ -188,6 +188,54 @@ int ref_pairedhit_features(int n_left, const uint32_t *ll, const uint32_t *lr, i
    return n;
 }
 
+/* HitCluster::collapseAndFilterHits (src/alignments.cpp:658-703) on the reference's own HitCluster, filled the way
+ * the reference fills it: every read goes through HitCluster::addOpenHit (:490-650: mate pairing, the cluster's
+ * read spans), in coordinate order (left ends ascending, ties in input order), then the reference's own collapse
+ * runs.  Pair p: left mate blocks [lo[p], lo[p+1]) of (ll, lr), right mate [ro[p], ro[p+1]) of (rl, rr) (one of
+ * them may be empty: a singleton), NH tag nh[p].  Out, per unique hit in the reference's order: the input pair it
+ * was made of (read id), its collapse mass; *cluster_mass = HitCluster::_weighted_mass.  Returns the number of
+ * unique hits, -1 when a read was refused.                                                                      */
+int ref_collapse_cluster(int n_pairs, const int64_t *lo, const uint32_t *ll, const uint32_t *lr, const int64_t *ro,
+                         const uint32_t *rl, const uint32_t *rr, const int32_t *nh, int32_t *uniq_pair_out,
+                         double *uniq_mass_out, double *cluster_mass_out)
+{
+   struct Rd {
+      uint32_t pos;
+      int pair, side;
+   };
+   std::vector<Rd> reads;
+   for (int p = 0; p < n_pairs; ++p) {
+      if (lo[p + 1] > lo[p]) reads.push_back({ll[lo[p]], p, 0});
+      if (ro[p + 1] > ro[p]) reads.push_back({rl[ro[p]], p, 1});
+   }
+   std::stable_sort(reads.begin(), reads.end(), [](const Rd &a, const Rd &b) { return a.pos < b.pos; });
+   auto make = [&](int p, int side) {
+      const int64_t o = side ? ro[p] : lo[p], n = (side ? ro[p + 1] : lo[p + 1]) - o;
+      const uint32_t *bl = (side ? rl : ll) + o, *br = (side ? rr : lr) + o;
+      std::vector<CigarOp> cig;
+      for (int64_t k = 0; k < n; ++k) {
+         if (k) cig.push_back(CigarOp(REF_SKIP, bl[k] - br[k - 1] - 1));
+         cig.push_back(CigarOp(MATCH, br[k] - bl[k] + 1));
+      }
+      const bool has_mate = side ? lo[p + 1] > lo[p] : ro[p + 1] > ro[p];
+      const int partner_pos = has_mate ? (int)(side ? ll[lo[p]] : rl[ro[p]]) : 0;
+      GenomicInterval iv(0, bl[0], br[n - 1], Strand_t::StrandPlus);
+      return ReadHitPtr(new ReadHit((ReadID)(p + 1), "r", iv, cig, 0, partner_pos, 0, nh[p], side ? 147u : 99u, 1.0, NULL));
+   };
+   HitCluster hc;
+   for (const Rd &r : reads)
+      if (!hc.addOpenHit(make(r.pair, r.side), true, true)) return -1;
+   const int n = hc.collapseAndFilterHits();
+   int k = 0;
+   for (const PairedHit &u : hc.uniq_hits()) {
+      uniq_pair_out[k] = (int32_t)((u._left_read ? u.left_read_obj().read_id() : u.right_read_obj().read_id()) - 1);
+      uniq_mass_out[k] = u.collapse_mass();
+      ++k;
+   }
+   *cluster_mass_out = hc._weighted_mass;
+   return n;
+}
+
 /* The six per-bin sequence statistics of the `-f` table, by the reference's own templates
  * exactly as src/alignments.cpp:1623-1629 calls them.  out6 = gc, entropy, 4 flags (0/1).
  * The caller keeps to len > 40: the reference's live asserts abort below that.           */

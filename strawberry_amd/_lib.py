@@ -22,7 +22,7 @@ SYMBOLS = [
     "sbgpu_version", "sbgpu_last_error", "sbgpu_device_count", "sbgpu_init", "sbgpu_finalize",
     "sbgpu_device_info", "sbgpu_synchronize", "sbgpu_plan_create", "sbgpu_plan_destroy", "sbgpu_plan_info",
     "sbgpu_plan_classes", "sbgpu_plan_locus_kinds", "sbgpu_em_run_device", "sbgpu_em_run_device_f32", "sbgpu_em_last_kernel_ms",
-    "sbgpu_set_timing", "sbgpu_em_last_phase_ms",
+    "sbgpu_set_timing", "sbgpu_em_last_phase_ms", "sbgpu_last_stage_ms",
     "sbgpu_comm_unique_id", "sbgpu_comm_init", "sbgpu_comm_info", "sbgpu_comm_destroy",
     "sbgpu_allreduce_sum_f64", "sbgpu_allreduce_sum_i64", "sbgpu_allreduce_sum_f64_host", "sbgpu_allreduce_sum_i64_host",
     "sbgpu_insert_pdf_table", "sbgpu_binweight_device", "sbgpu_binweight_host",
@@ -146,6 +146,7 @@ def load():
     L.sbgpu_plan_locus_kinds.argtypes = [vp, vp]
     L.sbgpu_em_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.sbgpu_set_timing.argtypes = [vp, C.c_int]
+    L.sbgpu_last_stage_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_char_p)]
     L.sbgpu_comm_unique_id.argtypes = [vp]
     L.sbgpu_comm_init.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
     L.sbgpu_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]

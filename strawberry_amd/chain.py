@@ -1,9 +1,13 @@
 """The fragments -> abundances chain on hits that are resident in HBM (sbgpu_quantify_device), and the synthetic
-human-scale input of bench.py's `c3-chain` workload.
+human-scale input of bench.py's chain workload.
 
-A small sample (a few hundred gene models with their read pairs, made on the host like the tests' inputs) is
-laid along the genome `copies` times: the annotation on the host (it is small), the hits ON THE DEVICE with
-torch index arithmetic -- 2e8 fragments are ~10 GB of features that never exist in host memory.
+The sample: `n_loci` DISTINCT gene models (synth.make_gene_models: 1-12 exons, 1-6 alternatively spliced isoforms,
+every locus drawn on its own -- no model is laid out twice) and ~2e8 read pairs sampled from them ON THE DEVICE with
+torch index arithmetic (2e8 fragments are ~10 GB of features that never exist in host memory): per locus a
+log-normal share of the fragments, per isoform a Dirichlet-like expression level, fragment length N(250, 30), start
+uniform along the transcript, mates of 75 bases mapped through the isoform's exon table, plus pairs that fit fewer
+isoforms or none (a mate shifted by a few bases; an unspliced left mate that runs into the intron).  Hits come out
+sorted by (locus, left end, right end) -- HitCluster::collapseAndFilterHits' order -- in the layout of sbgpu_hits_t.
 """
 import ctypes as C
 
@@ -15,27 +19,182 @@ from . import synth
 from .binweight import InsertSize
 
 
-class DeviceHits:
-    """Hits of a tiled sample as torch tensors on the device (layout of sbgpu_hits_t)."""
+class DeviceSample:
+    """Annotation (host arrays, it is small) + hits on the device."""
 
-    def __init__(self, torch, dev, base_hits, n_base_loci, copies, stride):
-        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
-        n, nf = base_hits.n_hits, int(base_hits.feat_off[-1])
-        k_hit = torch.arange(copies, device=dev, dtype=torch.int64).repeat_interleave(n)
-        k_feat = torch.arange(copies, device=dev, dtype=torch.int64).repeat_interleave(nf)
-        self.n_hits = n * copies
-        self.hit_locus = (up(base_hits.hit_locus).to(torch.int64).repeat(copies) + k_hit * n_base_loci).to(torch.int32)
-        self.feat_off = torch.cat([up(base_hits.feat_off[:-1]).repeat(copies) + k_hit * nf,
-                                   torch.tensor([nf * copies], device=dev, dtype=torch.int64)])
-        self.feat_code = up(base_hits.feat_code).repeat(copies)
-        # uint32 coordinates travel as int32 bit patterns
-        self.feat_left = (up(base_hits.feat_left.astype(np.int64)).repeat(copies) + k_feat * stride).to(torch.int32)
-        self.feat_right = (up(base_hits.feat_right.astype(np.int64)).repeat(copies) + k_feat * stride).to(torch.int32)
-        self.mass = up(base_hits.mass).repeat(copies)
-        del k_hit, k_feat
-        self.n_features = nf * copies
-        base_off = np.searchsorted(base_hits.hit_locus, np.arange(n_base_loci + 1), side="left").astype(np.int64)
-        self.locus_hit_off = np.concatenate([base_off[:-1] + k * n for k in range(copies)] + [[n * copies]]).astype(np.int64)
+    def __init__(self, torch, dev, n_loci=60000, n_frags=2e8, seed=31, read_len=75, mean=250.0, sd=30.0, noise=0.10,
+                 loci_subset=None):
+        """loci_subset: (rank, world) -- keep only this rank's share of the SAME sample's loci (strong scaling:
+        every rank draws the same annotation and the same per-locus fragment counts, then generates its own loci's
+        fragments only)."""
+        loci = synth.make_gene_models(n_loci, seed=seed)
+        rng = np.random.Generator(np.random.PCG64(seed ^ 0x5EED))
+        # per-locus share of the fragments: log-normal (sigma 1), like C3's law
+        w = rng.lognormal(0.0, 1.0, n_loci)
+        per_locus = np.maximum(0, np.rint(w / w.sum() * n_frags)).astype(np.int64)
+        self.world_loci = n_loci
+        if loci_subset is not None:
+            rank, world = loci_subset
+            mine = np.arange(rank, n_loci, world)          # locus l belongs to rank l mod world (examples/quantify_fragments.cpp)
+            loci = [loci[l] for l in mine]
+            per_locus = per_locus[mine]
+            n_loci = len(loci)
+        self.annot = eb.Annotation(loci)
+        a = self.annot
+        n_iso, n_exon = int(a.iso_off[-1]), int(a.exon_off[-1])
+        # ---- isoform tables on the host (small), then to the device
+        ex_len = (a.exon_right.astype(np.int64) - a.exon_left.astype(np.int64) + 1)
+        iso_len = np.add.reduceat(ex_len, a.exon_off[:-1]) if n_iso else np.zeros(0, np.int64)
+        ex_iso = np.repeat(np.arange(n_iso), np.diff(a.exon_off))
+        cum_incl = np.cumsum(ex_len) - np.repeat(np.concatenate([[0], np.cumsum(iso_len)[:-1]]), np.diff(a.exon_off))   # within the isoform, incl. this exon
+        cum_excl = cum_incl - ex_len
+        BIG = 1 << 20                                         # > any transcript length
+        assert iso_len.max(initial=0) < BIG
+        iso_locus = np.repeat(np.arange(n_loci), np.diff(a.iso_off))
+        # expression of an isoform inside its locus: Gamma(0.8) shares; isoforms too short for a pair get none
+        expr = rng.gamma(0.8, 1.0, n_iso) * (iso_len >= 2 * read_len + 1)
+        tot = np.bincount(iso_locus, weights=expr, minlength=n_loci)
+        per_locus = np.where(tot > 0, per_locus, 0)           # a locus of short isoforms only has no pairs
+        share = np.cumsum(expr) - np.repeat(np.concatenate([[0], np.cumsum(tot)[:-1]]), np.diff(a.iso_off))
+        share = share / np.maximum(tot[iso_locus], 1e-300)    # cumulative within the locus, last = 1
+        last = np.zeros(n_iso, bool)
+        last[a.iso_off[1:][np.diff(a.iso_off) > 0] - 1] = True
+        share[last] = 1.0
+        up = lambda x, dt=None: torch.from_numpy(np.ascontiguousarray(x if dt is None else x.astype(dt))).to(dev)  # noqa: E731
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed * 7919 + (0 if loci_subset is None else 1 + loci_subset[0]))
+        n = int(per_locus.sum())
+        d_locus = torch.repeat_interleave(torch.arange(n_loci, device=dev, dtype=torch.int32), up(per_locus))
+        # isoform of each fragment: first isoform of the locus whose cumulative share reaches u
+        key = up(iso_locus.astype(np.float64) + share * (1.0 - 1e-9))     # sorted: locus + cumulative share in (0, 1)
+        u = torch.rand(n, device=dev, generator=g, dtype=torch.float64) * (1.0 - 3e-9) + 1e-9   # in (0, 1 - 2e-9)
+        d_iso = torch.searchsorted(key, d_locus.to(torch.float64) + u, right=False).to(torch.int64)
+        del u, key
+        d_L = up(iso_len)[d_iso]
+        fl = torch.round(torch.randn(n, device=dev, generator=g) * sd + mean).to(torch.int64)
+        fl = torch.minimum(torch.clamp(fl, min=2 * read_len + 1), d_L)
+        st = torch.floor(torch.rand(n, device=dev, generator=g, dtype=torch.float64) * (d_L - fl + 1).to(torch.float64)).to(torch.int64)
+        st = torch.minimum(st, d_L - fl)
+        del d_L
+        kind = torch.rand(n, device=dev, generator=g)
+        shift = torch.where((kind >= noise / 2) & (kind < noise), torch.randint(1, 9, (n,), device=dev, generator=g), 0).to(torch.int64)
+        unspliced = kind < noise / 2
+        del kind
+        # ---- transcript coordinates -> genomic blocks through the isoform's exon table
+        d_cum_key = up(ex_iso.astype(np.int64) * BIG + cum_incl)          # sorted: (isoform, end of exon in transcript)
+        d_ex_left, d_cum_excl, d_ex_len = up(a.exon_left, np.int64), up(cum_excl), up(ex_len)
+
+        def exon_of(t):   # global exon index holding transcript base t of the fragment's isoform
+            return torch.searchsorted(d_cum_key, d_iso * BIG + t, right=True)
+
+        MAXB = 4
+
+        def mate(t0, t1):
+            """blocks of transcript interval [t0, t1): (count, left[MAXB], right[MAXB]) -- int64 [n] tensors"""
+            e0, e1 = exon_of(t0), exon_of(t1 - 1)
+            nb = (e1 - e0 + 1)
+            ls, rs = [], []
+            for k in range(MAXB):
+                e = torch.minimum(e0 + k, e1)
+                base = d_ex_left[e] - d_cum_excl[e]
+                ls.append(base + torch.maximum(t0, d_cum_excl[e]))
+                rs.append(base + torch.minimum(t1, d_cum_excl[e] + d_ex_len[e]) - 1)
+            return nb, ls, rs
+
+        nbl, ll, lr = mate(st, st + read_len)
+        nbr, rl, rr = mate(st + fl - read_len, st + fl)
+        del st, fl
+        # unspliced left mate: one block of read_len bases from its start (runs into the intron when it was spliced)
+        nbl = torch.where(unspliced, 1, nbl)
+        lr[0] = torch.where(unspliced, ll[0] + read_len - 1, lr[0])
+        rl = [x + shift for x in rl]
+        rr = [x + shift for x in rr]
+        del shift, unspliced
+        ok = (nbl <= MAXB) & (nbr <= MAXB)
+        left_end = lr[0]
+        for k in range(1, MAXB):
+            left_end = torch.where(nbl > k, lr[k], left_end)
+        right_end = rr[0]
+        for k in range(1, MAXB):
+            right_end = torch.where(nbr > k, rr[k], right_end)
+        ok &= rl[0] > left_end + 1                                       # a GAP of at least one base between the mates
+        # ---- HitCluster's order: (left end, right end); the loci lie along the genome in locus order.  Equal fragments
+        # are ONE unique hit whose mass is their number (HitCluster::collapseAndFilterHits merges them, alignments.cpp:685-696):
+        # inside a (left, right) run the fragments are ordered by a hash of their blocks
+        span = torch.where(ok, ll[0] * (1 << 31) + right_end, torch.iinfo(torch.int64).max)
+        sig = torch.zeros(n, dtype=torch.int64, device=dev)
+        for k in range(MAXB):
+            for x, nbx in ((ll[k], nbl), (lr[k], nbl), (rl[k], nbr), (rr[k], nbr)):
+                sig = (sig ^ torch.where(nbx > k, x, -1 - k)) * (-7046029254386353131) + 7145426229640650777   # (int64 arithmetic wraps)
+                sig = sig ^ (sig >> 29)
+        order = torch.argsort(sig)
+        order = order[torch.argsort(span[order], stable=True)]
+        n_ok = int(ok.sum().item())
+        order = order[:n_ok]
+        s_span, s_sig = span[order], sig[order]
+        # one fragment per (left, right): the reference sorts its pairs by the two ends only (std::sort, src/read.cpp:917-923)
+        # and merges equal NEIGHBOURS, so different fragments with equal ends would make its own output depend on its
+        # sort's tie order (A B A: the second A becomes a unique hit of its own, which the bins' std::set then drops).
+        # Of the fragments sharing their ends the first kind stays; its copies are its mass.
+        first = torch.ones(n_ok, dtype=torch.bool, device=dev)
+        first[1:] = s_span[1:] != s_span[:-1]
+        pos = torch.arange(n_ok, device=dev)
+        run_start = torch.cummax(torch.where(first, pos, 0), 0).values
+        keep = s_sig == s_sig[run_start]
+        run_id = torch.cumsum(first, 0) - 1
+        mass = torch.bincount(run_id[keep], minlength=int(run_id[-1].item()) + 1 if n_ok else 0).to(torch.float32)
+        del pos, run_start, keep
+        order = order[first]
+        self.n_pairs_drawn = n_ok
+        n_ok = int(order.numel())
+        del ok, right_end, span, sig, s_span, s_sig, first, run_id
+        take = lambda x: x[order]  # noqa: E731
+        d_locus, nbl, nbr, left_end = take(d_locus), take(nbl), take(nbr), take(left_end)
+        ll, lr, rl, rr = [take(x) for x in ll], [take(x) for x in lr], [take(x) for x in rl], [take(x) for x in rr]
+        del order, d_iso
+        # ---- features: left mate (MATCH, INTRON between), GAP, right mate
+        nf = 2 * nbl - 1 + 1 + 2 * nbr - 1
+        feat_off = torch.zeros(n_ok + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(nf, 0, out=feat_off[1:])
+        total = int(feat_off[-1].item())
+        code = torch.zeros(total, dtype=torch.uint8, device=dev)
+        fleft = torch.zeros(total, dtype=torch.int64, device=dev)
+        fright = torch.zeros(total, dtype=torch.int64, device=dev)
+        base = feat_off[:-1]
+
+        def put(mask, pos, c, l, r):
+            p = pos[mask]
+            code[p] = c
+            fleft[p] = l[mask]
+            fright[p] = r[mask]
+
+        every = torch.ones(n_ok, dtype=torch.bool, device=dev)
+        for k in range(MAXB):
+            m = nbl > k
+            put(m, base + 2 * k, eb.MATCH, ll[k], lr[k])
+            if k:
+                put(m, base + 2 * k - 1, eb.INTRON, lr[k - 1] + 1, ll[k] - 1)
+        gap_at = base + 2 * nbl - 1
+        put(every, gap_at, eb.GAP, left_end + 1, rl[0] - 1)
+        for k in range(MAXB):
+            m = nbr > k
+            put(m, gap_at + 1 + 2 * k, eb.MATCH, rl[k], rr[k])
+            if k:
+                put(m, gap_at + 2 * k, eb.INTRON, rr[k - 1] + 1, rl[k] - 1)
+        del ll, lr, rl, rr, nbl, nbr, left_end, every, gap_at, base, nf
+        self.n_hits, self.n_features = n_ok, total
+        self.hit_locus = d_locus
+        self.feat_off = feat_off
+        self.feat_code = code
+        self.feat_left = fleft.to(torch.int32)        # uint32 coordinates travel as int32 bit patterns (all < 2^31 here)
+        self.feat_right = fright.to(torch.int32)
+        del fleft, fright
+        self.mass = mass
+        self.n_fragments = int(mass.sum().item())     # read pairs behind the unique hits
+        cnt = torch.bincount(d_locus.to(torch.int64), minlength=n_loci)
+        self.locus_hit_off = np.concatenate([[0], np.cumsum(cnt.cpu().numpy())]).astype(np.int64)
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
 
     def struct(self):
         s = _lib.sbgpu_hits_t()
@@ -44,48 +203,29 @@ class DeviceHits:
             setattr(s, k, getattr(self, k).data_ptr())
         return s
 
-
-def tile_annotation(a, copies, stride):
-    """`copies` copies of the annotation `stride` bases apart (host arrays)."""
-    big = eb.Annotation.__new__(eb.Annotation)
-    n_iso, n_exon, n_seg = int(a.iso_off[-1]), int(a.exon_off[-1]), int(a.seg_off[-1])
-    rep = lambda off, total: np.concatenate([[0]] + [off[1:] + k * total for k in range(copies)]).astype(np.int64)  # noqa: E731
-    shift = lambda x: np.concatenate([x.astype(np.int64) + k * stride for k in range(copies)]).astype(np.uint32)  # noqa: E731
-    big.n_loci = a.n_loci * copies
-    big.iso_off, big.exon_off, big.seg_off = rep(a.iso_off, n_iso), rep(a.exon_off, n_exon), rep(a.seg_off, n_seg)
-    big.exon_left, big.exon_right = shift(a.exon_left), shift(a.exon_right)
-    big.seg_left, big.seg_right = shift(a.seg_left), shift(a.seg_right)
-    big.compat_words, big.key_words = a.compat_words, a.key_words
-    return big
+    def host_hits(self, n_loci):
+        """The hits of the first n_loci loci as host arrays (eb.Hits): what the oracle / the reference gets of the sample."""
+        h1 = int(self.locus_hit_off[n_loci])
+        f1 = int(self.feat_off[h1].item())
+        return eb.Hits.from_arrays(self.hit_locus[:h1].cpu().numpy(), self.feat_off[:h1 + 1].cpu().numpy(),
+                                   self.feat_code[:f1].cpu().numpy(), self.feat_left[:f1].cpu().numpy().view(np.uint32),
+                                   self.feat_right[:f1].cpu().numpy().view(np.uint32), self.mass[:h1].cpu().numpy())
 
 
 class ChainQuantifier:
     """step(): fragments (in HBM) -> compat / key words -> bins -> weights -> EM -> theta, one C-ABI call;
     then FPKM / TPM on the host arrays the call returns (the caller's own epilogue, as in the reference)."""
 
-    def __init__(self, ctx, n_loci=60000, n_frags=2e8, base_loci=100, seed=31, read_len=75):
+    def __init__(self, ctx, n_loci=60000, n_frags=2e8, seed=31, read_len=75, loci_subset=None):
         import torch
         self.torch, self.ctx = torch, ctx
         self.dev = torch.device("cuda", ctx.device)
-        copies = max(1, int(round(n_loci / base_loci)))
-        per_locus = max(1, int(round(n_frags / (copies * base_loci))))
-        loci = synth.make_gene_models(base_loci, seed=seed)
-        hl, pairs = synth.make_fragments(loci, per_locus, seed=seed + 1, single=0.0)
-        feats, loc = [], []
-        for l, (lb, rb) in zip(hl, pairs):
-            f = eb.hit_features(lb, rb)
-            if f is not None:
-                feats.append(f)
-                loc.append(l)
-        base_annot, base_hits = eb.Annotation(loci), eb.Hits(loc, feats)
-        stride = int(max(base_annot.exon_right.max(), base_hits.feat_right.max()) + 100000)
-        if stride * copies >= 2 ** 32:
-            raise ValueError("the tiled sample does not fit 32-bit coordinates")
-        self.annot = tile_annotation(base_annot, copies, stride)
-        self.hits = DeviceHits(torch, self.dev, base_hits, base_annot.n_loci, copies, stride)
+        self.sample = DeviceSample(torch, self.dev, n_loci, n_frags, seed, read_len, loci_subset=loci_subset)
+        self.annot, self.hits = self.sample.annot, self.sample
         self.insert = InsertSize(250.0, 30.0)
         self.read_len = read_len
-        self.n_loci, self.n_frags = self.annot.n_loci, self.hits.n_hits
+        # n_hits: unique hits (what the kernels touch); n_frags: the read pairs they stand for (their masses)
+        self.n_loci, self.n_hits, self.n_frags = self.annot.n_loci, self.hits.n_hits, self.hits.n_fragments
         self.n_iso = int(self.annot.iso_off[-1])
         self.theta = np.zeros(self.n_iso + 1)
         self.status = np.zeros(self.n_loci + 1, np.int32)
@@ -107,6 +247,20 @@ class ChainQuantifier:
             _lib.check(L.sbgpu_bins_info(h, info), "sbgpu_bins_info")
             self.info = {"n_bins": int(info[2]), "n_elem": int(info[3]), "n_pairs": int(info[4]), "hits_in_bins": int(info[6])}
         L.sbgpu_bins_destroy(h)
+
+    def stage_ms(self):
+        """HIP-event times of the kernel stages of one more (untimed) step -> {stage: ms}."""
+        L = self.ctx.L
+        _lib.check(L.sbgpu_set_timing(self.ctx.h, 1), "sbgpu_set_timing")
+        try:
+            self.step()
+            ms, names = (C.c_float * 16)(), (C.c_char_p * 16)()
+            n = L.sbgpu_last_stage_ms(self.ctx.h, 16, ms, names)
+            if n < 0:
+                _lib.check(n, "sbgpu_last_stage_ms")
+            return {names[i].decode(): float(ms[i]) for i in range(n)}
+        finally:
+            L.sbgpu_set_timing(self.ctx.h, 0)
 
     def finish(self):
         pass

@@ -32,7 +32,10 @@ void iso_segments(const sbgpu_annotation_t *annot, IsoSegments *out);
 // sbgpu_bins_create_device with the segment lists made beforehand (nullptr: made inside)
 int bins_create_device_impl(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *annot, const sbgpu_hits_t *d_hits, const float *d_mass,
                             const int64_t *locus_hit_off, int32_t compat_words, int32_t key_words, const uint32_t *d_compat,
-                            const uint32_t *d_key, int64_t *d_hit_bin, void *stream, const IsoSegments *iso_pre, sbgpu_bins_t **out);
+                            const uint32_t *d_key, int64_t *d_hit_bin, void *stream, const IsoSegments *iso_pre, sbgpu_bins_t **out,
+                            const uint64_t *d_span, const uint32_t *d_fhash); // spans / hashes of the hits (exonbin_device_impl), or null
+int exonbin_device_impl(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *annot, const sbgpu_hits_t *hits, int32_t compat_words,
+                        int32_t key_words, uint32_t *d_compat, uint32_t *d_key, uint64_t *d_span, uint32_t *d_fhash, void *stream);
 int api_fail(int code, const std::string &msg); // records sbgpu_last_error(), returns code
 hipStream_t ctx_stream(const sbgpu_ctx_t *ctx); // the context's own stream
 int ctx_cu_count(const sbgpu_ctx_t *ctx);
@@ -40,6 +43,11 @@ int ctx_device(const sbgpu_ctx_t *ctx);        // the HIP device the context was
 // device scratch that lives with the context (slot 0..7, grows on demand, never shrinks): valid until the next
 // request for the same slot; one host thread per context
 hipError_t ctx_scratch(sbgpu_ctx_t *ctx, int slot, size_t bytes, char **out);
+// kernel stages of the chain entry points: while sbgpu_set_timing is on, the launches between a begin and its end
+// are bracketed by HIP events on their stream (sbgpu_last_stage_ms reads them); no-ops otherwise
+void ctx_stage_reset(sbgpu_ctx_t *ctx);
+void ctx_stage_begin(sbgpu_ctx_t *ctx, const char *name, hipStream_t s);
+void ctx_stage_end(sbgpu_ctx_t *ctx, hipStream_t s);
 bool ctx_take_wide_error(sbgpu_ctx_t *ctx);    // true once if a wide-locus barrier timed out since the last call (clears the flag)
 // locus_bins.cpp: finish bins that were grouped on the device (host copies of the per-bin arrays)
 // `pairs`: made on the device already (the handle takes the arena over); nullptr: make them here, on the host

@@ -31,7 +31,8 @@ constexpr int kBinsSlotsMid = 2048, kBinsMaxMid = 1400;      // larger loci firs
 constexpr int kBinsSlotsBig = 8192, kBinsMaxBig = 5600;      // ~0.7 load
 constexpr int kBinsSmallHits = 256;
 constexpr int kBinsThreads = 256;      // the small table's workgroup
-constexpr int kBinsThreadsMid = 512;
+constexpr int kBinsThreadsMid = 512;   // the two-pass form's
+constexpr int kBinsThreadsAccum = 1024; // the single-pass form's middle table: two workgroups of 16 waves per CU
 constexpr int kBinsThreadsBig = 1024;  // the big table fills a CU's LDS: one workgroup per CU, so it brings 16 waves
 enum : int32_t { kBinsUnsorted = 1, kBinsFractional = 2, kBinsTableFull = 4, kBinsMassOverflow = 8, kBinsRunTooLong = 128 };
 
@@ -44,6 +45,8 @@ struct BinsArgs {
    const float *mass;
    int32_t compat_words, key_words;
    const uint32_t *compat, *key;
+   const uint64_t *span;    // [n_hits] first left end << 32 | last right end; 0 for a hit without features (exonbin_device.h)
+   const uint32_t *fhash;   // [n_hits] hash of the (left, right) sequence
    // hit-indexed scratch: bin b of locus l lives at index locus_hit_off[l] + b
    int32_t *hit_bin_local;  // [n_hits] rank of the hit's bin inside its locus, -1: dropped
    int32_t *bin_rep;        // [n_hits] a member hit of the bin (its key words are the bin's)
@@ -249,6 +252,207 @@ __global__ __launch_bounds__(kThreads) void bins_locus_kernel(BinsArgs a)
          a.n_used[l] = n_hits_in;
          if (RETRY && overflow) bad &= ~(int)kBinsTableFull;
          if (bad) atomicOr(a.flags, bad);
+      }
+      __syncthreads();
+   }
+}
+
+
+// ------------------------------------------------------------------ the single-pass form (round 3)
+// The two-pass kernel above reads a hit's feature offsets and end coordinates twice (gathers: ~150 bytes of traffic
+// per hit) and finds the bin of every earlier hit of a (left, right) run to apply the std::set<Contig> rule.  Two
+// observations remove both: (i) fragments with equal feature sequences have equal key and compat words, hence the
+// same bin, so "an equal fragment already in this bin" is "an equal fragment earlier in the run" -- a question about
+// hits alone; (ii) the exon-bin kernel, which has every hit's features in registers anyway, can leave the run key
+// (span) and a hash of the sequence per hit.  This kernel then reads 25 coalesced bytes per hit -- key, compat, mass,
+// span, hash -- ONCE: the table entry of a hit's key accumulates mass and compat union by SLOT while the bins are
+// still unranked, the ranking follows, and the per-bin results are written from the slots.  Features are touched
+// only to confirm a hash match (i.e. for true duplicates).  hit -> bin is a kernel of its own (bins_assign_kernel),
+// run only where somebody wants it.  Compat unions of up to two words; wider loci and loci of more bins than the
+// middle table holds keep the two-pass kernel.
+// The table of this form holds the key words themselves (at most two: 64 bits, never 0 for a hit that enters), so a
+// probe compares in LDS and never reads a member hit's words from global memory.
+__device__ __forceinline__ int bins_slot(unsigned long long *keyw, int slots, unsigned long long key, bool insert)
+{
+   unsigned long long x = key * 0x9E3779B97F4A7C15ull;
+   int slot = (int)(x >> 40) & (slots - 1);
+   for (int probe = 0; probe < slots; ++probe) {
+      unsigned long long t = keyw[slot];
+      if (t == key) return slot;
+      if (t == 0ull) {
+         if (!insert) return -1;
+         t = atomicCAS(&keyw[slot], 0ull, key);
+         if (t == 0ull || t == key) return slot;
+      }
+      slot = (slot + 1) & (slots - 1);
+   }
+   return -1;
+}
+
+constexpr int kBinsBatch = 4; // hits a thread has in flight per trip: their loads are issued together
+
+template <int kBinsSlots, int kBinsMaxPerLocus, int kThreads, int CW, bool RETRY = false>
+__global__ __launch_bounds__(kThreads) void bins_accum_kernel(BinsArgs a)
+{
+   __shared__ unsigned long long keyw[kBinsSlots];
+   __shared__ int first[kBinsSlots];          // first hit of the slot's bin (min)
+   __shared__ int acc_count[kBinsSlots];      // mass of the slot's bin
+   __shared__ unsigned acc_compat[CW * kBinsSlots];
+   __shared__ int used[kBinsMaxPerLocus], used_rank[kBinsMaxPerLocus];
+   __shared__ int n_used_slots, n_hits_in, bad;
+   const int tid = threadIdx.x;
+   const int kw = a.key_words; // 1 or 2; compat words: CW
+   for (int64_t li = blockIdx.x; li < a.n_loci; li += gridDim.x) {
+      const int64_t l = a.loci[li];
+      const int64_t q0 = a.locus_hit_off[l], q1 = a.locus_hit_off[l + 1];
+      int slots = 64;
+      while (slots < kBinsSlots && slots < 4 * (q1 - q0)) slots <<= 1;
+      for (int s = tid; s < slots; s += kThreads) {
+         keyw[s] = 0ull;
+         first[s] = 0x7fffffff;
+         acc_count[s] = 0;
+         for (int w = 0; w < CW; ++w) acc_compat[CW * s + w] = 0u;
+      }
+      if (tid == 0) n_used_slots = 0, n_hits_in = 0, bad = 0;
+      __syncthreads();
+      int my_bad = 0, my_used = 0;
+      for (int64_t base = q0 + tid; base < q1; base += (int64_t)kBinsBatch * kThreads) {
+         // ---- the batch's loads, all in flight together
+         uint64_t sp[kBinsBatch], sp1[kBinsBatch];
+         uint32_t fh[kBinsBatch], fh1[kBinsBatch], cv[kBinsBatch][CW];
+         unsigned long long key[kBinsBatch];
+         float m[kBinsBatch];
+#pragma unroll
+         for (int i = 0; i < kBinsBatch; ++i) {
+            const int64_t h = base + (int64_t)i * kThreads;
+            const bool in = h < q1;
+            const int64_t hc = in ? h : q0;
+            sp[i] = in ? a.span[hc] : 0ull;
+            fh[i] = a.fhash[hc];
+            const int64_t hp = hc > q0 ? hc - 1 : q0;
+            sp1[i] = hc > q0 ? a.span[hp] : 0ull;
+            fh1[i] = a.fhash[hp];
+            for (int w = 0; w < CW; ++w) cv[i][w] = in ? a.compat[hc * CW + w] : 0u;
+            key[i] = in ? (kw == 2 ? (((unsigned long long)a.key[hc * 2 + 1] << 32) | a.key[hc * 2]) : (unsigned long long)a.key[hc]) : 0ull;
+            m[i] = a.mass[hc];
+         }
+#pragma unroll
+         for (int i = 0; i < kBinsBatch; ++i) {
+            const int64_t h = base + (int64_t)i * kThreads;
+            if (h >= q1) break;
+            if (sp[i] && sp1[i] > sp[i]) my_bad |= kBinsUnsorted; // sorted by (left, right)?  (hits without features carry no position: 0)
+            uint32_t any_c = 0;
+            for (int w = 0; w < CW; ++w) any_c |= cv[i][w];
+            if (!any_c || !key[i]) {
+               a.dup[h] = 0;
+               continue;
+            }
+            if (!(m[i] >= 0.0f && m[i] < 16777216.0f && (float)(int)m[i] == m[i])) my_bad |= kBinsFractional;
+            const int slot = bins_slot(keyw, slots, key[i], true);
+            if (slot < 0) {
+               my_bad |= kBinsTableFull;
+               a.dup[h] = 0;
+               continue;
+            }
+            if (first[slot] > (int)(h - q0)) atomicMin(&first[slot], (int)(h - q0));
+            ++my_used;
+            for (int w = 0; w < CW; ++w)
+               if (cv[i][w] && (acc_compat[CW * slot + w] & cv[i][w]) != cv[i][w]) atomicOr(&acc_compat[CW * slot + w], cv[i][w]);
+            // std::set<Contig>: an equal fragment earlier in this (left, right) run?  (equal fragments share bin and words)
+            bool dup = false;
+            if (sp1[i] == sp[i] || sp1[i] == 0ull) { // (the common case -- the hit before starts another run -- costs no load)
+               for (int64_t p = h - 1; p >= q0 && !dup; --p) {
+                  const uint64_t ps = p == h - 1 ? sp1[i] : a.span[p];
+                  if (ps != sp[i]) {
+                     if (ps == 0ull) continue; // a hit without features sits anywhere
+                     break;
+                  }
+                  const uint32_t pf = p == h - 1 ? fh1[i] : a.fhash[p];
+                  dup = pf == fh[i] && bins_same_fragment(a, p, h);
+               }
+            }
+            a.dup[h] = dup ? 1 : 0;
+            if (!dup) atomicAdd(&acc_count[slot], (int)m[i]);
+         }
+      }
+      if (my_bad) atomicOr(&bad, my_bad);
+      if (my_used) atomicAdd(&n_hits_in, my_used);
+      __syncthreads();
+      // ---- the bins, ranked by their first hit
+      for (int s = tid; s < slots; s += kThreads)
+         if (keyw[s] != 0ull) {
+            const int k = atomicAdd(&n_used_slots, 1);
+            if (k < kBinsMaxPerLocus) used[k] = s;
+         }
+      __syncthreads();
+      int nb = n_used_slots;
+      const bool overflow = nb > kBinsMaxPerLocus || (bad & kBinsTableFull);
+      if (overflow) {
+         if (tid == 0 && !RETRY) atomicOr(&bad, (int)kBinsTableFull);
+         nb = 0; // the locus is not written; the flag sends the batch to the host (or, RETRY, the locus to the two-pass kernel)
+      }
+      for (int k = tid; k < nb; k += kThreads) {
+         const int fk = first[used[k]];
+         int r = 0;
+         for (int v = 0; v < nb; ++v) r += first[used[v]] < fk; // first hits are distinct: ranks are a permutation
+         used_rank[k] = r;
+      }
+      __syncthreads();
+      for (int k = tid; k < nb; k += kThreads) {
+         const int s = used[k], r = used_rank[k];
+         a.bin_rep[q0 + r] = first[s]; // a member hit (the first), relative to q0
+         a.bin_count[q0 + r] = acc_count[s];
+         for (int w = 0; w < CW; ++w) a.bin_compat[(q0 + r) * CW + w] = acc_compat[CW * s + w];
+      }
+      if (tid == 0) {
+         a.n_bins[l] = (RETRY && overflow) ? -1 : nb;
+         a.n_used[l] = n_hits_in;
+         if (RETRY && overflow) bad &= ~(int)kBinsTableFull;
+         if (bad) atomicOr(a.flags, bad);
+      }
+      __syncthreads();
+   }
+}
+
+// hit -> rank of its bin inside the locus (-1: in no bin), from the bins' member hits: the table is rebuilt from the
+// nb keys, then every hit looks its key up.  Key words: at most two.
+template <int kBinsSlots, int kThreads>
+__global__ __launch_bounds__(kThreads) void bins_assign_kernel(BinsArgs a)
+{
+   __shared__ unsigned long long keyw[kBinsSlots];
+   __shared__ int rank_of[kBinsSlots];
+   const int tid = threadIdx.x;
+   const int cw = a.compat_words, kw = a.key_words;
+   auto key_of = [&](int64_t h) -> unsigned long long {
+      return kw == 2 ? (((unsigned long long)a.key[h * 2 + 1] << 32) | a.key[h * 2]) : (unsigned long long)a.key[h];
+   };
+   for (int64_t li = blockIdx.x; li < a.n_loci; li += gridDim.x) {
+      const int64_t l = a.loci[li];
+      const int64_t q0 = a.locus_hit_off[l], q1 = a.locus_hit_off[l + 1];
+      const int nb = a.n_bins[l];
+      if (nb <= 0) {
+         for (int64_t h = q0 + tid; h < q1; h += kThreads) a.hit_bin_local[h] = -1;
+         continue;
+      }
+      int slots = 64;
+      while (slots < kBinsSlots && slots < 4 * nb) slots <<= 1;
+      for (int s = tid; s < slots; s += kThreads) keyw[s] = 0ull;
+      __syncthreads();
+      for (int b = tid; b < nb; b += kThreads) {
+         const int slot = bins_slot(keyw, slots, key_of(q0 + a.bin_rep[q0 + b]), true);
+         if (slot >= 0) rank_of[slot] = b;
+      }
+      __syncthreads();
+      for (int64_t h = q0 + tid; h < q1; h += kThreads) {
+         uint32_t any_c = 0;
+         for (int w = 0; w < cw; ++w) any_c |= a.compat[h * cw + w];
+         const unsigned long long key = key_of(h);
+         int b = -1;
+         if (any_c && key) {
+            const int slot = bins_slot(keyw, slots, key, false);
+            if (slot >= 0) b = rank_of[slot];
+         }
+         a.hit_bin_local[h] = b;
       }
       __syncthreads();
    }

@@ -109,6 +109,8 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
    const size_t o_compat = total; total += up256(nh1 * 4 * (size_t)cw);
    const size_t o_key = total; total += up256(nh1 * 4 * (size_t)kw);
    const size_t o_hbin = total; total += up256(nh1 * 8);
+   const size_t o_span = total; total += up256(nh1 * 8);
+   const size_t o_fhash = total; total += up256(nh1 * 4);
    DeviceBuf in;
    hipError_t e = sb::ctx_scratch(c, 0, total, &in.p);
    if (e != hipSuccess) return api_fail(e == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e));
@@ -161,10 +163,15 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
    }
    uint32_t *d_compat = (uint32_t *)(in.p + o_compat), *d_key = (uint32_t *)(in.p + o_key);
    int64_t *d_hit_bin = (int64_t *)(in.p + o_hbin);
+   uint64_t *d_span = (uint64_t *)(in.p + o_span);
+   uint32_t *d_fhash = (uint32_t *)(in.p + o_fhash);
 
    stage("upload");
+   sb::ctx_stage_reset(c);
    // ---- A5: the interval tests
-   if (nh) SB_RC(sbgpu_exonbin_device(c, &dan, &dh, cw, kw, d_compat, d_key, s));
+   sb::ctx_stage_begin(c, "exonbin_kernel", s);
+   if (nh) SB_RC(sb::exonbin_device_impl(c, &dan, &dh, cw, kw, d_compat, d_key, d_span, d_fhash, s));
+   sb::ctx_stage_end(c, s);
    stage("exonbin kernel");
    std::vector<uint32_t> compat_h, key_h;
    auto need_compat = [&]() -> int {
@@ -218,7 +225,9 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
    int rc = SBGPU_EUNSUPPORTED;
    if (grouped && nh) {
       if (iso_worker.t.joinable()) iso_worker.t.join();
-      rc = sb::bins_create_device_impl(c, an, &dh, d_mass, locus_hit_off.data(), cw, kw, d_compat, d_key, d_hit_bin, s, &iso_pre, &bins);
+      // (hits given on the device: the caller did not ask for hit -> bin, so it is not made)
+      rc = sb::bins_create_device_impl(c, an, &dh, d_mass, locus_hit_off.data(), cw, kw, d_compat, d_key, on_dev ? nullptr : d_hit_bin, s,
+                                       &iso_pre, &bins, d_span, d_fhash);
    }
    const bool on_device = rc == SBGPU_OK;
    if (rc == SBGPU_EUNSUPPORTED && on_dev)
@@ -316,16 +325,20 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
       }
       SB_TRY(hipMemcpyAsync(w.p + q_pdf, pdf.data(), (size_t)pdf_len * 8, hipMemcpyHostToDevice, s));
       const int32_t lmin_base = ins.use_emp ? ins.start_offset : ins.read_len;
+      sb::ctx_stage_begin(c, "binweight_kernel", s);
       SB_RC(sbgpu_binweight_device(c, n_pairs, d_off, d_seg, d_msk, d_len, d_idx, (const double *)(w.p + q_pdf), pdf_len,
                                    ins.read_len, lmin_base, ins.long_read, (double *)(w.p + q_F), s));
+      sb::ctx_stage_end(c, s);
    }
    stage("bin weights");
    // ---- A1/A2: the EM
    if (n_bins) SB_TRY(hipMemcpyAsync(w.p + q_cnt, count.data(), (size_t)n_bins * 4, hipMemcpyHostToDevice, s));
    sbgpu_plan_t *plan = nullptr;
    SB_RC(sbgpu_plan_create(c, nl, row_off.data(), iso_off.data(), f_off.data(), &plan));
+   sb::ctx_stage_begin(c, "em kernels", s);
    rc = sbgpu_em_run_device(c, plan, (const int32_t *)(w.p + q_cnt), (const double *)(w.p + q_F), (double *)(w.p + q_theta),
                             (int32_t *)(w.p + q_st), (int32_t *)(w.p + q_it), s);
+   sb::ctx_stage_end(c, s);
    if (rc != SBGPU_OK) {
       sbgpu_plan_destroy(plan);
       return rc;

@@ -75,6 +75,10 @@ int sbgpu_collapse_pairs_device(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_pair
       *out = U;
       return SBGPU_OK;
    }
+   // a locus the LDS sort does not hold is known from the host offsets: decline before anything is allocated or launched
+   for (int64_t l = 0; l < n_loci; ++l)
+      if (locus_pair_off[l + 1] - locus_pair_off[l] > sb::kCollapseMax)
+         return bail(SBGPU_EUNSUPPORTED, "sbgpu_collapse_pairs_device: not covered by the device form: a locus has more than 4096 read pairs; use sbgpu_collapse_pairs_host");
    SB_TRY(hipSetDevice(U->device));
    const size_t np1 = (size_t)np, nl1 = (size_t)n_loci + 1;
    size_t off = 0;

@@ -17,11 +17,10 @@
 
 using sb::api_fail;
 
-extern "C" {
-
-int sbgpu_exonbin_device(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgpu_hits_t *hits,
-                         int32_t compat_words, int32_t key_words, uint32_t *d_compat, uint32_t *d_key,
-                         void *stream)
+namespace sb {
+// sbgpu_exonbin_device that also leaves every hit's span and sequence hash (exonbin_device.h) when asked to
+int exonbin_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgpu_hits_t *hits, int32_t compat_words,
+                        int32_t key_words, uint32_t *d_compat, uint32_t *d_key, uint64_t *d_span, uint32_t *d_fhash, void *stream)
 {
    if (!c || !an || !hits) return api_fail(SBGPU_EINVAL, "sbgpu_exonbin_device: null argument");
    if (hits->n_hits == 0) return SBGPU_OK;
@@ -48,6 +47,8 @@ int sbgpu_exonbin_device(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
    a.key_words = key_words;
    a.compat = d_compat;
    a.key = d_key;
+   a.span = d_span;
+   a.fhash = d_span ? d_fhash : nullptr;
    const int64_t blocks_wanted = (hits->n_hits + 255) / 256;
    if (blocks_wanted > 0x7fffffff) return api_fail(SBGPU_ESHAPE, "sbgpu_exonbin_device: more than 2^39 hits in one call");
    static const bool lane_form = std::getenv("SBGPU_EXONBIN_LANE") && std::atoi(std::getenv("SBGPU_EXONBIN_LANE")) != 0;
@@ -55,12 +56,25 @@ int sbgpu_exonbin_device(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
       const int64_t cap = (int64_t)sb::ctx_cu_count(c) * 32;
       hipLaunchKernelGGL(sb::exonbin_lane_kernel, dim3((unsigned)(blocks_wanted < cap ? blocks_wanted : cap)), dim3(256), 0,
                          (hipStream_t)stream, a);
+      if (d_span)
+         hipLaunchKernelGGL(sb::hit_signature_kernel, dim3((unsigned)(blocks_wanted < cap ? blocks_wanted : cap)), dim3(256), 0,
+                            (hipStream_t)stream, a.n_hits, a.feat_off, a.feat_left, a.feat_right, d_span, d_fhash);
    } else {
       hipLaunchKernelGGL(sb::exonbin_kernel, dim3((unsigned)blocks_wanted), dim3(256), 0, (hipStream_t)stream, a);
    }
    hipError_t e = hipGetLastError();
    if (e != hipSuccess) return api_fail(SBGPU_EHIP, std::string("exonbin_kernel: ") + hipGetErrorString(e));
    return SBGPU_OK;
+}
+} // namespace sb
+
+extern "C" {
+
+int sbgpu_exonbin_device(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgpu_hits_t *hits,
+                         int32_t compat_words, int32_t key_words, uint32_t *d_compat, uint32_t *d_key,
+                         void *stream)
+{
+   return sb::exonbin_device_impl(c, an, hits, compat_words, key_words, d_compat, d_key, nullptr, nullptr, stream);
 }
 
 int sbgpu_exonbin_host(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgpu_hits_t *hits,
@@ -229,7 +243,8 @@ void iso_segments(const sbgpu_annotation_t *an, IsoSegments *out)
 
 int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgpu_hits_t *dh, const float *d_mass,
                             const int64_t *locus_hit_off, int32_t compat_words, int32_t key_words, const uint32_t *d_compat,
-                            const uint32_t *d_key, int64_t *d_hit_bin, void *stream, const IsoSegments *iso_pre, sbgpu_bins_t **out)
+                            const uint32_t *d_key, int64_t *d_hit_bin, void *stream, const IsoSegments *iso_pre, sbgpu_bins_t **out,
+                            const uint64_t *d_span, const uint32_t *d_fhash)
 {
    if (!c || !an || !dh || !locus_hit_off || !out) return api_fail(SBGPU_EINVAL, "sbgpu_bins_create_device: null argument");
    *out = nullptr;
@@ -273,6 +288,8 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
    const size_t o_roff = off; off += up((size_t)(nl + 1) * 8);
    const size_t o_order = off; off += up((size_t)nl * 4);
    const size_t o_dup = off; off += up(nh1);
+   const size_t o_span = off; off += d_span ? 0 : up(nh1 * 8);   // spans and hashes: the exon-bin kernel's, or made here
+   const size_t o_fhash = off; off += d_span ? 0 : up(nh1 * 4);
    // the scratch arenas live with the context (sb::ctx_scratch): nothing to free here
    char *d = nullptr, *d2 = nullptr;
    hipError_t e = sb::ctx_scratch(c, 2, off, &d);
@@ -297,6 +314,14 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
    a.key_words = key_words;
    a.compat = d_compat;
    a.key = d_key;
+   if (!d_span && nh) {
+      const int64_t blocks = (nh + 255) / 256, capb = (int64_t)sb::ctx_cu_count(c) * 32;
+      hipLaunchKernelGGL(sb::hit_signature_kernel, dim3((unsigned)(blocks < capb ? blocks : capb)), dim3(256), 0, s, nh,
+                         dh->feat_off, dh->feat_left, dh->feat_right, (uint64_t *)(d + o_span), (uint32_t *)(d + o_fhash));
+      SB_TRY(hipGetLastError());
+   }
+   a.span = d_span ? d_span : (const uint64_t *)(d + o_span);
+   a.fhash = d_span ? d_fhash : (const uint32_t *)(d + o_fhash);
    a.hit_bin_local = (int32_t *)(d + o_local);
    a.bin_rep = (int32_t *)(d + o_rep);
    a.bin_count = (int32_t *)(d + o_cnt);
@@ -314,22 +339,40 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
    int64_t n_big = 0;
    for (int64_t l = 0; l < nl; ++l)
       if (locus_hit_off[l + 1] - locus_hit_off[l] > sb::kBinsSmallHits) order[(size_t)(n_small + n_big++)] = (int32_t)l;
+   // the very big ones first, largest to smallest: a locus is one workgroup's work, and a locus of 10^5 hits that starts
+   // last would be the kernel's tail (only those few are sorted: a full sort of 55 000 loci costs 2.6 ms of host time)
+   {
+      const int64_t heavy = std::max<int64_t>(4096, 4 * (nh / std::max<int64_t>(nl, 1)));
+      auto hits_of = [&](int32_t l) { return locus_hit_off[l + 1] - locus_hit_off[l]; };
+      auto first_big = order.begin() + n_small, last_big = first_big + n_big;
+      auto mid = std::stable_partition(first_big, last_big, [&](int32_t l) { return hits_of(l) >= heavy; });
+      std::sort(first_big, mid, [&](int32_t x, int32_t y) { return hits_of(x) != hits_of(y) ? hits_of(x) > hits_of(y) : x < y; });
+   }
    SB_TRY(hipMemcpyAsync(d + o_order, order.data(), (size_t)nl * 4, hipMemcpyHostToDevice, s));
+   // the single-pass kernels (bins_device.h) where a bin's compat union fits two words; SBGPU_BINS_TWO_PASS=1: the older form (A/B)
+   static const bool two_pass_env = std::getenv("SBGPU_BINS_TWO_PASS") && std::atoi(std::getenv("SBGPU_BINS_TWO_PASS")) != 0;
+   const bool single_pass = compat_words <= 2 && key_words <= 2 && !two_pass_env;
+   sb::ctx_stage_begin(c, single_pass ? "bins_accum_kernel" : "bins_locus_kernel", s);
    if (n_small) {
       a.n_loci = n_small;
       a.loci = (const int32_t *)(d + o_order);
-      hipLaunchKernelGGL((sb::bins_locus_kernel<sb::kBinsSlotsSmall, sb::kBinsMaxSmall, sb::kBinsThreads>), dim3((unsigned)std::min<int64_t>(n_small, cap * 4)),
-                         dim3(sb::kBinsThreads), 0, s, a);
+      const dim3 grid((unsigned)std::min<int64_t>(n_small, cap * 4));
+      if (single_pass && compat_words == 1) hipLaunchKernelGGL((sb::bins_accum_kernel<sb::kBinsSlotsSmall, sb::kBinsMaxSmall, sb::kBinsThreads, 1>), grid, dim3(sb::kBinsThreads), 0, s, a);
+      else if (single_pass) hipLaunchKernelGGL((sb::bins_accum_kernel<sb::kBinsSlotsSmall, sb::kBinsMaxSmall, sb::kBinsThreads, 2>), grid, dim3(sb::kBinsThreads), 0, s, a);
+      else hipLaunchKernelGGL((sb::bins_locus_kernel<sb::kBinsSlotsSmall, sb::kBinsMaxSmall, sb::kBinsThreads>), grid, dim3(sb::kBinsThreads), 0, s, a);
       SB_TRY(hipGetLastError());
    }
    if (n_big) {
-      // first the middle table (four workgroups per CU); whatever has more bins than it holds is redone below
+      // first the middle table; whatever has more bins than it holds is redone below
       a.n_loci = n_big;
       a.loci = (const int32_t *)(d + o_order) + n_small;
-      hipLaunchKernelGGL((sb::bins_locus_kernel<sb::kBinsSlotsMid, sb::kBinsMaxMid, sb::kBinsThreadsMid, true>),
-                         dim3((unsigned)std::min<int64_t>(n_big, cap * 4)), dim3(sb::kBinsThreadsMid), 0, s, a);
+      const dim3 grid((unsigned)std::min<int64_t>(n_big, cap * 4));
+      if (single_pass && compat_words == 1) hipLaunchKernelGGL((sb::bins_accum_kernel<sb::kBinsSlotsMid, sb::kBinsMaxMid, sb::kBinsThreadsAccum, 1, true>), grid, dim3(sb::kBinsThreadsAccum), 0, s, a);
+      else if (single_pass) hipLaunchKernelGGL((sb::bins_accum_kernel<sb::kBinsSlotsMid, sb::kBinsMaxMid, sb::kBinsThreadsAccum, 2, true>), grid, dim3(sb::kBinsThreadsAccum), 0, s, a);
+      else hipLaunchKernelGGL((sb::bins_locus_kernel<sb::kBinsSlotsMid, sb::kBinsMaxMid, sb::kBinsThreadsMid, true>), grid, dim3(sb::kBinsThreadsMid), 0, s, a);
    }
    SB_TRY(hipGetLastError());
+   sb::ctx_stage_end(c, s);
    std::vector<int32_t> nb((size_t)nl), nu((size_t)nl);
    int32_t flags = 0;
    SB_TRY(hipMemcpyAsync(nb.data(), d + o_nb, (size_t)nl * 4, hipMemcpyDeviceToHost, s));
@@ -352,6 +395,22 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
          SB_TRY(hipMemcpyAsync(nu.data(), d + o_nu, (size_t)nl * 4, hipMemcpyDeviceToHost, s));
          SB_TRY(hipMemcpyAsync(&flags, d + o_flag, 4, hipMemcpyDeviceToHost, s));
          SB_TRY(hipStreamSynchronize(s));
+      }
+   }
+   // hit -> bin: the single-pass kernels leave it out; it is made where somebody reads it (the caller's hit_bin, the
+   // ordered masses below).  Loci the big table served have theirs already.
+   if (single_pass && (d_hit_bin || flags == sb::kBinsFractional) && nh) {
+      std::vector<int32_t> todo;
+      for (int64_t l = 0; l < nl; ++l)
+         if (nb[(size_t)l] <= sb::kBinsMaxMid) todo.push_back((int32_t)l);
+      if (!todo.empty()) {
+         SB_TRY(hipMemcpyAsync(d + o_order, todo.data(), todo.size() * 4, hipMemcpyHostToDevice, s));
+         a.n_loci = (int64_t)todo.size();
+         a.loci = (const int32_t *)(d + o_order);
+         hipLaunchKernelGGL((sb::bins_assign_kernel<sb::kBinsSlotsMid, sb::kBinsThreadsMid>),
+                            dim3((unsigned)std::min<int64_t>((int64_t)todo.size(), cap * 4)), dim3(sb::kBinsThreadsMid), 0, s, a);
+         SB_TRY(hipGetLastError());
+         SB_TRY(hipStreamSynchronize(s)); // (`todo` leaves scope)
       }
    }
    if (flags == sb::kBinsFractional) {
@@ -408,7 +467,9 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
    pk.bin_compat = (uint32_t *)(d2 + p_cmp);
    pk.hit_bin = d_hit_bin;
    pk.flags = a.flags;
+   sb::ctx_stage_begin(c, "bins_pack_kernel", s);
    hipLaunchKernelGGL(sb::bins_pack_kernel, dim3((unsigned)(nl < cap ? nl : cap)), dim3(256), 0, s, pk);
+   sb::ctx_stage_end(c, s);
    SB_TRY(hipGetLastError());
    std::vector<int32_t> count(nb1);
    std::vector<uint32_t> key(nb1 * (size_t)key_words), compat(nb1 * (size_t)compat_words);
@@ -500,7 +561,9 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
    pa.pair_out_index = nullptr;
    pa.flags = a.flags;
    const unsigned pgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_iso + 255) / 256, cap * 4));
+   sb::ctx_stage_begin(c, "bins_pairs_kernel<count>", s);
    hipLaunchKernelGGL(sb::bins_pairs_kernel<false>, dim3(pgrid), dim3(256), 0, s, pa);
+   sb::ctx_stage_end(c, s);
    SB_TRY3(hipGetLastError());
    std::vector<int32_t> pcnt(ni1), scnt(ni1);
    if (n_iso) {
@@ -537,7 +600,9 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
    pa.pair_mask = (uint32_t *)(dp.arena + dp.o_mask);
    pa.pair_iso_len = (int32_t *)(dp.arena + dp.o_iso_len);
    pa.pair_out_index = (int64_t *)(dp.arena + dp.o_out_index);
+   sb::ctx_stage_begin(c, "bins_pairs_kernel<fill>", s);
    hipLaunchKernelGGL(sb::bins_pairs_kernel<true>, dim3(pgrid), dim3(256), 0, s, pa);
+   sb::ctx_stage_end(c, s);
    SB_TRY3(hipGetLastError());
    SB_TRY3(hipStreamSynchronize(s));
 #undef SB_TRY3
@@ -557,7 +622,7 @@ int sbgpu_bins_create_device(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const
                              const uint32_t *d_key, int64_t *d_hit_bin, void *stream, sbgpu_bins_t **out)
 {
    return sb::bins_create_device_impl(c, an, dh, d_mass, locus_hit_off, compat_words, key_words, d_compat, d_key, d_hit_bin, stream,
-                                      nullptr, out);
+                                      nullptr, out, nullptr, nullptr);
 }
 
 } // extern "C"

@@ -36,7 +36,22 @@ struct ExonBinArgs {
    const uint32_t *feat_left, *feat_right;
    int32_t compat_words, key_words;
    uint32_t *compat, *key;
+   // optional (null: not written): what the grouping (bins_device.h) wants to know about a hit without touching its
+   // features again -- span = first left end << 32 | last right end (HitCluster's sort key, src/read.cpp:917-923),
+   // fhash = a hash of the (left, right) sequence: equal fragments (std::set<Contig>, isoform.h:133,267) have equal
+   // spans and hashes, and only those candidates are compared feature by feature
+   uint64_t *span;
+   uint32_t *fhash;
 };
+
+__device__ __forceinline__ uint64_t hit_sig_step(uint64_t h, uint32_t l, uint32_t r)
+{
+   h = (h ^ l) * 0x9E3779B97F4A7C15ull;
+   h = (h ^ r) * 0xC2B2AE3D27D4EB4Full;
+   return h ^ (h >> 31);
+}
+constexpr uint64_t kHitSigSeed = 0x243F6A8885A308D3ull;
+__device__ __forceinline__ uint32_t hit_sig_fold(uint64_t h) { return (uint32_t)(h ^ (h >> 32)); }
 
 constexpr int kExonBinRegFeats = 8; // features a hit may have and still be held in registers
 
@@ -319,6 +334,25 @@ __global__ __launch_bounds__(256) void exonbin_kernel(ExonBinArgs a)
       h.r[i] = in ? a.feat_right[f0 + i] : 0u;
       regular = regular & (!in | ((h.c[i] == 0) == ((i & 1) == 0)));
    }
+   if (a.span && active) {
+      uint64_t sig = kHitSigSeed;
+      uint64_t sp = 0;
+      if (is_long) {
+         for (int i = 0; i < nf; ++i) sig = hit_sig_step(sig, a.feat_left[f0 + i], a.feat_right[f0 + i]);
+         sp = ((uint64_t)a.feat_left[f0] << 32) | a.feat_right[f0 + nf - 1];
+      } else if (nf > 0) {
+         uint32_t last_r = 0;
+#pragma unroll
+         for (int i = 0; i < kExonBinRegFeats; ++i)
+            if (i < nf) {
+               sig = hit_sig_step(sig, h.l[i], h.r[i]);
+               last_r = h.r[i];
+            }
+         sp = ((uint64_t)h.l[0] << 32) | last_r;
+      }
+      a.span[hidx] = sp; // 0: a hit without features (it carries no position)
+      a.fhash[hidx] = hit_sig_fold(sig);
+   }
    BlockHit bh;
    bh.nb = regular ? (h.nf + 1) / 2 : 0;
 #pragma unroll
@@ -347,6 +381,20 @@ __global__ __launch_bounds__(256) void exonbin_kernel(ExonBinArgs a)
       exonbin_hit(a, hidx, m);
    } else if (active && (todo || !(regular || nf == 0))) {
       exonbin_hit(a, hidx, h);
+   }
+}
+
+// spans and hashes alone (a caller that made the words elsewhere: sbgpu_bins_create_device)
+__global__ __launch_bounds__(256) void hit_signature_kernel(int64_t n_hits, const int64_t *feat_off, const uint32_t *feat_left,
+                                                            const uint32_t *feat_right, uint64_t *span, uint32_t *fhash)
+{
+   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+   for (int64_t h = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; h < n_hits; h += stride) {
+      const int64_t f0 = feat_off[h], f1 = feat_off[h + 1];
+      uint64_t sig = kHitSigSeed;
+      for (int64_t i = f0; i < f1; ++i) sig = hit_sig_step(sig, feat_left[i], feat_right[i]);
+      span[h] = f1 > f0 ? (((uint64_t)feat_left[f0] << 32) | feat_right[f1 - 1]) : 0ull;
+      fhash[h] = hit_sig_fold(sig);
    }
 }
 

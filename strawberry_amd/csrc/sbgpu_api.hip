@@ -69,6 +69,12 @@ struct sbgpu_ctx {
    size_t scratch_bytes[8] = {};
    int32_t *d_pdf_support = nullptr; // [2] device: support of the insert-size table of the bin-weight launch in flight
    int32_t *wide_error = nullptr; // pinned host word the wide-locus kernel raises when a barrier times out
+   // kernel stages of the chain entry points, bracketed by events while `timing` is on (sb::ctx_stage_begin / _end)
+   static constexpr int kMaxStages = 16;
+   hipEvent_t stage_ev[kMaxStages][2] = {};
+   const char *stage_name[kMaxStages] = {};
+   int n_stages = 0;
+   bool stage_open = false;
 };
 
 namespace sb {
@@ -76,6 +82,24 @@ int api_fail(int code, const std::string &msg) { return fail(code, msg); }
 hipStream_t ctx_stream(const sbgpu_ctx_t *ctx) { return ctx->stream; }
 int ctx_cu_count(const sbgpu_ctx_t *ctx) { return ctx->n_cu; }
 int ctx_device(const sbgpu_ctx_t *ctx) { return ctx->device; }
+void ctx_stage_reset(sbgpu_ctx_t *ctx) { ctx->n_stages = 0, ctx->stage_open = false; }
+void ctx_stage_begin(sbgpu_ctx_t *ctx, const char *name, hipStream_t s)
+{
+   if (!ctx->timing || ctx->stage_open || ctx->n_stages >= sbgpu_ctx::kMaxStages) return;
+   hipEvent_t *ev = ctx->stage_ev[ctx->n_stages];
+   for (int i = 0; i < 2; ++i)
+      if (!ev[i] && hipEventCreate(&ev[i]) != hipSuccess) return;
+   if (hipEventRecord(ev[0], s) != hipSuccess) return;
+   ctx->stage_name[ctx->n_stages] = name;
+   ctx->stage_open = true;
+}
+void ctx_stage_end(sbgpu_ctx_t *ctx, hipStream_t s)
+{
+   if (!ctx->stage_open) return;
+   (void)hipEventRecord(ctx->stage_ev[ctx->n_stages][1], s);
+   ctx->stage_open = false;
+   ++ctx->n_stages;
+}
 hipError_t ctx_scratch(sbgpu_ctx_t *ctx, int slot, size_t bytes, char **out)
 {
    *out = nullptr;
@@ -393,6 +417,9 @@ int sbgpu_finalize(sbgpu_ctx_t *c)
       if (c->tp[i]) (void)hipEventDestroy(c->tp[i]);
    if (c->stream) (void)hipStreamDestroy(c->stream);
    if (c->wide_error) (void)hipHostFree(c->wide_error);
+   for (auto &ev : c->stage_ev)
+      for (hipEvent_t e : ev)
+         if (e) (void)hipEventDestroy(e);
    if (c->d_pdf_support) (void)hipFree(c->d_pdf_support);
    for (int i = 0; i < 8; ++i)
       if (c->scratch[i]) (void)hipFree(c->scratch[i]);
@@ -912,6 +939,21 @@ int sbgpu_em_run_device_f32(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t
                             float *d_theta, int32_t *d_status, int32_t *d_iters, void *stream)
 {
    return em_run_impl(c, p, d_count, d_F, d_theta, d_status, d_iters, stream, true);
+}
+
+int sbgpu_last_stage_ms(sbgpu_ctx_t *c, int cap, float *ms, const char **names)
+{
+   if (!c || cap < 0 || (cap > 0 && (!ms || !names))) return fail(SBGPU_EINVAL, "sbgpu_last_stage_ms: bad argument");
+   int n = 0;
+   for (int i = 0; i < c->n_stages && n < cap; ++i) {
+      float t = 0.0f;
+      if (hipEventSynchronize(c->stage_ev[i][1]) != hipSuccess || hipEventElapsedTime(&t, c->stage_ev[i][0], c->stage_ev[i][1]) != hipSuccess)
+         return fail(SBGPU_EHIP, "sbgpu_last_stage_ms: the stage events were not recorded");
+      ms[n] = t;
+      names[n] = c->stage_name[i];
+      ++n;
+   }
+   return n;
 }
 
 int sbgpu_set_timing(sbgpu_ctx_t *c, int on)

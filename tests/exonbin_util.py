@@ -112,3 +112,43 @@ def tile(annot, hits, copies, stride=None):
         np.concatenate([h.hit_locus + k * a.n_loci for k in range(copies)]), rep(h.feat_off, int(h.feat_off[-1])),
         np.tile(h.feat_code, copies), shift(h.feat_left), shift(h.feat_right), np.tile(h.mass, copies))
     return big, bh
+
+
+def check_collapse_against_oracle(oracle, n_loci, loc, nh, left, right, hits, cmass, info):
+    """Unique hits of a collapse (Hits, cluster masses, info dict) against oracle/collapse_oracle.c, cluster by cluster:
+    order, features (Contig(PairedHit) of the representative pair: the reference's own where oracle/_ref is built, else
+    sbgpu_hit_features, which the goldens pin), float masses, cluster masses, filtered / rejected counts, the mapped-read
+    total.  `nh`: the pairs' NH tags (pair mass 1 / NH)."""
+    from oracle import RefLib, have_ref
+    ref = RefLib() if have_ref() else None
+
+    def features(lb, rb):
+        if ref is not None and hasattr(ref.L, "ref_pairedhit_features"):
+            return ref.pairedhit_features(lb, rb)
+        return eb.hit_features(lb, rb)
+    at = filtered = rejected = total = 0
+    by_locus = [[] for _ in range(n_loci)]
+    for i, l in enumerate(loc):
+        by_locus[l].append(i)
+    for l in range(n_loci):
+        idx = by_locus[l]
+        if not idx:
+            assert cmass[l] == 0.0
+            continue
+        up, um, cm, nf = oracle.collapse_cluster([left[i] for i in idx], [right[i] for i in idx], [nh[i] for i in idx])
+        filtered += nf
+        assert abs(cmass[l] - cm) <= 1e-12 * max(1.0, cm), (l, cmass[l], cm)
+        total += int(cmass[l])
+        for a, m in zip(up, um):
+            f = features(left[idx[a]], right[idx[a]])
+            if not f:
+                rejected += 1
+                continue
+            assert hits.hit_locus[at] == l
+            s = slice(int(hits.feat_off[at]), int(hits.feat_off[at + 1]))
+            got = ([int(x) for x in hits.feat_code[s]], [int(x) for x in hits.feat_left[s]], [int(x) for x in hits.feat_right[s]])
+            assert got == ([int(x) for x in f[0]], [int(x) for x in f[1]], [int(x) for x in f[2]]), (l, at)
+            assert hits.mass[at] == np.float32(m), (l, at, hits.mass[at], m)
+            at += 1
+    assert at == hits.n_hits
+    assert info["filtered"] == filtered and info["rejected"] == rejected and info["total_mapped"] == total

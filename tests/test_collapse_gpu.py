@@ -1,7 +1,8 @@
 """GPU tests of sbgpu_collapse_pairs_device (HitCluster::collapseAndFilterHits + Contig(PairedHit) on the GPU,
-/root/reference/src/alignments.cpp:656-703, src/contig.cpp:216-267) against sbgpu_collapse_pairs_host, which is
-itself pinned to the reference binary's runs (tests/test_exonbin_oracle.py): unique hits, features, float masses,
-cluster masses and the int-truncated mapped-read total must be identical."""
+/root/reference/src/alignments.cpp:656-703, src/contig.cpp:216-267) against the ORACLE (oracle/collapse_oracle.c, pinned
+to the reference's own HitCluster by tests/test_collapse_oracle.py; features by the reference's Contig(PairedHit) where
+oracle/_ref is built) and against sbgpu_collapse_pairs_host: unique hits, features, float masses, cluster masses and
+the int-truncated mapped-read total must be identical."""
 import numpy as np
 import pytest
 
@@ -64,7 +65,7 @@ def test_device_collapse_filter_equality_and_rejects(ctx):
     assert g[2]["rejected"] == 1 and g[0].n_hits == 3
 
 
-def test_device_collapse_random_stress(ctx):
+def test_device_collapse_random_stress(ctx, oracle):
     """Random clusters: many duplicates, fractional masses (sums whose float / int truncation depends on the order),
     equal (left, right) ends with different blocks, single reads, spliced mates, up to 4000 pairs in a locus."""
     from strawberry_amd import exonbin as eb
@@ -92,14 +93,17 @@ def test_device_collapse_random_stress(ctx):
                     rs = lb[-1][1] + 1 + ins - rl if ins > rl else lb[0][0] + ins
                     rb = [(rs, rs + rl - 1)]
                 loc.append(l)
-                mass.append(float(rng.choice([1.0, 0.5, 1.0 / 3.0, 0.25])))
+                mass.append(int(rng.choice([1, 2, 3, 4])))     # the pair's NH tag: mass 1 / NH
                 left.append(lb)
                 right.append(rb)
         perm = rng.permutation(len(loc))
-        args = (n_loci, [loc[i] for i in perm], [mass[i] for i in perm], [left[i] for i in perm], [right[i] for i in perm])
+        nh = [mass[i] for i in perm]
+        args = (n_loci, [loc[i] for i in perm], [1.0 / k for k in nh], [left[i] for i in perm], [right[i] for i in perm])
         g, r = eb.collapse_pairs(*args, device=ctx), eb.collapse_pairs(*args)
         same(g[0], r[0], g[1], r[1], g[2], r[2])
         assert r[0].n_hits < len(loc) * 0.9      # the stress does collapse
+        # ... and against the independent checker, cluster by cluster
+        XU.check_collapse_against_oracle(oracle, n_loci, args[1], nh, args[3], args[4], g[0], g[1], g[2])
 
 
 def test_device_collapse_declines_what_it_does_not_cover(ctx):

@@ -448,33 +448,36 @@ def test_chain_from_fragments_reproduces_reference_run(ctx, oracle, which):
     assert "".join(gtf_text) == ref_gtf[2]
 
 
-def test_quantify_device_equals_quantify_host_on_tiled_sample():
-    """sbgpu_quantify_device (hits resident in HBM, laid out by torch on the device: strawberry_amd/chain.py) gives
-    the same theta, status and iteration counts as sbgpu_quantify_host on the same hits built on the host."""
-    import torch
-    from strawberry_amd import chain, em, exonbin as eb, synth
+def test_quantify_device_equals_quantify_host_on_the_chain_sample(oracle):
+    """The chain workload's sample (strawberry_amd/chain.py: distinct gene models, read pairs drawn on the device) is a
+    well-formed input -- sorted by (locus, left end, right end), every hit M (x M)* with one GAP -- and
+    sbgpu_quantify_device on the hits in HBM gives the same theta, status and iteration counts as sbgpu_quantify_host on
+    the same hits brought to the host; the words of every hit equal the oracle's."""
+    from strawberry_amd import chain, em
     from strawberry_amd.quantify import InsertSize, quantify_host
-    import exonbin_util as XU
     ctx = em.default_context(0)
-    q = chain.ChainQuantifier(ctx, n_loci=300, n_frags=300 * 150, base_loci=30, seed=5)
+    q = chain.ChainQuantifier(ctx, n_loci=400, n_frags=400 * 300, seed=5)
     q.step()
-    # the same sample on the host: the 30 gene models and their pairs tiled with the tests' own helper
-    loci = synth.make_gene_models(30, seed=5)
-    hl, pairs = synth.make_fragments(loci, 150, seed=6, single=0.0)
-    feats, loc = [], []
-    for l, (lb, rb) in zip(hl, pairs):
-        f = eb.hit_features(lb, rb)
-        if f is not None:
-            feats.append(f)
-            loc.append(l)
-    a0, h0 = eb.Annotation(loci), eb.Hits(loc, feats)
-    stride = int(max(a0.exon_right.max(), h0.feat_right.max()) + 100000)
-    annot, hits = XU.tile(a0, h0, 10, stride=stride)
-    assert hits.n_hits == q.n_frags and annot.n_loci == q.n_loci
-    np.testing.assert_array_equal(q.hits.feat_left.cpu().numpy().view(np.uint32), hits.feat_left)
-    np.testing.assert_array_equal(q.hits.feat_off.cpu().numpy(), hits.feat_off)
-    np.testing.assert_array_equal(q.hits.hit_locus.cpu().numpy(), hits.hit_locus)
-    r = quantify_host(annot, hits, InsertSize(250.0, 30.0), 75, ctx=ctx)
+    hits = q.hits.host_hits(q.n_loci)
+    assert hits.n_hits == q.n_hits > 50000 and q.n_frags == int(hits.mass.sum()) >= q.n_hits
+    assert (hits.mass >= 1).all() and (hits.mass > 1).any()          # equal fragments were merged into unique hits
+    # the order HitCluster::collapseAndFilterHits leaves: (locus, left end, right end)
+    first, last = hits.feat_left[hits.feat_off[:-1]].astype(np.int64), hits.feat_right[hits.feat_off[1:] - 1].astype(np.int64)
+    key = (hits.hit_locus.astype(np.int64) << 40) * 0 + first * (1 << 31) + last
+    assert (np.diff(hits.hit_locus) >= 0).all() and (np.diff(key) >= 0).all()
+    assert (hits.feat_code[hits.feat_off[:-1]] == 0).all() and (hits.feat_code[hits.feat_off[1:] - 1] == 0).all()
+    assert (np.bincount(np.repeat(np.arange(hits.n_hits), np.diff(hits.feat_off)), weights=(hits.feat_code == 2)) == 1).all()
+    r = quantify_host(q.annot, hits, InsertSize(250.0, 30.0), 75, ctx=ctx)
     np.testing.assert_array_equal(q.status[:q.n_loci], r["status"])
     np.testing.assert_array_equal(q.iters[:q.n_loci], r["iters"])
     np.testing.assert_array_equal(q.theta[:q.n_iso], r["theta"])
+    oc, _ = oracle.exonbin_batch(q.annot, hits)
+    np.testing.assert_array_equal(r["compat"], oc)
+    # pairs that fit no isoform exist (shifted / unspliced mates), and most pairs fit one
+    frac = float((oc != 0).any(axis=1).mean())
+    assert 0.85 < frac < 0.999
+    # a rank's share of the same sample (strong scaling): its loci are exactly its residue class, same gene models
+    q2 = chain.ChainQuantifier(ctx, n_loci=400, n_frags=400 * 300, seed=5, loci_subset=(1, 2))
+    assert q2.n_loci == 200
+    np.testing.assert_array_equal(q2.annot.exon_left[:int(q2.annot.exon_off[int(q2.annot.iso_off[1])])],
+                                  q.annot.exon_left[int(q.annot.exon_off[int(q.annot.iso_off[1])]):int(q.annot.exon_off[int(q.annot.iso_off[2])])])
