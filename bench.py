@@ -83,6 +83,12 @@ def pmc_traffic(workload, kind):
         return None, "no PMC summary committed for this workload"
     try:
         d = json.load(open(files[-1]))
+        from strawberry_amd import _lib
+        mine = _lib.load().sbgpu_build_id().decode()
+        theirs = d.get("_build_id")
+        if theirs != mine:
+            return None, "%s was taken with library build %s, this is build %s: not quoted (re-run tools/profile_round.sh)" % (
+                os.path.basename(files[-1]), theirs, mine)
         c = next(v for k, v in d.items() if key in k)
         fetch_kb, write_kb = c["FETCH_SIZE"]["mean_per_dispatch"], c["WRITE_SIZE"]["mean_per_dispatch"]
     except (StopIteration, KeyError, ValueError):
@@ -447,6 +453,13 @@ def main():
     # ---- weak scaling: every rank holds its OWN full-size batch
     batch = make_batch(args.workload, rank)
     solver, quant = make_quant(batch)
+    c5_bias = None
+    if args.workload == "c5":
+        # the bias factors: per bin from its sequence's GC ratio (bin-sequence kernel, on the device), per isoform a model
+        # constant; applied by the EM kernels at tile load (sbgpu_em_run_device_bias) for both precisions
+        from strawberry_amd import bias as sbias
+        rb, ib, c5_bias = sbias.make_c5_bias(ctx, batch, seed=0xB1A5 + rank)
+        solver.set_bias(rb, ib)
     wall, gpu_ms = timed_steps(quant, args.steps, args.warmup, dev, sdist, torch)
     counts = torch.tensor([batch.n_loci, batch.n_frags], dtype=torch.int64, device=dev)
     sdist.allreduce_sum_(counts)
@@ -492,13 +505,22 @@ def main():
         ok = np.isin(res64["status"], (0, 3)) & np.isin(res32["status"], (0, 3))
         m = ok[np.repeat(np.arange(batch.n_loci), batch.niso)]
         tpm_rel = np.abs(res32["tpm"] - res64["tpm"])[m] / np.maximum(res64["tpm"][m], 1e-3)
-        c5 = {"f32": {"value": n_loci_all * args.steps / wall32, "ms_per_step": wall32 / args.steps * 1e3},
+        c5 = {"bias": c5_bias,
+              "f32": {"value": n_loci_all * args.steps / wall32, "ms_per_step": wall32 / args.steps * 1e3},
               "f64": {"value": weak["value"], "ms_per_step": weak["ms_per_step"]},
               "tolerance": {"isoforms_within_1e-4_relative_tpm": float((tpm_rel < 1e-4).mean()),
                             "tpm_rel_err_p99": float(np.percentile(tpm_rel, 99)), "tpm_rel_err_max": float(tpm_rel.max()),
                             "loci_status_changed": int((res64["status"] != res32["status"]).sum()),
                             "loci_iteration_count_changed": int((res64["iters"] != res32["iters"]).sum()),
-                            "histogram": "profiles/r02_c5_sweep.json (tools/c5_sweep.py)"}}
+                            "histogram": "profiles/r03_c5_sweep.json (tools/c5_sweep.py)"}}
+        # the fp32 kernels' own times (HIP events per kind), for their roofline with s = 4
+        probe32 = []
+        solver.set_timing(True)
+        for _ in range(5):
+            q32.step()
+            probe32.append(solver.last_kernel_ms())
+        solver.set_timing(False)
+        c5["f32"]["kernel_ms_by_kind"] = [float(x) for x in np.mean(np.array(probe32), axis=0)]
         quant.step()   # leave the fp64 result in place for the roofline / parity legs below
 
     # ---- the chain leg of the default line: fragments -> abundances on 2e8 read pairs in HBM (every rank takes part:
@@ -567,9 +589,31 @@ def main():
         # the headline of this workload is the fp32 variant; the fp64 numbers of the same run sit beside it
         out.update({"value": c5["f32"]["value"], "ms_per_step": c5["f32"]["ms_per_step"], "dtype": "f32",
                     "mfrags_per_s": n_frags_all / (c5["f32"]["ms_per_step"] * 1e-3) / 1e6, "c5": c5})
-        out["roofline"]["note"] += "; roofline figures are the fp64 path's (kernel_ms, algorithmic bytes with s = 8)"
+        # the headline's own roofline: the fp32 instantiation of the dominant kind, algorithmic bytes with s = 4
+        # (weights and theta in fp32, counts int32, + the two factor arrays the tile load reads)
+        k32 = np.array(c5["f32"]["kernel_ms_by_kind"])
+        dom32 = int(np.argmax(k32))
+        sel32 = kinds == dom32
+        b32 = nrow * niso * 4 + nrow * 4 + niso * 4 + 24 + nrow * 4 + niso * 4
+        ach32 = float(b32[sel32].sum()) / (k32[dom32] * 1e-3) / 1e9
+        out["roofline_f64"] = out["roofline"]
+        out["roofline"] = {"bound": "hbm", "kernel": kind_names[dom32].replace(">", ", float>", 1) + " with the bias factors applied at tile load",
+                           "achieved": ach32, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach32 / HBM_PEAK_GBS, "traffic": None,
+                           "kernel_ms": float(k32[dom32]), "kernel_loci": int(sel32.sum()), "algorithmic_bytes": int(b32[sel32].sum()),
+                           "note": "fp32 kernel, HIP-event time on its own stream; the loop runs on-chip (see roofline_f64.fp64_valu for the fp64 twin)"}
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"], out["parity"] = cpu_baseline(batch, res)
+        cpu_batch = batch
+        if c5 is not None:   # the CPU solves the same biased problem: the factors multiplied into a host copy of F
+            from strawberry_amd import bias as sbias
+            from strawberry_amd.synth import LocusBatch
+            cpu_batch = LocusBatch(batch.row_off, batch.iso_off, batch.f_off, batch.count,
+                                   sbias.biased_weights(batch, solver.d_row_bias.cpu().numpy(), solver.d_iso_bias.cpu().numpy()),
+                                   batch.length, "C5 biased")
+        out["cpu_baseline"], out["parity"] = cpu_baseline(cpu_batch, res)
+        if c5 is not None:
+            # not a parity path: exp2 on the device against numpy's may move a weight's last bit, and with it, rarely, a count
+            out["parity"]["note"] = "fp64 run with the factors applied on the device vs the reference EmSolver on host-multiplied weights; informational"
+            out["parity"]["ok"] = bool(out["parity"]["status_mismatches"] <= 5 and out["parity"]["theta_max_rel_err"] < 1e-6)
         if not out["parity"]["ok"]:
             print(json.dumps(out))
             raise SystemExit("bench.py: the GPU result of the timed batch does not match the CPU %s: %r" % (

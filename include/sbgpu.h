@@ -104,6 +104,9 @@ typedef struct {
 /* ---- library / context ------------------------------------------------------ */
 const char *sbgpu_version(void);
 const char *sbgpu_last_error(void);
+/* 16 hex digits: a hash of every source file the library was built from (csrc/Makefile).  Profiles name the build
+ * they were taken with; a reader (bench.py) does not quote them for another build.                              */
+const char *sbgpu_build_id(void);
 int sbgpu_device_count(void);
 
 /* Bind to HIP device `device`; creates the context's streams and workspace.     */
@@ -155,6 +158,20 @@ int sbgpu_em_run_device_f32(sbgpu_ctx_t *ctx, const sbgpu_plan_t *plan,
                             const int32_t *d_count, const float *d_F,
                             float *d_theta, int32_t *d_status, int32_t *d_iters,
                             void *stream);
+
+/* BASELINE config 5, "bias kernel fused into the E-step": the weight of (bin i, isoform j) is
+ * F_ij * 2^(row_bias[i] * iso_bias[j]); the factor is applied to the operand while the register tile is loaded (once
+ * per solve), the iterations then run on the biased tile.  d_row_bias[total rows], d_iso_bias[total isoforms], both in
+ * [-1, 1] (b_ij in [0.5, 2]); how they are derived is the caller's model -- the reference has no bias arithmetic
+ * (src/bias.cpp is comments), so this is NOT a parity path; bench.py --workload c5 derives row_bias from the bins'
+ * GC ratio as sbgpu_binseq_device measures it.  Same result as sbgpu_em_run_device on the pre-multiplied weights up
+ * to exp2's rounding.  Tile kernels only (loci of up to 64 isoforms; plans without phases), else SBGPU_EUNSUPPORTED. */
+int sbgpu_em_run_device_bias(sbgpu_ctx_t *ctx, const sbgpu_plan_t *plan, const int32_t *d_count, const double *d_F,
+                             const double *d_row_bias, const double *d_iso_bias, double *d_theta, int32_t *d_status,
+                             int32_t *d_iters, void *stream);
+int sbgpu_em_run_device_bias_f32(sbgpu_ctx_t *ctx, const sbgpu_plan_t *plan, const int32_t *d_count, const float *d_F,
+                                 const float *d_row_bias, const float *d_iso_bias, float *d_theta, int32_t *d_status,
+                                 int32_t *d_iters, void *stream);
 
 /* Timing events around the EM kernels are off by default (they cost a few microseconds
  * per call); sbgpu_set_timing(ctx, 1) turns them on for the calls that follow.       */

@@ -19,9 +19,9 @@ STATUS_NAMES = {0: "OK", 1: "INIT_EMPTY", 2: "DENOM_ZERO", 3: "MAXITER"}
 
 # every symbol include/sbgpu.h declares (tests check the .so exports all of them)
 SYMBOLS = [
-    "sbgpu_version", "sbgpu_last_error", "sbgpu_device_count", "sbgpu_init", "sbgpu_finalize",
+    "sbgpu_version", "sbgpu_build_id", "sbgpu_last_error", "sbgpu_device_count", "sbgpu_init", "sbgpu_finalize",
     "sbgpu_device_info", "sbgpu_synchronize", "sbgpu_plan_create", "sbgpu_plan_destroy", "sbgpu_plan_info",
-    "sbgpu_plan_classes", "sbgpu_plan_locus_kinds", "sbgpu_em_run_device", "sbgpu_em_run_device_f32", "sbgpu_em_last_kernel_ms",
+    "sbgpu_plan_classes", "sbgpu_plan_locus_kinds", "sbgpu_em_run_device", "sbgpu_em_run_device_f32", "sbgpu_em_run_device_bias", "sbgpu_em_run_device_bias_f32", "sbgpu_em_last_kernel_ms",
     "sbgpu_set_timing", "sbgpu_em_last_phase_ms", "sbgpu_last_stage_ms",
     "sbgpu_comm_unique_id", "sbgpu_comm_init", "sbgpu_comm_info", "sbgpu_comm_destroy",
     "sbgpu_allreduce_sum_f64", "sbgpu_allreduce_sum_i64", "sbgpu_allreduce_sum_f64_host", "sbgpu_allreduce_sum_i64_host",
@@ -134,6 +134,7 @@ def load():
     vp, i64p = C.c_void_p, C.POINTER(C.c_int64)
     L.sbgpu_version.restype = C.c_char_p
     L.sbgpu_last_error.restype = C.c_char_p
+    L.sbgpu_build_id.restype = C.c_char_p
     L.sbgpu_device_count.restype = C.c_int
     L.sbgpu_init.argtypes = [C.c_int, C.POINTER(vp)]
     L.sbgpu_finalize.argtypes = [vp]
@@ -158,6 +159,8 @@ def load():
     L.sbgpu_em_last_phase_ms.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
     L.sbgpu_em_run_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.sbgpu_em_run_device_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.sbgpu_em_run_device_bias.argtypes = [vp] * 10
+    L.sbgpu_em_run_device_bias_f32.argtypes = [vp] * 10
     L.sbgpu_em_batch.argtypes = [vp, C.POINTER(sbgpu_batch_t), vp, vp, vp]
     L.sbgpu_abundance_device.argtypes = [vp, vp, vp, vp, vp, C.POINTER(sbgpu_abundance_params_t), vp, vp, vp, vp, vp]
     L.sbgpu_tpm_device.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp]

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -29,11 +30,20 @@ struct IsoSegments {
    std::vector<int32_t> seg_idx, locus, len; // segment indices within the locus; the isoform's locus; its exonic length
 };
 void iso_segments(const sbgpu_annotation_t *annot, IsoSegments *out);
+// What the device grouping knows once its last kernel (the pairs' fill) is in the stream: enough to launch the bin
+// weights and the EM behind it, BEFORE the host-side handle is built (which then runs beside those kernels).
+struct DeviceGrouping {
+   const int64_t *row_off, *f_off; // host, [n_loci + 1]
+   int64_t n_bins, n_elem;
+   const int32_t *d_count;         // device, [n_bins]: the bins' fragment counts
+   const DevicePairs *pairs;       // device arrays of the (bin, isoform) pairs
+};
 // sbgpu_bins_create_device with the segment lists made beforehand (nullptr: made inside)
 int bins_create_device_impl(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *annot, const sbgpu_hits_t *d_hits, const float *d_mass,
                             const int64_t *locus_hit_off, int32_t compat_words, int32_t key_words, const uint32_t *d_compat,
                             const uint32_t *d_key, int64_t *d_hit_bin, void *stream, const IsoSegments *iso_pre, sbgpu_bins_t **out,
-                            const uint64_t *d_span, const uint32_t *d_fhash); // spans / hashes of the hits (exonbin_device_impl), or null
+                            const uint64_t *d_span, const uint32_t *d_fhash, // spans / hashes of the hits (exonbin_device_impl), or null
+                            const std::function<int(const DeviceGrouping &)> *after_pairs = nullptr); // called once the pairs' fill is launched
 int exonbin_device_impl(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *annot, const sbgpu_hits_t *hits, int32_t compat_words,
                         int32_t key_words, uint32_t *d_compat, uint32_t *d_key, uint64_t *d_span, uint32_t *d_fhash, void *stream);
 int api_fail(int code, const std::string &msg); // records sbgpu_last_error(), returns code

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <system_error>
 #include <thread>
@@ -220,14 +221,120 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
       ins.long_read = long_read;
    }
    stage("insert size");
+   // ---- everything behind the bins: weights straight into the EM batch's F (A4), plan + EM (A1/A2), the downloads.
+   // With the device grouping it is launched from inside bins_create_device_impl -- as soon as the pairs' fill kernel is
+   // in the stream, before the host-side handle is built -- so that the handle's bookkeeping runs beside these kernels.
+   sbgpu_plan_t *plan = nullptr;
+   struct PlanGuard {
+      sbgpu_plan_t *&p;
+      ~PlanGuard() { if (p) sbgpu_plan_destroy(p); }
+   } plan_guard = {plan};
+   DeviceBuf w;
+   std::vector<double> pdf;
+   std::vector<double> F;
+   hipError_t e1 = hipSuccess, e2 = hipSuccess, e3 = hipSuccess, e4 = hipSuccess;
+   int64_t n_bins = 0, n_elem = 0, n_pairs = 0, n_psegs = 0;
+   size_t q_F = 0;
+   // host pair arrays (host grouping only)
+   std::vector<int64_t> row_off_h, iso_off_h, f_off_h, pair_seg_off, pair_out;
+   std::vector<int32_t> count_h, pair_len;
+   std::vector<uint32_t> pair_segs, pair_mask;
+   auto launch_rest = [&](const int64_t *row_off, const int64_t *f_off, const sb::DevicePairs *dpairs, const int32_t *d_count,
+                          const int32_t *h_count) -> int {
+      int64_t max_l = 1;
+      if (!long_read) {
+         if (dpairs) {
+            if (dpairs->any_wide) return api_fail(SBGPU_ESHAPE, "sbgpu_quantify_host: a bin spans more than 32 isoform segments");
+            // no pair spans more than its locus' segments together
+            for (int64_t l = 0; l < nl; ++l) {
+               int64_t tot = 0;
+               for (int64_t k = an->seg_off[l]; k < an->seg_off[l + 1]; ++k) tot += (int64_t)an->seg_right[k] - an->seg_left[k] + 1;
+               max_l = std::max(max_l, tot);
+            }
+         } else {
+            for (int64_t p = 0; p < n_pairs; ++p) {
+               int64_t l = 0;
+               for (int64_t k = pair_seg_off[(size_t)p]; k < pair_seg_off[(size_t)p + 1]; ++k) l += pair_segs[(size_t)k];
+               if (pair_seg_off[(size_t)p + 1] == pair_seg_off[(size_t)p])
+                  return api_fail(SBGPU_ESHAPE, "sbgpu_quantify_host: a bin spans more than 32 isoform segments");
+               max_l = std::max(max_l, l);
+            }
+         }
+      }
+      if (max_l > (1 << 26)) return api_fail(SBGPU_ESHAPE, "sbgpu_quantify_host: segment lengths out of range");
+      const int32_t pdf_len = (int32_t)max_l + 1;
+      pdf.assign((size_t)pdf_len, 0.0);
+      SB_RC(sbgpu_insert_pdf_table(&ins, pdf_len, pdf.data()));
+      const size_t np1 = (size_t)std::max<int64_t>(dpairs ? 1 : n_pairs, 1), ne1 = (size_t)std::max<int64_t>(n_elem, 1),
+                   nb1 = (size_t)std::max<int64_t>(n_bins, 1), ns1 = (size_t)(dpairs ? 1 : n_psegs + 1);
+      size_t t2 = 0;
+      const size_t q_off = t2; t2 += up256((np1 + 1) * 8);
+      const size_t q_idx = t2; t2 += up256(np1 * 8);
+      const size_t q_seg = t2; t2 += up256(ns1 * 4);
+      const size_t q_mask = t2; t2 += up256(np1 * 4);
+      const size_t q_len = t2; t2 += up256(np1 * 4);
+      const size_t q_pdf = t2; t2 += up256((size_t)pdf_len * 8);
+      const size_t q_cnt = t2; t2 += up256(nb1 * 4);
+      q_F = t2; t2 += up256(ne1 * 8);
+      const size_t q_theta = t2; t2 += up256((size_t)(n_iso + 1) * 8);
+      const size_t q_st = t2; t2 += up256((size_t)(nl + 1) * 4);
+      const size_t q_it = t2; t2 += up256((size_t)(nl + 1) * 4);
+      hipError_t ew = sb::ctx_scratch(c, 1, t2, &w.p);
+      if (ew != hipSuccess) return api_fail(ew == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("hipMalloc: ") + hipGetErrorString(ew));
+      SB_TRY(hipMemsetAsync(w.p + q_F, 0, ne1 * 8, s));
+      if (n_pairs) {
+         const int64_t *d_off = dpairs ? dpairs->seg_off() : (const int64_t *)(w.p + q_off);
+         const uint32_t *d_seg = dpairs ? dpairs->seg_lens() : (const uint32_t *)(w.p + q_seg);
+         const uint32_t *d_msk = dpairs ? dpairs->mask() : (const uint32_t *)(w.p + q_mask);
+         const int32_t *d_len = dpairs ? dpairs->iso_len() : (const int32_t *)(w.p + q_len);
+         const int64_t *d_idx = dpairs ? dpairs->out_index() : (const int64_t *)(w.p + q_idx);
+         if (!dpairs) {
+            SB_TRY(hipMemcpyAsync(w.p + q_off, pair_seg_off.data(), (size_t)(n_pairs + 1) * 8, hipMemcpyHostToDevice, s));
+            SB_TRY(hipMemcpyAsync(w.p + q_idx, pair_out.data(), (size_t)n_pairs * 8, hipMemcpyHostToDevice, s));
+            if (n_psegs) SB_TRY(hipMemcpyAsync(w.p + q_seg, pair_segs.data(), (size_t)n_psegs * 4, hipMemcpyHostToDevice, s));
+            SB_TRY(hipMemcpyAsync(w.p + q_mask, pair_mask.data(), (size_t)n_pairs * 4, hipMemcpyHostToDevice, s));
+            SB_TRY(hipMemcpyAsync(w.p + q_len, pair_len.data(), (size_t)n_pairs * 4, hipMemcpyHostToDevice, s));
+         }
+         SB_TRY(hipMemcpyAsync(w.p + q_pdf, pdf.data(), (size_t)pdf_len * 8, hipMemcpyHostToDevice, s));
+         const int32_t lmin_base = ins.use_emp ? ins.start_offset : ins.read_len;
+         sb::ctx_stage_begin(c, "binweight_kernel", s);
+         SB_RC(sbgpu_binweight_device(c, n_pairs, d_off, d_seg, d_msk, d_len, d_idx, (const double *)(w.p + q_pdf), pdf_len,
+                                      ins.read_len, lmin_base, ins.long_read, (double *)(w.p + q_F), s));
+         sb::ctx_stage_end(c, s);
+      }
+      stage("bin weights");
+      // ---- A1/A2: the EM (the counts are on the device already when the grouping ran there)
+      if (!d_count) {
+         if (n_bins) SB_TRY(hipMemcpyAsync(w.p + q_cnt, h_count, (size_t)n_bins * 4, hipMemcpyHostToDevice, s));
+         d_count = (const int32_t *)(w.p + q_cnt);
+      }
+      SB_RC(sbgpu_plan_create(c, nl, row_off, an->iso_off, f_off, &plan));
+      sb::ctx_stage_begin(c, "em kernels", s);
+      const int rce = sbgpu_em_run_device(c, plan, d_count, (const double *)(w.p + q_F), (double *)(w.p + q_theta),
+                                          (int32_t *)(w.p + q_st), (int32_t *)(w.p + q_it), s);
+      sb::ctx_stage_end(c, s);
+      if (rce != SBGPU_OK) return rce;
+      F.assign(on_dev ? (size_t)0 : (size_t)n_elem, 0.0); // (device entry: the weights are not brought back)
+      e1 = hipMemcpyAsync(theta_out, w.p + q_theta, (size_t)n_iso * 8, hipMemcpyDeviceToHost, s);
+      e2 = hipMemcpyAsync(status_out, w.p + q_st, (size_t)nl * 4, hipMemcpyDeviceToHost, s);
+      e3 = hipMemcpyAsync(iters_out, w.p + q_it, (size_t)nl * 4, hipMemcpyDeviceToHost, s);
+      e4 = (n_elem && !on_dev) ? hipMemcpyAsync(F.data(), w.p + q_F, (size_t)n_elem * 8, hipMemcpyDeviceToHost, s) : hipSuccess;
+      return SBGPU_OK;
+   };
    // ---- A5: bins (device; host when the device form declines)
    sbgpu_bins_t *bins = nullptr;
    int rc = SBGPU_EUNSUPPORTED;
+   bool rest_launched = false;
    if (grouped && nh) {
       if (iso_worker.t.joinable()) iso_worker.t.join();
+      const std::function<int(const sb::DeviceGrouping &)> after = [&](const sb::DeviceGrouping &g) -> int {
+         n_bins = g.n_bins, n_elem = g.n_elem, n_pairs = g.pairs->n_pairs, n_psegs = g.pairs->n_pair_segs;
+         rest_launched = true;
+         return launch_rest(g.row_off, g.f_off, g.pairs, g.d_count, nullptr);
+      };
       // (hits given on the device: the caller did not ask for hit -> bin, so it is not made)
       rc = sb::bins_create_device_impl(c, an, &dh, d_mass, locus_hit_off.data(), cw, kw, d_compat, d_key, on_dev ? nullptr : d_hit_bin, s,
-                                       &iso_pre, &bins, d_span, d_fhash);
+                                       &iso_pre, &bins, d_span, d_fhash, &after);
    }
    const bool on_device = rc == SBGPU_OK;
    if (rc == SBGPU_EUNSUPPORTED && on_dev)
@@ -248,114 +355,33 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
       ~BinsGuard() { sbgpu_bins_destroy(b); }
    } guard = {bins};
    stage("bins + pairs");
-   int64_t info[8];
-   SB_RC(sbgpu_bins_info(bins, info));
-   const int64_t n_bins = info[2], n_elem = info[3], n_pairs = info[4], n_psegs = info[5];
-   const sb::DevicePairs *dpairs = sb::bins_device_pairs(bins); // made on the device: used where they are
-   std::vector<int64_t> row_off((size_t)nl + 1), iso_off((size_t)nl + 1), f_off((size_t)nl + 1), pair_seg_off, pair_out;
-   std::vector<int32_t> count((size_t)n_bins + 1), pair_len;
-   std::vector<uint32_t> pair_segs, pair_mask;
-   if (!dpairs) {
-      pair_seg_off.resize((size_t)n_pairs + 1);
-      pair_out.resize((size_t)n_pairs + 1);
-      pair_len.resize((size_t)n_pairs + 1);
-      pair_segs.resize((size_t)n_psegs + 1);
-      pair_mask.resize((size_t)n_pairs + 1);
-   }
-   SB_RC(sbgpu_bins_export(bins, row_off.data(), iso_off.data(), f_off.data(), count.data(), nullptr, nullptr, nullptr, nullptr,
-                           dpairs ? nullptr : pair_seg_off.data(), dpairs ? nullptr : pair_segs.data(),
-                           dpairs ? nullptr : pair_mask.data(), dpairs ? nullptr : pair_len.data(),
-                           dpairs ? nullptr : pair_out.data()));
-   stage("export");
-   // ---- A4: weights straight into the EM batch's F
-   int64_t max_l = 1;
-   if (!long_read) {
-      if (dpairs) {
-         if (dpairs->any_wide) return api_fail(SBGPU_ESHAPE, "sbgpu_quantify_host: a bin spans more than 32 isoform segments");
-         // no pair spans more than its locus' segments together
-         for (int64_t l = 0; l < nl; ++l) {
-            int64_t tot = 0;
-            for (int64_t k = an->seg_off[l]; k < an->seg_off[l + 1]; ++k) tot += (int64_t)an->seg_right[k] - an->seg_left[k] + 1;
-            max_l = std::max(max_l, tot);
-         }
-      } else {
-         for (int64_t p = 0; p < n_pairs; ++p) {
-            int64_t l = 0;
-            for (int64_t k = pair_seg_off[(size_t)p]; k < pair_seg_off[(size_t)p + 1]; ++k) l += pair_segs[(size_t)k];
-            if (pair_seg_off[(size_t)p + 1] == pair_seg_off[(size_t)p])
-               return api_fail(SBGPU_ESHAPE, "sbgpu_quantify_host: a bin spans more than 32 isoform segments");
-            max_l = std::max(max_l, l);
-         }
-      }
-   }
-   if (max_l > (1 << 26)) return api_fail(SBGPU_ESHAPE, "sbgpu_quantify_host: segment lengths out of range");
-   const int32_t pdf_len = (int32_t)max_l + 1;
-   std::vector<double> pdf((size_t)pdf_len);
-   SB_RC(sbgpu_insert_pdf_table(&ins, pdf_len, pdf.data()));
-   const size_t np1 = (size_t)std::max<int64_t>(dpairs ? 1 : n_pairs, 1), ne1 = (size_t)std::max<int64_t>(n_elem, 1),
-                nb1 = (size_t)std::max<int64_t>(n_bins, 1), ns1 = (size_t)(dpairs ? 1 : n_psegs + 1);
-   size_t t2 = 0;
-   const size_t q_off = t2; t2 += up256((np1 + 1) * 8);
-   const size_t q_idx = t2; t2 += up256(np1 * 8);
-   const size_t q_seg = t2; t2 += up256(ns1 * 4);
-   const size_t q_mask = t2; t2 += up256(np1 * 4);
-   const size_t q_len = t2; t2 += up256(np1 * 4);
-   const size_t q_pdf = t2; t2 += up256((size_t)pdf_len * 8);
-   const size_t q_cnt = t2; t2 += up256(nb1 * 4);
-   const size_t q_F = t2; t2 += up256(ne1 * 8);
-   const size_t q_theta = t2; t2 += up256((size_t)(n_iso + 1) * 8);
-   const size_t q_st = t2; t2 += up256((size_t)(nl + 1) * 4);
-   const size_t q_it = t2; t2 += up256((size_t)(nl + 1) * 4);
-   DeviceBuf w;
-   e = sb::ctx_scratch(c, 1, t2, &w.p);
-   if (e != hipSuccess) return api_fail(e == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e));
-   SB_TRY(hipMemsetAsync(w.p + q_F, 0, ne1 * 8, s));
-   if (n_pairs) {
-      const int64_t *d_off = dpairs ? dpairs->seg_off() : (const int64_t *)(w.p + q_off);
-      const uint32_t *d_seg = dpairs ? dpairs->seg_lens() : (const uint32_t *)(w.p + q_seg);
-      const uint32_t *d_msk = dpairs ? dpairs->mask() : (const uint32_t *)(w.p + q_mask);
-      const int32_t *d_len = dpairs ? dpairs->iso_len() : (const int32_t *)(w.p + q_len);
-      const int64_t *d_idx = dpairs ? dpairs->out_index() : (const int64_t *)(w.p + q_idx);
+   if (!rest_launched) { // host grouping (or no hits at all): the pairs come from the handle
+      int64_t info[8];
+      SB_RC(sbgpu_bins_info(bins, info));
+      n_bins = info[2], n_elem = info[3], n_pairs = info[4], n_psegs = info[5];
+      const sb::DevicePairs *dpairs = sb::bins_device_pairs(bins);
+      row_off_h.resize((size_t)nl + 1), iso_off_h.resize((size_t)nl + 1), f_off_h.resize((size_t)nl + 1), count_h.resize((size_t)n_bins + 1);
       if (!dpairs) {
-         SB_TRY(hipMemcpyAsync(w.p + q_off, pair_seg_off.data(), (size_t)(n_pairs + 1) * 8, hipMemcpyHostToDevice, s));
-         SB_TRY(hipMemcpyAsync(w.p + q_idx, pair_out.data(), (size_t)n_pairs * 8, hipMemcpyHostToDevice, s));
-         if (n_psegs) SB_TRY(hipMemcpyAsync(w.p + q_seg, pair_segs.data(), (size_t)n_psegs * 4, hipMemcpyHostToDevice, s));
-         SB_TRY(hipMemcpyAsync(w.p + q_mask, pair_mask.data(), (size_t)n_pairs * 4, hipMemcpyHostToDevice, s));
-         SB_TRY(hipMemcpyAsync(w.p + q_len, pair_len.data(), (size_t)n_pairs * 4, hipMemcpyHostToDevice, s));
+         pair_seg_off.resize((size_t)n_pairs + 1);
+         pair_out.resize((size_t)n_pairs + 1);
+         pair_len.resize((size_t)n_pairs + 1);
+         pair_segs.resize((size_t)n_psegs + 1);
+         pair_mask.resize((size_t)n_pairs + 1);
       }
-      SB_TRY(hipMemcpyAsync(w.p + q_pdf, pdf.data(), (size_t)pdf_len * 8, hipMemcpyHostToDevice, s));
-      const int32_t lmin_base = ins.use_emp ? ins.start_offset : ins.read_len;
-      sb::ctx_stage_begin(c, "binweight_kernel", s);
-      SB_RC(sbgpu_binweight_device(c, n_pairs, d_off, d_seg, d_msk, d_len, d_idx, (const double *)(w.p + q_pdf), pdf_len,
-                                   ins.read_len, lmin_base, ins.long_read, (double *)(w.p + q_F), s));
-      sb::ctx_stage_end(c, s);
+      SB_RC(sbgpu_bins_export(bins, row_off_h.data(), iso_off_h.data(), f_off_h.data(), count_h.data(), nullptr, nullptr, nullptr, nullptr,
+                              dpairs ? nullptr : pair_seg_off.data(), dpairs ? nullptr : pair_segs.data(),
+                              dpairs ? nullptr : pair_mask.data(), dpairs ? nullptr : pair_len.data(),
+                              dpairs ? nullptr : pair_out.data()));
+      stage("export");
+      SB_RC(launch_rest(row_off_h.data(), f_off_h.data(), dpairs, nullptr, count_h.data()));
    }
-   stage("bin weights");
-   // ---- A1/A2: the EM
-   if (n_bins) SB_TRY(hipMemcpyAsync(w.p + q_cnt, count.data(), (size_t)n_bins * 4, hipMemcpyHostToDevice, s));
-   sbgpu_plan_t *plan = nullptr;
-   SB_RC(sbgpu_plan_create(c, nl, row_off.data(), iso_off.data(), f_off.data(), &plan));
-   sb::ctx_stage_begin(c, "em kernels", s);
-   rc = sbgpu_em_run_device(c, plan, (const int32_t *)(w.p + q_cnt), (const double *)(w.p + q_F), (double *)(w.p + q_theta),
-                            (int32_t *)(w.p + q_st), (int32_t *)(w.p + q_it), s);
-   sb::ctx_stage_end(c, s);
-   if (rc != SBGPU_OK) {
-      sbgpu_plan_destroy(plan);
-      return rc;
-   }
-   std::vector<double> F(on_dev ? (size_t)0 : (size_t)n_elem); // (device entry: the weights are not brought back)
    std::vector<int64_t> hit_bin;
-   hipError_t e1 = hipMemcpyAsync(theta_out, w.p + q_theta, (size_t)n_iso * 8, hipMemcpyDeviceToHost, s);
-   hipError_t e2 = hipMemcpyAsync(status_out, w.p + q_st, (size_t)nl * 4, hipMemcpyDeviceToHost, s);
-   hipError_t e3 = hipMemcpyAsync(iters_out, w.p + q_it, (size_t)nl * 4, hipMemcpyDeviceToHost, s);
-   hipError_t e4 = (n_elem && !on_dev) ? hipMemcpyAsync(F.data(), w.p + q_F, (size_t)n_elem * 8, hipMemcpyDeviceToHost, s) : hipSuccess;
    hipError_t e5 = hipSuccess;
    if (on_device && nh && !on_dev) { // (device hits: the caller did not ask for 8 bytes per hit over PCIe)
       hit_bin.resize((size_t)nh);
       e5 = hipMemcpyAsync(hit_bin.data(), d_hit_bin, (size_t)nh * 8, hipMemcpyDeviceToHost, s);
    }
    hipError_t e6 = hipStreamSynchronize(s);
-   sbgpu_plan_destroy(plan);
    stage("plan + EM + download");
    for (hipError_t x : {e1, e2, e3, e4, e5, e6})
       if (x != hipSuccess) return api_fail(SBGPU_EHIP, std::string("sbgpu_quantify_host: download: ") + hipGetErrorString(x));

@@ -46,6 +46,11 @@ struct EmArgsT {
    T *theta;
    int32_t *status;
    int32_t *iters;
+   // BASELINE config 5 ("bias kernel fused into the E-step"): null, or a factor per bin and per isoform -- the tile
+   // kernels then take F_ij * 2^(row_bias[i] * iso_bias[j]) as the weight, applied to the operand as the tile is
+   // loaded (once per solve; the iterations run on the biased tile).  Both in [-1, 1]: b_ij in [0.5, 2].
+   const T *row_bias = nullptr; // [total rows]
+   const T *iso_bias = nullptr; // [total isoforms]
 };
 typedef EmArgsT<double> EmArgs;
 
@@ -226,6 +231,8 @@ __device__ __forceinline__ float fast_div(float n, float d)
    const float q = n * r;
    return __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
 }
+__device__ __forceinline__ double bias_factor(double x) { return exp2(x); }
+__device__ __forceinline__ float bias_factor(float x) { return exp2f(x); }
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 // squared convergence threshold: largest value whose correctly rounded square root is below 1e-2
@@ -708,9 +715,19 @@ __device__ __forceinline__ void em_tile_body(const EmArgsT<T> &a, const ClassArg
                T x = T(0);
                if (nrow > 0) x = Fg[(int64_t)ic * ni + jc];
                x = (valid && j < ni) ? x : T(0);
-               mx = fmax(mx, x);
                v[jj] = x;
             }
+            if (a.row_bias && nrow > 0) { // (launch-uniform) config 5: the biased weight is the operand from here on
+               const T rb = a.row_bias[r0 + ic];
+#pragma unroll
+               for (int jj = 0; jj < CPL; ++jj) {
+                  const int j = gc * CPL + jj;
+                  const int jc = (j < ni) ? j : ni - 1;
+                  v[jj] *= bias_factor(rb * a.iso_bias[ib + jc]);
+               }
+            }
+#pragma unroll
+            for (int jj = 0; jj < CPL; ++jj) mx = fmax(mx, v[jj]);
             // any weight of the row > 1e-5 (:380), over all column lanes
             if constexpr (HIMAP) {
                if (CL >= 2) mx = fmax(mx, xor_get<1>(mx));

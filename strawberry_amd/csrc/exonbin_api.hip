@@ -244,7 +244,7 @@ void iso_segments(const sbgpu_annotation_t *an, IsoSegments *out)
 int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgpu_hits_t *dh, const float *d_mass,
                             const int64_t *locus_hit_off, int32_t compat_words, int32_t key_words, const uint32_t *d_compat,
                             const uint32_t *d_key, int64_t *d_hit_bin, void *stream, const IsoSegments *iso_pre, sbgpu_bins_t **out,
-                            const uint64_t *d_span, const uint32_t *d_fhash)
+                            const uint64_t *d_span, const uint32_t *d_fhash, const std::function<int(const DeviceGrouping &)> *after_pairs)
 {
    if (!c || !an || !dh || !locus_hit_off || !out) return api_fail(SBGPU_EINVAL, "sbgpu_bins_create_device: null argument");
    *out = nullptr;
@@ -473,12 +473,7 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
    SB_TRY(hipGetLastError());
    std::vector<int32_t> count(nb1);
    std::vector<uint32_t> key(nb1 * (size_t)key_words), compat(nb1 * (size_t)compat_words);
-   if (n_bins) {
-      SB_TRY(hipMemcpyAsync(count.data(), d2 + p_cnt, (size_t)n_bins * 4, hipMemcpyDeviceToHost, s));
-      SB_TRY(hipMemcpyAsync(key.data(), d2 + p_key, (size_t)n_bins * 4 * key_words, hipMemcpyDeviceToHost, s));
-      SB_TRY(hipMemcpyAsync(compat.data(), d2 + p_cmp, (size_t)n_bins * 4 * compat_words, hipMemcpyDeviceToHost, s));
-   }
-   stage("pack + D2H");
+   stage("pack");
    // ---- the (bin, isoform) pairs, on the device too (bins_pairs_kernel): the isoforms' segment lists
    // (Isoform::_exon_segs, include/isoform.h:59-71) come from the host annotation
    const int64_t n_iso = an->iso_off[nl];
@@ -604,10 +599,27 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
    hipLaunchKernelGGL(sb::bins_pairs_kernel<true>, dim3(pgrid), dim3(256), 0, s, pa);
    sb::ctx_stage_end(c, s);
    SB_TRY3(hipGetLastError());
+   // the per-bin arrays for the host-side handle (17 MB for 1.4 M bins): behind the fill kernel in the stream
+   if (n_bins) {
+      SB_TRY3(hipMemcpyAsync(count.data(), d2 + p_cnt, (size_t)n_bins * 4, hipMemcpyDeviceToHost, s));
+      SB_TRY3(hipMemcpyAsync(key.data(), d2 + p_key, (size_t)n_bins * 4 * key_words, hipMemcpyDeviceToHost, s));
+      SB_TRY3(hipMemcpyAsync(compat.data(), d2 + p_cmp, (size_t)n_bins * 4 * compat_words, hipMemcpyDeviceToHost, s));
+   }
    SB_TRY3(hipStreamSynchronize(s));
+   stage("pairs fill + D2H");
+   // the caller's kernels behind the grouping (bin weights, EM) go into the stream now: the handle below is host work
+   // (copies and per-locus bookkeeping, ~2 ms for 60 000 loci) that then runs beside them
+   if (after_pairs) {
+      const sb::DeviceGrouping g = {row_off.data(), f_off.data(), n_bins, f_off[(size_t)nl], (const int32_t *)(d2 + p_cnt), &dp};
+      const int rc_after = (*after_pairs)(g);
+      if (rc_after != SBGPU_OK) {
+         (void)hipStreamSynchronize(s);
+         (void)hipFree(dp.arena);
+         return rc_after;
+      }
+   }
 #undef SB_TRY3
 #undef SB_TRY
-   stage("pairs fill");
    const int rc = sb::bins_from_groups(an, compat_words, key_words, row_off.data(), count.data(), key.data(), compat.data(), used, &dp, out);
    if (rc != SBGPU_OK) (void)hipFree(dp.arena);
    stage("handle");

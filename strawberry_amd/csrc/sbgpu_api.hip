@@ -340,6 +340,11 @@ extern "C" {
 
 const char *sbgpu_version(void) { return "libsbgpu 0.1 (gfx950, strawberry EM hot path)"; }
 
+#ifndef SBGPU_BUILD_ID
+#define SBGPU_BUILD_ID "unknown"
+#endif
+const char *sbgpu_build_id(void) { return SBGPU_BUILD_ID; }
+
 const char *sbgpu_last_error(void) { return g_err.c_str(); }
 
 int sbgpu_device_count(void)
@@ -747,7 +752,8 @@ int sbgpu_plan_classes(const sbgpu_plan_t *p, int64_t *out, int cap)
 
 // fp64 (the product path) and fp32 (BASELINE config 5's tolerance sweep) share the launch structure
 static int em_run_impl(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_count, const void *d_F_any, void *d_theta_any,
-                       int32_t *d_status, int32_t *d_iters, void *stream, const bool f32)
+                       int32_t *d_status, int32_t *d_iters, void *stream, const bool f32, const void *d_row_bias = nullptr,
+                       const void *d_iso_bias = nullptr)
 {
    if (!c || !p) return fail(SBGPU_EINVAL, "sbgpu_em_run_device: null ctx/plan");
    if (p->host.n_loci == 0) return SBGPU_OK;
@@ -755,8 +761,13 @@ static int em_run_impl(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_c
       return fail(SBGPU_EINVAL, "sbgpu_em_run_device: null device pointer");
    if (f32 && (p->launches[sb::kStream].n_classes > 0 || p->launches[sb::kWaveH].n_classes > 0))
       return fail(SBGPU_EUNSUPPORTED, "sbgpu_em_run_device_f32: the fp32 variant covers loci of up to 64 isoforms in the tile kernels only");
+   if ((d_row_bias != nullptr) != (d_iso_bias != nullptr)) return fail(SBGPU_EINVAL, "sbgpu_em_run_device_bias: both bias arrays or none");
+   if (d_row_bias && (p->launches[sb::kStream].n_classes > 0 || !p->lat.empty()))
+      return fail(SBGPU_EUNSUPPORTED, "sbgpu_em_run_device_bias: the bias factors are applied by the tile kernels (loci of up to 64 isoforms, no phases)");
    hipStream_t main = (hipStream_t)stream;
    sb::EmArgs a;
+   a.row_bias = f32 ? nullptr : (const double *)d_row_bias;
+   a.iso_bias = f32 ? nullptr : (const double *)d_iso_bias;
    a.row_off = p->d_row_off;
    a.iso_off = p->d_iso_off;
    a.f_off = p->d_f_off;
@@ -768,6 +779,7 @@ static int em_run_impl(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_c
    sb::EmArgsT<float> a32;
    a32.row_off = a.row_off, a32.iso_off = a.iso_off, a32.f_off = a.f_off, a32.count = a.count;
    a32.F = (const float *)d_F_any, a32.theta = (float *)d_theta_any, a32.status = d_status, a32.iters = d_iters;
+   a32.row_bias = f32 ? (const float *)d_row_bias : nullptr, a32.iso_bias = f32 ? (const float *)d_iso_bias : nullptr;
    // Batches are dealt to the workgroups statically: nothing to reset between runs but the later phases' survivor
    // counts (only when the plan has phases)
    if (p->zero_bytes) HIP_TRY(hipMemsetAsync(p->d_zero, 0, p->zero_bytes, main));
@@ -954,6 +966,18 @@ int sbgpu_last_stage_ms(sbgpu_ctx_t *c, int cap, float *ms, const char **names)
       ++n;
    }
    return n;
+}
+
+int sbgpu_em_run_device_bias(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_count, const double *d_F, const double *d_row_bias,
+                             const double *d_iso_bias, double *d_theta, int32_t *d_status, int32_t *d_iters, void *stream)
+{
+   return em_run_impl(c, p, d_count, d_F, d_theta, d_status, d_iters, stream, false, d_row_bias, d_iso_bias);
+}
+
+int sbgpu_em_run_device_bias_f32(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_count, const float *d_F, const float *d_row_bias,
+                                 const float *d_iso_bias, float *d_theta, int32_t *d_status, int32_t *d_iters, void *stream)
+{
+   return em_run_impl(c, p, d_count, d_F, d_theta, d_status, d_iters, stream, true, d_row_bias, d_iso_bias);
 }
 
 int sbgpu_set_timing(sbgpu_ctx_t *c, int on)

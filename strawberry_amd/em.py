@@ -139,9 +139,22 @@ class EmBatchSolver:
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.dev).cuda_stream)
 
+    def set_bias(self, d_row_bias, d_iso_bias):
+        """BASELINE config 5: factors 2^(row_bias[i] * iso_bias[j]) on the weights, applied by the kernels as they load
+        their tiles (sbgpu_em_run_device_bias).  float64 device tensors [total rows] / [total isoforms]; None: off."""
+        self.d_row_bias, self.d_iso_bias = d_row_bias, d_iso_bias
+        self.d_row_bias32 = None if d_row_bias is None else d_row_bias.to(self.torch.float32)
+        self.d_iso_bias32 = None if d_iso_bias is None else d_iso_bias.to(self.torch.float32)
+
     def run_em(self):
         """EmSolver::init + run for every locus; asynchronous on torch's current stream."""
         L = self.ctx.L
+        if getattr(self, "d_row_bias", None) is not None:
+            _lib.check(L.sbgpu_em_run_device_bias(self.ctx.h, self.plan.h, self.d_count.data_ptr(), self.d_F.data_ptr(),
+                                                  self.d_row_bias.data_ptr(), self.d_iso_bias.data_ptr(), self.d_theta.data_ptr(),
+                                                  self.d_status.data_ptr(), self.d_iters.data_ptr(), self._stream()),
+                       "sbgpu_em_run_device_bias")
+            return
         _lib.check(L.sbgpu_em_run_device(self.ctx.h, self.plan.h, self.d_count.data_ptr(), self.d_F.data_ptr(),
                                          self.d_theta.data_ptr(), self.d_status.data_ptr(),
                                          self.d_iters.data_ptr(), self._stream()), "sbgpu_em_run_device")
@@ -153,6 +166,12 @@ class EmBatchSolver:
         if getattr(self, "d_F32", None) is None:
             self.d_F32 = self.d_F.to(torch.float32)
             self.d_theta32 = torch.zeros(max(self.n_iso, 1), dtype=torch.float32, device=self.dev)
+        if getattr(self, "d_row_bias", None) is not None:
+            _lib.check(self.ctx.L.sbgpu_em_run_device_bias_f32(
+                self.ctx.h, self.plan.h, self.d_count.data_ptr(), self.d_F32.data_ptr(), self.d_row_bias32.data_ptr(),
+                self.d_iso_bias32.data_ptr(), self.d_theta32.data_ptr(), self.d_status.data_ptr(), self.d_iters.data_ptr(),
+                self._stream()), "sbgpu_em_run_device_bias_f32")
+            return
         _lib.check(self.ctx.L.sbgpu_em_run_device_f32(self.ctx.h, self.plan.h, self.d_count.data_ptr(), self.d_F32.data_ptr(),
                                                      self.d_theta32.data_ptr(), self.d_status.data_ptr(),
                                                      self.d_iters.data_ptr(), self._stream()), "sbgpu_em_run_device_f32")

@@ -232,13 +232,12 @@ def concat_batches(parts, name="batch"):
 
 
 def make_c5(n_loci=60000, total_frags=4e8, seed=0x5745):
-    """Config C5: the C3 law at 4e8 fragments with every weight multiplied by a bias factor
-    b_ij in [0.5, 2] (log-uniform; the reference itself has no bias arithmetic, so the factors are ours).  The
-    input of the fp32-vs-fp64 tolerance sweep."""
+    """Config C5: the C3 law at 4e8 fragments.  The bias factors b_ij in [0.5, 2] are NOT multiplied in
+    here: they are applied on the device, inside the EM kernels, as the tiles are loaded (strawberry_amd/bias.py,
+    sbgpu_em_run_device_bias)."""
     b = make_c3(n_loci=n_loci, total_frags=total_frags, seed=seed)
-    rng = np.random.Generator(np.random.PCG64(seed ^ 0xB1A5))
-    F = b.F * np.exp2(rng.uniform(-1.0, 1.0, b.F.shape)) * (b.F != 0)
-    return LocusBatch(b.row_off, b.iso_off, b.f_off, b.count, np.ascontiguousarray(F), b.length, "C5")
+    b.name = "C5"
+    return b
 
 
 def make_random(n_loci=256, max_nrow=64, max_niso=12, density=0.4, max_count=60, seed=12345):

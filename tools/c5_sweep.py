@@ -33,7 +33,11 @@ def main():
     out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "c5_sweep.json")
     n_loci = int(sys.argv[2]) if len(sys.argv) > 2 else 60000
     b = synth.make_c5(n_loci=n_loci, total_frags=4e8 * n_loci / 60000)
-    s = em.EmBatchSolver(b, em.default_context(0))
+    ctx = em.default_context(0)
+    s = em.EmBatchSolver(b, ctx)
+    from strawberry_amd import bias as sbias
+    rb, ib, bias_info = sbias.make_c5_bias(ctx, b)        # factors from the bin-sequence kernel, applied at tile load
+    s.set_bias(rb, ib)
     total = min(b.n_frags, 2**31 - 1)
 
     def step64():
@@ -65,7 +69,8 @@ def main():
     tpm_hist = np.histogram(tpm_rel, bins=edges)[0]
     dit = r32["iters"].astype(np.int64) - r64["iters"].astype(np.int64)
     summary = {
-        "workload": "C5: C3 law, %d loci, %d fragments, bias factors 2^U(-1,1) on the weights" % (b.n_loci, b.n_frags),
+        "workload": "C5: C3 law, %d loci, %d fragments, bias factors applied on the device at tile load" % (b.n_loci, b.n_frags),
+        "bias": bias_info,
         "ms_per_step": {"f64": ms64, "f32": ms32, "speedup": ms64 / ms32},
         "loci_per_s": {"f64": b.n_loci / ms64 * 1e3, "f32": b.n_loci / ms32 * 1e3},
         "status_f64": np.bincount(r64["status"], minlength=4).tolist(),

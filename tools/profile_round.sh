@@ -31,8 +31,12 @@ for w in ("c3", "c2"):
             k = row["Kernel_Name"]
             if "sb::" in k:
                 acc[k.split("(")[0]][row["Counter_Name"]].append(float(row["Counter_Value"]))
-    json.dump({k: {c: {"mean_per_dispatch": sum(v) / len(v), "dispatches": len(v)} for c, v in cs.items()} for k, cs in acc.items()},
-              open("%s/%s_%s_pmc_summary.json" % (summ, r, w), "w"), indent=1)
+    import ctypes
+    L = ctypes.CDLL("strawberry_amd/lib/libsbgpu.so")
+    L.sbgpu_build_id.restype = ctypes.c_char_p
+    summary = {k: {c: {"mean_per_dispatch": sum(v) / len(v), "dispatches": len(v)} for c, v in cs.items()} for k, cs in acc.items()}
+    summary["_build_id"] = L.sbgpu_build_id().decode()     # bench.py quotes the traffic only for this build
+    json.dump(summary, open("%s/%s_%s_pmc_summary.json" % (summ, r, w), "w"), indent=1)
 PY
 # the bench lines come after the counter passes: bench.py reads roofline.traffic from profiles/*_pmc_summary.json
 cp $SUM/${R}_c3_pmc_summary.json $SUM/${R}_c2_pmc_summary.json $REPO/profiles/ 2>/dev/null
