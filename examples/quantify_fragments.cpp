@@ -6,7 +6,7 @@
 //
 //   g++ -std=c++14 -O2 -Iinclude examples/quantify_fragments.cpp -Lstrawberry_amd/lib -lsbgpu
 //       -Wl,-rpath,$PWD/strawberry_amd/lib -o quantify_fragments
-//   ./quantify_fragments input.txt out.gtf ctx.tsv [genome.fa] [--rank R --world W --comm-id FILE]
+//   ./quantify_fragments input.txt out.gtf ctx.tsv [genome.fa] [--rank R --world W --comm-id FILE [--comm-nonce N]]
 //         (genome.fa: the reference's `-b` option -- six sequence columns per bin in the -f table,
 //          src/alignments.cpp:1622-1636)
 //   Several GPUs: one process per GPU, rank R of W on GPU R; locus l belongs to rank l mod W.  Every rank reads
@@ -66,14 +66,16 @@ int main(int argc, char **argv)
 {
    int rank = 0, world = 1;
    std::string comm_id_file;
+   unsigned long long comm_nonce = 0; // the same value on every rank of ONE launch: an older launch's id file is not ours
    {
       // trailing options; what is left are the positional arguments
       int n = argc;
       for (int i = 1; i + 1 < n;) {
          const std::string a = argv[i];
-         if (a == "--rank" || a == "--world" || a == "--comm-id") {
+         if (a == "--rank" || a == "--world" || a == "--comm-id" || a == "--comm-nonce") {
             if (a == "--rank") rank = std::atoi(argv[i + 1]);
             else if (a == "--world") world = std::atoi(argv[i + 1]);
+            else if (a == "--comm-nonce") comm_nonce = std::strtoull(argv[i + 1], nullptr, 10);
             else comm_id_file = argv[i + 1];
             for (int k = i; k + 2 < n; ++k) argv[k] = argv[k + 2];
             n -= 2;
@@ -84,7 +86,7 @@ int main(int argc, char **argv)
       argc = n;
    }
    if ((argc != 4 && argc != 5) || world < 1 || rank < 0 || rank >= world) {
-      std::fprintf(stderr, "usage: %s input.txt out.gtf ctx.tsv [genome.fa] [--rank R --world W --comm-id FILE]\n", argv[0]);
+      std::fprintf(stderr, "usage: %s input.txt out.gtf ctx.tsv [genome.fa] [--rank R --world W --comm-id FILE [--comm-nonce N]]\n", argv[0]);
       return 2;
    }
    const std::string part = world > 1 ? ".rank" + std::to_string(rank) : std::string();
@@ -164,7 +166,7 @@ int main(int argc, char **argv)
 
    try {
       sbgpu::Context ctx(rank % std::max(1, sbgpu_device_count()));
-      sbgpu::Comm comm(ctx, rank, world, comm_id_file);
+      sbgpu::Comm comm(ctx, rank, world, comm_id_file, comm_nonce);
       // Sample::_total_mapped_reads counts the whole sample (src/alignments.cpp:1372): sum over the ranks
       total_mapped = (int)comm.allreduce_sum((int64_t)total_mapped);
       sbgpu::InsertSize ins(ins_mean, ins_sd); // `insert 0 0`: no -i, build the empirical distribution

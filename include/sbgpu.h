@@ -109,7 +109,14 @@ const char *sbgpu_last_error(void);
 const char *sbgpu_build_id(void);
 int sbgpu_device_count(void);
 
-/* Bind to HIP device `device`; creates the context's streams and workspace.     */
+/* Bind to HIP device `device`; creates the context's streams and workspace.
+ * Concurrency.  A context (and every plan / bins handle made with it) serves ONE call at a time, from one host thread:
+ * the multi-stage entry points (sbgpu_quantify_*, sbgpu_bins_create_device, sbgpu_binweight_device,
+ * sbgpu_collapse_pairs_device, sbgpu_em_batch) share per-context device state -- grow-only scratch arenas, the
+ * insert-size table's support, a plan's exchange buffers and epoch -- so two of them in flight on one context, even on
+ * different streams, race.  Use one context per concurrent caller (contexts are cheap; one process per GPU uses one).
+ * Device inputs handed to sbgpu_quantify_device / sbgpu_collapse_pairs_device must be complete when the call is made
+ * (synchronise the stream that produced them): those entry points run on the context's own stream.                */
 int sbgpu_init(int device, sbgpu_ctx_t **ctx_out);
 int sbgpu_finalize(sbgpu_ctx_t *ctx);
 /* Device facts for roofline accounting: out[0]=#CUs, out[1]=wave size,

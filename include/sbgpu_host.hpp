@@ -383,35 +383,45 @@ public:
 /* The collective of a multi-GPU run (one process per GPU, loci sharded over the ranks): the two cross-locus
  * sums of the reference, `_total_mapped_reads` (src/alignments.cpp:1372) and the FPKM total (:1821-1824).
  * Rank 0 makes the RCCL id and leaves it in `id_file` (written under a temporary name and renamed, so a reader
- * never sees half of it); the other ranks wait for the file.  world == 1 needs no file and no RCCL.         */
+ * never sees half of it); the other ranks wait for the file.  world == 1 needs no file and no RCCL.
+ * A file left behind by an earlier launch must not be taken for this one's: the file starts with `nonce` -- a value
+ * the launcher gives to ALL ranks of one launch (job id, start time; `--comm-nonce` of examples/quantify_fragments) --
+ * and readers wait for a file that carries theirs; rank 0 also removes a stale file before it writes and removes its
+ * own once every rank has joined (sbgpu_comm_init is collective: it returns when all have read the id).  With the
+ * default nonce 0 the path must not exist when the launch begins.                                              */
 class Comm {
  public:
-   Comm(const Context &ctx, int rank, int world, const std::string &id_file = std::string()) : h_(nullptr)
+   Comm(const Context &ctx, int rank, int world, const std::string &id_file = std::string(), uint64_t nonce = 0) : h_(nullptr)
    {
       uint8_t id[SBGPU_COMM_ID_BYTES] = {0};
       if (world > 1) {
          if (id_file.empty()) throw Error(SBGPU_EINVAL, "sbgpu::Comm: a world of several ranks needs an id file");
          if (rank == 0) {
+            std::remove(id_file.c_str()); /* whatever an earlier launch left */
             check(sbgpu_comm_unique_id(id), "sbgpu_comm_unique_id");
             const std::string tmp = id_file + ".tmp";
             FILE *f = std::fopen(tmp.c_str(), "wb");
-            if (!f || std::fwrite(id, 1, sizeof(id), f) != sizeof(id) || std::fclose(f) != 0 || std::rename(tmp.c_str(), id_file.c_str()) != 0)
+            if (!f || std::fwrite(&nonce, 1, sizeof(nonce), f) != sizeof(nonce) || std::fwrite(id, 1, sizeof(id), f) != sizeof(id) ||
+                std::fclose(f) != 0 || std::rename(tmp.c_str(), id_file.c_str()) != 0)
                throw Error(SBGPU_EINVAL, "sbgpu::Comm: cannot write " + id_file);
          } else {
             for (int tries = 0;; ++tries) {
                FILE *f = std::fopen(id_file.c_str(), "rb");
                if (f) {
+                  uint64_t theirs = 0;
+                  const size_t n0 = std::fread(&theirs, 1, sizeof(theirs), f);
                   const size_t n = std::fread(id, 1, sizeof(id), f);
                   std::fclose(f);
-                  if (n == sizeof(id)) break;
+                  if (n0 == sizeof(theirs) && n == sizeof(id) && theirs == nonce) break; /* (another launch's file: keep waiting) */
                }
-               if (tries > 6000) throw Error(SBGPU_ERCCL, "sbgpu::Comm: no id in " + id_file + " after 60 s");
+               if (tries > 6000) throw Error(SBGPU_ERCCL, "sbgpu::Comm: no id of this launch in " + id_file + " after 60 s");
                struct timespec ts = {0, 10 * 1000 * 1000};
                nanosleep(&ts, nullptr);
             }
          }
       }
       check(sbgpu_comm_init(ctx.get(), rank, world, world > 1 ? id : nullptr, &h_), "sbgpu_comm_init");
+      if (world > 1 && rank == 0) std::remove(id_file.c_str()); /* every rank has joined: nothing is left for the next launch to trip over */
    }
    ~Comm() { sbgpu_comm_destroy(h_); }
    Comm(const Comm &) = delete;

@@ -1090,6 +1090,9 @@ __global__ __launch_bounds__(NWAVES > 0 ? 64 * NWAVES : 64,
    // re-packs its survivors into the same layouts: phase_prepare_kernel has written it from the survivor counts.
    const int n_batches = ph.total_blocks ? *ph.total_blocks : ph.n_batches;
    for (int b = (int)blockIdx.x; b < n_batches; b += (int)gridDim.x) {
+   // block form serving a second batch (grids capped below the batch count): the next batch's first LDS round must not
+   // overwrite partials a slower wave of this workgroup still reads from the last one (the layout may differ too)
+   if (NWAVES > 0 && b != (int)blockIdx.x) __syncthreads();
    const int c = find_class(ph.table, ph.n_classes, b);
    const ClassDesc d = ph.table[c];
 #ifdef SB_STAMPS
