@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: the round's evidence.  Usage (repo root): bash tools/profile_round.sh r01
 # Everything judged is collected under gpurun_out/$R/summary/ -- copy that directory's files into profiles/.
-R=${1:-r02}
+R=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/$R
 SUM=$OUT/summary
@@ -10,11 +10,11 @@ cd $REPO
 (timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -4) > $SUM/${R}_pytest_gpu.txt
 cd /tmp && export TMPDIR=/tmp
 # kernel trace + stats in their own runs; every PMC group in its own run, never with a trace domain
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3 -o em -- python3 $REPO/bench.py --no-cpu-baseline --steps 10 > $OUT/stats_c3.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3 -o em -- python3 $REPO/bench.py --no-chain --no-cpu-baseline --steps 10 > $OUT/stats_c3.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c2 -o em -- python3 $REPO/bench.py --workload c2 --no-cpu-baseline --steps 10 > $OUT/stats_c2.log 2>&1
-timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_c3 -o em -- python3 $REPO/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_fetch.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_c3 -o em -- python3 $REPO/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_write.log 2>&1
-timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_sq_c3 -o em -- python3 $REPO/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_sq.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_c3 -o em -- python3 $REPO/bench.py --no-chain --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_c3 -o em -- python3 $REPO/bench.py --no-chain --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_write.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_sq_c3 -o em -- python3 $REPO/bench.py --no-chain --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_sq.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_c2 -o em -- python3 $REPO/bench.py --workload c2 --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_fetch_c2.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_c2 -o em -- python3 $REPO/bench.py --workload c2 --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_write_c2.log 2>&1
 cd $REPO
@@ -40,15 +40,42 @@ for w in ("c3", "c2"):
 PY
 # the bench lines come after the counter passes: bench.py reads roofline.traffic from profiles/*_pmc_summary.json
 cp $SUM/${R}_c3_pmc_summary.json $SUM/${R}_c2_pmc_summary.json $REPO/profiles/ 2>/dev/null
-(timeout 900 python bench.py 2>/dev/null) > $SUM/${R}_bench_c3.json
+(timeout 900 python bench.py 2>/dev/null | tail -1) > $SUM/${R}_bench_c3.json
 (timeout 600 python bench.py --workload c2 2>/dev/null) > $SUM/${R}_bench_c2.json
 (timeout 900 python bench.py --workload c5 --no-cpu-baseline 2>/dev/null) > $SUM/${R}_bench_c5.json
 (timeout 900 python bench.py --workload c3t --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null) > $SUM/${R}_bench_c3t.json
-(timeout 900 python bench.py --workload c3-chain --steps 5 --warmup 2 2>/dev/null) > $SUM/${R}_bench_c3chain.json
+(timeout 900 python bench.py --workload c3-chain --steps 10 --warmup 3 2>/dev/null) > $SUM/${R}_bench_c3chain.json
+(timeout 900 python bench.py --gpus 2 --steps 10 --warmup 3 --no-chain 2>/dev/null | tail -1) > $SUM/${R}_bench_c3_2ranks_one_gpu.json
 cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_chain -o ch -- python3 $REPO/bench.py --workload c3-chain --steps 3 --warmup 1 > $OUT/stats_chain.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_chain -o ch -- python3 $REPO/bench.py --workload c3-chain --no-cpu-baseline --steps 3 --warmup 1 > $OUT/stats_chain.log 2>&1
+for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_SALU"; do
+  tag=$(echo $pmc | cut -d' ' -f1)
+  timeout 900 rocprofv3 --pmc $pmc --output-format csv -d $OUT/pmc_${tag}_chain -o ch -- python3 $REPO/bench.py --workload c3-chain --no-cpu-baseline --steps 2 --warmup 1 > $OUT/pmc_${tag}_chain.log 2>&1
+done
+# the wide-locus kernel on C3-T: stats and counters
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3t -o w -- python3 $REPO/bench.py --workload c3t --no-cpu-baseline --steps 3 --warmup 1 > $OUT/stats_c3t.log 2>&1
+for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU"; do
+  tag=$(echo $pmc | cut -d' ' -f1)
+  timeout 900 rocprofv3 --pmc $pmc --output-format csv -d $OUT/pmc_${tag}_c3t -o w -- python3 $REPO/bench.py --workload c3t --no-cpu-baseline --steps 2 --warmup 1 > $OUT/pmc_${tag}_c3t.log 2>&1
+done
 cd $REPO
 for f in $(find $OUT/stats_chain -name "*kernel_stats.csv"); do cp $f $SUM/${R}_c3chain_kernel_stats.csv; done
+for f in $(find $OUT/stats_c3t -name "*kernel_stats.csv"); do cp $f $SUM/${R}_c3t_kernel_stats.csv; done
+python3 - "$OUT" "$SUM" "$R" <<'PY'
+import collections, csv, ctypes, glob, json, sys
+out, summ, r = sys.argv[1:4]
+L = ctypes.CDLL("strawberry_amd/lib/libsbgpu.so"); L.sbgpu_build_id.restype = ctypes.c_char_p
+for w, name in (("chain", "c3chain"), ("c3t", "c3t")):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(out + "/pmc_*_%s/**/*counter_collection.csv" % w, recursive=True):
+        for row in csv.DictReader(open(f)):
+            k = row["Kernel_Name"]
+            if "sb::" in k:
+                acc[k.split("(")[0]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    summary = {k: {c: {"mean_per_dispatch": sum(v) / len(v), "dispatches": len(v)} for c, v in cs.items()} for k, cs in acc.items()}
+    summary["_build_id"] = L.sbgpu_build_id().decode()
+    json.dump(summary, open("%s/%s_%s_pmc_summary.json" % (summ, r, name), "w"), indent=1)
+PY
 bash tools/profile_exonbin.sh $R > /dev/null 2>&1
 cp $OUT/exonbin/summary.json $SUM/${R}_exonbin_summary.json
 cp $OUT/exonbin/stats/eb_kernel_stats.csv $SUM/${R}_exonbin_kernel_stats.csv
@@ -59,7 +86,7 @@ bash tools/profile_binseq.sh $R > /dev/null 2>&1
 cp $OUT/binseq/summary.json $SUM/${R}_binseq_summary.json
 cp $OUT/binseq/stats/bs_kernel_stats.csv $SUM/${R}_binseq_kernel_stats.csv
 # wide loci (> 64 isoforms): multi-workgroup kernel, by shape and on C3-T
-(timeout 600 python tools/probe_c3t.py; timeout 300 python tools/probe_wide_loci.py; timeout 300 python tools/probe_wide_shapes.py) 2>/dev/null > $SUM/${R}_wide_loci.txt
+(timeout 600 python tools/probe_c3t.py; timeout 300 python tools/probe_wide_loci.py; timeout 300 python tools/probe_wide_shapes.py; timeout 600 python tools/check_wide_shapes.py) 2>/dev/null > $SUM/${R}_wide_loci.txt
 timeout 600 python tools/c5_sweep.py $SUM/${R}_c5_sweep.json > /dev/null 2>&1
 timeout 120 ./tools/bin/microbench > $SUM/${R}_microbench.txt 2>&1
 cat $SUM/${R}_pytest_gpu.txt; cat $SUM/${R}_bench_c3.json; echo; cat $SUM/${R}_bench_c2.json; echo; ls -la $SUM
