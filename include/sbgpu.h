@@ -440,6 +440,57 @@ int sbgpu_uniq_dev_hits(const sbgpu_uniq_dev_t *u, sbgpu_hits_t *d_hits, const f
 int sbgpu_uniq_dev_export(const sbgpu_uniq_dev_t *u, int32_t *hit_locus, int64_t *feat_off, uint8_t *feat_code,
                           uint32_t *feat_left, uint32_t *feat_right, float *hit_mass, double *cluster_mass);
 
+/* ---- mate pairing: alignment records -> read pairs --------------------------------------
+ * HitCluster::addOpenHit + addHit (src/alignments.cpp:423-655): the records of a cluster, in the order the
+ * position-sorted BAM gives them, become PairedHits.
+ *   - a record whose span exceeds kMaxFragSpan (1 000 000, src/common.cpp:17) is refused (:512-518);
+ *   - a record without a partner (partner_pos 0) or with its partner on another reference is a hit of its own: the
+ *     RIGHT mate of a pair without a left one when it is on the reverse strand, else the left mate (:535-545);
+ *   - otherwise the cluster's open mates of the same read id are searched, oldest first, for one that starts where
+ *     this record's partner starts, expects its partner where this record starts and whose strand (XS) agrees or is
+ *     unknown on either side (:590-623): the pair is complete and joins the cluster's hits NOW (the order of the hits
+ *     = the order in which pairs are completed); else the record waits as an open mate -- the left one when its
+ *     partner lies behind it, the right one when before it; a record whose partner starts where it starts is
+ *     refused (:559-585, 630-641);
+ *   - what still waits when the cluster is closed is dropped (clearOpenMates, :653).
+ * Pair mass: the two reads' masses, 0.5 / NH each; a single read's 1 / NH (src/read.cpp:49-53).
+ * The result is an sbgpu_pairs_t (mates as MATCH / INTRON feature lists, readhit_2_genomicFeats src/contig.cpp:12-53):
+ * the input of sbgpu_collapse_pairs_host / _device.  One difference a caller should know: the reference's cluster
+ * keeps the span of EVERY accepted record for its span filter (:527), the collapse here sees the spans of the
+ * mates of the pairs only -- records that never find their mate do not count.                                   */
+typedef struct {
+   int64_t n_reads;
+   const uint64_t *read_id;      /* [n_reads] ReadTable::get_id(read name): the mates of a pair share it      */
+   const int64_t *block_off;     /* [n_reads + 1] the record's aligned blocks (the M runs of an M / N CIGAR)  */
+   const uint32_t *block_left, *block_right; /* closed coordinates, ascending                                 */
+   const uint32_t *partner_pos;  /* [n_reads] where the mate starts; 0: none                                  */
+   const uint8_t *flags;         /* [n_reads] bit 0: reverse strand (BAM_FREVERSE); bit 1: the partner lies on
+                                    another reference; bits 2-3: transcription strand (XS) 0 unknown, 1 +, 2 - */
+   const int32_t *nh;            /* [n_reads] NH tag                                                          */
+} sbgpu_reads_t;
+#define SBGPU_READ_REVERSE 1u
+#define SBGPU_READ_PARTNER_ELSEWHERE 2u
+typedef struct sbgpu_matepairs sbgpu_matepairs_t;
+/* Host form: `reads` host arrays, the records of cluster l are [locus_read_off[l], locus_read_off[l + 1]). */
+int sbgpu_pair_mates_host(int64_t n_loci, const sbgpu_reads_t *reads, const int64_t *locus_read_off, sbgpu_matepairs_t **out);
+/* Device form (csrc/matepair_device.h): `d_reads` device arrays, locus_read_off host; one workgroup per cluster sorts
+ * its records by read id in LDS, walks every read id's records in arrival order, ranks the completed pairs by
+ * completion and writes the pairs where sbgpu_collapse_pairs_device reads them -- nothing but per-cluster counts
+ * comes back.  Clusters of up to 8192 records, up to 8 open mates per read id; else SBGPU_EUNSUPPORTED.        */
+int sbgpu_pair_mates_device(sbgpu_ctx_t *ctx, int64_t n_loci, const sbgpu_reads_t *d_reads, const int64_t *locus_read_off,
+                            void *stream, sbgpu_matepairs_t **out);
+void sbgpu_matepairs_destroy(sbgpu_matepairs_t *m);
+/* info: 0 pairs (single reads included), 1 complete pairs, 2 single reads, 3 records refused, 4 records that never
+ * found their mate, 5 features of the left mates, 6 of the right mates, 7: 1 when the arrays live on the device. */
+int sbgpu_matepairs_info(const sbgpu_matepairs_t *m, int64_t info[8]);
+/* The pairs where they are (host or device arrays, see info[7]) + locus_pair_off [n_loci + 1] (host): the arguments
+ * of sbgpu_collapse_pairs_host / _device.  pair_locus is set for the host form only.  Owned by the handle.      */
+int sbgpu_matepairs_pairs(const sbgpu_matepairs_t *m, sbgpu_pairs_t *pairs, const int64_t **locus_pair_off);
+/* Host copies of everything (NULL = skip): pair_mass [pairs], left_off / right_off [pairs + 1], the feature arrays. */
+int sbgpu_matepairs_export(const sbgpu_matepairs_t *m, double *pair_mass, int64_t *left_off, uint8_t *left_code,
+                           uint32_t *left_left, uint32_t *left_right, int64_t *right_off, uint8_t *right_code,
+                           uint32_t *right_left, uint32_t *right_right);
+
 /* LocusContext::assign_exon_bin + set_maps (src/estimate.cpp:135-198, estimate.hpp:29-52)
  * on the kernel's results (host copies of compat / key), hits visited in input order inside
  * each locus (= HitCluster::uniq_hits() order):

@@ -117,6 +117,24 @@ class OracleLib:
         L.sbo_collapse_cluster.restype = C.c_int
         L.sbo_phi.argtypes = [C.c_double]
         L.sbo_phi.restype = C.c_double
+        _u64 = _p(np.uint64, flags="C")
+        L.sbo_pair_mates.argtypes = [C.c_int, _u64, _i64, _u32, _u32, _u32, _p(np.uint8, flags="C"), _i32, _i32, _i32, _f64, _i32]
+        L.sbo_pair_mates.restype = C.c_int
+
+    # ---- mate pairing (HitCluster::addOpenHit + addHit)
+    def pair_mates(self, read_id, blocks, partner_pos, flags, nh):
+        """One cluster's records in arrival order (blocks: per record [(l, r), ...]).
+        -> (left_rec int32[n_pairs], right_rec, mass float64[n_pairs], counts dict)"""
+        off, bl, br = _blocks_csr(blocks)
+        n = len(blocks)
+        lr, rr, m = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.float64)
+        cnt = np.zeros(4, np.int32)
+        k = self.L.sbo_pair_mates(n, np.ascontiguousarray(read_id, np.uint64), off, bl, br,
+                                  np.ascontiguousarray(partner_pos if n else [0], np.uint32),
+                                  np.ascontiguousarray(flags if n else [0], np.uint8), np.ascontiguousarray(nh if n else [1], np.int32),
+                                  lr, rr, m, cnt)
+        return lr[:k].copy(), rr[:k].copy(), m[:k].copy(), {"complete": int(cnt[0]), "single": int(cnt[1]), "refused": int(cnt[2]),
+                                                           "orphan": int(cnt[3])}
 
     # ---- duplicate collapse (HitCluster::collapseAndFilterHits)
     def collapse_cluster(self, left_blocks, right_blocks, nh):
@@ -335,9 +353,26 @@ class RefLib:
         L.ref_pairedhit_features.restype = C.c_int
         L.ref_kmer_stats.argtypes = [C.c_char_p, C.c_int, _f64]
         L.ref_kmer_stats.restype = None
+        if hasattr(L, "ref_cluster_from_records"):
+            L.ref_cluster_from_records.argtypes = [C.c_int, _p(np.uint64, flags="C"), _i64, _u32, _u32, _u32, _u8, _i32, _i32, _i32,
+                                                   _f64, _f64, _i32]
+            L.ref_cluster_from_records.restype = C.c_int
         if hasattr(L, "ref_collapse_cluster"):
             L.ref_collapse_cluster.argtypes = [C.c_int, _i64, _u32, _u32, _i64, _u32, _u32, _i32, _i32, _f64, _f64]
             L.ref_collapse_cluster.restype = C.c_int
+
+    def cluster_from_records(self, read_id, blocks, partner_pos, flags, nh):
+        """Records -> the reference's HitCluster::addOpenHit (mate pairing) -> collapseAndFilterHits.
+        -> (left_rec, right_rec, uniq_mass, cluster_mass, n_hits_before_collapse)"""
+        off, bl, br = _blocks_csr(blocks)
+        n = len(blocks)
+        lr, rr, m = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.float64)
+        cm, nhits = np.zeros(1, np.float64), np.zeros(1, np.int32)
+        k = self.L.ref_cluster_from_records(n, np.ascontiguousarray(read_id, np.uint64), off, bl, br,
+                                            np.ascontiguousarray(partner_pos if n else [0], np.uint32),
+                                            np.ascontiguousarray(flags if n else [0], np.uint8), np.ascontiguousarray(nh if n else [1], np.int32),
+                                            lr, rr, m, cm, nhits)
+        return lr[:k].copy(), rr[:k].copy(), m[:k].copy(), float(cm[0]), int(nhits[0])
 
     def collapse_cluster(self, left_blocks, right_blocks, nh):
         """The reference's own HitCluster (addOpenHit for every read, then collapseAndFilterHits).

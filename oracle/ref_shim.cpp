@@ -236,6 +236,50 @@ int ref_collapse_cluster(int n_pairs, const int64_t *lo, const uint32_t *ll, con
    return n;
 }
 
+/* Mate pairing AND collapse on the reference's own HitCluster: the records go through HitCluster::addOpenHit
+ * (src/alignments.cpp:490-650) exactly as given -- order, read ids, partner positions, strands, NH -- then
+ * collapseAndFilterHits runs.  A record's name is its index, so the unique hits can name their mates.
+ * flags: bit 0 reverse strand, bit 1 partner on another reference, bits 2-3 XS strand (0 unknown, 1 +, 2 -).
+ * Out, per unique hit: left_rec / right_rec (record indices, -1: none), collapse mass; *cluster_mass; *n_hits = the
+ * number of PairedHits before the collapse (HitCluster::size()).  Returns the number of unique hits.              */
+int ref_cluster_from_records(int n_reads, const uint64_t *read_id, const int64_t *block_off, const uint32_t *bl, const uint32_t *br,
+                             const uint32_t *partner_pos, const uint8_t *flags, const int32_t *nh, int32_t *left_rec,
+                             int32_t *right_rec, double *uniq_mass, double *cluster_mass, int32_t *n_hits)
+{
+   HitCluster hc;
+   for (int r = 0; r < n_reads; ++r) {
+      const int64_t o = block_off[r], n = block_off[r + 1] - o;
+      if (n <= 0) continue;
+      std::vector<CigarOp> cig;
+      for (int64_t k = 0; k < n; ++k) {
+         if (k) cig.push_back(CigarOp(REF_SKIP, bl[o + k] - br[o + k - 1] - 1));
+         cig.push_back(CigarOp(MATCH, br[o + k] - bl[o + k] + 1));
+      }
+      const int xs = (flags[r] >> 2) & 3;
+      const Strand_t strand = xs == 1 ? Strand_t::StrandPlus : (xs == 2 ? Strand_t::StrandMinus : Strand_t::StrandUnknown);
+      GenomicInterval iv(0, bl[o], br[o + n - 1], strand);
+      const RefID partner_ref = (flags[r] & 2u) ? 1 : 0;
+      ReadHitPtr hit(new ReadHit((ReadID)read_id[r], std::to_string(r), iv, cig, partner_ref, (int)partner_pos[r], 0, nh[r],
+                                 (flags[r] & 1u) ? 16u : 0u, 1.0, NULL));
+      hc.addOpenHit(hit, true, true);
+   }
+   *n_hits = hc.size();
+   if (hc.size() == 0) {
+      *cluster_mass = 0.0;
+      return 0;
+   }
+   const int n = hc.collapseAndFilterHits();
+   int k = 0;
+   for (const PairedHit &u : hc.uniq_hits()) {
+      left_rec[k] = u._left_read ? std::stoi(u.left_read_obj().read_name()) : -1;
+      right_rec[k] = u._right_read ? std::stoi(u.right_read_obj().read_name()) : -1;
+      uniq_mass[k] = u.collapse_mass();
+      ++k;
+   }
+   *cluster_mass = hc._weighted_mass;
+   return n;
+}
+
 /* The six per-bin sequence statistics of the `-f` table, by the reference's own templates
  * exactly as src/alignments.cpp:1623-1629 calls them.  out6 = gc, entropy, 4 flags (0/1).
  * The caller keeps to len > 40: the reference's live asserts abort below that.           */

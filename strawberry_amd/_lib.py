@@ -22,7 +22,8 @@ SYMBOLS = [
     "sbgpu_version", "sbgpu_build_id", "sbgpu_last_error", "sbgpu_device_count", "sbgpu_init", "sbgpu_finalize",
     "sbgpu_device_info", "sbgpu_synchronize", "sbgpu_plan_create", "sbgpu_plan_destroy", "sbgpu_plan_info",
     "sbgpu_plan_classes", "sbgpu_plan_locus_kinds", "sbgpu_em_run_device", "sbgpu_em_run_device_f32", "sbgpu_em_run_device_bias", "sbgpu_em_run_device_bias_f32", "sbgpu_em_last_kernel_ms",
-    "sbgpu_set_timing", "sbgpu_em_last_phase_ms", "sbgpu_last_stage_ms",
+    "sbgpu_set_timing", "sbgpu_em_last_phase_ms", "sbgpu_last_stage_ms", "sbgpu_pair_mates_host", "sbgpu_pair_mates_device", "sbgpu_matepairs_destroy", "sbgpu_matepairs_info",
+    "sbgpu_matepairs_pairs", "sbgpu_matepairs_export",
     "sbgpu_comm_unique_id", "sbgpu_comm_init", "sbgpu_comm_info", "sbgpu_comm_destroy",
     "sbgpu_allreduce_sum_f64", "sbgpu_allreduce_sum_i64", "sbgpu_allreduce_sum_f64_host", "sbgpu_allreduce_sum_i64_host",
     "sbgpu_insert_pdf_table", "sbgpu_binweight_device", "sbgpu_binweight_host",
@@ -92,6 +93,11 @@ class sbgpu_pairs_t(C.Structure):
     _fields_ = [(n, C.c_int64 if n == "n_pairs" else C.c_void_p) for n in (
         "n_pairs", "pair_locus", "pair_mass", "left_off", "left_code", "left_left", "left_right", "right_off", "right_code",
         "right_left", "right_right")]
+
+
+class sbgpu_reads_t(C.Structure):
+    _fields_ = [("n_reads", C.c_int64), ("read_id", C.c_void_p), ("block_off", C.c_void_p), ("block_left", C.c_void_p),
+                ("block_right", C.c_void_p), ("partner_pos", C.c_void_p), ("flags", C.c_void_p), ("nh", C.c_void_p)]
 
 
 class sbgpu_hits_t(C.Structure):
@@ -187,6 +193,13 @@ def load():
     L.sbgpu_bins_export_weights.argtypes = [vp, vp]
     L.sbgpu_collapse_pairs_host.argtypes = [C.c_int64, C.POINTER(sbgpu_pairs_t), C.POINTER(vp)]
     L.sbgpu_collapse_pairs_device.argtypes = [vp, C.c_int64, C.POINTER(sbgpu_pairs_t), vp, vp, C.POINTER(vp)]
+    L.sbgpu_pair_mates_host.argtypes = [C.c_int64, C.POINTER(sbgpu_reads_t), vp, C.POINTER(vp)]
+    L.sbgpu_pair_mates_device.argtypes = [vp, C.c_int64, C.POINTER(sbgpu_reads_t), vp, vp, C.POINTER(vp)]
+    L.sbgpu_matepairs_destroy.argtypes = [vp]
+    L.sbgpu_matepairs_destroy.restype = None
+    L.sbgpu_matepairs_info.argtypes = [vp, i64p]
+    L.sbgpu_matepairs_pairs.argtypes = [vp, C.POINTER(sbgpu_pairs_t), C.POINTER(vp)]
+    L.sbgpu_matepairs_export.argtypes = [vp] * 10
     L.sbgpu_uniq_dev_destroy.argtypes = [vp]
     L.sbgpu_uniq_dev_destroy.restype = None
     L.sbgpu_uniq_dev_info.argtypes = [vp, i64p]

@@ -1,0 +1,365 @@
+// strawberry_amd/csrc/matepair_api.hip -- sbgpu_pair_mates_host / _device (include/sbgpu.h): alignment records ->
+// read pairs, HitCluster::addOpenHit + addHit (/root/reference/src/alignments.cpp:423-655).  Kernels: matepair_device.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/sbgpu.h"
+#include "api_internal.h"
+#include "matepair_device.h"
+
+using sb::api_fail;
+
+struct sbgpu_matepairs {
+   bool on_device = false;
+   int device = 0;
+   int64_t n_loci = 0, n_pairs = 0, n_complete = 0, n_single = 0, n_refused = 0, n_orphan = 0, n_lfeat = 0, n_rfeat = 0;
+   std::vector<int64_t> locus_pair_off; // host
+   // host form
+   std::vector<int32_t> pair_locus;
+   std::vector<double> pair_mass;
+   std::vector<int64_t> left_off, right_off;
+   std::vector<uint8_t> left_code, right_code;
+   std::vector<uint32_t> left_left, left_right, right_left, right_right;
+   // device form: one arena
+   char *arena = nullptr;
+   double *d_mass = nullptr;
+   int64_t *d_left_off = nullptr, *d_right_off = nullptr;
+   uint8_t *d_left_code = nullptr, *d_right_code = nullptr;
+   uint32_t *d_left_left = nullptr, *d_left_right = nullptr, *d_right_left = nullptr, *d_right_right = nullptr;
+};
+
+namespace {
+size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
+constexpr int kMaxFragSpanHost = 1000000; // src/common.cpp:17
+} // namespace
+
+extern "C" {
+
+void sbgpu_matepairs_destroy(sbgpu_matepairs_t *m)
+{
+   if (!m) return;
+   if (m->arena) {
+      (void)hipSetDevice(m->device);
+      (void)hipFree(m->arena);
+   }
+   delete m;
+}
+
+int sbgpu_pair_mates_host(int64_t n_loci, const sbgpu_reads_t *rd, const int64_t *locus_read_off, sbgpu_matepairs_t **out)
+{
+   if (!rd || !out || !locus_read_off || n_loci < 0) return api_fail(SBGPU_EINVAL, "sbgpu_pair_mates_host: bad argument");
+   *out = nullptr;
+   const int64_t nr = rd->n_reads;
+   if (nr < 0 || locus_read_off[0] != 0 || locus_read_off[n_loci] != nr) return api_fail(SBGPU_EINVAL, "sbgpu_pair_mates_host: locus_read_off does not cover the reads");
+   if (nr && (!rd->read_id || !rd->block_off || !rd->partner_pos || !rd->flags || !rd->nh)) return api_fail(SBGPU_EINVAL, "sbgpu_pair_mates_host: null array");
+   sbgpu_matepairs *M = new (std::nothrow) sbgpu_matepairs();
+   if (!M) return api_fail(SBGPU_ENOMEM, "sbgpu_pair_mates_host: out of memory");
+   try {
+      M->n_loci = n_loci;
+      M->locus_pair_off.assign((size_t)n_loci + 1, 0);
+      M->left_off.push_back(0);
+      M->right_off.push_back(0);
+      auto left_of = [&](int64_t r) { return rd->block_left[rd->block_off[r]]; };
+      auto push_mate = [&](int64_t r, std::vector<uint8_t> &c, std::vector<uint32_t> &l, std::vector<uint32_t> &rr) {
+         // readhit_2_genomicFeats, src/contig.cpp:12-53: the blocks with the introns between them
+         for (int64_t b = rd->block_off[r]; b < rd->block_off[r + 1]; ++b) {
+            if (b > rd->block_off[r]) {
+               c.push_back(1);
+               l.push_back(rd->block_right[b - 1] + 1);
+               rr.push_back(rd->block_left[b] - 1);
+            }
+            c.push_back(0);
+            l.push_back(rd->block_left[b]);
+            rr.push_back(rd->block_right[b]);
+         }
+      };
+      auto add_hit = [&](int64_t l, int64_t left_rec, int64_t right_rec) { // HitCluster::addHit, in completion order
+         if (left_rec >= 0) push_mate(left_rec, M->left_code, M->left_left, M->left_right);
+         if (right_rec >= 0) push_mate(right_rec, M->right_code, M->right_left, M->right_right);
+         M->left_off.push_back((int64_t)M->left_code.size());
+         M->right_off.push_back((int64_t)M->right_code.size());
+         double m = 0.0; // PairedHit::init_raw_mass, src/read.cpp:734-741 over ReadHit masses (:49-53)
+         if (left_rec >= 0 && right_rec >= 0) m = 0.5 / rd->nh[left_rec] + 0.5 / rd->nh[right_rec];
+         else m = 1.0 / rd->nh[left_rec >= 0 ? left_rec : right_rec];
+         M->pair_mass.push_back(m);
+         M->pair_locus.push_back((int32_t)l);
+      };
+      for (int64_t l = 0; l < n_loci; ++l) {
+         if (locus_read_off[l + 1] < locus_read_off[l]) {
+            delete M;
+            return api_fail(SBGPU_EINVAL, "sbgpu_pair_mates_host: locus_read_off must ascend");
+         }
+         std::unordered_map<uint64_t, std::vector<int64_t>> open; // HitCluster::_open_mates: read id -> waiting records, oldest first
+         for (int64_t r = locus_read_off[l]; r < locus_read_off[l + 1]; ++r) {
+            const int64_t b0 = rd->block_off[r], b1 = rd->block_off[r + 1];
+            if (b1 <= b0) {
+               ++M->n_refused;
+               continue;
+            }
+            const uint32_t left = rd->block_left[b0], right = rd->block_right[b1 - 1];
+            if ((int64_t)right - (int64_t)left > kMaxFragSpanHost) { // alignments.cpp:512-518
+               ++M->n_refused;
+               continue;
+            }
+            const uint32_t ppos = rd->partner_pos[r];
+            const uint8_t fl = rd->flags[r];
+            if (ppos == 0 || (fl & SBGPU_READ_PARTNER_ELSEWHERE)) { // :535-545
+               if (fl & SBGPU_READ_REVERSE) add_hit(l, -1, r);
+               else add_hit(l, r, -1);
+               ++M->n_single;
+               continue;
+            }
+            const int strand = (fl >> 2) & 3;
+            std::vector<int64_t> &chain = open[rd->read_id[r]];
+            bool done = false;
+            for (size_t o = 0; o < chain.size(); ++o) { // :590-623
+               const int64_t w = chain[o];
+               const int wstrand = (rd->flags[w] >> 2) & 3;
+               const bool strand_agree = wstrand == strand || strand == 0 || wstrand == 0;
+               if (left_of(w) == ppos && strand_agree && rd->partner_pos[w] == left) {
+                  const bool waiting_is_left = rd->partner_pos[w] > left_of(w);
+                  if (waiting_is_left) add_hit(l, w, r);
+                  else add_hit(l, r, w);
+                  chain.erase(chain.begin() + (std::ptrdiff_t)o);
+                  ++M->n_complete;
+                  done = true;
+                  break;
+               }
+            }
+            if (done) continue;
+            if (ppos == left) { // :585, :640
+               ++M->n_refused;
+               continue;
+            }
+            chain.push_back(r);
+         }
+         for (const auto &kv : open) M->n_orphan += (int64_t)kv.second.size(); // clearOpenMates (:653)
+         M->locus_pair_off[(size_t)l + 1] = (int64_t)M->pair_mass.size();
+      }
+      M->n_pairs = (int64_t)M->pair_mass.size();
+      M->n_lfeat = (int64_t)M->left_code.size();
+      M->n_rfeat = (int64_t)M->right_code.size();
+   } catch (const std::bad_alloc &) {
+      delete M;
+      return api_fail(SBGPU_ENOMEM, "sbgpu_pair_mates_host: out of memory");
+   }
+   *out = M;
+   return SBGPU_OK;
+}
+
+int sbgpu_pair_mates_device(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t *dr, const int64_t *locus_read_off, void *stream,
+                            sbgpu_matepairs_t **out)
+{
+   if (!c || !dr || !out || !locus_read_off || n_loci < 0) return api_fail(SBGPU_EINVAL, "sbgpu_pair_mates_device: bad argument");
+   *out = nullptr;
+   const int64_t nr = dr->n_reads;
+   if (nr < 0 || locus_read_off[0] != 0 || locus_read_off[n_loci] != nr) return api_fail(SBGPU_EINVAL, "sbgpu_pair_mates_device: locus_read_off does not cover the reads");
+   if (nr && (!dr->read_id || !dr->block_off || !dr->block_left || !dr->block_right || !dr->partner_pos || !dr->flags || !dr->nh))
+      return api_fail(SBGPU_EINVAL, "sbgpu_pair_mates_device: null device pointer");
+   for (int64_t l = 0; l < n_loci; ++l) {
+      if (locus_read_off[l + 1] < locus_read_off[l]) return api_fail(SBGPU_EINVAL, "sbgpu_pair_mates_device: locus_read_off must ascend");
+      if (locus_read_off[l + 1] - locus_read_off[l] > sb::kMateMaxReads)
+         return api_fail(SBGPU_EUNSUPPORTED, "sbgpu_pair_mates_device: not covered by the device form: a cluster has more than 8192 records; use sbgpu_pair_mates_host");
+   }
+   hipStream_t s = (hipStream_t)stream;
+   sbgpu_matepairs *M = new (std::nothrow) sbgpu_matepairs();
+   if (!M) return api_fail(SBGPU_ENOMEM, "sbgpu_pair_mates_device: out of host memory");
+   M->on_device = true;
+   M->device = sb::ctx_device(c);
+   M->n_loci = n_loci;
+   M->locus_pair_off.assign((size_t)n_loci + 1, 0);
+   char *w = nullptr;
+   auto bail = [&](int code, const std::string &msg) {
+      (void)hipFree(w);
+      sbgpu_matepairs_destroy(M);
+      return api_fail(code, msg);
+   };
+#define SB_TRY(expr)                                                                                     \
+   do {                                                                                                  \
+      hipError_t e_ = (expr);                                                                            \
+      if (e_ != hipSuccess) return bail(e_ == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+   } while (0)
+   if (nr == 0 || n_loci == 0) {
+      *out = M;
+      return SBGPU_OK;
+   }
+   SB_TRY(hipSetDevice(M->device));
+   const size_t nr1 = (size_t)nr, nl1 = (size_t)n_loci + 1;
+   size_t off = 0;
+   const size_t o_roff = off; off += up256(nl1 * 8);
+   const size_t o_fate = off; off += up256(nr1);
+   const size_t o_partner = off; off += up256(nr1 * 4);
+   const size_t o_rank = off; off += up256(nr1 * 4);
+   size_t o_cnt[7];
+   for (size_t &o : o_cnt) {
+      o = off;
+      off += up256(nl1 * 4);
+   }
+   const size_t o_flag = off; off += 256;
+   const size_t o_poff = off; off += up256(nl1 * 8);
+   const size_t o_lbase = off; off += up256(nl1 * 8);
+   const size_t o_rbase = off; off += up256(nl1 * 8);
+   SB_TRY(hipMalloc(&w, off));
+   SB_TRY(hipMemsetAsync(w + o_flag, 0, 256, s));
+   SB_TRY(hipMemcpyAsync(w + o_roff, locus_read_off, nl1 * 8, hipMemcpyHostToDevice, s));
+   sb::MateArgs a = {};
+   a.n_loci = n_loci;
+   a.locus_read_off = (const int64_t *)(w + o_roff);
+   a.read_id = dr->read_id;
+   a.block_off = dr->block_off;
+   a.block_left = dr->block_left, a.block_right = dr->block_right;
+   a.partner_pos = dr->partner_pos;
+   a.flags = dr->flags;
+   a.nh = dr->nh;
+   a.fate = (int8_t *)(w + o_fate);
+   a.partner = (int32_t *)(w + o_partner);
+   a.rank = (int32_t *)(w + o_rank);
+   a.n_pairs = (int32_t *)(w + o_cnt[0]), a.n_complete = (int32_t *)(w + o_cnt[1]), a.n_single = (int32_t *)(w + o_cnt[2]);
+   a.n_refused = (int32_t *)(w + o_cnt[3]), a.n_orphan = (int32_t *)(w + o_cnt[4]);
+   a.n_lfeat = (int32_t *)(w + o_cnt[5]), a.n_rfeat = (int32_t *)(w + o_cnt[6]);
+   a.flags_out = (int32_t *)(w + o_flag);
+   const unsigned grid = (unsigned)std::min<int64_t>(n_loci, (int64_t)sb::ctx_cu_count(c) * 4);
+   hipLaunchKernelGGL(sb::matepair_locus_kernel, dim3(grid), dim3(sb::kMateThreads), 0, s, a);
+   SB_TRY(hipGetLastError());
+   std::vector<int32_t> cnt[7];
+   for (int k = 0; k < 7; ++k) {
+      cnt[k].resize((size_t)n_loci);
+      SB_TRY(hipMemcpyAsync(cnt[k].data(), w + o_cnt[k], (size_t)n_loci * 4, hipMemcpyDeviceToHost, s));
+   }
+   int32_t flags = 0;
+   SB_TRY(hipMemcpyAsync(&flags, w + o_flag, 4, hipMemcpyDeviceToHost, s));
+   SB_TRY(hipStreamSynchronize(s));
+   if (flags) {
+      std::string why = "sbgpu_pair_mates_device: not covered by the device form:";
+      if (flags & sb::kMateTooMany) why += " a cluster has more than 8192 records;";
+      if (flags & sb::kMateOpenOverflow) why += " more than 8 mates of one read id wait at a time;";
+      return bail(SBGPU_EUNSUPPORTED, why + " use sbgpu_pair_mates_host");
+   }
+   std::vector<int64_t> lbase((size_t)n_loci + 1, 0), rbase((size_t)n_loci + 1, 0);
+   for (int64_t l = 0; l < n_loci; ++l) {
+      M->locus_pair_off[(size_t)l + 1] = M->locus_pair_off[(size_t)l] + cnt[0][(size_t)l];
+      lbase[(size_t)l + 1] = lbase[(size_t)l] + cnt[5][(size_t)l];
+      rbase[(size_t)l + 1] = rbase[(size_t)l] + cnt[6][(size_t)l];
+      M->n_complete += cnt[1][(size_t)l];
+      M->n_single += cnt[2][(size_t)l];
+      M->n_refused += cnt[3][(size_t)l];
+      M->n_orphan += cnt[4][(size_t)l];
+   }
+   M->n_pairs = M->locus_pair_off[(size_t)n_loci];
+   M->n_lfeat = lbase[(size_t)n_loci];
+   M->n_rfeat = rbase[(size_t)n_loci];
+   // ---- the pairs' own arena
+   const size_t np1 = (size_t)M->n_pairs + 1, nlf = (size_t)M->n_lfeat + 1, nrf = (size_t)M->n_rfeat + 1;
+   size_t t = 0;
+   const size_t u_mass = t; t += up256(np1 * 8);
+   const size_t u_loff = t; t += up256(np1 * 8);
+   const size_t u_roff = t; t += up256(np1 * 8);
+   const size_t u_ll = t; t += up256(nlf * 4);
+   const size_t u_lr = t; t += up256(nlf * 4);
+   const size_t u_rl = t; t += up256(nrf * 4);
+   const size_t u_rr = t; t += up256(nrf * 4);
+   const size_t u_lc = t; t += up256(nlf);
+   const size_t u_rc = t; t += up256(nrf);
+   SB_TRY(hipMalloc(&M->arena, t));
+   M->d_mass = (double *)(M->arena + u_mass);
+   M->d_left_off = (int64_t *)(M->arena + u_loff);
+   M->d_right_off = (int64_t *)(M->arena + u_roff);
+   M->d_left_left = (uint32_t *)(M->arena + u_ll), M->d_left_right = (uint32_t *)(M->arena + u_lr);
+   M->d_right_left = (uint32_t *)(M->arena + u_rl), M->d_right_right = (uint32_t *)(M->arena + u_rr);
+   M->d_left_code = (uint8_t *)(M->arena + u_lc), M->d_right_code = (uint8_t *)(M->arena + u_rc);
+   SB_TRY(hipMemcpyAsync(w + o_poff, M->locus_pair_off.data(), nl1 * 8, hipMemcpyHostToDevice, s));
+   SB_TRY(hipMemcpyAsync(w + o_lbase, lbase.data(), nl1 * 8, hipMemcpyHostToDevice, s));
+   SB_TRY(hipMemcpyAsync(w + o_rbase, rbase.data(), nl1 * 8, hipMemcpyHostToDevice, s));
+   SB_TRY(hipMemcpyAsync(M->d_left_off + M->n_pairs, &M->n_lfeat, 8, hipMemcpyHostToDevice, s));
+   SB_TRY(hipMemcpyAsync(M->d_right_off + M->n_pairs, &M->n_rfeat, 8, hipMemcpyHostToDevice, s));
+   a.pair_off = (const int64_t *)(w + o_poff);
+   a.lfeat_base = (const int64_t *)(w + o_lbase);
+   a.rfeat_base = (const int64_t *)(w + o_rbase);
+   a.pair_mass = M->d_mass;
+   a.left_off = M->d_left_off, a.right_off = M->d_right_off;
+   a.left_code = M->d_left_code, a.right_code = M->d_right_code;
+   a.left_left = M->d_left_left, a.left_right = M->d_left_right;
+   a.right_left = M->d_right_left, a.right_right = M->d_right_right;
+   hipLaunchKernelGGL(sb::matepair_fill_kernel, dim3(grid), dim3(sb::kMateThreads), 0, s, a);
+   SB_TRY(hipGetLastError());
+   SB_TRY(hipStreamSynchronize(s)); // the scratch goes away
+#undef SB_TRY
+   (void)hipFree(w);
+   *out = M;
+   return SBGPU_OK;
+}
+
+int sbgpu_matepairs_info(const sbgpu_matepairs_t *m, int64_t info[8])
+{
+   if (!m || !info) return api_fail(SBGPU_EINVAL, "sbgpu_matepairs_info: null argument");
+   info[0] = m->n_pairs;
+   info[1] = m->n_complete;
+   info[2] = m->n_single;
+   info[3] = m->n_refused;
+   info[4] = m->n_orphan;
+   info[5] = m->n_lfeat;
+   info[6] = m->n_rfeat;
+   info[7] = m->on_device ? 1 : 0;
+   return SBGPU_OK;
+}
+
+int sbgpu_matepairs_pairs(const sbgpu_matepairs_t *m, sbgpu_pairs_t *p, const int64_t **locus_pair_off)
+{
+   if (!m || !p) return api_fail(SBGPU_EINVAL, "sbgpu_matepairs_pairs: null argument");
+   p->n_pairs = m->n_pairs;
+   if (m->on_device) {
+      p->pair_locus = nullptr;
+      p->pair_mass = m->d_mass;
+      p->left_off = m->d_left_off, p->left_code = m->d_left_code, p->left_left = m->d_left_left, p->left_right = m->d_left_right;
+      p->right_off = m->d_right_off, p->right_code = m->d_right_code, p->right_left = m->d_right_left, p->right_right = m->d_right_right;
+   } else {
+      p->pair_locus = m->pair_locus.data();
+      p->pair_mass = m->pair_mass.data();
+      p->left_off = m->left_off.data(), p->left_code = m->left_code.data(), p->left_left = m->left_left.data(), p->left_right = m->left_right.data();
+      p->right_off = m->right_off.data(), p->right_code = m->right_code.data(), p->right_left = m->right_left.data(), p->right_right = m->right_right.data();
+   }
+   if (locus_pair_off) *locus_pair_off = m->locus_pair_off.data();
+   return SBGPU_OK;
+}
+
+int sbgpu_matepairs_export(const sbgpu_matepairs_t *m, double *pair_mass, int64_t *left_off, uint8_t *left_code, uint32_t *left_left,
+                           uint32_t *left_right, int64_t *right_off, uint8_t *right_code, uint32_t *right_left, uint32_t *right_right)
+{
+   if (!m) return api_fail(SBGPU_EINVAL, "sbgpu_matepairs_export: null argument");
+   const size_t np = (size_t)m->n_pairs, nl = (size_t)m->n_lfeat, nr = (size_t)m->n_rfeat;
+   if (m->on_device) {
+      hipError_t e = hipSetDevice(m->device);
+      auto get = [&](void *dst, const void *src, size_t bytes) {
+         if (e == hipSuccess && dst && bytes && src) e = hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
+      };
+      if (m->arena) {
+         get(pair_mass, m->d_mass, np * 8);
+         get(left_off, m->d_left_off, (np + 1) * 8);
+         get(right_off, m->d_right_off, (np + 1) * 8);
+         get(left_code, m->d_left_code, nl), get(left_left, m->d_left_left, nl * 4), get(left_right, m->d_left_right, nl * 4);
+         get(right_code, m->d_right_code, nr), get(right_left, m->d_right_left, nr * 4), get(right_right, m->d_right_right, nr * 4);
+      } else {
+         if (left_off) left_off[0] = 0;
+         if (right_off) right_off[0] = 0;
+      }
+      if (e != hipSuccess) return api_fail(SBGPU_EHIP, std::string("sbgpu_matepairs_export: ") + hipGetErrorString(e));
+      return SBGPU_OK;
+   }
+   auto cp = [](void *dst, const void *src, size_t bytes) {
+      if (dst && bytes) std::memcpy(dst, src, bytes);
+   };
+   cp(pair_mass, m->pair_mass.data(), np * 8);
+   cp(left_off, m->left_off.data(), (np + 1) * 8);
+   cp(right_off, m->right_off.data(), (np + 1) * 8);
+   cp(left_code, m->left_code.data(), nl), cp(left_left, m->left_left.data(), nl * 4), cp(left_right, m->left_right.data(), nl * 4);
+   cp(right_code, m->right_code.data(), nr), cp(right_left, m->right_left.data(), nr * 4), cp(right_right, m->right_right.data(), nr * 4);
+   return SBGPU_OK;
+}
+
+} // extern "C"

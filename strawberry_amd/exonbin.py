@@ -96,6 +96,70 @@ def hit_features(left_blocks, right_blocks):
     return oc[:n].tolist(), ol[:n].tolist(), orr[:n].tolist()
 
 
+class Reads:
+    """Alignment records of a batch of clusters (sbgpu_reads_t), a cluster's records in the order the BAM gives them."""
+
+    def __init__(self, read_locus, read_id, blocks, partner_pos, flags, nh):
+        self.n_reads = len(blocks)
+        self.read_locus = np.asarray(read_locus, np.int32)
+        self.read_id = np.ascontiguousarray(read_id, np.uint64)
+        off, bl, br = [0], [], []
+        for b in blocks:
+            for (x, y) in b:
+                bl.append(x)
+                br.append(y)
+            off.append(len(bl))
+        self.block_off = np.asarray(off, np.int64)
+        self.block_left, self.block_right = np.asarray(bl, np.uint32), np.asarray(br, np.uint32)
+        self.partner_pos = np.ascontiguousarray(partner_pos, np.uint32)
+        self.flags = np.ascontiguousarray(flags, np.uint8)
+        self.nh = np.ascontiguousarray(nh, np.int32)
+
+
+def pair_mates(n_loci, reads, device=None):
+    """Alignment records -> read pairs: HitCluster::addOpenHit + addHit (sbgpu_pair_mates_host; `device`: an
+    em.Context -> sbgpu_pair_mates_device on uploaded records, results brought back for comparison).
+    -> dict(pair_off [n_loci + 1], mass, left_off, left (code, left, right), right_off, right (...), info)"""
+    L = _lib.load()
+    r = reads
+    off = np.searchsorted(r.read_locus, np.arange(n_loci + 1), side="left").astype(np.int64)
+    handle = C.c_void_p()
+    if device is None:
+        rs = _lib.sbgpu_reads_t(r.n_reads, _ptr(r.read_id), _ptr(r.block_off), _ptr(r.block_left), _ptr(r.block_right),
+                                _ptr(r.partner_pos), _ptr(r.flags), _ptr(r.nh))
+        _lib.check(L.sbgpu_pair_mates_host(n_loci, C.byref(rs), off.ctypes.data, C.byref(handle)), "sbgpu_pair_mates_host")
+        keep = None
+    else:
+        import torch
+        dev = torch.device("cuda", device.device)
+        def up(x):
+            x = x.view(np.int32) if x.dtype == np.uint32 else (x.view(np.int64) if x.dtype == np.uint64 else x)
+            return torch.from_numpy(np.ascontiguousarray(x)).to(dev) if x.size else torch.zeros(1, dtype=torch.int64, device=dev)
+        keep = [up(x) for x in (r.read_id, r.block_off, r.block_left, r.block_right, r.partner_pos, r.flags, r.nh)]
+        rs = _lib.sbgpu_reads_t(r.n_reads, *[t.data_ptr() for t in keep])
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(L.sbgpu_pair_mates_device(device.h, n_loci, C.byref(rs), off.ctypes.data, stream, C.byref(handle)), "sbgpu_pair_mates_device")
+    try:
+        info = (C.c_int64 * 8)()
+        _lib.check(L.sbgpu_matepairs_info(handle, info), "sbgpu_matepairs_info")
+        n_p, n_l, n_r = int(info[0]), int(info[5]), int(info[6])
+        p = _lib.sbgpu_pairs_t()
+        poff = C.c_void_p()
+        _lib.check(L.sbgpu_matepairs_pairs(handle, C.byref(p), C.byref(poff)), "sbgpu_matepairs_pairs")
+        pair_off = np.ctypeslib.as_array(C.cast(poff, C.POINTER(C.c_int64)), shape=(n_loci + 1,)).copy()
+        mass = np.zeros(n_p)
+        lo, ro = np.zeros(n_p + 1, np.int64), np.zeros(n_p + 1, np.int64)
+        lc, ll, lr = np.zeros(n_l, np.uint8), np.zeros(n_l, np.uint32), np.zeros(n_l, np.uint32)
+        rc, rl, rr = np.zeros(n_r, np.uint8), np.zeros(n_r, np.uint32), np.zeros(n_r, np.uint32)
+        _lib.check(L.sbgpu_matepairs_export(handle, _ptr(mass), lo.ctypes.data, _ptr(lc), _ptr(ll), _ptr(lr), ro.ctypes.data,
+                                            _ptr(rc), _ptr(rl), _ptr(rr)), "sbgpu_matepairs_export")
+    finally:
+        L.sbgpu_matepairs_destroy(handle)
+    return {"pair_off": pair_off, "mass": mass, "left_off": lo, "left": (lc, ll, lr), "right_off": ro, "right": (rc, rl, rr),
+            "info": {"pairs": n_p, "complete": int(info[1]), "single": int(info[2]), "refused": int(info[3]), "orphan": int(info[4]),
+                     "on_device": bool(info[7])}}
+
+
 def collapse_pairs(n_loci, pair_locus, pair_mass, left_blocks, right_blocks, device=None):
     """Aligned read pairs -> unique hits: HitCluster::collapseAndFilterHits + Contig(PairedHit)
     (sbgpu_collapse_pairs_host).  left_blocks / right_blocks: per pair the mate's aligned blocks [(l, r), ...]

@@ -1,0 +1,129 @@
+"""GPU tests of sbgpu_pair_mates_device (HitCluster::addOpenHit + addHit on the GPU, /root/reference/src/alignments.cpp:
+423-655, csrc/matepair_device.h) against the oracle (oracle/matepair_oracle.c, pinned to the reference's own HitCluster by
+tests/test_matepair_oracle.py) -- pairs in completion order, mates' features, masses, counts -- and the front of the
+path end to end ON THE DEVICE: alignment records -> pairs -> unique hits (sbgpu_collapse_pairs_device) must be the
+unique hits of the reference binary's toy runs, bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import e2e_util as U
+import exonbin_util as XU
+import matepair_util as MU
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from strawberry_amd import em
+    return em.default_context(0)
+
+
+def check_against_oracle(oracle, clusters, got):
+    from strawberry_amd import exonbin as eb
+    at = 0
+    tot = {"complete": 0, "single": 0, "refused": 0, "orphan": 0}
+    for l, c in enumerate(clusters):
+        ids, blocks, ppos, flags, nh = MU.arrays(c)
+        lr, rr, m, cnt = oracle.pair_mates(ids, blocks, ppos, flags, nh)
+        for k in tot:
+            tot[k] += cnt[k]
+        assert got["pair_off"][l + 1] - got["pair_off"][l] == len(lr), l
+        for i, j, mm in zip(lr, rr, m):
+            for side, rec in (("left", i), ("right", j)):
+                s = slice(int(got[side + "_off"][at]), int(got[side + "_off"][at + 1]))
+                code, fl, fr = (x[s] for x in got[side])
+                want = eb.mate_features(blocks[rec]) if rec >= 0 else ([], [], [])
+                assert ([int(x) for x in code], [int(x) for x in fl], [int(x) for x in fr]) == tuple(list(x) for x in want), (l, at, side)
+            assert got["mass"][at] == mm
+            at += 1
+    assert at == got["info"]["pairs"]
+    assert {k: got["info"][k] for k in tot} == tot
+
+
+def test_device_pairing_equals_oracle_random_clusters(ctx, oracle):
+    from strawberry_amd import exonbin as eb
+    rng = np.random.default_rng(11)
+    for trial in range(3):
+        n_loci = int(rng.integers(2, 30))
+        clusters = [MU.random_cluster(rng, int(rng.integers(0, 1500 if l == 1 else 200)), base=300000 * (l + 1)) for l in range(n_loci)]
+        loc = [l for l, c in enumerate(clusters) for _ in c]
+        reads = eb.Reads(loc, *MU.arrays([r for c in clusters for r in c]))
+        got = eb.pair_mates(n_loci, reads, device=ctx)
+        assert got["info"]["on_device"]
+        check_against_oracle(oracle, clusters, got)
+        host = eb.pair_mates(n_loci, reads)
+        for k in ("pair_off", "mass", "left_off", "right_off"):
+            np.testing.assert_array_equal(got[k], host[k], err_msg=k)
+        for side in ("left", "right"):
+            for x, y in zip(got[side], host[side]):
+                np.testing.assert_array_equal(x, y)
+
+
+def test_device_pairing_declines_oversize_cluster(ctx):
+    from strawberry_amd import _lib, exonbin as eb
+    n = 8193
+    reads = eb.Reads([0] * n, list(range(1, n + 1)), [[(1000 + k, 1074 + k)] for k in range(n)], [0] * n, [0] * n, [1] * n)
+    with pytest.raises(_lib.SbgpuError, match="8192"):
+        eb.pair_mates(1, reads, device=ctx)
+
+
+@pytest.mark.parametrize("which", ["E2E", "E2E_MASS", "E2E_MINUS"])
+def test_records_to_unique_hits_on_the_device_equal_reference_runs(ctx, which):
+    """Every sequenced copy of a toy run as two alignment records in BAM order -> sbgpu_pair_mates_device ->
+    sbgpu_collapse_pairs_device: the unique hits (features, masses) and the mapped-read total of the reference run."""
+    import torch
+    from strawberry_amd import _lib, exonbin as eb
+    d = getattr(U, which)
+    ordered, rows, _, _ = U.load(d)
+    annot, hits, names, rejected = XU.e2e_inputs(d, ordered)
+    z = dict(np.load(__import__("os").path.join(d, "reads.npz")))
+    genes = list(U.parse_annotation(__import__("os").path.join(d, "toy.gtf")))
+    strands = U.gene_strands(d)
+    locus_of = XU.locus_of_gene_index(d, names)
+    recs, rid = [], 0
+    for k in range(len(z["gene"])):
+        gi = int(z["gene"][k])
+        xs = 1 if strands[genes[gi]] == "+" else 2
+        left = [(int(a), int(b)) for a, b in zip(z["left_l"][z["left_off"][k]:z["left_off"][k + 1]], z["left_r"][z["left_off"][k]:z["left_off"][k + 1]])]
+        right = [(int(a), int(b)) for a, b in zip(z["right_l"][z["right_off"][k]:z["right_off"][k + 1]], z["right_r"][z["right_off"][k]:z["right_off"][k + 1]])]
+        for nh in z["nh"][z["nh_off"][k]:z["nh_off"][k + 1]]:
+            rid += 1
+            recs.append((locus_of[gi], left[0][0], {"id": rid, "blocks": left, "ppos": right[0][0], "flags": xs << 2, "nh": int(nh)}))
+            recs.append((locus_of[gi], right[0][0], {"id": rid, "blocks": right, "ppos": left[0][0], "flags": 1 | (xs << 2), "nh": int(nh)}))
+    recs.sort(key=lambda r: (r[0], r[1]))        # the BAM's order inside every cluster (stable)
+    reads = eb.Reads([r[0] for r in recs], *MU.arrays([r[2] for r in recs]))
+    L = _lib.load()
+    dev = torch.device("cuda", 0)
+    def up(x):
+        x = x.view(np.int32) if x.dtype == np.uint32 else (x.view(np.int64) if x.dtype == np.uint64 else x)
+        return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    keep = [up(x) for x in (reads.read_id, reads.block_off, reads.block_left, reads.block_right, reads.partner_pos, reads.flags, reads.nh)]
+    rs = _lib.sbgpu_reads_t(reads.n_reads, *[t.data_ptr() for t in keep])
+    off = np.searchsorted(reads.read_locus, np.arange(len(names) + 1), side="left").astype(np.int64)
+    mh = C.c_void_p()
+    _lib.check(L.sbgpu_pair_mates_device(ctx.h, len(names), C.byref(rs), off.ctypes.data, None, C.byref(mh)), "sbgpu_pair_mates_device")
+    dp = _lib.sbgpu_pairs_t()
+    poff = C.c_void_p()
+    _lib.check(L.sbgpu_matepairs_pairs(mh, C.byref(dp), C.byref(poff)), "sbgpu_matepairs_pairs")
+    uh = C.c_void_p()
+    _lib.check(L.sbgpu_collapse_pairs_device(ctx.h, len(names), C.byref(dp), poff, None, C.byref(uh)), "sbgpu_collapse_pairs_device")
+    info = (C.c_int64 * 8)()
+    _lib.check(L.sbgpu_uniq_dev_info(uh, info), "sbgpu_uniq_dev_info")
+    nh_, nf_ = int(info[0]), int(info[1])
+    hl, fo = np.zeros(nh_, np.int32), np.zeros(nh_ + 1, np.int64)
+    fc, fl, fr, ms = np.zeros(nf_, np.uint8), np.zeros(nf_, np.uint32), np.zeros(nf_, np.uint32), np.zeros(nh_, np.float32)
+    cm = np.zeros(len(names))
+    _lib.check(L.sbgpu_uniq_dev_export(uh, hl.ctypes.data, fo.ctypes.data, fc.ctypes.data, fl.ctypes.data, fr.ctypes.data, ms.ctypes.data,
+                                       cm.ctypes.data), "sbgpu_uniq_dev_export")
+    L.sbgpu_uniq_dev_destroy(uh)
+    L.sbgpu_matepairs_destroy(mh)
+    np.testing.assert_array_equal(hl, hits.hit_locus)
+    np.testing.assert_array_equal(fo, hits.feat_off)
+    np.testing.assert_array_equal(fc, hits.feat_code)
+    np.testing.assert_array_equal(fl, hits.feat_left)
+    np.testing.assert_array_equal(fr, hits.feat_right)
+    np.testing.assert_array_equal(ms, hits.mass)
+    assert int(info[4]) == rows[0]["total_mapped"] == hits.total_mapped
