@@ -454,7 +454,7 @@ int sbgpu_uniq_dev_export(const sbgpu_uniq_dev_t *u, int32_t *hit_locus, int64_t
  *     refused (:559-585, 630-641);
  *   - what still waits when the cluster is closed is dropped (clearOpenMates, :653).
  * Pair mass: the two reads' masses, 0.5 / NH each; a single read's 1 / NH (src/read.cpp:49-53).
- * The result is an sbgpu_pairs_t (mates as MATCH / INTRON feature lists, readhit_2_genomicFeats src/contig.cpp:12-53):
+ * The result has the layout of sbgpu_pairs_t -- mates as MATCH / INTRON feature lists (readhit_2_genomicFeats, src/contig.cpp:12-53) --:
  * the input of sbgpu_collapse_pairs_host / _device.  One difference a caller should know: the reference's cluster
  * keeps the span of EVERY accepted record for its span filter (:527), the collapse here sees the spans of the
  * mates of the pairs only -- records that never find their mate do not count.                                   */
