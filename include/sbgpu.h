@@ -440,6 +440,36 @@ int sbgpu_uniq_dev_hits(const sbgpu_uniq_dev_t *u, sbgpu_hits_t *d_hits, const f
 int sbgpu_uniq_dev_export(const sbgpu_uniq_dev_t *u, int32_t *hit_locus, int64_t *feat_off, uint8_t *feat_code,
                           uint32_t *feat_left, uint32_t *feat_right, float *hit_mass, double *cluster_mass);
 
+/* ---- cluster streaming: which cluster does an alignment record belong to ---------------
+ * Sample::nextClusterRefDemand (src/alignments.cpp:1145-1187, quant mode: the clusters are the annotation's genes, in
+ * annotation order = sorted by (reference, left)): ONE forward pass over the position-sorted records.  For cluster k
+ * the pass resumes where cluster k - 1 stopped; a record that ends before the cluster begins (or lies on an earlier
+ * reference) is skipped for good (hit_lt_cluster, :32-37); a record that begins behind the cluster's end (or on a
+ * later reference) ends the cluster and is looked at again for the next one (hit_gt_cluster, :39-49); of the others,
+ * those whose transcription strand (XS) is known and differs from the cluster's are dropped, the rest join the
+ * cluster (addOpenHit).  A record is therefore offered to exactly one cluster -- the first whose end it does not
+ * lie behind -- even where genes overlap.
+ *   clusters (HOST arrays): reference id, [left, right] and strand (1 +, 2 -, 0 unknown) of every cluster, in order;
+ *   records: reference id, first and last aligned base, flags (bits 2-3: XS strand as in sbgpu_reads_t), sorted by
+ *   (reference, left) as the BAM is.
+ * Out: read_cluster[i] = the record's cluster or -1, and cluster_read_off[n_clusters + 1] (host): cluster k was offered
+ * the records [off[k], off[k + 1]) -- the ones with read_cluster == k among them are its members, in arrival order;
+ * with `flags_inout` given, the others get SBGPU_READ_SKIP set, so that range is sbgpu_pair_mates_*'s input as it
+ * stands.  Device form: one binary search per cluster, a prefix maximum on the host (clusters are few), one binary
+ * search per record.                                                                                            */
+typedef struct {
+   int64_t n_clusters;
+   const int32_t *ref;
+   const uint32_t *left, *right;
+   const uint8_t *strand;
+} sbgpu_clusters_t;
+#define SBGPU_READ_SKIP 16u /* (sbgpu_reads_t.flags) the record is not this cluster's: sbgpu_pair_mates_* pass over it */
+int sbgpu_assign_reads_host(const sbgpu_clusters_t *clusters, int64_t n_reads, const int32_t *read_ref, const uint32_t *read_left,
+                            const uint32_t *read_right, uint8_t *flags_inout, int32_t *read_cluster, int64_t *cluster_read_off);
+int sbgpu_assign_reads_device(sbgpu_ctx_t *ctx, const sbgpu_clusters_t *clusters, int64_t n_reads, const int32_t *d_read_ref,
+                              const uint32_t *d_read_left, const uint32_t *d_read_right, uint8_t *d_flags_inout,
+                              int32_t *d_read_cluster, int64_t *cluster_read_off, void *stream);
+
 /* ---- mate pairing: alignment records -> read pairs --------------------------------------
  * HitCluster::addOpenHit + addHit (src/alignments.cpp:423-655): the records of a cluster, in the order the
  * position-sorted BAM gives them, become PairedHits.

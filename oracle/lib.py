@@ -120,6 +120,18 @@ class OracleLib:
         _u64 = _p(np.uint64, flags="C")
         L.sbo_pair_mates.argtypes = [C.c_int, _u64, _i64, _u32, _u32, _u32, _p(np.uint8, flags="C"), _i32, _i32, _i32, _f64, _i32]
         L.sbo_pair_mates.restype = C.c_int
+        L.sbo_assign_reads.argtypes = [C.c_int, _i32, _u32, _u32, _p(np.uint8, flags="C"), C.c_int64, _i32, _u32, _u32, _p(np.uint8, flags="C"),
+                                       _i32, _i64]
+        L.sbo_assign_reads.restype = None
+
+    def assign_reads(self, c_ref, c_left, c_right, c_strand, r_ref, r_left, r_right, r_xs):
+        """Sample::nextClusterRefDemand's pass.  -> (read_cluster int32[n_reads], off int64[n_clusters + 1])"""
+        nc, nr = len(c_ref), len(r_ref)
+        out, off = np.zeros(max(nr, 1), np.int32), np.zeros(nc + 1, np.int64)
+        a = lambda x, t: np.ascontiguousarray(x if len(x) else [0], t)  # noqa: E731
+        self.L.sbo_assign_reads(nc, a(c_ref, np.int32), a(c_left, np.uint32), a(c_right, np.uint32), a(c_strand, np.uint8), nr,
+                                a(r_ref, np.int32), a(r_left, np.uint32), a(r_right, np.uint32), a(r_xs, np.uint8), out, off)
+        return out[:nr].copy(), off
 
     # ---- mate pairing (HitCluster::addOpenHit + addHit)
     def pair_mates(self, read_id, blocks, partner_pos, flags, nh):

@@ -77,3 +77,35 @@ int sbo_pair_mates(int n_reads, const uint64_t *read_id, const int64_t *block_of
    free(open);
    return n_pairs;
 }
+
+/* The read stream of quant mode (Sample::nextClusterRefDemand, src/alignments.cpp:1145-1187), as the loop it is:
+ * `cur` is the hit factory's position; a cluster takes records until one lies behind it (that one is "rewound":
+ * looked at again by the next cluster). */
+void sbo_assign_reads(int n_clusters, const int32_t *c_ref, const uint32_t *c_left, const uint32_t *c_right, const uint8_t *c_strand,
+                      int64_t n_reads, const int32_t *r_ref, const uint32_t *r_left, const uint32_t *r_right, const uint8_t *r_xs,
+                      int32_t *read_cluster, int64_t *off)
+{
+   for (int64_t i = 0; i < n_reads; ++i) read_cluster[i] = -1;
+   int64_t cur = 0;
+   for (int k = 0; k < n_clusters; ++k) {
+      off[k] = cur;
+      while (cur < n_reads) { /* recordsRemain() */
+         const int64_t i = cur++;
+         /* hit_lt_cluster(hit, cluster, 0), alignments.cpp:32-37 */
+         const int lt = r_ref[i] != c_ref[k] ? r_ref[i] < c_ref[k] : r_right[i] < c_left[k];
+         /* hit_gt_cluster(hit, cluster, 0), :39-49 */
+         const int gt = r_ref[i] != c_ref[k] ? r_ref[i] > c_ref[k] : r_left[i] > c_right[k];
+         if (lt) {
+            /* the hit lies before this region: passed over */
+         } else if (gt) {
+            --cur; /* rewindHit() */
+            break;
+         } else if (r_xs[i] != 0 && r_xs[i] != c_strand[k]) {
+            /* :1168: a known strand other than the cluster's */
+         } else {
+            read_cluster[i] = k; /* clusterOut.addOpenHit(new_hit, false, false) */
+         }
+      }
+   }
+   off[n_clusters] = cur;
+}

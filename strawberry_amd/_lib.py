@@ -23,7 +23,7 @@ SYMBOLS = [
     "sbgpu_device_info", "sbgpu_synchronize", "sbgpu_plan_create", "sbgpu_plan_destroy", "sbgpu_plan_info",
     "sbgpu_plan_classes", "sbgpu_plan_locus_kinds", "sbgpu_em_run_device", "sbgpu_em_run_device_f32", "sbgpu_em_run_device_bias", "sbgpu_em_run_device_bias_f32", "sbgpu_em_last_kernel_ms",
     "sbgpu_set_timing", "sbgpu_em_last_phase_ms", "sbgpu_last_stage_ms", "sbgpu_pair_mates_host", "sbgpu_pair_mates_device", "sbgpu_matepairs_destroy", "sbgpu_matepairs_info",
-    "sbgpu_matepairs_pairs", "sbgpu_matepairs_export",
+    "sbgpu_matepairs_pairs", "sbgpu_matepairs_export", "sbgpu_assign_reads_host", "sbgpu_assign_reads_device",
     "sbgpu_comm_unique_id", "sbgpu_comm_init", "sbgpu_comm_info", "sbgpu_comm_destroy",
     "sbgpu_allreduce_sum_f64", "sbgpu_allreduce_sum_i64", "sbgpu_allreduce_sum_f64_host", "sbgpu_allreduce_sum_i64_host",
     "sbgpu_insert_pdf_table", "sbgpu_binweight_device", "sbgpu_binweight_host",
@@ -93,6 +93,10 @@ class sbgpu_pairs_t(C.Structure):
     _fields_ = [(n, C.c_int64 if n == "n_pairs" else C.c_void_p) for n in (
         "n_pairs", "pair_locus", "pair_mass", "left_off", "left_code", "left_left", "left_right", "right_off", "right_code",
         "right_left", "right_right")]
+
+
+class sbgpu_clusters_t(C.Structure):
+    _fields_ = [("n_clusters", C.c_int64), ("ref", C.c_void_p), ("left", C.c_void_p), ("right", C.c_void_p), ("strand", C.c_void_p)]
 
 
 class sbgpu_reads_t(C.Structure):
@@ -200,6 +204,8 @@ def load():
     L.sbgpu_matepairs_info.argtypes = [vp, i64p]
     L.sbgpu_matepairs_pairs.argtypes = [vp, C.POINTER(sbgpu_pairs_t), C.POINTER(vp)]
     L.sbgpu_matepairs_export.argtypes = [vp] * 10
+    L.sbgpu_assign_reads_host.argtypes = [C.POINTER(sbgpu_clusters_t), C.c_int64, vp, vp, vp, vp, vp, vp]
+    L.sbgpu_assign_reads_device.argtypes = [vp, C.POINTER(sbgpu_clusters_t), C.c_int64, vp, vp, vp, vp, vp, vp, vp]
     L.sbgpu_uniq_dev_destroy.argtypes = [vp]
     L.sbgpu_uniq_dev_destroy.restype = None
     L.sbgpu_uniq_dev_info.argtypes = [vp, i64p]

@@ -98,6 +98,7 @@ int sbgpu_pair_mates_host(int64_t n_loci, const sbgpu_reads_t *rd, const int64_t
          std::unordered_map<uint64_t, std::vector<int64_t>> open; // HitCluster::_open_mates: read id -> waiting records, oldest first
          for (int64_t r = locus_read_off[l]; r < locus_read_off[l + 1]; ++r) {
             const int64_t b0 = rd->block_off[r], b1 = rd->block_off[r + 1];
+            if (rd->flags[r] & SBGPU_READ_SKIP) continue; // not this cluster's record (sbgpu_assign_reads_*)
             if (b1 <= b0) {
                ++M->n_refused;
                continue;
@@ -292,6 +293,113 @@ int sbgpu_pair_mates_device(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t 
 #undef SB_TRY
    (void)hipFree(w);
    *out = M;
+   return SBGPU_OK;
+}
+
+// ---- cluster streaming
+static int check_clusters(const sbgpu_clusters_t *cl, const char *who)
+{
+   if (!cl || cl->n_clusters < 0 || (cl->n_clusters && (!cl->ref || !cl->left || !cl->right || !cl->strand)))
+      return api_fail(SBGPU_EINVAL, std::string(who) + ": bad clusters");
+   for (int64_t k = 0; k + 1 < cl->n_clusters; ++k)
+      if (cl->ref[k] > cl->ref[k + 1] || (cl->ref[k] == cl->ref[k + 1] && cl->left[k] > cl->left[k + 1]))
+         return api_fail(SBGPU_EINVAL, std::string(who) + ": clusters must come sorted by (reference, left)");
+   return SBGPU_OK;
+}
+
+int sbgpu_assign_reads_host(const sbgpu_clusters_t *cl, int64_t n_reads, const int32_t *read_ref, const uint32_t *read_left,
+                            const uint32_t *read_right, uint8_t *flags, int32_t *read_cluster, int64_t *off)
+{
+   const int rc = check_clusters(cl, "sbgpu_assign_reads_host");
+   if (rc != SBGPU_OK) return rc;
+   if (n_reads < 0 || !off || (n_reads && (!read_ref || !read_left || !read_right || !read_cluster)))
+      return api_fail(SBGPU_EINVAL, "sbgpu_assign_reads_host: null argument");
+   auto key = [](int32_t ref, uint32_t pos) { return ((uint64_t)(uint32_t)ref << 32) | pos; };
+   // where every cluster's pass begins: the prefix maximum of "first record behind the cluster's end"
+   off[0] = 0;
+   for (int64_t k = 0; k < cl->n_clusters; ++k) {
+      const uint64_t end = key(cl->ref[k], cl->right[k]);
+      int64_t lo = 0, hi = n_reads;
+      while (lo < hi) {
+         const int64_t mid = (lo + hi) >> 1;
+         if (key(read_ref[mid], read_left[mid]) <= end) lo = mid + 1;
+         else hi = mid;
+      }
+      off[k + 1] = std::max(off[k], lo);
+   }
+   for (int64_t k = 0; k < cl->n_clusters; ++k)
+      for (int64_t i = off[k]; i < off[k + 1]; ++i) {
+         const bool lt = read_ref[i] < cl->ref[k] || (read_ref[i] == cl->ref[k] && read_right[i] < cl->left[k]);
+         const int xs = flags ? (flags[i] >> 2) & 3 : 0;
+         const bool strand_off = xs != 0 && xs != (int)cl->strand[k];
+         read_cluster[i] = (lt || strand_off) ? -1 : (int32_t)k;
+      }
+   for (int64_t i = cl->n_clusters ? off[cl->n_clusters] : 0; i < n_reads; ++i) read_cluster[i] = -1;
+   if (flags)
+      for (int64_t i = 0; i < n_reads; ++i)
+         if (read_cluster[i] < 0) flags[i] |= SBGPU_READ_SKIP;
+   return SBGPU_OK;
+}
+
+int sbgpu_assign_reads_device(sbgpu_ctx_t *c, const sbgpu_clusters_t *cl, int64_t n_reads, const int32_t *d_ref, const uint32_t *d_left,
+                              const uint32_t *d_right, uint8_t *d_flags, int32_t *d_read_cluster, int64_t *off, void *stream)
+{
+   const int rc = check_clusters(cl, "sbgpu_assign_reads_device");
+   if (rc != SBGPU_OK) return rc;
+   if (!c || n_reads < 0 || !off || (n_reads && (!d_ref || !d_left || !d_right || !d_read_cluster)))
+      return api_fail(SBGPU_EINVAL, "sbgpu_assign_reads_device: null argument");
+   const int64_t nc = cl->n_clusters;
+   off[0] = 0;
+   if (nc == 0 || n_reads == 0) {
+      for (int64_t k = 0; k < nc; ++k) off[k + 1] = 0;
+      if (n_reads) {
+         hipError_t e = hipMemsetAsync(d_read_cluster, 0xFF, (size_t)n_reads * 4, (hipStream_t)stream);
+         if (e != hipSuccess) return api_fail(SBGPU_EHIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e));
+      }
+      return SBGPU_OK;
+   }
+   hipStream_t s = (hipStream_t)stream;
+   char *w = nullptr;
+   const size_t nc1 = (size_t)nc + 1;
+   size_t t = 0;
+   const size_t o_ref = t; t += up256(nc1 * 4);
+   const size_t o_left = t; t += up256(nc1 * 4);
+   const size_t o_right = t; t += up256(nc1 * 4);
+   const size_t o_strand = t; t += up256(nc1);
+   const size_t o_ub = t; t += up256(nc1 * 8);
+   const size_t o_pos = t; t += up256(nc1 * 8);
+   hipError_t e = sb::ctx_scratch(c, 5, t, &w);
+   if (e != hipSuccess) return api_fail(e == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+#define SB_TRY(expr)                                                                                        \
+   do {                                                                                                     \
+      hipError_t e_ = (expr);                                                                               \
+      if (e_ != hipSuccess) return api_fail(SBGPU_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+   } while (0)
+   SB_TRY(hipMemcpyAsync(w + o_ref, cl->ref, (size_t)nc * 4, hipMemcpyHostToDevice, s));
+   SB_TRY(hipMemcpyAsync(w + o_left, cl->left, (size_t)nc * 4, hipMemcpyHostToDevice, s));
+   SB_TRY(hipMemcpyAsync(w + o_right, cl->right, (size_t)nc * 4, hipMemcpyHostToDevice, s));
+   SB_TRY(hipMemcpyAsync(w + o_strand, cl->strand, (size_t)nc, hipMemcpyHostToDevice, s));
+   sb::AssignArgs a = {};
+   a.n_clusters = nc, a.n_reads = n_reads;
+   a.c_ref = (const int32_t *)(w + o_ref);
+   a.c_left = (const uint32_t *)(w + o_left), a.c_right = (const uint32_t *)(w + o_right);
+   a.c_strand = (const uint8_t *)(w + o_strand);
+   a.r_ref = d_ref, a.r_left = d_left, a.r_right = d_right, a.r_flags = d_flags;
+   a.ub = (int64_t *)(w + o_ub);
+   a.pos = (const int64_t *)(w + o_pos);
+   a.read_cluster = d_read_cluster;
+   hipLaunchKernelGGL(sb::cluster_bounds_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, a);
+   SB_TRY(hipGetLastError());
+   std::vector<int64_t> ub((size_t)nc);
+   SB_TRY(hipMemcpyAsync(ub.data(), w + o_ub, (size_t)nc * 8, hipMemcpyDeviceToHost, s));
+   SB_TRY(hipStreamSynchronize(s));
+   for (int64_t k = 0; k < nc; ++k) off[k + 1] = std::max(off[k], ub[(size_t)k]); // the pass never goes back
+   SB_TRY(hipMemcpyAsync(w + o_pos, off, nc1 * 8, hipMemcpyHostToDevice, s));
+   const int64_t blocks = std::min<int64_t>((n_reads + 255) / 256, (int64_t)sb::ctx_cu_count(c) * 32);
+   hipLaunchKernelGGL(sb::assign_reads_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+   SB_TRY(hipGetLastError());
+   SB_TRY(hipStreamSynchronize(s)); // (`off` was read from host memory)
+#undef SB_TRY
    return SBGPU_OK;
 }
 

@@ -142,6 +142,10 @@ __global__ __launch_bounds__(kMateThreads) void matepair_locus_kernel(MateArgs a
             const uint32_t left = b1 > b0 ? a.block_left[b0] : 0u, right = b1 > b0 ? a.block_right[b1 - 1] : 0u;
             const uint32_t ppos = a.partner_pos[r];
             const uint8_t fl = a.flags[r];
+            if (fl & 16u) { // not this cluster's record (sbgpu_assign_reads_*): never offered to addOpenHit
+               a.fate[r] = kRecRefused;
+               continue;
+            }
             if (b1 <= b0 || (int64_t)right - (int64_t)left > kMaxFragSpanDev) { // :512-518
                a.fate[r] = kRecRefused;
                ++my_refused;
@@ -289,6 +293,58 @@ __global__ __launch_bounds__(kMateThreads) void matepair_fill_kernel(MateArgs a)
          a.pair_mass[p0 + k] = m;
       }
       __syncthreads();
+   }
+}
+
+// ------------------------------------------------------------------ cluster streaming (sbgpu_assign_reads_device)
+struct AssignArgs {
+   int64_t n_clusters, n_reads;
+   const int32_t *c_ref;
+   const uint32_t *c_left, *c_right;
+   const uint8_t *c_strand;
+   const int32_t *r_ref;
+   const uint32_t *r_left, *r_right;
+   uint8_t *r_flags; // may be null
+   int64_t *ub;            // [n_clusters] first record behind the cluster's end
+   const int64_t *pos;     // [n_clusters + 1] where every cluster's pass begins (prefix maximum of ub)
+   int32_t *read_cluster;
+};
+__device__ __forceinline__ unsigned long long ref_pos_key(int32_t ref, uint32_t pos) { return ((unsigned long long)(uint32_t)ref << 32) | pos; }
+
+__global__ __launch_bounds__(256) void cluster_bounds_kernel(AssignArgs a)
+{
+   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (k >= a.n_clusters) return;
+   const unsigned long long end = ref_pos_key(a.c_ref[k], a.c_right[k]);
+   int64_t lo = 0, hi = a.n_reads; // first record with (ref, left) > (cluster ref, cluster right): hit_gt_cluster
+   while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (ref_pos_key(a.r_ref[mid], a.r_left[mid]) <= end) lo = mid + 1;
+      else hi = mid;
+   }
+   a.ub[k] = lo;
+}
+
+__global__ __launch_bounds__(256) void assign_reads_kernel(AssignArgs a)
+{
+   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_reads; i += stride) {
+      int32_t c = -1;
+      if (i < a.pos[a.n_clusters]) {
+         int64_t lo = 0, hi = a.n_clusters; // the last cluster whose pass begins at or before record i and is not empty there
+         while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (a.pos[mid + 1] <= i) lo = mid + 1;
+            else hi = mid;
+         }
+         const int64_t k = lo; // pos[k] <= i < pos[k + 1]
+         const bool lt = a.r_ref[i] < a.c_ref[k] || (a.r_ref[i] == a.c_ref[k] && a.r_right[i] < a.c_left[k]); // hit_lt_cluster
+         const int xs = a.r_flags ? (a.r_flags[i] >> 2) & 3 : 0;
+         const bool strand_off = xs != 0 && xs != (int)a.c_strand[k]; // alignments.cpp:1168
+         if (!lt && !strand_off) c = (int32_t)k;
+      }
+      a.read_cluster[i] = c;
+      if (a.r_flags && c < 0) a.r_flags[i] |= 16u;
    }
 }
 

@@ -116,6 +116,33 @@ class Reads:
         self.nh = np.ascontiguousarray(nh, np.int32)
 
 
+def assign_reads(c_ref, c_left, c_right, c_strand, r_ref, r_left, r_right, flags, device=None):
+    """Which cluster a position-sorted alignment record belongs to (Sample::nextClusterRefDemand's pass):
+    sbgpu_assign_reads_host, or -- device: an em.Context -- sbgpu_assign_reads_device on uploaded records.
+    -> (read_cluster int32[n_reads], cluster_read_off int64[n_clusters + 1], flags with SBGPU_READ_SKIP set on the others)"""
+    L = _lib.load()
+    c_ref, c_left, c_right = (np.ascontiguousarray(x, t) for x, t in ((c_ref, np.int32), (c_left, np.uint32), (c_right, np.uint32)))
+    c_strand = np.ascontiguousarray(c_strand, np.uint8)
+    r_ref, r_left, r_right = (np.ascontiguousarray(x, t) for x, t in ((r_ref, np.int32), (r_left, np.uint32), (r_right, np.uint32)))
+    flags = np.ascontiguousarray(flags, np.uint8).copy()
+    cl = _lib.sbgpu_clusters_t(len(c_ref), _ptr(c_ref), _ptr(c_left), _ptr(c_right), _ptr(c_strand))
+    n = len(r_ref)
+    out, off = np.zeros(max(n, 1), np.int32), np.zeros(len(c_ref) + 1, np.int64)
+    if device is None:
+        _lib.check(L.sbgpu_assign_reads_host(C.byref(cl), n, _ptr(r_ref), _ptr(r_left), _ptr(r_right), _ptr(flags), out.ctypes.data,
+                                             off.ctypes.data), "sbgpu_assign_reads_host")
+        return out[:n], off, flags
+    import torch
+    dev = torch.device("cuda", device.device)
+    up = lambda x: torch.from_numpy(x.view(np.int32) if x.dtype == np.uint32 else x).to(dev) if x.size else torch.zeros(1, dtype=torch.int32, device=dev)  # noqa: E731
+    d_ref, d_left, d_right, d_flags = up(r_ref), up(r_left), up(r_right), up(flags)
+    d_out = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
+    _lib.check(L.sbgpu_assign_reads_device(device.h, C.byref(cl), n, d_ref.data_ptr(), d_left.data_ptr(), d_right.data_ptr(),
+                                           d_flags.data_ptr(), d_out.data_ptr(), off.ctypes.data,
+                                           C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "sbgpu_assign_reads_device")
+    return d_out.cpu().numpy()[:n], off, d_flags.cpu().numpy()[:n]
+
+
 def pair_mates(n_loci, reads, device=None):
     """Alignment records -> read pairs: HitCluster::addOpenHit + addHit (sbgpu_pair_mates_host; `device`: an
     em.Context -> sbgpu_pair_mates_device on uploaded records, results brought back for comparison).

@@ -70,7 +70,7 @@ def test_device_pairing_declines_oversize_cluster(ctx):
         eb.pair_mates(1, reads, device=ctx)
 
 
-@pytest.mark.parametrize("which", ["E2E", "E2E_MASS", "E2E_MINUS"])
+@pytest.mark.parametrize("which", ["E2E", "E2E_MASS", "E2E_MINUS", "E2E_CHROMS"])
 def test_records_to_unique_hits_on_the_device_equal_reference_runs(ctx, which):
     """Every sequenced copy of a toy run as two alignment records in BAM order -> sbgpu_pair_mates_device ->
     sbgpu_collapse_pairs_device: the unique hits (features, masses) and the mapped-read total of the reference run."""
@@ -93,8 +93,26 @@ def test_records_to_unique_hits_on_the_device_equal_reference_runs(ctx, which):
             rid += 1
             recs.append((locus_of[gi], left[0][0], {"id": rid, "blocks": left, "ppos": right[0][0], "flags": xs << 2, "nh": int(nh)}))
             recs.append((locus_of[gi], right[0][0], {"id": rid, "blocks": right, "ppos": left[0][0], "flags": 1 | (xs << 2), "nh": int(nh)}))
-    recs.sort(key=lambda r: (r[0], r[1]))        # the BAM's order inside every cluster (stable)
-    reads = eb.Reads([r[0] for r in recs], *MU.arrays([r[2] for r in recs]))
+    # the BAM's order: (chromosome, position), stable.  Which cluster a record joins is NOT taken from the simulation:
+    # the device's read stream (sbgpu_assign_reads_device: Sample::nextClusterRefDemand's pass over the genes of the
+    # annotation) must find it
+    chroms = U.gene_chroms(d)
+    chrom_id = {c: i for i, c in enumerate(sorted(set(chroms.values())))}
+    gene_of_locus = names
+    ref_of = [chrom_id[chroms[g]] for g in gene_of_locus]
+    recs = [(ref_of[r[0]], r[1], r[0], r[2]) for r in recs]
+    recs.sort(key=lambda r: (r[0], r[1]))
+    c_left = [min(e[0] for _, ex in ordered[g] for e in ex) for g in gene_of_locus]
+    c_right = [max(e[1] for _, ex in ordered[g] for e in ex) for g in gene_of_locus]
+    c_strand = [1 if strands[g] == "+" else 2 for g in gene_of_locus]
+    assert all((ref_of[k], c_left[k]) <= (ref_of[k + 1], c_left[k + 1]) for k in range(len(names) - 1))   # the reference's cluster order
+    r_right = [r[3]["blocks"][-1][1] for r in recs]
+    got_cluster, stream_off, stream_flags = eb.assign_reads(ref_of, c_left, c_right, c_strand, [r[0] for r in recs], [r[1] for r in recs],
+                                                            r_right, [r[3]["flags"] for r in recs], device=ctx)
+    np.testing.assert_array_equal(got_cluster, [r[2] for r in recs])          # every record reaches its gene's cluster
+    for r, f in zip(recs, stream_flags):
+        r[3]["flags"] = int(f)
+    reads = eb.Reads(got_cluster, *MU.arrays([r[3] for r in recs]))
     L = _lib.load()
     dev = torch.device("cuda", 0)
     def up(x):
@@ -102,7 +120,8 @@ def test_records_to_unique_hits_on_the_device_equal_reference_runs(ctx, which):
         return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
     keep = [up(x) for x in (reads.read_id, reads.block_off, reads.block_left, reads.block_right, reads.partner_pos, reads.flags, reads.nh)]
     rs = _lib.sbgpu_reads_t(reads.n_reads, *[t.data_ptr() for t in keep])
-    off = np.searchsorted(reads.read_locus, np.arange(len(names) + 1), side="left").astype(np.int64)
+    off = np.ascontiguousarray(stream_off, np.int64)       # the ranges the stream offered to the clusters
+    assert off[-1] == reads.n_reads
     mh = C.c_void_p()
     _lib.check(L.sbgpu_pair_mates_device(ctx.h, len(names), C.byref(rs), off.ctypes.data, None, C.byref(mh)), "sbgpu_pair_mates_device")
     dp = _lib.sbgpu_pairs_t()
@@ -127,3 +146,17 @@ def test_records_to_unique_hits_on_the_device_equal_reference_runs(ctx, which):
     np.testing.assert_array_equal(fr, hits.feat_right)
     np.testing.assert_array_equal(ms, hits.mass)
     assert int(info[4]) == rows[0]["total_mapped"] == hits.total_mapped
+
+
+def test_device_read_stream_equals_oracle(ctx, oracle):
+    from strawberry_amd import exonbin as eb
+    from test_matepair_oracle import stream_case
+    rng = np.random.default_rng(4)
+    for trial in range(6):
+        case = stream_case(rng, int(rng.integers(1, 400)), int(rng.integers(0, 200000)), refs=3)
+        want, woff = oracle.assign_reads(*case)
+        flags = [x << 2 for x in case[7]]
+        got, off, fl = eb.assign_reads(*case[:7], flags, device=ctx)
+        np.testing.assert_array_equal(got, want)
+        np.testing.assert_array_equal(off, woff)
+        np.testing.assert_array_equal((fl & 16) != 0, want < 0)

@@ -76,3 +76,39 @@ def test_product_host_pairing_equals_oracle(oracle):
             at += 1
     assert at == got["info"]["pairs"]
     assert {k: got["info"][k] for k in tot} == tot
+
+
+def stream_case(rng, n_clusters, n_reads, refs=2):
+    """Genes (some overlapping, some on another reference, either strand) and position-sorted records around them."""
+    c = sorted((int(rng.integers(0, refs)), int(rng.integers(1000, 60000))) for _ in range(n_clusters))
+    c_ref = [x[0] for x in c]
+    c_left = [x[1] for x in c]
+    c_right = [l + int(rng.integers(200, 6000)) for l in c_left]
+    c_strand = [int(rng.choice([1, 2, 1, 2, 0])) for _ in c]
+    r = sorted((int(rng.integers(0, refs + 1)), int(rng.integers(1, 70000))) for _ in range(n_reads))
+    r_ref = [x[0] for x in r]
+    r_left = [x[1] for x in r]
+    r_right = [l + int(rng.choice([74, 74, 300, 2500])) for l in r_left]
+    r_xs = [int(rng.choice([1, 2, 0, 0])) for _ in r]
+    return c_ref, c_left, c_right, c_strand, r_ref, r_left, r_right, r_xs
+
+
+def test_oracle_read_stream_known_case(oracle):
+    # two overlapping genes on one reference: a record is offered to the first cluster whose end it does not lie behind
+    got, off = oracle.assign_reads([0, 0], [100, 300], [500, 900], [1, 1],
+                                   [0, 0, 0, 0, 0, 0], [10, 90, 350, 501, 700, 950], [84, 164, 424, 575, 774, 1024], [0, 1, 2, 0, 1, 0])
+    #          before gene 1 | overlaps 1 | strand - in a + gene | behind gene 1: gene 2 | gene 2 | behind everything
+    assert list(got) == [-1, 0, -1, 1, 1, -1] and list(off) == [0, 3, 5]
+
+
+def test_product_host_read_stream_equals_oracle(oracle):
+    from strawberry_amd import exonbin as eb
+    rng = np.random.default_rng(3)
+    for trial in range(30):
+        case = stream_case(rng, int(rng.integers(0, 40)), int(rng.integers(0, 3000)))
+        want, woff = oracle.assign_reads(*case)
+        flags = [x << 2 for x in case[7]]
+        got, off, fl = eb.assign_reads(*case[:7], flags)
+        np.testing.assert_array_equal(got, want)
+        np.testing.assert_array_equal(off, woff)
+        np.testing.assert_array_equal((fl & 16) != 0, want < 0)
