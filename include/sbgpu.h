@@ -591,6 +591,16 @@ int sbgpu_quantify_host(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *annot, const
                         const float *hit_mass, const sbgpu_insert_t *insert, int32_t read_len,
                         int32_t long_read, double *theta_out, int32_t *status_out, int32_t *iters_out,
                         uint32_t *compat_out, sbgpu_insert_t *insert_used, sbgpu_bins_t **bins_out);
+/* Keep an annotation resident.  The reference reads its GTF once and streams the reads past it
+ * (src/Strawberry.cpp:245-275: one GffReader, loadRefmRNAs; :359: Sample::procSample over every cluster); a driver that calls
+ * sbgpu_quantify_host / _device batch after batch against the same annotation pins it once: the arrays are uploaded
+ * now, the tables the chain makes of an annotation alone (the isoforms' segment lists, the widest locus) are made
+ * now, and every later call on this context that is given an annotation with the SAME counts and array addresses uses
+ * them instead of uploading 10+ MB and rebuilding the tables per call.  The caller must not change the arrays while
+ * they are pinned (they are not compared).  One annotation per context: pinning another replaces it; unpin (or
+ * sbgpu_destroy) releases it.  Results are those of the unpinned call, bit for bit.                                    */
+int sbgpu_annotation_pin(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *annot);
+int sbgpu_annotation_unpin(sbgpu_ctx_t *ctx);
 /* The same chain for hits that are in HBM already (a driver that decodes or collapses on the device, or
  * that quantifies the same fragments again): d_hits' arrays and d_hit_mass are DEVICE pointers, grouped by
  * locus as locus_hit_off[n_loci + 1] (host) says and sorted inside a locus like HitCluster's uniq_hits();

@@ -216,7 +216,7 @@ class ChainQuantifier:
     """step(): fragments (in HBM) -> compat / key words -> bins -> weights -> EM -> theta, one C-ABI call;
     then FPKM / TPM on the host arrays the call returns (the caller's own epilogue, as in the reference)."""
 
-    def __init__(self, ctx, n_loci=60000, n_frags=2e8, seed=31, read_len=75, loci_subset=None):
+    def __init__(self, ctx, n_loci=60000, n_frags=2e8, seed=31, read_len=75, loci_subset=None, pin=True):
         import torch
         self.torch, self.ctx = torch, ctx
         self.dev = torch.device("cuda", ctx.device)
@@ -234,6 +234,10 @@ class ChainQuantifier:
         self._ht = self.hits.struct()
         self._ins = self.insert._struct(read_len)
         self.info = None
+        # the annotation is read once and the reads stream past it (Strawberry.cpp:245-275, :359): kept resident
+        self.pinned = bool(pin)
+        if pin:
+            _lib.check(ctx.L.sbgpu_annotation_pin(ctx.h, C.byref(self._an)), "sbgpu_annotation_pin")
 
     def step(self):
         h = C.c_void_p()
@@ -263,4 +267,6 @@ class ChainQuantifier:
             L.sbgpu_set_timing(self.ctx.h, 0)
 
     def finish(self):
-        pass
+        if self.pinned:
+            self.ctx.L.sbgpu_annotation_unpin(self.ctx.h)
+            self.pinned = False

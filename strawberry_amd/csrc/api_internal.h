@@ -5,16 +5,41 @@
 #include <hip/hip_runtime.h>
 
 #include <functional>
+#include <memory>
 #include <string>
 #include <vector>
 
 #include "../../include/sbgpu.h"
 
 namespace sb {
+// A vector whose resize() leaves new elements uninitialised: the targets of device-to-host copies of tens of MB,
+// where the zero fill of std::vector costs as much as the copy.
+template <class T>
+struct DefaultInitAlloc : std::allocator<T> {
+   template <class U>
+   struct rebind {
+      using other = DefaultInitAlloc<U>;
+   };
+   using std::allocator<T>::allocator;
+   template <class U>
+   void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value)
+   {
+      ::new ((void *)p) U;
+   }
+   template <class U, class... A>
+   void construct(U *p, A &&...a)
+   {
+      ::new ((void *)p) U(std::forward<A>(a)...);
+   }
+};
+template <class T>
+using PodVec = std::vector<T, DefaultInitAlloc<T>>;
+
 // (bin, isoform) pairs made on the device (bins_device.h): sbgpu_binweight_device's inputs in one arena.
 // A bins handle that holds them downloads them only when somebody exports the pair arrays.
 struct DevicePairs {
-   char *arena = nullptr; // hipMalloc'ed; owned by the handle it is attached to
+   char *arena = nullptr; // sb::dev_take'n; owned by the handle it is attached to
+   size_t capacity = 0;
    int64_t n_pairs = 0, n_pair_segs = 0;
    bool any_wide = false; // some pair spans more than 32 segments and carries none (fine for long reads only)
    size_t o_seg_off = 0, o_seg_lens = 0, o_mask = 0, o_iso_len = 0, o_out_index = 0;
@@ -38,12 +63,44 @@ struct DeviceGrouping {
    const int32_t *d_count;         // device, [n_bins]: the bins' fragment counts
    const DevicePairs *pairs;       // device arrays of the (bin, isoform) pairs
 };
+// The isoforms' segment lists (IsoSegments) in device memory
+struct DeviceIsoSegments {
+   const int64_t *seg_off = nullptr;
+   const int32_t *seg_idx = nullptr, *locus = nullptr, *len = nullptr;
+};
+// An annotation kept resident (sbgpu_annotation_pin, chain_api.hip): the caller's arrays remembered by address, their
+// device copies, and what the chain makes of an annotation alone.  Lives with the context.
+struct ResidentAnnotation {
+   sbgpu_annotation_t key;  // the caller's struct as pinned
+   char *arena = nullptr;   // device (sb::dev_take)
+   size_t capacity = 0;
+   sbgpu_annotation_t dev;  // the arrays' device copies
+   DeviceIsoSegments d_iso;
+   IsoSegments iso;         // host
+   int64_t max_locus_span = 1, max_iso = 1, max_seg = 1; // longest locus' segments together; widest locus
+   bool matches(const sbgpu_annotation_t *a) const
+   {
+      return a && a->n_loci == key.n_loci && a->iso_off == key.iso_off && a->exon_off == key.exon_off && a->exon_left == key.exon_left &&
+             a->exon_right == key.exon_right && a->seg_off == key.seg_off && a->seg_left == key.seg_left && a->seg_right == key.seg_right;
+   }
+};
+const ResidentAnnotation *ctx_resident_annotation(const sbgpu_ctx_t *ctx);
+void ctx_set_resident_annotation(sbgpu_ctx_t *ctx, ResidentAnnotation *r); // takes ownership; frees the one before (nullptr: just that)
+// What a caller that runs the grouping as one stage of a longer stream (chain_api.hip) hands in: all optional.
+struct GroupingHooks {
+   const sbgpu_annotation_t *d_annot = nullptr; // iso_off, seg_off, seg_left, seg_right of `annot` in device memory already
+   const DeviceIsoSegments *d_iso = nullptr;    // the segment lists too (then `iso_pre` must be given as well)
+   // called as soon as the loci's bin counts are on the host (row_off, f_off: [n_loci + 1]), while the middle kernels run
+   std::function<void(const int64_t *row_off, const int64_t *f_off)> rows_known;
+   // called once the pairs' fill kernel is launched, before the host-side handle is built
+   std::function<int(const DeviceGrouping &)> after_pairs;
+};
 // sbgpu_bins_create_device with the segment lists made beforehand (nullptr: made inside)
 int bins_create_device_impl(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *annot, const sbgpu_hits_t *d_hits, const float *d_mass,
                             const int64_t *locus_hit_off, int32_t compat_words, int32_t key_words, const uint32_t *d_compat,
                             const uint32_t *d_key, int64_t *d_hit_bin, void *stream, const IsoSegments *iso_pre, sbgpu_bins_t **out,
                             const uint64_t *d_span, const uint32_t *d_fhash, // spans / hashes of the hits (exonbin_device_impl), or null
-                            const std::function<int(const DeviceGrouping &)> *after_pairs = nullptr); // called once the pairs' fill is launched
+                            const GroupingHooks *hooks = nullptr);
 int exonbin_device_impl(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *annot, const sbgpu_hits_t *hits, int32_t compat_words,
                         int32_t key_words, uint32_t *d_compat, uint32_t *d_key, uint64_t *d_span, uint32_t *d_fhash, void *stream);
 int api_fail(int code, const std::string &msg); // records sbgpu_last_error(), returns code
@@ -53,6 +110,20 @@ int ctx_device(const sbgpu_ctx_t *ctx);        // the HIP device the context was
 // device scratch that lives with the context (slot 0..7, grows on demand, never shrinks): valid until the next
 // request for the same slot; one host thread per context
 hipError_t ctx_scratch(sbgpu_ctx_t *ctx, int slot, size_t bytes, char **out);
+// Device allocations that change hands (a handle's arenas, a plan's arena): a hipMalloc / hipFree pair per call costs a
+// few hundred microseconds and the free waits for the device, so blocks handed back are kept -- process-wide, per
+// device, at most 8 blocks and 4 GB -- and a request is served from them when one fits without wasting more than half.
+// dev_give does NOT wait for work that still uses the block: give it back only after that work was waited for.
+hipError_t dev_take(size_t bytes, char **out, size_t *capacity);
+void dev_give(char *block, size_t capacity);
+// pinned host scratch of the same kind (slot 0..3): the targets of small device-to-host copies that must not block the host
+hipError_t ctx_pinned(sbgpu_ctx_t *ctx, int slot, size_t bytes, char **out);
+// a second stream for copies that run beside the context's kernels, and events (0..5) to order the two (made on first use)
+hipError_t ctx_copy_stream(sbgpu_ctx_t *ctx, hipStream_t *out);
+hipError_t ctx_event(sbgpu_ctx_t *ctx, int which, hipEvent_t *out);
+// sizes of the last device grouping's pair arena (bytes): a hint that lets the next one allocate before it knows its own
+size_t ctx_pairs_hint(const sbgpu_ctx_t *ctx);
+void ctx_set_pairs_hint(sbgpu_ctx_t *ctx, size_t bytes);
 // kernel stages of the chain entry points: while sbgpu_set_timing is on, the launches between a begin and its end
 // are bracketed by HIP events on their stream (sbgpu_last_stage_ms reads them); no-ops otherwise
 void ctx_stage_reset(sbgpu_ctx_t *ctx);
@@ -61,9 +132,18 @@ void ctx_stage_end(sbgpu_ctx_t *ctx, hipStream_t s);
 bool ctx_take_wide_error(sbgpu_ctx_t *ctx);    // true once if a wide-locus barrier timed out since the last call (clears the flag)
 // locus_bins.cpp: finish bins that were grouped on the device (host copies of the per-bin arrays)
 // `pairs`: made on the device already (the handle takes the arena over); nullptr: make them here, on the host
+// The per-bin arrays of a device grouping -- count, key words, compat words, 12+ bytes per bin -- stay where the pack
+// kernel wrote them: one device arena the handle takes over, downloaded on the first export that asks for them (like
+// the pairs).  A caller that only wants abundances never pays the 17 MB (1.4 M bins) over PCIe.
+struct DeviceBinArrays {
+   char *arena = nullptr; // sb::dev_take'n; owned by the handle it is attached to
+   size_t capacity = 0;
+   size_t o_count = 0, o_key = 0, o_compat = 0;
+};
+// `iso_len`: the isoforms' exonic lengths where the caller has them (IsoSegments::len)
 int bins_from_groups(const sbgpu_annotation_t *annot, int32_t compat_words, int32_t key_words, const int64_t *row_off,
-                     const int32_t *count, const uint32_t *key, const uint32_t *compat, int64_t n_hits_used,
-                     const DevicePairs *pairs, sbgpu_bins_t **out);
+                     const DeviceBinArrays &arrays, int64_t n_hits_used, const DevicePairs *pairs, const std::vector<int32_t> *iso_len,
+                     sbgpu_bins_t **out);
 const DevicePairs *bins_device_pairs(const sbgpu_bins_t *bins); // nullptr when the pairs live on the host
 void bins_set_weights(sbgpu_bins_t *bins, std::vector<double> &&F);
 void bins_set_hit_bin(sbgpu_bins_t *bins, std::vector<int64_t> &&hit_bin);

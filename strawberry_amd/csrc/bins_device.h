@@ -568,7 +568,7 @@ __global__ __launch_bounds__(256) void bins_pack_kernel(BinsPackArgs a)
 // set_theory_bin_weight visits (src/estimate.cpp:203-213): the isoform's segments from the bin's first to
 // its last, and which of the inner ones the bin does not hold ("implicit": under the mate gap).
 // One lane per isoform, walking the bins of its locus: the pairs come out ordered by (isoform, bin), the
-// order of the host code.  Pass 1 counts, pass 2 (after the host's scan) fills.
+// order of the host code.  Pass 1 counts, pass 2 (after bins_scan_kernel<1>) fills.
 enum : int32_t { kPairsNotUnder = 16, kPairsForeignSegment = 32, kPairsWide = 64 };
 
 struct PairsArgs {
@@ -592,10 +592,141 @@ struct PairsArgs {
    int32_t *flags;
 };
 
+// Exclusive prefix sums between the grouping's kernels, so that they follow each other in the stream without a
+// host round trip.  MODE 0, over the loci: the bin counts -> row_off, bins x isoforms -> f_off (a count < 0 -- a
+// locus the middle table could not hold, redone later -- stands for 0).  MODE 1, over the isoforms: the pair and
+// segment counts -> pair_off, pseg_off.  Three small launches: tile sums (4096 entries per workgroup, 16 per lane:
+// one cache line of a lane's own), the scan of the tile sums (one workgroup), the tiles again with their bases.
+// 250 000 isoforms: 61 tiles, ~15 us together -- against a D2H, a host loop and an H2D.
+constexpr int kScanTile = 4096, kScanPerLane = 16;
+
+// Zero fill, 16 bytes per lane and step (`bytes` a multiple of 16, `p` 16-byte aligned): the runtime's
+// hipMemsetAsync kernel reaches 60 GB/s on this -- 0.2 ms for the 12 MB of 1.5 M hits -- this one the memory's rate.
+__global__ __launch_bounds__(256) void bins_zero_kernel(uint4 *p, int64_t n16)
+{
+   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) p[i] = make_uint4(0, 0, 0, 0);
+}
+
+struct ScanArgs {
+   int64_t n;
+   const int32_t *a, *b;     // MODE 0: a = bins per locus (b unused); MODE 1: pair counts, segment counts
+   const int64_t *iso_off;   // MODE 0
+   int64_t *out_a, *out_b;   // [n + 1]
+   int64_t *part_a, *part_b; // [tiles]: tile sums, then their exclusive scan
+   int64_t *totals;          // [2]
+};
+
+template <int MODE>
+__device__ __forceinline__ void scan_value(const ScanArgs &s, int64_t i, int64_t &va, int64_t &vb)
+{
+   if (MODE == 0) {
+      va = s.a[i] > 0 ? s.a[i] : 0;
+      vb = va * (s.iso_off[i + 1] - s.iso_off[i]);
+   } else {
+      va = s.a[i];
+      vb = s.b[i];
+   }
+}
+
+// sums over the workgroup's 256 lanes, inclusive per lane, through LDS (8 steps)
+__device__ __forceinline__ void scan_block256(int64_t *sa, int64_t *sb_, int t, int64_t &pa, int64_t &pb)
+{
+   sa[t] = pa;
+   sb_[t] = pb;
+   __syncthreads();
+   for (int d = 1; d < 256; d <<= 1) {
+      const int64_t xa = t >= d ? sa[t - d] : 0, xb = t >= d ? sb_[t - d] : 0;
+      __syncthreads();
+      sa[t] += xa;
+      sb_[t] += xb;
+      __syncthreads();
+   }
+   pa = sa[t];
+   pb = sb_[t];
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void bins_scan_tiles_kernel(ScanArgs s)
+{
+   __shared__ int64_t sa[256], sb_[256];
+   const int t = threadIdx.x;
+   const int64_t i0 = (int64_t)blockIdx.x * kScanTile + (int64_t)t * kScanPerLane;
+   int64_t pa = 0, pb = 0;
+   for (int k = 0; k < kScanPerLane; ++k)
+      if (i0 + k < s.n) {
+         int64_t va, vb;
+         scan_value<MODE>(s, i0 + k, va, vb);
+         pa += va;
+         pb += vb;
+      }
+   scan_block256(sa, sb_, t, pa, pb);
+   if (t == 255) {
+      s.part_a[blockIdx.x] = pa;
+      s.part_b[blockIdx.x] = pb;
+   }
+}
+
+// the tile sums -> their exclusive scan, in place; the grand totals -> out[n] and totals[0..1]
+__global__ __launch_bounds__(256) void bins_scan_parts_kernel(ScanArgs s, int64_t n_tiles)
+{
+   __shared__ int64_t sa[256], sb_[256];
+   const int t = threadIdx.x;
+   int64_t base_a = 0, base_b = 0;
+   for (int64_t c0 = 0; c0 < n_tiles; c0 += 256) { // (256 tiles = 10^6 entries per round)
+      const int64_t i = c0 + t;
+      const int64_t va = i < n_tiles ? s.part_a[i] : 0, vb = i < n_tiles ? s.part_b[i] : 0;
+      int64_t pa = va, pb = vb;
+      scan_block256(sa, sb_, t, pa, pb);
+      if (i < n_tiles) {
+         s.part_a[i] = base_a + pa - va;
+         s.part_b[i] = base_b + pb - vb;
+      }
+      base_a += sa[255];
+      base_b += sb_[255];
+      __syncthreads();
+   }
+   if (t == 0) {
+      s.out_a[s.n] = base_a;
+      s.out_b[s.n] = base_b;
+      s.totals[0] = base_a;
+      s.totals[1] = base_b;
+   }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void bins_scan_apply_kernel(ScanArgs s)
+{
+   __shared__ int64_t sa[256], sb_[256];
+   const int t = threadIdx.x;
+   const int64_t i0 = (int64_t)blockIdx.x * kScanTile + (int64_t)t * kScanPerLane;
+   int64_t va[kScanPerLane], vb[kScanPerLane];
+   int64_t pa = 0, pb = 0;
+#pragma unroll
+   for (int k = 0; k < kScanPerLane; ++k) {
+      va[k] = vb[k] = 0;
+      if (i0 + k < s.n) scan_value<MODE>(s, i0 + k, va[k], vb[k]);
+      pa += va[k];
+      pb += vb[k];
+   }
+   const int64_t own_a = pa, own_b = pb;
+   scan_block256(sa, sb_, t, pa, pb);
+   int64_t ra = s.part_a[blockIdx.x] + pa - own_a, rb = s.part_b[blockIdx.x] + pb - own_b;
+#pragma unroll
+   for (int k = 0; k < kScanPerLane; ++k)
+      if (i0 + k < s.n) {
+         s.out_a[i0 + k] = ra;
+         s.out_b[i0 + k] = rb;
+         ra += va[k];
+         rb += vb[k];
+      }
+}
+
 template <bool FILL>
 __global__ __launch_bounds__(256) void bins_pairs_kernel(PairsArgs a)
 {
    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+   if (FILL && blockIdx.x == 0 && threadIdx.x == 0) a.pair_seg_off[a.pair_off[a.n_iso]] = a.pseg_off[a.n_iso]; // the CSR's last entry
    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_iso; i += stride) {
       const int l = a.iso_locus[i];
       const int64_t i0 = a.iso_off[l];

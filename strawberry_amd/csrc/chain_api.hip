@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstring>
 #include <functional>
+#include <new>
 #include <string>
 #include <system_error>
 #include <thread>
@@ -51,10 +52,17 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
    const int64_t n_iso = an->iso_off[nl], n_exon = an->exon_off[n_iso], n_seg = an->seg_off[nl];
    int64_t n_feat = 0;
    if (nh && !on_dev) n_feat = hits->feat_off[nh];
+   // an annotation kept resident (sbgpu_annotation_pin) and given again: its device copies and tables are used as they are
+   const sb::ResidentAnnotation *res = sb::ctx_resident_annotation(c);
+   if (res && !res->matches(an)) res = nullptr;
    int64_t max_iso = 1, max_seg = 1;
-   for (int64_t l = 0; l < nl; ++l) {
-      max_iso = std::max(max_iso, an->iso_off[l + 1] - an->iso_off[l]);
-      max_seg = std::max(max_seg, an->seg_off[l + 1] - an->seg_off[l]);
+   if (res) {
+      max_iso = res->max_iso, max_seg = res->max_seg;
+   } else {
+      for (int64_t l = 0; l < nl; ++l) {
+         max_iso = std::max(max_iso, an->iso_off[l + 1] - an->iso_off[l]);
+         max_seg = std::max(max_seg, an->seg_off[l + 1] - an->seg_off[l]);
+      }
    }
    const int32_t cw = (int32_t)((max_iso + 31) / 32), kw = (int32_t)((max_seg + 31) / 32);
    // hits grouped by locus?  (the device grouping needs it; the host one does not)
@@ -74,12 +82,13 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
       for (int64_t l = 0; l < nl; ++l) locus_hit_off[(size_t)l + 1] += locus_hit_off[(size_t)l];
 
    hipStream_t s = sb::ctx_stream(c);
-   const bool timing = std::getenv("SBGPU_HOST_TIMING") != nullptr; // diagnostic: stage times on stderr (each stage synchronises)
+   const char *timing_env = std::getenv("SBGPU_HOST_TIMING");
+   const bool timing = timing_env != nullptr, timing_sync = timing && std::atoi(timing_env) != 2; // diagnostic: stage times on stderr; =2: host clock only, no synchronisation
    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
    double t_stage = now();
    auto stage = [&](const char *name) {
       if (timing) {
-         (void)hipStreamSynchronize(s);
+         if (timing_sync) (void)hipStreamSynchronize(s);
          const double t = now();
          std::fprintf(stderr, "sbgpu_quantify_host: %-18s %.2f ms\n", name, (t - t_stage) * 1e3);
          t_stage = t;
@@ -102,6 +111,8 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
    };
    if (on_dev)
       for (int k : {3, 8, 9, 10, 11, 12}) parts[k].bytes = 0; // the hits are in HBM already
+   if (res)
+      for (int k : {0, 1, 2, 4, 5, 6, 7}) parts[k].bytes = 0; // so is the annotation
    size_t total = 0;
    for (Part &p : parts) {
       p.off = total;
@@ -135,7 +146,7 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
          if (t.joinable()) t.join();
       }
    } iso_worker;
-   if (grouped && nh) {
+   if (grouped && nh && !res) {
       try {
          iso_worker.t = std::thread([&]() { sb::iso_segments(an, &iso_pre); });
       } catch (const std::system_error &) { // no thread to be had: make them here
@@ -145,13 +156,17 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
    for (Part &p : parts)
       if (p.bytes) SB_TRY(hipMemcpyAsync(in.p + p.off, p.src, p.bytes, hipMemcpyHostToDevice, s));
    sbgpu_annotation_t dan = *an;
-   dan.iso_off = (const int64_t *)(in.p + parts[0].off);
-   dan.exon_off = (const int64_t *)(in.p + parts[1].off);
-   dan.seg_off = (const int64_t *)(in.p + parts[2].off);
-   dan.exon_left = (const uint32_t *)(in.p + parts[4].off);
-   dan.exon_right = (const uint32_t *)(in.p + parts[5].off);
-   dan.seg_left = (const uint32_t *)(in.p + parts[6].off);
-   dan.seg_right = (const uint32_t *)(in.p + parts[7].off);
+   if (res) dan = res->dev;
+   else
+      dan.iso_off = (const int64_t *)(in.p + parts[0].off);
+   if (!res) {
+      dan.exon_off = (const int64_t *)(in.p + parts[1].off);
+      dan.seg_off = (const int64_t *)(in.p + parts[2].off);
+      dan.exon_left = (const uint32_t *)(in.p + parts[4].off);
+      dan.exon_right = (const uint32_t *)(in.p + parts[5].off);
+      dan.seg_left = (const uint32_t *)(in.p + parts[6].off);
+      dan.seg_right = (const uint32_t *)(in.p + parts[7].off);
+   }
    sbgpu_hits_t dh = *hits;
    const float *d_mass = hit_mass;
    if (!on_dev) {
@@ -221,17 +236,55 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
       ins.long_read = long_read;
    }
    stage("insert size");
+   // the insert-size table reaches as far as the longest locus' segments together (no (bin, isoform) pair spans more)
+   int64_t max_l = 1;
+   if (!long_read && res) max_l = res->max_locus_span;
+   else if (!long_read)
+      for (int64_t l = 0; l < nl; ++l) {
+         int64_t tot = 0;
+         for (int64_t k = an->seg_off[l]; k < an->seg_off[l + 1]; ++k) tot += (int64_t)an->seg_right[k] - an->seg_left[k] + 1;
+         max_l = std::max(max_l, tot);
+      }
+   if (max_l > (1 << 26)) return api_fail(SBGPU_ESHAPE, "sbgpu_quantify_host: segment lengths out of range");
+   const int32_t pdf_len = (int32_t)max_l + 1;
+   char *d_pdf = nullptr;
+   if (hipError_t ep = sb::ctx_scratch(c, 6, (size_t)pdf_len * 8, &d_pdf); ep != hipSuccess)
+      return api_fail(ep == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("hipMalloc: ") + hipGetErrorString(ep));
+   // the table of the law, on the copy stream beside the kernels (the bin-weight launch waits for its event)
+   std::vector<double> pdf((size_t)pdf_len, 0.0);
+   SB_RC(sbgpu_insert_pdf_table(&ins, pdf_len, pdf.data()));
+   hipStream_t cs = nullptr;
+   hipEvent_t ev_pdf = nullptr;
+   SB_TRY(sb::ctx_copy_stream(c, &cs));
+   SB_TRY(sb::ctx_event(c, 3, &ev_pdf));
+   SB_TRY(hipMemcpyAsync(d_pdf, pdf.data(), (size_t)pdf_len * 8, hipMemcpyHostToDevice, cs));
+   SB_TRY(hipEventRecord(ev_pdf, cs));
+   stage("pdf table");
    // ---- everything behind the bins: weights straight into the EM batch's F (A4), plan + EM (A1/A2), the downloads.
-   // With the device grouping it is launched from inside bins_create_device_impl -- as soon as the pairs' fill kernel is
-   // in the stream, before the host-side handle is built -- so that the handle's bookkeeping runs beside these kernels.
+   // With the device grouping the weights are launched from inside bins_create_device_impl -- as soon as the pairs' fill
+   // kernel is in the stream -- so that the handle's bookkeeping runs beside that kernel; the EM goes in once the plan's
+   // thread is through, still before the weights are done.
    sbgpu_plan_t *plan = nullptr;
    struct PlanGuard {
       sbgpu_plan_t *&p;
       ~PlanGuard() { if (p) sbgpu_plan_destroy(p); }
    } plan_guard = {plan};
    DeviceBuf w;
-   std::vector<double> pdf;
    std::vector<double> F;
+   // the EM plan is host work of a millisecond or two (size classes, one upload): with the device grouping a helper
+   // thread makes it as soon as the loci's bin counts are known, beside the pairs' kernels
+   struct PlanJob {
+      std::thread t;
+      std::vector<int64_t> row_off, f_off;
+      int rc = SBGPU_OK;
+      std::string err;
+      bool started = false;
+      ~PlanJob()
+      {
+         if (t.joinable()) t.join();
+      }
+   } plan_job; // (declared after plan_guard: joined before the plan is destroyed)
+   size_t q_theta = 0, q_st = 0, q_it = 0;
    hipError_t e1 = hipSuccess, e2 = hipSuccess, e3 = hipSuccess, e4 = hipSuccess;
    int64_t n_bins = 0, n_elem = 0, n_pairs = 0, n_psegs = 0;
    size_t q_F = 0;
@@ -239,32 +292,18 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
    std::vector<int64_t> row_off_h, iso_off_h, f_off_h, pair_seg_off, pair_out;
    std::vector<int32_t> count_h, pair_len;
    std::vector<uint32_t> pair_segs, pair_mask;
-   auto launch_rest = [&](const int64_t *row_off, const int64_t *f_off, const sb::DevicePairs *dpairs, const int32_t *d_count,
-                          const int32_t *h_count) -> int {
-      int64_t max_l = 1;
+   size_t q_cnt = 0;
+   // the bin weights, straight into the EM batch's F
+   auto launch_weights = [&](const sb::DevicePairs *dpairs) -> int {
       if (!long_read) {
          if (dpairs) {
             if (dpairs->any_wide) return api_fail(SBGPU_ESHAPE, "sbgpu_quantify_host: a bin spans more than 32 isoform segments");
-            // no pair spans more than its locus' segments together
-            for (int64_t l = 0; l < nl; ++l) {
-               int64_t tot = 0;
-               for (int64_t k = an->seg_off[l]; k < an->seg_off[l + 1]; ++k) tot += (int64_t)an->seg_right[k] - an->seg_left[k] + 1;
-               max_l = std::max(max_l, tot);
-            }
          } else {
-            for (int64_t p = 0; p < n_pairs; ++p) {
-               int64_t l = 0;
-               for (int64_t k = pair_seg_off[(size_t)p]; k < pair_seg_off[(size_t)p + 1]; ++k) l += pair_segs[(size_t)k];
+            for (int64_t p = 0; p < n_pairs; ++p)
                if (pair_seg_off[(size_t)p + 1] == pair_seg_off[(size_t)p])
                   return api_fail(SBGPU_ESHAPE, "sbgpu_quantify_host: a bin spans more than 32 isoform segments");
-               max_l = std::max(max_l, l);
-            }
          }
       }
-      if (max_l > (1 << 26)) return api_fail(SBGPU_ESHAPE, "sbgpu_quantify_host: segment lengths out of range");
-      const int32_t pdf_len = (int32_t)max_l + 1;
-      pdf.assign((size_t)pdf_len, 0.0);
-      SB_RC(sbgpu_insert_pdf_table(&ins, pdf_len, pdf.data()));
       const size_t np1 = (size_t)std::max<int64_t>(dpairs ? 1 : n_pairs, 1), ne1 = (size_t)std::max<int64_t>(n_elem, 1),
                    nb1 = (size_t)std::max<int64_t>(n_bins, 1), ns1 = (size_t)(dpairs ? 1 : n_psegs + 1);
       size_t t2 = 0;
@@ -273,15 +312,15 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
       const size_t q_seg = t2; t2 += up256(ns1 * 4);
       const size_t q_mask = t2; t2 += up256(np1 * 4);
       const size_t q_len = t2; t2 += up256(np1 * 4);
-      const size_t q_pdf = t2; t2 += up256((size_t)pdf_len * 8);
-      const size_t q_cnt = t2; t2 += up256(nb1 * 4);
+      q_cnt = t2; t2 += up256(nb1 * 4);
       q_F = t2; t2 += up256(ne1 * 8);
-      const size_t q_theta = t2; t2 += up256((size_t)(n_iso + 1) * 8);
-      const size_t q_st = t2; t2 += up256((size_t)(nl + 1) * 4);
-      const size_t q_it = t2; t2 += up256((size_t)(nl + 1) * 4);
+      q_theta = t2; t2 += up256((size_t)(n_iso + 1) * 8);
+      q_st = t2; t2 += up256((size_t)(nl + 1) * 4);
+      q_it = t2; t2 += up256((size_t)(nl + 1) * 4);
       hipError_t ew = sb::ctx_scratch(c, 1, t2, &w.p);
       if (ew != hipSuccess) return api_fail(ew == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("hipMalloc: ") + hipGetErrorString(ew));
       SB_TRY(hipMemsetAsync(w.p + q_F, 0, ne1 * 8, s));
+      SB_TRY(hipStreamWaitEvent(s, ev_pdf, 0));
       if (n_pairs) {
          const int64_t *d_off = dpairs ? dpairs->seg_off() : (const int64_t *)(w.p + q_off);
          const uint32_t *d_seg = dpairs ? dpairs->seg_lens() : (const uint32_t *)(w.p + q_seg);
@@ -295,31 +334,43 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
             SB_TRY(hipMemcpyAsync(w.p + q_mask, pair_mask.data(), (size_t)n_pairs * 4, hipMemcpyHostToDevice, s));
             SB_TRY(hipMemcpyAsync(w.p + q_len, pair_len.data(), (size_t)n_pairs * 4, hipMemcpyHostToDevice, s));
          }
-         SB_TRY(hipMemcpyAsync(w.p + q_pdf, pdf.data(), (size_t)pdf_len * 8, hipMemcpyHostToDevice, s));
          const int32_t lmin_base = ins.use_emp ? ins.start_offset : ins.read_len;
          sb::ctx_stage_begin(c, "binweight_kernel", s);
-         SB_RC(sbgpu_binweight_device(c, n_pairs, d_off, d_seg, d_msk, d_len, d_idx, (const double *)(w.p + q_pdf), pdf_len,
+         SB_RC(sbgpu_binweight_device(c, n_pairs, d_off, d_seg, d_msk, d_len, d_idx, (const double *)d_pdf, pdf_len,
                                       ins.read_len, lmin_base, ins.long_read, (double *)(w.p + q_F), s));
          sb::ctx_stage_end(c, s);
       }
       stage("bin weights");
-      // ---- A1/A2: the EM (the counts are on the device already when the grouping ran there)
+      return SBGPU_OK;
+   };
+   // ---- A1/A2: the EM behind them (the counts are on the device already when the grouping ran there)
+   auto launch_em = [&](const int64_t *row_off, const int64_t *f_off, const int32_t *d_count, const int32_t *h_count) -> int {
       if (!d_count) {
          if (n_bins) SB_TRY(hipMemcpyAsync(w.p + q_cnt, h_count, (size_t)n_bins * 4, hipMemcpyHostToDevice, s));
          d_count = (const int32_t *)(w.p + q_cnt);
       }
-      SB_RC(sbgpu_plan_create(c, nl, row_off, an->iso_off, f_off, &plan));
+      if (plan_job.started) {
+         plan_job.t.join();
+         plan_job.started = false;
+         if (plan_job.rc != SBGPU_OK) return api_fail(plan_job.rc, plan_job.err);
+      } else {
+         SB_RC(sbgpu_plan_create(c, nl, row_off, an->iso_off, f_off, &plan));
+      }
+      stage("plan");
       sb::ctx_stage_begin(c, "em kernels", s);
       const int rce = sbgpu_em_run_device(c, plan, d_count, (const double *)(w.p + q_F), (double *)(w.p + q_theta),
                                           (int32_t *)(w.p + q_st), (int32_t *)(w.p + q_it), s);
       sb::ctx_stage_end(c, s);
-      if (rce != SBGPU_OK) return rce;
+      return rce;
+   };
+   // the results come down last: a copy into the caller's pageable memory holds the host until the EM is done, and
+   // the handle's host work is to run beside the kernels, not behind them
+   auto download = [&]() {
       F.assign(on_dev ? (size_t)0 : (size_t)n_elem, 0.0); // (device entry: the weights are not brought back)
       e1 = hipMemcpyAsync(theta_out, w.p + q_theta, (size_t)n_iso * 8, hipMemcpyDeviceToHost, s);
       e2 = hipMemcpyAsync(status_out, w.p + q_st, (size_t)nl * 4, hipMemcpyDeviceToHost, s);
       e3 = hipMemcpyAsync(iters_out, w.p + q_it, (size_t)nl * 4, hipMemcpyDeviceToHost, s);
       e4 = (n_elem && !on_dev) ? hipMemcpyAsync(F.data(), w.p + q_F, (size_t)n_elem * 8, hipMemcpyDeviceToHost, s) : hipSuccess;
-      return SBGPU_OK;
    };
    // ---- A5: bins (device; host when the device form declines)
    sbgpu_bins_t *bins = nullptr;
@@ -327,14 +378,47 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
    bool rest_launched = false;
    if (grouped && nh) {
       if (iso_worker.t.joinable()) iso_worker.t.join();
-      const std::function<int(const sb::DeviceGrouping &)> after = [&](const sb::DeviceGrouping &g) -> int {
+      sb::GroupingHooks hooks;
+      hooks.d_annot = &dan;
+      if (res) hooks.d_iso = &res->d_iso;
+      hooks.rows_known = [&](const int64_t *row_off, const int64_t *f_off) {
+         plan_job.row_off.assign(row_off, row_off + nl + 1); // (the caller's arrays do not outlive its frame)
+         plan_job.f_off.assign(f_off, f_off + nl + 1);
+         try {
+            plan_job.t = std::thread([&]() {
+               plan_job.rc = sbgpu_plan_create(c, nl, plan_job.row_off.data(), an->iso_off, plan_job.f_off.data(), &plan);
+               if (plan_job.rc != SBGPU_OK) plan_job.err = sbgpu_last_error(); // (the error slot is per thread)
+            });
+            plan_job.started = true;
+         } catch (const std::system_error &) { // no thread to be had: launch_em makes the plan
+         }
+      };
+      const int32_t *d_count_dev = nullptr;
+      hooks.after_pairs = [&](const sb::DeviceGrouping &g) -> int {
          n_bins = g.n_bins, n_elem = g.n_elem, n_pairs = g.pairs->n_pairs, n_psegs = g.pairs->n_pair_segs;
+         d_count_dev = g.d_count; // (context scratch: stays valid after the grouping returns)
          rest_launched = true;
-         return launch_rest(g.row_off, g.f_off, g.pairs, g.d_count, nullptr);
+         return launch_weights(g.pairs);
       };
       // (hits given on the device: the caller did not ask for hit -> bin, so it is not made)
       rc = sb::bins_create_device_impl(c, an, &dh, d_mass, locus_hit_off.data(), cw, kw, d_compat, d_key, on_dev ? nullptr : d_hit_bin, s,
-                                       &iso_pre, &bins, d_span, d_fhash, &after);
+                                       res ? &res->iso : &iso_pre, &bins, d_span, d_fhash, &hooks);
+      if (rc == SBGPU_OK && rest_launched) rc = launch_em(plan_job.row_off.data(), plan_job.f_off.data(), d_count_dev, nullptr);
+      if (rc != SBGPU_OK) {
+         // a grouping that failed after the plan's thread was started: the thread is over before anything else happens
+         if (plan_job.t.joinable()) plan_job.t.join();
+         plan_job.started = false;
+         if (rest_launched) (void)hipStreamSynchronize(s);
+         if (plan) {
+            sbgpu_plan_destroy(plan);
+            plan = nullptr;
+         }
+         if (rest_launched) { // the handle exists already
+            sbgpu_bins_destroy(bins);
+            bins = nullptr;
+            return rc;
+         }
+      }
    }
    const bool on_device = rc == SBGPU_OK;
    if (rc == SBGPU_EUNSUPPORTED && on_dev)
@@ -373,8 +457,10 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
                               dpairs ? nullptr : pair_mask.data(), dpairs ? nullptr : pair_len.data(),
                               dpairs ? nullptr : pair_out.data()));
       stage("export");
-      SB_RC(launch_rest(row_off_h.data(), f_off_h.data(), dpairs, nullptr, count_h.data()));
+      SB_RC(launch_weights(dpairs));
+      SB_RC(launch_em(row_off_h.data(), f_off_h.data(), nullptr, count_h.data()));
    }
+   download();
    std::vector<int64_t> hit_bin;
    hipError_t e5 = hipSuccess;
    if (on_device && nh && !on_dev) { // (device hits: the caller did not ask for 8 bytes per hit over PCIe)
@@ -423,6 +509,72 @@ int sbgpu_quantify_host(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgp
 {
    return quantify_impl(c, an, hits, hit_mass, nullptr, insert, read_len, long_read, theta_out, status_out, iters_out, compat_out,
                         insert_used, bins_out);
+}
+
+int sbgpu_annotation_pin(sbgpu_ctx_t *c, const sbgpu_annotation_t *an)
+{
+   if (!c || !an) return api_fail(SBGPU_EINVAL, "sbgpu_annotation_pin: null argument");
+   const int64_t nl = an->n_loci;
+   if (nl < 1 || !an->iso_off || !an->exon_off || !an->seg_off) return api_fail(SBGPU_EINVAL, "sbgpu_annotation_pin: bad annotation");
+   const int64_t n_iso = an->iso_off[nl], n_exon = an->exon_off[n_iso], n_seg = an->seg_off[nl];
+   if ((n_exon && (!an->exon_left || !an->exon_right)) || (n_seg && (!an->seg_left || !an->seg_right)))
+      return api_fail(SBGPU_EINVAL, "sbgpu_annotation_pin: null array");
+   sb::ResidentAnnotation *r = new (std::nothrow) sb::ResidentAnnotation();
+   if (!r) return api_fail(SBGPU_ENOMEM, "sbgpu_annotation_pin: out of host memory");
+   r->key = *an;
+   for (int64_t l = 0; l < nl; ++l) {
+      r->max_iso = std::max(r->max_iso, an->iso_off[l + 1] - an->iso_off[l]);
+      r->max_seg = std::max(r->max_seg, an->seg_off[l + 1] - an->seg_off[l]);
+      int64_t tot = 0;
+      for (int64_t k = an->seg_off[l]; k < an->seg_off[l + 1]; ++k) tot += (int64_t)an->seg_right[k] - an->seg_left[k] + 1;
+      r->max_locus_span = std::max(r->max_locus_span, tot);
+   }
+   sb::iso_segments(an, &r->iso);
+   struct Part {
+      const void *src;
+      size_t bytes, off;
+   } parts[] = {
+      {an->iso_off, (size_t)(nl + 1) * 8, 0},    {an->exon_off, (size_t)(n_iso + 1) * 8, 0}, {an->seg_off, (size_t)(nl + 1) * 8, 0},
+      {an->exon_left, (size_t)n_exon * 4, 0},    {an->exon_right, (size_t)n_exon * 4, 0},    {an->seg_left, (size_t)n_seg * 4, 0},
+      {an->seg_right, (size_t)n_seg * 4, 0},     {r->iso.seg_off.data(), r->iso.seg_off.size() * 8, 0},
+      {r->iso.seg_idx.data(), r->iso.seg_idx.size() * 4, 0}, {r->iso.locus.data(), r->iso.locus.size() * 4, 0},
+      {r->iso.len.data(), r->iso.len.size() * 4, 0},
+   };
+   size_t total = 0;
+   for (Part &p : parts) {
+      p.off = total;
+      total += up256(p.bytes ? p.bytes : 8);
+   }
+   hipError_t e = hipSetDevice(sb::ctx_device(c));
+   if (e == hipSuccess) e = sb::dev_take(total, &r->arena, &r->capacity);
+   for (Part &p : parts)
+      if (e == hipSuccess && p.bytes) e = hipMemcpy(r->arena + p.off, p.src, p.bytes, hipMemcpyHostToDevice);
+   if (e != hipSuccess) {
+      sb::dev_give(r->arena, r->capacity);
+      delete r;
+      return api_fail(e == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("sbgpu_annotation_pin: ") + hipGetErrorString(e));
+   }
+   r->dev = *an;
+   r->dev.iso_off = (const int64_t *)(r->arena + parts[0].off);
+   r->dev.exon_off = (const int64_t *)(r->arena + parts[1].off);
+   r->dev.seg_off = (const int64_t *)(r->arena + parts[2].off);
+   r->dev.exon_left = (const uint32_t *)(r->arena + parts[3].off);
+   r->dev.exon_right = (const uint32_t *)(r->arena + parts[4].off);
+   r->dev.seg_left = (const uint32_t *)(r->arena + parts[5].off);
+   r->dev.seg_right = (const uint32_t *)(r->arena + parts[6].off);
+   r->d_iso.seg_off = (const int64_t *)(r->arena + parts[7].off);
+   r->d_iso.seg_idx = (const int32_t *)(r->arena + parts[8].off);
+   r->d_iso.locus = (const int32_t *)(r->arena + parts[9].off);
+   r->d_iso.len = (const int32_t *)(r->arena + parts[10].off);
+   sb::ctx_set_resident_annotation(c, r);
+   return SBGPU_OK;
+}
+
+int sbgpu_annotation_unpin(sbgpu_ctx_t *c)
+{
+   if (!c) return api_fail(SBGPU_EINVAL, "sbgpu_annotation_unpin: null context");
+   sb::ctx_set_resident_annotation(c, nullptr);
+   return SBGPU_OK;
 }
 
 int sbgpu_quantify_device(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgpu_hits_t *d_hits, const float *d_hit_mass,

@@ -244,7 +244,7 @@ void iso_segments(const sbgpu_annotation_t *an, IsoSegments *out)
 int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgpu_hits_t *dh, const float *d_mass,
                             const int64_t *locus_hit_off, int32_t compat_words, int32_t key_words, const uint32_t *d_compat,
                             const uint32_t *d_key, int64_t *d_hit_bin, void *stream, const IsoSegments *iso_pre, sbgpu_bins_t **out,
-                            const uint64_t *d_span, const uint32_t *d_fhash, const std::function<int(const DeviceGrouping &)> *after_pairs)
+                            const uint64_t *d_span, const uint32_t *d_fhash, const GroupingHooks *hooks)
 {
    if (!c || !an || !dh || !locus_hit_off || !out) return api_fail(SBGPU_EINVAL, "sbgpu_bins_create_device: null argument");
    *out = nullptr;
@@ -260,12 +260,13 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
          return api_fail(SBGPU_ESHAPE, "sbgpu_bins_create_device: word counts do not cover a locus");
    }
    hipStream_t s = (hipStream_t)stream;
-   const bool timing = std::getenv("SBGPU_HOST_TIMING") != nullptr; // diagnostic: stage times on stderr
+   const char *timing_env = std::getenv("SBGPU_HOST_TIMING");
+   const bool timing = timing_env != nullptr, timing_sync = timing && std::atoi(timing_env) != 2; // diagnostic: stage times on stderr; =2: host clock only, no synchronisation
    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
    double t_stage = now();
    auto stage = [&](const char *name) {
       if (timing) {
-         (void)hipStreamSynchronize(s);
+         if (timing_sync) (void)hipStreamSynchronize(s);
          const double t = now();
          std::fprintf(stderr, "  bins_create_device: %-16s %.2f ms\n", name, (t - t_stage) * 1e3);
          t_stage = t;
@@ -283,14 +284,14 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
    const size_t zero_bytes = off - o_zero;
    const size_t o_nb = off; off += up((size_t)nl * 4);
    const size_t o_nu = off; off += up((size_t)nl * 4);
-   const size_t o_flag = off; off += 256;
+   const size_t o_flag = off; off += 256; // [0]: the grouping kernels' flags, [1]: the middle's (pack, pairs)
    const size_t o_hoff = off; off += up((size_t)(nl + 1) * 8);
    const size_t o_roff = off; off += up((size_t)(nl + 1) * 8);
    const size_t o_order = off; off += up((size_t)nl * 4);
    const size_t o_dup = off; off += up(nh1);
    const size_t o_span = off; off += d_span ? 0 : up(nh1 * 8);   // spans and hashes: the exon-bin kernel's, or made here
    const size_t o_fhash = off; off += d_span ? 0 : up(nh1 * 4);
-   // the scratch arenas live with the context (sb::ctx_scratch): nothing to free here
+   // the scratch arenas live with the context (sb::ctx_scratch): nothing to free here (d2 is not scratch: below)
    char *d = nullptr, *d2 = nullptr;
    hipError_t e = sb::ctx_scratch(c, 2, off, &d);
    if (e != hipSuccess) return api_fail(e == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e));
@@ -300,9 +301,6 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
       hipError_t e_ = (expr);                                                               \
       if (e_ != hipSuccess) return bail(SBGPU_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
    } while (0)
-   SB_TRY(hipMemsetAsync(d + o_zero, 0, zero_bytes, s));
-   SB_TRY(hipMemsetAsync(d + o_flag, 0, 256, s));
-   SB_TRY(hipMemcpyAsync(d + o_hoff, locus_hit_off, (size_t)(nl + 1) * 8, hipMemcpyHostToDevice, s));
    sb::BinsArgs a;
    a.n_loci = nl;
    a.locus_hit_off = (const int64_t *)(d + o_hoff);
@@ -331,6 +329,88 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
    a.n_used = (int32_t *)(d + o_nu);
    a.flags = (int32_t *)(d + o_flag);
    const int64_t cap = (int64_t)sb::ctx_cu_count(c) * 8;
+   const int64_t n_iso = an->iso_off[nl], n_seg = an->seg_off[nl];
+   const sbgpu_annotation_t *d_an = hooks ? hooks->d_annot : nullptr;
+   // ---- the rest of the device memory, all sized before anything runs (bins <= hits), so that the kernels below
+   // follow each other in the stream: the packed per-bin arrays, and what the pairs' kernels read
+   // (an allocation of its own, not context scratch: the handle takes it over, see DeviceBinArrays)
+   size_t off2 = 0;
+   const size_t p_cnt = off2; off2 += up(nh1 * 4);
+   const size_t p_key = off2; off2 += up(nh1 * 4 * (size_t)key_words);
+   const size_t p_cmp = off2; off2 += up(nh1 * 4 * (size_t)compat_words);
+   size_t d2_cap = 0;
+   e = sb::dev_take(off2, &d2, &d2_cap);
+   if (e != hipSuccess) return bail(e == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+   struct ArenaGuard { // given back on every early return; released once the handle owns it
+      char *&p;
+      size_t &cap;
+      hipStream_t s;
+      ~ArenaGuard()
+      {
+         if (p) {
+            (void)hipStreamSynchronize(s);
+            sb::dev_give(p, cap);
+         }
+      }
+   } d2_guard = {d2, d2_cap, s};
+   sb::IsoSegments own_segments;
+   if (!iso_pre) { // a caller that knows the annotation earlier makes them while something else runs (chain_api.hip)
+      sb::iso_segments(an, &own_segments);
+      iso_pre = &own_segments;
+   }
+   const std::vector<int64_t> &iso_seg_off = iso_pre->seg_off;
+   const std::vector<int32_t> &iso_seg_idx = iso_pre->seg_idx, &iso_locus = iso_pre->locus, &iso_len = iso_pre->len;
+   const size_t ni1 = (size_t)(n_iso > 0 ? n_iso : 1), nsi1 = iso_seg_idx.empty() ? 1 : iso_seg_idx.size();
+   size_t off3 = 0;
+   const size_t r_isoff = off3; off3 += up((size_t)(nl + 1) * 8);
+   const size_t r_foff = off3; off3 += up((size_t)(nl + 1) * 8);
+   const size_t r_segoff = off3; off3 += up((size_t)(nl + 1) * 8);
+   const size_t r_segl = off3; off3 += up((size_t)(n_seg + 1) * 4);
+   const size_t r_segr = off3; off3 += up((size_t)(n_seg + 1) * 4);
+   const size_t r_isegoff = off3; off3 += up((ni1 + 1) * 8);
+   const size_t r_isegidx = off3; off3 += up(nsi1 * 4);
+   const size_t r_isoloc = off3; off3 += up(ni1 * 4);
+   const size_t r_isolen = off3; off3 += up(ni1 * 4);
+   const size_t r_pcnt = off3; off3 += up(ni1 * 4);
+   const size_t r_scnt = off3; off3 += up(ni1 * 4);
+   const size_t r_poff = off3; off3 += up((ni1 + 1) * 8);
+   const size_t r_soff = off3; off3 += up((ni1 + 1) * 8);
+   const size_t r_tot = off3; off3 += 256; // totals of the two scans: [n_bins, n_elem, n_pairs, n_pair_segs]
+   const int64_t row_tiles = (nl + sb::kScanTile - 1) / sb::kScanTile, iso_tiles = std::max<int64_t>(1, (n_iso + sb::kScanTile - 1) / sb::kScanTile);
+   const size_t r_part = off3; off3 += up((size_t)(2 * std::max(row_tiles, iso_tiles) + 2) * 8); // the scans' tile sums
+   char *d3 = nullptr;
+   e = sb::ctx_scratch(c, 4, off3, &d3);
+   if (e != hipSuccess) return bail(e == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+   // pinned host words for what comes back between the kernels (copies into pageable memory would hold the host
+   // until the stream has reached them): [bins per locus | hits used per locus | flags | totals]
+   const size_t h_nb = 0, h_nu = up((size_t)nl * 4), h_flag = h_nu + up((size_t)nl * 4), h_tot = h_flag + 256;
+   char *pin = nullptr;
+   e = sb::ctx_pinned(c, 0, h_tot + 256, &pin);
+   if (e != hipSuccess) return bail(SBGPU_ENOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+   int32_t *nb = (int32_t *)(pin + h_nb), *nu = (int32_t *)(pin + h_nu);
+   volatile int32_t *flags_h = (volatile int32_t *)(pin + h_flag);
+   volatile int64_t *totals_h = (volatile int64_t *)(pin + h_tot);
+   hipStream_t cs = nullptr;
+   hipEvent_t ev_up = nullptr, ev_rows = nullptr, ev_in = nullptr, ev_acc = nullptr;
+   SB_TRY(sb::ctx_copy_stream(c, &cs));
+   SB_TRY(sb::ctx_event(c, 0, &ev_up));
+   SB_TRY(sb::ctx_event(c, 1, &ev_rows));
+   SB_TRY(sb::ctx_event(c, 2, &ev_in));
+   SB_TRY(sb::ctx_event(c, 4, &ev_acc));
+   // ---- uploads on the copy stream, beside whatever the main stream still runs (the caller's exon-bin kernel): a copy
+   // in the main stream between two kernels costs the hand-over to the DMA engine and back, 0.3 ms each way measured.
+   // First what the grouping kernels read (hit offsets, the loci's order), then the annotation's part of the pairs' inputs.
+   // (Streams share hardware queues -- the copy stream may sit in the main stream's queue and then runs in issue order
+   // with it -- so nothing here counts on the overlap; the zero fill of the bins' counts and compat words is a kernel of
+   // this library because the runtime's takes 0.2 ms for the 12 MB of 1.5 M hits.)
+   SB_TRY(hipMemcpyAsync(d + o_hoff, locus_hit_off, (size_t)(nl + 1) * 8, hipMemcpyHostToDevice, cs));
+   {
+      const int64_t n16 = (int64_t)(zero_bytes / 16); // (the arena's parts are 256-byte multiples)
+      hipLaunchKernelGGL(sb::bins_zero_kernel, dim3((unsigned)std::min<int64_t>((n16 + 255) / 256, cap * 4)), dim3(256), 0, cs, (uint4 *)(d + o_zero), n16);
+      hipLaunchKernelGGL(sb::bins_zero_kernel, dim3(1), dim3(256), 0, cs, (uint4 *)(d + o_flag), (int64_t)16);
+      SB_TRY(hipGetLastError());
+   }
+   const int64_t *d_iso_off = d_an ? d_an->iso_off : (const int64_t *)(d3 + r_isoff);
    // small and big loci in two launches (two LDS table sizes)
    std::vector<int32_t> order((size_t)nl);
    int64_t n_small = 0;
@@ -348,7 +428,9 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
       auto mid = std::stable_partition(first_big, last_big, [&](int32_t l) { return hits_of(l) >= heavy; });
       std::sort(first_big, mid, [&](int32_t x, int32_t y) { return hits_of(x) != hits_of(y) ? hits_of(x) > hits_of(y) : x < y; });
    }
-   SB_TRY(hipMemcpyAsync(d + o_order, order.data(), (size_t)nl * 4, hipMemcpyHostToDevice, s));
+   SB_TRY(hipMemcpyAsync(d + o_order, order.data(), (size_t)nl * 4, hipMemcpyHostToDevice, cs));
+   SB_TRY(hipEventRecord(ev_in, cs));
+   SB_TRY(hipStreamWaitEvent(s, ev_in, 0));
    // the single-pass kernels (bins_device.h) where a bin's compat union fits two words; SBGPU_BINS_TWO_PASS=1: the older form (A/B)
    static const bool two_pass_env = std::getenv("SBGPU_BINS_TWO_PASS") && std::atoi(std::getenv("SBGPU_BINS_TWO_PASS")) != 0;
    const bool single_pass = compat_words <= 2 && key_words <= 2 && !two_pass_env;
@@ -373,84 +455,41 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
    }
    SB_TRY(hipGetLastError());
    sb::ctx_stage_end(c, s);
-   std::vector<int32_t> nb((size_t)nl), nu((size_t)nl);
-   int32_t flags = 0;
-   SB_TRY(hipMemcpyAsync(nb.data(), d + o_nb, (size_t)nl * 4, hipMemcpyDeviceToHost, s));
-   SB_TRY(hipMemcpyAsync(nu.data(), d + o_nu, (size_t)nl * 4, hipMemcpyDeviceToHost, s));
-   SB_TRY(hipMemcpyAsync(&flags, d + o_flag, 4, hipMemcpyDeviceToHost, s));
-   SB_TRY(hipStreamSynchronize(s));
-   {
-      // loci the middle table could not hold: again, with the big one
-      std::vector<int32_t> redo;
-      for (int64_t l = 0; l < nl; ++l)
-         if (nb[(size_t)l] < 0) redo.push_back((int32_t)l);
-      if (!redo.empty()) {
-         SB_TRY(hipMemcpyAsync(d + o_order, redo.data(), redo.size() * 4, hipMemcpyHostToDevice, s));
-         a.n_loci = (int64_t)redo.size();
-         a.loci = (const int32_t *)(d + o_order);
-         hipLaunchKernelGGL((sb::bins_locus_kernel<sb::kBinsSlotsBig, sb::kBinsMaxBig, sb::kBinsThreadsBig>),
-                            dim3((unsigned)std::min<int64_t>((int64_t)redo.size(), cap)), dim3(sb::kBinsThreadsBig), 0, s, a);
-         SB_TRY(hipGetLastError());
-         SB_TRY(hipMemcpyAsync(nb.data(), d + o_nb, (size_t)nl * 4, hipMemcpyDeviceToHost, s));
-         SB_TRY(hipMemcpyAsync(nu.data(), d + o_nu, (size_t)nl * 4, hipMemcpyDeviceToHost, s));
-         SB_TRY(hipMemcpyAsync(&flags, d + o_flag, 4, hipMemcpyDeviceToHost, s));
-         SB_TRY(hipStreamSynchronize(s));
+   // bins / hits used per locus and the grouping kernels' flags, to the pinned words -- on the copy stream, behind an
+   // event of the main one, which goes straight on to the middle (a copy in the main stream holds the next kernel back
+   // by the hand-over to the DMA engine: 0.25 ms measured here)
+   auto fetch_rows = [&]() -> hipError_t {
+      hipError_t x = hipEventRecord(ev_acc, s);
+      if (x == hipSuccess) x = hipStreamWaitEvent(cs, ev_acc, 0);
+      if (x == hipSuccess) x = hipMemcpyAsync(nb, d + o_nb, (size_t)nl * 4, hipMemcpyDeviceToHost, cs);
+      if (x == hipSuccess) x = hipMemcpyAsync(nu, d + o_nu, (size_t)nl * 4, hipMemcpyDeviceToHost, cs);
+      if (x == hipSuccess) x = hipMemcpyAsync((void *)flags_h, d + o_flag, 8, hipMemcpyDeviceToHost, cs);
+      if (x == hipSuccess) x = hipEventRecord(ev_rows, cs);
+      return x;
+   };
+   // (the annotation's part goes up while the grouping kernels run)
+   if (!d_an) {
+      SB_TRY(hipMemcpyAsync(d3 + r_isoff, an->iso_off, (size_t)(nl + 1) * 8, hipMemcpyHostToDevice, cs));
+      SB_TRY(hipMemcpyAsync(d3 + r_segoff, an->seg_off, (size_t)(nl + 1) * 8, hipMemcpyHostToDevice, cs));
+      if (n_seg) {
+         SB_TRY(hipMemcpyAsync(d3 + r_segl, an->seg_left, (size_t)n_seg * 4, hipMemcpyHostToDevice, cs));
+         SB_TRY(hipMemcpyAsync(d3 + r_segr, an->seg_right, (size_t)n_seg * 4, hipMemcpyHostToDevice, cs));
       }
    }
-   // hit -> bin: the single-pass kernels leave it out; it is made where somebody reads it (the caller's hit_bin, the
-   // ordered masses below).  Loci the big table served have theirs already.
-   if (single_pass && (d_hit_bin || flags == sb::kBinsFractional) && nh) {
-      std::vector<int32_t> todo;
-      for (int64_t l = 0; l < nl; ++l)
-         if (nb[(size_t)l] <= sb::kBinsMaxMid) todo.push_back((int32_t)l);
-      if (!todo.empty()) {
-         SB_TRY(hipMemcpyAsync(d + o_order, todo.data(), todo.size() * 4, hipMemcpyHostToDevice, s));
-         a.n_loci = (int64_t)todo.size();
-         a.loci = (const int32_t *)(d + o_order);
-         hipLaunchKernelGGL((sb::bins_assign_kernel<sb::kBinsSlotsMid, sb::kBinsThreadsMid>),
-                            dim3((unsigned)std::min<int64_t>((int64_t)todo.size(), cap * 4)), dim3(sb::kBinsThreadsMid), 0, s, a);
-         SB_TRY(hipGetLastError());
-         SB_TRY(hipStreamSynchronize(s)); // (`todo` leaves scope)
+   const sb::DeviceIsoSegments *d_iso = hooks ? hooks->d_iso : nullptr;
+   if (!d_iso) {
+      SB_TRY(hipMemcpyAsync(d3 + r_isegoff, iso_seg_off.data(), (size_t)(n_iso + 1) * 8, hipMemcpyHostToDevice, cs));
+      if (!iso_seg_idx.empty()) SB_TRY(hipMemcpyAsync(d3 + r_isegidx, iso_seg_idx.data(), iso_seg_idx.size() * 4, hipMemcpyHostToDevice, cs));
+      if (n_iso) {
+         SB_TRY(hipMemcpyAsync(d3 + r_isoloc, iso_locus.data(), (size_t)n_iso * 4, hipMemcpyHostToDevice, cs));
+         SB_TRY(hipMemcpyAsync(d3 + r_isolen, iso_len.data(), (size_t)n_iso * 4, hipMemcpyHostToDevice, cs));
       }
    }
-   if (flags == sb::kBinsFractional) {
-      // fractional masses (multi-mapped reads): the bins stand, their masses are summed again in float, in the
-      // order of the reference's std::set (bins_device.h)
-      std::vector<int32_t> all((size_t)nl);
-      for (int64_t l = 0; l < nl; ++l) all[(size_t)l] = (int32_t)l;
-      SB_TRY(hipMemcpyAsync(d + o_order, all.data(), (size_t)nl * 4, hipMemcpyHostToDevice, s));
-      SB_TRY(hipMemsetAsync(d + o_flag, 0, 4, s));
-      a.n_loci = nl;
-      a.loci = (const int32_t *)(d + o_order);
-      hipLaunchKernelGGL(sb::bins_ordered_mass_kernel, dim3((unsigned)std::min<int64_t>(nl, cap * 4)), dim3(256), 0, s, a);
-      SB_TRY(hipGetLastError());
-      SB_TRY(hipMemcpyAsync(&flags, d + o_flag, 4, hipMemcpyDeviceToHost, s));
-      SB_TRY(hipStreamSynchronize(s));
-   }
-   if (flags) {
-      std::string why = "sbgpu_bins_create_device: not covered by the device form:";
-      if (flags & sb::kBinsUnsorted) why += " hits of a locus are not sorted by (left, right);";
-      if (flags & sb::kBinsFractional) why += " fractional hit masses next to another obstacle;";
-      if (flags & sb::kBinsTableFull) why += " a locus has more bins than the LDS table holds;";
-      if (flags & sb::kBinsRunTooLong) why += " fractional masses and more than 48 fragments of one bin starting at one position;";
-      return bail(SBGPU_EUNSUPPORTED, why + " use sbgpu_bins_create");
-   }
-   stage("group kernel");
-   std::vector<int64_t> row_off((size_t)nl + 1, 0);
-   int64_t used = 0;
-   for (int64_t l = 0; l < nl; ++l) {
-      row_off[(size_t)l + 1] = row_off[(size_t)l] + nb[(size_t)l];
-      used += nu[(size_t)l];
-   }
-   const int64_t n_bins = row_off[(size_t)nl];
-   const size_t nb1 = (size_t)(n_bins > 0 ? n_bins : 1);
-   size_t off2 = 0;
-   const size_t p_cnt = off2; off2 += up(nb1 * 4);
-   const size_t p_key = off2; off2 += up(nb1 * 4 * (size_t)key_words);
-   const size_t p_cmp = off2; off2 += up(nb1 * 4 * (size_t)compat_words);
-   e = sb::ctx_scratch(c, 3, off2, &d2);
-   if (e != hipSuccess) return bail(e == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e));
-   SB_TRY(hipMemcpyAsync(d + o_roff, row_off.data(), (size_t)(nl + 1) * 8, hipMemcpyHostToDevice, s));
+   SB_TRY(hipEventRecord(ev_up, cs));
+   SB_TRY(fetch_rows());
+   // ---- the middle: rows scanned, bins packed, pairs counted and scanned -- behind the grouping kernels without a
+   // host round trip.  Its flags are a word of their own (o_flag + 4), cleared per launch: the middle may run a second
+   // time (below).
    sb::BinsPackArgs pk;
    pk.n_loci = nl;
    pk.locus_hit_off = a.locus_hit_off;
@@ -466,82 +505,19 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
    pk.bin_key = (uint32_t *)(d2 + p_key);
    pk.bin_compat = (uint32_t *)(d2 + p_cmp);
    pk.hit_bin = d_hit_bin;
-   pk.flags = a.flags;
-   sb::ctx_stage_begin(c, "bins_pack_kernel", s);
-   hipLaunchKernelGGL(sb::bins_pack_kernel, dim3((unsigned)(nl < cap ? nl : cap)), dim3(256), 0, s, pk);
-   sb::ctx_stage_end(c, s);
-   SB_TRY(hipGetLastError());
-   std::vector<int32_t> count(nb1);
-   std::vector<uint32_t> key(nb1 * (size_t)key_words), compat(nb1 * (size_t)compat_words);
-   stage("pack");
-   // ---- the (bin, isoform) pairs, on the device too (bins_pairs_kernel): the isoforms' segment lists
-   // (Isoform::_exon_segs, include/isoform.h:59-71) come from the host annotation
-   const int64_t n_iso = an->iso_off[nl];
-   std::vector<int64_t> f_off((size_t)nl + 1, 0);
-   sb::IsoSegments own_segments;
-   if (!iso_pre) { // a caller that knows the annotation earlier makes them while something else runs (chain_api.hip)
-      sb::iso_segments(an, &own_segments);
-      iso_pre = &own_segments;
-   }
-   const std::vector<int64_t> &iso_seg_off = iso_pre->seg_off;
-   const std::vector<int32_t> &iso_seg_idx = iso_pre->seg_idx, &iso_locus = iso_pre->locus, &iso_len = iso_pre->len;
-   for (int64_t l = 0; l < nl; ++l)
-      f_off[(size_t)l + 1] = f_off[(size_t)l] + (row_off[(size_t)l + 1] - row_off[(size_t)l]) * (an->iso_off[l + 1] - an->iso_off[l]);
-   stage("iso segments");
-   const size_t ni1 = (size_t)(n_iso > 0 ? n_iso : 1), nsi1 = iso_seg_idx.empty() ? 1 : iso_seg_idx.size();
-   const int64_t n_seg = an->seg_off[nl];
-   size_t off3 = 0;
-   const size_t r_isoff = off3; off3 += up((size_t)(nl + 1) * 8);
-   const size_t r_foff = off3; off3 += up((size_t)(nl + 1) * 8);
-   const size_t r_segoff = off3; off3 += up((size_t)(nl + 1) * 8);
-   const size_t r_segl = off3; off3 += up((size_t)(n_seg + 1) * 4);
-   const size_t r_segr = off3; off3 += up((size_t)(n_seg + 1) * 4);
-   const size_t r_isegoff = off3; off3 += up((ni1 + 1) * 8);
-   const size_t r_isegidx = off3; off3 += up(nsi1 * 4);
-   const size_t r_isoloc = off3; off3 += up(ni1 * 4);
-   const size_t r_isolen = off3; off3 += up(ni1 * 4);
-   const size_t r_pcnt = off3; off3 += up(ni1 * 4);
-   const size_t r_scnt = off3; off3 += up(ni1 * 4);
-   const size_t r_poff = off3; off3 += up((ni1 + 1) * 8);
-   const size_t r_soff = off3; off3 += up((ni1 + 1) * 8);
-   char *d3 = nullptr;
-   e = sb::ctx_scratch(c, 4, off3, &d3);
-   if (e != hipSuccess) return bail(e == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e));
-   sb::DevicePairs dp;
-   auto bail3 = [&](int code, const std::string &msg) {
-      (void)hipFree(dp.arena);
-      return bail(code, msg);
-   };
-#define SB_TRY3(expr)                                                                          \
-   do {                                                                                        \
-      hipError_t e_ = (expr);                                                                  \
-      if (e_ != hipSuccess) return bail3(SBGPU_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
-   } while (0)
-   SB_TRY3(hipMemcpyAsync(d3 + r_isoff, an->iso_off, (size_t)(nl + 1) * 8, hipMemcpyHostToDevice, s));
-   SB_TRY3(hipMemcpyAsync(d3 + r_foff, f_off.data(), (size_t)(nl + 1) * 8, hipMemcpyHostToDevice, s));
-   SB_TRY3(hipMemcpyAsync(d3 + r_segoff, an->seg_off, (size_t)(nl + 1) * 8, hipMemcpyHostToDevice, s));
-   if (n_seg) {
-      SB_TRY3(hipMemcpyAsync(d3 + r_segl, an->seg_left, (size_t)n_seg * 4, hipMemcpyHostToDevice, s));
-      SB_TRY3(hipMemcpyAsync(d3 + r_segr, an->seg_right, (size_t)n_seg * 4, hipMemcpyHostToDevice, s));
-   }
-   SB_TRY3(hipMemcpyAsync(d3 + r_isegoff, iso_seg_off.data(), (size_t)(n_iso + 1) * 8, hipMemcpyHostToDevice, s));
-   if (!iso_seg_idx.empty()) SB_TRY3(hipMemcpyAsync(d3 + r_isegidx, iso_seg_idx.data(), iso_seg_idx.size() * 4, hipMemcpyHostToDevice, s));
-   if (n_iso) {
-      SB_TRY3(hipMemcpyAsync(d3 + r_isoloc, iso_locus.data(), (size_t)n_iso * 4, hipMemcpyHostToDevice, s));
-      SB_TRY3(hipMemcpyAsync(d3 + r_isolen, iso_len.data(), (size_t)n_iso * 4, hipMemcpyHostToDevice, s));
-   }
+   pk.flags = a.flags + 1;
    sb::PairsArgs pa;
    pa.n_iso = n_iso;
-   pa.iso_locus = (const int32_t *)(d3 + r_isoloc);
-   pa.iso_off = (const int64_t *)(d3 + r_isoff);
+   pa.iso_locus = d_iso ? d_iso->locus : (const int32_t *)(d3 + r_isoloc);
+   pa.iso_off = d_iso_off;
    pa.row_off = pk.row_off;
    pa.f_off = (const int64_t *)(d3 + r_foff);
-   pa.seg_off = (const int64_t *)(d3 + r_segoff);
-   pa.seg_left = (const uint32_t *)(d3 + r_segl);
-   pa.seg_right = (const uint32_t *)(d3 + r_segr);
-   pa.iso_seg_off = (const int64_t *)(d3 + r_isegoff);
-   pa.iso_seg_idx = (const int32_t *)(d3 + r_isegidx);
-   pa.iso_len = (const int32_t *)(d3 + r_isolen);
+   pa.seg_off = d_an ? d_an->seg_off : (const int64_t *)(d3 + r_segoff);
+   pa.seg_left = d_an ? d_an->seg_left : (const uint32_t *)(d3 + r_segl);
+   pa.seg_right = d_an ? d_an->seg_right : (const uint32_t *)(d3 + r_segr);
+   pa.iso_seg_off = d_iso ? d_iso->seg_off : (const int64_t *)(d3 + r_isegoff);
+   pa.iso_seg_idx = d_iso ? d_iso->seg_idx : (const int32_t *)(d3 + r_isegidx);
+   pa.iso_len = d_iso ? d_iso->len : (const int32_t *)(d3 + r_isolen);
    pa.compat_words = compat_words;
    pa.key_words = key_words;
    pa.bin_key = pk.bin_key;
@@ -554,42 +530,152 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
    pa.pair_seg_lens = pa.pair_mask = nullptr;
    pa.pair_iso_len = nullptr;
    pa.pair_out_index = nullptr;
-   pa.flags = a.flags;
+   pa.flags = a.flags + 1;
    const unsigned pgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_iso + 255) / 256, cap * 4));
-   sb::ctx_stage_begin(c, "bins_pairs_kernel<count>", s);
-   hipLaunchKernelGGL(sb::bins_pairs_kernel<false>, dim3(pgrid), dim3(256), 0, s, pa);
-   sb::ctx_stage_end(c, s);
-   SB_TRY3(hipGetLastError());
-   std::vector<int32_t> pcnt(ni1), scnt(ni1);
-   if (n_iso) {
-      SB_TRY3(hipMemcpyAsync(pcnt.data(), d3 + r_pcnt, (size_t)n_iso * 4, hipMemcpyDeviceToHost, s));
-      SB_TRY3(hipMemcpyAsync(scnt.data(), d3 + r_scnt, (size_t)n_iso * 4, hipMemcpyDeviceToHost, s));
+   auto launch_middle = [&]() -> hipError_t {
+      hipError_t x = hipMemsetAsync(d + o_flag + 4, 0, 4, s);
+      if (x == hipSuccess) x = hipStreamWaitEvent(s, ev_up, 0);
+      if (x != hipSuccess) return x;
+      sb::ctx_stage_begin(c, "bins_scan_*_kernel<rows> + bins_pack_kernel", s);
+      int64_t *part_a = (int64_t *)(d3 + r_part), *part_b = part_a + std::max(row_tiles, iso_tiles) + 1;
+      sb::ScanArgs sr = {nl, a.n_bins, nullptr, d_iso_off, (int64_t *)(d + o_roff), (int64_t *)(d3 + r_foff), part_a, part_b, (int64_t *)(d3 + r_tot)};
+      hipLaunchKernelGGL(sb::bins_scan_tiles_kernel<0>, dim3((unsigned)row_tiles), dim3(256), 0, s, sr);
+      hipLaunchKernelGGL(sb::bins_scan_parts_kernel, dim3(1), dim3(256), 0, s, sr, row_tiles);
+      hipLaunchKernelGGL(sb::bins_scan_apply_kernel<0>, dim3((unsigned)row_tiles), dim3(256), 0, s, sr);
+      hipLaunchKernelGGL(sb::bins_pack_kernel, dim3((unsigned)(nl < cap ? nl : cap)), dim3(256), 0, s, pk);
+      sb::ctx_stage_end(c, s);
+      sb::ctx_stage_begin(c, "bins_pairs_kernel<count> + bins_scan_*_kernel<pairs>", s);
+      hipLaunchKernelGGL(sb::bins_pairs_kernel<false>, dim3(pgrid), dim3(256), 0, s, pa);
+      sb::ScanArgs sp = {n_iso, pa.pair_cnt, pa.seg_cnt, nullptr, (int64_t *)(d3 + r_poff), (int64_t *)(d3 + r_soff), part_a, part_b, (int64_t *)(d3 + r_tot) + 2};
+      hipLaunchKernelGGL(sb::bins_scan_tiles_kernel<1>, dim3((unsigned)iso_tiles), dim3(256), 0, s, sp);
+      hipLaunchKernelGGL(sb::bins_scan_parts_kernel, dim3(1), dim3(256), 0, s, sp, n_iso ? iso_tiles : 0);
+      hipLaunchKernelGGL(sb::bins_scan_apply_kernel<1>, dim3((unsigned)iso_tiles), dim3(256), 0, s, sp);
+      sb::ctx_stage_end(c, s);
+      if ((x = hipGetLastError()) != hipSuccess) return x;
+      x = hipMemcpyAsync((void *)totals_h, d3 + r_tot, 32, hipMemcpyDeviceToHost, s);
+      if (x == hipSuccess) x = hipMemcpyAsync((void *)flags_h, d + o_flag, 8, hipMemcpyDeviceToHost, s);
+      return x;
+   };
+   // Where nothing on the host has to come between (the usual case: single-pass kernels, hit -> bin not asked for), the
+   // middle is launched before the bin counts are back; should the counts then call for a fix-up -- a locus for the big
+   // table, fractional masses -- the fix-up runs and the middle is launched again over its result.
+   const bool speculative = single_pass && !d_hit_bin;
+   if (speculative) SB_TRY(launch_middle());
+   SB_TRY(hipEventSynchronize(ev_rows));
+   int32_t flags = flags_h[0];
+   bool fixed_up = false;
+   {
+      // loci the middle table could not hold: again, with the big one
+      std::vector<int32_t> redo;
+      for (int64_t l = 0; l < nl; ++l)
+         if (nb[(size_t)l] < 0) redo.push_back((int32_t)l);
+      if (!redo.empty()) {
+         fixed_up = true;
+         SB_TRY(hipStreamSynchronize(s));
+         SB_TRY(hipMemcpyAsync(d + o_order, redo.data(), redo.size() * 4, hipMemcpyHostToDevice, s));
+         a.n_loci = (int64_t)redo.size();
+         a.loci = (const int32_t *)(d + o_order);
+         hipLaunchKernelGGL((sb::bins_locus_kernel<sb::kBinsSlotsBig, sb::kBinsMaxBig, sb::kBinsThreadsBig>),
+                            dim3((unsigned)std::min<int64_t>((int64_t)redo.size(), cap)), dim3(sb::kBinsThreadsBig), 0, s, a);
+         SB_TRY(hipGetLastError());
+         SB_TRY(fetch_rows());
+         SB_TRY(hipEventSynchronize(ev_rows));
+         flags = flags_h[0];
+      }
    }
-   SB_TRY3(hipMemcpyAsync(&flags, d + o_flag, 4, hipMemcpyDeviceToHost, s));
+   // hit -> bin: the single-pass kernels leave it out; it is made where somebody reads it (the caller's hit_bin, the
+   // ordered masses below).  Loci the big table served have theirs already.
+   if (single_pass && (d_hit_bin || flags == sb::kBinsFractional) && nh) {
+      std::vector<int32_t> todo;
+      for (int64_t l = 0; l < nl; ++l)
+         if (nb[(size_t)l] <= sb::kBinsMaxMid) todo.push_back((int32_t)l);
+      if (!todo.empty()) {
+         SB_TRY(hipStreamSynchronize(s));
+         SB_TRY(hipMemcpyAsync(d + o_order, todo.data(), todo.size() * 4, hipMemcpyHostToDevice, s));
+         a.n_loci = (int64_t)todo.size();
+         a.loci = (const int32_t *)(d + o_order);
+         hipLaunchKernelGGL((sb::bins_assign_kernel<sb::kBinsSlotsMid, sb::kBinsThreadsMid>),
+                            dim3((unsigned)std::min<int64_t>((int64_t)todo.size(), cap * 4)), dim3(sb::kBinsThreadsMid), 0, s, a);
+         SB_TRY(hipGetLastError());
+         SB_TRY(hipStreamSynchronize(s)); // (`todo` leaves scope)
+      }
+   }
+   if (flags == sb::kBinsFractional) {
+      // fractional masses (multi-mapped reads): the bins stand, their masses are summed again in float, in the
+      // order of the reference's std::set (bins_device.h)
+      fixed_up = true;
+      std::vector<int32_t> all((size_t)nl);
+      for (int64_t l = 0; l < nl; ++l) all[(size_t)l] = (int32_t)l;
+      SB_TRY(hipStreamSynchronize(s));
+      SB_TRY(hipMemcpyAsync(d + o_order, all.data(), (size_t)nl * 4, hipMemcpyHostToDevice, s));
+      SB_TRY(hipMemsetAsync(d + o_flag, 0, 4, s));
+      a.n_loci = nl;
+      a.loci = (const int32_t *)(d + o_order);
+      hipLaunchKernelGGL(sb::bins_ordered_mass_kernel, dim3((unsigned)std::min<int64_t>(nl, cap * 4)), dim3(256), 0, s, a);
+      SB_TRY(hipGetLastError());
+      SB_TRY(hipMemcpyAsync((void *)flags_h, d + o_flag, 8, hipMemcpyDeviceToHost, s));
+      SB_TRY(hipStreamSynchronize(s));
+      flags = flags_h[0];
+   }
+   if (flags) {
+      (void)hipStreamSynchronize(s);
+      std::string why = "sbgpu_bins_create_device: not covered by the device form:";
+      if (flags & sb::kBinsUnsorted) why += " hits of a locus are not sorted by (left, right);";
+      if (flags & sb::kBinsFractional) why += " fractional hit masses next to another obstacle;";
+      if (flags & sb::kBinsTableFull) why += " a locus has more bins than the LDS table holds;";
+      if (flags & sb::kBinsRunTooLong) why += " fractional masses and more than 48 fragments of one bin starting at one position;";
+      return bail(SBGPU_EUNSUPPORTED, why + " use sbgpu_bins_create");
+   }
+   stage("group kernel");
+   // ---- host: the same prefix sums (the handle, the caller's plan), while the middle runs
+   std::vector<int64_t> row_off((size_t)nl + 1, 0), f_off((size_t)nl + 1, 0);
+   int64_t used = 0;
+   for (int64_t l = 0; l < nl; ++l) {
+      row_off[(size_t)l + 1] = row_off[(size_t)l] + nb[(size_t)l];
+      f_off[(size_t)l + 1] = f_off[(size_t)l] + (int64_t)nb[(size_t)l] * (an->iso_off[l + 1] - an->iso_off[l]);
+      used += nu[(size_t)l];
+   }
+   const int64_t n_bins = row_off[(size_t)nl];
+   if (hooks && hooks->rows_known) hooks->rows_known(row_off.data(), f_off.data());
+   // the pairs' arena, allocated by the size of the last call's while the middle runs (none yet, or too small: below)
+   sb::DevicePairs dp;
+   size_t dp_bytes = sb::ctx_pairs_hint(c);
+   if (dp_bytes && sb::dev_take(dp_bytes, &dp.arena, &dp.capacity) != hipSuccess) dp.arena = nullptr, dp.capacity = 0;
+   dp_bytes = dp.capacity;
+   auto bail3 = [&](int code, const std::string &msg) {
+      (void)hipStreamSynchronize(s);
+      sb::dev_give(dp.arena, dp.capacity);
+      return bail(code, msg);
+   };
+#define SB_TRY3(expr)                                                                          \
+   do {                                                                                        \
+      hipError_t e_ = (expr);                                                                  \
+      if (e_ != hipSuccess) return bail3(SBGPU_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+   } while (0)
+   if (!speculative || fixed_up) SB_TRY3(launch_middle());
    SB_TRY3(hipStreamSynchronize(s));
+   flags = flags_h[1];
+   if (totals_h[0] != n_bins || totals_h[1] != f_off[(size_t)nl]) return bail3(SBGPU_EHIP, "sbgpu_bins_create_device: device and host prefix sums differ");
    if (flags & sb::kBinsMassOverflow) return bail3(SBGPU_EUNSUPPORTED, "sbgpu_bins_create_device: a bin's mass reaches 2^24; use sbgpu_bins_create");
    if (flags & (sb::kPairsNotUnder | sb::kPairsForeignSegment))
       return bail3(SBGPU_EUNSUPPORTED, "sbgpu_bins_create_device: a bin does not sit under an isoform it is compatible with; sbgpu_bins_create reports the details");
-   stage("pairs count");
-   std::vector<int64_t> poff((size_t)n_iso + 1, 0), soff((size_t)n_iso + 1, 0);
-   for (int64_t i = 0; i < n_iso; ++i) {
-      poff[(size_t)i + 1] = poff[(size_t)i] + pcnt[(size_t)i];
-      soff[(size_t)i + 1] = soff[(size_t)i] + scnt[(size_t)i];
-   }
+   stage("pack + pairs count");
    dp.any_wide = (flags & sb::kPairsWide) != 0;
-   dp.n_pairs = poff[(size_t)n_iso];
-   dp.n_pair_segs = soff[(size_t)n_iso];
+   dp.n_pairs = totals_h[2];
+   dp.n_pair_segs = totals_h[3];
    size_t off4 = 0;
    dp.o_seg_off = off4; off4 += up(((size_t)dp.n_pairs + 1) * 8);
    dp.o_out_index = off4; off4 += up(((size_t)dp.n_pairs + 1) * 8);
    dp.o_seg_lens = off4; off4 += up(((size_t)dp.n_pair_segs + 1) * 4);
    dp.o_mask = off4; off4 += up(((size_t)dp.n_pairs + 1) * 4);
    dp.o_iso_len = off4; off4 += up(((size_t)dp.n_pairs + 1) * 4);
-   e = hipMalloc(&dp.arena, off4);
-   if (e != hipSuccess) return bail3(e == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e));
-   SB_TRY3(hipMemcpyAsync(d3 + r_poff, poff.data(), (size_t)(n_iso + 1) * 8, hipMemcpyHostToDevice, s));
-   SB_TRY3(hipMemcpyAsync(d3 + r_soff, soff.data(), (size_t)(n_iso + 1) * 8, hipMemcpyHostToDevice, s));
-   SB_TRY3(hipMemcpyAsync(dp.arena + dp.o_seg_off + (size_t)dp.n_pairs * 8, &dp.n_pair_segs, 8, hipMemcpyHostToDevice, s)); // the CSR's last entry
+   if (off4 > dp_bytes) {
+      sb::dev_give(dp.arena, dp.capacity);
+      dp.arena = nullptr;
+      e = sb::dev_take(off4, &dp.arena, &dp.capacity);
+      if (e != hipSuccess) return bail3(e == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+   }
+   sb::ctx_set_pairs_hint(c, off4);
    pa.pair_seg_off = (int64_t *)(dp.arena + dp.o_seg_off);
    pa.pair_seg_lens = (uint32_t *)(dp.arena + dp.o_seg_lens);
    pa.pair_mask = (uint32_t *)(dp.arena + dp.o_mask);
@@ -599,29 +685,27 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
    hipLaunchKernelGGL(sb::bins_pairs_kernel<true>, dim3(pgrid), dim3(256), 0, s, pa);
    sb::ctx_stage_end(c, s);
    SB_TRY3(hipGetLastError());
-   // the per-bin arrays for the host-side handle (17 MB for 1.4 M bins): behind the fill kernel in the stream
-   if (n_bins) {
-      SB_TRY3(hipMemcpyAsync(count.data(), d2 + p_cnt, (size_t)n_bins * 4, hipMemcpyDeviceToHost, s));
-      SB_TRY3(hipMemcpyAsync(key.data(), d2 + p_key, (size_t)n_bins * 4 * key_words, hipMemcpyDeviceToHost, s));
-      SB_TRY3(hipMemcpyAsync(compat.data(), d2 + p_cmp, (size_t)n_bins * 4 * compat_words, hipMemcpyDeviceToHost, s));
-   }
-   SB_TRY3(hipStreamSynchronize(s));
-   stage("pairs fill + D2H");
-   // the caller's kernels behind the grouping (bin weights, EM) go into the stream now: the handle below is host work
-   // (copies and per-locus bookkeeping, ~2 ms for 60 000 loci) that then runs beside them
-   if (after_pairs) {
+   stage("pairs fill launch");
+   // the caller's kernels behind the grouping (bin weights, EM) go into the stream now
+   if (hooks && hooks->after_pairs) {
       const sb::DeviceGrouping g = {row_off.data(), f_off.data(), n_bins, f_off[(size_t)nl], (const int32_t *)(d2 + p_cnt), &dp};
-      const int rc_after = (*after_pairs)(g);
+      const int rc_after = hooks->after_pairs(g);
       if (rc_after != SBGPU_OK) {
          (void)hipStreamSynchronize(s);
-         (void)hipFree(dp.arena);
+         sb::dev_give(dp.arena, dp.capacity);
          return rc_after;
       }
    }
 #undef SB_TRY3
 #undef SB_TRY
-   const int rc = sb::bins_from_groups(an, compat_words, key_words, row_off.data(), count.data(), key.data(), compat.data(), used, &dp, out);
-   if (rc != SBGPU_OK) (void)hipFree(dp.arena);
+   const sb::DeviceBinArrays dba = {d2, d2_cap, p_cnt, p_key, p_cmp};
+   const int rc = sb::bins_from_groups(an, compat_words, key_words, row_off.data(), dba, used, &dp, &iso_pre->len, out);
+   if (rc != SBGPU_OK) {
+      (void)hipStreamSynchronize(s);
+      sb::dev_give(dp.arena, dp.capacity);
+   } else {
+      d2 = nullptr; // the handle's now (d2_guard lets go)
+   }
    stage("handle");
    return rc;
 }

@@ -34,8 +34,8 @@ struct sbgpu_bins {
    int64_t n_loci = 0, n_iso = 0, n_bins = 0, n_elem = 0, n_pairs = 0, n_pair_segs = 0, n_hits_used = 0;
    int32_t key_words = 0, compat_words = 0;
    std::vector<int64_t> row_off, iso_off, f_off;
-   std::vector<int32_t> count;
-   std::vector<uint32_t> bin_key, bin_compat;
+   sb::PodVec<int32_t> count;
+   sb::PodVec<uint32_t> bin_key, bin_compat;
    std::vector<int32_t> iso_len;
    std::vector<int64_t> hit_bin; // global bin of every hit, -1 when it has no compatible isoform
    std::vector<int64_t> pair_seg_off, pair_out_index;
@@ -44,7 +44,13 @@ struct sbgpu_bins {
    std::vector<double> F; // the EM batch's weights, when the handle comes from sbgpu_quantify_host
    sb::DevicePairs dev;   // pairs made on the device: downloaded into the vectors above on first export
    bool pairs_on_device = false, pairs_downloaded = false;
-   ~sbgpu_bins() { (void)hipFree(dev.arena); }
+   sb::DeviceBinArrays dev_bins; // device grouping: count / key / compat stay on the device until an export asks for them
+   bool bins_downloaded = false;
+   ~sbgpu_bins()
+   {
+      sb::dev_give(dev.arena, dev.capacity);
+      sb::dev_give(dev_bins.arena, dev_bins.capacity);
+   }
 };
 
 namespace {
@@ -212,6 +218,9 @@ struct PreGrouped {
    const uint32_t *key, *compat;
    int64_t n_hits_used;
    const sb::DevicePairs *dev; // the pairs too were made on the device
+   // with `dev`: count / key / compat are device pointers into an arena the handle takes over; the isoforms' lengths
+   const sb::DeviceBinArrays *dev_bins;
+   const std::vector<int32_t> *iso_len;
 };
 
 int bins_create_impl(const sbgpu_annotation_t *an, const sbgpu_hits_t *hits, const float *hit_mass,
@@ -256,11 +265,15 @@ int bins_create_impl(const sbgpu_annotation_t *an, const sbgpu_hits_t *hits, con
       B->n_iso = n_iso;
       if (nl) B->iso_off.assign(an->iso_off, an->iso_off + nl + 1);
       else B->iso_off.assign(1, 0);
-      B->iso_len.resize((size_t)n_iso);
-      for (int64_t i = 0; i < n_iso; ++i) { // Contig::exonic_length, src/contig.cpp:436-445
-         int64_t len = 0;
-         for (int64_t e = an->exon_off[i]; e < an->exon_off[i + 1]; ++e) len += (int64_t)an->exon_right[e] - an->exon_left[e] + 1;
-         B->iso_len[(size_t)i] = (int32_t)len;
+      if (pre && pre->iso_len && (int64_t)pre->iso_len->size() == n_iso) {
+         B->iso_len = *pre->iso_len; // (sb::iso_segments made them already)
+      } else {
+         B->iso_len.resize((size_t)n_iso);
+         for (int64_t i = 0; i < n_iso; ++i) { // Contig::exonic_length, src/contig.cpp:436-445
+            int64_t len = 0;
+            for (int64_t e = an->exon_off[i]; e < an->exon_off[i + 1]; ++e) len += (int64_t)an->exon_right[e] - an->exon_left[e] + 1;
+            B->iso_len[(size_t)i] = (int32_t)len;
+         }
       }
       if (pre && pre->dev) {
          // bins and pairs both come from the device: the handle only takes the arrays over
@@ -270,9 +283,13 @@ int bins_create_impl(const sbgpu_annotation_t *an, const sbgpu_hits_t *hits, con
          for (int64_t l = 0; l < nl; ++l)
             B->f_off[(size_t)l + 1] = B->f_off[(size_t)l] + (B->row_off[(size_t)l + 1] - B->row_off[(size_t)l]) * (an->iso_off[l + 1] - an->iso_off[l]);
          B->n_elem = B->f_off[(size_t)nl];
-         B->count.assign(pre->count, pre->count + B->n_bins);
-         B->bin_key.assign(pre->key, pre->key + B->n_bins * key_words);
-         B->bin_compat.assign(pre->compat, pre->compat + B->n_bins * compat_words);
+         if (pre->dev_bins && pre->dev_bins->arena) {
+            B->dev_bins = *pre->dev_bins;
+         } else {
+            B->count.assign(pre->count, pre->count + B->n_bins);
+            B->bin_key.assign(pre->key, pre->key + B->n_bins * key_words);
+            B->bin_compat.assign(pre->compat, pre->compat + B->n_bins * compat_words);
+         }
          B->n_hits_used = pre->n_hits_used;
          B->dev = *pre->dev;
          B->pairs_on_device = true;
@@ -569,10 +586,10 @@ void bins_set_hit_bin(sbgpu_bins_t *b, std::vector<int64_t> &&hb) { b->hit_bin =
 const double *bins_weights_tail(const sbgpu_bins_t *b, size_t at) { return b->F.data() + at; }
 const DevicePairs *bins_device_pairs(const sbgpu_bins_t *b) { return b && b->pairs_on_device ? &b->dev : nullptr; }
 int bins_from_groups(const sbgpu_annotation_t *an, int32_t compat_words, int32_t key_words, const int64_t *row_off,
-                     const int32_t *count, const uint32_t *key, const uint32_t *compat, int64_t n_hits_used,
-                     const DevicePairs *pairs, sbgpu_bins_t **out)
+                     const DeviceBinArrays &arrays, int64_t n_hits_used, const DevicePairs *pairs, const std::vector<int32_t> *iso_len,
+                     sbgpu_bins_t **out)
 {
-   const PreGrouped pre = {row_off, count, key, compat, n_hits_used, pairs};
+   const PreGrouped pre = {row_off, nullptr, nullptr, nullptr, n_hits_used, pairs, &arrays, iso_len};
    return bins_create_impl(an, nullptr, nullptr, compat_words, key_words, nullptr, nullptr, &pre, out);
 }
 } // namespace sb
@@ -637,13 +654,27 @@ int sbgpu_bins_export(const sbgpu_bins_t *b, int64_t *row_off, int64_t *iso_off,
    }
 #define SB_COPY(dst, vec)                                                              \
    if (dst && !(vec).empty()) std::memcpy(dst, (vec).data(), (vec).size() * sizeof((vec)[0]))
+   if (b->dev_bins.arena && !b->bins_downloaded && (count || bin_key || bin_compat)) {
+      // the per-bin arrays of a device grouping: downloaded now, once
+      sbgpu_bins *m = const_cast<sbgpu_bins *>(b);
+      const sb::DeviceBinArrays &d = b->dev_bins;
+      m->count.resize((size_t)b->n_bins);
+      m->bin_key.resize((size_t)b->n_bins * b->key_words);
+      m->bin_compat.resize((size_t)b->n_bins * b->compat_words);
+      hipError_t e = hipSuccess;
+      if (b->n_bins) e = hipMemcpy(m->count.data(), d.arena + d.o_count, (size_t)b->n_bins * 4, hipMemcpyDeviceToHost);
+      if (e == hipSuccess && b->n_bins) e = hipMemcpy(m->bin_key.data(), d.arena + d.o_key, (size_t)b->n_bins * 4 * b->key_words, hipMemcpyDeviceToHost);
+      if (e == hipSuccess && b->n_bins) e = hipMemcpy(m->bin_compat.data(), d.arena + d.o_compat, (size_t)b->n_bins * 4 * b->compat_words, hipMemcpyDeviceToHost);
+      if (e != hipSuccess) return api_fail(SBGPU_EHIP, std::string("sbgpu_bins_export: download of the bins: ") + hipGetErrorString(e));
+      m->bins_downloaded = true;
+   }
+   SB_COPY(count, b->count);
+   SB_COPY(bin_key, b->bin_key);
+   SB_COPY(bin_compat, b->bin_compat);
    SB_COPY(row_off, b->row_off);
    SB_COPY(iso_off, b->iso_off);
    SB_COPY(f_off, b->f_off);
-   SB_COPY(count, b->count);
    SB_COPY(iso_len, b->iso_len);
-   SB_COPY(bin_key, b->bin_key);
-   SB_COPY(bin_compat, b->bin_compat);
    SB_COPY(hit_bin, b->hit_bin);
    SB_COPY(pair_seg_off, b->pair_seg_off);
    SB_COPY(pair_seg_lens, b->pair_seg_lens);

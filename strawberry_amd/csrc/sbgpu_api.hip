@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <system_error>
@@ -75,6 +76,13 @@ struct sbgpu_ctx {
    const char *stage_name[kMaxStages] = {};
    int n_stages = 0;
    bool stage_open = false;
+   // host-side helpers of the grouping (sb::ctx_pinned, ctx_copy_stream, ctx_event, ctx_pairs_hint)
+   char *pinned[4] = {};
+   size_t pinned_bytes[4] = {};
+   hipStream_t copy_stream = nullptr;
+   hipEvent_t order_ev[6] = {};
+   size_t pairs_hint = 0;
+   sb::ResidentAnnotation *resident = nullptr; // sbgpu_annotation_pin
 };
 
 namespace sb {
@@ -100,6 +108,128 @@ void ctx_stage_end(sbgpu_ctx_t *ctx, hipStream_t s)
    ctx->stage_open = false;
    ++ctx->n_stages;
 }
+hipError_t ctx_pinned(sbgpu_ctx_t *ctx, int slot, size_t bytes, char **out)
+{
+   *out = nullptr;
+   if (slot < 0 || slot >= 4) return hipErrorInvalidValue;
+   if (bytes < 4096) bytes = 4096;
+   if (ctx->pinned_bytes[slot] < bytes) {
+      if (ctx->pinned[slot]) (void)hipHostFree(ctx->pinned[slot]);
+      ctx->pinned[slot] = nullptr;
+      ctx->pinned_bytes[slot] = 0;
+      const size_t want = bytes + bytes / 4;
+      hipError_t e = hipHostMalloc((void **)&ctx->pinned[slot], want, hipHostMallocDefault);
+      if (e != hipSuccess) return e;
+      ctx->pinned_bytes[slot] = want;
+   }
+   *out = ctx->pinned[slot];
+   return hipSuccess;
+}
+hipError_t ctx_copy_stream(sbgpu_ctx_t *ctx, hipStream_t *out)
+{
+   if (!ctx->copy_stream) {
+      hipError_t e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+      if (e != hipSuccess) return e;
+   }
+   *out = ctx->copy_stream;
+   return hipSuccess;
+}
+hipError_t ctx_event(sbgpu_ctx_t *ctx, int which, hipEvent_t *out)
+{
+   if (which < 0 || which >= 6) return hipErrorInvalidValue;
+   if (!ctx->order_ev[which]) {
+      hipError_t e = hipEventCreateWithFlags(&ctx->order_ev[which], hipEventDisableTiming);
+      if (e != hipSuccess) return e;
+   }
+   *out = ctx->order_ev[which];
+   return hipSuccess;
+}
+namespace {
+struct DevBlock {
+   char *p;
+   size_t cap;
+   int device;
+};
+struct DevPool {
+   std::mutex m;
+   std::vector<DevBlock> blocks;
+   size_t bytes = 0;
+};
+DevPool &dev_pool()
+{
+   static DevPool *p = new DevPool(); // never destroyed: handles may be released during static destruction
+   return *p;
+}
+} // namespace
+hipError_t dev_take(size_t bytes, char **out, size_t *capacity)
+{
+   *out = nullptr;
+   *capacity = 0;
+   if (bytes < 256) bytes = 256;
+   int device = 0;
+   hipError_t e = hipGetDevice(&device);
+   if (e != hipSuccess) return e;
+   DevPool &pool = dev_pool();
+   {
+      std::lock_guard<std::mutex> g(pool.m);
+      size_t best = pool.blocks.size();
+      for (size_t i = 0; i < pool.blocks.size(); ++i) {
+         const DevBlock &b = pool.blocks[i];
+         if (b.device == device && b.cap >= bytes && b.cap <= 2 * bytes + (1u << 20) && (best == pool.blocks.size() || b.cap < pool.blocks[best].cap)) best = i;
+      }
+      if (best < pool.blocks.size()) {
+         *out = pool.blocks[best].p;
+         *capacity = pool.blocks[best].cap;
+         pool.bytes -= pool.blocks[best].cap;
+         pool.blocks.erase(pool.blocks.begin() + (long)best);
+         return hipSuccess;
+      }
+   }
+   const size_t want = bytes + bytes / 16; // head-room: the next request is often a little larger
+   e = hipMalloc(out, want);
+   if (e != hipSuccess) {
+      // out of memory with blocks idle in the pool: let them go and try once more
+      std::vector<DevBlock> idle;
+      {
+         std::lock_guard<std::mutex> g(pool.m);
+         idle.swap(pool.blocks);
+         pool.bytes = 0;
+      }
+      for (const DevBlock &b : idle) (void)hipFree(b.p);
+      (void)hipGetLastError();
+      e = hipMalloc(out, want);
+      if (e != hipSuccess) return e;
+   }
+   *capacity = want;
+   return hipSuccess;
+}
+void dev_give(char *block, size_t capacity)
+{
+   if (!block) return;
+   int device = 0;
+   if (hipGetDevice(&device) == hipSuccess) {
+      DevPool &pool = dev_pool();
+      std::lock_guard<std::mutex> g(pool.m);
+      if (pool.blocks.size() < 8 && pool.bytes + capacity <= ((size_t)4 << 30)) {
+         pool.blocks.push_back({block, capacity, device});
+         pool.bytes += capacity;
+         return;
+      }
+   }
+   (void)hipFree(block);
+}
+const ResidentAnnotation *ctx_resident_annotation(const sbgpu_ctx_t *ctx) { return ctx->resident; }
+void ctx_set_resident_annotation(sbgpu_ctx_t *ctx, ResidentAnnotation *r)
+{
+   if (ctx->resident) {
+      (void)hipStreamSynchronize(ctx->stream);
+      dev_give(ctx->resident->arena, ctx->resident->capacity);
+      delete ctx->resident;
+   }
+   ctx->resident = r;
+}
+size_t ctx_pairs_hint(const sbgpu_ctx_t *ctx) { return ctx->pairs_hint; }
+void ctx_set_pairs_hint(sbgpu_ctx_t *ctx, size_t bytes) { ctx->pairs_hint = bytes; }
 hipError_t ctx_scratch(sbgpu_ctx_t *ctx, int slot, size_t bytes, char **out)
 {
    *out = nullptr;
@@ -141,7 +271,8 @@ struct sbgpu_plan {
    sbgpu_ctx *ctx = nullptr;
    sb::HostPlan host;
    KindLaunch launches[sb::kNumKinds];
-   char *d_arena = nullptr;            // one allocation, one upload: the arrays below point into it
+   char *d_arena = nullptr;            // one allocation (sb::dev_take), one upload: the arrays below point into it
+   size_t arena_cap = 0;
    int64_t *d_row_off = nullptr, *d_iso_off = nullptr, *d_f_off = nullptr;
    int32_t *d_loci_all = nullptr;      // all class lists, concatenated (input of phase 0)
    int32_t *d_class_n = nullptr;       // loci per class (input count of phase 0)
@@ -428,6 +559,12 @@ int sbgpu_finalize(sbgpu_ctx_t *c)
    if (c->d_pdf_support) (void)hipFree(c->d_pdf_support);
    for (int i = 0; i < 8; ++i)
       if (c->scratch[i]) (void)hipFree(c->scratch[i]);
+   for (int i = 0; i < 4; ++i)
+      if (c->pinned[i]) (void)hipHostFree(c->pinned[i]);
+   for (hipEvent_t ev : c->order_ev)
+      if (ev) (void)hipEventDestroy(ev);
+   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+   sb::ctx_set_resident_annotation(c, nullptr);
    delete c;
    return SBGPU_OK;
 }
@@ -459,7 +596,14 @@ int sbgpu_plan_destroy(sbgpu_plan_t *p)
 {
    if (!p) return SBGPU_OK;
    if (p->ctx) (void)hipSetDevice(p->ctx->device);
-   (void)hipFree(p->d_arena); // every device array of the plan lives in this one allocation
+   // every device array of the plan lives in this one allocation; it goes back to the pool, which does not wait for
+   // the device as hipFree would: a run that is still in the context's streams is waited for here
+   if (p->d_arena && p->ctx) {
+      (void)hipStreamSynchronize(p->ctx->stream);
+      for (hipStream_t a : p->ctx->aux)
+         if (a) (void)hipStreamSynchronize(a);
+   }
+   sb::dev_give(p->d_arena, p->arena_cap);
    delete p;
    return SBGPU_OK;
 }
@@ -607,6 +751,7 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
       o_ltab[i] = at; at += up((p->host.lat[i].classes.size() + 1) * sizeof(sb::ClassDesc));
       o_lroute[i] = at; at += up((size_t)(n_loci + 1) * sizeof(int32_t));
    }
+   const size_t o_tick = at; at += up(sizeof(unsigned)); // (zero: it goes up with the staged head)
    const size_t staged = at;
    // zeroed before every run: every later phase's survivor counts and batch total
    const size_t o_cur = at;
@@ -620,9 +765,8 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
    }
    const size_t o_keep = at; at += up((size_t)p->host.n_rows + 1);
    const size_t o_sum = at; at += up((size_t)(n_loci + 1) * sizeof(double));
-   const size_t o_tick = at; at += up(sizeof(unsigned));
    const size_t o_wbuf = at; at += up((wide_buf_doubles + 1) * sizeof(double));
-   if ((e = hipMalloc(&p->d_arena, at)) != hipSuccess) return bail(e, "hipMalloc(plan arena)");
+   if ((e = sb::dev_take(at, &p->d_arena, &p->arena_cap)) != hipSuccess) return bail(e, "hipMalloc(plan arena)");
    stage("hipMalloc");
    p->d_row_off = (int64_t *)(p->d_arena + o_row);
    p->d_iso_off = (int64_t *)(p->d_arena + o_iso);
@@ -705,7 +849,6 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
    }
    stage("staging");
    if ((e = hipMemcpy(p->d_arena, stage_buf.data(), staged, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(plan)");
-   if ((e = hipMemset(p->d_epi_ticket, 0, sizeof(unsigned))) != hipSuccess) return bail(e, "hipMemset(plan)");
    // the wide kernel's exchange granules carry a per-run tag: start from a state no tag matches
    if (wide_buf_doubles && (e = hipMemset(p->d_wide_bufs, 0, wide_buf_doubles * sizeof(double))) != hipSuccess) return bail(e, "hipMemset(plan)");
    stage("upload");

@@ -481,3 +481,31 @@ def test_quantify_device_equals_quantify_host_on_the_chain_sample(oracle):
     assert q2.n_loci == 200
     np.testing.assert_array_equal(q2.annot.exon_left[:int(q2.annot.exon_off[int(q2.annot.iso_off[1])])],
                                   q.annot.exon_left[int(q.annot.exon_off[int(q.annot.iso_off[1])]):int(q.annot.exon_off[int(q.annot.iso_off[2])])])
+
+
+@pytest.mark.gpu
+def test_pinned_annotation_gives_the_unpinned_results():
+    """sbgpu_annotation_pin keeps the annotation's device copies and tables with the context; calls that are given the same
+    arrays use them.  Same theta / status / iterations, bit for bit, as the call that uploads everything itself; an
+    annotation that is NOT the pinned one takes the ordinary path; unpin restores it for the pinned one too."""
+    from strawberry_amd import chain, em
+    ctx = em.default_context(0)
+    a = chain.ChainQuantifier(ctx, n_loci=300, n_frags=300 * 200, seed=9, pin=False)
+    a.step()
+    want = (a.theta[:a.n_iso].copy(), a.status[:a.n_loci].copy(), a.iters[:a.n_loci].copy())
+    b = chain.ChainQuantifier(ctx, n_loci=300, n_frags=300 * 200, seed=9, pin=True)
+    for _ in range(2):
+        b.theta[:] = -1
+        b.step()
+        for got, w in zip((b.theta[:b.n_iso], b.status[:b.n_loci], b.iters[:b.n_loci]), want):
+            np.testing.assert_array_equal(got, w)
+    # another annotation while b's is pinned: not the resident one, so it is uploaded as ever
+    c = chain.ChainQuantifier(ctx, n_loci=200, n_frags=200 * 150, seed=10, pin=False)
+    c.step()
+    c_first = c.theta.copy()
+    b.finish()      # unpin
+    c.step()
+    np.testing.assert_array_equal(c.theta, c_first)
+    b.theta[:] = -1
+    b.step()
+    np.testing.assert_array_equal(b.theta[:b.n_iso], want[0])
