@@ -563,6 +563,19 @@ __global__ __launch_bounds__(256) void bins_pack_kernel(BinsPackArgs a)
    }
 }
 
+// the count and compat entries of the listed loci, zeroed (before bins_locus_kernel's global atomics run on loci whose
+// entries a single-pass kernel owned before)
+__global__ __launch_bounds__(256) void bins_zero_loci_kernel(BinsArgs a)
+{
+   for (int64_t i = blockIdx.x; i < a.n_loci; i += gridDim.x) {
+      const int64_t l = a.loci[i], q0 = a.locus_hit_off[l], q1 = a.locus_hit_off[l + 1];
+      for (int64_t h = q0 + threadIdx.x; h < q1; h += blockDim.x) {
+         a.bin_count[h] = 0;
+         for (int w = 0; w < a.compat_words; ++w) a.bin_compat[h * a.compat_words + w] = 0;
+      }
+   }
+}
+
 // ------------------------------------------------------------------ (bin, isoform) pairs
 // ExonBin::bin_under_iso (/root/reference/include/isoform.h:363-411) for every pair LocusContext::
 // set_theory_bin_weight visits (src/estimate.cpp:203-213): the isoform's segments from the bin's first to

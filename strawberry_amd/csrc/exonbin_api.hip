@@ -401,15 +401,18 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
    // in the main stream between two kernels costs the hand-over to the DMA engine and back, 0.3 ms each way measured.
    // First what the grouping kernels read (hit offsets, the loci's order), then the annotation's part of the pairs' inputs.
    // (Streams share hardware queues -- the copy stream may sit in the main stream's queue and then runs in issue order
-   // with it -- so nothing here counts on the overlap; the zero fill of the bins' counts and compat words is a kernel of
-   // this library because the runtime's takes 0.2 ms for the 12 MB of 1.5 M hits.)
+   // with it -- so nothing here counts on the overlap.)
    SB_TRY(hipMemcpyAsync(d + o_hoff, locus_hit_off, (size_t)(nl + 1) * 8, hipMemcpyHostToDevice, cs));
-   {
+   // The bins' counts and compat words are [n_hits]-sized (a locus' bins sit at its hit offset): 1.3 GB for 1.6e8 hits,
+   // 0.18 ms to zero at the memory's rate.  Only bins_locus_kernel's global atomics need the zeros -- the two-pass form
+   // and the big table; the single-pass kernels write every entry they own -- so they are made where those run.
+   auto zero_bins = [&](hipStream_t zs) -> hipError_t {
       const int64_t n16 = (int64_t)(zero_bytes / 16); // (the arena's parts are 256-byte multiples)
-      hipLaunchKernelGGL(sb::bins_zero_kernel, dim3((unsigned)std::min<int64_t>((n16 + 255) / 256, cap * 4)), dim3(256), 0, cs, (uint4 *)(d + o_zero), n16);
-      hipLaunchKernelGGL(sb::bins_zero_kernel, dim3(1), dim3(256), 0, cs, (uint4 *)(d + o_flag), (int64_t)16);
-      SB_TRY(hipGetLastError());
-   }
+      hipLaunchKernelGGL(sb::bins_zero_kernel, dim3((unsigned)std::min<int64_t>((n16 + 255) / 256, cap * 4)), dim3(256), 0, zs, (uint4 *)(d + o_zero), n16);
+      return hipGetLastError();
+   };
+   hipLaunchKernelGGL(sb::bins_zero_kernel, dim3(1), dim3(256), 0, cs, (uint4 *)(d + o_flag), (int64_t)16);
+   SB_TRY(hipGetLastError());
    const int64_t *d_iso_off = d_an ? d_an->iso_off : (const int64_t *)(d3 + r_isoff);
    // small and big loci in two launches (two LDS table sizes)
    std::vector<int32_t> order((size_t)nl);
@@ -428,12 +431,13 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
       auto mid = std::stable_partition(first_big, last_big, [&](int32_t l) { return hits_of(l) >= heavy; });
       std::sort(first_big, mid, [&](int32_t x, int32_t y) { return hits_of(x) != hits_of(y) ? hits_of(x) > hits_of(y) : x < y; });
    }
-   SB_TRY(hipMemcpyAsync(d + o_order, order.data(), (size_t)nl * 4, hipMemcpyHostToDevice, cs));
-   SB_TRY(hipEventRecord(ev_in, cs));
-   SB_TRY(hipStreamWaitEvent(s, ev_in, 0));
    // the single-pass kernels (bins_device.h) where a bin's compat union fits two words; SBGPU_BINS_TWO_PASS=1: the older form (A/B)
    static const bool two_pass_env = std::getenv("SBGPU_BINS_TWO_PASS") && std::atoi(std::getenv("SBGPU_BINS_TWO_PASS")) != 0;
    const bool single_pass = compat_words <= 2 && key_words <= 2 && !two_pass_env;
+   if (!single_pass) SB_TRY(zero_bins(cs));
+   SB_TRY(hipMemcpyAsync(d + o_order, order.data(), (size_t)nl * 4, hipMemcpyHostToDevice, cs));
+   SB_TRY(hipEventRecord(ev_in, cs));
+   SB_TRY(hipStreamWaitEvent(s, ev_in, 0));
    sb::ctx_stage_begin(c, single_pass ? "bins_accum_kernel" : "bins_locus_kernel", s);
    if (n_small) {
       a.n_loci = n_small;
@@ -575,6 +579,10 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
          SB_TRY(hipMemcpyAsync(d + o_order, redo.data(), redo.size() * 4, hipMemcpyHostToDevice, s));
          a.n_loci = (int64_t)redo.size();
          a.loci = (const int32_t *)(d + o_order);
+         if (single_pass) { // these loci's entries were never zeroed (the other loci's stand as they are)
+            hipLaunchKernelGGL(sb::bins_zero_loci_kernel, dim3((unsigned)std::min<int64_t>((int64_t)redo.size(), cap)), dim3(256), 0, s, a);
+            SB_TRY(hipGetLastError());
+         }
          hipLaunchKernelGGL((sb::bins_locus_kernel<sb::kBinsSlotsBig, sb::kBinsMaxBig, sb::kBinsThreadsBig>),
                             dim3((unsigned)std::min<int64_t>((int64_t)redo.size(), cap)), dim3(sb::kBinsThreadsBig), 0, s, a);
          SB_TRY(hipGetLastError());

@@ -255,6 +255,40 @@ def test_device_grouping_multiword_keys_and_table_limit(ctx):
     assert bd is None and bh.n_bins > 8192
 
 
+def test_device_grouping_single_pass_with_a_locus_for_the_big_table(ctx):
+    """One-word compat, two-word keys: the single-pass kernels group the loci; a locus with more bins than their table
+    holds (here ~3000 > 1400) is redone by the big-table kernel, whose entries are zeroed for it alone, while its
+    neighbours' bins stand.  The middle kernels, launched before the bin counts were back, run again over the result."""
+    from strawberry_amd import exonbin as eb
+    rng = np.random.default_rng(78)
+    loci = [[[(1000 * (l + 1) * 200 + 100 * k, 1000 * (l + 1) * 200 + 100 * k + 49) for k in range(40)]] * 20 for l in range(3)]
+    annot = eb.Annotation(loci)
+    assert annot.compat_words == 1 and annot.key_words == 2
+    loc, feats, masses, compat, key = [], [], [], [], []
+    for l, (n_keys, n_hits) in enumerate([(300, 2500), (3000, 9000), (200, 1500)]):
+        base = 1000 * (l + 1) * 200
+        keys = rng.integers(1, 2 ** 32, (n_keys, 2), dtype=np.uint64).astype(np.uint32)
+        keys[:, 1] &= 255                   # 40 segments
+        comps = rng.integers(1, 2 ** 20, (n_keys, 1), dtype=np.uint64).astype(np.uint32)   # 20 isoforms
+        pick = np.sort(rng.integers(0, n_keys, n_hits))
+        # distinct fragments: the single-pass kernels rest on "equal fragments have equal words" (true of words made from
+        # the fragments; not of the arbitrary words of this test)
+        lefts = np.sort(rng.choice(np.arange(base, base + 12000), n_hits, replace=False))
+        for q in range(n_hits):
+            loc.append(l)
+            feats.append(([0], [int(lefts[q])], [int(lefts[q]) + 74]))
+            masses.append(float(rng.integers(1, 4)))
+            key.append(keys[pick[q]])
+            compat.append(comps[pick[q]])
+    hits, compat, key = eb.Hits(loc, feats, mass=masses), np.array(compat, np.uint32), np.array(key, np.uint32)
+    bd, bh = group_both_ways(ctx, annot, hits, compat, key)
+    assert bd is not None
+    nb = np.diff(bh.row_off)
+    assert nb[1] > 1400 and nb[0] < 1400 and nb[2] < 1400
+    for x, y in zip(bins_arrays_no_pairs(bd), bins_arrays_no_pairs(bh)):
+        np.testing.assert_array_equal(x, y)
+
+
 def bins_arrays_no_pairs(b):
     return [b.row_off, b.f_off, b.count, b.bin_key, b.bin_compat, np.asarray(b.hit_bin)]
 
