@@ -290,6 +290,10 @@ struct sbgpu_plan {
    sb::ClassDesc *d_tables = nullptr;  // one descriptor per class
    std::vector<int64_t> loci_off;      // per class: offset into d_loci_all
    uint8_t *d_row_keep = nullptr;      // streaming path: init() row flags
+   // SBGPU_GRAPH=1: the launches of sbgpu_em_run_device captured once per (plan, argument pointers, stream) and replayed
+   // (an experiment: DESIGN.md section 8)
+   mutable hipGraphExec_t graph_exec = nullptr;
+   mutable const void *graph_key[6] = {};
    double *d_locus_sum = nullptr;      // abundance epilogue: kept-FPKM sum per workgroup of 256 loci
    unsigned *d_epi_ticket = nullptr;   // abundance epilogue: finished workgroups (the last one sums; it leaves 0 behind)
    size_t stream_lds_bytes = 0;
@@ -603,6 +607,7 @@ int sbgpu_plan_destroy(sbgpu_plan_t *p)
       for (hipStream_t a : p->ctx->aux)
          if (a) (void)hipStreamSynchronize(a);
    }
+   if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
    sb::dev_give(p->d_arena, p->arena_cap);
    delete p;
    return SBGPU_OK;
@@ -1087,7 +1092,31 @@ extern "C" {
 int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_count, const double *d_F,
                         double *d_theta, int32_t *d_status, int32_t *d_iters, void *stream)
 {
-   return em_run_impl(c, p, d_count, d_F, d_theta, d_status, d_iters, stream, false);
+   static const bool use_graph = std::getenv("SBGPU_GRAPH") && std::atoi(std::getenv("SBGPU_GRAPH")) != 0;
+   if (!use_graph || !c || !p || c->timing || p->n_wide_desc) // (cooperative launches and timing events stay outside)
+      return em_run_impl(c, p, d_count, d_F, d_theta, d_status, d_iters, stream, false);
+   const void *key[6] = {d_count, d_F, d_theta, d_status, d_iters, stream};
+   if (!p->graph_exec || std::memcmp(key, p->graph_key, sizeof key) != 0) {
+      if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
+      p->graph_exec = nullptr;
+      hipGraph_t g = nullptr;
+      // captured on the context's own stream (the caller's may be the legacy default stream, which cannot capture);
+      // the graph is launched into the caller's
+      HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+      const int rc = em_run_impl(c, p, d_count, d_F, d_theta, d_status, d_iters, c->stream, false);
+      const hipError_t e = hipStreamEndCapture(c->stream, &g);
+      if (rc != SBGPU_OK) {
+         if (g) (void)hipGraphDestroy(g);
+         return rc;
+      }
+      HIP_TRY(e);
+      const hipError_t ei = hipGraphInstantiate(&p->graph_exec, g, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(g);
+      HIP_TRY(ei);
+      std::memcpy(p->graph_key, key, sizeof key);
+   }
+   HIP_TRY(hipGraphLaunch(p->graph_exec, (hipStream_t)stream));
+   return SBGPU_OK;
 }
 
 int sbgpu_em_run_device_f32(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_count, const float *d_F,
