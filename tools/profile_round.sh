@@ -52,6 +52,9 @@ for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAI
   tag=$(echo $pmc | cut -d' ' -f1)
   timeout 900 rocprofv3 --pmc $pmc --output-format csv -d $OUT/pmc_${tag}_chain -o ch -- python3 $REPO/bench.py --workload c3-chain --no-cpu-baseline --steps 2 --warmup 1 > $OUT/pmc_${tag}_chain.log 2>&1
 done
+# the chain step's timeline on the GPU: every kernel with the idle gap before it (tools/chain_gpu_gaps.py)
+timeout 900 rocprofv3 --kernel-trace -d $OUT/trace_chain -o ch -- python3 $REPO/bench.py --workload c3-chain --no-cpu-baseline --steps 6 --warmup 2 > $OUT/trace_chain.log 2>&1
+python3 $REPO/tools/chain_gpu_gaps.py $(find $OUT/trace_chain -name "ch_results.db" | head -1) > $SUM/${R}_c3chain_timeline.txt 2>&1
 # the wide-locus kernel on C3-T: stats and counters
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3t -o w -- python3 $REPO/bench.py --workload c3t --no-cpu-baseline --steps 3 --warmup 1 > $OUT/stats_c3t.log 2>&1
 for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU"; do
