@@ -423,13 +423,20 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
    for (int64_t l = 0; l < nl; ++l)
       if (locus_hit_off[l + 1] - locus_hit_off[l] > sb::kBinsSmallHits) order[(size_t)(n_small + n_big++)] = (int32_t)l;
    // the very big ones first, largest to smallest: a locus is one workgroup's work, and a locus of 10^5 hits that starts
-   // last would be the kernel's tail (only those few are sorted: a full sort of 55 000 loci costs 2.6 ms of host time)
+   // last would be the kernel's tail (only those few are sorted: a full sort of 55 000 loci costs 2.6 ms of host time).
+   // They also get a launch of their own with 1024 threads; the loci between -- a few thousand hits, two or three per
+   // thread of such a workgroup -- are bound by the per-locus fixed cost (table set-up, six workgroup barriers, the
+   // ranking), which 256-thread workgroups, several per CU, pay side by side: 2.62 -> 1.83 ms on the chain sample
+   // (SBGPU_BINS_MID_THREADS=1024|512|256, SBGPU_BINS_HEAVY_HITS=n for A/B; 8192 was the best of 2000 ... 100 000).
+   int64_t n_heavy = 0;
+   static const int64_t heavy_env = std::getenv("SBGPU_BINS_HEAVY_HITS") ? std::atoll(std::getenv("SBGPU_BINS_HEAVY_HITS")) : 0;
    {
-      const int64_t heavy = std::max<int64_t>(4096, 4 * (nh / std::max<int64_t>(nl, 1)));
+      const int64_t heavy = heavy_env > 0 ? heavy_env : std::max<int64_t>(8192, 3 * (nh / std::max<int64_t>(nl, 1)));
       auto hits_of = [&](int32_t l) { return locus_hit_off[l + 1] - locus_hit_off[l]; };
       auto first_big = order.begin() + n_small, last_big = first_big + n_big;
       auto mid = std::stable_partition(first_big, last_big, [&](int32_t l) { return hits_of(l) >= heavy; });
       std::sort(first_big, mid, [&](int32_t x, int32_t y) { return hits_of(x) != hits_of(y) ? hits_of(x) > hits_of(y) : x < y; });
+      n_heavy = mid - first_big;
    }
    // the single-pass kernels (bins_device.h) where a bin's compat union fits two words; SBGPU_BINS_TWO_PASS=1: the older form (A/B)
    static const bool two_pass_env = std::getenv("SBGPU_BINS_TWO_PASS") && std::atoi(std::getenv("SBGPU_BINS_TWO_PASS")) != 0;
@@ -453,6 +460,23 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
       a.n_loci = n_big;
       a.loci = (const int32_t *)(d + o_order) + n_small;
       const dim3 grid((unsigned)std::min<int64_t>(n_big, cap * 4));
+      static const int mid_threads = std::getenv("SBGPU_BINS_MID_THREADS") ? std::atoi(std::getenv("SBGPU_BINS_MID_THREADS")) : 256;
+      if (single_pass && mid_threads != 1024 && n_heavy < n_big) {
+         // the heavy loci on 1024 threads, the others on fewer (more workgroups per CU, cheaper barriers)
+         if (n_heavy) {
+            a.n_loci = n_heavy;
+            const dim3 gh((unsigned)std::min<int64_t>(n_heavy, cap * 4));
+            if (compat_words == 1) hipLaunchKernelGGL((sb::bins_accum_kernel<sb::kBinsSlotsMid, sb::kBinsMaxMid, sb::kBinsThreadsAccum, 1, true>), gh, dim3(sb::kBinsThreadsAccum), 0, s, a);
+            else hipLaunchKernelGGL((sb::bins_accum_kernel<sb::kBinsSlotsMid, sb::kBinsMaxMid, sb::kBinsThreadsAccum, 2, true>), gh, dim3(sb::kBinsThreadsAccum), 0, s, a);
+         }
+         a.n_loci = n_big - n_heavy;
+         a.loci = (const int32_t *)(d + o_order) + n_small + n_heavy;
+         const dim3 gm((unsigned)std::min<int64_t>(a.n_loci, cap * 8));
+         if (mid_threads == 256 && compat_words == 1) hipLaunchKernelGGL((sb::bins_accum_kernel<sb::kBinsSlotsMid, sb::kBinsMaxMid, 256, 1, true>), gm, dim3(256), 0, s, a);
+         else if (mid_threads == 256) hipLaunchKernelGGL((sb::bins_accum_kernel<sb::kBinsSlotsMid, sb::kBinsMaxMid, 256, 2, true>), gm, dim3(256), 0, s, a);
+         else if (compat_words == 1) hipLaunchKernelGGL((sb::bins_accum_kernel<sb::kBinsSlotsMid, sb::kBinsMaxMid, 512, 1, true>), gm, dim3(512), 0, s, a);
+         else hipLaunchKernelGGL((sb::bins_accum_kernel<sb::kBinsSlotsMid, sb::kBinsMaxMid, 512, 2, true>), gm, dim3(512), 0, s, a);
+      } else
       if (single_pass && compat_words == 1) hipLaunchKernelGGL((sb::bins_accum_kernel<sb::kBinsSlotsMid, sb::kBinsMaxMid, sb::kBinsThreadsAccum, 1, true>), grid, dim3(sb::kBinsThreadsAccum), 0, s, a);
       else if (single_pass) hipLaunchKernelGGL((sb::bins_accum_kernel<sb::kBinsSlotsMid, sb::kBinsMaxMid, sb::kBinsThreadsAccum, 2, true>), grid, dim3(sb::kBinsThreadsAccum), 0, s, a);
       else hipLaunchKernelGGL((sb::bins_locus_kernel<sb::kBinsSlotsMid, sb::kBinsMaxMid, sb::kBinsThreadsMid, true>), grid, dim3(sb::kBinsThreadsMid), 0, s, a);
