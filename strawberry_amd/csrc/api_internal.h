@@ -101,8 +101,10 @@ int bins_create_device_impl(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *annot, c
                             const uint32_t *d_key, int64_t *d_hit_bin, void *stream, const IsoSegments *iso_pre, sbgpu_bins_t **out,
                             const uint64_t *d_span, const uint32_t *d_fhash, // spans / hashes of the hits (exonbin_device_impl), or null
                             const GroupingHooks *hooks = nullptr);
+// n_iso: the annotation's isoform count where the caller knows it on the host (-1: read from the device)
 int exonbin_device_impl(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *annot, const sbgpu_hits_t *hits, int32_t compat_words,
-                        int32_t key_words, uint32_t *d_compat, uint32_t *d_key, uint64_t *d_span, uint32_t *d_fhash, void *stream);
+                        int32_t key_words, uint32_t *d_compat, uint32_t *d_key, uint64_t *d_span, uint32_t *d_fhash, void *stream,
+                        int64_t n_iso = -1);
 int api_fail(int code, const std::string &msg); // records sbgpu_last_error(), returns code
 hipStream_t ctx_stream(const sbgpu_ctx_t *ctx); // the context's own stream
 int ctx_cu_count(const sbgpu_ctx_t *ctx);

@@ -186,7 +186,7 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
    sb::ctx_stage_reset(c);
    // ---- A5: the interval tests
    sb::ctx_stage_begin(c, "exonbin_kernel", s);
-   if (nh) SB_RC(sb::exonbin_device_impl(c, &dan, &dh, cw, kw, d_compat, d_key, d_span, d_fhash, s));
+   if (nh) SB_RC(sb::exonbin_device_impl(c, &dan, &dh, cw, kw, d_compat, d_key, d_span, d_fhash, s, n_iso));
    sb::ctx_stage_end(c, s);
    stage("exonbin kernel");
    std::vector<uint32_t> compat_h, key_h;

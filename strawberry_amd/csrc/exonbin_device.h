@@ -42,16 +42,24 @@ struct ExonBinArgs {
    // spans and hashes, and only those candidates are compared feature by feature
    uint64_t *span;
    uint32_t *fhash;
+   // optional (null: the exon walk everywhere): the isoforms in the SEGMENT basis (iso_masks_kernel below) -- bit s of
+   // iso_member[i]: segment s of the locus lies in isoform i; bit s of iso_start[i]: one of its exons starts there -- and
+   // per locus whether that form may be used (<= 64 segments, every exon a run of adjacent segments)
+   const uint64_t *iso_member, *iso_start;
+   const uint32_t *locus_seg_ok; // 0: no (the exon walk), 1: yes, up to 32 segments, 2: yes, up to 64
+   const uint64_t *locus_adj; // per locus: bit s = segment s begins right behind segment s - 1
 };
 
-__device__ __forceinline__ uint64_t hit_sig_step(uint64_t h, uint32_t l, uint32_t r)
+// (a 32-bit hash on purpose: two integer multiplies per feature -- 64-bit products cost four each, and integer
+// multiplies run at a quarter of the vector rate; collisions only cost a feature-by-feature compare)
+__device__ __forceinline__ uint32_t hit_sig_step(uint32_t h, uint32_t l, uint32_t r)
 {
-   h = (h ^ l) * 0x9E3779B97F4A7C15ull;
-   h = (h ^ r) * 0xC2B2AE3D27D4EB4Full;
-   return h ^ (h >> 31);
+   h = (h ^ l) * 0x9E3779B1u;
+   h = (h ^ r) * 0x85EBCA77u;
+   return h ^ (h >> 15);
 }
-constexpr uint64_t kHitSigSeed = 0x243F6A8885A308D3ull;
-__device__ __forceinline__ uint32_t hit_sig_fold(uint64_t h) { return (uint32_t)(h ^ (h >> 32)); }
+constexpr uint32_t kHitSigSeed = 0x243F6A88u;
+__device__ __forceinline__ uint32_t hit_sig_fold(uint32_t h) { return h ^ (h >> 13); }
 
 constexpr int kExonBinRegFeats = 8; // features a hit may have and still be held in registers
 
@@ -311,6 +319,150 @@ __device__ __forceinline__ void exonbin_locus_uniform(const ExonBinArgs &a, int 
    }
 }
 
+// ------------------------------------------------------------------ segment-basis form
+// The exon walk above costs ~1000 scalar instructions per wave (mask logic per isoform, exon and block) and the
+// kernel is bound by the CU's one scalar unit.  For loci of up to 64 segments the same answers come from bit masks.
+// The segments are the disjoint pieces of the union of the locus' exons (IRanges::disjoint), so every exon is a run of
+// adjacent segments, and for a hit whose blocks ascend (M (x M)*, every INTRON connector filling the gap between its
+// two blocks exactly):
+//   * a block lies inside ONE exon of isoform i  <=>  the segments it touches cover it completely (a statement about
+//     the hit alone: the overlap lengths add up to the block's length), all of them are members of i, and none but
+//     the first is an exon start of i.  Exons of an isoform are disjoint and sorted and the blocks ascend, so "the
+//     first exon reaching block 0 contains it" (contig.cpp:560-568) and "an exon from `it` on contains block j"
+//     (:582-591) both say just that.
+//   * an INTRON connector between blocks j-1 and j equals the intron after the exon holding block j-1 (:575-581)
+//     <=>  block j-1 ends where its last segment ends, block j starts where its first segment starts (the hit alone),
+//     that first segment is an exon start of i, and no segment strictly between the two is a member of i.
+// Per hit: masks need_member / forbid_start / need_start / forbid_member from ONE uniform walk over the segments in
+// the wave's span (the walk the bin key needs anyway); per isoform: four AND tests against two 64-bit words.
+// iso_masks_kernel checks the premise per locus (every exon exactly a run of adjacent segments) and leaves the exon
+// walk to the loci that fail it or have more than 64 segments.
+__global__ __launch_bounds__(256) void iso_masks_kernel(ExonBinArgs a, int64_t n_loci, uint64_t *member, uint64_t *start, uint32_t *seg_ok,
+                                                        uint64_t *locus_adj)
+{
+   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+   for (int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; l < n_loci; l += stride) {
+      const int64_t i0 = a.iso_off[l], i1 = a.iso_off[l + 1], s0 = a.seg_off[l];
+      const int nseg = (int)(a.seg_off[l + 1] - s0);
+      bool ok = nseg >= 1 && nseg <= 64;
+      for (int64_t i = i0; i < i1; ++i) {
+         uint64_t m = 0, st = 0;
+         int sidx = 0;
+         for (int64_t e = a.exon_off[i]; ok && e < a.exon_off[i + 1]; ++e) {
+            const uint32_t xl = a.exon_left[e], xr = a.exon_right[e];
+            while (sidx < nseg && a.seg_left[s0 + sidx] < xl) ++sidx;
+            if (sidx >= nseg || a.seg_left[s0 + sidx] != xl) {
+               ok = false;
+               break;
+            }
+            st |= 1ull << sidx;
+            uint32_t reach = xl - 1;
+            while (sidx < nseg && a.seg_left[s0 + sidx] == reach + 1 && a.seg_right[s0 + sidx] <= xr) {
+               m |= 1ull << sidx;
+               reach = a.seg_right[s0 + sidx];
+               ++sidx;
+            }
+            if (reach != xr) ok = false;
+         }
+         member[i] = m;
+         start[i] = st;
+      }
+      uint64_t adj = 0;
+      for (int sg = 1; sg < nseg && sg < 64; ++sg)
+         if (a.seg_left[s0 + sg] == a.seg_right[s0 + sg - 1] + 1u) adj |= 1ull << sg;
+      locus_adj[l] = adj;
+      seg_ok[l] = ok ? (nseg <= 32 ? 1u : 2u) : 0u;
+   }
+}
+
+template <class M> // uint32_t where the locus has up to 32 segments (half the mask arithmetic), else uint64_t
+__device__ __forceinline__ void exonbin_locus_segbasis(const ExonBinArgs &a, int loc, bool mine, const BlockHit &h, int64_t hidx)
+{
+   const SB_AS4 int64_t *iso_off = scalar_ptr(a.iso_off), *seg_off = scalar_ptr(a.seg_off);
+   const SB_AS4 uint32_t *SL = scalar_ptr(a.seg_left), *SR = scalar_ptr(a.seg_right);
+   const SB_AS4 uint64_t *MEM = scalar_ptr(a.iso_member), *STA = scalar_ptr(a.iso_start);
+   const int64_t i0 = iso_off[loc];
+   const int niso = (int)(iso_off[loc + 1] - i0);
+   const int64_t s0 = seg_off[loc];
+   const int nseg = (int)(seg_off[loc + 1] - s0);
+   const bool live = mine && h.nb > 0;
+   uint32_t rmax = 0;
+#pragma unroll
+   for (int j = 0; j < kExonBinBlocks; ++j) rmax = (j < h.nb) ? max(rmax, h.r[j]) : rmax;
+   const uint32_t lo = wave_min_u32(live ? h.l[0] : 0xffffffffu);
+   const uint32_t hi = wave_max_u32(live ? rmax : 0u);
+   const int nbmax = (int)wave_max_u32(live ? (uint32_t)h.nb : 0u);
+   // A block's touched segments are an index range [sa, sb] (segments are sorted and disjoint): sa = the number of
+   // segments that end before it, sb + 1 = the number that begin no later than it ends -- two compares and two carry
+   // adds per (segment, block) in the uniform walk, nothing else.
+   uint32_t n_before[kExonBinBlocks], n_upto[kExonBinBlocks];
+#pragma unroll
+   for (int j = 0; j < kExonBinBlocks; ++j) n_before[j] = 0u, n_upto[j] = 0u;
+   const int k_lo = nbmax > 0 ? first_reaching(SR + s0, nseg, lo) : nseg;
+   for (int sg = k_lo; sg < nseg; ++sg) {
+      const uint32_t sl = SL[s0 + sg];
+      if (sl > hi) break;
+      const uint32_t sr = SR[s0 + sg];
+#pragma unroll
+      for (int j = 0; j < kExonBinBlocks; ++j) {
+         if (j >= nbmax) break;
+         n_before[j] += (sr < h.l[j]) ? 1u : 0u;
+         n_upto[j] += (sl <= h.r[j]) ? 1u : 0u;
+      }
+   }
+   const M adj = (M)scalar_ptr(a.locus_adj)[loc]; // bit s: segment s begins right behind segment s - 1
+   bool valid = live;
+   M need_member = 0, forbid_start = 0, need_start = 0, forbid_member = 0;
+   constexpr uint32_t kTop = 8 * sizeof(M) - 1;
+   constexpr M kOne = 1, kTwo = 2, kAll = ~(M)0;
+   uint32_t sa_prev = 0, sb_prev = 0;
+   bool ends_prev = false;
+#pragma unroll
+   for (int j = 0; j < kExonBinBlocks; ++j) {
+      const bool in = live & (j < h.nb);
+      const uint32_t sa = (uint32_t)k_lo + n_before[j], sb1 = (uint32_t)k_lo + n_upto[j]; // [sa, sb1)
+      const bool any = in & (sb1 > sa);
+      const uint32_t sb = any ? sb1 - 1u : 0u, sa_c = any ? sa : 0u;
+      // the block's own ends against its first and last segment (two gathers per block, neighbours in memory)
+      const uint32_t first_l = a.seg_left[s0 + sa_c], last_r = a.seg_right[s0 + sb];
+      const M upto_sb = (sb >= kTop) ? kAll : (M)((kTwo << sb) - kOne);
+      const M mask = any ? (M)(upto_sb & ~(M)((kOne << sa_c) - kOne)) : (M)0; // bits sa .. sb
+      const M inner = mask & (M)(mask - kOne);                                // all but the first
+      // covered completely: it begins and ends inside its first / last segment and the segments between are adjacent
+      valid = valid & (!(live & (j < h.nb)) | (any & (h.l[j] >= first_l) & (h.r[j] <= last_r) & ((M)(inner & ~adj) == (M)0)));
+      need_member |= mask;
+      forbid_start |= inner;
+      if (j > 0) {
+         const bool intr = in & h.intron[j];
+         valid = valid & (!intr | (any & ends_prev & (h.l[j] == first_l)));
+         const M first_j = any ? (M)(kOne << sa_c) : (M)0, upto_prev = (sb_prev >= kTop) ? kAll : (M)((kTwo << sb_prev) - kOne);
+         need_start |= intr ? first_j : (M)0;
+         forbid_member |= intr ? (M)((M)(first_j - kOne) & ~upto_prev) : (M)0; // strictly between block j-1's last and block j's first
+      }
+      sa_prev = sa_c, sb_prev = sb;
+      ends_prev = any & (h.r[j] == last_r);
+   }
+   (void)sa_prev;
+   uint32_t *__restrict__ cout = a.compat + hidx * a.compat_words;
+   uint32_t *__restrict__ kout = a.key + hidx * a.key_words;
+   for (int w = 0; w < a.compat_words; ++w) {
+      uint32_t word = 0;
+      const int nbits = niso - 32 * w < 32 ? niso - 32 * w : 32;
+      for (int b = 0; b < nbits; ++b) {
+         const M m = (M)MEM[i0 + 32 * w + b], st = (M)STA[i0 + 32 * w + b];
+         const M bad = (need_member & ~m) | (forbid_start & st) | (need_start & ~st) | (forbid_member & m);
+         word |= (valid & (bad == (M)0) & (m != (M)0)) ? (1u << b) : 0u; // (m == 0: an isoform without exons is compatible with nothing)
+      }
+      if (mine) cout[w] = word;
+   }
+   const uint64_t keybits = live ? (uint64_t)need_member : 0ull;
+   if (mine) {
+      if (a.key_words > 0) kout[0] = (uint32_t)keybits;
+      if (a.key_words > 1) kout[1] = (uint32_t)(keybits >> 32);
+      for (int w = 2; w < a.key_words; ++w) kout[w] = 0u;
+   }
+}
+
 __global__ __launch_bounds__(256) void exonbin_kernel(ExonBinArgs a)
 {
    const int64_t hidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; // one hit per lane, no loop
@@ -335,7 +487,7 @@ __global__ __launch_bounds__(256) void exonbin_kernel(ExonBinArgs a)
       regular = regular & (!in | ((h.c[i] == 0) == ((i & 1) == 0)));
    }
    if (a.span && active) {
-      uint64_t sig = kHitSigSeed;
+      uint32_t sig = kHitSigSeed;
       uint64_t sp = 0;
       if (is_long) {
          for (int i = 0; i < nf; ++i) sig = hit_sig_step(sig, a.feat_left[f0 + i], a.feat_right[f0 + i]);
@@ -364,23 +516,41 @@ __global__ __launch_bounds__(256) void exonbin_kernel(ExonBinArgs a)
       bh.cr[j] = (in && j) ? h.r[2 * j - 1] : 0u;
       bh.intron[j] = in && j && h.c[2 * j - 1] == 1;
    }
+   // the segment-basis form also wants the blocks ascending and every INTRON connector to fill its gap exactly
+   bool seg_regular = regular;
+#pragma unroll
+   for (int j = 1; j < kExonBinBlocks; ++j) {
+      const bool in = j < bh.nb;
+      seg_regular = seg_regular & (!in | (bh.l[j] > bh.r[j - 1]));
+      seg_regular = seg_regular & (!(in & bh.intron[j]) | ((bh.cl[j] == bh.r[j - 1] + 1u) & (bh.cr[j] + 1u == bh.l[j])));
+   }
    // hits without features are "regular" with no blocks: all-zero words, written by the wave form
    bool todo = active && (regular || nf == 0);
+   bool per_lane = false; // a regular hit the segment-basis form does not take, in a locus that uses it
+   const SB_AS4 uint32_t *seg_ok = scalar_ptr(a.locus_seg_ok);
    for (int round = 0; round < kExonBinWaveLoci; ++round) {
       const uint64_t m = __ballot(todo);
       if (!m) break;
       const int loc = __builtin_amdgcn_readlane(my_loc, __ffsll((long long)m) - 1);
       const bool mine = todo && my_loc == loc;
-      exonbin_locus_uniform(a, loc, mine, bh, hidx);
+      const uint32_t form = a.locus_seg_ok ? seg_ok[loc] : 0u; // 0: exon walk; 1: <= 32 segments; 2: <= 64
+      if (form) {
+         per_lane = per_lane || (mine && !(seg_regular || nf == 0));
+         // (a uint32_t instantiation for loci of up to 32 segments was measured: 5.5 instead of 4.9 ms on the chain
+         // sample -- the second copy of the code costs more than the halved mask arithmetic saves)
+         exonbin_locus_segbasis<uint64_t>(a, loc, mine && (seg_regular || nf == 0), bh, hidx);
+      } else {
+         exonbin_locus_uniform(a, loc, mine, bh, hidx);
+      }
       todo = todo && !mine;
    }
    // per-lane walk: more features than the registers hold, an irregular feature list, or a wave
    // spread over many small loci
-   if (active && is_long) {
+   // (its features are read again from memory: keeping the register copy alive across the loop above costs 24
+   // registers and two waves per SIMD of occupancy, for the few lanes that come here)
+   if (active && (is_long || todo || per_lane || !(regular || nf == 0))) {
       MemHit m = {a.feat_code + f0, a.feat_left + f0, a.feat_right + f0, nf};
       exonbin_hit(a, hidx, m);
-   } else if (active && (todo || !(regular || nf == 0))) {
-      exonbin_hit(a, hidx, h);
    }
 }
 
@@ -391,7 +561,7 @@ __global__ __launch_bounds__(256) void hit_signature_kernel(int64_t n_hits, cons
    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
    for (int64_t h = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; h < n_hits; h += stride) {
       const int64_t f0 = feat_off[h], f1 = feat_off[h + 1];
-      uint64_t sig = kHitSigSeed;
+      uint32_t sig = kHitSigSeed;
       for (int64_t i = f0; i < f1; ++i) sig = hit_sig_step(sig, feat_left[i], feat_right[i]);
       span[h] = f1 > f0 ? (((uint64_t)feat_left[f0] << 32) | feat_right[f1 - 1]) : 0ull;
       fhash[h] = hit_sig_fold(sig);
