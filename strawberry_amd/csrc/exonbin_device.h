@@ -237,14 +237,22 @@ constexpr int kExonBinWaveLoci = 4; // loci a wave serves uniformly before its s
 
 struct BlockHit {
    uint32_t l[kExonBinBlocks], r[kExonBinBlocks];   // MATCH blocks; padding: l > r, inside nothing
-   uint32_t cl[kExonBinBlocks], cr[kExonBinBlocks]; // connector in front of block j >= 1
    bool intron[kExonBinBlocks];                     // ... is an INTRON (else a GAP)
    int nb;
 };
 
 __device__ __forceinline__ void exonbin_locus_uniform(const ExonBinArgs &a, int loc, bool mine, const BlockHit &h,
-                                                      int64_t hidx)
+                                                      int64_t hidx, int64_t f0)
 {
+   // the connector in front of block j >= 1, read again here (feature 2j - 1 of the hit): the segment-basis form, which
+   // serves nearly every locus, does not need them, and eight registers held for this path cost it a wave per SIMD
+   uint32_t cl[kExonBinBlocks], cr[kExonBinBlocks];
+#pragma unroll
+   for (int j = 0; j < kExonBinBlocks; ++j) {
+      const bool in = mine && j > 0 && j < h.nb;
+      cl[j] = in ? a.feat_left[f0 + 2 * j - 1] : 0u;
+      cr[j] = in ? a.feat_right[f0 + 2 * j - 1] : 0u;
+   }
    const SB_AS4 int64_t *iso_off = scalar_ptr(a.iso_off), *exon_off = scalar_ptr(a.exon_off), *seg_off = scalar_ptr(a.seg_off);
    const SB_AS4 uint32_t *XL = scalar_ptr(a.exon_left), *XR = scalar_ptr(a.exon_right);
    const SB_AS4 uint32_t *SL = scalar_ptr(a.seg_left), *SR = scalar_ptr(a.seg_right);
@@ -287,7 +295,7 @@ __device__ __forceinline__ void exonbin_locus_uniform(const ExonBinArgs &a, int 
 #pragma unroll
             for (int j = 1; j < kExonBinBlocks; ++j) {
                if (j >= nbmax) break;
-               const bool same_intron = has_next & (h.cl[j] == in_l) & (h.cr[j] == in_r); // :575-581
+               const bool same_intron = has_next & (cl[j] == in_l) & (cr[j] == in_r); // :575-581
                ok = ok & !(placed & h.intron[j] & !same_intron);
                placed = ok & (stage == j) & (xl <= h.l[j]) & (xr >= h.r[j]);              // :582-591
                stage += placed ? 1 : 0;
@@ -344,7 +352,7 @@ __global__ __launch_bounds__(256) void iso_masks_kernel(ExonBinArgs a, int64_t n
    for (int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; l < n_loci; l += stride) {
       const int64_t i0 = a.iso_off[l], i1 = a.iso_off[l + 1], s0 = a.seg_off[l];
       const int nseg = (int)(a.seg_off[l + 1] - s0);
-      bool ok = nseg >= 1 && nseg <= 64;
+      bool ok = nseg >= 1 && nseg <= 64 && i1 - i0 <= 64; // (a lane per segment and per isoform in exonbin_locus_segbasis)
       for (int64_t i = i0; i < i1; ++i) {
          uint64_t m = 0, st = 0;
          int sidx = 0;
@@ -375,16 +383,31 @@ __global__ __launch_bounds__(256) void iso_masks_kernel(ExonBinArgs a, int64_t n
    }
 }
 
-template <class M> // uint32_t where the locus has up to 32 segments (half the mask arithmetic), else uint64_t
+// The locus' segments (<= 64) are read ONCE per wave, lane s holding segment s: two coalesced loads in flight together.  Everything after that is register traffic --
+// v_readlane for the uniform walks, a ballot for "the first segment reaching the wave's span", ds_bpermute for a
+// block's first / last segment -- where the scalar-load form waited for some twenty dependent s_loads per wave (a
+// binary search, two loads per segment step, two per isoform) and the kernel sat 60 % of its cycles in s_waitcnt.
+__device__ __forceinline__ uint32_t lane_bcast(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+__device__ __forceinline__ uint64_t lane_bcast(uint64_t v, int lane)
+{
+   return ((uint64_t)lane_bcast((uint32_t)(v >> 32), lane) << 32) | lane_bcast((uint32_t)v, lane);
+}
+__device__ __forceinline__ uint32_t lane_gather(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lane << 2), (int)v); }
+
+template <class M>
 __device__ __forceinline__ void exonbin_locus_segbasis(const ExonBinArgs &a, int loc, bool mine, const BlockHit &h, int64_t hidx)
 {
    const SB_AS4 int64_t *iso_off = scalar_ptr(a.iso_off), *seg_off = scalar_ptr(a.seg_off);
-   const SB_AS4 uint32_t *SL = scalar_ptr(a.seg_left), *SR = scalar_ptr(a.seg_right);
-   const SB_AS4 uint64_t *MEM = scalar_ptr(a.iso_member), *STA = scalar_ptr(a.iso_start);
    const int64_t i0 = iso_off[loc];
    const int niso = (int)(iso_off[loc + 1] - i0);
    const int64_t s0 = seg_off[loc];
    const int nseg = (int)(seg_off[loc + 1] - s0);
+   const M adj = (M)scalar_ptr(a.locus_adj)[loc]; // bit s: segment s begins right behind segment s - 1
+   const int lane = (int)(threadIdx.x & 63u);
+   const uint32_t my_sl = lane < nseg ? a.seg_left[s0 + lane] : 0xffffffffu;
+   const uint32_t my_sr = lane < nseg ? a.seg_right[s0 + lane] : 0xffffffffu; // (past the end: reaches anything)
+   const SB_AS4 uint64_t *MEM = scalar_ptr(a.iso_member), *STA = scalar_ptr(a.iso_start); // (two s_loads per isoform: keeping the
+   // masks in lanes as well costs four more registers and, at 83, two waves per SIMD -- measured slower)
    const bool live = mine && h.nb > 0;
    uint32_t rmax = 0;
 #pragma unroll
@@ -395,41 +418,40 @@ __device__ __forceinline__ void exonbin_locus_segbasis(const ExonBinArgs &a, int
    // A block's touched segments are an index range [sa, sb] (segments are sorted and disjoint): sa = the number of
    // segments that end before it, sb + 1 = the number that begin no later than it ends -- two compares and two carry
    // adds per (segment, block) in the uniform walk, nothing else.
-   uint32_t n_before[kExonBinBlocks], n_upto[kExonBinBlocks];
+   uint32_t n_cnt[kExonBinBlocks]; // low half: segments ending before the block; high half: segments beginning no later than its end
 #pragma unroll
-   for (int j = 0; j < kExonBinBlocks; ++j) n_before[j] = 0u, n_upto[j] = 0u;
-   const int k_lo = nbmax > 0 ? first_reaching(SR + s0, nseg, lo) : nseg;
+   for (int j = 0; j < kExonBinBlocks; ++j) n_cnt[j] = 0u;
+   const uint64_t reaching = __ballot(my_sr >= lo); // (lanes from nseg on always do: k_lo <= nseg)
+   const int k_lo = nbmax > 0 ? (int)__ffsll((long long)reaching) - 1 : nseg;
    for (int sg = k_lo; sg < nseg; ++sg) {
-      const uint32_t sl = SL[s0 + sg];
+      const uint32_t sl = lane_bcast(my_sl, sg);
       if (sl > hi) break;
-      const uint32_t sr = SR[s0 + sg];
+      const uint32_t sr = lane_bcast(my_sr, sg);
 #pragma unroll
       for (int j = 0; j < kExonBinBlocks; ++j) {
          if (j >= nbmax) break;
-         n_before[j] += (sr < h.l[j]) ? 1u : 0u;
-         n_upto[j] += (sl <= h.r[j]) ? 1u : 0u;
+         n_cnt[j] += ((sr < h.l[j]) ? 1u : 0u) + ((sl <= h.r[j]) ? 0x10000u : 0u);
       }
    }
-   const M adj = (M)scalar_ptr(a.locus_adj)[loc]; // bit s: segment s begins right behind segment s - 1
    bool valid = live;
    M need_member = 0, forbid_start = 0, need_start = 0, forbid_member = 0;
    constexpr uint32_t kTop = 8 * sizeof(M) - 1;
    constexpr M kOne = 1, kTwo = 2, kAll = ~(M)0;
-   uint32_t sa_prev = 0, sb_prev = 0;
+   uint32_t sb_prev = 0;
    bool ends_prev = false;
 #pragma unroll
    for (int j = 0; j < kExonBinBlocks; ++j) {
       const bool in = live & (j < h.nb);
-      const uint32_t sa = (uint32_t)k_lo + n_before[j], sb1 = (uint32_t)k_lo + n_upto[j]; // [sa, sb1)
+      const uint32_t sa = (uint32_t)k_lo + (n_cnt[j] & 0xffffu), sb1 = (uint32_t)k_lo + (n_cnt[j] >> 16); // [sa, sb1)
       const bool any = in & (sb1 > sa);
       const uint32_t sb = any ? sb1 - 1u : 0u, sa_c = any ? sa : 0u;
-      // the block's own ends against its first and last segment (two gathers per block, neighbours in memory)
-      const uint32_t first_l = a.seg_left[s0 + sa_c], last_r = a.seg_right[s0 + sb];
+      // the block's own ends against its first and last segment
+      const uint32_t first_l = lane_gather(my_sl, sa_c), last_r = lane_gather(my_sr, sb);
       const M upto_sb = (sb >= kTop) ? kAll : (M)((kTwo << sb) - kOne);
       const M mask = any ? (M)(upto_sb & ~(M)((kOne << sa_c) - kOne)) : (M)0; // bits sa .. sb
       const M inner = mask & (M)(mask - kOne);                                // all but the first
       // covered completely: it begins and ends inside its first / last segment and the segments between are adjacent
-      valid = valid & (!(live & (j < h.nb)) | (any & (h.l[j] >= first_l) & (h.r[j] <= last_r) & ((M)(inner & ~adj) == (M)0)));
+      valid = valid & (!in | (any & (h.l[j] >= first_l) & (h.r[j] <= last_r) & ((M)(inner & ~adj) == (M)0)));
       need_member |= mask;
       forbid_start |= inner;
       if (j > 0) {
@@ -439,10 +461,9 @@ __device__ __forceinline__ void exonbin_locus_segbasis(const ExonBinArgs &a, int
          need_start |= intr ? first_j : (M)0;
          forbid_member |= intr ? (M)((M)(first_j - kOne) & ~upto_prev) : (M)0; // strictly between block j-1's last and block j's first
       }
-      sa_prev = sa_c, sb_prev = sb;
+      sb_prev = sb;
       ends_prev = any & (h.r[j] == last_r);
    }
-   (void)sa_prev;
    uint32_t *__restrict__ cout = a.compat + hidx * a.compat_words;
    uint32_t *__restrict__ kout = a.key + hidx * a.key_words;
    for (int w = 0; w < a.compat_words; ++w) {
@@ -512,8 +533,6 @@ __global__ __launch_bounds__(256) void exonbin_kernel(ExonBinArgs a)
       const bool in = j < bh.nb;
       bh.l[j] = in ? h.l[2 * j] : 0xffffffffu;
       bh.r[j] = in ? h.r[2 * j] : 0u;
-      bh.cl[j] = (in && j) ? h.l[2 * j - 1] : 0u;
-      bh.cr[j] = (in && j) ? h.r[2 * j - 1] : 0u;
       bh.intron[j] = in && j && h.c[2 * j - 1] == 1;
    }
    // the segment-basis form also wants the blocks ascending and every INTRON connector to fill its gap exactly
@@ -522,7 +541,7 @@ __global__ __launch_bounds__(256) void exonbin_kernel(ExonBinArgs a)
    for (int j = 1; j < kExonBinBlocks; ++j) {
       const bool in = j < bh.nb;
       seg_regular = seg_regular & (!in | (bh.l[j] > bh.r[j - 1]));
-      seg_regular = seg_regular & (!(in & bh.intron[j]) | ((bh.cl[j] == bh.r[j - 1] + 1u) & (bh.cr[j] + 1u == bh.l[j])));
+      seg_regular = seg_regular & (!(in & bh.intron[j]) | ((h.l[2 * j - 1] == bh.r[j - 1] + 1u) & (h.r[2 * j - 1] + 1u == bh.l[j])));
    }
    // hits without features are "regular" with no blocks: all-zero words, written by the wave form
    bool todo = active && (regular || nf == 0);
@@ -540,7 +559,7 @@ __global__ __launch_bounds__(256) void exonbin_kernel(ExonBinArgs a)
          // sample -- the second copy of the code costs more than the halved mask arithmetic saves)
          exonbin_locus_segbasis<uint64_t>(a, loc, mine && (seg_regular || nf == 0), bh, hidx);
       } else {
-         exonbin_locus_uniform(a, loc, mine, bh, hidx);
+         exonbin_locus_uniform(a, loc, mine, bh, hidx, f0);
       }
       todo = todo && !mine;
    }
