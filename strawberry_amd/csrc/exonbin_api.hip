@@ -498,7 +498,12 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
          a.n_loci = n_big - n_heavy;
          a.loci = (const int32_t *)(d + o_order) + n_small + n_heavy;
          const dim3 gm((unsigned)std::min<int64_t>(a.n_loci, cap * 8));
-         if (mid_threads == 256 && compat_words == 1) hipLaunchKernelGGL((sb::bins_accum_kernel<sb::kBinsSlotsMid, sb::kBinsMaxMid, 256, 1, true>), gm, dim3(256), 0, s, a);
+         // ... and on a table of 1024 slots / 512 bins (24 KB of LDS: six workgroups per CU instead of three; a locus of
+         // more bins is redone with the big table like any other overflow): 1.83 -> 1.41 ms (SBGPU_BINS_MID_SLOTS=2048 for A/B)
+         static const int mid_slots = std::getenv("SBGPU_BINS_MID_SLOTS") ? std::atoi(std::getenv("SBGPU_BINS_MID_SLOTS")) : 1024;
+         if (mid_threads == 256 && mid_slots == 1024 && compat_words == 1) hipLaunchKernelGGL((sb::bins_accum_kernel<1024, 512, 256, 1, true>), gm, dim3(256), 0, s, a);
+         else if (mid_threads == 256 && mid_slots == 1024) hipLaunchKernelGGL((sb::bins_accum_kernel<1024, 512, 256, 2, true>), gm, dim3(256), 0, s, a);
+         else if (mid_threads == 256 && compat_words == 1) hipLaunchKernelGGL((sb::bins_accum_kernel<sb::kBinsSlotsMid, sb::kBinsMaxMid, 256, 1, true>), gm, dim3(256), 0, s, a);
          else if (mid_threads == 256) hipLaunchKernelGGL((sb::bins_accum_kernel<sb::kBinsSlotsMid, sb::kBinsMaxMid, 256, 2, true>), gm, dim3(256), 0, s, a);
          else if (compat_words == 1) hipLaunchKernelGGL((sb::bins_accum_kernel<sb::kBinsSlotsMid, sb::kBinsMaxMid, 512, 1, true>), gm, dim3(512), 0, s, a);
          else hipLaunchKernelGGL((sb::bins_accum_kernel<sb::kBinsSlotsMid, sb::kBinsMaxMid, 512, 2, true>), gm, dim3(512), 0, s, a);
