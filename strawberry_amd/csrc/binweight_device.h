@@ -175,6 +175,12 @@ __global__ __launch_bounds__(256) void pdf_support_kernel(const double *pdf, int
 
 constexpr int kBinWeightMaxSeg = 32; // the reference's `1u << idx` masks stop at 32 segments too
 
+__device__ __forceinline__ int bw_bcast(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ int64_t bw_bcast(int64_t v, int lane)
+{
+   return (int64_t)(((uint64_t)(uint32_t)bw_bcast((int)(v >> 32), lane) << 32) | (uint32_t)bw_bcast((int)v, lane));
+}
+
 __global__ __launch_bounds__(64) void binweight_kernel(BinWeightArgs a)
 {
    __shared__ uint32_t s_seg[kBinWeightMaxSeg];
@@ -183,68 +189,83 @@ __global__ __launch_bounds__(64) void binweight_kernel(BinWeightArgs a)
    // IEEE mode on purpose: the fp64 division below needs denormal support to be exact.
    // The reference's FTZ arithmetic is mirrored where it is observable, in the pdf table
    // (subnormal densities are 0, sbgpu_insert_pdf_table).
-   // one wave per pair, pairs strided over the grid (the caller interleaves heavy and
-   // light pairs; a pair's cost is known only after reading its segments)
-   for (int64_t p = blockIdx.x; p < a.n_pairs; p += gridDim.x) {
-      const int64_t off = a.seg_off[p];
-      const int nseg = (int)(a.seg_off[p + 1] - off);
-      const int L = a.iso_len[p];
-      const int64_t dst = a.out_index ? a.out_index[p] : p;
-      double acc = 0.0;
-      if (a.long_read) { // estimate.cpp:236-247
-         acc = 1.0 / (double)L;
-      } else if (nseg <= 4) {
-         // closed forms (1-4 segments, nearly all pairs): the segment lengths are wave-uniform scalars, no LDS,
-         // no barrier
-         uint32_t s4[4] = {0u, 0u, 0u, 0u};
+   // One wave per pair, lanes over the fragment lengths -- but a wave takes a BATCH of 64 consecutive pairs: lane i
+   // reads pair i's description (offsets, isoform length, implicit mask, target, its first four segment lengths) with
+   // coalesced loads, two round trips for the 64 pairs, and the pairs are then served one after the other from those
+   // registers (v_readlane).  Read per pair through the scalar cache, the description was three dependent round trips
+   // in front of every pair's arithmetic and the kernel sat 60 % of its cycles waiting.  Results collect in the lanes and
+   // leave with one store.
+   const int64_t n_batches = (a.n_pairs + 63) / 64;
+   for (int64_t bt = blockIdx.x; bt < n_batches; bt += gridDim.x) {
+      const int64_t pm = bt * 64 + lane;
+      const bool in = pm < a.n_pairs;
+      const int64_t my_off = in ? a.seg_off[pm] : 0;
+      const int my_nseg = in ? (int)(a.seg_off[pm + 1] - my_off) : 0;
+      const int my_L = in ? a.iso_len[pm] : 1;
+      const int my_imask = in ? (int)a.implicit_mask[pm] : 0;
+      int my_s[4];
 #pragma unroll
-         for (int k = 0; k < 4; ++k)
-            if (k < nseg) s4[k] = a.seg_lens[off + k];
-         const uint32_t imask = a.implicit_mask[p];
-         const int nimp = __popc(imask);
-         const int lmax = (int)(s4[0] + s4[1] + s4[2] + s4[3]);
-         const int inner = nseg > 2 ? lmax - (int)s4[0] - (int)s4[nseg - 1] : 0;
-         int lmin = a.lmin_base;                // estimate.cpp:214-219
-         if (nseg > 2) lmin = max(lmin, inner); // :220-221
-         const int f0 = max(lmin, a.pdf_support[0]), f1 = min(lmax, a.pdf_support[1]);
-         for (int fl = f0 + lane; fl <= f1; fl += 64) { // :223-227, lanes over fl
-            const int e = effective_len(s4, (const int *)nullptr, (const int *)nullptr, nseg, imask, nimp, inner, fl, a.read_len);
-            acc += bw_div(a.pdf[fl] * (double)e, (double)(L - fl + 1));
-         }
-         acc = wave_group_sum<64>(acc);
-      } else {
-         __syncthreads(); // the previous pair's readers are done with s_seg
-         if (lane < nseg) s_seg[lane] = a.seg_lens[off + lane];
-         __syncthreads();
-         if (lane < nseg - 1) {
-            // prefix sums over the inner segments 1 .. nseg-2, from the left and from the right
-            int sl = 0, sr = 0;
-            for (int m = 1; m <= lane; ++m) {
-               sl += (int)s_seg[m];
-               sr += (int)s_seg[nseg - 1 - m];
+      for (int k = 0; k < 4; ++k) my_s[k] = (in && !a.long_read && my_nseg <= 4 && k < my_nseg) ? (int)a.seg_lens[my_off + k] : 0;
+      double my_acc = 0.0;
+      const int npb = (int)(a.n_pairs - bt * 64 < 64 ? a.n_pairs - bt * 64 : 64);
+      for (int q = 0; q < npb; ++q) {
+         const int nseg = bw_bcast(my_nseg, q), L = bw_bcast(my_L, q);
+         double acc = 0.0;
+         if (a.long_read) { // estimate.cpp:236-247
+            acc = 1.0 / (double)L;
+         } else if (nseg <= 4) {
+            // closed forms (1-4 segments, nearly all pairs): the segment lengths are wave-uniform scalars, no LDS,
+            // no barrier
+            const uint32_t s4[4] = {(uint32_t)bw_bcast(my_s[0], q), (uint32_t)bw_bcast(my_s[1], q), (uint32_t)bw_bcast(my_s[2], q),
+                                    (uint32_t)bw_bcast(my_s[3], q)};
+            const uint32_t imask = (uint32_t)bw_bcast(my_imask, q);
+            const int nimp = __popc(imask);
+            const int lmax = (int)(s4[0] + s4[1] + s4[2] + s4[3]);
+            const int inner = nseg > 2 ? lmax - (int)s4[0] - (int)s4[nseg > 0 ? nseg - 1 : 0] : 0;
+            int lmin = a.lmin_base;                // estimate.cpp:214-219
+            if (nseg > 2) lmin = max(lmin, inner); // :220-221
+            const int f0 = max(lmin, a.pdf_support[0]), f1 = min(lmax, a.pdf_support[1]);
+            for (int fl = f0 + lane; fl <= f1; fl += 64) { // :223-227, lanes over fl
+               const int e = effective_len(s4, (const int *)nullptr, (const int *)nullptr, nseg, imask, nimp, inner, fl, a.read_len);
+               acc += bw_div(a.pdf[fl] * (double)e, (double)(L - fl + 1));
             }
-            s_SL[lane] = sl;
-            s_SR[lane] = sr;
+            acc = wave_group_sum<64>(acc);
+         } else {
+            const int64_t off = bw_bcast(my_off, q);
+            __syncthreads(); // the previous pair's readers are done with s_seg
+            if (lane < nseg) s_seg[lane] = a.seg_lens[off + lane];
+            __syncthreads();
+            if (lane < nseg - 1) {
+               // prefix sums over the inner segments 1 .. nseg-2, from the left and from the right
+               int sl = 0, sr = 0;
+               for (int m = 1; m <= lane; ++m) {
+                  sl += (int)s_seg[m];
+                  sr += (int)s_seg[nseg - 1 - m];
+               }
+               s_SL[lane] = sl;
+               s_SR[lane] = sr;
+            }
+            __syncthreads();
+            const uint32_t imask = (uint32_t)bw_bcast(my_imask, q);
+            const int nimp = __popc(imask);
+            int lmax = 0, inner = 0;
+            for (int k = 0; k < nseg; ++k) {
+               lmax += (int)s_seg[k];
+               if (k >= 1 && k < nseg - 1) inner += (int)s_seg[k];
+            }
+            int lmin = a.lmin_base;                // estimate.cpp:214-219
+            if (nseg > 2) lmin = max(lmin, inner); // :220-221
+            const int f0 = max(lmin, a.pdf_support[0]), f1 = min(lmax, a.pdf_support[1]);
+            for (int fl = f0 + lane; fl <= f1; fl += 64) { // :223-227, lanes over fl
+               const int e = effective_len((const uint32_t *)s_seg, s_SL, s_SR, nseg, imask, nimp, inner, fl, a.read_len);
+               acc += bw_div(a.pdf[fl] * (double)e, (double)(L - fl + 1));
+            }
+            // wave sum (order differs from the reference's sequential loop by rounding only)
+            acc = wave_group_sum<64>(acc);
          }
-         __syncthreads();
-         const uint32_t imask = a.implicit_mask[p];
-         const int nimp = __popc(imask);
-         int lmax = 0, inner = 0;
-         for (int k = 0; k < nseg; ++k) {
-            lmax += (int)s_seg[k];
-            if (k >= 1 && k < nseg - 1) inner += (int)s_seg[k];
-         }
-         int lmin = a.lmin_base;                // estimate.cpp:214-219
-         if (nseg > 2) lmin = max(lmin, inner); // :220-221
-         const int f0 = max(lmin, a.pdf_support[0]), f1 = min(lmax, a.pdf_support[1]);
-         for (int fl = f0 + lane; fl <= f1; fl += 64) { // :223-227, lanes over fl
-            const int e = effective_len((const uint32_t *)s_seg, s_SL, s_SR, nseg, imask, nimp, inner, fl, a.read_len);
-            acc += bw_div(a.pdf[fl] * (double)e, (double)(L - fl + 1));
-         }
-         // wave sum (order differs from the reference's sequential loop by rounding only)
-         acc = wave_group_sum<64>(acc);
+         my_acc = lane == q ? acc : my_acc;
       }
-      if (lane == 0) a.out[dst] = acc;
+      if (in) a.out[a.out_index ? a.out_index[pm] : pm] = my_acc;
    }
 }
 

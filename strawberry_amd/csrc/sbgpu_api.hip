@@ -1394,7 +1394,8 @@ int sbgpu_binweight_device(sbgpu_ctx_t *c, int64_t n_pairs, const int64_t *d_seg
    a.lmin_base = lmin_base;
    a.long_read = long_read;
    // one wave per pair; enough waves to fill the chip several times over
-   const int64_t want = n_pairs < (int64_t)c->n_cu * 64 ? n_pairs : (int64_t)c->n_cu * 64;
+   const int64_t n_batches = (n_pairs + 63) / 64; // a wave serves batches of 64 pairs
+   const int64_t want = n_batches < (int64_t)c->n_cu * 64 ? n_batches : (int64_t)c->n_cu * 64;
    hipLaunchKernelGGL(sb::binweight_kernel, dim3((unsigned)want), dim3(64), 0, s, a);
    HIP_TRY(hipGetLastError());
    return SBGPU_OK;
