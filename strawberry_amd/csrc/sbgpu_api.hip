@@ -939,10 +939,15 @@ static int em_run_impl(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_c
    int kinds = 0;
    for (int k = 0; k < sb::kNumKinds; ++k) kinds += p->launches[k].n_classes > 0;
    const bool fork = kinds > 1;
+   // SBGPU_WAVE_ON_MAIN=1: the wave kinds (stream slot 0: the kinds that end last) run on the caller's stream itself, so
+   // that neither their start nor the epilogue behind them waits for an event to cross hardware queues; the other
+   // kinds fork off and join as before
+   static const bool wave_on_main = std::getenv("SBGPU_WAVE_ON_MAIN") && std::atoi(std::getenv("SBGPU_WAVE_ON_MAIN")) != 0;
+   auto stream_of = [&](int k) -> hipStream_t { return (!fork || (wave_on_main && kKindStream[k] == 0)) ? main : c->aux[kKindStream[k]]; };
    if (fork) {
       HIP_TRY(hipEventRecord(c->fork, main));
       for (int k = 0; k < sb::kNumKinds; ++k)
-         if (p->launches[k].n_classes > 0) HIP_TRY(hipStreamWaitEvent(c->aux[kKindStream[k]], c->fork, 0));
+         if (p->launches[k].n_classes > 0 && stream_of(k) != main) HIP_TRY(hipStreamWaitEvent(stream_of(k), c->fork, 0));
    }
    for (int k = 0; k < sb::kNumKinds; ++k) c->timed[k] = false;
    c->n_phase_timed = 0;
@@ -960,11 +965,11 @@ static int em_run_impl(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_c
       if (pass == 1) {
          for (int o = 0; o < sb::kNumKinds; ++o) {
             if (o == k || p->launches[o].n_classes == 0) continue;
-            HIP_TRY(hipEventRecord(c->join[o], c->aux[kKindStream[o]]));
-            HIP_TRY(hipStreamWaitEvent(c->aux[kKindStream[k]], c->join[o], 0));
+            HIP_TRY(hipEventRecord(c->join[o], stream_of(o)));
+            HIP_TRY(hipStreamWaitEvent(stream_of(k), c->join[o], 0));
          }
       }
-      hipStream_t s = fork ? c->aux[kKindStream[k]] : main;
+      hipStream_t s = stream_of(k);
       // Start order.  A tall-tile workgroup needs a whole CU's registers, a block-kind one half of them: once the
       // workgroups of a lighter kind have spread over the chip, a heavier one waits for a CU to drain -- the 9
       // tall workgroups of C3 then finish at 1.48 ms instead of 0.65 ms, behind everything else (they start within a
@@ -1080,7 +1085,8 @@ static int em_run_impl(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_c
    if (fork) {
       for (int k = 0; k < sb::kNumKinds; ++k) {
          if (p->launches[k].n_classes == 0) continue;
-         HIP_TRY(hipEventRecord(c->join[k], c->aux[kKindStream[k]]));
+         if (stream_of(k) == main) continue;
+         HIP_TRY(hipEventRecord(c->join[k], stream_of(k)));
          HIP_TRY(hipStreamWaitEvent(main, c->join[k], 0));
       }
    }
