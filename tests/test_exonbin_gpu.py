@@ -141,6 +141,83 @@ def test_irregular_feature_lists(ctx, oracle):
     np.testing.assert_array_equal(key, o_key)
 
 
+def test_segment_basis_form_on_coinciding_boundaries(ctx, oracle):
+    """exonbin_kernel decides compatibility in the SEGMENT basis (bit masks per isoform, exonbin_device.h) for loci of up
+    to 64 segments.  Its equivalence with Contig::is_compatible rests on how exons, segments and blocks meet at their
+    ends, so everything here lives on a coarse grid: exon ends on multiples of 10 -- abutting exons inside one isoform,
+    alternative 5' / 3' ends, retained introns, exons inside other isoforms' exons -- and read blocks on multiples of 5:
+    blocks that end exactly with an exon, stick out by half a cell, span abutting exons, sit in introns; INTRON
+    connectors that match an isoform's intron, match another isoform's, or nothing; connectors that do not touch their
+    blocks, and blocks out of order (the per-lane walk takes those).  Plus a locus of more than 64 segments (the exon
+    walk).  Words equal the oracle's, bit for bit."""
+    from strawberry_amd import exonbin as eb
+    rng = np.random.default_rng(2024)
+    loci = []
+    for l in range(60):
+        base = 1000 * (l + 1)
+        n_cells = int(rng.integers(6, 40)) if l else 90          # locus 0: many segments
+        isoforms = []
+        for _ in range(int(rng.integers(1, 9))):
+            exons, pos = [], int(rng.integers(0, 4))
+            while pos < n_cells - 1:
+                length = int(rng.integers(1, 5))
+                end = min(pos + length, n_cells)
+                exons.append((base + 10 * pos, base + 10 * end - 1))
+                pos = end + int(rng.choice([0, 0, 1, 2, 3]))     # 0: the next exon abuts this one
+            if l == 0:
+                exons = [(base + 10 * k, base + 10 * k + 6) for k in range(0, 90, 1 + int(rng.integers(0, 2)))]
+            if exons:
+                isoforms.append(exons)
+        if l % 7 == 3:
+            isoforms.append([])                                   # an isoform without exons
+        loci.append(isoforms)
+    annot = eb.Annotation(loci)
+    assert annot.key_words >= 3                                    # locus 0 is beyond the mask form
+    nseg = np.diff(annot.seg_off)
+    assert (nseg[1:] <= 64).all() and nseg[0] > 64
+    loc, feats = [], []
+    for l, isoforms in enumerate(loci):
+        base = 1000 * (l + 1)
+        span = max((e[-1][1] for e in isoforms if e), default=base + 50) - base
+        for _ in range(400):
+            nb = int(rng.integers(1, 5))
+            starts = np.sort(rng.integers(0, max(2, span // 5), nb * 2)) * 5 + base
+            c, le, ri = [], [], []
+            for j in range(nb):
+                a, b = int(starts[2 * j]), int(starts[2 * j + 1])
+                if j:
+                    kind = int(rng.choice([1, 1, 2]))
+                    cl, cr = ri[-1] + 1, a - 1
+                    u = rng.random()
+                    if u < 0.04:
+                        cl += 5                                  # a connector that does not touch its block
+                    c.append(kind), le.append(cl), ri.append(max(cr, cl))
+                c.append(0), le.append(a), ri.append(max(b - 1, a))
+            if rng.random() < 0.02 and nb >= 2:                  # blocks out of order
+                le[0], le[-1] = le[-1], le[0]
+                ri[0], ri[-1] = ri[-1], ri[0]
+            # half of the hits: snap the blocks to an isoform's exon ends, so that introns and exon ends are hit exactly
+            if isoforms and isoforms[0] and rng.random() < 0.5:
+                ex = isoforms[int(rng.integers(0, len(isoforms)))] or isoforms[0]
+                k = int(rng.integers(0, len(ex)))
+                c, le, ri = [0], [int(rng.integers(ex[k][0], ex[k][1] + 1))], [ex[k][1]]
+                for k2 in range(k + 1, min(k + nb, len(ex))):
+                    c += [int(rng.choice([1, 1, 1, 2])), 0]
+                    le += [ri[-1] + 1, ex[k2][0]]
+                    ri += [ex[k2][0] - 1, ex[k2][1] if k2 + 1 < min(k + nb, len(ex)) else int(rng.integers(ex[k2][0], ex[k2][1] + 1))]
+                    if ri[-2] < le[-2]:                         # abutting exons: no room for a connector
+                        del c[-2:], le[-2:], ri[-2:]
+                        break
+            loc.append(l), feats.append((c, le, ri))
+    hits = eb.Hits(loc, feats)
+    compat, key = eb.compat_and_keys(annot, hits, ctx)
+    o_compat, o_key = oracle.exonbin_batch(annot, hits)
+    np.testing.assert_array_equal(key, o_key)
+    np.testing.assert_array_equal(compat, o_compat)
+    frac = (compat != 0).any(axis=1).mean()
+    assert 0.1 < frac < 0.9, frac                                 # both answers are common
+
+
 def bins_arrays(b):
     return [b.row_off, b.f_off, b.count, b.bin_key, b.bin_compat, np.asarray(b.hit_bin), b.pair_seg_off, b.pair_seg_lens,
             b.pair_implicit_mask, b.pair_iso_len, b.pair_out_index]
