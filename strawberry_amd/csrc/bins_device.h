@@ -603,6 +603,7 @@ struct PairsArgs {
    int32_t *pair_iso_len;
    int64_t *pair_out_index;
    int32_t *flags;
+   int32_t only_wide_loci; // thread-per-isoform kernel: serve only loci of more than 64 isoforms (the wave-per-locus kernel has the others)
 };
 
 // Exclusive prefix sums between the grouping's kernels, so that they follow each other in the stream without a
@@ -739,11 +740,12 @@ template <bool FILL>
 __global__ __launch_bounds__(256) void bins_pairs_kernel(PairsArgs a)
 {
    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-   if (FILL && blockIdx.x == 0 && threadIdx.x == 0) a.pair_seg_off[a.pair_off[a.n_iso]] = a.pseg_off[a.n_iso]; // the CSR's last entry
+   if (FILL && !a.only_wide_loci && blockIdx.x == 0 && threadIdx.x == 0) a.pair_seg_off[a.pair_off[a.n_iso]] = a.pseg_off[a.n_iso]; // the CSR's last entry
    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_iso; i += stride) {
       const int l = a.iso_locus[i];
       const int64_t i0 = a.iso_off[l];
       const int j = (int)(i - i0), niso = (int)(a.iso_off[l + 1] - i0);
+      if (a.only_wide_loci && niso <= 64) continue;
       const int64_t b0 = a.row_off[l], b1 = a.row_off[l + 1], s0 = a.seg_off[l];
       const int32_t *is = a.iso_seg_idx + a.iso_seg_off[i];
       const int nis = (int)(a.iso_seg_off[i + 1] - a.iso_seg_off[i]);
@@ -820,6 +822,145 @@ __global__ __launch_bounds__(256) void bins_pairs_kernel(PairsArgs a)
       if (!FILL) {
          a.pair_cnt[i] = np;
          a.seg_cnt[i] = ns;
+      }
+      if (bad) atomicOr(a.flags, bad);
+   }
+}
+
+// The same pairs, one WAVE per locus (loci of up to 64 isoforms: a lane per isoform holds its running offsets): lanes
+// over the locus' bins, 64 at a time; a bin's key is analysed once (first / last segment, number of segments), not once
+// per isoform; per isoform the lanes whose bin is compatible do the two lower_bounds, and a ballot / prefix count gives
+// every pair its place, so the pairs of one isoform leave as consecutive words.  The thread-per-isoform kernel above
+// reads every bin's words once per isoform with one lane per address and writes its pairs as partial lines (1 GB of
+// traffic for 73 MB of pairs); it stays for loci of more isoforms.
+__device__ __forceinline__ int wave_excl_scan(int v, int lane)
+{
+   int x = v;
+#pragma unroll
+   for (int d = 1; d < 64; d <<= 1) {
+      const int y = __builtin_amdgcn_ds_bpermute(((lane - d) & 63) << 2, x);
+      x += lane >= d ? y : 0;
+   }
+   return x - v;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void bins_pairs_locus_kernel(PairsArgs a, int64_t n_loci)
+{
+   const int lane = threadIdx.x & 63;
+   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+   const int cw = a.compat_words, kw = a.key_words;
+   if (FILL && blockIdx.x == 0 && threadIdx.x == 0) a.pair_seg_off[a.pair_off[a.n_iso]] = a.pseg_off[a.n_iso]; // the CSR's last entry
+   for (int64_t l = wave; l < n_loci; l += n_waves) {
+      const int64_t i0 = a.iso_off[l];
+      const int niso = (int)(a.iso_off[l + 1] - i0);
+      if (niso > 64) continue; // (the launcher sends such loci to the other kernel)
+      const int64_t b0 = a.row_off[l], b1 = a.row_off[l + 1], s0 = a.seg_off[l], f0 = a.f_off[l];
+      // lane j: isoform i0 + j
+      const bool has_iso = lane < niso;
+      const int64_t my_seg0 = has_iso ? a.iso_seg_off[i0 + lane] : 0;
+      const int my_nis = has_iso ? (int)(a.iso_seg_off[i0 + lane + 1] - my_seg0) : 0;
+      const int my_len = has_iso ? a.iso_len[i0 + lane] : 0;
+      int64_t my_p = (FILL && has_iso) ? a.pair_off[i0 + lane] : 0, my_so = (FILL && has_iso) ? a.pseg_off[i0 + lane] : 0;
+      int my_np = 0, my_ns = 0, bad = 0;
+      for (int64_t c0 = b0; c0 < b1; c0 += 64) {
+         const int64_t b = c0 + lane;
+         const bool has_bin = b < b1;
+         // the bin's key, once: first / last segment and how many
+         int bf = -1, bl = -1, nbits = 0;
+         uint32_t k0 = 0, k1 = 0; // the first two key words (all there are for loci of up to 64 segments)
+         for (int w = 0; w < kw; ++w) {
+            const uint32_t k = has_bin ? a.bin_key[b * kw + w] : 0u;
+            if (w == 0) k0 = k;
+            if (w == 1) k1 = k;
+            if (!k) continue;
+            if (bf < 0) bf = 32 * w + __ffs(k) - 1;
+            bl = 32 * w + 31 - __clz(k);
+            nbits += __popc(k);
+         }
+         uint32_t c0w = (has_bin && cw > 0) ? a.bin_compat[b * cw] : 0u, c1w = (has_bin && cw > 1) ? a.bin_compat[b * cw + 1] : 0u;
+         for (int j = 0; j < niso; ++j) {
+            const bool set = has_bin && (((j < 32 ? c0w : c1w) >> (j & 31)) & 1u);
+            const uint64_t m = __ballot(set);
+            if (!m) continue;
+            const int64_t seg0 = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(my_seg0 >> 32), j) << 32) |
+                                           (uint32_t)__builtin_amdgcn_readlane((int)my_seg0, j));
+            const int nis = __builtin_amdgcn_readlane(my_nis, j);
+            const int32_t *is = a.iso_seg_idx + seg0;
+            int n_eff = 0, ok = 0;
+            uint32_t mask = 0;
+            int low = 0;
+            if (set) {
+               // isoform.h:381-391: lower_bound of the bin's first and last segment among the isoform's
+               int lo = 0, hi = nis;
+               while (lo < hi) {
+                  const int mid = (lo + hi) >> 1;
+                  if (is[mid] < bf) lo = mid + 1;
+                  else hi = mid;
+               }
+               low = lo;
+               hi = nis;
+               while (lo < hi) {
+                  const int mid = (lo + hi) >> 1;
+                  if (is[mid] < bl) lo = mid + 1;
+                  else hi = mid;
+               }
+               const int up = lo;
+               if (low >= nis || up >= nis || up < low) {
+                  bad |= kPairsNotUnder;
+               } else {
+                  ok = 1;
+                  const int n = up - low + 1;
+                  n_eff = n;
+                  if (n > 32) {
+                     n_eff = 0; // see locus_bins.cpp: such a pair carries no segments (long-read workflow only)
+                     bad |= kPairsWide;
+                  } else {
+                     // :393-409: an inner isoform segment the bin does not hold is implicit; every segment the bin
+                     // holds between its ends must be one of the isoform's
+                     int inside = 0;
+                     for (int q = 1; q + 1 < n; ++q) {
+                        const int sidx = is[low + q];
+                        const uint32_t kwd = sidx < 32 ? k0 : (sidx < 64 ? k1 : a.bin_key[b * kw + (sidx >> 5)]);
+                        if ((kwd >> (sidx & 31)) & 1u) ++inside;
+                        else mask |= 1u << q;
+                     }
+                     if (nbits >= 2 && inside != nbits - 2) bad |= kPairsForeignSegment;
+                  }
+               }
+            }
+            const uint64_t okm = __ballot(ok != 0);
+            const int n_here = __popcll(okm);
+            const int rank = __popcll(okm & ((1ull << lane) - 1ull));
+            const int seg_before = wave_excl_scan(ok ? n_eff : 0, lane);
+            const int seg_here = __builtin_amdgcn_readlane(seg_before + (ok ? n_eff : 0), 63);
+            if (FILL) {
+               const int len_j = __builtin_amdgcn_readlane(my_len, j);
+               const int64_t pb = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(my_p >> 32), j) << 32) |
+                                            (uint32_t)__builtin_amdgcn_readlane((int)my_p, j));
+               const int64_t sb = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(my_so >> 32), j) << 32) |
+                                            (uint32_t)__builtin_amdgcn_readlane((int)my_so, j));
+               if (ok) {
+                  const int64_t p = pb + rank, so = sb + seg_before;
+                  a.pair_seg_off[p] = so;
+                  for (int q = 0; q < n_eff; ++q) {
+                     const int sidx = is[low + q];
+                     a.pair_seg_lens[so + q] = a.seg_right[s0 + sidx] - a.seg_left[s0 + sidx] + 1;
+                  }
+                  a.pair_mask[p] = mask;
+                  a.pair_iso_len[p] = len_j;
+                  a.pair_out_index[p] = f0 + (b - b0) * niso + j;
+               }
+            }
+            if (lane == j) {
+               my_p += n_here, my_so += seg_here;
+               my_np += n_here, my_ns += seg_here;
+            }
+         }
+      }
+      if (!FILL && has_iso) {
+         a.pair_cnt[i0 + lane] = my_np;
+         a.seg_cnt[i0 + lane] = my_ns;
       }
       if (bad) atomicOr(a.flags, bad);
    }

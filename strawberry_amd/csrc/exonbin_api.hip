@@ -590,6 +590,13 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
    pa.pair_iso_len = nullptr;
    pa.pair_out_index = nullptr;
    pa.flags = a.flags + 1;
+   // one wave per locus (bins_pairs_locus_kernel) for loci of up to 64 isoforms, the thread-per-isoform kernel for the
+   // others; SBGPU_PAIRS_BY_ISOFORM=1: the latter everywhere (A/B)
+   static const bool pairs_by_iso = std::getenv("SBGPU_PAIRS_BY_ISOFORM") && std::atoi(std::getenv("SBGPU_PAIRS_BY_ISOFORM")) != 0;
+   bool any_wide_locus = false;
+   for (int64_t l = 0; l < nl && !any_wide_locus; ++l) any_wide_locus = an->iso_off[l + 1] - an->iso_off[l] > 64;
+   pa.only_wide_loci = pairs_by_iso ? 0 : 1;
+   const unsigned lgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((nl + 3) / 4, cap * 8));
    const unsigned pgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_iso + 255) / 256, cap * 4));
    auto launch_middle = [&]() -> hipError_t {
       hipError_t x = hipMemsetAsync(d + o_flag + 4, 0, 4, s);
@@ -604,7 +611,8 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
       hipLaunchKernelGGL(sb::bins_pack_kernel, dim3((unsigned)(nl < cap ? nl : cap)), dim3(256), 0, s, pk);
       sb::ctx_stage_end(c, s);
       sb::ctx_stage_begin(c, "bins_pairs_kernel<count> + bins_scan_*_kernel<pairs>", s);
-      hipLaunchKernelGGL(sb::bins_pairs_kernel<false>, dim3(pgrid), dim3(256), 0, s, pa);
+      if (pairs_by_iso || any_wide_locus) hipLaunchKernelGGL(sb::bins_pairs_kernel<false>, dim3(pgrid), dim3(256), 0, s, pa);
+      if (!pairs_by_iso) hipLaunchKernelGGL(sb::bins_pairs_locus_kernel<false>, dim3(lgrid), dim3(256), 0, s, pa, nl);
       sb::ScanArgs sp = {n_iso, pa.pair_cnt, pa.seg_cnt, nullptr, (int64_t *)(d3 + r_poff), (int64_t *)(d3 + r_soff), part_a, part_b, (int64_t *)(d3 + r_tot) + 2};
       hipLaunchKernelGGL(sb::bins_scan_tiles_kernel<1>, dim3((unsigned)iso_tiles), dim3(256), 0, s, sp);
       hipLaunchKernelGGL(sb::bins_scan_parts_kernel, dim3(1), dim3(256), 0, s, sp, n_iso ? iso_tiles : 0);
@@ -745,7 +753,8 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
    pa.pair_iso_len = (int32_t *)(dp.arena + dp.o_iso_len);
    pa.pair_out_index = (int64_t *)(dp.arena + dp.o_out_index);
    sb::ctx_stage_begin(c, "bins_pairs_kernel<fill>", s);
-   hipLaunchKernelGGL(sb::bins_pairs_kernel<true>, dim3(pgrid), dim3(256), 0, s, pa);
+   if (pairs_by_iso || any_wide_locus) hipLaunchKernelGGL(sb::bins_pairs_kernel<true>, dim3(pgrid), dim3(256), 0, s, pa);
+   if (!pairs_by_iso) hipLaunchKernelGGL(sb::bins_pairs_locus_kernel<true>, dim3(lgrid), dim3(256), 0, s, pa, nl);
    sb::ctx_stage_end(c, s);
    SB_TRY3(hipGetLastError());
    stage("pairs fill launch");

@@ -262,6 +262,34 @@ def test_device_grouping_equals_host_grouping(ctx, oracle):
     assert (naive != bh.count).sum() > 50
 
 
+def test_device_pairs_for_narrow_and_wide_loci_in_one_call(ctx):
+    """The (bin, isoform) pairs come from two kernels: one wave per locus for loci of up to 64 isoforms, one thread per
+    isoform for the others.  A batch with both kinds -- and loci of more than 64 bins, which the wave takes in several
+    rounds -- gives the host code's pair arrays, entry for entry."""
+    from strawberry_amd import exonbin as eb
+    from strawberry_amd import synth
+    from strawberry_amd.quantify import InsertSize, LocusQuantifier
+    loci = synth.make_gene_models(40, seed=51, max_exons=30, max_isoforms=90, ex_lo=60, ex_hi=160)
+    n_iso = np.array([len(l) for l in loci])
+    assert (n_iso > 64).any() and (n_iso <= 64).any()
+    hl, pairs = synth.make_fragments(loci, 900, seed=52)
+    rows = []
+    for l, (lb, rb) in zip(hl, pairs):
+        f = eb.hit_features(lb, rb)
+        if f is not None:
+            rows.append((l, f[1][0], f[2][-1], f))
+    rows.sort(key=lambda r: (r[0], r[1], r[2]))
+    annot = eb.Annotation(loci)
+    hits = eb.Hits([r[0] for r in rows], [r[3] for r in rows])
+    qd = LocusQuantifier(annot, hits, InsertSize(250.0, 30.0), 75, ctx=ctx, device_bins=True)
+    qh = LocusQuantifier(annot, hits, InsertSize(250.0, 30.0), 75, ctx=ctx, device_bins=False)
+    bd, bh = qd.assign_bins(), qh.assign_bins()
+    assert qd.bins_on_device and not qh.bins_on_device
+    assert (np.diff(bh.row_off) > 64).any() and bh.n_pairs > 10000
+    for x, y in zip(bins_arrays(bd), bins_arrays(bh)):
+        np.testing.assert_array_equal(x, y)
+
+
 def group_both_ways(ctx, annot, hits, compat, key):
     """(device bins or None, host bins) for arbitrary word arrays (they need not come from the kernel)."""
     import ctypes as C
