@@ -68,6 +68,14 @@ struct DeviceIsoSegments {
    const int64_t *seg_off = nullptr;
    const int32_t *seg_idx = nullptr, *locus = nullptr, *len = nullptr;
 };
+// The isoforms in the segment basis (exonbin_device.h: iso_masks_kernel): made per call, or once for a resident annotation
+struct DeviceSegBasis {
+   const uint64_t *member = nullptr, *start = nullptr, *adj = nullptr;
+   const uint32_t *ok = nullptr;
+};
+size_t seg_basis_bytes(int64_t n_loci, int64_t n_iso);
+// launches iso_masks_kernel on `stream` over a device annotation, into `mem` (seg_basis_bytes): -> the pointers
+int make_seg_basis(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *d_annot, int64_t n_iso, char *mem, void *stream, DeviceSegBasis *out);
 // An annotation kept resident (sbgpu_annotation_pin, chain_api.hip): the caller's arrays remembered by address, their
 // device copies, and what the chain makes of an annotation alone.  Lives with the context.
 struct ResidentAnnotation {
@@ -76,6 +84,7 @@ struct ResidentAnnotation {
    size_t capacity = 0;
    sbgpu_annotation_t dev;  // the arrays' device copies
    DeviceIsoSegments d_iso;
+   DeviceSegBasis seg_basis; // (same arena)
    IsoSegments iso;         // host
    int64_t max_locus_span = 1, max_iso = 1, max_seg = 1; // longest locus' segments together; widest locus
    bool matches(const sbgpu_annotation_t *a) const
@@ -104,7 +113,7 @@ int bins_create_device_impl(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *annot, c
 // n_iso: the annotation's isoform count where the caller knows it on the host (-1: read from the device)
 int exonbin_device_impl(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *annot, const sbgpu_hits_t *hits, int32_t compat_words,
                         int32_t key_words, uint32_t *d_compat, uint32_t *d_key, uint64_t *d_span, uint32_t *d_fhash, void *stream,
-                        int64_t n_iso = -1);
+                        int64_t n_iso = -1, const DeviceSegBasis *seg_basis = nullptr);
 int api_fail(int code, const std::string &msg); // records sbgpu_last_error(), returns code
 hipStream_t ctx_stream(const sbgpu_ctx_t *ctx); // the context's own stream
 int ctx_cu_count(const sbgpu_ctx_t *ctx);

@@ -186,7 +186,7 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
    sb::ctx_stage_reset(c);
    // ---- A5: the interval tests
    sb::ctx_stage_begin(c, "exonbin_kernel", s);
-   if (nh) SB_RC(sb::exonbin_device_impl(c, &dan, &dh, cw, kw, d_compat, d_key, d_span, d_fhash, s, n_iso));
+   if (nh) SB_RC(sb::exonbin_device_impl(c, &dan, &dh, cw, kw, d_compat, d_key, d_span, d_fhash, s, n_iso, res ? &res->seg_basis : nullptr));
    sb::ctx_stage_end(c, s);
    stage("exonbin kernel");
    std::vector<uint32_t> compat_h, key_h;
@@ -545,6 +545,8 @@ int sbgpu_annotation_pin(sbgpu_ctx_t *c, const sbgpu_annotation_t *an)
       p.off = total;
       total += up256(p.bytes ? p.bytes : 8);
    }
+   const size_t o_segbasis = total;
+   total += sb::seg_basis_bytes(nl, n_iso);
    hipError_t e = hipSetDevice(sb::ctx_device(c));
    if (e == hipSuccess) e = sb::dev_take(total, &r->arena, &r->capacity);
    for (Part &p : parts)
@@ -566,6 +568,14 @@ int sbgpu_annotation_pin(sbgpu_ctx_t *c, const sbgpu_annotation_t *an)
    r->d_iso.seg_idx = (const int32_t *)(r->arena + parts[8].off);
    r->d_iso.locus = (const int32_t *)(r->arena + parts[9].off);
    r->d_iso.len = (const int32_t *)(r->arena + parts[10].off);
+   // the isoforms in the segment basis (the exon-bin kernel's masks): once, here
+   int rc_sb = sb::make_seg_basis(c, &r->dev, n_iso, r->arena + o_segbasis, sb::ctx_stream(c), &r->seg_basis);
+   if (rc_sb == SBGPU_OK && hipStreamSynchronize(sb::ctx_stream(c)) != hipSuccess) rc_sb = api_fail(SBGPU_EHIP, "sbgpu_annotation_pin: iso_masks_kernel failed");
+   if (rc_sb != SBGPU_OK) {
+      sb::dev_give(r->arena, r->capacity);
+      delete r;
+      return rc_sb;
+   }
    sb::ctx_set_resident_annotation(c, r);
    return SBGPU_OK;
 }

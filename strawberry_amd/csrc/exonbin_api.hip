@@ -19,9 +19,39 @@ using sb::api_fail;
 
 namespace sb {
 // sbgpu_exonbin_device that also leaves every hit's span and sequence hash (exonbin_device.h) when asked to
+static size_t up256b(size_t b) { return (b + 255) & ~(size_t)255; }
+size_t seg_basis_bytes(int64_t n_loci, int64_t n_iso)
+{
+   const size_t ni1 = (size_t)(n_iso > 0 ? n_iso : 1);
+   return 2 * up256b(ni1 * 8) + up256b((size_t)n_loci * 8) + up256b((size_t)n_loci * 4);
+}
+int make_seg_basis(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, int64_t n_iso, char *dm, void *stream, DeviceSegBasis *out)
+{
+   const size_t ni1 = (size_t)(n_iso > 0 ? n_iso : 1);
+   const size_t o_mem = 0, o_sta = up256b(ni1 * 8), o_adj = 2 * o_sta, o_ok = o_adj + up256b((size_t)an->n_loci * 8);
+   sb::ExonBinArgs a = {};
+   a.iso_off = an->iso_off;
+   a.exon_off = an->exon_off;
+   a.exon_left = an->exon_left;
+   a.exon_right = an->exon_right;
+   a.seg_off = an->seg_off;
+   a.seg_left = an->seg_left;
+   a.seg_right = an->seg_right;
+   const int64_t cap = (int64_t)sb::ctx_cu_count(c) * 8, lb = (an->n_loci + 255) / 256;
+   hipLaunchKernelGGL(sb::iso_masks_kernel, dim3((unsigned)(lb < cap ? lb : cap)), dim3(256), 0, (hipStream_t)stream, a, an->n_loci,
+                      (uint64_t *)(dm + o_mem), (uint64_t *)(dm + o_sta), (uint32_t *)(dm + o_ok), (uint64_t *)(dm + o_adj));
+   const hipError_t e = hipGetLastError();
+   if (e != hipSuccess) return api_fail(SBGPU_EHIP, std::string("iso_masks_kernel: ") + hipGetErrorString(e));
+   out->member = (const uint64_t *)(dm + o_mem);
+   out->start = (const uint64_t *)(dm + o_sta);
+   out->adj = (const uint64_t *)(dm + o_adj);
+   out->ok = (const uint32_t *)(dm + o_ok);
+   return SBGPU_OK;
+}
+
 int exonbin_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgpu_hits_t *hits, int32_t compat_words,
                         int32_t key_words, uint32_t *d_compat, uint32_t *d_key, uint64_t *d_span, uint32_t *d_fhash, void *stream,
-                        int64_t n_iso)
+                        int64_t n_iso, const DeviceSegBasis *seg_pre)
 {
    if (!c || !an || !hits) return api_fail(SBGPU_EINVAL, "sbgpu_exonbin_device: null argument");
    if (hits->n_hits == 0) return SBGPU_OK;
@@ -56,24 +86,25 @@ int exonbin_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgp
    // the isoforms in the segment basis (exonbin_device.h): loci of up to 64 segments (key_words <= 2 covers them all)
    static const bool seg_basis = !(std::getenv("SBGPU_EXONBIN_SEGBASIS") && std::atoi(std::getenv("SBGPU_EXONBIN_SEGBASIS")) == 0);
    if (seg_basis && key_words >= 1 && compat_words >= 1) {
-      if (n_iso < 0) { // a caller with a device annotation only: one 8-byte read
-         hipError_t ec = hipMemcpyAsync(&n_iso, an->iso_off + an->n_loci, 8, hipMemcpyDeviceToHost, (hipStream_t)stream);
-         if (ec == hipSuccess) ec = hipStreamSynchronize((hipStream_t)stream);
-         if (ec != hipSuccess) return api_fail(SBGPU_EHIP, std::string("sbgpu_exonbin_device: ") + hipGetErrorString(ec));
+      DeviceSegBasis sbz;
+      if (seg_pre) {
+         sbz = *seg_pre; // made once for a resident annotation
+      } else {
+         if (n_iso < 0) { // a caller with a device annotation only: one 8-byte read
+            hipError_t ec = hipMemcpyAsync(&n_iso, an->iso_off + an->n_loci, 8, hipMemcpyDeviceToHost, (hipStream_t)stream);
+            if (ec == hipSuccess) ec = hipStreamSynchronize((hipStream_t)stream);
+            if (ec != hipSuccess) return api_fail(SBGPU_EHIP, std::string("sbgpu_exonbin_device: ") + hipGetErrorString(ec));
+         }
+         char *dm = nullptr;
+         hipError_t em = sb::ctx_scratch(c, 3, seg_basis_bytes(an->n_loci, n_iso), &dm);
+         if (em != hipSuccess) return api_fail(em == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("hipMalloc: ") + hipGetErrorString(em));
+         const int rc = make_seg_basis(c, an, n_iso, dm, stream, &sbz);
+         if (rc != SBGPU_OK) return rc;
       }
-      const size_t ni1 = (size_t)(n_iso > 0 ? n_iso : 1);
-      const size_t o_mem = 0, o_sta = ((ni1 * 8 + 255) & ~(size_t)255), o_adj = 2 * o_sta,
-                   o_ok = o_adj + (((size_t)an->n_loci * 8 + 255) & ~(size_t)255);
-      char *dm = nullptr;
-      hipError_t em = sb::ctx_scratch(c, 3, o_ok + (size_t)an->n_loci * 4 + 256, &dm);
-      if (em != hipSuccess) return api_fail(em == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("hipMalloc: ") + hipGetErrorString(em));
-      const int64_t cap = (int64_t)sb::ctx_cu_count(c) * 8, lb = (an->n_loci + 255) / 256;
-      hipLaunchKernelGGL(sb::iso_masks_kernel, dim3((unsigned)(lb < cap ? lb : cap)), dim3(256), 0, (hipStream_t)stream, a, an->n_loci,
-                         (uint64_t *)(dm + o_mem), (uint64_t *)(dm + o_sta), (uint32_t *)(dm + o_ok), (uint64_t *)(dm + o_adj));
-      a.locus_adj = (const uint64_t *)(dm + o_adj);
-      a.iso_member = (const uint64_t *)(dm + o_mem);
-      a.iso_start = (const uint64_t *)(dm + o_sta);
-      a.locus_seg_ok = (const uint32_t *)(dm + o_ok);
+      a.iso_member = sbz.member;
+      a.iso_start = sbz.start;
+      a.locus_seg_ok = sbz.ok;
+      a.locus_adj = sbz.adj;
    }
    const int64_t blocks_wanted = (hits->n_hits + 255) / 256;
    if (blocks_wanted > 0x7fffffff) return api_fail(SBGPU_ESHAPE, "sbgpu_exonbin_device: more than 2^39 hits in one call");

@@ -7,6 +7,7 @@ import sqlite3, sys
 cur = sqlite3.connect(sys.argv[1]).cursor()
 rows = [r for r in cur.execute("select name, start, end from kernels order by start") if 'sb::' in r[0]]
 first = [i for i, r in enumerate(rows) if 'exonbin_kernel' in r[0]]
+first = [i - 1 if i and 'iso_masks_kernel' in rows[i - 1][0] else i for i in first]   # (an annotation that is not pinned: its masks are made first)
 i0, i1 = first[-2], first[-1]
 t0 = rows[i0][1]
 prev_end, busy = t0, 0
