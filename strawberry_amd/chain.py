@@ -267,6 +267,9 @@ class ChainQuantifier:
             L.sbgpu_set_timing(self.ctx.h, 0)
 
     def finish(self):
+        pass
+
+    def unpin(self):
         if self.pinned:
             self.ctx.L.sbgpu_annotation_unpin(self.ctx.h)
             self.pinned = False

@@ -642,7 +642,7 @@ def test_pinned_annotation_gives_the_unpinned_results():
     c = chain.ChainQuantifier(ctx, n_loci=200, n_frags=200 * 150, seed=10, pin=False)
     c.step()
     c_first = c.theta.copy()
-    b.finish()      # unpin
+    b.unpin()
     c.step()
     np.testing.assert_array_equal(c.theta, c_first)
     b.theta[:] = -1
