@@ -422,8 +422,10 @@ int sbgpu_uniq_export(const sbgpu_uniq_t *u, int32_t *hit_locus, int64_t *feat_o
  * sbgpu_hits_t layout -- sbgpu_uniq_dev_hits hands them to sbgpu_exonbin_device / sbgpu_quantify_device -- and
  * only the per-locus counts and cluster masses come back.  One workgroup per locus sorts its pairs in LDS
  * ((left, right), ties in input order), applies the span filter, collapses equal neighbours (masses added in
- * double, in that order) and builds Contig(PairedHit)'s features.  Covers loci of up to 4096 pairs and mates of up
- * to 24 features; otherwise SBGPU_EUNSUPPORTED (use sbgpu_collapse_pairs_host).  Synchronises on `stream`.
+ * double, in that order) and builds Contig(PairedHit)'s features; a locus of more than 4096 pairs (any highly
+ * expressed gene) takes the same steps with 1024 threads and its arrays in global memory.  Covers loci of up to 2^24
+ * pairs and mates of up to 24 features; otherwise SBGPU_EUNSUPPORTED (use sbgpu_collapse_pairs_host).  Synchronises
+ * on `stream`.
  * The span filter evaluates phi() with the device's exp(): a pair exactly on the 0.999 boundary could fall on the
  * other side than with the host's libm (not observed).                                                        */
 typedef struct sbgpu_uniq_dev sbgpu_uniq_dev_t;

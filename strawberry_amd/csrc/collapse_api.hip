@@ -75,10 +75,34 @@ int sbgpu_collapse_pairs_device(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_pair
       *out = U;
       return SBGPU_OK;
    }
-   // a locus the LDS sort does not hold is known from the host offsets: decline before anything is allocated or launched
-   for (int64_t l = 0; l < n_loci; ++l)
-      if (locus_pair_off[l + 1] - locus_pair_off[l] > sb::kCollapseMax)
-         return bail(SBGPU_EUNSUPPORTED, "sbgpu_collapse_pairs_device: not covered by the device form: a locus has more than 4096 read pairs; use sbgpu_collapse_pairs_host");
+   // loci the LDS sort does not hold (more than 4096 pairs: any highly expressed gene) get a workgroup of their own with
+   // the arrays in global scratch (collapse_big_kernel); known from the host offsets
+   std::vector<int32_t> big_loci;
+   std::vector<int64_t> big_off(1, 0);
+   for (int64_t l = 0; l < n_loci; ++l) {
+      const int64_t n = locus_pair_off[l + 1] - locus_pair_off[l];
+      if (n <= sb::kCollapseMax) continue;
+      if (n > (int64_t)1 << 24)
+         return bail(SBGPU_EUNSUPPORTED, "sbgpu_collapse_pairs_device: not covered by the device form: a locus has more than 2^24 read pairs; use sbgpu_collapse_pairs_host");
+      int64_t n2 = 1;
+      while (n2 < n) n2 <<= 1;
+      big_loci.push_back((int32_t)l);
+      big_off.push_back(big_off.back() + n2);
+   }
+   // the biggest first: a locus is one workgroup's work
+   if (big_loci.size() > 1) {
+      std::vector<size_t> ord(big_loci.size());
+      for (size_t i = 0; i < ord.size(); ++i) ord[i] = i;
+      std::sort(ord.begin(), ord.end(), [&](size_t x, size_t y) { return big_off[x + 1] - big_off[x] > big_off[y + 1] - big_off[y]; });
+      std::vector<int32_t> bl(big_loci.size());
+      std::vector<int64_t> bo(1, 0);
+      for (size_t i = 0; i < ord.size(); ++i) {
+         bl[i] = big_loci[ord[i]];
+         bo.push_back(bo.back() + (big_off[ord[i] + 1] - big_off[ord[i]]));
+      }
+      big_loci.swap(bl), big_off.swap(bo);
+   }
+   const size_t n_big = big_loci.size(), big_elems = (size_t)big_off.back();
    SB_TRY(hipSetDevice(U->device));
    const size_t np1 = (size_t)np, nl1 = (size_t)n_loci + 1;
    size_t off = 0;
@@ -94,6 +118,13 @@ int sbgpu_collapse_pairs_device(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_pair
    const size_t o_flag = off; off += 256;
    const size_t o_hoff = off; off += up256(nl1 * 8);
    const size_t o_fbase = off; off += up256(nl1 * 8);
+   const size_t o_bloci = off; off += up256((n_big + 1) * 4);
+   const size_t o_boff = off; off += up256((n_big + 1) * 8);
+   const size_t o_bkey = off; off += up256((big_elems + 1) * 8);
+   const size_t o_bidx = off; off += up256((big_elems + 1) * 4);
+   const size_t o_bsl = off; off += up256((big_elems + 1) * 4);
+   const size_t o_bsr = off; off += up256((big_elems + 1) * 4);
+   const size_t o_bskip = off; off += up256(big_elems + 1);
    SB_TRY(hipMalloc(&w, off));
    SB_TRY(hipMemsetAsync(w + o_flag, 0, 256, s));
    SB_TRY(hipMemcpyAsync(w + o_poff, locus_pair_off, nl1 * 8, hipMemcpyHostToDevice, s));
@@ -115,6 +146,21 @@ int sbgpu_collapse_pairs_device(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_pair
    a.n_rejected = (int32_t *)(w + o_nr);
    a.flags = (int32_t *)(w + o_flag);
    const unsigned grid = (unsigned)std::min<int64_t>(n_loci, (int64_t)sb::ctx_cu_count(c) * 8);
+   if (n_big) { // first: they are the long ones
+      SB_TRY(hipMemcpyAsync(w + o_bloci, big_loci.data(), n_big * 4, hipMemcpyHostToDevice, s));
+      SB_TRY(hipMemcpyAsync(w + o_boff, big_off.data(), (n_big + 1) * 8, hipMemcpyHostToDevice, s));
+      sb::CollapseBigArgs b;
+      b.n_big = (int32_t)n_big;
+      b.loci = (const int32_t *)(w + o_bloci);
+      b.big_off = (const int64_t *)(w + o_boff);
+      b.key = (unsigned long long *)(w + o_bkey);
+      b.idx = (int *)(w + o_bidx);
+      b.span_l = (int *)(w + o_bsl);
+      b.span_r = (int *)(w + o_bsr);
+      b.skip = (unsigned char *)(w + o_bskip);
+      hipLaunchKernelGGL(sb::collapse_big_kernel, dim3((unsigned)std::min<size_t>(n_big, (size_t)sb::ctx_cu_count(c) * 2)), dim3(sb::kCollapseBigThreads), 0, s, a, b);
+      SB_TRY(hipGetLastError());
+   }
    hipLaunchKernelGGL(sb::collapse_locus_kernel, dim3(grid), dim3(sb::kCollapseThreads), 0, s, a);
    SB_TRY(hipGetLastError());
    std::vector<int32_t> nh((size_t)n_loci), nf((size_t)n_loci), nfi((size_t)n_loci), nr((size_t)n_loci);
@@ -128,7 +174,6 @@ int sbgpu_collapse_pairs_device(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_pair
    SB_TRY(hipStreamSynchronize(s));
    if (flags) {
       std::string why = "sbgpu_collapse_pairs_device: not covered by the device form:";
-      if (flags & sb::kCollapseTooMany) why += " a locus has more than 4096 read pairs;";
       if (flags & sb::kCollapseLongMate) why += " a mate has more than 24 features;";
       if (flags & sb::kCollapseNoMates) return bail(SBGPU_EINVAL, "sbgpu_collapse_pairs_device: a pair without mates");
       return bail(SBGPU_EUNSUPPORTED, why + " use sbgpu_collapse_pairs_host");

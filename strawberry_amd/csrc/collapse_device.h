@@ -12,8 +12,8 @@
 //      the cluster's mass is one sequential double sum in sorted order, a unique hit's mass one per group;
 //   4. after the host has turned the per-locus counts into offsets, a second kernel writes the unique hits
 //      (sbgpu_hits_t layout) where the exon-bin kernel reads them.
-// Limits, each reported through a flag (the caller then uses sbgpu_collapse_pairs_host): at most 4096 pairs per
-// locus, at most 24 features per mate.
+// Loci of more than 4096 pairs take the same steps with their arrays in global memory (collapse_big_kernel).
+// Limit, reported through a flag (the caller then uses sbgpu_collapse_pairs_host): at most 24 features per mate.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -159,6 +159,169 @@ __device__ __forceinline__ uint32_t pair_right_pos(const MateRef &a, const MateR
    return b.n ? b.r[b.n - 1] : a.r[a.n - 1];
 }
 
+// What a workgroup shares while it serves one locus (LDS in both forms)
+struct CollapseShared {
+   double mean, sd5;
+   int nmates, hits, feats, filt, rej, bad;
+};
+
+// One locus by one workgroup of THREADS threads.  key / idx [n2 = pow2ceil(np)], span_l / span_r / skip [np]: LDS for
+// loci of up to kCollapseMax pairs, global scratch for bigger ones (collapse_big_kernel) -- the same steps either way.
+template <int THREADS>
+__device__ __forceinline__ void collapse_one_locus(const CollapseArgs &a, int64_t l, int np, unsigned long long *key, int *idx, int *span_l,
+                                                   int *span_r, unsigned char *skip, double *red, CollapseShared &sh)
+{
+   const int tid = threadIdx.x;
+   const int64_t q0 = a.locus_pair_off[l];
+   int n2 = 1;
+   while (n2 < np) n2 <<= 1;
+   // ---- keys, spans
+   int bad = 0;
+   double span_sum = 0.0;
+   int n_mates = 0;
+   for (int i = tid; i < n2; i += THREADS) {
+      unsigned long long k = ~0ull;
+      if (i < np) {
+         const MateRef x = left_mate(a, q0 + i), y = right_mate(a, q0 + i);
+         if (x.n > kMateFeatMax || y.n > kMateFeatMax) bad |= kCollapseLongMate;
+         if (x.n == 0 && y.n == 0) {
+            bad |= kCollapseNoMates;
+         } else {
+            k = ((unsigned long long)pair_left_pos(x, y) << 32) | pair_right_pos(x, y);
+         }
+         span_l[i] = x.n ? (int)(x.r[x.n - 1] - x.l[0] + 1) : -1;
+         span_r[i] = y.n ? (int)(y.r[y.n - 1] - y.l[0] + 1) : -1;
+         if (x.n) span_sum += (double)span_l[i], ++n_mates;
+         if (y.n) span_sum += (double)span_r[i], ++n_mates;
+      }
+      key[i] = k;
+      idx[i] = i;
+   }
+   if (bad) atomicOr(&sh.bad, bad);
+   // the spans are whole numbers: their sum is exact whatever the order
+   red[tid] = span_sum;
+   __syncthreads();
+   for (int w = THREADS / 2; w > 0; w >>= 1) {
+      if (tid < w) red[tid] += red[tid + w];
+      __syncthreads();
+   }
+   const double total_span = red[0];
+   __syncthreads();
+   red[tid] = (double)n_mates;
+   __syncthreads();
+   for (int w = THREADS / 2; w > 0; w >>= 1) {
+      if (tid < w) red[tid] += red[tid + w];
+      __syncthreads();
+   }
+   if (tid == 0) {
+      sh.nmates = (int)red[0];
+      sh.mean = total_span / red[0];
+   }
+   __syncthreads();
+   if (sh.bad) {
+      if (tid == 0) atomicOr(a.flags, sh.bad);
+      __syncthreads();
+      return;
+   }
+   // ---- bitonic sort of (key, input index)
+   for (int k2 = 2; k2 <= n2; k2 <<= 1)
+      for (int j = k2 >> 1; j > 0; j >>= 1) {
+         for (int i = tid; i < n2; i += THREADS) {
+            const int p = i ^ j;
+            if (p > i) {
+               const bool up = (i & k2) == 0;
+               const unsigned long long ki = key[i], kp = key[p];
+               const int ii = idx[i], ip = idx[p];
+               const bool greater = ki > kp || (ki == kp && ii > ip);
+               if (greater == up) {
+                  key[i] = kp, key[p] = ki;
+                  idx[i] = ip, idx[p] = ii;
+               }
+            }
+         }
+         __syncthreads();
+      }
+   // ---- sd: the squared deviations added in INPUT order (left mate, then right mate of each pair), by one thread
+   if (tid == 0) {
+      const double mean = sh.mean;
+      double sq = 0.0;
+      for (int i = 0; i < np; ++i) {
+         if (span_l[i] >= 0) {
+            const double d = (double)span_l[i] - mean;
+            sq += d * d;
+         }
+         if (span_r[i] >= 0) {
+            const double d = (double)span_r[i] - mean;
+            sq += d * d;
+         }
+      }
+      sh.sd5 = sqrt(sq / (double)sh.nmates) * 5;
+   }
+   __syncthreads();
+   // ---- the span filter (:670-682), and the masses in sorted order
+   double *pmass = (double *)key;
+   for (int i = tid; i < np; i += THREADS) {
+      const int p = idx[i];
+      a.order[q0 + i] = p;
+      bool sk = false;
+      if (span_l[p] >= 0 && ref_phi_dev(((double)(uint32_t)span_l[p] - sh.mean) / sh.sd5) > 0.999) sk = true;
+      if (span_r[p] >= 0 && ref_phi_dev(((double)(uint32_t)span_r[p] - sh.mean) / sh.sd5) > 0.999) sk = true;
+      skip[i] = sk ? 1 : 0;
+   }
+   __syncthreads(); // everybody is done with key[] as keys
+   for (int i = tid; i < np; i += THREADS) pmass[i] = a.pair_mass[q0 + idx[i]];
+   __syncthreads();
+   // ---- the cluster's mass: kept pairs in sorted order, one running double (:683-684)
+   if (tid == 0) {
+      double m = 0.0;
+      for (int i = 0; i < np; ++i)
+         if (!skip[i]) m += pmass[i];
+      a.cluster_mass[l] = m;
+   }
+   // ---- unique hits: a kept pair that differs from the previous kept pair (:685-697)
+   int my_hits = 0, my_feats = 0, my_filt = 0, my_rej = 0;
+   for (int i = tid; i < np; i += THREADS) {
+      a.nfeat[q0 + i] = 0;
+      a.mass[q0 + i] = 0.0f;
+      if (skip[i]) {
+         ++my_filt;
+         continue;
+      }
+      const MateRef x = left_mate(a, q0 + idx[i]), y = right_mate(a, q0 + idx[i]);
+      int prev = i - 1;
+      while (prev >= 0 && skip[prev]) --prev;
+      if (prev >= 0 && mate_equal(left_mate(a, q0 + idx[prev]), x) && mate_equal(right_mate(a, q0 + idx[prev]), y)) continue;
+      // head of a group: its mass = the members' masses added in order, in double; stored as float (Contig::mass())
+      double m = pmass[i];
+      for (int k = i + 1; k < np; ++k) {
+         if (skip[k]) continue;
+         if (!(mate_equal(left_mate(a, q0 + idx[k]), x) && mate_equal(right_mate(a, q0 + idx[k]), y))) break;
+         m += pmass[k];
+      }
+      const int nf = hit_features_dev(x, y, nullptr, nullptr, nullptr);
+      if (nf <= 0) {
+         ++my_rej; // Contig(PairedHit) rejects the pair: no hit, its mass stays in the cluster's
+         continue;
+      }
+      a.nfeat[q0 + i] = nf;
+      a.mass[q0 + i] = (float)m;
+      ++my_hits;
+      my_feats += nf;
+   }
+   if (my_hits) atomicAdd(&sh.hits, my_hits);
+   if (my_feats) atomicAdd(&sh.feats, my_feats);
+   if (my_filt) atomicAdd(&sh.filt, my_filt);
+   if (my_rej) atomicAdd(&sh.rej, my_rej);
+   __syncthreads();
+   if (tid == 0) {
+      a.n_hits[l] = sh.hits;
+      a.n_feats[l] = sh.feats;
+      a.n_filtered[l] = sh.filt;
+      a.n_rejected[l] = sh.rej;
+   }
+   __syncthreads();
+}
+
 __global__ __launch_bounds__(kCollapseThreads) void collapse_locus_kernel(CollapseArgs a)
 {
    __shared__ unsigned long long key[kCollapseMax]; // sort keys; afterwards the pairs' masses (as doubles)
@@ -166,170 +329,51 @@ __global__ __launch_bounds__(kCollapseThreads) void collapse_locus_kernel(Collap
    __shared__ int span_l[kCollapseMax], span_r[kCollapseMax]; // by input index; -1: no such mate
    __shared__ unsigned char skip[kCollapseMax];               // by sorted position
    __shared__ double red[kCollapseThreads];
-   __shared__ double s_mean, s_sd5;
-   __shared__ int s_nmates, c_hits, c_feats, c_filt, c_rej, s_bad;
+   __shared__ CollapseShared sh;
    const int tid = threadIdx.x;
    for (int64_t l = blockIdx.x; l < a.n_loci; l += gridDim.x) {
       const int64_t q0 = a.locus_pair_off[l];
-      const int np = (int)min<int64_t>(a.locus_pair_off[l + 1] - q0, (int64_t)kCollapseMax + 1);
+      const int64_t npl = a.locus_pair_off[l + 1] - q0;
+      if (npl > kCollapseMax) continue; // collapse_big_kernel's
       if (tid == 0) {
          a.cluster_mass[l] = 0.0;
          a.n_hits[l] = a.n_feats[l] = a.n_filtered[l] = a.n_rejected[l] = 0;
-         c_hits = c_feats = c_filt = c_rej = s_bad = 0;
-      }
-      if (np == 0) continue;
-      if (np > kCollapseMax) {
-         if (tid == 0) atomicOr(a.flags, (int)kCollapseTooMany);
-         continue;
+         sh.hits = sh.feats = sh.filt = sh.rej = sh.bad = 0;
       }
       __syncthreads();
-      int n2 = 1;
-      while (n2 < np) n2 <<= 1;
-      // ---- keys, spans
-      int bad = 0;
-      double span_sum = 0.0;
-      int n_mates = 0;
-      for (int i = tid; i < n2; i += kCollapseThreads) {
-         unsigned long long k = ~0ull;
-         if (i < np) {
-            const MateRef x = left_mate(a, q0 + i), y = right_mate(a, q0 + i);
-            if (x.n > kMateFeatMax || y.n > kMateFeatMax) bad |= kCollapseLongMate;
-            if (x.n == 0 && y.n == 0) {
-               bad |= kCollapseNoMates;
-            } else {
-               k = ((unsigned long long)pair_left_pos(x, y) << 32) | pair_right_pos(x, y);
-            }
-            span_l[i] = x.n ? (int)(x.r[x.n - 1] - x.l[0] + 1) : -1;
-            span_r[i] = y.n ? (int)(y.r[y.n - 1] - y.l[0] + 1) : -1;
-            if (x.n) span_sum += (double)span_l[i], ++n_mates;
-            if (y.n) span_sum += (double)span_r[i], ++n_mates;
-         }
-         key[i] = k;
-         idx[i] = i;
-      }
-      if (bad) atomicOr(&s_bad, bad);
-      // the spans are whole numbers: their sum is exact whatever the order
-      red[tid] = span_sum;
-      __syncthreads();
-      for (int w = kCollapseThreads / 2; w > 0; w >>= 1) {
-         if (tid < w) red[tid] += red[tid + w];
-         __syncthreads();
-      }
-      const double total_span = red[0];
-      __syncthreads();
-      red[tid] = (double)n_mates;
-      __syncthreads();
-      for (int w = kCollapseThreads / 2; w > 0; w >>= 1) {
-         if (tid < w) red[tid] += red[tid + w];
-         __syncthreads();
-      }
+      if (npl == 0) continue;
+      collapse_one_locus<kCollapseThreads>(a, l, (int)npl, key, idx, span_l, span_r, skip, red, sh);
+   }
+}
+
+// Loci of more than kCollapseMax pairs (any highly expressed gene): the same steps with the arrays in global scratch
+// and 1024 threads -- the bitonic sort then runs through the caches (a locus of 10^5 pairs: 153 passes of 64
+// compare-exchanges per thread), the two order-bound sums stay one thread's loops.  One workgroup per such locus.
+constexpr int kCollapseBigThreads = 1024;
+struct CollapseBigArgs {
+   int32_t n_big;
+   const int32_t *loci;      // [n_big] their locus numbers
+   const int64_t *big_off;   // [n_big + 1] first scratch element of each (in units of its n2: pow2ceil of its pairs)
+   unsigned long long *key;  // [big_off[n_big]]
+   int *idx, *span_l, *span_r;
+   unsigned char *skip;
+};
+
+__global__ __launch_bounds__(kCollapseBigThreads) void collapse_big_kernel(CollapseArgs a, CollapseBigArgs b)
+{
+   __shared__ double red[kCollapseBigThreads];
+   __shared__ CollapseShared sh;
+   const int tid = threadIdx.x;
+   for (int i = blockIdx.x; i < b.n_big; i += gridDim.x) {
+      const int64_t l = b.loci[i], o = b.big_off[i];
+      const int64_t npl = a.locus_pair_off[l + 1] - a.locus_pair_off[l];
       if (tid == 0) {
-         s_nmates = (int)red[0];
-         s_mean = total_span / red[0];
+         a.cluster_mass[l] = 0.0;
+         a.n_hits[l] = a.n_feats[l] = a.n_filtered[l] = a.n_rejected[l] = 0;
+         sh.hits = sh.feats = sh.filt = sh.rej = sh.bad = 0;
       }
       __syncthreads();
-      if (s_bad) {
-         if (tid == 0) atomicOr(a.flags, s_bad);
-         __syncthreads();
-         continue;
-      }
-      // ---- bitonic sort of (key, input index)
-      for (int k2 = 2; k2 <= n2; k2 <<= 1)
-         for (int j = k2 >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < n2; i += kCollapseThreads) {
-               const int p = i ^ j;
-               if (p > i) {
-                  const bool up = (i & k2) == 0;
-                  const unsigned long long ki = key[i], kp = key[p];
-                  const int ii = idx[i], ip = idx[p];
-                  const bool greater = ki > kp || (ki == kp && ii > ip);
-                  if (greater == up) {
-                     key[i] = kp, key[p] = ki;
-                     idx[i] = ip, idx[p] = ii;
-                  }
-               }
-            }
-            __syncthreads();
-         }
-      // ---- sd: the squared deviations added in INPUT order (left mate, then right mate of each pair), by one thread
-      if (tid == 0) {
-         const double mean = s_mean;
-         double sq = 0.0;
-         for (int i = 0; i < np; ++i) {
-            if (span_l[i] >= 0) {
-               const double d = (double)span_l[i] - mean;
-               sq += d * d;
-            }
-            if (span_r[i] >= 0) {
-               const double d = (double)span_r[i] - mean;
-               sq += d * d;
-            }
-         }
-         s_sd5 = sqrt(sq / (double)s_nmates) * 5;
-      }
-      __syncthreads();
-      // ---- the span filter (:670-682), and the masses into LDS in sorted order
-      double *pmass = (double *)key;
-      for (int i = tid; i < np; i += kCollapseThreads) {
-         const int p = idx[i];
-         a.order[q0 + i] = p;
-         bool sk = false;
-         if (span_l[p] >= 0 && ref_phi_dev(((double)(uint32_t)span_l[p] - s_mean) / s_sd5) > 0.999) sk = true;
-         if (span_r[p] >= 0 && ref_phi_dev(((double)(uint32_t)span_r[p] - s_mean) / s_sd5) > 0.999) sk = true;
-         skip[i] = sk ? 1 : 0;
-      }
-      __syncthreads(); // everybody is done with key[] as keys
-      for (int i = tid; i < np; i += kCollapseThreads) pmass[i] = a.pair_mass[q0 + idx[i]];
-      __syncthreads();
-      // ---- the cluster's mass: kept pairs in sorted order, one running double (:683-684)
-      if (tid == 0) {
-         double m = 0.0;
-         for (int i = 0; i < np; ++i)
-            if (!skip[i]) m += pmass[i];
-         a.cluster_mass[l] = m;
-      }
-      // ---- unique hits: a kept pair that differs from the previous kept pair (:685-697)
-      int my_hits = 0, my_feats = 0, my_filt = 0, my_rej = 0;
-      for (int i = tid; i < np; i += kCollapseThreads) {
-         a.nfeat[q0 + i] = 0;
-         a.mass[q0 + i] = 0.0f;
-         if (skip[i]) {
-            ++my_filt;
-            continue;
-         }
-         const MateRef x = left_mate(a, q0 + idx[i]), y = right_mate(a, q0 + idx[i]);
-         int prev = i - 1;
-         while (prev >= 0 && skip[prev]) --prev;
-         if (prev >= 0 && mate_equal(left_mate(a, q0 + idx[prev]), x) && mate_equal(right_mate(a, q0 + idx[prev]), y)) continue;
-         // head of a group: its mass = the members' masses added in order, in double; stored as float (Contig::mass())
-         double m = pmass[i];
-         for (int k = i + 1; k < np; ++k) {
-            if (skip[k]) continue;
-            if (!(mate_equal(left_mate(a, q0 + idx[k]), x) && mate_equal(right_mate(a, q0 + idx[k]), y))) break;
-            m += pmass[k];
-         }
-         const int nf = hit_features_dev(x, y, nullptr, nullptr, nullptr);
-         if (nf <= 0) {
-            ++my_rej; // Contig(PairedHit) rejects the pair: no hit, its mass stays in the cluster's
-            continue;
-         }
-         a.nfeat[q0 + i] = nf;
-         a.mass[q0 + i] = (float)m;
-         ++my_hits;
-         my_feats += nf;
-      }
-      if (my_hits) atomicAdd(&c_hits, my_hits);
-      if (my_feats) atomicAdd(&c_feats, my_feats);
-      if (my_filt) atomicAdd(&c_filt, my_filt);
-      if (my_rej) atomicAdd(&c_rej, my_rej);
-      __syncthreads();
-      if (tid == 0) {
-         a.n_hits[l] = c_hits;
-         a.n_feats[l] = c_feats;
-         a.n_filtered[l] = c_filt;
-         a.n_rejected[l] = c_rej;
-      }
-      __syncthreads();
+      collapse_one_locus<kCollapseBigThreads>(a, l, (int)npl, b.key + o, b.idx + o, b.span_l + o, b.span_r + o, b.skip + o, red, sh);
    }
 }
 

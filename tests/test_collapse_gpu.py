@@ -67,7 +67,8 @@ def test_device_collapse_filter_equality_and_rejects(ctx):
 
 def test_device_collapse_random_stress(ctx, oracle):
     """Random clusters: many duplicates, fractional masses (sums whose float / int truncation depends on the order),
-    equal (left, right) ends with different blocks, single reads, spliced mates, up to 4000 pairs in a locus."""
+    equal (left, right) ends with different blocks, single reads, spliced mates, up to 4000 pairs in a locus (bigger
+    ones: test_device_collapse_big_loci)."""
     from strawberry_amd import exonbin as eb
     rng = np.random.default_rng(123)
     for trial in range(4):
@@ -106,12 +107,41 @@ def test_device_collapse_random_stress(ctx, oracle):
         XU.check_collapse_against_oracle(oracle, n_loci, args[1], nh, args[3], args[4], g[0], g[1], g[2])
 
 
+def test_device_collapse_big_loci(ctx, oracle):
+    """Loci of more than 4096 pairs (the LDS sort's limit) take the same steps with their arrays in global memory
+    (collapse_big_kernel): 4097 (just over), 20 000 and 70 000 pairs next to small loci, duplicates, NH masses whose sums
+    depend on the order, single reads; identical to the host form, and the smaller big locus against the oracle."""
+    from strawberry_amd import exonbin as eb
+    rng = np.random.default_rng(321)
+    sizes = [300, 4097, 50, 20000, 0, 70000, 700]
+    loc, nh, left, right = [], [], [], []
+    for l, n in enumerate(sizes):
+        base = 1000000 * (l + 1)
+        starts = rng.integers(base, base + max(400, n // 8), n)      # ~8 pairs per start: many duplicates
+        for k in range(n):
+            s0 = int(starts[k])
+            lb = [(s0, s0 + 74)]
+            if rng.random() < 0.2:
+                cut = int(rng.integers(10, 60))
+                lb = [(s0, s0 + cut - 1), (s0 + cut + 300, s0 + 300 + 74)]
+            rb = [] if rng.random() < 0.1 else [(lb[-1][1] + 1 + int(rng.choice([120, 150])), lb[-1][1] + 75 + int(rng.choice([120, 150])))]
+            if rb and rb[0][1] - rb[0][0] != 74:
+                rb = [(rb[0][0], rb[0][0] + 74)]
+            loc.append(l), nh.append(int(rng.choice([1, 2, 3]))), left.append(lb), right.append(rb)
+    perm = rng.permutation(len(loc))
+    args = (len(sizes), [loc[i] for i in perm], [1.0 / nh[i] for i in perm], [left[i] for i in perm], [right[i] for i in perm])
+    g, r = eb.collapse_pairs(*args, device=ctx), eb.collapse_pairs(*args)
+    same(g[0], r[0], g[1], r[1], g[2], r[2])
+    assert r[0].n_hits < len(loc) * 0.8
+    # the oracle on everything but the largest locus (it is plain C, but the Python around it is per pair)
+    keep = [i for i in perm if loc[i] != 5]
+    sub = (len(sizes), [loc[i] for i in keep], [1.0 / nh[i] for i in keep], [left[i] for i in keep], [right[i] for i in keep])
+    g2 = eb.collapse_pairs(*sub, device=ctx)
+    XU.check_collapse_against_oracle(oracle, len(sizes), sub[1], [nh[i] for i in keep], sub[3], sub[4], g2[0], g2[1], g2[2])
+
+
 def test_device_collapse_declines_what_it_does_not_cover(ctx):
     from strawberry_amd import _lib, exonbin as eb
-    n = 4097
-    left = [[(1000 + k, 1074 + k)] for k in range(n)]
-    with pytest.raises(_lib.SbgpuError, match="4096"):
-        eb.collapse_pairs(1, [0] * n, [1.0] * n, left, [[] for _ in range(n)], device=ctx)
     long_mate = [[(1000 + 100 * k, 1040 + 100 * k) for k in range(13)]]      # 25 features
     with pytest.raises(_lib.SbgpuError, match="24 features"):
         eb.collapse_pairs(1, [0], [1.0], long_mate, [[]], device=ctx)
