@@ -508,7 +508,8 @@ int sbgpu_pair_mates_host(int64_t n_loci, const sbgpu_reads_t *reads, const int6
 /* Device form (csrc/matepair_device.h): `d_reads` device arrays, locus_read_off host; one workgroup per cluster sorts
  * its records by read id in LDS, walks every read id's records in arrival order, ranks the completed pairs by
  * completion and writes the pairs where sbgpu_collapse_pairs_device reads them -- nothing but per-cluster counts
- * comes back.  Clusters of up to 8192 records, up to 8 open mates per read id; else SBGPU_EUNSUPPORTED.        */
+ * comes back.  A cluster of more than 8192 records takes the same steps with the sort's arrays in global memory.
+ * Clusters of up to 2^24 records, up to 8 open mates per read id; else SBGPU_EUNSUPPORTED.                           */
 int sbgpu_pair_mates_device(sbgpu_ctx_t *ctx, int64_t n_loci, const sbgpu_reads_t *d_reads, const int64_t *locus_read_off,
                             void *stream, sbgpu_matepairs_t **out);
 void sbgpu_matepairs_destroy(sbgpu_matepairs_t *m);

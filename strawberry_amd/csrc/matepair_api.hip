@@ -163,11 +163,28 @@ int sbgpu_pair_mates_device(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t 
    if (nr < 0 || locus_read_off[0] != 0 || locus_read_off[n_loci] != nr) return api_fail(SBGPU_EINVAL, "sbgpu_pair_mates_device: locus_read_off does not cover the reads");
    if (nr && (!dr->read_id || !dr->block_off || !dr->block_left || !dr->block_right || !dr->partner_pos || !dr->flags || !dr->nh))
       return api_fail(SBGPU_EINVAL, "sbgpu_pair_mates_device: null device pointer");
+   // clusters the LDS sort does not hold (more than 8192 records) get a workgroup of their own with the sort's arrays in
+   // global scratch (matepair_big_kernel), the biggest first
+   std::vector<int32_t> big_loci;
+   std::vector<int64_t> big_off(1, 0);
    for (int64_t l = 0; l < n_loci; ++l) {
       if (locus_read_off[l + 1] < locus_read_off[l]) return api_fail(SBGPU_EINVAL, "sbgpu_pair_mates_device: locus_read_off must ascend");
-      if (locus_read_off[l + 1] - locus_read_off[l] > sb::kMateMaxReads)
-         return api_fail(SBGPU_EUNSUPPORTED, "sbgpu_pair_mates_device: not covered by the device form: a cluster has more than 8192 records; use sbgpu_pair_mates_host");
+      const int64_t n = locus_read_off[l + 1] - locus_read_off[l];
+      if (n <= sb::kMateMaxReads) continue;
+      if (n > (int64_t)1 << 24)
+         return api_fail(SBGPU_EUNSUPPORTED, "sbgpu_pair_mates_device: not covered by the device form: a cluster has more than 2^24 records; use sbgpu_pair_mates_host");
+      big_loci.push_back((int32_t)l);
    }
+   std::sort(big_loci.begin(), big_loci.end(), [&](int32_t x, int32_t y) {
+      const int64_t nx = locus_read_off[x + 1] - locus_read_off[x], ny = locus_read_off[y + 1] - locus_read_off[y];
+      return nx != ny ? nx > ny : x < y;
+   });
+   for (int32_t l : big_loci) {
+      int64_t n2 = 1;
+      while (n2 < locus_read_off[l + 1] - locus_read_off[l]) n2 <<= 1;
+      big_off.push_back(big_off.back() + n2);
+   }
+   const size_t n_big = big_loci.size(), big_elems = (size_t)big_off.back();
    hipStream_t s = (hipStream_t)stream;
    sbgpu_matepairs *M = new (std::nothrow) sbgpu_matepairs();
    if (!M) return api_fail(SBGPU_ENOMEM, "sbgpu_pair_mates_device: out of host memory");
@@ -206,6 +223,12 @@ int sbgpu_pair_mates_device(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t 
    const size_t o_poff = off; off += up256(nl1 * 8);
    const size_t o_lbase = off; off += up256(nl1 * 8);
    const size_t o_rbase = off; off += up256(nl1 * 8);
+   const size_t o_bloci = off; off += up256((n_big + 1) * 4);
+   const size_t o_boff = off; off += up256((n_big + 1) * 8);
+   const size_t o_bkey = off; off += up256((big_elems + 1) * 8);
+   const size_t o_bidx = off; off += up256((big_elems + 1) * 4);
+   const size_t o_bcl = off; off += up256((big_elems + 1) * 4);
+   const size_t o_bcr = off; off += up256((big_elems + 1) * 4);
    SB_TRY(hipMalloc(&w, off));
    SB_TRY(hipMemsetAsync(w + o_flag, 0, 256, s));
    SB_TRY(hipMemcpyAsync(w + o_roff, locus_read_off, nl1 * 8, hipMemcpyHostToDevice, s));
@@ -226,6 +249,20 @@ int sbgpu_pair_mates_device(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t 
    a.n_lfeat = (int32_t *)(w + o_cnt[5]), a.n_rfeat = (int32_t *)(w + o_cnt[6]);
    a.flags_out = (int32_t *)(w + o_flag);
    const unsigned grid = (unsigned)std::min<int64_t>(n_loci, (int64_t)sb::ctx_cu_count(c) * 4);
+   sb::MateBigArgs b = {};
+   if (n_big) { // first: they are the long ones
+      SB_TRY(hipMemcpyAsync(w + o_bloci, big_loci.data(), n_big * 4, hipMemcpyHostToDevice, s));
+      SB_TRY(hipMemcpyAsync(w + o_boff, big_off.data(), (n_big + 1) * 8, hipMemcpyHostToDevice, s));
+      b.n_big = (int32_t)n_big;
+      b.loci = (const int32_t *)(w + o_bloci);
+      b.big_off = (const int64_t *)(w + o_boff);
+      b.key = (unsigned long long *)(w + o_bkey);
+      b.idx = (int *)(w + o_bidx);
+      b.cl = (int *)(w + o_bcl);
+      b.cr = (int *)(w + o_bcr);
+      hipLaunchKernelGGL(sb::matepair_big_kernel, dim3((unsigned)std::min<size_t>(n_big, (size_t)sb::ctx_cu_count(c) * 2)), dim3(sb::kMateBigThreads), 0, s, a, b);
+      SB_TRY(hipGetLastError());
+   }
    hipLaunchKernelGGL(sb::matepair_locus_kernel, dim3(grid), dim3(sb::kMateThreads), 0, s, a);
    SB_TRY(hipGetLastError());
    std::vector<int32_t> cnt[7];
@@ -238,7 +275,6 @@ int sbgpu_pair_mates_device(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t 
    SB_TRY(hipStreamSynchronize(s));
    if (flags) {
       std::string why = "sbgpu_pair_mates_device: not covered by the device form:";
-      if (flags & sb::kMateTooMany) why += " a cluster has more than 8192 records;";
       if (flags & sb::kMateOpenOverflow) why += " more than 8 mates of one read id wait at a time;";
       return bail(SBGPU_EUNSUPPORTED, why + " use sbgpu_pair_mates_host");
    }
@@ -287,6 +323,10 @@ int sbgpu_pair_mates_device(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t 
    a.left_code = M->d_left_code, a.right_code = M->d_right_code;
    a.left_left = M->d_left_left, a.left_right = M->d_left_right;
    a.right_left = M->d_right_left, a.right_right = M->d_right_right;
+   if (n_big) {
+      hipLaunchKernelGGL(sb::matepair_big_fill_kernel, dim3((unsigned)std::min<size_t>(n_big, (size_t)sb::ctx_cu_count(c) * 2)), dim3(sb::kMateBigThreads), 0, s, a, b);
+      SB_TRY(hipGetLastError());
+   }
    hipLaunchKernelGGL(sb::matepair_fill_kernel, dim3(grid), dim3(sb::kMateThreads), 0, s, a);
    SB_TRY(hipGetLastError());
    SB_TRY(hipStreamSynchronize(s)); // the scratch goes away

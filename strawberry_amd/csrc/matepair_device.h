@@ -57,11 +57,12 @@ __device__ __forceinline__ bool mate_key_less(unsigned long long ka, int ia, uns
    return ka != kb ? ka < kb : ia < ib;
 }
 
-// exclusive prefix sums of v[0 .. n) in LDS, in place, by the whole workgroup (n <= kMateMaxReads)
-__device__ inline void block_exclusive_scan(int *v, int n, int *partial /*[kMateThreads]*/)
+// exclusive prefix sums of v[0 .. n), in place, by the whole workgroup of THREADS threads
+template <int THREADS>
+__device__ inline void block_exclusive_scan(int *v, int n, int *partial /*[THREADS]*/)
 {
    const int tid = threadIdx.x;
-   const int chunk = (n + kMateThreads - 1) / kMateThreads;
+   const int chunk = (n + THREADS - 1) / THREADS;
    const int lo = min(n, tid * chunk), hi = min(n, lo + chunk);
    int s = 0;
    for (int i = lo; i < hi; ++i) s += v[i];
@@ -69,7 +70,7 @@ __device__ inline void block_exclusive_scan(int *v, int n, int *partial /*[kMate
    __syncthreads();
    if (tid == 0) {
       int run = 0;
-      for (int t = 0; t < kMateThreads; ++t) {
+      for (int t = 0; t < THREADS; ++t) {
          const int x = partial[t];
          partial[t] = run;
          run += x;
@@ -85,6 +86,136 @@ __device__ inline void block_exclusive_scan(int *v, int n, int *partial /*[kMate
    __syncthreads();
 }
 
+// One cluster by one workgroup of THREADS threads.  key / idx [pow2ceil(n)]: LDS for clusters of up to kMateMaxReads
+// records, global scratch for bigger ones (matepair_big_kernel) -- the same steps either way.
+template <int THREADS>
+__device__ __forceinline__ void matepair_one_locus(const MateArgs &a, int64_t l, int n, unsigned long long *key, int *idx, int *partial, int *counts)
+{
+   const int tid = threadIdx.x;
+   const int64_t q0 = a.locus_read_off[l];
+   int npad = 1;
+   while (npad < n) npad <<= 1;
+   for (int i = tid; i < npad; i += THREADS) {
+      key[i] = i < n ? a.read_id[q0 + i] : ~0ull;
+      idx[i] = i < n ? i : 0x7fffffff;
+   }
+   __syncthreads();
+   // ---- bitonic sort on (read id, arrival index)
+   for (int k = 2; k <= npad; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+         for (int i = tid; i < npad; i += THREADS) {
+            const int p = i ^ j;
+            if (p > i) {
+               const bool up = (i & k) == 0;
+               const unsigned long long ki = key[i], kp = key[p];
+               const int ii = idx[i], ip = idx[p];
+               const bool swap = up ? mate_key_less(kp, ip, ki, ii) : mate_key_less(ki, ii, kp, ip);
+               if (swap) {
+                  key[i] = kp, key[p] = ki;
+                  idx[i] = ip, idx[p] = ii;
+               }
+            }
+         }
+         __syncthreads();
+      }
+   // ---- every read id's records, in arrival order, with the reference's open-mate list (alignments.cpp:535-641)
+   int my_refused = 0, my_orphan = 0, my_single = 0, my_complete = 0, my_bad = 0;
+   for (int s = tid; s < n; s += THREADS) {
+      if (s > 0 && key[s - 1] == key[s]) continue; // not the first of its read id
+      int open[kMateOpenMax];
+      int n_open = 0;
+      for (int t = s; t < n && key[t] == key[s]; ++t) {
+         const int i = idx[t];
+         const int64_t r = q0 + i;
+         const int64_t b0 = a.block_off[r], b1 = a.block_off[r + 1];
+         const uint32_t left = b1 > b0 ? a.block_left[b0] : 0u, right = b1 > b0 ? a.block_right[b1 - 1] : 0u;
+         const uint32_t ppos = a.partner_pos[r];
+         const uint8_t fl = a.flags[r];
+         if (fl & 16u) { // not this cluster's record (sbgpu_assign_reads_*): never offered to addOpenHit
+            a.fate[r] = kRecRefused;
+            continue;
+         }
+         if (b1 <= b0 || (int64_t)right - (int64_t)left > kMaxFragSpanDev) { // :512-518
+            a.fate[r] = kRecRefused;
+            ++my_refused;
+            continue;
+         }
+         if (ppos == 0 || (fl & 2u)) { // a single read (:535-545)
+            a.fate[r] = (fl & 1u) ? kRecSingleRight : kRecSingleLeft;
+            a.partner[r] = -1;
+            ++my_single;
+            continue;
+         }
+         const int strand = (fl >> 2) & 3;
+         int hit = -1;
+         for (int o = 0; o < n_open && hit < 0; ++o) { // :590-623, oldest first
+            const int64_t w = q0 + open[o];
+            const int wstrand = (a.flags[w] >> 2) & 3;
+            const bool strand_agree = wstrand == strand || strand == 0 || wstrand == 0;
+            if (a.block_left[a.block_off[w]] == ppos && strand_agree && a.partner_pos[w] == left) hit = o;
+         }
+         if (hit >= 0) {
+            const int64_t w = q0 + open[hit];
+            // the waiting mate is the left one when its partner lies behind it (:559-585)
+            const bool waiting_is_left = a.partner_pos[w] > a.block_left[a.block_off[w]];
+            a.fate[r] = waiting_is_left ? kRecCompletesAsRight : kRecCompletesAsLeft;
+            a.partner[r] = open[hit];
+            a.fate[w] = kRecFirst;
+            for (int o = hit; o + 1 < n_open; ++o) open[o] = open[o + 1];
+            --n_open;
+            ++my_complete;
+         } else if (ppos == left) { // :585, :640: partner and read start at the same position
+            a.fate[r] = kRecRefused;
+            ++my_refused;
+         } else if (n_open < kMateOpenMax) {
+            a.fate[r] = kRecOrphan; // until its partner comes
+            open[n_open++] = i;
+         } else {
+            a.fate[r] = kRecOrphan;
+            my_bad |= kMateOpenOverflow;
+         }
+      }
+      my_orphan += n_open;
+   }
+   if (my_refused) atomicAdd(&counts[0], my_refused);
+   if (my_orphan) atomicAdd(&counts[1], my_orphan);
+   if (my_single) atomicAdd(&counts[2], my_single);
+   if (my_complete) atomicAdd(&counts[3], my_complete);
+   if (my_bad) atomicOr(a.flags_out, my_bad);
+   __syncthreads();
+   // ---- ranks in completion order: prefix count of the completing records over the arrival order
+   int *flag = idx; // (the sort's indices are no longer needed)
+   for (int i = tid; i < n; i += THREADS) flag[i] = a.fate[q0 + i] >= kRecCompletesAsRight ? 1 : 0;
+   __syncthreads();
+   block_exclusive_scan<THREADS>(flag, n, partial);
+   int lf = 0, rf = 0;
+   for (int i = tid; i < n; i += THREADS) {
+      const int64_t r = q0 + i;
+      const int8_t f = a.fate[r];
+      if (f < kRecCompletesAsRight) continue;
+      a.rank[r] = flag[i];
+      const int nb_me = (int)(a.block_off[r + 1] - a.block_off[r]);
+      const int nb_w = a.partner[r] >= 0 ? (int)(a.block_off[q0 + a.partner[r] + 1] - a.block_off[q0 + a.partner[r]]) : 0;
+      const bool me_right = f == kRecCompletesAsRight || f == kRecSingleRight;
+      const int nl = me_right ? nb_w : nb_me, nr = me_right ? nb_me : nb_w;
+      lf += nl ? 2 * nl - 1 : 0;
+      rf += nr ? 2 * nr - 1 : 0;
+   }
+   if (lf) atomicAdd(&counts[4], lf);
+   if (rf) atomicAdd(&counts[5], rf);
+   __syncthreads();
+   if (tid == 0) {
+      a.n_refused[l] = counts[0];
+      a.n_orphan[l] = counts[1];
+      a.n_single[l] = counts[2];
+      a.n_complete[l] = counts[3];
+      a.n_pairs[l] = counts[2] + counts[3];
+      a.n_lfeat[l] = counts[4];
+      a.n_rfeat[l] = counts[5];
+   }
+   __syncthreads();
+}
+
 __global__ __launch_bounds__(kMateThreads) void matepair_locus_kernel(MateArgs a)
 {
    __shared__ unsigned long long key[kMateMaxReads];
@@ -93,138 +224,35 @@ __global__ __launch_bounds__(kMateThreads) void matepair_locus_kernel(MateArgs a
    __shared__ int counts[8];
    const int tid = threadIdx.x;
    for (int64_t l = blockIdx.x; l < a.n_loci; l += gridDim.x) {
-      const int64_t q0 = a.locus_read_off[l];
-      const int n = (int)min<int64_t>(a.locus_read_off[l + 1] - q0, (int64_t)kMateMaxReads + 1);
+      const int64_t nl = a.locus_read_off[l + 1] - a.locus_read_off[l];
+      if (nl > kMateMaxReads) continue; // matepair_big_kernel's
       if (tid < 8) counts[tid] = 0;
-      if (n > kMateMaxReads) {
-         if (tid == 0) {
-            atomicOr(a.flags_out, (int)kMateTooMany);
-            a.n_pairs[l] = a.n_complete[l] = a.n_single[l] = a.n_refused[l] = a.n_orphan[l] = a.n_lfeat[l] = a.n_rfeat[l] = 0;
-         }
-         __syncthreads();
-         continue;
-      }
-      int npad = 1;
-      while (npad < n) npad <<= 1;
-      for (int i = tid; i < npad; i += kMateThreads) {
-         key[i] = i < n ? a.read_id[q0 + i] : ~0ull;
-         idx[i] = i < n ? i : 0x7fffffff;
-      }
       __syncthreads();
-      // ---- bitonic sort on (read id, arrival index)
-      for (int k = 2; k <= npad; k <<= 1)
-         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < npad; i += kMateThreads) {
-               const int p = i ^ j;
-               if (p > i) {
-                  const bool up = (i & k) == 0;
-                  const unsigned long long ki = key[i], kp = key[p];
-                  const int ii = idx[i], ip = idx[p];
-                  const bool swap = up ? mate_key_less(kp, ip, ki, ii) : mate_key_less(ki, ii, kp, ip);
-                  if (swap) {
-                     key[i] = kp, key[p] = ki;
-                     idx[i] = ip, idx[p] = ii;
-                  }
-               }
-            }
-            __syncthreads();
-         }
-      // ---- every read id's records, in arrival order, with the reference's open-mate list (alignments.cpp:535-641)
-      int my_refused = 0, my_orphan = 0, my_single = 0, my_complete = 0, my_bad = 0;
-      for (int s = tid; s < n; s += kMateThreads) {
-         if (s > 0 && key[s - 1] == key[s]) continue; // not the first of its read id
-         int open[kMateOpenMax];
-         int n_open = 0;
-         for (int t = s; t < n && key[t] == key[s]; ++t) {
-            const int i = idx[t];
-            const int64_t r = q0 + i;
-            const int64_t b0 = a.block_off[r], b1 = a.block_off[r + 1];
-            const uint32_t left = b1 > b0 ? a.block_left[b0] : 0u, right = b1 > b0 ? a.block_right[b1 - 1] : 0u;
-            const uint32_t ppos = a.partner_pos[r];
-            const uint8_t fl = a.flags[r];
-            if (fl & 16u) { // not this cluster's record (sbgpu_assign_reads_*): never offered to addOpenHit
-               a.fate[r] = kRecRefused;
-               continue;
-            }
-            if (b1 <= b0 || (int64_t)right - (int64_t)left > kMaxFragSpanDev) { // :512-518
-               a.fate[r] = kRecRefused;
-               ++my_refused;
-               continue;
-            }
-            if (ppos == 0 || (fl & 2u)) { // a single read (:535-545)
-               a.fate[r] = (fl & 1u) ? kRecSingleRight : kRecSingleLeft;
-               a.partner[r] = -1;
-               ++my_single;
-               continue;
-            }
-            const int strand = (fl >> 2) & 3;
-            int hit = -1;
-            for (int o = 0; o < n_open && hit < 0; ++o) { // :590-623, oldest first
-               const int64_t w = q0 + open[o];
-               const int wstrand = (a.flags[w] >> 2) & 3;
-               const bool strand_agree = wstrand == strand || strand == 0 || wstrand == 0;
-               if (a.block_left[a.block_off[w]] == ppos && strand_agree && a.partner_pos[w] == left) hit = o;
-            }
-            if (hit >= 0) {
-               const int64_t w = q0 + open[hit];
-               // the waiting mate is the left one when its partner lies behind it (:559-585)
-               const bool waiting_is_left = a.partner_pos[w] > a.block_left[a.block_off[w]];
-               a.fate[r] = waiting_is_left ? kRecCompletesAsRight : kRecCompletesAsLeft;
-               a.partner[r] = open[hit];
-               a.fate[w] = kRecFirst;
-               for (int o = hit; o + 1 < n_open; ++o) open[o] = open[o + 1];
-               --n_open;
-               ++my_complete;
-            } else if (ppos == left) { // :585, :640: partner and read start at the same position
-               a.fate[r] = kRecRefused;
-               ++my_refused;
-            } else if (n_open < kMateOpenMax) {
-               a.fate[r] = kRecOrphan; // until its partner comes
-               open[n_open++] = i;
-            } else {
-               a.fate[r] = kRecOrphan;
-               my_bad |= kMateOpenOverflow;
-            }
-         }
-         my_orphan += n_open;
-      }
-      if (my_refused) atomicAdd(&counts[0], my_refused);
-      if (my_orphan) atomicAdd(&counts[1], my_orphan);
-      if (my_single) atomicAdd(&counts[2], my_single);
-      if (my_complete) atomicAdd(&counts[3], my_complete);
-      if (my_bad) atomicOr(a.flags_out, my_bad);
+      matepair_one_locus<kMateThreads>(a, l, (int)nl, key, idx, partial, counts);
+   }
+}
+
+// Clusters of more than kMateMaxReads records (a highly expressed gene): the same steps with 1024 threads and the sort's
+// arrays in global scratch, one workgroup per such cluster.
+constexpr int kMateBigThreads = 1024;
+struct MateBigArgs {
+   int32_t n_big;
+   const int32_t *loci;     // [n_big]
+   const int64_t *big_off;  // [n_big + 1] first scratch element of each (pow2ceil of its records)
+   unsigned long long *key; // [big_off[n_big]]
+   int *idx, *cl, *cr;      // idx: the sort; cl / cr: the fill kernel's feature counts
+};
+
+__global__ __launch_bounds__(kMateBigThreads) void matepair_big_kernel(MateArgs a, MateBigArgs b)
+{
+   __shared__ int partial[kMateBigThreads];
+   __shared__ int counts[8];
+   const int tid = threadIdx.x;
+   for (int i = blockIdx.x; i < b.n_big; i += gridDim.x) {
+      const int64_t l = b.loci[i], o = b.big_off[i];
+      if (tid < 8) counts[tid] = 0;
       __syncthreads();
-      // ---- ranks in completion order: prefix count of the completing records over the arrival order
-      int *flag = idx; // (the sort's indices are no longer needed)
-      for (int i = tid; i < n; i += kMateThreads) flag[i] = a.fate[q0 + i] >= kRecCompletesAsRight ? 1 : 0;
-      __syncthreads();
-      block_exclusive_scan(flag, n, partial);
-      int lf = 0, rf = 0;
-      for (int i = tid; i < n; i += kMateThreads) {
-         const int64_t r = q0 + i;
-         const int8_t f = a.fate[r];
-         if (f < kRecCompletesAsRight) continue;
-         a.rank[r] = flag[i];
-         const int nb_me = (int)(a.block_off[r + 1] - a.block_off[r]);
-         const int nb_w = a.partner[r] >= 0 ? (int)(a.block_off[q0 + a.partner[r] + 1] - a.block_off[q0 + a.partner[r]]) : 0;
-         const bool me_right = f == kRecCompletesAsRight || f == kRecSingleRight;
-         const int nl = me_right ? nb_w : nb_me, nr = me_right ? nb_me : nb_w;
-         lf += nl ? 2 * nl - 1 : 0;
-         rf += nr ? 2 * nr - 1 : 0;
-      }
-      if (lf) atomicAdd(&counts[4], lf);
-      if (rf) atomicAdd(&counts[5], rf);
-      __syncthreads();
-      if (tid == 0) {
-         a.n_refused[l] = counts[0];
-         a.n_orphan[l] = counts[1];
-         a.n_single[l] = counts[2];
-         a.n_complete[l] = counts[3];
-         a.n_pairs[l] = counts[2] + counts[3];
-         a.n_lfeat[l] = counts[4];
-         a.n_rfeat[l] = counts[5];
-      }
-      __syncthreads();
+      matepair_one_locus<kMateBigThreads>(a, l, (int)(a.locus_read_off[l + 1] - a.locus_read_off[l]), b.key + o, b.idx + o, partial, counts);
    }
 }
 
@@ -246,54 +274,67 @@ __device__ __forceinline__ void write_mate(const MateArgs &a, int64_t r, uint8_t
    }
 }
 
+template <int THREADS>
+__device__ __forceinline__ void matepair_fill_one(const MateArgs &a, int64_t l, int *cl, int *cr, int *partial)
+{
+   const int tid = threadIdx.x;
+   const int64_t q0 = a.locus_read_off[l];
+   const int n = (int)(a.locus_read_off[l + 1] - q0);
+   const int64_t p0 = a.pair_off[l];
+   const int np = (int)(a.pair_off[l + 1] - p0);
+   if (np == 0) return;
+   for (int i = tid; i < n; i += THREADS) {
+      const int64_t r = q0 + i;
+      const int8_t f = a.fate[r];
+      if (f < kRecCompletesAsRight) continue;
+      const int k = a.rank[r];
+      const int nb_me = (int)(a.block_off[r + 1] - a.block_off[r]);
+      const int64_t w = a.partner[r] >= 0 ? q0 + a.partner[r] : -1;
+      const int nb_w = w >= 0 ? (int)(a.block_off[w + 1] - a.block_off[w]) : 0;
+      const bool me_right = f == kRecCompletesAsRight || f == kRecSingleRight;
+      const int nl = me_right ? nb_w : nb_me, nr = me_right ? nb_me : nb_w;
+      cl[k] = nl ? 2 * nl - 1 : 0;
+      cr[k] = nr ? 2 * nr - 1 : 0;
+   }
+   __syncthreads();
+   block_exclusive_scan<THREADS>(cl, np, partial);
+   block_exclusive_scan<THREADS>(cr, np, partial);
+   for (int i = tid; i < n; i += THREADS) {
+      const int64_t r = q0 + i;
+      const int8_t f = a.fate[r];
+      if (f < kRecCompletesAsRight) continue;
+      const int k = a.rank[r];
+      const int64_t w = a.partner[r] >= 0 ? q0 + a.partner[r] : -1;
+      const bool me_right = f == kRecCompletesAsRight || f == kRecSingleRight;
+      const int64_t rl = me_right ? w : r, rr = me_right ? r : w; // the left / right mate's record (-1: none)
+      const int64_t lo = a.lfeat_base[l] + cl[k], ro = a.rfeat_base[l] + cr[k];
+      a.left_off[p0 + k] = lo;
+      a.right_off[p0 + k] = ro;
+      if (rl >= 0) write_mate(a, rl, a.left_code, a.left_left, a.left_right, lo);
+      if (rr >= 0) write_mate(a, rr, a.right_code, a.right_left, a.right_right, ro);
+      // the reads' masses (src/read.cpp:49-53, 734-741)
+      double m = 0.0;
+      if (w >= 0) m = 0.5 / (double)a.nh[rl] + 0.5 / (double)a.nh[rr];
+      else m = 1.0 / (double)a.nh[r];
+      a.pair_mass[p0 + k] = m;
+   }
+   __syncthreads();
+}
+
 __global__ __launch_bounds__(kMateThreads) void matepair_fill_kernel(MateArgs a)
 {
    __shared__ int cl[kMateMaxReads], cr[kMateMaxReads]; // per pair (rank order): feature counts, then offsets
    __shared__ int partial[kMateThreads];
-   const int tid = threadIdx.x;
    for (int64_t l = blockIdx.x; l < a.n_loci; l += gridDim.x) {
-      const int64_t q0 = a.locus_read_off[l];
-      const int n = (int)(a.locus_read_off[l + 1] - q0);
-      const int64_t p0 = a.pair_off[l];
-      const int np = (int)(a.pair_off[l + 1] - p0);
-      if (np == 0) continue;
-      for (int i = tid; i < n; i += kMateThreads) {
-         const int64_t r = q0 + i;
-         const int8_t f = a.fate[r];
-         if (f < kRecCompletesAsRight) continue;
-         const int k = a.rank[r];
-         const int nb_me = (int)(a.block_off[r + 1] - a.block_off[r]);
-         const int64_t w = a.partner[r] >= 0 ? q0 + a.partner[r] : -1;
-         const int nb_w = w >= 0 ? (int)(a.block_off[w + 1] - a.block_off[w]) : 0;
-         const bool me_right = f == kRecCompletesAsRight || f == kRecSingleRight;
-         const int nl = me_right ? nb_w : nb_me, nr = me_right ? nb_me : nb_w;
-         cl[k] = nl ? 2 * nl - 1 : 0;
-         cr[k] = nr ? 2 * nr - 1 : 0;
-      }
-      __syncthreads();
-      block_exclusive_scan(cl, np, partial);
-      block_exclusive_scan(cr, np, partial);
-      for (int i = tid; i < n; i += kMateThreads) {
-         const int64_t r = q0 + i;
-         const int8_t f = a.fate[r];
-         if (f < kRecCompletesAsRight) continue;
-         const int k = a.rank[r];
-         const int64_t w = a.partner[r] >= 0 ? q0 + a.partner[r] : -1;
-         const bool me_right = f == kRecCompletesAsRight || f == kRecSingleRight;
-         const int64_t rl = me_right ? w : r, rr = me_right ? r : w; // the left / right mate's record (-1: none)
-         const int64_t lo = a.lfeat_base[l] + cl[k], ro = a.rfeat_base[l] + cr[k];
-         a.left_off[p0 + k] = lo;
-         a.right_off[p0 + k] = ro;
-         if (rl >= 0) write_mate(a, rl, a.left_code, a.left_left, a.left_right, lo);
-         if (rr >= 0) write_mate(a, rr, a.right_code, a.right_left, a.right_right, ro);
-         // the reads' masses (src/read.cpp:49-53, 734-741)
-         double m = 0.0;
-         if (w >= 0) m = 0.5 / (double)a.nh[rl] + 0.5 / (double)a.nh[rr];
-         else m = 1.0 / (double)a.nh[r];
-         a.pair_mass[p0 + k] = m;
-      }
-      __syncthreads();
+      if (a.locus_read_off[l + 1] - a.locus_read_off[l] > kMateMaxReads) continue; // matepair_big_fill_kernel's
+      matepair_fill_one<kMateThreads>(a, l, cl, cr, partial);
    }
+}
+
+__global__ __launch_bounds__(kMateBigThreads) void matepair_big_fill_kernel(MateArgs a, MateBigArgs b)
+{
+   __shared__ int partial[kMateBigThreads];
+   for (int i = blockIdx.x; i < b.n_big; i += gridDim.x) matepair_fill_one<kMateBigThreads>(a, b.loci[i], b.cl + b.big_off[i], b.cr + b.big_off[i], partial);
 }
 
 // ------------------------------------------------------------------ cluster streaming (sbgpu_assign_reads_device)

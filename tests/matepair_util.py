@@ -12,7 +12,7 @@ def random_cluster(rng, n_frag, base=100000, exotic=True):
     rid = int(rng.integers(1, 1 << 40))
     # every fragment starts at a position of its own: no two DIFFERENT hits share (left end, right end), whose order the
     # reference leaves to std::sort (PCR duplicates do share theirs, and are equal)
-    starts = rng.permutation(4000)[:2 * n_frag] + base
+    starts = rng.permutation(max(4000, 2 * n_frag))[:2 * n_frag] + base
     for f in range(n_frag):
         rid += int(rng.integers(1, 1000))
         s = int(starts[2 * f])

@@ -62,12 +62,35 @@ def test_device_pairing_equals_oracle_random_clusters(ctx, oracle):
                 np.testing.assert_array_equal(x, y)
 
 
-def test_device_pairing_declines_oversize_cluster(ctx):
-    from strawberry_amd import _lib, exonbin as eb
+def test_device_pairing_big_clusters(ctx, oracle):
+    """Clusters of more than 8192 records (the LDS sort's limit) take the same steps with 1024 threads and the sort's
+    arrays in global memory (matepair_big_kernel): 8193 single reads (just over), and random clusters of 6 000 and
+    25 000 fragments (multi-mapped reads, orphans, refused records) next to small ones: identical to the host form; the
+    6 000-fragment cluster (> 8192 records) also against the oracle."""
+    from strawberry_amd import exonbin as eb
     n = 8193
     reads = eb.Reads([0] * n, list(range(1, n + 1)), [[(1000 + k, 1074 + k)] for k in range(n)], [0] * n, [0] * n, [1] * n)
-    with pytest.raises(_lib.SbgpuError, match="8192"):
-        eb.pair_mates(1, reads, device=ctx)
+    got, host = eb.pair_mates(1, reads, device=ctx), eb.pair_mates(1, reads)
+    assert got["info"]["pairs"] == n and got["info"]["single"] == n
+    np.testing.assert_array_equal(got["left_off"], host["left_off"])
+    rng = np.random.default_rng(77)
+    sizes = [150, 6000, 0, 25000, 40]
+    clusters = [MU.random_cluster(rng, k, base=400000 * (l + 1)) for l, k in enumerate(sizes)]
+    assert len(clusters[1]) > 8192 and len(clusters[3]) > 8192
+    loc = [l for l, c in enumerate(clusters) for _ in c]
+    reads = eb.Reads(loc, *MU.arrays([r for c in clusters for r in c]))
+    got, host = eb.pair_mates(len(sizes), reads, device=ctx), eb.pair_mates(len(sizes), reads)
+    assert got["info"]["on_device"]
+    for k in ("pair_off", "mass", "left_off", "right_off"):
+        np.testing.assert_array_equal(got[k], host[k], err_msg=k)
+    for side in ("left", "right"):
+        for x, y in zip(got[side], host[side]):
+            np.testing.assert_array_equal(x, y)
+    assert {k: got["info"][k] for k in ("complete", "single", "refused", "orphan")} == {k: host["info"][k] for k in ("complete", "single", "refused", "orphan")}
+    sub = clusters[:3]
+    loc = [l for l, c in enumerate(sub) for _ in c]
+    got3 = eb.pair_mates(3, eb.Reads(loc, *MU.arrays([r for c in sub for r in c])), device=ctx)
+    check_against_oracle(oracle, sub, got3)
 
 
 @pytest.mark.parametrize("which", ["E2E", "E2E_MASS", "E2E_MINUS", "E2E_CHROMS"])
