@@ -124,7 +124,8 @@ hipError_t ctx_scratch(sbgpu_ctx_t *ctx, int slot, size_t bytes, char **out);
 // Device allocations that change hands (a handle's arenas, a plan's arena): a hipMalloc / hipFree pair per call costs a
 // few hundred microseconds and the free waits for the device, so blocks handed back are kept -- process-wide, per
 // device, at most 8 blocks and 4 GB -- and a request is served from them when one fits without wasting more than half.
-// dev_give does NOT wait for work that still uses the block: give it back only after that work was waited for.
+// dev_give waits for the device first, as hipFree does (a handle may be destroyed while a kernel on the caller's stream
+// still reads its arena).
 hipError_t dev_take(size_t bytes, char **out, size_t *capacity);
 void dev_give(char *block, size_t capacity);
 // pinned host scratch of the same kind (slot 0..3): the targets of small device-to-host copies that must not block the host

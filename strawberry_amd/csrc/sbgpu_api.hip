@@ -206,6 +206,10 @@ hipError_t dev_take(size_t bytes, char **out, size_t *capacity)
 void dev_give(char *block, size_t capacity)
 {
    if (!block) return;
+   // hipFree waits for the device before it lets memory go, and callers have relied on that (a handle destroyed while a
+   // kernel on the CALLER's stream still reads its arena): a block that goes back to the pool waits the same way.  On an
+   // idle device -- every call site has synchronised its own stream already -- this costs ~10 us.
+   (void)hipDeviceSynchronize();
    int device = 0;
    if (hipGetDevice(&device) == hipSuccess) {
       DevPool &pool = dev_pool();
@@ -600,15 +604,10 @@ int sbgpu_plan_destroy(sbgpu_plan_t *p)
 {
    if (!p) return SBGPU_OK;
    if (p->ctx) (void)hipSetDevice(p->ctx->device);
-   // every device array of the plan lives in this one allocation; it goes back to the pool, which does not wait for
-   // the device as hipFree would: a run that is still in the context's streams is waited for here
-   if (p->d_arena && p->ctx) {
-      (void)hipStreamSynchronize(p->ctx->stream);
-      for (hipStream_t a : p->ctx->aux)
-         if (a) (void)hipStreamSynchronize(a);
-   }
-   if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
+   // every device array of the plan lives in this one allocation; it goes back to the pool (dev_give waits for the device,
+   // as hipFree did: a run on the caller's stream may still be reading it)
    sb::dev_give(p->d_arena, p->arena_cap);
+   if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
    delete p;
    return SBGPU_OK;
 }
