@@ -66,7 +66,7 @@ def make_batch(name, rank):
     raise SystemExit("unknown workload " + name)
 
 
-def pmc_traffic(workload, kind):
+def pmc_traffic(workload, kind, kernel_key=None):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
     very command (tools/profile_round.sh: separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` runs,
     summarised in profiles/rNN_<workload>_pmc_summary.json).  A counter pass cannot run inside the
@@ -75,8 +75,8 @@ def pmc_traffic(workload, kind):
     tallies 128-B requests at 64 B, so it is doubled before it is compared with a byte count."""
     import glob
     import json
-    key = ["em_fused_kernel<0, 1,", "em_fused_kernel<0, 2,", "em_fused_kernel<0, 4,", "em_fused_kernel<4, 2,",
-           "em_fused_kernel<4, 12,", "em_wide_kernel"][kind]
+    key = kernel_key or ["em_fused_kernel<0, 1,", "em_fused_kernel<0, 2,", "em_fused_kernel<0, 4,", "em_fused_kernel<4, 2,",
+                         "em_fused_kernel<4, 12,", "em_wide_kernel"][kind]
     here = os.path.dirname(os.path.abspath(__file__))
     files = sorted(glob.glob(os.path.join(here, "profiles", "r*_%s_pmc_summary.json" % workload)))
     if not files:
@@ -297,9 +297,10 @@ def chain_leg(args, ctx, dev, rank, world, sdist, torch, strong=False, with_cpu=
     roof = None
     if dom:
         ach = alg[dom] / (stage[dom] * 1e-3) / 1e9
+        traffic, tnote = pmc_traffic("c3chain", 0, kernel_key="sb::" + dom)
         roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": None, "kernel_ms": stage[dom], "algorithmic_bytes": int(alg[dom]),
-                "note": "kernel time from HIP events on the kernels' stream (sbgpu_last_stage_ms); PMC traffic of this kernel: profiles/r03_c3chain_pmc_summary.json"}
+                "traffic": traffic, "traffic_note": tnote, "kernel_ms": stage[dom], "algorithmic_bytes": int(alg[dom]),
+                "note": "kernel time from HIP events on the kernels' stream (sbgpu_last_stage_ms)"}
     out = {
         "workload": WORKLOADS["c3-chain"], "scaling": "strong" if strong else "weak",
         "loci": int(counts[0]), "fragments": int(counts[1]), "unique_hits": int(counts[2]), "features_per_hit": feats,
