@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -161,7 +162,13 @@ int sbgpu_collapse_pairs_device(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_pair
       hipLaunchKernelGGL(sb::collapse_big_kernel, dim3((unsigned)std::min<size_t>(n_big, (size_t)sb::ctx_cu_count(c) * 2)), dim3(sb::kCollapseBigThreads), 0, s, a, b);
       SB_TRY(hipGetLastError());
    }
-   hipLaunchKernelGGL(sb::collapse_locus_kernel, dim3(grid), dim3(sb::kCollapseThreads), 0, s, a);
+   static const bool one_class = std::getenv("SBGPU_FRONT_ONE_CLASS") && std::atoi(std::getenv("SBGPU_FRONT_ONE_CLASS")) != 0; // (A/B)
+   if (one_class) {
+      hipLaunchKernelGGL((sb::collapse_locus_kernel<sb::kCollapseMax, -1>), dim3(grid), dim3(sb::kCollapseThreads), 0, s, a);
+   } else {
+      hipLaunchKernelGGL((sb::collapse_locus_kernel<sb::kCollapseMax, sb::kCollapseSmall>), dim3(grid), dim3(sb::kCollapseThreads), 0, s, a);
+      hipLaunchKernelGGL((sb::collapse_locus_kernel<sb::kCollapseSmall, -1>), dim3((unsigned)std::min<int64_t>(n_loci, (int64_t)sb::ctx_cu_count(c) * 32)), dim3(sb::kCollapseThreads), 0, s, a);
+   }
    SB_TRY(hipGetLastError());
    std::vector<int32_t> nh((size_t)n_loci), nf((size_t)n_loci), nfi((size_t)n_loci), nr((size_t)n_loci);
    int32_t flags = 0;

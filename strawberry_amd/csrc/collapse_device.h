@@ -322,19 +322,23 @@ __device__ __forceinline__ void collapse_one_locus(const CollapseArgs &a, int64_
    __syncthreads();
 }
 
+// CAP: the LDS arrays' capacity.  Two instantiations: loci of up to kCollapseSmall pairs (23 KB of LDS: seven workgroups
+// per CU; with the full-size arrays a CU holds one) and loci of up to kCollapseMax; each serves the loci in (LO, CAP].
+constexpr int kCollapseSmall = 1024;
+template <int CAP, int LO>
 __global__ __launch_bounds__(kCollapseThreads) void collapse_locus_kernel(CollapseArgs a)
 {
-   __shared__ unsigned long long key[kCollapseMax]; // sort keys; afterwards the pairs' masses (as doubles)
-   __shared__ int idx[kCollapseMax];
-   __shared__ int span_l[kCollapseMax], span_r[kCollapseMax]; // by input index; -1: no such mate
-   __shared__ unsigned char skip[kCollapseMax];               // by sorted position
+   __shared__ unsigned long long key[CAP]; // sort keys; afterwards the pairs' masses (as doubles)
+   __shared__ int idx[CAP];
+   __shared__ int span_l[CAP], span_r[CAP]; // by input index; -1: no such mate
+   __shared__ unsigned char skip[CAP];      // by sorted position
    __shared__ double red[kCollapseThreads];
    __shared__ CollapseShared sh;
    const int tid = threadIdx.x;
    for (int64_t l = blockIdx.x; l < a.n_loci; l += gridDim.x) {
       const int64_t q0 = a.locus_pair_off[l];
       const int64_t npl = a.locus_pair_off[l + 1] - q0;
-      if (npl > kCollapseMax) continue; // collapse_big_kernel's
+      if (npl > CAP || npl <= LO) continue; // another instantiation's, or collapse_big_kernel's
       if (tid == 0) {
          a.cluster_mass[l] = 0.0;
          a.n_hits[l] = a.n_feats[l] = a.n_filtered[l] = a.n_rejected[l] = 0;

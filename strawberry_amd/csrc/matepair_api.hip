@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -249,6 +250,8 @@ int sbgpu_pair_mates_device(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t 
    a.n_lfeat = (int32_t *)(w + o_cnt[5]), a.n_rfeat = (int32_t *)(w + o_cnt[6]);
    a.flags_out = (int32_t *)(w + o_flag);
    const unsigned grid = (unsigned)std::min<int64_t>(n_loci, (int64_t)sb::ctx_cu_count(c) * 4);
+   const unsigned grid_small = (unsigned)std::min<int64_t>(n_loci, (int64_t)sb::ctx_cu_count(c) * 32);
+   const unsigned grid_mid = (unsigned)std::min<int64_t>(n_loci, (int64_t)sb::ctx_cu_count(c) * 12);
    sb::MateBigArgs b = {};
    if (n_big) { // first: they are the long ones
       SB_TRY(hipMemcpyAsync(w + o_bloci, big_loci.data(), n_big * 4, hipMemcpyHostToDevice, s));
@@ -263,7 +266,14 @@ int sbgpu_pair_mates_device(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t 
       hipLaunchKernelGGL(sb::matepair_big_kernel, dim3((unsigned)std::min<size_t>(n_big, (size_t)sb::ctx_cu_count(c) * 2)), dim3(sb::kMateBigThreads), 0, s, a, b);
       SB_TRY(hipGetLastError());
    }
-   hipLaunchKernelGGL(sb::matepair_locus_kernel, dim3(grid), dim3(sb::kMateThreads), 0, s, a);
+   static const bool one_class = std::getenv("SBGPU_FRONT_ONE_CLASS") && std::atoi(std::getenv("SBGPU_FRONT_ONE_CLASS")) != 0; // (A/B)
+   if (one_class) {
+      hipLaunchKernelGGL((sb::matepair_locus_kernel<sb::kMateMaxReads, -1>), dim3(grid), dim3(sb::kMateThreads), 0, s, a);
+   } else {
+      hipLaunchKernelGGL((sb::matepair_locus_kernel<sb::kMateMaxReads, sb::kMateMidReads>), dim3(grid), dim3(sb::kMateThreads), 0, s, a);
+      hipLaunchKernelGGL((sb::matepair_locus_kernel<sb::kMateMidReads, sb::kMateSmallReads>), dim3(grid_mid), dim3(sb::kMateThreads), 0, s, a);
+      hipLaunchKernelGGL((sb::matepair_locus_kernel<sb::kMateSmallReads, -1>), dim3(grid_small), dim3(sb::kMateThreads), 0, s, a);
+   }
    SB_TRY(hipGetLastError());
    std::vector<int32_t> cnt[7];
    for (int k = 0; k < 7; ++k) {
@@ -327,7 +337,13 @@ int sbgpu_pair_mates_device(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t 
       hipLaunchKernelGGL(sb::matepair_big_fill_kernel, dim3((unsigned)std::min<size_t>(n_big, (size_t)sb::ctx_cu_count(c) * 2)), dim3(sb::kMateBigThreads), 0, s, a, b);
       SB_TRY(hipGetLastError());
    }
-   hipLaunchKernelGGL(sb::matepair_fill_kernel, dim3(grid), dim3(sb::kMateThreads), 0, s, a);
+   if (one_class) {
+      hipLaunchKernelGGL((sb::matepair_fill_kernel<sb::kMateMaxReads, -1>), dim3(grid), dim3(sb::kMateThreads), 0, s, a);
+   } else {
+      hipLaunchKernelGGL((sb::matepair_fill_kernel<sb::kMateMaxReads, sb::kMateMidReads>), dim3(grid), dim3(sb::kMateThreads), 0, s, a);
+      hipLaunchKernelGGL((sb::matepair_fill_kernel<sb::kMateMidReads, sb::kMateSmallReads>), dim3(grid_mid), dim3(sb::kMateThreads), 0, s, a);
+      hipLaunchKernelGGL((sb::matepair_fill_kernel<sb::kMateSmallReads, -1>), dim3(grid_small), dim3(sb::kMateThreads), 0, s, a);
+   }
    SB_TRY(hipGetLastError());
    SB_TRY(hipStreamSynchronize(s)); // the scratch goes away
 #undef SB_TRY

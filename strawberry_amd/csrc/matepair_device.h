@@ -216,16 +216,21 @@ __device__ __forceinline__ void matepair_one_locus(const MateArgs &a, int64_t l,
    __syncthreads();
 }
 
+// CAP: the LDS arrays' capacity.  Three instantiations: clusters of up to kMateSmallReads records (12 KB of LDS: many
+// workgroups per CU -- with the full-size arrays a CU holds ONE workgroup, and 20 000 clusters of a thousand records
+// take their turns 78 deep), up to kMateMidReads (48 KB) and up to kMateMaxReads; each serves the clusters in (LO, CAP].
+constexpr int kMateSmallReads = 1024, kMateMidReads = 4096;
+template <int CAP, int LO>
 __global__ __launch_bounds__(kMateThreads) void matepair_locus_kernel(MateArgs a)
 {
-   __shared__ unsigned long long key[kMateMaxReads];
-   __shared__ int idx[kMateMaxReads];
+   __shared__ unsigned long long key[CAP];
+   __shared__ int idx[CAP];
    __shared__ int partial[kMateThreads];
    __shared__ int counts[8];
    const int tid = threadIdx.x;
    for (int64_t l = blockIdx.x; l < a.n_loci; l += gridDim.x) {
       const int64_t nl = a.locus_read_off[l + 1] - a.locus_read_off[l];
-      if (nl > kMateMaxReads) continue; // matepair_big_kernel's
+      if (nl > CAP || nl <= LO) continue; // another instantiation's, or matepair_big_kernel's
       if (tid < 8) counts[tid] = 0;
       __syncthreads();
       matepair_one_locus<kMateThreads>(a, l, (int)nl, key, idx, partial, counts);
@@ -321,12 +326,14 @@ __device__ __forceinline__ void matepair_fill_one(const MateArgs &a, int64_t l, 
    __syncthreads();
 }
 
+template <int CAP, int LO>
 __global__ __launch_bounds__(kMateThreads) void matepair_fill_kernel(MateArgs a)
 {
-   __shared__ int cl[kMateMaxReads], cr[kMateMaxReads]; // per pair (rank order): feature counts, then offsets
+   __shared__ int cl[CAP], cr[CAP]; // per pair (rank order): feature counts, then offsets
    __shared__ int partial[kMateThreads];
    for (int64_t l = blockIdx.x; l < a.n_loci; l += gridDim.x) {
-      if (a.locus_read_off[l + 1] - a.locus_read_off[l] > kMateMaxReads) continue; // matepair_big_fill_kernel's
+      const int64_t nl = a.locus_read_off[l + 1] - a.locus_read_off[l];
+      if (nl > CAP || nl <= LO) continue; // another instantiation's, or matepair_big_fill_kernel's
       matepair_fill_one<kMateThreads>(a, l, cl, cr, partial);
    }
 }

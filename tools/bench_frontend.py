@@ -52,7 +52,7 @@ stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 big_pair = int((2 * per > 8192).sum()); big_col = int((per > 4096).sum())
 times = {"pair_mates": [], "collapse": []}
 info_p, info_u = (C.c_int64 * 8)(), (C.c_int64 * 8)()
-for it in range(4):
+for it in range(9):
     hp, hu = C.c_void_p(), C.c_void_p()
     torch.cuda.synchronize(); t = time.time()
     _lib.check(L.sbgpu_pair_mates_device(ctx.h, n_cl, C.byref(rs), read_off_np.ctypes.data, stream, C.byref(hp)), "sbgpu_pair_mates_device")
@@ -65,11 +65,12 @@ for it in range(4):
     torch.cuda.synchronize(); t3 = time.time()
     _lib.check(L.sbgpu_uniq_dev_info(hu, info_u), "sbgpu_uniq_dev_info")
     L.sbgpu_uniq_dev_destroy(hu); L.sbgpu_matepairs_destroy(hp)
-    if it:
+    if it >= 2:
         times["pair_mates"].append((t1 - t) * 1e3); times["collapse"].append((t3 - t2) * 1e3)
-pm, co = float(np.mean(times["pair_mates"])), float(np.mean(times["collapse"]))
+pm, co = float(np.median(times["pair_mates"])), float(np.median(times["collapse"]))
 print(json.dumps({"metric": "front end on resident records: records -> pairs -> unique hits", "clusters": n_cl, "records": n_rec,
                   "pairs": int(info_p[0]), "complete_pairs": int(info_p[1]), "unique_hits": int(info_u[0]),
                   "largest_cluster_records": int(2 * per.max()), "clusters_beyond_8192_records": big_pair, "clusters_beyond_4096_pairs": big_col,
                   "pair_mates_ms": pm, "collapse_ms": co, "records_per_s": n_rec / (pm * 1e-3), "pairs_per_s_collapse": int(info_p[0]) / (co * 1e-3),
-                  "note": "whole calls incl. their host synchronisations and scratch allocation; mean of 3 after a warm-up"}))
+                  "pair_mates_ms_min": float(np.min(times["pair_mates"])), "collapse_ms_min": float(np.min(times["collapse"])),
+                  "note": "whole calls incl. their host synchronisations and scratch allocation; median (and minimum) of 7 after two warm-up rounds"}))
