@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "bitonic_big.h"
+
 namespace sb {
 
 constexpr int kCollapseMax = 4096;   // pairs of one locus (LDS sort)
@@ -167,9 +169,13 @@ struct CollapseShared {
 
 // One locus by one workgroup of THREADS threads.  key / idx [n2 = pow2ceil(np)], span_l / span_r / skip [np]: LDS for
 // loci of up to kCollapseMax pairs, global scratch for bigger ones (collapse_big_kernel) -- the same steps either way.
+// stage_k / stage_i (CH elements each, LDS): given by the global-memory form only -- the sort's chunk buffers, and where the
+// two one-thread sums read their operands from (a dependent global load per step costs a microsecond; 10^5 of them, 0.1 s)
+constexpr int kCollapseStage = 4096;
 template <int THREADS>
 __device__ __forceinline__ void collapse_one_locus(const CollapseArgs &a, int64_t l, int np, unsigned long long *key, int *idx, int *span_l,
-                                                   int *span_r, unsigned char *skip, double *red, CollapseShared &sh)
+                                                   int *span_r, unsigned char *skip, double *red, CollapseShared &sh,
+                                                   unsigned long long *stage_k = nullptr, int *stage_i = nullptr)
 {
    const int tid = threadIdx.x;
    const int64_t q0 = a.locus_pair_off[l];
@@ -224,6 +230,8 @@ __device__ __forceinline__ void collapse_one_locus(const CollapseArgs &a, int64_
       return;
    }
    // ---- bitonic sort of (key, input index)
+   if (stage_k) bitonic_sort_global<THREADS, kCollapseStage>(key, idx, n2, stage_k, stage_i);
+   else
    for (int k2 = 2; k2 <= n2; k2 <<= 1)
       for (int j = k2 >> 1; j > 0; j >>= 1) {
          for (int i = tid; i < n2; i += THREADS) {
@@ -242,20 +250,46 @@ __device__ __forceinline__ void collapse_one_locus(const CollapseArgs &a, int64_
          __syncthreads();
       }
    // ---- sd: the squared deviations added in INPUT order (left mate, then right mate of each pair), by one thread
-   if (tid == 0) {
-      const double mean = sh.mean;
-      double sq = 0.0;
-      for (int i = 0; i < np; ++i) {
-         if (span_l[i] >= 0) {
-            const double d = (double)span_l[i] - mean;
-            sq += d * d;
+   if (!stage_k) {
+      if (tid == 0) {
+         const double mean = sh.mean;
+         double sq = 0.0;
+         for (int i = 0; i < np; ++i) {
+            if (span_l[i] >= 0) {
+               const double d = (double)span_l[i] - mean;
+               sq += d * d;
+            }
+            if (span_r[i] >= 0) {
+               const double d = (double)span_r[i] - mean;
+               sq += d * d;
+            }
          }
-         if (span_r[i] >= 0) {
-            const double d = (double)span_r[i] - mean;
-            sq += d * d;
-         }
+         sh.sd5 = sqrt(sq / (double)sh.nmates) * 5;
       }
-      sh.sd5 = sqrt(sq / (double)sh.nmates) * 5;
+   } else {
+      // the same sum, the spans staged through LDS a chunk at a time (the order of the additions is unchanged)
+      int *sl = stage_i, *sr = (int *)stage_k;
+      double sq = 0.0;
+      for (int c0 = 0; c0 < np; c0 += kCollapseStage) {
+         const int m = min(kCollapseStage, np - c0);
+         for (int t = tid; t < m; t += THREADS) sl[t] = span_l[c0 + t], sr[t] = span_r[c0 + t];
+         __syncthreads();
+         if (tid == 0) {
+            const double mean = sh.mean;
+            for (int i = 0; i < m; ++i) {
+               if (sl[i] >= 0) {
+                  const double d = (double)sl[i] - mean;
+                  sq += d * d;
+               }
+               if (sr[i] >= 0) {
+                  const double d = (double)sr[i] - mean;
+                  sq += d * d;
+               }
+            }
+         }
+         __syncthreads();
+      }
+      if (tid == 0) sh.sd5 = sqrt(sq / (double)sh.nmates) * 5;
    }
    __syncthreads();
    // ---- the span filter (:670-682), and the masses in sorted order
@@ -272,11 +306,27 @@ __device__ __forceinline__ void collapse_one_locus(const CollapseArgs &a, int64_
    for (int i = tid; i < np; i += THREADS) pmass[i] = a.pair_mass[q0 + idx[i]];
    __syncthreads();
    // ---- the cluster's mass: kept pairs in sorted order, one running double (:683-684)
-   if (tid == 0) {
+   if (!stage_k) {
+      if (tid == 0) {
+         double m = 0.0;
+         for (int i = 0; i < np; ++i)
+            if (!skip[i]) m += pmass[i];
+         a.cluster_mass[l] = m;
+      }
+   } else {
+      double *pm = (double *)stage_k; // (staged like the spans above; skipped pairs go in as -1)
       double m = 0.0;
-      for (int i = 0; i < np; ++i)
-         if (!skip[i]) m += pmass[i];
-      a.cluster_mass[l] = m;
+      for (int c0 = 0; c0 < np; c0 += kCollapseStage) {
+         const int mm = min(kCollapseStage, np - c0);
+         __syncthreads();
+         for (int t = tid; t < mm; t += THREADS) pm[t] = skip[c0 + t] ? -1.0 : pmass[c0 + t];
+         __syncthreads();
+         if (tid == 0)
+            for (int i = 0; i < mm; ++i)
+               if (pm[i] >= 0.0) m += pm[i];
+      }
+      if (tid == 0) a.cluster_mass[l] = m;
+      __syncthreads();
    }
    // ---- unique hits: a kept pair that differs from the previous kept pair (:685-697)
    int my_hits = 0, my_feats = 0, my_filt = 0, my_rej = 0;
@@ -367,6 +417,8 @@ __global__ __launch_bounds__(kCollapseBigThreads) void collapse_big_kernel(Colla
 {
    __shared__ double red[kCollapseBigThreads];
    __shared__ CollapseShared sh;
+   __shared__ unsigned long long stage_k[kCollapseStage];
+   __shared__ int stage_i[kCollapseStage];
    const int tid = threadIdx.x;
    for (int i = blockIdx.x; i < b.n_big; i += gridDim.x) {
       const int64_t l = b.loci[i], o = b.big_off[i];
@@ -377,7 +429,7 @@ __global__ __launch_bounds__(kCollapseBigThreads) void collapse_big_kernel(Colla
          sh.hits = sh.feats = sh.filt = sh.rej = sh.bad = 0;
       }
       __syncthreads();
-      collapse_one_locus<kCollapseBigThreads>(a, l, (int)npl, b.key + o, b.idx + o, b.span_l + o, b.span_r + o, b.skip + o, red, sh);
+      collapse_one_locus<kCollapseBigThreads>(a, l, (int)npl, b.key + o, b.idx + o, b.span_l + o, b.span_r + o, b.skip + o, red, sh, stage_k, stage_i);
    }
 }
 

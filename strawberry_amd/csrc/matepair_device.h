@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "bitonic_big.h"
+
 namespace sb {
 
 constexpr int kMateMaxReads = 8192;  // records of one cluster (LDS sort)
@@ -89,7 +91,8 @@ __device__ inline void block_exclusive_scan(int *v, int n, int *partial /*[THREA
 // One cluster by one workgroup of THREADS threads.  key / idx [pow2ceil(n)]: LDS for clusters of up to kMateMaxReads
 // records, global scratch for bigger ones (matepair_big_kernel) -- the same steps either way.
 template <int THREADS>
-__device__ __forceinline__ void matepair_one_locus(const MateArgs &a, int64_t l, int n, unsigned long long *key, int *idx, int *partial, int *counts)
+__device__ __forceinline__ void matepair_one_locus(const MateArgs &a, int64_t l, int n, unsigned long long *key, int *idx, int *partial, int *counts,
+                                                   unsigned long long *stage_k = nullptr, int *stage_i = nullptr) // (LDS chunk buffers: the global-memory form's sort)
 {
    const int tid = threadIdx.x;
    const int64_t q0 = a.locus_read_off[l];
@@ -101,6 +104,8 @@ __device__ __forceinline__ void matepair_one_locus(const MateArgs &a, int64_t l,
    }
    __syncthreads();
    // ---- bitonic sort on (read id, arrival index)
+   if (stage_k) bitonic_sort_global<THREADS, 4096>(key, idx, npad, stage_k, stage_i);
+   else
    for (int k = 2; k <= npad; k <<= 1)
       for (int j = k >> 1; j > 0; j >>= 1) {
          for (int i = tid; i < npad; i += THREADS) {
@@ -252,12 +257,14 @@ __global__ __launch_bounds__(kMateBigThreads) void matepair_big_kernel(MateArgs 
 {
    __shared__ int partial[kMateBigThreads];
    __shared__ int counts[8];
+   __shared__ unsigned long long stage_k[4096];
+   __shared__ int stage_i[4096];
    const int tid = threadIdx.x;
    for (int i = blockIdx.x; i < b.n_big; i += gridDim.x) {
       const int64_t l = b.loci[i], o = b.big_off[i];
       if (tid < 8) counts[tid] = 0;
       __syncthreads();
-      matepair_one_locus<kMateBigThreads>(a, l, (int)(a.locus_read_off[l + 1] - a.locus_read_off[l]), b.key + o, b.idx + o, partial, counts);
+      matepair_one_locus<kMateBigThreads>(a, l, (int)(a.locus_read_off[l + 1] - a.locus_read_off[l]), b.key + o, b.idx + o, partial, counts, stage_k, stage_i);
    }
 }
 
