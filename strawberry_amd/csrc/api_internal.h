@@ -116,6 +116,7 @@ int exonbin_device_impl(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *annot, const
                         int64_t n_iso = -1, const DeviceSegBasis *seg_basis = nullptr);
 int api_fail(int code, const std::string &msg); // records sbgpu_last_error(), returns code
 hipStream_t ctx_stream(const sbgpu_ctx_t *ctx); // the context's own stream
+hipStream_t ctx_aux_stream(const sbgpu_ctx_t *ctx, int i); // one of the context's side streams (0..7; the EM's kinds use 0, 1, 2, 6)
 int ctx_cu_count(const sbgpu_ctx_t *ctx);
 int ctx_device(const sbgpu_ctx_t *ctx);        // the HIP device the context was made on
 // device scratch that lives with the context (slot 0..7, grows on demand, never shrinks): valid until the next

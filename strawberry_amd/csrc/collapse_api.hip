@@ -147,6 +147,8 @@ int sbgpu_collapse_pairs_device(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_pair
    a.n_rejected = (int32_t *)(w + o_nr);
    a.flags = (int32_t *)(w + o_flag);
    const unsigned grid = (unsigned)std::min<int64_t>(n_loci, (int64_t)sb::ctx_cu_count(c) * 8);
+   hipStream_t side = sb::ctx_aux_stream(c, 3);
+   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
    if (n_big) { // first: they are the long ones
       SB_TRY(hipMemcpyAsync(w + o_bloci, big_loci.data(), n_big * 4, hipMemcpyHostToDevice, s));
       SB_TRY(hipMemcpyAsync(w + o_boff, big_off.data(), (n_big + 1) * 8, hipMemcpyHostToDevice, s));
@@ -159,8 +161,15 @@ int sbgpu_collapse_pairs_device(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_pair
       b.span_l = (int *)(w + o_bsl);
       b.span_r = (int *)(w + o_bsr);
       b.skip = (unsigned char *)(w + o_bskip);
-      hipLaunchKernelGGL(sb::collapse_big_kernel, dim3((unsigned)std::min<size_t>(n_big, (size_t)sb::ctx_cu_count(c) * 2)), dim3(sb::kCollapseBigThreads), 0, s, a, b);
+      // on a side stream of the context, beside the LDS kernels below (a big workgroup leaves most of its CU's LDS and half
+      // its wave slots free); joined before the counts are read
+      SB_TRY(sb::ctx_event(c, 0, &ev_fork));
+      SB_TRY(sb::ctx_event(c, 1, &ev_join));
+      SB_TRY(hipEventRecord(ev_fork, s));
+      SB_TRY(hipStreamWaitEvent(side, ev_fork, 0));
+      hipLaunchKernelGGL(sb::collapse_big_kernel, dim3((unsigned)std::min<size_t>(n_big, (size_t)sb::ctx_cu_count(c) * 2)), dim3(sb::kCollapseBigThreads), 0, side, a, b);
       SB_TRY(hipGetLastError());
+      SB_TRY(hipEventRecord(ev_join, side));
    }
    static const bool one_class = std::getenv("SBGPU_FRONT_ONE_CLASS") && std::atoi(std::getenv("SBGPU_FRONT_ONE_CLASS")) != 0; // (A/B)
    if (one_class) {
@@ -170,6 +179,7 @@ int sbgpu_collapse_pairs_device(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_pair
       hipLaunchKernelGGL((sb::collapse_locus_kernel<sb::kCollapseSmall, -1>), dim3((unsigned)std::min<int64_t>(n_loci, (int64_t)sb::ctx_cu_count(c) * 32)), dim3(sb::kCollapseThreads), 0, s, a);
    }
    SB_TRY(hipGetLastError());
+   if (n_big) SB_TRY(hipStreamWaitEvent(s, ev_join, 0));
    std::vector<int32_t> nh((size_t)n_loci), nf((size_t)n_loci), nfi((size_t)n_loci), nr((size_t)n_loci);
    int32_t flags = 0;
    SB_TRY(hipMemcpyAsync(nh.data(), w + o_nh, (size_t)n_loci * 4, hipMemcpyDeviceToHost, s));

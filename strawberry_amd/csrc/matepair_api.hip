@@ -253,6 +253,8 @@ int sbgpu_pair_mates_device(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t 
    const unsigned grid_small = (unsigned)std::min<int64_t>(n_loci, (int64_t)sb::ctx_cu_count(c) * 32);
    const unsigned grid_mid = (unsigned)std::min<int64_t>(n_loci, (int64_t)sb::ctx_cu_count(c) * 12);
    sb::MateBigArgs b = {};
+   hipStream_t side = sb::ctx_aux_stream(c, 3);
+   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
    if (n_big) { // first: they are the long ones
       SB_TRY(hipMemcpyAsync(w + o_bloci, big_loci.data(), n_big * 4, hipMemcpyHostToDevice, s));
       SB_TRY(hipMemcpyAsync(w + o_boff, big_off.data(), (n_big + 1) * 8, hipMemcpyHostToDevice, s));
@@ -263,8 +265,14 @@ int sbgpu_pair_mates_device(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t 
       b.idx = (int *)(w + o_bidx);
       b.cl = (int *)(w + o_bcl);
       b.cr = (int *)(w + o_bcr);
-      hipLaunchKernelGGL(sb::matepair_big_kernel, dim3((unsigned)std::min<size_t>(n_big, (size_t)sb::ctx_cu_count(c) * 2)), dim3(sb::kMateBigThreads), 0, s, a, b);
+      // on a side stream of the context, beside the LDS kernels below; joined before the counts are read
+      SB_TRY(sb::ctx_event(c, 0, &ev_fork));
+      SB_TRY(sb::ctx_event(c, 1, &ev_join));
+      SB_TRY(hipEventRecord(ev_fork, s));
+      SB_TRY(hipStreamWaitEvent(side, ev_fork, 0));
+      hipLaunchKernelGGL(sb::matepair_big_kernel, dim3((unsigned)std::min<size_t>(n_big, (size_t)sb::ctx_cu_count(c) * 2)), dim3(sb::kMateBigThreads), 0, side, a, b);
       SB_TRY(hipGetLastError());
+      SB_TRY(hipEventRecord(ev_join, side));
    }
    static const bool one_class = std::getenv("SBGPU_FRONT_ONE_CLASS") && std::atoi(std::getenv("SBGPU_FRONT_ONE_CLASS")) != 0; // (A/B)
    if (one_class) {
@@ -275,6 +283,7 @@ int sbgpu_pair_mates_device(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t 
       hipLaunchKernelGGL((sb::matepair_locus_kernel<sb::kMateSmallReads, -1>), dim3(grid_small), dim3(sb::kMateThreads), 0, s, a);
    }
    SB_TRY(hipGetLastError());
+   if (n_big) SB_TRY(hipStreamWaitEvent(s, ev_join, 0));
    std::vector<int32_t> cnt[7];
    for (int k = 0; k < 7; ++k) {
       cnt[k].resize((size_t)n_loci);
@@ -334,8 +343,11 @@ int sbgpu_pair_mates_device(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t 
    a.left_left = M->d_left_left, a.left_right = M->d_left_right;
    a.right_left = M->d_right_left, a.right_right = M->d_right_right;
    if (n_big) {
-      hipLaunchKernelGGL(sb::matepair_big_fill_kernel, dim3((unsigned)std::min<size_t>(n_big, (size_t)sb::ctx_cu_count(c) * 2)), dim3(sb::kMateBigThreads), 0, s, a, b);
+      SB_TRY(hipEventRecord(ev_fork, s)); // (behind the uploads above)
+      SB_TRY(hipStreamWaitEvent(side, ev_fork, 0));
+      hipLaunchKernelGGL(sb::matepair_big_fill_kernel, dim3((unsigned)std::min<size_t>(n_big, (size_t)sb::ctx_cu_count(c) * 2)), dim3(sb::kMateBigThreads), 0, side, a, b);
       SB_TRY(hipGetLastError());
+      SB_TRY(hipEventRecord(ev_join, side));
    }
    if (one_class) {
       hipLaunchKernelGGL((sb::matepair_fill_kernel<sb::kMateMaxReads, -1>), dim3(grid), dim3(sb::kMateThreads), 0, s, a);
@@ -345,6 +357,7 @@ int sbgpu_pair_mates_device(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t 
       hipLaunchKernelGGL((sb::matepair_fill_kernel<sb::kMateSmallReads, -1>), dim3(grid_small), dim3(sb::kMateThreads), 0, s, a);
    }
    SB_TRY(hipGetLastError());
+   if (n_big) SB_TRY(hipStreamWaitEvent(s, ev_join, 0));
    SB_TRY(hipStreamSynchronize(s)); // the scratch goes away
 #undef SB_TRY
    (void)hipFree(w);

@@ -88,6 +88,7 @@ struct sbgpu_ctx {
 namespace sb {
 int api_fail(int code, const std::string &msg) { return fail(code, msg); }
 hipStream_t ctx_stream(const sbgpu_ctx_t *ctx) { return ctx->stream; }
+hipStream_t ctx_aux_stream(const sbgpu_ctx_t *ctx, int i) { return (i >= 0 && i < kAuxStreams) ? ctx->aux[i] : ctx->stream; }
 int ctx_cu_count(const sbgpu_ctx_t *ctx) { return ctx->n_cu; }
 int ctx_device(const sbgpu_ctx_t *ctx) { return ctx->device; }
 void ctx_stage_reset(sbgpu_ctx_t *ctx) { ctx->n_stages = 0, ctx->stage_open = false; }
