@@ -38,14 +38,6 @@ for w in ("c3", "c2"):
     summary["_build_id"] = L.sbgpu_build_id().decode()     # bench.py quotes the traffic only for this build
     json.dump(summary, open("%s/%s_%s_pmc_summary.json" % (summ, r, w), "w"), indent=1)
 PY
-# the bench lines come after the counter passes: bench.py reads roofline.traffic from profiles/*_pmc_summary.json
-cp $SUM/${R}_c3_pmc_summary.json $SUM/${R}_c2_pmc_summary.json $REPO/profiles/ 2>/dev/null
-(timeout 900 python bench.py 2>/dev/null | tail -1) > $SUM/${R}_bench_c3.json
-(timeout 600 python bench.py --workload c2 2>/dev/null) > $SUM/${R}_bench_c2.json
-(timeout 900 python bench.py --workload c5 --no-cpu-baseline 2>/dev/null) > $SUM/${R}_bench_c5.json
-(timeout 900 python bench.py --workload c3t --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null) > $SUM/${R}_bench_c3t.json
-(timeout 900 python bench.py --workload c3-chain --steps 10 --warmup 3 2>/dev/null) > $SUM/${R}_bench_c3chain.json
-(timeout 900 python bench.py --gpus 2 --steps 10 --warmup 3 --no-chain 2>/dev/null | tail -1) > $SUM/${R}_bench_c3_2ranks_one_gpu.json
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_chain -o ch -- python3 $REPO/bench.py --workload c3-chain --no-cpu-baseline --steps 3 --warmup 1 > $OUT/stats_chain.log 2>&1
 for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_SALU"; do
@@ -79,6 +71,14 @@ for w, name in (("chain", "c3chain"), ("c3t", "c3t")):
     summary["_build_id"] = L.sbgpu_build_id().decode()
     json.dump(summary, open("%s/%s_%s_pmc_summary.json" % (summ, r, name), "w"), indent=1)
 PY
+# the bench lines come after the counter passes: bench.py reads roofline.traffic from profiles/*_pmc_summary.json
+cp $SUM/${R}_c3_pmc_summary.json $SUM/${R}_c2_pmc_summary.json $SUM/${R}_c3chain_pmc_summary.json $SUM/${R}_c3t_pmc_summary.json $REPO/profiles/ 2>/dev/null
+(timeout 900 python bench.py 2>/dev/null | tail -1) > $SUM/${R}_bench_c3.json
+(timeout 600 python bench.py --workload c2 2>/dev/null) > $SUM/${R}_bench_c2.json
+(timeout 900 python bench.py --workload c5 --no-cpu-baseline 2>/dev/null) > $SUM/${R}_bench_c5.json
+(timeout 900 python bench.py --workload c3t --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null) > $SUM/${R}_bench_c3t.json
+(timeout 900 python bench.py --workload c3-chain --steps 10 --warmup 3 2>/dev/null) > $SUM/${R}_bench_c3chain.json
+(timeout 900 python bench.py --gpus 2 --steps 10 --warmup 3 --no-chain 2>/dev/null | tail -1) > $SUM/${R}_bench_c3_2ranks_one_gpu.json
 bash tools/profile_exonbin.sh $R > /dev/null 2>&1
 cp $OUT/exonbin/summary.json $SUM/${R}_exonbin_summary.json
 cp $OUT/exonbin/stats/eb_kernel_stats.csv $SUM/${R}_exonbin_kernel_stats.csv
