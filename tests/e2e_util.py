@@ -22,6 +22,7 @@ E2E_BIAS = os.path.join(HERE, "golden", "e2e_toy_bias")     # -b genome.fa: six 
 E2E_MINUS = os.path.join(HERE, "golden", "e2e_toy_minus")   # every other gene on the minus strand
 E2E_CHROMS = os.path.join(HERE, "golden", "e2e_toy_chroms")  # genes alternating between two chromosomes
 E2E_FILTER = os.path.join(HERE, "golden", "e2e_toy_filter")  # e2e_toy_long's reads with -e 0.05: isoforms erased
+E2E_ASSEMBLY = os.path.join(HERE, "golden", "e2e_toy_assembly")  # DEFAULT mode (no -g / -r): assembled contigs quantified, Frac < 0.01 erased
 
 
 def load(directory):

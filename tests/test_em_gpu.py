@@ -30,7 +30,7 @@ def solve(batch, ctx):
     return s, s.results()
 
 
-@pytest.mark.parametrize("name", ["em_edge", "em_random_256", "em_c2_64", "em_c3_400"])
+@pytest.mark.parametrize("name", ["em_edge", "em_random_256", "em_c2_64", "em_c3_400", "em_c4_assembled"])
 def test_gpu_matches_reference_goldens(ctx, oracle, golden, name):
     b, ref_theta, ref_flags = golden(name)
     _, r = solve(b, ctx)

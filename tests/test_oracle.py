@@ -27,7 +27,7 @@ def test_oracle_known_answers(oracle, name, n, F, status, theta):
         assert it == 0
 
 
-@pytest.mark.parametrize("name", ["em_edge", "em_random_256", "em_c2_64", "em_c3_400"])
+@pytest.mark.parametrize("name", ["em_edge", "em_random_256", "em_c2_64", "em_c3_400", "em_c4_assembled"])
 def test_oracle_matches_reference_goldens(oracle, golden, name):
     """theta from the restatement == theta from the reference's EmSolver (1e-12 rel,
     the agreement BASELINE.md asks for before the restatement is trusted)."""

@@ -22,6 +22,8 @@ sys.path.insert(0, ROOT)
 from oracle import build  # noqa: E402
 from oracle.lib import REF_BIN, SAM2BAM  # noqa: E402
 
+DUMP_BIN = os.path.join(ROOT, "oracle", "_ref", "strawberry_dump")   # the reference program with a tap on EmSolver (oracle/em_dump_shim.cpp)
+
 RL = 75
 MEAN, SD = 250.0, 30.0
 
@@ -235,10 +237,96 @@ def main():
     # e2e_toy_chroms: the genes alternate between two chromosomes: the mapped-read total runs over both
     #          (alignments.cpp:1372) and the output is written chromosome by chromosome.
     make("e2e_toy_chroms", 4949, 150, 500, chroms=2)
+    # e2e_toy_assembly (BASELINE config 4 / C1 plumbing): the reference in its DEFAULT mode -- no -g, no -r: the first pass
+    #          assembles transcripts from the reads (assembleSample, alignments.cpp:1658), the second quantifies the
+    #          ASSEMBLED contigs (reset_refmRNAs, alignments.cpp:1091-1101) with kMinIsoformFrac = 0.01, so the post-EM
+    #          filter fires (estimate.cpp:346-355: this seed loses one of 18 isoforms).  toy.gtf is only the
+    #          simulation's source here; the program never sees it.
+    make("e2e_toy_assembly", 5165, 150, 500, n_frags=2500, assembly=True)
+    if not only or "em_c4_assembled" in only:
+        make_c4_em_golden()
+
+
+def write_sam(recs, genes, chrom_len, path):
+    with open(path, "w") as f:
+        f.write("@HD\tVN:1.0\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % (c, chrom_len) for c in sorted(set(g["chrom"] for g in genes))))
+        for _, line in recs:
+            f.write(line + "\n")
+
+
+def read_em_dump(path):
+    """oracle/em_dump_shim.cpp's records -> [(n[nrow] int32, alpha[nrow, niso] f64, init, run, theta[niso])]."""
+    import struct
+    d = open(path, "rb").read()
+    loci, p = [], 0
+    while p < len(d):
+        tag = d[p:p + 1]
+        p += 1
+        if tag == b"I":
+            niso, nrow = struct.unpack_from("ii", d, p)
+            p += 8
+            n = np.frombuffer(d, np.int32, nrow, p).copy()
+            p += 4 * nrow
+            alpha = np.frombuffer(d, np.float64, nrow * niso, p).reshape(nrow, niso).copy()
+            p += 8 * nrow * niso
+            ok, = struct.unpack_from("i", d, p)
+            p += 4
+            loci.append([n, alpha, ok, 0, None])
+        else:
+            assert tag == b"R", tag
+            ok, k = struct.unpack_from("ii", d, p)
+            p += 8
+            loci[-1][3] = ok
+            loci[-1][4] = np.frombuffer(d, np.float64, k, p).copy()
+            p += 8 * k
+    return loci
+
+
+def make_c4_em_golden():
+    """tests/golden/em_c4_assembled.npz: the EXACT (n, alpha) that loci of ASSEMBLED isoforms hand to EmSolver::init in
+    the reference's default mode, with the reference's own theta / flags -- captured by oracle/_ref/strawberry_dump
+    (the reference program; em_dump_shim.cpp taps the seam and forwards to the reference's bodies).  Four runs of 40
+    genes each over different exon-size ranges; loci the assembler leaves with one isoform are kept (1-column EM)."""
+    from strawberry_amd import synth
+    loci, thetas, flags = [], [], []
+    for seed, ex_lo, ex_hi, n_frags in ((6101, 150, 500, 1500), (6102, 60, 400, 2500), (6103, 300, 800, 800), (6104, 100, 300, 4000)):
+        rng = np.random.Generator(np.random.PCG64(seed))
+        genes, chrom_len = make_annotation(rng, 40, ex_lo, ex_hi)
+        with tempfile.TemporaryDirectory() as tmp:
+            recs, _ = simulate(rng, genes, n_frags)
+            write_sam(recs, genes, chrom_len, os.path.join(tmp, "toy.sam"))
+            subprocess.check_call([SAM2BAM, os.path.join(tmp, "toy.sam"), os.path.join(tmp, "toy.bam")], stderr=subprocess.DEVNULL)
+            outs = {}
+            for prog in (REF_BIN, DUMP_BIN):     # the tap must not change the program's outputs
+                for n in ("out.gtf", "ctx.tsv", "log.txt"):
+                    if os.path.exists(os.path.join(tmp, n)):
+                        os.remove(os.path.join(tmp, n))
+                r = subprocess.run([prog, "toy.bam", "-i", "%d/%d" % (MEAN, SD), "-o", "out.gtf", "-T", "log.txt", "-f", "ctx.tsv"], cwd=tmp,
+                                   capture_output=True, text=True, env=dict(os.environ, SB_EM_DUMP=os.path.join(tmp, "em.bin")))
+                r.check_returncode()
+                outs[prog] = [open(os.path.join(tmp, "out.gtf")).read().split("\n", 1)[1], open(os.path.join(tmp, "ctx.tsv")).read()]
+            assert outs[REF_BIN] == outs[DUMP_BIN], "strawberry_dump's outputs differ from strawberry_ref's"
+            got = read_em_dump(os.path.join(tmp, "em.bin"))
+            n_log = sum("raw read count" in l for l in open(os.path.join(tmp, "log.txt")))
+            n_out = sum("\ttranscript\t" in l for l in open(os.path.join(tmp, "out.gtf")))
+            print("seed %d: %d records, %d loci reached the EM, %d isoforms solved, %d survive the 0.01 filter" % (
+                seed, len(recs), len(got), n_log, n_out))
+        for n, alpha, ok, ran, theta in got:
+            loci.append((n, alpha))
+            if theta is None:           # init() false: run() never called; theta_0 is not observable -- the flags say so
+                theta = np.full(alpha.shape[1], float(n.sum()) / alpha.shape[1])
+            thetas.append(theta)
+            flags.append((1 if ok else 0) | (2 if ran else 0))
+    b = synth.from_loci(loci, name="c4_assembled")
+    path = os.path.join(ROOT, "tests", "golden", "em_c4_assembled.npz")
+    np.savez_compressed(path, row_off=b.row_off, iso_off=b.iso_off, f_off=b.f_off, count=b.count, F=b.F, length=b.length,
+                        ref_theta=np.concatenate(thetas), ref_flags=np.asarray(flags, np.int32))
+    print("em_c4_assembled: %d loci, %d isoforms, %d bins -> %s (%d KB)" % (
+        b.n_loci, int(b.iso_off[-1]), int(b.row_off[-1]), os.path.relpath(path, ROOT), os.path.getsize(path) // 1024))
 
 
 def make(name, seed, ex_lo, ex_hi, dup=0.0, multi=0.0, extra=(), insert=True, single=False, long_reads=False, n_frags=900,
-         genome=False, minus=False, chroms=1):
+         genome=False, minus=False, chroms=1, assembly=False):
     rng = np.random.Generator(np.random.PCG64(seed))
     genes, chrom_len = make_annotation(rng, 6, ex_lo, ex_hi)
     if minus:
@@ -265,7 +353,7 @@ def make(name, seed, ex_lo, ex_hi, dup=0.0, multi=0.0, extra=(), insert=True, si
         if genome:
             write_genome(rng, chrom_len + 500, tmp)
             extra += ["-b", "genome.fa"]
-        cmd = [REF_BIN, bam, "-g", gtf, "-r"] + (["-i", "%d/%d" % (MEAN, SD)] if insert else []) + ["-o", os.path.join(tmp, "out.gtf"),
+        cmd = [REF_BIN, bam] + ([] if assembly else ["-g", gtf, "-r"]) + (["-i", "%d/%d" % (MEAN, SD)] if insert else []) + ["-o", os.path.join(tmp, "out.gtf"),
                "-T", os.path.join(tmp, "log.txt"), "-f", os.path.join(tmp, "ctx.tsv")] + list(extra)
         r = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True)
         print(r.stdout[-2000:])
@@ -281,9 +369,10 @@ def make(name, seed, ex_lo, ex_hi, dup=0.0, multi=0.0, extra=(), insert=True, si
         with open(os.path.join(out_dir, "README.txt"), "w") as f:
             f.write("Generated by tools/make_e2e_golden.py from the reference binary (oracle/_ref/strawberry_ref):\n"
                     "  %s\n"
-                    "toy.gtf is our synthetic annotation; out.gtf, ctx.tsv and theta_log.txt are the reference's outputs.\n"
+                    "toy.gtf is our synthetic annotation%s; out.gtf, ctx.tsv and theta_log.txt are the reference's outputs.\n"
                     "%d read records, read length %d, %s, %d genes.\n" % (
-                        " ".join(os.path.basename(c) if c.startswith("/") else c for c in cmd), len(recs), RL,
+                        " ".join(os.path.basename(c) if c.startswith("/") else c for c in cmd),
+                        " (the simulation's source only: the run is in assembly mode and never reads it)" if assembly else "", len(recs), RL,
                         ("insert size -i %d/%d (Gaussian)" % (MEAN, SD)) if insert else
                         "no -i: empirical insert-size distribution (fragments simulated from N(%d, %d))" % (MEAN, SD),
                         len(genes)))
