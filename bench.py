@@ -7,11 +7,11 @@ A step = one pass of the hot path over one batch of synthetic loci that is alrea
 resident in HBM: EM (init + run to convergence) for every locus, the FPKM/Frac
 epilogue, the TPM all-reduce (N > 1) and the TPM kernel.  N > 1 is launched by
 torchrun (one rank per GPU, RCCL).  Two measurements, both in the line:
-  weak_scaling    every rank holds its OWN full-size batch (seed + rank); value = the loci
-                  all ranks processed per second (the headline `value` by default);
   strong_scaling  BASELINE config 3, "loci sharded 1 -> 2 -> 4 -> 8": ONE batch, its loci
                   dealt to the ranks by dist.shard_loci, one all-reduce per step; value =
-                  that batch's loci per second (`--scaling strong` makes it the headline).
+                  that batch's loci per second -- the headline `value` (default);
+  weak_scaling    every rank holds its OWN full-size batch (seed + rank); value = the loci
+                  all ranks processed per second (`--scaling weak` makes it the headline).
 At N = 1 the two are the same run.
 
 Prints ONE JSON line on rank 0.  Besides the driver's fields it carries
@@ -174,7 +174,7 @@ def timed_steps(quant, steps, warmup, dev, sdist, torch):
     return float(tmax.item()), ev[0].elapsed_time(ev[1])
 
 
-def chain_cpu_baseline(q, budget_frags=3.5e5):
+def chain_cpu_baseline(q, budget_frags=3.2e6):
     """The reference PROGRAM (oracle/_ref/strawberry_ref: Strawberry's own main, BAM decode, clustering, LocusContext,
     EmSolver, output -- compiled from /root/reference) on the first loci of the chain sample, one thread, timed on
     this box's host; and the GPU chain's theta of those loci against the theta lines of its log (estimate.cpp:312).
@@ -191,41 +191,13 @@ def chain_cpu_baseline(q, budget_frags=3.5e5):
     K = int(np.searchsorted(q.hits.locus_hit_off, budget_frags, side="right"))
     K = max(1, min(K, q.n_loci))
     h = q.hits.host_hits(K)
+    from oracle.lib import write_gtf_from_annotation, write_sam_from_hits
     with tempfile.TemporaryDirectory() as tmp:
         gtf, sam, bam = (os.path.join(tmp, n) for n in ("s.gtf", "s.sam", "s.bam"))
-        with open(gtf, "w") as f:
-            for l in range(K):
-                for j, i in enumerate(range(int(a.iso_off[l]), int(a.iso_off[l + 1]))):
-                    e0, e1 = int(a.exon_off[i]), int(a.exon_off[i + 1])
-                    attr = 'gene_id "G%d"; transcript_id "G%d.%d";' % (l, l, j + 1)
-                    f.write("chr1\tsynth\ttranscript\t%d\t%d\t.\t+\t.\t%s\n" % (a.exon_left[e0], a.exon_right[e1 - 1], attr))
-                    for e in range(e0, e1):
-                        f.write("chr1\tsynth\texon\t%d\t%d\t.\t+\t.\t%s\n" % (a.exon_left[e], a.exon_right[e], attr))
-        # hits -> read pairs: the features before the GAP are the left mate's, those behind it the right mate's
-        off, code, fl, fr = h.feat_off, h.feat_code, h.feat_left.astype(np.int64), h.feat_right.astype(np.int64)
-        recs, pos = [], []
-        for k in range(h.n_hits):
-            f0, f1 = int(off[k]), int(off[k + 1])
-            g = f0 + int(np.nonzero(code[f0:f1] == 2)[0][0])
-
-            def mate(x0, x1):
-                c, n = "", 0
-                for i in range(x0, x1):
-                    ln = int(fr[i] - fl[i] + 1)
-                    c += "%d%s" % (ln, "M" if code[i] == 0 else "N")
-                    n += ln if code[i] == 0 else 0
-                return c, n
-            (cl, nl), (cr, nr) = mate(f0, g), mate(g + 1, f1)
-            pl, pr = int(fl[f0]), int(fl[g + 1])
-            tlen = int(fr[f1 - 1]) - pl + 1
-            for c in range(int(h.mass[k])):      # every read pair behind the unique hit
-                recs.append("r%d_%d\t99\tchr1\t%d\t255\t%s\t=\t%d\t%d\t%s\t%s\tNH:i:1\tXS:A:+" % (k, c, pl, cl, pr, tlen, "A" * nl, "I" * nl))
-                recs.append("r%d_%d\t147\tchr1\t%d\t255\t%s\t=\t%d\t%d\t%s\t%s\tNH:i:1\tXS:A:+" % (k, c, pr, cr, pl, -tlen, "A" * nr, "I" * nr))
-                pos += [pl, pr]
-        order = np.argsort(np.asarray(pos), kind="stable")
-        with open(sam, "w") as f:
-            f.write("@HD\tVN:1.0\tSO:coordinate\n@SQ\tSN:chr1\tLN:%d\n" % (int(fr.max()) + 10000))
-            f.write("\n".join(recs[i] for i in order) + "\n")
+        write_gtf_from_annotation(gtf, a, K)
+        # hits -> read pairs: the features before the GAP are the left mate's, those behind it the right mate's; every read
+        # pair behind a unique hit gets its own two records (oracle/sam_writer.c)
+        write_sam_from_hits(sam, h)
         subprocess.check_call([sam2bam, sam, bam], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         cmd = [ref_bin, bam, "-g", gtf, "-r", "-i", "250/30", "-o", os.path.join(tmp, "out.gtf"), "-T", os.path.join(tmp, "log.txt"),
                "-f", os.path.join(tmp, "ctx.tsv")]
@@ -383,9 +355,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: every rank its own full batch (the headline line); strong: ONE batch, loci sharded "
-                         "over the ranks (BASELINE config 3) -- measured either way and reported under `strong_scaling`")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="strong (default): ONE batch / ONE chain sample, its loci sharded over the ranks -- BASELINE config 3, "
+                         "'loci sharded 1 -> 2 -> 4 -> 8' -- is the headline (`value`, `ms_per_step`); weak: every rank its own "
+                         "full batch.  Both are measured either way and reported under `strong_scaling` / `weak_scaling`; "
+                         "at one rank they are the same run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-chain", action="store_true", help="default workload: leave the fragments -> abundances leg out of the line")
     args = ap.parse_args()
@@ -434,7 +408,8 @@ def main():
     collective = ("C ABI (sbgpu_allreduce_sum_f64 over RCCL)" if comm is not None else
                   "gloo on a host copy (%d ranks share %d device(s): RCCL refuses two ranks per device)" % (world, n_dev)
                   if oversub else "torch.distributed (RCCL)" if world > 1 else "none (one rank)")
-    launch = {"world_size": world, "devices": n_dev, "collective": collective}
+    launch = {"world_size": world, "devices": n_dev, "collective": collective,
+              "rccl_ranks": comm.rccl_ranks() if comm is not None else None}     # ncclCommCount of the C-ABI communicator
     if oversub:
         launch["oversubscribed"] = True
     if comm_note:

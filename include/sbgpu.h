@@ -237,7 +237,10 @@ int sbgpu_tpm_device(sbgpu_ctx_t *ctx, int64_t n_iso, const double *d_fpkm,
  * makes an id with sbgpu_comm_unique_id and hands its 128 bytes to the other ranks by
  * whatever channel the driver has (a file, a socket, argv); every rank then calls
  * sbgpu_comm_init(ctx, rank, world, id) -- a collective call -- on the GPU of its ctx.
- * world == 1 needs no id (NULL) and no RCCL: its all-reduce is the identity.
+ * world == 1 needs no id (NULL) and no RCCL: its all-reduce is the identity.  (With
+ * SBGPU_COMM_FORCE_RCCL=1 in the environment a world of one takes the RCCL path all the
+ * same -- its own id, ncclCommInitRank(1), ncclAllReduce -- so that a one-GPU box can
+ * exercise the binding; sbgpu_comm_rccl_ranks then reports 1 instead of 0.)
  * The all-reduces are in place, on device buffers, asynchronous on `stream`.             */
 #define SBGPU_COMM_ID_BYTES 128
 typedef struct sbgpu_comm sbgpu_comm_t;
@@ -245,6 +248,9 @@ int sbgpu_comm_unique_id(uint8_t id_out[SBGPU_COMM_ID_BYTES]);
 int sbgpu_comm_init(sbgpu_ctx_t *ctx, int rank, int world, const uint8_t id[SBGPU_COMM_ID_BYTES],
                     sbgpu_comm_t **comm_out);
 int sbgpu_comm_info(const sbgpu_comm_t *comm, int *rank, int *world);
+/* ranks in the RCCL communicator behind `comm` (ncclCommCount); 0 when the communicator is a
+ * world of one that never opened RCCL.                                                     */
+int sbgpu_comm_rccl_ranks(const sbgpu_comm_t *comm, int *ranks);
 int sbgpu_comm_destroy(sbgpu_comm_t *comm);
 int sbgpu_allreduce_sum_f64(sbgpu_comm_t *comm, double *d_buf, int64_t n, void *stream);
 int sbgpu_allreduce_sum_i64(sbgpu_comm_t *comm, int64_t *d_buf, int64_t n, void *stream);

@@ -313,6 +313,43 @@ class OracleLib:
         return gc[:n], ent[:n], fl[:n]
 
 
+def write_sam_from_hits(path, hits, lib=None):
+    """Unique hits (exonbin.Hits: left mate's features, one GAP, right mate's features; mass = read pairs behind the hit)
+    -> the coordinate-sorted SAM of those read pairs (oracle/sam_writer.c).  -> number of records"""
+    L = (lib or OracleLib()).L
+    cnt = np.asarray(hits.mass).astype(np.int64)
+    pair_off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+    gap_idx = np.flatnonzero(hits.feat_code == 2).astype(np.int64)
+    assert len(gap_idx) == hits.n_hits, "every hit must hold exactly one GAP (paired-end hits)"
+    fl = hits.feat_left.astype(np.int64)
+    pl, pr = fl[hits.feat_off[:-1]], fl[gap_idx + 1]
+    pos = np.stack([np.repeat(pl, cnt), np.repeat(pr, cnt)], 1).ravel()
+    order = np.argsort(pos, kind="stable").astype(np.int64)
+    L.sbo_write_sam.restype = C.c_int
+    L.sbo_write_sam.argtypes = [C.c_char_p, C.c_int64, C.c_int64, _i64, _p(np.uint8, flags="C"), _u32, _u32, _i64, _i64, C.c_int64, _i64]
+    rc = L.sbo_write_sam(path.encode(), int(hits.feat_right.max()) + 10000, hits.n_hits, np.ascontiguousarray(hits.feat_off, np.int64),
+                         np.ascontiguousarray(hits.feat_code, np.uint8), np.ascontiguousarray(hits.feat_left, np.uint32),
+                         np.ascontiguousarray(hits.feat_right, np.uint32), gap_idx, pair_off, len(order), order)
+    if rc != 0:
+        raise RuntimeError("sbo_write_sam failed for " + path)
+    return len(order)
+
+
+def write_gtf_from_annotation(path, annot, n_loci=None):
+    """The first n_loci gene models of an exonbin.Annotation as a GTF on chr1, plus strand (genes G<l>, transcripts G<l>.<j+1>)."""
+    a = annot
+    n_loci = a.n_loci if n_loci is None else n_loci
+    el, er = a.exon_left.tolist(), a.exon_right.tolist()
+    with open(path, "w") as f:
+        for l in range(n_loci):
+            for j, i in enumerate(range(int(a.iso_off[l]), int(a.iso_off[l + 1]))):
+                e0, e1 = int(a.exon_off[i]), int(a.exon_off[i + 1])
+                attr = 'gene_id "G%d"; transcript_id "G%d.%d";' % (l, l, j + 1)
+                f.write("chr1\tsynth\ttranscript\t%d\t%d\t.\t+\t.\t%s\n" % (el[e0], er[e1 - 1], attr))
+                for e in range(e0, e1):
+                    f.write("chr1\tsynth\texon\t%d\t%d\t.\t+\t.\t%s\n" % (el[e], er[e], attr))
+
+
 def _blocks_csr(blocks_list):
     off, l, r = [0], [], []
     for b in blocks_list:

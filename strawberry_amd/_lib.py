@@ -24,7 +24,7 @@ SYMBOLS = [
     "sbgpu_plan_classes", "sbgpu_plan_locus_kinds", "sbgpu_em_run_device", "sbgpu_em_run_device_f32", "sbgpu_em_run_device_bias", "sbgpu_em_run_device_bias_f32", "sbgpu_em_last_kernel_ms",
     "sbgpu_set_timing", "sbgpu_em_last_phase_ms", "sbgpu_last_stage_ms", "sbgpu_pair_mates_host", "sbgpu_pair_mates_device", "sbgpu_matepairs_destroy", "sbgpu_matepairs_info",
     "sbgpu_matepairs_pairs", "sbgpu_matepairs_export", "sbgpu_assign_reads_host", "sbgpu_assign_reads_device",
-    "sbgpu_comm_unique_id", "sbgpu_comm_init", "sbgpu_comm_info", "sbgpu_comm_destroy",
+    "sbgpu_comm_unique_id", "sbgpu_comm_init", "sbgpu_comm_info", "sbgpu_comm_rccl_ranks", "sbgpu_comm_destroy",
     "sbgpu_allreduce_sum_f64", "sbgpu_allreduce_sum_i64", "sbgpu_allreduce_sum_f64_host", "sbgpu_allreduce_sum_i64_host",
     "sbgpu_insert_pdf_table", "sbgpu_binweight_device", "sbgpu_binweight_host",
     "sbgpu_exonbin_device", "sbgpu_exonbin_host", "sbgpu_segments_host", "sbgpu_hit_features", "sbgpu_frag_lens_host",
@@ -162,6 +162,7 @@ def load():
     L.sbgpu_comm_unique_id.argtypes = [vp]
     L.sbgpu_comm_init.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
     L.sbgpu_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.sbgpu_comm_rccl_ranks.argtypes = [vp, C.POINTER(C.c_int)]
     L.sbgpu_comm_destroy.argtypes = [vp]
     L.sbgpu_allreduce_sum_f64.argtypes = [vp, vp, C.c_int64, vp]
     L.sbgpu_allreduce_sum_i64.argtypes = [vp, vp, C.c_int64, vp]

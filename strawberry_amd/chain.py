@@ -239,7 +239,8 @@ class ChainQuantifier:
         if pin:
             _lib.check(ctx.L.sbgpu_annotation_pin(ctx.h, C.byref(self._an)), "sbgpu_annotation_pin")
 
-    def step(self):
+    def step(self, keep=False):
+        """keep=True: -> (LocusBins, F) of this step's handle (exported to the host: tests compare them with the oracle's)."""
         h = C.c_void_p()
         L = self.ctx.L
         _lib.check(L.sbgpu_quantify_device(self.ctx.h, C.byref(self._an), C.byref(self._ht), self.hits.mass.data_ptr(),
@@ -250,6 +251,12 @@ class ChainQuantifier:
             info = (C.c_int64 * 8)()
             _lib.check(L.sbgpu_bins_info(h, info), "sbgpu_bins_info")
             self.info = {"n_bins": int(info[2]), "n_elem": int(info[3]), "n_pairs": int(info[4]), "hits_in_bins": int(info[6])}
+        if keep:
+            F = np.zeros(max(self.info["n_elem"], 1), np.float64)
+            _lib.check(L.sbgpu_bins_export_weights(h, F.ctypes.data), "sbgpu_bins_export_weights")
+            bins = eb.LocusBins.__new__(eb.LocusBins)
+            bins._export(L, self.annot, h, self.n_hits, self.annot.compat_words, self.annot.key_words, with_hit_bin=False)   # destroys the handle
+            return bins, F[:self.info["n_elem"]]
         L.sbgpu_bins_destroy(h)
 
     def stage_ms(self):
@@ -267,9 +274,23 @@ class ChainQuantifier:
             L.sbgpu_set_timing(self.ctx.h, 0)
 
     def finish(self):
-        pass
+        """Release what this object keeps with the (shared) context: the pinned annotation.  The pin is keyed on the
+        annotation arrays' addresses (+ a sampled fingerprint); it must not outlive the arrays."""
+        self.unpin()
 
     def unpin(self):
-        if self.pinned:
-            self.ctx.L.sbgpu_annotation_unpin(self.ctx.h)
+        if getattr(self, "pinned", False):
             self.pinned = False
+            self.ctx.L.sbgpu_annotation_unpin(self.ctx.h)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.finish()
+
+    def __del__(self):
+        try:
+            self.unpin()
+        except Exception:       # interpreter shutdown: the library may be gone already
+            pass

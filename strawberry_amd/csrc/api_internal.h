@@ -87,10 +87,31 @@ struct ResidentAnnotation {
    DeviceSegBasis seg_basis; // (same arena)
    IsoSegments iso;         // host
    int64_t max_locus_span = 1, max_iso = 1, max_seg = 1; // longest locus' segments together; widest locus
+   uint64_t print = 0;      // fingerprint() of the caller's arrays when they were pinned
+   // A cheap content check beside the addresses: the totals, and up to 256 evenly spaced entries of every array (FNV-1a).
+   // The caller's arrays may have been freed and their addresses recycled by another annotation of the same shape since the
+   // pin; that one does not match (it would otherwise be served the stale device copies and tables -- wrong theta, no error).
+   static uint64_t fingerprint(const sbgpu_annotation_t *a)
+   {
+      uint64_t h = 1469598103934665603ull;
+      auto mix = [&h](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
+      const int64_t nl = a->n_loci, n_iso = a->iso_off[nl], n_exon = a->exon_off[n_iso], n_seg = a->seg_off[nl];
+      mix((uint64_t)nl), mix((uint64_t)n_iso), mix((uint64_t)n_exon), mix((uint64_t)n_seg);
+      auto sample = [&mix](auto *p, int64_t n) {
+         if (!p || n <= 0) return;
+         const int64_t step = n > 256 ? n / 256 : 1;
+         for (int64_t k = 0; k < n; k += step) mix((uint64_t)p[k]);
+         mix((uint64_t)p[n - 1]);
+      };
+      sample(a->iso_off, nl + 1), sample(a->exon_off, n_iso + 1), sample(a->seg_off, nl + 1);
+      sample(a->exon_left, n_exon), sample(a->exon_right, n_exon), sample(a->seg_left, n_seg), sample(a->seg_right, n_seg);
+      return h;
+   }
    bool matches(const sbgpu_annotation_t *a) const
    {
       return a && a->n_loci == key.n_loci && a->iso_off == key.iso_off && a->exon_off == key.exon_off && a->exon_left == key.exon_left &&
-             a->exon_right == key.exon_right && a->seg_off == key.seg_off && a->seg_left == key.seg_left && a->seg_right == key.seg_right;
+             a->exon_right == key.exon_right && a->seg_off == key.seg_off && a->seg_left == key.seg_left && a->seg_right == key.seg_right &&
+             fingerprint(a) == print;
    }
 };
 const ResidentAnnotation *ctx_resident_annotation(const sbgpu_ctx_t *ctx);

@@ -522,6 +522,7 @@ int sbgpu_annotation_pin(sbgpu_ctx_t *c, const sbgpu_annotation_t *an)
    sb::ResidentAnnotation *r = new (std::nothrow) sb::ResidentAnnotation();
    if (!r) return api_fail(SBGPU_ENOMEM, "sbgpu_annotation_pin: out of host memory");
    r->key = *an;
+   r->print = sb::ResidentAnnotation::fingerprint(an);
    for (int64_t l = 0; l < nl; ++l) {
       r->max_iso = std::max(r->max_iso, an->iso_off[l + 1] - an->iso_off[l]);
       r->max_seg = std::max(r->max_seg, an->seg_off[l + 1] - an->seg_off[l]);

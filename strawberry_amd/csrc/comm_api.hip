@@ -4,11 +4,14 @@
 // (/root/reference/src/alignments.cpp:1372) and the FPKM total after it (:1821-1824).  With the loci sharded over
 // one process per GPU these become all-reduce(sum) of a few bytes: RCCL over xGMI.  librccl.so is opened when the
 // first communicator of more than one rank is made (dlopen), so a single-GPU user of libsbgpu.so does not need it.
-// A world of one rank needs neither RCCL nor an id: its all-reduce is the identity.
+// A world of one rank needs neither RCCL nor an id: its all-reduce is the identity -- unless SBGPU_COMM_FORCE_RCCL=1 is
+// set in the environment, which sends a world of ONE through the same RCCL calls as a world of eight (dlopen, id,
+// ncclCommInitRank, ncclAllReduce on the caller's stream): the way to exercise the binding on a one-GPU box.
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -31,6 +34,7 @@ struct Rccl {
    int (*CommInitRank)(RcclComm *, int, RcclUniqueId, int) = nullptr;
    int (*AllReduce)(const void *, void *, size_t, int, int, RcclComm, hipStream_t) = nullptr;
    int (*CommDestroy)(RcclComm) = nullptr;
+   int (*CommCount)(RcclComm, int *) = nullptr;
    const char *(*GetErrorString)(int) = nullptr;
    std::string why; // non-empty: RCCL is unusable, and why
 };
@@ -58,6 +62,7 @@ const Rccl &rccl()
       g_rccl.CommInitRank = (int (*)(RcclComm *, int, RcclUniqueId, int))sym("ncclCommInitRank");
       g_rccl.AllReduce = (int (*)(const void *, void *, size_t, int, int, RcclComm, hipStream_t))sym("ncclAllReduce");
       g_rccl.CommDestroy = (int (*)(RcclComm))sym("ncclCommDestroy");
+      g_rccl.CommCount = (int (*)(RcclComm, int *))sym("ncclCommCount");
       g_rccl.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
    });
    return g_rccl;
@@ -105,8 +110,10 @@ int sbgpu_comm_init(sbgpu_ctx_t *ctx, int rank, int world, const uint8_t id[SBGP
    if (!c) return sb::api_fail(SBGPU_ENOMEM, "sbgpu_comm_init: out of host memory");
    c->rank = rank, c->world = world, c->device = sb::ctx_device(ctx);
    c->stream = sb::ctx_stream(ctx);
-   if (world > 1) {
-      if (!id) {
+   const char *force = std::getenv("SBGPU_COMM_FORCE_RCCL");
+   const bool forced = world == 1 && force && force[0] == '1';
+   if (world > 1 || forced) {
+      if (!id && !forced) {
          delete c;
          return sb::api_fail(SBGPU_EINVAL, "sbgpu_comm_init: world > 1 needs the id rank 0 made with sbgpu_comm_unique_id");
       }
@@ -114,6 +121,15 @@ int sbgpu_comm_init(sbgpu_ctx_t *ctx, int rank, int world, const uint8_t id[SBGP
       if (!r.why.empty()) {
          delete c;
          return sb::api_fail(SBGPU_ERCCL, "sbgpu_comm_init: " + r.why);
+      }
+      uint8_t own_id[SBGPU_COMM_ID_BYTES];
+      if (!id) { // a forced world of one without an id: it is its own rank 0
+         const int rc_id = sbgpu_comm_unique_id(own_id);
+         if (rc_id != SBGPU_OK) {
+            delete c;
+            return rc_id;
+         }
+         id = own_id;
       }
       hipError_t e = hipSetDevice(c->device);
       if (e != hipSuccess) {
@@ -150,6 +166,18 @@ int sbgpu_comm_destroy(sbgpu_comm_t *c)
    return SBGPU_OK;
 }
 
+int sbgpu_comm_rccl_ranks(const sbgpu_comm_t *c, int *ranks)
+{
+   if (!c || !ranks) return sb::api_fail(SBGPU_EINVAL, "sbgpu_comm_rccl_ranks: null argument");
+   *ranks = 0;
+   if (!c->comm) return SBGPU_OK; // a world of one without RCCL
+   const Rccl &r = rccl();
+   if (!r.CommCount) return sb::api_fail(SBGPU_ERCCL, "sbgpu_comm_rccl_ranks: librccl.so lacks ncclCommCount");
+   const int rc = r.CommCount(c->comm, ranks);
+   if (rc != 0) return rccl_fail("ncclCommCount", rc);
+   return SBGPU_OK;
+}
+
 int sbgpu_comm_info(const sbgpu_comm_t *c, int *rank, int *world)
 {
    if (!c) return sb::api_fail(SBGPU_EINVAL, "sbgpu_comm_info: null comm");
@@ -162,7 +190,7 @@ static int allreduce(sbgpu_comm_t *c, void *d_buf, int64_t n, int dtype, void *s
 {
    if (!c) return sb::api_fail(SBGPU_EINVAL, std::string(who) + ": null comm");
    if (n < 0 || (n > 0 && !d_buf)) return sb::api_fail(SBGPU_EINVAL, std::string(who) + ": bad buffer");
-   if (c->world == 1 || n == 0) return SBGPU_OK; // the sum over one rank
+   if (!c->comm || n == 0) return SBGPU_OK; // the sum over one rank (a forced world of one has a communicator and goes on)
    const int rc = rccl().AllReduce(d_buf, d_buf, (size_t)n, dtype, kRcclSum, c->comm, (hipStream_t)stream);
    if (rc != 0) return rccl_fail(who, rc);
    return SBGPU_OK;
@@ -183,7 +211,7 @@ static int allreduce_host(sbgpu_comm_t *c, void *buf, int64_t n, int dtype, cons
 {
    if (!c) return sb::api_fail(SBGPU_EINVAL, std::string(who) + ": null comm");
    if (n < 0 || (n > 0 && !buf) || (size_t)n * 8 > kScratchBytes) return sb::api_fail(SBGPU_EINVAL, std::string(who) + ": 0 <= n <= 512 values");
-   if (c->world == 1 || n == 0) return SBGPU_OK;
+   if (!c->comm || n == 0) return SBGPU_OK;
    hipError_t e = hipSetDevice(c->device);
    if (e == hipSuccess) e = hipMemcpyAsync(c->d_scratch, buf, (size_t)n * 8, hipMemcpyHostToDevice, c->stream);
    if (e != hipSuccess) return sb::api_fail(SBGPU_EHIP, std::string(who) + ": " + hipGetErrorString(e));

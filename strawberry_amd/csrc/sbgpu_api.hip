@@ -207,21 +207,32 @@ hipError_t dev_take(size_t bytes, char **out, size_t *capacity)
 void dev_give(char *block, size_t capacity)
 {
    if (!block) return;
+   // The block belongs to the device it was allocated on, whichever device is current in the calling thread (a process
+   // that drives several GPUs destroys handles while another device is current): ask the runtime, wait for THAT device,
+   // pool the block under it, and leave the caller's current device as it was.
+   int current = 0, owner = -1;
+   const bool have_current = hipGetDevice(&current) == hipSuccess;
+   hipPointerAttribute_t attr;
+   if (hipPointerGetAttributes(&attr, block) == hipSuccess) owner = attr.device;
+   else (void)hipGetLastError();
+   if (owner < 0) owner = have_current ? current : 0;
+   const bool switched = have_current && owner != current && hipSetDevice(owner) == hipSuccess;
    // hipFree waits for the device before it lets memory go, and callers have relied on that (a handle destroyed while a
    // kernel on the CALLER's stream still reads its arena): a block that goes back to the pool waits the same way.  On an
    // idle device -- every call site has synchronised its own stream already -- this costs ~10 us.
    (void)hipDeviceSynchronize();
-   int device = 0;
-   if (hipGetDevice(&device) == hipSuccess) {
+   bool pooled = false;
+   {
       DevPool &pool = dev_pool();
       std::lock_guard<std::mutex> g(pool.m);
       if (pool.blocks.size() < 8 && pool.bytes + capacity <= ((size_t)4 << 30)) {
-         pool.blocks.push_back({block, capacity, device});
+         pool.blocks.push_back({block, capacity, owner});
          pool.bytes += capacity;
-         return;
+         pooled = true;
       }
    }
-   (void)hipFree(block);
+   if (!pooled) (void)hipFree(block);
+   if (switched) (void)hipSetDevice(current);
 }
 const ResidentAnnotation *ctx_resident_annotation(const sbgpu_ctx_t *ctx) { return ctx->resident; }
 void ctx_set_resident_annotation(sbgpu_ctx_t *ctx, ResidentAnnotation *r)

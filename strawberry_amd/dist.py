@@ -116,11 +116,13 @@ class AbiComm:
         ident = None
         if self.world > 1:
             buf = (C.c_uint8 * 128)()
+            # what travels: ONE status byte (1 = an id follows, 0 = an error message follows) + the payload.  A failure on
+            # rank 0 must still reach the broadcast below, or the other ranks wait for it forever -- and it must not be
+            # inferred from the payload's length (a 127-byte message is not an id).
             raw = b""
             if self.rank == 0:
-                # a failure here must still reach the broadcast below, or the other ranks wait for it forever
                 rc = self.L.sbgpu_comm_unique_id(buf)
-                raw = bytes(buf) if rc == 0 else b"!" + (self.L.sbgpu_last_error() or b"sbgpu_comm_unique_id failed")
+                raw = (b"\x01" + bytes(buf)) if rc == 0 else b"\x00" + (self.L.sbgpu_last_error() or b"sbgpu_comm_unique_id failed")
             if broadcast_id is None:
                 import torch.distributed as dist
                 box = [raw]
@@ -128,12 +130,22 @@ class AbiComm:
                 raw = box[0]
             else:
                 raw = broadcast_id(raw)
-            if len(raw) != 128:
+            if raw[:1] != b"\x01":
                 raise _lib.SbgpuError("rank 0 could not make an RCCL id: " + raw[1:].decode(errors="replace"))
-            ident = (C.c_uint8 * 128).from_buffer_copy(raw)
+            if len(raw) != 129:
+                raise _lib.SbgpuError("the RCCL id arrived with %d bytes instead of 128" % (len(raw) - 1))
+            ident = (C.c_uint8 * 128).from_buffer_copy(raw[1:])
         h = C.c_void_p()
         _lib.check(self.L.sbgpu_comm_init(ctx.h, self.rank, self.world, ident, C.byref(h)), "sbgpu_comm_init")
         self.h = h
+
+    def rccl_ranks(self):
+        """Ranks in the RCCL communicator behind this one (ncclCommCount); 0: a world of one that never opened RCCL."""
+        import ctypes as C
+        from . import _lib
+        n = C.c_int(-1)
+        _lib.check(self.L.sbgpu_comm_rccl_ranks(self.h, C.byref(n)), "sbgpu_comm_rccl_ranks")
+        return int(n.value)
 
     def allreduce_sum_(self, tensor):
         """In place, on the tensor's device buffer, asynchronous on torch's current stream."""

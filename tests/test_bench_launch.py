@@ -27,6 +27,8 @@ def test_gpus_2_launches_two_ranks_itself():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["rank_sum"] == 1
     assert out["max_over_ranks"] == 2.0 and out["steps"] == 3 and out["warmup"] == 1
+    # the headline at N > 1 is BASELINE config 3: ONE problem, loci sharded over the ranks
+    assert out["scaling"] == "strong"
 
 
 def test_world_size_that_differs_from_gpus_fails_loudly():

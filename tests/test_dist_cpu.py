@@ -95,3 +95,20 @@ def test_two_rank_gloo_tpm_equals_single_process(tmp_path, oracle):
             got[b.iso_off[l]:b.iso_off[l + 1]] = z["tpm"][z["iso_off"][pos]:z["iso_off"][pos] + n]
     assert not np.isnan(got).any()
     np.testing.assert_allclose(got, tpm, rtol=1e-12, atol=0)
+
+
+def test_abi_comm_id_broadcast_carries_an_explicit_status():
+    """Rank 0's id (or its failure) travels as status byte + payload; a receiver never infers failure from the length:
+    an error message of exactly 127 bytes used to pass as an id and went into sbgpu_comm_init."""
+    import pytest
+    from strawberry_amd import _lib, dist
+
+    class NoCtx:        # never reached: the payload is refused before the communicator is made
+        h = None
+
+    with pytest.raises(_lib.SbgpuError, match="could not make an RCCL id: " + "x" * 127):
+        dist.AbiComm(NoCtx(), rank=1, world=2, broadcast_id=lambda raw: b"\x00" + b"x" * 127)
+    with pytest.raises(_lib.SbgpuError, match="arrived with 5 bytes"):
+        dist.AbiComm(NoCtx(), rank=1, world=2, broadcast_id=lambda raw: b"\x01" + b"short")
+    with pytest.raises(_lib.SbgpuError, match="could not make an RCCL id"):
+        dist.AbiComm(NoCtx(), rank=1, world=2, broadcast_id=lambda raw: b"")

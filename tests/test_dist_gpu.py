@@ -91,3 +91,49 @@ def test_abi_comm_world_of_one_and_bad_arguments():
     buf = (C.c_uint8 * 128)()
     assert L.sbgpu_comm_unique_id(buf) == 0 and any(buf)
     comm.close()
+
+
+def test_rccl_runs_at_world_one_when_forced(tmp_path):
+    """SBGPU_COMM_FORCE_RCCL=1: a world of ONE goes through the same RCCL calls as a world of eight -- dlopen(librccl.so),
+    ncclGetUniqueId, ncclCommInitRank(1), ncclAllReduce of an f64 and an i64 buffer on a NON-default stream, the host-buffer
+    forms, ncclCommCount -- so the C-ABI collective is executed code before an 8-GPU node ever runs it.  In a child
+    process: the variable is read when the communicator is made, and RCCL stays loaded for the life of a process."""
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent("""
+        import ctypes as C, os, sys
+        sys.path.insert(0, %r)
+        import torch
+        from strawberry_amd import _lib, dist, em
+        ctx = em.default_context(0)
+        comm = dist.AbiComm(ctx, rank=0, world=1)
+        assert comm.rccl_ranks() == 1, comm.rccl_ranks()            # a real RCCL communicator of one rank
+        L = _lib.load()
+        rank, world = C.c_int(-1), C.c_int(-1)
+        assert L.sbgpu_comm_info(comm.h, C.byref(rank), C.byref(world)) == 0 and (rank.value, world.value) == (0, 1)
+        side = torch.cuda.Stream(device="cuda:0")
+        with torch.cuda.stream(side):
+            x = torch.arange(1, 1025, dtype=torch.float64, device="cuda:0") * 0.5
+            n = torch.tensor([7, -3, 1 << 40], dtype=torch.int64, device="cuda:0")
+            for _ in range(3):
+                comm.allreduce_sum_(x)
+                comm.allreduce_sum_(n)
+        side.synchronize()
+        assert x.tolist() == [0.5 * k for k in range(1, 1025)] and n.tolist() == [7, -3, 1 << 40]
+        hf = (C.c_double * 2)(1.25, -2.5)
+        hi = (C.c_int64 * 2)(5, 1 << 50)
+        _lib.check(L.sbgpu_allreduce_sum_f64_host(comm.h, hf, 2), "f64_host")
+        _lib.check(L.sbgpu_allreduce_sum_i64_host(comm.h, hi, 2), "i64_host")
+        assert list(hf) == [1.25, -2.5] and list(hi) == [5, 1 << 50]
+        comm.close()
+        print("rccl world-1 ok")
+    """ % ROOT)
+    env = dict(os.environ, SBGPU_COMM_FORCE_RCCL="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl world-1 ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+    # and without the variable a world of one opens no RCCL at all
+    from strawberry_amd import dist, em
+    comm = dist.AbiComm(em.default_context(0), rank=0, world=1)
+    assert comm.rccl_ranks() == 0
+    comm.close()
