@@ -240,7 +240,8 @@ class ChainQuantifier:
             _lib.check(ctx.L.sbgpu_annotation_pin(ctx.h, C.byref(self._an)), "sbgpu_annotation_pin")
 
     def step(self, keep=False):
-        """keep=True: -> (LocusBins, F) of this step's handle (exported to the host: tests compare them with the oracle's)."""
+        """keep=True: -> the LocusBins of this step's handle, exported to the host (tests compare them with the oracle's;
+        the weights of the device entry stay in HBM -- sbgpu_quantify_host on the same hits returns them)."""
         h = C.c_void_p()
         L = self.ctx.L
         _lib.check(L.sbgpu_quantify_device(self.ctx.h, C.byref(self._an), C.byref(self._ht), self.hits.mass.data_ptr(),
@@ -252,11 +253,9 @@ class ChainQuantifier:
             _lib.check(L.sbgpu_bins_info(h, info), "sbgpu_bins_info")
             self.info = {"n_bins": int(info[2]), "n_elem": int(info[3]), "n_pairs": int(info[4]), "hits_in_bins": int(info[6])}
         if keep:
-            F = np.zeros(max(self.info["n_elem"], 1), np.float64)
-            _lib.check(L.sbgpu_bins_export_weights(h, F.ctypes.data), "sbgpu_bins_export_weights")
             bins = eb.LocusBins.__new__(eb.LocusBins)
             bins._export(L, self.annot, h, self.n_hits, self.annot.compat_words, self.annot.key_words, with_hit_bin=False)   # destroys the handle
-            return bins, F[:self.info["n_elem"]]
+            return bins
         L.sbgpu_bins_destroy(h)
 
     def stage_ms(self):

@@ -30,7 +30,11 @@ struct BinWeightArgs {
    const double *pdf;             // pdf[fl], fl in [0, pdf_len)
    double *out;
    int32_t pdf_len;
-   const int32_t *pdf_support;    // [2] first and last fl with pdf[fl] != 0 (pdf_support_kernel): the terms outside are exact zeros and are skipped
+   // [5] pdf_support_kernel: [0], [1] first and last fl with pdf[fl] != 0 -- the terms outside are exact zeros and are skipped;
+   // [2], [3] first and last fl with pdf[fl] >= kBwTiny; [4] != 0: a tiny non-zero density lies strictly between them.
+   // A pair whose fragment lengths stay inside [2]..[3] (and [4] == 0) cannot produce a subnormal intermediate; the
+   // others take the loop that flushes them like the reference's FTZ arithmetic does.
+   const int32_t *pdf_support;
    int32_t read_len;              // rl = read_len_mode()
    int32_t lmin_base;             // _use_emp ? _start_offset : rl   (estimate.cpp:214-219)
    int32_t long_read;             // set_bin_weight_without_frag_dist: F = 1/L (estimate.cpp:236-247)
@@ -150,26 +154,56 @@ __device__ __forceinline__ double bw_div(double n, double d)
    return __builtin_fma(__builtin_fma(-d, q, n), r, q);
 }
 
-// first and last index of a non-zero density (one workgroup); an all-zero table gives the empty range [1, 0]
+// A density at or above this cannot lead to a subnormal product or quotient: pdf * eff >= pdf (eff >= 1, or the term is an
+// exact 0), and the quotient by L - fl + 1 < 2^31 stays above 1e-290.
+constexpr double kBwTiny = 1e-280;
+// The reference is built -Ofast: FTZ / DAZ.  Its term `pdf * le_eff / (L - fl + 1)` (estimate.cpp:225) is flushed to 0 where
+// the product or the quotient comes out subnormal; the sum of the (normal or zero) terms is subnormal only through a cancellation of two of them that the tests have never seen.
+// Only densities below 1e-290 -- a fragment length some thirty standard deviations out -- get there, but a weight that is
+// exactly 0 in the reference must not be 1e-310 here (the -f table prints it).
+__device__ __forceinline__ double bw_flush(double x) { return __builtin_fabs(x) < 2.2250738585072014e-308 ? 0.0 : x; } // (an effective length can be negative: isoform.h:105-129)
+
+// first and last index of a non-zero density, and of a density >= kBwTiny (one workgroup); an all-zero table gives the
+// empty ranges [1, 0]
 __global__ __launch_bounds__(256) void pdf_support_kernel(const double *pdf, int n, int32_t *out)
 {
-   __shared__ int lo, hi;
-   if (threadIdx.x == 0) lo = 0x7fffffff, hi = -1;
+   __shared__ int lo, hi, blo, bhi, inner;
+   if (threadIdx.x == 0) lo = blo = 0x7fffffff, hi = bhi = -1, inner = 0;
    __syncthreads();
-   int mylo = 0x7fffffff, myhi = -1;
-   for (int i = threadIdx.x; i < n; i += 256)
-      if (pdf[i] != 0.0) {
+   int mylo = 0x7fffffff, myhi = -1, myblo = 0x7fffffff, mybhi = -1;
+   for (int i = threadIdx.x; i < n; i += 256) {
+      const double v = pdf[i];
+      if (v != 0.0) {
          mylo = min(mylo, i);
          myhi = max(myhi, i);
       }
+      if (v >= kBwTiny) {
+         myblo = min(myblo, i);
+         mybhi = max(mybhi, i);
+      }
+   }
    if (myhi >= 0) {
       atomicMin(&lo, mylo);
       atomicMax(&hi, myhi);
    }
+   if (mybhi >= 0) {
+      atomicMin(&blo, myblo);
+      atomicMax(&bhi, mybhi);
+   }
+   __syncthreads();
+   int tiny_inside = 0;
+   for (int i = threadIdx.x; i < n; i += 256) {
+      const double v = pdf[i];
+      if (v != 0.0 && v < kBwTiny && i > blo && i < bhi) tiny_inside = 1;
+   }
+   if (tiny_inside) atomicOr(&inner, 1);
    __syncthreads();
    if (threadIdx.x == 0) {
       out[0] = hi >= 0 ? lo : 1;
       out[1] = hi >= 0 ? hi : 0;
+      out[2] = bhi >= 0 ? blo : 1;
+      out[3] = bhi >= 0 ? bhi : 0;
+      out[4] = inner;
    }
 }
 
@@ -187,8 +221,9 @@ __global__ __launch_bounds__(64) void binweight_kernel(BinWeightArgs a)
    __shared__ int s_SL[kBinWeightMaxSeg], s_SR[kBinWeightMaxSeg];
    const int lane = threadIdx.x;
    // IEEE mode on purpose: the fp64 division below needs denormal support to be exact.
-   // The reference's FTZ arithmetic is mirrored where it is observable, in the pdf table
-   // (subnormal densities are 0, sbgpu_insert_pdf_table).
+   // The reference's FTZ arithmetic is mirrored where it is observable: in the pdf table
+   // (subnormal densities are 0, sbgpu_insert_pdf_table) and, for the pairs whose fragment
+   // lengths reach the table's tiny tail, term by term (bw_flush).
    // One wave per pair, lanes over the fragment lengths -- but a wave takes a BATCH of 64 consecutive pairs: lane i
    // reads pair i's description (offsets, isoform length, implicit mask, target, its first four segment lengths) with
    // coalesced loads, two round trips for the 64 pairs, and the pairs are then served one after the other from those
@@ -225,9 +260,16 @@ __global__ __launch_bounds__(64) void binweight_kernel(BinWeightArgs a)
             int lmin = a.lmin_base;                // estimate.cpp:214-219
             if (nseg > 2) lmin = max(lmin, inner); // :220-221
             const int f0 = max(lmin, a.pdf_support[0]), f1 = min(lmax, a.pdf_support[1]);
-            for (int fl = f0 + lane; fl <= f1; fl += 64) { // :223-227, lanes over fl
-               const int e = effective_len(s4, (const int *)nullptr, (const int *)nullptr, nseg, imask, nimp, inner, fl, a.read_len);
-               acc += bw_div(a.pdf[fl] * (double)e, (double)(L - fl + 1));
+            if (f0 >= a.pdf_support[2] && f1 <= a.pdf_support[3] && !a.pdf_support[4]) {
+               for (int fl = f0 + lane; fl <= f1; fl += 64) { // :223-227, lanes over fl
+                  const int e = effective_len(s4, (const int *)nullptr, (const int *)nullptr, nseg, imask, nimp, inner, fl, a.read_len);
+                  acc += bw_div(a.pdf[fl] * (double)e, (double)(L - fl + 1));
+               }
+            } else { // fragment lengths in the table's tiny tail: subnormal intermediates are flushed like the reference's
+               for (int fl = f0 + lane; fl <= f1; fl += 64) {
+                  const int e = effective_len(s4, (const int *)nullptr, (const int *)nullptr, nseg, imask, nimp, inner, fl, a.read_len);
+                  acc += bw_flush(bw_div(bw_flush(a.pdf[fl] * (double)e), (double)(L - fl + 1)));
+               }
             }
             acc = wave_group_sum<64>(acc);
          } else {
@@ -256,9 +298,16 @@ __global__ __launch_bounds__(64) void binweight_kernel(BinWeightArgs a)
             int lmin = a.lmin_base;                // estimate.cpp:214-219
             if (nseg > 2) lmin = max(lmin, inner); // :220-221
             const int f0 = max(lmin, a.pdf_support[0]), f1 = min(lmax, a.pdf_support[1]);
-            for (int fl = f0 + lane; fl <= f1; fl += 64) { // :223-227, lanes over fl
-               const int e = effective_len((const uint32_t *)s_seg, s_SL, s_SR, nseg, imask, nimp, inner, fl, a.read_len);
-               acc += bw_div(a.pdf[fl] * (double)e, (double)(L - fl + 1));
+            if (f0 >= a.pdf_support[2] && f1 <= a.pdf_support[3] && !a.pdf_support[4]) {
+               for (int fl = f0 + lane; fl <= f1; fl += 64) { // :223-227, lanes over fl
+                  const int e = effective_len((const uint32_t *)s_seg, s_SL, s_SR, nseg, imask, nimp, inner, fl, a.read_len);
+                  acc += bw_div(a.pdf[fl] * (double)e, (double)(L - fl + 1));
+               }
+            } else { // (see above)
+               for (int fl = f0 + lane; fl <= f1; fl += 64) {
+                  const int e = effective_len((const uint32_t *)s_seg, s_SL, s_SR, nseg, imask, nimp, inner, fl, a.read_len);
+                  acc += bw_flush(bw_div(bw_flush(a.pdf[fl] * (double)e), (double)(L - fl + 1)));
+               }
             }
             // wave sum (order differs from the reference's sequential loop by rounding only)
             acc = wave_group_sum<64>(acc);

@@ -68,7 +68,7 @@ struct sbgpu_ctx {
    // tens to hundreds of milliseconds): sb::ctx_scratch
    char *scratch[8] = {};
    size_t scratch_bytes[8] = {};
-   int32_t *d_pdf_support = nullptr; // [2] device: support of the insert-size table of the bin-weight launch in flight
+   int32_t *d_pdf_support = nullptr; // [5] device: support of the insert-size table of the bin-weight launch in flight (pdf_support_kernel)
    int32_t *wide_error = nullptr; // pinned host word the wide-locus kernel raises when a barrier times out
    // kernel stages of the chain entry points, bracketed by events while `timing` is on (sb::ctx_stage_begin / _end)
    static constexpr int kMaxStages = 16;
@@ -540,7 +540,7 @@ int sbgpu_init(int device, sbgpu_ctx_t **ctx_out)
       if (e == hipSuccess) e = hipEventCreateWithFlags(&c->join[i], hipEventDisableTiming);
    }
    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
-   if (e == hipSuccess) e = hipMalloc((void **)&c->d_pdf_support, 2 * sizeof(int32_t));
+   if (e == hipSuccess) e = hipMalloc((void **)&c->d_pdf_support, 8 * sizeof(int32_t));
    if (e == hipSuccess) e = hipHostMalloc((void **)&c->wide_error, sizeof(int32_t), hipHostMallocDefault);
    if (e == hipSuccess) *c->wide_error = 0;
    for (int k = 0; e == hipSuccess && k < sb::kNumKinds; ++k) {

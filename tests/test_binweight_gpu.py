@@ -19,13 +19,38 @@ def ctx():
 
 
 def check(w, ref, rtol=RTOL):
-    """Weights below 1e-280 are far-tail products around the subnormal range, where the
-    reference (built -Ofast: FTZ/DAZ) and IEEE arithmetic may round differently or disagree on
-    being 0; everything else must agree to `rtol`."""
-    big = np.abs(ref) > 1e-280
-    assert (np.abs(w[~big]) < 1e-270).all()
-    err = np.abs(w[big] - ref[big]) / np.abs(ref[big])
-    assert err.max() < rtol, (err.max(), int(np.nonzero(big)[0][err.argmax()]))
+    """Every weight, the far tail included: the reference is built -Ofast (FTZ / DAZ), so a term whose product or
+    quotient comes out subnormal is 0 there; the kernel flushes the same terms (bw_flush).  A weight that is exactly 0 in
+    the reference is exactly 0 here; the others agree to `rtol`."""
+    nz = ref != 0
+    assert ((w != 0) == nz).all(), int(np.nonzero((w != 0) != nz)[0][0])
+    err = np.abs(w[nz] - ref[nz]) / np.abs(ref[nz])
+    assert err.max() < rtol, (err.max(), int(np.nonzero(nz)[0][err.argmax()]))
+
+
+def test_binweight_far_tail_is_flushed_like_the_reference(ctx, oracle):
+    """Bins over long segments: fragment lengths thirty and more standard deviations out, densities from 1e-280 down to the
+    smallest normal and below.  The oracle runs with FTZ (liboracle.so is built -Ofast like the reference); the kernel
+    agrees on every weight to 1e-12 and on which weights are exact zeros."""
+    from strawberry_amd.binweight import InsertSize, bin_weights, pack_pairs
+    rng = np.random.Generator(np.random.PCG64(77))
+    segs, imps, lens = [], [], []
+    for _ in range(3000):
+        nseg = int(rng.integers(2, 9))
+        s = rng.integers(50, 420, nseg)
+        # the inner segments are implicit (the mates' gap swallows them): lmin = their sum, hundreds to thousands of bases
+        imp = list(range(1, nseg - 1)) if rng.random() < 0.8 else sorted(rng.choice(np.arange(1, nseg - 1), max(0, nseg - 3), replace=False).tolist()) if nseg > 3 else []
+        segs.append(s)
+        imps.append(imp)
+        lens.append(int(s.sum() + rng.integers(0, 1500)))
+    seg_off, seg_lens, mask = pack_pairs(segs, imps)
+    for rl, mean, sd in ((75, 250.0, 30.0), (50, 200.0, 20.0)):
+        w = bin_weights(seg_off, seg_lens, mask, lens, InsertSize(mean, sd), rl, ctx=ctx)
+        ins = oracle.make_insert(mean, sd)
+        ref = np.array([oracle.bin_weight(s, i, L, rl, ins) for s, i, L in zip(segs, imps, lens)])
+        tiny = (ref != 0) & (ref < 1e-280)
+        assert tiny.sum() >= 5 and (ref == 0).sum() >= 50 and (ref > 1e-200).sum() >= 50, (int(tiny.sum()), int((ref == 0).sum()))
+        check(w, ref, 1e-12)
 
 
 def test_binweight_matches_reference_goldens(ctx):

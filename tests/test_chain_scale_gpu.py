@@ -118,18 +118,29 @@ def test_chain_sample_every_locus_against_the_oracle_chain(oracle):
     from strawberry_amd import exonbin as eb
     ctx = em.default_context(0)
     threads = min(32, os.cpu_count() or 1)
+    from strawberry_amd.quantify import InsertSize, quantify_host
     with chain.ChainQuantifier(ctx, n_loci=N_LOCI, n_frags=N_FRAGS, seed=41, pin=True) as q:
-        bins, F = q.step(keep=True)
+        bins = q.step(keep=True)                      # sbgpu_quantify_device: hits resident in HBM
         theta, status, iters = q.theta[:q.n_iso].copy(), q.status[:q.n_loci].copy(), q.iters[:q.n_loci].copy()
         hits = q.hits.host_hits(q.n_loci)
         annot = q.annot
         n_frags = q.n_frags
+        # the same hits through the host entry (same kernels; it also returns the words per hit and the weights, which the
+        # device entry leaves in HBM): the two entries agree bit for bit
+        r = quantify_host(annot, hits, InsertSize(MEAN, SD), RL, ctx=ctx)
+    np.testing.assert_array_equal(r["theta"], theta)
+    np.testing.assert_array_equal(r["status"], status)
+    np.testing.assert_array_equal(r["iters"], iters)
+    np.testing.assert_array_equal(r["bins"].count, bins.count)
+    np.testing.assert_array_equal(r["bins"].bin_key, bins.bin_key)
+    F = r["F"]
     assert annot.n_loci == N_LOCI >= 6000 or "SB_CHAIN_TEST_LOCI" in os.environ
     assert n_frags >= 2e7 or "SB_CHAIN_TEST_FRAGS" in os.environ
     assert annot.compat_words == 1 and annot.key_words == 1
 
     # ---- stage 1 + 2: words from the oracle, grouped by the numpy restatement; the device chain's bins must be these
     o_compat, o_key = oracle.exonbin_batch(annot, hits)
+    np.testing.assert_array_equal(r["compat"], o_compat)          # every hit's compatibility word
     row_off, bin_key, bin_compat, count, used = numpy_grouping(annot, hits, o_compat, o_key)
     np.testing.assert_array_equal(bins.row_off, row_off)
     np.testing.assert_array_equal(bins.bin_key[:, 0], bin_key)
