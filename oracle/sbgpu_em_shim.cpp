@@ -13,9 +13,25 @@
 // stores the solution in the private members the class already has.
 #include "estimate.hpp" // the reference's: /root/reference/include/estimate.hpp:225-257
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 #include "sbgpu_host.hpp"
 
 namespace {
+// SBGPU_DROPIN_TIMING=1: the wall time spent inside the per-locus device calls, reported when the program ends
+// (tools/dropin_timing.py puts it beside the batched drop-in's one call)
+struct SeamClock {
+   double seconds = 0.0;
+   long long calls = 0;
+   ~SeamClock()
+   {
+      const char *t = std::getenv("SBGPU_DROPIN_TIMING");
+      if (t && t[0] == '1')
+         std::fprintf(stderr, "sbgpu per-locus seam: %lld EmSolver::init calls (one plan + upload + launch + synchronise each), %.3f s inside them\n", calls, seconds);
+   }
+} seam_clock;
 const sbgpu::Context &device_context()
 {
    static const sbgpu::Context ctx(0); // throws (no CPU fallback) when there is no gfx950 device
@@ -26,8 +42,11 @@ const sbgpu::Context &device_context()
 // estimate.hpp:241-243.  The device solves the locus here; _theta holds theta_0 until run(), as in the reference.
 bool EmSolver::init(const int num_iso, const std::vector<int> &count, const std::vector<std::vector<double>> &model)
 {
+   const auto t0 = std::chrono::steady_clock::now();
    sbgpu::EmSolver solver(device_context());
    const bool ok = solver.init(num_iso, count, model);
+   seam_clock.seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+   ++seam_clock.calls;
    _theta = solver._theta;                       // theta_0 (estimate.cpp:374-375)
    const bool ran = ok && solver.run();
    _theta_after_zero = solver._theta;            // the solution (or theta_0 again after a zero denominator)

@@ -20,6 +20,11 @@ import e2e_util as U
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_DIR = os.path.join(ROOT, "oracle", "_ref")
 DRIVER = os.path.join(REF_DIR, "strawberry_sbgpu")
+# the BATCHED drop-in (oracle/sbgpu_batched_shim.cpp): Sample::procSample replaced as well -- clusters collected with the
+# reference's own classes, ONE sbgpu_em_batch call for the whole sample, then the reference's epilogue in cluster order
+BATCHED = os.path.join(REF_DIR, "strawberry_sbgpu_batched")
+# the same restructured loop with the reference's own EmSolver bodies doing the solve: no GPU in it (the CPU suite's check)
+BATCHED_REFEM = os.path.join(REF_DIR, "strawberry_batched_refem")
 SAM2BAM = os.path.join(REF_DIR, "sam2bam")
 RL = 75
 
@@ -41,9 +46,9 @@ RUNS = {
 ASSEMBLY_MODE = {"E2E_ASSEMBLY"}
 
 
-def need_driver():
-    if not (os.path.exists(DRIVER) and os.path.exists(SAM2BAM)):
-        pytest.skip("oracle/_ref/strawberry_sbgpu not built (`make -C oracle ref` where /root/reference is mounted)")
+def need_driver(driver=DRIVER):
+    if not (os.path.exists(driver) and os.path.exists(SAM2BAM)):
+        pytest.skip("oracle/_ref/%s not built (`make -C oracle ref` where /root/reference is mounted)" % os.path.basename(driver))
 
 
 def cigar(blocks):
@@ -85,14 +90,14 @@ def write_sam(directory, path):
     return len(recs)
 
 
-def run_driver(which, tmp_path):
+def run_driver(which, tmp_path, driver=DRIVER):
     directory, extra, insert = RUNS[which]
     sam, bam = str(tmp_path / "toy.sam"), str(tmp_path / "toy.bam")
     n = write_sam(directory, sam)
     assert ("%d read records" % n) in open(os.path.join(directory, "README.txt")).read()     # the golden run's input
     subprocess.check_call([SAM2BAM, sam, bam])
     annot = [] if which in ASSEMBLY_MODE else ["-g", os.path.join(directory, "toy.gtf"), "-r"]
-    cmd = [DRIVER, bam] + annot + (["-i", "250/30"] if insert else []) + [
+    cmd = [driver, bam] + annot + (["-i", "250/30"] if insert else []) + [
         "-o", str(tmp_path / "out.gtf"), "-T", str(tmp_path / "log.txt"), "-f", str(tmp_path / "ctx.tsv")] + extra
     return subprocess.run(cmd, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
 
@@ -108,12 +113,8 @@ def test_reference_driver_over_libsbgpu_has_no_cpu_path(tmp_path):
     assert r.returncode != 0 and "sbgpu_init" in (r.stderr + r.stdout)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("which", sorted(RUNS))
-def test_reference_driver_over_libsbgpu_reproduces_reference_files(which, tmp_path):
-    need_driver()
+def check_files(which, tmp_path, r, log_in_locus_order=True):
     directory = RUNS[which][0]
-    r = run_driver(which, tmp_path)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     for name in ("out.gtf", "ctx.tsv"):
         # (the GTF's first line is a comment holding the program's own command line, temporary paths included)
@@ -123,4 +124,32 @@ def test_reference_driver_over_libsbgpu_reproduces_reference_files(which, tmp_pa
     # the theta lines of the reference's log (estimate.cpp:312) as well
     want = open(os.path.join(directory, "theta_log.txt")).read()
     got = "".join(l for l in open(str(tmp_path / "log.txt")) if "raw read count" in l or "not compatible" in l)
+    if not log_in_locus_order:
+        # the batched loop builds every LocusContext (whose constructor logs the rejected pairs, estimate.hpp:74-76) before the
+        # first locus is solved: the same lines, the "not compatible" ones ahead of the theta lines instead of between them
+        order = lambda text: "".join(sorted(text.splitlines(True), key=lambda l: "raw read count" in l))  # noqa: E731 (stable)
+        want, got = order(want), order(got)
     assert got == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", sorted(RUNS))
+def test_reference_driver_over_libsbgpu_reproduces_reference_files(which, tmp_path):
+    need_driver()
+    check_files(which, tmp_path, run_driver(which, tmp_path))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", sorted(RUNS))
+def test_batched_reference_driver_reproduces_reference_files(which, tmp_path):
+    """collect -> ONE sbgpu_em_batch -> epilogue under the reference's own main: same files, byte for byte."""
+    need_driver(BATCHED)
+    check_files(which, tmp_path, run_driver(which, tmp_path, BATCHED), log_in_locus_order=False)
+
+
+@pytest.mark.parametrize("which", sorted(RUNS))
+def test_batched_loop_by_itself_reproduces_reference_files(which, tmp_path):
+    """The restructured loop with the REFERENCE's EmSolver doing the solve (no GPU): what the replacement of
+    Sample::procSample changes -- nothing -- checked on the CPU, apart from what the device adds."""
+    need_driver(BATCHED_REFEM)
+    check_files(which, tmp_path, run_driver(which, tmp_path, BATCHED_REFEM), log_in_locus_order=False)
