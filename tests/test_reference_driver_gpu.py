@@ -23,6 +23,9 @@ DRIVER = os.path.join(REF_DIR, "strawberry_sbgpu")
 # the BATCHED drop-in (oracle/sbgpu_batched_shim.cpp): Sample::procSample replaced as well -- clusters collected with the
 # reference's own classes, ONE sbgpu_em_batch call for the whole sample, then the reference's epilogue in cluster order
 BATCHED = os.path.join(REF_DIR, "strawberry_sbgpu_batched")
+# the drop-in ONE LEVEL UP (oracle/sbgpu_chain_shim.cpp): procSample collects every locus' transcripts and unique hits with the
+# reference's classes; ONE sbgpu_quantify_host call does exon bins + bin weights + EM for the whole sample (no LocusContext)
+CHAIN = os.path.join(REF_DIR, "strawberry_sbgpu_chain")
 # the same restructured loop with the reference's own EmSolver bodies doing the solve: no GPU in it (the CPU suite's check)
 BATCHED_REFEM = os.path.join(REF_DIR, "strawberry_batched_refem")
 SAM2BAM = os.path.join(REF_DIR, "sam2bam")
@@ -145,6 +148,17 @@ def test_batched_reference_driver_reproduces_reference_files(which, tmp_path):
     """collect -> ONE sbgpu_em_batch -> epilogue under the reference's own main: same files, byte for byte."""
     need_driver(BATCHED)
     check_files(which, tmp_path, run_driver(which, tmp_path, BATCHED), log_in_locus_order=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", sorted(RUNS))
+def test_chain_level_reference_driver_reproduces_reference_files(which, tmp_path):
+    """The reference's main, BAM decode, clustering, pairing and collapse; bins, weights and EM of ALL loci in one
+    sbgpu_quantify_host call; the reference's print2gtf and the library's -f formatter: same files, byte for byte -- in
+    quant-only mode, with duplicates and multi-mapped reads, the -e filter, empirical insert sizes, both strands, two
+    chromosomes, and in assembly mode (C4: the assembled contigs are the annotation, Frac < 0.01 erased)."""
+    need_driver(CHAIN)
+    check_files(which, tmp_path, run_driver(which, tmp_path, CHAIN), log_in_locus_order=False)
 
 
 @pytest.mark.parametrize("which", sorted(RUNS))
