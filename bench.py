@@ -287,6 +287,13 @@ def chain_leg(args, ctx, dev, rank, world, sdist, torch, strong=False, with_cpu=
     }
     if with_cpu and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"], out["parity"] = chain_cpu_baseline(q)
+    if with_cpu and world == 1 and os.environ.get("SB_CHAIN_PCIE", "1") == "1":
+        # the same sample through the HOST entry (sbgpu_quantify_host): hits in pageable host memory, uploaded inside the call.
+        # Never the headline (`value` is the resident number); reported beside it.
+        pc = q.host_entry(reps=2)
+        pc["note"] = ("sbgpu_quantify_host on the same sample: %.1f GB of hits uploaded from pageable host memory per call, same kernels, "
+                      "theta downloaded; whole call = %.0f ms against %.1f ms with the hits resident" % (pc["hit_bytes"] / 1e9, pc["ms_per_call"], ms))
+        out["pcie_inclusive"] = pc
     return out
 
 

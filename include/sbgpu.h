@@ -568,6 +568,12 @@ void sbgpu_bins_destroy(sbgpu_bins_t *bins);
 /* info: 0 n_loci, 1 n_iso, 2 n_bins, 3 n_elem (= f_off[n_loci]), 4 n_pairs, 5 total pair
  * segments, 6 hits that landed in a bin, 7 key_words.                                      */
 int sbgpu_bins_info(const sbgpu_bins_t *bins, int64_t info[8]);
+/* Which grouping made the handle's bins: *on_device = 1 the device kernels (sbgpu_bins_create_device, or the device stage of
+ * sbgpu_quantify_host / _device), 0 the library's host code (sbgpu_bins_create).  sbgpu_quantify_host takes the host code
+ * when the device form declines (SBGPU_EUNSUPPORTED above); *why_host (optional) then points at the reason, a string owned
+ * by the handle ("" when the host code was simply what the caller called).  The results are the same either way; the
+ * host path is slower, so a caller that cares can tell.                                                              */
+int sbgpu_bins_grouping(const sbgpu_bins_t *bins, int32_t *on_device, const char **why_host);
 /* Copies out what the caller asks for (NULL = skip).  The first five arrays are exactly an
  * sbgpu_batch_t minus F (row_off/iso_off/f_off [n_loci+1], count [n_bins]) plus iso_len
  * [n_iso]; bin_key [n_bins*key_words], bin_compat [n_bins*compat_words], hit_bin [n_hits]

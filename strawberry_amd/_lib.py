@@ -31,7 +31,7 @@ SYMBOLS = [
     "sbgpu_bins_create", "sbgpu_bins_create_device", "sbgpu_bins_destroy", "sbgpu_quantify_host", "sbgpu_quantify_device",
     "sbgpu_annotation_pin", "sbgpu_annotation_unpin",
     "sbgpu_bins_export_weights", "sbgpu_collapse_pairs_host", "sbgpu_uniq_destroy", "sbgpu_uniq_info", "sbgpu_uniq_export",
-    "sbgpu_collapse_pairs_device", "sbgpu_uniq_dev_destroy", "sbgpu_uniq_dev_info", "sbgpu_uniq_dev_hits", "sbgpu_uniq_dev_export", "sbgpu_bins_info", "sbgpu_bins_export",
+    "sbgpu_collapse_pairs_device", "sbgpu_uniq_dev_destroy", "sbgpu_uniq_dev_info", "sbgpu_uniq_dev_hits", "sbgpu_uniq_dev_export", "sbgpu_bins_info", "sbgpu_bins_grouping", "sbgpu_bins_export",
     "sbgpu_format_value", "sbgpu_format_gtf_transcript", "sbgpu_format_context_row", "sbgpu_format_context_row_seq",
     "sbgpu_binseq_device", "sbgpu_binseq_host", "sbgpu_em_batch", "sbgpu_abundance_device", "sbgpu_tpm_device",
 ]
@@ -222,6 +222,7 @@ def load():
     L.sbgpu_bins_destroy.argtypes = [vp]
     L.sbgpu_bins_destroy.restype = None
     L.sbgpu_bins_info.argtypes = [vp, i64p]
+    L.sbgpu_bins_grouping.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_char_p)]
     L.sbgpu_bins_export.argtypes = [vp] * 14
     L.sbgpu_format_value.argtypes = [C.c_double, C.c_char_p]
     L.sbgpu_format_gtf_transcript.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_char, C.c_char_p, C.c_char_p,

@@ -56,7 +56,9 @@ class DeviceSample:
         tot = np.bincount(iso_locus, weights=expr, minlength=n_loci)
         per_locus = np.where(tot > 0, per_locus, 0)           # a locus of short isoforms only has no pairs
         share = np.cumsum(expr) - np.repeat(np.concatenate([[0], np.cumsum(tot)[:-1]]), np.diff(a.iso_off))
-        share = share / np.maximum(tot[iso_locus], 1e-300)    # cumulative within the locus, last = 1
+        # cumulative within the locus, last = 1.  (The two running sums above cancel to within 1e-11 only: a locus without
+        # expression must not turn that residue into a huge number -- `key` below has to stay sorted.)
+        share = np.clip(np.where(tot[iso_locus] > 0, share / np.maximum(tot[iso_locus], 1e-300), 0.0), 0.0, 1.0)
         last = np.zeros(n_iso, bool)
         last[a.iso_off[1:][np.diff(a.iso_off) > 0] - 1] = True
         share[last] = 1.0
@@ -191,6 +193,8 @@ class DeviceSample:
         del fleft, fright
         self.mass = mass
         self.n_fragments = int(mass.sum().item())     # read pairs behind the unique hits
+        if n_ok > 1 and not bool((d_locus[1:] >= d_locus[:-1]).all().item()):
+            raise AssertionError("DeviceSample: the hits are not grouped by locus")
         cnt = torch.bincount(d_locus.to(torch.int64), minlength=n_loci)
         self.locus_hit_off = np.concatenate([[0], np.cumsum(cnt.cpu().numpy())]).astype(np.int64)
         if dev.type == "cuda":
@@ -271,6 +275,35 @@ class ChainQuantifier:
             return {names[i].decode(): float(ms[i]) for i in range(n)}
         finally:
             L.sbgpu_set_timing(self.ctx.h, 0)
+
+    def host_entry(self, reps=2):
+        """The PCIe-inclusive form of the same call: the sample's hits brought to PAGEABLE host memory (where a C++ driver holds
+        them) and handed to sbgpu_quantify_host, which uploads them, runs the same kernels and returns theta.  -> dict with
+        the median wall time of `reps` calls (after one warm-up call), the bytes of hits uploaded per call, and whether theta /
+        status / iterations equal the resident call's bit for bit."""
+        import time
+        L = self.ctx.L
+        self.step()
+        want = (self.theta[:self.n_iso].copy(), self.status[:self.n_loci].copy(), self.iters[:self.n_loci].copy())
+        hits = self.hits.host_hits(self.n_loci)
+        a, h = self.annot._struct(), hits._struct()
+        nbytes = sum(getattr(hits, k).nbytes for k in ("hit_locus", "feat_off", "feat_code", "feat_left", "feat_right", "mass"))
+        theta, status, iters = np.zeros(self.n_iso + 1), np.zeros(self.n_loci + 1, np.int32), np.zeros(self.n_loci + 1, np.int32)
+        used = _lib.sbgpu_insert_t()
+        times, on_dev = [], C.c_int32(0)
+        for _ in range(reps + 1):
+            handle = C.c_void_p()
+            t = time.perf_counter()
+            _lib.check(L.sbgpu_quantify_host(self.ctx.h, C.byref(a), C.byref(h), hits.mass.ctypes.data, C.byref(self._ins), self.read_len, 0,
+                                             theta.ctypes.data, status.ctypes.data, iters.ctypes.data, None, C.byref(used),
+                                             C.byref(handle)), "sbgpu_quantify_host")
+            times.append(time.perf_counter() - t)
+            _lib.check(L.sbgpu_bins_grouping(handle, C.byref(on_dev), None), "sbgpu_bins_grouping")
+            L.sbgpu_bins_destroy(handle)
+        ms = float(np.median(times[1:])) * 1e3
+        same = bool((theta[:self.n_iso] == want[0]).all() and (status[:self.n_loci] == want[1]).all() and (iters[:self.n_loci] == want[2]).all())
+        return {"ms_per_call": ms, "first_call_ms": times[0] * 1e3, "hit_bytes": int(nbytes), "GBps_end_to_end": nbytes / ms / 1e6,
+                "grouped_on_device": bool(on_dev.value), "equals_resident_call_bitwise": same}
 
     def finish(self):
         """Release what this object keeps with the (shared) context: the pinned annotation.  The pin is keyed on the

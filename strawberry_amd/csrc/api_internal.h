@@ -180,6 +180,8 @@ int bins_from_groups(const sbgpu_annotation_t *annot, int32_t compat_words, int3
                      sbgpu_bins_t **out);
 const DevicePairs *bins_device_pairs(const sbgpu_bins_t *bins); // nullptr when the pairs live on the host
 void bins_set_weights(sbgpu_bins_t *bins, std::vector<double> &&F);
+void bins_set_grouping(sbgpu_bins_t *bins, bool on_device, const std::string &why_host); // what sbgpu_bins_grouping reports
 void bins_set_hit_bin(sbgpu_bins_t *bins, std::vector<int64_t> &&hit_bin);
+void bins_set_device_hit_bin(sbgpu_bins_t *bins, char *arena, size_t capacity, int64_t n); // hit -> bin left in HBM (the handle owns the arena)
 const double *bins_weights_tail(const sbgpu_bins_t *bins, size_t at); // F.data() + at (the empirical histogram lives there)
 } // namespace sb

@@ -3,6 +3,8 @@
 // what a C / C++ driver calls (include/sbgpu_host.hpp wraps it).
 #include <hip/hip_runtime.h>
 
+#include <climits>
+
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -72,15 +74,6 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
       locus_hit_off.assign(dev_hit_off, dev_hit_off + nl + 1);
       if (locus_hit_off[0] != 0 || locus_hit_off[(size_t)nl] != nh) return api_fail(SBGPU_EINVAL, "sbgpu_quantify_device: locus_hit_off does not cover the hits");
    }
-   for (int64_t h = 0; h < (on_dev ? 0 : nh); ++h) {
-      const int32_t l = hits->hit_locus[h];
-      if (l < 0 || l >= nl) return api_fail(SBGPU_EINVAL, "sbgpu_quantify_host: hit_locus out of range");
-      if (h && l < hits->hit_locus[h - 1]) grouped = false;
-      ++locus_hit_off[(size_t)l + 1];
-   }
-   if (!on_dev)
-      for (int64_t l = 0; l < nl; ++l) locus_hit_off[(size_t)l + 1] += locus_hit_off[(size_t)l];
-
    hipStream_t s = sb::ctx_stream(c);
    const char *timing_env = std::getenv("SBGPU_HOST_TIMING");
    const bool timing = timing_env != nullptr, timing_sync = timing && std::atoi(timing_env) != 2; // diagnostic: stage times on stderr; =2: host clock only, no synchronisation
@@ -94,6 +87,52 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
          t_stage = t;
       }
    };
+   if (!on_dev && nh) {
+      // every hit's locus in range, and the hits grouped by locus?  A pass over 4 bytes per hit (0.7 GB at 1.8e8 hits): split
+      // over a few host threads; the loci's offsets are then binary searches (grouped) or a counting pass (not grouped)
+      const int32_t *hl = hits->hit_locus;
+      const int T = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)16, (int64_t)std::thread::hardware_concurrency(), nh / (1 << 20) + 1}));
+      std::vector<int> bad((size_t)T, 0), unsorted((size_t)T, 0);
+      auto scan = [&](int t) {
+         const int64_t h0 = nh * t / T, h1 = nh * (t + 1) / T;
+         int b = 0, u = 0;
+         int32_t prev = h0 ? hl[h0 - 1] : -1;
+         for (int64_t h = h0; h < h1; ++h) {
+            const int32_t l = hl[h];
+            b |= (l < 0) | (l >= nl);
+            u |= l < prev;
+            // grouped hits: locus k's hits begin where the first locus >= k appears (the thread that sees the step writes the
+            // entries; every step is seen by exactly one thread).  Garbage when the hits turn out not to be grouped: redone below.
+            if (l > prev && !b && prev >= -1)
+               for (int64_t k = (int64_t)prev + 1; k <= l; ++k) locus_hit_off[(size_t)k] = h;
+            prev = l;
+         }
+         bad[(size_t)t] = b, unsorted[(size_t)t] = u;
+      };
+      {
+         std::vector<std::thread> pool;
+         try {
+            for (int t = 1; t < T; ++t) pool.emplace_back(scan, t);
+         } catch (const std::system_error &) { // fewer threads than hoped: the rest is done here
+         }
+         for (int t = (int)pool.size() + 1; t < T; ++t) scan(t);
+         scan(0);
+         for (std::thread &th : pool) th.join();
+      }
+      for (int t = 0; t < T; ++t) {
+         if (bad[(size_t)t]) return api_fail(SBGPU_EINVAL, "sbgpu_quantify_host: hit_locus out of range");
+         if (unsorted[(size_t)t]) grouped = false;
+      }
+      if (grouped) {
+         for (int64_t l = (int64_t)hl[nh - 1] + 1; l <= nl; ++l) locus_hit_off[(size_t)l] = nh; // loci behind the last hit
+      } else {
+         std::fill(locus_hit_off.begin(), locus_hit_off.end(), 0);
+         for (int64_t h = 0; h < nh; ++h) ++locus_hit_off[(size_t)hl[h] + 1];
+         for (int64_t l = 0; l < nl; ++l) locus_hit_off[(size_t)l + 1] += locus_hit_off[(size_t)l];
+      }
+   }
+
+   stage("validate hits");
    // ---- inputs: one arena, one copy per array
    struct Part {
       const void *src;
@@ -120,7 +159,7 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
    }
    const size_t o_compat = total; total += up256(nh1 * 4 * (size_t)cw);
    const size_t o_key = total; total += up256(nh1 * 4 * (size_t)kw);
-   const size_t o_hbin = total; total += up256(nh1 * 8);
+   const size_t o_hbin = total; total += up256(8); // (hit -> bin has an arena of its own where it is made at all)
    const size_t o_span = total; total += up256(nh1 * 8);
    const size_t o_fhash = total; total += up256(nh1 * 4);
    DeviceBuf in;
@@ -178,7 +217,17 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
       d_mass = (const float *)(in.p + parts[12].off);
    }
    uint32_t *d_compat = (uint32_t *)(in.p + o_compat), *d_key = (uint32_t *)(in.p + o_key);
-   int64_t *d_hit_bin = (int64_t *)(in.p + o_hbin);
+   // hit -> bin of the host entry: the handle keeps it in HBM (an arena of its own) and brings it over when an export asks
+   struct ArenaGuard {
+      char *p = nullptr;
+      size_t cap = 0;
+      ~ArenaGuard() { sb::dev_give(p, cap); }
+   } hb_arena;
+   if (!on_dev && nh) {
+      const hipError_t eh = sb::dev_take((size_t)nh * 8, &hb_arena.p, &hb_arena.cap);
+      if (eh != hipSuccess) return api_fail(eh == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("hipMalloc(hit -> bin): ") + hipGetErrorString(eh));
+   }
+   int64_t *d_hit_bin = hb_arena.p ? (int64_t *)hb_arena.p : (int64_t *)(in.p + o_hbin);
    uint64_t *d_span = (uint64_t *)(in.p + o_span);
    uint32_t *d_fhash = (uint32_t *)(in.p + o_fhash);
 
@@ -423,6 +472,12 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
    const bool on_device = rc == SBGPU_OK;
    if (rc == SBGPU_EUNSUPPORTED && on_dev)
       return api_fail(rc, "sbgpu_quantify_device: the device grouping does not cover these hits (unsorted, fractional masses or a locus of thousands of bins): use sbgpu_quantify_host");
+   std::string why_host;
+   if (rc == SBGPU_EUNSUPPORTED || !(grouped && nh)) {
+      // the host code groups (same bins, slower): the handle says so and why (sbgpu_bins_grouping)
+      why_host = !nh ? "no hits" : !grouped ? "the hits are not grouped by locus" : sbgpu_last_error();
+      if (timing && nh) std::fprintf(stderr, "sbgpu_quantify_host: the device grouping declined: %s\n", why_host.c_str());
+   }
    if (rc == SBGPU_EUNSUPPORTED) {
       SB_RC(need_compat());
       key_h.resize(nh1 * (size_t)kw);
@@ -434,6 +489,7 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
       rc = sbgpu_bins_create(an, hits, hit_mass, cw, kw, compat_h.data(), key_h.data(), &bins);
    }
    if (rc != SBGPU_OK) return rc;
+   if (!on_device) sb::bins_set_grouping(bins, false, why_host);
    struct BinsGuard {
       sbgpu_bins_t *b;
       ~BinsGuard() { sbgpu_bins_destroy(b); }
@@ -461,12 +517,7 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
       SB_RC(launch_em(row_off_h.data(), f_off_h.data(), nullptr, count_h.data()));
    }
    download();
-   std::vector<int64_t> hit_bin;
    hipError_t e5 = hipSuccess;
-   if (on_device && nh && !on_dev) { // (device hits: the caller did not ask for 8 bytes per hit over PCIe)
-      hit_bin.resize((size_t)nh);
-      e5 = hipMemcpyAsync(hit_bin.data(), d_hit_bin, (size_t)nh * 8, hipMemcpyDeviceToHost, s);
-   }
    hipError_t e6 = hipStreamSynchronize(s);
    stage("plan + EM + download");
    for (hipError_t x : {e1, e2, e3, e4, e5, e6})
@@ -478,7 +529,10 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
       SB_RC(need_compat());
       if (nh) std::memcpy(compat_out, compat_h.data(), (size_t)nh * cw * 4);
    }
-   if (on_device && nh && !on_dev) sb::bins_set_hit_bin(bins, std::move(hit_bin));
+   if (on_device && nh && !on_dev) { // hit -> bin stays in HBM with the handle (8 bytes per hit cross PCIe on request only)
+      sb::bins_set_device_hit_bin(bins, hb_arena.p, hb_arena.cap, nh);
+      hb_arena.p = nullptr, hb_arena.cap = 0;
+   }
    if (insert_used) {
       *insert_used = ins;
       if (!insert) {
@@ -497,6 +551,7 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
 #undef SB_RC
    guard.b = nullptr;
    *bins_out = bins;
+   stage("results + handle");
    return SBGPU_OK;
 }
 

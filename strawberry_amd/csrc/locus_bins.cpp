@@ -38,6 +38,11 @@ struct sbgpu_bins {
    sb::PodVec<uint32_t> bin_key, bin_compat;
    std::vector<int32_t> iso_len;
    std::vector<int64_t> hit_bin; // global bin of every hit, -1 when it has no compatible isoform
+   // ... or, from the device grouping of sbgpu_quantify_host, still in HBM (8 bytes per hit: it crosses PCIe when an export
+   // asks for it, not before): an arena of its own (sb::dev_take), n_dev_hit_bin entries
+   char *dev_hit_bin = nullptr;
+   size_t dev_hit_bin_cap = 0;
+   int64_t n_dev_hit_bin = 0;
    std::vector<int64_t> pair_seg_off, pair_out_index;
    std::vector<uint32_t> pair_seg_lens, pair_mask;
    std::vector<int32_t> pair_iso_len;
@@ -46,10 +51,15 @@ struct sbgpu_bins {
    bool pairs_on_device = false, pairs_downloaded = false;
    sb::DeviceBinArrays dev_bins; // device grouping: count / key / compat stay on the device until an export asks for them
    bool bins_downloaded = false;
+   // how the hits were grouped (sbgpu_bins_grouping): on the device, or by the host code -- and then why the device form
+   // was not used (empty: nobody asked it, e.g. sbgpu_bins_create called directly)
+   bool grouped_on_device = false;
+   std::string host_grouping_reason;
    ~sbgpu_bins()
    {
       sb::dev_give(dev.arena, dev.capacity);
       sb::dev_give(dev_bins.arena, dev_bins.capacity);
+      sb::dev_give(dev_hit_bin, dev_hit_bin_cap);
    }
 };
 
@@ -243,6 +253,7 @@ int bins_create_impl(const sbgpu_annotation_t *an, const sbgpu_hits_t *hits, con
          return api_fail(SBGPU_ESHAPE, "sbgpu_bins_create: word counts do not cover a locus");
    sbgpu_bins *B = new (std::nothrow) sbgpu_bins();
    if (!B) return api_fail(SBGPU_ENOMEM, "sbgpu_bins_create: out of memory");
+   B->grouped_on_device = pre != nullptr; // a handle made from the device grouping's arrays
    auto bail = [&](int code, const char *msg) {
       delete B;
       return api_fail(code, msg);
@@ -582,7 +593,18 @@ int bins_create_impl(const sbgpu_annotation_t *an, const sbgpu_hits_t *hits, con
 
 namespace sb {
 void bins_set_weights(sbgpu_bins_t *b, std::vector<double> &&F) { b->F = std::move(F); }
+void bins_set_grouping(sbgpu_bins_t *b, bool on_device, const std::string &why_host)
+{
+   b->grouped_on_device = on_device;
+   b->host_grouping_reason = why_host;
+}
 void bins_set_hit_bin(sbgpu_bins_t *b, std::vector<int64_t> &&hb) { b->hit_bin = std::move(hb); }
+void bins_set_device_hit_bin(sbgpu_bins_t *b, char *arena, size_t capacity, int64_t n)
+{
+   b->dev_hit_bin = arena;
+   b->dev_hit_bin_cap = capacity;
+   b->n_dev_hit_bin = n;
+}
 const double *bins_weights_tail(const sbgpu_bins_t *b, size_t at) { return b->F.data() + at; }
 const DevicePairs *bins_device_pairs(const sbgpu_bins_t *b) { return b && b->pairs_on_device ? &b->dev : nullptr; }
 int bins_from_groups(const sbgpu_annotation_t *an, int32_t compat_words, int32_t key_words, const int64_t *row_off,
@@ -611,6 +633,14 @@ int sbgpu_bins_export_weights(const sbgpu_bins_t *b, double *F_out)
    if ((int64_t)b->F.size() < b->n_elem || (b->F.empty() && b->n_elem == 0 && b->n_bins > 0))
       return api_fail(SBGPU_EINVAL, "sbgpu_bins_export_weights: this handle holds no weights");
    if (b->n_elem) std::memcpy(F_out, b->F.data(), (size_t)b->n_elem * sizeof(double));
+   return SBGPU_OK;
+}
+
+int sbgpu_bins_grouping(const sbgpu_bins_t *b, int32_t *on_device, const char **why_host)
+{
+   if (!b || !on_device) return api_fail(SBGPU_EINVAL, "sbgpu_bins_grouping: null argument");
+   *on_device = b->grouped_on_device ? 1 : 0;
+   if (why_host) *why_host = b->host_grouping_reason.c_str();
    return SBGPU_OK;
 }
 
@@ -676,6 +706,10 @@ int sbgpu_bins_export(const sbgpu_bins_t *b, int64_t *row_off, int64_t *iso_off,
    SB_COPY(f_off, b->f_off);
    SB_COPY(iso_len, b->iso_len);
    SB_COPY(hit_bin, b->hit_bin);
+   if (hit_bin && b->hit_bin.empty() && b->dev_hit_bin && b->n_dev_hit_bin) { // straight into the caller's array
+      const hipError_t e = hipMemcpy(hit_bin, b->dev_hit_bin, (size_t)b->n_dev_hit_bin * 8, hipMemcpyDeviceToHost);
+      if (e != hipSuccess) return api_fail(SBGPU_EHIP, std::string("sbgpu_bins_export: download of hit -> bin: ") + hipGetErrorString(e));
+   }
    SB_COPY(pair_seg_off, b->pair_seg_off);
    SB_COPY(pair_seg_lens, b->pair_seg_lens);
    SB_COPY(pair_implicit_mask, b->pair_mask);

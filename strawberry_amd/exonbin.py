@@ -362,6 +362,10 @@ class LocusBins:
             info = (C.c_int64 * 8)()
             _lib.check(L.sbgpu_bins_info(handle, info), "sbgpu_bins_info")
             (self.n_loci, self.n_iso, self.n_bins, self.n_elem, self.n_pairs, n_pair_segs, self.n_hits_used, _) = list(info)
+            on_dev, why = C.c_int32(0), C.c_char_p()
+            _lib.check(L.sbgpu_bins_grouping(handle, C.byref(on_dev), C.byref(why)), "sbgpu_bins_grouping")
+            # which grouping made these bins: the device kernels, or the library's host code (and then why)
+            self.grouped_on_device, self.host_grouping_reason = bool(on_dev.value), (why.value or b"").decode()
             self.row_off = np.zeros(self.n_loci + 1, np.int64)
             self.iso_off = np.zeros(self.n_loci + 1, np.int64)
             self.f_off = np.zeros(self.n_loci + 1, np.int64)

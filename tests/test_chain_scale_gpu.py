@@ -128,6 +128,7 @@ def test_chain_sample_every_locus_against_the_oracle_chain(oracle):
         # the same hits through the host entry (same kernels; it also returns the words per hit and the weights, which the
         # device entry leaves in HBM): the two entries agree bit for bit
         r = quantify_host(annot, hits, InsertSize(MEAN, SD), RL, ctx=ctx)
+    assert r["bins"].grouped_on_device, r["bins"].host_grouping_reason     # the host entry did not fall to the host grouping
     np.testing.assert_array_equal(r["theta"], theta)
     np.testing.assert_array_equal(r["status"], status)
     np.testing.assert_array_equal(r["iters"], iters)
