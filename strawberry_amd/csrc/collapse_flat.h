@@ -1,0 +1,389 @@
+// strawberry_amd/csrc/collapse_flat.h -- HitCluster::collapseAndFilterHits for ALL clusters of a call at once
+// (/root/reference/src/alignments.cpp:656-703; round 4: replaces one-workgroup-per-cluster, collapse_device.h).
+//
+// The per-cluster form sorted each cluster's pairs with a bitonic network in LDS (55-105 barrier passes for a cluster of a
+// few thousand pairs) or through global memory (a highly expressed gene: one workgroup of 1024 threads, milliseconds), and a
+// sample's time was its biggest clusters'.  Here nothing but two order-bound sums is per cluster:
+//
+//   keys      a thread per pair: the sort keys, the mates' spans, the clusters' integer span sums (exact in any order);
+//   sort      TWO stable device-wide radix sorts (rocPRIM onesweep): by the right end, then by (cluster << 32 | left end).
+//             LSD order: the second sort keeps the first one's order among equal (cluster, left) and both keep the input
+//             order among equal keys -- std::sort on (left, right) with ties in input order, which is what the host form's
+//             stable sort and the per-cluster kernel's (key, index) network give (src/read.cpp:917-923);
+//   sd        the reference adds the squared deviations of the spans in INPUT order, one running double (std::inner_product,
+//             common.h:100-110) -- sequential by definition -- but the sum is only ever used in a PREDICATE, the span filter
+//             phi((span - mean) / (5 sd)) > 0.999 (:666-682).  The spans are integers, so the exact sum of squared deviations
+//             is (n S2 - S1^2) / n with S1 = sum of spans, S2 = sum of squares -- integers, exact in any order (128-bit).
+//             The filter is decided with the sd from that; a decision that an error of n ulps in the sd could flip (phi
+//             within 1e-9 + 1e-15 n (1 + |x|) of 0.999: not observed) marks its cluster, and marked clusters get the
+//             reference's running sum after all (a WAVE per cluster: the values handed round with v_readlane, every lane
+//             carrying the same sum) and their flags again;
+//   flags     a thread per sorted position: the span filter;
+//   heads     "differs from the previous KEPT pair" (:685-697): the previous kept position is a device-wide running
+//             maximum (scan), the comparison and Contig(PairedHit)'s feature count are per-position work;
+//   ranks     three device-wide scans give every unique hit its group, its place and its first feature's place -- the
+//             per-cluster offsets are those scans read at the clusters' first positions (no host prefix sums in between);
+//   masses    the cluster's mass and every group's are running doubles in SORTED order (:683-684, :688-696).  Where every
+//             mass of a cluster is a multiple of 2^-20 below 2^31 -- always, unless multi-mapped reads are let in with NH 3, 5,
+//             ... -- every partial sum is exact and the order cannot matter: a thread per position, the lanes of a wave that
+//             share a cluster / a group add up in registers, one hardware fp64 atomic per run.  The other clusters get the
+//             running sums (a wave per cluster, as for the sd);
+//   fill      a thread per unique hit writes it where the exon-bin kernel reads it.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "collapse_device.h"
+
+namespace sb {
+
+struct FlatCollapseArgs {
+   CollapseArgs a; // the pairs (inputs) and the unique hits' arrays (outputs of the fill)
+   int64_t n_pairs;
+   // per pair, input order
+   uint32_t *key_right;          // sort 1
+   unsigned long long *key_hi;   // (cluster << 32) | left end: sort 2, gathered through sort 1's permutation
+   int32_t *span_l, *span_r;     // -1: no such mate
+   // per cluster
+   unsigned long long *span_sum; // S1: integer sum of the mates' spans
+   unsigned long long *span_sq;  // S2: integer sum of their squares
+   int32_t *n_mates;
+   int32_t *cl_flags;            // kNeedSeqMass / kNeedSeqSd: this cluster's sums must run in the reference's order
+   double *mean, *sd5;
+   // per sorted position (the clusters keep their ranges: the cluster is the key's high part)
+   const int32_t *perm1;              // after sort 1
+   unsigned long long *key2;          // key_hi gathered by perm1 (sort 2's input)
+   const unsigned long long *key2s;   // sort 2's keys out: cluster of a sorted position = key2s[s] >> 32
+   const int32_t *order;              // input pair (global index) at sorted position s
+   uint8_t *skip, *head;
+   int32_t *kept_pos;                 // s where kept, -1 where skipped; scanned (running max) into last_kept
+   const int32_t *last_kept;
+   int32_t *nfeat;                    // > 0: a unique hit with that many features starts here
+   int32_t *is_hit;                   // nfeat > 0 (scan input)
+   const int32_t *gid;                // inclusive scan of head: the group of a kept position (1-based)
+   const int64_t *hit_rank;           // exclusive scan of is_hit (one entry beyond the end: the total)
+   const int64_t *feat_base;          // exclusive scan of nfeat  (likewise)
+   double *gmass;                     // [groups + 1]
+   int64_t *locus_hit_off;            // [n_loci + 1]
+   unsigned long long *counts;        // [0] filtered, [1] rejected
+};
+
+enum : int32_t { kNeedSeqMass = 1, kNeedSeqSd = 2 };
+
+__device__ __forceinline__ int32_t flat_locus_of(const int64_t *off, int64_t n_loci, int64_t p)
+{
+   int64_t lo = 0, hi = n_loci; // last l with off[l] <= p
+   while (hi - lo > 1) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (off[mid] <= p) lo = mid;
+      else hi = mid;
+   }
+   return (int32_t)lo;
+}
+
+// ---- keys: a thread per pair
+__global__ __launch_bounds__(256) void flat_keys_kernel(FlatCollapseArgs f)
+{
+   const CollapseArgs &a = f.a;
+   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+   int bad = 0, need = 0;
+   int32_t l = -1;
+   unsigned long long sum = 0, sum2 = 0;
+   int nm = 0;
+   if (p < f.n_pairs) {
+      l = flat_locus_of(a.locus_pair_off, a.n_loci, p);
+      const MateRef x = left_mate(a, p), y = right_mate(a, p);
+      if (x.n > kMateFeatMax || y.n > kMateFeatMax) bad |= kCollapseLongMate;
+      uint32_t lp = 0xffffffffu, rp = 0xffffffffu;
+      if (x.n == 0 && y.n == 0) bad |= kCollapseNoMates;
+      else lp = pair_left_pos(x, y), rp = pair_right_pos(x, y);
+      f.key_right[p] = rp;
+      f.key_hi[p] = ((unsigned long long)(uint32_t)l << 32) | lp;
+      const int sl = x.n ? (int)(x.r[x.n - 1] - x.l[0] + 1) : -1, sr = y.n ? (int)(y.r[y.n - 1] - y.l[0] + 1) : -1;
+      f.span_l[p] = sl;
+      f.span_r[p] = sr;
+      if (sl >= 0) sum += (unsigned long long)sl, sum2 += (unsigned long long)sl * (unsigned long long)sl, ++nm;
+      if (sr >= 0) sum += (unsigned long long)sr, sum2 += (unsigned long long)sr * (unsigned long long)sr, ++nm;
+      if (sl >= (1 << 24) || sr >= (1 << 24)) need |= kNeedSeqSd; // (S2 could leave 64 bits)
+      // a mass that is a multiple of 2^-20 below 2^31: sums of up to 2^31 of them are exact whatever the order
+      const double m = a.pair_mass[p], m20 = m * 1048576.0;
+      if (!(m >= 0.0 && m < 2147483648.0 && m20 == (double)(unsigned long long)m20)) need |= kNeedSeqMass;
+      if (need) atomicOr(&f.cl_flags[l], need);
+   }
+   if (bad) atomicOr(a.flags, bad);
+   // the spans are whole numbers: their sum is exact in any order.  The lanes of a wave mostly share their cluster:
+   // the lanes whose cluster is the first active lane's add up in registers, one atomic for them; the others on their own
+   const int32_t l0 = __shfl(l, __ffsll((long long)__ballot(l >= 0)) - 1);
+   const bool with_first = l >= 0 && l == l0;
+   unsigned long long s2 = with_first ? sum : 0, q2 = with_first ? sum2 : 0;
+   int n2 = with_first ? nm : 0;
+   for (int o = 32; o > 0; o >>= 1) {
+      s2 += __shfl_xor(s2, o);
+      q2 += __shfl_xor(q2, o);
+      n2 += __shfl_xor(n2, o);
+   }
+   if (l >= 0) {
+      if (!with_first) {
+         atomicAdd(&f.span_sum[l], sum);
+         atomicAdd(&f.span_sq[l], sum2);
+         atomicAdd(&f.n_mates[l], nm);
+      } else if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(with_first)) - 1) {
+         atomicAdd(&f.span_sum[l], s2);
+         atomicAdd(&f.span_sq[l], q2);
+         atomicAdd(&f.n_mates[l], n2);
+      }
+   }
+}
+
+__global__ __launch_bounds__(256) void flat_gather_kernel(FlatCollapseArgs f)
+{
+   const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+   if (s < f.n_pairs) f.key2[s] = f.key_hi[f.perm1[s]];
+}
+
+// a double held by lane k of the wave, as a wave-uniform value
+__device__ __forceinline__ double flat_bcast(double v, int k)
+{
+   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), k), __builtin_amdgcn_readlane(__double2loint(v), k));
+}
+
+// ---- sd: a wave per cluster; the squared deviations in INPUT order (left mate, then right mate of each pair).
+// The lanes square their own element's deviations side by side; only the additions are sequential: the values come round as
+// wave-uniform scalars (v_readlane) and every lane carries the same running sum.  A mate that is not there adds 0.0, which
+// leaves a non-negative sum as it is (the reference skips it).  The next 64 elements are loaded while these are added.
+__global__ __launch_bounds__(64) void flat_sd_kernel(FlatCollapseArgs f)
+{
+   const CollapseArgs &a = f.a;
+   const int lane = threadIdx.x;
+   for (int64_t l = blockIdx.x; l < a.n_loci; l += gridDim.x) {
+      const int64_t q0 = a.locus_pair_off[l], q1 = a.locus_pair_off[l + 1];
+      const int nm = f.n_mates[l];
+      if (q1 == q0 || nm == 0 || !(f.cl_flags[l] & kNeedSeqSd)) continue; // (the usual cluster: decided from the integer moments)
+      const double mean = (double)f.span_sum[l] / (double)nm;
+      double sq = 0.0;
+      int sl = q0 + lane < q1 ? f.span_l[q0 + lane] : -1, sr = q0 + lane < q1 ? f.span_r[q0 + lane] : -1;
+      for (int64_t c0 = q0; c0 < q1; c0 += 64) {
+         const int m = (int)min((int64_t)64, q1 - c0);
+         const double el = (double)sl - mean, er = (double)sr - mean;
+         const double dl = sl >= 0 ? el * el : 0.0, dr = sr >= 0 ? er * er : 0.0;
+         const int64_t nx = c0 + 64 + lane; // the next chunk's loads, in flight during the additions below
+         sl = nx < q1 ? f.span_l[nx] : -1;
+         sr = nx < q1 ? f.span_r[nx] : -1;
+         if (m == 64) {
+#pragma unroll
+            for (int k = 0; k < 64; ++k) {
+               sq += flat_bcast(dl, k);
+               sq += flat_bcast(dr, k);
+            }
+         } else {
+            for (int k = 0; k < m; ++k) {
+               sq += flat_bcast(dl, k);
+               sq += flat_bcast(dr, k);
+            }
+         }
+      }
+      if (lane == 0) {
+         f.mean[l] = mean;
+         f.sd5[l] = sqrt(sq / (double)nm) * 5;
+      }
+   }
+}
+
+// ---- the span filter (:666-682): a thread per sorted position.  PASS 1 decides from the integer moments and marks the
+// clusters where that is not safe; PASS 2 (after flat_sd_kernel has given those the reference's running sum) redoes theirs.
+template <int PASS>
+__global__ __launch_bounds__(256) void flat_flags_kernel(FlatCollapseArgs f)
+{
+   const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+   if (s >= f.n_pairs) return;
+   const int32_t l = (int32_t)(f.key2s[s] >> 32);
+   const int need = f.cl_flags[l] & kNeedSeqSd;
+   if (PASS == 2 && !need) return;
+   const int32_t p = f.order[s];
+   const int sl = f.span_l[p], sr = f.span_r[p];
+   bool sk = false;
+   if (PASS == 2) {
+      const double mean = f.mean[l], sd5 = f.sd5[l];
+      if (sl >= 0 && ref_phi_dev(((double)(uint32_t)sl - mean) / sd5) > 0.999) sk = true;
+      if (sr >= 0 && ref_phi_dev(((double)(uint32_t)sr - mean) / sd5) > 0.999) sk = true;
+   } else if (!need) {
+      const int nm = f.n_mates[l];
+      const unsigned long long S1 = f.span_sum[l], S2 = f.span_sq[l];
+      const double mean = (double)S1 / (double)nm; // (the reference's mean, to the bit: an exact integer over a count)
+      const unsigned __int128 num = (unsigned __int128)S2 * (unsigned)nm - (unsigned __int128)S1 * S1; // n^2 x the variance: exact
+      const double numd = (double)(unsigned long long)(num >> 64) * 18446744073709551616.0 + (double)(unsigned long long)num;
+      const double sq = numd / (double)nm;         // the sum of squared deviations, to a few ulps
+      const double sd5 = sqrt(sq / (double)nm) * 5;
+      const double tol0 = 1e-9 + 1e-15 * (double)nm;
+      // all spans equal (num == 0: every read unspliced and of one length): the reference's running sum is 0.0 too -- every
+      // deviation is exactly 0 -- so its sd is this one to the bit (the filter then sees 0 / 0 and keeps the pair)
+      bool unsure = false;
+      const bool exact = num == 0;
+      if (sl >= 0) {
+         const double x = ((double)(uint32_t)sl - mean) / sd5, ph = ref_phi_dev(x);
+         sk |= ph > 0.999;
+         unsure |= !exact && !(fabs(ph - 0.999) > tol0 * (1.0 + fabs(x)));
+      }
+      if (sr >= 0) {
+         const double x = ((double)(uint32_t)sr - mean) / sd5, ph = ref_phi_dev(x);
+         sk |= ph > 0.999;
+         unsure |= !exact && !(fabs(ph - 0.999) > tol0 * (1.0 + fabs(x)));
+      }
+      if (unsure) atomicOr(&f.cl_flags[l], kNeedSeqSd); // (a NaN that is not the all-equal case included)
+   }
+   f.skip[s] = sk ? 1 : 0;
+   f.kept_pos[s] = sk ? -1 : (int32_t)s;
+}
+
+// ---- unique hits: a kept pair that differs from the previous kept pair of its cluster (:685-697)
+__global__ __launch_bounds__(256) void flat_heads_kernel(FlatCollapseArgs f)
+{
+   const CollapseArgs &a = f.a;
+   const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+   int filt = 0, rej = 0;
+   if (s < f.n_pairs) {
+      int32_t nf = 0;
+      uint8_t hd = 0;
+      if (f.skip[s]) {
+         filt = 1;
+      } else {
+         const int32_t l = (int32_t)(f.key2s[s] >> 32);
+         const int64_t q0 = a.locus_pair_off[l];
+         const int64_t p = f.order[s];
+         const MateRef x = left_mate(a, p), y = right_mate(a, p);
+         const int64_t prev = s > 0 ? (int64_t)f.last_kept[s - 1] : -1;
+         bool same = false;
+         if (prev >= q0) {
+            const int64_t pp = f.order[prev];
+            same = mate_equal(left_mate(a, pp), x) && mate_equal(right_mate(a, pp), y);
+         }
+         if (!same) {
+            hd = 1;
+            nf = hit_features_dev(x, y, nullptr, nullptr, nullptr);
+            if (nf <= 0) nf = 0, rej = 1; // Contig(PairedHit) rejects the pair: no hit, its mass stays in the cluster's
+         }
+      }
+      f.head[s] = hd;
+      f.nfeat[s] = nf;
+      f.is_hit[s] = nf > 0 ? 1 : 0;
+   }
+   const unsigned long long bf = __ballot(filt), br = __ballot(rej);
+   if ((threadIdx.x & 63) == 0) {
+      if (bf) atomicAdd(&f.counts[0], (unsigned long long)__popcll(bf));
+      if (br) atomicAdd(&f.counts[1], (unsigned long long)__popcll(br));
+   }
+}
+
+// ---- masses: a wave per cluster; the cluster's mass and each group's as running doubles over the KEPT pairs in sorted
+// order (:683-684, :688-696) -- same pattern as the sd: the lanes fetch their element's mass side by side (a skipped pair
+// brings 0.0: adding it changes nothing), the additions go round as wave-uniform scalars, the next 64 elements are
+// fetched meanwhile.  Also the cluster's first unique hit (the scan read at its first position).
+struct FlatMassElem {
+   double pm;
+   int code, gi; // code: 0 skipped, 1 kept, 3 kept and the head of a group
+};
+__device__ __forceinline__ FlatMassElem flat_mass_load(const FlatCollapseArgs &f, int64_t s, int64_t q1)
+{
+   FlatMassElem e = {0.0, 0, 0};
+   if (s < q1 && !f.skip[s]) {
+      e.code = f.head[s] ? 3 : 1;
+      e.pm = f.a.pair_mass[f.order[s]];
+      e.gi = f.gid[s];
+   }
+   return e;
+}
+__global__ __launch_bounds__(64) void flat_mass_kernel(FlatCollapseArgs f)
+{
+   const CollapseArgs &a = f.a;
+   const int lane = threadIdx.x;
+   for (int64_t l = blockIdx.x; l < a.n_loci; l += gridDim.x) {
+      if (!(f.cl_flags[l] & kNeedSeqMass)) continue; // (the usual cluster: flat_mass_any_order_kernel)
+      const int64_t q0 = a.locus_pair_off[l], q1 = a.locus_pair_off[l + 1];
+      double m = 0.0, g = 0.0;
+      int gcur = 0; // the group being summed (0: none yet)
+      FlatMassElem nxt = flat_mass_load(f, q0 + lane, q1);
+      for (int64_t c0 = q0; c0 < q1; c0 += 64) {
+         const int n = (int)min((int64_t)64, q1 - c0);
+         const FlatMassElem e = nxt;
+         nxt = flat_mass_load(f, c0 + 64 + lane, q1);
+         // lanes whose element starts a group, as a mask: the additions run from head to head without looking at the codes
+         unsigned long long heads = __ballot(e.code == 3);
+         int k = 0;
+         while (k < n) {
+            const int stop = heads ? min(n, (int)__ffsll((long long)heads) - 1) : n; // the next head at or behind k (heads below k are cleared)
+            for (; k < stop; ++k) {
+               const double v = flat_bcast(e.pm, k);
+               g += v;
+               m += v;
+            }
+            if (k < n) { // k is a head: the group before it is complete
+               if (gcur && lane == 0) f.gmass[gcur] = g;
+               gcur = __builtin_amdgcn_readlane(e.gi, k);
+               const double v = flat_bcast(e.pm, k);
+               g = v;
+               m += v;
+               heads &= heads - 1;
+               ++k;
+            }
+         }
+      }
+      if (lane == 0) {
+         if (gcur) f.gmass[gcur] = g;
+         a.cluster_mass[l] = m;
+      }
+   }
+}
+
+// sum of v over the lanes that share `key` (keys do not decrease along the wave); true in the LAST lane of each run, which
+// then holds the run's sum
+__device__ __forceinline__ bool flat_run_sum(int key, double &v)
+{
+   const int lane = threadIdx.x & 63;
+   for (int o = 1; o < 64; o <<= 1) {
+      const double w = __shfl_up(v, o);
+      const int k = __shfl_up(key, o);
+      if (lane >= o && k == key) v += w;
+   }
+   const int kn = __shfl_down(key, 1);
+   return lane == 63 || kn != key;
+}
+
+// ---- masses where the order cannot matter (every mass of the cluster a multiple of 2^-20: see the head of the file):
+// a thread per sorted position; runs of one cluster / one group inside a wave add up in registers, one atomic per run.
+// Also every cluster's first unique hit (the scan read at its first position).
+__global__ __launch_bounds__(256) void flat_mass_any_order_kernel(FlatCollapseArgs f)
+{
+   const CollapseArgs &a = f.a;
+   const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+   if (s <= a.n_loci) f.locus_hit_off[s] = f.hit_rank[s < a.n_loci ? a.locus_pair_off[s] : f.n_pairs];
+   int l = -1, gk = 0x7fffffff; // (beyond the last position: keys that keep the runs apart)
+   double v = 0.0;
+   if (s < f.n_pairs) {
+      l = (int32_t)(f.key2s[s] >> 32);
+      gk = f.gid[s]; // the group of the last head at or before s (a skipped position adds 0.0 to it: nothing)
+      if (f.cl_flags[l] & kNeedSeqMass) l = -1; // flat_mass_kernel's
+      else if (!f.skip[s]) v = a.pair_mass[f.order[s]];
+   }
+   double vc = v, vg = v;
+   const bool last_c = flat_run_sum(l, vc), last_g = flat_run_sum(gk, vg);
+   if (l >= 0 && last_c && vc != 0.0) unsafeAtomicAdd(&a.cluster_mass[l], vc);
+   if (last_g && vg != 0.0) unsafeAtomicAdd(&f.gmass[gk], vg);
+}
+
+// ---- fill: a thread per sorted position that starts a unique hit
+__global__ __launch_bounds__(256) void flat_fill_kernel(FlatCollapseArgs f)
+{
+   const CollapseArgs &a = f.a;
+   const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+   if (s >= f.n_pairs) return;
+   const int n = f.nfeat[s];
+   if (n <= 0) return;
+   const int64_t h = f.hit_rank[s], fb = f.feat_base[s], p = f.order[s];
+   a.hit_locus[h] = (int32_t)(f.key2s[s] >> 32);
+   a.feat_off[h] = fb;
+   a.hit_mass[h] = (float)f.gmass[f.gid[s]]; // stored as float (Contig::mass())
+   hit_features_dev(left_mate(a, p), right_mate(a, p), a.feat_code + fb, a.feat_left + fb, a.feat_right + fb);
+}
+
+} // namespace sb

@@ -194,3 +194,40 @@ def test_collapsed_hits_feed_the_chain_without_leaving_the_device(ctx):
     r = quantify_host(annot, hits, InsertSize(250.0, 30.0), 75, ctx=ctx)
     np.testing.assert_array_equal(theta[:n_iso], r["theta"])
     np.testing.assert_array_equal(iters[:annot.n_loci], r["iters"])
+
+
+def test_flat_collapse_any_order_paths_equal_the_running_sums(ctx, oracle, monkeypatch):
+    """The flat form decides the span filter from the spans' exact integer moments and, where every mass of a cluster is a
+    multiple of 2^-20 (NH 1, 2, 4 ...), adds the masses in any order (hardware atomics); clusters where that is not safe
+    take the reference's running sums.  Both routes, on the same input: masses that are dyadic in some clusters and not in
+    others (NH 3), spans that are all equal in one cluster (sd 0: the filter sees 0 / 0), a cluster of 30 000 pairs with
+    thousands of copies of one pair (one group's mass = thousands of additions) -- identical to the host form and to each
+    other, and SBGPU_COLLAPSE_FORCE_SEQ=1 (every cluster on the running sums) gives the same bits."""
+    from strawberry_amd import exonbin as eb
+    rng = np.random.default_rng(99)
+    sizes = [500, 30000, 0, 1200, 64, 65, 5000]
+    nh_choices = [[1, 2, 4], [1], [1], [1, 3], [2], [1, 2, 3, 4], [1, 4]]
+    loc, nh, left, right = [], [], [], []
+    for l, n in enumerate(sizes):
+        base = 1000000 * (l + 1)
+        starts = rng.integers(base, base + max(50, n // 40), n)              # many copies per start
+        for k in range(n):
+            s0 = int(starts[k])
+            lb = [(s0, s0 + 74)]
+            if l != 4 and rng.random() < 0.25:                                # (locus 4: every span 75)
+                cut = int(rng.integers(10, 60))
+                gap = 30000 if rng.random() < 0.02 else 300                   # a few mates spanning 30 kb: the filter's outliers
+                lb = [(s0, s0 + cut - 1), (s0 + cut + gap, s0 + cut + gap + 74 - cut)]
+            rb = [(lb[-1][1] + 100, lb[-1][1] + 174)]
+            loc.append(l), nh.append(int(rng.choice(nh_choices[l]))), left.append(lb), right.append(rb)
+    perm = rng.permutation(len(loc))
+    args = (len(sizes), [loc[i] for i in perm], [1.0 / nh[i] for i in perm], [left[i] for i in perm], [right[i] for i in perm])
+    r = eb.collapse_pairs(*args)
+    g = eb.collapse_pairs(*args, device=ctx)
+    same(g[0], r[0], g[1], r[1], g[2], r[2])
+    assert g[2]["filtered"] > 0 and r[0].n_hits < len(loc) * 0.5
+    monkeypatch.setenv("SBGPU_COLLAPSE_FORCE_SEQ", "1")
+    g2 = eb.collapse_pairs(*args, device=ctx)
+    monkeypatch.delenv("SBGPU_COLLAPSE_FORCE_SEQ")
+    same(g2[0], r[0], g2[1], r[1], g2[2], r[2])
+    XU.check_collapse_against_oracle(oracle, len(sizes), args[1], [nh[i] for i in perm], args[3], args[4], g[0], g[1], g[2])
