@@ -10,9 +10,12 @@
 #include <unordered_map>
 #include <vector>
 
+#include <rocprim/rocprim.hpp>
+
 #include "../../include/sbgpu.h"
 #include "api_internal.h"
 #include "matepair_device.h"
+#include "matepair_flat.h"
 
 using sb::api_fail;
 
@@ -27,8 +30,9 @@ struct sbgpu_matepairs {
    std::vector<int64_t> left_off, right_off;
    std::vector<uint8_t> left_code, right_code;
    std::vector<uint32_t> left_left, left_right, right_left, right_right;
-   // device form: one arena
+   // device form: one arena (sb::dev_take'n)
    char *arena = nullptr;
+   size_t arena_cap = 0;
    double *d_mass = nullptr;
    int64_t *d_left_off = nullptr, *d_right_off = nullptr;
    uint8_t *d_left_code = nullptr, *d_right_code = nullptr;
@@ -40,15 +44,140 @@ size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
 constexpr int kMaxFragSpanHost = 1000000; // src/common.cpp:17
 } // namespace
 
+// ---- the flat form (matepair_flat.h): every cluster of the call at once
+static int pair_mates_flat(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t *dr, const int64_t *locus_read_off, hipStream_t s,
+                           sbgpu_matepairs *M)
+{
+   const int64_t nr = dr->n_reads;
+   if (nr >= ((int64_t)1 << 31) - 2) return api_fail(SBGPU_EUNSUPPORTED, "sbgpu_pair_mates_device: more than 2^31 records in one call; split the call or use sbgpu_pair_mates_host");
+   char *w = nullptr;
+   size_t w_cap = 0;
+   auto bail = [&](int code, const std::string &msg) {
+      (void)hipStreamSynchronize(s);
+      sb::dev_give(w, w_cap);
+      return api_fail(code, msg);
+   };
+#define SB_TRY(expr)                                                                                     \
+   do {                                                                                                  \
+      hipError_t e_ = (expr);                                                                            \
+      if (e_ != hipSuccess) return bail(e_ == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+   } while (0)
+   SB_TRY(hipSetDevice(M->device));
+   const size_t n = (size_t)nr, n1 = n + 1, nl1 = (size_t)n_loci + 1;
+   unsigned locus_bits = 1;
+   while (((int64_t)1 << locus_bits) < n_loci) ++locus_bits;
+   size_t tmp_bytes = 0;
+   {
+      size_t b = 0;
+      (void)rocprim::radix_sort_pairs(nullptr, b, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, rocprim::counting_iterator<int32_t>(0), (int32_t *)nullptr, n, 0, 32 + locus_bits, s);
+      tmp_bytes = std::max(tmp_bytes, b);
+      (void)rocprim::radix_sort_pairs(nullptr, b, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr, n, 0, 32, s);
+      tmp_bytes = std::max(tmp_bytes, b);
+      (void)rocprim::exclusive_scan(nullptr, b, rocprim::make_transform_iterator((const int32_t *)nullptr, [] __device__(int32_t v) { return (int64_t)v; }), (int64_t *)nullptr, (int64_t)0, n1, rocprim::plus<int64_t>(), s);
+      tmp_bytes = std::max(tmp_bytes, b);
+   }
+   size_t off = 0;
+   auto take = [&](size_t bytes) {
+      const size_t o = off;
+      off += up256(bytes ? bytes : 8);
+      return o;
+   };
+   const size_t o_roff = take(nl1 * 8), o_key = take(n * 8), o_skey = take(n * 8), o_order = take(n * 4), o_rec = take(n * sizeof(sb::FlatRec));
+   const size_t o_state = take(n), o_okey = take(n * 4), o_oval = take(n * 4), o_prec = take(n * 4), o_pval = take(n * 4);
+   const size_t o_lf = take(n1 * 4), o_rf = take(n1 * 4), o_ls = take(n1 * 8), o_rs = take(n1 * 8), o_poff = take(nl1 * 8), o_counts = take(64 * 64), o_tmp = take(tmp_bytes);
+   SB_TRY(sb::dev_take(off, &w, &w_cap));
+   SB_TRY(hipMemsetAsync(w + o_counts, 0, 64 * 64, s));
+   SB_TRY(hipMemcpyAsync(w + o_roff, locus_read_off, nl1 * 8, hipMemcpyHostToDevice, s));
+   sb::FlatMateArgs f = {};
+   sb::MateArgs &a = f.a;
+   a.n_loci = n_loci;
+   a.locus_read_off = (const int64_t *)(w + o_roff);
+   a.read_id = dr->read_id;
+   a.block_off = dr->block_off;
+   a.block_left = dr->block_left, a.block_right = dr->block_right;
+   a.partner_pos = dr->partner_pos;
+   a.flags = dr->flags;
+   a.nh = dr->nh;
+   f.n_reads = nr;
+   f.key = (unsigned long long *)(w + o_key);
+   f.skey = (const unsigned long long *)(w + o_skey);
+   f.order = (const int32_t *)(w + o_order);
+   f.rec = (sb::FlatRec *)(w + o_rec);
+   f.state = (uint8_t *)(w + o_state);
+   f.out_key = (uint32_t *)(w + o_okey), f.out_val = (uint32_t *)(w + o_oval);
+   f.pair_rec = (const uint32_t *)(w + o_prec), f.pair_val = (const uint32_t *)(w + o_pval);
+   f.lfeat = (int32_t *)(w + o_lf), f.rfeat = (int32_t *)(w + o_rf);
+   f.lscan = (const int64_t *)(w + o_ls), f.rscan = (const int64_t *)(w + o_rs);
+   f.locus_pair_off = (int64_t *)(w + o_poff);
+   f.counts = (unsigned long long *)(w + o_counts);
+   const unsigned gr = (unsigned)((n + 255) / 256), gr1 = (unsigned)((std::max(n1, nl1) + 255) / 256);
+   void *tmp = w + o_tmp;
+   size_t tb = tmp_bytes;
+   hipLaunchKernelGGL(sb::flat_mate_keys_kernel, dim3(gr), dim3(256), 0, s, f);
+   SB_TRY(hipGetLastError());
+   SB_TRY(rocprim::radix_sort_pairs(tmp, tb, (const unsigned long long *)f.key, (unsigned long long *)(w + o_skey), rocprim::counting_iterator<int32_t>(0), (int32_t *)(w + o_order), n, 0, 32 + locus_bits, s));
+   hipLaunchKernelGGL(sb::flat_mate_pack_kernel, dim3(gr), dim3(256), 0, s, f);
+   hipLaunchKernelGGL(sb::flat_mate_walk_kernel, dim3(gr), dim3(256), 0, s, f);
+   SB_TRY(hipGetLastError());
+   tb = tmp_bytes;
+   SB_TRY(rocprim::radix_sort_pairs(tmp, tb, (const uint32_t *)f.out_key, (uint32_t *)(w + o_prec), (const uint32_t *)f.out_val, (uint32_t *)(w + o_pval), n, 0, 32, s));
+   hipLaunchKernelGGL(sb::flat_mate_count_kernel, dim3(gr1), dim3(256), 0, s, f);
+   SB_TRY(hipGetLastError());
+   tb = tmp_bytes;
+   SB_TRY(rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator((const int32_t *)f.lfeat, [] __device__(int32_t v) { return (int64_t)v; }), (int64_t *)(w + o_ls), (int64_t)0, n1, rocprim::plus<int64_t>(), s));
+   tb = tmp_bytes;
+   SB_TRY(rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator((const int32_t *)f.rfeat, [] __device__(int32_t v) { return (int64_t)v; }), (int64_t *)(w + o_rs), (int64_t)0, n1, rocprim::plus<int64_t>(), s));
+   unsigned long long slots[64 * 8], counts[4] = {0, 0, 0, 0};
+   int64_t totals[2] = {0, 0};
+   SB_TRY(hipMemcpyAsync(slots, w + o_counts, sizeof(slots), hipMemcpyDeviceToHost, s));
+   SB_TRY(hipMemcpyAsync(&totals[0], w + o_ls + n * 8, 8, hipMemcpyDeviceToHost, s));
+   SB_TRY(hipMemcpyAsync(&totals[1], w + o_rs + n * 8, 8, hipMemcpyDeviceToHost, s));
+   SB_TRY(hipMemcpyAsync(M->locus_pair_off.data(), w + o_poff, nl1 * 8, hipMemcpyDeviceToHost, s));
+   SB_TRY(hipStreamSynchronize(s));
+   for (int k = 0; k < 64; ++k)
+      for (int i = 0; i < 4; ++i) counts[i] += slots[k * 8 + i]; // (wrapping sums: a slot's orphan count may be "negative")
+   M->n_refused = (int64_t)counts[0], M->n_orphan = (int64_t)counts[1], M->n_single = (int64_t)counts[2], M->n_complete = (int64_t)counts[3];
+   M->n_pairs = M->locus_pair_off[(size_t)n_loci];
+   M->n_lfeat = totals[0], M->n_rfeat = totals[1];
+   if (M->n_pairs != M->n_single + M->n_complete) return bail(SBGPU_EHIP, "sbgpu_pair_mates_device: the pairs' count and the walk's counters disagree");
+   // ---- the pairs' own arena
+   const size_t np1 = (size_t)M->n_pairs + 1, nlf = (size_t)M->n_lfeat + 1, nrf = (size_t)M->n_rfeat + 1;
+   size_t t = 0;
+   const size_t u_mass = t; t += up256(np1 * 8);
+   const size_t u_loff = t; t += up256(np1 * 8);
+   const size_t u_roff = t; t += up256(np1 * 8);
+   const size_t u_ll = t; t += up256(nlf * 4);
+   const size_t u_lr = t; t += up256(nlf * 4);
+   const size_t u_rl = t; t += up256(nrf * 4);
+   const size_t u_rr = t; t += up256(nrf * 4);
+   const size_t u_lc = t; t += up256(nlf);
+   const size_t u_rc = t; t += up256(nrf);
+   SB_TRY(sb::dev_take(t, &M->arena, &M->arena_cap));
+   M->d_mass = (double *)(M->arena + u_mass);
+   M->d_left_off = (int64_t *)(M->arena + u_loff);
+   M->d_right_off = (int64_t *)(M->arena + u_roff);
+   M->d_left_left = (uint32_t *)(M->arena + u_ll), M->d_left_right = (uint32_t *)(M->arena + u_lr);
+   M->d_right_left = (uint32_t *)(M->arena + u_rl), M->d_right_right = (uint32_t *)(M->arena + u_rr);
+   M->d_left_code = (uint8_t *)(M->arena + u_lc), M->d_right_code = (uint8_t *)(M->arena + u_rc);
+   a.pair_mass = M->d_mass;
+   a.left_off = M->d_left_off, a.right_off = M->d_right_off;
+   a.left_code = M->d_left_code, a.right_code = M->d_right_code;
+   a.left_left = M->d_left_left, a.left_right = M->d_left_right;
+   a.right_left = M->d_right_left, a.right_right = M->d_right_right;
+   hipLaunchKernelGGL(sb::flat_mate_fill_kernel, dim3((unsigned)((np1 + 255) / 256)), dim3(256), 0, s, f, M->n_pairs);
+   SB_TRY(hipGetLastError());
+   SB_TRY(hipStreamSynchronize(s)); // the scratch goes back to the pool
+#undef SB_TRY
+   sb::dev_give(w, w_cap);
+   return SBGPU_OK;
+}
+
 extern "C" {
 
 void sbgpu_matepairs_destroy(sbgpu_matepairs_t *m)
 {
    if (!m) return;
-   if (m->arena) {
-      (void)hipSetDevice(m->device);
-      (void)hipFree(m->arena);
-   }
+   sb::dev_give(m->arena, m->arena_cap); // (waits for the device the arena lives on, as hipFree did)
    delete m;
 }
 
@@ -208,6 +337,18 @@ int sbgpu_pair_mates_device(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t 
       *out = M;
       return SBGPU_OK;
    }
+   // The flat form (matepair_flat.h: one device-wide sort brings the records of a read id together, another orders the pairs)
+   // serves every call; SBGPU_PAIR_PER_LOCUS=1 selects round 3's one-workgroup-per-cluster kernels (A/B runs, tests).
+   static const bool per_locus = std::getenv("SBGPU_PAIR_PER_LOCUS") && std::atoi(std::getenv("SBGPU_PAIR_PER_LOCUS")) != 0;
+   if (!per_locus) {
+      const int rc = pair_mates_flat(c, n_loci, dr, locus_read_off, s, M);
+      if (rc != SBGPU_OK) {
+         sbgpu_matepairs_destroy(M);
+         return rc;
+      }
+      *out = M;
+      return SBGPU_OK;
+   }
    SB_TRY(hipSetDevice(M->device));
    const size_t nr1 = (size_t)nr, nl1 = (size_t)n_loci + 1;
    size_t off = 0;
@@ -322,7 +463,7 @@ int sbgpu_pair_mates_device(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t 
    const size_t u_rr = t; t += up256(nrf * 4);
    const size_t u_lc = t; t += up256(nlf);
    const size_t u_rc = t; t += up256(nrf);
-   SB_TRY(hipMalloc(&M->arena, t));
+   SB_TRY(sb::dev_take(t, &M->arena, &M->arena_cap));
    M->d_mass = (double *)(M->arena + u_mass);
    M->d_left_off = (int64_t *)(M->arena + u_loff);
    M->d_right_off = (int64_t *)(M->arena + u_roff);

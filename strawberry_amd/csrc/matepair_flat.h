@@ -1,0 +1,252 @@
+// strawberry_amd/csrc/matepair_flat.h -- HitCluster::addOpenHit / addHit for ALL clusters of a call at once
+// (/root/reference/src/alignments.cpp:423-655; round 4: replaces one-workgroup-per-cluster, matepair_device.h).
+//
+// Only records of ONE read id of ONE cluster ever interact.  The per-cluster form brought them together with a bitonic sort
+// per cluster (LDS, or global memory for a highly expressed gene) and a sample's time was its biggest clusters'.  Here:
+//
+//   keys    a thread per record: (cluster << 32) | a 32-bit hash of the read id;
+//   sort    ONE stable device-wide radix sort (rocPRIM onesweep) on that key, the arrival index as value: the records of a
+//           read id become neighbours in ARRIVAL order.  Two read ids of a cluster that share a hash share a run of the key;
+//           the walk below takes the records of ITS read id out of the run (the ids themselves are compared), so a collision
+//           costs a few extra comparisons and nothing else;
+//   pack    the fields the rules look at, gathered into sorted order once (24 bytes per record, read in sequence afterwards);
+//   walk    the first record of every read id walks its group with the reference's open-mate rules (:535-641): a waiting
+//           mate is a state byte per record ("open" until a partner takes it, oldest first), so any number of mates of one
+//           read id may wait -- the per-cluster form's list of 8 is gone;
+//   rank    addHit is called when the SECOND mate arrives: the pairs are ordered by their completing record's arrival index.
+//           A second radix sort, on that index (records that complete nothing last), IS that order -- for all clusters at
+//           once, because the records come cluster by cluster; where a cluster's pairs begin is a binary search in it;
+//   count   the mates' feature counts per pair, two device-wide scans for their places;
+//   fill    a thread per pair writes its mates as MATCH / INTRON features (contig.cpp:12-53) and its mass.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "matepair_device.h"
+
+namespace sb {
+
+struct FlatRec { // a record as the rules see it (sorted order)
+   uint32_t rid_lo, rid_hi;
+   uint32_t left, right; // first block's left end, last block's right end
+   uint32_t ppos;        // the mate's position
+   uint32_t misc;        // bits 0-7: the record's flags; bit 8: it has blocks
+};
+
+struct FlatMateArgs {
+   MateArgs a;       // the records (inputs) and the pairs' arrays (outputs of the fill)
+   int64_t n_reads;
+   unsigned long long *key;         // per record, arrival order
+   const unsigned long long *skey;  // sorted
+   const int32_t *order;            // record (arrival index) at sorted position s
+   FlatRec *rec;                    // sorted order
+   uint8_t *state;                  // sorted order: 0 nothing, 1 waits for its mate, 2 taken
+   uint32_t *out_key, *out_val;     // sorted order: the completing record's arrival index (0xFFFFFFFF: completes nothing);
+                                    // bit 31: the completing record is the RIGHT mate, bits 0-30: the waiting mate's arrival
+                                    // index (0x7FFFFFFF: a single read)
+   const uint32_t *pair_rec, *pair_val; // out_key / out_val sorted by out_key: pair k of the call
+   int32_t *lfeat, *rfeat;          // per pair (one entry beyond the end: 0)
+   const int64_t *lscan, *rscan;    // exclusive scans of those
+   int64_t *locus_pair_off;         // [n_loci + 1]
+   unsigned long long *counts;      // 64 slots of 8 words (a cache line each): [0] refused [1] orphan [2] single [3] complete
+};
+
+__device__ __forceinline__ uint32_t flat_hash32(uint64_t x)
+{
+   x ^= x >> 33;
+   x *= 0xff51afd7ed558ccdull;
+   x ^= x >> 33;
+   x *= 0xc4ceb9fe1a85ec53ull;
+   x ^= x >> 33;
+   return (uint32_t)x;
+}
+
+__global__ __launch_bounds__(256) void flat_mate_keys_kernel(FlatMateArgs f)
+{
+   const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+   if (r >= f.n_reads) return;
+   int64_t lo = 0, hi = f.a.n_loci; // last cluster whose records begin at or before r
+   while (hi - lo > 1) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (f.a.locus_read_off[mid] <= r) lo = mid;
+      else hi = mid;
+   }
+   f.key[r] = ((unsigned long long)lo << 32) | flat_hash32(f.a.read_id[r]);
+}
+
+__global__ __launch_bounds__(256) void flat_mate_pack_kernel(FlatMateArgs f)
+{
+   const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+   if (s >= f.n_reads) return;
+   const MateArgs &a = f.a;
+   const int64_t r = f.order[s];
+   const int64_t b0 = a.block_off[r], b1 = a.block_off[r + 1];
+   const uint64_t rid = a.read_id[r];
+   FlatRec q;
+   q.rid_lo = (uint32_t)rid, q.rid_hi = (uint32_t)(rid >> 32);
+   q.left = b1 > b0 ? a.block_left[b0] : 0u;
+   q.right = b1 > b0 ? a.block_right[b1 - 1] : 0u;
+   q.ppos = a.partner_pos[r];
+   q.misc = (uint32_t)a.flags[r] | (b1 > b0 ? 256u : 0u);
+   f.rec[s] = q;
+   f.state[s] = 0;
+   f.out_key[s] = 0xFFFFFFFFu;
+   f.out_val[s] = 0;
+}
+
+// the first record of every read id walks its group (arrival order) with the reference's open-mate rules
+__global__ __launch_bounds__(256) void flat_mate_walk_kernel(FlatMateArgs f)
+{
+   const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+   int refused = 0, orphan = 0, single = 0, complete = 0;
+   if (s < f.n_reads) {
+      const unsigned long long k = f.skey[s];
+      const FlatRec me = f.rec[s];
+      bool first = true; // no earlier record of this read id in the key's run
+      for (int64_t t = s - 1; t >= 0 && f.skey[t] == k; --t)
+         if (f.rec[t].rid_lo == me.rid_lo && f.rec[t].rid_hi == me.rid_hi) {
+            first = false;
+            break;
+         }
+      if (first) {
+         // which records of the run wait for their mate: the first 64 positions behind s as a bit mask in registers (every
+         // group but a read with dozens of alignments in one cluster ends there), the rest as state bytes in memory
+         unsigned long long open_mask = 0;
+         bool far_open = false;
+         for (int64_t t = s; t < f.n_reads && f.skey[t] == k; ++t) {
+            const FlatRec q = t == s ? me : f.rec[t];
+            if (q.rid_lo != me.rid_lo || q.rid_hi != me.rid_hi) continue; // another read id with the same hash
+            const uint32_t fl = q.misc & 255u;
+            if (fl & 16u) continue; // not this cluster's record (sbgpu_assign_reads_*): never offered to addOpenHit
+            if (!(q.misc & 256u) || (int64_t)q.right - (int64_t)q.left > kMaxFragSpanDev) { // :512-518
+               ++refused;
+               continue;
+            }
+            const uint32_t r_t = (uint32_t)f.order[t];
+            if (q.ppos == 0 || (fl & 2u)) { // a single read (:535-545)
+               f.out_key[t] = r_t;
+               f.out_val[t] = ((fl & 1u) ? 0x80000000u : 0u) | 0x7FFFFFFFu;
+               ++single;
+               continue;
+            }
+            const int strand = (fl >> 2) & 3;
+            auto fits = [&](const FlatRec &w) { // :590-623
+               const int wstrand = (w.misc >> 2) & 3;
+               const bool strand_agree = wstrand == strand || strand == 0 || wstrand == 0;
+               return w.left == q.ppos && strand_agree && w.ppos == q.left;
+            };
+            int64_t hit = -1;
+            for (unsigned long long m = open_mask; m && hit < 0; m &= m - 1) { // oldest first
+               const int64_t o = s + (__ffsll((long long)m) - 1);
+               if (fits(o == s ? me : f.rec[o])) hit = o;
+            }
+            if (hit < 0 && far_open)
+               for (int64_t o = s + 64; o < t && hit < 0; ++o) {
+                  if (f.state[o] != 1) continue;
+                  const FlatRec w = f.rec[o];
+                  if (w.rid_lo != me.rid_lo || w.rid_hi != me.rid_hi) continue; // (another read id of the run, waiting for ITS mate)
+                  if (fits(w)) hit = o;
+               }
+            if (hit >= 0) {
+               const FlatRec w = hit == s ? me : f.rec[hit];
+               const bool waiting_is_left = w.ppos > w.left; // the waiting mate is the left one when its partner lies behind it (:559-585)
+               f.out_key[t] = r_t;
+               f.out_val[t] = (waiting_is_left ? 0x80000000u : 0u) | (uint32_t)f.order[hit];
+               if (hit - s < 64) open_mask &= ~(1ull << (hit - s));
+               else f.state[hit] = 2;
+               ++complete;
+               --orphan;
+            } else if (q.ppos == q.left) { // :585, :640: partner and read start at the same position
+               ++refused;
+            } else { // waits for its partner
+               if (t - s < 64) open_mask |= 1ull << (t - s);
+               else f.state[t] = 1, far_open = true;
+               ++orphan;
+            }
+         }
+      }
+   }
+   // the call's totals: a wave adds up in registers, the workgroup in LDS, and one lane adds the workgroup's four numbers to
+   // one of 64 slots (a slot per cache line): 3e5 waves adding to ONE word take their turns at the L2 -- 3.7 of this
+   // kernel's first 3.8 ms were that queue
+   for (int o = 32; o > 0; o >>= 1) {
+      refused += __shfl_xor(refused, o);
+      orphan += __shfl_xor(orphan, o);
+      single += __shfl_xor(single, o);
+      complete += __shfl_xor(complete, o);
+   }
+   __shared__ int part[4][4];
+   const int wave = threadIdx.x >> 6;
+   if ((threadIdx.x & 63) == 0) part[wave][0] = refused, part[wave][1] = orphan, part[wave][2] = single, part[wave][3] = complete;
+   __syncthreads();
+   if (threadIdx.x < 4) {
+      const long long v = (long long)part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+      if (v) atomicAdd(&f.counts[(size_t)(blockIdx.x & 63) * 8 + threadIdx.x], (unsigned long long)v);
+   }
+}
+
+// pair k (the k-th completing record in arrival order): its mates' feature counts; and where every cluster's pairs begin
+__global__ __launch_bounds__(256) void flat_mate_count_kernel(FlatMateArgs f)
+{
+   const MateArgs &a = f.a;
+   const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+   if (k <= a.n_loci) { // the first pair whose completing record is this cluster's: the keys ascend, cluster by cluster
+      const uint32_t want = (uint32_t)a.locus_read_off[k];
+      int64_t lo = 0, hi = f.n_reads;
+      while (lo < hi) {
+         const int64_t mid = (lo + hi) >> 1;
+         if (f.pair_rec[mid] < want) lo = mid + 1;
+         else hi = mid;
+      }
+      f.locus_pair_off[k] = k == a.n_loci ? [&] { // (all pairs: the first key that completes nothing)
+         int64_t l2 = 0, h2 = f.n_reads;
+         while (l2 < h2) {
+            const int64_t mid = (l2 + h2) >> 1;
+            if (f.pair_rec[mid] != 0xFFFFFFFFu) l2 = mid + 1;
+            else h2 = mid;
+         }
+         return l2;
+      }() : lo;
+   }
+   if (k > f.n_reads) return;
+   int lf = 0, rf = 0;
+   if (k < f.n_reads && f.pair_rec[k] != 0xFFFFFFFFu) {
+      const int64_t r = f.pair_rec[k];
+      const uint32_t v = f.pair_val[k];
+      const bool me_right = (v >> 31) != 0;
+      const int64_t w = (v & 0x7FFFFFFFu) == 0x7FFFFFFFu ? -1 : (int64_t)(v & 0x7FFFFFFFu);
+      const int nb_me = (int)(a.block_off[r + 1] - a.block_off[r]);
+      const int nb_w = w >= 0 ? (int)(a.block_off[w + 1] - a.block_off[w]) : 0;
+      const int nl = me_right ? nb_w : nb_me, nr = me_right ? nb_me : nb_w;
+      lf = nl ? 2 * nl - 1 : 0;
+      rf = nr ? 2 * nr - 1 : 0;
+   }
+   f.lfeat[k] = lf;
+   f.rfeat[k] = rf;
+}
+
+__global__ __launch_bounds__(256) void flat_mate_fill_kernel(FlatMateArgs f, int64_t n_pairs)
+{
+   const MateArgs &a = f.a;
+   const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+   if (k > n_pairs) return;
+   const int64_t lo = f.lscan[k], ro = f.rscan[k];
+   a.left_off[k] = lo;
+   a.right_off[k] = ro;
+   if (k == n_pairs) return; // (the entry beyond the last pair: the totals)
+   const int64_t r = f.pair_rec[k];
+   const uint32_t v = f.pair_val[k];
+   const bool me_right = (v >> 31) != 0;
+   const int64_t w = (v & 0x7FFFFFFFu) == 0x7FFFFFFFu ? -1 : (int64_t)(v & 0x7FFFFFFFu);
+   const int64_t rl = me_right ? w : r, rr = me_right ? r : w; // the left / right mate's record (-1: none)
+   if (rl >= 0) write_mate(a, rl, a.left_code, a.left_left, a.left_right, lo);
+   if (rr >= 0) write_mate(a, rr, a.right_code, a.right_left, a.right_right, ro);
+   // the reads' masses (src/read.cpp:49-53, 734-741)
+   double m;
+   if (w >= 0) m = 0.5 / (double)a.nh[rl] + 0.5 / (double)a.nh[rr];
+   else m = 1.0 / (double)a.nh[r];
+   a.pair_mass[k] = m;
+}
+
+} // namespace sb
