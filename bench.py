@@ -89,8 +89,13 @@ def pmc_traffic(workload, kind, kernel_key=None):
         if theirs != mine:
             return None, "%s was taken with library build %s, this is build %s: not quoted (re-run tools/profile_round.sh)" % (
                 os.path.basename(files[-1]), theirs, mine)
-        c = next(v for k, v in d.items() if key in k)
-        fetch_kb, write_kb = c["FETCH_SIZE"]["mean_per_dispatch"], c["WRITE_SIZE"]["mean_per_dispatch"]
+        # a stage may be several instantiations of one kernel template (bins_accum_kernel<1024,256,..>, <2048,1400,..>, ...), each
+        # launched once per step: the stage's traffic is the SUM over the summary's entries that match, like its time
+        match = [v for k, v in d.items() if isinstance(v, dict) and key in k]
+        if not match:
+            raise StopIteration
+        fetch_kb = sum(c["FETCH_SIZE"]["mean_per_dispatch"] for c in match)
+        write_kb = sum(c["WRITE_SIZE"]["mean_per_dispatch"] for c in match)
     except (StopIteration, KeyError, ValueError):
         return None, "PMC summary %s has no FETCH_SIZE/WRITE_SIZE for %s" % (os.path.basename(files[-1]), key)
     return (int((2.0 * fetch_kb + write_kb) * 1024),

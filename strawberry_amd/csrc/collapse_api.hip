@@ -149,6 +149,7 @@ static int collapse_flat(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_pairs_t *dp
    tb = tmp_bytes;
    SB_TRY(rocprim::inclusive_scan(tmp, tb, (const int32_t *)f.kept_pos, (int32_t *)(w + o_last), n, rocprim::maximum<int32_t>(), s));
    hipLaunchKernelGGL(sb::flat_heads_kernel, dim3(gp), dim3(256), 0, s, f);
+   hipLaunchKernelGGL(sb::flat_heads_long_kernel, dim3(256), dim3(64), 0, s, f); // (returns at once unless a mate has more than 24 features)
    SB_TRY(hipGetLastError());
    tb = tmp_bytes;
    SB_TRY(rocprim::inclusive_scan(tmp, tb, rocprim::make_transform_iterator((const uint8_t *)f.head, [] __device__(uint8_t v) { return (int32_t)v; }), (int32_t *)(w + o_gid), n, rocprim::plus<int32_t>(), s));
@@ -171,7 +172,7 @@ static int collapse_flat(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_pairs_t *dp
    SB_TRY(hipStreamSynchronize(s));
    if (flags) {
       if (flags & sb::kCollapseNoMates) return bail(SBGPU_EINVAL, "sbgpu_collapse_pairs_device: a pair without mates");
-      return bail(SBGPU_EUNSUPPORTED, "sbgpu_collapse_pairs_device: not covered by the device form: a mate has more than 24 features; use sbgpu_collapse_pairs_host");
+      return bail(SBGPU_EUNSUPPORTED, "sbgpu_collapse_pairs_device: not covered by the device form: a mate has more than 512 features; use sbgpu_collapse_pairs_host");
    }
    U->n_filtered = (int64_t)counts[0];
    U->n_rejected = (int64_t)counts[1];
@@ -202,6 +203,7 @@ static int collapse_flat(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_pairs_t *dp
    a.feat_right = U->d_feat_right;
    a.hit_mass = U->d_mass;
    hipLaunchKernelGGL(sb::flat_fill_kernel, dim3(gp), dim3(256), 0, s, f);
+   hipLaunchKernelGGL(sb::flat_fill_long_kernel, dim3(256), dim3(64), 0, s, f);
    SB_TRY(hipGetLastError());
    SB_TRY(hipStreamSynchronize(s)); // the scratch goes back to the pool
 #undef SB_TRY

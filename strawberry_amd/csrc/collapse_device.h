@@ -25,7 +25,8 @@ namespace sb {
 
 constexpr int kCollapseMax = 4096;   // pairs of one locus (LDS sort)
 constexpr int kCollapseThreads = 256;
-constexpr int kMateFeatMax = 24;     // features of one mate the device form handles
+constexpr int kMateFeatMax = 24;     // features of one mate the main kernels handle (the merged list in registers)
+constexpr int kMateFeatLong = 512;   // ... and the flat form's kernels for long mates (long reads: the list in private memory)
 enum : int32_t { kCollapseTooMany = 1, kCollapseLongMate = 2, kCollapseNoMates = 4 };
 
 struct CollapseArgs {
@@ -95,9 +96,11 @@ struct Feat {
    uint8_t c;
 };
 __device__ __forceinline__ bool feat_less(const Feat &x, const Feat &y) { return x.l != y.l ? x.l < y.l : (x.r - x.l) < (y.r - y.l); }
-__device__ inline int hit_features_dev(const MateRef &a, const MateRef &b, uint8_t *out_c, uint32_t *out_l, uint32_t *out_r)
+// CAP: the most features a mate may have (the merged list lives in registers / private memory: 2 CAP + 1 entries)
+template <int CAP>
+__device__ inline int hit_features_cap(const MateRef &a, const MateRef &b, uint8_t *out_c, uint32_t *out_l, uint32_t *out_r)
 {
-   Feat g[2 * kMateFeatMax + 1];
+   Feat g[2 * CAP + 1];
    int n = 0;
    auto push_sorted = [&](const Feat &f) { // insertion keeps g sorted by (offset, length)
       int pos = n++;
@@ -148,6 +151,11 @@ __device__ inline int hit_features_dev(const MateRef &a, const MateRef &b, uint8
          out_r[i] = g[i].r;
       }
    return n;
+}
+
+__device__ inline int hit_features_dev(const MateRef &a, const MateRef &b, uint8_t *out_c, uint32_t *out_l, uint32_t *out_r)
+{
+   return hit_features_cap<kMateFeatMax>(a, b, out_c, out_l, out_r);
 }
 
 __device__ __forceinline__ uint32_t pair_left_pos(const MateRef &a, const MateRef &b)

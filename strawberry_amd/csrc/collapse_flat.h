@@ -66,7 +66,7 @@ struct FlatCollapseArgs {
    const int64_t *feat_base;          // exclusive scan of nfeat  (likewise)
    double *gmass;                     // [groups + 1]
    int64_t *locus_hit_off;            // [n_loci + 1]
-   unsigned long long *counts;        // [0] filtered, [1] rejected
+   unsigned long long *counts;        // [0] filtered, [1] rejected, [2] != 0: a pair with a long mate was met
 };
 
 enum : int32_t { kNeedSeqMass = 1, kNeedSeqSd = 2 };
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void flat_keys_kernel(FlatCollapseArgs f)
    if (p < f.n_pairs) {
       l = flat_locus_of(a.locus_pair_off, a.n_loci, p);
       const MateRef x = left_mate(a, p), y = right_mate(a, p);
-      if (x.n > kMateFeatMax || y.n > kMateFeatMax) bad |= kCollapseLongMate;
+      if (x.n > kMateFeatLong || y.n > kMateFeatLong) bad |= kCollapseLongMate;
       uint32_t lp = 0xffffffffu, rp = 0xffffffffu;
       if (x.n == 0 && y.n == 0) bad |= kCollapseNoMates;
       else lp = pair_left_pos(x, y), rp = pair_right_pos(x, y);
@@ -260,8 +260,13 @@ __global__ __launch_bounds__(256) void flat_heads_kernel(FlatCollapseArgs f)
          }
          if (!same) {
             hd = 1;
-            nf = hit_features_dev(x, y, nullptr, nullptr, nullptr);
-            if (nf <= 0) nf = 0, rej = 1; // Contig(PairedHit) rejects the pair: no hit, its mass stays in the cluster's
+            if (x.n > kMateFeatMax || y.n > kMateFeatMax) { // a long mate (long reads): flat_heads_long_kernel counts its features
+               nf = -1;
+               f.counts[2] = 1; // (any writer, same value)
+            } else {
+               nf = hit_features_dev(x, y, nullptr, nullptr, nullptr);
+               if (nf <= 0) nf = 0, rej = 1; // Contig(PairedHit) rejects the pair: no hit, its mass stays in the cluster's
+            }
          }
       }
       f.head[s] = hd;
@@ -272,6 +277,40 @@ __global__ __launch_bounds__(256) void flat_heads_kernel(FlatCollapseArgs f)
    if ((threadIdx.x & 63) == 0) {
       if (bf) atomicAdd(&f.counts[0], (unsigned long long)__popcll(bf));
       if (br) atomicAdd(&f.counts[1], (unsigned long long)__popcll(br));
+   }
+}
+
+// ---- pairs with a mate of more than kMateFeatMax features (long reads: dozens of exons): the same two steps -- the
+// features' count for the heads, the features themselves for the fill -- with the merged list in private memory
+// (hit_features_cap<kMateFeatLong>: 12 KB per lane).  Launched with a small grid after the main kernels; it returns at once
+// when they met no such pair (counts[2]).
+__global__ __launch_bounds__(64) void flat_heads_long_kernel(FlatCollapseArgs f)
+{
+   if (!f.counts[2]) return;
+   const CollapseArgs &a = f.a;
+   for (int64_t s = (int64_t)blockIdx.x * 64 + threadIdx.x; s < f.n_pairs; s += (int64_t)gridDim.x * 64) {
+      if (f.nfeat[s] != -1) continue;
+      const int64_t p = f.order[s];
+      int nf = hit_features_cap<kMateFeatLong>(left_mate(a, p), right_mate(a, p), nullptr, nullptr, nullptr);
+      if (nf <= 0) {
+         nf = 0;
+         atomicAdd(&f.counts[1], 1ull);
+      }
+      f.nfeat[s] = nf;
+      f.is_hit[s] = nf > 0 ? 1 : 0;
+   }
+}
+__global__ __launch_bounds__(64) void flat_fill_long_kernel(FlatCollapseArgs f)
+{
+   if (!f.counts[2]) return;
+   const CollapseArgs &a = f.a;
+   for (int64_t s = (int64_t)blockIdx.x * 64 + threadIdx.x; s < f.n_pairs; s += (int64_t)gridDim.x * 64) {
+      if (f.nfeat[s] <= 0) continue;
+      const int64_t p = f.order[s];
+      const MateRef x = left_mate(a, p), y = right_mate(a, p);
+      if (x.n <= kMateFeatMax && y.n <= kMateFeatMax) continue; // flat_fill_kernel's
+      const int64_t fb = f.feat_base[s];
+      hit_features_cap<kMateFeatLong>(x, y, a.feat_code + fb, a.feat_left + fb, a.feat_right + fb);
    }
 }
 
@@ -383,7 +422,9 @@ __global__ __launch_bounds__(256) void flat_fill_kernel(FlatCollapseArgs f)
    a.hit_locus[h] = (int32_t)(f.key2s[s] >> 32);
    a.feat_off[h] = fb;
    a.hit_mass[h] = (float)f.gmass[f.gid[s]]; // stored as float (Contig::mass())
-   hit_features_dev(left_mate(a, p), right_mate(a, p), a.feat_code + fb, a.feat_left + fb, a.feat_right + fb);
+   const MateRef x = left_mate(a, p), y = right_mate(a, p);
+   if (x.n <= kMateFeatMax && y.n <= kMateFeatMax) hit_features_dev(x, y, a.feat_code + fb, a.feat_left + fb, a.feat_right + fb);
+   // (else: flat_fill_long_kernel writes the features)
 }
 
 } // namespace sb

@@ -141,10 +141,15 @@ def test_device_collapse_big_loci(ctx, oracle):
 
 
 def test_device_collapse_declines_what_it_does_not_cover(ctx):
+    """Round 4: a mate of 25 features (13 blocks) is served -- the limit of 24 was the per-cluster kernels'; the flat form's
+    long-mate kernels go to 512 features, and only beyond that the call declines."""
     from strawberry_amd import _lib, exonbin as eb
     long_mate = [[(1000 + 100 * k, 1040 + 100 * k) for k in range(13)]]      # 25 features
-    with pytest.raises(_lib.SbgpuError, match="24 features"):
-        eb.collapse_pairs(1, [0], [1.0], long_mate, [[]], device=ctx)
+    g, r = eb.collapse_pairs(1, [0], [1.0], long_mate, [[]], device=ctx), eb.collapse_pairs(1, [0], [1.0], long_mate, [[]])
+    same(g[0], r[0], g[1], r[1], g[2], r[2])
+    huge_mate = [[(1000 + 100 * k, 1040 + 100 * k) for k in range(300)]]     # 599 features
+    with pytest.raises(_lib.SbgpuError, match="512 features"):
+        eb.collapse_pairs(1, [0], [1.0], huge_mate, [[]], device=ctx)
 
 
 def test_collapsed_hits_feed_the_chain_without_leaving_the_device(ctx):
@@ -231,3 +236,42 @@ def test_flat_collapse_any_order_paths_equal_the_running_sums(ctx, oracle, monke
     monkeypatch.delenv("SBGPU_COLLAPSE_FORCE_SEQ")
     same(g2[0], r[0], g2[1], r[1], g2[2], r[2])
     XU.check_collapse_against_oracle(oracle, len(sizes), args[1], [nh[i] for i in perm], args[3], args[4], g[0], g[1], g[2])
+
+
+def test_device_collapse_long_mates(ctx, oracle):
+    """Long reads: mates of 13 to 120 blocks (25 to 239 features; the main kernels keep a mate's 24 in registers), next to
+    ordinary pairs, duplicates of the long ones included; overlapping long mates whose blocks merge, and one pair the merge
+    rejects.  The device form (flat_heads_long_kernel / flat_fill_long_kernel) equals the host form and the oracle."""
+    from strawberry_amd import exonbin as eb
+    rng = np.random.default_rng(7)
+
+    def blocks(start, n, ex=40, intron=100):
+        return [(start + k * (ex + intron), start + k * (ex + intron) + ex - 1) for k in range(n)]
+
+    loc, nh, left, right = [], [], [], []
+    for l in range(3):
+        base = 2_000_000 * (l + 1)
+        for k in range(300):
+            s0 = base + int(rng.integers(0, 60))
+            kind = rng.random()
+            if kind < 0.5:                                   # ordinary pair
+                lb, rb = [(s0, s0 + 74)], [(s0 + 200, s0 + 274)]
+            elif kind < 0.8:                                 # a long left mate, single read or with a short right mate far behind
+                n = int(rng.choice([13, 30, 120]))
+                lb = blocks(s0, n)
+                rb = [] if rng.random() < 0.5 else [(lb[-1][1] + 500, lb[-1][1] + 574)]
+            else:                                            # two long mates that overlap: the shared blocks merge
+                n = int(rng.choice([20, 45]))
+                lb = blocks(s0, n)
+                rb = blocks(lb[n // 2][0], n)                # starts at one of the left mate's blocks: same exon grid
+            loc.append(l), nh.append(int(rng.choice([1, 2]))), left.append(lb), right.append(rb)
+    # overlapping long mates on DIFFERENT exon grids: two different introns meet -> Contig(PairedHit) rejects the pair
+    loc.append(0), nh.append(1), left.append(blocks(2_000_000, 30)), right.append(blocks(2_000_000 + 17, 30, ex=40, intron=100)[:30])
+    perm = rng.permutation(len(loc))
+    args = (3, [loc[i] for i in perm], [1.0 / nh[i] for i in perm], [left[i] for i in perm], [right[i] for i in perm])
+    r = eb.collapse_pairs(*args)
+    g = eb.collapse_pairs(*args, device=ctx)
+    same(g[0], r[0], g[1], r[1], g[2], r[2])
+    nfeat = np.diff(g[0].feat_off)
+    assert nfeat.max() > 200 and (nfeat > 48).sum() > 20 and g[2]["rejected"] >= 1
+    XU.check_collapse_against_oracle(oracle, 3, args[1], [nh[i] for i in perm], args[3], args[4], g[0], g[1], g[2])
