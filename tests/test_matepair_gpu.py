@@ -183,3 +183,32 @@ def test_device_read_stream_equals_oracle(ctx, oracle):
         np.testing.assert_array_equal(got, want)
         np.testing.assert_array_equal(off, woff)
         np.testing.assert_array_equal((fl & 16) != 0, want < 0)
+
+
+def test_device_pairing_many_waiting_mates_and_long_groups(ctx, oracle):
+    """A multi-mapped read with 12 and one with 40 left mates that ALL arrive before the first right mate (the
+    per-cluster kernels kept at most 8 waiting mates of a read id and declined beyond; the flat form keeps a register mask
+    for a group's first 64 records and state bytes behind it), and one read id with 150 alignments in the cluster (its
+    group runs past the mask): every pair, in the reference's completion order -- equal to the oracle and the host form."""
+    from strawberry_amd import exonbin as eb
+    rng = np.random.default_rng(5)
+    recs = []
+    base = 500000
+    for rid, n_aln in ((11, 12), (22, 40), (33, 150)):
+        lefts = base + rid * 100000 + np.sort(rng.permutation(50000)[:n_aln])
+        for s0 in lefts.tolist():
+            recs.append({"id": rid, "blocks": [(s0, s0 + 74)], "ppos": s0 + 60000, "flags": (1 << 2), "nh": n_aln})
+        for s0 in lefts.tolist():                          # the right mates arrive later, in the same order: oldest waiting mate first
+            recs.append({"id": rid, "blocks": [(s0 + 60000, s0 + 60074)], "ppos": s0, "flags": MU.REVERSE | (1 << 2), "nh": n_aln})
+    recs += MU.random_cluster(rng, 300, base=base + 50)
+    order = np.argsort([r["blocks"][0][0] for r in recs], kind="stable")
+    cluster = [recs[i] for i in order]
+    reads = eb.Reads([0] * len(cluster), *MU.arrays(cluster))
+    got, host = eb.pair_mates(1, reads, device=ctx), eb.pair_mates(1, reads)
+    assert got["info"]["on_device"] and got["info"]["complete"] >= 12 + 40 + 150
+    for k in ("pair_off", "mass", "left_off", "right_off"):
+        np.testing.assert_array_equal(got[k], host[k], err_msg=k)
+    for side in ("left", "right"):
+        for x, y in zip(got[side], host[side]):
+            np.testing.assert_array_equal(x, y)
+    check_against_oracle(oracle, [cluster], got)
