@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: the round's evidence.  Usage (repo root): bash tools/profile_round.sh r01
 # Everything judged is collected under gpurun_out/$R/summary/ -- copy that directory's files into profiles/.
-R=${1:-r03}
+R=${1:-r04}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/$R
 SUM=$OUT/summary
@@ -92,4 +92,11 @@ cp $OUT/binseq/stats/bs_kernel_stats.csv $SUM/${R}_binseq_kernel_stats.csv
 (timeout 600 python tools/probe_c3t.py; timeout 300 python tools/probe_wide_loci.py; timeout 300 python tools/probe_wide_shapes.py; timeout 600 python tools/check_wide_shapes.py) 2>/dev/null > $SUM/${R}_wide_loci.txt
 timeout 600 python tools/c5_sweep.py $SUM/${R}_c5_sweep.json > /dev/null 2>&1
 timeout 120 ./tools/bin/microbench > $SUM/${R}_microbench.txt 2>&1
+# round 4: the front end (records -> pairs -> unique hits, flat kernels) with its kernel stats; the PCIe-inclusive host entry;
+# the drop-in under the reference's own driver, timed (oracle/_ref binaries)
+(timeout 300 python tools/bench_frontend.py; timeout 300 python tools/bench_frontend.py 20000 1e7 0.5) 2>/dev/null > $SUM/${R}_frontend.json
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_frontend -o fe -- python3 $REPO/tools/bench_frontend.py > $OUT/stats_frontend.log 2>&1)
+for f in $(find $OUT/stats_frontend -name "*kernel_stats.csv"); do cp $f $SUM/${R}_frontend_kernel_stats.csv; done
+(timeout 600 python tools/bench_host_entry.py 60000 2e8 3 2>/dev/null | tail -1) > $SUM/${R}_host_entry.json
+(timeout 1200 python tools/dropin_timing.py 2>/dev/null) > $SUM/${R}_dropin.txt
 cat $SUM/${R}_pytest_gpu.txt; cat $SUM/${R}_bench_c3.json; echo; cat $SUM/${R}_bench_c2.json; echo; ls -la $SUM
