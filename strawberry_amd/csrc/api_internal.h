@@ -71,6 +71,7 @@ struct DeviceIsoSegments {
 // The isoforms in the segment basis (exonbin_device.h: iso_masks_kernel): made per call, or once for a resident annotation
 struct DeviceSegBasis {
    const uint64_t *member = nullptr, *start = nullptr, *adj = nullptr;
+   const uint64_t *member_hi = nullptr, *start_hi = nullptr, *adj_hi = nullptr; // bits 64-127 (loci of 65-128 segments / isoforms)
    const uint32_t *ok = nullptr;
 };
 size_t seg_basis_bytes(int64_t n_loci, int64_t n_iso);

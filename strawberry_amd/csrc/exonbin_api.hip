@@ -23,12 +23,13 @@ static size_t up256b(size_t b) { return (b + 255) & ~(size_t)255; }
 size_t seg_basis_bytes(int64_t n_loci, int64_t n_iso)
 {
    const size_t ni1 = (size_t)(n_iso > 0 ? n_iso : 1);
-   return 2 * up256b(ni1 * 8) + up256b((size_t)n_loci * 8) + up256b((size_t)n_loci * 4);
+   return 4 * up256b(ni1 * 8) + 2 * up256b((size_t)n_loci * 8) + up256b((size_t)n_loci * 4);
 }
 int make_seg_basis(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, int64_t n_iso, char *dm, void *stream, DeviceSegBasis *out)
 {
    const size_t ni1 = (size_t)(n_iso > 0 ? n_iso : 1);
-   const size_t o_mem = 0, o_sta = up256b(ni1 * 8), o_adj = 2 * o_sta, o_ok = o_adj + up256b((size_t)an->n_loci * 8);
+   const size_t isz = up256b(ni1 * 8), lsz = up256b((size_t)an->n_loci * 8);
+   const size_t o_mem = 0, o_sta = isz, o_memh = 2 * isz, o_stah = 3 * isz, o_adj = 4 * isz, o_adjh = o_adj + lsz, o_ok = o_adjh + lsz;
    sb::ExonBinArgs a = {};
    a.iso_off = an->iso_off;
    a.exon_off = an->exon_off;
@@ -37,14 +38,19 @@ int make_seg_basis(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, int64_t n_iso, 
    a.seg_off = an->seg_off;
    a.seg_left = an->seg_left;
    a.seg_right = an->seg_right;
-   const int64_t cap = (int64_t)sb::ctx_cu_count(c) * 8, lb = (an->n_loci + 255) / 256;
-   hipLaunchKernelGGL(sb::iso_masks_kernel, dim3((unsigned)(lb < cap ? lb : cap)), dim3(256), 0, (hipStream_t)stream, a, an->n_loci,
-                      (uint64_t *)(dm + o_mem), (uint64_t *)(dm + o_sta), (uint32_t *)(dm + o_ok), (uint64_t *)(dm + o_adj));
+   const int64_t cap = (int64_t)sb::ctx_cu_count(c) * 8, lb = (an->n_loci + 255) / 256, ib = ((int64_t)ni1 + 255) / 256;
+   hipLaunchKernelGGL(sb::iso_masks_locus_kernel, dim3((unsigned)(lb < cap ? lb : cap)), dim3(256), 0, (hipStream_t)stream, a, an->n_loci,
+                      (uint32_t *)(dm + o_ok), (uint64_t *)(dm + o_adj), (uint64_t *)(dm + o_adjh));
+   hipLaunchKernelGGL(sb::iso_masks_kernel, dim3((unsigned)(ib < cap * 4 ? ib : cap * 4)), dim3(256), 0, (hipStream_t)stream, a, an->n_loci, n_iso,
+                      (uint64_t *)(dm + o_mem), (uint64_t *)(dm + o_sta), (uint32_t *)(dm + o_ok), (uint64_t *)(dm + o_memh), (uint64_t *)(dm + o_stah));
    const hipError_t e = hipGetLastError();
    if (e != hipSuccess) return api_fail(SBGPU_EHIP, std::string("iso_masks_kernel: ") + hipGetErrorString(e));
    out->member = (const uint64_t *)(dm + o_mem);
    out->start = (const uint64_t *)(dm + o_sta);
    out->adj = (const uint64_t *)(dm + o_adj);
+   out->member_hi = (const uint64_t *)(dm + o_memh);
+   out->start_hi = (const uint64_t *)(dm + o_stah);
+   out->adj_hi = (const uint64_t *)(dm + o_adjh);
    out->ok = (const uint32_t *)(dm + o_ok);
    return SBGPU_OK;
 }
@@ -83,6 +89,7 @@ int exonbin_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgp
    a.iso_member = a.iso_start = nullptr;
    a.locus_seg_ok = nullptr;
    a.locus_adj = nullptr;
+   a.iso_member_hi = a.iso_start_hi = a.locus_adj_hi = nullptr;
    // the isoforms in the segment basis (exonbin_device.h): loci of up to 64 segments (key_words <= 2 covers them all)
    static const bool seg_basis = !(std::getenv("SBGPU_EXONBIN_SEGBASIS") && std::atoi(std::getenv("SBGPU_EXONBIN_SEGBASIS")) == 0);
    if (seg_basis && key_words >= 1 && compat_words >= 1) {
@@ -105,6 +112,9 @@ int exonbin_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgp
       a.iso_start = sbz.start;
       a.locus_seg_ok = sbz.ok;
       a.locus_adj = sbz.adj;
+      a.iso_member_hi = sbz.member_hi;
+      a.iso_start_hi = sbz.start_hi;
+      a.locus_adj_hi = sbz.adj_hi;
    }
    const int64_t blocks_wanted = (hits->n_hits + 255) / 256;
    if (blocks_wanted > 0x7fffffff) return api_fail(SBGPU_ESHAPE, "sbgpu_exonbin_device: more than 2^39 hits in one call");
@@ -118,6 +128,10 @@ int exonbin_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgp
                             (hipStream_t)stream, a.n_hits, a.feat_off, a.feat_left, a.feat_right, d_span, d_fhash);
    } else {
       hipLaunchKernelGGL(sb::exonbin_kernel, dim3((unsigned)blocks_wanted), dim3(256), 0, (hipStream_t)stream, a);
+      // loci of 65-128 segments or isoforms (form 3 of iso_masks_kernel): their regular hits in the 128-bit segment basis.
+      // Only an annotation with words beyond two can have such a locus; everywhere else the kernel is not launched.
+      if (a.locus_seg_ok && (key_words > 2 || compat_words > 2))
+         hipLaunchKernelGGL(sb::exonbin_seg128_kernel, dim3((unsigned)blocks_wanted), dim3(256), 0, (hipStream_t)stream, a);
    }
    hipError_t e = hipGetLastError();
    if (e != hipSuccess) return api_fail(SBGPU_EHIP, std::string("exonbin_kernel: ") + hipGetErrorString(e));

@@ -46,8 +46,10 @@ struct ExonBinArgs {
    // iso_member[i]: segment s of the locus lies in isoform i; bit s of iso_start[i]: one of its exons starts there -- and
    // per locus whether that form may be used (<= 64 segments, every exon a run of adjacent segments)
    const uint64_t *iso_member, *iso_start;
-   const uint32_t *locus_seg_ok; // 0: no (the exon walk), 1: yes, up to 32 segments, 2: yes, up to 64
+   const uint32_t *locus_seg_ok; // 0: no (the exon walk), 1: yes, up to 32 segments, 2: yes, up to 64, 3: yes, 65-128 segments
+                                 // or isoforms: bits 64-127 of the masks in the *_hi arrays, served by exonbin_seg128_kernel
    const uint64_t *locus_adj; // per locus: bit s = segment s begins right behind segment s - 1
+   const uint64_t *iso_member_hi, *iso_start_hi, *locus_adj_hi;
 };
 
 // (a 32-bit hash on purpose: two integer multiplies per feature -- 64-bit products cost four each, and integer
@@ -345,41 +347,62 @@ __device__ __forceinline__ void exonbin_locus_uniform(const ExonBinArgs &a, int 
 // the wave's span (the walk the bin key needs anyway); per isoform: four AND tests against two 64-bit words.
 // iso_masks_kernel checks the premise per locus (every exon exactly a run of adjacent segments) and leaves the exon
 // walk to the loci that fail it or have more than 64 segments.
-__global__ __launch_bounds__(256) void iso_masks_kernel(ExonBinArgs a, int64_t n_loci, uint64_t *member, uint64_t *start, uint32_t *seg_ok,
-                                                        uint64_t *locus_adj)
+// Two launches: iso_masks_locus_kernel (a thread per locus: the shape test, the adjacency words) and iso_masks_kernel (a
+// thread per ISOFORM: its member / start words; an exon that is not a run of adjacent segments clears the locus' form).  A
+// thread per locus for everything took 3.9 ms on 1 500 loci of a hundred segments and a dozen isoforms each.
+__global__ __launch_bounds__(256) void iso_masks_locus_kernel(ExonBinArgs a, int64_t n_loci, uint32_t *seg_ok, uint64_t *locus_adj, uint64_t *locus_adj_hi)
 {
    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
    for (int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; l < n_loci; l += stride) {
-      const int64_t i0 = a.iso_off[l], i1 = a.iso_off[l + 1], s0 = a.seg_off[l];
+      const int64_t ni = a.iso_off[l + 1] - a.iso_off[l], s0 = a.seg_off[l];
       const int nseg = (int)(a.seg_off[l + 1] - s0);
-      bool ok = nseg >= 1 && nseg <= 64 && i1 - i0 <= 64; // (a lane per segment and per isoform in exonbin_locus_segbasis)
-      for (int64_t i = i0; i < i1; ++i) {
-         uint64_t m = 0, st = 0;
-         int sidx = 0;
-         for (int64_t e = a.exon_off[i]; ok && e < a.exon_off[i + 1]; ++e) {
-            const uint32_t xl = a.exon_left[e], xr = a.exon_right[e];
-            while (sidx < nseg && a.seg_left[s0 + sidx] < xl) ++sidx;
-            if (sidx >= nseg || a.seg_left[s0 + sidx] != xl) {
-               ok = false;
-               break;
-            }
-            st |= 1ull << sidx;
-            uint32_t reach = xl - 1;
-            while (sidx < nseg && a.seg_left[s0 + sidx] == reach + 1 && a.seg_right[s0 + sidx] <= xr) {
-               m |= 1ull << sidx;
-               reach = a.seg_right[s0 + sidx];
-               ++sidx;
-            }
-            if (reach != xr) ok = false;
-         }
-         member[i] = m;
-         start[i] = st;
+      const bool ok = nseg >= 1 && nseg <= 128 && ni <= 128; // (exonbin_seg128_kernel: two segments per lane, masks of 128 bits)
+      const bool small = nseg <= 64 && ni <= 64;             // (exonbin_locus_segbasis: a lane per segment and per isoform)
+      uint64_t adj[2] = {0, 0};
+      for (int sg = 1; sg < nseg && sg < 128; ++sg)
+         if (a.seg_left[s0 + sg] == a.seg_right[s0 + sg - 1] + 1u) adj[sg >> 6] |= 1ull << (sg & 63);
+      locus_adj[l] = adj[0];
+      locus_adj_hi[l] = adj[1];
+      seg_ok[l] = ok ? (small ? (nseg <= 32 ? 1u : 2u) : 3u) : 0u;
+   }
+}
+__global__ __launch_bounds__(256) void iso_masks_kernel(ExonBinArgs a, int64_t n_loci, int64_t n_iso, uint64_t *member, uint64_t *start, uint32_t *seg_ok,
+                                                        uint64_t *member_hi, uint64_t *start_hi)
+{
+   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_iso; i += stride) {
+      int64_t lo = 0, hi = n_loci; // the isoform's locus: the last l with iso_off[l] <= i
+      while (hi - lo > 1) {
+         const int64_t mid = (lo + hi) >> 1;
+         if (a.iso_off[mid] <= i) lo = mid;
+         else hi = mid;
       }
-      uint64_t adj = 0;
-      for (int sg = 1; sg < nseg && sg < 64; ++sg)
-         if (a.seg_left[s0 + sg] == a.seg_right[s0 + sg - 1] + 1u) adj |= 1ull << sg;
-      locus_adj[l] = adj;
-      seg_ok[l] = ok ? (nseg <= 32 ? 1u : 2u) : 0u;
+      const int64_t l = lo, s0 = a.seg_off[l];
+      const int nseg = (int)(a.seg_off[l + 1] - s0);
+      bool ok = seg_ok[l] != 0u; // (the shape; another isoform's thread may clear it meanwhile: then these words are not read)
+      uint64_t m[2] = {0, 0}, st[2] = {0, 0};
+      int sidx = 0;
+      for (int64_t e = a.exon_off[i]; ok && e < a.exon_off[i + 1]; ++e) {
+         const uint32_t xl = a.exon_left[e], xr = a.exon_right[e];
+         while (sidx < nseg && a.seg_left[s0 + sidx] < xl) ++sidx;
+         if (sidx >= nseg || a.seg_left[s0 + sidx] != xl) {
+            ok = false;
+            break;
+         }
+         st[sidx >> 6] |= 1ull << (sidx & 63);
+         uint32_t reach = xl - 1;
+         while (sidx < nseg && a.seg_left[s0 + sidx] == reach + 1 && a.seg_right[s0 + sidx] <= xr) {
+            m[sidx >> 6] |= 1ull << (sidx & 63);
+            reach = a.seg_right[s0 + sidx];
+            ++sidx;
+         }
+         if (reach != xr) ok = false;
+      }
+      member[i] = m[0];
+      start[i] = st[0];
+      member_hi[i] = m[1];
+      start_hi[i] = st[1];
+      if (!ok && seg_ok[l] != 0u) seg_ok[l] = 0u; // an exon that is no run of adjacent segments: the exon walk for this locus
    }
 }
 
@@ -553,7 +576,11 @@ __global__ __launch_bounds__(256) void exonbin_kernel(ExonBinArgs a)
       const int loc = __builtin_amdgcn_readlane(my_loc, __ffsll((long long)m) - 1);
       const bool mine = todo && my_loc == loc;
       const uint32_t form = a.locus_seg_ok ? seg_ok[loc] : 0u; // 0: exon walk; 1: <= 32 segments; 2: <= 64
-      if (form) {
+      if (form == 3u) {
+         // 65-128 segments or isoforms: the regular hits are exonbin_seg128_kernel's (launched behind this one); the others
+         // take the per-lane walk below
+         per_lane = per_lane || (mine && !(seg_regular || nf == 0));
+      } else if (form) {
          per_lane = per_lane || (mine && !(seg_regular || nf == 0));
          // (a uint32_t instantiation for loci of up to 32 segments was measured: 5.5 instead of 4.9 ms on the chain
          // sample -- the second copy of the code costs more than the halved mask arithmetic saves)
@@ -570,6 +597,155 @@ __global__ __launch_bounds__(256) void exonbin_kernel(ExonBinArgs a)
    if (active && (is_long || todo || per_lane || !(regular || nf == 0))) {
       MemHit m = {a.feat_code + f0, a.feat_left + f0, a.feat_right + f0, nf};
       exonbin_hit(a, hidx, m);
+   }
+}
+
+// ------------------------------------------------------------------ segment basis, 65-128 segments or isoforms
+// The same statements as exonbin_locus_segbasis with masks of 128 bits: a lane holds two segments (s and s + 64), the
+// uniform walk and the blocks' first / last segments pick the register by the index' bit 6.  A kernel of its own, launched
+// behind exonbin_kernel only when the annotation has such a locus (key or compat words beyond two): the 64-bit form, which
+// serves nearly every locus, keeps its registers and its code as they are.  Hits of other loci and hits the segment basis
+// does not take (irregular feature lists, more than 7 features) return at once: exonbin_kernel has served them.
+typedef unsigned __int128 u128;
+__device__ __forceinline__ u128 make_u128(uint64_t lo, uint64_t hi) { return ((u128)hi << 64) | lo; }
+
+__device__ __forceinline__ void exonbin_locus_seg128(const ExonBinArgs &a, int loc, bool mine, const BlockHit &h, int64_t hidx)
+{
+   const SB_AS4 int64_t *iso_off = scalar_ptr(a.iso_off), *seg_off = scalar_ptr(a.seg_off);
+   const int64_t i0 = iso_off[loc];
+   const int niso = (int)(iso_off[loc + 1] - i0);
+   const int64_t s0 = seg_off[loc];
+   const int nseg = (int)(seg_off[loc + 1] - s0);
+   const u128 adj = make_u128(scalar_ptr(a.locus_adj)[loc], scalar_ptr(a.locus_adj_hi)[loc]);
+   const int lane = (int)(threadIdx.x & 63u);
+   uint32_t my_sl[2], my_sr[2];
+#pragma unroll
+   for (int w = 0; w < 2; ++w) {
+      my_sl[w] = lane + 64 * w < nseg ? a.seg_left[s0 + lane + 64 * w] : 0xffffffffu;
+      my_sr[w] = lane + 64 * w < nseg ? a.seg_right[s0 + lane + 64 * w] : 0xffffffffu; // (past the end: reaches anything)
+   }
+   const SB_AS4 uint64_t *MEM = scalar_ptr(a.iso_member), *STA = scalar_ptr(a.iso_start);
+   const SB_AS4 uint64_t *MEMH = scalar_ptr(a.iso_member_hi), *STAH = scalar_ptr(a.iso_start_hi);
+   const bool live = mine && h.nb > 0;
+   uint32_t rmax = 0;
+#pragma unroll
+   for (int j = 0; j < kExonBinBlocks; ++j) rmax = (j < h.nb) ? max(rmax, h.r[j]) : rmax;
+   const uint32_t lo = wave_min_u32(live ? h.l[0] : 0xffffffffu);
+   const uint32_t hi = wave_max_u32(live ? rmax : 0u);
+   const int nbmax = (int)wave_max_u32(live ? (uint32_t)h.nb : 0u);
+   uint32_t n_cnt[kExonBinBlocks];
+#pragma unroll
+   for (int j = 0; j < kExonBinBlocks; ++j) n_cnt[j] = 0u;
+   const uint64_t reach0 = __ballot(my_sr[0] >= lo), reach1 = __ballot(my_sr[1] >= lo);
+   const int k_lo = nbmax > 0 ? (reach0 ? (int)__ffsll((long long)reach0) - 1 : 64 + (int)__ffsll((long long)reach1) - 1) : nseg;
+   for (int sg = k_lo; sg < nseg; ++sg) {
+      const uint32_t sl = sg < 64 ? lane_bcast(my_sl[0], sg) : lane_bcast(my_sl[1], sg - 64);
+      if (sl > hi) break;
+      const uint32_t sr = sg < 64 ? lane_bcast(my_sr[0], sg) : lane_bcast(my_sr[1], sg - 64);
+#pragma unroll
+      for (int j = 0; j < kExonBinBlocks; ++j) {
+         if (j >= nbmax) break;
+         n_cnt[j] += ((sr < h.l[j]) ? 1u : 0u) + ((sl <= h.r[j]) ? 0x10000u : 0u);
+      }
+   }
+   bool valid = live;
+   u128 need_member = 0, forbid_start = 0, need_start = 0, forbid_member = 0;
+   constexpr u128 kOne = 1, kAll = ~(u128)0;
+   uint32_t sb_prev = 0;
+   bool ends_prev = false;
+#pragma unroll
+   for (int j = 0; j < kExonBinBlocks; ++j) {
+      const bool in = live & (j < h.nb);
+      const uint32_t sa = (uint32_t)k_lo + (n_cnt[j] & 0xffffu), sb1 = (uint32_t)k_lo + (n_cnt[j] >> 16); // [sa, sb1)
+      const bool any = in & (sb1 > sa);
+      const uint32_t sb = any ? sb1 - 1u : 0u, sa_c = any ? sa : 0u;
+      const uint32_t fl0 = lane_gather(my_sl[0], sa_c & 63u), fl1 = lane_gather(my_sl[1], sa_c & 63u);
+      const uint32_t lr0 = lane_gather(my_sr[0], sb & 63u), lr1 = lane_gather(my_sr[1], sb & 63u);
+      const uint32_t first_l = sa_c < 64u ? fl0 : fl1, last_r = sb < 64u ? lr0 : lr1;
+      const u128 upto_sb = (sb >= 127u) ? kAll : (u128)((kOne << (sb + 1u)) - kOne);
+      const u128 mask = any ? (u128)(upto_sb & ~(u128)((kOne << sa_c) - kOne)) : (u128)0; // bits sa .. sb
+      const u128 inner = mask & (u128)(mask - kOne);                                      // all but the first
+      valid = valid & (!in | (any & (h.l[j] >= first_l) & (h.r[j] <= last_r) & ((u128)(inner & ~adj) == (u128)0)));
+      need_member |= mask;
+      forbid_start |= inner;
+      if (j > 0) {
+         const bool intr = in & h.intron[j];
+         valid = valid & (!intr | (any & ends_prev & (h.l[j] == first_l)));
+         const u128 first_j = any ? (u128)(kOne << sa_c) : (u128)0, upto_prev = (sb_prev >= 127u) ? kAll : (u128)((kOne << (sb_prev + 1u)) - kOne);
+         need_start |= intr ? first_j : (u128)0;
+         forbid_member |= intr ? (u128)((u128)(first_j - kOne) & ~upto_prev) : (u128)0;
+      }
+      sb_prev = sb;
+      ends_prev = any & (h.r[j] == last_r);
+   }
+   uint32_t *__restrict__ cout = a.compat + hidx * a.compat_words;
+   uint32_t *__restrict__ kout = a.key + hidx * a.key_words;
+   for (int w = 0; w < a.compat_words; ++w) {
+      uint32_t word = 0;
+      const int nbits = niso - 32 * w < 32 ? niso - 32 * w : 32;
+      for (int b = 0; b < nbits; ++b) {
+         const u128 m = make_u128(MEM[i0 + 32 * w + b], MEMH[i0 + 32 * w + b]), st = make_u128(STA[i0 + 32 * w + b], STAH[i0 + 32 * w + b]);
+         const u128 bad = (need_member & ~m) | (forbid_start & st) | (need_start & ~st) | (forbid_member & m);
+         word |= (valid & (bad == (u128)0) & (m != (u128)0)) ? (1u << b) : 0u;
+      }
+      if (mine) cout[w] = word;
+   }
+   const u128 keybits = live ? need_member : (u128)0;
+   if (mine)
+      for (int w = 0; w < a.key_words; ++w) kout[w] = w < 4 ? (uint32_t)(keybits >> (32 * w)) : 0u;
+}
+
+__global__ __launch_bounds__(256) void exonbin_seg128_kernel(ExonBinArgs a)
+{
+   const int64_t hidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   const bool active = hidx < a.n_hits;
+   const int my_loc = active ? a.hit_locus[hidx] : -1;
+   const bool big = active && a.locus_seg_ok[my_loc] == 3u;
+   if (!__ballot(big)) return; // (the usual wave: no hit of such a locus)
+   int64_t f0 = 0;
+   int nf = 0;
+   if (big) {
+      f0 = a.feat_off[hidx];
+      nf = (int)(a.feat_off[hidx + 1] - f0);
+   }
+   // the hit as exonbin_kernel reads it: M (x M)* with the MATCH blocks at the even positions, at most kExonBinRegFeats features
+   const bool fits = big && nf <= kExonBinRegFeats;
+   RegHit h;
+   h.nf = fits ? nf : 0;
+   bool regular = (h.nf & 1) != 0;
+#pragma unroll
+   for (int i = 0; i < kExonBinRegFeats; ++i) {
+      const bool in = i < h.nf;
+      h.c[i] = in ? a.feat_code[f0 + i] : (uint8_t)2;
+      h.l[i] = in ? a.feat_left[f0 + i] : 0u;
+      h.r[i] = in ? a.feat_right[f0 + i] : 0u;
+      regular = regular & (!in | ((h.c[i] == 0) == ((i & 1) == 0)));
+   }
+   BlockHit bh;
+   bh.nb = regular ? (h.nf + 1) / 2 : 0;
+#pragma unroll
+   for (int j = 0; j < kExonBinBlocks; ++j) {
+      const bool in = j < bh.nb;
+      bh.l[j] = in ? h.l[2 * j] : 0xffffffffu;
+      bh.r[j] = in ? h.r[2 * j] : 0u;
+      bh.intron[j] = in && j && h.c[2 * j - 1] == 1;
+   }
+   bool seg_regular = regular;
+#pragma unroll
+   for (int j = 1; j < kExonBinBlocks; ++j) {
+      const bool in = j < bh.nb;
+      seg_regular = seg_regular & (!in | (bh.l[j] > bh.r[j - 1]));
+      seg_regular = seg_regular & (!(in & bh.intron[j]) | ((h.l[2 * j - 1] == bh.r[j - 1] + 1u) & (h.r[2 * j - 1] + 1u == bh.l[j])));
+   }
+   // exactly the hits exonbin_kernel left: regular for the segment basis (or without features), in a locus of form 3
+   bool todo = big && ((fits && seg_regular) || nf == 0);
+   for (int round = 0; round < 64; ++round) { // (one locus per round; a wave rarely spans two)
+      const uint64_t m = __ballot(todo);
+      if (!m) break;
+      const int loc = __builtin_amdgcn_readlane(my_loc, __ffsll((long long)m) - 1);
+      const bool mine = todo && my_loc == loc;
+      exonbin_locus_seg128(a, loc, mine, bh, hidx);
+      todo = todo && !mine;
    }
 }
 

@@ -650,3 +650,62 @@ def test_pinned_annotation_gives_the_unpinned_results():
     b.theta[:] = -1
     b.step()
     np.testing.assert_array_equal(b.theta[:b.n_iso], want[0])
+
+
+def test_segment_basis_128_bit_form(ctx, oracle):
+    """Loci of 65-128 segments or isoforms take the segment basis with 128-bit masks in a kernel of their own
+    (exonbin_seg128_kernel, launched behind exonbin_kernel when the annotation's words go beyond two); beyond 128 the exon
+    walk.  Same grid construction as above -- exon ends on multiples of 10, blocks on multiples of 5, snapped hits that meet
+    exon ends and introns exactly -- on loci of ~70, ~100, 128 and 129+ segments, 3 to 120 isoforms, next to small loci
+    (a wave that spans a small and a big locus).  Words equal the oracle's, bit for bit."""
+    from strawberry_amd import exonbin as eb
+    rng = np.random.default_rng(4096)
+    shapes = [(70, 6), (12, 4), (100, 40), (128, 9), (140, 5), (30, 90), (64, 120), (9, 3), (127, 127), (200, 130)]   # (cells, isoforms)
+    loci = []
+    for l, (n_cells, n_iso) in enumerate(shapes):
+        base = 5000 * (l + 1)
+        isoforms = [[(base + 10 * k, base + 10 * k + 6) for k in range(n_cells)]]      # one isoform with every cell: n_cells segments at least
+        for _ in range(n_iso - 1):
+            exons, pos = [], int(rng.integers(0, 4))
+            while pos < n_cells:
+                if rng.random() < 0.6:
+                    exons.append((base + 10 * pos, base + 10 * pos + 6))
+                pos += 1 + int(rng.choice([0, 0, 1, 3]))
+            isoforms.append(exons or [(base, base + 6)])
+        loci.append(isoforms)
+    annot = eb.Annotation(loci)
+    nseg, niso = np.diff(annot.seg_off), np.diff(annot.iso_off)
+    assert annot.key_words >= 5 and annot.compat_words >= 4
+    assert ((nseg > 64) & (nseg <= 128)).sum() >= 4 and (nseg > 128).sum() >= 2 and ((niso > 64) & (niso <= 128)).sum() >= 3
+    loc, feats = [], []
+    for l, isoforms in enumerate(loci):
+        n_cells = shapes[l][0]
+        base = 5000 * (l + 1)
+        for _ in range(500):
+            ex = isoforms[int(rng.integers(0, len(isoforms)))]
+            k = int(rng.integers(0, len(ex)))
+            nb = int(rng.integers(1, 5))
+            c, le, ri = [0], [int(rng.integers(ex[k][0], ex[k][1] + 1))], [ex[k][1]]
+            for k2 in range(k + 1, min(k + nb, len(ex))):
+                last = k2 + 1 == min(k + nb, len(ex))
+                c += [int(rng.choice([1, 1, 1, 2])), 0]
+                le += [ri[-1] + 1, ex[k2][0]]
+                ri += [ex[k2][0] - 1, int(rng.integers(ex[k2][0], ex[k2][1] + 1)) if last else ex[k2][1]]
+            u = rng.random()
+            if u < 0.15:                                   # off the grid: a block that sticks out of its exon, or sits in an intron
+                j = 2 * int(rng.integers(0, (len(c) + 1) // 2))
+                ri[j] += int(rng.choice([1, 3, 5]))
+                if j + 1 < len(c):
+                    le[j + 1] = ri[j] + 1
+                    ri[j + 1] = max(ri[j + 1], le[j + 1])
+            elif u < 0.2:                                  # blocks out of order (the per-lane walk)
+                le[0], le[-1], ri[0], ri[-1] = le[-1], le[0], ri[-1], ri[0]
+            loc.append(l), feats.append((c, le, ri))
+    order = np.argsort(np.asarray(loc), kind="stable")
+    hits = eb.Hits([loc[i] for i in order], [feats[i] for i in order])
+    compat, key = eb.compat_and_keys(annot, hits, ctx)
+    o_compat, o_key = oracle.exonbin_batch(annot, hits)
+    np.testing.assert_array_equal(key, o_key)
+    np.testing.assert_array_equal(compat, o_compat)
+    frac = (compat != 0).any(axis=1).mean()
+    assert 0.3 < frac < 0.97, frac
