@@ -99,4 +99,8 @@ timeout 120 ./tools/bin/microbench > $SUM/${R}_microbench.txt 2>&1
 for f in $(find $OUT/stats_frontend -name "*kernel_stats.csv"); do cp $f $SUM/${R}_frontend_kernel_stats.csv; done
 (timeout 600 python tools/bench_host_entry.py 60000 2e8 3 2>/dev/null | tail -1) > $SUM/${R}_host_entry.json
 (timeout 1200 python tools/dropin_timing.py 2>/dev/null) > $SUM/${R}_dropin.txt
+# loci of 65-128 segments: the 128-bit segment basis against the exon walk
+(timeout 300 python tools/bench_exonbin_big.py; SBGPU_EXONBIN_SEGBASIS=0 timeout 300 python tools/bench_exonbin_big.py) 2>/dev/null | grep "^{" > $SUM/${R}_exonbin_big_loci.json
+# random stress on this build (tails; the library's build id on top)
+(python -c "import sys; sys.path.insert(0, '.'); from strawberry_amd import _lib; print('libsbgpu build', _lib.load().sbgpu_build_id().decode())"; timeout 900 python tools/stress_em.py 48 2>&1 | tail -3; timeout 600 python tools/stress_exonbin.py 48 2>&1 | tail -2; timeout 600 python tools/stress_binseq.py 2>&1 | tail -2) > $SUM/${R}_stress.txt 2>&1
 cat $SUM/${R}_pytest_gpu.txt; cat $SUM/${R}_bench_c3.json; echo; cat $SUM/${R}_bench_c2.json; echo; ls -la $SUM
