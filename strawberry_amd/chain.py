@@ -306,8 +306,11 @@ class ChainQuantifier:
                 "grouped_on_device": bool(on_dev.value), "equals_resident_call_bitwise": same}
 
     def finish(self):
+        """(bench.py's timed_steps calls this when the timed steps are issued: every step() has synchronised already)"""
+
+    def close(self):
         """Release what this object keeps with the (shared) context: the pinned annotation.  The pin is keyed on the
-        annotation arrays' addresses (+ a sampled fingerprint); it must not outlive the arrays."""
+        annotation arrays' addresses (+ a sampled fingerprint); it must not outlive the arrays.  Also on __exit__ / __del__."""
         self.unpin()
 
     def unpin(self):
@@ -319,7 +322,7 @@ class ChainQuantifier:
         return self
 
     def __exit__(self, *exc):
-        self.finish()
+        self.close()
 
     def __del__(self):
         try:

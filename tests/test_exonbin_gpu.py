@@ -620,8 +620,8 @@ def test_quantify_device_equals_quantify_host_on_the_chain_sample(oracle):
     assert q2.n_loci == 200
     np.testing.assert_array_equal(q2.annot.exon_left[:int(q2.annot.exon_off[int(q2.annot.iso_off[1])])],
                                   q.annot.exon_left[int(q.annot.exon_off[int(q.annot.iso_off[1])]):int(q.annot.exon_off[int(q.annot.iso_off[2])])])
-    q.finish()      # (the pin is keyed on the annotation arrays: it goes before they do)
-    q2.finish()
+    q.close()       # (the pin is keyed on the annotation arrays: it goes before they do)
+    q2.close()
 
 
 @pytest.mark.gpu

@@ -34,7 +34,7 @@ def main():
     out.update({"loci": q.n_loci, "read_pairs": q.n_frags, "unique_hits": q.n_hits, "quantify_device_ms": dev_ms,
                 "pcie_inclusive_over_resident": out["ms_per_call"] / dev_ms})
     print(json.dumps(out))
-    q.finish()
+    q.close()
 
 
 if __name__ == "__main__":
