@@ -445,7 +445,7 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
       const int32_t *d_count_dev = nullptr;
       hooks.after_pairs = [&](const sb::DeviceGrouping &g) -> int {
          n_bins = g.n_bins, n_elem = g.n_elem, n_pairs = g.pairs->n_pairs, n_psegs = g.pairs->n_pair_segs;
-         d_count_dev = g.d_count; // (context scratch: stays valid after the grouping returns)
+         d_count_dev = g.d_count; // (the handle's own arena, sb::dev_take'n by the grouping: valid as long as the handle lives)
          rest_launched = true;
          return launch_weights(g.pairs);
       };
