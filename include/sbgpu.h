@@ -423,15 +423,16 @@ int sbgpu_uniq_info(const sbgpu_uniq_t *u, int64_t info[8]);
 int sbgpu_uniq_export(const sbgpu_uniq_t *u, int32_t *hit_locus, int64_t *feat_off, uint8_t *feat_code,
                       uint32_t *feat_left, uint32_t *feat_right, float *hit_mass, double *cluster_mass);
 
-/* The same on the GPU (csrc/collapse_device.h): the pairs' arrays of `d_pairs` are DEVICE pointers (pair_locus is
+/* The same on the GPU (csrc/collapse_flat.h): the pairs' arrays of `d_pairs` are DEVICE pointers (pair_locus is
  * not read), grouped by locus as locus_pair_off[n_loci + 1] (host) says; the unique hits stay in HBM in
  * sbgpu_hits_t layout -- sbgpu_uniq_dev_hits hands them to sbgpu_exonbin_device / sbgpu_quantify_device -- and
- * only the per-locus counts and cluster masses come back.  One workgroup per locus sorts its pairs in LDS
- * ((left, right), ties in input order), applies the span filter, collapses equal neighbours (masses added in
- * double, in that order) and builds Contig(PairedHit)'s features; a locus of more than 4096 pairs (any highly
- * expressed gene) takes the same steps with 1024 threads and its arrays in global memory.  Covers loci of up to 2^24
- * pairs and mates of up to 24 features; otherwise SBGPU_EUNSUPPORTED (use sbgpu_collapse_pairs_host).  Synchronises
- * on `stream`.
+ * only the per-locus offsets and cluster masses come back.  All clusters of the call at once: two stable device-wide
+ * radix sorts give the (left, right) order with ties in input order; the span filter is decided from the spans' exact
+ * integer moments (the reference's running sum of squared deviations is taken where a decision could depend on its
+ * rounding); equal neighbours collapse, their masses added in double in that order (in any order where every mass
+ * of the cluster is a multiple of 2^-20: the sums are then exact); Contig(PairedHit)'s features per unique hit.
+ * Up to 2^31 pairs per call and mates of up to 512 features; beyond: SBGPU_EUNSUPPORTED (use
+ * sbgpu_collapse_pairs_host).  Synchronises on `stream`.
  * The span filter evaluates phi() with the device's exp(): a pair exactly on the 0.999 boundary could fall on the
  * other side than with the host's libm (not observed).                                                        */
 typedef struct sbgpu_uniq_dev sbgpu_uniq_dev_t;
@@ -511,11 +512,12 @@ typedef struct {
 typedef struct sbgpu_matepairs sbgpu_matepairs_t;
 /* Host form: `reads` host arrays, the records of cluster l are [locus_read_off[l], locus_read_off[l + 1]). */
 int sbgpu_pair_mates_host(int64_t n_loci, const sbgpu_reads_t *reads, const int64_t *locus_read_off, sbgpu_matepairs_t **out);
-/* Device form (csrc/matepair_device.h): `d_reads` device arrays, locus_read_off host; one workgroup per cluster sorts
- * its records by read id in LDS, walks every read id's records in arrival order, ranks the completed pairs by
- * completion and writes the pairs where sbgpu_collapse_pairs_device reads them -- nothing but per-cluster counts
- * comes back.  A cluster of more than 8192 records takes the same steps with the sort's arrays in global memory.
- * Clusters of up to 2^24 records, up to 8 open mates per read id; else SBGPU_EUNSUPPORTED.                           */
+/* Device form (csrc/matepair_flat.h): `d_reads` device arrays, locus_read_off host.  All clusters of the call at once:
+ * one stable device-wide radix sort on (cluster, hash of the read id) brings a read id's records together in arrival
+ * order, the first record of every read id walks its group with the reference's open-mate rules (any number of mates
+ * of one read id may wait), a second sort ranks the pairs by completion, and the pairs are written where
+ * sbgpu_collapse_pairs_device reads them -- nothing but per-cluster offsets and four counters comes back.
+ * Up to 2^31 records per call; beyond: SBGPU_EUNSUPPORTED.                                                          */
 int sbgpu_pair_mates_device(sbgpu_ctx_t *ctx, int64_t n_loci, const sbgpu_reads_t *d_reads, const int64_t *locus_read_off,
                             void *stream, sbgpu_matepairs_t **out);
 void sbgpu_matepairs_destroy(sbgpu_matepairs_t *m);
@@ -588,7 +590,9 @@ int sbgpu_bins_export(const sbgpu_bins_t *bins, int64_t *row_off, int64_t *iso_o
  * LocusContext's constructor + the EM of estimate_abundances for every locus of a batch
  * (include/estimate.hpp:60-103, src/estimate.cpp:279-308), host buffers in, host buffers out:
  * uploads the annotation and the hits once, runs sbgpu_exonbin_device, groups the hits into bins
- * on the device (on the host when sbgpu_bins_create_device declines), builds the pairs, runs
+ * on the device (with the library's host code, sbgpu_bins_create, when the device form declines --
+ * hits that do not come grouped by locus, ...: same bins, slower; sbgpu_bins_grouping says which ran
+ * and why), builds the pairs, runs
  * sbgpu_binweight_device straight into the EM batch's F, plans and runs sbgpu_em_run_device.
  * Nothing but the per-bin arrays, theta and (on request) F comes back over PCIe.
  *   annot          host arrays incl. the segments (sbgpu_segments_host)

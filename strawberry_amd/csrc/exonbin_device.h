@@ -52,16 +52,24 @@ struct ExonBinArgs {
    const uint64_t *iso_member_hi, *iso_start_hi, *locus_adj_hi;
 };
 
-// (a 32-bit hash on purpose: two integer multiplies per feature -- 64-bit products cost four each, and integer
-// multiplies run at a quarter of the vector rate; collisions only cost a feature-by-feature compare)
+// (32 bits, and no multiply per feature: integer multiplies run at a quarter of the vector rate and exonbin_kernel is
+// bound by its vector instructions -- a step is xor, rotate, xor, shift-add, each a bijection of h for given (l, r),
+// the two ends entering at different rotations; the two multiplies of the avalanche come once per hit.  Collisions
+// only cost a feature-by-feature compare.)
 __device__ __forceinline__ uint32_t hit_sig_step(uint32_t h, uint32_t l, uint32_t r)
 {
-   h = (h ^ l) * 0x9E3779B1u;
-   h = (h ^ r) * 0x85EBCA77u;
-   return h ^ (h >> 15);
+   h = __builtin_rotateleft32(h ^ l, 13) ^ r;
+   return h + (h << 3);
 }
 constexpr uint32_t kHitSigSeed = 0x243F6A88u;
-__device__ __forceinline__ uint32_t hit_sig_fold(uint32_t h) { return h ^ (h >> 13); }
+__device__ __forceinline__ uint32_t hit_sig_fold(uint32_t h)
+{
+   h ^= h >> 16;
+   h *= 0x85EBCA6Bu;
+   h ^= h >> 13;
+   h *= 0xC2B2AE35u;
+   return h ^ (h >> 16);
+}
 
 constexpr int kExonBinRegFeats = 8; // features a hit may have and still be held in registers
 
@@ -417,20 +425,21 @@ __device__ __forceinline__ uint64_t lane_bcast(uint64_t v, int lane)
 }
 __device__ __forceinline__ uint32_t lane_gather(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lane << 2), (int)v); }
 
+// The locus' numbers (first isoform / segment, counts, adjacency word) arrive as arguments: exonbin_kernel has them in
+// lanes (vector loads issued beside the feature loads) and hands the round's locus over with v_readlane -- the scalar
+// loads this function made itself (five dependent s_loads before the first segment could be asked for) were a memory
+// round trip per locus on the wave's critical path.  The isoforms' member / start words sit in lanes too (lane i:
+// isoform i), loaded together with the segments.
 template <class M>
-__device__ __forceinline__ void exonbin_locus_segbasis(const ExonBinArgs &a, int loc, bool mine, const BlockHit &h, int64_t hidx)
+__device__ __forceinline__ void exonbin_locus_segbasis(const ExonBinArgs &a, int64_t i0, int niso, int64_t s0, int nseg, uint64_t adj64,
+                                                       bool mine, const BlockHit &h, int64_t hidx)
 {
-   const SB_AS4 int64_t *iso_off = scalar_ptr(a.iso_off), *seg_off = scalar_ptr(a.seg_off);
-   const int64_t i0 = iso_off[loc];
-   const int niso = (int)(iso_off[loc + 1] - i0);
-   const int64_t s0 = seg_off[loc];
-   const int nseg = (int)(seg_off[loc + 1] - s0);
-   const M adj = (M)scalar_ptr(a.locus_adj)[loc]; // bit s: segment s begins right behind segment s - 1
+   const M adj = (M)adj64; // bit s: segment s begins right behind segment s - 1
    const int lane = (int)(threadIdx.x & 63u);
    const uint32_t my_sl = lane < nseg ? a.seg_left[s0 + lane] : 0xffffffffu;
    const uint32_t my_sr = lane < nseg ? a.seg_right[s0 + lane] : 0xffffffffu; // (past the end: reaches anything)
-   const SB_AS4 uint64_t *MEM = scalar_ptr(a.iso_member), *STA = scalar_ptr(a.iso_start); // (two s_loads per isoform: keeping the
-   // masks in lanes as well costs four more registers and, at 83, two waves per SIMD -- measured slower)
+   const M my_mem = lane < niso ? (M)a.iso_member[i0 + lane] : (M)0;
+   const M my_sta = lane < niso ? (M)a.iso_start[i0 + lane] : (M)0;
    const bool live = mine && h.nb > 0;
    uint32_t rmax = 0;
 #pragma unroll
@@ -493,7 +502,7 @@ __device__ __forceinline__ void exonbin_locus_segbasis(const ExonBinArgs &a, int
       uint32_t word = 0;
       const int nbits = niso - 32 * w < 32 ? niso - 32 * w : 32;
       for (int b = 0; b < nbits; ++b) {
-         const M m = (M)MEM[i0 + 32 * w + b], st = (M)STA[i0 + 32 * w + b];
+         const M m = lane_bcast(my_mem, 32 * w + b), st = lane_bcast(my_sta, 32 * w + b);
          const M bad = (need_member & ~m) | (forbid_start & st) | (need_start & ~st) | (forbid_member & m);
          word |= (valid & (bad == (M)0) & (m != (M)0)) ? (1u << b) : 0u; // (m == 0: an isoform without exons is compatible with nothing)
       }
@@ -507,29 +516,93 @@ __device__ __forceinline__ void exonbin_locus_segbasis(const ExonBinArgs &a, int
    }
 }
 
-__global__ __launch_bounds__(256) void exonbin_kernel(ExonBinArgs a)
+// A lane's features, all kExonBinRegFeats slots of the three arrays, with FIVE loads in flight together: two
+// global_load_dwordx4 per coordinate array and one 8-byte load of the codes, from the hit's first feature on (the
+// slots past its last feature read the next hits' -- masked off afterwards).  The form before asked for every slot
+// under its own `i < nf` branch, and the codes were consumed as they came: five dependent memory round trips at the
+// head of every wave, most of a wave's 8 us.  Reading eight slots from f0 must stay inside the arrays: `wide` says so
+// (every lane's f0 + 8 <= the feature count; only the last wave of a launch fails it and loads slot by slot, clamped).
+struct __attribute__((packed, aligned(4))) PackedU32x4 {
+   uint32_t v[4];
+};
+struct __attribute__((packed, aligned(1))) PackedU64 {
+   uint64_t v;
+};
+static_assert(kExonBinRegFeats == 8, "the wide feature loads are written for eight slots");
+
+__device__ __forceinline__ void load_hit_slots(const ExonBinArgs &a, int64_t f0, int64_t n_feat, bool wide, uint64_t &codes,
+                                               uint32_t (&L)[kExonBinRegFeats], uint32_t (&R)[kExonBinRegFeats])
 {
-   const int64_t hidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; // one hit per lane, no loop
-   const bool active = hidx < a.n_hits;
-   int64_t f0 = 0;
-   int nf = 0, my_loc = -1;
-   if (active) {
-      f0 = a.feat_off[hidx];
-      nf = (int)(a.feat_off[hidx + 1] - f0);
-      my_loc = a.hit_locus[hidx];
-   }
-   const bool is_long = nf > kExonBinRegFeats;
-   RegHit h;
-   h.nf = is_long ? 0 : nf;
-   bool regular = (h.nf & 1) != 0; // M (x M)*: odd count, MATCH exactly at the even positions
+   if (wide) { // (uniform)
+      const PackedU32x4 l0 = *reinterpret_cast<const PackedU32x4 *>(a.feat_left + f0), l1 = *reinterpret_cast<const PackedU32x4 *>(a.feat_left + f0 + 4);
+      const PackedU32x4 r0 = *reinterpret_cast<const PackedU32x4 *>(a.feat_right + f0), r1 = *reinterpret_cast<const PackedU32x4 *>(a.feat_right + f0 + 4);
+      const PackedU64 c0 = *reinterpret_cast<const PackedU64 *>(a.feat_code + f0);
 #pragma unroll
-   for (int i = 0; i < kExonBinRegFeats; ++i) {
-      const bool in = i < h.nf;
-      h.c[i] = in ? a.feat_code[f0 + i] : (uint8_t)2;
-      h.l[i] = in ? a.feat_left[f0 + i] : 0u;
-      h.r[i] = in ? a.feat_right[f0 + i] : 0u;
-      regular = regular & (!in | ((h.c[i] == 0) == ((i & 1) == 0)));
+      for (int i = 0; i < 4; ++i) {
+         L[i] = l0.v[i];
+         L[i + 4] = l1.v[i];
+         R[i] = r0.v[i];
+         R[i + 4] = r1.v[i];
+      }
+      codes = c0.v; // byte i: the code of slot i
+   } else if (n_feat > 0) {
+      codes = 0;
+#pragma unroll
+      for (int i = 0; i < kExonBinRegFeats; ++i) {
+         const int64_t idx = f0 + i < n_feat ? f0 + i : n_feat - 1;
+         codes |= (uint64_t)a.feat_code[idx] << (8 * i);
+         L[i] = a.feat_left[idx];
+         R[i] = a.feat_right[idx];
+      }
+   } else {
+      codes = 0;
+#pragma unroll
+      for (int i = 0; i < kExonBinRegFeats; ++i) L[i] = R[i] = 0u;
    }
+}
+
+__device__ __forceinline__ void exonbin_tile(const ExonBinArgs &a, const int64_t hidx, const int64_t n_feat)
+{
+   const bool active = hidx < a.n_hits;
+   // first level: the hit's offsets and its locus, together (idle lanes of the last wave read hit 0 -- no branch around
+   // the loads, so none of them is waited for before the other is on its way)
+   const int64_t hq = active ? hidx : 0;
+   int loc_q = a.hit_locus[hq];
+   int64_t f0_q = a.feat_off[hq], f1_q = a.feat_off[hq + 1];
+   // (all three are wanted before the second level goes out: without this pin the compiler waits for the offsets only,
+   // and later -- at the join of the two feature-load forms -- for everything in flight, to get at the locus)
+   asm volatile("" : "+v"(loc_q), "+v"(f0_q), "+v"(f1_q));
+   const int64_t f0 = active ? f0_q : 0;
+   const int nf = active ? (int)(f1_q - f0_q) : 0;
+   const int my_loc = active ? loc_q : -1;
+   // second level, all in flight together: the hit's feature slots and its locus' numbers (most lanes of a wave read
+   // the same locus: one cache line)
+   int64_t my_i0 = 0, my_i1 = 0, my_s0 = 0, my_s1 = 0;
+   uint32_t my_form = 0;
+   uint64_t my_adj = 0;
+   if (a.locus_seg_ok) { // (uniform; idle lanes read locus 0 -- no branch around the loads, nothing waits for them here)
+      const int lq = active ? my_loc : 0;
+      my_form = a.locus_seg_ok[lq];
+      my_i0 = a.iso_off[lq];
+      my_i1 = a.iso_off[lq + 1];
+      my_s0 = a.seg_off[lq];
+      my_s1 = a.seg_off[lq + 1];
+      my_adj = a.locus_adj[lq];
+   }
+   const bool wide = !__ballot(f0 + kExonBinRegFeats > n_feat);
+   uint64_t codes;
+   uint32_t L[kExonBinRegFeats], R[kExonBinRegFeats]; // (slots past the hit's last feature hold the next hits': every use asks i < nf)
+   load_hit_slots(a, f0, n_feat, wide, codes, L, R);
+   const bool is_long = nf > kExonBinRegFeats;
+   const int nfr = is_long ? 0 : nf; // the features held in registers
+   // M (x M)*: an odd count, MATCH (code 0) exactly at the even positions -- asked of the eight code bytes at once: the
+   // bytes of the hit's own slots, "byte is non-zero" as bit 7 of every byte (the carry of 0x7f + the low seven bits,
+   // or bit 7 itself)
+   constexpr uint64_t kEvenBytes = 0x00ff00ff00ff00ffull, kOddTop = 0x8000800080008000ull, kLow7 = 0x7f7f7f7f7f7f7f7full;
+   const uint64_t own = nfr >= 8 ? ~0ull : ((1ull << (8 * nfr)) - 1ull);
+   const uint64_t cw = codes & own;
+   const uint64_t nonzero = (((cw & kLow7) + kLow7) | cw) & ~kLow7;
+   const bool regular = ((nfr & 1) != 0) & ((cw & kEvenBytes) == 0ull) & ((nonzero & kOddTop) == (own & kOddTop));
    if (a.span && active) {
       uint32_t sig = kHitSigSeed;
       uint64_t sp = 0;
@@ -539,24 +612,25 @@ __global__ __launch_bounds__(256) void exonbin_kernel(ExonBinArgs a)
       } else if (nf > 0) {
          uint32_t last_r = 0;
 #pragma unroll
-         for (int i = 0; i < kExonBinRegFeats; ++i)
-            if (i < nf) {
-               sig = hit_sig_step(sig, h.l[i], h.r[i]);
-               last_r = h.r[i];
-            }
-         sp = ((uint64_t)h.l[0] << 32) | last_r;
+         for (int i = 0; i < kExonBinRegFeats; ++i) {
+            const bool in = i < nf;
+            const uint32_t nx = hit_sig_step(sig, L[i], R[i]);
+            sig = in ? nx : sig;
+            last_r = in ? R[i] : last_r;
+         }
+         sp = ((uint64_t)L[0] << 32) | last_r;
       }
       a.span[hidx] = sp; // 0: a hit without features (it carries no position)
       a.fhash[hidx] = hit_sig_fold(sig);
    }
    BlockHit bh;
-   bh.nb = regular ? (h.nf + 1) / 2 : 0;
+   bh.nb = regular ? (nfr + 1) / 2 : 0;
 #pragma unroll
    for (int j = 0; j < kExonBinBlocks; ++j) {
       const bool in = j < bh.nb;
-      bh.l[j] = in ? h.l[2 * j] : 0xffffffffu;
-      bh.r[j] = in ? h.r[2 * j] : 0u;
-      bh.intron[j] = in && j && h.c[2 * j - 1] == 1;
+      bh.l[j] = in ? L[2 * j] : 0xffffffffu;
+      bh.r[j] = in ? R[2 * j] : 0u;
+      bh.intron[j] = in && j && (uint32_t)((cw >> (8 * (2 * j - 1 > 0 ? 2 * j - 1 : 0))) & 0xffull) == 1u;
    }
    // the segment-basis form also wants the blocks ascending and every INTRON connector to fill its gap exactly
    bool seg_regular = regular;
@@ -564,27 +638,29 @@ __global__ __launch_bounds__(256) void exonbin_kernel(ExonBinArgs a)
    for (int j = 1; j < kExonBinBlocks; ++j) {
       const bool in = j < bh.nb;
       seg_regular = seg_regular & (!in | (bh.l[j] > bh.r[j - 1]));
-      seg_regular = seg_regular & (!(in & bh.intron[j]) | ((h.l[2 * j - 1] == bh.r[j - 1] + 1u) & (h.r[2 * j - 1] + 1u == bh.l[j])));
+      seg_regular = seg_regular & (!(in & bh.intron[j]) | ((L[2 * j - 1] == bh.r[j - 1] + 1u) & (R[2 * j - 1] + 1u == bh.l[j])));
    }
    // hits without features are "regular" with no blocks: all-zero words, written by the wave form
    bool todo = active && (regular || nf == 0);
    bool per_lane = false; // a regular hit the segment-basis form does not take, in a locus that uses it
-   const SB_AS4 uint32_t *seg_ok = scalar_ptr(a.locus_seg_ok);
    for (int round = 0; round < kExonBinWaveLoci; ++round) {
       const uint64_t m = __ballot(todo);
       if (!m) break;
-      const int loc = __builtin_amdgcn_readlane(my_loc, __ffsll((long long)m) - 1);
+      const int src = __ffsll((long long)m) - 1; // the first lane of the round's locus hands its numbers over
+      const int loc = __builtin_amdgcn_readlane(my_loc, src);
       const bool mine = todo && my_loc == loc;
-      const uint32_t form = a.locus_seg_ok ? seg_ok[loc] : 0u; // 0: exon walk; 1: <= 32 segments; 2: <= 64
+      const uint32_t form = lane_bcast(my_form, src); // 0: exon walk; 1: <= 32 segments; 2: <= 64
       if (form == 3u) {
          // 65-128 segments or isoforms: the regular hits are exonbin_seg128_kernel's (launched behind this one); the others
          // take the per-lane walk below
          per_lane = per_lane || (mine && !(seg_regular || nf == 0));
       } else if (form) {
          per_lane = per_lane || (mine && !(seg_regular || nf == 0));
-         // (a uint32_t instantiation for loci of up to 32 segments was measured: 5.5 instead of 4.9 ms on the chain
-         // sample -- the second copy of the code costs more than the halved mask arithmetic saves)
-         exonbin_locus_segbasis<uint64_t>(a, loc, mine && (seg_regular || nf == 0), bh, hidx);
+         const int64_t i0 = (int64_t)lane_bcast((uint64_t)my_i0, src), s0 = (int64_t)lane_bcast((uint64_t)my_s0, src);
+         const int niso = (int)(lane_bcast((uint32_t)my_i1, src) - (uint32_t)i0), nseg = (int)(lane_bcast((uint32_t)my_s1, src) - (uint32_t)s0); // (<= 64 each)
+         // (a uint32_t instantiation for the loci of up to 32 segments was measured twice, in round 3 and on this form of
+         // the kernel: 4.18 ms either way on the chain sample -- one copy of the code)
+         exonbin_locus_segbasis<uint64_t>(a, i0, niso, s0, nseg, lane_bcast(my_adj, src), mine && (seg_regular || nf == 0), bh, hidx);
       } else {
          exonbin_locus_uniform(a, loc, mine, bh, hidx, f0);
       }
@@ -598,6 +674,15 @@ __global__ __launch_bounds__(256) void exonbin_kernel(ExonBinArgs a)
       MemHit m = {a.feat_code + f0, a.feat_left + f0, a.feat_right + f0, nf};
       exonbin_hit(a, hidx, m);
    }
+}
+
+// One hit per lane, a workgroup per 256 hits, no loop.  (Workgroups that loop over tiles were measured on the chain sample:
+// 4.8 ms with five resident workgroups per CU, 4.3 ms with 160, against 4.2 ms for a workgroup per tile -- the short-lived
+// waves are not what the kernel waits for; its vector instructions are, 78 % of the SIMDs' cycles.)
+__global__ __launch_bounds__(256) void exonbin_kernel(ExonBinArgs a)
+{
+   const int64_t n_feat = scalar_ptr(a.feat_off)[a.n_hits]; // (an s_load beside the lanes' own offsets)
+   exonbin_tile(a, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, n_feat);
 }
 
 // ------------------------------------------------------------------ segment basis, 65-128 segments or isoforms

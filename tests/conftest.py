@@ -15,6 +15,38 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+REF_DIR = os.path.join(ROOT, "oracle", "_ref")
+REF_PROGRAMS = ("libstrawberry_ref.so", "strawberry_ref", "strawberry_sbgpu", "strawberry_sbgpu_batched",
+                "strawberry_sbgpu_chain", "strawberry_dump", "sam2bam")
+
+
+def pytest_report_header(config):
+    """Says up front whether the compiled reference (oracle/_ref: git-ignored, built only where /root/reference exists,
+    carried to the GPU box with the tree) is there -- the tests that link or run it skip without it, and a run on a
+    clean checkout should not lose them quietly.  SBGPU_REQUIRE_REF=1 turns those skips into failures."""
+    have = [f for f in REF_PROGRAMS if os.path.exists(os.path.join(REF_DIR, f))]
+    miss = [f for f in REF_PROGRAMS if f not in have]
+    line = "oracle/_ref (the reference compiled from its own sources): %d of %d files present" % (len(have), len(REF_PROGRAMS))
+    if miss:
+        line += "; MISSING " + ", ".join(miss) + " -> the tests against the reference itself will SKIP (goldens and the oracle still run)"
+    return [line]
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    skipped = [r for r in terminalreporter.stats.get("skipped", []) if "oracle/_ref" in str(getattr(r, "longrepr", ""))]
+    if skipped:
+        terminalreporter.write_line("NOTE: %d test(s) skipped because oracle/_ref is not built here (needs /root/reference; "
+                                    "`make -C oracle ref`)" % len(skipped), yellow=True)
+
+
+def need_ref(what="oracle/_ref"):
+    """skip (or, with SBGPU_REQUIRE_REF=1, fail) a test that needs the compiled reference"""
+    msg = "%s not built (oracle/_ref needs /root/reference; `make -C oracle ref`)" % what
+    if os.environ.get("SBGPU_REQUIRE_REF") == "1":
+        pytest.fail(msg)
+    pytest.skip(msg)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import OracleLib, build
@@ -27,7 +59,7 @@ def reflib():
     """The reference's own EmSolver (oracle/_ref); only where it has been built."""
     from oracle import RefLib, have_ref
     if not have_ref():
-        pytest.skip("oracle/_ref not built (needs /root/reference; `make -C oracle ref`)")
+        need_ref("oracle/_ref/libstrawberry_ref.so")
     return RefLib()
 
 

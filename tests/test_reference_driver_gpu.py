@@ -51,7 +51,8 @@ ASSEMBLY_MODE = {"E2E_ASSEMBLY"}
 
 def need_driver(driver=DRIVER):
     if not (os.path.exists(driver) and os.path.exists(SAM2BAM)):
-        pytest.skip("oracle/_ref/%s not built (`make -C oracle ref` where /root/reference is mounted)" % os.path.basename(driver))
+        from conftest import need_ref
+        need_ref("oracle/_ref/%s" % os.path.basename(driver))
 
 
 def cigar(blocks):
