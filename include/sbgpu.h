@@ -493,7 +493,8 @@ int sbgpu_assign_reads_device(sbgpu_ctx_t *ctx, const sbgpu_clusters_t *clusters
  *     refused (:559-585, 630-641);
  *   - what still waits when the cluster is closed is dropped (clearOpenMates, :653).
  * Pair mass: the two reads' masses, 0.5 / NH each; a single read's 1 / NH (src/read.cpp:49-53).
- * The result has the layout of sbgpu_pairs_t -- mates as MATCH / INTRON feature lists (readhit_2_genomicFeats, src/contig.cpp:12-53) --:
+ * The result has the layout of sbgpu_pairs_t -- mates as MATCH / INTRON feature lists (readhit_2_genomicFeats, src/contig.cpp:12-53:
+ * an INTRON between two blocks, none where they touch -- an insertion in the read) --:
  * the input of sbgpu_collapse_pairs_host / _device.  One difference a caller should know: the reference's cluster
  * keeps the span of EVERY accepted record for its span filter (:527), the collapse here sees the spans of the
  * mates of the pairs only -- records that never find their mate do not count.                                   */
@@ -531,6 +532,75 @@ int sbgpu_matepairs_pairs(const sbgpu_matepairs_t *m, sbgpu_pairs_t *pairs, cons
 int sbgpu_matepairs_export(const sbgpu_matepairs_t *m, double *pair_mass, int64_t *left_off, uint8_t *left_code,
                            uint32_t *left_left, uint32_t *left_right, int64_t *right_off, uint8_t *right_code,
                            uint32_t *right_left, uint32_t *right_right);
+
+/* ---- BAM alignment records -> the read stream (replaces BAMHitFactory::getHitFromBuf) --------
+ * /root/reference/src/read.cpp:480-715: a BAM record becomes a ReadHit -- or is refused -- on its flag word, its CIGAR,
+ * the XS / NM / NH tags and four option globals.  In: the UNCOMPRESSED record stream behind the BAM header (what
+ * samtools' bam_read1 reads after BGZF inflate, which stays with the caller): per record int32 block_size, the 32-byte
+ * core, read name, CIGAR, sequence, qualities, tags.  Out: the accepted records, in file order, as the arrays
+ * sbgpu_assign_reads_* and sbgpu_pair_mates_* take, plus why each of the others was refused.
+ *   - refused: unmapped (flag 0x4 or no reference); a CIGAR operation of length 0; an operation other than M I D N S H P;
+ *     an N outside [min_intron, max_intron]; an I or D that is not between two M, or that is among the first two operations
+ *     the reference keeps (H and P are not kept: "10M2I10M" is refused, "3S10M2I10M" is not -- the reference's `i-1 <= 0`,
+ *     :594); at most one aligned base; NH > 1 or a secondary alignment while unique_only;
+ *   - interval [pos + 1, pos + M + D + N lengths], 1-based closed; blocks = the M runs, a D extends the block before it,
+ *     an I leaves two blocks that touch (readhit_2_genomicFeats, src/contig.cpp:12-53: no INTRON between them);
+ *   - flags as sbgpu_reads_t's: bit 0 reverse (the record's 0x10), bit 1 partner on another reference (the mate's id differs;
+ *     no mate reference included), bits 2-3
+ *     strand from XS:A ('+' / '-'), else from the library type and the first-in-pair / reverse bits (:636-651);
+ *   - read id = FNV-1 of the read name (ReadTable::get_id, include/read.hpp:164-173); reference id = the file's (the
+ *     reference numbers the @SQ lines in order); partner_pos = mate position + 1 (0: none); NH 1 when absent; NM as the
+ *     reference keeps it (through an unsigned char); read_len = M + S + I (ReadHit::read_len);
+ *   - tags are found as samtools 0.1.19 finds them (external/samtools-0.1.19/bam_aux.c:28-47): a `d` value is stepped over as
+ *     if it had no payload; no read leaves the record (a record whose own lengths exceed its block_size: TRUNCATED).  */
+typedef struct {
+   int32_t min_intron;  /* kMinIntronLength, 20 (src/common.cpp:21; -j)                     */
+   int32_t max_intron;  /* kMaxIntronLength, 300000 (src/common.cpp:20; -J)                 */
+   int32_t unique_only; /* use_only_unique_hits, 1 (src/common.cpp:67; --multiple-hit: 0)   */
+   int32_t library;     /* 0 unstranded, 1 fr_strand, 2 rf_strand (src/common.cpp:68-69)    */
+   int32_t n_ref;       /* references in the header: a larger id is refused; 0: not checked */
+} sbgpu_bam_opts_t;
+enum {
+   SBGPU_BAM_OK = 0,
+   SBGPU_BAM_UNMAPPED = 1,
+   SBGPU_BAM_BAD_REF = 2,
+   SBGPU_BAM_ZERO_OP = 3,
+   SBGPU_BAM_OP = 4,
+   SBGPU_BAM_INTRON_LONG = 5,
+   SBGPU_BAM_INTRON_SHORT = 6,
+   SBGPU_BAM_INDEL = 7,
+   SBGPU_BAM_SHORT = 8,
+   SBGPU_BAM_MULTI = 9,
+   SBGPU_BAM_TRUNCATED = 10
+};
+typedef struct sbgpu_bamreads sbgpu_bamreads_t;
+/* The records' offsets in the stream: rec_off[0 .. n] (rec_off[n] = n_bytes).  Returns n, or -1 (sbgpu_last_error) when
+ * the stream ends inside a record or `cap` records are not enough.  A caller that inflates BGZF blocks itself can note
+ * the offsets as it goes instead.                                                                                     */
+int64_t sbgpu_bam_index_host(const uint8_t *bytes, int64_t n_bytes, int64_t *rec_off, int64_t cap);
+/* Host form: host arrays in, host arrays in the handle. */
+int sbgpu_bam_decode_host(const uint8_t *bytes, int64_t n_bytes, const int64_t *rec_off, int64_t n_records,
+                          const sbgpu_bam_opts_t *opts, sbgpu_bamreads_t **out);
+/* Device form (csrc/bamdecode_device.h): `d_bytes` and `d_rec_off` device arrays; one lane per record decides and counts
+ * its blocks, two device-wide scans place the accepted records and their blocks, a second pass writes them.  The
+ * handle's arrays stay on the device: sbgpu_bamreads_reads hands them to sbgpu_assign_reads_device /
+ * sbgpu_pair_mates_device as they are.                                                                                */
+int sbgpu_bam_decode_device(sbgpu_ctx_t *ctx, const uint8_t *d_bytes, int64_t n_bytes, const int64_t *d_rec_off, int64_t n_records,
+                            const sbgpu_bam_opts_t *opts, void *stream, sbgpu_bamreads_t **out);
+void sbgpu_bamreads_destroy(sbgpu_bamreads_t *b);
+/* info: 0 records, 1 accepted, 2 aligned blocks of the accepted, 3: 1 when some record that got as far as the
+ * reference's :605 carries the paired flag (the reference then clears SINGLE_END_EXP), 4: 1 when the arrays live on the
+ * device, 5 + s: records of status s (SBGPU_BAM_OK .. SBGPU_BAM_TRUNCATED).                                            */
+int sbgpu_bamreads_info(const sbgpu_bamreads_t *b, int64_t info[16]);
+/* The accepted records where they are (host or device, info[4]): `reads` for sbgpu_pair_mates_*, and reference id /
+ * first / last aligned base for sbgpu_assign_reads_*.  Owned by the handle.                                            */
+int sbgpu_bamreads_reads(const sbgpu_bamreads_t *b, sbgpu_reads_t *reads, const int32_t **read_ref, const uint32_t **read_left,
+                         const uint32_t **read_right);
+/* Host copies (NULL = skip): status [records]; per accepted record its index in the stream, read id, reference, interval,
+ * partner_pos, flags, NH, NM, read_len, the record's flag word; block_off [accepted + 1], the blocks.                  */
+int sbgpu_bamreads_export(const sbgpu_bamreads_t *b, uint8_t *status, int64_t *record, uint64_t *read_id, int32_t *ref, uint32_t *left,
+                          uint32_t *right, uint32_t *partner_pos, uint8_t *flags, int32_t *nh, int32_t *nm, int32_t *read_len,
+                          uint32_t *sam_flag, int64_t *block_off, uint32_t *block_left, uint32_t *block_right);
 
 /* LocusContext::assign_exon_bin + set_maps (src/estimate.cpp:135-198, estimate.hpp:29-52)
  * on the kernel's results (host copies of compat / key), hits visited in input order inside

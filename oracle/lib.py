@@ -133,6 +133,57 @@ class OracleLib:
                                 a(r_ref, np.int32), a(r_left, np.uint32), a(r_right, np.uint32), a(r_xs, np.uint8), out, off)
         return out[:nr].copy(), off
 
+    # ---- BAM records -> ReadHits (BAMHitFactory::getHitFromBuf)
+    def bam_index(self, rec_bytes):
+        """Record offsets of an uncompressed BAM record stream -> int64[n + 1]."""
+        b = np.ascontiguousarray(rec_bytes, np.uint8)
+        cap = b.size // 36 + 1
+        off = np.zeros(cap + 1, np.int64)
+        self.L.sbo_bam_index.argtypes = [_p(np.uint8, flags="C"), C.c_int64, _i64, C.c_int64]
+        self.L.sbo_bam_index.restype = C.c_int64
+        n = self.L.sbo_bam_index(b if b.size else np.zeros(1, np.uint8), b.size, off, cap)
+        if n < 0:
+            raise ValueError("sbo_bam_index: the stream ends inside a record")
+        return off[:n + 1].copy()
+
+    def bam_decode(self, rec_bytes, rec_off=None, min_intron=20, max_intron=300000, unique_only=True, library=0, n_ref=0):
+        """oracle/bamdecode_oracle.c on an uncompressed record stream -> dict of per-record arrays (see the header)."""
+        b = np.ascontiguousarray(rec_bytes, np.uint8)
+        off = self.bam_index(b) if rec_off is None else np.ascontiguousarray(rec_off, np.int64)
+        n = off.size - 1
+        m = max(b.size // 4, 1)
+        _u8, _u64 = _p(np.uint8, flags="C"), _p(np.uint64, flags="C")
+        opts = (C.c_int32 * 5)(int(min_intron), int(max_intron), int(bool(unique_only)), int(library), int(n_ref))
+        N = max(n, 1)
+        z = dict(status=np.zeros(N, np.uint8), read_id=np.zeros(N, np.uint64), ref=np.zeros(N, np.int32), left=np.zeros(N, np.uint32),
+                 right=np.zeros(N, np.uint32), strand=np.zeros(N, np.uint8), partner_same_ref=np.zeros(N, np.uint8),
+                 partner_pos=np.zeros(N, np.uint32), nm=np.zeros(N, np.int32), nh=np.zeros(N, np.int32), sam_flag=np.zeros(N, np.uint32),
+                 singleton=np.zeros(N, np.uint8), mass=np.zeros(N, np.float64), read_len=np.zeros(N, np.int32),
+                 cig_off=np.zeros(N + 1, np.int64), cig_type=np.zeros(m, np.uint8), cig_len=np.zeros(m, np.uint32),
+                 feat_off=np.zeros(N + 1, np.int64), feat_code=np.zeros(m, np.uint8), feat_left=np.zeros(m, np.uint32),
+                 feat_right=np.zeros(m, np.uint32))
+        ap = np.zeros(1, np.int32)
+        self.L.sbo_bam_decode.argtypes = [_u8, _i64, C.c_int64, C.c_void_p, _u8, _u64, _i32, _u32, _u32, _u8, _u8, _u32, _i32, _i32, _u32, _u8,
+                                          _f64, _i32, _i64, _u8, _u32, _i64, _u8, _u32, _u32, _i32]
+        self.L.sbo_bam_decode.restype = None
+        self.L.sbo_bam_decode(b if b.size else np.zeros(1, np.uint8), off, n, C.cast(opts, C.c_void_p), z["status"], z["read_id"], z["ref"],
+                              z["left"], z["right"], z["strand"], z["partner_same_ref"], z["partner_pos"], z["nm"], z["nh"], z["sam_flag"],
+                              z["singleton"], z["mass"], z["read_len"], z["cig_off"], z["cig_type"], z["cig_len"], z["feat_off"],
+                              z["feat_code"], z["feat_left"], z["feat_right"], ap)
+        for key in list(z):
+            if key in ("cig_off", "feat_off"):
+                z[key] = z[key][:n + 1].copy()
+            elif key in ("cig_type", "cig_len"):
+                z[key] = z[key][:z["cig_off"][n]].copy()
+            elif key in ("feat_code", "feat_left", "feat_right"):
+                z[key] = z[key][:z["feat_off"][n]].copy()
+            else:
+                z[key] = z[key][:n].copy()
+        z["any_paired"] = int(ap[0])
+        z["n"] = n
+        z["rec_off"] = off
+        return z
+
     # ---- mate pairing (HitCluster::addOpenHit + addHit)
     def pair_mates(self, read_id, blocks, partner_pos, flags, nh):
         """One cluster's records in arrival order (blocks: per record [(l, r), ...]).
@@ -409,6 +460,46 @@ class RefLib:
         if hasattr(L, "ref_collapse_cluster"):
             L.ref_collapse_cluster.argtypes = [C.c_int, _i64, _u32, _u32, _i64, _u32, _u32, _i32, _i32, _f64, _f64]
             L.ref_collapse_cluster.restype = C.c_int
+
+    def bam_decode(self, bam_path, n_records, n_ops, min_intron=20, max_intron=300000, unique_only=True, library=0):
+        """Every record of a BAM file through the reference's own BAMHitFactory::getHitFromBuf (src/read.cpp:480-715)
+        with the option globals set as the command line would; n_records / n_ops: array capacities (records, CIGAR
+        operations in all).  -> dict of per-record arrays (file order), the kept CIGARs and readhit_2_genomicFeats'
+        features as CSR, and `single_end` (the global SINGLE_END_EXP afterwards)."""
+        L = self.L
+        if not hasattr(L, "ref_bam_decode"):
+            raise RuntimeError("oracle/_ref/libstrawberry_ref.so predates ref_bam_decode: `make -C oracle ref`")
+        _u8 = _p(np.uint8, flags="C")
+        _u64 = _p(np.uint64, flags="C")
+        L.ref_bam_decode.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, _u8, _u64, _i32, _u32, _u32, _u8,
+                                     _u8, _u32, _i32, _i32, _u32, _f64, _i32, _i64, _u8, _u32, _i64, _u8, _u32, _u32, _i32]
+        L.ref_bam_decode.restype = C.c_int
+        n, m = max(int(n_records), 1), max(int(n_ops), 1)
+        z = dict(accepted=np.zeros(n, np.uint8), read_id=np.zeros(n, np.uint64), ref=np.zeros(n, np.int32), left=np.zeros(n, np.uint32),
+                 right=np.zeros(n, np.uint32), strand=np.zeros(n, np.uint8), partner_same_ref=np.zeros(n, np.uint8),
+                 partner_pos=np.zeros(n, np.uint32), nm=np.zeros(n, np.int32), nh=np.zeros(n, np.int32), flag_bits=np.zeros(n, np.uint32),
+                 mass=np.zeros(n, np.float64), read_len=np.zeros(n, np.int32), cig_off=np.zeros(n + 1, np.int64), cig_type=np.zeros(m, np.uint8),
+                 cig_len=np.zeros(m, np.uint32), feat_off=np.zeros(n + 1, np.int64), feat_code=np.zeros(m, np.uint8),
+                 feat_left=np.zeros(m, np.uint32), feat_right=np.zeros(m, np.uint32))
+        se = np.zeros(1, np.int32)
+        k = L.ref_bam_decode(str(bam_path).encode(), int(min_intron), int(max_intron), int(bool(unique_only)), int(library), n, m,
+                             z["accepted"], z["read_id"], z["ref"], z["left"], z["right"], z["strand"], z["partner_same_ref"],
+                             z["partner_pos"], z["nm"], z["nh"], z["flag_bits"], z["mass"], z["read_len"], z["cig_off"], z["cig_type"],
+                             z["cig_len"], z["feat_off"], z["feat_code"], z["feat_left"], z["feat_right"], se)
+        if k < 0:
+            raise RuntimeError("ref_bam_decode: capacities too small")
+        for key in list(z):
+            if key in ("cig_off", "feat_off"):
+                z[key] = z[key][:k + 1].copy()
+            elif key not in ("cig_type", "cig_len", "feat_code", "feat_left", "feat_right"):
+                z[key] = z[key][:k].copy()
+        for key in ("cig_type", "cig_len"):
+            z[key] = z[key][:z["cig_off"][-1]].copy()
+        for key in ("feat_code", "feat_left", "feat_right"):
+            z[key] = z[key][:z["feat_off"][-1]].copy()
+        z["single_end"] = int(se[0])
+        z["n"] = k
+        return z
 
     def cluster_from_records(self, read_id, blocks, partner_pos, flags, nh):
         """Records -> the reference's HitCluster::addOpenHit (mate pairing) -> collapseAndFilterHits.

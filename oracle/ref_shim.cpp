@@ -163,7 +163,8 @@ static ReadHitPtr make_readhit(int n, const uint32_t *bl, const uint32_t *br, ui
 {
    std::vector<CigarOp> cig;
    for (int k = 0; k < n; ++k) {
-      if (k) cig.push_back(CigarOp(REF_SKIP, bl[k] - br[k - 1] - 1));
+      if (k && bl[k] != br[k - 1] + 1) cig.push_back(CigarOp(REF_SKIP, bl[k] - br[k - 1] - 1));
+      else if (k) cig.push_back(CigarOp(INS, 1)); /* blocks that touch: an insertion in the read (M I M) */
       cig.push_back(CigarOp(MATCH, br[k] - bl[k] + 1));
    }
    GenomicInterval iv(0, bl[0], br[n - 1], Strand_t::StrandPlus);
@@ -252,7 +253,8 @@ int ref_cluster_from_records(int n_reads, const uint64_t *read_id, const int64_t
       if (n <= 0) continue;
       std::vector<CigarOp> cig;
       for (int64_t k = 0; k < n; ++k) {
-         if (k) cig.push_back(CigarOp(REF_SKIP, bl[o + k] - br[o + k - 1] - 1));
+         if (k && bl[o + k] != br[o + k - 1] + 1) cig.push_back(CigarOp(REF_SKIP, bl[o + k] - br[o + k - 1] - 1));
+         else if (k) cig.push_back(CigarOp(INS, 1)); /* blocks that touch: an insertion in the read */
          cig.push_back(CigarOp(MATCH, br[o + k] - bl[o + k] + 1));
       }
       const int xs = (flags[r] >> 2) & 3;
@@ -292,6 +294,76 @@ void ref_kmer_stats(const char *seq, int len, double *out6)
    out6[3] = Kmer<std::string>::HighGCStrech(s.begin(), s.end(), 20, 0.9);
    out6[4] = Kmer<std::string>::HighGCStrech(s.begin(), s.end(), 40, 0.8);
    out6[5] = Kmer<std::string>::HighGCStrech(s.begin(), s.end(), 40, 0.9);
+}
+
+/* BAMHitFactory::getHitFromBuf (src/read.cpp:480-715) on every record of a BAM file, through the reference's own
+ * BAMHitFactory (samopen + bam_read1 of the vendored samtools 0.1.19), with the reference's option globals set as the
+ * command line would set them (-j / -J, --multiple-hit, --fr / --rf; src/Strawberry.cpp:129-169).  Per record, in file
+ * order: accepted (getHitFromBuf's return value), and for the accepted ones the ReadHit's fields (sam_flag: the bits the
+ * class shows -- 16 reverse, 64 first, 128 second -- and bit 31 = is_singleton()).  The CIGAR the
+ * ReadHit keeps (H and P ops are not in it) is flattened into cig_type / cig_len at cig_off[r]; the features
+ * readhit_2_genomicFeats (src/contig.cpp:12-53) makes of it into feat_* at feat_off[r].  Returns the number of
+ * records read, or -1 when an array is too small.  *single_end_out = the global SINGLE_END_EXP afterwards.      */
+int ref_bam_decode(const char *bam_path, int min_intron, int max_intron, int unique_only, int library, int64_t cap_records,
+                   int64_t cap_ops, uint8_t *accepted, uint64_t *read_id, int32_t *ref_id, uint32_t *left, uint32_t *right,
+                   uint8_t *strand, uint8_t *partner_same_ref, uint32_t *partner_pos, int32_t *num_mismatch, int32_t *num_hits,
+                   uint32_t *sam_flag, double *mass, int32_t *read_len, int64_t *cig_off, uint8_t *cig_type, uint32_t *cig_len,
+                   int64_t *feat_off, uint8_t *feat_code, uint32_t *feat_left, uint32_t *feat_right, int32_t *single_end_out)
+{
+   kMinIntronLength = min_intron;
+   kMaxIntronLength = max_intron;
+   use_only_unique_hits = unique_only != 0;
+   fr_strand = library == 1;
+   rf_strand = library == 2;
+   SINGLE_END_EXP = true;
+   ReadTable rt;
+   RefSeqTable st(true);
+   BAMHitFactory hf(bam_path, rt, st);
+   hf.inspect_header(); /* fills the reference-name table from the @SQ lines, as Sample's constructor does */
+   int64_t n = 0, nc = 0, nf = 0;
+   const char *buf = NULL;
+   size_t buf_size = 0;
+   cig_off[0] = feat_off[0] = 0;
+   while (hf.nextRecord(buf, buf_size)) {
+      if (n >= cap_records) return -1;
+      ReadHit rh;
+      const bool ok = hf.getHitFromBuf(buf, rh);
+      accepted[n] = ok ? 1 : 0;
+      if (ok) {
+         read_id[n] = (uint64_t)rh.read_id();
+         ref_id[n] = (int32_t)rh.ref_id();
+         left[n] = rh.left();
+         right[n] = rh.right();
+         strand[n] = rh.strand() == Strand_t::StrandPlus ? 1 : (rh.strand() == Strand_t::StrandMinus ? 2 : 0);
+         partner_same_ref[n] = rh.partner_ref_id() == rh.ref_id() ? 1 : 0;
+         partner_pos[n] = (uint32_t)rh.partner_pos();
+         num_mismatch[n] = rh.num_mismatch();
+         num_hits[n] = rh.numHits();
+         sam_flag[n] = (rh.reverseCompl() ? 16u : 0u) | (rh.is_first() ? 64u : 0u) | (rh.is_second() ? 128u : 0u) | (rh.is_singleton() ? 1u << 31 : 0u);
+         mass[n] = rh.mass();
+         read_len[n] = (int32_t)rh.read_len();
+         for (const CigarOp &c : rh.cigar()) {
+            if (nc >= cap_ops) return -1;
+            cig_type[nc] = (uint8_t)c._type;
+            cig_len[nc] = c._length;
+            ++nc;
+         }
+         std::vector<GenomicFeature> feats;
+         readhit_2_genomicFeats(rh, feats);
+         for (const GenomicFeature &f : feats) {
+            if (nf >= cap_ops) return -1;
+            feat_code[nf] = (uint8_t)f._match_op._code;
+            feat_left[nf] = f.left();
+            feat_right[nf] = f.right();
+            ++nf;
+         }
+      }
+      ++n;
+      cig_off[n] = nc;
+      feat_off[n] = nf;
+   }
+   *single_end_out = SINGLE_END_EXP ? 1 : 0;
+   return (int)n;
 }
 
 } /* extern "C" */

@@ -24,6 +24,8 @@ SYMBOLS = [
     "sbgpu_plan_classes", "sbgpu_plan_locus_kinds", "sbgpu_em_run_device", "sbgpu_em_run_device_f32", "sbgpu_em_run_device_bias", "sbgpu_em_run_device_bias_f32", "sbgpu_em_last_kernel_ms",
     "sbgpu_set_timing", "sbgpu_em_last_phase_ms", "sbgpu_last_stage_ms", "sbgpu_pair_mates_host", "sbgpu_pair_mates_device", "sbgpu_matepairs_destroy", "sbgpu_matepairs_info",
     "sbgpu_matepairs_pairs", "sbgpu_matepairs_export", "sbgpu_assign_reads_host", "sbgpu_assign_reads_device",
+    "sbgpu_bam_index_host", "sbgpu_bam_decode_host", "sbgpu_bam_decode_device", "sbgpu_bamreads_destroy", "sbgpu_bamreads_info",
+    "sbgpu_bamreads_reads", "sbgpu_bamreads_export",
     "sbgpu_comm_unique_id", "sbgpu_comm_init", "sbgpu_comm_info", "sbgpu_comm_rccl_ranks", "sbgpu_comm_destroy",
     "sbgpu_allreduce_sum_f64", "sbgpu_allreduce_sum_i64", "sbgpu_allreduce_sum_f64_host", "sbgpu_allreduce_sum_i64_host",
     "sbgpu_insert_pdf_table", "sbgpu_binweight_device", "sbgpu_binweight_host",
@@ -103,6 +105,14 @@ class sbgpu_clusters_t(C.Structure):
 class sbgpu_reads_t(C.Structure):
     _fields_ = [("n_reads", C.c_int64), ("read_id", C.c_void_p), ("block_off", C.c_void_p), ("block_left", C.c_void_p),
                 ("block_right", C.c_void_p), ("partner_pos", C.c_void_p), ("flags", C.c_void_p), ("nh", C.c_void_p)]
+
+
+class sbgpu_bam_opts_t(C.Structure):
+    _fields_ = [("min_intron", C.c_int32), ("max_intron", C.c_int32), ("unique_only", C.c_int32), ("library", C.c_int32),
+                ("n_ref", C.c_int32)]
+
+
+BAM_STATUS_NAMES = ["OK", "UNMAPPED", "BAD_REF", "ZERO_OP", "OP", "INTRON_LONG", "INTRON_SHORT", "INDEL", "SHORT", "MULTI", "TRUNCATED"]
 
 
 class sbgpu_hits_t(C.Structure):
@@ -208,6 +218,15 @@ def load():
     L.sbgpu_matepairs_info.argtypes = [vp, i64p]
     L.sbgpu_matepairs_pairs.argtypes = [vp, C.POINTER(sbgpu_pairs_t), C.POINTER(vp)]
     L.sbgpu_matepairs_export.argtypes = [vp] * 10
+    L.sbgpu_bam_index_host.argtypes = [vp, C.c_int64, vp, C.c_int64]
+    L.sbgpu_bam_index_host.restype = C.c_int64
+    L.sbgpu_bam_decode_host.argtypes = [vp, C.c_int64, vp, C.c_int64, C.POINTER(sbgpu_bam_opts_t), C.POINTER(vp)]
+    L.sbgpu_bam_decode_device.argtypes = [vp, vp, C.c_int64, vp, C.c_int64, C.POINTER(sbgpu_bam_opts_t), vp, C.POINTER(vp)]
+    L.sbgpu_bamreads_destroy.argtypes = [vp]
+    L.sbgpu_bamreads_destroy.restype = None
+    L.sbgpu_bamreads_info.argtypes = [vp, i64p]
+    L.sbgpu_bamreads_reads.argtypes = [vp, C.POINTER(sbgpu_reads_t), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.sbgpu_bamreads_export.argtypes = [vp] * 16
     L.sbgpu_assign_reads_host.argtypes = [C.POINTER(sbgpu_clusters_t), C.c_int64, vp, vp, vp, vp, vp, vp]
     L.sbgpu_assign_reads_device.argtypes = [vp, C.POINTER(sbgpu_clusters_t), C.c_int64, vp, vp, vp, vp, vp, vp, vp]
     L.sbgpu_uniq_dev_destroy.argtypes = [vp]

@@ -1,0 +1,316 @@
+// strawberry_amd/csrc/bamdecode_api.hip -- sbgpu_bam_index_host / sbgpu_bam_decode_host / _device (include/sbgpu.h): BAM
+// alignment records -> the read stream, BAMHitFactory::getHitFromBuf (/root/reference/src/read.cpp:480-715).  The decoder
+// body and the two kernels: bamdecode_device.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include <rocprim/rocprim.hpp>
+
+#include "../../include/sbgpu.h"
+#include "api_internal.h"
+#include "bamdecode_device.h"
+
+using sb::api_fail;
+
+struct sbgpu_bamreads {
+   bool on_device = false;
+   int device = 0;
+   int64_t n_records = 0, n_reads = 0, n_blocks = 0, any_paired = 0;
+   int64_t by_status[11] = {};
+   std::vector<char> host; // host form: one buffer
+   char *arena = nullptr;  // device form: one arena (sb::dev_take'n)
+   size_t arena_cap = 0;
+   // into the buffer / arena
+   uint8_t *status = nullptr;   // [n_records]
+   int64_t *record = nullptr;   // [n_reads] ...
+   uint64_t *read_id = nullptr;
+   int32_t *ref = nullptr, *nh = nullptr, *nm = nullptr, *read_len = nullptr;
+   uint32_t *left = nullptr, *right = nullptr, *partner_pos = nullptr, *sam_flag = nullptr;
+   uint8_t *flags = nullptr;
+   int64_t *block_off = nullptr; // [n_reads + 1]
+   uint32_t *block_left = nullptr, *block_right = nullptr; // [n_blocks]
+};
+
+namespace {
+size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// the handle's arrays inside one block of memory; returns its size
+size_t lay_out(sbgpu_bamreads *B, char *base)
+{
+   size_t off = 0;
+   auto take = [&](size_t bytes) {
+      char *p = base ? base + off : nullptr;
+      off += up256(bytes ? bytes : 8);
+      return p;
+   };
+   const size_t n = (size_t)B->n_records, m = (size_t)B->n_reads, nb = (size_t)B->n_blocks;
+   B->status = (uint8_t *)take(n);
+   B->record = (int64_t *)take(m * 8);
+   B->read_id = (uint64_t *)take(m * 8);
+   B->ref = (int32_t *)take(m * 4), B->nh = (int32_t *)take(m * 4), B->nm = (int32_t *)take(m * 4), B->read_len = (int32_t *)take(m * 4);
+   B->left = (uint32_t *)take(m * 4), B->right = (uint32_t *)take(m * 4), B->partner_pos = (uint32_t *)take(m * 4);
+   B->sam_flag = (uint32_t *)take(m * 4);
+   B->flags = (uint8_t *)take(m);
+   B->block_off = (int64_t *)take((m + 1) * 8);
+   B->block_left = (uint32_t *)take(nb * 4), B->block_right = (uint32_t *)take(nb * 4);
+   return off;
+}
+
+int check_opts(const sbgpu_bam_opts_t *o, const char *who)
+{
+   if (!o) return api_fail(SBGPU_EINVAL, std::string(who) + ": null options");
+   if (o->library < 0 || o->library > 2) return api_fail(SBGPU_EINVAL, std::string(who) + ": library must be 0 (unstranded), 1 (fr) or 2 (rf)");
+   return SBGPU_OK;
+}
+} // namespace
+
+extern "C" {
+
+int64_t sbgpu_bam_index_host(const uint8_t *bytes, int64_t n_bytes, int64_t *rec_off, int64_t cap)
+{
+   if ((!bytes && n_bytes) || !rec_off || n_bytes < 0 || cap < 0) {
+      api_fail(SBGPU_EINVAL, "sbgpu_bam_index_host: bad argument");
+      return -1;
+   }
+   int64_t n = 0, p = 0;
+   while (p < n_bytes) {
+      if (p + 4 > n_bytes) {
+         api_fail(SBGPU_ESHAPE, "sbgpu_bam_index_host: the stream ends inside a record's size word");
+         return -1;
+      }
+      const int32_t bs = sb::bam_i32(bytes + p);
+      if (bs < 0 || p + 4 + (int64_t)bs > n_bytes) {
+         api_fail(SBGPU_ESHAPE, "sbgpu_bam_index_host: record " + std::to_string(n) + " runs past the end of the stream");
+         return -1;
+      }
+      if (n >= cap) {
+         api_fail(SBGPU_ESHAPE, "sbgpu_bam_index_host: more than `cap` records");
+         return -1;
+      }
+      rec_off[n++] = p;
+      p += 4 + (int64_t)bs;
+   }
+   rec_off[n] = p;
+   return n;
+}
+
+void sbgpu_bamreads_destroy(sbgpu_bamreads_t *b)
+{
+   if (!b) return;
+   sb::dev_give(b->arena, b->arena_cap);
+   delete b;
+}
+
+int sbgpu_bam_decode_host(const uint8_t *bytes, int64_t n_bytes, const int64_t *rec_off, int64_t n, const sbgpu_bam_opts_t *opts,
+                          sbgpu_bamreads_t **out)
+{
+   if (!out || n < 0 || n_bytes < 0 || (n && (!bytes || !rec_off))) return api_fail(SBGPU_EINVAL, "sbgpu_bam_decode_host: bad argument");
+   *out = nullptr;
+   if (const int rc = check_opts(opts, "sbgpu_bam_decode_host")) return rc;
+   for (int64_t r = 0; r < n; ++r)
+      if (rec_off[r] < 0 || rec_off[r + 1] < rec_off[r] || rec_off[r + 1] > n_bytes)
+         return api_fail(SBGPU_EINVAL, "sbgpu_bam_decode_host: rec_off is not an ascending list of offsets inside the stream");
+   sbgpu_bamreads *B = new (std::nothrow) sbgpu_bamreads();
+   if (!B) return api_fail(SBGPU_ENOMEM, "sbgpu_bam_decode_host: out of memory");
+   try {
+      B->n_records = n;
+      std::vector<sb::BamRead> rd((size_t)n);
+      for (int64_t r = 0; r < n; ++r) {
+         sb::bam_decode_record(bytes + rec_off[r], rec_off[r + 1] - rec_off[r], *opts, rd[(size_t)r]);
+         const sb::BamRead &x = rd[(size_t)r];
+         ++B->by_status[x.status <= SBGPU_BAM_TRUNCATED ? x.status : SBGPU_BAM_TRUNCATED];
+         if (x.paired) B->any_paired = 1;
+         if (x.status == SBGPU_BAM_OK) ++B->n_reads, B->n_blocks += x.n_blocks;
+      }
+      B->host.resize(lay_out(B, nullptr));
+      lay_out(B, B->host.data());
+      int64_t k = 0, b = 0;
+      for (int64_t r = 0; r < n; ++r) {
+         const sb::BamRead &x = rd[(size_t)r];
+         B->status[r] = x.status;
+         if (x.status != SBGPU_BAM_OK) continue;
+         B->record[k] = r, B->read_id[k] = x.read_id, B->ref[k] = x.ref, B->nh[k] = x.nh, B->nm[k] = x.nm, B->read_len[k] = x.read_len;
+         B->left[k] = x.left, B->right[k] = x.right, B->partner_pos[k] = x.partner_pos, B->sam_flag[k] = x.sam_flag, B->flags[k] = x.flags;
+         B->block_off[k] = b;
+         sb::bam_record_blocks(bytes + rec_off[r], B->block_left + b, B->block_right + b);
+         b += x.n_blocks;
+         ++k;
+      }
+      B->block_off[k] = b;
+   } catch (const std::bad_alloc &) {
+      delete B;
+      return api_fail(SBGPU_ENOMEM, "sbgpu_bam_decode_host: out of memory");
+   }
+   *out = B;
+   return SBGPU_OK;
+}
+
+int sbgpu_bam_decode_device(sbgpu_ctx_t *c, const uint8_t *d_bytes, int64_t n_bytes, const int64_t *d_rec_off, int64_t n,
+                            const sbgpu_bam_opts_t *opts, void *stream, sbgpu_bamreads_t **out)
+{
+   if (!c || !out || n < 0 || n_bytes < 0 || (n && (!d_bytes || !d_rec_off))) return api_fail(SBGPU_EINVAL, "sbgpu_bam_decode_device: bad argument");
+   *out = nullptr;
+   if (const int rc = check_opts(opts, "sbgpu_bam_decode_device")) return rc;
+   if (n >= ((int64_t)1 << 31) - 2) return api_fail(SBGPU_EUNSUPPORTED, "sbgpu_bam_decode_device: more than 2^31 records in one call; split the stream");
+   sbgpu_bamreads *B = new (std::nothrow) sbgpu_bamreads();
+   if (!B) return api_fail(SBGPU_ENOMEM, "sbgpu_bam_decode_device: out of memory");
+   B->on_device = true;
+   B->device = sb::ctx_device(c);
+   B->n_records = n;
+   hipStream_t s = stream ? (hipStream_t)stream : sb::ctx_stream(c);
+   char *w = nullptr;
+   size_t w_cap = 0;
+   auto bail = [&](int code, const std::string &msg) {
+      (void)hipStreamSynchronize(s);
+      sb::dev_give(w, w_cap);
+      sbgpu_bamreads_destroy(B);
+      return api_fail(code, msg);
+   };
+#define SB_TRY(expr)                                                                                     \
+   do {                                                                                                  \
+      hipError_t e_ = (expr);                                                                            \
+      if (e_ != hipSuccess) return bail(e_ == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+   } while (0)
+   SB_TRY(hipSetDevice(B->device));
+   if (n == 0) {
+      *out = B;
+      return SBGPU_OK;
+   }
+   const size_t nn = (size_t)n, n1 = nn + 1;
+   auto as_i64_u8 = [] __device__(uint8_t v) { return (int64_t)v; };
+   auto as_i64_i32 = [] __device__(int32_t v) { return (int64_t)v; };
+   size_t tmp_bytes = 0;
+   {
+      size_t b = 0;
+      (void)rocprim::exclusive_scan(nullptr, b, rocprim::make_transform_iterator((const uint8_t *)nullptr, as_i64_u8), (int64_t *)nullptr, (int64_t)0, n1, rocprim::plus<int64_t>(), s);
+      tmp_bytes = std::max(tmp_bytes, b);
+      (void)rocprim::exclusive_scan(nullptr, b, rocprim::make_transform_iterator((const int32_t *)nullptr, as_i64_i32), (int64_t *)nullptr, (int64_t)0, n1, rocprim::plus<int64_t>(), s);
+      tmp_bytes = std::max(tmp_bytes, b);
+   }
+   size_t off = 0;
+   auto take = [&](size_t bytes) {
+      const size_t o = off;
+      off += up256(bytes ? bytes : 8);
+      return o;
+   };
+   const size_t o_status = take(nn), o_acc = take(n1), o_nb = take(n1 * 4), o_rid = take(nn * 8), o_ref = take(nn * 4), o_nh = take(nn * 4),
+                o_nm = take(nn * 4), o_rl = take(nn * 4), o_left = take(nn * 4), o_right = take(nn * 4), o_pp = take(nn * 4), o_sf = take(nn * 4),
+                o_fl = take(nn), o_rat = take(n1 * 8), o_bat = take(n1 * 8), o_cnt = take(16 * 8), o_tmp = take(tmp_bytes);
+   SB_TRY(sb::dev_take(off, &w, &w_cap));
+   SB_TRY(hipMemsetAsync(w + o_cnt, 0, 16 * 8, s));
+   SB_TRY(hipMemsetAsync(w + o_acc + nn, 0, 1, s));
+   SB_TRY(hipMemsetAsync(w + o_nb + nn * 4, 0, 4, s));
+   sb::BamScanArgs a = {};
+   a.bytes = d_bytes, a.rec_off = d_rec_off, a.n = n, a.opts = *opts;
+   a.status = (uint8_t *)(w + o_status), a.n_blocks = (int32_t *)(w + o_nb), a.accepted = (uint8_t *)(w + o_acc);
+   a.read_id = (uint64_t *)(w + o_rid), a.ref = (int32_t *)(w + o_ref), a.nh = (int32_t *)(w + o_nh), a.nm = (int32_t *)(w + o_nm);
+   a.read_len = (int32_t *)(w + o_rl), a.left = (uint32_t *)(w + o_left), a.right = (uint32_t *)(w + o_right);
+   a.partner_pos = (uint32_t *)(w + o_pp), a.sam_flag = (uint32_t *)(w + o_sf), a.flags = (uint8_t *)(w + o_fl);
+   a.counts = (unsigned long long *)(w + o_cnt);
+   const int64_t cap = (int64_t)sb::ctx_cu_count(c) * 32, blocks = std::min<int64_t>((n + 255) / 256, cap);
+   hipLaunchKernelGGL(sb::bam_scan_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+   SB_TRY(hipGetLastError());
+   size_t tb = tmp_bytes;
+   SB_TRY(rocprim::exclusive_scan(w + o_tmp, tb, rocprim::make_transform_iterator((const uint8_t *)a.accepted, as_i64_u8), (int64_t *)(w + o_rat), (int64_t)0, n1, rocprim::plus<int64_t>(), s));
+   tb = tmp_bytes;
+   SB_TRY(rocprim::exclusive_scan(w + o_tmp, tb, rocprim::make_transform_iterator((const int32_t *)a.n_blocks, as_i64_i32), (int64_t *)(w + o_bat), (int64_t)0, n1, rocprim::plus<int64_t>(), s));
+   // the totals: the output arena's size depends on them
+   int64_t totals[2] = {0, 0};
+   unsigned long long counts[16];
+   SB_TRY(hipMemcpyAsync(&totals[0], w + o_rat + nn * 8, 8, hipMemcpyDeviceToHost, s));
+   SB_TRY(hipMemcpyAsync(&totals[1], w + o_bat + nn * 8, 8, hipMemcpyDeviceToHost, s));
+   SB_TRY(hipMemcpyAsync(counts, w + o_cnt, sizeof(counts), hipMemcpyDeviceToHost, s));
+   SB_TRY(hipStreamSynchronize(s));
+   B->n_reads = totals[0], B->n_blocks = totals[1];
+   for (int k = 0; k <= SBGPU_BAM_TRUNCATED; ++k) B->by_status[k] = (int64_t)counts[k];
+   B->any_paired = counts[11] ? 1 : 0;
+   SB_TRY(sb::dev_take(lay_out(B, nullptr), &B->arena, &B->arena_cap));
+   lay_out(B, B->arena);
+   SB_TRY(hipMemcpyAsync(B->status, w + o_status, nn, hipMemcpyDeviceToDevice, s));
+   sb::BamFillArgs f = {};
+   f.bytes = d_bytes, f.rec_off = d_rec_off, f.n = n;
+   f.accepted = a.accepted, f.read_at = (const int64_t *)(w + o_rat), f.block_at = (const int64_t *)(w + o_bat);
+   f.read_id = a.read_id, f.ref = a.ref, f.nh = a.nh, f.nm = a.nm, f.read_len = a.read_len;
+   f.left = a.left, f.right = a.right, f.partner_pos = a.partner_pos, f.sam_flag = a.sam_flag, f.flags = a.flags;
+   f.o_record = B->record, f.o_read_id = B->read_id, f.o_ref = B->ref, f.o_nh = B->nh, f.o_nm = B->nm, f.o_read_len = B->read_len;
+   f.o_left = B->left, f.o_right = B->right, f.o_partner_pos = B->partner_pos, f.o_sam_flag = B->sam_flag, f.o_flags = B->flags;
+   f.o_block_off = B->block_off, f.o_block_left = B->block_left, f.o_block_right = B->block_right;
+   hipLaunchKernelGGL(sb::bam_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, f);
+   SB_TRY(hipGetLastError());
+   SB_TRY(hipStreamSynchronize(s)); // (the scratch goes back to the pool; the handle's arrays are complete when the call returns)
+   sb::dev_give(w, w_cap);
+#undef SB_TRY
+   *out = B;
+   return SBGPU_OK;
+}
+
+int sbgpu_bamreads_info(const sbgpu_bamreads_t *b, int64_t info[16])
+{
+   if (!b || !info) return api_fail(SBGPU_EINVAL, "sbgpu_bamreads_info: null argument");
+   info[0] = b->n_records, info[1] = b->n_reads, info[2] = b->n_blocks, info[3] = b->any_paired, info[4] = b->on_device ? 1 : 0;
+   for (int k = 0; k <= SBGPU_BAM_TRUNCATED; ++k) info[5 + k] = b->by_status[k];
+   return SBGPU_OK;
+}
+
+int sbgpu_bamreads_reads(const sbgpu_bamreads_t *b, sbgpu_reads_t *reads, const int32_t **read_ref, const uint32_t **read_left,
+                         const uint32_t **read_right)
+{
+   if (!b || !reads) return api_fail(SBGPU_EINVAL, "sbgpu_bamreads_reads: null argument");
+   reads->n_reads = b->n_reads;
+   reads->read_id = b->read_id;
+   reads->block_off = b->block_off;
+   reads->block_left = b->block_left, reads->block_right = b->block_right;
+   reads->partner_pos = b->partner_pos;
+   reads->flags = b->flags;
+   reads->nh = b->nh;
+   if (read_ref) *read_ref = b->ref;
+   if (read_left) *read_left = b->left;
+   if (read_right) *read_right = b->right;
+   return SBGPU_OK;
+}
+
+int sbgpu_bamreads_export(const sbgpu_bamreads_t *b, uint8_t *status, int64_t *record, uint64_t *read_id, int32_t *ref, uint32_t *left,
+                          uint32_t *right, uint32_t *partner_pos, uint8_t *flags, int32_t *nh, int32_t *nm, int32_t *read_len,
+                          uint32_t *sam_flag, int64_t *block_off, uint32_t *block_left, uint32_t *block_right)
+{
+   if (!b) return api_fail(SBGPU_EINVAL, "sbgpu_bamreads_export: null handle");
+   if (b->on_device) {
+      const hipError_t e0 = hipSetDevice(b->device);
+      if (e0 != hipSuccess) return api_fail(SBGPU_EHIP, std::string("sbgpu_bamreads_export: ") + hipGetErrorString(e0));
+   }
+   if (b->n_records == 0) {
+      if (block_off) block_off[0] = 0;
+      return SBGPU_OK;
+   }
+   auto put = [&](void *dst, const void *src, size_t bytes) -> hipError_t {
+      if (!dst || !bytes) return hipSuccess;
+      if (b->on_device) return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
+      std::memcpy(dst, src, bytes);
+      return hipSuccess;
+   };
+   const size_t n = (size_t)b->n_records, m = (size_t)b->n_reads, nb = (size_t)b->n_blocks;
+   hipError_t e = put(status, b->status, n);
+   if (e == hipSuccess) e = put(record, b->record, m * 8);
+   if (e == hipSuccess) e = put(read_id, b->read_id, m * 8);
+   if (e == hipSuccess) e = put(ref, b->ref, m * 4);
+   if (e == hipSuccess) e = put(left, b->left, m * 4);
+   if (e == hipSuccess) e = put(right, b->right, m * 4);
+   if (e == hipSuccess) e = put(partner_pos, b->partner_pos, m * 4);
+   if (e == hipSuccess) e = put(flags, b->flags, m);
+   if (e == hipSuccess) e = put(nh, b->nh, m * 4);
+   if (e == hipSuccess) e = put(nm, b->nm, m * 4);
+   if (e == hipSuccess) e = put(read_len, b->read_len, m * 4);
+   if (e == hipSuccess) e = put(sam_flag, b->sam_flag, m * 4);
+   if (e == hipSuccess) e = put(block_off, b->block_off, (m + 1) * 8);
+   if (e == hipSuccess) e = put(block_left, b->block_left, nb * 4);
+   if (e == hipSuccess) e = put(block_right, b->block_right, nb * 4);
+   if (e != hipSuccess) return api_fail(SBGPU_EHIP, std::string("sbgpu_bamreads_export: ") + hipGetErrorString(e));
+   return SBGPU_OK;
+}
+
+} // extern "C"

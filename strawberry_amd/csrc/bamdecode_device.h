@@ -1,0 +1,316 @@
+// strawberry_amd/csrc/bamdecode_device.h -- BAM alignment records -> the read stream (the part of it
+// that sits in front of the clusters: BAMHitFactory::getHitFromBuf, /root/reference/src/read.cpp:480-715).
+//
+// The reference reads a BAM record (samtools 0.1.19's bam_read1), then decides -- on the flag word, the CIGAR, three
+// auxiliary tags and four option globals -- whether the record becomes a ReadHit and with which interval, strand, mate
+// position, NH and read id.  Integer and byte work on ~150-400 bytes per record, every record by itself: one lane per
+// record here, two passes (decide + count the aligned blocks; compact the accepted records and write their blocks), a
+// device-wide scan between them.  The same decoder body serves the host entry (sbgpu_bam_decode_host).
+//
+// What is decoded is the UNCOMPRESSED record stream (after BGZF inflate, which stays with the caller -- zlib on host
+// cores) behind the BAM header: int32 block_size, the 32-byte core, read name, CIGAR, sequence, qualities, tags.
+//
+// Kept from the reference, quirks included (oracle/bamdecode_oracle.c states them line by line):
+//   - refused: unmapped (flag 0x4 or no reference); a CIGAR operation of length 0; an operation other than M I D N S H P;
+//     an N outside [min_intron, max_intron]; an I or D that is not between two M or that is among the first two KEPT
+//     operations (H and P are not kept); at most one aligned base; NH > 1 or a secondary alignment while unique_only;
+//   - the interval is [pos + 1, pos + M + D + N lengths]; the aligned blocks are the M runs, a D extends the block in front
+//     of it, an I leaves two blocks that touch (sbgpu_pair_mates_* write no INTRON between touching blocks);
+//   - strand: the XS:A tag ('+' / '-'; any other type or value: unknown), else the library type (fr / rf) with the
+//     first-in-pair and reverse bits (:636-651);
+//   - read id: FNV-1 of the name with the bytes as signed chars (include/read.hpp:164-173);
+//   - tags are found the way samtools 0.1.19 finds them (bam_aux.c:28-47): types upper-cased, sizes 1 / 2 / 4, Z and H to
+//     their NUL, B by its count -- and a `d` as if it had no payload.  No read leaves the record.
+#pragma once
+
+#include <stdint.h>
+
+#include "../../include/sbgpu.h"
+
+#ifdef __HIPCC__
+#define SB_HD __host__ __device__ __forceinline__
+#else
+#define SB_HD inline
+#endif
+
+namespace sb {
+
+struct BamRead {
+   uint64_t read_id;
+   int32_t ref;
+   uint32_t left, right, partner_pos, sam_flag;
+   int32_t nh, nm, read_len, n_blocks;
+   uint8_t status, flags, paired;
+};
+
+SB_HD uint32_t bam_u32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+SB_HD int32_t bam_i32(const uint8_t *p) { return (int32_t)bam_u32(p); }
+SB_HD int bam_aux_size(int x) // bam_aux_type2size, samtools-0.1.19/bam.h:772-778
+{
+   if (x == 'C' || x == 'c' || x == 'A') return 1;
+   if (x == 'S' || x == 's') return 2;
+   if (x == 'I' || x == 'i' || x == 'f' || x == 'F') return 4;
+   return 0;
+}
+SB_HD int32_t bam_aux_int(const uint8_t *s, const uint8_t *end) // bam_aux2i on the tag's type byte
+{
+   const int type = *s++;
+   if (type == 'c') return s + 1 <= end ? (int32_t)(int8_t)s[0] : 0;
+   if (type == 'C') return s + 1 <= end ? (int32_t)s[0] : 0;
+   if (type == 's') return s + 2 <= end ? (int32_t)(int16_t)((uint16_t)s[0] | ((uint16_t)s[1] << 8)) : 0;
+   if (type == 'S') return s + 2 <= end ? (int32_t)((uint16_t)s[0] | ((uint16_t)s[1] << 8)) : 0;
+   if (type == 'i' || type == 'I') return s + 4 <= end ? bam_i32(s) : 0;
+   return 0;
+}
+
+// One record: `rec` points at its block_size word, `avail` bytes are the record's (to the next record's start).
+SB_HD void bam_decode_record(const uint8_t *rec, int64_t avail, const sbgpu_bam_opts_t &o, BamRead &out)
+{
+   out.read_id = 0, out.ref = -1, out.left = out.right = out.partner_pos = out.sam_flag = 0;
+   out.nh = 1, out.nm = 0, out.read_len = 0, out.n_blocks = 0, out.flags = 0, out.paired = 0;
+   out.status = SBGPU_BAM_TRUNCATED;
+   if (avail < 36) return;
+   const int32_t block_size = bam_i32(rec);
+   if (block_size < 32 || (int64_t)block_size + 4 > avail) return;
+   const uint8_t *core = rec + 4, *data = rec + 36, *end = rec + 4 + block_size;
+   const int32_t tid = bam_i32(core), pos0 = bam_i32(core + 4);
+   const uint32_t bin_mq_nl = bam_u32(core + 8), flag_nc = bam_u32(core + 12);
+   const int32_t l_qseq = bam_i32(core + 16), mtid = bam_i32(core + 20), mpos0 = bam_i32(core + 24);
+   const int l_qname = (int)(bin_mq_nl & 0xffu), n_cigar = (int)(flag_nc & 0xffffu);
+   const uint32_t flag = flag_nc >> 16;
+   out.sam_flag = flag;
+   if (l_qseq < 0 || 32 + (int64_t)l_qname + 4 * (int64_t)n_cigar + ((int64_t)l_qseq + 1) / 2 + (int64_t)l_qseq > (int64_t)block_size) return;
+   { // :504 ReadTable::get_id
+      uint64_t h = 0xcbf29ce484222325ull;
+      for (int k = 0; k < l_qname && data[k]; ++k) {
+         h *= 1099511628211ull;
+         h ^= (uint64_t)(int64_t)(int8_t)data[k];
+      }
+      out.read_id = h;
+   }
+   if ((flag & 0x4u) || tid < 0) { // :508
+      out.status = SBGPU_BAM_UNMAPPED;
+      return;
+   }
+   if (o.n_ref > 0 && tid >= o.n_ref) { // :531
+      out.status = SBGPU_BAM_BAD_REF;
+      return;
+   }
+   // :536-599 the CIGAR.  The reference first walks every operation (length, kind, intron limits), then tests the kept
+   // list for misplaced insertions / deletions: one walk here, the first complaint of the first kind wins over the second.
+   const uint8_t *cig = data + l_qname;
+   int64_t rlen = 0, eff = 0;
+   int32_t qlen = 0, blocks = 0;
+   int kept = 0, prev = -1;       // kept operations so far; the kind of the last one
+   bool indel_open = false, indel_bad = false;
+   int walk = SBGPU_BAM_OK;
+   for (int i = 0; i < n_cigar; ++i) {
+      const uint32_t w = bam_u32(cig + 4 * i);
+      const int32_t length = (int32_t)(w >> 4);
+      if (length <= 0) {
+         walk = SBGPU_BAM_ZERO_OP;
+         break;
+      }
+      const int op = (int)(w & 0xfu);
+      if (op == 5 || op == 6) continue; // H, P: not kept
+      if (op > 6) {
+         walk = SBGPU_BAM_OP;
+         break;
+      }
+      if (indel_open) { // the operation behind an I / D must be an M
+         indel_bad |= op != 0;
+         indel_open = false;
+      }
+      if (op == 0) {
+         rlen += length, eff += length, qlen += length, ++blocks;
+      } else if (op == 1 || op == 2) {
+         indel_bad |= (kept - 1 <= 0) | (prev != 0); // `i-1 <= 0`: among the first two kept operations (:594)
+         indel_open = true;
+         if (op == 1) qlen += length;
+         else rlen += length;
+      } else if (op == 4) {
+         qlen += length;
+      } else { // N
+         rlen += length;
+         if (length > o.max_intron) walk = SBGPU_BAM_INTRON_LONG;
+         else if (length < o.min_intron) walk = SBGPU_BAM_INTRON_SHORT;
+         if (walk != SBGPU_BAM_OK) break;
+      }
+      prev = op;
+      ++kept;
+   }
+   if (walk != SBGPU_BAM_OK) {
+      out.status = (uint8_t)walk;
+      return;
+   }
+   if (indel_bad || indel_open) { // (open at the end: no operation behind it, :594)
+      out.status = SBGPU_BAM_INDEL;
+      return;
+   }
+   if (eff <= 1) { // :601
+      out.status = SBGPU_BAM_SHORT;
+      return;
+   }
+   out.paired = (flag & 0x1u) ? 1 : 0; // :605-607 (SINGLE_END_EXP = false), whatever the tests below say
+   // the tags: XS (:619-634), NM (:653-656), NH (:658-661); the first of each, found by ONE scan of the list
+   int sd = 0;
+   {
+      const uint8_t *s = data + l_qname + 4 * (int64_t)n_cigar + l_qseq + (l_qseq + 1) / 2;
+      bool got_xs = false, got_nm = false, got_nh = false;
+      while (s + 1 < end && !(got_xs && got_nm && got_nh)) {
+         const int x = ((int)s[0] << 8) | s[1];
+         s += 2;
+         if (s >= end) break;
+         if (x == (('X' << 8) | 'S') && !got_xs) {
+            got_xs = true;
+            if (s + 1 < end && s[0] == 'A') sd = s[1] == '+' ? 1 : (s[1] == '-' ? 2 : 0);
+         } else if (x == (('N' << 8) | 'M') && !got_nm) {
+            got_nm = true;
+            out.nm = (int32_t)(uint8_t)bam_aux_int(s, end); // through an unsigned char (:617)
+         } else if (x == (('N' << 8) | 'H') && !got_nh) {
+            got_nh = true;
+            out.nh = bam_aux_int(s, end);
+         }
+         int type = *s++;
+         if (type >= 'a' && type <= 'z') type -= 32; // toupper (__skip_tag)
+         if (type == 'Z' || type == 'H') {
+            while (s < end && *s) ++s;
+            ++s;
+         } else if (type == 'B') {
+            if (s + 5 > end) break;
+            const int64_t count = bam_i32(s + 1);
+            if (count < 0) break;
+            s += 5 + (int64_t)bam_aux_size(*s) * count;
+         } else {
+            s += bam_aux_size(type);
+         }
+      }
+   }
+   const bool rev = (flag & 0x10u) != 0, fr = o.library == 1, rf = o.library == 2;
+   if (sd == 0 && (fr || rf)) { // :636-651
+      const bool toward = (rf && rev) || (fr && !rev);
+      sd = (flag & 0x40u) ? (toward ? 1 : 2) : (toward ? 2 : 1);
+   }
+   if (o.unique_only && (out.nh > 1 || (flag & 0x100u))) { // :670
+      out.status = SBGPU_BAM_MULTI;
+      return;
+   }
+   const uint32_t pos = (uint32_t)pos0 + 1u;
+   out.status = SBGPU_BAM_OK;
+   out.ref = tid;
+   out.left = pos;
+   out.right = pos + (uint32_t)rlen - 1u;
+   out.partner_pos = (uint32_t)mpos0 + 1u;
+   out.flags = (uint8_t)((rev ? SBGPU_READ_REVERSE : 0u) | (mtid != tid ? SBGPU_READ_PARTNER_ELSEWHERE : 0u) | ((uint32_t)sd << 2));
+   out.read_len = qlen;
+   out.n_blocks = blocks;
+}
+
+// The aligned blocks of an ACCEPTED record (readhit_2_genomicFeats' MATCH features, src/contig.cpp:12-53): every M
+// starts a block at the running offset, a D extends the block in front of it, N and D move the offset, I / S / H / P do not.
+SB_HD void bam_record_blocks(const uint8_t *rec, uint32_t *block_left, uint32_t *block_right)
+{
+   const uint8_t *core = rec + 4, *data = rec + 36;
+   const int l_qname = (int)(bam_u32(core + 8) & 0xffu), n_cigar = (int)(bam_u32(core + 12) & 0xffffu);
+   const uint8_t *cig = data + l_qname;
+   uint32_t offset = (uint32_t)bam_i32(core + 4) + 1u;
+   int b = -1;
+   for (int i = 0; i < n_cigar; ++i) {
+      const uint32_t w = bam_u32(cig + 4 * i), len = w >> 4;
+      const int op = (int)(w & 0xfu);
+      if (op == 0) {
+         ++b;
+         block_left[b] = offset;
+         block_right[b] = offset + len - 1u;
+         offset += len;
+      } else if (op == 2) {
+         block_right[b] += len;
+         offset += len;
+      } else if (op == 3) {
+         offset += len;
+      }
+   }
+}
+
+#ifdef __HIPCC__
+struct BamScanArgs {
+   const uint8_t *bytes;
+   const int64_t *rec_off; // [n + 1]
+   int64_t n;
+   sbgpu_bam_opts_t opts;
+   // per record
+   uint8_t *status;
+   int32_t *n_blocks; // 0 for a refused record
+   uint8_t *accepted; // 0 / 1
+   uint64_t *read_id;
+   int32_t *ref, *nh, *nm, *read_len;
+   uint32_t *left, *right, *partner_pos, *sam_flag;
+   uint8_t *flags;
+   unsigned long long *counts; // [16]: 0-10 by status, 11: accepted records with the paired flag... see bamdecode_api.hip
+};
+
+__global__ __launch_bounds__(256) void bam_scan_kernel(BamScanArgs a)
+{
+   __shared__ unsigned int cnt[16];
+   if (threadIdx.x < 16) cnt[threadIdx.x] = 0;
+   __syncthreads();
+   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+   for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.n; r += stride) {
+      const int64_t o0 = a.rec_off[r], o1 = a.rec_off[r + 1];
+      BamRead x;
+      bam_decode_record(a.bytes + o0, o1 - o0, a.opts, x);
+      a.status[r] = x.status;
+      a.accepted[r] = x.status == SBGPU_BAM_OK;
+      a.n_blocks[r] = x.status == SBGPU_BAM_OK ? x.n_blocks : 0;
+      a.read_id[r] = x.read_id;
+      a.ref[r] = x.ref, a.nh[r] = x.nh, a.nm[r] = x.nm, a.read_len[r] = x.read_len;
+      a.left[r] = x.left, a.right[r] = x.right, a.partner_pos[r] = x.partner_pos, a.sam_flag[r] = x.sam_flag;
+      a.flags[r] = x.flags;
+      atomicAdd(&cnt[x.status < 11 ? x.status : 10], 1u);
+      if (x.paired) atomicAdd(&cnt[11], 1u);
+   }
+   __syncthreads();
+   if (threadIdx.x < 16 && cnt[threadIdx.x]) atomicAdd(&a.counts[threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
+}
+
+struct BamFillArgs {
+   const uint8_t *bytes;
+   const int64_t *rec_off;
+   int64_t n;
+   const uint8_t *accepted;
+   const int64_t *read_at;  // [n + 1] exclusive scan of accepted
+   const int64_t *block_at; // [n + 1] exclusive scan of n_blocks
+   // per record (the scan's)
+   const uint64_t *read_id;
+   const int32_t *ref, *nh, *nm, *read_len;
+   const uint32_t *left, *right, *partner_pos, *sam_flag;
+   const uint8_t *flags;
+   // per accepted record
+   int64_t *o_record;
+   uint64_t *o_read_id;
+   int32_t *o_ref, *o_nh, *o_nm, *o_read_len;
+   uint32_t *o_left, *o_right, *o_partner_pos, *o_sam_flag;
+   uint8_t *o_flags;
+   int64_t *o_block_off; // [accepted + 1]
+   uint32_t *o_block_left, *o_block_right;
+};
+
+__global__ __launch_bounds__(256) void bam_fill_kernel(BamFillArgs a)
+{
+   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+   for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.n; r += stride) {
+      if (r == a.n - 1) a.o_block_off[a.read_at[a.n]] = a.block_at[a.n];
+      if (!a.accepted[r]) continue;
+      const int64_t k = a.read_at[r], b = a.block_at[r];
+      a.o_record[k] = r;
+      a.o_read_id[k] = a.read_id[r];
+      a.o_ref[k] = a.ref[r], a.o_nh[k] = a.nh[r], a.o_nm[k] = a.nm[r], a.o_read_len[k] = a.read_len[r];
+      a.o_left[k] = a.left[r], a.o_right[k] = a.right[r], a.o_partner_pos[k] = a.partner_pos[r], a.o_sam_flag[k] = a.sam_flag[r];
+      a.o_flags[k] = a.flags[r];
+      a.o_block_off[k] = b;
+      bam_record_blocks(a.bytes + a.rec_off[r], a.o_block_left + b, a.o_block_right + b);
+   }
+}
+#endif
+
+} // namespace sb

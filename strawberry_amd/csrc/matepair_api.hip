@@ -197,9 +197,10 @@ int sbgpu_pair_mates_host(int64_t n_loci, const sbgpu_reads_t *rd, const int64_t
       M->right_off.push_back(0);
       auto left_of = [&](int64_t r) { return rd->block_left[rd->block_off[r]]; };
       auto push_mate = [&](int64_t r, std::vector<uint8_t> &c, std::vector<uint32_t> &l, std::vector<uint32_t> &rr) {
-         // readhit_2_genomicFeats, src/contig.cpp:12-53: the blocks with the introns between them
+         // readhit_2_genomicFeats, src/contig.cpp:12-53: the blocks with the introns between them (none between blocks
+         // that touch: an insertion in the read)
          for (int64_t b = rd->block_off[r]; b < rd->block_off[r + 1]; ++b) {
-            if (b > rd->block_off[r]) {
+            if (b > rd->block_off[r] && rd->block_left[b] != rd->block_right[b - 1] + 1u) {
                c.push_back(1);
                l.push_back(rd->block_right[b - 1] + 1);
                rr.push_back(rd->block_left[b] - 1);

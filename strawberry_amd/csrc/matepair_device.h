@@ -54,6 +54,17 @@ struct MateArgs {
    uint32_t *left_left, *left_right, *right_left, *right_right;
 };
 
+// The features a record's aligned blocks make (readhit_2_genomicFeats, src/contig.cpp:12-53): a MATCH per block, an INTRON
+// between two blocks -- none where they touch: an insertion in the read (M I M) leaves two MATCH features side by side
+__device__ __forceinline__ int mate_feature_count(const MateArgs &a, int64_t r)
+{
+   const int64_t b0 = a.block_off[r], b1 = a.block_off[r + 1];
+   if (b1 <= b0) return 0;
+   int n = 1;
+   for (int64_t b = b0 + 1; b < b1; ++b) n += (a.block_left[b] == a.block_right[b - 1] + 1u) ? 1 : 2;
+   return n;
+}
+
 __device__ __forceinline__ bool mate_key_less(unsigned long long ka, int ia, unsigned long long kb, int ib)
 {
    return ka != kb ? ka < kb : ia < ib;
@@ -199,12 +210,11 @@ __device__ __forceinline__ void matepair_one_locus(const MateArgs &a, int64_t l,
       const int8_t f = a.fate[r];
       if (f < kRecCompletesAsRight) continue;
       a.rank[r] = flag[i];
-      const int nb_me = (int)(a.block_off[r + 1] - a.block_off[r]);
-      const int nb_w = a.partner[r] >= 0 ? (int)(a.block_off[q0 + a.partner[r] + 1] - a.block_off[q0 + a.partner[r]]) : 0;
+      const int nf_me = mate_feature_count(a, r);
+      const int nf_w = a.partner[r] >= 0 ? mate_feature_count(a, q0 + a.partner[r]) : 0;
       const bool me_right = f == kRecCompletesAsRight || f == kRecSingleRight;
-      const int nl = me_right ? nb_w : nb_me, nr = me_right ? nb_me : nb_w;
-      lf += nl ? 2 * nl - 1 : 0;
-      rf += nr ? 2 * nr - 1 : 0;
+      lf += me_right ? nf_w : nf_me;
+      rf += me_right ? nf_me : nf_w;
    }
    if (lf) atomicAdd(&counts[4], lf);
    if (rf) atomicAdd(&counts[5], rf);
@@ -273,7 +283,7 @@ __device__ __forceinline__ void write_mate(const MateArgs &a, int64_t r, uint8_t
 {
    const int64_t b0 = a.block_off[r], b1 = a.block_off[r + 1];
    for (int64_t b = b0; b < b1; ++b) {
-      if (b > b0) {
+      if (b > b0 && a.block_left[b] != a.block_right[b - 1] + 1u) { // (touching blocks: an insertion, no intron)
          code[at] = 1;
          left[at] = a.block_right[b - 1] + 1;
          right[at] = a.block_left[b] - 1;
@@ -300,13 +310,12 @@ __device__ __forceinline__ void matepair_fill_one(const MateArgs &a, int64_t l, 
       const int8_t f = a.fate[r];
       if (f < kRecCompletesAsRight) continue;
       const int k = a.rank[r];
-      const int nb_me = (int)(a.block_off[r + 1] - a.block_off[r]);
+      const int nf_me = mate_feature_count(a, r);
       const int64_t w = a.partner[r] >= 0 ? q0 + a.partner[r] : -1;
-      const int nb_w = w >= 0 ? (int)(a.block_off[w + 1] - a.block_off[w]) : 0;
+      const int nf_w = w >= 0 ? mate_feature_count(a, w) : 0;
       const bool me_right = f == kRecCompletesAsRight || f == kRecSingleRight;
-      const int nl = me_right ? nb_w : nb_me, nr = me_right ? nb_me : nb_w;
-      cl[k] = nl ? 2 * nl - 1 : 0;
-      cr[k] = nr ? 2 * nr - 1 : 0;
+      cl[k] = me_right ? nf_w : nf_me;
+      cr[k] = me_right ? nf_me : nf_w;
    }
    __syncthreads();
    block_exclusive_scan<THREADS>(cl, np, partial);

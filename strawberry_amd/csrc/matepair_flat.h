@@ -216,11 +216,10 @@ __global__ __launch_bounds__(256) void flat_mate_count_kernel(FlatMateArgs f)
       const uint32_t v = f.pair_val[k];
       const bool me_right = (v >> 31) != 0;
       const int64_t w = (v & 0x7FFFFFFFu) == 0x7FFFFFFFu ? -1 : (int64_t)(v & 0x7FFFFFFFu);
-      const int nb_me = (int)(a.block_off[r + 1] - a.block_off[r]);
-      const int nb_w = w >= 0 ? (int)(a.block_off[w + 1] - a.block_off[w]) : 0;
-      const int nl = me_right ? nb_w : nb_me, nr = me_right ? nb_me : nb_w;
-      lf = nl ? 2 * nl - 1 : 0;
-      rf = nr ? 2 * nr - 1 : 0;
+      const int nf_me = mate_feature_count(a, r);
+      const int nf_w = w >= 0 ? mate_feature_count(a, w) : 0;
+      lf = me_right ? nf_w : nf_me;
+      rf = me_right ? nf_me : nf_w;
    }
    f.lfeat[k] = lf;
    f.rfeat[k] = rf;
