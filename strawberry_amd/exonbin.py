@@ -66,11 +66,11 @@ class Annotation:
 
 
 def mate_features(blocks):
-    """A mate's aligned blocks [(l, r), ...] -> (code, left, right) with the introns between them
-    (readhit_2_genomicFeats for an M/N CIGAR, src/contig.cpp:12-53)."""
+    """A mate's aligned blocks [(l, r), ...] -> (code, left, right) with the introns between them -- none between two
+    blocks that touch: an insertion in the read (readhit_2_genomicFeats, src/contig.cpp:12-53)."""
     code, left, right = [], [], []
     for k, (a, b) in enumerate(blocks):
-        if k:
+        if k and a != blocks[k - 1][1] + 1:
             code.append(INTRON)
             left.append(blocks[k - 1][1] + 1)
             right.append(a - 1)

@@ -202,3 +202,44 @@ def random_records(rng, n, n_ref=len(REFS)):
         out.append(record(tid, pos, flag, name, cig, mapq=int(rng.integers(0, 61)), mtid=mtid, mpos=mpos,
                           tlen=int(rng.integers(-500, 500)), tags=tags, with_seq=rng.random() < 0.9))
     return out
+
+
+def toy_run_as_bam_records(d, names):
+    """The read pairs of a toy run (reads.npz: what tools/make_e2e_golden.py wrote as SAM for the reference binary) as BAM
+    records in the file's order -> (record bytes, reference names, clusters as sbgpu_assign_reads wants them)."""
+    import os
+    import e2e_util as U
+    z = dict(np.load(os.path.join(d, "reads.npz")))
+    ordered, _, _, _ = U.load(d)
+    genes = list(U.parse_annotation(os.path.join(d, "toy.gtf")))
+    strands, chroms = U.gene_strands(d), U.gene_chroms(d)
+    chrom_names = sorted(set(chroms.values()))
+    chrom_id = {c: i for i, c in enumerate(chrom_names)}
+    recs = []
+    serial = 0
+    for k in range(len(z["gene"])):
+        g = genes[int(z["gene"][k])]
+        tid = chrom_id[chroms[g]]
+        xs = "+" if strands[g] == "+" else "-"
+        left = list(zip(z["left_l"][z["left_off"][k]:z["left_off"][k + 1]].tolist(), z["left_r"][z["left_off"][k]:z["left_off"][k + 1]].tolist()))
+        right = list(zip(z["right_l"][z["right_off"][k]:z["right_off"][k + 1]].tolist(), z["right_r"][z["right_off"][k]:z["right_off"][k + 1]].tolist()))
+
+        def cigar(blocks):
+            out = []
+            for i, (a, b) in enumerate(blocks):
+                if i:
+                    out.append(("N", a - blocks[i - 1][1] - 1))
+                out.append(("M", b - a + 1))
+            return out
+        for nh in z["nh"][z["nh_off"][k]:z["nh_off"][k + 1]]:
+            serial += 1
+            name = "frag%d" % serial
+            tags = [("NH", "C", int(nh)), ("XS", "A", xs)]
+            recs.append((tid, left[0][0], record(tid, left[0][0] - 1, 1 | 2 | 0x20 | 0x40, name, cigar(left), mtid=tid, mpos=right[0][0] - 1, tags=tags)))
+            recs.append((tid, right[0][0], record(tid, right[0][0] - 1, 1 | 2 | 0x10 | 0x80, name, cigar(right), mtid=tid, mpos=left[0][0] - 1, tags=tags)))
+    recs.sort(key=lambda r: (r[0], r[1]))                      # the BAM's order: (reference, position), stable
+    ref_of = [chrom_id[chroms[g]] for g in names]
+    c_left = [min(e[0] for _, ex in ordered[g] for e in ex) for g in names]
+    c_right = [max(e[1] for _, ex in ordered[g] for e in ex) for g in names]
+    c_strand = [1 if strands[g] == "+" else 2 for g in names]
+    return np.frombuffer(b"".join(r[2] for r in recs), np.uint8), chrom_names, (ref_of, c_left, c_right, c_strand)

@@ -140,3 +140,68 @@ def test_indel_position_quirk_and_blocks():
            for k in range(d.n_reads)]
     assert got == want
     np.testing.assert_array_equal(d.right, [b[-1][1] for b in want])
+
+
+def test_touching_blocks_make_no_intron_like_the_reference(reflib):
+    """An insertion leaves two aligned blocks that touch; readhit_2_genomicFeats (src/contig.cpp:12-53) then makes two MATCH
+    features side by side, Contig(PairedHit) keeps them apart when the mates do not overlap and refuses the pair when they do
+    (merge_genomicFeats, include/contig.h:111-137).  The library's feature lists from blocks (host pairing) and its
+    Contig(PairedHit) restatement (sbgpu_hit_features) against the reference's own classes."""
+    from strawberry_amd import exonbin as eb
+    left = [(100, 109), (110, 130), (400, 420)]          # 10M 2I 21M 269N 21M
+    right = [(600, 640), (641, 660)]                      # 41M 1I 20M
+    assert eb.mate_features(left) == ([0, 0, 1, 0], [100, 110, 131, 400], [109, 130, 399, 420])
+    for lb, rb in ((left, right), (left, []), ([], right), (left, [(415, 450), (451, 470)]), (left, [(405, 430)])):
+        want = reflib.pairedhit_features(lb, rb)
+        assert eb.hit_features(lb, rb) == want, (lb, rb)
+    assert reflib.pairedhit_features(left, right)[0] == [0, 0, 1, 0, 2, 0, 0]
+    assert reflib.pairedhit_features(left, [(415, 450), (451, 470)]) is None     # overlapping mates, blocks that only touch
+    # the host pairing writes the mates' features that way
+    reads = eb.Reads([0, 0], [7, 7], [left, right], [600, 100], [1 << 2, 1 | (1 << 2)], [1, 1])
+    got = eb.pair_mates(1, reads)
+    assert got["info"]["complete"] == 1
+    assert [x.tolist() for x in got["left"]] == [list(x) for x in eb.mate_features(left)]
+    assert [x.tolist() for x in got["right"]] == [list(x) for x in eb.mate_features(right)]
+
+
+@pytest.mark.parametrize("which", ["E2E", "E2E_MASS", "E2E_MINUS", "E2E_CHROMS"])
+def test_bam_bytes_to_unique_hits_on_the_host_equal_reference_runs(which):
+    """The read pairs of the reference binary's toy runs as BAM records, in the file's order -> sbgpu_bam_decode_host ->
+    sbgpu_assign_reads_host -> sbgpu_pair_mates_host -> sbgpu_collapse_pairs_host: the unique hits (features, masses) and the
+    mapped-read total of the reference run (tests/test_bamdecode_gpu.py does the same on the device)."""
+    import ctypes as C
+    import e2e_util as U
+    import exonbin_util as XU
+    from strawberry_amd import _lib, bam, exonbin as eb
+    d = getattr(U, which)
+    ordered, rows, _, _ = U.load(d)
+    annot, hits, names, rejected = XU.e2e_inputs(d, ordered)
+    raw, chrom_names, (c_ref, c_left, c_right, c_strand) = B.toy_run_as_bam_records(d, names)
+    dec = bam.decode(raw, None, bam.BamOptions(unique_only=which != "E2E_MASS", n_ref=len(chrom_names)))   # (the mass run: --multiple-hit)
+    assert dec.n_reads == dec.n_records and dec.any_paired
+    got_cluster, off, fl = eb.assign_reads(c_ref, c_left, c_right, c_strand, dec.ref, dec.left, dec.right, dec.flags)
+    L = _lib.load()
+    fl = np.ascontiguousarray(fl, np.uint8)
+    rs = _lib.sbgpu_reads_t(dec.n_reads, dec.read_id.ctypes.data, dec.block_off.ctypes.data, dec.block_left.ctypes.data,
+                            dec.block_right.ctypes.data, dec.partner_pos.ctypes.data, fl.ctypes.data, dec.nh.ctypes.data)
+    mh, uh, dp, poff = C.c_void_p(), C.c_void_p(), _lib.sbgpu_pairs_t(), C.c_void_p()
+    _lib.check(L.sbgpu_pair_mates_host(len(names), C.byref(rs), off.ctypes.data, C.byref(mh)), "sbgpu_pair_mates_host")
+    _lib.check(L.sbgpu_matepairs_pairs(mh, C.byref(dp), C.byref(poff)), "sbgpu_matepairs_pairs")
+    _lib.check(L.sbgpu_collapse_pairs_host(len(names), C.byref(dp), C.byref(uh)), "sbgpu_collapse_pairs_host")
+    info = (C.c_int64 * 8)()
+    _lib.check(L.sbgpu_uniq_info(uh, info), "sbgpu_uniq_info")
+    nh_, nf_ = int(info[0]), int(info[1])
+    hl, fo = np.zeros(nh_, np.int32), np.zeros(nh_ + 1, np.int64)
+    fc, fl_, fr, ms = np.zeros(nf_, np.uint8), np.zeros(nf_, np.uint32), np.zeros(nf_, np.uint32), np.zeros(nh_, np.float32)
+    cm = np.zeros(len(names))
+    _lib.check(L.sbgpu_uniq_export(uh, hl.ctypes.data, fo.ctypes.data, fc.ctypes.data, fl_.ctypes.data, fr.ctypes.data, ms.ctypes.data,
+                                   cm.ctypes.data), "sbgpu_uniq_export")
+    L.sbgpu_uniq_destroy(uh)
+    L.sbgpu_matepairs_destroy(mh)
+    np.testing.assert_array_equal(hl, hits.hit_locus)
+    np.testing.assert_array_equal(fo, hits.feat_off)
+    np.testing.assert_array_equal(fc, hits.feat_code)
+    np.testing.assert_array_equal(fl_, hits.feat_left)
+    np.testing.assert_array_equal(fr, hits.feat_right)
+    np.testing.assert_array_equal(ms, hits.mass)
+    assert int(info[4]) == rows[0]["total_mapped"] == hits.total_mapped
