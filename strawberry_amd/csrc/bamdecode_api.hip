@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -200,7 +201,7 @@ int sbgpu_bam_decode_device(sbgpu_ctx_t *c, const uint8_t *d_bytes, int64_t n_by
    };
    const size_t o_status = take(nn), o_acc = take(n1), o_nb = take(n1 * 4), o_rid = take(nn * 8), o_ref = take(nn * 4), o_nh = take(nn * 4),
                 o_nm = take(nn * 4), o_rl = take(nn * 4), o_left = take(nn * 4), o_right = take(nn * 4), o_pp = take(nn * 4), o_sf = take(nn * 4),
-                o_fl = take(nn), o_rat = take(n1 * 8), o_bat = take(n1 * 8), o_cnt = take(16 * 8), o_tmp = take(tmp_bytes);
+                o_fl = take(nn), o_ib = take(nn * 4 * 2 * sb::kBamInlineBlocks), o_rat = take(n1 * 8), o_bat = take(n1 * 8), o_cnt = take(16 * 8), o_tmp = take(tmp_bytes);
    SB_TRY(sb::dev_take(off, &w, &w_cap));
    SB_TRY(hipMemsetAsync(w + o_cnt, 0, 16 * 8, s));
    SB_TRY(hipMemsetAsync(w + o_acc + nn, 0, 1, s));
@@ -211,9 +212,17 @@ int sbgpu_bam_decode_device(sbgpu_ctx_t *c, const uint8_t *d_bytes, int64_t n_by
    a.read_id = (uint64_t *)(w + o_rid), a.ref = (int32_t *)(w + o_ref), a.nh = (int32_t *)(w + o_nh), a.nm = (int32_t *)(w + o_nm);
    a.read_len = (int32_t *)(w + o_rl), a.left = (uint32_t *)(w + o_left), a.right = (uint32_t *)(w + o_right);
    a.partner_pos = (uint32_t *)(w + o_pp), a.sam_flag = (uint32_t *)(w + o_sf), a.flags = (uint8_t *)(w + o_fl);
+   a.inline_blocks = (uint32_t *)(w + o_ib);
    a.counts = (unsigned long long *)(w + o_cnt);
    const int64_t cap = (int64_t)sb::ctx_cu_count(c) * 32, blocks = std::min<int64_t>((n + 255) / 256, cap);
-   hipLaunchKernelGGL(sb::bam_scan_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+   // the staging buffer of a workgroup (one wave, 64 records): 1.1 x 64 average records, 8-64 KB (SBGPU_BAM_STAGE_KB overrides)
+   static const int stage_kb_env = std::getenv("SBGPU_BAM_STAGE_KB") ? std::atoi(std::getenv("SBGPU_BAM_STAGE_KB")) : 0;
+   int stage_bytes = 8 * 1024;
+   while (stage_bytes < 64 * 1024 && (int64_t)stage_bytes < 70 * (n_bytes / n + 1)) stage_bytes += 2 * 1024;
+   if (stage_kb_env > 0) stage_bytes = std::min(64, std::max(1, stage_kb_env)) * 1024;
+   const int resident = std::max(1, std::min(16, (int)(160 * 1024 / (stage_bytes + 256))));
+   const int64_t scan_blocks = std::min<int64_t>((n + 63) / 64, (int64_t)sb::ctx_cu_count(c) * resident * 4);
+   hipLaunchKernelGGL(sb::bam_scan_kernel, dim3((unsigned)scan_blocks), dim3(64), (size_t)stage_bytes, s, a, stage_bytes);
    SB_TRY(hipGetLastError());
    size_t tb = tmp_bytes;
    SB_TRY(rocprim::exclusive_scan(w + o_tmp, tb, rocprim::make_transform_iterator((const uint8_t *)a.accepted, as_i64_u8), (int64_t *)(w + o_rat), (int64_t)0, n1, rocprim::plus<int64_t>(), s));
@@ -237,6 +246,7 @@ int sbgpu_bam_decode_device(sbgpu_ctx_t *c, const uint8_t *d_bytes, int64_t n_by
    f.accepted = a.accepted, f.read_at = (const int64_t *)(w + o_rat), f.block_at = (const int64_t *)(w + o_bat);
    f.read_id = a.read_id, f.ref = a.ref, f.nh = a.nh, f.nm = a.nm, f.read_len = a.read_len;
    f.left = a.left, f.right = a.right, f.partner_pos = a.partner_pos, f.sam_flag = a.sam_flag, f.flags = a.flags;
+   f.n_blocks = a.n_blocks, f.inline_blocks = a.inline_blocks;
    f.o_record = B->record, f.o_read_id = B->read_id, f.o_ref = B->ref, f.o_nh = B->nh, f.o_nm = B->nm, f.o_read_len = B->read_len;
    f.o_left = B->left, f.o_right = B->right, f.o_partner_pos = B->partner_pos, f.o_sam_flag = B->sam_flag, f.o_flags = B->flags;
    f.o_block_off = B->block_off, f.o_block_left = B->block_left, f.o_block_right = B->block_right;

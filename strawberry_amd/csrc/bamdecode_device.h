@@ -35,11 +35,13 @@
 
 namespace sb {
 
+constexpr int kBamInlineBlocks = 3; // a record's first aligned blocks travel with its scalars (more: the CIGAR is walked again)
 struct BamRead {
    uint64_t read_id;
    int32_t ref;
    uint32_t left, right, partner_pos, sam_flag;
    int32_t nh, nm, read_len, n_blocks;
+   uint32_t bl[kBamInlineBlocks], br[kBamInlineBlocks];
    uint8_t status, flags, paired;
 };
 
@@ -52,39 +54,68 @@ SB_HD int bam_aux_size(int x) // bam_aux_type2size, samtools-0.1.19/bam.h:772-77
    if (x == 'I' || x == 'i' || x == 'f' || x == 'F') return 4;
    return 0;
 }
-SB_HD int32_t bam_aux_int(const uint8_t *s, const uint8_t *end) // bam_aux2i on the tag's type byte
+
+// How the decoder reads the record's bytes.  ByteLoads: a load per byte (host, and records walked in global memory).
+// ByteWindow: the aligned 8 bytes around the last byte asked for stay in registers -- the decoder walks names, CIGARs and
+// tags front to back, so seven of eight bytes come from the registers instead of a dependent load each (a lane's walk
+// is one long chain of dependent reads: ~100 of them per record at a load's latency each was 90 % of the kernel).  The
+// window reaches up to 7 bytes beyond either end of the record: only for records inside the kernel's staging buffer.
+struct ByteLoads {
+   SB_HD uint32_t u8(const uint8_t *p) { return *p; }
+};
+struct ByteWindow {
+   const uint8_t *base = nullptr;
+   uint64_t w = 0;
+   SB_HD uint32_t u8(const uint8_t *p)
+   {
+      const uintptr_t q = (uintptr_t)p;
+      const uint8_t *b = (const uint8_t *)(q & ~(uintptr_t)7);
+      if (b != base) {
+         base = b;
+         w = *reinterpret_cast<const uint64_t *>(b);
+      }
+      return (uint32_t)(w >> (8u * (unsigned)(q & 7u))) & 0xffu;
+   }
+};
+template <class RD>
+SB_HD uint32_t rd_u32(RD &rd, const uint8_t *p) { return rd.u8(p) | (rd.u8(p + 1) << 8) | (rd.u8(p + 2) << 16) | (rd.u8(p + 3) << 24); }
+template <class RD>
+SB_HD int32_t rd_aux_int(RD &rd, const uint8_t *s, const uint8_t *end) // bam_aux2i on the tag's type byte
 {
-   const int type = *s++;
-   if (type == 'c') return s + 1 <= end ? (int32_t)(int8_t)s[0] : 0;
-   if (type == 'C') return s + 1 <= end ? (int32_t)s[0] : 0;
-   if (type == 's') return s + 2 <= end ? (int32_t)(int16_t)((uint16_t)s[0] | ((uint16_t)s[1] << 8)) : 0;
-   if (type == 'S') return s + 2 <= end ? (int32_t)((uint16_t)s[0] | ((uint16_t)s[1] << 8)) : 0;
-   if (type == 'i' || type == 'I') return s + 4 <= end ? bam_i32(s) : 0;
+   const int type = (int)rd.u8(s++);
+   if (type == 'c') return s + 1 <= end ? (int32_t)(int8_t)rd.u8(s) : 0;
+   if (type == 'C') return s + 1 <= end ? (int32_t)rd.u8(s) : 0;
+   if (type == 's') return s + 2 <= end ? (int32_t)(int16_t)(uint16_t)(rd.u8(s) | (rd.u8(s + 1) << 8)) : 0;
+   if (type == 'S') return s + 2 <= end ? (int32_t)(rd.u8(s) | (rd.u8(s + 1) << 8)) : 0;
+   if (type == 'i' || type == 'I') return s + 4 <= end ? (int32_t)rd_u32(rd, s) : 0;
    return 0;
 }
 
 // One record: `rec` points at its block_size word, `avail` bytes are the record's (to the next record's start).
-SB_HD void bam_decode_record(const uint8_t *rec, int64_t avail, const sbgpu_bam_opts_t &o, BamRead &out)
+template <class RD>
+SB_HD void bam_decode_record(RD &rd, const uint8_t *rec, int64_t avail, const sbgpu_bam_opts_t &o, BamRead &out)
 {
    out.read_id = 0, out.ref = -1, out.left = out.right = out.partner_pos = out.sam_flag = 0;
    out.nh = 1, out.nm = 0, out.read_len = 0, out.n_blocks = 0, out.flags = 0, out.paired = 0;
    out.status = SBGPU_BAM_TRUNCATED;
    if (avail < 36) return;
-   const int32_t block_size = bam_i32(rec);
+   const int32_t block_size = (int32_t)rd_u32(rd, rec);
    if (block_size < 32 || (int64_t)block_size + 4 > avail) return;
    const uint8_t *core = rec + 4, *data = rec + 36, *end = rec + 4 + block_size;
-   const int32_t tid = bam_i32(core), pos0 = bam_i32(core + 4);
-   const uint32_t bin_mq_nl = bam_u32(core + 8), flag_nc = bam_u32(core + 12);
-   const int32_t l_qseq = bam_i32(core + 16), mtid = bam_i32(core + 20), mpos0 = bam_i32(core + 24);
+   const int32_t tid = (int32_t)rd_u32(rd, core), pos0 = (int32_t)rd_u32(rd, core + 4);
+   const uint32_t bin_mq_nl = rd_u32(rd, core + 8), flag_nc = rd_u32(rd, core + 12);
+   const int32_t l_qseq = (int32_t)rd_u32(rd, core + 16), mtid = (int32_t)rd_u32(rd, core + 20), mpos0 = (int32_t)rd_u32(rd, core + 24);
    const int l_qname = (int)(bin_mq_nl & 0xffu), n_cigar = (int)(flag_nc & 0xffffu);
    const uint32_t flag = flag_nc >> 16;
    out.sam_flag = flag;
    if (l_qseq < 0 || 32 + (int64_t)l_qname + 4 * (int64_t)n_cigar + ((int64_t)l_qseq + 1) / 2 + (int64_t)l_qseq > (int64_t)block_size) return;
    { // :504 ReadTable::get_id
       uint64_t h = 0xcbf29ce484222325ull;
-      for (int k = 0; k < l_qname && data[k]; ++k) {
+      for (int k = 0; k < l_qname; ++k) {
+         const uint32_t c = rd.u8(data + k);
+         if (!c) break;
          h *= 1099511628211ull;
-         h ^= (uint64_t)(int64_t)(int8_t)data[k];
+         h ^= (uint64_t)(int64_t)(int8_t)c;
       }
       out.read_id = h;
    }
@@ -102,10 +133,13 @@ SB_HD void bam_decode_record(const uint8_t *rec, int64_t avail, const sbgpu_bam_
    int64_t rlen = 0, eff = 0;
    int32_t qlen = 0, blocks = 0;
    int kept = 0, prev = -1;       // kept operations so far; the kind of the last one
+   const uint32_t pos = (uint32_t)pos0 + 1u;
+#pragma unroll
+   for (int k = 0; k < kBamInlineBlocks; ++k) out.bl[k] = out.br[k] = 0u;
    bool indel_open = false, indel_bad = false;
    int walk = SBGPU_BAM_OK;
    for (int i = 0; i < n_cigar; ++i) {
-      const uint32_t w = bam_u32(cig + 4 * i);
+      const uint32_t w = rd_u32(rd, cig + 4 * i);
       const int32_t length = (int32_t)(w >> 4);
       if (length <= 0) {
          walk = SBGPU_BAM_ZERO_OP;
@@ -122,12 +156,22 @@ SB_HD void bam_decode_record(const uint8_t *rec, int64_t avail, const sbgpu_bam_
          indel_open = false;
       }
       if (op == 0) {
+         // a block [offset, offset + length - 1] (readhit_2_genomicFeats); the first few are kept here (static indices: registers)
+#pragma unroll
+         for (int k = 0; k < kBamInlineBlocks; ++k)
+            if (blocks == k) out.bl[k] = pos + (uint32_t)rlen, out.br[k] = pos + (uint32_t)rlen + (uint32_t)length - 1u;
          rlen += length, eff += length, qlen += length, ++blocks;
       } else if (op == 1 || op == 2) {
          indel_bad |= (kept - 1 <= 0) | (prev != 0); // `i-1 <= 0`: among the first two kept operations (:594)
          indel_open = true;
-         if (op == 1) qlen += length;
-         else rlen += length;
+         if (op == 1) {
+            qlen += length;
+         } else { // a deletion extends the block in front of it
+#pragma unroll
+            for (int k = 0; k < kBamInlineBlocks; ++k)
+               if (blocks == k + 1) out.br[k] += (uint32_t)length;
+            rlen += length;
+         }
       } else if (op == 4) {
          qlen += length;
       } else { // N
@@ -158,29 +202,32 @@ SB_HD void bam_decode_record(const uint8_t *rec, int64_t avail, const sbgpu_bam_
       const uint8_t *s = data + l_qname + 4 * (int64_t)n_cigar + l_qseq + (l_qseq + 1) / 2;
       bool got_xs = false, got_nm = false, got_nh = false;
       while (s + 1 < end && !(got_xs && got_nm && got_nh)) {
-         const int x = ((int)s[0] << 8) | s[1];
+         const int x = (int)((rd.u8(s) << 8) | rd.u8(s + 1));
          s += 2;
          if (s >= end) break;
          if (x == (('X' << 8) | 'S') && !got_xs) {
             got_xs = true;
-            if (s + 1 < end && s[0] == 'A') sd = s[1] == '+' ? 1 : (s[1] == '-' ? 2 : 0);
+            if (s + 1 < end && rd.u8(s) == 'A') {
+               const uint32_t v = rd.u8(s + 1);
+               sd = v == '+' ? 1 : (v == '-' ? 2 : 0);
+            }
          } else if (x == (('N' << 8) | 'M') && !got_nm) {
             got_nm = true;
-            out.nm = (int32_t)(uint8_t)bam_aux_int(s, end); // through an unsigned char (:617)
+            out.nm = (int32_t)(uint8_t)rd_aux_int(rd, s, end); // through an unsigned char (:617)
          } else if (x == (('N' << 8) | 'H') && !got_nh) {
             got_nh = true;
-            out.nh = bam_aux_int(s, end);
+            out.nh = rd_aux_int(rd, s, end);
          }
-         int type = *s++;
+         int type = (int)rd.u8(s++);
          if (type >= 'a' && type <= 'z') type -= 32; // toupper (__skip_tag)
          if (type == 'Z' || type == 'H') {
-            while (s < end && *s) ++s;
+            while (s < end && rd.u8(s)) ++s;
             ++s;
          } else if (type == 'B') {
             if (s + 5 > end) break;
-            const int64_t count = bam_i32(s + 1);
+            const int64_t count = (int32_t)rd_u32(rd, s + 1);
             if (count < 0) break;
-            s += 5 + (int64_t)bam_aux_size(*s) * count;
+            s += 5 + (int64_t)bam_aux_size((int)rd.u8(s)) * count;
          } else {
             s += bam_aux_size(type);
          }
@@ -195,7 +242,6 @@ SB_HD void bam_decode_record(const uint8_t *rec, int64_t avail, const sbgpu_bam_
       out.status = SBGPU_BAM_MULTI;
       return;
    }
-   const uint32_t pos = (uint32_t)pos0 + 1u;
    out.status = SBGPU_BAM_OK;
    out.ref = tid;
    out.left = pos;
@@ -204,6 +250,11 @@ SB_HD void bam_decode_record(const uint8_t *rec, int64_t avail, const sbgpu_bam_
    out.flags = (uint8_t)((rev ? SBGPU_READ_REVERSE : 0u) | (mtid != tid ? SBGPU_READ_PARTNER_ELSEWHERE : 0u) | ((uint32_t)sd << 2));
    out.read_len = qlen;
    out.n_blocks = blocks;
+}
+SB_HD void bam_decode_record(const uint8_t *rec, int64_t avail, const sbgpu_bam_opts_t &o, BamRead &out)
+{
+   ByteLoads rd;
+   bam_decode_record(rd, rec, avail, o, out);
 }
 
 // The aligned blocks of an ACCEPTED record (readhit_2_genomicFeats' MATCH features, src/contig.cpp:12-53): every M
@@ -246,31 +297,81 @@ struct BamScanArgs {
    int32_t *ref, *nh, *nm, *read_len;
    uint32_t *left, *right, *partner_pos, *sam_flag;
    uint8_t *flags;
-   unsigned long long *counts; // [16]: 0-10 by status, 11: accepted records with the paired flag... see bamdecode_api.hip
+   uint32_t *inline_blocks; // [n][2 * kBamInlineBlocks]: left ends, right ends of the record's first blocks
+   unsigned long long *counts; // [16]: 0-10 by status, 11: records with the paired flag that got as far as :605
 };
 
-__global__ __launch_bounds__(256) void bam_scan_kernel(BamScanArgs a)
+// One wave per workgroup, 64 records per pass.  A lane that walks its record straight from global memory touches two or
+// three cache lines of its own per record, byte by byte: with every lane of every wave doing so the vector L1 holds nothing
+// and every byte load becomes an L2 request -- 10 GB of them for a 0.9 GB stream (1.1 ms per 4 * 10^6 records, 0.8 TB/s).
+// The 64 records of a wave are CONTIGUOUS in the stream, so the wave copies their whole range into LDS with 16-byte loads,
+// eight in flight per lane (every cache line of the stream is read once, by one instruction), and the lanes walk their
+// records there through ByteWindow.  The buffer's size comes with the launch (dynamic LDS: ~1.1 x 64 average records, so
+// that several workgroups fit a CU); a range beyond it (long reads) is walked in global memory as before.
+__global__ __launch_bounds__(64) void bam_scan_kernel(BamScanArgs a, int stage_bytes)
 {
+   extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
    __shared__ unsigned int cnt[16];
-   if (threadIdx.x < 16) cnt[threadIdx.x] = 0;
+   const int lane = threadIdx.x;
+   if (lane < 16) cnt[lane] = 0;
    __syncthreads();
-   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-   for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.n; r += stride) {
-      const int64_t o0 = a.rec_off[r], o1 = a.rec_off[r + 1];
-      BamRead x;
-      bam_decode_record(a.bytes + o0, o1 - o0, a.opts, x);
-      a.status[r] = x.status;
-      a.accepted[r] = x.status == SBGPU_BAM_OK;
-      a.n_blocks[r] = x.status == SBGPU_BAM_OK ? x.n_blocks : 0;
-      a.read_id[r] = x.read_id;
-      a.ref[r] = x.ref, a.nh[r] = x.nh, a.nm[r] = x.nm, a.read_len[r] = x.read_len;
-      a.left[r] = x.left, a.right[r] = x.right, a.partner_pos[r] = x.partner_pos, a.sam_flag[r] = x.sam_flag;
-      a.flags[r] = x.flags;
-      atomicAdd(&cnt[x.status < 11 ? x.status : 10], 1u);
-      if (x.paired) atomicAdd(&cnt[11], 1u);
+   const int64_t n_tiles = (a.n + 63) >> 6;
+   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+      const int64_t r0 = tile << 6, r1 = r0 + 64 < a.n ? r0 + 64 : a.n;
+      const int64_t s0 = a.rec_off[r0], s1 = a.rec_off[r1];
+      const uint8_t *g = a.bytes + s0;
+      const int shift = (int)((uintptr_t)g & 15u);
+      const bool staged = s1 - s0 <= (int64_t)stage_bytes - 16;
+      if (staged) {
+         const int len = (int)(s1 - s0);
+         const int head = min((16 - shift) & 15, len), nbody = (len - head) >> 4, tail = len - head - (nbody << 4);
+         if (lane < head) stage[shift + lane] = g[lane];
+         const uint4 *src = reinterpret_cast<const uint4 *>(g + head);
+         uint4 *dst = reinterpret_cast<uint4 *>(stage + shift + head);
+         for (int c0 = 0; c0 < nbody; c0 += 8 * 64) {
+            uint4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+               const int c = c0 + k * 64 + lane;
+               v[k] = c < nbody ? src[c] : uint4{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+               const int c = c0 + k * 64 + lane;
+               if (c < nbody) dst[c] = v[k];
+            }
+         }
+         if (lane < tail) stage[shift + head + (nbody << 4) + lane] = g[head + (nbody << 4) + lane];
+      }
+      __syncthreads();
+      const int64_t r = r0 + lane;
+      if (r < r1) {
+         const int64_t o0 = a.rec_off[r], o1 = a.rec_off[r + 1];
+         BamRead x;
+         if (staged) {
+            ByteWindow rd;
+            bam_decode_record(rd, stage + shift + (o0 - s0), o1 - o0, a.opts, x);
+         } else {
+            bam_decode_record(a.bytes + o0, o1 - o0, a.opts, x);
+         }
+         a.status[r] = x.status;
+         a.accepted[r] = x.status == SBGPU_BAM_OK;
+         a.n_blocks[r] = x.status == SBGPU_BAM_OK ? x.n_blocks : 0;
+         a.read_id[r] = x.read_id;
+         a.ref[r] = x.ref, a.nh[r] = x.nh, a.nm[r] = x.nm, a.read_len[r] = x.read_len;
+         a.left[r] = x.left, a.right[r] = x.right, a.partner_pos[r] = x.partner_pos, a.sam_flag[r] = x.sam_flag;
+         a.flags[r] = x.flags;
+         if (x.status == SBGPU_BAM_OK) {
+            uint32_t *ib = a.inline_blocks + r * (2 * kBamInlineBlocks);
+#pragma unroll
+            for (int k = 0; k < kBamInlineBlocks; ++k) ib[k] = x.bl[k], ib[kBamInlineBlocks + k] = x.br[k];
+         }
+         atomicAdd(&cnt[x.status < 11 ? x.status : 10], 1u);
+         if (x.paired) atomicAdd(&cnt[11], 1u);
+      }
+      __syncthreads(); // (the next pass overwrites the buffer)
    }
-   __syncthreads();
-   if (threadIdx.x < 16 && cnt[threadIdx.x]) atomicAdd(&a.counts[threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
+   if (lane < 16 && cnt[lane]) atomicAdd(&a.counts[lane], (unsigned long long)cnt[lane]);
 }
 
 struct BamFillArgs {
@@ -285,6 +386,8 @@ struct BamFillArgs {
    const int32_t *ref, *nh, *nm, *read_len;
    const uint32_t *left, *right, *partner_pos, *sam_flag;
    const uint8_t *flags;
+   const int32_t *n_blocks;
+   const uint32_t *inline_blocks;
    // per accepted record
    int64_t *o_record;
    uint64_t *o_read_id;
@@ -308,7 +411,13 @@ __global__ __launch_bounds__(256) void bam_fill_kernel(BamFillArgs a)
       a.o_left[k] = a.left[r], a.o_right[k] = a.right[r], a.o_partner_pos[k] = a.partner_pos[r], a.o_sam_flag[k] = a.sam_flag[r];
       a.o_flags[k] = a.flags[r];
       a.o_block_off[k] = b;
-      bam_record_blocks(a.bytes + a.rec_off[r], a.o_block_left + b, a.o_block_right + b);
+      const int nb = a.n_blocks[r];
+      if (nb <= kBamInlineBlocks) { // (nearly every record: nothing of the stream is read again)
+         const uint32_t *ib = a.inline_blocks + r * (2 * kBamInlineBlocks);
+         for (int q = 0; q < nb; ++q) a.o_block_left[b + q] = ib[q], a.o_block_right[b + q] = ib[kBamInlineBlocks + q];
+      } else {
+         bam_record_blocks(a.bytes + a.rec_off[r], a.o_block_left + b, a.o_block_right + b);
+      }
    }
 }
 #endif
