@@ -102,6 +102,10 @@ for f in $(find $OUT/stats_frontend -name "*kernel_stats.csv"); do cp $f $SUM/${
 # loci of 65-128 segments: the 128-bit segment basis against the exon walk (kernel rows of two profiled runs)
 (cd /tmp; for z in 1 0; do SBGPU_EXONBIN_SEGBASIS=$z timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_ebbig_$z -o eb -- python3 $REPO/tools/bench_exonbin_big.py > $OUT/stats_ebbig_$z.log 2>&1; done)
 (echo "# 1500 loci of ~98 segments, 4.5 M hits (tools/bench_exonbin_big.py under rocprofv3 --kernel-trace --stats): kernel rows"; echo "## 128-bit segment basis (default)"; python3 tools/kernel_stats.py $OUT/stats_ebbig_1 6 | grep sb::; echo "## exon walk everywhere (SBGPU_EXONBIN_SEGBASIS=0)"; python3 tools/kernel_stats.py $OUT/stats_ebbig_0 4 | grep sb::) > $SUM/${R}_exonbin_big_loci.txt
+# BAM records -> the read stream: the bench line and its kernel rows
+(timeout 300 python tools/bench_bamdecode.py 4e6 2>/dev/null | tail -1) > $SUM/${R}_bamdecode.json
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bamdecode -o bd -- python3 $REPO/tools/bench_bamdecode.py 4e6 --no-cpu-baseline > $OUT/stats_bamdecode.log 2>&1)
+for f in $(find $OUT/stats_bamdecode -name "*kernel_stats.csv"); do cp $f $SUM/${R}_bamdecode_kernel_stats.csv; done
 # random stress on this build (tails; the library's build id on top)
 (python -c "import sys; sys.path.insert(0, '.'); from strawberry_amd import _lib; print('libsbgpu build', _lib.load().sbgpu_build_id().decode())"; timeout 900 python tools/stress_em.py 48 2>&1 | tail -3; timeout 600 python tools/stress_exonbin.py 48 2>&1 | tail -2; timeout 600 python tools/stress_binseq.py 2>&1 | tail -2) > $SUM/${R}_stress.txt 2>&1
 cat $SUM/${R}_pytest_gpu.txt; cat $SUM/${R}_bench_c3.json; echo; cat $SUM/${R}_bench_c2.json; echo; ls -la $SUM
