@@ -243,3 +243,22 @@ def toy_run_as_bam_records(d, names):
     c_right = [max(e[1] for _, ex in ordered[g] for e in ex) for g in names]
     c_strand = [1 if strands[g] == "+" else 2 for g in names]
     return np.frombuffer(b"".join(r[2] for r in recs), np.uint8), chrom_names, (ref_of, c_left, c_right, c_strand)
+
+
+def garbage_records(rng, n):
+    """Records whose bytes are noise behind a valid size word; every other one with a head that passes the decoder's first
+    tests (mapped, short name, 1-3 CIGAR operations, no sequence), so that the noise is walked as tags."""
+    recs = []
+    for k in range(n):
+        size = int(rng.integers(0, 400))
+        body = rng.integers(0, 256, size, dtype=np.uint8).tobytes()
+        if k % 2 and size >= 32:
+            n_cig = int(rng.integers(1, 4))
+            l_qname = int(rng.integers(1, 9))
+            if 32 + l_qname + 4 * n_cig <= size:
+                core = struct.pack("<iiIIiiii", int(rng.integers(0, 3)), int(rng.integers(0, 1000)), (30 << 8) | l_qname,
+                                   (int(rng.integers(0, 4)) << 20) | n_cig, 0, int(rng.integers(-1, 3)), int(rng.integers(-1, 1000)), 0)
+                cig = b"".join(struct.pack("<I", (int(rng.integers(1, 90)) << 4) | int(rng.choice([0, 0, 0, 3, 4]))) for _ in range(n_cig))
+                body = core + body[32:32 + l_qname] + cig + body[32 + l_qname + 4 * n_cig:]
+        recs.append(struct.pack("<i", len(body)) + body)
+    return recs

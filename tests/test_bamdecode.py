@@ -205,3 +205,18 @@ def test_bam_bytes_to_unique_hits_on_the_host_equal_reference_runs(which):
     np.testing.assert_array_equal(fr, hits.feat_right)
     np.testing.assert_array_equal(ms, hits.mass)
     assert int(info[4]) == rows[0]["total_mapped"] == hits.total_mapped
+
+
+def test_host_decode_on_garbage_records(oracle):
+    """Records whose bytes are noise behind a valid size word (and some with a plausible head and noise for tags): nothing may
+    be read outside a record, and the library must take the same way through the noise as the oracle."""
+    from strawberry_amd import bam
+    recs = B.garbage_records(np.random.default_rng(31), 4000)
+    raw = np.frombuffer(b"".join(recs), np.uint8)
+    off = bam.index(raw)
+    assert off.size - 1 == len(recs)
+    for kw in (dict(), dict(unique_only=False, library=2)):
+        d = bam.decode(raw, off, bam.BamOptions(n_ref=3, **kw))
+        o = oracle.bam_decode(raw, off, n_ref=3, **kw)
+        check_library_against_oracle(d, o)
+        assert d.by_status["OK"] > 50 and d.by_status["TRUNCATED"] > 500

@@ -66,6 +66,22 @@ def test_device_decode_large_stream_and_edges(ctx, oracle):
     assert e.n_records == 0 and e.n_reads == 0
 
 
+def test_device_decode_on_garbage_records(ctx, oracle):
+    """Noise behind valid size words (tests/test_bamdecode.py has the host form under AddressSanitizer): the device must take
+    the oracle's way through it -- staged in LDS or walked in global memory (SBGPU_BAM_STAGE_KB is read once per process, so the
+    second form is reached through records too long for the buffer)."""
+    from strawberry_amd import bam
+    recs = B.garbage_records(np.random.default_rng(32), 20000)
+    long_tail = [B.record(1, 50, 0, "long%d" % k, [("M", 30000)], tags=[("NH", "C", 1), ("XS", "A", "-")]) for k in range(70)]   # 45 KB each
+    raw = np.frombuffer(b"".join(recs + long_tail + recs[:500]), np.uint8)
+    off = bam.index(raw)
+    for kw in (dict(), dict(unique_only=False, library=1)):
+        d = bam.decode(raw, off, bam.BamOptions(n_ref=3, **kw), device=ctx)
+        check_library_against_oracle(d, oracle.bam_decode(raw, off, n_ref=3, **kw))
+        assert d.by_status["OK"] > 300
+        d.close()
+
+
 def test_device_pairing_with_insertions(ctx, oracle):
     """Mates whose aligned blocks touch (an insertion in the read): no INTRON between them, on the device as on the host."""
     from strawberry_amd import exonbin as eb
