@@ -120,3 +120,40 @@ def test_cxx_emsolver_known_answers(kat):
     for k, (i, rn, th) in ref.items():
         assert got[k][0] == i and got[k][1] == rn, (k, got[k])
         np.testing.assert_allclose([float(x) for x in got[k][2:]], th, rtol=1e-11, atol=1e-12)
+
+
+def test_bam_reads_example_prints_the_reference_read_stream(tmp_path_factory, tmp_path):
+    """examples/bam_reads.cpp (C++14, zlib + the C ABI's host entry points): a BGZF file of the committed decode cases -> one
+    line per record the REFERENCE's BAMHitFactory::getHitFromBuf accepted (tests/golden/bamdecode_cases.npz), with its
+    ReadHit's fields; also under --multiple-hit --fr."""
+    import bam_util as B
+    from strawberry_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    exe = str(tmp_path_factory.mktemp("cpp") / "bam_reads")
+    cmd = ["g++", "-std=c++14", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "bam_reads.cpp"),
+           "-L" + LIBDIR, "-lsbgpu", "-lz", "-Wl,-rpath," + LIBDIR, "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    z = np.load(os.path.join(ROOT, "tests", "golden", "bamdecode_cases.npz"))
+    bam_path = str(tmp_path / "cases.bam")
+    with open(bam_path, "wb") as f:
+        f.write(B.bgzf_compress(B.header_bytes(B.REFS) + z["rec_bytes"].tobytes()))
+    for pre, args in (("default/", []), ("multi_fr/", ["--multiple-hit", "--fr"])):
+        r = subprocess.run([exe, bam_path] + args, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        rows = [ln.split("\t") for ln in r.stdout.splitlines()]
+        acc = np.flatnonzero(z[pre + "accepted"])
+        assert [int(x[0]) for x in rows] == acc.tolist()
+        assert ("%d records, paired-end library" % len(z[pre + "accepted"])) in r.stderr
+        for x, k in zip(rows, acc):
+            assert int(x[1], 16) == int(z[pre + "read_id"][k])
+            assert x[2] == B.REFS[int(z[pre + "ref"][k])][0]
+            assert (int(x[3]), int(x[4])) == (int(z[pre + "left"][k]), int(z[pre + "right"][k]))
+            assert x[5] == ".+-"[int(z[pre + "strand"][k])]
+            assert int(x[6]) == int(z[pre + "partner_pos"][k])
+            assert ("e" in x[7]) == (int(z[pre + "partner_same_ref"][k]) == 0) and ("r" in x[7]) == bool(int(z[pre + "flag_bits"][k]) & 16)
+            assert (int(x[8]), int(x[9]), int(x[10])) == (int(z[pre + "nh"][k]), int(z[pre + "nm"][k]), int(z[pre + "read_len"][k]))
+            f0, f1 = int(z[pre + "feat_off"][k]), int(z[pre + "feat_off"][k + 1])
+            want = ["%d-%d" % (l, rr) for c, l, rr in zip(z[pre + "feat_code"][f0:f1], z[pre + "feat_left"][f0:f1], z[pre + "feat_right"][f0:f1]) if c == 0]
+            assert x[11].split(",") == want
