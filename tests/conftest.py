@@ -17,7 +17,7 @@ def pytest_configure(config):
 
 REF_DIR = os.path.join(ROOT, "oracle", "_ref")
 REF_PROGRAMS = ("libstrawberry_ref.so", "strawberry_ref", "strawberry_sbgpu", "strawberry_sbgpu_batched",
-                "strawberry_sbgpu_chain", "strawberry_dump", "sam2bam")
+                "strawberry_sbgpu_chain", "strawberry_sbgpu_front", "strawberry_dump", "sam2bam")
 
 
 def pytest_report_header(config):

@@ -26,6 +26,9 @@ BATCHED = os.path.join(REF_DIR, "strawberry_sbgpu_batched")
 # the drop-in ONE LEVEL UP (oracle/sbgpu_chain_shim.cpp): procSample collects every locus' transcripts and unique hits with the
 # reference's classes; ONE sbgpu_quantify_host call does exon bins + bin weights + EM for the whole sample (no LocusContext)
 CHAIN = os.path.join(REF_DIR, "strawberry_sbgpu_chain")
+# the drop-in AT ITS DEEPEST (oracle/sbgpu_front_shim.cpp): all three passes over the BAM replaced (inspect_read_len, preProcess,
+# procSample) -- one inflate, then decode -> read stream -> pairs -> unique hits -> bins -> weights -> EM through the library
+FRONT = os.path.join(REF_DIR, "strawberry_sbgpu_front")
 # the same restructured loop with the reference's own EmSolver bodies doing the solve: no GPU in it (the CPU suite's check)
 BATCHED_REFEM = os.path.join(REF_DIR, "strawberry_batched_refem")
 SAM2BAM = os.path.join(REF_DIR, "sam2bam")
@@ -160,6 +163,18 @@ def test_chain_level_reference_driver_reproduces_reference_files(which, tmp_path
     chromosomes, and in assembly mode (C4: the assembled contigs are the annotation, Frac < 0.01 erased)."""
     need_driver(CHAIN)
     check_files(which, tmp_path, run_driver(which, tmp_path, CHAIN), log_in_locus_order=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", sorted(set(RUNS) - ASSEMBLY_MODE))
+def test_front_level_reference_driver_reproduces_reference_files(which, tmp_path):
+    """The reference's main, option parsing, GTF reader and print2gtf -- and NOTHING of its BAM handling: the file is inflated
+    once, every record decided on the device (sbgpu_bam_decode_device = BAMHitFactory::getHitFromBuf), offered to the clusters
+    of the reference's own addRef2Cluster (sbgpu_assign_reads_device), paired, collapsed, quantified: same files, byte for
+    byte -- duplicates and multi-mapped reads, the -e filter, empirical insert sizes (the sample of fragment lengths comes
+    from sbgpu_frag_lens_host), both strands, two chromosomes."""
+    need_driver(FRONT)
+    check_files(which, tmp_path, run_driver(which, tmp_path, FRONT), log_in_locus_order=False)
 
 
 @pytest.mark.parametrize("which", sorted(RUNS))

@@ -2,7 +2,7 @@
 """The drop-in under the reference's OWN driver, timed.
 
 A synthetic sample of >= 10 000 loci (strawberry_amd/chain.py::DeviceSample, the chain workload's law at a smaller size) is
-written out as GTF + coordinate-sorted BAM, and three programs run on it with the same command line
+written out as GTF + coordinate-sorted BAM, and five programs run on it with the same command line
 (`<bam> -g <gtf> -r -i 250/30`, one thread):
 
   strawberry_ref            the reference program, compiled from /root/reference (oracle/Makefile)
@@ -12,6 +12,10 @@ written out as GTF + coordinate-sorted BAM, and three programs run on it with th
                             epilogue (oracle/sbgpu_batched_shim.cpp)
   strawberry_sbgpu_chain    the same one level up: the loci's transcripts and unique hits are collected, ONE
                             sbgpu_quantify_host call does bins + weights + EM on the device (oracle/sbgpu_chain_shim.cpp)
+
+  strawberry_sbgpu_front    the deepest: the reference's three passes over the BAM file (read lengths, preProcess, procSample)
+                            replaced -- one inflate, then sbgpu_bam_decode_device -> sbgpu_assign_reads_device ->
+                            sbgpu_pair_mates_device -> sbgpu_collapse_pairs_device -> sbgpu_quantify_host (oracle/sbgpu_front_shim.cpp)
 
 All must write the same out.gtf and -f table; the table of wall times goes to stdout (-> profiles/r04_dropin.txt).
 Test infrastructure: runs on the GPU box (the programs travel there as oracle/_ref/ binaries)."""
@@ -40,7 +44,8 @@ def main():
     progs = [("strawberry_ref", "reference program (CPU)"),
              ("strawberry_sbgpu", "reference driver, EmSolver on the device one locus per call"),
              ("strawberry_sbgpu_batched", "reference driver, procSample batched: ONE sbgpu_em_batch"),
-             ("strawberry_sbgpu_chain", "reference driver, procSample batched one level up: ONE sbgpu_quantify_host (bins + weights + EM on the device)")]
+             ("strawberry_sbgpu_chain", "reference driver, procSample batched one level up: ONE sbgpu_quantify_host (bins + weights + EM on the device)"),
+             ("strawberry_sbgpu_front", "reference driver, none of its BAM handling: inflate once, then decode -> stream -> pairs -> unique hits -> chain on the device")]
     rows, outs = [], {}
     with tempfile.TemporaryDirectory() as tmp:
         t = time.perf_counter()
