@@ -584,7 +584,7 @@ int sbgpu_bam_decode_host(const uint8_t *bytes, int64_t n_bytes, const int64_t *
 /* Device form (csrc/bamdecode_device.h): `d_bytes` and `d_rec_off` device arrays; one lane per record decides and counts
  * its blocks, two device-wide scans place the accepted records and their blocks, a second pass writes them.  The
  * handle's arrays stay on the device: sbgpu_bamreads_reads hands them to sbgpu_assign_reads_device /
- * sbgpu_pair_mates_device as they are.                                                                                */
+ * sbgpu_pair_mates_device as they are.  A record whose offsets do not ascend inside [0, n_bytes] is TRUNCATED, not read.                                                                                */
 int sbgpu_bam_decode_device(sbgpu_ctx_t *ctx, const uint8_t *d_bytes, int64_t n_bytes, const int64_t *d_rec_off, int64_t n_records,
                             const sbgpu_bam_opts_t *opts, void *stream, sbgpu_bamreads_t **out);
 void sbgpu_bamreads_destroy(sbgpu_bamreads_t *b);

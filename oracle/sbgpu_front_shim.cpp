@@ -4,7 +4,7 @@
 // objects -- its main, option parsing, GTF reader, Contig::print2gtf -- with THREE functions replaced (weakened in a copy
 // of alignments.o): Sample::inspect_read_len, Sample::preProcess and Sample::procSample
 // (/root/reference/src/alignments.cpp:957-974, 1189-1232, 1736-1834), i.e. all three passes the reference makes over the
-// BAM file.  The replacement reads the file ONCE (zlib: BGZF inflate stays on the host) and does the rest through libsbgpu:
+// BAM file.  The replacement reads the file ONCE (zlib on host threads: BGZF inflate stays on the host) and does the rest through libsbgpu:
 //   sbgpu_bam_decode_device        BAMHitFactory::getHitFromBuf for every record            (read.cpp:480-715)
 //   sbgpu_assign_reads_device      Sample::nextClusterRefDemand's pass                       (alignments.cpp:1145-1187)
 //   sbgpu_pair_mates_device        HitCluster::addOpenHit / addHit                           (alignments.cpp:423-655)
@@ -25,7 +25,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <atomic>
 #include <memory>
+#include <thread>
 
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
@@ -71,30 +73,98 @@ Front &front()
    return f;
 }
 int32_t le32(const uint8_t *p) { return (int32_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)); }
+// BGZF: a chain of gzip members of at most 64 KB each, every one carrying its own compressed size (the BC subfield) and
+// its inflated size (the member's last word): the members are found by a walk over the headers and inflated by host
+// threads, each into its place.  (Inflate is host work and stays the caller's; this is the caller.)
+void inflate_bgzf(const std::string &path, std::vector<uint8_t> &out)
+{
+   FILE *f = std::fopen(path.c_str(), "rb");
+   if (!f) {
+      std::fprintf(stderr, "strawberry_sbgpu_front: cannot open %s\n", path.c_str());
+      std::exit(1);
+   }
+   std::fseek(f, 0, SEEK_END);
+   const long sz = std::ftell(f);
+   std::fseek(f, 0, SEEK_SET);
+   std::vector<uint8_t> comp((size_t)sz);
+   if (sz && std::fread(comp.data(), 1, (size_t)sz, f) != (size_t)sz) {
+      std::fprintf(stderr, "strawberry_sbgpu_front: cannot read %s\n", path.c_str());
+      std::exit(1);
+   }
+   std::fclose(f);
+   struct Member {
+      size_t in, in_len, out, out_len;
+   };
+   std::vector<Member> members;
+   size_t p = 0, total = 0;
+   while (p + 18 <= comp.size()) {
+      const uint8_t *h = comp.data() + p;
+      if (!(h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4))) break;
+      const size_t xlen = (size_t)h[10] | ((size_t)h[11] << 8);
+      size_t bsize = 0;
+      for (size_t q = 12; q + 4 <= 12 + xlen;) {
+         const size_t slen = (size_t)h[q + 2] | ((size_t)h[q + 3] << 8);
+         if (h[q] == 'B' && h[q + 1] == 'C' && slen == 2) bsize = ((size_t)h[q + 4] | ((size_t)h[q + 5] << 8)) + 1;
+         q += 4 + slen;
+      }
+      if (!bsize || p + bsize > comp.size()) break;
+      const size_t isize = (size_t)(uint32_t)le32(h + bsize - 4);
+      members.push_back({p + 12 + xlen, bsize - 12 - xlen - 8, total, isize});
+      total += isize;
+      p += bsize;
+   }
+   if (p != comp.size()) {
+      std::fprintf(stderr, "strawberry_sbgpu_front: %s is not a BGZF file\n", path.c_str());
+      std::exit(1);
+   }
+   out.resize(total);
+   const unsigned hw = std::thread::hardware_concurrency();
+   const size_t n_threads = std::max<size_t>(1, std::min<size_t>(hw ? hw : 4, 16));
+   std::vector<std::thread> pool;
+   std::atomic<size_t> next(0);
+   std::atomic<int> failed(0);
+   for (size_t t = 0; t < n_threads; ++t)
+      pool.emplace_back([&] {
+         for (;;) {
+            const size_t first = next.fetch_add(64);
+            if (first >= members.size()) break;
+            for (size_t k = first; k < std::min(first + 64, members.size()); ++k) {
+               const Member &m = members[k];
+               if (!m.out_len) continue;
+               z_stream zs;
+               std::memset(&zs, 0, sizeof(zs));
+               if (inflateInit2(&zs, -15) != Z_OK) {
+                  failed = 1;
+                  continue;
+               }
+               zs.next_in = comp.data() + m.in;
+               zs.avail_in = (uInt)m.in_len;
+               zs.next_out = out.data() + m.out;
+               zs.avail_out = (uInt)m.out_len;
+               if (inflate(&zs, Z_FINISH) != Z_STREAM_END || zs.avail_out != 0) failed = 1;
+               inflateEnd(&zs);
+            }
+         }
+      });
+   for (std::thread &t : pool) t.join();
+   if (failed) {
+      std::fprintf(stderr, "strawberry_sbgpu_front: inflate failed\n");
+      std::exit(1);
+   }
+}
 } // namespace
+
 
 // replaces /root/reference/src/alignments.cpp:957-974 -- and reads the file, for all three passes
 void Sample::inspect_read_len()
 {
    Front &F = front();
+   if (!no_assembly) {
+      std::fprintf(stderr, "strawberry_sbgpu_front: assembly mode is not covered by this driver (give -g and -r, or use strawberry_sbgpu_chain)\n");
+      std::exit(2);
+   }
    const clk::time_point t0 = clk::now();
-   gzFile f = gzopen(sample_path().c_str(), "rb");
-   if (!f) {
-      std::fprintf(stderr, "strawberry_sbgpu_front: cannot open %s\n", sample_path().c_str());
-      std::exit(1);
-   }
-   gzbuffer(f, 1 << 20);
-   std::vector<uint8_t> chunk(8 << 20);
-   for (;;) {
-      const int n = gzread(f, chunk.data(), (unsigned)chunk.size());
-      if (n < 0) {
-         std::fprintf(stderr, "strawberry_sbgpu_front: inflate failed\n");
-         std::exit(1);
-      }
-      if (n == 0) break;
-      F.raw.insert(F.raw.end(), chunk.begin(), chunk.begin() + n);
-   }
-   gzclose(f);
+   inflate_bgzf(sample_path(), F.raw);
    size_t p = 8 + (size_t)le32(F.raw.data() + 4);
    const int32_t n_ref = le32(F.raw.data() + p);
    p += 4;

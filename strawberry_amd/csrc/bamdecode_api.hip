@@ -207,7 +207,7 @@ int sbgpu_bam_decode_device(sbgpu_ctx_t *c, const uint8_t *d_bytes, int64_t n_by
    SB_TRY(hipMemsetAsync(w + o_acc + nn, 0, 1, s));
    SB_TRY(hipMemsetAsync(w + o_nb + nn * 4, 0, 4, s));
    sb::BamScanArgs a = {};
-   a.bytes = d_bytes, a.rec_off = d_rec_off, a.n = n, a.opts = *opts;
+   a.bytes = d_bytes, a.n_bytes = n_bytes, a.rec_off = d_rec_off, a.n = n, a.opts = *opts;
    a.status = (uint8_t *)(w + o_status), a.n_blocks = (int32_t *)(w + o_nb), a.accepted = (uint8_t *)(w + o_acc);
    a.read_id = (uint64_t *)(w + o_rid), a.ref = (int32_t *)(w + o_ref), a.nh = (int32_t *)(w + o_nh), a.nm = (int32_t *)(w + o_nm);
    a.read_len = (int32_t *)(w + o_rl), a.left = (uint32_t *)(w + o_left), a.right = (uint32_t *)(w + o_right);

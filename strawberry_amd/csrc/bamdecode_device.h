@@ -286,6 +286,7 @@ SB_HD void bam_record_blocks(const uint8_t *rec, uint32_t *block_left, uint32_t 
 #ifdef __HIPCC__
 struct BamScanArgs {
    const uint8_t *bytes;
+   int64_t n_bytes;
    const int64_t *rec_off; // [n + 1]
    int64_t n;
    sbgpu_bam_opts_t opts;
@@ -321,7 +322,8 @@ __global__ __launch_bounds__(64) void bam_scan_kernel(BamScanArgs a, int stage_b
       const int64_t s0 = a.rec_off[r0], s1 = a.rec_off[r1];
       const uint8_t *g = a.bytes + s0;
       const int shift = (int)((uintptr_t)g & 15u);
-      const bool staged = s1 - s0 <= (int64_t)stage_bytes - 16;
+      // (offsets that do not ascend inside the stream: nothing is staged, and the lanes below refuse their records)
+      const bool staged = s0 >= 0 && s1 >= s0 && s1 <= a.n_bytes && s1 - s0 <= (int64_t)stage_bytes - 16;
       if (staged) {
          const int len = (int)(s1 - s0);
          const int head = min((16 - shift) & 15, len), nbody = (len - head) >> 4, tail = len - head - (nbody << 4);
@@ -347,8 +349,11 @@ __global__ __launch_bounds__(64) void bam_scan_kernel(BamScanArgs a, int stage_b
       const int64_t r = r0 + lane;
       if (r < r1) {
          const int64_t o0 = a.rec_off[r], o1 = a.rec_off[r + 1];
+         const bool inside = o0 >= s0 && o1 >= o0 && o1 <= s1 && o0 >= 0 && o1 <= a.n_bytes; // (the caller's offsets are device data)
          BamRead x;
-         if (staged) {
+         if (!inside) {
+            bam_decode_record(a.bytes, 0, a.opts, x); // TRUNCATED, nothing read
+         } else if (staged) {
             ByteWindow rd;
             bam_decode_record(rd, stage + shift + (o0 - s0), o1 - o0, a.opts, x);
          } else {

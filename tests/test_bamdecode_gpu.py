@@ -82,6 +82,29 @@ def test_device_decode_on_garbage_records(ctx, oracle):
         d.close()
 
 
+def test_device_decode_refuses_offsets_outside_the_stream(ctx, oracle):
+    """The device form cannot look at the caller's offsets beforehand (they are device data): a record whose offsets do not
+    ascend inside the stream comes back TRUNCATED and is not read; its neighbours are decoded as ever."""
+    from strawberry_amd import bam
+    z = np.load(os.path.join(GOLDEN, "bamdecode_cases.npz"))
+    raw = z["rec_bytes"]
+    off = bam.index(raw)
+    o = oracle.bam_decode(raw, off, n_ref=3)
+    bad = off.copy()
+    bad[200] = off[203]              # record 199 is given too much room (it knows its own size); 200 starts behind its end
+    bad[700] = -5                    # 699 and 700
+    bad[-1] = raw.size + 4096        # the last record claims bytes beyond the stream
+    d = bam.decode(raw, bad, bam.BamOptions(n_ref=3), device=ctx)
+    want = o["status"].copy()
+    want[[200, 699, 700, off.size - 2]] = 10
+    np.testing.assert_array_equal(d.status, want)
+    keep = np.flatnonzero(want == 0)
+    np.testing.assert_array_equal(d.record, keep)
+    np.testing.assert_array_equal(d.left, o["left"][keep])
+    np.testing.assert_array_equal(d.read_id, o["read_id"][keep])
+    d.close()
+
+
 def test_device_pairing_with_insertions(ctx, oracle):
     """Mates whose aligned blocks touch (an insertion in the read): no INTRON between them, on the device as on the host."""
     from strawberry_amd import exonbin as eb
