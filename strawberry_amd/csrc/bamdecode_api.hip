@@ -8,6 +8,8 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <system_error>
+#include <thread>
 #include <vector>
 
 #include <rocprim/rocprim.hpp>
@@ -119,33 +121,67 @@ int sbgpu_bam_decode_host(const uint8_t *bytes, int64_t n_bytes, const int64_t *
    sbgpu_bamreads *B = new (std::nothrow) sbgpu_bamreads();
    if (!B) return api_fail(SBGPU_ENOMEM, "sbgpu_bam_decode_host: out of memory");
    try {
+      // Two passes over the records on host threads (SBGPU_HOST_THREADS, default min(16, hardware threads)), each thread a
+      // contiguous range: (A) decide and count, (B) decode again and write -- nothing is kept per record between them.
       B->n_records = n;
-      std::vector<sb::BamRead> rd((size_t)n);
-      for (int64_t r = 0; r < n; ++r) {
-         sb::bam_decode_record(bytes + rec_off[r], rec_off[r + 1] - rec_off[r], *opts, rd[(size_t)r]);
-         const sb::BamRead &x = rd[(size_t)r];
-         ++B->by_status[x.status <= SBGPU_BAM_TRUNCATED ? x.status : SBGPU_BAM_TRUNCATED];
-         if (x.paired) B->any_paired = 1;
-         if (x.status == SBGPU_BAM_OK) ++B->n_reads, B->n_blocks += x.n_blocks;
+      unsigned nt = std::thread::hardware_concurrency();
+      nt = nt ? std::min(nt, 16u) : 4u;
+      if (const char *e = std::getenv("SBGPU_HOST_THREADS")) nt = (unsigned)std::atoi(e);
+      nt = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)nt, (n + 4095) / 4096));
+      struct Part {
+         int64_t r0 = 0, r1 = 0, reads = 0, blocks = 0, paired = 0, by_status[11] = {};
+      };
+      std::vector<Part> part(nt);
+      for (unsigned t = 0; t < nt; ++t) part[t].r0 = n * t / nt, part[t].r1 = n * (t + 1) / nt;
+      auto run = [&](auto &&fn) {
+         std::vector<std::thread> pool;
+         for (unsigned t = 1; t < nt; ++t) pool.emplace_back(fn, t);
+         fn(0u);
+         for (std::thread &th : pool) th.join();
+      };
+      run([&](unsigned t) {
+         Part &p = part[t];
+         sb::BamRead x;
+         for (int64_t r = p.r0; r < p.r1; ++r) {
+            sb::bam_decode_record(bytes + rec_off[r], rec_off[r + 1] - rec_off[r], *opts, x);
+            ++p.by_status[x.status <= SBGPU_BAM_TRUNCATED ? x.status : SBGPU_BAM_TRUNCATED];
+            p.paired |= x.paired;
+            if (x.status == SBGPU_BAM_OK) ++p.reads, p.blocks += x.n_blocks;
+         }
+      });
+      std::vector<int64_t> read_base(nt + 1, 0), block_base(nt + 1, 0);
+      for (unsigned t = 0; t < nt; ++t) {
+         read_base[t + 1] = read_base[t] + part[t].reads;
+         block_base[t + 1] = block_base[t] + part[t].blocks;
+         B->any_paired |= part[t].paired;
+         for (int k = 0; k <= SBGPU_BAM_TRUNCATED; ++k) B->by_status[k] += part[t].by_status[k];
       }
+      B->n_reads = read_base[nt], B->n_blocks = block_base[nt];
       B->host.resize(lay_out(B, nullptr));
       lay_out(B, B->host.data());
-      int64_t k = 0, b = 0;
-      for (int64_t r = 0; r < n; ++r) {
-         const sb::BamRead &x = rd[(size_t)r];
-         B->status[r] = x.status;
-         if (x.status != SBGPU_BAM_OK) continue;
-         B->record[k] = r, B->read_id[k] = x.read_id, B->ref[k] = x.ref, B->nh[k] = x.nh, B->nm[k] = x.nm, B->read_len[k] = x.read_len;
-         B->left[k] = x.left, B->right[k] = x.right, B->partner_pos[k] = x.partner_pos, B->sam_flag[k] = x.sam_flag, B->flags[k] = x.flags;
-         B->block_off[k] = b;
-         sb::bam_record_blocks(bytes + rec_off[r], B->block_left + b, B->block_right + b);
-         b += x.n_blocks;
-         ++k;
-      }
-      B->block_off[k] = b;
+      run([&](unsigned t) {
+         const Part &p = part[t];
+         int64_t k = read_base[t], b = block_base[t];
+         sb::BamRead x;
+         for (int64_t r = p.r0; r < p.r1; ++r) {
+            sb::bam_decode_record(bytes + rec_off[r], rec_off[r + 1] - rec_off[r], *opts, x);
+            B->status[r] = x.status;
+            if (x.status != SBGPU_BAM_OK) continue;
+            B->record[k] = r, B->read_id[k] = x.read_id, B->ref[k] = x.ref, B->nh[k] = x.nh, B->nm[k] = x.nm, B->read_len[k] = x.read_len;
+            B->left[k] = x.left, B->right[k] = x.right, B->partner_pos[k] = x.partner_pos, B->sam_flag[k] = x.sam_flag, B->flags[k] = x.flags;
+            B->block_off[k] = b;
+            sb::bam_record_blocks(bytes + rec_off[r], B->block_left + b, B->block_right + b);
+            b += x.n_blocks;
+            ++k;
+         }
+      });
+      B->block_off[B->n_reads] = B->n_blocks;
    } catch (const std::bad_alloc &) {
       delete B;
       return api_fail(SBGPU_ENOMEM, "sbgpu_bam_decode_host: out of memory");
+   } catch (const std::system_error &e) {
+      delete B;
+      return api_fail(SBGPU_ENOMEM, std::string("sbgpu_bam_decode_host: ") + e.what());
    }
    *out = B;
    return SBGPU_OK;

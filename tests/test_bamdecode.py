@@ -220,3 +220,21 @@ def test_host_decode_on_garbage_records(oracle):
         o = oracle.bam_decode(raw, off, n_ref=3, **kw)
         check_library_against_oracle(d, o)
         assert d.by_status["OK"] > 50 and d.by_status["TRUNCATED"] > 500
+
+
+def test_host_decode_on_several_threads(oracle, monkeypatch):
+    """sbgpu_bam_decode_host splits the records over host threads (count, then write): the same arrays whatever their number."""
+    from strawberry_amd import bam
+    recs = B.random_records(np.random.default_rng(77), 5000)
+    raw = np.frombuffer(b"".join(recs) * 6, np.uint8)
+    off = bam.index(raw)
+    o = oracle.bam_decode(raw, off, n_ref=3, unique_only=False)
+    got = []
+    for nt in ("1", "3", "7"):
+        monkeypatch.setenv("SBGPU_HOST_THREADS", nt)
+        d = bam.decode(raw, off, bam.BamOptions(n_ref=3, unique_only=False))
+        check_library_against_oracle(d, o)
+        got.append(d)
+    for k in ("status", "record", "read_id", "left", "right", "flags", "block_off", "block_left", "block_right"):
+        for d in got[1:]:
+            np.testing.assert_array_equal(getattr(d, k), getattr(got[0], k), err_msg=k)
