@@ -111,7 +111,8 @@ def decode(rec_bytes, rec_off=None, options=None, device=None):
         return DecodedReads(h)
     import torch
     dev = torch.device("cuda", device.device)
-    db = torch.from_numpy(b if b.size else np.zeros(1, np.uint8)).to(dev)
+    hb = b if b.size else np.zeros(1, np.uint8)
+    db = torch.from_numpy(hb if hb.flags.writeable else hb.copy()).to(dev)
     do = torch.from_numpy(off).to(dev)
     _lib.check(L.sbgpu_bam_decode_device(device.h, db.data_ptr(), b.size, do.data_ptr(), n, C.byref(opts), None, C.byref(h)),
                "sbgpu_bam_decode_device")
