@@ -107,5 +107,5 @@ for f in $(find $OUT/stats_frontend -name "*kernel_stats.csv"); do cp $f $SUM/${
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bamdecode -o bd -- python3 $REPO/tools/bench_bamdecode.py 4e6 --no-cpu-baseline > $OUT/stats_bamdecode.log 2>&1)
 for f in $(find $OUT/stats_bamdecode -name "*kernel_stats.csv"); do cp $f $SUM/${R}_bamdecode_kernel_stats.csv; done
 # random stress on this build (tails; the library's build id on top)
-(python -c "import sys; sys.path.insert(0, '.'); from strawberry_amd import _lib; print('libsbgpu build', _lib.load().sbgpu_build_id().decode())"; timeout 900 python tools/stress_em.py 48 2>&1 | tail -3; timeout 600 python tools/stress_exonbin.py 48 2>&1 | tail -2; timeout 600 python tools/stress_binseq.py 2>&1 | tail -2) > $SUM/${R}_stress.txt 2>&1
+(python -c "import sys; sys.path.insert(0, '.'); from strawberry_amd import _lib; print('libsbgpu build', _lib.load().sbgpu_build_id().decode())"; timeout 900 python tools/stress_em.py 48 2>&1 | tail -3; timeout 600 python tools/stress_exonbin.py 48 2>&1 | tail -2; timeout 600 python tools/stress_binseq.py 2>&1 | tail -2; timeout 600 python tools/stress_bamdecode.py 48 2>/dev/null | tail -2) > $SUM/${R}_stress.txt 2>&1
 cat $SUM/${R}_pytest_gpu.txt; cat $SUM/${R}_bench_c3.json; echo; cat $SUM/${R}_bench_c2.json; echo; ls -la $SUM
