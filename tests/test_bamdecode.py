@@ -238,3 +238,39 @@ def test_host_decode_on_several_threads(oracle, monkeypatch):
     for k in ("status", "record", "read_id", "left", "right", "flags", "block_off", "block_left", "block_right"):
         for d in got[1:]:
             np.testing.assert_array_equal(getattr(d, k), getattr(got[0], k), err_msg=k)
+
+
+def test_names_and_long_cigars_against_the_live_reference(oracle, reflib, tmp_path, capfd):
+    """Read names with bytes >= 0x80 (hashString xors a SIGNED char, include/read.hpp:164-173), names of 254 bytes and of none,
+    CIGARs of hundreds of operations: the reference's own BAMHitFactory, the oracle, the library's host decoder."""
+    import struct
+    from strawberry_amd import bam
+    rng = np.random.default_rng(5)
+    recs = []
+    for k in range(400):
+        nm = bytes(rng.integers(1, 256, int(rng.choice([0, 1, 5, 40, 254])), dtype=np.uint8).tolist())
+        n_ops = int(rng.choice([1, 3, 60, 400]))
+        cig = []
+        for j in range(n_ops):
+            cig.append(("M", int(rng.integers(1, 30))))
+            if j + 1 < n_ops:
+                cig.append(("N", int(rng.integers(20, 200))))
+        r = bytearray(B.record(int(rng.integers(0, 3)), int(rng.integers(0, 10 ** 6)), int(rng.choice([0, 16, 99, 147])), "x", cig,
+                               mtid=int(rng.integers(-1, 3)), mpos=int(rng.integers(-1, 10 ** 6)), tags=[("NH", "C", 1), ("XS", "A", "+")], with_seq=False))
+        # swap the one-letter name for the bytes wanted (the name's length byte and the record's size word follow)
+        body = bytes(r[4:36]) + nm + b"\0" + bytes(r[36 + 2:])
+        core = bytearray(body[:32])
+        core[8:12] = struct.pack("<I", (struct.unpack("<I", core[8:12])[0] & ~0xff) | (len(nm) + 1))
+        body = bytes(core) + body[32:]
+        recs.append(struct.pack("<i", len(body)) + body)
+    path = str(tmp_path / "names.bam")
+    B.write_bam(path, B.REFS, recs)
+    refs, raw = B.read_bam_records(path)
+    z = reflib.bam_decode(path, len(recs) + 8, raw.size // 4 + 8)
+    o = oracle.bam_decode(raw, n_ref=len(refs))
+    against_reference(o, z)
+    assert int((o["status"] == 0).sum()) > 380 and set(np.unique(o["status"])) <= {0, 8}   # (a lone 1M is too short)
+    assert len(set(o["read_id"].tolist())) > 300          # (the empty names share one id)
+    d = bam.decode(raw, None, bam.BamOptions(n_ref=len(refs)))
+    check_library_against_oracle(d, o)
+    capfd.readouterr()
