@@ -39,7 +39,7 @@ def _tag_bytes(tag, typ, val):
 def record(tid, pos, flag, name, cigar, mapq=30, mtid=-1, mpos=-1, tlen=0, tags=(), with_seq=True):
     """cigar: [(op char, length)]; pos / mpos 0-based as in the file; tags: [(two letters, type char, value)]."""
     qlen = sum(n for op, n in cigar if op in QUERY_OPS) if with_seq else 0
-    qname = name.encode() + b"\0"
+    qname = (name if isinstance(name, bytes) else name.encode()) + b"\0"
     cig = b"".join(struct.pack("<I", (n << 4) | CIGAR_OPS.index(op)) for op, n in cigar)
     seq = bytes([0x12] * ((qlen + 1) // 2))
     qual = bytes([30] * qlen)
@@ -199,6 +199,8 @@ def random_records(rng, n, n_ref=len(REFS)):
             # bytes as tags.  Kept LAST: behind it that scan would wander through whatever follows, here it runs out.
             tags.append(("XD", "d", 2.5))
         name = "r%d:%s" % (i // 2 if paired else i, "x" * int(rng.integers(0, 25)))
+        if rng.random() < 0.04:   # bytes >= 0x80 (the reference's hash xors a signed char), a name of 254 bytes, an empty one
+            name = bytes(rng.integers(1, 256, int(rng.choice([0, 3, 30, 254])), dtype=np.uint8).tolist())
         out.append(record(tid, pos, flag, name, cig, mapq=int(rng.integers(0, 61)), mtid=mtid, mpos=mpos,
                           tlen=int(rng.integers(-500, 500)), tags=tags, with_seq=rng.random() < 0.9))
     return out
