@@ -3,7 +3,7 @@
 // src/read.cpp:455-715) hands to its clusters, for the whole file at once.
 //
 //   g++ -std=c++14 -Iinclude examples/bam_reads.cpp -Lstrawberry_amd/lib -lsbgpu -lz -Wl,-rpath,$PWD/strawberry_amd/lib
-//   ./a.out in.bam [-j min_intron] [-J max_intron] [--multiple-hit] [--fr | --rf] > reads.tsv
+//   ./a.out in.bam [-j min_intron] [-J max_intron] [--allow-multimapped-hits] [--fr | --rf] > reads.tsv
 //
 // The program inflates the BGZF blocks with zlib (gzread walks the chain of gzip members), skips the BAM header, lets
 // sbgpu_bam_index_host find the records and sbgpu_bam_decode_host decide about them (sbgpu_bam_decode_device takes the same
@@ -26,7 +26,7 @@ static int32_t le32(const uint8_t *p) { return (int32_t)((uint32_t)p[0] | ((uint
 int main(int argc, char **argv)
 {
    if (argc < 2) {
-      std::fprintf(stderr, "usage: %s in.bam [-j min_intron] [-J max_intron] [--multiple-hit] [--fr | --rf]\n", argv[0]);
+      std::fprintf(stderr, "usage: %s in.bam [-j min_intron] [-J max_intron] [--allow-multimapped-hits] [--fr | --rf]\n", argv[0]);
       return 2;
    }
    sbgpu_bam_opts_t opts = {20, 300000, 1, 0, 0}; // the reference's defaults (src/common.cpp:19-21,67-69)
@@ -34,7 +34,7 @@ int main(int argc, char **argv)
       const std::string a = argv[i];
       if (a == "-j" && i + 1 < argc) opts.min_intron = std::atoi(argv[++i]);
       else if (a == "-J" && i + 1 < argc) opts.max_intron = std::atoi(argv[++i]);
-      else if (a == "--multiple-hit") opts.unique_only = 0;
+      else if (a == "--allow-multimapped-hits") opts.unique_only = 0;
       else if (a == "--fr") opts.library = 1;
       else if (a == "--rf") opts.library = 2;
       else {

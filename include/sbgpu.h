@@ -546,8 +546,8 @@ int sbgpu_matepairs_export(const sbgpu_matepairs_t *m, double *pair_mass, int64_
  *   - interval [pos + 1, pos + M + D + N lengths], 1-based closed; blocks = the M runs, a D extends the block before it,
  *     an I leaves two blocks that touch (readhit_2_genomicFeats, src/contig.cpp:12-53: no INTRON between them);
  *   - flags as sbgpu_reads_t's: bit 0 reverse (the record's 0x10), bit 1 partner on another reference (the mate's id differs;
- *     no mate reference included), bits 2-3
- *     strand from XS:A ('+' / '-'), else from the library type and the first-in-pair / reverse bits (:636-651);
+ *     no mate reference included), bits 2-3 the strand: from XS:A ('+' / '-'), else from the library type and the
+ *     first-in-pair / reverse bits (:636-651);
  *   - read id = FNV-1 of the read name (ReadTable::get_id, include/read.hpp:164-173); reference id = the file's (the
  *     reference numbers the @SQ lines in order); partner_pos = mate position + 1 (0: none); NH 1 when absent; NM as the
  *     reference keeps it (through an unsigned char); read_len = M + S + I (ReadHit::read_len);
@@ -556,7 +556,7 @@ int sbgpu_matepairs_export(const sbgpu_matepairs_t *m, double *pair_mass, int64_
 typedef struct {
    int32_t min_intron;  /* kMinIntronLength, 20 (src/common.cpp:21; -j)                     */
    int32_t max_intron;  /* kMaxIntronLength, 300000 (src/common.cpp:20; -J)                 */
-   int32_t unique_only; /* use_only_unique_hits, 1 (src/common.cpp:67; --multiple-hit: 0)   */
+   int32_t unique_only; /* use_only_unique_hits, 1 (src/common.cpp:67; --allow-multimapped-hits: 0)   */
    int32_t library;     /* 0 unstranded, 1 fr_strand, 2 rf_strand (src/common.cpp:68-69)    */
    int32_t n_ref;       /* references in the header: a larger id is refused; 0: not checked */
 } sbgpu_bam_opts_t;

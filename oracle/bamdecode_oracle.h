@@ -6,7 +6,7 @@
 typedef struct {
    int32_t min_intron;  /* kMinIntronLength (src/common.cpp:21; -j)             */
    int32_t max_intron;  /* kMaxIntronLength (src/common.cpp:20; -J)             */
-   int32_t unique_only; /* use_only_unique_hits (src/common.cpp:67; --multiple-hit clears it) */
+   int32_t unique_only; /* use_only_unique_hits (src/common.cpp:67; --allow-multimapped-hits clears it) */
    int32_t library;     /* 0 unstranded, 1 fr_strand, 2 rf_strand (src/common.cpp:68-69)     */
    int32_t n_ref;       /* references in the header (records with a larger id are refused); <= 0: not checked */
 } sbo_bam_opts;

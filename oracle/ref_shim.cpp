@@ -298,7 +298,7 @@ void ref_kmer_stats(const char *seq, int len, double *out6)
 
 /* BAMHitFactory::getHitFromBuf (src/read.cpp:480-715) on every record of a BAM file, through the reference's own
  * BAMHitFactory (samopen + bam_read1 of the vendored samtools 0.1.19), with the reference's option globals set as the
- * command line would set them (-j / -J, --multiple-hit, --fr / --rf; src/Strawberry.cpp:129-169).  Per record, in file
+ * command line would set them (-j / -J, --allow-multimapped-hits, --fr / --rf; src/Strawberry.cpp:129-169).  Per record, in file
  * order: accepted (getHitFromBuf's return value), and for the accepted ones the ReadHit's fields (sam_flag: the bits the
  * class shows -- 16 reverse, 64 first, 128 second -- and bit 31 = is_singleton()).  The CIGAR the
  * ReadHit keeps (H and P ops are not in it) is flattened into cig_type / cig_len at cig_off[r]; the features

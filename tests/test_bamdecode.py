@@ -177,7 +177,7 @@ def test_bam_bytes_to_unique_hits_on_the_host_equal_reference_runs(which):
     ordered, rows, _, _ = U.load(d)
     annot, hits, names, rejected = XU.e2e_inputs(d, ordered)
     raw, chrom_names, (c_ref, c_left, c_right, c_strand) = B.toy_run_as_bam_records(d, names)
-    dec = bam.decode(raw, None, bam.BamOptions(unique_only=which != "E2E_MASS", n_ref=len(chrom_names)))   # (the mass run: --multiple-hit)
+    dec = bam.decode(raw, None, bam.BamOptions(unique_only=which != "E2E_MASS", n_ref=len(chrom_names)))   # (the mass run: --allow-multimapped-hits)
     assert dec.n_reads == dec.n_records and dec.any_paired
     got_cluster, off, fl = eb.assign_reads(c_ref, c_left, c_right, c_strand, dec.ref, dec.left, dec.right, dec.flags)
     L = _lib.load()

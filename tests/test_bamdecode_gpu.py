@@ -145,7 +145,7 @@ def test_bam_bytes_to_unique_hits_on_the_device_equal_reference_runs(ctx, which)
     annot, hits, names, rejected = XU.e2e_inputs(d, ordered)
     raw, chrom_names, (c_ref, c_left, c_right, c_strand) = B.toy_run_as_bam_records(d, names)
     L = _lib.load()
-    dec = bam.decode(raw, None, bam.BamOptions(unique_only=which != "E2E_MASS", n_ref=len(chrom_names)), device=ctx)   # (the mass run: --multiple-hit)
+    dec = bam.decode(raw, None, bam.BamOptions(unique_only=which != "E2E_MASS", n_ref=len(chrom_names)), device=ctx)   # (the mass run: --allow-multimapped-hits)
     assert dec.on_device and dec.n_reads == dec.n_records and dec.any_paired
     rs, d_ref, d_left, d_right = dec.device_reads()
     # the read stream: which cluster every record is offered to (Sample::nextClusterRefDemand's pass), flags in place

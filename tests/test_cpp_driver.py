@@ -125,7 +125,7 @@ def test_cxx_emsolver_known_answers(kat):
 def test_bam_reads_example_prints_the_reference_read_stream(tmp_path_factory, tmp_path):
     """examples/bam_reads.cpp (C++14, zlib + the C ABI's host entry points): a BGZF file of the committed decode cases -> one
     line per record the REFERENCE's BAMHitFactory::getHitFromBuf accepted (tests/golden/bamdecode_cases.npz), with its
-    ReadHit's fields; also under --multiple-hit --fr."""
+    ReadHit's fields; also under --allow-multimapped-hits --fr."""
     import bam_util as B
     from strawberry_amd import _lib
     if not os.path.exists(_lib.LIB_PATH):
@@ -139,7 +139,7 @@ def test_bam_reads_example_prints_the_reference_read_stream(tmp_path_factory, tm
     bam_path = str(tmp_path / "cases.bam")
     with open(bam_path, "wb") as f:
         f.write(B.bgzf_compress(B.header_bytes(B.REFS) + z["rec_bytes"].tobytes()))
-    for pre, args in (("default/", []), ("multi_fr/", ["--multiple-hit", "--fr"])):
+    for pre, args in (("default/", []), ("multi_fr/", ["--allow-multimapped-hits", "--fr"])):
         r = subprocess.run([exe, bam_path] + args, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
         rows = [ln.split("\t") for ln in r.stdout.splitlines()]
