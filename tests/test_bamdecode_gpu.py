@@ -82,6 +82,25 @@ def test_device_decode_on_garbage_records(ctx, oracle):
         d.close()
 
 
+def test_device_decode_of_long_records_only(ctx, oracle):
+    """Streams whose AVERAGE record is long (long reads: kilobases of sequence and qualities in the record): 64 of them fit no
+    staging buffer, every record is walked in global memory -- and the launch must not ask for more LDS than a workgroup has."""
+    from strawberry_amd import bam
+    rng = np.random.default_rng(8)
+    for length in (900, 3000, 20000):
+        recs = []
+        for k in range(300):
+            n = int(rng.integers(length // 2, length))
+            cig = [("S", 5), ("M", n // 2), ("N", 500), ("M", n - n // 2)] if k % 3 else [("M", n)]
+            recs.append(B.record(int(rng.integers(0, 3)), int(rng.integers(0, 10 ** 6)), 0, "long.%d" % k, cig, tags=[("NH", "C", 1), ("XS", "A", "-"), ("NM", "C", 3)]))
+        raw = np.frombuffer(b"".join(recs), np.uint8)
+        d = bam.decode(raw, None, bam.BamOptions(n_ref=3), device=ctx)
+        o = oracle.bam_decode(raw, n_ref=3)
+        check_library_against_oracle(d, o)
+        assert d.n_reads == 300 and (d.read_len > length // 2 - 1).all()
+        d.close()
+
+
 def test_device_decode_refuses_offsets_outside_the_stream(ctx, oracle):
     """The device form cannot look at the caller's offsets beforehand (they are device data): a record whose offsets do not
     ascend inside the stream comes back TRUNCATED and is not read; its neighbours are decoded as ever."""
