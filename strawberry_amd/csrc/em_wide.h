@@ -11,12 +11,19 @@
 // workgroups thus hold bitwise identical theta and take identical decisions (convergence, zero denominator);
 // two buffers alternate, there is no barrier object at all.
 //
-// Round 3 layout.  A wave is a 2-D grid of lanes like the tile kernels' groups (em_device.h, "matrix lane map"):
+// Layout.  A wave is a 2-D grid of lanes like the tile kernels' groups (em_device.h, "matrix lane map"):
 // CL = 16, 32 or 64 COLUMN lanes on the lane bits 4 5 0 1 (3 (2)) -- a row's denominator is summed over them by a
 // PAIR of v_mfma_f64_4x4x4 (+ one or two rotations of the 16-lane row) -- and 4, 2 or 1 ROW lanes on the bits
 // left (3 2): the column sums of a wave take two, one or no rotation step per column.  A lane keeps R rows x CPL
-// columns (96 doubles: 192 of its 256 registers; the old layout kept 40-64 and spent 12 reduction steps per row on
-// all 64 lanes), the counts of its rows sit in LDS, "row kept" is a lane mask per row slot in scalar registers.
+// columns in REGISTERS (64-72 doubles: up to 144 of its 256 registers) and, round 5, RL more rows x CPL columns in
+// LDS (its own slots, [slot][thread]: conflict-free 8-byte reads, nothing shared) -- 21-36 doubles more per lane,
+// which is what the 160 KB of a CU's LDS hold beside the exchange's arrays.  A round of the tail is bound by the
+// hand-off between a locus' workgroups, not by its arithmetic, so what counts is how many rows a CU holds: a third
+// more rows per workgroup are a quarter fewer workgroups per locus and a quarter fewer rounds.  Columns per lane come
+// in steps of one (4 ... 8) so that a locus' width is padded by 9 % on average instead of 22 %.
+// A row's count and its "not part of the problem" flag sit in LDS once per row (8 bytes, read as a broadcast): the
+// flag is ADDED to the row's denominator (0 for a kept row -- exact --, 1 for the others, whose weights and count
+// are 0), so that neither a lane mask per row slot nor a select is on the path.
 // Two workgroup barriers per iteration (partials visible / phi visible): the zero-denominator flag rides in the
 // granules' tag words and the shares of ||next - theta||^2 are read after the second barrier, with theta's update
 // already written -- the thread that owns a column keeps the previous theta in a register, so the pre-update value
@@ -29,6 +36,8 @@
 // fp64 flush mode.
 #pragma once
 
+#include <utility>
+
 #include "em_device.h"
 
 namespace sb {
@@ -37,35 +46,54 @@ constexpr int kWideWaves = 8;                  // 2 per SIMD: up to 256 VGPRs ea
 constexpr int kWideThreads = 64 * kWideWaves;
 constexpr unsigned kWideSpinLimit = 1u << 20;  // sweeps of an exchange's partials before giving up (~ seconds)
 constexpr int kWideSweep = 8;                  // granules a thread has in flight per sweep
+constexpr size_t kWideLdsCap = 159 * 1024;     // of the 160 KB a workgroup may ask for on gfx950
 
-// (log2 column lanes, columns per lane, rows per lane, rows that share one v_rcp_f64): 72-80 doubles of F per lane --
-// what fits beside the ~90 registers the iteration itself needs (phi and the partial sums of the lane's columns, a
-// block's denominators and reciprocals, the owner thread's theta / phi / scale), without a spill
+// (log2 column lanes, columns per lane, rows per lane in registers, rows per lane in LDS, register rows that share one
+// v_rcp_f64, LDS rows per block): 64-72 doubles of F per lane in registers -- what fits beside the ~100 registers the
+// iteration itself needs (phi and the partial sums of the lane's columns, a block's denominators and reciprocals, an
+// LDS block's weights in flight, the owner thread's theta / phi / scale) -- and what the LDS holds beside
 struct WideLayout {
-   int lb_cl, cpl, r, rblk;
+   int lb_cl, cpl, r, rl, rblk, lblk;
 };
-constexpr int kWideLayouts = 7;
+constexpr int kWideLayouts = 13;
 constexpr WideLayout wide_layout(int id)
 {
-   return id == 0 ? WideLayout{4, 4, 16, 4} : id == 1 ? WideLayout{4, 6, 12, 4} : id == 2 ? WideLayout{4, 8, 10, 2}
-        : id == 3 ? WideLayout{5, 6, 12, 4} : id == 4 ? WideLayout{5, 8, 10, 2} : id == 5 ? WideLayout{6, 6, 12, 4}
-                                                                                           : WideLayout{6, 8, 10, 2};
+   constexpr WideLayout t[kWideLayouts] = {
+      {4, 4, 16, 9, 4, 2}, {4, 5, 14, 7, 4, 2}, {4, 6, 12, 6, 4, 2}, {4, 7, 10, 5, 2, 1}, {4, 8, 9, 4, 2, 1},
+      {5, 5, 14, 6, 4, 2}, {5, 6, 12, 5, 4, 2}, {5, 7, 10, 4, 2, 1}, {5, 8, 9, 4, 2, 1},
+      {6, 5, 14, 6, 4, 2}, {6, 6, 12, 4, 4, 2}, {6, 7, 10, 4, 2, 1}, {6, 8, 9, 3, 2, 1}};
+   return t[id];
 }
 constexpr int wide_cols(int id) { return (1 << wide_layout(id).lb_cl) * wide_layout(id).cpl; } // 64 ... 512
-constexpr int wide_rows_per_block(int id) { return kWideWaves * (64 >> wide_layout(id).lb_cl) * wide_layout(id).r; }
-constexpr int kWideMaxCols = wide_cols(kWideLayouts - 1);
-inline int wide_layout_for(int64_t niso)
-{
-   for (int id = 0; id < kWideLayouts; ++id)
-      if (niso <= wide_cols(id)) return id;
-   return -1;
-}
-// dynamic LDS of a workgroup: phi[npad] | accw[waves][npad] | part[waves] | misc[8] | zf[16 ints] | counts[R][threads] doubles
-// | stage[2 npad] granules (the two-level exchange)
+constexpr int wide_rows_per_block(int id) { return kWideWaves * (64 >> wide_layout(id).lb_cl) * (wide_layout(id).r + wide_layout(id).rl); }
+constexpr int kWideMaxCols = 512;
+// dynamic LDS of a workgroup: phi[npad] | accw[waves][npad] | part[waves] | misc[8] doubles | zf[16 ints] |
+// row[rows per block] {count, flag} | stage[2 npad] granules (the two-level exchange) | F[rl][cpl][threads] doubles
 constexpr size_t wide_lds_bytes(int id)
 {
    return (size_t)(wide_cols(id) * (1 + kWideWaves) + kWideWaves + 8) * sizeof(double) + 16 * sizeof(int) +
-          (size_t)wide_layout(id).r * kWideThreads * sizeof(double) + (size_t)2 * wide_cols(id) * 16;
+          (size_t)wide_rows_per_block(id) * 8 + (size_t)2 * wide_cols(id) * 16 +
+          (size_t)wide_layout(id).rl * wide_layout(id).cpl * kWideThreads * sizeof(double);
+}
+constexpr bool wide_layouts_fit()
+{
+   for (int id = 0; id < kWideLayouts; ++id)
+      if (wide_lds_bytes(id) > kWideLdsCap || wide_cols(id) > kWideMaxCols) return false;
+   return true;
+}
+static_assert(wide_layouts_fit(), "a wide layout asks for more LDS than a workgroup may have");
+// the layout that serves a locus with the fewest workgroups (then the narrowest: less to exchange); -1: too wide
+inline int wide_layout_for(int64_t niso, int64_t nrow)
+{
+   int best = -1;
+   int64_t best_g = 0;
+   for (int id = 0; id < kWideLayouts; ++id) {
+      if (niso > wide_cols(id)) continue;
+      const int64_t rpb = wide_rows_per_block(id);
+      const int64_t g = nrow <= rpb ? 1 : (nrow + rpb - 1) / rpb;
+      if (best < 0 || g < best_g || (g == best_g && wide_cols(id) < wide_cols(best))) best = id, best_g = g;
+   }
+   return best;
 }
 // columns per slice of the two-level exchange: the smallest power of two m with m * G >= npad (m * G < 2 npad)
 inline int wide_lb_slice(int npad, int G)
@@ -114,11 +142,115 @@ __device__ __forceinline__ void granule_store(void *p, double v, unsigned round,
    g.y = (unsigned)__double2hiint(v);
    g.z = round;
    g.w = ~round ^ flag;
-   asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(g) : "memory");
+   // (s_nop: a store of more than 8 bytes followed by a write of its data registers wants wait states, and the
+   // compiler's hazard recogniser does not look into the statement)
+   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(g) : "memory");
 }
 __device__ __forceinline__ bool granule_ready(const u32x4 &g, unsigned round) { return g.z == round && (g.w ^ ~round) <= 1u; }
 __device__ __forceinline__ unsigned granule_flag(const u32x4 &g, unsigned round) { return (g.w ^ ~round) & 1u; }
 __device__ __forceinline__ double granule_value(const u32x4 &g) { return __hiloint2double((int)g.y, (int)g.x); }
+
+// One sweep of N granules (base + off[k], k < N), all in flight together, as ONE asm statement that ends with the wait:
+// the registers the loads write are outputs of a statement that has completed when the compiler sees them.  (Round 4 had
+// a statement per load and a separate wait; once the register allocator spills around the exchange it is free to store
+// a granule's registers between the two -- before the data has arrived -- and reload the stale words behind the wait: a
+// partial that "never arrives".  Seen as a sporadic time-out the day the tile grew.)
+template <int N>
+__device__ __forceinline__ void granule_sweep(const char *base_ptr, const unsigned (&off)[kWideSweep], u32x4 (&gr)[kWideSweep])
+{
+   static_assert(N >= 1 && N <= kWideSweep && kWideSweep == 8, "sweep");
+   // the base in scalar registers (it is wave-uniform; the compiler cannot always tell).  The statements start with
+   // s_nop 4: a v_readfirstlane's scalar result wants five wait states before a memory instruction reads it, and the
+   // compiler's hazard recogniser does not look into an asm statement (seen: the loads went out with the register
+   // pair's previous contents -- a memory access fault)
+   const uint64_t bp = (uint64_t)base_ptr;
+   const uint64_t base = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(bp >> 32)) << 32) |
+                         (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bp);
+   if (N == 1)
+      asm volatile("s_nop 4\n\t"
+                   "global_load_dwordx4 %0, %1, %2 sc1\n\t"
+                   "s_waitcnt vmcnt(0)"
+                   : "=&v"(gr[0])
+                   : "v"(off[0]), "s"(base)
+                   : "memory");
+   if (N == 2)
+      asm volatile("s_nop 4\n\t"
+                   "global_load_dwordx4 %0, %2, %4 sc1\n\t"
+                   "global_load_dwordx4 %1, %3, %4 sc1\n\t"
+                   "s_waitcnt vmcnt(0)"
+                   : "=&v"(gr[0]), "=&v"(gr[1])
+                   : "v"(off[0]), "v"(off[1]), "s"(base)
+                   : "memory");
+   if (N == 3)
+      asm volatile("s_nop 4\n\t"
+                   "global_load_dwordx4 %0, %3, %6 sc1\n\t"
+                   "global_load_dwordx4 %1, %4, %6 sc1\n\t"
+                   "global_load_dwordx4 %2, %5, %6 sc1\n\t"
+                   "s_waitcnt vmcnt(0)"
+                   : "=&v"(gr[0]), "=&v"(gr[1]), "=&v"(gr[2])
+                   : "v"(off[0]), "v"(off[1]), "v"(off[2]), "s"(base)
+                   : "memory");
+   if (N == 4)
+      asm volatile("s_nop 4\n\t"
+                   "global_load_dwordx4 %0, %4, %8 sc1\n\t"
+                   "global_load_dwordx4 %1, %5, %8 sc1\n\t"
+                   "global_load_dwordx4 %2, %6, %8 sc1\n\t"
+                   "global_load_dwordx4 %3, %7, %8 sc1\n\t"
+                   "s_waitcnt vmcnt(0)"
+                   : "=&v"(gr[0]), "=&v"(gr[1]), "=&v"(gr[2]), "=&v"(gr[3])
+                   : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "s"(base)
+                   : "memory");
+   if (N == 5)
+      asm volatile("s_nop 4\n\t"
+                   "global_load_dwordx4 %0, %5, %10 sc1\n\t"
+                   "global_load_dwordx4 %1, %6, %10 sc1\n\t"
+                   "global_load_dwordx4 %2, %7, %10 sc1\n\t"
+                   "global_load_dwordx4 %3, %8, %10 sc1\n\t"
+                   "global_load_dwordx4 %4, %9, %10 sc1\n\t"
+                   "s_waitcnt vmcnt(0)"
+                   : "=&v"(gr[0]), "=&v"(gr[1]), "=&v"(gr[2]), "=&v"(gr[3]), "=&v"(gr[4])
+                   : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "s"(base)
+                   : "memory");
+   if (N == 6)
+      asm volatile("s_nop 4\n\t"
+                   "global_load_dwordx4 %0, %6, %12 sc1\n\t"
+                   "global_load_dwordx4 %1, %7, %12 sc1\n\t"
+                   "global_load_dwordx4 %2, %8, %12 sc1\n\t"
+                   "global_load_dwordx4 %3, %9, %12 sc1\n\t"
+                   "global_load_dwordx4 %4, %10, %12 sc1\n\t"
+                   "global_load_dwordx4 %5, %11, %12 sc1\n\t"
+                   "s_waitcnt vmcnt(0)"
+                   : "=&v"(gr[0]), "=&v"(gr[1]), "=&v"(gr[2]), "=&v"(gr[3]), "=&v"(gr[4]), "=&v"(gr[5])
+                   : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[5]), "s"(base)
+                   : "memory");
+   if (N == 7)
+      asm volatile("s_nop 4\n\t"
+                   "global_load_dwordx4 %0, %7, %14 sc1\n\t"
+                   "global_load_dwordx4 %1, %8, %14 sc1\n\t"
+                   "global_load_dwordx4 %2, %9, %14 sc1\n\t"
+                   "global_load_dwordx4 %3, %10, %14 sc1\n\t"
+                   "global_load_dwordx4 %4, %11, %14 sc1\n\t"
+                   "global_load_dwordx4 %5, %12, %14 sc1\n\t"
+                   "global_load_dwordx4 %6, %13, %14 sc1\n\t"
+                   "s_waitcnt vmcnt(0)"
+                   : "=&v"(gr[0]), "=&v"(gr[1]), "=&v"(gr[2]), "=&v"(gr[3]), "=&v"(gr[4]), "=&v"(gr[5]), "=&v"(gr[6])
+                   : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[5]), "v"(off[6]), "s"(base)
+                   : "memory");
+   if (N == 8)
+      asm volatile("s_nop 4\n\t"
+                   "global_load_dwordx4 %0, %8, %16 sc1\n\t"
+                   "global_load_dwordx4 %1, %9, %16 sc1\n\t"
+                   "global_load_dwordx4 %2, %10, %16 sc1\n\t"
+                   "global_load_dwordx4 %3, %11, %16 sc1\n\t"
+                   "global_load_dwordx4 %4, %12, %16 sc1\n\t"
+                   "global_load_dwordx4 %5, %13, %16 sc1\n\t"
+                   "global_load_dwordx4 %6, %14, %16 sc1\n\t"
+                   "global_load_dwordx4 %7, %15, %16 sc1\n\t"
+                   "s_waitcnt vmcnt(0)"
+                   : "=&v"(gr[0]), "=&v"(gr[1]), "=&v"(gr[2]), "=&v"(gr[3]), "=&v"(gr[4]), "=&v"(gr[5]), "=&v"(gr[6]), "=&v"(gr[7])
+                   : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[5]), "v"(off[6]), "v"(off[7]), "s"(base)
+                   : "memory");
+}
 
 // all-reduce of N values over the column lanes of a wave (lane bits 4 5 0 1, then 3, then 2)
 template <int LB_CL, int N, int NA>
@@ -164,19 +296,32 @@ __device__ __forceinline__ void wide_row_lanes_sum(double (&x)[N])
    }
 }
 
-template <int LB_CL, int CPL, int R, int RBLK>
+// calls fn(integral_constant<int, 0>) ... fn(integral_constant<int, N - 1>): a loop whose index is a constant
+// expression in the body (block shapes differ; the register tile must be indexed by constants)
+template <class Fn, int... B>
+__device__ __forceinline__ void wide_for_each(Fn &fn, std::integer_sequence<int, B...>)
+{
+   (fn(std::integral_constant<int, B>{}), ...);
+}
+
+template <int LB_CL, int CPL, int R, int RL, int RBLK, int LBLK>
 __device__ __forceinline__ void em_wide_body(const WideArgs &g, const int di)
 {
    constexpr int CL = 1 << LB_CL, GR = 64 / CL, NPAD = CL * CPL;
    constexpr int ROWSTEP = kWideWaves * GR; // rows of the block between a lane's consecutive row slots
-   static_assert(R % RBLK == 0 && (RBLK == 4 || RBLK == 2 || RBLK == 1) && CPL % 2 == 0 && NPAD <= kWideThreads, "layout");
+   constexpr int RT = R + RL;               // a lane's row slots: the first R in registers, the others in LDS
+   // the slots are worked on in blocks that share a v_rcp_f64: register blocks of RBLK rows, then LDS blocks of LBLK rows
+   constexpr int NBR = (R + RBLK - 1) / RBLK, NBL = (RL + LBLK - 1) / LBLK, NBLK = NBR + NBL;
+   static_assert((RBLK == 4 || RBLK == 2 || RBLK == 1) && (LBLK == 2 || LBLK == 1) && NPAD <= kWideThreads && NBLK <= 32, "layout");
    extern __shared__ double s_dyn[];
    double *phi = s_dyn;                       // [NPAD] theta_j * scale_j of the iteration about to run
    double *accw = phi + NPAD;                 // [kWideWaves][NPAD] the waves' partial column sums
    double *s_part = accw + kWideWaves * NPAD; // [kWideWaves] the owner waves' shares of ||next - theta||^2
    double *s_misc = s_part + kWideWaves;      // 0: total count, 1: rows kept, 3: abort, 4 + parity: zero-denominator flag of an iteration
    int *s_zf = (int *)(s_misc + 8);           // [kWideWaves] "a kept row of this wave had a zero denominator"
-   double *s_cnt = (double *)(s_zf + 16);     // [R][kWideThreads] counts of the lanes' rows as doubles (0 for rows not kept)
+   int2 *s_row = (int2 *)(s_zf + 16);         // [RT * ROWSTEP] per row of the block: {count (0 unless kept), 1 unless kept}
+   u32x4 *stage = (u32x4 *)(s_row + RT * ROWSTEP); // [2 NPAD] granules of the two-level exchange
+   double *s_F = (double *)(stage + 2 * NPAD);     // [RL][CPL][kWideThreads] the lanes' rows beyond the register tile
    const EmArgs &a = g.a;
    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
    set_fp64_flush_denormals();
@@ -196,59 +341,57 @@ __device__ __forceinline__ void em_wide_body(const WideArgs &g, const int di)
    const int c16 = ((lane >> 4) & 3) | ((lane & 3) << 2);
    const int c = LB_CL == 4 ? c16 : (LB_CL == 5 ? (c16 | (((lane >> 3) & 1) << 4)) : (c16 | (((lane >> 3) & 1) << 4) | (((lane >> 2) & 1) << 5)));
    const int b = LB_CL == 4 ? ((lane >> 2) & 3) : (LB_CL == 5 ? ((lane >> 2) & 1) : 0);
+   const int row_slot0 = wave * GR + b; // slot r of this lane is row r * ROWSTEP + row_slot0 of the block
 
    // ---- my rows: block w owns rows [w * rows_per_block, ...); the lane's slot r is row r * ROWSTEP + wave * GR + b of it
    const int row_lo = w * d.rows_per_block;
    const int row_hi = min(nrow, row_lo + d.rows_per_block);
    double F[R][CPL];
-   bool keep[R]; // lane masks in scalar registers
    double csum[CPL];
 #pragma unroll
    for (int k = 0; k < CPL; ++k) csum[k] = 0.0;
    double tot = 0.0;
    int kept = 0;
+   unsigned blk_live = 0; // bit per block: some lane of this wave has a kept row in it
+   // (the LDS slots first: their values pass through registers the tile does not occupy yet)
 #pragma unroll
-   for (int r = 0; r < R; ++r) {
-      const int i = row_lo + r * ROWSTEP + wave * GR + b;
+   for (int rr = 0; rr < RT; ++rr) {
+      const int r = rr < RL ? R + rr : rr - RL;
+      if (rr == RL) __builtin_amdgcn_sched_barrier(0);
+      const int i = row_lo + r * ROWSTEP + row_slot0;
       const bool valid = i < row_hi;
       const int ic = valid ? i : row_lo; // (row_lo < nrow: every block owns at least one row)
       int cnt = a.count[r0 + ic];
       cnt = valid ? cnt : 0;
+      double x[CPL];
       double mx = 0.0;
 #pragma unroll
       for (int k = 0; k < CPL; ++k) {
          const int j = k * CL + c; // the lane's k-th column: consecutive column lanes, consecutive columns (LDS banks)
          const bool ok = valid && j < niso;
-         double x = Fg[(int64_t)ic * niso + (j < niso ? j : 0)]; // unconditional load, then select: no branch per element
-         x = ok ? x : 0.0;
-         F[r][k] = x;
-         mx = fmax(mx, x);
+         double v = Fg[(int64_t)ic * niso + (j < niso ? j : 0)]; // unconditional load, then select: no branch per element
+         v = ok ? v : 0.0;
+         x[k] = v;
+         mx = fmax(mx, v);
       }
       mx = wide_col_lanes_max<LB_CL>(mx);
-      keep[r] = valid && mx > kRowEps; // estimate.cpp:380
-      if (!keep[r]) {
+      const bool keep = valid && mx > kRowEps; // estimate.cpp:380
 #pragma unroll
-         for (int k = 0; k < CPL; ++k) F[r][k] = 0.0;
+      for (int k = 0; k < CPL; ++k) {
+         const double v = keep ? x[k] : 0.0;
+         if (r < R) F[r < R ? r : 0][k] = v;
+         else s_F[((r - R) * CPL + k) * kWideThreads + tid] = v;
+         csum[k] += v;
       }
-      s_cnt[r * kWideThreads + tid] = keep[r] ? (double)cnt : 0.0;
-      if (c == 0) tot += (double)cnt; // theta_0 counts ALL rows (:374-375); one lane per row
-      kept |= keep[r] ? 1 : 0;
-#pragma unroll
-      for (int k = 0; k < CPL; ++k) csum[k] += F[r][k];
-   }
-
-   // per block of row slots, for this wave: 0 = no kept row in any lane, 1 = a kept row in every lane, 2 = mixed
-   int blk_kind[R / RBLK];
-#pragma unroll
-   for (int rb = 0; rb < R; rb += RBLK) {
-      bool any = false, all = true;
-#pragma unroll
-      for (int q = 0; q < RBLK; ++q) {
-         any |= keep[rb + q];
-         all &= keep[rb + q];
+      if (c == 0) {
+         s_row[r * ROWSTEP + row_slot0] = make_int2(keep ? cnt : 0, keep ? 0 : 1);
+         tot += (double)cnt; // theta_0 counts ALL rows (:374-375); one lane per row
       }
-      blk_kind[rb / RBLK] = !wave_any(any) ? 0 : (wave_any(!all) ? 2 : 1);
+      kept |= keep ? 1 : 0;
+      const int blk = r < R ? r / RBLK : NBR + (r - R) / LBLK;
+      if (wave_any(keep)) blk_live |= 1u << blk;
    }
+   blk_live = (unsigned)__builtin_amdgcn_readfirstlane((int)blk_live);
 
    // The exchange: the thread that owns item `tid` (tid < n_items) hands in its workgroup's partial `s` and the
    // workgroup's flag bit and gets the sum of the G workgroups' partials, added in workgroup order (identical in
@@ -258,11 +401,11 @@ __device__ __forceinline__ void em_wide_body(const WideArgs &g, const int di)
    //   w sums the columns [w << lb_slice, ...) (one granule per thread, staged in LDS, a workgroup barrier, added in
    //   workgroup order) and publishes the totals, then every owner reads the ONE total of its item.
    bool aborted = false;
-   u32x4 *stage = (u32x4 *)(s_cnt + R * kWideThreads);
    // one granule, polled until it carries this exchange's tag
    auto fetch = [&](const char *p, u32x4 &gr) {
       for (unsigned spins = 0;; ++spins) {
-         asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(gr) : "v"(p) : "memory");
+         asm volatile("s_nop 4\n\t"
+                   "global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(gr) : "v"(p) : "memory");
          if (granule_ready(gr, round)) break;
          if (spins > kWideSpinLimit || ((spins & 63) == 63 && __hip_atomic_load(g_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
             aborted = true;
@@ -282,38 +425,43 @@ __device__ __forceinline__ void em_wide_body(const WideArgs &g, const int di)
       __builtin_amdgcn_s_sleep(8);
       if (G <= kWideSweep) {
          if (tid < n_items) {
-            const char *in = buf1 + (size_t)tid * 16;
-            unsigned pending = 0;
+            // granule k of my column: buf1 + (k * NPAD + tid) * 16 -- a 32-bit offset per granule on a scalar base
+            unsigned off[kWideSweep];
 #pragma unroll
-            for (int k = 0; k < kWideSweep; ++k)
-               if (k < G) pending |= 1u << k;
-            u32x4 gr[kWideSweep];
+            for (int k = 0; k < kWideSweep; ++k) off[k] = (unsigned)(((k < G ? k : G - 1) * NPAD + tid) * 16);
+            double sum = 0.0;
+            unsigned fl = 0;
             for (unsigned spins = 0;; ++spins) {
+               // every sweep fetches all G granules (a second sweep is the exception): nothing of a sweep outlives it
+               u32x4 gr[kWideSweep];
+               switch (G) {
+               case 2: granule_sweep<2>(buf1, off, gr); break;
+               case 3: granule_sweep<3>(buf1, off, gr); break;
+               case 4: granule_sweep<4>(buf1, off, gr); break;
+               case 5: granule_sweep<5>(buf1, off, gr); break;
+               case 6: granule_sweep<6>(buf1, off, gr); break;
+               case 7: granule_sweep<7>(buf1, off, gr); break;
+               default: granule_sweep<8>(buf1, off, gr); break;
+               }
+               bool all = true;
 #pragma unroll
                for (int k = 0; k < kWideSweep; ++k)
-                  if (pending & (1u << k))
-                     asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(gr[k]) : "v"(in + (size_t)k * NPAD * 16) : "memory");
-               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                  if (k < G) all = all && granule_ready(gr[k], round);
+               if (all) {
 #pragma unroll
-               for (int k = 0; k < kWideSweep; ++k)
-                  if ((pending & (1u << k)) && granule_ready(gr[k], round)) pending &= ~(1u << k);
-               if (!pending) break;
+                  for (int k = 0; k < kWideSweep; ++k)
+                     if (k < G) {
+                        sum += granule_value(gr[k]);
+                        fl |= granule_flag(gr[k], round);
+                     }
+                  break;
+               }
                // give up: after the spin limit, or when another workgroup has (the error word lives in host memory)
                if (spins > kWideSpinLimit || ((spins & 63) == 63 && __hip_atomic_load(g_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
                   aborted = true;
                   break;
                }
                __builtin_amdgcn_s_sleep(1);
-            }
-            double sum = 0.0;
-            unsigned fl = 0;
-            if (!aborted) {
-#pragma unroll
-               for (int k = 0; k < kWideSweep; ++k)
-                  if (k < G) {
-                     sum += granule_value(gr[k]);
-                     fl |= granule_flag(gr[k], round);
-                  }
             }
             s = sum;
             flag_out = fl;
@@ -470,36 +618,42 @@ __device__ __forceinline__ void em_wide_body(const WideArgs &g, const int di)
 #pragma unroll
       for (int k = 0; k < CPL; ++k) ph[k] = phi[k * CL + c];
       bool zf = false;
-#ifdef SB_WIDE_DIAG
-      if (!(SB_WIDE_DIAG & 1))
-#endif
+      auto block = [&](auto tag) {
+         constexpr int BLK = decltype(tag)::value;
+         constexpr bool IN_LDS = BLK >= NBR;
+         constexpr int S0 = IN_LDS ? R + (BLK - NBR) * LBLK : BLK * RBLK;                       // the block's first row slot
+         constexpr int NB = IN_LDS ? (RL - (BLK - NBR) * LBLK < LBLK ? RL - (BLK - NBR) * LBLK : LBLK)
+                                   : (R - BLK * RBLK < RBLK ? R - BLK * RBLK : RBLK);           // its rows
+         if (BLK > 0 && !((blk_live >> BLK) & 1u)) return; // no lane of this wave has a kept row in these slots: nothing to add
+         int2 ri[NB];
 #pragma unroll
-      for (int rb = 0; rb < R; rb += RBLK) {
-         constexpr int NB = RBLK; // rows of this block (R is a multiple of RBLK)
-         const int kind = blk_kind[rb / RBLK];
-         if (rb > 0 && kind == 0) continue; // no lane of this wave has a kept row in these slots: nothing to add
-         double cnt[NB];
+         for (int q = 0; q < NB; ++q) ri[q] = s_row[(S0 + q) * ROWSTEP + row_slot0];
+         // (an LDS block's reads stay behind the block before it: hoisted to the top of the pass -- nothing they depend
+         // on -- they would all be live at once, RL x CPL doubles the tile has no registers for)
+         if (IN_LDS) __builtin_amdgcn_sched_barrier(0);
+         double fb[NB][CPL]; // the block's weights: the register tile itself, or the lane's LDS slots read once for both steps
 #pragma unroll
-         for (int q = 0; q < NB; ++q) cnt[q] = s_cnt[(rb + q) * kWideThreads + tid];
+         for (int q = 0; q < NB; ++q) {
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) fb[q][k] = IN_LDS ? s_F[((S0 + q - R) * CPL + k) * kWideThreads + tid] : F[IN_LDS ? 0 : S0 + q][k];
+         }
          double dd[4];
 #pragma unroll
          for (int q = 0; q < NB; ++q) {
             double part = 0.0;
 #pragma unroll
-            for (int k = 0; k < CPL; ++k) part = __builtin_fma(F[rb + q][k], ph[k], part); // :450
+            for (int k = 0; k < CPL; ++k) part = __builtin_fma(fb[q][k], ph[k], part); // :450
             dd[q] = part;
          }
          wide_col_lanes_sum<LB_CL, NB>(dd);
+         // a row outside the problem (dropped by init(), or beyond the block's rows) has weights 0, count 0 and flag 1:
+         // its denominator is 0 + 1 and its weight 0 / 1; a kept row's is dd + 0, exactly dd
          double de[4], inv[4];
-         double prod = 1.0;
-         if (kind == 1) { // every lane's row is a kept one
 #pragma unroll
-            for (int q = 0; q < NB; ++q) de[q] = dd[q];
-         } else {
-#pragma unroll
-            for (int q = 0; q < NB; ++q) de[q] = keep[rb + q] ? dd[q] : 1.0; // a row outside the problem: n = 0, weight 0 / 1
-         }
+         for (int q = 0; q < NB; ++q) de[q] = dd[q] + (double)ri[q].y;
+         double prod;
          if (NB == 4) prod = (de[0] * de[1]) * (de[2] * de[3]);
+         else if (NB == 3) prod = (de[0] * de[1]) * de[2];
          else if (NB == 2) prod = de[0] * de[1];
          else prod = de[0];
          // the block's reciprocals from one v_rcp_f64 (em_device.h: batch_reciprocals) unless their product leaves the
@@ -511,26 +665,27 @@ __device__ __forceinline__ void em_wide_body(const WideArgs &g, const int di)
          } else {
 #pragma unroll
             for (int q = 0; q < NB; ++q) {
-               zf |= keep[rb + q] && dd[q] == 0.0; // :451
+               zf |= de[q] == 0.0; // :451 (a kept row: the others' denominators are 1)
                inv[q] = newton_rcp(de[q]);
             }
          }
 #pragma unroll
          for (int q = 0; q < NB; ++q) {
-            const double wgt = cnt[q] * inv[q];
-            if (rb == 0 && q == 0) { // the first row starts the column partials
+            const double wgt = (double)ri[q].x * inv[q];
+            if (BLK == 0 && q == 0) { // the first row starts the column partials
 #pragma unroll
-               for (int k = 0; k < CPL; ++k) acc[k] = wgt * F[0][k];
+               for (int k = 0; k < CPL; ++k) acc[k] = wgt * fb[0][k];
             } else {
 #pragma unroll
-               for (int k = 0; k < CPL; ++k) acc[k] = __builtin_fma(wgt, F[rb + q][k], acc[k]);
+               for (int k = 0; k < CPL; ++k) acc[k] = __builtin_fma(wgt, fb[q][k], acc[k]);
             }
          }
          // one block's temporaries at a time (the tile leaves few registers): the empty asm pins the column partials
          // here, so the block's updates cannot be sunk behind the later blocks' reciprocals
 #pragma unroll
          for (int k = 0; k < CPL; ++k) asm volatile("" : "+v"(acc[k]));
-      }
+      };
+      wide_for_each(block, std::make_integer_sequence<int, NBLK>{});
       wide_row_lanes_sum<LB_CL>(acc);
       if (b == 0) {
 #pragma unroll
@@ -540,9 +695,6 @@ __device__ __forceinline__ void em_wide_body(const WideArgs &g, const int di)
          const int zw = wave_any(zf) ? 1 : 0;
          if (lane == 0) s_zf[wave] = zw;
       }
-#ifdef SB_WIDE_DIAG
-      if (!(SB_WIDE_DIAG & 2))
-#endif
       __syncthreads(); // (A) the waves' partial column sums and flags (and the previous iteration's shares) are visible
       if (s_misc[3] != 0.0) {
          if (tid == 0) __hip_atomic_store(g_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -553,18 +705,12 @@ __device__ __forceinline__ void em_wide_body(const WideArgs &g, const int di)
 #pragma unroll
          for (int v = 0; v < kWideWaves; ++v) p[v] = s_part[v];
          const double dsum = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
-#ifdef SB_WIDE_DIAG
-         if (false)
-#endif
          if (s_misc[4 + ((it - 1) & 1)] != 0.0) { // run() == false, _theta untouched (:451-453)
             st = kStDenomZero;
             theta0_out = true;
             it_done = it - 1;
             break;
          }
-#ifdef SB_WIDE_DIAG
-         if (false)
-#endif
          if (dsum <= kThetaLimitSq) { // sqrt(d2) < 1e-2 (:479-480), theta NOT updated: the value of before
             st = kStOk;
             prev_out = true;
@@ -573,9 +719,6 @@ __device__ __forceinline__ void em_wide_body(const WideArgs &g, const int di)
          }
       }
       // ---- the owner of column tid: the locus-wide sum, next_theta (:454-464), its share of ||next - theta||^2
-#ifdef SB_WIDE_DIAG
-      if (!(SB_WIDE_DIAG & 8))
-#endif
       {
          double s = 0.0;
          unsigned flag = 0;
@@ -605,9 +748,6 @@ __device__ __forceinline__ void em_wide_body(const WideArgs &g, const int di)
             if (aborted) s_misc[3] = 1.0;
          }
       }
-#ifdef SB_WIDE_DIAG
-      if (!(SB_WIDE_DIAG & 4))
-#endif
       __syncthreads(); // (B) phi is complete
    }
    if (w == 0) {
@@ -632,10 +772,10 @@ __global__ __launch_bounds__(kWideThreads) void em_wide_kernel(WideArgs g)
    switch (g.table[di].layout) {
 #ifdef SB_WIDE_ONLY // diagnostic: one instantiation per build (register report)
 #define SB_WIDE_CASE(ID) \
-   case ID: if (ID == SB_WIDE_ONLY) em_wide_body<wide_layout(ID).lb_cl, wide_layout(ID).cpl, wide_layout(ID).r, wide_layout(ID).rblk>(g, di); break;
+   case ID: if (ID == SB_WIDE_ONLY) em_wide_body<wide_layout(ID).lb_cl, wide_layout(ID).cpl, wide_layout(ID).r, wide_layout(ID).rl, wide_layout(ID).rblk, wide_layout(ID).lblk>(g, di); break;
 #else
 #define SB_WIDE_CASE(ID) \
-   case ID: em_wide_body<wide_layout(ID).lb_cl, wide_layout(ID).cpl, wide_layout(ID).r, wide_layout(ID).rblk>(g, di); break;
+   case ID: em_wide_body<wide_layout(ID).lb_cl, wide_layout(ID).cpl, wide_layout(ID).r, wide_layout(ID).rl, wide_layout(ID).rblk, wide_layout(ID).lblk>(g, di); break;
 #endif
       SB_WIDE_CASE(0)
       SB_WIDE_CASE(1)
@@ -644,6 +784,12 @@ __global__ __launch_bounds__(kWideThreads) void em_wide_kernel(WideArgs g)
       SB_WIDE_CASE(4)
       SB_WIDE_CASE(5)
       SB_WIDE_CASE(6)
+      SB_WIDE_CASE(7)
+      SB_WIDE_CASE(8)
+      SB_WIDE_CASE(9)
+      SB_WIDE_CASE(10)
+      SB_WIDE_CASE(11)
+      SB_WIDE_CASE(12)
 #undef SB_WIDE_CASE
    }
 }

@@ -691,11 +691,11 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
       // workgroups exchange partials, so loci of like workgroup counts share rounds: largest first
       std::vector<std::pair<int, int32_t>> wide;
       std::vector<int32_t> rest;
-      // a locus' layout follows from its isoform count (em_wide.h: 16 / 32 / 64 column lanes x 4-8 columns), the
-      // number of workgroups from its rows; the rows are then dealt evenly
+      // a locus' layout is the one that serves it with the fewest workgroups (em_wide.h: 16 / 32 / 64 column lanes x
+      // 4-8 columns; rows per workgroup = register rows + LDS rows); the rows are then dealt evenly
       auto groups_of = [&](int32_t l, int &layout) -> int64_t {
          const int64_t nrow = row_off[l + 1] - row_off[l], niso = iso_off[l + 1] - iso_off[l];
-         layout = sb::wide_layout_for(niso);
+         layout = sb::wide_layout_for(niso, nrow);
          if (layout < 0) return -1;
          const int64_t rpb = sb::wide_rows_per_block(layout);
          return std::max<int64_t>(1, (nrow + rpb - 1) / rpb);
