@@ -21,9 +21,10 @@
 // hand-off between a locus' workgroups, not by its arithmetic, so what counts is how many rows a CU holds: a third
 // more rows per workgroup are a quarter fewer workgroups per locus and a quarter fewer rounds.  Columns per lane come
 // in steps of one (4 ... 8) so that a locus' width is padded by 9 % on average instead of 22 %.
-// A row's count and its "not part of the problem" flag sit in LDS once per row (8 bytes, read as a broadcast): the
-// flag is ADDED to the row's denominator (0 for a kept row -- exact --, 1 for the others, whose weights and count
-// are 0), so that neither a lane mask per row slot nor a select is on the path.
+// A row's count sits in LDS once per row (a double, read as a broadcast; -1 marks a row that is not part of the
+// problem: dropped by init() or beyond the workgroup's rows -- its weights are 0, its denominator counts as 1); a
+// wave-uniform bit per block of rows says whether any lane has to look for the mark, so neither a lane mask per row
+// slot nor a select is on the common path.
 // Two workgroup barriers per iteration (partials visible / phi visible): the zero-denominator flag rides in the
 // granules' tag words and the shares of ||next - theta||^2 are read after the second barrier, with theta's update
 // already written -- the thread that owns a column keeps the previous theta in a register, so the pre-update value
@@ -319,7 +320,7 @@ __device__ __forceinline__ void em_wide_body(const WideArgs &g, const int di)
    double *s_part = accw + kWideWaves * NPAD; // [kWideWaves] the owner waves' shares of ||next - theta||^2
    double *s_misc = s_part + kWideWaves;      // 0: total count, 1: rows kept, 3: abort, 4 + parity: zero-denominator flag of an iteration
    int *s_zf = (int *)(s_misc + 8);           // [kWideWaves] "a kept row of this wave had a zero denominator"
-   int2 *s_row = (int2 *)(s_zf + 16);         // [RT * ROWSTEP] per row of the block: {count (0 unless kept), 1 unless kept}
+   double *s_row = (double *)(s_zf + 16);     // [RT * ROWSTEP] per row of the block: its count, -1 for a row outside the problem
    u32x4 *stage = (u32x4 *)(s_row + RT * ROWSTEP); // [2 NPAD] granules of the two-level exchange
    double *s_F = (double *)(stage + 2 * NPAD);     // [RL][CPL][kWideThreads] the lanes' rows beyond the register tile
    const EmArgs &a = g.a;
@@ -352,7 +353,8 @@ __device__ __forceinline__ void em_wide_body(const WideArgs &g, const int di)
    for (int k = 0; k < CPL; ++k) csum[k] = 0.0;
    double tot = 0.0;
    int kept = 0;
-   unsigned blk_live = 0; // bit per block: some lane of this wave has a kept row in it
+   unsigned blk_live = 0;  // bit per block: some lane of this wave has a kept row in it
+   unsigned blk_mixed = 0; // bit per block: some lane's row is kept and some lane's is not
    // (the LDS slots first: their values pass through registers the tile does not occupy yet)
 #pragma unroll
    for (int rr = 0; rr < RT; ++rr) {
@@ -384,14 +386,16 @@ __device__ __forceinline__ void em_wide_body(const WideArgs &g, const int di)
          csum[k] += v;
       }
       if (c == 0) {
-         s_row[r * ROWSTEP + row_slot0] = make_int2(keep ? cnt : 0, keep ? 0 : 1);
+         s_row[r * ROWSTEP + row_slot0] = keep ? (double)cnt : -1.0;
          tot += (double)cnt; // theta_0 counts ALL rows (:374-375); one lane per row
       }
       kept |= keep ? 1 : 0;
       const int blk = r < R ? r / RBLK : NBR + (r - R) / LBLK;
       if (wave_any(keep)) blk_live |= 1u << blk;
+      if (wave_any(!keep)) blk_mixed |= 1u << blk;
    }
    blk_live = (unsigned)__builtin_amdgcn_readfirstlane((int)blk_live);
+   blk_mixed = (unsigned)__builtin_amdgcn_readfirstlane((int)blk_mixed); // (block 0 runs whether it is live or not)
 
    // The exchange: the thread that owns item `tid` (tid < n_items) hands in its workgroup's partial `s` and the
    // workgroup's flag bit and gets the sum of the G workgroups' partials, added in workgroup order (identical in
@@ -625,9 +629,9 @@ __device__ __forceinline__ void em_wide_body(const WideArgs &g, const int di)
          constexpr int NB = IN_LDS ? (RL - (BLK - NBR) * LBLK < LBLK ? RL - (BLK - NBR) * LBLK : LBLK)
                                    : (R - BLK * RBLK < RBLK ? R - BLK * RBLK : RBLK);           // its rows
          if (BLK > 0 && !((blk_live >> BLK) & 1u)) return; // no lane of this wave has a kept row in these slots: nothing to add
-         int2 ri[NB];
+         double cnt[NB];
 #pragma unroll
-         for (int q = 0; q < NB; ++q) ri[q] = s_row[(S0 + q) * ROWSTEP + row_slot0];
+         for (int q = 0; q < NB; ++q) cnt[q] = s_row[(S0 + q) * ROWSTEP + row_slot0];
          // (an LDS block's reads stay behind the block before it: hoisted to the top of the pass -- nothing they depend
          // on -- they would all be live at once, RL x CPL doubles the tile has no registers for)
          if (IN_LDS) __builtin_amdgcn_sched_barrier(0);
@@ -646,11 +650,29 @@ __device__ __forceinline__ void em_wide_body(const WideArgs &g, const int di)
             dd[q] = part;
          }
          wide_col_lanes_sum<LB_CL, NB>(dd);
-         // a row outside the problem (dropped by init(), or beyond the block's rows) has weights 0, count 0 and flag 1:
-         // its denominator is 0 + 1 and its weight 0 / 1; a kept row's is dd + 0, exactly dd
+         // The matrix instruction's result wants six wait states before a vector instruction reads it.  The compiler
+         // counts them along the fall-through path only: with a branch between the two (the mixed-block test below) the
+         // taken path's first instruction read the sums early -- NaN in every theta of one layout.  Eight wait states
+         // tied to the sums, so that nothing that reads them can come before
+         if (NB == 4) asm volatile("s_nop 7" : "+v"(dd[0]), "+v"(dd[1]), "+v"(dd[2]), "+v"(dd[3]));
+         else if (NB == 3) asm volatile("s_nop 7" : "+v"(dd[0]), "+v"(dd[1]), "+v"(dd[2]));
+         else if (NB == 2) asm volatile("s_nop 7" : "+v"(dd[0]), "+v"(dd[1]));
+         else asm volatile("s_nop 7" : "+v"(dd[0]));
+         // a row outside the problem (dropped by init(), or beyond the block's rows) has weights 0 and "count" -1: its
+         // denominator is 0 + 1 and its weight 0 / 1.  Only a block with such a row in some lane looks (a wave-uniform
+         // bit per block): elsewhere the denominators are the sums and the counts the counts
          double de[4], inv[4];
+         if ((blk_mixed >> BLK) & 1u) {
 #pragma unroll
-         for (int q = 0; q < NB; ++q) de[q] = dd[q] + (double)ri[q].y;
+            for (int q = 0; q < NB; ++q) {
+               const bool out = cnt[q] < 0.0;
+               de[q] = out ? 1.0 : dd[q];
+               cnt[q] = out ? 0.0 : cnt[q];
+            }
+         } else {
+#pragma unroll
+            for (int q = 0; q < NB; ++q) de[q] = dd[q];
+         }
          double prod;
          if (NB == 4) prod = (de[0] * de[1]) * (de[2] * de[3]);
          else if (NB == 3) prod = (de[0] * de[1]) * de[2];
@@ -665,13 +687,13 @@ __device__ __forceinline__ void em_wide_body(const WideArgs &g, const int di)
          } else {
 #pragma unroll
             for (int q = 0; q < NB; ++q) {
-               zf |= de[q] == 0.0; // :451 (a kept row: the others' denominators are 1)
+               zf |= de[q] == 0.0; // :451 (a kept row's: the others' denominators are 1)
                inv[q] = newton_rcp(de[q]);
             }
          }
 #pragma unroll
          for (int q = 0; q < NB; ++q) {
-            const double wgt = (double)ri[q].x * inv[q];
+            const double wgt = cnt[q] * inv[q];
             if (BLK == 0 && q == 0) { // the first row starts the column partials
 #pragma unroll
                for (int k = 0; k < CPL; ++k) acc[k] = wgt * fb[0][k];

@@ -16,7 +16,8 @@ shapes = [(64, 400), (128, 194), (256, 100), (700, 40), (300, 70), (90, 96), (50
           (100, 385), (64, 512), (1500, 300), (2600, 130), (3000, 500), (5000, 65), (1, 100), (7, 300),
           # round 5: the layouts of 5 and 7 columns per lane, rows in LDS slots only partly filled, the last register block of 1-3 rows
           (300, 75), (801, 80), (900, 110), (450, 112), (1200, 150), (257, 160), (400, 210), (161, 224), (2000, 310),
-          (129, 320), (800, 440), (81, 448), (513, 64), (20, 66), (577, 97), (97, 512), (4000, 400)]
+          (129, 320), (800, 440), (81, 448), (513, 64), (20, 66), (577, 97), (97, 512), (4000, 400),
+          (200, 128), (1500, 120), (417, 113), (300, 256), (1300, 240), (209, 225)]
 for nrow, niso in shapes:
     b = _generate(rng, np.array([nrow], np.int64), np.array([niso], np.int64), np.array([nrow * 50], np.int64))
     s = em.EmBatchSolver(b, ctx)
