@@ -170,6 +170,7 @@ def timed_steps(quant, steps, warmup, dev, sdist, torch):
         quant.step()
     ev[1].record()
     torch.cuda.synchronize(dev)
+    timed_steps.own_wall = time.perf_counter() - t0   # this rank's K steps, before it waits for the others (diagnostic)
     sdist.barrier()
     torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t0
@@ -257,6 +258,9 @@ def chain_leg(args, ctx, dev, rank, world, sdist, torch, strong=False, with_cpu=
     wall, _ = timed_steps(q, args.steps, args.warmup, dev, sdist, torch)
     counts = torch.tensor([q.n_loci, q.n_frags, q.n_hits], dtype=torch.int64, device=dev)
     sdist.allreduce_sum_(counts)
+    per_rank = None
+    if world > 1:   # every rank's own K steps (before it waits for the others), its loci and unique hits
+        per_rank = sdist.gather_values([timed_steps.own_wall / args.steps * 1e3, q.n_loci, q.n_hits], rank, world, device=dev)
     if rank != 0:
         return None
     ms = wall / args.steps * 1e3
@@ -290,6 +294,9 @@ def chain_leg(args, ctx, dev, rank, world, sdist, torch, strong=False, with_cpu=
                       "mean_iters": float(q.iters[:q.n_loci].mean())},
         "roofline": roof,
     }
+    if per_rank is not None:
+        out.update({"per_rank_ms": [float(x) for x in per_rank[:, 0]], "slowest_rank": int(per_rank[:, 0].argmax()),
+                    "loci_per_rank": [int(x) for x in per_rank[:, 1]], "unique_hits_per_rank": [int(x) for x in per_rank[:, 2]]})
     if with_cpu and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"], out["parity"] = chain_cpu_baseline(q)
     if with_cpu and world == 1 and os.environ.get("SB_CHAIN_PCIE", "1") == "1":
@@ -353,11 +360,14 @@ def dry_run(args):
     sdist.allreduce_max_(t)
     n = torch.tensor([1, rank], dtype=torch.int64)
     sdist.allreduce_sum_(n)
+    tab = sdist.gather_values([float(rank + 1), 10 * rank], rank, world)   # the per-rank table of a real run's line
     sdist.barrier()
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": int(n[0]), "rank_sum": int(n[1]),
                           "max_over_ranks": float(t.item()), "steps": args.steps, "warmup": args.warmup,
                           "workload": args.workload, "scaling": args.scaling,
+                          "per_rank_ms": [float(x) for x in tab[:, 0]], "slowest_rank": int(tab[:, 0].argmax()),
+                          "capped_loci_per_rank": [int(x) for x in tab[:, 1]], "value_strong": None, "value_weak": None,
                           "note": "SB_BENCH_DRY_RUN: launch + collectives only, nothing measured"}))
 
 
@@ -459,12 +469,32 @@ def main():
     if world > 1:
         whole = make_batch(args.workload, 0)
         shard = whole.select(sdist.shard_loci(whole.nrow, whole.niso, world)[rank])
-        _, squant = make_quant(shard)
+        ssolver, squant = make_quant(shard)
         swall, _ = timed_steps(squant, args.steps, args.warmup, dev, sdist, torch)
         strong = {"value": whole.n_loci * args.steps / swall, "ms_per_step": swall / args.steps * 1e3,
                   "mfrags_per_s": whole.n_frags * args.steps / swall / 1e6, "loci": whole.n_loci,
                   "loci_this_rank": shard.n_loci}
-        del squant
+        # Who sets the step.  Every step ends in the all-reduce, so the ranks' wall times are coupled; what tells them
+        # apart is each rank's OWN kernel time: the shard's EM kernels alone (HIP events on their streams, a few untimed
+        # steps without the collective).  Gathered over one all-reduce of a zero-padded table.
+        own_ms = timed_steps.own_wall / args.steps * 1e3
+        sres = ssolver.results()
+        ssolver.set_timing(True)
+        em_probe = []
+        for _ in range(3):
+            ssolver.run_em()
+            ssolver.synchronize()
+            em_probe.append(max(ssolver.last_kernel_ms()))
+        ssolver.set_timing(False)
+        tab = sdist.gather_values([own_ms, float(np.min(em_probe)), shard.n_loci, int((sres["status"] == 3).sum()),
+                                   float((shard.nrow * shard.niso).sum())], rank, world, device=dev)
+        strong.update({"per_rank_ms": [float(x) for x in tab[:, 0]], "per_rank_em_kernel_ms": [float(x) for x in tab[:, 1]],
+                       "slowest_rank": int(np.argmax(tab[:, 1])), "loci_per_rank": [int(x) for x in tab[:, 2]],
+                       "capped_loci_per_rank": [int(x) for x in tab[:, 3]], "elements_per_rank": [int(x) for x in tab[:, 4]],
+                       "per_rank_note": "per_rank_ms: a rank's K steps up to its own synchronize (the per-step all-reduce couples "
+                                        "the ranks); per_rank_em_kernel_ms: its EM kernels alone, longest kind, HIP events -- a "
+                                        "shard cannot end before one of its 1000-iteration loci does (capped_loci_per_rank)"})
+        del squant, ssolver
     else:
         strong = dict(weak, loci_this_rank=batch.n_loci)   # one rank: the same run
     strong["sharding"] = "one %d-locus batch, LPT shards by elements x predicted iterations (dist.shard_loci), " \
@@ -569,6 +599,11 @@ def main():
         "wave_phase_ms": phase_ms,
         "weak_scaling": weak,
         "strong_scaling": strong,
+        # both values beside the headline, for a reader of the N = 1, 2, 4, 8 series: the strong one divides ONE batch
+        # (bounded below by a 1000-iteration locus per rank), the weak one gives every rank a batch of its own
+        "value_strong": strong["value"], "value_weak": weak["value"],
+        "per_rank_ms": strong.get("per_rank_ms"), "slowest_rank": strong.get("slowest_rank"),
+        "capped_loci_per_rank": strong.get("capped_loci_per_rank"),
         "roofline": roofline,
     }
     if chain_obj is not None:

@@ -94,6 +94,16 @@ def allreduce_max_(tensor):
     return _allreduce_(tensor, dist.ReduceOp.MAX)
 
 
+def gather_values(values, rank, world, device=None):
+    """Every rank hands in a list of numbers; every rank gets the [world][len(values)] table back (a diagnostic that
+    rides on ONE all-reduce(sum) of a zero-padded table: no second collective type, works over RCCL and gloo alike)."""
+    import torch
+    t = torch.zeros((world, len(values)), dtype=torch.float64, device=device)
+    t[rank] = torch.tensor([float(v) for v in values], dtype=torch.float64)
+    allreduce_sum_(t)
+    return t.cpu().numpy()
+
+
 def barrier():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:

@@ -29,6 +29,10 @@ def test_gpus_2_launches_two_ranks_itself():
     assert out["max_over_ranks"] == 2.0 and out["steps"] == 3 and out["warmup"] == 1
     # the headline at N > 1 is BASELINE config 3: ONE problem, loci sharded over the ranks
     assert out["scaling"] == "strong"
+    # ... and the line explains itself: every rank's own time, who was slowest, the 1000-iteration loci per rank, and
+    # the weak value beside the strong one (gathered through the run's own all-reduce)
+    assert out["per_rank_ms"] == [1.0, 2.0] and out["slowest_rank"] == 1 and out["capped_loci_per_rank"] == [0, 10]
+    assert "value_strong" in out and "value_weak" in out
 
 
 def test_world_size_that_differs_from_gpus_fails_loudly():
