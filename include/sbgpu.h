@@ -690,6 +690,11 @@ int sbgpu_quantify_host(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *annot, const
  * sbgpu_destroy) releases it.  Results are those of the unpinned call, bit for bit.                                    */
 int sbgpu_annotation_pin(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *annot);
 int sbgpu_annotation_unpin(sbgpu_ctx_t *ctx);
+/* The owner's form of unpin: releases the context's pin only if it is the pin of THESE arrays (addresses and counts; the
+ * arrays are not read).  Several objects may share a context and each pin its own annotation, the later pin replacing
+ * the earlier: the earlier owner's release must then leave the later pin alone (sbgpu_annotation_unpin would drop it and
+ * every later call would quietly go back to uploading the annotation).  *released (may be NULL): 1 if a pin went.      */
+int sbgpu_annotation_unpin_matching(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *annot, int32_t *released);
 /* The same chain for hits that are in HBM already (a driver that decodes or collapses on the device, or
  * that quantifies the same fragments again): d_hits' arrays and d_hit_mass are DEVICE pointers, grouped by
  * locus as locus_hit_off[n_loci + 1] (host) says and sorted inside a locus like HitCluster's uniq_hits();

@@ -47,7 +47,7 @@ def split_header(bam_bytes):
 def index(rec_bytes):
     """-> int64[n + 1]: where every record starts (and where the stream ends)."""
     b = np.ascontiguousarray(rec_bytes, np.uint8)
-    cap = b.size // 36 + 1
+    cap = b.size // 4 + 1      # the indexer accepts any block_size (a malformed stream comes back as TRUNCATED records, not as an error)
     off = np.zeros(cap + 1, np.int64)
     n = _lib.load().sbgpu_bam_index_host(b.ctypes.data if b.size else None, b.size, off.ctypes.data, cap)
     if n < 0:

@@ -314,9 +314,11 @@ class ChainQuantifier:
         self.unpin()
 
     def unpin(self):
+        """Releases THIS object's pin only: another quantifier on the same context may have pinned its own annotation since
+        (one pin per context, the later replaces the earlier) and must keep it."""
         if getattr(self, "pinned", False):
             self.pinned = False
-            self.ctx.L.sbgpu_annotation_unpin(self.ctx.h)
+            self.ctx.L.sbgpu_annotation_unpin_matching(self.ctx.h, C.byref(self._an), None)
 
     def __enter__(self):
         return self

@@ -108,12 +108,14 @@ struct ResidentAnnotation {
       sample(a->exon_left, n_exon), sample(a->exon_right, n_exon), sample(a->seg_left, n_seg), sample(a->seg_right, n_seg);
       return h;
    }
-   bool matches(const sbgpu_annotation_t *a) const
+   // the pin was made for these arrays (addresses and counts only: the arrays may be gone already -- an owner releasing
+   // ITS pin must not read them, and must not release a pin that another annotation has replaced it with)
+   bool same_arrays(const sbgpu_annotation_t *a) const
    {
       return a && a->n_loci == key.n_loci && a->iso_off == key.iso_off && a->exon_off == key.exon_off && a->exon_left == key.exon_left &&
-             a->exon_right == key.exon_right && a->seg_off == key.seg_off && a->seg_left == key.seg_left && a->seg_right == key.seg_right &&
-             fingerprint(a) == print;
+             a->exon_right == key.exon_right && a->seg_off == key.seg_off && a->seg_left == key.seg_left && a->seg_right == key.seg_right;
    }
+   bool matches(const sbgpu_annotation_t *a) const { return same_arrays(a) && fingerprint(a) == print; }
 };
 const ResidentAnnotation *ctx_resident_annotation(const sbgpu_ctx_t *ctx);
 void ctx_set_resident_annotation(sbgpu_ctx_t *ctx, ResidentAnnotation *r); // takes ownership; frees the one before (nullptr: just that)

@@ -133,10 +133,17 @@ int sbgpu_bam_decode_host(const uint8_t *bytes, int64_t n_bytes, const int64_t *
       };
       std::vector<Part> part(nt);
       for (unsigned t = 0; t < nt; ++t) part[t].r0 = n * t / nt, part[t].r1 = n * (t + 1) / nt;
+      // (a thread that cannot be started -- std::system_error -- must not leave joinable threads behind in a vector
+      // that is being destroyed: its part and the ones after it run on the calling thread, what was started is joined)
       auto run = [&](auto &&fn) {
          std::vector<std::thread> pool;
-         for (unsigned t = 1; t < nt; ++t) pool.emplace_back(fn, t);
+         unsigned started = 1;
+         try {
+            for (; started < nt; ++started) pool.emplace_back(fn, started);
+         } catch (const std::system_error &) {
+         }
          fn(0u);
+         for (unsigned t = started; t < nt; ++t) fn(t);
          for (std::thread &th : pool) th.join();
       };
       run([&](unsigned t) {
@@ -256,9 +263,18 @@ int sbgpu_bam_decode_device(sbgpu_ctx_t *c, const uint8_t *d_bytes, int64_t n_by
    int stage_bytes = 8 * 1024;
    while (stage_bytes < 64 * 1024 && (int64_t)stage_bytes < 70 * (n_bytes / n + 1)) stage_bytes += 2 * 1024;
    if (stage_kb_env > 0) stage_bytes = std::min(64, std::max(1, stage_kb_env)) * 1024;
+   // what a workgroup may ask for on this device, less the kernel's static words; a launch that is refused all the same
+   // is repeated without the buffer (the kernel then walks every record in global memory: slower, same results)
+   int lds_max = 0;
+   if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, sb::ctx_device(c)) != hipSuccess || lds_max <= 0) lds_max = 64 * 1024;
+   stage_bytes = std::max(0, std::min(stage_bytes, lds_max - 256));
    const int resident = std::max(1, std::min(16, (int)(160 * 1024 / (stage_bytes + 256))));
    const int64_t scan_blocks = std::min<int64_t>((n + 63) / 64, (int64_t)sb::ctx_cu_count(c) * resident * 4);
    hipLaunchKernelGGL(sb::bam_scan_kernel, dim3((unsigned)scan_blocks), dim3(64), (size_t)stage_bytes, s, a, stage_bytes);
+   if (hipGetLastError() != hipSuccess && stage_bytes > 0) {
+      stage_bytes = 0;
+      hipLaunchKernelGGL(sb::bam_scan_kernel, dim3((unsigned)scan_blocks), dim3(64), 0, s, a, 0);
+   }
    SB_TRY(hipGetLastError());
    size_t tb = tmp_bytes;
    SB_TRY(rocprim::exclusive_scan(w + o_tmp, tb, rocprim::make_transform_iterator((const uint8_t *)a.accepted, as_i64_u8), (int64_t *)(w + o_rat), (int64_t)0, n1, rocprim::plus<int64_t>(), s));

@@ -643,6 +643,16 @@ int sbgpu_annotation_unpin(sbgpu_ctx_t *c)
    return SBGPU_OK;
 }
 
+int sbgpu_annotation_unpin_matching(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, int32_t *released)
+{
+   if (!c || !an) return api_fail(SBGPU_EINVAL, "sbgpu_annotation_unpin_matching: null argument");
+   const sb::ResidentAnnotation *res = sb::ctx_resident_annotation(c);
+   const bool mine = res && res->same_arrays(an);
+   if (mine) sb::ctx_set_resident_annotation(c, nullptr);
+   if (released) *released = mine ? 1 : 0;
+   return SBGPU_OK;
+}
+
 int sbgpu_quantify_device(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgpu_hits_t *d_hits, const float *d_hit_mass,
                           const int64_t *locus_hit_off, const sbgpu_insert_t *insert, int32_t read_len, int32_t long_read,
                           double *theta_out, int32_t *status_out, int32_t *iters_out, sbgpu_bins_t **bins_out)

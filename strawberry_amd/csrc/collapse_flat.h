@@ -106,9 +106,11 @@ __global__ __launch_bounds__(256) void flat_keys_kernel(FlatCollapseArgs f)
       if (sl >= 0) sum += (unsigned long long)sl, sum2 += (unsigned long long)sl * (unsigned long long)sl, ++nm;
       if (sr >= 0) sum += (unsigned long long)sr, sum2 += (unsigned long long)sr * (unsigned long long)sr, ++nm;
       if (sl >= (1 << 24) || sr >= (1 << 24)) need |= kNeedSeqSd; // (S2 could leave 64 bits)
-      // a mass that is a multiple of 2^-20 below 2^31: sums of up to 2^31 of them are exact whatever the order
+      // a mass that is a multiple of 2^-20 and at most 2 (the reference's are 1 / NH and 0.5 / NH): sums of up to 2^31 of
+      // them stay below 2^32 in units of 2^-20 -- 52 bits -- so every partial sum is exact whatever the order.  Anything
+      // else (a caller's own masses) takes the running sums in the reference's order
       const double m = a.pair_mass[p], m20 = m * 1048576.0;
-      if (!(m >= 0.0 && m < 2147483648.0 && m20 == (double)(unsigned long long)m20)) need |= kNeedSeqMass;
+      if (!(m >= 0.0 && m <= 2.0 && m20 == (double)(unsigned long long)m20)) need |= kNeedSeqMass;
       if (need) atomicOr(&f.cl_flags[l], need);
    }
    if (bad) atomicOr(a.flags, bad);

@@ -62,7 +62,7 @@ const Rccl &rccl()
       g_rccl.CommInitRank = (int (*)(RcclComm *, int, RcclUniqueId, int))sym("ncclCommInitRank");
       g_rccl.AllReduce = (int (*)(const void *, void *, size_t, int, int, RcclComm, hipStream_t))sym("ncclAllReduce");
       g_rccl.CommDestroy = (int (*)(RcclComm))sym("ncclCommDestroy");
-      g_rccl.CommCount = (int (*)(RcclComm, int *))sym("ncclCommCount");
+      g_rccl.CommCount = (int (*)(RcclComm, int *))dlsym(g_rccl.lib, "ncclCommCount"); // optional: only sbgpu_comm_rccl_ranks asks
       g_rccl.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
    });
    return g_rccl;

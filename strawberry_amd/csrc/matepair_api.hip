@@ -294,28 +294,8 @@ int sbgpu_pair_mates_device(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t 
    if (nr < 0 || locus_read_off[0] != 0 || locus_read_off[n_loci] != nr) return api_fail(SBGPU_EINVAL, "sbgpu_pair_mates_device: locus_read_off does not cover the reads");
    if (nr && (!dr->read_id || !dr->block_off || !dr->block_left || !dr->block_right || !dr->partner_pos || !dr->flags || !dr->nh))
       return api_fail(SBGPU_EINVAL, "sbgpu_pair_mates_device: null device pointer");
-   // clusters the LDS sort does not hold (more than 8192 records) get a workgroup of their own with the sort's arrays in
-   // global scratch (matepair_big_kernel), the biggest first
-   std::vector<int32_t> big_loci;
-   std::vector<int64_t> big_off(1, 0);
-   for (int64_t l = 0; l < n_loci; ++l) {
+   for (int64_t l = 0; l < n_loci; ++l)
       if (locus_read_off[l + 1] < locus_read_off[l]) return api_fail(SBGPU_EINVAL, "sbgpu_pair_mates_device: locus_read_off must ascend");
-      const int64_t n = locus_read_off[l + 1] - locus_read_off[l];
-      if (n <= sb::kMateMaxReads) continue;
-      if (n > (int64_t)1 << 24)
-         return api_fail(SBGPU_EUNSUPPORTED, "sbgpu_pair_mates_device: not covered by the device form: a cluster has more than 2^24 records; use sbgpu_pair_mates_host");
-      big_loci.push_back((int32_t)l);
-   }
-   std::sort(big_loci.begin(), big_loci.end(), [&](int32_t x, int32_t y) {
-      const int64_t nx = locus_read_off[x + 1] - locus_read_off[x], ny = locus_read_off[y + 1] - locus_read_off[y];
-      return nx != ny ? nx > ny : x < y;
-   });
-   for (int32_t l : big_loci) {
-      int64_t n2 = 1;
-      while (n2 < locus_read_off[l + 1] - locus_read_off[l]) n2 <<= 1;
-      big_off.push_back(big_off.back() + n2);
-   }
-   const size_t n_big = big_loci.size(), big_elems = (size_t)big_off.back();
    hipStream_t s = (hipStream_t)stream;
    sbgpu_matepairs *M = new (std::nothrow) sbgpu_matepairs();
    if (!M) return api_fail(SBGPU_ENOMEM, "sbgpu_pair_mates_device: out of host memory");
@@ -350,6 +330,28 @@ int sbgpu_pair_mates_device(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t 
       *out = M;
       return SBGPU_OK;
    }
+   // ---- round 3's per-cluster form (the flat form above has no limit per cluster)
+   // clusters the LDS sort does not hold (more than 8192 records) get a workgroup of their own with the sort's arrays in
+   // global scratch (matepair_big_kernel), the biggest first
+   std::vector<int32_t> big_loci;
+   std::vector<int64_t> big_off(1, 0);
+   for (int64_t l = 0; l < n_loci; ++l) {
+      const int64_t n = locus_read_off[l + 1] - locus_read_off[l];
+      if (n <= sb::kMateMaxReads) continue;
+      if (n > (int64_t)1 << 24)
+         return bail(SBGPU_EUNSUPPORTED, "sbgpu_pair_mates_device: not covered by the per-cluster form (SBGPU_PAIR_PER_LOCUS): a cluster has more than 2^24 records");
+      big_loci.push_back((int32_t)l);
+   }
+   std::sort(big_loci.begin(), big_loci.end(), [&](int32_t x, int32_t y) {
+      const int64_t nx = locus_read_off[x + 1] - locus_read_off[x], ny = locus_read_off[y + 1] - locus_read_off[y];
+      return nx != ny ? nx > ny : x < y;
+   });
+   for (int32_t l : big_loci) {
+      int64_t n2 = 1;
+      while (n2 < locus_read_off[l + 1] - locus_read_off[l]) n2 <<= 1;
+      big_off.push_back(big_off.back() + n2);
+   }
+   const size_t n_big = big_loci.size(), big_elems = (size_t)big_off.back();
    SB_TRY(hipSetDevice(M->device));
    const size_t nr1 = (size_t)nr, nl1 = (size_t)n_loci + 1;
    size_t off = 0;

@@ -20,6 +20,19 @@ REF_PROGRAMS = ("libstrawberry_ref.so", "strawberry_ref", "strawberry_sbgpu", "s
                 "strawberry_sbgpu_chain", "strawberry_sbgpu_front", "strawberry_dump", "sam2bam")
 
 
+def _ref_half_shipped():
+    """libstrawberry_ref.so is there (the tree carries a built oracle/_ref) but some of its programs are not."""
+    return os.path.exists(os.path.join(REF_DIR, "libstrawberry_ref.so")) and not all(
+        os.path.exists(os.path.join(REF_DIR, f)) for f in REF_PROGRAMS)
+
+
+# A tree that carries oracle/_ref must carry ALL of it: where the reference library is present at collection time the
+# tests that need any of its files FAIL instead of skipping (a half-shipped _ref would otherwise lose tests quietly).
+# A clean checkout (no _ref at all) still skips them, and says so in the header.
+if os.path.exists(os.path.join(REF_DIR, "libstrawberry_ref.so")):
+    os.environ.setdefault("SBGPU_REQUIRE_REF", "1")
+
+
 def pytest_report_header(config):
     """Says up front whether the compiled reference (oracle/_ref: git-ignored, built only where /root/reference exists,
     carried to the GPU box with the tree) is there -- the tests that link or run it skip without it, and a run on a
@@ -28,7 +41,9 @@ def pytest_report_header(config):
     miss = [f for f in REF_PROGRAMS if f not in have]
     line = "oracle/_ref (the reference compiled from its own sources): %d of %d files present" % (len(have), len(REF_PROGRAMS))
     if miss:
-        line += "; MISSING " + ", ".join(miss) + " -> the tests against the reference itself will SKIP (goldens and the oracle still run)"
+        line += "; MISSING " + ", ".join(miss) + (" -> the tests that need them will FAIL (SBGPU_REQUIRE_REF=1: the reference library "
+                                                  "is here, so the rest of oracle/_ref must be)" if os.environ.get("SBGPU_REQUIRE_REF") == "1" else
+                                                  " -> the tests against the reference itself will SKIP (goldens and the oracle still run)")
     return [line]
 
 

@@ -652,6 +652,29 @@ def test_pinned_annotation_gives_the_unpinned_results():
     np.testing.assert_array_equal(b.theta[:b.n_iso], want[0])
 
 
+@pytest.mark.gpu
+def test_a_quantifier_releases_only_its_own_pin():
+    """One pin per context: a second quantifier's pin replaces the first one's.  The first owner's release (close / unpin /
+    garbage collection) must then leave the second pin alone -- sbgpu_annotation_unpin would drop it, and every later step
+    would quietly go back to uploading the annotation."""
+    import ctypes as C
+    from strawberry_amd import chain, em
+    ctx = em.default_context(0)
+    a = chain.ChainQuantifier(ctx, n_loci=120, n_frags=120 * 100, seed=3, pin=True)
+    b = chain.ChainQuantifier(ctx, n_loci=150, n_frags=150 * 100, seed=4, pin=True)      # replaces a's pin
+    b.step()
+    want = b.theta.copy()
+    a.close()                                                                              # must not touch b's pin
+    released = C.c_int32(-1)
+    assert ctx.L.sbgpu_annotation_unpin_matching(ctx.h, C.byref(a._an), C.byref(released)) == 0 and released.value == 0
+    b.step()
+    np.testing.assert_array_equal(b.theta, want)
+    assert ctx.L.sbgpu_annotation_unpin_matching(ctx.h, C.byref(b._an), C.byref(released)) == 0 and released.value == 1   # it was still there
+    b.pinned = False
+    b.step()
+    np.testing.assert_array_equal(b.theta, want)
+
+
 def test_segment_basis_128_bit_form(ctx, oracle):
     """Loci of 65-128 segments or isoforms take the segment basis with 128-bit masks in a kernel of their own
     (exonbin_seg128_kernel, launched behind exonbin_kernel when the annotation's words go beyond two); beyond 128 the exon
