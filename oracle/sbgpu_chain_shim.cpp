@@ -12,7 +12,9 @@
 // No LocusContext is ever built: bins and weights are 45 % of the reference's quantification time.
 //
 // tests/test_reference_driver_gpu.py: its files equal the reference binary's byte for byte; tools/dropin_timing.py times it.
-// Not covered (the program says so and stops): -b (the -f table's sequence columns need the chromosome's bases per bin).
+// -b genome.fa (round 5): the chromosomes' bases come from the reference's own FaSeqGetter (Sample::load_chrom_fasta,
+// alignments.cpp:811-819, as its loop does at :1763-1779); the six sequence columns of the -f table (alignments.cpp:1622-1636)
+// are the library's -- sbgpu_binseq_host for all bins of a chromosome at once, sbgpu_format_context_row_seq per row.
 #include "alignments.h" // the reference's: /root/reference/include/alignments.h:178-290 (Sample)
 #include "estimate.hpp"
 
@@ -40,10 +42,6 @@ struct Locus {
 // replaces /root/reference/src/alignments.cpp:1736-1834
 void Sample::procSample(FILE *pfile, FILE *plogfile, FILE *fragfile)
 {
-   if (BIAS_CORRECTION) {
-      std::fprintf(stderr, "strawberry_sbgpu_chain: -b is not covered by this driver (use strawberry_sbgpu_batched)\n");
-      std::exit(2);
-   }
    using clk = std::chrono::steady_clock;
    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
    const clk::time_point t_begin = clk::now();
@@ -62,10 +60,18 @@ void Sample::procSample(FILE *pfile, FILE *plogfile, FILE *fragfile)
    std::vector<Locus> loci;
    std::vector<uint8_t> code;
    std::vector<uint32_t> fl, fr;
+   // -b: every chromosome's bases, loaded when the clusters reach it (the reference's loop: alignments.cpp:1763-1779)
+   std::map<RefID, std::string> chrom_seq;
    while (true) {
       std::shared_ptr<HitCluster> cluster(new HitCluster());
       if (-1 == nextClusterRefDemand(*cluster)) break;
       if (cluster->ref_id() == -1) continue;
+      if (BIAS_CORRECTION && !chrom_seq.count(cluster->ref_id())) {
+         load_chrom_fasta(cluster->ref_id());
+         const uint n = _fasta_getter->loadSeq(); // (the number of bases it holds now)
+         std::string &seq = chrom_seq[cluster->ref_id()];
+         for (uint at = 1; at <= n; at += 1u << 20) seq += _fasta_getter->fetchSeq(at, std::min<uint>(1u << 20, n - at + 1)); // (fetchSeq builds its answer on the stack)
+      }
       finalizeCluster(cluster, true);
       Locus lc = {cluster->ref_id(), cluster->left(), cluster->right(), cluster->ref_mRNAs()};
       std::vector<std::vector<std::pair<uint32_t, uint32_t>>> tx;
@@ -96,19 +102,25 @@ void Sample::procSample(FILE *pfile, FILE *plogfile, FILE *fragfile)
 
    // ---- solve: bins, weights and the EM of all loci in ONE call; the reference's epilogue arithmetic (LocusBatch::quantify)
    sbgpu::InsertSize ins;
-   ins.mean = _insert_size_dist->_mean;
-   ins.sd = _insert_size_dist->_sd;
-   ins.use_emp = _insert_size_dist->_use_emp;
-   ins.start_offset = _insert_size_dist->_start_offset;
-   ins.end_offset = _insert_size_dist->_end_offset;
-   ins.total_reads = _insert_size_dist->_total_reads;
-   ins.emp_dist = _insert_size_dist->_emp_dist;
+   // (a long-read sample has no insert-size law -- main never makes one, Strawberry.cpp:338-353 -- and needs none: its
+   // bin weights are 1 / L_j, estimate.cpp:236-247; the library is handed a placeholder it does not read)
+   if (_insert_size_dist) {
+      ins.mean = _insert_size_dist->_mean;
+      ins.sd = _insert_size_dist->_sd;
+      ins.use_emp = _insert_size_dist->_use_emp;
+      ins.start_offset = _insert_size_dist->_start_offset;
+      ins.end_offset = _insert_size_dist->_end_offset;
+      ins.total_reads = _insert_size_dist->_total_reads;
+      ins.emp_dist = _insert_size_dist->_emp_dist;
+   } else {
+      ins.mean = 200.0, ins.sd = 80.0;
+   }
    sbgpu_abundance_params_t par = {};
    par.total_mapped_reads = total_mapped_reads();
    par.filter_by_expression = filter_by_expression ? 1 : 0;
    par.min_isoform_frac = kMinIsoformFrac;
    par.effective_len_norm = effective_len_norm ? 1 : 0;
-   par.insert_mean = _insert_size_dist->_mean;
+   par.insert_mean = _insert_size_dist ? _insert_size_dist->_mean : 0.0;
    if (batch.n_loci() > 0)
       batch.quantify(device_context(), &ins, _hit_factory->_reads_table.read_len_mode(), par, long_read_sample);
    const clk::time_point t_solved = clk::now();
@@ -138,6 +150,36 @@ void Sample::procSample(FILE *pfile, FILE *plogfile, FILE *fragfile)
          last_hit[(size_t)b] = h;
          ++n_in_bin[(size_t)b];
       }
+   // -b: GC ratio, hexamer entropy and the four high-GC-stretch flags of every bin's sequence (its segments' bases in
+   // order: ExonBin::bin_dnaseq, isoform.h:173-182), a chromosome's bins in one sbgpu_binseq_host call
+   std::vector<double> bin_gc((size_t)n_bins, 0.0), bin_entropy((size_t)n_bins, 0.0);
+   std::vector<uint8_t> bin_flags((size_t)n_bins, 0);
+   if (BIAS_CORRECTION && fragfile != NULL) {
+      for (int64_t l0 = 0; l0 < batch.n_loci();) {
+         int64_t l1 = l0;
+         while (l1 < batch.n_loci() && loci[(size_t)l1].ref_id == loci[(size_t)l0].ref_id) ++l1;
+         const std::string &seq = chrom_seq[loci[(size_t)l0].ref_id];
+         const int64_t b0 = batch.row_off[(size_t)l0], b1 = batch.row_off[(size_t)l1];
+         std::vector<int64_t> off(1, 0);
+         std::vector<uint32_t> sl, sr;
+         for (int64_t l = l0; l < l1; ++l) {
+            const int64_t s0 = batch.seg_off[(size_t)l], nseg = batch.seg_off[(size_t)l + 1] - s0;
+            for (int64_t b = batch.row_off[(size_t)l]; b < batch.row_off[(size_t)l + 1]; ++b) {
+               for (int64_t s2 = 0; s2 < nseg; ++s2)
+                  if ((batch.bin_key[(size_t)(b * batch.key_words + (s2 >> 5))] >> (s2 & 31)) & 1u) {
+                     sl.push_back(batch.seg_left[(size_t)(s0 + s2)]);
+                     sr.push_back(batch.seg_right[(size_t)(s0 + s2)]);
+                  }
+               off.push_back((int64_t)sl.size());
+            }
+         }
+         if (b1 > b0)
+            sbgpu::check(sbgpu_binseq_host(device_context().get(), (const uint8_t *)seq.data(), 1, (int64_t)seq.size(), b1 - b0, off.data(),
+                                           sl.data(), sr.data(), bin_gc.data() + b0, bin_entropy.data() + b0, bin_flags.data() + b0),
+                         "sbgpu_binseq_host");
+         l0 = l1;
+      }
+   }
    for (int64_t l = 0; l < batch.n_loci(); ++l) {
       const Locus &lc = loci[(size_t)l];
       if (batch.status[(size_t)l] == SBGPU_EM_INIT_EMPTY) continue; // estimate_abundances() false: the locus is omitted
@@ -187,9 +229,14 @@ void Sample::procSample(FILE *pfile, FILE *plogfile, FILE *fragfile)
             sl.push_back(c.first);
             sr.push_back(c.second);
          }
-         const int n = sbgpu_format_context_row(buf.data(), (int)buf.size(), sample.c_str(), total_mapped_reads(), gene.c_str(), gene_frags,
-                                                (int)kept.size(), names.data(), fpkm.data(), prob.data(), frac.data(), (int)sl.size(),
-                                                sl.data(), sr.data(), (uint32_t)n_in_bin[(size_t)b]);
+         const int n = BIAS_CORRECTION
+                          ? sbgpu_format_context_row_seq(buf.data(), (int)buf.size(), sample.c_str(), total_mapped_reads(), gene.c_str(), gene_frags,
+                                                         (int)kept.size(), names.data(), fpkm.data(), prob.data(), frac.data(), (int)sl.size(),
+                                                         sl.data(), sr.data(), (uint32_t)n_in_bin[(size_t)b], bin_gc[(size_t)b],
+                                                         bin_entropy[(size_t)b], bin_flags[(size_t)b])
+                          : sbgpu_format_context_row(buf.data(), (int)buf.size(), sample.c_str(), total_mapped_reads(), gene.c_str(), gene_frags,
+                                                     (int)kept.size(), names.data(), fpkm.data(), prob.data(), frac.data(), (int)sl.size(),
+                                                     sl.data(), sr.data(), (uint32_t)n_in_bin[(size_t)b]);
          sbgpu::check(n, "sbgpu_format_context_row");
          std::fwrite(buf.data(), 1, (size_t)n, fragfile);
       }

@@ -339,19 +339,25 @@ void Sample::procSample(FILE *pfile, FILE *plogfile, FILE *fragfile)
    const std::vector<Locus> &loci = F.loci;
    // ---- solve: bins, weights and the EM of all loci in ONE call; the reference's epilogue arithmetic (LocusBatch::quantify)
    sbgpu::InsertSize ins;
-   ins.mean = _insert_size_dist->_mean;
-   ins.sd = _insert_size_dist->_sd;
-   ins.use_emp = _insert_size_dist->_use_emp;
-   ins.start_offset = _insert_size_dist->_start_offset;
-   ins.end_offset = _insert_size_dist->_end_offset;
-   ins.total_reads = _insert_size_dist->_total_reads;
-   ins.emp_dist = _insert_size_dist->_emp_dist;
+   // (a long-read sample has no insert-size law -- main never makes one, Strawberry.cpp:338-353 -- and needs none: its
+   // bin weights are 1 / L_j, estimate.cpp:236-247; the library is handed a placeholder it does not read)
+   if (_insert_size_dist) {
+      ins.mean = _insert_size_dist->_mean;
+      ins.sd = _insert_size_dist->_sd;
+      ins.use_emp = _insert_size_dist->_use_emp;
+      ins.start_offset = _insert_size_dist->_start_offset;
+      ins.end_offset = _insert_size_dist->_end_offset;
+      ins.total_reads = _insert_size_dist->_total_reads;
+      ins.emp_dist = _insert_size_dist->_emp_dist;
+   } else {
+      ins.mean = 200.0, ins.sd = 80.0;
+   }
    sbgpu_abundance_params_t par = {};
    par.total_mapped_reads = total_mapped_reads();
    par.filter_by_expression = filter_by_expression ? 1 : 0;
    par.min_isoform_frac = kMinIsoformFrac;
    par.effective_len_norm = effective_len_norm ? 1 : 0;
-   par.insert_mean = _insert_size_dist->_mean;
+   par.insert_mean = _insert_size_dist ? _insert_size_dist->_mean : 0.0;
    if (batch.n_loci() > 0)
       batch.quantify(device_context(), &ins, _hit_factory->_reads_table.read_len_mode(), par, long_read_sample);
    const clk::time_point t_solved = clk::now();
