@@ -46,6 +46,10 @@ WORKLOADS = {
                 "(log-normal share per locus, expression per isoform, N(250,30) fragments, 10% pairs that fit fewer isoforms or none), "
                 "resident in HBM, through fragment x isoform compatibility + bin keys -> bins -> (bin, isoform) pairs -> bin weights "
                 "-> EM -> theta (sbgpu_quantify_device)",
+    "c3-front": "C3-scale, records -> theta: the BAM alignment records of the c3-chain sample's read pairs (two records per pair, "
+                "~170 bytes each: the uncompressed stream behind a BAM file's header, coordinate-sorted) resident in HBM, through "
+                "sbgpu_bam_decode_device -> sbgpu_assign_reads_device -> sbgpu_pair_mates_device -> sbgpu_collapse_pairs_device -> "
+                "sbgpu_quantify_device; only cluster offsets and theta come back to the host",
     "c5": "C5 synthetic: the C3 law at 4e8 fragments, bias factors 2^U(-1,1) on the weights; fp32 variant of the EM "
           "timed next to the fp64 path (tolerance sweep: tools/c5_sweep.py)",
 }
@@ -330,6 +334,73 @@ def chain_main(args, ctx, dev, rank, world, sdist, torch, launch):
         raise SystemExit("bench.py: the chain's theta does not match the reference program's: %r" % c["parity"])
 
 
+def front_main(args, ctx, dev, rank, world, sdist, torch, launch):
+    """--workload c3-front: alignment records in HBM -> theta, every stage of SURVEY 8(f) rank 4 in front of the chain
+    (strawberry_amd/front.py).  A step = one pass over ALL records of the sample.  Size: SB_FRONT_LOCI / SB_FRONT_FRAGS
+    (default: the chain sample, 60 000 loci / 2e8 read pairs = ~3.9e8 records, ~66 GB of record bytes)."""
+    from strawberry_amd import front
+    if world > 1:
+        raise SystemExit("bench.py --workload c3-front is a one-GPU line (the stages shard by cluster like the chain; not wired up)")
+    n_loci = int(float(os.environ.get("SB_FRONT_LOCI", "60000")))
+    n_frags = float(os.environ.get("SB_FRONT_FRAGS", "2e8"))
+    q = front.FrontQuantifier(ctx, n_loci=n_loci, n_frags=n_frags, seed=31)
+    torch.cuda.empty_cache()      # the packer's temporaries go back to the driver: the library allocates for itself
+    wall, _ = timed_steps(q, args.steps, args.warmup, dev, sdist, torch)
+    ms = wall / args.steps * 1e3
+    probe = []
+    for _ in range(3):
+        q.step()
+        probe.append(dict(q.stage_wall_ms))
+    stage = {k: float(np.median([p[k] for p in probe])) for k in front.FrontQuantifier.STAGES}
+    chain_stage = q.stage_ms()    # the chain's kernels inside the last stage (HIP events)
+    with_chain = q.compare_with_chain()
+    c = q.counts
+    n_rec, acc, feats = c["records"], c["accepted_records"], c["features"]
+    blocks = acc * 1.3
+    # algorithmic bytes per stage: what each must read and write once
+    alg = {
+        "bam_decode": q.n_bytes + 8.0 * (n_rec + 1) + n_rec + acc * (8 + 8 + 4 * 8 + 1 + 8) + blocks * 8,
+        "assign_reads": acc * (4 + 4 + 4 + 1 + 4 + 1),
+        "pair_mates": acc * (8 + 8 + 4 + 1 + 4) + blocks * 8 + (acc / 2) * (8 + 16) + blocks * 2 * 9.0,
+        "collapse_pairs": (acc / 2) * (8 + 16) + blocks * 2 * 9.0 + c["unique_hits"] * (4 + 8 + 4) + feats * 9.0,
+        "quantify": 9.0 * feats + q.n_hits * (24.0 + 4.0 * (q.annot.compat_words + q.annot.key_words)),   # its exon-bin kernel's bytes (DESIGN 3.5)
+    }
+    dom = max(stage, key=lambda k: stage[k])
+    ach = alg[dom] / (stage[dom] * 1e-3) / 1e9
+    roof = {"bound": "hbm", "kernel": "sbgpu_%s%s (whole call: its kernels, device-wide sorts and scans, and the host synchronisations between them)" % (
+                dom, "" if dom == "quantify" else "_device"),
+            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "traffic_note": "no counter pass for this stage yet", "stage_ms": stage[dom], "algorithmic_bytes": int(alg[dom]),
+            "per_stage": {k: {"ms": stage[k], "algorithmic_bytes": int(alg[k]), "GBps": alg[k] / (stage[k] * 1e-3) / 1e9,
+                              "frac": alg[k] / (stage[k] * 1e-3) / 1e9 / HBM_PEAK_GBS} for k in stage},
+            "note": "stage times are wall clock around synchronised calls (every stage's totals size the next one's arrays)"}
+    out = {
+        "metric": "loci/s and G records/s, BAM alignment records -> abundances (C3-scale)", "value": q.n_loci * args.steps / wall,
+        "unit": "loci/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u8 records, u32 intervals, f64", "data": "synthetic",
+        "grecords_per_s": n_rec * args.steps / wall / 1e9, "mfrags_per_s": q.n_frags * args.steps / wall / 1e6,
+        "config": {"workload": WORKLOADS["c3-front"], "loci": q.n_loci, "read_pairs": q.n_frags, "records": n_rec,
+                   "record_bytes": q.n_bytes, "bytes_per_record": q.n_bytes / max(n_rec, 1), "unique_hits": c["unique_hits"],
+                   "records_packed_in_s": q.pack_s},
+        "launch": launch, "stage_ms": stage, "stages_sum_ms": float(sum(stage.values())),
+        "chain_kernel_ms": chain_stage, "shape": q.info, "counts": c,
+        "em_status": {"ok": int((q.status[:q.n_loci] == 0).sum()), "init_empty": int((q.status[:q.n_loci] == 1).sum()),
+                      "denom_zero": int((q.status[:q.n_loci] == 2).sum()), "maxiter": int((q.status[:q.n_loci] == 3).sum()),
+                      "mean_iters": float(q.iters[:q.n_loci].mean())},
+        "roofline": roof,
+        "parity_with_chain": dict(with_chain, what="theta / status / iterations of the records -> theta pass against sbgpu_quantify_device on the "
+                                  "sample's own unique hits (c3-chain), locus by locus: bit for bit wherever the reference's span filter "
+                                  "(alignments.cpp:666-682) dropped no pair", unique_hits_front=c["unique_hits"], unique_hits_sample=q.n_hits),
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"], out["parity"] = chain_cpu_baseline(q)
+    print(json.dumps(out))
+    if not with_chain["ok"]:
+        raise SystemExit("bench.py: the records -> theta pass does not reproduce the chain's theta on the same sample")
+    if out.get("parity") and not out["parity"]["ok"]:
+        raise SystemExit("bench.py: theta does not match the reference program's: %r" % out["parity"])
+
+
 def self_launch(args):
     """`--gpus N` (N > 1) without a torchrun environment: start the N ranks ourselves, one process per GPU, with the
     driver's own command line (`python -m torch.distributed.run --nproc-per-node N bench.py ...`).  This process has
@@ -439,6 +510,8 @@ def main():
 
     if args.workload == "c3-chain":
         return chain_main(args, ctx, dev, rank, world, sdist, torch, launch)
+    if args.workload == "c3-front":
+        return front_main(args, ctx, dev, rank, world, sdist, torch, launch)
 
     def make_quant(b, f32=False, solver=None):
         solver = solver or em.EmBatchSolver(b, ctx)

@@ -1,0 +1,238 @@
+"""Records -> theta in one resident pass: the BAM alignment records of the chain sample in HBM, then
+
+    sbgpu_bam_decode_device      BAMHitFactory::getHitFromBuf            /root/reference/src/read.cpp:480-715
+    sbgpu_assign_reads_device    Sample::nextClusterRefDemand            /root/reference/src/alignments.cpp:1145-1187
+    sbgpu_pair_mates_device      HitCluster::addOpenHit / addHit         /root/reference/src/alignments.cpp:423-655
+    sbgpu_collapse_pairs_device  HitCluster::collapseAndFilterHits       /root/reference/src/alignments.cpp:656-703
+    sbgpu_quantify_device        Sample::quantifyCluster (bins, weights, EM)  alignments.cpp:1510-1546
+
+every stage handing its device arrays to the next; only per-cluster offsets and theta come back to the host.
+
+The record stream is synthetic (bench.py: `data: synthetic`): every read pair behind the chain sample's unique hits
+(strawberry_amd/chain.py::DeviceSample) gets its two BAM records -- the uncompressed records behind the BAM header, as
+samtools' bam_read1 sees them after BGZF inflate -- packed on the device with torch index arithmetic (4e8 records are
+~70 GB that never exist in host memory), sorted by position like a coordinate-sorted BAM.  Plumbing, not product: the
+library never sees how the bytes were made.
+"""
+import ctypes as C
+import time
+
+import numpy as np
+
+from . import _lib
+from . import bam
+from . import exonbin as eb
+from .chain import ChainQuantifier
+
+_FIXED = 36          # block_size + the 32 bytes of fixed fields behind it
+_NAME = 11           # "r%09d" + NUL
+
+
+def pack_bam_records(torch, s, read_len=75, chunk=1 << 21):
+    """DeviceSample -> (bytes uint8 [total], rec_off int64 [n_records + 1]) on the sample's device.
+
+    A unique hit of mass m stands for m read pairs: 2 m records (flag 99 at the left mate's start, 147 at the right
+    mate's), named r%09d by pair, CIGAR = the mate's blocks as M with N between, NH:i:1, XS:A:+, 75 bases of sequence and
+    qualities (never looked at by the decoder, but they are what a record is mostly made of); records in (position, left
+    before right) order, stable."""
+    dev = s.feat_off.device
+    H = s.n_hits
+    code = s.feat_code
+    gap_idx = torch.nonzero(code == eb.GAP).reshape(-1)
+    assert int(gap_idx.numel()) == H, "every hit of the chain sample holds exactly one GAP (paired-end hits)"
+    f0 = s.feat_off[:-1]
+    nbl = (gap_idx - f0 + 1) // 2                          # MATCH blocks of the left mate (M, I, M, ... : 2 nb - 1 features)
+    nbr = (s.feat_off[1:] - gap_idx) // 2
+    fleft, fright = s.feat_left.to(torch.int64), s.feat_right.to(torch.int64)
+    cnt = s.mass.to(torch.int64)
+    P = int(cnt.sum().item())
+    pair_hit = torch.repeat_interleave(torch.arange(H, device=dev), cnt)
+    lpos, rpos = fleft[f0][pair_hit], fleft[gap_idx + 1][pair_hit]
+    # the fragment's last base (the right mate's last block's end) for TLEN
+    frag_end = fright[s.feat_off[1:] - 1][pair_hit]
+    n = 2 * P
+    rec_pos = torch.stack([lpos, rpos], 1).reshape(-1)
+    order = torch.argsort(rec_pos * 2 + torch.tensor([0, 1], device=dev).repeat(P), stable=True)
+    del rec_pos
+    rec_pair = order >> 1
+    rec_right = (order & 1).to(torch.bool)
+    del order
+    rec_hit = pair_hit[rec_pair]
+    nb = torch.where(rec_right, nbr[rec_hit], nbl[rec_hit])
+    first_feat = torch.where(rec_right, gap_idx[rec_hit] + 1, f0[rec_hit])
+    tail = (read_len + 1) // 2 + read_len + 8               # sequence, qualities, NH:i:1 (4 bytes as NH C 1), XS:A:+ (4 bytes)
+    rec_len = _FIXED + _NAME + 4 * (2 * nb - 1) + tail
+    rec_off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(rec_len, 0, out=rec_off[1:])
+    total = int(rec_off[-1].item())
+    buf = torch.empty(total, dtype=torch.uint8, device=dev)
+    max_nb = int(nb.max().item()) if n else 1
+
+    def le32(rows, col, v):
+        for k in range(4):
+            rows[:, col + k] = ((v >> (8 * k)) & 0xFF).to(torch.uint8)
+
+    templates = {}
+    for b in range(1, max_nb + 1):
+        L = _FIXED + _NAME + 4 * (2 * b - 1) + tail
+        t = np.zeros(L, np.uint8)
+        t[0:4] = np.frombuffer(np.int32(L - 4).tobytes(), np.uint8)
+        t[12] = _NAME
+        t[13] = 255                                        # MAPQ
+        t[20:24] = np.frombuffer(np.int32(read_len).tobytes(), np.uint8)
+        t[36] = ord("r")
+        c = _FIXED + _NAME + 4 * (2 * b - 1)
+        t[c:c + (read_len + 1) // 2] = 0x11                # AAAA...
+        c += (read_len + 1) // 2
+        t[c:c + read_len] = 40
+        c += read_len
+        t[c:c + 8] = np.frombuffer(b"NHC\x01XSA+", np.uint8)
+        templates[b] = torch.from_numpy(t).to(dev)
+    for a in range(0, n, chunk):
+        z = min(n, a + chunk)
+        nb_c = nb[a:z]
+        for b in range(1, max_nb + 1):
+            sel = torch.nonzero(nb_c == b).reshape(-1) + a
+            m = int(sel.numel())
+            if m == 0:
+                continue
+            L = int(templates[b].numel())
+            rows = templates[b].repeat(m, 1)
+            right = rec_right[sel]
+            pr = rec_pair[sel]
+            ff = first_feat[sel]
+            le32(rows, 8, fleft[ff] - 1)                                                   # pos (0-based)
+            le32(rows, 16, torch.where(right, 147, 99).to(torch.int64) * 65536 + (2 * b - 1))   # flag << 16 | n_cigar_op
+            le32(rows, 28, torch.where(right, lpos[pr], rpos[pr]) - 1)                     # next_pos
+            tlen = frag_end[pr] - lpos[pr] + 1
+            le32(rows, 32, torch.where(right, -tlen, tlen))
+            d = pr.clone()
+            for k in range(9):                                                             # r%09d
+                rows[:, 36 + 9 - k] = (d % 10 + 48).to(torch.uint8)
+                d = d // 10
+            for k in range(b):                                                             # M (N M)*
+                le32(rows, _FIXED + _NAME + 8 * k, (fright[ff + 2 * k] - fleft[ff + 2 * k] + 1) * 16)
+                if k + 1 < b:
+                    le32(rows, _FIXED + _NAME + 8 * k + 4, (fleft[ff + 2 * k + 2] - fright[ff + 2 * k] - 1) * 16 + 3)
+            idx = rec_off[sel].unsqueeze(1) + torch.arange(L, device=dev).unsqueeze(0)
+            buf[idx.reshape(-1)] = rows.reshape(-1)
+            del rows, idx
+    return buf, rec_off
+
+
+class FrontQuantifier(ChainQuantifier):
+    """The chain sample's alignment records in HBM -> theta.  step() runs the five stages; stage_wall_ms keeps the last
+    step's per-stage wall times (every stage ends synchronised: its totals decide the next one's allocations)."""
+
+    STAGES = ("bam_decode", "assign_reads", "pair_mates", "collapse_pairs", "quantify")
+
+    def __init__(self, ctx, n_loci=60000, n_frags=2e8, seed=31, read_len=75):
+        super().__init__(ctx, n_loci=n_loci, n_frags=n_frags, seed=seed, read_len=read_len, pin=True)
+        torch = self.torch
+        t = time.perf_counter()
+        self.d_bytes, self.d_rec_off = pack_bam_records(torch, self.sample, read_len)
+        torch.cuda.synchronize(self.dev)
+        self.pack_s = time.perf_counter() - t
+        self.n_records, self.n_bytes = int(self.d_rec_off.numel()) - 1, int(self.d_bytes.numel())
+        a = self.annot
+        # the clusters of quant mode: one per gene model, [first exon's start, last exon's end] (addRef2Cluster), strand +
+        first_exon = a.exon_off[a.iso_off[:-1]]
+        lefts = np.minimum.reduceat(a.exon_left, a.exon_off[:-1])       # per isoform
+        rights = np.maximum.reduceat(a.exon_right, a.exon_off[:-1])
+        self._c_left = np.ascontiguousarray(np.minimum.reduceat(lefts, a.iso_off[:-1]), np.uint32)
+        self._c_right = np.ascontiguousarray(np.maximum.reduceat(rights, a.iso_off[:-1]), np.uint32)
+        del first_exon
+        self._c_ref = np.zeros(self.n_loci, np.int32)
+        self._c_strand = np.ones(self.n_loci, np.uint8)
+        self._clusters = _lib.sbgpu_clusters_t(self.n_loci, self._c_ref.ctypes.data, self._c_left.ctypes.data, self._c_right.ctypes.data,
+                                               self._c_strand.ctypes.data)
+        self._opts = bam.BamOptions(n_ref=1).c()
+        self._read_off = np.zeros(self.n_loci + 1, np.int64)
+        self.stage_wall_ms = {}
+        self.counts = {}
+
+    def step(self, keep=False):
+        torch, L, ctx = self.torch, self.ctx.L, self.ctx
+        sync = lambda: torch.cuda.synchronize(self.dev)  # noqa: E731
+        ms = {}
+        sync()
+        t = time.perf_counter()
+        hb = C.c_void_p()
+        _lib.check(L.sbgpu_bam_decode_device(ctx.h, self.d_bytes.data_ptr(), self.n_bytes, self.d_rec_off.data_ptr(), self.n_records,
+                                             C.byref(self._opts), None, C.byref(hb)), "sbgpu_bam_decode_device")
+        rs = _lib.sbgpu_reads_t()
+        d_ref, d_left, d_right = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _lib.check(L.sbgpu_bamreads_reads(hb, C.byref(rs), C.byref(d_ref), C.byref(d_left), C.byref(d_right)), "sbgpu_bamreads_reads")
+        sync()
+        t1 = time.perf_counter()
+        ms["bam_decode"] = (t1 - t) * 1e3
+        n_reads = int(rs.n_reads)
+        d_cluster = torch.empty(max(n_reads, 1), dtype=torch.int32, device=self.dev)
+        _lib.check(L.sbgpu_assign_reads_device(ctx.h, C.byref(self._clusters), n_reads, d_ref, d_left, d_right, rs.flags, d_cluster.data_ptr(),
+                                               self._read_off.ctypes.data, None), "sbgpu_assign_reads_device")
+        sync()
+        t2 = time.perf_counter()
+        ms["assign_reads"] = (t2 - t1) * 1e3
+        hm = C.c_void_p()
+        _lib.check(L.sbgpu_pair_mates_device(ctx.h, self.n_loci, C.byref(rs), self._read_off.ctypes.data, None, C.byref(hm)), "sbgpu_pair_mates_device")
+        dp, poff = _lib.sbgpu_pairs_t(), C.c_void_p()
+        _lib.check(L.sbgpu_matepairs_pairs(hm, C.byref(dp), C.byref(poff)), "sbgpu_matepairs_pairs")
+        sync()
+        t3 = time.perf_counter()
+        ms["pair_mates"] = (t3 - t2) * 1e3
+        del d_cluster
+        L.sbgpu_bamreads_destroy(hb)           # (the pairs hold what they need of the reads)
+        hu = C.c_void_p()
+        _lib.check(L.sbgpu_collapse_pairs_device(ctx.h, self.n_loci, C.byref(dp), poff, None, C.byref(hu)), "sbgpu_collapse_pairs_device")
+        dh = _lib.sbgpu_hits_t()
+        d_mass, hoff = C.c_void_p(), C.c_void_p()
+        _lib.check(L.sbgpu_uniq_dev_hits(hu, C.byref(dh), C.byref(d_mass), C.byref(hoff)), "sbgpu_uniq_dev_hits")
+        sync()
+        t4 = time.perf_counter()
+        ms["collapse_pairs"] = (t4 - t3) * 1e3
+        self.front_hit_off = np.ctypeslib.as_array(C.cast(hoff, C.POINTER(C.c_int64)), shape=(self.n_loci + 1,)).copy()
+        L.sbgpu_matepairs_destroy(hm)
+        h = C.c_void_p()
+        _lib.check(L.sbgpu_quantify_device(ctx.h, C.byref(self._an), C.byref(dh), d_mass, hoff, C.byref(self._ins), self.read_len, 0,
+                                           self.theta.ctypes.data, self.status.ctypes.data, self.iters.ctypes.data, C.byref(h)),
+                   "sbgpu_quantify_device")
+        sync()
+        ms["quantify"] = (time.perf_counter() - t4) * 1e3
+        if not self.counts:
+            pi, ui = (C.c_int64 * 8)(), (C.c_int64 * 8)()
+            # (the handles are gone for the pairs; the unique hits' handle still lives)
+            _lib.check(L.sbgpu_uniq_dev_info(hu, ui), "sbgpu_uniq_dev_info")
+            self.counts = {"records": self.n_records, "accepted_records": n_reads, "unique_hits": int(ui[0]), "features": int(ui[1]),
+                           "pairs_dropped_by_the_span_filter": int(ui[2]), "mapped_reads": int(ui[4])}
+            info = (C.c_int64 * 8)()
+            _lib.check(L.sbgpu_bins_info(h, info), "sbgpu_bins_info")
+            self.info = {"n_bins": int(info[2]), "n_elem": int(info[3]), "n_pairs": int(info[4]), "hits_in_bins": int(info[6])}
+        L.sbgpu_bins_destroy(h)
+        L.sbgpu_uniq_dev_destroy(hu)
+        self.stage_wall_ms = ms
+
+    def chain_step(self):
+        """The same sample through the chain alone (its unique hits as DeviceSample made them): what step() must reproduce."""
+        ChainQuantifier.step(self)
+
+    def compare_with_chain(self):
+        """After a step(): run the chain on the sample's own unique hits and compare locus by locus.  The front end applies
+        the reference's span filter (HitCluster::collapseAndFilterHits drops a pair whose mate's span is an outlier of its
+        cluster's spans, alignments.cpp:666-682: a spliced mate in a cluster of thousands of unspliced ones), which the
+        sample generator -- it draws unique hits directly -- does not: a locus that lost a pair to it is compared on its hit
+        count only, every other locus must agree bit for bit.  -> dict; the front's results are put back in place."""
+        front = (self.theta.copy(), self.status.copy(), self.iters.copy())
+        self.chain_step()
+        same_hits = np.diff(self.front_hit_off) == np.diff(self.hits.locus_hit_off)
+        a = self.annot
+        iso_same = np.repeat(same_hits, np.diff(a.iso_off))
+        ok = bool(np.array_equal(front[0][:self.n_iso][iso_same], self.theta[:self.n_iso][iso_same]) and
+                  np.array_equal(front[1][:self.n_loci][same_hits], self.status[:self.n_loci][same_hits]) and
+                  np.array_equal(front[2][:self.n_loci][same_hits], self.iters[:self.n_loci][same_hits]))
+        lost = int((np.diff(self.hits.locus_hit_off) - np.diff(self.front_hit_off)).sum())
+        out = {"loci_with_the_samples_hits": int(same_hits.sum()), "bitwise_equal_there": ok,
+               "loci_that_lost_pairs_to_the_span_filter": int((~same_hits).sum()), "unique_hits_lost_there": lost,
+               "pairs_dropped_by_the_span_filter": self.counts.get("pairs_dropped_by_the_span_filter"),
+               "ok": bool(ok and lost >= 0 and lost <= max(self.counts.get("pairs_dropped_by_the_span_filter", 0), 0))}
+        self.theta[:], self.status[:], self.iters[:] = front
+        return out

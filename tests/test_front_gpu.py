@@ -1,0 +1,30 @@
+"""Records -> theta on the device (strawberry_amd/front.py, bench.py --workload c3-front): the BAM records of a chain
+sample's read pairs, resident in HBM, through sbgpu_bam_decode_device -> sbgpu_assign_reads_device ->
+sbgpu_pair_mates_device -> sbgpu_collapse_pairs_device -> sbgpu_quantify_device must hand the chain the sample's
+unique hits (less the pairs the reference's span filter drops): theta, status and iteration counts equal sbgpu_quantify_device's on those hits BIT FOR BIT (and through it the
+oracle chain's and the reference program's, tests/test_chain_scale_gpu.py, bench.py's parity legs).  tests/test_front.py
+checks the packed records themselves on the CPU (host decoder, oracle decoder, host pairing and collapse)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_records_to_theta_equals_the_chain_on_the_same_sample():
+    from strawberry_amd import em, front
+    ctx = em.default_context(0)
+    q = front.FrontQuantifier(ctx, n_loci=2500, n_frags=2.5e6, seed=44)
+    assert q.n_records == 2 * q.n_frags and q.n_frags > q.n_hits
+    for _ in range(2):                       # (the second step reuses pooled scratch)
+        q.theta[:] = -1
+        q.step()
+        assert q.counts["accepted_records"] == q.n_records
+        assert set(q.stage_wall_ms) == set(front.FrontQuantifier.STAGES)
+        # locus by locus against the chain on the sample's own unique hits: bit for bit, except where the reference's span
+        # filter (alignments.cpp:666-682; the sample generator does not model it) dropped a pair -- a handful of loci
+        c = q.compare_with_chain()
+        assert c["ok"] and c["bitwise_equal_there"], c
+        assert c["loci_with_the_samples_hits"] >= q.n_loci - 20 and c["unique_hits_lost_there"] <= c["pairs_dropped_by_the_span_filter"] <= 50, c
+        assert q.counts["unique_hits"] == q.n_hits - c["unique_hits_lost_there"]
+    assert (q.status[:q.n_loci] != 1).sum() > 2000 and q.iters[:q.n_loci].max() > 100
+    q.close()
