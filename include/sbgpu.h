@@ -119,6 +119,11 @@ int sbgpu_device_count(void);
  * (synchronise the stream that produced them): those entry points run on the context's own stream.                */
 int sbgpu_init(int device, sbgpu_ctx_t **ctx_out);
 int sbgpu_finalize(sbgpu_ctx_t *ctx);
+/* Device memory the library keeps between calls: the arenas of handles and plans go back to a process-wide pool when they are
+ * released (a sample-sized call's arenas are tens of GB; allocating and freeing them per call costs seconds), at most
+ * half of the device's memory (environment: SBGPU_POOL_GB).  A caller that wants that memory for something else
+ * hands it back to the driver with this; returns the bytes released.                                                  */
+int64_t sbgpu_release_idle_memory(void);
 /* Device facts for roofline accounting: out[0]=#CUs, out[1]=wave size,
  * out[2]=LDS bytes per CU, out[3]=max clock kHz, out[4]=total HBM bytes (MiB).   */
 int sbgpu_device_info(sbgpu_ctx_t *ctx, int64_t out[8]);

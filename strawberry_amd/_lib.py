@@ -31,7 +31,7 @@ SYMBOLS = [
     "sbgpu_insert_pdf_table", "sbgpu_binweight_device", "sbgpu_binweight_host",
     "sbgpu_exonbin_device", "sbgpu_exonbin_host", "sbgpu_segments_host", "sbgpu_hit_features", "sbgpu_frag_lens_host",
     "sbgpu_bins_create", "sbgpu_bins_create_device", "sbgpu_bins_destroy", "sbgpu_quantify_host", "sbgpu_quantify_device",
-    "sbgpu_annotation_pin", "sbgpu_annotation_unpin", "sbgpu_annotation_unpin_matching",
+    "sbgpu_annotation_pin", "sbgpu_annotation_unpin", "sbgpu_annotation_unpin_matching", "sbgpu_release_idle_memory",
     "sbgpu_bins_export_weights", "sbgpu_collapse_pairs_host", "sbgpu_uniq_destroy", "sbgpu_uniq_info", "sbgpu_uniq_export",
     "sbgpu_collapse_pairs_device", "sbgpu_uniq_dev_destroy", "sbgpu_uniq_dev_info", "sbgpu_uniq_dev_hits", "sbgpu_uniq_dev_export", "sbgpu_bins_info", "sbgpu_bins_grouping", "sbgpu_bins_export",
     "sbgpu_format_value", "sbgpu_format_gtf_transcript", "sbgpu_format_context_row", "sbgpu_format_context_row_seq",
@@ -206,6 +206,8 @@ def load():
                                       C.c_int32, C.c_int32, vp, vp, vp, vp, C.POINTER(sbgpu_insert_t), C.POINTER(vp)]
     L.sbgpu_annotation_pin.argtypes = [vp, C.POINTER(sbgpu_annotation_t)]
     L.sbgpu_annotation_unpin.argtypes = [vp]
+    L.sbgpu_release_idle_memory.argtypes = []
+    L.sbgpu_release_idle_memory.restype = C.c_int64
     L.sbgpu_annotation_unpin_matching.argtypes = [vp, C.POINTER(sbgpu_annotation_t), C.POINTER(C.c_int32)]
     L.sbgpu_quantify_device.argtypes = [vp, C.POINTER(sbgpu_annotation_t), C.POINTER(sbgpu_hits_t), vp, vp, C.POINTER(sbgpu_insert_t),
                                         C.c_int32, C.c_int32, vp, vp, vp, C.POINTER(vp)]

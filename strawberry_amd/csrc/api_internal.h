@@ -147,11 +147,14 @@ int ctx_device(const sbgpu_ctx_t *ctx);        // the HIP device the context was
 // request for the same slot; one host thread per context
 hipError_t ctx_scratch(sbgpu_ctx_t *ctx, int slot, size_t bytes, char **out);
 // Device allocations that change hands (a handle's arenas, a plan's arena): a hipMalloc / hipFree pair per call costs a
-// few hundred microseconds and the free waits for the device, so blocks handed back are kept -- process-wide, per
-// device, at most 8 blocks and 4 GB -- and a request is served from them when one fits without wasting more than half.
+// few hundred microseconds -- seconds for the tens of GB of a sample-sized call -- and the free waits for the device, so
+// blocks handed back are kept -- process-wide, per device, at most 24 blocks and half of the device's memory
+// (SBGPU_POOL_GB) -- and a request is served from them when one fits without wasting more than half;
+// dev_release_idle (sbgpu_release_idle_memory) lets the idle blocks go.
 // dev_give waits for the device first, as hipFree does (a handle may be destroyed while a kernel on the caller's stream
 // still reads its arena).
 hipError_t dev_take(size_t bytes, char **out, size_t *capacity);
+size_t dev_release_idle();
 void dev_give(char *block, size_t capacity);
 // pinned host scratch of the same kind (slot 0..3): the targets of small device-to-host copies that must not block the host
 hipError_t ctx_pinned(sbgpu_ctx_t *ctx, int slot, size_t bytes, char **out);

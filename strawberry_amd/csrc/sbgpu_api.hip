@@ -155,7 +155,27 @@ struct DevPool {
    std::mutex m;
    std::vector<DevBlock> blocks;
    size_t bytes = 0;
+   size_t limit = 0; // idle bytes the pool may hold; 0: not decided yet
 };
+// How much idle memory the pool may hold.  The arenas of a sample-sized call are tens of GB (a chain sample's alignment
+// records decode into 25 GB of reads, pair into 15 GB of pairs, ...): with a 4 GB pool every one of them went through
+// hipMalloc and hipFree in every call -- 2.9 of a step's 4.1 seconds at 3.9e8 records.  The part is built around 288 GB:
+// half of the device's memory may idle here (SBGPU_POOL_GB overrides; an allocation that fails -- the library's own
+// -- lets the idle blocks go and tries again, see dev_take).
+size_t dev_pool_limit(DevPool &pool)
+{
+   if (pool.limit) return pool.limit;
+   size_t lim = (size_t)4 << 30;
+   if (const char *e = std::getenv("SBGPU_POOL_GB")) {
+      lim = (size_t)std::max(0.0, std::atof(e) * 1073741824.0);
+   } else {
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b / 2 > lim) lim = total_b / 2;
+      else (void)hipGetLastError();
+   }
+   pool.limit = lim ? lim : 1;
+   return pool.limit;
+}
 DevPool &dev_pool()
 {
    static DevPool *p = new DevPool(); // never destroyed: handles may be released during static destruction
@@ -204,6 +224,20 @@ hipError_t dev_take(size_t bytes, char **out, size_t *capacity)
    *capacity = want;
    return hipSuccess;
 }
+size_t dev_release_idle()
+{
+   std::vector<DevBlock> idle;
+   size_t bytes = 0;
+   {
+      DevPool &pool = dev_pool();
+      std::lock_guard<std::mutex> g(pool.m);
+      idle.swap(pool.blocks);
+      bytes = pool.bytes;
+      pool.bytes = 0;
+   }
+   for (const DevBlock &b : idle) (void)hipFree(b.p);
+   return bytes;
+}
 void dev_give(char *block, size_t capacity)
 {
    if (!block) return;
@@ -225,7 +259,7 @@ void dev_give(char *block, size_t capacity)
    {
       DevPool &pool = dev_pool();
       std::lock_guard<std::mutex> g(pool.m);
-      if (pool.blocks.size() < 8 && pool.bytes + capacity <= ((size_t)4 << 30)) {
+      if (pool.blocks.size() < 24 && pool.bytes + capacity <= dev_pool_limit(pool)) {
          pool.blocks.push_back({block, capacity, owner});
          pool.bytes += capacity;
          pooled = true;
@@ -600,6 +634,8 @@ int sbgpu_device_info(sbgpu_ctx_t *c, int64_t out[8])
    out[5] = out[6] = out[7] = 0;
    return SBGPU_OK;
 }
+
+int64_t sbgpu_release_idle_memory(void) { return (int64_t)sb::dev_release_idle(); }
 
 int sbgpu_synchronize(sbgpu_ctx_t *c, void *stream)
 {
