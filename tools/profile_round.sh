@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: the round's evidence.  Usage (repo root): bash tools/profile_round.sh r01
 # Everything judged is collected under gpurun_out/$R/summary/ -- copy that directory's files into profiles/.
-R=${1:-r04}
+R=${1:-r05}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/$R
 SUM=$OUT/summary
@@ -15,6 +15,8 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_c3 -o em -- python3 $REPO/bench.py --no-chain --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_c3 -o em -- python3 $REPO/bench.py --no-chain --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_write.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_sq_c3 -o em -- python3 $REPO/bench.py --no-chain --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_sq.log 2>&1
+# the matrix pipe: instructions, busy cycles (north star: "MFMA-busy where used" -- v_mfma_f64_4x4x4 is the cross-lane reducer of every EM kernel)
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/pmc_mfma_c3 -o em -- python3 $REPO/bench.py --no-chain --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_mfma.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_c2 -o em -- python3 $REPO/bench.py --workload c2 --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_fetch_c2.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_c2 -o em -- python3 $REPO/bench.py --workload c2 --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_write_c2.log 2>&1
 cd $REPO
@@ -49,7 +51,7 @@ timeout 900 rocprofv3 --kernel-trace -d $OUT/trace_chain -o ch -- python3 $REPO/
 python3 $REPO/tools/chain_gpu_gaps.py $(find $OUT/trace_chain -name "ch_results.db" | head -1) > $SUM/${R}_c3chain_timeline.txt 2>&1
 # the wide-locus kernel on C3-T: stats and counters
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3t -o w -- python3 $REPO/bench.py --workload c3t --no-cpu-baseline --steps 3 --warmup 1 > $OUT/stats_c3t.log 2>&1
-for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU"; do
+for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES"; do
   tag=$(echo $pmc | cut -d' ' -f1)
   timeout 900 rocprofv3 --pmc $pmc --output-format csv -d $OUT/pmc_${tag}_c3t -o w -- python3 $REPO/bench.py --workload c3t --no-cpu-baseline --steps 2 --warmup 1 > $OUT/pmc_${tag}_c3t.log 2>&1
 done
