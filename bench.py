@@ -603,7 +603,7 @@ def main():
                             "tpm_rel_err_p99": float(np.percentile(tpm_rel, 99)), "tpm_rel_err_max": float(tpm_rel.max()),
                             "loci_status_changed": int((res64["status"] != res32["status"]).sum()),
                             "loci_iteration_count_changed": int((res64["iters"] != res32["iters"]).sum()),
-                            "histogram": "profiles/r04_c5_sweep.json (tools/c5_sweep.py)"}}
+                            "histogram": "profiles/r05_c5_sweep.json (tools/c5_sweep.py)"}}
         # the fp32 kernels' own times (HIP events per kind), for their roofline with s = 4
         probe32 = []
         solver.set_timing(True)

@@ -108,6 +108,14 @@ for f in $(find $OUT/stats_frontend -name "*kernel_stats.csv"); do cp $f $SUM/${
 (timeout 300 python tools/bench_bamdecode.py 4e6 2>/dev/null | tail -1) > $SUM/${R}_bamdecode.json
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bamdecode -o bd -- python3 $REPO/tools/bench_bamdecode.py 4e6 --no-cpu-baseline > $OUT/stats_bamdecode.log 2>&1)
 for f in $(find $OUT/stats_bamdecode -name "*kernel_stats.csv"); do cp $f $SUM/${R}_bamdecode_kernel_stats.csv; done
+# round 5: strong-scaling shards a rank at a time (EM kinds, plan settings of a small shard, the chain's shards); records -> theta
+# (c3-front) with its kernel rows; instructions per algorithmic FMA of the tile kernels by layout; a full wide-locus tile's counters
+((timeout 600 python tools/probe_strong_kinds.py; echo; echo "# the world-8 shards under plan settings that trade lanes for iteration latency (tools/probe_strong_small.py)"; timeout 600 python tools/probe_strong_small.py 8; echo; echo "# the CHAIN's shards (tools/probe_strong_chain.py)"; timeout 900 python tools/probe_strong_chain.py) 2>/dev/null | grep -v amdgpu.ids) > $SUM/${R}_strong_shards.txt
+(timeout 1500 python bench.py --workload c3-front --steps 5 --warmup 2 2>/dev/null | tail -1) > $SUM/${R}_bench_c3front.json
+(cd /tmp && timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/stats_front_$R -o fr -- python3 $REPO/bench.py --workload c3-front --steps 2 --warmup 1 --no-cpu-baseline > /tmp/stats_front_$R.log 2>&1)
+for f in $(find /tmp/stats_front_$R -name "*kernel_stats.csv"); do cp $f $SUM/${R}_c3front_kernel_stats.csv; done
+bash tools/pmc_em_layouts.sh > $SUM/${R}_em_layout_instr.txt 2>&1
+(bash tools/pmc_wide_one.sh 2>&1 | grep "^gpurun_out/pmcw") > $SUM/${R}_wide_tile_pmc.txt
 # random stress on this build (tails; the library's build id on top)
 (python -c "import sys; sys.path.insert(0, '.'); from strawberry_amd import _lib; print('libsbgpu build', _lib.load().sbgpu_build_id().decode())"; timeout 900 python tools/stress_em.py 48 2>&1 | tail -3; timeout 600 python tools/stress_exonbin.py 48 2>&1 | tail -2; timeout 600 python tools/stress_binseq.py 2>&1 | tail -2; timeout 600 python tools/stress_bamdecode.py 48 2>/dev/null | tail -2) > $SUM/${R}_stress.txt 2>&1
 cat $SUM/${R}_pytest_gpu.txt; cat $SUM/${R}_bench_c3.json; echo; cat $SUM/${R}_bench_c2.json; echo; ls -la $SUM
