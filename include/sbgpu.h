@@ -177,7 +177,9 @@ int sbgpu_em_run_device_f32(sbgpu_ctx_t *ctx, const sbgpu_plan_t *plan,
  * [-1, 1] (b_ij in [0.5, 2]); how they are derived is the caller's model -- the reference has no bias arithmetic
  * (src/bias.cpp is comments), so this is NOT a parity path; bench.py --workload c5 derives row_bias from the bins'
  * GC ratio as sbgpu_binseq_device measures it.  Same result as sbgpu_em_run_device on the pre-multiplied weights up
- * to exp2's rounding.  Tile kernels only (loci of up to 64 isoforms; plans without phases), else SBGPU_EUNSUPPORTED. */
+ * to exp2's rounding.  Served by the tile kernels and the multi-workgroup kernel of the wide loci (up to 512 isoforms);
+ * a plan with phases, or with a locus on the streaming fallback (more than 512 isoforms or 256 workgroups): SBGPU_EUNSUPPORTED.
+ * The fp32 form covers loci of up to 64 isoforms only (it is a tolerance experiment, not a product path).              */
 int sbgpu_em_run_device_bias(sbgpu_ctx_t *ctx, const sbgpu_plan_t *plan, const int32_t *d_count, const double *d_F,
                              const double *d_row_bias, const double *d_iso_bias, double *d_theta, int32_t *d_status,
                              int32_t *d_iters, void *stream);

@@ -8,7 +8,7 @@ hipError_t launch_wide(const WideArgs &g, int n_blocks, size_t lds_bytes, hipStr
    WideArgs arg = g;
    void *params[] = {&arg};
    // cooperative: all workgroups resident, or the launch fails -- the exchange among a locus' workgroups needs it
-   return hipLaunchCooperativeKernel((const void *)em_wide_kernel, dim3((unsigned)n_blocks), dim3(kWideThreads), params,
-                                     (unsigned)lds_bytes, s);
+   return hipLaunchCooperativeKernel(arg.a.row_bias ? (const void *)em_wide_kernel<true> : (const void *)em_wide_kernel<false>,
+                                     dim3((unsigned)n_blocks), dim3(kWideThreads), params, (unsigned)lds_bytes, s);
 }
 } // namespace sb

@@ -253,6 +253,17 @@ __device__ __forceinline__ void granule_sweep(const char *base_ptr, const unsign
                    : "memory");
 }
 
+// Between two sweeps of an exchange.  Inside a run of iterations the partials are there at the first or second sweep; a
+// workgroup that reaches a locus before its partners (the job form: they may still be on their previous locus for
+// milliseconds) must not keep hundreds of polling loads in flight meanwhile -- pollers take bandwidth from the workgroups
+// that compute (MI355X_MICROARCH.md, polling-cost): after a few misses the pauses grow to ~3 us.
+__device__ __forceinline__ void wide_poll_pause(unsigned spins)
+{
+   if (spins < 8) __builtin_amdgcn_s_sleep(1);
+   else if (spins < 32) __builtin_amdgcn_s_sleep(16);
+   else __builtin_amdgcn_s_sleep(127);
+}
+
 // all-reduce of N values over the column lanes of a wave (lane bits 4 5 0 1, then 3, then 2)
 template <int LB_CL, int N, int NA>
 __device__ __forceinline__ void wide_col_lanes_sum(double (&x)[NA])
@@ -305,8 +316,8 @@ __device__ __forceinline__ void wide_for_each(Fn &fn, std::integer_sequence<int,
    (fn(std::integral_constant<int, B>{}), ...);
 }
 
-template <int LB_CL, int CPL, int R, int RL, int RBLK, int LBLK>
-__device__ __forceinline__ void em_wide_body(const WideArgs &g, const int di)
+template <int LB_CL, int CPL, int R, int RL, int RBLK, int LBLK, bool BIAS>
+__device__ __forceinline__ void em_wide_body(const WideArgs &g, const int di, const int w)
 {
    constexpr int CL = 1 << LB_CL, GR = 64 / CL, NPAD = CL * CPL;
    constexpr int ROWSTEP = kWideWaves * GR; // rows of the block between a lane's consecutive row slots
@@ -327,7 +338,7 @@ __device__ __forceinline__ void em_wide_body(const WideArgs &g, const int di)
    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
    set_fp64_flush_denormals();
    const WideDesc d = g.table[di];
-   const int w = (int)blockIdx.x - d.first_block, G = d.n_blocks;
+   const int G = d.n_blocks;
    const int locus = d.locus;
    const int64_t r0 = a.row_off[locus];
    const int nrow = (int)(a.row_off[locus + 1] - r0);
@@ -372,6 +383,10 @@ __device__ __forceinline__ void em_wide_body(const WideArgs &g, const int di)
          const int j = k * CL + c; // the lane's k-th column: consecutive column lanes, consecutive columns (LDS banks)
          const bool ok = valid && j < niso;
          double v = Fg[(int64_t)ic * niso + (j < niso ? j : 0)]; // unconditional load, then select: no branch per element
+         // config 5: the biased weight F_ij * 2^(row_bias_i * iso_bias_j) is the operand from here on, as in the tile kernels
+         // (em_device.h).  An instantiation of its own: with the factors as a run-time branch of the one kernel the plain
+         // path lost 3 % (C3-T 38.2 -> 39.3 ms: two more pointers across the unrolled load)
+         if (BIAS) v *= bias_factor(a.row_bias[r0 + ic] * a.iso_bias[iso_base + (j < niso ? j : 0)]);
          v = ok ? v : 0.0;
          x[k] = v;
          mx = fmax(mx, v);
@@ -415,7 +430,7 @@ __device__ __forceinline__ void em_wide_body(const WideArgs &g, const int di)
             aborted = true;
             break;
          }
-         __builtin_amdgcn_s_sleep(1);
+         wide_poll_pause(spins);
       }
    };
    auto exchange = [&](double s, unsigned flag, const int n_items, unsigned &flag_out) -> double {
@@ -465,7 +480,7 @@ __device__ __forceinline__ void em_wide_body(const WideArgs &g, const int di)
                   aborted = true;
                   break;
                }
-               __builtin_amdgcn_s_sleep(1);
+               wide_poll_pause(spins);
             }
             s = sum;
             flag_out = fl;
@@ -785,20 +800,29 @@ __device__ __forceinline__ void em_wide_body(const WideArgs &g, const int di)
 // launches do not overlap, so rounds should be few and full): the workgroup looks up its locus and jumps to the
 // instantiation its width needs.
 #ifdef SB_COMPILE_WIDE_KERNEL
+// One launch serves loci of all widths (a round's workgroups must all be resident together, and cooperative
+// launches do not overlap, so rounds should be few and full): the workgroup looks up its locus and jumps to the
+// instantiation its width needs.  (Round 5 measured two forms of ONE launch for the whole tail -- every resident workgroup
+// working through a list of (locus, part) jobs, scheduled on the host or taken from a queue on the device -- against the
+// rounds: 41.6 and 39.9 ms against 39.0 on C3-T.  A locus starts when the LAST of its workgroups is free, and rounds of
+// loci of like workgroup counts, all of which run the same 1000 iterations, keep the workgroups aligned; a queue lets them
+// drift apart.  profiles/EXPERIMENTS_r05.md.)
+#ifdef SB_WIDE_ONLY // diagnostic: one instantiation per build (register report)
+#define SB_WIDE_CASE(ID) \
+   case ID: if (ID == SB_WIDE_ONLY) em_wide_body<wide_layout(ID).lb_cl, wide_layout(ID).cpl, wide_layout(ID).r, wide_layout(ID).rl, wide_layout(ID).rblk, wide_layout(ID).lblk, BIAS>(g, di, w); break;
+#else
+#define SB_WIDE_CASE(ID) \
+   case ID: em_wide_body<wide_layout(ID).lb_cl, wide_layout(ID).cpl, wide_layout(ID).r, wide_layout(ID).rl, wide_layout(ID).rblk, wide_layout(ID).lblk, BIAS>(g, di, w); break;
+#endif
+template <bool BIAS>
 __global__ __launch_bounds__(kWideThreads) void em_wide_kernel(WideArgs g)
 {
    int di = 0;
    for (int k = 1; k < g.n_desc; ++k)
       if (g.table[k].first_block <= (int)blockIdx.x) di = k;
    di = __builtin_amdgcn_readfirstlane(di);
+   const int w = (int)blockIdx.x - g.table[di].first_block;
    switch (g.table[di].layout) {
-#ifdef SB_WIDE_ONLY // diagnostic: one instantiation per build (register report)
-#define SB_WIDE_CASE(ID) \
-   case ID: if (ID == SB_WIDE_ONLY) em_wide_body<wide_layout(ID).lb_cl, wide_layout(ID).cpl, wide_layout(ID).r, wide_layout(ID).rl, wide_layout(ID).rblk, wide_layout(ID).lblk>(g, di); break;
-#else
-#define SB_WIDE_CASE(ID) \
-   case ID: em_wide_body<wide_layout(ID).lb_cl, wide_layout(ID).cpl, wide_layout(ID).r, wide_layout(ID).rl, wide_layout(ID).rblk, wide_layout(ID).lblk>(g, di); break;
-#endif
       SB_WIDE_CASE(0)
       SB_WIDE_CASE(1)
       SB_WIDE_CASE(2)
@@ -812,9 +836,9 @@ __global__ __launch_bounds__(kWideThreads) void em_wide_kernel(WideArgs g)
       SB_WIDE_CASE(10)
       SB_WIDE_CASE(11)
       SB_WIDE_CASE(12)
-#undef SB_WIDE_CASE
    }
 }
+#undef SB_WIDE_CASE
 #endif
 
 hipError_t launch_wide(const WideArgs &g, int n_blocks, size_t lds_bytes, hipStream_t s);

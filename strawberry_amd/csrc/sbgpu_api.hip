@@ -957,8 +957,14 @@ static int em_run_impl(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_c
    if (f32 && (p->launches[sb::kStream].n_classes > 0 || p->launches[sb::kWaveH].n_classes > 0))
       return fail(SBGPU_EUNSUPPORTED, "sbgpu_em_run_device_f32: the fp32 variant covers loci of up to 64 isoforms in the tile kernels only");
    if ((d_row_bias != nullptr) != (d_iso_bias != nullptr)) return fail(SBGPU_EINVAL, "sbgpu_em_run_device_bias: both bias arrays or none");
-   if (d_row_bias && (p->launches[sb::kStream].n_classes > 0 || !p->lat.empty()))
-      return fail(SBGPU_EUNSUPPORTED, "sbgpu_em_run_device_bias: the bias factors are applied by the tile kernels (loci of up to 64 isoforms, no phases)");
+   // the bias factors are applied where a kernel loads its tile: the tile kernels and, round 5, the multi-workgroup kernel
+   // of the wide loci; the streaming fallback (more than 512 isoforms or 256 workgroups) and the later phases do not
+   bool stream_fallback = false;
+   if (p->launches[sb::kStream].n_classes > 0)
+      stream_fallback = (int32_t)p->host.classes[p->launches[sb::kStream].first_class].loci.size() > p->n_wide_loci;
+   if (d_row_bias && (stream_fallback || !p->lat.empty()))
+      return fail(SBGPU_EUNSUPPORTED, "sbgpu_em_run_device_bias: the bias factors are applied at tile load (tile kernels and the wide-locus kernel: "
+                                      "no locus on the streaming fallback, no phases)");
    hipStream_t main = (hipStream_t)stream;
    sb::EmArgs a;
    a.row_bias = f32 ? nullptr : (const double *)d_row_bias;
