@@ -745,37 +745,50 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
       }
       std::stable_sort(wide.begin(), wide.end(), [](const std::pair<int, int32_t> &x, const std::pair<int, int32_t> &y) { return x.first > y.first; });
       sc.loci.clear();
-      sbgpu_plan::WideRound round;
-      round.first_desc = (int)wide_table.size();
+      // Rounds: every launch holds at most n_cu workgroups, all resident.  First fit, most workgroups first: a locus goes
+      // to the first round that has room (a round is as long as its slowest locus, and a locus of fewer workgroups is never
+      // slower than one of more: filling the gaps of the early rounds with small loci costs nothing and can save the last,
+      // mostly empty launch).  A round's descriptors are consecutive in the table, ordered by their first workgroup.
+      std::vector<std::vector<std::pair<int, int32_t>>> members;
+      std::vector<int> used;
       for (const auto &gl : wide) {
-         const int32_t l = gl.second;
-         const int G = gl.first;
-         const int64_t nrow = row_off[l + 1] - row_off[l];
-         int layout;
-         (void)groups_of(l, layout);
-         if (round.n_blocks + G > c->n_cu) { // this launch is full: all its workgroups must be resident
-            p->wide_rounds.push_back(round);
-            round = sbgpu_plan::WideRound();
-            round.first_desc = (int)wide_table.size();
+         size_t r = 0;
+         while (r < used.size() && used[r] + gl.first > c->n_cu) ++r;
+         if (r == used.size()) {
+            used.push_back(0);
+            members.emplace_back();
          }
-         sb::WideDesc d;
-         d.locus = l;
-         d.first_block = round.n_blocks;
-         d.n_blocks = G;
-         d.rows_per_block = (int32_t)std::max<int64_t>(1, (nrow + G - 1) / G);
-         d.npad = sb::wide_cols(layout);
-         d.buf_off = (int64_t)wide_buf_doubles;
-         d.layout = layout;
-         d.lb_slice = sb::wide_lb_slice(d.npad, G);
-         d.pad_ = 0;
-         wide_buf_doubles += (size_t)4 * G * d.npad + (size_t)4 * d.npad; // two buffers of G x npad 16-byte granules (partials) + two of npad (totals)
-         round.n_blocks += G;
-         round.n_desc += 1;
-         round.lds_bytes = std::max(round.lds_bytes, sb::wide_lds_bytes(layout));
-         wide_table.push_back(d);
-         sc.loci.push_back(l);
+         used[r] += gl.first;
+         members[r].push_back(gl);
       }
-      if (round.n_desc) p->wide_rounds.push_back(round);
+      for (size_t r = 0; r < members.size(); ++r) {
+         sbgpu_plan::WideRound round;
+         round.first_desc = (int)wide_table.size();
+         for (const auto &gl : members[r]) {
+            const int32_t l = gl.second;
+            const int G = gl.first;
+            const int64_t nrow = row_off[l + 1] - row_off[l];
+            int layout;
+            (void)groups_of(l, layout);
+            sb::WideDesc d;
+            d.locus = l;
+            d.first_block = round.n_blocks;
+            d.n_blocks = G;
+            d.rows_per_block = (int32_t)std::max<int64_t>(1, (nrow + G - 1) / G);
+            d.npad = sb::wide_cols(layout);
+            d.buf_off = (int64_t)wide_buf_doubles;
+            d.layout = layout;
+            d.lb_slice = sb::wide_lb_slice(d.npad, G);
+            d.pad_ = 0;
+            wide_buf_doubles += (size_t)4 * G * d.npad + (size_t)4 * d.npad; // two buffers of G x npad 16-byte granules (partials) + two of npad (totals)
+            round.n_blocks += G;
+            round.n_desc += 1;
+            round.lds_bytes = std::max(round.lds_bytes, sb::wide_lds_bytes(layout));
+            wide_table.push_back(d);
+            sc.loci.push_back(l);
+         }
+         p->wide_rounds.push_back(round);
+      }
       p->n_wide_loci = (int32_t)sc.loci.size();
       sc.loci.insert(sc.loci.end(), rest.begin(), rest.end());
       sc.n_blocks = (int)rest.size(); // what is left for the streaming kernel
