@@ -60,6 +60,9 @@ WORKER = textwrap.dedent("""
     tpm = np.where(keep != 0, 1e6 * fpkm / s.item(), 0.0)
     np.savez(os.path.join(%(out)r, "rank%%d.npz" %% rank), idx=parts[rank], iso_off=mine.iso_off, tpm=tpm,
              total_mapped=total_mapped, sum_fpkm=s.item())
+    # the per-rank table of bench.py's N > 1 line: every rank hands in its numbers, every rank gets all of them
+    tab = dist.gather_values([rank + 0.5, mine.n_loci, int((status == 3).sum())], rank, world)
+    np.save(os.path.join(%(out)r, "table%%d.npy" %% rank), tab)
     dist.barrier()
 """)
 
@@ -95,6 +98,11 @@ def test_two_rank_gloo_tpm_equals_single_process(tmp_path, oracle):
             got[b.iso_off[l]:b.iso_off[l + 1]] = z["tpm"][z["iso_off"][pos]:z["iso_off"][pos] + n]
     assert not np.isnan(got).any()
     np.testing.assert_allclose(got, tpm, rtol=1e-12, atol=0)
+    # dist.gather_values: both ranks hold the same [world][values] table, row r is rank r's
+    t0, t1 = np.load(tmp_path / "table0.npy"), np.load(tmp_path / "table1.npy")
+    np.testing.assert_array_equal(t0, t1)
+    assert t0.shape == (2, 3) and t0[0, 0] == 0.5 and t0[1, 0] == 1.5
+    assert t0[:, 1].sum() == b.n_loci and t0[:, 2].sum() == (status == 3).sum()
 
 
 def test_abi_comm_id_broadcast_carries_an_explicit_status():

@@ -675,6 +675,25 @@ def test_a_quantifier_releases_only_its_own_pin():
     np.testing.assert_array_equal(b.theta, want)
 
 
+@pytest.mark.gpu
+def test_idle_arenas_are_kept_for_the_next_call_and_can_be_released():
+    """The arenas of released handles go back to a process-wide pool (up to half of the device's memory: a sample-sized
+    call's arenas are tens of GB, and allocating them per call costs seconds); sbgpu_release_idle_memory hands them back
+    to the driver, and the next call allocates again -- same results either way."""
+    from strawberry_amd import chain, em
+    ctx = em.default_context(0)
+    with chain.ChainQuantifier(ctx, n_loci=400, n_frags=400 * 300, seed=12, pin=False) as q:
+        q.step()
+        want = q.theta.copy()
+        q.step()                                       # (the first step's handle arenas are in the pool by now)
+        np.testing.assert_array_equal(q.theta, want)
+        released = ctx.L.sbgpu_release_idle_memory()
+        assert released > 0
+        assert ctx.L.sbgpu_release_idle_memory() == 0  # nothing idle any more
+        q.step()
+        np.testing.assert_array_equal(q.theta, want)
+
+
 def test_segment_basis_128_bit_form(ctx, oracle):
     """Loci of 65-128 segments or isoforms take the segment basis with 128-bit masks in a kernel of their own
     (exonbin_seg128_kernel, launched behind exonbin_kernel when the annotation's words go beyond two); beyond 128 the exon

@@ -111,9 +111,28 @@ for f in $(find $OUT/stats_bamdecode -name "*kernel_stats.csv"); do cp $f $SUM/$
 # round 5: strong-scaling shards a rank at a time (EM kinds, plan settings of a small shard, the chain's shards); records -> theta
 # (c3-front) with its kernel rows; instructions per algorithmic FMA of the tile kernels by layout; a full wide-locus tile's counters
 ((timeout 600 python tools/probe_strong_kinds.py; echo; echo "# the world-8 shards under plan settings that trade lanes for iteration latency (tools/probe_strong_small.py)"; timeout 600 python tools/probe_strong_small.py 8; echo; echo "# the CHAIN's shards (tools/probe_strong_chain.py)"; timeout 900 python tools/probe_strong_chain.py) 2>/dev/null | grep -v amdgpu.ids) > $SUM/${R}_strong_shards.txt
-(timeout 1500 python bench.py --workload c3-front --steps 5 --warmup 2 2>/dev/null | tail -1) > $SUM/${R}_bench_c3front.json
 (cd /tmp && timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/stats_front_$R -o fr -- python3 $REPO/bench.py --workload c3-front --steps 2 --warmup 1 --no-cpu-baseline > /tmp/stats_front_$R.log 2>&1)
 for f in $(find /tmp/stats_front_$R -name "*kernel_stats.csv"); do cp $f $SUM/${R}_c3front_kernel_stats.csv; done
+# HBM traffic counters of the records -> theta pass (every kernel of one step; separate FETCH / WRITE runs)
+for pmc in FETCH_SIZE WRITE_SIZE; do
+  (cd /tmp && timeout 1500 rocprofv3 --pmc $pmc --output-format csv -d /tmp/pmc_${pmc}_front_$R -o fr -- python3 $REPO/bench.py --workload c3-front --steps 1 --warmup 1 --no-cpu-baseline > /tmp/pmc_${pmc}_front_$R.log 2>&1)
+done
+python3 - "$SUM" "$R" <<'PY'
+import collections, csv, ctypes, glob, json, sys
+summ, r = sys.argv[1:3]
+L = ctypes.CDLL("strawberry_amd/lib/libsbgpu.so"); L.sbgpu_build_id.restype = ctypes.c_char_p
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("/tmp/pmc_*_front_%s/**/*counter_collection.csv" % r, recursive=True):
+    for row in csv.DictReader(open(f)):
+        k = row["Kernel_Name"]
+        if "sb::" in k or "rocprim" in k:
+            acc[k.split("(")[0][:160]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+summary = {k: {c: {"mean_per_dispatch": sum(v) / len(v), "dispatches": len(v)} for c, v in cs.items()} for k, cs in acc.items()}
+summary["_build_id"] = L.sbgpu_build_id().decode()
+json.dump(summary, open("%s/%s_c3front_pmc_summary.json" % (summ, r), "w"), indent=1)
+PY
+cp $SUM/${R}_c3front_pmc_summary.json $REPO/profiles/ 2>/dev/null
+(timeout 1500 python bench.py --workload c3-front --steps 5 --warmup 2 2>/dev/null | tail -1) > $SUM/${R}_bench_c3front.json
 bash tools/pmc_em_layouts.sh > $SUM/${R}_em_layout_instr.txt 2>&1
 (bash tools/pmc_wide_one.sh 2>&1 | grep "^gpurun_out/pmcw") > $SUM/${R}_wide_tile_pmc.txt
 # random stress on this build (tails; the library's build id on top)
