@@ -67,3 +67,27 @@ def test_packed_records_decode_pair_and_collapse_back_to_the_samples_unique_hits
     np.testing.assert_array_equal(left, want.feat_left)
     np.testing.assert_array_equal(right, want.feat_right)
     np.testing.assert_array_equal(hmass, want.mass)
+
+
+def test_packed_records_through_the_references_own_bam_reader(oracle, reflib, tmp_path, capfd):
+    """The same packed stream as a BGZF BAM file through the REFERENCE's BAMHitFactory::getHitFromBuf (samtools 0.1.19
+    underneath; oracle/_ref): every record accepted, and read id, interval, strand, mate position, NH, read length, the kept
+    CIGAR and readhit_2_genomicFeats' features equal the oracle decoder's on the bytes -- the synthetic input of the c3-front
+    line is a BAM file the reference itself reads as the reads the sample drew."""
+    import torch
+    import bam_util as B
+    from test_bamdecode import against_reference
+    from strawberry_amd import chain, front
+    s = chain.DeviceSample(torch, torch.device("cpu"), n_loci=40, n_frags=3000, seed=9)
+    raw_t, off_t = front.pack_bam_records(torch, s)
+    raw = raw_t.numpy()
+    n = int(off_t.numel()) - 1
+    top = int(s.feat_right.max()) + 10000
+    path = str(tmp_path / "packed.bam")
+    with open(path, "wb") as f:
+        f.write(B.bgzf_compress(B.header_bytes([("chr1", top)]) + raw.tobytes()))
+    z = reflib.bam_decode(path, n + 8, raw.size // 4 + 8)
+    o = oracle.bam_decode(raw, off_t.numpy(), n_ref=1)
+    assert (o["status"] == 0).all() and o["n"] == n
+    against_reference(o, z)
+    capfd.readouterr()
