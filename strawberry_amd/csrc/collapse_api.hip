@@ -148,7 +148,7 @@ static int collapse_flat(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_pairs_t *dp
    SB_TRY(hipGetLastError());
    tb = tmp_bytes;
    SB_TRY(rocprim::inclusive_scan(tmp, tb, (const int32_t *)f.kept_pos, (int32_t *)(w + o_last), n, rocprim::maximum<int32_t>(), s));
-   hipLaunchKernelGGL(sb::flat_heads_kernel, dim3(gp), dim3(256), 0, s, f);
+   hipLaunchKernelGGL(sb::flat_heads_kernel, dim3(sb::xcd_grid(gp)), dim3(256), 0, s, f);
    hipLaunchKernelGGL(sb::flat_heads_long_kernel, dim3(256), dim3(64), 0, s, f); // (returns at once unless a mate has more than 24 features)
    SB_TRY(hipGetLastError());
    tb = tmp_bytes;
@@ -157,7 +157,7 @@ static int collapse_flat(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_pairs_t *dp
    SB_TRY(rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator((const int32_t *)f.is_hit, [] __device__(int32_t v) { return (int64_t)v; }), (int64_t *)(w + o_hrank), (int64_t)0, n1, rocprim::plus<int64_t>(), s));
    tb = tmp_bytes;
    SB_TRY(rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator((const int32_t *)f.nfeat, [] __device__(int32_t v) { return (int64_t)v; }), (int64_t *)(w + o_fbase), (int64_t)0, n1, rocprim::plus<int64_t>(), s));
-   hipLaunchKernelGGL(sb::flat_mass_any_order_kernel, dim3((unsigned)((std::max(n, nl1) + 255) / 256)), dim3(256), 0, s, f);
+   hipLaunchKernelGGL(sb::flat_mass_any_order_kernel, dim3(sb::xcd_grid((int64_t)((std::max(n, nl1) + 255) / 256))), dim3(256), 0, s, f);
    hipLaunchKernelGGL(sb::flat_mass_kernel, dim3(gw), dim3(64), 0, s, f); // the clusters with a mass that is no multiple of 2^-20
    SB_TRY(hipGetLastError());
    // ---- what the host needs: the flags, the totals, the clusters' first hits and masses
@@ -202,7 +202,7 @@ static int collapse_flat(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_pairs_t *dp
    a.feat_left = U->d_feat_left;
    a.feat_right = U->d_feat_right;
    a.hit_mass = U->d_mass;
-   hipLaunchKernelGGL(sb::flat_fill_kernel, dim3(gp), dim3(256), 0, s, f);
+   hipLaunchKernelGGL(sb::flat_fill_kernel, dim3(sb::xcd_grid(gp)), dim3(256), 0, s, f);
    hipLaunchKernelGGL(sb::flat_fill_long_kernel, dim3(256), dim3(64), 0, s, f);
    SB_TRY(hipGetLastError());
    SB_TRY(hipStreamSynchronize(s)); // the scratch goes back to the pool

@@ -35,6 +35,7 @@
 #include <stdint.h>
 
 #include "collapse_device.h"
+#include "device_common.h"
 
 namespace sb {
 
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(256) void flat_flags_kernel(FlatCollapseArgs f)
 __global__ __launch_bounds__(256) void flat_heads_kernel(FlatCollapseArgs f)
 {
    const CollapseArgs &a = f.a;
-   const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+   const int64_t s = xcd_tile() * 256 + threadIdx.x; // (XCD-aware tile order: device_common.h)
    int filt = 0, rej = 0;
    if (s < f.n_pairs) {
       int32_t nf = 0;
@@ -396,7 +397,7 @@ __device__ __forceinline__ bool flat_run_sum(int key, double &v)
 __global__ __launch_bounds__(256) void flat_mass_any_order_kernel(FlatCollapseArgs f)
 {
    const CollapseArgs &a = f.a;
-   const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+   const int64_t s = xcd_tile() * 256 + threadIdx.x; // (XCD-aware tile order: device_common.h)
    if (s <= a.n_loci) f.locus_hit_off[s] = f.hit_rank[s < a.n_loci ? a.locus_pair_off[s] : f.n_pairs];
    int l = -1, gk = 0x7fffffff; // (beyond the last position: keys that keep the runs apart)
    double v = 0.0;
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(256) void flat_mass_any_order_kernel(FlatCollapseAr
 __global__ __launch_bounds__(256) void flat_fill_kernel(FlatCollapseArgs f)
 {
    const CollapseArgs &a = f.a;
-   const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+   const int64_t s = xcd_tile() * 256 + threadIdx.x; // (XCD-aware tile order: device_common.h)
    if (s >= f.n_pairs) return;
    const int n = f.nfeat[s];
    if (n <= 0) return;

@@ -28,6 +28,19 @@ __device__ __forceinline__ void set_flush_denormals()
    else set_fp64_flush_denormals();
 }
 
+// XCD-aware tile order for kernels whose neighbouring tiles read neighbouring memory (a gather through a permutation that
+// is local: sorted positions against arrival order inside a cluster).  The hardware deals workgroups round-robin over the 8
+// XCDs, each with its own L2 (MI355X_MICROARCH.md, workgroup dispatch; observed, not promised -- this is for speed only): with
+// tile = workgroup index, the lines two neighbouring tiles share are fetched from HBM by two L2s -- by all eight over a few
+// tiles.  Here XCD x works through the x-th CONTIGUOUS eighth of the tiles, so a line is fetched by one L2.  The grid must
+// be a multiple of 8 (xcd_grid); tiles beyond the last are the caller's bounds check.
+__device__ __forceinline__ int64_t xcd_tile()
+{
+   const int64_t b = blockIdx.x, per = gridDim.x >> 3;
+   return (b & 7) * per + (b >> 3);
+}
+inline unsigned xcd_grid(int64_t n_tiles) { return (unsigned)((n_tiles + 7) & ~(int64_t)7); }
+
 // value of lane (lane ^ MASK), true xor for every MASK
 template <int MASK>
 __device__ __forceinline__ int xor_get_i(int x)

@@ -83,6 +83,7 @@ static int pair_mates_flat(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t *
       return o;
    };
    const size_t o_roff = take(nl1 * 8), o_key = take(n * 8), o_skey = take(n * 8), o_order = take(n * 4), o_rec = take(n * sizeof(sb::FlatRec));
+   const size_t o_rarr = take(n * sizeof(sb::FlatRec));
    const size_t o_state = take(n), o_okey = take(n * 4), o_oval = take(n * 4), o_prec = take(n * 4), o_pval = take(n * 4);
    const size_t o_lf = take(n1 * 4), o_rf = take(n1 * 4), o_ls = take(n1 * 8), o_rs = take(n1 * 8), o_poff = take(nl1 * 8), o_counts = take(64 * 64), o_tmp = take(tmp_bytes);
    SB_TRY(sb::dev_take(off, &w, &w_cap));
@@ -103,6 +104,7 @@ static int pair_mates_flat(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t *
    f.skey = (const unsigned long long *)(w + o_skey);
    f.order = (const int32_t *)(w + o_order);
    f.rec = (sb::FlatRec *)(w + o_rec);
+   f.rec_arr = (sb::FlatRec *)(w + o_rarr);
    f.state = (uint8_t *)(w + o_state);
    f.out_key = (uint32_t *)(w + o_okey), f.out_val = (uint32_t *)(w + o_oval);
    f.pair_rec = (const uint32_t *)(w + o_prec), f.pair_val = (const uint32_t *)(w + o_pval);
@@ -121,7 +123,7 @@ static int pair_mates_flat(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t *
    SB_TRY(hipGetLastError());
    tb = tmp_bytes;
    SB_TRY(rocprim::radix_sort_pairs(tmp, tb, (const uint32_t *)f.out_key, (uint32_t *)(w + o_prec), (const uint32_t *)f.out_val, (uint32_t *)(w + o_pval), n, 0, 32, s));
-   hipLaunchKernelGGL(sb::flat_mate_count_kernel, dim3(gr1), dim3(256), 0, s, f);
+   hipLaunchKernelGGL(sb::flat_mate_count_kernel, dim3(sb::xcd_grid(gr1)), dim3(256), 0, s, f);
    SB_TRY(hipGetLastError());
    tb = tmp_bytes;
    SB_TRY(rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator((const int32_t *)f.lfeat, [] __device__(int32_t v) { return (int64_t)v; }), (int64_t *)(w + o_ls), (int64_t)0, n1, rocprim::plus<int64_t>(), s));
@@ -164,7 +166,7 @@ static int pair_mates_flat(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t *
    a.left_code = M->d_left_code, a.right_code = M->d_right_code;
    a.left_left = M->d_left_left, a.left_right = M->d_left_right;
    a.right_left = M->d_right_left, a.right_right = M->d_right_right;
-   hipLaunchKernelGGL(sb::flat_mate_fill_kernel, dim3((unsigned)((np1 + 255) / 256)), dim3(256), 0, s, f, M->n_pairs);
+   hipLaunchKernelGGL(sb::flat_mate_fill_kernel, dim3(sb::xcd_grid((int64_t)((np1 + 255) / 256))), dim3(256), 0, s, f, M->n_pairs);
    SB_TRY(hipGetLastError());
    SB_TRY(hipStreamSynchronize(s)); // the scratch goes back to the pool
 #undef SB_TRY

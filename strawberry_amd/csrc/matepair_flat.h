@@ -24,6 +24,7 @@
 #include <stdint.h>
 
 #include "matepair_device.h"
+#include "device_common.h"
 
 namespace sb {
 
@@ -40,6 +41,7 @@ struct FlatMateArgs {
    unsigned long long *key;         // per record, arrival order
    const unsigned long long *skey;  // sorted
    const int32_t *order;            // record (arrival index) at sorted position s
+   FlatRec *rec_arr;                // the records as the rules see them, ARRIVAL order (made beside the keys, with coalesced loads)
    FlatRec *rec;                    // sorted order
    uint8_t *state;                  // sorted order: 0 nothing, 1 waits for its mate, 2 taken
    uint32_t *out_key, *out_val;     // sorted order: the completing record's arrival index (0xFFFFFFFF: completes nothing);
@@ -72,24 +74,27 @@ __global__ __launch_bounds__(256) void flat_mate_keys_kernel(FlatMateArgs f)
       if (f.a.locus_read_off[mid] <= r) lo = mid;
       else hi = mid;
    }
-   f.key[r] = ((unsigned long long)lo << 32) | flat_hash32(f.a.read_id[r]);
-}
-
-__global__ __launch_bounds__(256) void flat_mate_pack_kernel(FlatMateArgs f)
-{
-   const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
-   if (s >= f.n_reads) return;
    const MateArgs &a = f.a;
-   const int64_t r = f.order[s];
-   const int64_t b0 = a.block_off[r], b1 = a.block_off[r + 1];
    const uint64_t rid = a.read_id[r];
+   f.key[r] = ((unsigned long long)lo << 32) | flat_hash32(rid);
+   // the record as the rules see it, here where the lanes' records are neighbours in every array (round 5: the pack kernel
+   // used to collect these fields in SORTED order -- seven scattered reads per record, 94 GB fetched for 15 GB wanted at
+   // 3.9e8 records; it now moves one 24-byte struct per record)
+   const int64_t b0 = a.block_off[r], b1 = a.block_off[r + 1];
    FlatRec q;
    q.rid_lo = (uint32_t)rid, q.rid_hi = (uint32_t)(rid >> 32);
    q.left = b1 > b0 ? a.block_left[b0] : 0u;
    q.right = b1 > b0 ? a.block_right[b1 - 1] : 0u;
    q.ppos = a.partner_pos[r];
    q.misc = (uint32_t)a.flags[r] | (b1 > b0 ? 256u : 0u);
-   f.rec[s] = q;
+   f.rec_arr[r] = q;
+}
+
+__global__ __launch_bounds__(256) void flat_mate_pack_kernel(FlatMateArgs f)
+{
+   const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+   if (s >= f.n_reads) return;
+   f.rec[s] = f.rec_arr[f.order[s]];
    f.state[s] = 0;
    f.out_key[s] = 0xFFFFFFFFu;
    f.out_val[s] = 0;
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(256) void flat_mate_walk_kernel(FlatMateArgs f)
 __global__ __launch_bounds__(256) void flat_mate_count_kernel(FlatMateArgs f)
 {
    const MateArgs &a = f.a;
-   const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+   const int64_t k = xcd_tile() * 256 + threadIdx.x; // (XCD-aware tile order: device_common.h)
    if (k <= a.n_loci) { // the first pair whose completing record is this cluster's: the keys ascend, cluster by cluster
       const uint32_t want = (uint32_t)a.locus_read_off[k];
       int64_t lo = 0, hi = f.n_reads;
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(256) void flat_mate_count_kernel(FlatMateArgs f)
 __global__ __launch_bounds__(256) void flat_mate_fill_kernel(FlatMateArgs f, int64_t n_pairs)
 {
    const MateArgs &a = f.a;
-   const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+   const int64_t k = xcd_tile() * 256 + threadIdx.x; // (XCD-aware tile order: device_common.h)
    if (k > n_pairs) return;
    const int64_t lo = f.lscan[k], ro = f.rscan[k];
    a.left_off[k] = lo;
