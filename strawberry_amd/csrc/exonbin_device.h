@@ -471,8 +471,11 @@ __device__ __forceinline__ void exonbin_locus_segbasis(const ExonBinArgs &a, int
    constexpr M kOne = 1, kTwo = 2, kAll = ~(M)0;
    uint32_t sb_prev = 0;
    bool ends_prev = false;
+   // (blocks no lane of the wave has are skipped: they would change nothing -- every statement below is under `in` --, and
+   // the typical wave's longest hit has two blocks of the four the loop is unrolled for)
 #pragma unroll
    for (int j = 0; j < kExonBinBlocks; ++j) {
+      if (j >= nbmax) break; // (uniform)
       const bool in = live & (j < h.nb);
       const uint32_t sa = (uint32_t)k_lo + (n_cnt[j] & 0xffffu), sb1 = (uint32_t)k_lo + (n_cnt[j] >> 16); // [sa, sb1)
       const bool any = in & (sb1 > sa);
@@ -614,6 +617,7 @@ __device__ __forceinline__ void exonbin_tile(const ExonBinArgs &a, const int64_t
 #pragma unroll
          for (int i = 0; i < kExonBinRegFeats; ++i) {
             const bool in = i < nf;
+            if (!__ballot(in)) break; // (uniform: the wave's longest list of features is typically three of the eight slots)
             const uint32_t nx = hit_sig_step(sig, L[i], R[i]);
             sig = in ? nx : sig;
             last_r = in ? R[i] : last_r;
@@ -738,8 +742,11 @@ __device__ __forceinline__ void exonbin_locus_seg128(const ExonBinArgs &a, int l
    constexpr u128 kOne = 1, kAll = ~(u128)0;
    uint32_t sb_prev = 0;
    bool ends_prev = false;
+   // (blocks no lane of the wave has are skipped: they would change nothing -- every statement below is under `in` --, and
+   // the typical wave's longest hit has two blocks of the four the loop is unrolled for)
 #pragma unroll
    for (int j = 0; j < kExonBinBlocks; ++j) {
+      if (j >= nbmax) break; // (uniform)
       const bool in = live & (j < h.nb);
       const uint32_t sa = (uint32_t)k_lo + (n_cnt[j] & 0xffffu), sb1 = (uint32_t)k_lo + (n_cnt[j] >> 16); // [sa, sb1)
       const bool any = in & (sb1 > sa);
