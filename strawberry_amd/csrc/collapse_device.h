@@ -96,19 +96,44 @@ struct Feat {
    uint8_t c;
 };
 __device__ __forceinline__ bool feat_less(const Feat &x, const Feat &y) { return x.l != y.l ? x.l < y.l : (x.r - x.l) < (y.r - y.l); }
-// CAP: the most features a mate may have (the merged list lives in registers / private memory: 2 CAP + 1 entries)
-template <int CAP>
-__device__ inline int hit_features_cap(const MateRef &a, const MateRef &b, uint8_t *out_c, uint32_t *out_l, uint32_t *out_r)
+// Where the merged list lives while it is sorted and fused.  Private memory (scratch) serves any length; for the short
+// mates of short reads the list sits in the workgroup's LDS, a column per thread: through scratch every pair of the
+// sorted-order kernels cost a round trip of its lines to HBM (profiles/r05_c3front_pmc_summary.json: flat_heads wrote
+// 17 GB for 1.8 GB of results, flat_fill 33 GB for 8 GB).
+template <int N>
+struct FeatsPrivate {
+   Feat g[N];
+   __device__ __forceinline__ Feat get(int i) const { return g[i]; }
+   __device__ __forceinline__ void set(int i, const Feat &f) { g[i] = f; }
+};
+struct FeatsLds { // entry i of this thread: lr[i * stride], c[i * stride] (the pointers carry the thread's own offset)
+   uint2 *lr;
+   uint8_t *c;
+   int stride;
+   __device__ __forceinline__ Feat get(int i) const
+   {
+      const uint2 v = lr[i * stride];
+      return Feat{v.x, v.y, c[i * stride]};
+   }
+   __device__ __forceinline__ void set(int i, const Feat &f) const
+   {
+      lr[i * stride] = uint2{f.l, f.r};
+      c[i * stride] = f.c;
+   }
+};
+template <class G>
+__device__ __forceinline__ int hit_features_in(G &g, const MateRef &a, const MateRef &b, uint8_t *out_c, uint32_t *out_l, uint32_t *out_r)
 {
-   Feat g[2 * CAP + 1];
    int n = 0;
    auto push_sorted = [&](const Feat &f) { // insertion keeps g sorted by (offset, length)
       int pos = n++;
-      while (pos > 0 && feat_less(f, g[pos - 1])) {
-         g[pos] = g[pos - 1];
+      while (pos > 0) {
+         const Feat q = g.get(pos - 1);
+         if (!feat_less(f, q)) break;
+         g.set(pos, q);
          --pos;
       }
-      g[pos] = f;
+      g.set(pos, f);
    };
    for (int i = 0; i < a.n; ++i) push_sorted(Feat{a.l[i], a.r[i], a.c[i]});
    for (int i = 0; i < b.n; ++i) push_sorted(Feat{b.l[i], b.r[i], b.c[i]});
@@ -119,38 +144,50 @@ __device__ inline int hit_features_cap(const MateRef &a, const MateRef &b, uint8
       } else {
          int m = 0;
          for (int i = 0; i < n; ++i) {
-            Feat f = g[i];
-            while (i + 1 < n && f.c == g[i + 1].c) {
+            Feat f = g.get(i);
+            while (i + 1 < n) {
+               const Feat q = g.get(i + 1);
+               if (f.c != q.c) break;
                if (f.c == 1) {
-                  if (!(f.l == g[i + 1].l && f.r == g[i + 1].r)) return 0; // two different introns
+                  if (!(f.l == q.l && f.r == q.r)) return 0; // two different introns
                } else {
-                  if (f.r < g[i + 1].l) return 0; // blocks that do not overlap (abutting included)
-                  f.r = max(f.r, g[i + 1].r);
+                  if (f.r < q.l) return 0; // blocks that do not overlap (abutting included)
+                  f.r = max(f.r, q.r);
                }
                ++i;
             }
-            g[m++] = f;
+            g.set(m++, f);
          }
          n = m;
          // merged blocks keep their offsets, so the (offset, length) order can only change among equal offsets
          for (int i = 1; i < n; ++i) {
-            const Feat f = g[i];
+            const Feat f = g.get(i);
             int pos = i;
-            while (pos > 0 && feat_less(f, g[pos - 1])) {
-               g[pos] = g[pos - 1];
+            while (pos > 0) {
+               const Feat q = g.get(pos - 1);
+               if (!feat_less(f, q)) break;
+               g.set(pos, q);
                --pos;
             }
-            g[pos] = f;
+            g.set(pos, f);
          }
       }
    }
    if (out_c)
       for (int i = 0; i < n; ++i) {
-         out_c[i] = g[i].c;
-         out_l[i] = g[i].l;
-         out_r[i] = g[i].r;
+         const Feat f = g.get(i);
+         out_c[i] = f.c;
+         out_l[i] = f.l;
+         out_r[i] = f.r;
       }
    return n;
+}
+// CAP: the most features a mate may have (the merged list in private memory: 2 CAP + 1 entries)
+template <int CAP>
+__device__ inline int hit_features_cap(const MateRef &a, const MateRef &b, uint8_t *out_c, uint32_t *out_l, uint32_t *out_r)
+{
+   FeatsPrivate<2 * CAP + 1> g;
+   return hit_features_in(g, a, b, out_c, out_l, out_r);
 }
 
 __device__ inline int hit_features_dev(const MateRef &a, const MateRef &b, uint8_t *out_c, uint32_t *out_l, uint32_t *out_r)

@@ -72,6 +72,20 @@ struct FlatCollapseArgs {
 
 enum : int32_t { kNeedSeqMass = 1, kNeedSeqSd = 2 };
 
+// The merged feature list of a pair of SHORT mates (at most kShortFeat features each: every short read) in the
+// workgroup's LDS; longer mates' in private memory.  `lr` / `c`: (2 kShortFeat + 1) x 256 entries of the calling workgroup.
+constexpr int kShortFeat = 4;
+constexpr int kShortSlots = 2 * kShortFeat + 1;
+__device__ __forceinline__ int flat_hit_features(const MateRef &x, const MateRef &y, uint2 *lr, uint8_t *c, uint8_t *out_c, uint32_t *out_l,
+                                                 uint32_t *out_r)
+{
+   if (x.n <= kShortFeat && y.n <= kShortFeat) {
+      FeatsLds g = {lr + threadIdx.x, c + threadIdx.x, 256};
+      return hit_features_in(g, x, y, out_c, out_l, out_r);
+   }
+   return hit_features_dev(x, y, out_c, out_l, out_r);
+}
+
 __device__ __forceinline__ int32_t flat_locus_of(const int64_t *off, int64_t n_loci, int64_t p)
 {
    int64_t lo = 0, hi = n_loci; // last l with off[l] <= p
@@ -242,6 +256,8 @@ __global__ __launch_bounds__(256) void flat_flags_kernel(FlatCollapseArgs f)
 // ---- unique hits: a kept pair that differs from the previous kept pair of its cluster (:685-697)
 __global__ __launch_bounds__(256) void flat_heads_kernel(FlatCollapseArgs f)
 {
+   __shared__ uint2 s_lr[kShortSlots * 256];
+   __shared__ uint8_t s_c[kShortSlots * 256];
    const CollapseArgs &a = f.a;
    const int64_t s = xcd_tile() * 256 + threadIdx.x; // (XCD-aware tile order: device_common.h)
    int filt = 0, rej = 0;
@@ -267,7 +283,7 @@ __global__ __launch_bounds__(256) void flat_heads_kernel(FlatCollapseArgs f)
                nf = -1;
                f.counts[2] = 1; // (any writer, same value)
             } else {
-               nf = hit_features_dev(x, y, nullptr, nullptr, nullptr);
+               nf = flat_hit_features(x, y, s_lr, s_c, nullptr, nullptr, nullptr);
                if (nf <= 0) nf = 0, rej = 1; // Contig(PairedHit) rejects the pair: no hit, its mass stays in the cluster's
             }
          }
@@ -416,6 +432,8 @@ __global__ __launch_bounds__(256) void flat_mass_any_order_kernel(FlatCollapseAr
 // ---- fill: a thread per sorted position that starts a unique hit
 __global__ __launch_bounds__(256) void flat_fill_kernel(FlatCollapseArgs f)
 {
+   __shared__ uint2 s_lr[kShortSlots * 256];
+   __shared__ uint8_t s_c[kShortSlots * 256];
    const CollapseArgs &a = f.a;
    const int64_t s = xcd_tile() * 256 + threadIdx.x; // (XCD-aware tile order: device_common.h)
    if (s >= f.n_pairs) return;
@@ -426,7 +444,7 @@ __global__ __launch_bounds__(256) void flat_fill_kernel(FlatCollapseArgs f)
    a.feat_off[h] = fb;
    a.hit_mass[h] = (float)f.gmass[f.gid[s]]; // stored as float (Contig::mass())
    const MateRef x = left_mate(a, p), y = right_mate(a, p);
-   if (x.n <= kMateFeatMax && y.n <= kMateFeatMax) hit_features_dev(x, y, a.feat_code + fb, a.feat_left + fb, a.feat_right + fb);
+   if (x.n <= kMateFeatMax && y.n <= kMateFeatMax) flat_hit_features(x, y, s_lr, s_c, a.feat_code + fb, a.feat_left + fb, a.feat_right + fb);
    // (else: flat_fill_long_kernel writes the features)
 }
 
