@@ -64,12 +64,27 @@ static int pair_mates_flat(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t *
    } while (0)
    SB_TRY(hipSetDevice(M->device));
    const size_t n = (size_t)nr, n1 = n + 1, nl1 = (size_t)n_loci + 1;
+   if (n_loci > ((int64_t)1 << 23)) return api_fail(SBGPU_EUNSUPPORTED, "sbgpu_pair_mates_device: more than 2^23 clusters in one call; split the call");
+   // the first sort's key (flat_mate_keys_kernel): 32 bits = the number of a group of 2^g neighbouring clusters, then a hash
+   // of (cluster, read id) of two bits more than the logarithm of the biggest group's record count; the smallest g that fits
    unsigned locus_bits = 1;
    while (((int64_t)1 << locus_bits) < n_loci) ++locus_bits;
+   unsigned hash_bits = 32, group_shift = locus_bits, sort_bits = 32;
+   for (unsigned g = 0; g <= locus_bits; ++g) {
+      int64_t biggest = 1;
+      for (int64_t l = 0; l < n_loci; l += (int64_t)1 << g) biggest = std::max(biggest, locus_read_off[std::min<int64_t>(n_loci, l + ((int64_t)1 << g))] - locus_read_off[l]);
+      unsigned hb = 2;
+      while (((int64_t)1 << (hb - 2)) < biggest) ++hb;
+      if (locus_bits - g + hb <= 32 || g == locus_bits) {
+         hash_bits = std::min(32u, hb), group_shift = g;
+         sort_bits = std::min(32u, locus_bits - g + hash_bits);
+         break;
+      }
+   }
    size_t tmp_bytes = 0;
    {
       size_t b = 0;
-      (void)rocprim::radix_sort_pairs(nullptr, b, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, rocprim::counting_iterator<int32_t>(0), (int32_t *)nullptr, n, 0, 32 + locus_bits, s);
+      (void)rocprim::radix_sort_pairs(nullptr, b, (const uint32_t *)nullptr, (uint32_t *)nullptr, rocprim::counting_iterator<int32_t>(0), (int32_t *)nullptr, n, 0, sort_bits, s);
       tmp_bytes = std::max(tmp_bytes, b);
       (void)rocprim::radix_sort_pairs(nullptr, b, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr, n, 0, 32, s);
       tmp_bytes = std::max(tmp_bytes, b);
@@ -82,7 +97,7 @@ static int pair_mates_flat(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t *
       off += up256(bytes ? bytes : 8);
       return o;
    };
-   const size_t o_roff = take(nl1 * 8), o_key = take(n * 8), o_skey = take(n * 8), o_order = take(n * 4), o_rec = take(n * sizeof(sb::FlatRec));
+   const size_t o_roff = take(nl1 * 8), o_key = take(n * 4), o_skey = take(n * 4), o_order = take(n * 4), o_rec = take(n * sizeof(sb::FlatRec));
    const size_t o_rarr = take(n * sizeof(sb::FlatRec));
    const size_t o_state = take(n), o_okey = take(n * 4), o_oval = take(n * 4), o_prec = take(n * 4), o_pval = take(n * 4);
    const size_t o_lf = take(n1 * 4), o_rf = take(n1 * 4), o_ls = take(n1 * 8), o_rs = take(n1 * 8), o_poff = take(nl1 * 8), o_counts = take(64 * 64), o_tmp = take(tmp_bytes);
@@ -100,8 +115,9 @@ static int pair_mates_flat(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t *
    a.flags = dr->flags;
    a.nh = dr->nh;
    f.n_reads = nr;
-   f.key = (unsigned long long *)(w + o_key);
-   f.skey = (const unsigned long long *)(w + o_skey);
+   f.key = (uint32_t *)(w + o_key);
+   f.skey = (const uint32_t *)(w + o_skey);
+   f.hash_bits = (int)hash_bits, f.group_shift = (int)group_shift;
    f.order = (const int32_t *)(w + o_order);
    f.rec = (sb::FlatRec *)(w + o_rec);
    f.rec_arr = (sb::FlatRec *)(w + o_rarr);
@@ -117,7 +133,7 @@ static int pair_mates_flat(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t *
    size_t tb = tmp_bytes;
    hipLaunchKernelGGL(sb::flat_mate_keys_kernel, dim3(gr), dim3(256), 0, s, f);
    SB_TRY(hipGetLastError());
-   SB_TRY(rocprim::radix_sort_pairs(tmp, tb, (const unsigned long long *)f.key, (unsigned long long *)(w + o_skey), rocprim::counting_iterator<int32_t>(0), (int32_t *)(w + o_order), n, 0, 32 + locus_bits, s));
+   SB_TRY(rocprim::radix_sort_pairs(tmp, tb, (const uint32_t *)f.key, (uint32_t *)(w + o_skey), rocprim::counting_iterator<int32_t>(0), (int32_t *)(w + o_order), n, 0, sort_bits, s));
    hipLaunchKernelGGL(sb::flat_mate_pack_kernel, dim3(gr), dim3(256), 0, s, f);
    hipLaunchKernelGGL(sb::flat_mate_walk_kernel, dim3(gr), dim3(256), 0, s, f);
    SB_TRY(hipGetLastError());

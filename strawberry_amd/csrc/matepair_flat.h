@@ -32,14 +32,15 @@ struct FlatRec { // a record as the rules see it (sorted order)
    uint32_t rid_lo, rid_hi;
    uint32_t left, right; // first block's left end, last block's right end
    uint32_t ppos;        // the mate's position
-   uint32_t misc;        // bits 0-7: the record's flags; bit 8: it has blocks
+   uint32_t misc;        // bits 0-7: the record's flags; bit 8: it has blocks; bits 9-31: its cluster
 };
 
 struct FlatMateArgs {
    MateArgs a;       // the records (inputs) and the pairs' arrays (outputs of the fill)
    int64_t n_reads;
-   unsigned long long *key;         // per record, arrival order
-   const unsigned long long *skey;  // sorted
+   uint32_t *key;                   // per record, arrival order: (cluster >> group_shift) << hash_bits | the top hash_bits of a hash of (cluster, read id)
+   const uint32_t *skey;            // sorted
+   int hash_bits, group_shift;
    const int32_t *order;            // record (arrival index) at sorted position s
    FlatRec *rec_arr;                // the records as the rules see them, ARRIVAL order (made beside the keys, with coalesced loads)
    FlatRec *rec;                    // sorted order
@@ -76,7 +77,15 @@ __global__ __launch_bounds__(256) void flat_mate_keys_kernel(FlatMateArgs f)
    }
    const MateArgs &a = f.a;
    const uint64_t rid = a.read_id[r];
-   f.key[r] = ((unsigned long long)lo << 32) | flat_hash32(rid);
+   // The sort only has to bring the records of a (cluster, read id) together, in arrival order (it is stable); the pairs
+   // are put in order by the second sort.  So the key is a hash of the two -- as many bits as the records of a GROUP of
+   // neighbouring clusters ask for (two more than their count's logarithm: a run holds half a foreign record on average;
+   // the walk tells them apart by read id and cluster) -- behind the group's number: 32 bits in all, four passes over
+   // 8-byte elements where (cluster << 32 | hash) took six over 12-byte ones.  The group in front keeps the sorted order
+   // local: the pack kernel's gather of a sorted position's record then stays inside the group's records (a few MB, in
+   // cache), where a key that is all hash sends every lane to a line of its own anywhere in the call's 9 GB.
+   const uint32_t h = f.hash_bits ? flat_hash32(rid ^ ((uint64_t)lo * 0x9E3779B97F4A7C15ull)) >> (32 - f.hash_bits) : 0u;
+   f.key[r] = (f.hash_bits < 32 ? (uint32_t)(lo >> f.group_shift) << f.hash_bits : 0u) | h;
    // the record as the rules see it, here where the lanes' records are neighbours in every array (round 5: the pack kernel
    // used to collect these fields in SORTED order -- seven scattered reads per record, 94 GB fetched for 15 GB wanted at
    // 3.9e8 records; it now moves one 24-byte struct per record)
@@ -86,7 +95,7 @@ __global__ __launch_bounds__(256) void flat_mate_keys_kernel(FlatMateArgs f)
    q.left = b1 > b0 ? a.block_left[b0] : 0u;
    q.right = b1 > b0 ? a.block_right[b1 - 1] : 0u;
    q.ppos = a.partner_pos[r];
-   q.misc = (uint32_t)a.flags[r] | (b1 > b0 ? 256u : 0u);
+   q.misc = (uint32_t)a.flags[r] | (b1 > b0 ? 256u : 0u) | ((uint32_t)lo << 9);
    f.rec_arr[r] = q;
 }
 
@@ -106,11 +115,12 @@ __global__ __launch_bounds__(256) void flat_mate_walk_kernel(FlatMateArgs f)
    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
    int refused = 0, orphan = 0, single = 0, complete = 0;
    if (s < f.n_reads) {
-      const unsigned long long k = f.skey[s];
+      const uint32_t k = f.skey[s];
       const FlatRec me = f.rec[s];
-      bool first = true; // no earlier record of this read id in the key's run
+      auto mine = [&](const FlatRec &q) { return q.rid_lo == me.rid_lo && q.rid_hi == me.rid_hi && (q.misc >> 9) == (me.misc >> 9); };
+      bool first = true; // no earlier record of this read id (and cluster) in the key's run
       for (int64_t t = s - 1; t >= 0 && f.skey[t] == k; --t)
-         if (f.rec[t].rid_lo == me.rid_lo && f.rec[t].rid_hi == me.rid_hi) {
+         if (mine(f.rec[t])) {
             first = false;
             break;
          }
@@ -121,7 +131,7 @@ __global__ __launch_bounds__(256) void flat_mate_walk_kernel(FlatMateArgs f)
          bool far_open = false;
          for (int64_t t = s; t < f.n_reads && f.skey[t] == k; ++t) {
             const FlatRec q = t == s ? me : f.rec[t];
-            if (q.rid_lo != me.rid_lo || q.rid_hi != me.rid_hi) continue; // another read id with the same hash
+            if (!mine(q)) continue; // another read id (or cluster) with the same hash
             const uint32_t fl = q.misc & 255u;
             if (fl & 16u) continue; // not this cluster's record (sbgpu_assign_reads_*): never offered to addOpenHit
             if (!(q.misc & 256u) || (int64_t)q.right - (int64_t)q.left > kMaxFragSpanDev) { // :512-518
@@ -150,7 +160,7 @@ __global__ __launch_bounds__(256) void flat_mate_walk_kernel(FlatMateArgs f)
                for (int64_t o = s + 64; o < t && hit < 0; ++o) {
                   if (f.state[o] != 1) continue;
                   const FlatRec w = f.rec[o];
-                  if (w.rid_lo != me.rid_lo || w.rid_hi != me.rid_hi) continue; // (another read id of the run, waiting for ITS mate)
+                  if (!mine(w)) continue; // (another read id of the run, waiting for ITS mate)
                   if (fits(w)) hit = o;
                }
             if (hit >= 0) {
