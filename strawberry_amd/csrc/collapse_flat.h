@@ -86,17 +86,6 @@ __device__ __forceinline__ int flat_hit_features(const MateRef &x, const MateRef
    return hit_features_dev(x, y, out_c, out_l, out_r);
 }
 
-__device__ __forceinline__ int32_t flat_locus_of(const int64_t *off, int64_t n_loci, int64_t p)
-{
-   int64_t lo = 0, hi = n_loci; // last l with off[l] <= p
-   while (hi - lo > 1) {
-      const int64_t mid = (lo + hi) >> 1;
-      if (off[mid] <= p) lo = mid;
-      else hi = mid;
-   }
-   return (int32_t)lo;
-}
-
 // ---- keys: a thread per pair
 __global__ __launch_bounds__(256) void flat_keys_kernel(FlatCollapseArgs f)
 {
@@ -106,8 +95,10 @@ __global__ __launch_bounds__(256) void flat_keys_kernel(FlatCollapseArgs f)
    int32_t l = -1;
    unsigned long long sum = 0, sum2 = 0;
    int nm = 0;
+   const int64_t p0 = p - (int64_t)(threadIdx.x & 63u); // (the wave's first pair; the search is the wave's: device_common.h)
+   const int32_t lw = p0 < f.n_pairs ? (int32_t)wave_range_of(a.locus_pair_off, a.n_loci, p0, f.n_pairs) : -1;
    if (p < f.n_pairs) {
-      l = flat_locus_of(a.locus_pair_off, a.n_loci, p);
+      l = lw;
       const MateRef x = left_mate(a, p), y = right_mate(a, p);
       if (x.n > kMateFeatLong || y.n > kMateFeatLong) bad |= kCollapseLongMate;
       uint32_t lp = 0xffffffffu, rp = 0xffffffffu;

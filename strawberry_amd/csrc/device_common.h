@@ -84,4 +84,33 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
 
+// The range an element of a wave lies in -- "the last l with off[l] <= e", off ascending from off[0] <= e -- for the 64
+// CONSECUTIVE elements e0 .. e0 + 63 of a wave (e = e0 + lane; elements from n_elems on ask as the last real one).  A lane
+// that searches by itself makes log2(n_off) DEPENDENT loads (17 for 60 000 ranges); here the wave finds the ranges of
+// its first and of its last element 64 ways at a time (three rounds of two loads for 60 000), and a lane then only
+// searches between those two -- usually the same range or neighbours.  Every lane of the wave must call.
+__device__ __forceinline__ int64_t wave_range_of(const int64_t *__restrict__ off, int64_t n_off, int64_t e0, int64_t n_elems)
+{
+   const int lane = (int)(threadIdx.x & 63u);
+   const int64_t first = e0, last = e0 + 63 < n_elems ? e0 + 63 : n_elems - 1; // (uniform)
+   int64_t lo_a = 0, hi_a = n_off, lo_b = 0, hi_b = n_off;                     // the answers lie in [lo, hi)
+   while (hi_a - lo_a > 1 || hi_b - lo_b > 1) {
+      const int64_t st_a = (hi_a - lo_a + 63) >> 6, st_b = (hi_b - lo_b + 63) >> 6;
+      const int64_t ia = lo_a + lane * st_a, ib = lo_b + lane * st_b;
+      const int64_t va = ia < hi_a ? off[ia] : INT64_MAX, vb = ib < hi_b ? off[ib] : INT64_MAX;
+      const unsigned long long ma = __ballot(va <= first), mb = __ballot(vb <= last); // (prefixes of the lanes: off ascends)
+      const int ka = ma ? 63 - __clzll((long long)ma) : 0, kb = mb ? 63 - __clzll((long long)mb) : 0;
+      lo_a += ka * st_a, hi_a = lo_a + st_a < hi_a ? lo_a + st_a : hi_a;
+      lo_b += kb * st_b, hi_b = lo_b + st_b < hi_b ? lo_b + st_b : hi_b;
+   }
+   const int64_t e = e0 + lane < n_elems ? e0 + lane : n_elems - 1;
+   int64_t lo = lo_a, hi = lo_b + 1;
+   while (hi - lo > 1) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (off[mid] <= e) lo = mid;
+      else hi = mid;
+   }
+   return lo;
+}
+
 } // namespace sb

@@ -68,13 +68,10 @@ __device__ __forceinline__ uint32_t flat_hash32(uint64_t x)
 __global__ __launch_bounds__(256) void flat_mate_keys_kernel(FlatMateArgs f)
 {
    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+   const int64_t r0 = r - (int64_t)(threadIdx.x & 63u);
+   if (r0 >= f.n_reads) return; // (the whole wave)
+   const int64_t lo = wave_range_of(f.a.locus_read_off, f.a.n_loci, r0, f.n_reads); // last cluster whose records begin at or before r
    if (r >= f.n_reads) return;
-   int64_t lo = 0, hi = f.a.n_loci; // last cluster whose records begin at or before r
-   while (hi - lo > 1) {
-      const int64_t mid = (lo + hi) >> 1;
-      if (f.a.locus_read_off[mid] <= r) lo = mid;
-      else hi = mid;
-   }
    const MateArgs &a = f.a;
    const uint64_t rid = a.read_id[r];
    // The sort only has to bring the records of a (cluster, read id) together, in arrival order (it is stable); the pairs
