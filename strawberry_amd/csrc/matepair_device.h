@@ -19,6 +19,7 @@
 #include <stdint.h>
 
 #include "bitonic_big.h"
+#include "device_common.h"
 
 namespace sb {
 
@@ -392,16 +393,17 @@ __global__ __launch_bounds__(256) void cluster_bounds_kernel(AssignArgs a)
 __global__ __launch_bounds__(256) void assign_reads_kernel(AssignArgs a)
 {
    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_reads; i += stride) {
+   const int64_t n_in = min(a.n_reads, a.pos[a.n_clusters]); // the records inside some cluster's pass
+   const int lane = (int)(threadIdx.x & 63u);
+   for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x - lane; i0 < a.n_reads; i0 += stride) { // (a wave's records: uniform)
+      const int64_t i = i0 + lane;
+      // the last cluster whose pass begins at or before record i and is not empty there: pos[k] <= i < pos[k + 1] (the
+      // wave's search, device_common.h)
+      const int64_t kw = i0 < n_in ? wave_range_of(a.pos, a.n_clusters, i0, n_in) : 0;
+      if (i >= a.n_reads) continue;
       int32_t c = -1;
-      if (i < a.pos[a.n_clusters]) {
-         int64_t lo = 0, hi = a.n_clusters; // the last cluster whose pass begins at or before record i and is not empty there
-         while (lo < hi) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (a.pos[mid + 1] <= i) lo = mid + 1;
-            else hi = mid;
-         }
-         const int64_t k = lo; // pos[k] <= i < pos[k + 1]
+      if (i < n_in) {
+         const int64_t k = kw;
          const bool lt = a.r_ref[i] < a.c_ref[k] || (a.r_ref[i] == a.c_ref[k] && a.r_right[i] < a.c_left[k]); // hit_lt_cluster
          const int xs = a.r_flags ? (a.r_flags[i] >> 2) & 3 : 0;
          const bool strand_off = xs != 0 && xs != (int)a.c_strand[k]; // alignments.cpp:1168
