@@ -225,15 +225,12 @@ int sbgpu_bam_decode_device(sbgpu_ctx_t *c, const uint8_t *d_bytes, int64_t n_by
       *out = B;
       return SBGPU_OK;
    }
-   const size_t nn = (size_t)n, n1 = nn + 1;
-   auto as_i64_u8 = [] __device__(uint8_t v) { return (int64_t)v; };
+   const size_t nn = (size_t)n, n1 = nn + 1, nt = (nn + 63) / 64, nt1 = nt + 1; // (tiles of 64 records: a wave's pass)
    auto as_i64_i32 = [] __device__(int32_t v) { return (int64_t)v; };
    size_t tmp_bytes = 0;
    {
       size_t b = 0;
-      (void)rocprim::exclusive_scan(nullptr, b, rocprim::make_transform_iterator((const uint8_t *)nullptr, as_i64_u8), (int64_t *)nullptr, (int64_t)0, n1, rocprim::plus<int64_t>(), s);
-      tmp_bytes = std::max(tmp_bytes, b);
-      (void)rocprim::exclusive_scan(nullptr, b, rocprim::make_transform_iterator((const int32_t *)nullptr, as_i64_i32), (int64_t *)nullptr, (int64_t)0, n1, rocprim::plus<int64_t>(), s);
+      (void)rocprim::exclusive_scan(nullptr, b, rocprim::make_transform_iterator((const int32_t *)nullptr, as_i64_i32), (int64_t *)nullptr, (int64_t)0, nt1, rocprim::plus<int64_t>(), s);
       tmp_bytes = std::max(tmp_bytes, b);
    }
    size_t off = 0;
@@ -244,11 +241,12 @@ int sbgpu_bam_decode_device(sbgpu_ctx_t *c, const uint8_t *d_bytes, int64_t n_by
    };
    const size_t o_status = take(nn), o_acc = take(n1), o_nb = take(n1 * 4), o_rid = take(nn * 8), o_ref = take(nn * 4), o_nh = take(nn * 4),
                 o_nm = take(nn * 4), o_rl = take(nn * 4), o_left = take(nn * 4), o_right = take(nn * 4), o_pp = take(nn * 4), o_sf = take(nn * 4),
-                o_fl = take(nn), o_ib = take(nn * 4 * 2 * sb::kBamInlineBlocks), o_rat = take(n1 * 8), o_bat = take(n1 * 8), o_cnt = take(16 * 8), o_tmp = take(tmp_bytes);
+                o_fl = take(nn), o_ib = take(nn * 4 * 2 * sb::kBamInlineBlocks), o_tr = take(nt1 * 4), o_tb = take(nt1 * 4), o_rat = take(nt1 * 8), o_bat = take(nt1 * 8),
+                o_cnt = take(16 * 8), o_tmp = take(tmp_bytes);
    SB_TRY(sb::dev_take(off, &w, &w_cap));
    SB_TRY(hipMemsetAsync(w + o_cnt, 0, 16 * 8, s));
-   SB_TRY(hipMemsetAsync(w + o_acc + nn, 0, 1, s));
-   SB_TRY(hipMemsetAsync(w + o_nb + nn * 4, 0, 4, s));
+   SB_TRY(hipMemsetAsync(w + o_tr + nt * 4, 0, 4, s)); // (the scans' entry beyond the last tile)
+   SB_TRY(hipMemsetAsync(w + o_tb + nt * 4, 0, 4, s));
    sb::BamScanArgs a = {};
    a.bytes = d_bytes, a.n_bytes = n_bytes, a.rec_off = d_rec_off, a.n = n, a.opts = *opts;
    a.status = (uint8_t *)(w + o_status), a.n_blocks = (int32_t *)(w + o_nb), a.accepted = (uint8_t *)(w + o_acc);
@@ -257,6 +255,7 @@ int sbgpu_bam_decode_device(sbgpu_ctx_t *c, const uint8_t *d_bytes, int64_t n_by
    a.partner_pos = (uint32_t *)(w + o_pp), a.sam_flag = (uint32_t *)(w + o_sf), a.flags = (uint8_t *)(w + o_fl);
    a.inline_blocks = (uint32_t *)(w + o_ib);
    a.counts = (unsigned long long *)(w + o_cnt);
+   a.tile_reads = (int32_t *)(w + o_tr), a.tile_blocks = (int32_t *)(w + o_tb);
    const int64_t cap = (int64_t)sb::ctx_cu_count(c) * 32, blocks = std::min<int64_t>((n + 255) / 256, cap);
    // the staging buffer of a workgroup (one wave, 64 records): 1.1 x 64 average records, 8-64 KB (SBGPU_BAM_STAGE_KB overrides)
    static const int stage_kb_env = std::getenv("SBGPU_BAM_STAGE_KB") ? std::atoi(std::getenv("SBGPU_BAM_STAGE_KB")) : 0;
@@ -277,14 +276,14 @@ int sbgpu_bam_decode_device(sbgpu_ctx_t *c, const uint8_t *d_bytes, int64_t n_by
    }
    SB_TRY(hipGetLastError());
    size_t tb = tmp_bytes;
-   SB_TRY(rocprim::exclusive_scan(w + o_tmp, tb, rocprim::make_transform_iterator((const uint8_t *)a.accepted, as_i64_u8), (int64_t *)(w + o_rat), (int64_t)0, n1, rocprim::plus<int64_t>(), s));
+   SB_TRY(rocprim::exclusive_scan(w + o_tmp, tb, rocprim::make_transform_iterator((const int32_t *)a.tile_reads, as_i64_i32), (int64_t *)(w + o_rat), (int64_t)0, nt1, rocprim::plus<int64_t>(), s));
    tb = tmp_bytes;
-   SB_TRY(rocprim::exclusive_scan(w + o_tmp, tb, rocprim::make_transform_iterator((const int32_t *)a.n_blocks, as_i64_i32), (int64_t *)(w + o_bat), (int64_t)0, n1, rocprim::plus<int64_t>(), s));
+   SB_TRY(rocprim::exclusive_scan(w + o_tmp, tb, rocprim::make_transform_iterator((const int32_t *)a.tile_blocks, as_i64_i32), (int64_t *)(w + o_bat), (int64_t)0, nt1, rocprim::plus<int64_t>(), s));
    // the totals: the output arena's size depends on them
    int64_t totals[2] = {0, 0};
    unsigned long long counts[16];
-   SB_TRY(hipMemcpyAsync(&totals[0], w + o_rat + nn * 8, 8, hipMemcpyDeviceToHost, s));
-   SB_TRY(hipMemcpyAsync(&totals[1], w + o_bat + nn * 8, 8, hipMemcpyDeviceToHost, s));
+   SB_TRY(hipMemcpyAsync(&totals[0], w + o_rat + nt * 8, 8, hipMemcpyDeviceToHost, s));
+   SB_TRY(hipMemcpyAsync(&totals[1], w + o_bat + nt * 8, 8, hipMemcpyDeviceToHost, s));
    SB_TRY(hipMemcpyAsync(counts, w + o_cnt, sizeof(counts), hipMemcpyDeviceToHost, s));
    SB_TRY(hipStreamSynchronize(s));
    B->n_reads = totals[0], B->n_blocks = totals[1];
@@ -295,7 +294,7 @@ int sbgpu_bam_decode_device(sbgpu_ctx_t *c, const uint8_t *d_bytes, int64_t n_by
    SB_TRY(hipMemcpyAsync(B->status, w + o_status, nn, hipMemcpyDeviceToDevice, s));
    sb::BamFillArgs f = {};
    f.bytes = d_bytes, f.rec_off = d_rec_off, f.n = n;
-   f.accepted = a.accepted, f.read_at = (const int64_t *)(w + o_rat), f.block_at = (const int64_t *)(w + o_bat);
+   f.accepted = a.accepted, f.tile_read_at = (const int64_t *)(w + o_rat), f.tile_block_at = (const int64_t *)(w + o_bat);
    f.read_id = a.read_id, f.ref = a.ref, f.nh = a.nh, f.nm = a.nm, f.read_len = a.read_len;
    f.left = a.left, f.right = a.right, f.partner_pos = a.partner_pos, f.sam_flag = a.sam_flag, f.flags = a.flags;
    f.n_blocks = a.n_blocks, f.inline_blocks = a.inline_blocks;

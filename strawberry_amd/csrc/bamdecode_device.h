@@ -300,6 +300,7 @@ struct BamScanArgs {
    uint8_t *flags;
    uint32_t *inline_blocks; // [n][2 * kBamInlineBlocks]: left ends, right ends of the record's first blocks
    unsigned long long *counts; // [16]: 0-10 by status, 11: records with the paired flag that got as far as :605
+   int32_t *tile_reads, *tile_blocks; // per tile of 64 records (a wave's pass): accepted records, their blocks
 };
 
 // One wave per workgroup, 64 records per pass.  A lane that walks its record straight from global memory touches two or
@@ -347,6 +348,8 @@ __global__ __launch_bounds__(64) void bam_scan_kernel(BamScanArgs a, int stage_b
       }
       __syncthreads();
       const int64_t r = r0 + lane;
+      bool my_ok = false;
+      int my_nb = 0;
       if (r < r1) {
          const int64_t o0 = a.rec_off[r], o1 = a.rec_off[r + 1];
          const bool inside = o0 >= s0 && o1 >= o0 && o1 <= s1 && o0 >= 0 && o1 <= a.n_bytes; // (the caller's offsets are device data)
@@ -373,7 +376,15 @@ __global__ __launch_bounds__(64) void bam_scan_kernel(BamScanArgs a, int stage_b
          }
          atomicAdd(&cnt[x.status < 11 ? x.status : 10], 1u);
          if (x.paired) atomicAdd(&cnt[11], 1u);
+         my_ok = x.status == SBGPU_BAM_OK;
+         my_nb = my_ok ? x.n_blocks : 0;
       }
+      // the tile's counts: the device-wide scans run over TILES (1/64 of the records), the fill finds a record's place from
+      // its tile's and its neighbours' inside the wave
+      const unsigned long long okm = __ballot(my_ok);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) my_nb += __shfl_xor(my_nb, o);
+      if (lane == 0) a.tile_reads[tile] = (int32_t)__popcll(okm), a.tile_blocks[tile] = my_nb;
       __syncthreads(); // (the next pass overwrites the buffer)
    }
    if (lane < 16 && cnt[lane]) atomicAdd(&a.counts[lane], (unsigned long long)cnt[lane]);
@@ -384,8 +395,8 @@ struct BamFillArgs {
    const int64_t *rec_off;
    int64_t n;
    const uint8_t *accepted;
-   const int64_t *read_at;  // [n + 1] exclusive scan of accepted
-   const int64_t *block_at; // [n + 1] exclusive scan of n_blocks
+   const int64_t *tile_read_at;  // [tiles + 1] exclusive scan of the tiles' accepted records (a tile: 64 records)
+   const int64_t *tile_block_at; // [tiles + 1] ... of their blocks
    // per record (the scan's)
    const uint64_t *read_id;
    const int32_t *ref, *nh, *nm, *read_len;
@@ -405,18 +416,29 @@ struct BamFillArgs {
 
 __global__ __launch_bounds__(256) void bam_fill_kernel(BamFillArgs a)
 {
-   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-   for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.n; r += stride) {
-      if (r == a.n - 1) a.o_block_off[a.read_at[a.n]] = a.block_at[a.n];
-      if (!a.accepted[r]) continue;
-      const int64_t k = a.read_at[r], b = a.block_at[r];
+   const int lane = (int)(threadIdx.x & 63u);
+   const int64_t n_tiles = (a.n + 63) >> 6, wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+   for (int64_t tile = wave; tile < n_tiles; tile += n_waves) { // a wave per tile of 64 records
+      const int64_t r = (tile << 6) + lane;
+      const bool acc = r < a.n && a.accepted[r];
+      const int nb = acc ? a.n_blocks[r] : 0;
+      // the record's place: its tile's (the scans over the tiles) and the accepted records / blocks of the lanes in front
+      const unsigned long long okm = __ballot(acc);
+      int incl = nb;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+         const int t = __shfl_up(incl, o);
+         if (lane >= o) incl += t;
+      }
+      if (r == a.n - 1) a.o_block_off[a.tile_read_at[n_tiles]] = a.tile_block_at[n_tiles];
+      if (!acc) continue;
+      const int64_t k = a.tile_read_at[tile] + __popcll(okm & ((1ull << lane) - 1ull)), b = a.tile_block_at[tile] + (incl - nb);
       a.o_record[k] = r;
       a.o_read_id[k] = a.read_id[r];
       a.o_ref[k] = a.ref[r], a.o_nh[k] = a.nh[r], a.o_nm[k] = a.nm[r], a.o_read_len[k] = a.read_len[r];
       a.o_left[k] = a.left[r], a.o_right[k] = a.right[r], a.o_partner_pos[k] = a.partner_pos[r], a.o_sam_flag[k] = a.sam_flag[r];
       a.o_flags[k] = a.flags[r];
       a.o_block_off[k] = b;
-      const int nb = a.n_blocks[r];
       if (nb <= kBamInlineBlocks) { // (nearly every record: nothing of the stream is read again)
          const uint32_t *ib = a.inline_blocks + r * (2 * kBamInlineBlocks);
          for (int q = 0; q < nb; ++q) a.o_block_left[b + q] = ib[q], a.o_block_right[b + q] = ib[kBamInlineBlocks + q];
