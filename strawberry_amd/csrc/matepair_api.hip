@@ -67,6 +67,7 @@ static int pair_mates_flat(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t *
    if (n_loci > ((int64_t)1 << 23)) return api_fail(SBGPU_EUNSUPPORTED, "sbgpu_pair_mates_device: more than 2^23 clusters in one call; split the call");
    // the first sort's key (flat_mate_keys_kernel): 32 bits = the number of a group of 2^g neighbouring clusters, then a hash
    // of (cluster, read id) of two bits more than the logarithm of the biggest group's record count; the smallest g that fits
+   const size_t nt = (n1 + 63) / 64, nt1 = nt + 1; // tiles of 64 pairs (flat_mate_count_kernel's waves)
    unsigned locus_bits = 1;
    while (((int64_t)1 << locus_bits) < n_loci) ++locus_bits;
    unsigned hash_bits = 32, group_shift = locus_bits, sort_bits = 32;
@@ -88,7 +89,7 @@ static int pair_mates_flat(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t *
       tmp_bytes = std::max(tmp_bytes, b);
       (void)rocprim::radix_sort_pairs(nullptr, b, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr, n, 0, 32, s);
       tmp_bytes = std::max(tmp_bytes, b);
-      (void)rocprim::exclusive_scan(nullptr, b, rocprim::make_transform_iterator((const int32_t *)nullptr, [] __device__(int32_t v) { return (int64_t)v; }), (int64_t *)nullptr, (int64_t)0, n1, rocprim::plus<int64_t>(), s);
+      (void)rocprim::exclusive_scan(nullptr, b, rocprim::make_transform_iterator((const int32_t *)nullptr, [] __device__(int32_t v) { return (int64_t)v; }), (int64_t *)nullptr, (int64_t)0, nt1, rocprim::plus<int64_t>(), s);
       tmp_bytes = std::max(tmp_bytes, b);
    }
    size_t off = 0;
@@ -100,9 +101,11 @@ static int pair_mates_flat(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t *
    const size_t o_roff = take(nl1 * 8), o_key = take(n * 4), o_skey = take(n * 4), o_order = take(n * 4), o_rec = take(n * sizeof(sb::FlatRec));
    const size_t o_rarr = take(n * sizeof(sb::FlatRec));
    const size_t o_state = take(n), o_okey = take(n * 4), o_oval = take(n * 4), o_prec = take(n * 4), o_pval = take(n * 4);
-   const size_t o_lf = take(n1 * 4), o_rf = take(n1 * 4), o_ls = take(n1 * 8), o_rs = take(n1 * 8), o_poff = take(nl1 * 8), o_counts = take(64 * 64), o_tmp = take(tmp_bytes);
+   const size_t o_lf = take(n1 * 4), o_rf = take(n1 * 4), o_tl = take(nt1 * 4), o_tr = take(nt1 * 4), o_ls = take(nt1 * 8), o_rs = take(nt1 * 8), o_poff = take(nl1 * 8), o_counts = take(64 * 64), o_tmp = take(tmp_bytes);
    SB_TRY(sb::dev_take(off, &w, &w_cap));
    SB_TRY(hipMemsetAsync(w + o_counts, 0, 64 * 64, s));
+   SB_TRY(hipMemsetAsync(w + o_tl + nt * 4, 0, 4, s)); // (the scans' entry beyond the last tile)
+   SB_TRY(hipMemsetAsync(w + o_tr + nt * 4, 0, 4, s));
    SB_TRY(hipMemcpyAsync(w + o_roff, locus_read_off, nl1 * 8, hipMemcpyHostToDevice, s));
    sb::FlatMateArgs f = {};
    sb::MateArgs &a = f.a;
@@ -125,6 +128,7 @@ static int pair_mates_flat(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t *
    f.out_key = (uint32_t *)(w + o_okey), f.out_val = (uint32_t *)(w + o_oval);
    f.pair_rec = (const uint32_t *)(w + o_prec), f.pair_val = (const uint32_t *)(w + o_pval);
    f.lfeat = (int32_t *)(w + o_lf), f.rfeat = (int32_t *)(w + o_rf);
+   f.tile_l = (int32_t *)(w + o_tl), f.tile_r = (int32_t *)(w + o_tr);
    f.lscan = (const int64_t *)(w + o_ls), f.rscan = (const int64_t *)(w + o_rs);
    f.locus_pair_off = (int64_t *)(w + o_poff);
    f.counts = (unsigned long long *)(w + o_counts);
@@ -142,14 +146,14 @@ static int pair_mates_flat(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t *
    hipLaunchKernelGGL(sb::flat_mate_count_kernel, dim3(sb::xcd_grid(gr1)), dim3(256), 0, s, f);
    SB_TRY(hipGetLastError());
    tb = tmp_bytes;
-   SB_TRY(rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator((const int32_t *)f.lfeat, [] __device__(int32_t v) { return (int64_t)v; }), (int64_t *)(w + o_ls), (int64_t)0, n1, rocprim::plus<int64_t>(), s));
+   SB_TRY(rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator((const int32_t *)f.tile_l, [] __device__(int32_t v) { return (int64_t)v; }), (int64_t *)(w + o_ls), (int64_t)0, nt1, rocprim::plus<int64_t>(), s));
    tb = tmp_bytes;
-   SB_TRY(rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator((const int32_t *)f.rfeat, [] __device__(int32_t v) { return (int64_t)v; }), (int64_t *)(w + o_rs), (int64_t)0, n1, rocprim::plus<int64_t>(), s));
+   SB_TRY(rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator((const int32_t *)f.tile_r, [] __device__(int32_t v) { return (int64_t)v; }), (int64_t *)(w + o_rs), (int64_t)0, nt1, rocprim::plus<int64_t>(), s));
    unsigned long long slots[64 * 8], counts[4] = {0, 0, 0, 0};
    int64_t totals[2] = {0, 0};
    SB_TRY(hipMemcpyAsync(slots, w + o_counts, sizeof(slots), hipMemcpyDeviceToHost, s));
-   SB_TRY(hipMemcpyAsync(&totals[0], w + o_ls + n * 8, 8, hipMemcpyDeviceToHost, s));
-   SB_TRY(hipMemcpyAsync(&totals[1], w + o_rs + n * 8, 8, hipMemcpyDeviceToHost, s));
+   SB_TRY(hipMemcpyAsync(&totals[0], w + o_ls + nt * 8, 8, hipMemcpyDeviceToHost, s));
+   SB_TRY(hipMemcpyAsync(&totals[1], w + o_rs + nt * 8, 8, hipMemcpyDeviceToHost, s));
    SB_TRY(hipMemcpyAsync(M->locus_pair_off.data(), w + o_poff, nl1 * 8, hipMemcpyDeviceToHost, s));
    SB_TRY(hipStreamSynchronize(s));
    for (int k = 0; k < 64; ++k)

@@ -50,7 +50,9 @@ struct FlatMateArgs {
                                     // index (0x7FFFFFFF: a single read)
    const uint32_t *pair_rec, *pair_val; // out_key / out_val sorted by out_key: pair k of the call
    int32_t *lfeat, *rfeat;          // per pair (one entry beyond the end: 0)
-   const int64_t *lscan, *rscan;    // exclusive scans of those
+   int32_t *tile_l, *tile_r;        // their sums over tiles of 64 pairs (a wave of the count kernel; one entry beyond the end: 0)
+   const int64_t *lscan, *rscan;    // exclusive scans of the TILES' sums: the device-wide scans run over 1/64 of the pairs, the
+                                    // fill adds the part inside its wave
    int64_t *locus_pair_off;         // [n_loci + 1]
    unsigned long long *counts;      // 64 slots of 8 words (a cache line each): [0] refused [1] orphan [2] single [3] complete
 };
@@ -221,8 +223,7 @@ __global__ __launch_bounds__(256) void flat_mate_count_kernel(FlatMateArgs f)
          return l2;
       }() : lo;
    }
-   if (k > f.n_reads) return;
-   int lf = 0, rf = 0;
+   int lf = 0, rf = 0; // (lanes beyond the end stay for the wave's sums)
    if (k < f.n_reads && f.pair_rec[k] != 0xFFFFFFFFu) {
       const int64_t r = f.pair_rec[k];
       const uint32_t v = f.pair_val[k];
@@ -233,16 +234,31 @@ __global__ __launch_bounds__(256) void flat_mate_count_kernel(FlatMateArgs f)
       lf = me_right ? nf_w : nf_me;
       rf = me_right ? nf_me : nf_w;
    }
-   f.lfeat[k] = lf;
-   f.rfeat[k] = rf;
+   if (k <= f.n_reads) f.lfeat[k] = lf, f.rfeat[k] = rf;
+   int sl = lf, sr = rf; // (a wave's 64 k are one tile)
+#pragma unroll
+   for (int o = 32; o > 0; o >>= 1) {
+      sl += __shfl_xor(sl, o);
+      sr += __shfl_xor(sr, o);
+   }
+   if ((threadIdx.x & 63u) == 0 && k <= f.n_reads) f.tile_l[k >> 6] = sl, f.tile_r[k >> 6] = sr;
 }
 
 __global__ __launch_bounds__(256) void flat_mate_fill_kernel(FlatMateArgs f, int64_t n_pairs)
 {
    const MateArgs &a = f.a;
    const int64_t k = xcd_tile() * 256 + threadIdx.x; // (XCD-aware tile order: device_common.h)
+   // the pair's first features: its tile's (the scans over the tiles) and the features of the pairs in front of it in the wave
+   const int lane = (int)(threadIdx.x & 63u);
+   const int lf = k <= f.n_reads ? f.lfeat[k] : 0, rf = k <= f.n_reads ? f.rfeat[k] : 0;
+   int il = lf, ir = rf;
+#pragma unroll
+   for (int o = 1; o < 64; o <<= 1) {
+      const int tl = __shfl_up(il, o), tr = __shfl_up(ir, o);
+      if (lane >= o) il += tl, ir += tr;
+   }
    if (k > n_pairs) return;
-   const int64_t lo = f.lscan[k], ro = f.rscan[k];
+   const int64_t lo = f.lscan[k >> 6] + (il - lf), ro = f.rscan[k >> 6] + (ir - rf);
    a.left_off[k] = lo;
    a.right_off[k] = ro;
    if (k == n_pairs) return; // (the entry beyond the last pair: the totals)
