@@ -87,8 +87,6 @@ static int pair_mates_flat(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t *
       size_t b = 0;
       (void)rocprim::radix_sort_pairs(nullptr, b, (const uint32_t *)nullptr, (uint32_t *)nullptr, rocprim::counting_iterator<int32_t>(0), (int32_t *)nullptr, n, 0, sort_bits, s);
       tmp_bytes = std::max(tmp_bytes, b);
-      (void)rocprim::radix_sort_pairs(nullptr, b, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr, n, 0, 32, s);
-      tmp_bytes = std::max(tmp_bytes, b);
       (void)rocprim::exclusive_scan(nullptr, b, rocprim::make_transform_iterator((const int32_t *)nullptr, [] __device__(int32_t v) { return (int64_t)v; }), (int64_t *)nullptr, (int64_t)0, nt1, rocprim::plus<int64_t>(), s);
       tmp_bytes = std::max(tmp_bytes, b);
    }
@@ -100,11 +98,12 @@ static int pair_mates_flat(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t *
    };
    const size_t o_roff = take(nl1 * 8), o_key = take(n * 4), o_skey = take(n * 4), o_order = take(n * 4), o_rec = take(n * sizeof(sb::FlatRec));
    const size_t o_rarr = take(n * sizeof(sb::FlatRec));
-   const size_t o_state = take(n), o_okey = take(n * 4), o_oval = take(n * 4), o_prec = take(n * 4), o_pval = take(n * 4);
+   const size_t o_state = take(n), o_done = take(n * 8), o_td = take(nt1 * 4), o_tda = take(nt1 * 8), o_prec = take(n * 4), o_pval = take(n * 4);
    const size_t o_lf = take(n1 * 4), o_rf = take(n1 * 4), o_tl = take(nt1 * 4), o_tr = take(nt1 * 4), o_ls = take(nt1 * 8), o_rs = take(nt1 * 8), o_poff = take(nl1 * 8), o_counts = take(64 * 64), o_tmp = take(tmp_bytes);
    SB_TRY(sb::dev_take(off, &w, &w_cap));
    SB_TRY(hipMemsetAsync(w + o_counts, 0, 64 * 64, s));
-   SB_TRY(hipMemsetAsync(w + o_tl + nt * 4, 0, 4, s)); // (the scans' entry beyond the last tile)
+   SB_TRY(hipMemsetAsync(w + o_td + ((n + 63) / 64) * 4, 0, 4, s)); // (the scans' entry beyond the last tile)
+   SB_TRY(hipMemsetAsync(w + o_tl + nt * 4, 0, 4, s));
    SB_TRY(hipMemsetAsync(w + o_tr + nt * 4, 0, 4, s));
    SB_TRY(hipMemcpyAsync(w + o_roff, locus_read_off, nl1 * 8, hipMemcpyHostToDevice, s));
    sb::FlatMateArgs f = {};
@@ -125,7 +124,9 @@ static int pair_mates_flat(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t *
    f.rec = (sb::FlatRec *)(w + o_rec);
    f.rec_arr = (sb::FlatRec *)(w + o_rarr);
    f.state = (uint8_t *)(w + o_state);
-   f.out_key = (uint32_t *)(w + o_okey), f.out_val = (uint32_t *)(w + o_oval);
+   f.done = (unsigned long long *)(w + o_done);
+   f.tile_done = (int32_t *)(w + o_td), f.tile_done_at = (const int64_t *)(w + o_tda);
+   f.pair_rec_w = (uint32_t *)(w + o_prec), f.pair_val_w = (uint32_t *)(w + o_pval);
    f.pair_rec = (const uint32_t *)(w + o_prec), f.pair_val = (const uint32_t *)(w + o_pval);
    f.lfeat = (int32_t *)(w + o_lf), f.rfeat = (int32_t *)(w + o_rf);
    f.tile_l = (int32_t *)(w + o_tl), f.tile_r = (int32_t *)(w + o_tr);
@@ -141,8 +142,10 @@ static int pair_mates_flat(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t *
    hipLaunchKernelGGL(sb::flat_mate_pack_kernel, dim3(gr), dim3(256), 0, s, f);
    hipLaunchKernelGGL(sb::flat_mate_walk_kernel, dim3(gr), dim3(256), 0, s, f);
    SB_TRY(hipGetLastError());
+   hipLaunchKernelGGL(sb::flat_mate_done_tiles_kernel, dim3(gr), dim3(256), 0, s, f);
    tb = tmp_bytes;
-   SB_TRY(rocprim::radix_sort_pairs(tmp, tb, (const uint32_t *)f.out_key, (uint32_t *)(w + o_prec), (const uint32_t *)f.out_val, (uint32_t *)(w + o_pval), n, 0, 32, s));
+   SB_TRY(rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator((const int32_t *)f.tile_done, [] __device__(int32_t v) { return (int64_t)v; }), (int64_t *)(w + o_tda), (int64_t)0, (n + 63) / 64 + 1, rocprim::plus<int64_t>(), s));
+   hipLaunchKernelGGL(sb::flat_mate_order_kernel, dim3(gr), dim3(256), 0, s, f);
    hipLaunchKernelGGL(sb::flat_mate_count_kernel, dim3(sb::xcd_grid(gr1)), dim3(256), 0, s, f);
    SB_TRY(hipGetLastError());
    tb = tmp_bytes;

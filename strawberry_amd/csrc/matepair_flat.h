@@ -45,10 +45,14 @@ struct FlatMateArgs {
    FlatRec *rec_arr;                // the records as the rules see them, ARRIVAL order (made beside the keys, with coalesced loads)
    FlatRec *rec;                    // sorted order
    uint8_t *state;                  // sorted order: 0 nothing, 1 waits for its mate, 2 taken
-   uint32_t *out_key, *out_val;     // sorted order: the completing record's arrival index (0xFFFFFFFF: completes nothing);
-                                    // bit 31: the completing record is the RIGHT mate, bits 0-30: the waiting mate's arrival
-                                    // index (0x7FFFFFFF: a single read)
-   const uint32_t *pair_rec, *pair_val; // out_key / out_val sorted by out_key: pair k of the call
+   unsigned long long *done;        // ARRIVAL order, zeroed by the keys kernel: what record r completes -- 0 nothing, else bit 32 set and
+                                    // in the low word: bit 31 the completing record is the RIGHT mate, bits 0-30 the waiting mate's
+                                    // arrival index (0x7FFFFFFF: a single read)
+   int32_t *tile_done;              // completing records per tile of 64 arrival positions (one entry beyond the end: 0)
+   const int64_t *tile_done_at;     // ... their exclusive scan
+   uint32_t *pair_rec_w, *pair_val_w;   // (pair_rec / pair_val, writable)
+   const uint32_t *pair_rec, *pair_val; // pair k of the call: the completing records in arrival order (their arrival index; 0xFFFFFFFF
+                                        // from the last pair on) and their low words of `done`
    int32_t *lfeat, *rfeat;          // per pair (one entry beyond the end: 0)
    int32_t *tile_l, *tile_r;        // their sums over tiles of 64 pairs (a wave of the count kernel; one entry beyond the end: 0)
    const int64_t *lscan, *rscan;    // exclusive scans of the TILES' sums: the device-wide scans run over 1/64 of the pairs, the
@@ -96,6 +100,7 @@ __global__ __launch_bounds__(256) void flat_mate_keys_kernel(FlatMateArgs f)
    q.ppos = a.partner_pos[r];
    q.misc = (uint32_t)a.flags[r] | (b1 > b0 ? 256u : 0u) | ((uint32_t)lo << 9);
    f.rec_arr[r] = q;
+   f.done[r] = 0ull;
 }
 
 __global__ __launch_bounds__(256) void flat_mate_pack_kernel(FlatMateArgs f)
@@ -104,8 +109,6 @@ __global__ __launch_bounds__(256) void flat_mate_pack_kernel(FlatMateArgs f)
    if (s >= f.n_reads) return;
    f.rec[s] = f.rec_arr[f.order[s]];
    f.state[s] = 0;
-   f.out_key[s] = 0xFFFFFFFFu;
-   f.out_val[s] = 0;
 }
 
 // the first record of every read id walks its group (arrival order) with the reference's open-mate rules
@@ -139,8 +142,7 @@ __global__ __launch_bounds__(256) void flat_mate_walk_kernel(FlatMateArgs f)
             }
             const uint32_t r_t = (uint32_t)f.order[t];
             if (q.ppos == 0 || (fl & 2u)) { // a single read (:535-545)
-               f.out_key[t] = r_t;
-               f.out_val[t] = ((fl & 1u) ? 0x80000000u : 0u) | 0x7FFFFFFFu;
+               f.done[r_t] = (1ull << 32) | ((fl & 1u) ? 0x80000000u : 0u) | 0x7FFFFFFFu;
                ++single;
                continue;
             }
@@ -165,8 +167,7 @@ __global__ __launch_bounds__(256) void flat_mate_walk_kernel(FlatMateArgs f)
             if (hit >= 0) {
                const FlatRec w = hit == s ? me : f.rec[hit];
                const bool waiting_is_left = w.ppos > w.left; // the waiting mate is the left one when its partner lies behind it (:559-585)
-               f.out_key[t] = r_t;
-               f.out_val[t] = (waiting_is_left ? 0x80000000u : 0u) | (uint32_t)f.order[hit];
+               f.done[r_t] = (1ull << 32) | (waiting_is_left ? 0x80000000u : 0u) | (uint32_t)f.order[hit];
                if (hit - s < 64) open_mask &= ~(1ull << (hit - s));
                else f.state[hit] = 2;
                ++complete;
@@ -198,6 +199,33 @@ __global__ __launch_bounds__(256) void flat_mate_walk_kernel(FlatMateArgs f)
       const long long v = (long long)part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
       if (v) atomicAdd(&f.counts[(size_t)(blockIdx.x & 63) * 8 + threadIdx.x], (unsigned long long)v);
    }
+}
+
+// ---- the pairs' order: addHit is called when the second mate arrives, so pair k of the call is the k-th COMPLETING record in
+// arrival order.  Round 4 sorted (completing record's arrival index, value) once more (four radix passes over 3.9e8
+// elements, half of them "completes nothing"); the walk now leaves the value AT the completing record's arrival index
+// (`done`; a scatter inside the group's records), and the order is a compaction: completing records per tile of 64
+// arrival positions, a scan over the tiles, a pass that writes every completing record to its rank.
+__global__ __launch_bounds__(256) void flat_mate_done_tiles_kernel(FlatMateArgs f)
+{
+   const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+   const unsigned long long m = __ballot(r < f.n_reads && f.done[r] != 0ull);
+   if ((threadIdx.x & 63u) == 0 && r < f.n_reads) f.tile_done[r >> 6] = (int32_t)__popcll(m);
+}
+__global__ __launch_bounds__(256) void flat_mate_order_kernel(FlatMateArgs f)
+{
+   const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+   const int lane = (int)(threadIdx.x & 63u);
+   const unsigned long long d = r < f.n_reads ? f.done[r] : 0ull;
+   const unsigned long long m = __ballot(d != 0ull);
+   if (r >= f.n_reads) return;
+   const int64_t n_pairs = f.tile_done_at[(f.n_reads + 63) >> 6];
+   if (d != 0ull) {
+      const int64_t k = f.tile_done_at[r >> 6] + __popcll(m & ((1ull << lane) - 1ull));
+      f.pair_rec_w[k] = (uint32_t)r;
+      f.pair_val_w[k] = (uint32_t)d;
+   }
+   if (r >= n_pairs) f.pair_rec_w[r] = 0xFFFFFFFFu; // (position r of the list, not record r: from the last pair on)
 }
 
 // pair k (the k-th completing record in arrival order): its mates' feature counts; and where every cluster's pairs begin
