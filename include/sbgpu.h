@@ -521,11 +521,12 @@ typedef struct sbgpu_matepairs sbgpu_matepairs_t;
 /* Host form: `reads` host arrays, the records of cluster l are [locus_read_off[l], locus_read_off[l + 1]). */
 int sbgpu_pair_mates_host(int64_t n_loci, const sbgpu_reads_t *reads, const int64_t *locus_read_off, sbgpu_matepairs_t **out);
 /* Device form (csrc/matepair_flat.h): `d_reads` device arrays, locus_read_off host.  All clusters of the call at once:
- * one stable device-wide radix sort on (cluster, hash of the read id) brings a read id's records together in arrival
- * order, the first record of every read id walks its group with the reference's open-mate rules (any number of mates
- * of one read id may wait), a second sort ranks the pairs by completion, and the pairs are written where
- * sbgpu_collapse_pairs_device reads them -- nothing but per-cluster offsets and four counters comes back.
- * Up to 2^31 records per call; beyond: SBGPU_EUNSUPPORTED.                                                          */
+ * one stable device-wide radix sort on a 32-bit key (a group of neighbouring clusters, then a hash of (cluster, read id))
+ * brings a read id's records together in arrival order, the first record of every read id walks its group with the
+ * reference's open-mate rules (any number of mates of one read id may wait), a compaction of the completing records in
+ * arrival order ranks the pairs, and the pairs are written where sbgpu_collapse_pairs_device reads them -- nothing but
+ * per-cluster offsets and four counters comes back.
+ * Up to 2^31 records and 2^23 clusters per call; beyond: SBGPU_EUNSUPPORTED.                                        */
 int sbgpu_pair_mates_device(sbgpu_ctx_t *ctx, int64_t n_loci, const sbgpu_reads_t *d_reads, const int64_t *locus_read_off,
                             void *stream, sbgpu_matepairs_t **out);
 void sbgpu_matepairs_destroy(sbgpu_matepairs_t *m);
@@ -589,7 +590,7 @@ int64_t sbgpu_bam_index_host(const uint8_t *bytes, int64_t n_bytes, int64_t *rec
 int sbgpu_bam_decode_host(const uint8_t *bytes, int64_t n_bytes, const int64_t *rec_off, int64_t n_records,
                           const sbgpu_bam_opts_t *opts, sbgpu_bamreads_t **out);
 /* Device form (csrc/bamdecode_device.h): `d_bytes` and `d_rec_off` device arrays; one lane per record decides and counts
- * its blocks, two device-wide scans place the accepted records and their blocks, a second pass writes them.  The
+ * its blocks, two scans over the waves' totals place the accepted records and their blocks, a second pass writes them.  The
  * handle's arrays stay on the device: sbgpu_bamreads_reads hands them to sbgpu_assign_reads_device /
  * sbgpu_pair_mates_device as they are.  A record whose offsets do not ascend inside [0, n_bytes] is TRUNCATED, not read.                                                                                */
 int sbgpu_bam_decode_device(sbgpu_ctx_t *ctx, const uint8_t *d_bytes, int64_t n_bytes, const int64_t *d_rec_off, int64_t n_records,

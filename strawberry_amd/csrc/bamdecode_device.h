@@ -4,8 +4,8 @@
 // The reference reads a BAM record (samtools 0.1.19's bam_read1), then decides -- on the flag word, the CIGAR, three
 // auxiliary tags and four option globals -- whether the record becomes a ReadHit and with which interval, strand, mate
 // position, NH and read id.  Integer and byte work on ~150-400 bytes per record, every record by itself: one lane per
-// record here, two passes (decide + count the aligned blocks; compact the accepted records and write their blocks), a
-// device-wide scan between them.  The same decoder body serves the host entry (sbgpu_bam_decode_host).
+// record here, two passes (decide + count the aligned blocks; compact the accepted records and write their blocks), two
+// scans over the waves' totals (tiles of 64 records) between them.  The same decoder body serves the host entry (sbgpu_bam_decode_host).
 //
 // What is decoded is the UNCOMPRESSED record stream (after BGZF inflate, which stays with the caller -- zlib on host
 // cores) behind the BAM header: int32 block_size, the 32-byte core, read name, CIGAR, sequence, qualities, tags.

@@ -25,7 +25,7 @@ namespace sb {
 
 constexpr int kCollapseMax = 4096;   // pairs of one locus (LDS sort)
 constexpr int kCollapseThreads = 256;
-constexpr int kMateFeatMax = 24;     // features of one mate the main kernels handle (the merged list in registers)
+constexpr int kMateFeatMax = 24;     // features of one mate the main kernels handle (the merged list in LDS up to four per mate -- collapse_flat.h -- else in private memory)
 constexpr int kMateFeatLong = 512;   // ... and the flat form's kernels for long mates (long reads: the list in private memory)
 enum : int32_t { kCollapseTooMany = 1, kCollapseLongMate = 2, kCollapseNoMates = 4 };
 

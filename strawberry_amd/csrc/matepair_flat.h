@@ -4,19 +4,23 @@
 // Only records of ONE read id of ONE cluster ever interact.  The per-cluster form brought them together with a bitonic sort
 // per cluster (LDS, or global memory for a highly expressed gene) and a sample's time was its biggest clusters'.  Here:
 //
-//   keys    a thread per record: (cluster << 32) | a 32-bit hash of the read id;
+//   keys    a thread per record: a 32-bit key -- the number of a group of neighbouring clusters, then a hash of (cluster,
+//           read id) -- and the 24 bytes of the record the rules look at, both in arrival order (coalesced);
 //   sort    ONE stable device-wide radix sort (rocPRIM onesweep) on that key, the arrival index as value: the records of a
-//           read id become neighbours in ARRIVAL order.  Two read ids of a cluster that share a hash share a run of the key;
-//           the walk below takes the records of ITS read id out of the run (the ids themselves are compared), so a collision
-//           costs a few extra comparisons and nothing else;
-//   pack    the fields the rules look at, gathered into sorted order once (24 bytes per record, read in sequence afterwards);
+//           read id become neighbours in ARRIVAL order.  Records of other read ids or clusters that share the key share
+//           the run; the walk below takes the records of ITS read id and cluster out of it (ids and clusters themselves
+//           are compared), so a collision costs a few extra comparisons and nothing else;
+//   pack    the records' 24 bytes moved into sorted order once (read in sequence afterwards);
 //   walk    the first record of every read id walks its group with the reference's open-mate rules (:535-641): a waiting
 //           mate is a state byte per record ("open" until a partner takes it, oldest first), so any number of mates of one
-//           read id may wait -- the per-cluster form's list of 8 is gone;
-//   rank    addHit is called when the SECOND mate arrives: the pairs are ordered by their completing record's arrival index.
-//           A second radix sort, on that index (records that complete nothing last), IS that order -- for all clusters at
-//           once, because the records come cluster by cluster; where a cluster's pairs begin is a binary search in it;
-//   count   the mates' feature counts per pair, two device-wide scans for their places;
+//           read id may wait -- the per-cluster form's list of 8 is gone.  What a record completes is left at the
+//           record's ARRIVAL index;
+//   rank    addHit is called when the SECOND mate arrives: the pairs are ordered by their completing record's arrival index
+//           -- a compaction of the completing records in arrival order (counts per tile of 64 positions, a scan over the
+//           tiles, a pass that writes every completing record to its rank; round 4 sorted a second time), for all
+//           clusters at once, because the records come cluster by cluster; where a cluster's pairs begin is a binary
+//           search in the list;
+//   count   the mates' feature counts per pair and their sums per tile of 64 pairs; two scans over the tiles;
 //   fill    a thread per pair writes its mates as MATCH / INTRON features (contig.cpp:12-53) and its mass.
 #pragma once
 
@@ -28,7 +32,7 @@
 
 namespace sb {
 
-struct FlatRec { // a record as the rules see it (sorted order)
+struct FlatRec { // a record as the rules see it
    uint32_t rid_lo, rid_hi;
    uint32_t left, right; // first block's left end, last block's right end
    uint32_t ppos;        // the mate's position

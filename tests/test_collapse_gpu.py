@@ -107,6 +107,27 @@ def test_device_collapse_random_stress(ctx, oracle):
         XU.check_collapse_against_oracle(oracle, n_loci, args[1], nh, args[3], args[4], g[0], g[1], g[2])
 
 
+def test_device_collapse_many_small_clusters(ctx):
+    """A pair's cluster is found by a search the WAVE makes 64 ways at a time (wave_range_of, csrc/device_common.h): cluster
+    counts around the powers of 64, empty clusters in between, zero to three pairs each -- the host form's unique hits."""
+    from strawberry_amd import exonbin as eb
+    rng = np.random.default_rng(29)
+    for n_loci in (1, 2, 63, 64, 65, 130, 4095, 4097, 9000):
+        loc, mass, left, right = [], [], [], []
+        for l in range(n_loci):
+            for _ in range(int(rng.integers(0, 4)) if rng.random() < 0.8 else 0):
+                a = 1000 + 5000 * l + int(rng.integers(0, 40))
+                loc.append(l)
+                mass.append(1.0 if rng.random() < 0.8 else 0.5)
+                left.append([(a, a + 74)])
+                right.append([(a + 200, a + 274)] if rng.random() < 0.8 else [])
+        if not loc:
+            loc, mass, left, right = [0], [1.0], [[(1000, 1074)]], [[]]
+        args = (n_loci, loc, mass, left, right)
+        g, r = eb.collapse_pairs(*args, device=ctx), eb.collapse_pairs(*args)
+        same(g[0], r[0], g[1], r[1], g[2], r[2])
+
+
 def test_device_collapse_big_loci(ctx, oracle):
     """Loci of more than 4096 pairs (the LDS sort's limit) take the same steps with their arrays in global memory
     (collapse_big_kernel): 4097 (just over), 20 000 and 70 000 pairs next to small loci, duplicates, NH masses whose sums

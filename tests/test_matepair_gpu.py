@@ -62,6 +62,29 @@ def test_device_pairing_equals_oracle_random_clusters(ctx, oracle):
                 np.testing.assert_array_equal(x, y)
 
 
+def test_device_pairing_many_small_clusters(ctx):
+    """The kernels find a record's / a pair's cluster with a search the WAVE makes 64 ways at a time (wave_range_of,
+    csrc/device_common.h), and the pairing's sort key holds a GROUP of clusters in its upper bits: cluster counts around the
+    powers of 64 and of two, with empty clusters in between, one record to a few pairs each -- the pairs must be the host form's
+    (tests/test_collapse_gpu.py has the same for the unique hits)."""
+    from strawberry_amd import exonbin as eb
+    rng = np.random.default_rng(23)
+    for n_loci in (1, 2, 63, 64, 65, 130, 4095, 4097, 9000):
+        clusters = [MU.random_cluster(rng, int(rng.integers(0, 4)) if rng.random() < 0.8 else 0, base=1000 + 5000 * l, exotic=False)
+                    for l in range(n_loci)]
+        if not any(clusters):
+            clusters[0] = MU.random_cluster(rng, 2, base=1000, exotic=False)
+        loc = [l for l, c in enumerate(clusters) for _ in c]
+        reads = eb.Reads(loc, *MU.arrays([r for c in clusters for r in c]))
+        got, host = eb.pair_mates(n_loci, reads, device=ctx), eb.pair_mates(n_loci, reads)
+        assert got["info"] == dict(host["info"], on_device=True), n_loci
+        for k in ("pair_off", "mass", "left_off", "right_off"):
+            np.testing.assert_array_equal(got[k], host[k], err_msg="%s %d" % (k, n_loci))
+        for side in ("left", "right"):
+            for x, y in zip(got[side], host[side]):
+                np.testing.assert_array_equal(x, y)
+
+
 def test_device_pairing_big_clusters(ctx, oracle):
     """Clusters of more than 8192 records (the LDS sort's limit) take the same steps with 1024 threads and the sort's
     arrays in global memory (matepair_big_kernel): 8193 single reads (just over), and random clusters of 6 000 and
