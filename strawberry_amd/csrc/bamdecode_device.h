@@ -293,7 +293,8 @@ struct BamScanArgs {
    // per record
    uint8_t *status;
    int32_t *n_blocks; // 0 for a refused record
-   uint8_t *accepted; // 0 / 1
+   uint8_t *accepted; // 0: refused; 1: accepted; 2: accepted, and its ONE block is [left, right] (an unspliced read: nearly every
+                      // record) -- its inline blocks are then neither written here nor read by the fill
    uint64_t *read_id;
    int32_t *ref, *nh, *nm, *read_len;
    uint32_t *left, *right, *partner_pos, *sam_flag;
@@ -363,13 +364,14 @@ __global__ __launch_bounds__(64) void bam_scan_kernel(BamScanArgs a, int stage_b
             bam_decode_record(a.bytes + o0, o1 - o0, a.opts, x);
          }
          a.status[r] = x.status;
-         a.accepted[r] = x.status == SBGPU_BAM_OK;
+         const bool one_plain = x.status == SBGPU_BAM_OK && x.n_blocks == 1 && x.bl[0] == x.left && x.br[0] == x.right;
+         a.accepted[r] = x.status == SBGPU_BAM_OK ? (one_plain ? 2 : 1) : 0;
          a.n_blocks[r] = x.status == SBGPU_BAM_OK ? x.n_blocks : 0;
          a.read_id[r] = x.read_id;
          a.ref[r] = x.ref, a.nh[r] = x.nh, a.nm[r] = x.nm, a.read_len[r] = x.read_len;
          a.left[r] = x.left, a.right[r] = x.right, a.partner_pos[r] = x.partner_pos, a.sam_flag[r] = x.sam_flag;
          a.flags[r] = x.flags;
-         if (x.status == SBGPU_BAM_OK) {
+         if (x.status == SBGPU_BAM_OK && !one_plain) {
             uint32_t *ib = a.inline_blocks + r * (2 * kBamInlineBlocks);
 #pragma unroll
             for (int k = 0; k < kBamInlineBlocks; ++k) ib[k] = x.bl[k], ib[kBamInlineBlocks + k] = x.br[k];
@@ -420,7 +422,8 @@ __global__ __launch_bounds__(256) void bam_fill_kernel(BamFillArgs a)
    const int64_t n_tiles = (a.n + 63) >> 6, wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
    for (int64_t tile = wave; tile < n_tiles; tile += n_waves) { // a wave per tile of 64 records
       const int64_t r = (tile << 6) + lane;
-      const bool acc = r < a.n && a.accepted[r];
+      const int acc_kind = r < a.n ? (int)a.accepted[r] : 0;
+      const bool acc = acc_kind != 0;
       const int nb = acc ? a.n_blocks[r] : 0;
       // the record's place: its tile's (the scans over the tiles) and the accepted records / blocks of the lanes in front
       const unsigned long long okm = __ballot(acc);
@@ -436,10 +439,13 @@ __global__ __launch_bounds__(256) void bam_fill_kernel(BamFillArgs a)
       a.o_record[k] = r;
       a.o_read_id[k] = a.read_id[r];
       a.o_ref[k] = a.ref[r], a.o_nh[k] = a.nh[r], a.o_nm[k] = a.nm[r], a.o_read_len[k] = a.read_len[r];
-      a.o_left[k] = a.left[r], a.o_right[k] = a.right[r], a.o_partner_pos[k] = a.partner_pos[r], a.o_sam_flag[k] = a.sam_flag[r];
+      const uint32_t left = a.left[r], right = a.right[r];
+      a.o_left[k] = left, a.o_right[k] = right, a.o_partner_pos[k] = a.partner_pos[r], a.o_sam_flag[k] = a.sam_flag[r];
       a.o_flags[k] = a.flags[r];
       a.o_block_off[k] = b;
-      if (nb <= kBamInlineBlocks) { // (nearly every record: nothing of the stream is read again)
+      if (acc_kind == 2) { // one block, the read's own interval
+         a.o_block_left[b] = left, a.o_block_right[b] = right;
+      } else if (nb <= kBamInlineBlocks) { // (nearly every record: nothing of the stream is read again)
          const uint32_t *ib = a.inline_blocks + r * (2 * kBamInlineBlocks);
          for (int q = 0; q < nb; ++q) a.o_block_left[b + q] = ib[q], a.o_block_right[b + q] = ib[kBamInlineBlocks + q];
       } else {

@@ -79,6 +79,24 @@ constexpr int kShortSlots = 2 * kShortFeat + 1;
 __device__ __forceinline__ int flat_hit_features(const MateRef &x, const MateRef &y, uint2 *lr, uint8_t *c, uint8_t *out_c, uint32_t *out_l,
                                                  uint32_t *out_r)
 {
+   // Mates that lie apart (a GAP between them: the usual paired-end fragment), or a single mate: the list is the left mate's
+   // features, the GAP, the right mate's -- already in (offset, length) order when each mate's own features ascend, which
+   // is checked while they are read (a caller's pairs need not; sbgpu_pair_mates_* write them so).  Nothing to sort or fuse.
+   {
+      const bool both = x.n > 0 && y.n > 0;
+      bool plain = !both || (int64_t)y.l[0] - (int64_t)x.r[x.n - 1] - 1 > 0;
+      for (int i = 1; plain && i < x.n; ++i) plain = x.l[i] > x.l[i - 1];
+      for (int i = 1; plain && i < y.n; ++i) plain = y.l[i] > y.l[i - 1];
+      if (plain) {
+         if (out_c) {
+            int n = 0;
+            for (int i = 0; i < x.n; ++i, ++n) out_c[n] = x.c[i], out_l[n] = x.l[i], out_r[n] = x.r[i];
+            if (both) out_c[n] = 2, out_l[n] = x.r[x.n - 1] + 1u, out_r[n] = y.l[0] - 1u, ++n;
+            for (int i = 0; i < y.n; ++i, ++n) out_c[n] = y.c[i], out_l[n] = y.l[i], out_r[n] = y.r[i];
+         }
+         return x.n + y.n + (both ? 1 : 0);
+      }
+   }
    if (x.n <= kShortFeat && y.n <= kShortFeat) {
       FeatsLds g = {lr + threadIdx.x, c + threadIdx.x, 256};
       return hit_features_in(g, x, y, out_c, out_l, out_r);
@@ -244,6 +262,92 @@ __global__ __launch_bounds__(256) void flat_flags_kernel(FlatCollapseArgs f)
    f.kept_pos[s] = sk ? -1 : (int32_t)s;
 }
 
+// A pair whose mates have at most kShortFeat features each, in registers: every load of the pair goes out together (a
+// level of the kernels below), none waits for another.  Slots beyond a mate's features hold zeros, so two pairs are equal
+// (ReadHit::operator== on both mates) exactly when every word is.
+struct ShortPair {
+   int nl, nr; // -1: not held here (a mate with more features): the arrays serve
+   uint32_t l[2 * kShortFeat], r[2 * kShortFeat];
+   uint32_t c[2]; // the codes, a byte per slot: [0] the left mate's, [1] the right mate's
+};
+struct PairOffsets {
+   int64_t lo, ro;
+   int nl, nr;
+};
+__device__ __forceinline__ PairOffsets flat_pair_offsets(const CollapseArgs &a, int64_t p, bool live)
+{
+   PairOffsets o = {0, 0, 0, 0};
+   if (live) { // (four loads in flight together)
+      const int64_t l0 = a.left_off[p], l1 = a.left_off[p + 1], r0 = a.right_off[p], r1 = a.right_off[p + 1];
+      o.lo = l0, o.ro = r0, o.nl = (int)(l1 - l0), o.nr = (int)(r1 - r0);
+   }
+   return o;
+}
+// A mate's (up to) four features come with ONE 16-byte load per coordinate array and one 4-byte load of the codes, from its
+// first feature on -- what lies behind its last feature (the next mates') is masked off --, where four slots x three arrays
+// cost twelve loads and twelve 64-bit addresses per mate.  Reading four slots from the mate's first must stay inside the
+// arrays: `nlf` / `nrf`, the arrays' lengths (left_off / right_off at n_pairs); a mate too close to the end is read slot
+// by slot.
+struct __attribute__((packed, aligned(4))) CollapseU32x4 {
+   uint32_t v[4];
+};
+struct __attribute__((packed, aligned(1))) CollapseU32 {
+   uint32_t v;
+};
+static_assert(kShortFeat == 4, "the wide feature loads are written for four slots");
+__device__ __forceinline__ void flat_short_mate(const uint8_t *code, const uint32_t *left, const uint32_t *right, int64_t o, int n, bool held,
+                                                int64_t total, uint32_t *l, uint32_t *r, uint32_t &c)
+{
+   c = 0u;
+   if (held && n > 0 && o + kShortFeat <= total) {
+      const CollapseU32x4 vl = *reinterpret_cast<const CollapseU32x4 *>(left + o), vr = *reinterpret_cast<const CollapseU32x4 *>(right + o);
+      const uint32_t vc = reinterpret_cast<const CollapseU32 *>(code + o)->v;
+#pragma unroll
+      for (int i = 0; i < kShortFeat; ++i) l[i] = i < n ? vl.v[i] : 0u, r[i] = i < n ? vr.v[i] : 0u;
+      c = n >= 4 ? vc : (vc & ((1u << (8 * n)) - 1u));
+   } else {
+#pragma unroll
+      for (int i = 0; i < kShortFeat; ++i) {
+         const bool in = held && i < n;
+         l[i] = in ? left[o + i] : 0u;
+         r[i] = in ? right[o + i] : 0u;
+         c |= in ? (uint32_t)code[o + i] << (8 * i) : 0u;
+      }
+   }
+}
+__device__ __forceinline__ ShortPair flat_short_pair(const CollapseArgs &a, const PairOffsets &o, bool live, int64_t nlf, int64_t nrf)
+{
+   ShortPair q;
+   const bool held = live && o.nl <= kShortFeat && o.nr <= kShortFeat;
+   q.nl = held ? o.nl : -1, q.nr = held ? o.nr : -1;
+   flat_short_mate(a.left_code, a.left_left, a.left_right, o.lo, o.nl, held, nlf, q.l, q.r, q.c[0]);
+   flat_short_mate(a.right_code, a.right_left, a.right_right, o.ro, o.nr, held, nrf, q.l + kShortFeat, q.r + kShortFeat, q.c[1]);
+   return q;
+}
+__device__ __forceinline__ bool short_pair_equal(const ShortPair &x, const ShortPair &y)
+{
+   bool e = x.nl == y.nl && x.nr == y.nr && x.c[0] == y.c[0] && x.c[1] == y.c[1];
+#pragma unroll
+   for (int i = 0; i < 2 * kShortFeat; ++i) e = e && x.l[i] == y.l[i] && x.r[i] == y.r[i];
+   return e;
+}
+// the mates lie apart (or there is one mate) and each mate's features ascend: the hit's features are the left mate's, the
+// GAP, the right mate's, as they are (flat_hit_features' first case, asked of the registers)
+__device__ __forceinline__ bool short_pair_plain(const ShortPair &q)
+{
+   const bool both = q.nl > 0 && q.nr > 0;
+   bool plain = true;
+#pragma unroll
+   for (int i = 1; i < kShortFeat; ++i) {
+      plain = plain && (i >= q.nl || q.l[i] > q.l[i - 1]);
+      plain = plain && (i >= q.nr || q.l[kShortFeat + i] > q.l[kShortFeat + i - 1]);
+   }
+   uint32_t last_r = 0;
+#pragma unroll
+   for (int i = 0; i < kShortFeat; ++i) last_r = i == q.nl - 1 ? q.r[i] : last_r;
+   return plain && (!both || (int64_t)q.l[kShortFeat] - (int64_t)last_r - 1 > 0);
+}
+
 // ---- unique hits: a kept pair that differs from the previous kept pair of its cluster (:685-697)
 __global__ __launch_bounds__(256) void flat_heads_kernel(FlatCollapseArgs f)
 {
@@ -255,18 +359,37 @@ __global__ __launch_bounds__(256) void flat_heads_kernel(FlatCollapseArgs f)
    if (s < f.n_pairs) {
       int32_t nf = 0;
       uint8_t hd = 0;
-      if (f.skip[s]) {
+      // The loads go out level by level, each level's together (round 5: as written before -- a position's pair, its
+      // offsets, its features one by one inside the comparison's loop, then the same for the previous kept pair -- a wave
+      // made ten DEPENDENT round trips and took 22 us for 14 GB of traffic in all):
+      //   1  skip, cluster, pair, the previous kept position      2  the cluster's first position, that position's pair,
+      //   this pair's offsets      3  this pair's features, the previous pair's offsets      4  the previous pair's features
+      const int64_t nlf = a.left_off[f.n_pairs], nrf = a.right_off[f.n_pairs]; // (uniform: the feature arrays' lengths)
+      const bool sk = f.skip[s] != 0;
+      const int32_t l = (int32_t)(f.key2s[s] >> 32);
+      const int64_t p = f.order[s];
+      const int64_t prev = s > 0 ? (int64_t)f.last_kept[s - 1] : -1;
+      const int64_t q0 = a.locus_pair_off[l];
+      const bool has_prev = !sk && prev >= 0; // (prev >= q0 is asked below: q0 arrives with this level)
+      const int64_t pp = has_prev ? (int64_t)f.order[prev] : 0;
+      const PairOffsets op = flat_pair_offsets(a, p, !sk);
+      const bool cmp = has_prev && prev >= q0;
+      const PairOffsets opp = flat_pair_offsets(a, pp, cmp);
+      const ShortPair me = flat_short_pair(a, op, !sk, nlf, nrf);
+      const ShortPair pr = flat_short_pair(a, opp, cmp, nlf, nrf);
+      if (sk) {
          filt = 1;
       } else {
-         const int32_t l = (int32_t)(f.key2s[s] >> 32);
-         const int64_t q0 = a.locus_pair_off[l];
-         const int64_t p = f.order[s];
-         const MateRef x = left_mate(a, p), y = right_mate(a, p);
-         const int64_t prev = s > 0 ? (int64_t)f.last_kept[s - 1] : -1;
+         const MateRef x = MateRef{a.left_code + op.lo, a.left_left + op.lo, a.left_right + op.lo, op.nl};
+         const MateRef y = MateRef{a.right_code + op.ro, a.right_left + op.ro, a.right_right + op.ro, op.nr};
          bool same = false;
-         if (prev >= q0) {
-            const int64_t pp = f.order[prev];
-            same = mate_equal(left_mate(a, pp), x) && mate_equal(right_mate(a, pp), y);
+         if (cmp) {
+            if (me.nl >= 0 && pr.nl >= 0) {
+               same = short_pair_equal(me, pr);
+            } else if (op.nl == opp.nl && op.nr == opp.nr) { // (a mate of more than four features: the arrays)
+               same = mate_equal(MateRef{a.left_code + opp.lo, a.left_left + opp.lo, a.left_right + opp.lo, opp.nl}, x) &&
+                      mate_equal(MateRef{a.right_code + opp.ro, a.right_left + opp.ro, a.right_right + opp.ro, opp.nr}, y);
+            }
          }
          if (!same) {
             hd = 1;
@@ -274,7 +397,8 @@ __global__ __launch_bounds__(256) void flat_heads_kernel(FlatCollapseArgs f)
                nf = -1;
                f.counts[2] = 1; // (any writer, same value)
             } else {
-               nf = flat_hit_features(x, y, s_lr, s_c, nullptr, nullptr, nullptr);
+               if (me.nl >= 0 && short_pair_plain(me)) nf = me.nl + me.nr + ((me.nl > 0 && me.nr > 0) ? 1 : 0);
+               else nf = flat_hit_features(x, y, s_lr, s_c, nullptr, nullptr, nullptr);
                if (nf <= 0) nf = 0, rej = 1; // Contig(PairedHit) rejects the pair: no hit, its mass stays in the cluster's
             }
          }
@@ -428,13 +552,49 @@ __global__ __launch_bounds__(256) void flat_fill_kernel(FlatCollapseArgs f)
    const CollapseArgs &a = f.a;
    const int64_t s = xcd_tile() * 256 + threadIdx.x; // (XCD-aware tile order: device_common.h)
    if (s >= f.n_pairs) return;
+   // (levels as in flat_heads_kernel: 1 the position's own numbers; 2 the pair's offsets, the group's mass; 3 the features)
    const int n = f.nfeat[s];
-   if (n <= 0) return;
    const int64_t h = f.hit_rank[s], fb = f.feat_base[s], p = f.order[s];
-   a.hit_locus[h] = (int32_t)(f.key2s[s] >> 32);
+   const int32_t loc = (int32_t)(f.key2s[s] >> 32), g = f.gid[s];
+   const bool live = n > 0;
+   const PairOffsets op = flat_pair_offsets(a, p, live);
+   const double gm = live ? f.gmass[g] : 0.0;
+   const ShortPair me = flat_short_pair(a, op, live, a.left_off[f.n_pairs], a.right_off[f.n_pairs]);
+   if (!live) return;
+   a.hit_locus[h] = loc;
    a.feat_off[h] = fb;
-   a.hit_mass[h] = (float)f.gmass[f.gid[s]]; // stored as float (Contig::mass())
-   const MateRef x = left_mate(a, p), y = right_mate(a, p);
+   a.hit_mass[h] = (float)gm; // stored as float (Contig::mass())
+   if (me.nl >= 0 && short_pair_plain(me)) { // the left mate's features, the GAP, the right mate's: from the registers
+      const bool both = me.nl > 0 && me.nr > 0;
+      uint32_t last_r = 0;
+#pragma unroll
+      for (int i = 0; i < kShortFeat; ++i) {
+         if (i < me.nl) {
+            a.feat_code[fb + i] = (uint8_t)(me.c[0] >> (8 * i));
+            a.feat_left[fb + i] = me.l[i];
+            a.feat_right[fb + i] = me.r[i];
+            last_r = me.r[i];
+         }
+      }
+      int64_t at = fb + me.nl;
+      if (both) {
+         a.feat_code[at] = 2;
+         a.feat_left[at] = last_r + 1u;
+         a.feat_right[at] = me.l[kShortFeat] - 1u;
+         ++at;
+      }
+#pragma unroll
+      for (int i = 0; i < kShortFeat; ++i) {
+         if (i < me.nr) {
+            a.feat_code[at + i] = (uint8_t)(me.c[1] >> (8 * i));
+            a.feat_left[at + i] = me.l[kShortFeat + i];
+            a.feat_right[at + i] = me.r[kShortFeat + i];
+         }
+      }
+      return;
+   }
+   const MateRef x = MateRef{a.left_code + op.lo, a.left_left + op.lo, a.left_right + op.lo, op.nl};
+   const MateRef y = MateRef{a.right_code + op.ro, a.right_left + op.ro, a.right_right + op.ro, op.nr};
    if (x.n <= kMateFeatMax && y.n <= kMateFeatMax) flat_hit_features(x, y, s_lr, s_c, a.feat_code + fb, a.feat_left + fb, a.feat_right + fb);
    // (else: flat_fill_long_kernel writes the features)
 }
