@@ -128,6 +128,28 @@ def test_device_collapse_many_small_clusters(ctx):
         same(g[0], r[0], g[1], r[1], g[2], r[2])
 
 
+def test_device_collapse_mates_apart_abutting_and_overlapping(ctx):
+    """The device form takes a short cut for mates that lie apart -- the hit's features are the left mate's, the GAP, the
+    right mate's, as they are -- and merges the two lists otherwise (Contig(PairedHit), contig.cpp:216-267).  Spliced and
+    unspliced mates at every distance around the boundary (a gap of 2, 1, 0 bases, abutting, overlapping by 1 ... 40): the
+    host form's unique hits, its rejects included."""
+    from strawberry_amd import exonbin as eb
+    rng = np.random.default_rng(31)
+    loc, mass, left, right = [], [], [], []
+    for l in range(40):
+        for k in range(int(rng.integers(20, 80))):
+            a = 1000 + 20000 * l + int(rng.integers(0, 300))
+            lm = [(a, a + 30), (a + 200, a + 243)] if rng.random() < 0.6 else [(a, a + 74)]
+            d = int(rng.integers(-40, 200)) if k % 3 else int(rng.integers(-1, 4))     # (the right mate's start - the left mate's end)
+            b = lm[-1][1] + d
+            rm = [(b, b + 20), (b + 500, b + 553)] if rng.random() < 0.5 else ([(b, b + 74)] if rng.random() < 0.8 else [])
+            loc.append(l), mass.append(1.0), left.append(lm), right.append(rm)
+    args = (40, loc, mass, left, right)
+    g, r = eb.collapse_pairs(*args, device=ctx), eb.collapse_pairs(*args)
+    same(g[0], r[0], g[1], r[1], g[2], r[2])
+    assert g[0].n_hits > 1000 and g[2]["rejected"] > 20
+
+
 def test_device_collapse_big_loci(ctx, oracle):
     """Loci of more than 4096 pairs (the LDS sort's limit) take the same steps with their arrays in global memory
     (collapse_big_kernel): 4097 (just over), 20 000 and 70 000 pairs next to small loci, duplicates, NH masses whose sums
