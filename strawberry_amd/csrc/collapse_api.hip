@@ -67,6 +67,10 @@ static int collapse_flat(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_pairs_t *dp
       tmp_bytes = std::max(tmp_bytes, b);
       (void)rocprim::radix_sort_pairs(nullptr, b, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, (const int32_t *)nullptr, (int32_t *)nullptr, n, 0, 32 + locus_bits, s);
       tmp_bytes = std::max(tmp_bytes, b);
+      (void)rocprim::radix_sort_pairs(nullptr, b, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, rocprim::counting_iterator<int32_t>(0), (int32_t *)nullptr, n, 0, 64, s);
+      tmp_bytes = std::max(tmp_bytes, b);
+      (void)rocprim::exclusive_scan(nullptr, b, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, 0ull, nl1, rocprim::plus<unsigned long long>(), s);
+      tmp_bytes = std::max(tmp_bytes, b);
       (void)rocprim::inclusive_scan(nullptr, b, (const int32_t *)nullptr, (int32_t *)nullptr, n, rocprim::maximum<int32_t>(), s);
       tmp_bytes = std::max(tmp_bytes, b);
       (void)rocprim::inclusive_scan(nullptr, b, rocprim::make_transform_iterator((const uint8_t *)nullptr, [] __device__(uint8_t v) { return (int32_t)v; }), (int32_t *)nullptr, n, rocprim::plus<int32_t>(), s);
@@ -85,6 +89,7 @@ static int collapse_flat(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_pairs_t *dp
    const size_t o_perm1 = take(n * 4), o_key2 = take(n * 8), o_key2s = take(n * 8), o_order = take(n * 4);
    const size_t o_skip = take(n), o_head = take(n), o_kept = take(n * 4), o_last = take(n * 4), o_nfeat = take(n1 * 4), o_ishit = take(n1 * 4);
    const size_t o_gid = take(n * 4), o_hrank = take(n1 * 8), o_fbase = take(n1 * 8), o_gmass = take(n1 * 8), o_hoff = take(nl1 * 8);
+   const size_t o_minl = take(nl1 * 4), o_maxl = take(nl1 * 4), o_cspan = take(nl1 * 8), o_cbase = take(nl1 * 8), o_clof = take(n * 4), o_ostat = take(64);
    const size_t o_counts = take(64), o_flag = take(64), o_tmp = take(tmp_bytes);
    SB_TRY(sb::dev_take(off, &w, &w_cap));
    // what must start at zero: the clusters' sums, the counters and flags, the entry beyond the last position of the two scan inputs
@@ -94,6 +99,9 @@ static int collapse_flat(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_pairs_t *dp
    if (const char *fs = std::getenv("SBGPU_COLLAPSE_FORCE_SEQ"); fs && std::atoi(fs) != 0)
       SB_TRY(hipMemsetD32Async((hipDeviceptr_t)(w + o_clf), sb::kNeedSeqMass | sb::kNeedSeqSd, nl1, s));
    SB_TRY(hipMemsetAsync(w + o_counts, 0, o_tmp - o_counts, s));
+   SB_TRY(hipMemsetAsync(w + o_minl, 0xFF, nl1 * 4, s)); // (the clusters' leftmost left end starts at the top)
+   SB_TRY(hipMemsetAsync(w + o_maxl, 0, nl1 * 4, s));
+   SB_TRY(hipMemsetAsync(w + o_ostat, 0, 64, s));
    SB_TRY(hipMemsetAsync(w + o_nfeat + n * 4, 0, 4, s));
    SB_TRY(hipMemsetAsync(w + o_ishit + n * 4, 0, 4, s));
    SB_TRY(hipMemcpyAsync(w + o_poff, locus_pair_off, nl1 * 8, hipMemcpyHostToDevice, s));
@@ -130,17 +138,50 @@ static int collapse_flat(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_pairs_t *dp
    f.gmass = (double *)(w + o_gmass);
    f.locus_hit_off = (int64_t *)(w + o_hoff);
    f.counts = (unsigned long long *)(w + o_counts);
+   f.cl_minl = (uint32_t *)(w + o_minl), f.cl_maxl = (uint32_t *)(w + o_maxl);
+   f.cl_span = (unsigned long long *)(w + o_cspan), f.cl_base = (const unsigned long long *)(w + o_cbase);
+   f.order_stats = (unsigned long long *)(w + o_ostat);
+   f.cluster_of = (int32_t *)(w + o_clof);
    const unsigned gp = (unsigned)((n + 255) / 256);
    const unsigned gw = (unsigned)std::min<int64_t>(n_loci + 1, (int64_t)sb::ctx_cu_count(c) * 64);
    void *tmp = w + o_tmp;
    size_t tb = tmp_bytes;
    hipLaunchKernelGGL(sb::flat_keys_kernel, dim3(gp), dim3(256), 0, s, f);
    SB_TRY(hipGetLastError());
-   // the order of std::sort on (left end, right end), ties in input order: two stable sorts, least significant key first
-   SB_TRY(rocprim::radix_sort_pairs(tmp, tb, (const uint32_t *)f.key_right, (uint32_t *)(w + o_kr2), rocprim::counting_iterator<int32_t>(0), (int32_t *)(w + o_perm1), n, 0, 32, s));
-   hipLaunchKernelGGL(sb::flat_gather_kernel, dim3(gp), dim3(256), 0, s, f);
+   // The order of std::sort on (left end, right end), ties in input order.  ONE stable sort where the key fits 64 bits (it does
+   // unless the clusters' ranges of left ends add up to more than 2^(64 - bits of the longest pair)): a cluster's left ends
+   // relative to its leftmost, the clusters' ranges laid end to end, the pair's length below (collapse_flat.h).  What
+   // the key's width is, the host must know: one 24-byte read-back after the keys kernel.  Otherwise (or with
+   // SBGPU_COLLAPSE_TWO_SORTS=1: tests) round 4's two sorts, least significant key first: by the right end, then by
+   // (cluster << 32 | left end).
+   hipLaunchKernelGGL(sb::flat_cluster_spans_kernel, dim3((unsigned)((nl1 + 255) / 256)), dim3(256), 0, s, f);
+   SB_TRY(rocprim::exclusive_scan(tmp, tb, (const unsigned long long *)f.cl_span, (unsigned long long *)(w + o_cbase), 0ull, nl1, rocprim::plus<unsigned long long>(), s));
+   unsigned long long x_total = 0, ostat[2] = {0, 0};
+   SB_TRY(hipMemcpyAsync(&x_total, w + o_cbase + (size_t)n_loci * 8, 8, hipMemcpyDeviceToHost, s));
+   SB_TRY(hipMemcpyAsync(ostat, w + o_ostat, 16, hipMemcpyDeviceToHost, s));
+   SB_TRY(hipStreamSynchronize(s));
+   auto bits_of = [](unsigned long long v) {
+      unsigned b = 0;
+      while (b < 64 && (v >> b)) ++b;
+      return b;
+   };
+   const unsigned span_bits = bits_of(ostat[0]), x_bits = bits_of(x_total);
+   const bool two_sorts_env = std::getenv("SBGPU_COLLAPSE_TWO_SORTS") && std::atoi(std::getenv("SBGPU_COLLAPSE_TWO_SORTS")) != 0;
+   const bool one_sort = !two_sorts_env && !ostat[1] && span_bits + x_bits <= 64;
+   f.span_bits = (int)span_bits;
    tb = tmp_bytes;
-   SB_TRY(rocprim::radix_sort_pairs(tmp, tb, (const unsigned long long *)f.key2, (unsigned long long *)(w + o_key2s), f.perm1, (int32_t *)(w + o_order), n, 0, 32 + locus_bits, s));
+   if (one_sort) {
+      hipLaunchKernelGGL(sb::flat_rekey_kernel, dim3(gp), dim3(256), 0, s, f);
+      SB_TRY(rocprim::radix_sort_pairs(tmp, tb, (const unsigned long long *)f.key2, (unsigned long long *)(w + o_key2s), rocprim::counting_iterator<int32_t>(0), (int32_t *)(w + o_order), n, 0, std::max(1u, span_bits + x_bits), s));
+      hipLaunchKernelGGL(sb::flat_cluster_of_kernel<false>, dim3(gp), dim3(256), 0, s, f);
+   } else {
+      SB_TRY(rocprim::radix_sort_pairs(tmp, tb, (const uint32_t *)f.key_right, (uint32_t *)(w + o_kr2), rocprim::counting_iterator<int32_t>(0), (int32_t *)(w + o_perm1), n, 0, 32, s));
+      hipLaunchKernelGGL(sb::flat_gather_kernel, dim3(gp), dim3(256), 0, s, f);
+      tb = tmp_bytes;
+      SB_TRY(rocprim::radix_sort_pairs(tmp, tb, (const unsigned long long *)f.key2, (unsigned long long *)(w + o_key2s), f.perm1, (int32_t *)(w + o_order), n, 0, 32 + locus_bits, s));
+      hipLaunchKernelGGL(sb::flat_cluster_of_kernel<true>, dim3(gp), dim3(256), 0, s, f);
+   }
+   SB_TRY(hipGetLastError());
    // the span filter from the integer moments; the clusters it marks (none, as a rule) get the running sum and their flags again
    hipLaunchKernelGGL(sb::flat_flags_kernel<1>, dim3(gp), dim3(256), 0, s, f);
    hipLaunchKernelGGL(sb::flat_sd_kernel, dim3(gw), dim3(64), 0, s, f);

@@ -55,7 +55,16 @@ struct FlatCollapseArgs {
    // per sorted position (the clusters keep their ranges: the cluster is the key's high part)
    const int32_t *perm1;              // after sort 1
    unsigned long long *key2;          // key_hi gathered by perm1 (sort 2's input)
-   const unsigned long long *key2s;   // sort 2's keys out: cluster of a sorted position = key2s[s] >> 32
+   const unsigned long long *key2s;   // sort 2's keys out: cluster of a sorted position = key2s[s] >> 32 (two-sort form)
+   // the one-sort form (round 5): a cluster's pairs lie in [min left, max left]; those ranges laid end to end give every
+   // pair a "concatenated coordinate" X = base[cluster] + left - min left that ascends with (cluster, left), and
+   // (X << span_bits) | (right - left) is ONE key for the whole order wherever it fits 64 bits
+   uint32_t *cl_minl, *cl_maxl;       // per cluster (min starts at 0xFFFFFFFF, max at 0)
+   unsigned long long *cl_span;       // per cluster (+ one entry: 0): max left - min left + 1, 0 for a cluster without pairs
+   const unsigned long long *cl_base; // its exclusive scan (one entry beyond the end: the total)
+   unsigned long long *order_stats;   // [0] the longest pair (right - left) of the call, [1] != 0: a pair with right < left (two sorts then)
+   int span_bits;
+   int32_t *cluster_of;               // per sorted position: its cluster (both forms; what the later kernels read)
    const int32_t *order;              // input pair (global index) at sorted position s
    uint8_t *skip, *head;
    int32_t *kept_pos;                 // s where kept, -1 where skipped; scanned (running max) into last_kept
@@ -113,6 +122,8 @@ __global__ __launch_bounds__(256) void flat_keys_kernel(FlatCollapseArgs f)
    int32_t l = -1;
    unsigned long long sum = 0, sum2 = 0;
    int nm = 0;
+   uint32_t my_lp = 0xffffffffu, my_rp = 0u; // the pair's ends (have_ends: it has mates)
+   bool have_ends = false;
    const int64_t p0 = p - (int64_t)(threadIdx.x & 63u); // (the wave's first pair; the search is the wave's: device_common.h)
    const int32_t lw = p0 < f.n_pairs ? (int32_t)wave_range_of(a.locus_pair_off, a.n_loci, p0, f.n_pairs) : -1;
    if (p < f.n_pairs) {
@@ -121,7 +132,7 @@ __global__ __launch_bounds__(256) void flat_keys_kernel(FlatCollapseArgs f)
       if (x.n > kMateFeatLong || y.n > kMateFeatLong) bad |= kCollapseLongMate;
       uint32_t lp = 0xffffffffu, rp = 0xffffffffu;
       if (x.n == 0 && y.n == 0) bad |= kCollapseNoMates;
-      else lp = pair_left_pos(x, y), rp = pair_right_pos(x, y);
+      else lp = pair_left_pos(x, y), rp = pair_right_pos(x, y), my_lp = lp, my_rp = rp, have_ends = true;
       f.key_right[p] = rp;
       f.key_hi[p] = ((unsigned long long)(uint32_t)l << 32) | lp;
       const int sl = x.n ? (int)(x.r[x.n - 1] - x.l[0] + 1) : -1, sr = y.n ? (int)(y.r[y.n - 1] - y.l[0] + 1) : -1;
@@ -138,6 +149,36 @@ __global__ __launch_bounds__(256) void flat_keys_kernel(FlatCollapseArgs f)
       if (need) atomicOr(&f.cl_flags[l], need);
    }
    if (bad) atomicOr(a.flags, bad);
+   // the one-sort form's numbers: the cluster's leftmost and rightmost left end, the call's longest pair
+   {
+      const bool have = have_ends;
+      const uint32_t klo = have ? my_lp : 0xffffffffu, khi = have ? my_lp : 0u, krp = have ? my_rp : 0u;
+      const bool backwards = have && krp < klo;
+      uint32_t span = have && !backwards ? krp - klo : 0u;
+      const int32_t lf = __shfl(l, __ffsll((long long)__ballot(l >= 0)) - 1);
+      const bool wf = have && l == lf;
+      uint32_t mn = wf ? klo : 0xffffffffu, mx = wf ? khi : 0u;
+      for (int o = 32; o > 0; o >>= 1) {
+         mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
+         mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+         span = max(span, (uint32_t)__shfl_xor((int)span, o));
+      }
+      const unsigned long long anyb = __ballot(backwards), anyw = __ballot(wf);
+      if (have && !wf) {
+         atomicMin(&f.cl_minl[l], klo);
+         atomicMax(&f.cl_maxl[l], khi);
+      } else if (wf && (int)(threadIdx.x & 63) == __ffsll((long long)anyw) - 1) {
+         atomicMin(&f.cl_minl[l], mn);
+         atomicMax(&f.cl_maxl[l], mx);
+      }
+      if ((threadIdx.x & 63) == 0) {
+         // (a plain read first: three million waves' atomics on ONE word queue at the L2, ~10 ns each -- 25 ms; only a
+         // wave that would raise the maximum goes there)
+         if ((unsigned long long)span > __hip_atomic_load(&f.order_stats[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(&f.order_stats[0], (unsigned long long)span);
+         if (anyb) f.order_stats[1] = 1ull; // (any writer, same value)
+      }
+   }
    // the spans are whole numbers: their sum is exact in any order.  The lanes of a wave mostly share their cluster:
    // the lanes whose cluster is the first active lane's add up in registers, one atomic for them; the others on their own
    const int32_t l0 = __shfl(l, __ffsll((long long)__ballot(l >= 0)) - 1);
@@ -166,6 +207,39 @@ __global__ __launch_bounds__(256) void flat_gather_kernel(FlatCollapseArgs f)
 {
    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
    if (s < f.n_pairs) f.key2[s] = f.key_hi[f.perm1[s]];
+}
+
+// ---- the one-sort form: the clusters' spans (a thread per cluster), then every pair's key (a thread per pair, input order)
+__global__ __launch_bounds__(256) void flat_cluster_spans_kernel(FlatCollapseArgs f)
+{
+   const int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;
+   if (l > f.a.n_loci) return;
+   const bool any = l < f.a.n_loci && f.cl_maxl[l] >= f.cl_minl[l];
+   f.cl_span[l] = any ? (unsigned long long)(f.cl_maxl[l] - f.cl_minl[l]) + 1ull : 0ull;
+}
+__global__ __launch_bounds__(256) void flat_rekey_kernel(FlatCollapseArgs f)
+{
+   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+   if (p >= f.n_pairs) return;
+   const unsigned long long kh = f.key_hi[p];
+   const int32_t l = (int32_t)(kh >> 32);
+   const uint32_t lp = (uint32_t)kh;
+   const unsigned long long x = f.cl_base[l] + (unsigned long long)(lp - f.cl_minl[l]);
+   f.key2[p] = (x << f.span_bits) | (unsigned long long)(f.key_right[p] - lp);
+}
+// the cluster of every sorted position: the clusters keep their ranges under either order
+template <bool FROM_KEYS>
+__global__ __launch_bounds__(256) void flat_cluster_of_kernel(FlatCollapseArgs f)
+{
+   const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+   if (FROM_KEYS) {
+      if (s < f.n_pairs) f.cluster_of[s] = (int32_t)(f.key2s[s] >> 32);
+   } else {
+      const int64_t s0 = s - (int64_t)(threadIdx.x & 63u);
+      if (s0 >= f.n_pairs) return; // (the whole wave)
+      const int32_t l = (int32_t)wave_range_of(f.a.locus_pair_off, f.a.n_loci, s0, f.n_pairs);
+      if (s < f.n_pairs) f.cluster_of[s] = l;
+   }
 }
 
 // a double held by lane k of the wave, as a wave-uniform value
@@ -223,7 +297,7 @@ __global__ __launch_bounds__(256) void flat_flags_kernel(FlatCollapseArgs f)
 {
    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
    if (s >= f.n_pairs) return;
-   const int32_t l = (int32_t)(f.key2s[s] >> 32);
+   const int32_t l = f.cluster_of[s];
    const int need = f.cl_flags[l] & kNeedSeqSd;
    if (PASS == 2 && !need) return;
    const int32_t p = f.order[s];
@@ -366,7 +440,7 @@ __global__ __launch_bounds__(256) void flat_heads_kernel(FlatCollapseArgs f)
       //   this pair's offsets      3  this pair's features, the previous pair's offsets      4  the previous pair's features
       const int64_t nlf = a.left_off[f.n_pairs], nrf = a.right_off[f.n_pairs]; // (uniform: the feature arrays' lengths)
       const bool sk = f.skip[s] != 0;
-      const int32_t l = (int32_t)(f.key2s[s] >> 32);
+      const int32_t l = f.cluster_of[s];
       const int64_t p = f.order[s];
       const int64_t prev = s > 0 ? (int64_t)f.last_kept[s - 1] : -1;
       const int64_t q0 = a.locus_pair_off[l];
@@ -533,7 +607,7 @@ __global__ __launch_bounds__(256) void flat_mass_any_order_kernel(FlatCollapseAr
    int l = -1, gk = 0x7fffffff; // (beyond the last position: keys that keep the runs apart)
    double v = 0.0;
    if (s < f.n_pairs) {
-      l = (int32_t)(f.key2s[s] >> 32);
+      l = f.cluster_of[s];
       gk = f.gid[s]; // the group of the last head at or before s (a skipped position adds 0.0 to it: nothing)
       if (f.cl_flags[l] & kNeedSeqMass) l = -1; // flat_mass_kernel's
       else if (!f.skip[s]) v = a.pair_mass[f.order[s]];
@@ -555,7 +629,7 @@ __global__ __launch_bounds__(256) void flat_fill_kernel(FlatCollapseArgs f)
    // (levels as in flat_heads_kernel: 1 the position's own numbers; 2 the pair's offsets, the group's mass; 3 the features)
    const int n = f.nfeat[s];
    const int64_t h = f.hit_rank[s], fb = f.feat_base[s], p = f.order[s];
-   const int32_t loc = (int32_t)(f.key2s[s] >> 32), g = f.gid[s];
+   const int32_t loc = f.cluster_of[s], g = f.gid[s];
    const bool live = n > 0;
    const PairOffsets op = flat_pair_offsets(a, p, live);
    const double gm = live ? f.gmass[g] : 0.0;
