@@ -433,8 +433,9 @@ int sbgpu_uniq_export(const sbgpu_uniq_t *u, int32_t *hit_locus, int64_t *feat_o
 /* The same on the GPU (csrc/collapse_flat.h): the pairs' arrays of `d_pairs` are DEVICE pointers (pair_locus is
  * not read), grouped by locus as locus_pair_off[n_loci + 1] (host) says; the unique hits stay in HBM in
  * sbgpu_hits_t layout -- sbgpu_uniq_dev_hits hands them to sbgpu_exonbin_device / sbgpu_quantify_device -- and
- * only the per-locus offsets and cluster masses come back.  All clusters of the call at once: two stable device-wide
- * radix sorts give the (left, right) order with ties in input order; the span filter is decided from the spans' exact
+ * only the per-locus offsets and cluster masses come back.  All clusters of the call at once: one stable device-wide
+ * radix sort (two where its key would not fit 64 bits) gives the (left, right) order with ties in input order; the span
+ * filter is decided from the spans' exact
  * integer moments (the reference's running sum of squared deviations is taken where a decision could depend on its
  * rounding); equal neighbours collapse, their masses added in double in that order (in any order where every mass
  * of the cluster is a multiple of 2^-20: the sums are then exact); Contig(PairedHit)'s features per unique hit.

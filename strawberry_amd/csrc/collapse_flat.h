@@ -6,10 +6,12 @@
 // sample's time was its biggest clusters'.  Here nothing but two order-bound sums is per cluster:
 //
 //   keys      a thread per pair: the sort keys, the mates' spans, the clusters' integer span sums (exact in any order);
-//   sort      TWO stable device-wide radix sorts (rocPRIM onesweep): by the right end, then by (cluster << 32 | left end).
-//             LSD order: the second sort keeps the first one's order among equal (cluster, left) and both keep the input
-//             order among equal keys -- std::sort on (left, right) with ties in input order, which is what the host form's
-//             stable sort and the per-cluster kernel's (key, index) network give (src/read.cpp:917-923);
+//   sort      the order is std::sort's on (left, right) with ties in input order, which is what the host form's stable sort and
+//             the per-cluster kernel's (key, index) network give (src/read.cpp:917-923).  ONE stable device-wide radix sort
+//             (rocPRIM onesweep) where its key fits 64 bits -- a pair's left end relative to its cluster's leftmost, the
+//             clusters' ranges laid end to end (ascending with (cluster, left)), the pair's length in the bits below; the host
+//             reads the two widths back after the keys kernel.  Else round 4's TWO sorts, least significant key first: by the
+//             right end, then by (cluster << 32 | left end);
 //   sd        the reference adds the squared deviations of the spans in INPUT order, one running double (std::inner_product,
 //             common.h:100-110) -- sequential by definition -- but the sum is only ever used in a PREDICATE, the span filter
 //             phi((span - mean) / (5 sd)) > 0.999 (:666-682).  The spans are integers, so the exact sum of squared deviations

@@ -107,6 +107,43 @@ def test_device_collapse_random_stress(ctx, oracle):
         XU.check_collapse_against_oracle(oracle, n_loci, args[1], nh, args[3], args[4], g[0], g[1], g[2])
 
 
+def test_device_collapse_one_sort_and_two_sorts(ctx, monkeypatch):
+    """The pairs' order -- std::sort on (left end, right end), ties in input order -- comes from ONE device-wide sort whose
+    key lays the clusters' ranges of left ends end to end, with the pair's length below; where that key does not fit 64
+    bits (or SBGPU_COLLAPSE_TWO_SORTS=1) from round 4's two sorts.  Both routes on a sample with duplicates and ties, and a
+    sample whose clusters reach across the whole 32-bit coordinate range with pairs as long (the key would need 65 bits: the
+    library must take the two sorts by itself): the host form's unique hits either way."""
+    from strawberry_amd import exonbin as eb
+    rng = np.random.default_rng(41)
+    loc, mass, left, right = [], [], [], []
+    for l in range(12):
+        base = 100000 * (l + 1)
+        for s in rng.integers(base, base + 300, int(rng.integers(50, 1500))):
+            s, d = int(s), int(rng.choice([150, 151, 180]))
+            loc.append(l), mass.append(1.0), left.append([(s, s + 74)])
+            right.append([(s + d, s + d + 74)] if rng.random() < 0.9 else [])
+    args = (12, loc, mass, left, right)
+    host = eb.collapse_pairs(*args)
+    for env in ("0", "1"):
+        monkeypatch.setenv("SBGPU_COLLAPSE_TWO_SORTS", env)
+        g = eb.collapse_pairs(*args, device=ctx)
+        same(g[0], host[0], g[1], host[1], g[2], host[2])
+    monkeypatch.delenv("SBGPU_COLLAPSE_TWO_SORTS")
+    # clusters across the whole coordinate range, pairs as long as the range
+    far = 4200000000
+    loc, mass, left, right = [], [], [], []
+    for l in range(3):
+        for k in range(40):
+            a = 1000 + 7 * (k % 5) + l
+            loc.append(l), mass.append(1.0), left.append([(a, a + 74)])
+            right.append([(far + 3 * (k % 4), far + 3 * (k % 4) + 74)] if k % 2 else [(a + 200, a + 274)])
+        loc.append(l), mass.append(1.0), left.append([(far - 500, far - 426)]), right.append([])
+    args = (3, loc, mass, left, right)
+    g, r = eb.collapse_pairs(*args, device=ctx), eb.collapse_pairs(*args)
+    same(g[0], r[0], g[1], r[1], g[2], r[2])
+    assert g[0].n_hits > 20
+
+
 def test_device_collapse_many_small_clusters(ctx):
     """A pair's cluster is found by a search the WAVE makes 64 ways at a time (wave_range_of, csrc/device_common.h): cluster
     counts around the powers of 64, empty clusters in between, zero to three pairs each -- the host form's unique hits."""
