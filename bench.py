@@ -339,14 +339,41 @@ def front_main(args, ctx, dev, rank, world, sdist, torch, launch):
     (strawberry_amd/front.py).  A step = one pass over ALL records of the sample.  Size: SB_FRONT_LOCI / SB_FRONT_FRAGS
     (default: the chain sample, 60 000 loci / 2e8 read pairs = ~3.9e8 records, ~66 GB of record bytes)."""
     from strawberry_amd import front
-    if world > 1:
-        raise SystemExit("bench.py --workload c3-front is a one-GPU line (the stages shard by cluster like the chain; not wired up)")
     n_loci = int(float(os.environ.get("SB_FRONT_LOCI", "60000")))
     n_frags = float(os.environ.get("SB_FRONT_FRAGS", "2e8"))
-    q = front.FrontQuantifier(ctx, n_loci=n_loci, n_frags=n_frags, seed=31)
+    # N > 1: ONE sample, locus l (= cluster l) on rank l mod N with its records -- the stages work cluster by cluster, nothing
+    # but the step's barrier couples the ranks (strong scaling, like c3-chain's)
+    q = front.FrontQuantifier(ctx, n_loci=n_loci, n_frags=n_frags, seed=31, loci_subset=(rank, world) if world > 1 else None)
     torch.cuda.empty_cache()      # the packer's temporaries go back to the driver: the library allocates for itself
     wall, _ = timed_steps(q, args.steps, args.warmup, dev, sdist, torch)
     ms = wall / args.steps * 1e3
+    if world > 1:
+        with_chain = q.compare_with_chain()
+        tot = torch.tensor([q.n_loci, q.n_records, q.n_frags, 1 if with_chain["ok"] else 0], dtype=torch.float64, device=dev)
+        sdist.allreduce_sum_(tot)
+        per_rank = sdist.gather_values([timed_steps.own_wall / args.steps * 1e3, q.n_loci, q.n_records] + [q.stage_wall_ms[k] for k in front.FrontQuantifier.STAGES],
+                                       rank, world, device=dev)
+        if rank != 0:
+            return
+        loci, recs, frags, oks = (float(x) for x in tot.tolist())
+        out = {
+            "metric": "loci/s and G records/s, BAM alignment records -> abundances (C3-scale)", "value": loci * args.steps / wall,
+            "unit": "loci/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u8 records, u32 intervals, f64", "data": "synthetic",
+            "grecords_per_s": recs * args.steps / wall / 1e9, "mfrags_per_s": frags * args.steps / wall / 1e6,
+            "config": {"workload": WORKLOADS["c3-front"], "loci": int(loci), "read_pairs": int(frags), "records": int(recs),
+                       "sharding": "locus l (its cluster and its records) on rank l mod N of ONE sample"},
+            "launch": launch, "per_rank_ms": [p[0] for p in per_rank], "slowest_rank": int(np.argmax([p[0] for p in per_rank])),
+            "loci_per_rank": [int(p[1]) for p in per_rank], "records_per_rank": [int(p[2]) for p in per_rank],
+            "per_rank_stage_ms": [dict(zip(front.FrontQuantifier.STAGES, p[3:])) for p in per_rank],
+            "parity_with_chain": {"ranks_ok": int(oks), "ok": int(oks) == world,
+                                  "what": "every rank: theta / status / iterations of its records -> theta pass against sbgpu_quantify_device on its "
+                                          "shard's own unique hits, bit for bit wherever the span filter dropped no pair"},
+        }
+        print(json.dumps(out))
+        if int(oks) != world:
+            raise SystemExit("bench.py: a rank's records -> theta pass does not reproduce the chain's theta on its shard")
+        return
     probe = []
     for _ in range(3):
         q.step()

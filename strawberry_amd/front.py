@@ -126,8 +126,10 @@ class FrontQuantifier(ChainQuantifier):
 
     STAGES = ("bam_decode", "assign_reads", "pair_mates", "collapse_pairs", "quantify")
 
-    def __init__(self, ctx, n_loci=60000, n_frags=2e8, seed=31, read_len=75):
-        super().__init__(ctx, n_loci=n_loci, n_frags=n_frags, seed=seed, read_len=read_len, pin=True)
+    def __init__(self, ctx, n_loci=60000, n_frags=2e8, seed=31, read_len=75, loci_subset=None):
+        """loci_subset = (rank, world): this rank's loci of ONE sample (locus l on rank l mod world, as the chain shards) --
+        its records only; the clusters, like the reference's, are the shard's own gene models."""
+        super().__init__(ctx, n_loci=n_loci, n_frags=n_frags, seed=seed, read_len=read_len, loci_subset=loci_subset, pin=True)
         torch = self.torch
         t = time.perf_counter()
         self.d_bytes, self.d_rec_off = pack_bam_records(torch, self.sample, read_len)

@@ -4,10 +4,16 @@ sbgpu_pair_mates_device -> sbgpu_collapse_pairs_device -> sbgpu_quantify_device 
 unique hits (less the pairs the reference's span filter drops): theta, status and iteration counts equal sbgpu_quantify_device's on those hits BIT FOR BIT (and through it the
 oracle chain's and the reference program's, tests/test_chain_scale_gpu.py, bench.py's parity legs).  tests/test_front.py
 checks the packed records themselves on the CPU (host decoder, oracle decoder, host pairing and collapse)."""
+import json
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_records_to_theta_equals_the_chain_on_the_same_sample():
@@ -28,3 +34,18 @@ def test_records_to_theta_equals_the_chain_on_the_same_sample():
         assert q.counts["unique_hits"] == q.n_hits - c["unique_hits_lost_there"]
     assert (q.status[:q.n_loci] != 1).sum() > 2000 and q.iters[:q.n_loci].max() > 100
     q.close()
+
+
+def test_bench_c3_front_shards_the_sample_over_two_ranks():
+    """`bench.py --workload c3-front --gpus 2` (here: two ranks on the one GPU): ONE sample, locus l -- its cluster and its
+    records -- on rank l mod 2, every stage on the rank's own records, nothing but the step's barrier between the ranks.
+    Every rank's theta must be the chain's on its shard; the line carries the ranks' own times and stage times."""
+    env = dict(os.environ, SB_FRONT_LOCI="3000", SB_FRONT_FRAGS="3e6", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c3-front", "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["parity_with_chain"]["ok"] and d["parity_with_chain"]["ranks_ok"] == 2
+    assert d["loci_per_rank"] == [1500, 1500] and sum(d["records_per_rank"]) == d["config"]["records"] == 2 * d["config"]["read_pairs"]
+    assert len(d["per_rank_ms"]) == 2 and set(d["per_rank_stage_ms"][1]) == {"bam_decode", "assign_reads", "pair_mates", "collapse_pairs", "quantify"}
+    assert d["value"] > 0 and d["ms_per_step"] >= max(d["per_rank_ms"]) * 0.5

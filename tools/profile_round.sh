@@ -111,6 +111,7 @@ for f in $(find $OUT/stats_bamdecode -name "*kernel_stats.csv"); do cp $f $SUM/$
 # round 5: strong-scaling shards a rank at a time (EM kinds, plan settings of a small shard, the chain's shards); records -> theta
 # (c3-front) with its kernel rows; instructions per algorithmic FMA of the tile kernels by layout; a full wide-locus tile's counters
 ((timeout 600 python tools/probe_strong_kinds.py; echo; echo "# the world-8 shards under plan settings that trade lanes for iteration latency (tools/probe_strong_small.py)"; timeout 600 python tools/probe_strong_small.py 8; echo; echo "# the CHAIN's shards (tools/probe_strong_chain.py)"; timeout 900 python tools/probe_strong_chain.py) 2>/dev/null | grep -v amdgpu.ids) > $SUM/${R}_strong_shards.txt
+((echo "# records -> theta (bench.py --workload c3-front --gpus N), a rank at a time (tools/probe_strong_front.py)"; timeout 1200 python tools/probe_strong_front.py 2>/dev/null | grep world) > $SUM/${R}_strong_shards_front.txt)
 (cd /tmp && timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/stats_front_$R -o fr -- python3 $REPO/bench.py --workload c3-front --steps 2 --warmup 1 --no-cpu-baseline > /tmp/stats_front_$R.log 2>&1)
 for f in $(find /tmp/stats_front_$R -name "*kernel_stats.csv"); do cp $f $SUM/${R}_c3front_kernel_stats.csv; done
 # HBM traffic counters of the records -> theta pass (every kernel of one step; separate FETCH / WRITE runs)
