@@ -313,6 +313,72 @@ def chain_leg(args, ctx, dev, rank, world, sdist, torch, strong=False, with_cpu=
     return out
 
 
+def front_leg(args, ctx, dev, rank, world, sdist, torch):
+    """The records -> theta leg of the default line (strawberry_amd/front.py, `--workload c3-front` is its own line): the chain
+    sample's BAM alignment records resident in HBM -> decode -> read stream -> pairs -> unique hits -> chain -> theta.  N > 1:
+    ONE sample, locus l (its cluster and its records) on rank l mod N.  Every rank times its own steps -- the stages have no
+    collective -- and nothing in here is collective except ONE gather at the end, which every rank reaches whatever happened
+    to it before (a rank that could not run the leg hands in zeros): no rank can leave another waiting."""
+    from strawberry_amd import front
+    stages = front.FrontQuantifier.STAGES
+    vals, note, q = [0.0] * (5 + len(stages)), None, None
+    n_loci = int(float(os.environ.get("SB_FRONT_LOCI", "60000")))
+    n_frags = float(os.environ.get("SB_FRONT_FRAGS", "2e8"))
+    steps = max(1, min(args.steps, 5))
+    try:
+        torch.cuda.empty_cache()
+        ctx.L.sbgpu_release_idle_memory(ctx.h)
+        need = 2.8 * 2 * 175.0 * n_frags / world      # the shard's records, the library's arenas for them, the packer's temporaries
+        free = torch.cuda.mem_get_info(dev)[0]
+        if free < need:
+            note = "skipped: %.0f GB free on the device, %.0f GB wanted" % (free / 1e9, need / 1e9)
+        else:
+            q = front.FrontQuantifier(ctx, n_loci=n_loci, n_frags=n_frags, seed=31, loci_subset=(rank, world) if world > 1 else None)
+            torch.cuda.empty_cache()
+            for _ in range(2):
+                q.step()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                q.step()
+            torch.cuda.synchronize(dev)
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            st = dict(q.stage_wall_ms)
+            ok = bool(q.compare_with_chain()["ok"])
+            vals = [1.0, 1.0 if ok else 0.0, ms, float(q.n_loci), float(q.n_records)] + [float(st[k]) for k in stages]
+    except Exception as e:      # (memory, a launch that fails: the default line must come out all the same)
+        note = "failed: %r" % (e,)
+    finally:
+        try:
+            if q is not None:
+                q.close()
+            del q
+            torch.cuda.empty_cache()
+            ctx.L.sbgpu_release_idle_memory(ctx.h)
+        except Exception:
+            pass
+    table = sdist.gather_values(vals, rank, world, device=dev)
+    if rank != 0:
+        return None
+    ran = [int(r) for r in range(world) if table[r][0] > 0]
+    out = {"workload": WORKLOADS["c3-front"], "scaling": "strong", "steps": steps, "ranks_that_ran": ran}
+    if note:
+        out["note_rank0"] = note[:300]
+    if len(ran) == world:
+        ms_all = [float(table[r][2]) for r in range(world)]
+        step = max(ms_all)
+        out.update({
+            "ms_per_step": step, "per_rank_ms": ms_all, "slowest_rank": int(np.argmax(ms_all)),
+            "loci": int(table[:, 3].sum()), "records": int(table[:, 4].sum()),
+            "loci_per_s": float(table[:, 3].sum()) / (step * 1e-3), "grecords_per_s": float(table[:, 4].sum()) / (step * 1e-3) / 1e9,
+            "loci_per_rank": [int(x) for x in table[:, 3]], "records_per_rank": [int(x) for x in table[:, 4]],
+            "per_rank_stage_ms": [dict(zip(stages, (float(x) for x in table[r][5:]))) for r in range(world)],
+            "parity_with_chain": {"ranks_ok": int(table[:, 1].sum()), "ok": int(table[:, 1].sum()) == world},
+            "timing": "every rank its own K steps, synchronised on its own device only (the stages have no collective); the step is the slowest rank's",
+        })
+    return out
+
+
 def chain_main(args, ctx, dev, rank, world, sdist, torch, launch):
     """--workload c3-chain: the chain is the headline of the line."""
     c = chain_leg(args, ctx, dev, rank, world, sdist, torch, strong=args.scaling == "strong")
@@ -497,6 +563,7 @@ def main():
                          "at one rank they are the same run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-chain", action="store_true", help="default workload: leave the fragments -> abundances leg out of the line")
+    ap.add_argument("--no-front", action="store_true", help="default workload: leave the records -> theta leg out of the line (also SB_BENCH_NO_FRONT=1)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
@@ -662,9 +729,14 @@ def main():
     if args.workload == "c3" and not args.no_chain:
         res_keep = solver.results() if rank == 0 else None       # (the chain reuses the context's scratch; results first)
         chain_obj = chain_leg(args, ctx, dev, rank, world, sdist, torch, strong=args.scaling == "strong")
+    front_obj = None
+    if args.workload == "c3" and not args.no_front and not os.environ.get("SB_BENCH_NO_FRONT"):
+        if chain_obj is None:
+            res_keep = solver.results() if rank == 0 else None
+        front_obj = front_leg(args, ctx, dev, rank, world, sdist, torch)
     if rank != 0:
         return
-    res = res_keep if chain_obj is not None else solver.results()
+    res = res_keep if (chain_obj is not None or front_obj is not None) else solver.results()
     head = strong if args.scaling == "strong" else weak
     ms_per_step = head["ms_per_step"]
 
@@ -723,6 +795,8 @@ def main():
     }
     if chain_obj is not None:
         out["chain"] = chain_obj
+    if front_obj is not None:
+        out["front"] = front_obj
     if c5 is not None:
         # the headline of this workload is the fp32 variant; the fp64 numbers of the same run sit beside it
         out.update({"value": c5["f32"]["value"], "ms_per_step": c5["f32"]["ms_per_step"], "dtype": "f32",

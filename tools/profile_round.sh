@@ -10,13 +10,13 @@ cd $REPO
 (timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -4) > $SUM/${R}_pytest_gpu.txt
 cd /tmp && export TMPDIR=/tmp
 # kernel trace + stats in their own runs; every PMC group in its own run, never with a trace domain
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3 -o em -- python3 $REPO/bench.py --no-chain --no-cpu-baseline --steps 10 > $OUT/stats_c3.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3 -o em -- python3 $REPO/bench.py --no-chain --no-front --no-cpu-baseline --steps 10 > $OUT/stats_c3.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c2 -o em -- python3 $REPO/bench.py --workload c2 --no-cpu-baseline --steps 10 > $OUT/stats_c2.log 2>&1
-timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_c3 -o em -- python3 $REPO/bench.py --no-chain --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_fetch.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_c3 -o em -- python3 $REPO/bench.py --no-chain --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_write.log 2>&1
-timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_sq_c3 -o em -- python3 $REPO/bench.py --no-chain --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_sq.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_c3 -o em -- python3 $REPO/bench.py --no-chain --no-front --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_c3 -o em -- python3 $REPO/bench.py --no-chain --no-front --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_write.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_sq_c3 -o em -- python3 $REPO/bench.py --no-chain --no-front --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_sq.log 2>&1
 # the matrix pipe: instructions, busy cycles (north star: "MFMA-busy where used" -- v_mfma_f64_4x4x4 is the cross-lane reducer of every EM kernel)
-timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/pmc_mfma_c3 -o em -- python3 $REPO/bench.py --no-chain --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_mfma.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/pmc_mfma_c3 -o em -- python3 $REPO/bench.py --no-chain --no-front --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_mfma.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_c2 -o em -- python3 $REPO/bench.py --workload c2 --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_fetch_c2.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_c2 -o em -- python3 $REPO/bench.py --workload c2 --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_write_c2.log 2>&1
 cd $REPO
@@ -80,7 +80,7 @@ cp $SUM/${R}_c3_pmc_summary.json $SUM/${R}_c2_pmc_summary.json $SUM/${R}_c3chain
 (timeout 900 python bench.py --workload c5 --no-cpu-baseline 2>/dev/null) > $SUM/${R}_bench_c5.json
 (timeout 900 python bench.py --workload c3t --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null) > $SUM/${R}_bench_c3t.json
 (timeout 900 python bench.py --workload c3-chain --steps 10 --warmup 3 2>/dev/null) > $SUM/${R}_bench_c3chain.json
-(timeout 900 python bench.py --gpus 2 --steps 10 --warmup 3 --no-chain 2>/dev/null | tail -1) > $SUM/${R}_bench_c3_2ranks_one_gpu.json
+(timeout 900 python bench.py --gpus 2 --steps 10 --warmup 3 --no-chain --no-front 2>/dev/null | tail -1) > $SUM/${R}_bench_c3_2ranks_one_gpu.json
 bash tools/profile_exonbin.sh $R > /dev/null 2>&1
 cp $OUT/exonbin/summary.json $SUM/${R}_exonbin_summary.json
 cp $OUT/exonbin/stats/eb_kernel_stats.csv $SUM/${R}_exonbin_kernel_stats.csv
