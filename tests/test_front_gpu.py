@@ -49,3 +49,21 @@ def test_bench_c3_front_shards_the_sample_over_two_ranks():
     assert d["loci_per_rank"] == [1500, 1500] and sum(d["records_per_rank"]) == d["config"]["records"] == 2 * d["config"]["read_pairs"]
     assert len(d["per_rank_ms"]) == 2 and set(d["per_rank_stage_ms"][1]) == {"bam_decode", "assign_reads", "pair_mates", "collapse_pairs", "quantify"}
     assert d["value"] > 0 and d["ms_per_step"] >= max(d["per_rank_ms"]) * 0.5
+
+
+def test_default_bench_line_carries_the_front_leg_and_survives_its_failure():
+    """`python bench.py` (the driver's command) times records -> theta as a leg of the default line ("front").  The leg must never
+    cost the line: where it cannot run (here: a sample that cannot fit the device) the line comes out without its numbers."""
+    def run(**kw):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", **kw)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-chain", "--no-cpu-baseline", "--steps", "3", "--warmup", "1"],
+                           env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    d = run(SB_FRONT_LOCI="3000", SB_FRONT_FRAGS="3e6")
+    f = d["front"]
+    assert d["n_gpus"] == 1 and d["value"] > 0 and f["ranks_that_ran"] == [0] and f["parity_with_chain"]["ok"]
+    assert f["loci"] == 3000 and f["records"] > 5000000
+    assert set(f["per_rank_stage_ms"][0]) == {"bam_decode", "assign_reads", "pair_mates", "collapse_pairs", "quantify"} and f["ms_per_step"] > 0
+    d = run(SB_FRONT_LOCI="3000", SB_FRONT_FRAGS="1e12")
+    assert d["value"] > 0 and d["front"]["ranks_that_ran"] == [] and "skipped" in d["front"]["note_rank0"] and "ms_per_step" not in d["front"]
