@@ -327,7 +327,7 @@ def front_leg(args, ctx, dev, rank, world, sdist, torch):
     steps = max(1, min(args.steps, 5))
     try:
         torch.cuda.empty_cache()
-        ctx.L.sbgpu_release_idle_memory(ctx.h)
+        ctx.L.sbgpu_release_idle_memory()
         need = 2.8 * 2 * 175.0 * n_frags / world      # the shard's records, the library's arenas for them, the packer's temporaries
         free = torch.cuda.mem_get_info(dev)[0]
         if free < need:
@@ -354,7 +354,7 @@ def front_leg(args, ctx, dev, rank, world, sdist, torch):
                 q.close()
             del q
             torch.cuda.empty_cache()
-            ctx.L.sbgpu_release_idle_memory(ctx.h)
+            ctx.L.sbgpu_release_idle_memory()
         except Exception:
             pass
     table = sdist.gather_values(vals, rank, world, device=dev)

@@ -30,4 +30,4 @@ for world in (1, 2, 4, 8):
         q.close()
         del q
         torch.cuda.empty_cache()
-        ctx.L.sbgpu_release_idle_memory(ctx.h)
+        ctx.L.sbgpu_release_idle_memory()
