@@ -266,6 +266,17 @@ int sbgpu_allreduce_sum_i64(sbgpu_comm_t *comm, int64_t *d_buf, int64_t n, void 
  * context's stream; returns when the result is in `buf`.                                 */
 int sbgpu_allreduce_sum_f64_host(sbgpu_comm_t *comm, double *buf, int64_t n);
 int sbgpu_allreduce_sum_i64_host(sbgpu_comm_t *comm, int64_t *buf, int64_t n);
+/* all-reduce(max): what lets the ranks agree on the LENGTH of an array they are about to sum -- the histogram of the
+ * empirical insert-size law (sbgpu_quantify_resident), whose length is the longest locus of any rank's shard.      */
+int sbgpu_allreduce_max_i64(sbgpu_comm_t *comm, int64_t *d_buf, int64_t n, void *stream);
+int sbgpu_allreduce_max_i64_host(sbgpu_comm_t *comm, int64_t *buf, int64_t n);
+/* A communicator whose exchange is the CALLER's (a driver that already has MPI, sockets or -- the tests -- gloo, or whose
+ * ranks share a GPU, which RCCL does not serve): `fn(user, buf, n, is_f64, op)` must all-reduce the n 8-byte values of the
+ * HOST buffer `buf` in place over the ranks (is_f64: doubles, else int64; op 0 = sum, 1 = max) and return 0.  Every
+ * sbgpu_allreduce_* call on such a communicator stages its buffer through host memory and synchronises `stream`.      */
+typedef int (*sbgpu_host_allreduce_fn)(void *user, void *buf, int64_t n, int32_t is_f64, int32_t op);
+int sbgpu_comm_init_host(sbgpu_ctx_t *ctx, int rank, int world, sbgpu_host_allreduce_fn fn, void *user,
+                         sbgpu_comm_t **comm_out);
 
 /* ---- bin-weight model: what fills F ----------------------------
  * Replaces LocusContext::set_theory_bin_weight, src/estimate.cpp:201-234, with
@@ -707,7 +718,8 @@ int sbgpu_annotation_unpin_matching(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *
 /* The same chain for hits that are in HBM already (a driver that decodes or collapses on the device, or
  * that quantifies the same fragments again): d_hits' arrays and d_hit_mass are DEVICE pointers, grouped by
  * locus as locus_hit_off[n_loci + 1] (host) says and sorted inside a locus like HitCluster's uniq_hits();
- * `annot` holds host pointers; the insert-size law must be given.  The hits take the device grouping
+ * `annot` holds host pointers; insert == NULL builds the empirical law on the device (see sbgpu_quantify_resident, which
+ * also returns it).  The hits take the device grouping
  * (sbgpu_bins_create_device) -- where that declines (fractional masses, ...) the call returns
  * SBGPU_EUNSUPPORTED and the caller uses sbgpu_quantify_host.  theta_out / status_out / iters_out are host
  * arrays; the handle holds the bins (no per-hit bin indices and no weights: sbgpu_bins_export_weights on it
@@ -716,6 +728,42 @@ int sbgpu_quantify_device(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *annot, con
                           const float *d_hit_mass, const int64_t *locus_hit_off, const sbgpu_insert_t *insert,
                           int32_t read_len, int32_t long_read, double *theta_out, int32_t *status_out,
                           int32_t *iters_out, sbgpu_bins_t **bins_out);
+/* The resident path end to end: sbgpu_quantify_device's chain with pass 1 in front of it and the epilogue behind it, the
+ * path's collectives INSIDE the call -- what Sample::preProcess + Sample::procSample compute between the unique hits and
+ * the numbers print2gtf prints (src/alignments.cpp:1189-1232, 1736-1834), without theta, F or a per-hit array crossing PCIe:
+ *   insert == NULL   the reference's DEFAULT mode (no -i): Sample::fragLenDist (alignments.cpp:1363-1410) on the device -- the
+ *                    hits that are compatible with exactly one transcript, Contig::exonic_overlaps_len (contig.cpp:412-426),
+ *                    an integer histogram --, all-reduced over `comm`, then InsertSize(frag_lens) (read.cpp:238-262) from
+ *                    it: every rank holds the law of the WHOLE sample; returned in *insert_used (emp_hist points into the
+ *                    handle).  sbgpu_quantify_host / _device with insert == NULL build their law the same way.
+ *   mapped_reads     this rank's part of Sample::total_mapped_reads(): sum over its clusters of (int) weighted_mass()
+ *                    (alignments.cpp:1372; sbgpu_uniq_dev_info's info[4]); all-reduced over `comm`
+ *   params           the reference's globals; total_mapped_reads and insert_mean are NOT read (the call fills them in
+ *                    from the all-reduced total and the law in use)
+ *   comm             NULL (or a world of one): no exchange.  Otherwise every rank of the communicator must make this
+ *                    call: all-reduce(max) of one int64 and all-reduce(sum) of the histogram (empirical mode only),
+ *                    all-reduce(sum) of the mapped-read total, and -- the one collective per step of north_star --
+ *                    all-reduce(sum) of the ranks' FPKM totals between abundance_kernel and tpm_kernel
+ *                    (estimate.cpp:314-345, alignments.cpp:1821-1829)
+ *   out              host arrays to fill (any may be NULL) and, on return, the device arrays of all of them -- the
+ *                    context's own memory, valid until its next sbgpu_quantify_* call -- plus the totals
+ * Declines like sbgpu_quantify_device (SBGPU_EUNSUPPORTED: the caller uses sbgpu_quantify_host).                        */
+typedef struct {
+   double *theta, *fpkm, *frac, *tpm; /* in: host [n_iso], or NULL                                    */
+   int32_t *keep;                     /* in: host [n_iso], or NULL: 0 erased, 1 kept, 2 kept "NA"    */
+   int32_t *status, *iters;           /* in: host [n_loci], or NULL                                   */
+   const double *d_theta, *d_fpkm, *d_frac, *d_tpm; /* out: device [n_iso]                            */
+   const int32_t *d_keep;                           /* out: device [n_iso]                            */
+   const int32_t *d_status, *d_iters;               /* out: device [n_loci]                           */
+   int64_t total_mapped_reads;        /* out: Sample::total_mapped_reads(), all ranks                 */
+   double total_fpkm;                 /* out: the FPKM total TPM divides by, all ranks                */
+   int64_t n_frag_lens;               /* out: size of the empirical sample, all ranks (0: a law was given) */
+} sbgpu_abundances_t;
+int sbgpu_quantify_resident(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *annot, const sbgpu_hits_t *d_hits,
+                            const float *d_hit_mass, const int64_t *locus_hit_off, const sbgpu_insert_t *insert,
+                            int32_t read_len, int32_t long_read, int64_t mapped_reads,
+                            const sbgpu_abundance_params_t *params, sbgpu_comm_t *comm, sbgpu_insert_t *insert_used,
+                            sbgpu_abundances_t *out, sbgpu_bins_t **bins_out);
 /* F of the EM batch a handle from sbgpu_quantify_host holds: F_out[info[3]] (row-major per locus). */
 int sbgpu_bins_export_weights(const sbgpu_bins_t *bins, double *F_out);
 

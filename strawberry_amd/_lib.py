@@ -36,6 +36,7 @@ SYMBOLS = [
     "sbgpu_collapse_pairs_device", "sbgpu_uniq_dev_destroy", "sbgpu_uniq_dev_info", "sbgpu_uniq_dev_hits", "sbgpu_uniq_dev_export", "sbgpu_bins_info", "sbgpu_bins_grouping", "sbgpu_bins_export",
     "sbgpu_format_value", "sbgpu_format_gtf_transcript", "sbgpu_format_context_row", "sbgpu_format_context_row_seq",
     "sbgpu_binseq_device", "sbgpu_binseq_host", "sbgpu_em_batch", "sbgpu_abundance_device", "sbgpu_tpm_device",
+    "sbgpu_quantify_resident", "sbgpu_allreduce_max_i64", "sbgpu_allreduce_max_i64_host", "sbgpu_comm_init_host",
 ]
 
 
@@ -77,6 +78,16 @@ class sbgpu_insert_t(C.Structure):
         ("read_len", C.c_int32),
         ("long_read", C.c_int32),
     ]
+
+
+class sbgpu_abundances_t(C.Structure):
+    _fields_ = ([(n, C.c_void_p) for n in ("theta", "fpkm", "frac", "tpm", "keep", "status", "iters",
+                                           "d_theta", "d_fpkm", "d_frac", "d_tpm", "d_keep", "d_status", "d_iters")] +
+                [("total_mapped_reads", C.c_int64), ("total_fpkm", C.c_double), ("n_frag_lens", C.c_int64)])
+
+
+# the caller's all-reduce of a host buffer (sbgpu_comm_init_host): fn(user, buf, n, is_f64, op) -> 0
+HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32)
 
 
 class sbgpu_annotation_t(C.Structure):
@@ -211,6 +222,12 @@ def load():
     L.sbgpu_annotation_unpin_matching.argtypes = [vp, C.POINTER(sbgpu_annotation_t), C.POINTER(C.c_int32)]
     L.sbgpu_quantify_device.argtypes = [vp, C.POINTER(sbgpu_annotation_t), C.POINTER(sbgpu_hits_t), vp, vp, C.POINTER(sbgpu_insert_t),
                                         C.c_int32, C.c_int32, vp, vp, vp, C.POINTER(vp)]
+    L.sbgpu_quantify_resident.argtypes = [vp, C.POINTER(sbgpu_annotation_t), C.POINTER(sbgpu_hits_t), vp, vp, C.POINTER(sbgpu_insert_t),
+                                          C.c_int32, C.c_int32, C.c_int64, C.POINTER(sbgpu_abundance_params_t), vp,
+                                          C.POINTER(sbgpu_insert_t), C.POINTER(sbgpu_abundances_t), C.POINTER(vp)]
+    L.sbgpu_allreduce_max_i64.argtypes = [vp, vp, C.c_int64, vp]
+    L.sbgpu_allreduce_max_i64_host.argtypes = [vp, vp, C.c_int64]
+    L.sbgpu_comm_init_host.argtypes = [vp, C.c_int, C.c_int, HOST_ALLREDUCE_FN, vp, C.POINTER(vp)]
     L.sbgpu_bins_export_weights.argtypes = [vp, vp]
     L.sbgpu_collapse_pairs_host.argtypes = [C.c_int64, C.POINTER(sbgpu_pairs_t), C.POINTER(vp)]
     L.sbgpu_collapse_pairs_device.argtypes = [vp, C.c_int64, C.POINTER(sbgpu_pairs_t), vp, vp, C.POINTER(vp)]

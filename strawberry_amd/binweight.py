@@ -37,6 +37,25 @@ class InsertSize:
         self.emp_hist = np.bincount(fl - fl.min(), minlength=self.end_offset - self.start_offset + 1).astype(np.float64)
         return self
 
+    @classmethod
+    def from_hist(cls, start_offset, hist):
+        """The same law from its histogram alone (hist[k] = number of fragments of length start_offset + k, first and last
+        entries non-zero): what sbgpu_quantify_* builds from the device's pass 1 -- integer sums, one rounding each."""
+        h = np.asarray(hist)
+        n = int(h.sum())
+        if n < 1:
+            raise ValueError("Not enough reads")
+        self = cls()
+        lens = [int(start_offset) + k for k in range(len(h))]
+        tot = sum(int(c) * l for c, l in zip(h, lens))
+        sq = sum(int(c) * l * l for c, l in zip(h, lens))
+        self.mean = float(tot) / float(n)
+        self.sd = float(np.sqrt(float(sq) / float(n) - self.mean * self.mean))
+        self.use_emp = True
+        self.start_offset, self.end_offset, self.total_reads = int(start_offset), int(start_offset) + len(h) - 1, n
+        self.emp_hist = np.ascontiguousarray(h, np.float64)
+        return self
+
     def _struct(self, read_len, long_read=False):
         s = _lib.sbgpu_insert_t()
         s.mean, s.sd, s.use_emp = self.mean, self.sd, int(self.use_emp)

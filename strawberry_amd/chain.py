@@ -220,7 +220,12 @@ class ChainQuantifier:
     """step(): fragments (in HBM) -> compat / key words -> bins -> weights -> EM -> theta, one C-ABI call;
     then FPKM / TPM on the host arrays the call returns (the caller's own epilogue, as in the reference)."""
 
-    def __init__(self, ctx, n_loci=60000, n_frags=2e8, seed=31, read_len=75, loci_subset=None, pin=True):
+    def __init__(self, ctx, n_loci=60000, n_frags=2e8, seed=31, read_len=75, loci_subset=None, pin=True, resident=False,
+                 empirical=False, comm=None, min_isoform_frac=0.0):
+        """resident=True: step() is sbgpu_quantify_resident -- the chain with the reference's pass 1 in front (empirical=True: no
+        insert-size law is given, the device builds it from the hits; Strawberry's default mode) and the FPKM / Frac / TPM
+        epilogue behind it, the collectives over `comm` (dist.AbiComm / dist.HostComm; None: a world of one) inside the call;
+        theta, FPKM, Frac, keep and TPM land in the object's host arrays, `law` holds the insert-size law that was used."""
         import torch
         self.torch, self.ctx = torch, ctx
         self.dev = torch.device("cuda", ctx.device)
@@ -238,6 +243,17 @@ class ChainQuantifier:
         self._ht = self.hits.struct()
         self._ins = self.insert._struct(read_len)
         self.info = None
+        self.resident, self.empirical, self.comm = bool(resident), bool(empirical), comm
+        if resident:
+            self.fpkm, self.frac, self.tpm = np.zeros(self.n_iso + 1), np.zeros(self.n_iso + 1), np.zeros(self.n_iso + 1)
+            self.keep = np.zeros(self.n_iso + 1, np.int32)
+            self._par = _lib.sbgpu_abundance_params_t(0, 0, 1, 0, 0.0, float(min_isoform_frac))
+            self._out = _lib.sbgpu_abundances_t()
+            for k in ("theta", "fpkm", "frac", "tpm", "keep", "status", "iters"):
+                setattr(self._out, k, getattr(self, k).ctypes.data)
+            self._used = _lib.sbgpu_insert_t()
+            self.law = None
+            self.mapped_override = None     # tests: a mapped-read total other than this object's own
         # the annotation is read once and the reads stream past it (Strawberry.cpp:245-275, :359): kept resident
         self.pinned = bool(pin)
         if pin:
@@ -248,10 +264,13 @@ class ChainQuantifier:
         the weights of the device entry stay in HBM -- sbgpu_quantify_host on the same hits returns them)."""
         h = C.c_void_p()
         L = self.ctx.L
-        _lib.check(L.sbgpu_quantify_device(self.ctx.h, C.byref(self._an), C.byref(self._ht), self.hits.mass.data_ptr(),
-                                           self.hits.locus_hit_off.ctypes.data, C.byref(self._ins), self.read_len, 0,
-                                           self.theta.ctypes.data, self.status.ctypes.data, self.iters.ctypes.data,
-                                           C.byref(h)), "sbgpu_quantify_device")
+        if self.resident:
+            self._resident_call(L, self._ht, self.hits.mass.data_ptr(), self.hits.locus_hit_off.ctypes.data, self.n_frags, h)
+        else:
+            _lib.check(L.sbgpu_quantify_device(self.ctx.h, C.byref(self._an), C.byref(self._ht), self.hits.mass.data_ptr(),
+                                               self.hits.locus_hit_off.ctypes.data, C.byref(self._ins), self.read_len, 0,
+                                               self.theta.ctypes.data, self.status.ctypes.data, self.iters.ctypes.data,
+                                               C.byref(h)), "sbgpu_quantify_device")
         if self.info is None:
             info = (C.c_int64 * 8)()
             _lib.check(L.sbgpu_bins_info(h, info), "sbgpu_bins_info")
@@ -261,6 +280,26 @@ class ChainQuantifier:
             bins._export(L, self.annot, h, self.n_hits, self.annot.compat_words, self.annot.key_words, with_hit_bin=False)   # destroys the handle
             return bins
         L.sbgpu_bins_destroy(h)
+
+    def set_law(self, insert):
+        """Quantify under a GIVEN insert-size law from now on (an InsertSize: -i mean/sd, or an empirical law made elsewhere)."""
+        self.insert, self.empirical = insert, False
+        self._ins = insert._struct(self.read_len)
+
+    def _resident_call(self, L, hits_struct, d_mass, hit_off, mapped_reads, h):
+        """sbgpu_quantify_resident on device hits; mapped_reads: this rank's part of Sample::total_mapped_reads()."""
+        if self.mapped_override is not None:
+            mapped_reads = self.mapped_override
+        _lib.check(L.sbgpu_quantify_resident(self.ctx.h, C.byref(self._an), C.byref(hits_struct), d_mass, hit_off,
+                                             None if self.empirical else C.byref(self._ins), self.read_len, 0, int(mapped_reads),
+                                             C.byref(self._par), self.comm.h if self.comm is not None else None,
+                                             C.byref(self._used), C.byref(self._out), C.byref(h)), "sbgpu_quantify_resident")
+        u = self._used
+        self.law = {"mean": u.mean, "sd": u.sd, "use_emp": int(u.use_emp), "start_offset": int(u.start_offset),
+                    "end_offset": int(u.end_offset), "total_reads": int(u.total_reads)}
+        if u.use_emp:   # (emp_hist points into the handle: copied while it lives)
+            self.law["emp_hist"] = np.ctypeslib.as_array(u.emp_hist, shape=(u.end_offset - u.start_offset + 1,)).copy()
+        self.total_fpkm, self.total_mapped_reads = float(self._out.total_fpkm), int(self._out.total_mapped_reads)
 
     def stage_ms(self):
         """HIP-event times of the kernel stages of one more (untimed) step -> {stage: ms}."""

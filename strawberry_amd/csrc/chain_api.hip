@@ -20,6 +20,7 @@
 
 #include "../../include/sbgpu.h"
 #include "api_internal.h"
+#include "fraglen_device.h"
 
 using sb::api_fail;
 
@@ -32,6 +33,14 @@ struct DeviceBuf {
 
 size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
 
+// what sbgpu_quantify_resident adds to the chain: the epilogue behind the EM, with the path's collectives inside the call
+struct ResidentOpts {
+   int64_t mapped_reads;                   // this rank's part of Sample::total_mapped_reads()
+   const sbgpu_abundance_params_t *params; // total_mapped_reads and insert_mean are filled in here
+   sbgpu_comm_t *comm;                     // nullptr: a world of one
+   sbgpu_abundances_t *out;
+};
+
 } // namespace
 
 // `dev_hit_off` != nullptr: the hits (hits->..., hit_mass) are DEVICE arrays already, grouped by locus as
@@ -39,10 +48,10 @@ size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
 static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgpu_hits_t *hits, const float *hit_mass,
                          const int64_t *dev_hit_off, const sbgpu_insert_t *insert, int32_t read_len, int32_t long_read,
                          double *theta_out, int32_t *status_out, int32_t *iters_out, uint32_t *compat_out,
-                         sbgpu_insert_t *insert_used, sbgpu_bins_t **bins_out)
+                         sbgpu_insert_t *insert_used, sbgpu_bins_t **bins_out, const ResidentOpts *ro = nullptr)
 {
    const bool on_dev = dev_hit_off != nullptr;
-   if (!c || !an || !hits || !theta_out || !status_out || !iters_out || !bins_out)
+   if (!c || !an || !hits || !bins_out || (!ro && (!theta_out || !status_out || !iters_out)))
       return api_fail(SBGPU_EINVAL, "sbgpu_quantify_host: null argument");
    *bins_out = nullptr;
    const int64_t nl = an->n_loci, nh = hits->n_hits;
@@ -50,7 +59,7 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
    if (!an->iso_off || !an->exon_off || !an->seg_off || (nh && (!hits->hit_locus || !hits->feat_off || !hit_mass)))
       return api_fail(SBGPU_EINVAL, "sbgpu_quantify_host: null array");
    if (!insert && !insert_used) return api_fail(SBGPU_EINVAL, "sbgpu_quantify_host: insert_used is needed when no insert-size law is given");
-   if (on_dev && (!insert || compat_out)) return api_fail(SBGPU_EINVAL, "sbgpu_quantify_device: needs an insert-size law and returns no compat words");
+   if (on_dev && compat_out) return api_fail(SBGPU_EINVAL, "sbgpu_quantify_device: returns no compat words");
    const int64_t n_iso = an->iso_off[nl], n_exon = an->exon_off[n_iso], n_seg = an->seg_off[nl];
    int64_t n_feat = 0;
    if (nh && !on_dev) n_feat = hits->feat_off[nh];
@@ -247,44 +256,6 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
       }
       return SBGPU_OK;
    };
-   // ---- the insert-size law: given, or the empirical one from the hits (pass 1 of the reference)
-   sbgpu_insert_t ins;
-   std::vector<double> emp_hist;
-   if (insert) {
-      ins = *insert;
-      ins.read_len = read_len;
-      ins.long_read = long_read;
-   } else {
-      SB_RC(need_compat());
-      std::vector<int32_t> fl(nh1, -1);
-      const int64_t n = sbgpu_frag_lens_host(an, hits, cw, compat_h.data(), fl.data());
-      if (n < 0) return (int)n;
-      if (n < 1) return api_fail(SBGPU_EINVAL, "sbgpu_quantify_host: no hit fits exactly one transcript: no empirical insert-size law (\"Not enough reads\")");
-      // InsertSize(const vector<int> frag_lens), src/read.cpp:238-262; mean_and_sd_insert_size :14-20
-      double sum = 0.0, sq = 0.0;
-      int32_t lo = 0x7fffffff, hi = -1;
-      for (int64_t h = 0; h < nh; ++h)
-         if (fl[(size_t)h] >= 0) {
-            sum += fl[(size_t)h];
-            lo = std::min(lo, fl[(size_t)h]);
-            hi = std::max(hi, fl[(size_t)h]);
-         }
-      for (int64_t h = 0; h < nh; ++h)
-         if (fl[(size_t)h] >= 0) sq += (double)fl[(size_t)h] * fl[(size_t)h];
-      emp_hist.assign((size_t)(hi - lo + 1), 0.0);
-      for (int64_t h = 0; h < nh; ++h)
-         if (fl[(size_t)h] >= 0) emp_hist[(size_t)(fl[(size_t)h] - lo)] += 1.0;
-      ins.mean = sum / (double)n;
-      ins.sd = std::sqrt(sq / (double)n - ins.mean * ins.mean);
-      ins.use_emp = 1;
-      ins.start_offset = lo;
-      ins.end_offset = hi;
-      ins.total_reads = (int32_t)n;
-      ins.emp_hist = emp_hist.data();
-      ins.read_len = read_len;
-      ins.long_read = long_read;
-   }
-   stage("insert size");
    // the insert-size table reaches as far as the longest locus' segments together (no (bin, isoform) pair spans more)
    int64_t max_l = 1;
    if (!long_read && res) max_l = res->max_locus_span;
@@ -299,15 +270,101 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
    char *d_pdf = nullptr;
    if (hipError_t ep = sb::ctx_scratch(c, 6, (size_t)pdf_len * 8, &d_pdf); ep != hipSuccess)
       return api_fail(ep == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("hipMalloc: ") + hipGetErrorString(ep));
-   // the table of the law, on the copy stream beside the kernels (the bin-weight launch waits for its event)
    std::vector<double> pdf((size_t)pdf_len, 0.0);
-   SB_RC(sbgpu_insert_pdf_table(&ins, pdf_len, pdf.data()));
    hipStream_t cs = nullptr;
-   hipEvent_t ev_pdf = nullptr;
+   hipEvent_t ev_pdf = nullptr, ev_hist = nullptr;
    SB_TRY(sb::ctx_copy_stream(c, &cs));
    SB_TRY(sb::ctx_event(c, 3, &ev_pdf));
-   SB_TRY(hipMemcpyAsync(d_pdf, pdf.data(), (size_t)pdf_len * 8, hipMemcpyHostToDevice, cs));
-   SB_TRY(hipEventRecord(ev_pdf, cs));
+   // ---- the insert-size law: given, or the empirical one from the hits (pass 1 of the reference: Sample::fragLenDist,
+   // src/alignments.cpp:1363-1410, on the device -- fraglen_device.h)
+   sbgpu_insert_t ins;
+   std::vector<double> emp_hist;
+   int64_t n_frag_lens = 0, hist_len = 0;
+   const unsigned long long *h_hist = nullptr; // pinned: the histogram as the device (and the other ranks) made it
+   int64_t mapped_total = ro ? ro->mapped_reads : 0;
+   if (insert) {
+      ins = *insert;
+      ins.read_len = read_len;
+      ins.long_read = long_read;
+      // the table of the law, on the copy stream beside the kernels (the bin-weight launch waits for its event)
+      SB_RC(sbgpu_insert_pdf_table(&ins, pdf_len, pdf.data()));
+      SB_TRY(hipMemcpyAsync(d_pdf, pdf.data(), (size_t)pdf_len * 8, hipMemcpyHostToDevice, cs));
+      SB_TRY(hipEventRecord(ev_pdf, cs));
+      if (ro && ro->comm) { // Sample::total_mapped_reads() over all ranks (alignments.cpp:1372)
+         SB_RC(sbgpu_allreduce_sum_i64_host(ro->comm, &mapped_total, 1));
+      }
+   } else {
+      // every rank's histogram has the same length: the longest locus of any of them
+      hist_len = pdf_len;
+      if (ro && ro->comm) SB_RC(sbgpu_allreduce_max_i64_host(ro->comm, &hist_len, 1));
+      char *d_hist = nullptr, *pin = nullptr;
+      const size_t hist_bytes = (size_t)(hist_len + 2) * 8; // [hist_len]: lengths beyond the table; [hist_len + 1]: the mapped-read total
+      if (hipError_t eh = sb::ctx_scratch(c, 7, hist_bytes, &d_hist); eh != hipSuccess)
+         return api_fail(eh == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("hipMalloc: ") + hipGetErrorString(eh));
+      SB_TRY(sb::ctx_pinned(c, 1, hist_bytes, &pin));
+      SB_TRY(sb::ctx_event(c, 5, &ev_hist));
+      SB_TRY(hipMemsetAsync(d_hist, 0, hist_bytes, s));
+      if (ro) SB_TRY(hipMemcpyAsync(d_hist + (size_t)(hist_len + 1) * 8, &ro->mapped_reads, 8, hipMemcpyHostToDevice, s));
+      sb::ctx_stage_begin(c, "fraglen_hist_kernel", s);
+      if (nh) {
+         sb::FragLenArgs fa;
+         fa.n_hits = nh, fa.compat_words = cw;
+         fa.hit_locus = dh.hit_locus, fa.compat = d_compat, fa.span = d_span;
+         fa.iso_off = dan.iso_off, fa.exon_off = dan.exon_off, fa.exon_left = dan.exon_left, fa.exon_right = dan.exon_right;
+         fa.hist_len = hist_len, fa.hist = (unsigned long long *)d_hist;
+         const int64_t want = std::min<int64_t>((nh + 255) / 256, (int64_t)sb::ctx_cu_count(c) * 8);
+         hipLaunchKernelGGL(sb::fraglen_hist_kernel, dim3((unsigned)want), dim3(256), 0, s, fa);
+         SB_TRY(hipGetLastError());
+      }
+      sb::ctx_stage_end(c, s);
+      // the law is the WHOLE sample's: one all-reduce(sum) of the histogram (exact integers) with the mapped-read total behind it
+      if (ro && ro->comm) SB_RC(sbgpu_allreduce_sum_i64(ro->comm, (int64_t *)d_hist, hist_len + 2, s));
+      SB_TRY(hipMemcpyAsync(pin, d_hist, hist_bytes, hipMemcpyDeviceToHost, s));
+      SB_TRY(hipEventRecord(ev_hist, s));
+      h_hist = (const unsigned long long *)pin;
+   }
+   // called before the bin weights are launched: by then the histogram has long arrived (the grouping's kernels ran behind it)
+   bool law_ready = insert != nullptr;
+   auto finish_law = [&]() -> int {
+      if (law_ready) return SBGPU_OK;
+      SB_TRY(hipEventSynchronize(ev_hist));
+      if (h_hist[hist_len]) return api_fail(SBGPU_ESHAPE, "sbgpu_quantify_host: a fragment length beyond the longest locus");
+      if (ro) mapped_total = (int64_t)h_hist[hist_len + 1];
+      // InsertSize(const vector<int> frag_lens), src/read.cpp:238-262; mean_and_sd_insert_size :14-20 -- size, sum, sum of
+      // squares, extremes and histogram of the sample, all read off the histogram (integers: exact in any order; the
+      // reference's running doubles are the same numbers as long as they stay below 2^53)
+      int64_t lo = -1, hi = -1;
+      unsigned long long n = 0;
+      unsigned __int128 sum = 0, sq = 0;
+      for (int64_t l = 0; l < hist_len; ++l)
+         if (const unsigned long long k = h_hist[l]) {
+            if (lo < 0) lo = l;
+            hi = l;
+            n += k;
+            sum += (unsigned __int128)k * (unsigned long long)l;
+            sq += (unsigned __int128)k * (unsigned long long)l * (unsigned long long)l;
+         }
+      if (n < 1) return api_fail(SBGPU_EINVAL, "sbgpu_quantify_host: no hit fits exactly one transcript: no empirical insert-size law (\"Not enough reads\")");
+      if (n > (unsigned long long)INT32_MAX) return api_fail(SBGPU_ESHAPE, "sbgpu_quantify_host: more than 2^31 fragment lengths");
+      emp_hist.assign((size_t)(hi - lo + 1), 0.0);
+      for (int64_t l = lo; l <= hi; ++l) emp_hist[(size_t)(l - lo)] = (double)h_hist[l];
+      n_frag_lens = (int64_t)n;
+      ins.mean = (double)sum / (double)n;
+      ins.sd = std::sqrt((double)sq / (double)n - ins.mean * ins.mean);
+      ins.use_emp = 1;
+      ins.start_offset = (int32_t)lo;
+      ins.end_offset = (int32_t)hi;
+      ins.total_reads = (int32_t)n;
+      ins.emp_hist = emp_hist.data();
+      ins.read_len = read_len;
+      ins.long_read = long_read;
+      SB_RC(sbgpu_insert_pdf_table(&ins, pdf_len, pdf.data()));
+      SB_TRY(hipMemcpyAsync(d_pdf, pdf.data(), (size_t)pdf_len * 8, hipMemcpyHostToDevice, cs));
+      SB_TRY(hipEventRecord(ev_pdf, cs));
+      law_ready = true;
+      stage("insert size");
+      return SBGPU_OK;
+   };
    stage("pdf table");
    // ---- everything behind the bins: weights straight into the EM batch's F (A4), plan + EM (A1/A2), the downloads.
    // With the device grouping the weights are launched from inside bins_create_device_impl -- as soon as the pairs' fill
@@ -333,7 +390,7 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
          if (t.joinable()) t.join();
       }
    } plan_job; // (declared after plan_guard: joined before the plan is destroyed)
-   size_t q_theta = 0, q_st = 0, q_it = 0;
+   size_t q_theta = 0, q_st = 0, q_it = 0, q_fpkm = 0, q_frac = 0, q_tpm = 0, q_keep = 0, q_sum = 0, q_ilen = 0;
    hipError_t e1 = hipSuccess, e2 = hipSuccess, e3 = hipSuccess, e4 = hipSuccess;
    int64_t n_bins = 0, n_elem = 0, n_pairs = 0, n_psegs = 0;
    size_t q_F = 0;
@@ -366,9 +423,18 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
       q_theta = t2; t2 += up256((size_t)(n_iso + 1) * 8);
       q_st = t2; t2 += up256((size_t)(nl + 1) * 4);
       q_it = t2; t2 += up256((size_t)(nl + 1) * 4);
+      if (ro) { // the epilogue's arrays (sbgpu_quantify_resident)
+         q_fpkm = t2; t2 += up256((size_t)(n_iso + 1) * 8);
+         q_frac = t2; t2 += up256((size_t)(n_iso + 1) * 8);
+         q_tpm = t2; t2 += up256((size_t)(n_iso + 1) * 8);
+         q_keep = t2; t2 += up256((size_t)(n_iso + 1) * 4);
+         q_ilen = t2; t2 += up256((size_t)(n_iso + 1) * 4);
+         q_sum = t2; t2 += up256(8);
+      }
       hipError_t ew = sb::ctx_scratch(c, 1, t2, &w.p);
       if (ew != hipSuccess) return api_fail(ew == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string("hipMalloc: ") + hipGetErrorString(ew));
       SB_TRY(hipMemsetAsync(w.p + q_F, 0, ne1 * 8, s));
+      SB_RC(finish_law());
       SB_TRY(hipStreamWaitEvent(s, ev_pdf, 0));
       if (n_pairs) {
          const int64_t *d_off = dpairs ? dpairs->seg_off() : (const int64_t *)(w.p + q_off);
@@ -412,14 +478,55 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
       sb::ctx_stage_end(c, s);
       return rce;
    };
+   // ---- A3 / A7 behind the EM (sbgpu_quantify_resident): theta -> FPKM / Frac / keep (estimate.cpp:314-355), the FPKM total of
+   // ALL ranks (alignments.cpp:1821-1824: the path's one collective per step), TPM (:1825-1829) -- theta never leaves the device
+   auto launch_epilogue = [&]() -> int {
+      if (!ro) return SBGPU_OK;
+      if (mapped_total < 1 || mapped_total > (int64_t)INT32_MAX)
+         return api_fail(SBGPU_EINVAL, "sbgpu_quantify_resident: the mapped-read total must be in [1, 2^31) (Sample::total_mapped_reads() is an int)");
+      const int32_t *d_len = nullptr;
+      if (res) {
+         d_len = res->d_iso.len;
+      } else {
+         if ((int64_t)iso_pre.len.size() != n_iso) sb::iso_segments(an, &iso_pre);
+         SB_TRY(hipMemcpyAsync(w.p + q_ilen, iso_pre.len.data(), (size_t)n_iso * 4, hipMemcpyHostToDevice, s));
+         d_len = (const int32_t *)(w.p + q_ilen);
+      }
+      sbgpu_abundance_params_t par = *ro->params;
+      par.total_mapped_reads = (int32_t)mapped_total;
+      par.insert_mean = ins.mean; // _sample._insert_size_dist->_mean (estimate.cpp:318)
+      sb::ctx_stage_begin(c, "abundance + tpm", s);
+      SB_RC(sbgpu_abundance_device(c, plan, (const double *)(w.p + q_theta), (const int32_t *)(w.p + q_st), d_len, &par, (double *)(w.p + q_fpkm),
+                                   (double *)(w.p + q_frac), (int32_t *)(w.p + q_keep), (double *)(w.p + q_sum), s));
+      if (ro->comm) SB_RC(sbgpu_allreduce_sum_f64(ro->comm, (double *)(w.p + q_sum), 1, s));
+      SB_RC(sbgpu_tpm_device(c, n_iso, (const double *)(w.p + q_fpkm), (const int32_t *)(w.p + q_keep), (const double *)(w.p + q_sum),
+                             (double *)(w.p + q_tpm), s));
+      sb::ctx_stage_end(c, s);
+      return SBGPU_OK;
+   };
    // the results come down last: a copy into the caller's pageable memory holds the host until the EM is done, and
    // the handle's host work is to run beside the kernels, not behind them
+   hipError_t e7 = hipSuccess;
    auto download = [&]() {
       F.assign(on_dev ? (size_t)0 : (size_t)n_elem, 0.0); // (device entry: the weights are not brought back)
-      e1 = hipMemcpyAsync(theta_out, w.p + q_theta, (size_t)n_iso * 8, hipMemcpyDeviceToHost, s);
-      e2 = hipMemcpyAsync(status_out, w.p + q_st, (size_t)nl * 4, hipMemcpyDeviceToHost, s);
-      e3 = hipMemcpyAsync(iters_out, w.p + q_it, (size_t)nl * 4, hipMemcpyDeviceToHost, s);
+      double *h_theta = ro ? ro->out->theta : theta_out;
+      int32_t *h_st = ro ? ro->out->status : status_out, *h_it = ro ? ro->out->iters : iters_out;
+      if (h_theta) e1 = hipMemcpyAsync(h_theta, w.p + q_theta, (size_t)n_iso * 8, hipMemcpyDeviceToHost, s);
+      if (h_st) e2 = hipMemcpyAsync(h_st, w.p + q_st, (size_t)nl * 4, hipMemcpyDeviceToHost, s);
+      if (h_it) e3 = hipMemcpyAsync(h_it, w.p + q_it, (size_t)nl * 4, hipMemcpyDeviceToHost, s);
       e4 = (n_elem && !on_dev) ? hipMemcpyAsync(F.data(), w.p + q_F, (size_t)n_elem * 8, hipMemcpyDeviceToHost, s) : hipSuccess;
+      if (ro) {
+         sbgpu_abundances_t *o = ro->out;
+         auto get = [&](void *dst, size_t off, size_t bytes) {
+            if (dst && e7 == hipSuccess) e7 = hipMemcpyAsync(dst, w.p + off, bytes, hipMemcpyDeviceToHost, s);
+         };
+         get(o->fpkm, q_fpkm, (size_t)n_iso * 8), get(o->frac, q_frac, (size_t)n_iso * 8), get(o->tpm, q_tpm, (size_t)n_iso * 8);
+         get(o->keep, q_keep, (size_t)n_iso * 4), get(&o->total_fpkm, q_sum, 8);
+         o->d_theta = (const double *)(w.p + q_theta), o->d_fpkm = (const double *)(w.p + q_fpkm), o->d_frac = (const double *)(w.p + q_frac);
+         o->d_tpm = (const double *)(w.p + q_tpm), o->d_keep = (const int32_t *)(w.p + q_keep);
+         o->d_status = (const int32_t *)(w.p + q_st), o->d_iters = (const int32_t *)(w.p + q_it);
+         o->total_mapped_reads = mapped_total, o->n_frag_lens = n_frag_lens;
+      }
    };
    // ---- A5: bins (device; host when the device form declines)
    sbgpu_bins_t *bins = nullptr;
@@ -453,6 +560,7 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
       rc = sb::bins_create_device_impl(c, an, &dh, d_mass, locus_hit_off.data(), cw, kw, d_compat, d_key, on_dev ? nullptr : d_hit_bin, s,
                                        res ? &res->iso : &iso_pre, &bins, d_span, d_fhash, &hooks);
       if (rc == SBGPU_OK && rest_launched) rc = launch_em(plan_job.row_off.data(), plan_job.f_off.data(), d_count_dev, nullptr);
+      if (rc == SBGPU_OK && rest_launched) rc = launch_epilogue();
       if (rc != SBGPU_OK) {
          // a grouping that failed after the plan's thread was started: the thread is over before anything else happens
          if (plan_job.t.joinable()) plan_job.t.join();
@@ -470,7 +578,7 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
       }
    }
    const bool on_device = rc == SBGPU_OK;
-   if (rc == SBGPU_EUNSUPPORTED && on_dev)
+   if (rc == SBGPU_EUNSUPPORTED && on_dev && nh) // (no hits at all: the host code makes the empty handle)
       return api_fail(rc, "sbgpu_quantify_device: the device grouping does not cover these hits (unsorted, fractional masses or a locus of thousands of bins): use sbgpu_quantify_host");
    std::string why_host;
    if (rc == SBGPU_EUNSUPPORTED || !(grouped && nh)) {
@@ -515,12 +623,13 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
       stage("export");
       SB_RC(launch_weights(dpairs));
       SB_RC(launch_em(row_off_h.data(), f_off_h.data(), nullptr, count_h.data()));
+      SB_RC(launch_epilogue());
    }
    download();
    hipError_t e5 = hipSuccess;
    hipError_t e6 = hipStreamSynchronize(s);
    stage("plan + EM + download");
-   for (hipError_t x : {e1, e2, e3, e4, e5, e6})
+   for (hipError_t x : {e1, e2, e3, e4, e5, e6, e7})
       if (x != hipSuccess) return api_fail(SBGPU_EHIP, std::string("sbgpu_quantify_host: download: ") + hipGetErrorString(x));
    // a wide-locus barrier that timed out leaves its loci unsolved (status SBGPU_EM_UNSOLVED): that is a failed call
    if (sb::ctx_take_wide_error(c))
@@ -661,6 +770,19 @@ int sbgpu_quantify_device(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sb
    sbgpu_insert_t used;
    return quantify_impl(c, an, d_hits, d_hit_mass, locus_hit_off, insert, read_len, long_read, theta_out, status_out, iters_out,
                         nullptr, &used, bins_out);
+}
+
+int sbgpu_quantify_resident(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgpu_hits_t *d_hits, const float *d_hit_mass,
+                            const int64_t *locus_hit_off, const sbgpu_insert_t *insert, int32_t read_len, int32_t long_read,
+                            int64_t mapped_reads, const sbgpu_abundance_params_t *params, sbgpu_comm_t *comm,
+                            sbgpu_insert_t *insert_used, sbgpu_abundances_t *out, sbgpu_bins_t **bins_out)
+{
+   if (!locus_hit_off || !params || !out) return api_fail(SBGPU_EINVAL, "sbgpu_quantify_resident: null argument");
+   if (mapped_reads < 0) return api_fail(SBGPU_EINVAL, "sbgpu_quantify_resident: negative mapped-read count");
+   sbgpu_insert_t used;
+   const ResidentOpts ro = {mapped_reads, params, comm, out};
+   return quantify_impl(c, an, d_hits, d_hit_mass, locus_hit_off, insert, read_len, long_read, nullptr, nullptr, nullptr, nullptr,
+                        insert_used ? insert_used : &used, bins_out, &ro);
 }
 
 } // extern "C"

@@ -16,6 +16,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/sbgpu.h"
 #include "api_internal.h"
@@ -27,7 +28,7 @@ typedef struct {
    char internal[128];
 } RcclUniqueId;
 typedef void *RcclComm;
-constexpr int kRcclSum = 0, kRcclInt64 = 4, kRcclFloat64 = 8;
+constexpr int kRcclSum = 0, kRcclMax = 2, kRcclInt64 = 4, kRcclFloat64 = 8;
 struct Rccl {
    void *lib = nullptr;
    int (*GetUniqueId)(RcclUniqueId *) = nullptr;
@@ -81,6 +82,8 @@ struct sbgpu_comm {
    RcclComm comm = nullptr;
    hipStream_t stream = nullptr; // the context's own stream: the host-buffer forms run on it
    void *d_scratch = nullptr;    // kScratchBytes of device memory for the host-buffer forms
+   sbgpu_host_allreduce_fn host_fn = nullptr; // sbgpu_comm_init_host: the exchange is the caller's, on host buffers
+   void *host_user = nullptr;
 };
 namespace {
 constexpr size_t kScratchBytes = 4096;
@@ -186,12 +189,25 @@ int sbgpu_comm_info(const sbgpu_comm_t *c, int *rank, int *world)
    return SBGPU_OK;
 }
 
-static int allreduce(sbgpu_comm_t *c, void *d_buf, int64_t n, int dtype, void *stream, const char *who)
+static int allreduce(sbgpu_comm_t *c, void *d_buf, int64_t n, int dtype, void *stream, const char *who, int op = kRcclSum)
 {
    if (!c) return sb::api_fail(SBGPU_EINVAL, std::string(who) + ": null comm");
    if (n < 0 || (n > 0 && !d_buf)) return sb::api_fail(SBGPU_EINVAL, std::string(who) + ": bad buffer");
+   if (c->host_fn && n > 0 && c->world > 1) { // the caller's exchange: through host memory, synchronous
+      std::vector<char> h((size_t)n * 8);
+      hipError_t e = hipSetDevice(c->device);
+      if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d_buf, h.size(), hipMemcpyDeviceToHost, (hipStream_t)stream);
+      if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+      if (e != hipSuccess) return sb::api_fail(SBGPU_EHIP, std::string(who) + ": " + hipGetErrorString(e));
+      if (c->host_fn(c->host_user, h.data(), n, dtype == kRcclFloat64 ? 1 : 0, op == kRcclMax ? 1 : 0) != 0)
+         return sb::api_fail(SBGPU_ERCCL, std::string(who) + ": the caller's all-reduce failed");
+      e = hipMemcpyAsync(d_buf, h.data(), h.size(), hipMemcpyHostToDevice, (hipStream_t)stream);
+      if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+      if (e != hipSuccess) return sb::api_fail(SBGPU_EHIP, std::string(who) + ": " + hipGetErrorString(e));
+      return SBGPU_OK;
+   }
    if (!c->comm || n == 0) return SBGPU_OK; // the sum over one rank (a forced world of one has a communicator and goes on)
-   const int rc = rccl().AllReduce(d_buf, d_buf, (size_t)n, dtype, kRcclSum, c->comm, (hipStream_t)stream);
+   const int rc = rccl().AllReduce(d_buf, d_buf, (size_t)n, dtype, op, c->comm, (hipStream_t)stream);
    if (rc != 0) return rccl_fail(who, rc);
    return SBGPU_OK;
 }
@@ -206,16 +222,26 @@ int sbgpu_allreduce_sum_i64(sbgpu_comm_t *c, int64_t *d_buf, int64_t n, void *st
    return allreduce(c, d_buf, n, kRcclInt64, stream, "sbgpu_allreduce_sum_i64");
 }
 
+int sbgpu_allreduce_max_i64(sbgpu_comm_t *c, int64_t *d_buf, int64_t n, void *stream)
+{
+   return allreduce(c, d_buf, n, kRcclInt64, stream, "sbgpu_allreduce_max_i64", kRcclMax);
+}
+
 // host buffers: staged through the communicator's scratch on the context's stream, synchronous
-static int allreduce_host(sbgpu_comm_t *c, void *buf, int64_t n, int dtype, const char *who)
+static int allreduce_host(sbgpu_comm_t *c, void *buf, int64_t n, int dtype, const char *who, int op = kRcclSum)
 {
    if (!c) return sb::api_fail(SBGPU_EINVAL, std::string(who) + ": null comm");
    if (n < 0 || (n > 0 && !buf) || (size_t)n * 8 > kScratchBytes) return sb::api_fail(SBGPU_EINVAL, std::string(who) + ": 0 <= n <= 512 values");
+   if (c->host_fn && n > 0 && c->world > 1) {
+      if (c->host_fn(c->host_user, buf, n, dtype == kRcclFloat64 ? 1 : 0, op == kRcclMax ? 1 : 0) != 0)
+         return sb::api_fail(SBGPU_ERCCL, std::string(who) + ": the caller's all-reduce failed");
+      return SBGPU_OK;
+   }
    if (!c->comm || n == 0) return SBGPU_OK;
    hipError_t e = hipSetDevice(c->device);
    if (e == hipSuccess) e = hipMemcpyAsync(c->d_scratch, buf, (size_t)n * 8, hipMemcpyHostToDevice, c->stream);
    if (e != hipSuccess) return sb::api_fail(SBGPU_EHIP, std::string(who) + ": " + hipGetErrorString(e));
-   const int rc = allreduce(c, c->d_scratch, n, dtype, c->stream, who);
+   const int rc = allreduce(c, c->d_scratch, n, dtype, c->stream, who, op);
    if (rc != SBGPU_OK) return rc;
    e = hipMemcpyAsync(buf, c->d_scratch, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream);
    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -231,6 +257,25 @@ int sbgpu_allreduce_sum_f64_host(sbgpu_comm_t *c, double *buf, int64_t n)
 int sbgpu_allreduce_sum_i64_host(sbgpu_comm_t *c, int64_t *buf, int64_t n)
 {
    return allreduce_host(c, buf, n, kRcclInt64, "sbgpu_allreduce_sum_i64_host");
+}
+
+int sbgpu_allreduce_max_i64_host(sbgpu_comm_t *c, int64_t *buf, int64_t n)
+{
+   return allreduce_host(c, buf, n, kRcclInt64, "sbgpu_allreduce_max_i64_host", kRcclMax);
+}
+
+int sbgpu_comm_init_host(sbgpu_ctx_t *ctx, int rank, int world, sbgpu_host_allreduce_fn fn, void *user, sbgpu_comm_t **comm_out)
+{
+   if (!ctx || !comm_out || !fn) return sb::api_fail(SBGPU_EINVAL, "sbgpu_comm_init_host: null argument");
+   *comm_out = nullptr;
+   if (world < 1 || rank < 0 || rank >= world) return sb::api_fail(SBGPU_EINVAL, "sbgpu_comm_init_host: need 0 <= rank < world");
+   sbgpu_comm *c = new (std::nothrow) sbgpu_comm();
+   if (!c) return sb::api_fail(SBGPU_ENOMEM, "sbgpu_comm_init_host: out of host memory");
+   c->rank = rank, c->world = world, c->device = sb::ctx_device(ctx);
+   c->stream = sb::ctx_stream(ctx);
+   c->host_fn = fn, c->host_user = user;
+   *comm_out = c;
+   return SBGPU_OK;
 }
 
 } // extern "C"

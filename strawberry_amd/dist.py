@@ -184,6 +184,49 @@ class AbiComm:
             pass
 
 
+class HostComm:
+    """A communicator whose exchange is the caller's (sbgpu_comm_init_host): every all-reduce of the library is staged
+    through a host buffer and handed to torch.distributed's default group -- gloo in the CPU tests and wherever several
+    ranks share one GPU (RCCL does not serve two ranks on one device); a world of one never calls back."""
+
+    def __init__(self, ctx, rank=None, world=None):
+        import ctypes as C
+        from . import _lib
+        self.L = _lib.load()
+        r, w, _ = env_world()
+        self.rank = r if rank is None else rank
+        self.world = w if world is None else world
+        self.calls = 0
+
+        def fn(user, buf, n, is_f64, op):
+            try:
+                import torch
+                import torch.distributed as dist
+                a = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_double if is_f64 else C.c_int64)), shape=(int(n),))
+                t = torch.from_numpy(a)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
+                self.calls += 1
+                return 0
+            except Exception:
+                return 1
+
+        self._fn = _lib.HOST_ALLREDUCE_FN(fn)     # (kept alive with the object)
+        h = C.c_void_p()
+        _lib.check(self.L.sbgpu_comm_init_host(ctx.h, self.rank, self.world, self._fn, None, C.byref(h)), "sbgpu_comm_init_host")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.L.sbgpu_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ShardQuantifier:
     """A rank's share of the quantification: EM -> FPKM/Frac -> all-reduce -> TPM.
 

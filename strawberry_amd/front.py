@@ -126,10 +126,11 @@ class FrontQuantifier(ChainQuantifier):
 
     STAGES = ("bam_decode", "assign_reads", "pair_mates", "collapse_pairs", "quantify")
 
-    def __init__(self, ctx, n_loci=60000, n_frags=2e8, seed=31, read_len=75, loci_subset=None):
+    def __init__(self, ctx, n_loci=60000, n_frags=2e8, seed=31, read_len=75, loci_subset=None, **resident_kw):
         """loci_subset = (rank, world): this rank's loci of ONE sample (locus l on rank l mod world, as the chain shards) --
-        its records only; the clusters, like the reference's, are the shard's own gene models."""
-        super().__init__(ctx, n_loci=n_loci, n_frags=n_frags, seed=seed, read_len=read_len, loci_subset=loci_subset, pin=True)
+        its records only; the clusters, like the reference's, are the shard's own gene models.  resident_kw: ChainQuantifier's
+        resident / empirical / comm / min_isoform_frac (the last stage is then sbgpu_quantify_resident: records -> TPM)."""
+        super().__init__(ctx, n_loci=n_loci, n_frags=n_frags, seed=seed, read_len=read_len, loci_subset=loci_subset, pin=True, **resident_kw)
         torch = self.torch
         t = time.perf_counter()
         self.d_bytes, self.d_rec_off = pack_bam_records(torch, self.sample, read_len)
@@ -195,9 +196,14 @@ class FrontQuantifier(ChainQuantifier):
         self.front_hit_off = np.ctypeslib.as_array(C.cast(hoff, C.POINTER(C.c_int64)), shape=(self.n_loci + 1,)).copy()
         L.sbgpu_matepairs_destroy(hm)
         h = C.c_void_p()
-        _lib.check(L.sbgpu_quantify_device(ctx.h, C.byref(self._an), C.byref(dh), d_mass, hoff, C.byref(self._ins), self.read_len, 0,
-                                           self.theta.ctypes.data, self.status.ctypes.data, self.iters.ctypes.data, C.byref(h)),
-                   "sbgpu_quantify_device")
+        if self.resident:
+            ui = (C.c_int64 * 8)()
+            _lib.check(L.sbgpu_uniq_dev_info(hu, ui), "sbgpu_uniq_dev_info")
+            self._resident_call(L, dh, d_mass, hoff, int(ui[4]), h)     # ui[4]: sum over the clusters of (int) weighted_mass()
+        else:
+            _lib.check(L.sbgpu_quantify_device(ctx.h, C.byref(self._an), C.byref(dh), d_mass, hoff, C.byref(self._ins), self.read_len, 0,
+                                               self.theta.ctypes.data, self.status.ctypes.data, self.iters.ctypes.data, C.byref(h)),
+                       "sbgpu_quantify_device")
         sync()
         ms["quantify"] = (time.perf_counter() - t4) * 1e3
         if not self.counts:
@@ -214,7 +220,8 @@ class FrontQuantifier(ChainQuantifier):
         self.stage_wall_ms = ms
 
     def chain_step(self):
-        """The same sample through the chain alone (its unique hits as DeviceSample made them): what step() must reproduce."""
+        """The same sample through the chain alone (its unique hits as DeviceSample made them): what step() must reproduce.
+        (In -i mode; an empirical law is the whole sample's, span-filtered pairs included, so the two laws may differ.)"""
         ChainQuantifier.step(self)
 
     def compare_with_chain(self):

@@ -162,3 +162,55 @@ def quantify_host(annot, hits, insert, read_len, long_read=False, ctx=None, devi
             "compat": compat[:hits.n_hits], "bins": bins, "F": F[:int(info[3])],
             "insert": {"mean": used.mean, "sd": used.sd, "use_emp": bool(used.use_emp), "start_offset": used.start_offset,
                        "end_offset": used.end_offset, "total_reads": used.total_reads, "emp_hist": emp}}
+
+
+def quantify_resident(annot, hits, insert, read_len, mapped_reads, long_read=False, ctx=None, device=0, comm=None,
+                      min_isoform_frac=0.0, filter_by_expression=True, effective_len_norm=False):
+    """sbgpu_quantify_resident on host hits brought to the device first (torch owns the copies): pass 1 (insert=None: the
+    empirical insert-size law, built on the device), bins, weights, EM, FPKM / Frac / keep, the FPKM all-reduce over `comm`
+    (dist.AbiComm / dist.HostComm; None: a world of one), TPM.  The hits must come grouped by locus.
+    -> dict(theta, fpkm, frac, tpm, keep, status, iters, insert, total_fpkm, total_mapped_reads, n_frag_lens, info)"""
+    import torch
+    ctx = ctx or default_context(device)
+    L = ctx.L
+    dev = torch.device("cuda", ctx.device)
+    if hits.n_hits > 1 and (np.diff(hits.hit_locus) < 0).any():
+        raise ValueError("quantify_resident: hits must be grouped by locus")
+    off = np.concatenate([[0], np.cumsum(np.bincount(hits.hit_locus, minlength=annot.n_loci))]).astype(np.int64)
+    up = lambda x, dt: torch.from_numpy(np.ascontiguousarray(x).view(dt)).to(dev)  # noqa: E731
+    d = {"hit_locus": up(hits.hit_locus, np.int32), "feat_off": up(hits.feat_off, np.int64), "feat_code": up(hits.feat_code, np.uint8),
+         "feat_left": up(hits.feat_left, np.int32), "feat_right": up(hits.feat_right, np.int32)}
+    d_mass = up(hits.mass, np.float32)
+    hs = _lib.sbgpu_hits_t()
+    hs.n_hits = hits.n_hits
+    for k, v in d.items():
+        setattr(hs, k, v.data_ptr())
+    a = annot._struct()
+    n_iso, nl = int(annot.iso_off[-1]), annot.n_loci
+    res = {k: np.zeros(n_iso + 1, np.float64) for k in ("theta", "fpkm", "frac", "tpm")}
+    res["keep"] = np.zeros(n_iso + 1, np.int32)
+    res["status"], res["iters"] = np.zeros(nl + 1, np.int32), np.zeros(nl + 1, np.int32)
+    out = _lib.sbgpu_abundances_t()
+    for k, v in res.items():
+        setattr(out, k, v.ctypes.data)
+    par = _lib.sbgpu_abundance_params_t(0, int(effective_len_norm), int(filter_by_expression), 0, 0.0, float(min_isoform_frac))
+    used = _lib.sbgpu_insert_t()
+    ins = insert._struct(read_len, long_read) if insert is not None else None
+    handle = C.c_void_p()
+    torch.cuda.synchronize(dev)
+    _lib.check(L.sbgpu_quantify_resident(ctx.h, C.byref(a), C.byref(hs), d_mass.data_ptr(), off.ctypes.data,
+                                         C.byref(ins) if ins is not None else None, int(read_len), int(long_read), int(mapped_reads),
+                                         C.byref(par), comm.h if comm is not None else None, C.byref(used), C.byref(out),
+                                         C.byref(handle)), "sbgpu_quantify_resident")
+    emp = None
+    if used.use_emp:
+        emp = np.ctypeslib.as_array(used.emp_hist, shape=(used.end_offset - used.start_offset + 1,)).copy()
+    info = (C.c_int64 * 8)()
+    _lib.check(L.sbgpu_bins_info(handle, info), "sbgpu_bins_info")
+    L.sbgpu_bins_destroy(handle)
+    r = {k: (v[:n_iso] if k not in ("status", "iters") else v[:nl]) for k, v in res.items()}
+    r.update({"insert": {"mean": used.mean, "sd": used.sd, "use_emp": bool(used.use_emp), "start_offset": used.start_offset,
+                         "end_offset": used.end_offset, "total_reads": used.total_reads, "emp_hist": emp},
+              "total_fpkm": float(out.total_fpkm), "total_mapped_reads": int(out.total_mapped_reads), "n_frag_lens": int(out.n_frag_lens),
+              "info": {"n_bins": int(info[2]), "n_elem": int(info[3]), "n_pairs": int(info[4])}})
+    return r
