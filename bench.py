@@ -187,7 +187,10 @@ def timed_steps(quant, steps, warmup, dev, sdist, torch):
 def chain_cpu_baseline(q, budget_frags=3.2e6):
     """The reference PROGRAM (oracle/_ref/strawberry_ref: Strawberry's own main, BAM decode, clustering, LocusContext,
     EmSolver, output -- compiled from /root/reference) on the first loci of the chain sample, one thread, timed on
-    this box's host; and the GPU chain's theta of those loci against the theta lines of its log (estimate.cpp:312).
+    this box's host, in the mode the GPU leg ran in: its DEFAULT mode (no -i: pass 1 builds the empirical insert-size law)
+    when the leg was empirical, else -i 250/30.  Parity: an empirical law is the law of the sample it was built from, so the
+    GPU side of the comparison is sbgpu_quantify_resident on the SAME first loci alone (their hits, their law, their mapped-read
+    total) -- theta against the theta lines of the program's log (estimate.cpp:312), FPKM and TPM against its GTF.
     The sample's hits are turned back into a coordinate-sorted BAM (our sam2bam) and a GTF of its gene models.
     -> (cpu_baseline dict, parity dict), or (None, None) where oracle/_ref is not built."""
     import re
@@ -209,8 +212,9 @@ def chain_cpu_baseline(q, budget_frags=3.2e6):
         # pair behind a unique hit gets its own two records (oracle/sam_writer.c)
         write_sam_from_hits(sam, h)
         subprocess.check_call([sam2bam, sam, bam], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        cmd = [ref_bin, bam, "-g", gtf, "-r", "-i", "250/30", "-o", os.path.join(tmp, "out.gtf"), "-T", os.path.join(tmp, "log.txt"),
-               "-f", os.path.join(tmp, "ctx.tsv")]
+        empirical = bool(getattr(q, "empirical", False))
+        cmd = [ref_bin, bam, "-g", gtf, "-r"] + ([] if empirical else ["-i", "250/30"]) + [
+            "-o", os.path.join(tmp, "out.gtf"), "-T", os.path.join(tmp, "log.txt"), "-f", os.path.join(tmp, "ctx.tsv")]
         t = time.perf_counter()
         r = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True)
         dt = time.perf_counter() - t
@@ -229,27 +233,60 @@ def chain_cpu_baseline(q, budget_frags=3.2e6):
             f = line.rstrip("\n").split("\t")
             if k and len(f) >= 10 and (not genes or genes[-1][0] != f[2]):
                 genes.append((f[2], f[4].split(",")))
+        ref_gtf = {}
+        for line in open(os.path.join(tmp, "out.gtf")):
+            f = line.rstrip("\n").split("\t")
+            if len(f) >= 9 and f[2] == "transcript":
+                t = re.search(r'transcript_id "([^"]+)"', f[8]).group(1)
+                ref_gtf[t] = tuple(float(re.search(r'%s "([^"]+)"' % k, f[8]).group(1)) for k in ("FPKM", "TPM"))
     n_pairs = int(h.mass.sum())
+    mode = "default mode: empirical insert-size law from pass 1" if empirical else "-i 250/30"
+    if getattr(q, "resident", False):
+        # the GPU side: the same first loci alone, resident entry (pass 1 on the device in default mode, FPKM / TPM on the device)
+        from strawberry_amd.quantify import quantify_resident
+        sub = quantify_resident(a.prefix(K), h, None if empirical else q.insert, q.read_len, n_pairs, ctx=q.ctx)
+        g_theta, g_status = sub["theta"], sub["status"]
+    else:
+        sub, g_theta, g_status = None, q.theta, q.status
     base = {"value": n_pairs / dt, "unit": "fragments/s", "cores": 1, "kind": "reference",
             "sample": "the first %d loci of the same sample (%d read pairs, %d unique hits) as a BAM + GTF through the reference program "
-                      "(strawberry_ref -g -r -i 250/30: two BAM passes, clustering, bins, weights, EM, output), 1 thread, %.2f s" % (K, n_pairs, h.n_hits, dt),
+                      "(strawberry_ref -g -r, %s: two BAM passes, clustering, bins, weights, EM, output), 1 thread, %.2f s" % (K, n_pairs, h.n_hits, mode, dt),
             "loci_per_s": K / dt}
-    worst, checked = 0.0, 0
+    worst, checked, worst_tpm, worst_fpkm, n_tpm = 0.0, 0, 0.0, 0.0, 0
     ok = len(genes) == len(thetas)
     for (gid, tx), th in zip(genes, thetas):
         l = int(gid[1:])
         for t, v in zip(tx, th):
             j = int(t.split(".")[1]) - 1
-            mine = float(q.theta[int(a.iso_off[l]) + j])
-            worst = max(worst, abs(mine - v) / max(abs(v), 1.0))
+            k = int(a.iso_off[l]) + j
+            worst = max(worst, abs(float(g_theta[k]) - v) / max(abs(v), 1.0))
             checked += 1
-        ok &= int(q.status[l]) in (0, 2, 3)
-    parity = {"against": "reference program's theta log (printed %f)", "loci_checked": len(genes), "isoforms_checked": checked,
+            if sub is not None and t in ref_gtf:      # FPKM / TPM as the program printed them (six decimals)
+                rf, rt = ref_gtf[t]
+                worst_fpkm = max(worst_fpkm, abs(float(sub["fpkm"][k]) - rf) / max(abs(rf), 1.0))
+                worst_tpm = max(worst_tpm, abs(float(sub["tpm"][k]) - rt) / max(abs(rt), 1.0))
+                n_tpm += 1
+        ok &= int(g_status[l]) in (0, 2, 3)
+    parity = {"against": "reference program's theta log (printed %f)" + (", its GTF's FPKM and TPM" if sub is not None else ""), "mode": mode,
+              "loci_checked": len(genes), "isoforms_checked": checked,
               "theta_max_err": worst, "tolerance": 2e-6, "ok": bool(ok and checked > 0 and worst < 2e-6)}
+    if sub is not None:
+        parity.update({"gpu_side": "sbgpu_quantify_resident on the same first loci alone (their own law and mapped-read total)",
+                       "transcripts_checked_in_gtf": n_tpm, "fpkm_max_rel_err": worst_fpkm, "tpm_max_rel_err": worst_tpm, "tpm_tolerance": 1e-4,
+                       "law": {k: v for k, v in sub["insert"].items() if k != "emp_hist"}, "mapped_reads": sub["total_mapped_reads"]})
+        parity["ok"] = bool(parity["ok"] and n_tpm > 0 and worst_tpm < 1e-4 and worst_fpkm < 1e-4)
     return base, parity
 
 
-def chain_leg(args, ctx, dev, rank, world, sdist, torch, strong=False, with_cpu=True):
+def resident_comm(ctx, rank, world, comm, sdist):
+    """The communicator sbgpu_quantify_resident exchanges over: the C ABI's RCCL one where bench.py made it, else (several ranks on
+    one device, SB_COMM=torch) the caller's exchange through torch.distributed (sbgpu_comm_init_host); None for one rank."""
+    if world == 1:
+        return None
+    return comm if comm is not None else sdist.HostComm(ctx, rank, world)
+
+
+def chain_leg(args, ctx, dev, rank, world, sdist, torch, strong=False, with_cpu=True, comm=None):
     """The fragments -> abundances chain (sbgpu_quantify_device) on the chain sample (strawberry_amd/chain.py): 60 000
     distinct gene models, ~2e8 read pairs resident in HBM.  Weak scaling: every rank its own sample; strong: ONE
     sample, locus l on rank l mod world (no locus data crosses ranks; the caller's FPKM total is the one collective).
@@ -258,7 +295,11 @@ def chain_leg(args, ctx, dev, rank, world, sdist, torch, strong=False, with_cpu=
     n_frags = float(os.environ.get("SB_CHAIN_FRAGS", "2e8"))
     n_loci = int(float(os.environ.get("SB_CHAIN_LOCI", "60000")))
     sub = (rank, world) if (strong and world > 1) else None
-    q = chain.ChainQuantifier(ctx, n_loci=n_loci, n_frags=n_frags, seed=31 + (0 if strong else rank), loci_subset=sub)
+    # the reference's DEFAULT mode end to end (SB_CHAIN_INSERT=given: -i 250/30): pass 1 on the device, the law and the mapped-read
+    # total all-reduced, bins, weights, EM, FPKM / Frac, the FPKM all-reduce, TPM -- sbgpu_quantify_resident, one call per step
+    empirical = os.environ.get("SB_CHAIN_INSERT", "empirical") != "given"
+    q = chain.ChainQuantifier(ctx, n_loci=n_loci, n_frags=n_frags, seed=31 + (0 if strong else rank), loci_subset=sub, resident=True,
+                              empirical=empirical, comm=resident_comm(ctx, rank, world, comm, sdist))
     wall, _ = timed_steps(q, args.steps, args.warmup, dev, sdist, torch)
     counts = torch.tensor([q.n_loci, q.n_frags, q.n_hits], dtype=torch.int64, device=dev)
     sdist.allreduce_sum_(counts)
@@ -288,6 +329,12 @@ def chain_leg(args, ctx, dev, rank, world, sdist, torch, strong=False, with_cpu=
                 "note": "kernel time from HIP events on the kernels' stream (sbgpu_last_stage_ms)"}
     out = {
         "workload": WORKLOADS["c3-chain"], "scaling": "strong" if strong else "weak",
+        "insert": "empirical" if empirical else "given (-i 250/30)", "tpm": True,
+        "law": {k: v for k, v in (q.law or {}).items() if k != "emp_hist"}, "total_mapped_reads": q.total_mapped_reads,
+        "tpm_sum_this_rank": float(q.tpm[:q.n_iso].sum()),
+        "collectives_per_step": ("none (one rank)" if world == 1 else
+                                 ("all-reduce(max) of the histogram's length + all-reduce(sum) of the fragment-length histogram with the mapped-read total"
+                                  if empirical else "all-reduce(sum) of the mapped-read total") + " + all-reduce(sum) of the FPKM total, inside sbgpu_quantify_resident"),
         "loci": int(counts[0]), "fragments": int(counts[1]), "unique_hits": int(counts[2]), "features_per_hit": feats,
         "ms_per_step": ms, "loci_per_s": int(counts[0]) * args.steps / wall, "gfrags_per_s": int(counts[1]) * args.steps / wall / 1e9,
         "kernel_ms": stage, "kernels_sum_ms": float(sum(stage.values())),
@@ -313,15 +360,17 @@ def chain_leg(args, ctx, dev, rank, world, sdist, torch, strong=False, with_cpu=
     return out
 
 
-def front_leg(args, ctx, dev, rank, world, sdist, torch):
-    """The records -> theta leg of the default line (strawberry_amd/front.py, `--workload c3-front` is its own line): the chain
-    sample's BAM alignment records resident in HBM -> decode -> read stream -> pairs -> unique hits -> chain -> theta.  N > 1:
-    ONE sample, locus l (its cluster and its records) on rank l mod N.  Every rank times its own steps -- the stages have no
-    collective -- and nothing in here is collective except ONE gather at the end, which every rank reaches whatever happened
-    to it before (a rank that could not run the leg hands in zeros): no rank can leave another waiting."""
+def front_leg(args, ctx, dev, rank, world, sdist, torch, comm=None):
+    """The records -> TPM leg of the default line (strawberry_amd/front.py, `--workload c3-front` is its own line): the chain
+    sample's BAM alignment records resident in HBM -> decode -> read stream -> pairs -> unique hits -> pass 1 (the empirical
+    insert-size law: the reference's default mode) -> bins -> weights -> EM -> FPKM -> TPM.  N > 1: ONE sample, locus l (its cluster
+    and its records) on rank l mod N; the law's histogram, the mapped-read total and the FPKM total are all-reduced inside the last
+    stage of every step.  The ranks agree beforehand that each of them holds its shard (a rank that could not make it hands in a
+    zero and nobody steps); the gather at the end is reached by every rank whatever happened to it."""
     from strawberry_amd import front
     stages = front.FrontQuantifier.STAGES
     vals, note, q = [0.0] * (5 + len(stages)), None, None
+    law, totals = None, (None, None, None)
     n_loci = int(float(os.environ.get("SB_FRONT_LOCI", "60000")))
     n_frags = float(os.environ.get("SB_FRONT_FRAGS", "2e8"))
     steps = max(1, min(args.steps, 5))
@@ -333,8 +382,18 @@ def front_leg(args, ctx, dev, rank, world, sdist, torch):
         if free < need:
             note = "skipped: %.0f GB free on the device, %.0f GB wanted" % (free / 1e9, need / 1e9)
         else:
-            q = front.FrontQuantifier(ctx, n_loci=n_loci, n_frags=n_frags, seed=31, loci_subset=(rank, world) if world > 1 else None)
+            q = front.FrontQuantifier(ctx, n_loci=n_loci, n_frags=n_frags, seed=31, loci_subset=(rank, world) if world > 1 else None,
+                                      resident=True, empirical=True, comm=resident_comm(ctx, rank, world, comm, sdist))
             torch.cuda.empty_cache()
+    except Exception as e:      # (memory, a launch that fails: the default line must come out all the same)
+        note = "failed: %r" % (e,)
+        q = None
+    # The steps are collective from here on (the law, the mapped-read total and the FPKM total are all ranks'): the ranks first
+    # agree that every one of them holds its shard -- a rank that could not make it must not leave the others in an all-reduce
+    ready = sdist.gather_values([1.0 if q is not None else 0.0], rank, world, device=dev)
+    all_ready = bool((ready[:, 0] > 0).all())
+    try:
+        if q is not None and all_ready:
             for _ in range(2):
                 q.step()
             torch.cuda.synchronize(dev)
@@ -344,9 +403,13 @@ def front_leg(args, ctx, dev, rank, world, sdist, torch):
             torch.cuda.synchronize(dev)
             ms = (time.perf_counter() - t0) / steps * 1e3
             st = dict(q.stage_wall_ms)
+            law = {k: v for k, v in q.law.items() if k != "emp_hist"}
+            totals = (q.total_mapped_reads, q.total_fpkm, float(q.tpm[:q.n_iso].sum()))
             ok = bool(q.compare_with_chain()["ok"])
             vals = [1.0, 1.0 if ok else 0.0, ms, float(q.n_loci), float(q.n_records)] + [float(st[k]) for k in stages]
-    except Exception as e:      # (memory, a launch that fails: the default line must come out all the same)
+        elif q is not None:
+            note = "skipped: another rank could not hold its shard"
+    except Exception as e:      # noqa: BLE001
         note = "failed: %r" % (e,)
     finally:
         try:
@@ -361,7 +424,7 @@ def front_leg(args, ctx, dev, rank, world, sdist, torch):
     if rank != 0:
         return None
     ran = [int(r) for r in range(world) if table[r][0] > 0]
-    out = {"workload": WORKLOADS["c3-front"], "scaling": "strong", "steps": steps, "ranks_that_ran": ran}
+    out = {"workload": WORKLOADS["c3-front"], "scaling": "strong", "steps": steps, "ranks_that_ran": ran, "insert": "empirical", "tpm": True}
     if note:
         out["note_rank0"] = note[:300]
     if len(ran) == world:
@@ -374,14 +437,16 @@ def front_leg(args, ctx, dev, rank, world, sdist, torch):
             "loci_per_rank": [int(x) for x in table[:, 3]], "records_per_rank": [int(x) for x in table[:, 4]],
             "per_rank_stage_ms": [dict(zip(stages, (float(x) for x in table[r][5:]))) for r in range(world)],
             "parity_with_chain": {"ranks_ok": int(table[:, 1].sum()), "ok": int(table[:, 1].sum()) == world},
-            "timing": "every rank its own K steps, synchronised on its own device only (the stages have no collective); the step is the slowest rank's",
+            "law": law, "total_mapped_reads": totals[0], "total_fpkm": totals[1], "tpm_sum_rank0": totals[2],
+            "timing": "every rank its own K steps; the last stage (sbgpu_quantify_resident) exchanges the law's histogram, the mapped-read total and "
+                      "the FPKM total with the other ranks inside the step; the step is the slowest rank's",
         })
     return out
 
 
-def chain_main(args, ctx, dev, rank, world, sdist, torch, launch):
+def chain_main(args, ctx, dev, rank, world, sdist, torch, launch, comm=None):
     """--workload c3-chain: the chain is the headline of the line."""
-    c = chain_leg(args, ctx, dev, rank, world, sdist, torch, strong=args.scaling == "strong")
+    c = chain_leg(args, ctx, dev, rank, world, sdist, torch, strong=args.scaling == "strong", comm=comm)
     if rank != 0:
         return
     out = {
@@ -400,7 +465,7 @@ def chain_main(args, ctx, dev, rank, world, sdist, torch, launch):
         raise SystemExit("bench.py: the chain's theta does not match the reference program's: %r" % c["parity"])
 
 
-def front_main(args, ctx, dev, rank, world, sdist, torch, launch):
+def front_main(args, ctx, dev, rank, world, sdist, torch, launch, comm=None):
     """--workload c3-front: alignment records in HBM -> theta, every stage of SURVEY 8(f) rank 4 in front of the chain
     (strawberry_amd/front.py).  A step = one pass over ALL records of the sample.  Size: SB_FRONT_LOCI / SB_FRONT_FRAGS
     (default: the chain sample, 60 000 loci / 2e8 read pairs = ~3.9e8 records, ~66 GB of record bytes)."""
@@ -409,7 +474,9 @@ def front_main(args, ctx, dev, rank, world, sdist, torch, launch):
     n_frags = float(os.environ.get("SB_FRONT_FRAGS", "2e8"))
     # N > 1: ONE sample, locus l (= cluster l) on rank l mod N with its records -- the stages work cluster by cluster, nothing
     # but the step's barrier couples the ranks (strong scaling, like c3-chain's)
-    q = front.FrontQuantifier(ctx, n_loci=n_loci, n_frags=n_frags, seed=31, loci_subset=(rank, world) if world > 1 else None)
+    q = front.FrontQuantifier(ctx, n_loci=n_loci, n_frags=n_frags, seed=31, loci_subset=(rank, world) if world > 1 else None,
+                              resident=True, empirical=os.environ.get("SB_CHAIN_INSERT", "empirical") != "given",
+                              comm=resident_comm(ctx, rank, world, comm, sdist))
     torch.cuda.empty_cache()      # the packer's temporaries go back to the driver: the library allocates for itself
     wall, _ = timed_steps(q, args.steps, args.warmup, dev, sdist, torch)
     ms = wall / args.steps * 1e3
@@ -429,6 +496,8 @@ def front_main(args, ctx, dev, rank, world, sdist, torch, launch):
             "grecords_per_s": recs * args.steps / wall / 1e9, "mfrags_per_s": frags * args.steps / wall / 1e6,
             "config": {"workload": WORKLOADS["c3-front"], "loci": int(loci), "read_pairs": int(frags), "records": int(recs),
                        "sharding": "locus l (its cluster and its records) on rank l mod N of ONE sample"},
+            "insert": "empirical" if q.empirical else "given (-i 250/30)", "tpm": True,
+            "law": {k: v for k, v in q.law.items() if k != "emp_hist"}, "total_mapped_reads": q.total_mapped_reads, "total_fpkm": q.total_fpkm,
             "launch": launch, "per_rank_ms": [p[0] for p in per_rank], "slowest_rank": int(np.argmax([p[0] for p in per_rank])),
             "loci_per_rank": [int(p[1]) for p in per_rank], "records_per_rank": [int(p[2]) for p in per_rank],
             "per_rank_stage_ms": [dict(zip(front.FrontQuantifier.STAGES, p[3:])) for p in per_rank],
@@ -491,6 +560,9 @@ def front_main(args, ctx, dev, rank, world, sdist, torch, launch):
                    "record_bytes": q.n_bytes, "bytes_per_record": q.n_bytes / max(n_rec, 1), "unique_hits": c["unique_hits"],
                    "records_packed_in_s": q.pack_s},
         "launch": launch, "stage_ms": stage, "stages_sum_ms": float(sum(stage.values())),
+        "insert": "empirical" if q.empirical else "given (-i 250/30)", "tpm": True,
+        "law": {k: v for k, v in q.law.items() if k != "emp_hist"}, "total_mapped_reads": q.total_mapped_reads, "total_fpkm": q.total_fpkm,
+        "tpm_sum": float(q.tpm[:q.n_iso].sum()),
         "chain_kernel_ms": chain_stage, "shape": q.info, "counts": c,
         "em_status": {"ok": int((q.status[:q.n_loci] == 0).sum()), "init_empty": int((q.status[:q.n_loci] == 1).sum()),
                       "denom_zero": int((q.status[:q.n_loci] == 2).sum()), "maxiter": int((q.status[:q.n_loci] == 3).sum()),
@@ -618,9 +690,9 @@ def main():
         launch["collective_note"] = comm_note
 
     if args.workload == "c3-chain":
-        return chain_main(args, ctx, dev, rank, world, sdist, torch, launch)
+        return chain_main(args, ctx, dev, rank, world, sdist, torch, launch, comm=comm)
     if args.workload == "c3-front":
-        return front_main(args, ctx, dev, rank, world, sdist, torch, launch)
+        return front_main(args, ctx, dev, rank, world, sdist, torch, launch, comm=comm)
 
     def make_quant(b, f32=False, solver=None):
         solver = solver or em.EmBatchSolver(b, ctx)
@@ -728,12 +800,12 @@ def main():
     chain_obj = None
     if args.workload == "c3" and not args.no_chain:
         res_keep = solver.results() if rank == 0 else None       # (the chain reuses the context's scratch; results first)
-        chain_obj = chain_leg(args, ctx, dev, rank, world, sdist, torch, strong=args.scaling == "strong")
+        chain_obj = chain_leg(args, ctx, dev, rank, world, sdist, torch, strong=args.scaling == "strong", comm=comm)
     front_obj = None
     if args.workload == "c3" and not args.no_front and not os.environ.get("SB_BENCH_NO_FRONT"):
         if chain_obj is None:
             res_keep = solver.results() if rank == 0 else None
-        front_obj = front_leg(args, ctx, dev, rank, world, sdist, torch)
+        front_obj = front_leg(args, ctx, dev, rank, world, sdist, torch, comm=comm)
     if rank != 0:
         return
     res = res_keep if (chain_obj is not None or front_obj is not None) else solver.results()

@@ -333,7 +333,8 @@ class ChainQuantifier:
         for _ in range(reps + 1):
             handle = C.c_void_p()
             t = time.perf_counter()
-            _lib.check(L.sbgpu_quantify_host(self.ctx.h, C.byref(a), C.byref(h), hits.mass.ctypes.data, C.byref(self._ins), self.read_len, 0,
+            _lib.check(L.sbgpu_quantify_host(self.ctx.h, C.byref(a), C.byref(h), hits.mass.ctypes.data,
+                                             None if self.empirical else C.byref(self._ins), self.read_len, 0,
                                              theta.ctypes.data, status.ctypes.data, iters.ctypes.data, None, C.byref(used),
                                              C.byref(handle)), "sbgpu_quantify_host")
             times.append(time.perf_counter() - t)

@@ -312,8 +312,8 @@ static int quantify_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbg
          fa.hit_locus = dh.hit_locus, fa.compat = d_compat, fa.span = d_span;
          fa.iso_off = dan.iso_off, fa.exon_off = dan.exon_off, fa.exon_left = dan.exon_left, fa.exon_right = dan.exon_right;
          fa.hist_len = hist_len, fa.hist = (unsigned long long *)d_hist;
-         const int64_t want = std::min<int64_t>((nh + 255) / 256, (int64_t)sb::ctx_cu_count(c) * 8);
-         hipLaunchKernelGGL(sb::fraglen_hist_kernel, dim3((unsigned)want), dim3(256), 0, s, fa);
+         const int64_t want = std::min<int64_t>((nh + sb::kFragLenThreads - 1) / sb::kFragLenThreads, (int64_t)sb::ctx_cu_count(c) * 2);
+         hipLaunchKernelGGL(sb::fraglen_hist_kernel, dim3((unsigned)want), dim3(sb::kFragLenThreads), 0, s, fa);
          SB_TRY(hipGetLastError());
       }
       sb::ctx_stage_end(c, s);

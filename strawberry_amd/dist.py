@@ -204,7 +204,13 @@ class HostComm:
                 import torch.distributed as dist
                 a = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_double if is_f64 else C.c_int64)), shape=(int(n),))
                 t = torch.from_numpy(a)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
+                red = dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM
+                if dist.get_backend() == "nccl":      # (RCCL reduces device buffers only)
+                    d = t.cuda()
+                    dist.all_reduce(d, op=red)
+                    t.copy_(d.cpu())
+                else:
+                    dist.all_reduce(t, op=red)
                 self.calls += 1
                 return 0
             except Exception:

@@ -52,6 +52,19 @@ class Annotation:
         self.compat_words = max(1, int(-(-np.diff(self.iso_off).max(initial=0) // 32)))
         self.key_words = max(1, int(-(-np.diff(self.seg_off).max(initial=0) // 32)))
 
+    def prefix(self, n_loci):
+        """The first n_loci loci as an annotation of their own (copies)."""
+        a = Annotation.__new__(Annotation)
+        a.n_loci = int(n_loci)
+        ni = int(self.iso_off[n_loci])
+        ne, ns = int(self.exon_off[ni]), int(self.seg_off[n_loci])
+        a.iso_off, a.exon_off, a.seg_off = self.iso_off[:n_loci + 1].copy(), self.exon_off[:ni + 1].copy(), self.seg_off[:n_loci + 1].copy()
+        a.exon_left, a.exon_right = self.exon_left[:ne].copy(), self.exon_right[:ne].copy()
+        a.seg_left, a.seg_right = self.seg_left[:ns].copy(), self.seg_right[:ns].copy()
+        a.compat_words = max(1, int(-(-np.diff(a.iso_off).max(initial=0) // 32)))
+        a.key_words = max(1, int(-(-np.diff(a.seg_off).max(initial=0) // 32)))
+        return a
+
     def segments(self, locus):
         s = slice(self.seg_off[locus], self.seg_off[locus + 1])
         return list(zip(self.seg_left[s].tolist(), self.seg_right[s].tolist()))

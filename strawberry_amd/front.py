@@ -229,19 +229,34 @@ class FrontQuantifier(ChainQuantifier):
         the reference's span filter (HitCluster::collapseAndFilterHits drops a pair whose mate's span is an outlier of its
         cluster's spans, alignments.cpp:666-682: a spliced mate in a cluster of thousands of unspliced ones), which the
         sample generator -- it draws unique hits directly -- does not: a locus that lost a pair to it is compared on its hit
-        count only, every other locus must agree bit for bit.  -> dict; the front's results are put back in place."""
-        front = (self.theta.copy(), self.status.copy(), self.iters.copy())
+        count only, every other locus must agree bit for bit.  Resident mode: the chain is given the law and the mapped-read
+        total the records -> TPM pass ended with (an empirical law is the WHOLE sample's, all ranks', the filtered pairs left out)
+        and runs without the exchange: theta, status, iterations, FPKM, Frac and keep are compared (TPM divides by all ranks'
+        FPKM total).  -> dict; the front's results are put back in place."""
+        names = ("theta", "status", "iters") + (("fpkm", "frac", "keep") if self.resident else ())
+        front = {k: getattr(self, k).copy() for k in names + (("tpm",) if self.resident else ())}
+        saved = None
+        if self.resident:
+            saved = (self.insert, self.empirical, self._ins, self.comm, self.mapped_override, dict(self.law), self.total_fpkm, self.total_mapped_reads)
+            if self.law["use_emp"]:
+                from .binweight import InsertSize
+                self.set_law(InsertSize.from_hist(self.law["start_offset"], self.law["emp_hist"]))
+            self.comm, self.mapped_override = None, self.total_mapped_reads
         self.chain_step()
         same_hits = np.diff(self.front_hit_off) == np.diff(self.hits.locus_hit_off)
         a = self.annot
         iso_same = np.repeat(same_hits, np.diff(a.iso_off))
-        ok = bool(np.array_equal(front[0][:self.n_iso][iso_same], self.theta[:self.n_iso][iso_same]) and
-                  np.array_equal(front[1][:self.n_loci][same_hits], self.status[:self.n_loci][same_hits]) and
-                  np.array_equal(front[2][:self.n_loci][same_hits], self.iters[:self.n_loci][same_hits]))
+        ok = True
+        for k in names:
+            n, m = (self.n_loci, same_hits) if k in ("status", "iters") else (self.n_iso, iso_same)
+            ok = ok and bool(np.array_equal(front[k][:n][m], getattr(self, k)[:n][m]))
         lost = int((np.diff(self.hits.locus_hit_off) - np.diff(self.front_hit_off)).sum())
-        out = {"loci_with_the_samples_hits": int(same_hits.sum()), "bitwise_equal_there": ok,
+        out = {"loci_with_the_samples_hits": int(same_hits.sum()), "bitwise_equal_there": ok, "compared": list(names),
                "loci_that_lost_pairs_to_the_span_filter": int((~same_hits).sum()), "unique_hits_lost_there": lost,
                "pairs_dropped_by_the_span_filter": self.counts.get("pairs_dropped_by_the_span_filter"),
                "ok": bool(ok and lost >= 0 and lost <= max(self.counts.get("pairs_dropped_by_the_span_filter", 0), 0))}
-        self.theta[:], self.status[:], self.iters[:] = front
+        for k, v in front.items():
+            getattr(self, k)[:] = v
+        if saved is not None:
+            self.insert, self.empirical, self._ins, self.comm, self.mapped_override, self.law, self.total_fpkm, self.total_mapped_reads = saved
         return out
