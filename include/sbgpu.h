@@ -543,7 +543,10 @@ int sbgpu_pair_mates_device(sbgpu_ctx_t *ctx, int64_t n_loci, const sbgpu_reads_
                             void *stream, sbgpu_matepairs_t **out);
 void sbgpu_matepairs_destroy(sbgpu_matepairs_t *m);
 /* info: 0 pairs (single reads included), 1 complete pairs, 2 single reads, 3 records refused, 4 records that never
- * found their mate, 5 features of the left mates, 6 of the right mates, 7: 1 when the arrays live on the device. */
+ * found their mate, 5 features of the left mates, 6 of the right mates, 7: 0 host arrays; else bit 0 set (the arrays live on
+ * the device), bit 1: the positional matching served the call (no sort: the records of every cluster ascend by position and
+ * no read id is aligned twice in a cluster), else bits 2.. say why the sorted form did: 1 records not in position order,
+ * 2 a read id with more than one fitting mate (0: SBGPU_PAIR_FORCE_SORT).                                                */
 int sbgpu_matepairs_info(const sbgpu_matepairs_t *m, int64_t info[8]);
 /* The pairs where they are (host or device arrays, see info[7]) + locus_pair_off [n_loci + 1] (host): the arguments
  * of sbgpu_collapse_pairs_host / _device.  pair_locus is set for the host form only.  Owned by the handle.      */

@@ -37,6 +37,8 @@ struct sbgpu_matepairs {
    int64_t *d_left_off = nullptr, *d_right_off = nullptr;
    uint8_t *d_left_code = nullptr, *d_right_code = nullptr;
    uint32_t *d_left_left = nullptr, *d_left_right = nullptr, *d_right_left = nullptr, *d_right_right = nullptr;
+   bool positional = false;  // device form: the positional matching served the call (no sort)
+   uint32_t why_sorted = 0;  // else: sb::kPosUnsorted | kPosConflict (0: forced)
 };
 
 namespace {
@@ -82,11 +84,11 @@ static int pair_mates_flat(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t *
          break;
       }
    }
-   size_t tmp_bytes = 0;
+   size_t tmp_bytes = 0, sort_tmp_bytes = 0;
    {
       size_t b = 0;
       (void)rocprim::radix_sort_pairs(nullptr, b, (const uint32_t *)nullptr, (uint32_t *)nullptr, rocprim::counting_iterator<int32_t>(0), (int32_t *)nullptr, n, 0, sort_bits, s);
-      tmp_bytes = std::max(tmp_bytes, b);
+      sort_tmp_bytes = b;
       (void)rocprim::exclusive_scan(nullptr, b, rocprim::make_transform_iterator((const int32_t *)nullptr, [] __device__(int32_t v) { return (int64_t)v; }), (int64_t *)nullptr, (int64_t)0, nt1, rocprim::plus<int64_t>(), s);
       tmp_bytes = std::max(tmp_bytes, b);
    }
@@ -96,12 +98,12 @@ static int pair_mates_flat(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t *
       off += up256(bytes ? bytes : 8);
       return o;
    };
-   const size_t o_roff = take(nl1 * 8), o_key = take(n * 4), o_skey = take(n * 4), o_order = take(n * 4), o_rec = take(n * sizeof(sb::FlatRec));
-   const size_t o_rarr = take(n * sizeof(sb::FlatRec));
-   const size_t o_state = take(n), o_done = take(n * 8), o_td = take(nt1 * 4), o_tda = take(nt1 * 8), o_prec = take(n * 4), o_pval = take(n * 4);
-   const size_t o_lf = take(n1 * 4), o_rf = take(n1 * 4), o_tl = take(nt1 * 4), o_tr = take(nt1 * 4), o_ls = take(nt1 * 8), o_rs = take(nt1 * 8), o_poff = take(nl1 * 8), o_counts = take(64 * 64), o_tmp = take(tmp_bytes);
+   // what both forms use
+   const size_t o_roff = take(nl1 * 8), o_rarr = take(n * sizeof(sb::FlatRec)), o_lefts = take(n * 4), o_claim = take(n * 4), o_slot = take(n * 8), o_runlen = take(n * 4);
+   const size_t o_done = take(n * 8), o_td = take(nt1 * 4), o_tda = take(nt1 * 8), o_prec = take(n * 4), o_pval = take(n * 4);
+   const size_t o_lf = take(n1 * 4), o_rf = take(n1 * 4), o_tl = take(nt1 * 4), o_tr = take(nt1 * 4), o_ls = take(nt1 * 8), o_rs = take(nt1 * 8), o_poff = take(nl1 * 8), o_counts = take(64 * 64 + 256), o_tmp = take(tmp_bytes);
    SB_TRY(sb::dev_take(off, &w, &w_cap));
-   SB_TRY(hipMemsetAsync(w + o_counts, 0, 64 * 64, s));
+   SB_TRY(hipMemsetAsync(w + o_counts, 0, 64 * 64 + 256, s));
    SB_TRY(hipMemsetAsync(w + o_td + ((n + 63) / 64) * 4, 0, 4, s)); // (the scans' entry beyond the last tile)
    SB_TRY(hipMemsetAsync(w + o_tl + nt * 4, 0, 4, s));
    SB_TRY(hipMemsetAsync(w + o_tr + nt * 4, 0, 4, s));
@@ -117,13 +119,10 @@ static int pair_mates_flat(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t *
    a.flags = dr->flags;
    a.nh = dr->nh;
    f.n_reads = nr;
-   f.key = (uint32_t *)(w + o_key);
-   f.skey = (const uint32_t *)(w + o_skey);
    f.hash_bits = (int)hash_bits, f.group_shift = (int)group_shift;
-   f.order = (const int32_t *)(w + o_order);
-   f.rec = (sb::FlatRec *)(w + o_rec);
    f.rec_arr = (sb::FlatRec *)(w + o_rarr);
-   f.state = (uint8_t *)(w + o_state);
+   f.lefts = (uint32_t *)(w + o_lefts), f.claim = (uint32_t *)(w + o_claim);
+   f.slot = (uint32_t *)(w + o_slot), f.runlen = (uint32_t *)(w + o_runlen);
    f.done = (unsigned long long *)(w + o_done);
    f.tile_done = (int32_t *)(w + o_td), f.tile_done_at = (const int64_t *)(w + o_tda);
    f.pair_rec_w = (uint32_t *)(w + o_prec), f.pair_val_w = (uint32_t *)(w + o_pval);
@@ -133,32 +132,87 @@ static int pair_mates_flat(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t *
    f.lscan = (const int64_t *)(w + o_ls), f.rscan = (const int64_t *)(w + o_rs);
    f.locus_pair_off = (int64_t *)(w + o_poff);
    f.counts = (unsigned long long *)(w + o_counts);
+   f.trouble = (uint32_t *)(w + o_counts + 64 * 64);
    const unsigned gr = (unsigned)((n + 255) / 256), gr1 = (unsigned)((std::max(n1, nl1) + 255) / 256);
    void *tmp = w + o_tmp;
    size_t tb = tmp_bytes;
-   hipLaunchKernelGGL(sb::flat_mate_keys_kernel, dim3(gr), dim3(256), 0, s, f);
-   SB_TRY(hipGetLastError());
-   SB_TRY(rocprim::radix_sort_pairs(tmp, tb, (const uint32_t *)f.key, (uint32_t *)(w + o_skey), rocprim::counting_iterator<int32_t>(0), (int32_t *)(w + o_order), n, 0, sort_bits, s));
-   hipLaunchKernelGGL(sb::flat_mate_pack_kernel, dim3(gr), dim3(256), 0, s, f);
-   hipLaunchKernelGGL(sb::flat_mate_walk_kernel, dim3(gr), dim3(256), 0, s, f);
-   SB_TRY(hipGetLastError());
-   hipLaunchKernelGGL(sb::flat_mate_done_tiles_kernel, dim3(gr), dim3(256), 0, s, f);
-   tb = tmp_bytes;
-   SB_TRY(rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator((const int32_t *)f.tile_done, [] __device__(int32_t v) { return (int64_t)v; }), (int64_t *)(w + o_tda), (int64_t)0, (n + 63) / 64 + 1, rocprim::plus<int64_t>(), s));
-   hipLaunchKernelGGL(sb::flat_mate_order_kernel, dim3(gr), dim3(256), 0, s, f);
-   hipLaunchKernelGGL(sb::flat_mate_count_kernel, dim3(sb::xcd_grid(gr1)), dim3(256), 0, s, f);
-   SB_TRY(hipGetLastError());
-   tb = tmp_bytes;
-   SB_TRY(rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator((const int32_t *)f.tile_l, [] __device__(int32_t v) { return (int64_t)v; }), (int64_t *)(w + o_ls), (int64_t)0, nt1, rocprim::plus<int64_t>(), s));
-   tb = tmp_bytes;
-   SB_TRY(rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator((const int32_t *)f.tile_r, [] __device__(int32_t v) { return (int64_t)v; }), (int64_t *)(w + o_rs), (int64_t)0, nt1, rocprim::plus<int64_t>(), s));
    unsigned long long slots[64 * 8], counts[4] = {0, 0, 0, 0};
    int64_t totals[2] = {0, 0};
-   SB_TRY(hipMemcpyAsync(slots, w + o_counts, sizeof(slots), hipMemcpyDeviceToHost, s));
-   SB_TRY(hipMemcpyAsync(&totals[0], w + o_ls + nt * 8, 8, hipMemcpyDeviceToHost, s));
-   SB_TRY(hipMemcpyAsync(&totals[1], w + o_rs + nt * 8, 8, hipMemcpyDeviceToHost, s));
-   SB_TRY(hipMemcpyAsync(M->locus_pair_off.data(), w + o_poff, nl1 * 8, hipMemcpyDeviceToHost, s));
-   SB_TRY(hipStreamSynchronize(s));
+   uint32_t trouble = 0;
+   // what follows the matching, whichever form made it: the pairs in the order their completing records arrive, the mates'
+   // feature counts, where every pair's features go; the totals come back with one synchronisation
+   auto rank_and_count = [&]() -> int {
+      hipLaunchKernelGGL(sb::flat_mate_done_tiles_kernel, dim3(gr), dim3(256), 0, s, f);
+      tb = tmp_bytes;
+      SB_TRY(rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator((const int32_t *)f.tile_done, [] __device__(int32_t v) { return (int64_t)v; }), (int64_t *)(w + o_tda), (int64_t)0, (n + 63) / 64 + 1, rocprim::plus<int64_t>(), s));
+      hipLaunchKernelGGL(sb::flat_mate_order_kernel, dim3(gr), dim3(256), 0, s, f);
+      hipLaunchKernelGGL(sb::flat_mate_count_kernel, dim3(sb::xcd_grid(gr1)), dim3(256), 0, s, f);
+      SB_TRY(hipGetLastError());
+      tb = tmp_bytes;
+      SB_TRY(rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator((const int32_t *)f.tile_l, [] __device__(int32_t v) { return (int64_t)v; }), (int64_t *)(w + o_ls), (int64_t)0, nt1, rocprim::plus<int64_t>(), s));
+      tb = tmp_bytes;
+      SB_TRY(rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator((const int32_t *)f.tile_r, [] __device__(int32_t v) { return (int64_t)v; }), (int64_t *)(w + o_rs), (int64_t)0, nt1, rocprim::plus<int64_t>(), s));
+      SB_TRY(hipMemcpyAsync(slots, w + o_counts, sizeof(slots), hipMemcpyDeviceToHost, s));
+      SB_TRY(hipMemcpyAsync(&trouble, w + o_counts + 64 * 64, 4, hipMemcpyDeviceToHost, s));
+      SB_TRY(hipMemcpyAsync(&totals[0], w + o_ls + nt * 8, 8, hipMemcpyDeviceToHost, s));
+      SB_TRY(hipMemcpyAsync(&totals[1], w + o_rs + nt * 8, 8, hipMemcpyDeviceToHost, s));
+      SB_TRY(hipMemcpyAsync(M->locus_pair_off.data(), w + o_poff, nl1 * 8, hipMemcpyDeviceToHost, s));
+      SB_TRY(hipStreamSynchronize(s));
+      return SBGPU_OK;
+   };
+   // ---- the positional form (matepair_flat.h): no sort.  Its kernels say when they cannot serve the call (records that do
+   // not ascend by position inside a cluster, a read id with several fitting mates); the ranking behind them has run by then -- it costs the call one more pass, in the rare case.
+   // SBGPU_PAIR_FORCE_SORT=1 (tests): every call takes the sorted form.
+   const char *force_env = std::getenv("SBGPU_PAIR_FORCE_SORT");
+   bool sorted_form = force_env && std::atoi(force_env) != 0;
+   if (!sorted_form) {
+      SB_TRY(hipMemsetAsync(w + o_slot, 0, n * 8, s));
+      hipLaunchKernelGGL(sb::flat_mate_rec_kernel, dim3(sb::xcd_grid(gr)), dim3(256), 0, s, f);
+      hipLaunchKernelGGL(sb::flat_mate_match_kernel, dim3(sb::xcd_grid(gr)), dim3(256), 0, s, f);
+      SB_TRY(hipGetLastError());
+      if (const int rc = rank_and_count(); rc != SBGPU_OK) return rc;
+      sorted_form = trouble != 0;
+   }
+   M->positional = !sorted_form;
+   M->why_sorted = trouble;
+   if (sorted_form) {
+      // ---- the sorted form: ONE stable radix sort brings the records of a read id together in arrival order, a walk pairs them
+      // with the reference's chain rules (any number of waiting mates per read id)
+      char *w2 = nullptr;
+      size_t w2_cap = 0, off2 = 0;
+      auto take2 = [&](size_t bytes) {
+         const size_t o = off2;
+         off2 += up256(bytes ? bytes : 8);
+         return o;
+      };
+      const size_t o_key = take2(n * 4), o_skey = take2(n * 4), o_order = take2(n * 4), o_rec = take2(n * sizeof(sb::FlatRec)), o_state = take2(n), o_stmp = take2(sort_tmp_bytes);
+      SB_TRY(sb::dev_take(off2, &w2, &w2_cap));
+      struct Give {
+         char *&p;
+         size_t &cap;
+         hipStream_t s;
+         ~Give()
+         {
+            (void)hipStreamSynchronize(s);
+            sb::dev_give(p, cap);
+         }
+      } give2 = {w2, w2_cap, s};
+      f.key = (uint32_t *)(w2 + o_key);
+      f.skey = (const uint32_t *)(w2 + o_skey);
+      f.order = (const int32_t *)(w2 + o_order);
+      f.rec = (sb::FlatRec *)(w2 + o_rec);
+      f.state = (uint8_t *)(w2 + o_state);
+      f.claim = nullptr;
+      SB_TRY(hipMemsetAsync(w + o_counts, 0, 64 * 64 + 256, s));
+      hipLaunchKernelGGL(sb::flat_mate_keys_kernel, dim3(gr), dim3(256), 0, s, f); // (also: the records as the rules see them, `done` zeroed)
+      SB_TRY(hipGetLastError());
+      size_t stb = sort_tmp_bytes;
+      SB_TRY(rocprim::radix_sort_pairs(w2 + o_stmp, stb, (const uint32_t *)f.key, (uint32_t *)(w2 + o_skey), rocprim::counting_iterator<int32_t>(0), (int32_t *)(w2 + o_order), n, 0, sort_bits, s));
+      hipLaunchKernelGGL(sb::flat_mate_pack_kernel, dim3(gr), dim3(256), 0, s, f);
+      hipLaunchKernelGGL(sb::flat_mate_walk_kernel, dim3(gr), dim3(256), 0, s, f);
+      SB_TRY(hipGetLastError());
+      if (const int rc = rank_and_count(); rc != SBGPU_OK) return rc;
+   }
    for (int k = 0; k < 64; ++k)
       for (int i = 0; i < 4; ++i) counts[i] += slots[k * 8 + i]; // (wrapping sums: a slot's orphan count may be "negative")
    M->n_refused = (int64_t)counts[0], M->n_orphan = (int64_t)counts[1], M->n_single = (int64_t)counts[2], M->n_complete = (int64_t)counts[3];
@@ -651,7 +705,7 @@ int sbgpu_matepairs_info(const sbgpu_matepairs_t *m, int64_t info[8])
    info[4] = m->n_orphan;
    info[5] = m->n_lfeat;
    info[6] = m->n_rfeat;
-   info[7] = m->on_device ? 1 : 0;
+   info[7] = m->on_device ? (1 | (m->positional ? 2 : 0) | ((int64_t)m->why_sorted << 2)) : 0;
    return SBGPU_OK;
 }
 

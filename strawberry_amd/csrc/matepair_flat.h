@@ -63,7 +63,14 @@ struct FlatMateArgs {
                                     // fill adds the part inside its wave
    int64_t *locus_pair_off;         // [n_loci + 1]
    unsigned long long *counts;      // 64 slots of 8 words (a cache line each): [0] refused [1] orphan [2] single [3] complete
+   // the positional form (flat_mate_match_kernel): no sort at all where the records come sorted by position
+   uint32_t *lefts;                 // per record, arrival order: its first block's left end (what the search looks at)
+   uint32_t *claim;                 // per record: 1 + the arrival index of the record that completes it (nullptr in the sorted form)
+   uint32_t *slot;                  // TWO per record, zeroed: the runs as hash tables of their openers (1 + arrival index)
+   uint32_t *runlen;                // per record, written at the runs' first records: the run's length
+   uint32_t *trouble;               // [1], zeroed: kPosUnsorted | kPosConflict -- the call is then served by the sorted form
 };
+enum : uint32_t { kPosUnsorted = 1u, kPosConflict = 2u };
 
 __device__ __forceinline__ uint32_t flat_hash32(uint64_t x)
 {
@@ -105,6 +112,299 @@ __global__ __launch_bounds__(256) void flat_mate_keys_kernel(FlatMateArgs f)
    q.misc = (uint32_t)a.flags[r] | (b1 > b0 ? 256u : 0u) | ((uint32_t)lo << 9);
    f.rec_arr[r] = q;
    f.done[r] = 0ull;
+}
+
+// ---- The positional form (round 6).  The reference's match rule is positional (src/alignments.cpp:612-615: a waiting mate fits
+// when it.left_pos() == hit_partner_pos && expected_pos == hit->left(), same read id, strands agree), the records of a cluster
+// arrive sorted by position, and a record's mate position says where its partner lies: a record whose mate lies BEFORE it
+// (partner_pos < left: the closing mate of a properly oriented pair) finds the records that start at partner_pos by a search
+// in its own cluster's records and looks for its read id among them.  No record has to be moved: the sort that brought the
+// records of a read id together (one radix sort over all records, a gather into sorted order, a walk: 26 of the stage's 47 ms at
+// 3.9e8 records) is not needed.
+//
+// Exactness.  Call x and y RELATED when they are records of one cluster and one read id, eligible for pairing, x before y in
+// arrival order, x.left == y.partner_pos, x.partner_pos == y.left and their strands agree -- the reference's test.  addOpenHit
+// pairs y with the OLDEST waiting record related to it (:593-641); when every record is related to at most one other, the
+// relation IS the reference's result, whatever else the read id's chain holds: x had nobody to complete when it arrived
+// (its only relation arrives later), so it waits; y finds it, first fit or not, because nothing else in the chain fits.  A
+// record with two relations -- a closing mate that finds two fitting openers, an opener two closers fit: reads aligned more
+// than once in a cluster, --allow-multimapped-hits -- makes the outcome depend on the chain's order; the kernel then raises
+// kPosConflict and the whole call is served by the sorted form below, which walks the chains in arrival order.  So is a call
+// whose records do not ascend by left end inside a cluster (kPosUnsorted: the search would not be a search).  A record whose
+// mate position is its own left end never waits and never completes (:585, :640 -- neither does anything related to it).
+__device__ __forceinline__ bool flat_mate_eligible(const FlatRec &q) // offered to addOpenHit, not refused, not a single read
+{
+   const uint32_t fl = q.misc & 255u;
+   return !(fl & 16u) && (q.misc & 256u) && (int64_t)q.right - (int64_t)q.left <= kMaxFragSpanDev && q.ppos != 0 && !(fl & 2u);
+}
+
+// The records that start at one position of one cluster are a RUN of the arrival order [start, end).  Looking through a run for
+// a read id costs its length, and a sample's deep positions hold thousands of records (every closing mate looking through all
+// of them: 58 ms at 3.9e8 records, the sort it was to replace took 26).  So the run doubles as a hash table: `slot[2 start + k]`,
+// k = hash(read id) mod twice the run's length (two slots per record: a run of openers alone -- thousands of copies of one
+// fragment -- is then half full), linear probing inside the run -- an opener (a record that waits: its partner lies behind it)
+// puts its arrival index there, a closing mate probes from the same k until it meets an empty slot.  Everything a thread touches
+// lies inside the run.
+//
+// Where a run begins and ends: a record is a HEAD when it is its cluster's first or starts elsewhere than the record before it;
+// a wave's ballot of heads answers for the runs that begin / end inside the wave's 64 records, a search for the others (in the
+// call's own arrays: `lefts` is being written by this very launch).
+__device__ __forceinline__ uint32_t flat_left_of(const MateArgs &a, int64_t r)
+{
+   const int64_t b = a.block_off[r];
+   return b < a.block_off[r + 1] ? a.block_left[b] : 0u; // (a record without blocks: such a call is kPosUnsorted anyway)
+}
+
+// ONE pass over the records in arrival order: the record as the rules see it, its left end for the searches, the heads, the
+// openers into their runs' tables (`slot` zeroed by the caller), the runs' lengths at their heads; kPosUnsorted where the
+// left ends of a cluster do not ascend or a record has no blocks.
+__global__ __launch_bounds__(256) void flat_mate_rec_kernel(FlatMateArgs f)
+{
+   const int64_t r = xcd_tile() * 256 + threadIdx.x; // (XCD-aware tile order: a run's slots stay in ONE L2, the closing mates' too)
+   const int lane = (int)(threadIdx.x & 63u);
+   const int64_t r0 = r - lane;
+   if (r0 >= f.n_reads) return; // (the whole wave)
+   const int64_t lo = wave_range_of(f.a.locus_read_off, f.a.n_loci, r0, f.n_reads); // last cluster whose records begin at or before r
+   const MateArgs &a = f.a;
+   const bool in = r < f.n_reads;
+   bool blocks = false;
+   FlatRec q = {};
+   if (in) {
+      const uint64_t rid = a.read_id[r];
+      const int64_t b0 = a.block_off[r], b1 = a.block_off[r + 1];
+      blocks = b1 > b0;
+      q.rid_lo = (uint32_t)rid, q.rid_hi = (uint32_t)(rid >> 32);
+      q.left = blocks ? a.block_left[b0] : 0u;
+      q.right = blocks ? a.block_right[b1 - 1] : 0u;
+      q.ppos = a.partner_pos[r];
+      q.misc = (uint32_t)a.flags[r] | (blocks ? 256u : 0u) | ((uint32_t)lo << 9);
+      f.rec_arr[r] = q;
+      f.lefts[r] = q.left;
+   }
+   // against the record before (the wave's first lane: a load): heads, and the order the searches need
+   uint32_t prev_left = (uint32_t)__shfl_up((int)q.left, 1);
+   int64_t prev_lo = __shfl_up(lo, 1);
+   bool prev_blocks = __shfl_up((int)blocks, 1) != 0;
+   if (lane == 0 && r > 0) {
+      const int64_t p0 = a.block_off[r - 1], p1 = a.block_off[r];
+      prev_blocks = p1 > p0;
+      prev_left = prev_blocks ? a.block_left[p0] : 0u;
+      prev_lo = a.locus_read_off[lo] == r ? lo - 1 : lo; // (the record before a cluster's first belongs to another cluster)
+   }
+   const bool bad = in && (!blocks || (r > 0 && prev_lo == lo && (!prev_blocks || prev_left > q.left)));
+   if (__ballot(bad) && lane == 0) atomicOr(f.trouble, kPosUnsorted);
+   const bool head = in && (r == 0 || prev_lo != lo || prev_left != q.left);
+   const unsigned long long heads = __ballot(head);
+   const bool opener = in && flat_mate_eligible(q) && q.ppos > q.left;
+   if (!head && !opener) return;
+   const int64_t c0 = a.locus_read_off[lo], c1 = a.locus_read_off[lo + 1];
+   // the run's end: the next head behind this record -- in the wave, or where the left ends first exceed this one
+   int64_t end;
+   const unsigned long long above = lane < 63 ? heads & (~0ull << (lane + 1)) : 0ull;
+   if (above) {
+      end = r0 + (__ffsll((long long)above) - 1);
+   } else {
+      int64_t at = min(r0 + 63, f.n_reads - 1); // the wave's last record: of this run (no head behind this lane)
+      if (at + 1 >= c1) end = c1;
+      else {
+         int64_t step = 64;
+         while (at + step < c1 && flat_left_of(a, at + step) == q.left) at += step, step <<= 1;
+         int64_t hi = min(at + step, c1); // not of the run (or the cluster's end)
+         while (hi - at > 1) {
+            const int64_t mid = (at + hi) >> 1;
+            if (flat_left_of(a, mid) == q.left) at = mid;
+            else hi = mid;
+         }
+         end = hi;
+      }
+   }
+   if (head) f.runlen[r] = (uint32_t)(end - r);
+   if (!opener) return;
+   // the run's start: the last head at or before this record
+   int64_t start;
+   const unsigned long long upto = heads & (lane < 63 ? ((1ull << (lane + 1)) - 1ull) : ~0ull);
+   if (upto) {
+      start = r0 + (63 - __clzll((long long)upto));
+   } else {
+      int64_t hi = r0, step = 64; // r0 is of the run (no head up to this lane); the first such index >= c0
+      int64_t lo2 = hi - step;
+      while (lo2 >= c0 && flat_left_of(a, lo2) == q.left) hi = lo2, step <<= 1, lo2 = hi - step;
+      if (lo2 < c0) lo2 = c0 - 1; // (a virtual record before the cluster's first: not of the run)
+      while (hi - lo2 > 1) {      // lo2: not of the run; hi: of the run
+         const int64_t mid = (lo2 + hi) >> 1;
+         if (flat_left_of(a, mid) == q.left) hi = mid;
+         else lo2 = mid;
+      }
+      start = hi;
+   }
+   const uint32_t len = 2u * (uint32_t)(end - start);
+   const uint64_t rid = ((uint64_t)q.rid_hi << 32) | q.rid_lo;
+   int64_t at = 2 * start + (int64_t)(flat_hash32(rid) % len);
+   for (uint32_t tries = 0; tries < len; ++tries) {
+      if (atomicCAS(&f.slot[at], 0u, (uint32_t)r + 1u) == 0u) break;
+      if (++at == 2 * end) at = 2 * start;
+   }
+}
+
+// lower_bound of `want` in lefts[lo0 .. hi0) (ascending), a lane by itself: gallop back from hi0, then bisect
+__device__ __forceinline__ int64_t flat_lower_bound_back(const uint32_t *__restrict__ lefts, int64_t lo0, int64_t hi0, uint32_t want)
+{
+   int64_t hi = hi0, step = 64; // lefts[hi] >= want (or hi == hi0)
+   int64_t lo = hi0 - step;
+   while (lo > lo0 && lefts[lo] >= want) {
+      hi = lo;
+      step <<= 1;
+      lo = hi0 - step;
+   }
+   if (lo < lo0) lo = lo0;
+   if (lo >= hi) return hi;
+   if (lefts[lo] >= want) return lo; // (the range's first element)
+   while (hi - lo > 1) {             // lefts[lo] < want <= lefts[hi]
+      const int64_t mid = (lo + hi) >> 1;
+      if (lefts[mid] < want) lo = mid;
+      else hi = mid;
+   }
+   return hi;
+}
+
+__global__ __launch_bounds__(256) void flat_mate_match_kernel(FlatMateArgs f)
+{
+   const int64_t r = xcd_tile() * 256 + threadIdx.x; // (XCD-aware tile order, as the openers': the probes hit the L2 that holds the run)
+   const int lane = (int)(threadIdx.x & 63u);
+   const int64_t r0 = r - lane;
+   int refused = 0, orphan = 0, single = 0, complete = 0;
+   bool conflict = false;
+   FlatRec q = {};
+   int kind = 0; // 1: a closing mate (its partner lies before it): it searches
+   unsigned long long done = 0ull; // what this record completes (written for EVERY record: nobody zeroed the array)
+   if (r < f.n_reads) {
+      q = f.rec_arr[r];
+      const uint32_t fl = q.misc & 255u;
+      if (fl & 16u) { // not this cluster's record (sbgpu_assign_reads_*): never offered to addOpenHit
+      } else if (!(q.misc & 256u) || (int64_t)q.right - (int64_t)q.left > kMaxFragSpanDev) { // :512-518
+         ++refused;
+      } else if (q.ppos == 0 || (fl & 2u)) { // a single read (:535-545)
+         done = (1ull << 32) | ((fl & 1u) ? 0x80000000u : 0u) | 0x7FFFFFFFu;
+         ++single;
+      } else if (q.ppos > q.left) { // its partner lies behind it: it waits (whoever completes it takes it off the orphans' count)
+         ++orphan;
+      } else if (q.ppos == q.left) { // :585, :640
+         ++refused;
+      } else {
+         kind = 1;
+      }
+   }
+   // ---- where the records that start at partner_pos begin.  A wave's closing mates are neighbours: their partners lie in ONE
+   // stretch of the cluster's records, a few hundred to a few thousand records back.  The wave finds that stretch's beginning
+   // 64 ways at a time (two or three coalesced loads), every lane then bisects inside it -- ten steps that stay in the
+   // vector cache -- where a lane by itself galloped and bisected through sixteen dependent loads from further away.
+   const unsigned long long closers = __ballot(kind == 1);
+   if (closers) {
+      const uint32_t cl = q.misc >> 9;
+      const uint32_t cl0 = (uint32_t)__builtin_amdgcn_readlane((int)cl, __ffsll((long long)closers) - 1);
+      const bool together = __ballot(kind == 1 && cl != cl0) == 0ull; // (the closing mates of the wave share a cluster)
+      int64_t hi = -1; // lower_bound of q.ppos in this cluster's records before r
+      if (together) {
+         const int64_t c0 = f.a.locus_read_off[cl0];
+         const uint32_t pmin = wave_min_u32(kind == 1 ? q.ppos : 0xFFFFFFFFu);
+         // "below": a record that starts before pmin (the record before the cluster's first: virtually).  a_lo = the last record
+         // before the wave that is below; every closing mate's answer lies behind it.
+         // coarse: probes at strides of 64, 4096, ... back from the wave's first record, 64 at a time
+         int64_t a_lo, a_hi; // a_lo is below; a_hi is not (or is the wave's first record): the last below lies in [a_lo, a_hi)
+         {
+            int64_t top = r0, stride = 64;
+            for (;;) {
+               const int64_t idx = top - (int64_t)(lane + 1) * stride;
+               const bool below = idx < c0 || f.lefts[idx] < pmin;
+               const unsigned long long m = __ballot(below); // (from some lane on: the lanes go back in time, `lefts` ascends)
+               if (m) {
+                  const int first = __ffsll((long long)m) - 1;
+                  a_lo = top - (int64_t)(first + 1) * stride;
+                  a_hi = top - (int64_t)first * stride;
+                  break;
+               }
+               top -= 64 * stride;
+               stride *= 64;
+            }
+            if (a_lo < c0) a_lo = c0 - 1;
+         }
+         // fine: 64 probes across what is left, until one record is
+         while (a_hi - a_lo > 1) {
+            const int64_t st = (a_hi - a_lo - 1 + 63) >> 6; // candidates a_lo + 1 .. a_hi - 1
+            const int64_t idx = a_lo + 1 + (int64_t)lane * st;
+            const bool below = idx < a_hi && f.lefts[idx] < pmin;
+            const int nb = __popcll(__ballot(below)); // (the first nb lanes)
+            if (nb == 0) {
+               a_hi = a_lo + 1;
+            } else {
+               const int64_t next = a_lo + 1 + (int64_t)nb * st;
+               a_lo = a_lo + 1 + (int64_t)(nb - 1) * st;
+               if (next < a_hi) a_hi = next;
+            }
+         }
+         if (kind == 1) { // lefts[a_lo] < pmin <= partner_pos: the answer lies in (a_lo, r]
+            int64_t lo = a_lo;
+            hi = r;
+            while (hi - lo > 1) {
+               const int64_t mid = (lo + hi) >> 1;
+               if (f.lefts[mid] < q.ppos) lo = mid;
+               else hi = mid;
+            }
+         }
+      } else if (kind == 1) {
+         hi = flat_lower_bound_back(f.lefts, f.a.locus_read_off[cl], r, q.ppos);
+      }
+      if (kind == 1) {
+         const uint32_t fl = q.misc & 255u;
+         const int strand = (int)(fl >> 2) & 3;
+         int64_t hit = -1;
+         int n_fit = 0;
+         if (hi < r && f.lefts[hi] == q.ppos) { // a run starts there: probe it for this read id
+            const int64_t start = hi, end = hi + (int64_t)f.runlen[hi];
+            const uint32_t len = 2u * (uint32_t)(end - start);
+            const uint64_t rid = ((uint64_t)q.rid_hi << 32) | q.rid_lo;
+            int64_t at = 2 * start + (int64_t)(flat_hash32(rid) % len);
+            for (uint32_t tries = 0; tries < len; ++tries) {
+               const uint32_t v = f.slot[at];
+               if (v == 0u) break;
+               const int64_t t = (int64_t)v - 1;
+               const FlatRec w = f.rec_arr[t]; // (an opener: eligible, its partner behind it)
+               const int wstrand = (int)((w.misc & 255u) >> 2) & 3;
+               if (w.rid_lo == q.rid_lo && w.rid_hi == q.rid_hi && w.ppos == q.left && (wstrand == strand || strand == 0 || wstrand == 0))
+                  if (n_fit++ == 0) hit = t;
+               if (++at == 2 * end) at = 2 * start;
+            }
+         }
+         if (n_fit == 1) {
+            // an opener that two closing mates fit is a conflict: each writes its own index here (a plain store: no atomic round
+            // trip per pair), and flat_mate_count_kernel, which visits every pair, checks that the opener still names ITS closing mate
+            f.claim[hit] = (uint32_t)r + 1u;
+            done = (1ull << 32) | 0x80000000u | (uint32_t)hit; // (the waiting mate is the left one, :559-585)
+            ++complete;
+            --orphan;
+         } else if (n_fit == 0) {
+            ++orphan; // waits for a partner that never comes
+         } else {
+            conflict = true; // two openers fit: which one is the oldest WAITING one is the chain's business
+         }
+      }
+   }
+   if (r < f.n_reads) f.done[r] = done;
+   if (__ballot(conflict) && (threadIdx.x & 63u) == 0) atomicOr(f.trouble, kPosConflict);
+   for (int o = 32; o > 0; o >>= 1) {
+      refused += __shfl_xor(refused, o);
+      orphan += __shfl_xor(orphan, o);
+      single += __shfl_xor(single, o);
+      complete += __shfl_xor(complete, o);
+   }
+   __shared__ int part[4][4];
+   const int wave = threadIdx.x >> 6;
+   if ((threadIdx.x & 63) == 0) part[wave][0] = refused, part[wave][1] = orphan, part[wave][2] = single, part[wave][3] = complete;
+   __syncthreads();
+   if (threadIdx.x < 4) {
+      const long long v = (long long)part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+      if (v) atomicAdd(&f.counts[(size_t)(blockIdx.x & 63) * 8 + threadIdx.x], (unsigned long long)v);
+   }
 }
 
 __global__ __launch_bounds__(256) void flat_mate_pack_kernel(FlatMateArgs f)
@@ -265,6 +565,8 @@ __global__ __launch_bounds__(256) void flat_mate_count_kernel(FlatMateArgs f)
       const int nf_w = w >= 0 ? mate_feature_count(a, w) : 0;
       lf = me_right ? nf_w : nf_me;
       rf = me_right ? nf_me : nf_w;
+      // (the positional form: two closing mates that took the same opener -- the second store won)
+      if (f.claim && w >= 0 && f.claim[w] != (uint32_t)r + 1u) atomicOr(f.trouble, kPosConflict);
    }
    if (k <= f.n_reads) f.lfeat[k] = lf, f.rfeat[k] = rf;
    int sl = lf, sr = rf; // (a wave's 64 k are one tile)

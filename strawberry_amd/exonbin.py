@@ -197,7 +197,10 @@ def pair_mates(n_loci, reads, device=None):
         L.sbgpu_matepairs_destroy(handle)
     return {"pair_off": pair_off, "mass": mass, "left_off": lo, "left": (lc, ll, lr), "right_off": ro, "right": (rc, rl, rr),
             "info": {"pairs": n_p, "complete": int(info[1]), "single": int(info[2]), "refused": int(info[3]), "orphan": int(info[4]),
-                     "on_device": bool(info[7])}}
+                     "on_device": bool(info[7] & 1)},
+            # device form: did the positional matching serve the call (no sort)?  else why the sorted form did
+            # (1 records not in position order, 2 a read id with several fitting mates)
+            "positional": bool(info[7] & 2), "why_sorted": int(info[7]) >> 2}
 
 
 def collapse_pairs(n_loci, pair_locus, pair_mass, left_blocks, right_blocks, device=None):

@@ -235,3 +235,84 @@ def test_device_pairing_many_waiting_mates_and_long_groups(ctx, oracle):
         for x, y in zip(got[side], host[side]):
             np.testing.assert_array_equal(x, y)
     check_against_oracle(oracle, [cluster], got)
+
+
+def _assert_same_pairs(got, host):
+    for k in ("pair_off", "mass", "left_off", "right_off"):
+        np.testing.assert_array_equal(got[k], host[k], err_msg=k)
+    for side in ("left", "right"):
+        for x, y in zip(got[side], host[side]):
+            np.testing.assert_array_equal(x, y)
+    assert {k: got["info"][k] for k in ("pairs", "complete", "single", "refused", "orphan")} == {k: host["info"][k] for k in ("pairs", "complete", "single", "refused", "orphan")}
+
+
+def test_positional_and_sorted_forms_agree(ctx, oracle, monkeypatch):
+    """Round 6: where a cluster's records ascend by position and no read id has two fitting mates, no sort is needed -- a closing
+    mate searches its cluster for the records that start at its partner's position (the reference's rule is positional,
+    alignments.cpp:612-615).  Random clusters (single reads, orphans, mates elsewhere, strands that disagree, partners at the
+    read's own position, reads aligned at several PLACES under one id, PCR duplicates, a record beyond kMaxFragSpan) are served
+    by the positional form; SBGPU_PAIR_FORCE_SORT=1 sends the same call through the sorted form: same pairs, same order, same
+    counts, equal to the oracle and the host form."""
+    from strawberry_amd import exonbin as eb
+    rng = np.random.default_rng(101)
+    for trial in range(3):
+        n_loci = int(rng.integers(2, 40))
+        clusters = [MU.random_cluster(rng, int(rng.integers(0, 3000 if l == 2 else 300)), base=400000 * (l + 1)) for l in range(n_loci)]
+        loc = [l for l, c in enumerate(clusters) for _ in c]
+        reads = eb.Reads(loc, *MU.arrays([r for c in clusters for r in c]))
+        monkeypatch.delenv("SBGPU_PAIR_FORCE_SORT", raising=False)
+        pos = eb.pair_mates(n_loci, reads, device=ctx)
+        assert pos["positional"] and pos["why_sorted"] == 0
+        monkeypatch.setenv("SBGPU_PAIR_FORCE_SORT", "1")
+        srt = eb.pair_mates(n_loci, reads, device=ctx)
+        monkeypatch.delenv("SBGPU_PAIR_FORCE_SORT")
+        assert not srt["positional"] and srt["why_sorted"] == 0
+        _assert_same_pairs(pos, srt)
+        _assert_same_pairs(pos, eb.pair_mates(n_loci, reads))
+        check_against_oracle(oracle, clusters, pos)
+
+
+def test_positional_form_steps_aside(ctx, oracle):
+    """What the positional form does not decide, it hands to the sorted form, and says why (sbgpu_matepairs_info[7]):
+    a read id aligned twice at the SAME place (two openers fit one closing mate; the reference takes the oldest waiting one,
+    alignments.cpp:593-641 -- the chain's order), one opener that two closing mates fit, records that do not ascend by position.
+    Every case: the oracle's pairs, in its order.  5 000 records starting at ONE position are the positional form's own (a run
+    of the arrival order is a hash table of its openers: a closing mate does not look through the run)."""
+    from strawberry_amd import exonbin as eb
+    rng = np.random.default_rng(202)
+
+    def run(cluster, why):
+        reads = eb.Reads([0] * len(cluster), *MU.arrays(cluster))
+        got = eb.pair_mates(1, reads, device=ctx)
+        assert not got["positional"] and got["why_sorted"] & why, (got["positional"], got["why_sorted"], why)
+        _assert_same_pairs(got, eb.pair_mates(1, reads))
+        check_against_oracle(oracle, [cluster], got)
+
+    def sort_by_pos(recs):
+        order = np.argsort([r["blocks"][0][0] for r in recs], kind="stable")
+        return [recs[i] for i in order]
+
+    bg = MU.random_cluster(rng, 200, base=700000)
+    L = lambda rid, s, p, xs=1: {"id": rid, "blocks": [(s, s + 74)], "ppos": p, "flags": (xs << 2), "nh": 2}   # noqa: E731
+    R = lambda rid, s, p, xs=1: {"id": rid, "blocks": [(s, s + 74)], "ppos": p, "flags": MU.REVERSE | (xs << 2), "nh": 2}   # noqa: E731
+    # two alignments of read 5 at the same place: left, left, right, right
+    run(sort_by_pos(bg + [L(5, 650000, 650200), L(5, 650000, 650200), R(5, 650200, 650000), R(5, 650200, 650000)]), 2)
+    # one opener, two closing mates (the second finds it taken)
+    run(sort_by_pos(bg + [L(6, 651000, 651200), R(6, 651200, 651000), R(6, 651200, 651000)]), 2)
+    # two openers, one closing mate; the first opener's strand does not agree with the closer's, the second's does
+    run(sort_by_pos(bg + [L(7, 652000, 652200, xs=2), L(7, 652000, 652200, xs=1), L(7, 652000, 652200, xs=1), R(7, 652200, 652000, xs=1)]), 2)
+    # records out of position order
+    c = sort_by_pos(list(bg))
+    k = next(i for i in range(len(c) - 1) if c[i]["blocks"][0][0] != c[i + 1]["blocks"][0][0])
+    c[k], c[k + 1] = c[k + 1], c[k]
+    run(c, 1)
+    # 5 000 records start at one position, their mates 300 bases on
+    deep = []
+    for i in range(5000):
+        deep += [dict(L(1000 + i, 660000, 660300), nh=1), dict(R(1000 + i, 660300, 660000), nh=1)]
+    cluster = sort_by_pos(bg + deep)
+    reads = eb.Reads([0] * len(cluster), *MU.arrays(cluster))
+    got = eb.pair_mates(1, reads, device=ctx)
+    assert got["positional"] and got["info"]["complete"] >= 5000
+    _assert_same_pairs(got, eb.pair_mates(1, reads))
+    check_against_oracle(oracle, [cluster], got)
