@@ -581,6 +581,135 @@ def front_main(args, ctx, dev, rank, world, sdist, torch, launch, comm=None):
         raise SystemExit("bench.py: theta does not match the reference program's: %r" % out["parity"])
 
 
+def front_host_main(args, ctx, dev, torch, launch):
+    """--workload c3-front --from-host: the same records -> TPM pass for a caller that holds the inflated record stream in HOST
+    memory (page-locked where the box allows): sbgpu_front_stream_begin / push / end (include/sbgpu.h) -- chunks of whole
+    records (SB_FRONT_CHUNK_MB, default 512) uploaded while the chunk before is decoded, paired, collapsed; one
+    sbgpu_quantify_resident over the unique hits at the end.  The device never holds more than two chunk buffers, a chunk's
+    arenas and the unique hits.  Reported: the pass' wall time against the upload alone (the same chunks copied to the device and
+    nothing else) and against the resident pass (the compute alone), its peak device memory, and that its results equal the
+    resident pass' bit for bit.  BGZF inflate is the caller's and not in any of the numbers.
+    A sample of more than 2.4e8 read pairs (SB_FRONT_FRAGS=4e8: BASELINE config 5's size) cannot even be PACKED on the device in
+    one piece: it is made as two samples of half the size on references 0 and 1, brought to the host one after the other, and pushed
+    as ONE stream of 120 000 clusters; its parity is theta / status / iterations of a given-law pass against the two halves'
+    resident passes (with a given law the loci are independent), its timing the empirical pass."""
+    from strawberry_amd import front
+    n_loci = int(float(os.environ.get("SB_FRONT_LOCI", "60000")))
+    n_frags = float(os.environ.get("SB_FRONT_FRAGS", "2e8"))
+    chunk = int(float(os.environ.get("SB_FRONT_CHUNK_MB", "512")) * (1 << 20))
+    empirical = os.environ.get("SB_CHAIN_INSERT", "empirical") != "given"
+    pinned = os.environ.get("SB_FRONT_PINNED", "1") == "1"
+    note = None
+    try:
+        import psutil
+        avail = psutil.virtual_memory().available
+        need = 2 * 175.0 * n_frags * 1.15
+        if avail < need:
+            n_frags = float(int(avail / 1.15 / 350.0))
+            note = "host memory: %.0f GB available, sample cut to %.3g read pairs" % (avail / 1e9, n_frags)
+    except ImportError:
+        pass
+    n_parts = 2 if n_frags > 2.4e8 else 1
+    size_of = lambda q: {"theta": q.n_iso, "fpkm": q.n_iso, "frac": q.n_iso, "tpm": q.n_iso, "keep": q.n_iso, "status": q.n_loci, "iters": q.n_loci}  # noqa: E731
+    parts, want, resident_ms, to_host_s, pinned_all = [], [], 0.0, 0.0, True
+    for k in range(n_parts):
+        # (a multi-part sample is checked under a GIVEN law: the halves' resident passes are then independent of each other)
+        q = front.FrontQuantifier(ctx, n_loci=n_loci, n_frags=n_frags / n_parts, seed=31 + 1000 * k, resident=True,
+                                  empirical=empirical and n_parts == 1)
+        torch.cuda.empty_cache()
+        for _ in range(2):
+            q.step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            q.step()
+        torch.cuda.synchronize(dev)
+        resident_ms += (time.perf_counter() - t0) / 3 * 1e3
+        want.append(({n: getattr(q, n)[:m].copy() for n, m in size_of(q).items()}, q.front_hit_off.copy()))
+        t0 = time.perf_counter()
+        host = q.to_host(chunk, pinned=pinned, ref_id=k)
+        to_host_s += time.perf_counter() - t0
+        pinned_all = pinned_all and host["pinned"]
+        note = note or host["note"]
+        q.unpin()
+        ctx.L.sbgpu_release_idle_memory()
+        torch.cuda.empty_cache()
+        parts.append(q)
+    n_bytes, n_records = sum(q.n_bytes for q in parts), sum(q.n_records for q in parts)
+    free0 = torch.cuda.mem_get_info(dev)[0]
+    # the upload alone: the same chunks, host -> one device buffer, nothing else
+    dbuf = torch.empty(chunk, dtype=torch.uint8, device=dev)
+    up = []
+    for _ in range(2):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for q in parts:
+            for (i, j, b0, b1, off) in q.h_chunks:
+                dbuf[:b1 - b0].copy_(q.h_bytes[b0:b1], non_blocking=True)
+        torch.cuda.synchronize(dev)
+        up.append((time.perf_counter() - t0) * 1e3)
+    upload_ms = min(up)
+    del dbuf
+    torch.cuda.empty_cache()
+    steps = max(1, min(args.steps, 3))
+    if n_parts == 1:
+        q = parts[0]
+        run = lambda: q.stream_step()                                        # noqa: E731
+    else:
+        run = lambda: front.FrontQuantifier.stream_parts(parts, empirical=empirical)   # noqa: E731
+    res = run()                                 # (warm-up: the pool gets its blocks)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = run()
+    torch.cuda.synchronize(dev)
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    if n_parts == 1:
+        info = res
+        same = bool(np.array_equal(q.front_hit_off, want[0][1]) and all(np.array_equal(getattr(q, n)[:size_of(q)[n]], v) for n, v in want[0][0].items()))
+        parity_what = "unique hits, theta, FPKM, Frac, keep, TPM, status, iterations == the resident pass' (sbgpu_bam_decode_device .. sbgpu_quantify_resident on the whole sample), bit for bit"
+        law, tpm_sum, n_loci_all, n_pairs_all = q.law, float(q.tpm[:q.n_iso].sum()), q.n_loci, q.n_frags
+    else:
+        info, law, tpm_sum = res["info"], res["law"], float(res["tpm"].sum())
+        given = front.FrontQuantifier.stream_parts(parts, empirical=False)
+        same, j0, l0 = True, 0, 0
+        for q, (w, _) in zip(parts, want):
+            same = same and bool(np.array_equal(given["theta"][j0:j0 + q.n_iso], w["theta"]) and np.array_equal(given["status"][l0:l0 + q.n_loci], w["status"]) and
+                                 np.array_equal(given["iters"][l0:l0 + q.n_loci], w["iters"]))
+            j0, l0 = j0 + q.n_iso, l0 + q.n_loci
+        parity_what = ("a given-law (-i 250/30) pass over the joined stream: theta, status, iterations of each half == that half's own resident pass, bit for bit "
+                       "(the timed pass is the empirical one; the joined sample cannot be resident: that is the point)")
+        n_loci_all, n_pairs_all = sum(q.n_loci for q in parts), sum(q.n_frags for q in parts)
+    bound = max(upload_ms, resident_ms)
+    peak = int(free0 - info["least_free_device_bytes"])
+    out = {
+        "metric": "loci/s and G records/s, BAM alignment records in HOST memory -> abundances (C3-scale)", "value": n_loci_all / (ms * 1e-3),
+        "unit": "loci/s", "n_gpus": 1, "steps": steps, "warmup": 1, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8 records, u32 intervals, f64", "data": "synthetic",
+        "grecords_per_s": n_records / (ms * 1e-3) / 1e9, "mfrags_per_s": n_pairs_all / (ms * 1e-3) / 1e6,
+        "config": {"workload": WORKLOADS["c3-front"] + "; the records start in HOST memory and are pushed in chunks (sbgpu_front_stream_*)",
+                   "loci": n_loci_all, "read_pairs": n_pairs_all, "records": n_records, "record_bytes": n_bytes, "chunk_bytes": chunk,
+                   "chunks": info["chunks"], "host_memory": "page-locked" if pinned_all else "pageable", "parts": n_parts, "note": note},
+        "launch": launch, "insert": "empirical" if empirical else "given (-i 250/30)", "tpm": True,
+        "law": {k: v for k, v in law.items() if k != "emp_hist"}, "tpm_sum": tpm_sum,
+        "from_host": {
+            "ms_per_step": ms, "upload_alone_ms": upload_ms, "upload_GBps": n_bytes / upload_ms / 1e6, "resident_pass_ms": resident_ms,
+            "over_the_larger_of_the_two": ms / bound, "end_to_end_GBps": n_bytes / ms / 1e6,
+            "peak_device_bytes": peak, "peak_device_GB": peak / 1e9, "device_free_before_GB": free0 / 1e9, "stream": info,
+            "parity_ok": same, "parity": parity_what, "records_to_host_s": to_host_s,
+            "what": "peak_device_bytes: free device memory before the first pass (the library's pool empty, torch's cache empty) minus the least free "
+                    "memory any pass saw (hipMemGetInfo after every chunk and after the last stage): two chunk buffers of 2 x chunk_bytes, a chunk's "
+                    "arenas, the store of unique hits, the last stage's scratch, and whatever the library's pool holds idle; resident_pass_ms: "
+                    "the device entries on the resident sample%s" % (" (the two halves' passes added)" if n_parts > 1 else "")},
+        "roofline": {"bound": "pcie", "kernel": "host -> device copies of the record stream (the pass is upload-bound)", "achieved": n_bytes / ms / 1e6,
+                     "peak": n_bytes / upload_ms / 1e6, "unit": "GB/s", "frac": upload_ms / ms, "traffic": None,
+                     "note": "peak = the measured rate of the same chunks' uploads alone on this box; the kernels' own rooflines are c3-front's (resident)"},
+    }
+    print(json.dumps(out))
+    if not same:
+        raise SystemExit("bench.py: the chunked pass does not reproduce the resident pass")
+
+
 def self_launch(args):
     """`--gpus N` (N > 1) without a torchrun environment: start the N ranks ourselves, one process per GPU, with the
     driver's own command line (`python -m torch.distributed.run --nproc-per-node N bench.py ...`).  This process has
@@ -635,6 +764,7 @@ def main():
                          "at one rank they are the same run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-chain", action="store_true", help="default workload: leave the fragments -> abundances leg out of the line")
+    ap.add_argument("--from-host", action="store_true", help="c3-front: the records start in host memory and are pushed in chunks (sbgpu_front_stream_*)")
     ap.add_argument("--no-front", action="store_true", help="default workload: leave the records -> theta leg out of the line (also SB_BENCH_NO_FRONT=1)")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -691,6 +821,10 @@ def main():
 
     if args.workload == "c3-chain":
         return chain_main(args, ctx, dev, rank, world, sdist, torch, launch, comm=comm)
+    if args.workload == "c3-front" and args.from_host:
+        if world != 1:
+            raise SystemExit("bench.py: --from-host is a one-GPU line")
+        return front_host_main(args, ctx, dev, torch, launch)
     if args.workload == "c3-front":
         return front_main(args, ctx, dev, rank, world, sdist, torch, launch, comm=comm)
 

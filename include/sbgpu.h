@@ -767,6 +767,41 @@ int sbgpu_quantify_resident(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *annot, c
                             int32_t read_len, int32_t long_read, int64_t mapped_reads,
                             const sbgpu_abundance_params_t *params, sbgpu_comm_t *comm, sbgpu_insert_t *insert_used,
                             sbgpu_abundances_t *out, sbgpu_bins_t **bins_out);
+/* ---- records in HOST memory -> abundances, chunk by chunk, with a bounded footprint on the device -------------------------
+ * The reference streams: Sample::nextClusterRefDemand / procSample hold one cluster's reads at a time
+ * (src/alignments.cpp:1145-1187, 1736-1811).  The device entries above take a whole sample's records resident; a caller that
+ * inflates a BAM file on the host uses this instead (csrc/front_stream_api.hip):
+ *   begin   the clusters of quant mode (sorted by (reference, left), as sbgpu_assign_reads_*; cluster k = locus k of the
+ *           annotation given to end), the decoder's options, and the most bytes one chunk will hold: two device buffers of
+ *           twice that (a chunk + room for the records carried over from the chunk before)
+ *   push    the next chunk of the inflated record stream -- WHOLE records, in file order -- from host memory, with the records'
+ *           offsets in the chunk (rec_off[0 .. n_records], rec_off[n_records] = n_bytes; NULL: found here with
+ *           sbgpu_bam_index_host).  The bytes start their way to the device, and while they travel the chunk pushed BEFORE is
+ *           decoded, assigned to the clusters, and the clusters it completes (a record behind their end has been seen) are
+ *           paired, collapsed, and their unique hits added to the stream's store on the device; the records of the first
+ *           incomplete cluster onward are decoded again with the next chunk.  The caller must leave the bytes AND the offsets
+ *           of a push untouched until the NEXT push (or end) returns.  From page-locked memory (hipHostMalloc, cudaHostRegister'ed
+ *           buffers a driver inflates into) the upload runs beside the kernels; from pageable memory it is staged by the
+ *           runtime before the call computes (correct, no overlap).  A cluster whose records exceed a chunk: SBGPU_ESHAPE.
+ *   end     the last chunk, then ONE sbgpu_quantify_resident over the store (arguments as there; mapped_reads is the
+ *           stream's own count): the empirical insert-size law is the whole sample's, TPM needs every locus.
+ * Results: those of sbgpu_bam_decode_device .. sbgpu_quantify_resident on the whole sample at once, bit for bit.
+ * info: 0 records pushed, 1 accepted records consumed, 2 pairs, 3 unique hits, 4 their features, 5 pairs the span filter
+ * dropped, 6 mapped reads, 7 chunks, 8 clusters finished, 9 most bytes carried over, 10 records decoded twice, 11 the LEAST free
+ * device memory seen since begin (bytes, hipMemGetInfo after every chunk and after the last stage: blocks the library's pool
+ * holds idle count as used), 12 bytes per chunk buffer half, 13: 1 once ended, 14 free device memory at begin.               */
+typedef struct sbgpu_front_stream sbgpu_front_stream_t;
+int sbgpu_front_stream_begin(sbgpu_ctx_t *ctx, const sbgpu_clusters_t *clusters, const sbgpu_bam_opts_t *opts, int64_t chunk_bytes,
+                             sbgpu_front_stream_t **out);
+int sbgpu_front_stream_push(sbgpu_front_stream_t *fs, const uint8_t *bytes, int64_t n_bytes, const int64_t *rec_off, int64_t n_records);
+int sbgpu_front_stream_end(sbgpu_front_stream_t *fs, const sbgpu_annotation_t *annot, const sbgpu_insert_t *insert, int32_t read_len,
+                           int32_t long_read, const sbgpu_abundance_params_t *params, sbgpu_comm_t *comm, sbgpu_insert_t *insert_used,
+                           sbgpu_abundances_t *out, sbgpu_bins_t **bins_out);
+int sbgpu_front_stream_info(const sbgpu_front_stream_t *fs, int64_t info[16]);
+/* the store: the unique hits of the clusters finished so far (device arrays, the stream's), their masses, and where every
+ * cluster's hits begin (host, [n_clusters + 1]; complete after end)                                                            */
+int sbgpu_front_stream_hits(const sbgpu_front_stream_t *fs, sbgpu_hits_t *d_hits, const float **d_hit_mass, const int64_t **locus_hit_off);
+void sbgpu_front_stream_destroy(sbgpu_front_stream_t *fs);
 /* F of the EM batch a handle from sbgpu_quantify_host holds: F_out[info[3]] (row-major per locus). */
 int sbgpu_bins_export_weights(const sbgpu_bins_t *bins, double *F_out);
 

@@ -37,6 +37,8 @@ SYMBOLS = [
     "sbgpu_format_value", "sbgpu_format_gtf_transcript", "sbgpu_format_context_row", "sbgpu_format_context_row_seq",
     "sbgpu_binseq_device", "sbgpu_binseq_host", "sbgpu_em_batch", "sbgpu_abundance_device", "sbgpu_tpm_device",
     "sbgpu_quantify_resident", "sbgpu_allreduce_max_i64", "sbgpu_allreduce_max_i64_host", "sbgpu_comm_init_host",
+    "sbgpu_front_stream_begin", "sbgpu_front_stream_push", "sbgpu_front_stream_end", "sbgpu_front_stream_info", "sbgpu_front_stream_hits",
+    "sbgpu_front_stream_destroy",
 ]
 
 
@@ -228,6 +230,15 @@ def load():
     L.sbgpu_allreduce_max_i64.argtypes = [vp, vp, C.c_int64, vp]
     L.sbgpu_allreduce_max_i64_host.argtypes = [vp, vp, C.c_int64]
     L.sbgpu_comm_init_host.argtypes = [vp, C.c_int, C.c_int, HOST_ALLREDUCE_FN, vp, C.POINTER(vp)]
+    L.sbgpu_front_stream_begin.argtypes = [vp, C.POINTER(sbgpu_clusters_t), C.POINTER(sbgpu_bam_opts_t), C.c_int64, C.POINTER(vp)]
+    L.sbgpu_front_stream_push.argtypes = [vp, vp, C.c_int64, vp, C.c_int64]
+    L.sbgpu_front_stream_end.argtypes = [vp, C.POINTER(sbgpu_annotation_t), C.POINTER(sbgpu_insert_t), C.c_int32, C.c_int32,
+                                         C.POINTER(sbgpu_abundance_params_t), vp, C.POINTER(sbgpu_insert_t), C.POINTER(sbgpu_abundances_t),
+                                         C.POINTER(vp)]
+    L.sbgpu_front_stream_info.argtypes = [vp, i64p]
+    L.sbgpu_front_stream_hits.argtypes = [vp, C.POINTER(sbgpu_hits_t), C.POINTER(vp), C.POINTER(vp)]
+    L.sbgpu_front_stream_destroy.argtypes = [vp]
+    L.sbgpu_front_stream_destroy.restype = None
     L.sbgpu_bins_export_weights.argtypes = [vp, vp]
     L.sbgpu_collapse_pairs_host.argtypes = [C.c_int64, C.POINTER(sbgpu_pairs_t), C.POINTER(vp)]
     L.sbgpu_collapse_pairs_device.argtypes = [vp, C.c_int64, C.POINTER(sbgpu_pairs_t), vp, vp, C.POINTER(vp)]

@@ -138,6 +138,8 @@ int bins_create_device_impl(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *annot, c
 int exonbin_device_impl(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *annot, const sbgpu_hits_t *hits, int32_t compat_words,
                         int32_t key_words, uint32_t *d_compat, uint32_t *d_key, uint64_t *d_span, uint32_t *d_fhash, void *stream,
                         int64_t n_iso = -1, const DeviceSegBasis *seg_basis = nullptr);
+// bamdecode_api.hip: the device array `record` of a device handle (accepted read -> its record's index)
+const int64_t *bamreads_device_record(const sbgpu_bamreads_t *reads);
 int api_fail(int code, const std::string &msg); // records sbgpu_last_error(), returns code
 hipStream_t ctx_stream(const sbgpu_ctx_t *ctx); // the context's own stream
 hipStream_t ctx_aux_stream(const sbgpu_ctx_t *ctx, int i); // one of the context's side streams (0..7; the EM's kinds use 0, 1, 2, 6)
@@ -156,6 +158,15 @@ hipError_t ctx_scratch(sbgpu_ctx_t *ctx, int slot, size_t bytes, char **out);
 hipError_t dev_take(size_t bytes, char **out, size_t *capacity);
 size_t dev_release_idle();
 void dev_give(char *block, size_t capacity);
+// While one of these lives in a thread, its dev_give calls do NOT wait for the device: for a caller whose blocks were only ever
+// used on streams it has synchronised itself, and that runs other work -- an upload on another stream -- it must not wait for
+// (sbgpu_front_stream_*: every stage's handle goes back to the pool while the next chunk is on its way).
+struct DevGiveStreamSynced {
+   DevGiveStreamSynced();
+   ~DevGiveStreamSynced();
+   DevGiveStreamSynced(const DevGiveStreamSynced &) = delete;
+   DevGiveStreamSynced &operator=(const DevGiveStreamSynced &) = delete;
+};
 // pinned host scratch of the same kind (slot 0..3): the targets of small device-to-host copies that must not block the host
 hipError_t ctx_pinned(sbgpu_ctx_t *ctx, int slot, size_t bytes, char **out);
 // a second stream for copies that run beside the context's kernels, and events (0..5) to order the two (made on first use)

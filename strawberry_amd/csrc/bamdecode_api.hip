@@ -39,6 +39,10 @@ struct sbgpu_bamreads {
    uint32_t *block_left = nullptr, *block_right = nullptr; // [n_blocks]
 };
 
+namespace sb {
+const int64_t *bamreads_device_record(const sbgpu_bamreads_t *b) { return b && b->on_device ? b->record : nullptr; }
+} // namespace sb
+
 namespace {
 size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
 

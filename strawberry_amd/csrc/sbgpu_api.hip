@@ -238,6 +238,11 @@ size_t dev_release_idle()
    for (const DevBlock &b : idle) (void)hipFree(b.p);
    return bytes;
 }
+namespace {
+thread_local int g_give_without_device_sync = 0;
+}
+DevGiveStreamSynced::DevGiveStreamSynced() { ++g_give_without_device_sync; }
+DevGiveStreamSynced::~DevGiveStreamSynced() { --g_give_without_device_sync; }
 void dev_give(char *block, size_t capacity)
 {
    if (!block) return;
@@ -254,7 +259,7 @@ void dev_give(char *block, size_t capacity)
    // hipFree waits for the device before it lets memory go, and callers have relied on that (a handle destroyed while a
    // kernel on the CALLER's stream still reads its arena): a block that goes back to the pool waits the same way.  On an
    // idle device -- every call site has synchronised its own stream already -- this costs ~10 us.
-   (void)hipDeviceSynchronize();
+   if (!g_give_without_device_sync) (void)hipDeviceSynchronize();
    bool pooled = false;
    {
       DevPool &pool = dev_pool();

@@ -65,6 +65,27 @@ class Annotation:
         a.key_words = max(1, int(-(-np.diff(a.seg_off).max(initial=0) // 32)))
         return a
 
+    @classmethod
+    def concat(cls, parts):
+        """Several annotations one after the other (their loci keep their order; the arrays are joined, the offsets shifted)."""
+        a = cls.__new__(cls)
+        a.n_loci = sum(p.n_loci for p in parts)
+
+        def join_off(name, count_of):
+            out, base = [np.zeros(1, np.int64)], 0
+            for p in parts:
+                out.append(getattr(p, name)[1:] + base)
+                base += count_of(p)
+            return np.concatenate(out)
+        a.iso_off = join_off("iso_off", lambda p: int(p.iso_off[-1]))
+        a.exon_off = join_off("exon_off", lambda p: int(p.exon_off[-1]))
+        a.seg_off = join_off("seg_off", lambda p: int(p.seg_off[-1]))
+        for name in ("exon_left", "exon_right", "seg_left", "seg_right"):
+            setattr(a, name, np.concatenate([getattr(p, name) for p in parts]))
+        a.compat_words = max(p.compat_words for p in parts)
+        a.key_words = max(p.key_words for p in parts)
+        return a
+
     def segments(self, locus):
         s = slice(self.seg_off[locus], self.seg_off[locus + 1])
         return list(zip(self.seg_left[s].tolist(), self.seg_right[s].tolist()))

@@ -219,6 +219,139 @@ class FrontQuantifier(ChainQuantifier):
         L.sbgpu_uniq_dev_destroy(hu)
         self.stage_wall_ms = ms
 
+    # ---- the same pass for a caller that holds the records in HOST memory: sbgpu_front_stream_* (chunks, bounded footprint)
+    def to_host(self, chunk_bytes, pinned=True, ref_id=0):
+        """Bring the packed record stream to host memory (page-locked when `pinned` and the box allows it) and cut it into chunks
+        of whole records of at most chunk_bytes: what a driver that inflates BGZF blocks holds -- the bytes, and the records'
+        offsets noted on the way.  The device copy is released.  ref_id: the reference this sample's records (and their mates)
+        lie on -- several samples on references 0, 1, ... pushed one after the other are ONE coordinate-sorted stream
+        (stream_parts).  -> dict(bytes moved, pinned or not, chunks)."""
+        torch = self.torch
+        n = self.n_bytes
+        if ref_id:
+            at = self.d_rec_off[:-1]
+            self.d_bytes[at + 4] = int(ref_id)       # refID (the template's is 0; ids below 256: one byte)
+            self.d_bytes[at + 24] = int(ref_id)      # next_refID
+            self._c_ref[:] = int(ref_id)
+        rec_off = self.d_rec_off.cpu().numpy()
+        note = None
+        try:
+            host = torch.empty(n, dtype=torch.uint8, pin_memory=bool(pinned))
+        except RuntimeError as e:       # (not enough lockable memory)
+            host, pinned, note = torch.empty(n, dtype=torch.uint8), False, "page-locked allocation failed: %s" % str(e)[:80]
+        step = 1 << 30
+        for a in range(0, n, step):
+            host[a:a + step].copy_(self.d_bytes[a:a + step])
+        torch.cuda.synchronize(self.dev)
+        self.d_bytes = self.d_rec_off = None
+        torch.cuda.empty_cache()
+        self.h_bytes, self.h_pinned, self.h_rec_off = host, bool(pinned), rec_off
+        self.cut(chunk_bytes)
+        return {"bytes": n, "pinned": bool(pinned), "chunks": len(self.h_chunks), "note": note}
+
+    def cut(self, chunk_bytes):
+        """The host copy's chunks: as many whole records as fit chunk_bytes, with the records' offsets inside the chunk."""
+        torch = self.torch
+        rec_off, cuts, i = self.h_rec_off, [], 0
+        while i < self.n_records:
+            j = int(np.searchsorted(rec_off, rec_off[i] + chunk_bytes, side="right")) - 1
+            if j <= i:
+                raise ValueError("a record is longer than a chunk")
+            # (the offsets as the inflating driver notes them: inside the chunk, in memory of the same kind as the bytes)
+            off = torch.from_numpy(rec_off[i:j + 1] - rec_off[i])
+            if self.h_pinned:
+                try:
+                    off = off.pin_memory()
+                except RuntimeError:
+                    pass
+            cuts.append((i, j, int(rec_off[i]), int(rec_off[j]), off))
+            i = j
+        self.h_chunks, self.chunk_bytes = cuts, int(chunk_bytes)
+
+    def stream_step(self):
+        """One pass records (host) -> TPM through sbgpu_front_stream_begin / push / end; the results land where step() puts
+        them (resident mode).  -> the stream's info (sbgpu_front_stream_info) as a dict."""
+        L, ctx = self.ctx.L, self.ctx
+        fs = C.c_void_p()
+        _lib.check(L.sbgpu_front_stream_begin(ctx.h, C.byref(self._clusters), C.byref(self._opts), self.chunk_bytes, C.byref(fs)), "sbgpu_front_stream_begin")
+        try:
+            base = self.h_bytes.data_ptr()
+            for (i, j, b0, b1, off) in self.h_chunks:
+                _lib.check(L.sbgpu_front_stream_push(fs, base + b0, b1 - b0, off.data_ptr(), j - i), "sbgpu_front_stream_push")
+            h = C.c_void_p()
+            _lib.check(L.sbgpu_front_stream_end(fs, C.byref(self._an), None if self.empirical else C.byref(self._ins), self.read_len, 0,
+                                                C.byref(self._par), self.comm.h if self.comm is not None else None, C.byref(self._used),
+                                                C.byref(self._out), C.byref(h)), "sbgpu_front_stream_end")
+            u = self._used
+            self.law = {"mean": u.mean, "sd": u.sd, "use_emp": int(u.use_emp), "start_offset": int(u.start_offset),
+                        "end_offset": int(u.end_offset), "total_reads": int(u.total_reads)}
+            if u.use_emp:
+                self.law["emp_hist"] = np.ctypeslib.as_array(u.emp_hist, shape=(u.end_offset - u.start_offset + 1,)).copy()
+            self.total_fpkm, self.total_mapped_reads = float(self._out.total_fpkm), int(self._out.total_mapped_reads)
+            hoff = C.c_void_p()
+            _lib.check(L.sbgpu_front_stream_hits(fs, None, None, C.byref(hoff)), "sbgpu_front_stream_hits")
+            self.front_hit_off = np.ctypeslib.as_array(C.cast(hoff, C.POINTER(C.c_int64)), shape=(self.n_loci + 1,)).copy()
+            info = (C.c_int64 * 16)()
+            _lib.check(L.sbgpu_front_stream_info(fs, info), "sbgpu_front_stream_info")
+            L.sbgpu_bins_destroy(h)
+        finally:
+            L.sbgpu_front_stream_destroy(fs)
+        keys = ("records", "accepted_records", "pairs", "unique_hits", "features", "pairs_dropped_by_the_span_filter", "mapped_reads", "chunks",
+                "clusters_finished", "most_bytes_carried", "records_decoded_twice", "least_free_device_bytes", "chunk_bytes", "ended",
+                "free_device_bytes_at_begin")
+        self.stream_info = {k: int(info[i]) for i, k in enumerate(keys)}
+        self.counts = dict(self.counts or {}, pairs_dropped_by_the_span_filter=self.stream_info["pairs_dropped_by_the_span_filter"],
+                           unique_hits=self.stream_info["unique_hits"])
+        return self.stream_info
+
+    @staticmethod
+    def stream_parts(parts, empirical=True, comm=None, min_isoform_frac=0.0):
+        """Several samples (FrontQuantifiers brought to_host with ref_id 0, 1, ...) pushed one after the other as ONE stream: a
+        sample too large to be packed on the device in one piece (BASELINE config 5: 4e8 read pairs).  -> dict of results over
+        all parts' loci (theta, fpkm, frac, tpm, keep, status, iters, law, totals, info)."""
+        from .exonbin import Annotation
+        p0 = parts[0]
+        L, ctx = p0.ctx.L, p0.ctx
+        annot = Annotation.concat([p.annot for p in parts])
+        n_iso, n_loci = int(annot.iso_off[-1]), annot.n_loci
+        c_ref = np.ascontiguousarray(np.concatenate([p._c_ref for p in parts]), np.int32)
+        c_left = np.ascontiguousarray(np.concatenate([p._c_left for p in parts]), np.uint32)
+        c_right = np.ascontiguousarray(np.concatenate([p._c_right for p in parts]), np.uint32)
+        c_strand = np.ascontiguousarray(np.concatenate([p._c_strand for p in parts]), np.uint8)
+        clusters = _lib.sbgpu_clusters_t(n_loci, c_ref.ctypes.data, c_left.ctypes.data, c_right.ctypes.data, c_strand.ctypes.data)
+        opts = bam.BamOptions(n_ref=len(parts)).c()
+        res = {k: np.zeros(n_iso + 1, np.float64) for k in ("theta", "fpkm", "frac", "tpm")}
+        res["keep"] = np.zeros(n_iso + 1, np.int32)
+        res["status"], res["iters"] = np.zeros(n_loci + 1, np.int32), np.zeros(n_loci + 1, np.int32)
+        out = _lib.sbgpu_abundances_t()
+        for k, v in res.items():
+            setattr(out, k, v.ctypes.data)
+        par = _lib.sbgpu_abundance_params_t(0, 0, 1, 0, 0.0, float(min_isoform_frac))
+        used, an = _lib.sbgpu_insert_t(), annot._struct()
+        fs, h = C.c_void_p(), C.c_void_p()
+        _lib.check(L.sbgpu_front_stream_begin(ctx.h, C.byref(clusters), C.byref(opts), max(p.chunk_bytes for p in parts), C.byref(fs)), "sbgpu_front_stream_begin")
+        try:
+            for p in parts:
+                base = p.h_bytes.data_ptr()
+                for (i, j, b0, b1, off) in p.h_chunks:
+                    _lib.check(L.sbgpu_front_stream_push(fs, base + b0, b1 - b0, off.data_ptr(), j - i), "sbgpu_front_stream_push")
+            _lib.check(L.sbgpu_front_stream_end(fs, C.byref(an), None if empirical else C.byref(p0._ins), p0.read_len, 0, C.byref(par),
+                                                comm.h if comm is not None else None, C.byref(used), C.byref(out), C.byref(h)), "sbgpu_front_stream_end")
+            law = {"mean": used.mean, "sd": used.sd, "use_emp": int(used.use_emp), "start_offset": int(used.start_offset),
+                   "end_offset": int(used.end_offset), "total_reads": int(used.total_reads)}
+            info = (C.c_int64 * 16)()
+            _lib.check(L.sbgpu_front_stream_info(fs, info), "sbgpu_front_stream_info")
+            L.sbgpu_bins_destroy(h)
+        finally:
+            L.sbgpu_front_stream_destroy(fs)
+        keys = ("records", "accepted_records", "pairs", "unique_hits", "features", "pairs_dropped_by_the_span_filter", "mapped_reads", "chunks",
+                "clusters_finished", "most_bytes_carried", "records_decoded_twice", "least_free_device_bytes", "chunk_bytes", "ended",
+                "free_device_bytes_at_begin")
+        r = {k: (v[:n_iso] if k not in ("status", "iters") else v[:n_loci]) for k, v in res.items()}
+        r.update({"law": law, "total_fpkm": float(out.total_fpkm), "total_mapped_reads": int(out.total_mapped_reads),
+                  "info": {k: int(info[i]) for i, k in enumerate(keys)}, "annot": annot})
+        return r
+
     def chain_step(self):
         """The same sample through the chain alone (its unique hits as DeviceSample made them): what step() must reproduce.
         (In -i mode; an empirical law is the whole sample's, span-filtered pairs included, so the two laws may differ.)"""

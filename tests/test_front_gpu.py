@@ -67,3 +67,39 @@ def test_default_bench_line_carries_the_front_leg_and_survives_its_failure():
     assert set(f["per_rank_stage_ms"][0]) == {"bam_decode", "assign_reads", "pair_mates", "collapse_pairs", "quantify"} and f["ms_per_step"] > 0
     d = run(SB_FRONT_LOCI="3000", SB_FRONT_FRAGS="1e12")
     assert d["value"] > 0 and d["front"]["ranks_that_ran"] == [] and "skipped" in d["front"]["note_rank0"] and "ms_per_step" not in d["front"]
+
+
+def test_records_from_host_in_chunks_equal_the_resident_pass():
+    """sbgpu_front_stream_begin / push / end (include/sbgpu.h): the record stream in HOST memory, pushed in chunks of whole
+    records -- 40 and 7 chunks, so that clusters straddle chunk after chunk and records are decoded twice -- gives the unique
+    hits, the law, theta, FPKM, Frac, keep and TPM of the resident pass over the whole sample, bit for bit; with the empirical law
+    and with a given one; a chunk smaller than a cluster's records is refused (SBGPU_ESHAPE), not mis-served."""
+    from strawberry_amd import _lib, em, front
+    ctx = em.default_context(0)
+    for empirical in (True, False):
+        q = front.FrontQuantifier(ctx, n_loci=2500, n_frags=2.5e6, seed=44, resident=True, empirical=empirical)
+        q.step()
+        size = {"theta": q.n_iso, "fpkm": q.n_iso, "frac": q.n_iso, "tpm": q.n_iso, "keep": q.n_iso, "status": q.n_loci, "iters": q.n_loci}
+        want = {k: getattr(q, k)[:n].copy() for k, n in size.items()}
+        want_law, want_off, want_tot = dict(q.law), q.front_hit_off.copy(), (q.total_fpkm, q.total_mapped_reads)
+        n_bytes = q.n_bytes
+        q.to_host(n_bytes // 40 + 4096, pinned=True)
+        for chunk in (n_bytes // 40 + 4096, n_bytes // 7 + 4096):
+            q.cut(chunk)
+            for k in want:
+                getattr(q, k)[:] = -1
+            info = q.stream_step()
+            assert info["records"] == q.n_records and info["chunks"] == len(q.h_chunks) and info["clusters_finished"] == q.n_loci
+            np.testing.assert_array_equal(q.front_hit_off, want_off)
+            for k, v in want.items():
+                np.testing.assert_array_equal(getattr(q, k)[:size[k]], v, err_msg="%s (chunk %d)" % (k, chunk))
+            assert (q.total_fpkm, q.total_mapped_reads) == want_tot
+            for k in ("mean", "sd", "use_emp", "start_offset", "end_offset", "total_reads"):
+                assert q.law[k] == want_law[k], k
+            if empirical:
+                np.testing.assert_array_equal(q.law["emp_hist"], want_law["emp_hist"])
+            assert info["records_decoded_twice"] > 0 and 0 < info["least_free_device_bytes"] <= info["free_device_bytes_at_begin"]
+        q.cut(1 << 16)          # a cluster's records must fit a chunk
+        with pytest.raises(_lib.SbgpuError, match="exceed a chunk"):
+            q.stream_step()
+        q.close()
