@@ -155,7 +155,14 @@ int sbgpu_plan_locus_kinds(const sbgpu_plan_t *plan, int8_t *out);
  * Inputs resident in HBM; outputs written to HBM:
  *   d_theta[iso_off[n_loci]]  = em._theta of every locus (concatenated)
  *   d_status[n_loci]          = SBGPU_EM_*
- *   d_iters[n_loci]           = E-steps started (0 for INIT_EMPTY)
+ *   d_iters[n_loci]           = E-steps started (0 for INIT_EMPTY).  The reference's iteration count for status
+ *                               OK and MAXITER.  UNSPECIFIED (+-1) for SBGPU_EM_DENOM_ZERO: the count of a failed
+ *                               solve is not part of the reference's output, and WHEN a decaying denominator is
+ *                               flushed to zero depends on one rounding -- the E-step's dot product is a chain of
+ *                               fused multiply-adds (csrc/em_device.h: `sum = fma(F, theta, sum)`), in which a product
+ *                               that is subnormal by itself survives, where the reference's separate multiply
+ *                               (-Ofast: FTZ) flushes it: one locus in 6e5 of the stress runs sees its zero one
+ *                               iteration later (theta and status identical; profiles/r05_stress.txt)
  * Asynchronous on `stream`.                                                     */
 int sbgpu_em_run_device(sbgpu_ctx_t *ctx, const sbgpu_plan_t *plan,
                         const int32_t *d_count, const double *d_F,

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <functional>
 #include <memory>
 #include <string>
@@ -141,6 +142,21 @@ int exonbin_device_impl(sbgpu_ctx_t *ctx, const sbgpu_annotation_t *annot, const
 // bamdecode_api.hip: the device array `record` of a device handle (accepted read -> its record's index)
 const int64_t *bamreads_device_record(const sbgpu_bamreads_t *reads);
 int api_fail(int code, const std::string &msg); // records sbgpu_last_error(), returns code
+// Experiment switches: SBGPU_* variables that select paths DESIGN.md / profiles/EXPERIMENTS_*.md record as measured and NOT adopted
+// (phased execution, launch graphs, tile and schedule variants, A/B forms of the grouping ...).  They exist only in a library built
+// with -DSB_EXPERIMENTS (`make experiments` -> libsbgpu_exp.so, never shipped, never timed by bench.py); the shipped library does
+// not read them.  What stays a plain getenv: resources (SBGPU_POOL_GB, SBGPU_HOST_THREADS), diagnostics (SBGPU_HOST_TIMING) and the
+// tests' hooks that force a fallback route the default inputs do not take (SBGPU_PAIR_FORCE_SORT, SBGPU_COLLAPSE_FORCE_SEQ,
+// SBGPU_COLLAPSE_TWO_SORTS, SBGPU_BAM_STAGE_KB, SBGPU_NO_WIDE, SBGPU_COMM_FORCE_RCCL).
+inline const char *exp_env(const char *name)
+{
+#ifdef SB_EXPERIMENTS
+   return std::getenv(name);
+#else
+   (void)name;
+   return nullptr;
+#endif
+}
 hipStream_t ctx_stream(const sbgpu_ctx_t *ctx); // the context's own stream
 hipStream_t ctx_aux_stream(const sbgpu_ctx_t *ctx, int i); // one of the context's side streams (0..7; the EM's kinds use 0, 1, 2, 6)
 int ctx_cu_count(const sbgpu_ctx_t *ctx);

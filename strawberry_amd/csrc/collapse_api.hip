@@ -279,195 +279,16 @@ int sbgpu_collapse_pairs_device(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_pair
    U->n_loci = n_loci;
    U->locus_hit_off.assign((size_t)n_loci + 1, 0);
    U->cluster_mass.assign((size_t)n_loci, 0.0);
-   char *w = nullptr; // scratch
-   auto bail = [&](int code, const std::string &msg) {
-      (void)hipFree(w);
-      sbgpu_uniq_dev_destroy(U);
-      return api_fail(code, msg);
-   };
-#define SB_TRY(expr)                                                                                     \
-   do {                                                                                                  \
-      hipError_t e_ = (expr);                                                                            \
-      if (e_ != hipSuccess) return bail(e_ == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
-   } while (0)
    if (np == 0 || n_loci == 0) {
       *out = U;
       return SBGPU_OK;
    }
-   // The flat form (collapse_flat.h: two device-wide radix sorts, scans, a wave per cluster for the order-bound sums) serves
-   // every call; SBGPU_COLLAPSE_PER_LOCUS=1 selects round 3's one-workgroup-per-cluster kernels (kept for A/B runs and tests:
-   // both must give the same unique hits, bit for bit).
-   static const bool per_locus = std::getenv("SBGPU_COLLAPSE_PER_LOCUS") && std::atoi(std::getenv("SBGPU_COLLAPSE_PER_LOCUS")) != 0;
-   if (!per_locus) {
-      const int rc = collapse_flat(c, n_loci, dp, locus_pair_off, s, U);
-      if (rc != SBGPU_OK) {
-         sbgpu_uniq_dev_destroy(U);
-         return rc;
-      }
-      *out = U;
-      return SBGPU_OK;
+   // every cluster of the call at once (collapse_flat.h)
+   const int rc = collapse_flat(c, n_loci, dp, locus_pair_off, s, U);
+   if (rc != SBGPU_OK) {
+      sbgpu_uniq_dev_destroy(U);
+      return rc;
    }
-   // loci the LDS sort does not hold (more than 4096 pairs: any highly expressed gene) get a workgroup of their own with
-   // the arrays in global scratch (collapse_big_kernel); known from the host offsets
-   std::vector<int32_t> big_loci;
-   std::vector<int64_t> big_off(1, 0);
-   for (int64_t l = 0; l < n_loci; ++l) {
-      const int64_t n = locus_pair_off[l + 1] - locus_pair_off[l];
-      if (n <= sb::kCollapseMax) continue;
-      if (n > (int64_t)1 << 24)
-         return bail(SBGPU_EUNSUPPORTED, "sbgpu_collapse_pairs_device: not covered by the device form: a locus has more than 2^24 read pairs; use sbgpu_collapse_pairs_host");
-      int64_t n2 = 1;
-      while (n2 < n) n2 <<= 1;
-      big_loci.push_back((int32_t)l);
-      big_off.push_back(big_off.back() + n2);
-   }
-   // the biggest first: a locus is one workgroup's work
-   if (big_loci.size() > 1) {
-      std::vector<size_t> ord(big_loci.size());
-      for (size_t i = 0; i < ord.size(); ++i) ord[i] = i;
-      std::sort(ord.begin(), ord.end(), [&](size_t x, size_t y) { return big_off[x + 1] - big_off[x] > big_off[y + 1] - big_off[y]; });
-      std::vector<int32_t> bl(big_loci.size());
-      std::vector<int64_t> bo(1, 0);
-      for (size_t i = 0; i < ord.size(); ++i) {
-         bl[i] = big_loci[ord[i]];
-         bo.push_back(bo.back() + (big_off[ord[i] + 1] - big_off[ord[i]]));
-      }
-      big_loci.swap(bl), big_off.swap(bo);
-   }
-   const size_t n_big = big_loci.size(), big_elems = (size_t)big_off.back();
-   SB_TRY(hipSetDevice(U->device));
-   const size_t np1 = (size_t)np, nl1 = (size_t)n_loci + 1;
-   size_t off = 0;
-   const size_t o_poff = off; off += up256(nl1 * 8);
-   const size_t o_order = off; off += up256(np1 * 4);
-   const size_t o_nfeat = off; off += up256(np1 * 4);
-   const size_t o_mass = off; off += up256(np1 * 4);
-   const size_t o_cm = off; off += up256(nl1 * 8);
-   const size_t o_nh = off; off += up256(nl1 * 4);
-   const size_t o_nf = off; off += up256(nl1 * 4);
-   const size_t o_nfi = off; off += up256(nl1 * 4);
-   const size_t o_nr = off; off += up256(nl1 * 4);
-   const size_t o_flag = off; off += 256;
-   const size_t o_hoff = off; off += up256(nl1 * 8);
-   const size_t o_fbase = off; off += up256(nl1 * 8);
-   const size_t o_bloci = off; off += up256((n_big + 1) * 4);
-   const size_t o_boff = off; off += up256((n_big + 1) * 8);
-   const size_t o_bkey = off; off += up256((big_elems + 1) * 8);
-   const size_t o_bidx = off; off += up256((big_elems + 1) * 4);
-   const size_t o_bsl = off; off += up256((big_elems + 1) * 4);
-   const size_t o_bsr = off; off += up256((big_elems + 1) * 4);
-   const size_t o_bskip = off; off += up256(big_elems + 1);
-   SB_TRY(hipMalloc(&w, off));
-   SB_TRY(hipMemsetAsync(w + o_flag, 0, 256, s));
-   SB_TRY(hipMemcpyAsync(w + o_poff, locus_pair_off, nl1 * 8, hipMemcpyHostToDevice, s));
-   sb::CollapseArgs a = {};
-   a.n_loci = n_loci;
-   a.locus_pair_off = (const int64_t *)(w + o_poff);
-   a.pair_mass = dp->pair_mass;
-   a.left_off = dp->left_off, a.right_off = dp->right_off;
-   a.left_code = dp->left_code, a.right_code = dp->right_code;
-   a.left_left = dp->left_left, a.left_right = dp->left_right;
-   a.right_left = dp->right_left, a.right_right = dp->right_right;
-   a.order = (int32_t *)(w + o_order);
-   a.nfeat = (int32_t *)(w + o_nfeat);
-   a.mass = (float *)(w + o_mass);
-   a.cluster_mass = (double *)(w + o_cm);
-   a.n_hits = (int32_t *)(w + o_nh);
-   a.n_feats = (int32_t *)(w + o_nf);
-   a.n_filtered = (int32_t *)(w + o_nfi);
-   a.n_rejected = (int32_t *)(w + o_nr);
-   a.flags = (int32_t *)(w + o_flag);
-   const unsigned grid = (unsigned)std::min<int64_t>(n_loci, (int64_t)sb::ctx_cu_count(c) * 8);
-   hipStream_t side = sb::ctx_aux_stream(c, 3);
-   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-   if (n_big) { // first: they are the long ones
-      SB_TRY(hipMemcpyAsync(w + o_bloci, big_loci.data(), n_big * 4, hipMemcpyHostToDevice, s));
-      SB_TRY(hipMemcpyAsync(w + o_boff, big_off.data(), (n_big + 1) * 8, hipMemcpyHostToDevice, s));
-      sb::CollapseBigArgs b;
-      b.n_big = (int32_t)n_big;
-      b.loci = (const int32_t *)(w + o_bloci);
-      b.big_off = (const int64_t *)(w + o_boff);
-      b.key = (unsigned long long *)(w + o_bkey);
-      b.idx = (int *)(w + o_bidx);
-      b.span_l = (int *)(w + o_bsl);
-      b.span_r = (int *)(w + o_bsr);
-      b.skip = (unsigned char *)(w + o_bskip);
-      // on a side stream of the context, beside the LDS kernels below (a big workgroup leaves most of its CU's LDS and half
-      // its wave slots free); joined before the counts are read
-      SB_TRY(sb::ctx_event(c, 0, &ev_fork));
-      SB_TRY(sb::ctx_event(c, 1, &ev_join));
-      SB_TRY(hipEventRecord(ev_fork, s));
-      SB_TRY(hipStreamWaitEvent(side, ev_fork, 0));
-      hipLaunchKernelGGL(sb::collapse_big_kernel, dim3((unsigned)std::min<size_t>(n_big, (size_t)sb::ctx_cu_count(c) * 2)), dim3(sb::kCollapseBigThreads), 0, side, a, b);
-      SB_TRY(hipGetLastError());
-      SB_TRY(hipEventRecord(ev_join, side));
-   }
-   static const bool one_class = std::getenv("SBGPU_FRONT_ONE_CLASS") && std::atoi(std::getenv("SBGPU_FRONT_ONE_CLASS")) != 0; // (A/B)
-   if (one_class) {
-      hipLaunchKernelGGL((sb::collapse_locus_kernel<sb::kCollapseMax, -1>), dim3(grid), dim3(sb::kCollapseThreads), 0, s, a);
-   } else {
-      hipLaunchKernelGGL((sb::collapse_locus_kernel<sb::kCollapseMax, sb::kCollapseSmall>), dim3(grid), dim3(sb::kCollapseThreads), 0, s, a);
-      hipLaunchKernelGGL((sb::collapse_locus_kernel<sb::kCollapseSmall, -1>), dim3((unsigned)std::min<int64_t>(n_loci, (int64_t)sb::ctx_cu_count(c) * 32)), dim3(sb::kCollapseThreads), 0, s, a);
-   }
-   SB_TRY(hipGetLastError());
-   if (n_big) SB_TRY(hipStreamWaitEvent(s, ev_join, 0));
-   std::vector<int32_t> nh((size_t)n_loci), nf((size_t)n_loci), nfi((size_t)n_loci), nr((size_t)n_loci);
-   int32_t flags = 0;
-   SB_TRY(hipMemcpyAsync(nh.data(), w + o_nh, (size_t)n_loci * 4, hipMemcpyDeviceToHost, s));
-   SB_TRY(hipMemcpyAsync(nf.data(), w + o_nf, (size_t)n_loci * 4, hipMemcpyDeviceToHost, s));
-   SB_TRY(hipMemcpyAsync(nfi.data(), w + o_nfi, (size_t)n_loci * 4, hipMemcpyDeviceToHost, s));
-   SB_TRY(hipMemcpyAsync(nr.data(), w + o_nr, (size_t)n_loci * 4, hipMemcpyDeviceToHost, s));
-   SB_TRY(hipMemcpyAsync(U->cluster_mass.data(), w + o_cm, (size_t)n_loci * 8, hipMemcpyDeviceToHost, s));
-   SB_TRY(hipMemcpyAsync(&flags, w + o_flag, 4, hipMemcpyDeviceToHost, s));
-   SB_TRY(hipStreamSynchronize(s));
-   if (flags) {
-      std::string why = "sbgpu_collapse_pairs_device: not covered by the device form:";
-      if (flags & sb::kCollapseLongMate) why += " a mate has more than 24 features;";
-      if (flags & sb::kCollapseNoMates) return bail(SBGPU_EINVAL, "sbgpu_collapse_pairs_device: a pair without mates");
-      return bail(SBGPU_EUNSUPPORTED, why + " use sbgpu_collapse_pairs_host");
-   }
-   std::vector<int64_t> feat_base((size_t)n_loci + 1, 0);
-   for (int64_t l = 0; l < n_loci; ++l) {
-      U->locus_hit_off[(size_t)l + 1] = U->locus_hit_off[(size_t)l] + nh[(size_t)l];
-      feat_base[(size_t)l + 1] = feat_base[(size_t)l] + nf[(size_t)l];
-      U->n_filtered += nfi[(size_t)l];
-      U->n_rejected += nr[(size_t)l];
-      U->total_mapped += (int64_t)(int)U->cluster_mass[(size_t)l]; // src/alignments.cpp:1372
-   }
-   U->n_hits = U->locus_hit_off[(size_t)n_loci];
-   U->n_feat = feat_base[(size_t)n_loci];
-   // ---- the unique hits' own arena
-   const size_t nh1 = (size_t)U->n_hits + 1, nfe1 = (size_t)U->n_feat + 1;
-   size_t t = 0;
-   const size_t u_off = t; t += up256(nh1 * 8);
-   const size_t u_loc = t; t += up256(nh1 * 4);
-   const size_t u_mass = t; t += up256(nh1 * 4);
-   const size_t u_left = t; t += up256(nfe1 * 4);
-   const size_t u_right = t; t += up256(nfe1 * 4);
-   const size_t u_code = t; t += up256(nfe1);
-   SB_TRY(sb::dev_take(t, &U->arena, &U->arena_cap));
-   U->d_feat_off = (int64_t *)(U->arena + u_off);
-   U->d_hit_locus = (int32_t *)(U->arena + u_loc);
-   U->d_mass = (float *)(U->arena + u_mass);
-   U->d_feat_left = (uint32_t *)(U->arena + u_left);
-   U->d_feat_right = (uint32_t *)(U->arena + u_right);
-   U->d_feat_code = (uint8_t *)(U->arena + u_code);
-   SB_TRY(hipMemcpyAsync(w + o_hoff, U->locus_hit_off.data(), nl1 * 8, hipMemcpyHostToDevice, s));
-   SB_TRY(hipMemcpyAsync(w + o_fbase, feat_base.data(), nl1 * 8, hipMemcpyHostToDevice, s));
-   SB_TRY(hipMemcpyAsync(U->d_feat_off + U->n_hits, &U->n_feat, 8, hipMemcpyHostToDevice, s));
-   a.hit_off = (const int64_t *)(w + o_hoff);
-   a.feat_base = (const int64_t *)(w + o_fbase);
-   a.hit_locus = U->d_hit_locus;
-   a.feat_off = U->d_feat_off;
-   a.feat_code = U->d_feat_code;
-   a.feat_left = U->d_feat_left;
-   a.feat_right = U->d_feat_right;
-   a.hit_mass = U->d_mass;
-   hipLaunchKernelGGL(sb::collapse_fill_kernel, dim3(grid), dim3(sb::kCollapseThreads), 0, s, a);
-   SB_TRY(hipGetLastError());
-   SB_TRY(hipStreamSynchronize(s)); // the scratch goes away
-#undef SB_TRY
-   (void)hipFree(w);
    *out = U;
    return SBGPU_OK;
 }

@@ -1,25 +1,13 @@
-// strawberry_amd/csrc/collapse_device.h -- HitCluster::collapseAndFilterHits on the GPU.
-//
-// /root/reference/src/alignments.cpp:656-703: the read pairs of a cluster are sorted by (left end, right end),
-// pairs with a mate whose reference span is an outlier are skipped, the others add their raw mass to the
-// cluster's mass and are collapsed with the previous unique hit when both mates are equal; every unique hit
-// then becomes a Contig (src/contig.cpp:216-267).  One workgroup per locus:
-//   1. sort keys (left << 32 | right) and the pairs' input indices go to LDS; a bitonic sort on (key, index)
-//      gives the reference's order with ties in input order (what sbgpu_collapse_pairs_host's stable sort gives);
-//   2. the mates' spans are integers, so their sum -- and the mean -- are exact in any order; the sum of squared
-//      deviations is not, so one thread adds it in input order, as std::inner_product does (common.h:100-110);
-//   3. the filter, "equal to the previous kept pair" and Contig(PairedHit)'s feature count are per-pair work;
-//      the cluster's mass is one sequential double sum in sorted order, a unique hit's mass one per group;
-//   4. after the host has turned the per-locus counts into offsets, a second kernel writes the unique hits
-//      (sbgpu_hits_t layout) where the exon-bin kernel reads them.
-// Loci of more than 4096 pairs take the same steps with their arrays in global memory (collapse_big_kernel).
-// Limit, reported through a flag (the caller then uses sbgpu_collapse_pairs_host): at most 24 features per mate.
+// strawberry_amd/csrc/collapse_device.h -- what the duplicate-collapse kernels share (HitCluster::collapseAndFilterHits on the
+// GPU; /root/reference/src/alignments.cpp:656-703, src/contig.cpp:216-267): the pairs' arrays, a mate as a
+// feature list, "two mates are equal", the reference's phi(), and Contig(PairedHit)'s merged feature list.  The collapse
+// itself: collapse_flat.h (all clusters of a call at once; round 3's one-workgroup-per-cluster kernels, which nothing had
+// reached since round 4, are gone).
 #pragma once
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "bitonic_big.h"
 
 namespace sb {
 
@@ -207,320 +195,5 @@ __device__ __forceinline__ uint32_t pair_right_pos(const MateRef &a, const MateR
 }
 
 // What a workgroup shares while it serves one locus (LDS in both forms)
-struct CollapseShared {
-   double mean, sd5;
-   int nmates, hits, feats, filt, rej, bad;
-};
-
-// One locus by one workgroup of THREADS threads.  key / idx [n2 = pow2ceil(np)], span_l / span_r / skip [np]: LDS for
-// loci of up to kCollapseMax pairs, global scratch for bigger ones (collapse_big_kernel) -- the same steps either way.
-// stage_k / stage_i (CH elements each, LDS): given by the global-memory form only -- the sort's chunk buffers, and where the
-// two one-thread sums read their operands from (a dependent global load per step costs a microsecond; 10^5 of them, 0.1 s)
-constexpr int kCollapseStage = 4096;
-template <int THREADS>
-__device__ __forceinline__ void collapse_one_locus(const CollapseArgs &a, int64_t l, int np, unsigned long long *key, int *idx, int *span_l,
-                                                   int *span_r, unsigned char *skip, double *red, CollapseShared &sh,
-                                                   unsigned long long *stage_k = nullptr, int *stage_i = nullptr)
-{
-   const int tid = threadIdx.x;
-   const int64_t q0 = a.locus_pair_off[l];
-   int n2 = 1;
-   while (n2 < np) n2 <<= 1;
-   // ---- keys, spans
-   int bad = 0;
-   double span_sum = 0.0;
-   int n_mates = 0;
-   for (int i = tid; i < n2; i += THREADS) {
-      unsigned long long k = ~0ull;
-      if (i < np) {
-         const MateRef x = left_mate(a, q0 + i), y = right_mate(a, q0 + i);
-         if (x.n > kMateFeatMax || y.n > kMateFeatMax) bad |= kCollapseLongMate;
-         if (x.n == 0 && y.n == 0) {
-            bad |= kCollapseNoMates;
-         } else {
-            k = ((unsigned long long)pair_left_pos(x, y) << 32) | pair_right_pos(x, y);
-         }
-         span_l[i] = x.n ? (int)(x.r[x.n - 1] - x.l[0] + 1) : -1;
-         span_r[i] = y.n ? (int)(y.r[y.n - 1] - y.l[0] + 1) : -1;
-         if (x.n) span_sum += (double)span_l[i], ++n_mates;
-         if (y.n) span_sum += (double)span_r[i], ++n_mates;
-      }
-      key[i] = k;
-      idx[i] = i;
-   }
-   if (bad) atomicOr(&sh.bad, bad);
-   // the spans are whole numbers: their sum is exact whatever the order
-   red[tid] = span_sum;
-   __syncthreads();
-   for (int w = THREADS / 2; w > 0; w >>= 1) {
-      if (tid < w) red[tid] += red[tid + w];
-      __syncthreads();
-   }
-   const double total_span = red[0];
-   __syncthreads();
-   red[tid] = (double)n_mates;
-   __syncthreads();
-   for (int w = THREADS / 2; w > 0; w >>= 1) {
-      if (tid < w) red[tid] += red[tid + w];
-      __syncthreads();
-   }
-   if (tid == 0) {
-      sh.nmates = (int)red[0];
-      sh.mean = total_span / red[0];
-   }
-   __syncthreads();
-   if (sh.bad) {
-      if (tid == 0) atomicOr(a.flags, sh.bad);
-      __syncthreads();
-      return;
-   }
-   // ---- bitonic sort of (key, input index)
-   if (stage_k) bitonic_sort_global<THREADS, kCollapseStage>(key, idx, n2, stage_k, stage_i);
-   else
-   for (int k2 = 2; k2 <= n2; k2 <<= 1)
-      for (int j = k2 >> 1; j > 0; j >>= 1) {
-         for (int i = tid; i < n2; i += THREADS) {
-            const int p = i ^ j;
-            if (p > i) {
-               const bool up = (i & k2) == 0;
-               const unsigned long long ki = key[i], kp = key[p];
-               const int ii = idx[i], ip = idx[p];
-               const bool greater = ki > kp || (ki == kp && ii > ip);
-               if (greater == up) {
-                  key[i] = kp, key[p] = ki;
-                  idx[i] = ip, idx[p] = ii;
-               }
-            }
-         }
-         __syncthreads();
-      }
-   // ---- sd: the squared deviations added in INPUT order (left mate, then right mate of each pair), by one thread
-   if (!stage_k) {
-      if (tid == 0) {
-         const double mean = sh.mean;
-         double sq = 0.0;
-         for (int i = 0; i < np; ++i) {
-            if (span_l[i] >= 0) {
-               const double d = (double)span_l[i] - mean;
-               sq += d * d;
-            }
-            if (span_r[i] >= 0) {
-               const double d = (double)span_r[i] - mean;
-               sq += d * d;
-            }
-         }
-         sh.sd5 = sqrt(sq / (double)sh.nmates) * 5;
-      }
-   } else {
-      // the same sum, the spans staged through LDS a chunk at a time (the order of the additions is unchanged)
-      int *sl = stage_i, *sr = (int *)stage_k;
-      double sq = 0.0;
-      for (int c0 = 0; c0 < np; c0 += kCollapseStage) {
-         const int m = min(kCollapseStage, np - c0);
-         for (int t = tid; t < m; t += THREADS) sl[t] = span_l[c0 + t], sr[t] = span_r[c0 + t];
-         __syncthreads();
-         if (tid == 0) {
-            const double mean = sh.mean;
-            for (int i = 0; i < m; ++i) {
-               if (sl[i] >= 0) {
-                  const double d = (double)sl[i] - mean;
-                  sq += d * d;
-               }
-               if (sr[i] >= 0) {
-                  const double d = (double)sr[i] - mean;
-                  sq += d * d;
-               }
-            }
-         }
-         __syncthreads();
-      }
-      if (tid == 0) sh.sd5 = sqrt(sq / (double)sh.nmates) * 5;
-   }
-   __syncthreads();
-   // ---- the span filter (:670-682), and the masses in sorted order
-   double *pmass = (double *)key;
-   for (int i = tid; i < np; i += THREADS) {
-      const int p = idx[i];
-      a.order[q0 + i] = p;
-      bool sk = false;
-      if (span_l[p] >= 0 && ref_phi_dev(((double)(uint32_t)span_l[p] - sh.mean) / sh.sd5) > 0.999) sk = true;
-      if (span_r[p] >= 0 && ref_phi_dev(((double)(uint32_t)span_r[p] - sh.mean) / sh.sd5) > 0.999) sk = true;
-      skip[i] = sk ? 1 : 0;
-   }
-   __syncthreads(); // everybody is done with key[] as keys
-   for (int i = tid; i < np; i += THREADS) pmass[i] = a.pair_mass[q0 + idx[i]];
-   __syncthreads();
-   // ---- the cluster's mass: kept pairs in sorted order, one running double (:683-684)
-   if (!stage_k) {
-      if (tid == 0) {
-         double m = 0.0;
-         for (int i = 0; i < np; ++i)
-            if (!skip[i]) m += pmass[i];
-         a.cluster_mass[l] = m;
-      }
-   } else {
-      double *pm = (double *)stage_k; // (staged like the spans above; skipped pairs go in as -1)
-      double m = 0.0;
-      for (int c0 = 0; c0 < np; c0 += kCollapseStage) {
-         const int mm = min(kCollapseStage, np - c0);
-         __syncthreads();
-         for (int t = tid; t < mm; t += THREADS) pm[t] = skip[c0 + t] ? -1.0 : pmass[c0 + t];
-         __syncthreads();
-         if (tid == 0)
-            for (int i = 0; i < mm; ++i)
-               if (pm[i] >= 0.0) m += pm[i];
-      }
-      if (tid == 0) a.cluster_mass[l] = m;
-      __syncthreads();
-   }
-   // ---- unique hits: a kept pair that differs from the previous kept pair (:685-697)
-   int my_hits = 0, my_feats = 0, my_filt = 0, my_rej = 0;
-   for (int i = tid; i < np; i += THREADS) {
-      a.nfeat[q0 + i] = 0;
-      a.mass[q0 + i] = 0.0f;
-      if (skip[i]) {
-         ++my_filt;
-         continue;
-      }
-      const MateRef x = left_mate(a, q0 + idx[i]), y = right_mate(a, q0 + idx[i]);
-      int prev = i - 1;
-      while (prev >= 0 && skip[prev]) --prev;
-      if (prev >= 0 && mate_equal(left_mate(a, q0 + idx[prev]), x) && mate_equal(right_mate(a, q0 + idx[prev]), y)) continue;
-      // head of a group: its mass = the members' masses added in order, in double; stored as float (Contig::mass())
-      double m = pmass[i];
-      for (int k = i + 1; k < np; ++k) {
-         if (skip[k]) continue;
-         if (!(mate_equal(left_mate(a, q0 + idx[k]), x) && mate_equal(right_mate(a, q0 + idx[k]), y))) break;
-         m += pmass[k];
-      }
-      const int nf = hit_features_dev(x, y, nullptr, nullptr, nullptr);
-      if (nf <= 0) {
-         ++my_rej; // Contig(PairedHit) rejects the pair: no hit, its mass stays in the cluster's
-         continue;
-      }
-      a.nfeat[q0 + i] = nf;
-      a.mass[q0 + i] = (float)m;
-      ++my_hits;
-      my_feats += nf;
-   }
-   if (my_hits) atomicAdd(&sh.hits, my_hits);
-   if (my_feats) atomicAdd(&sh.feats, my_feats);
-   if (my_filt) atomicAdd(&sh.filt, my_filt);
-   if (my_rej) atomicAdd(&sh.rej, my_rej);
-   __syncthreads();
-   if (tid == 0) {
-      a.n_hits[l] = sh.hits;
-      a.n_feats[l] = sh.feats;
-      a.n_filtered[l] = sh.filt;
-      a.n_rejected[l] = sh.rej;
-   }
-   __syncthreads();
-}
-
-// CAP: the LDS arrays' capacity.  Two instantiations: loci of up to kCollapseSmall pairs (23 KB of LDS: seven workgroups
-// per CU; with the full-size arrays a CU holds one) and loci of up to kCollapseMax; each serves the loci in (LO, CAP].
-constexpr int kCollapseSmall = 1024;
-template <int CAP, int LO>
-__global__ __launch_bounds__(kCollapseThreads) void collapse_locus_kernel(CollapseArgs a)
-{
-   __shared__ unsigned long long key[CAP]; // sort keys; afterwards the pairs' masses (as doubles)
-   __shared__ int idx[CAP];
-   __shared__ int span_l[CAP], span_r[CAP]; // by input index; -1: no such mate
-   __shared__ unsigned char skip[CAP];      // by sorted position
-   __shared__ double red[kCollapseThreads];
-   __shared__ CollapseShared sh;
-   const int tid = threadIdx.x;
-   for (int64_t l = blockIdx.x; l < a.n_loci; l += gridDim.x) {
-      const int64_t q0 = a.locus_pair_off[l];
-      const int64_t npl = a.locus_pair_off[l + 1] - q0;
-      if (npl > CAP || npl <= LO) continue; // another instantiation's, or collapse_big_kernel's
-      if (tid == 0) {
-         a.cluster_mass[l] = 0.0;
-         a.n_hits[l] = a.n_feats[l] = a.n_filtered[l] = a.n_rejected[l] = 0;
-         sh.hits = sh.feats = sh.filt = sh.rej = sh.bad = 0;
-      }
-      __syncthreads();
-      if (npl == 0) continue;
-      collapse_one_locus<kCollapseThreads>(a, l, (int)npl, key, idx, span_l, span_r, skip, red, sh);
-   }
-}
-
-// Loci of more than kCollapseMax pairs (any highly expressed gene): the same steps with the arrays in global scratch
-// and 1024 threads -- the bitonic sort then runs through the caches (a locus of 10^5 pairs: 153 passes of 64
-// compare-exchanges per thread), the two order-bound sums stay one thread's loops.  One workgroup per such locus.
-constexpr int kCollapseBigThreads = 1024;
-struct CollapseBigArgs {
-   int32_t n_big;
-   const int32_t *loci;      // [n_big] their locus numbers
-   const int64_t *big_off;   // [n_big + 1] first scratch element of each (in units of its n2: pow2ceil of its pairs)
-   unsigned long long *key;  // [big_off[n_big]]
-   int *idx, *span_l, *span_r;
-   unsigned char *skip;
-};
-
-__global__ __launch_bounds__(kCollapseBigThreads) void collapse_big_kernel(CollapseArgs a, CollapseBigArgs b)
-{
-   __shared__ double red[kCollapseBigThreads];
-   __shared__ CollapseShared sh;
-   __shared__ unsigned long long stage_k[kCollapseStage];
-   __shared__ int stage_i[kCollapseStage];
-   const int tid = threadIdx.x;
-   for (int i = blockIdx.x; i < b.n_big; i += gridDim.x) {
-      const int64_t l = b.loci[i], o = b.big_off[i];
-      const int64_t npl = a.locus_pair_off[l + 1] - a.locus_pair_off[l];
-      if (tid == 0) {
-         a.cluster_mass[l] = 0.0;
-         a.n_hits[l] = a.n_feats[l] = a.n_filtered[l] = a.n_rejected[l] = 0;
-         sh.hits = sh.feats = sh.filt = sh.rej = sh.bad = 0;
-      }
-      __syncthreads();
-      collapse_one_locus<kCollapseBigThreads>(a, l, (int)npl, b.key + o, b.idx + o, b.span_l + o, b.span_r + o, b.skip + o, red, sh, stage_k, stage_i);
-   }
-}
-
-// pass 2: the unique hits of every locus at their final places
-__global__ __launch_bounds__(kCollapseThreads) void collapse_fill_kernel(CollapseArgs a)
-{
-   __shared__ int cnt_h[kCollapseThreads], cnt_f[kCollapseThreads];
-   const int tid = threadIdx.x;
-   for (int64_t l = blockIdx.x; l < a.n_loci; l += gridDim.x) {
-      const int64_t q0 = a.locus_pair_off[l];
-      const int np = (int)(a.locus_pair_off[l + 1] - q0);
-      const int64_t h0 = a.hit_off[l], f0 = a.feat_base[l];
-      // thread t owns the sorted positions [t * per, t * per + per): hits come out in sorted order
-      const int per = (np + kCollapseThreads - 1) / kCollapseThreads;
-      int nh = 0, nf = 0;
-      for (int i = tid * per; i < min(np, tid * per + per); ++i)
-         if (a.nfeat[q0 + i] > 0) {
-            ++nh;
-            nf += a.nfeat[q0 + i];
-         }
-      cnt_h[tid] = nh;
-      cnt_f[tid] = nf;
-      __syncthreads();
-      if (tid == 0) {
-         int sh = 0, sf = 0;
-         for (int t = 0; t < kCollapseThreads; ++t) {
-            const int ch = cnt_h[t], cf = cnt_f[t];
-            cnt_h[t] = sh, cnt_f[t] = sf;
-            sh += ch, sf += cf;
-         }
-      }
-      __syncthreads();
-      int64_t h = h0 + cnt_h[tid], f = f0 + cnt_f[tid];
-      for (int i = tid * per; i < min(np, tid * per + per); ++i) {
-         const int n = a.nfeat[q0 + i];
-         if (n <= 0) continue;
-         const int64_t p = q0 + a.order[q0 + i];
-         a.hit_locus[h] = (int32_t)l;
-         a.feat_off[h] = f;
-         a.hit_mass[h] = a.mass[q0 + i];
-         hit_features_dev(left_mate(a, p), right_mate(a, p), a.feat_code + f, a.feat_left + f, a.feat_right + f);
-         ++h;
-         f += n;
-      }
-      __syncthreads();
-   }
-}
 
 } // namespace sb

@@ -1,14 +1,11 @@
 // strawberry_amd/csrc/em_kernels_block.hip -- one instantiation of the fused EM kernel per
 // translation unit (they compile in parallel); see em_device.h.
 #include "em_device.h"
-#include <cstdlib>
 
 namespace sb {
 hipError_t launch_fused_block(const FusedLaunch &l, hipStream_t s)
 {
-   // experiment: dynamic LDS nobody uses, to bound the workgroups per CU
-   static const int extra_lds = std::getenv("SBGPU_BLOCK_LDS") ? std::atoi(std::getenv("SBGPU_BLOCK_LDS")) : 0;
-   hipLaunchKernelGGL((em_fused_kernel<kBlockWaves, 2>), dim3(l.n_blocks), dim3(64 * kBlockWaves), extra_lds, s, l.a, l.ph);
+   hipLaunchKernelGGL((em_fused_kernel<kBlockWaves, 2>), dim3(l.n_blocks), dim3(64 * kBlockWaves), 0, s, l.a, l.ph);
    return hipGetLastError();
 }
 #ifdef SB_STAMPS

@@ -91,7 +91,7 @@ int exonbin_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgp
    a.locus_adj = nullptr;
    a.iso_member_hi = a.iso_start_hi = a.locus_adj_hi = nullptr;
    // the isoforms in the segment basis (exonbin_device.h): loci of up to 64 segments (key_words <= 2 covers them all)
-   static const bool seg_basis = !(std::getenv("SBGPU_EXONBIN_SEGBASIS") && std::atoi(std::getenv("SBGPU_EXONBIN_SEGBASIS")) == 0);
+   static const bool seg_basis = !(sb::exp_env("SBGPU_EXONBIN_SEGBASIS") && std::atoi(sb::exp_env("SBGPU_EXONBIN_SEGBASIS")) == 0);
    if (seg_basis && key_words >= 1 && compat_words >= 1) {
       DeviceSegBasis sbz;
       if (seg_pre) {
@@ -118,7 +118,7 @@ int exonbin_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const sbgp
    }
    const int64_t blocks_wanted = (hits->n_hits + 255) / 256;
    if (blocks_wanted > 0x7fffffff) return api_fail(SBGPU_ESHAPE, "sbgpu_exonbin_device: more than 2^39 hits in one call");
-   static const bool lane_form = std::getenv("SBGPU_EXONBIN_LANE") && std::atoi(std::getenv("SBGPU_EXONBIN_LANE")) != 0;
+   static const bool lane_form = sb::exp_env("SBGPU_EXONBIN_LANE") && std::atoi(sb::exp_env("SBGPU_EXONBIN_LANE")) != 0;
    if (lane_form) { // per-lane kernel only (A/B measurements)
       const int64_t cap = (int64_t)sb::ctx_cu_count(c) * 32;
       hipLaunchKernelGGL(sb::exonbin_lane_kernel, dim3((unsigned)(blocks_wanted < cap ? blocks_wanted : cap)), dim3(256), 0,
@@ -500,7 +500,7 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
    // ranking), which 256-thread workgroups, several per CU, pay side by side: 2.62 -> 1.83 ms on the chain sample
    // (SBGPU_BINS_MID_THREADS=1024|512|256, SBGPU_BINS_HEAVY_HITS=n for A/B; 8192 was the best of 2000 ... 100 000).
    int64_t n_heavy = 0;
-   static const int64_t heavy_env = std::getenv("SBGPU_BINS_HEAVY_HITS") ? std::atoll(std::getenv("SBGPU_BINS_HEAVY_HITS")) : 0;
+   static const int64_t heavy_env = sb::exp_env("SBGPU_BINS_HEAVY_HITS") ? std::atoll(sb::exp_env("SBGPU_BINS_HEAVY_HITS")) : 0;
    {
       const int64_t heavy = heavy_env > 0 ? heavy_env : std::max<int64_t>(8192, 3 * (nh / std::max<int64_t>(nl, 1)));
       auto hits_of = [&](int32_t l) { return locus_hit_off[l + 1] - locus_hit_off[l]; };
@@ -510,7 +510,7 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
       n_heavy = mid - first_big;
    }
    // the single-pass kernels (bins_device.h) where a bin's compat union fits two words; SBGPU_BINS_TWO_PASS=1: the older form (A/B)
-   static const bool two_pass_env = std::getenv("SBGPU_BINS_TWO_PASS") && std::atoi(std::getenv("SBGPU_BINS_TWO_PASS")) != 0;
+   static const bool two_pass_env = sb::exp_env("SBGPU_BINS_TWO_PASS") && std::atoi(sb::exp_env("SBGPU_BINS_TWO_PASS")) != 0;
    const bool single_pass = compat_words <= 2 && key_words <= 2 && !two_pass_env;
    if (!single_pass) SB_TRY(zero_bins(cs));
    SB_TRY(hipMemcpyAsync(d + o_order, order.data(), (size_t)nl * 4, hipMemcpyHostToDevice, cs));
@@ -531,7 +531,7 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
       a.n_loci = n_big;
       a.loci = (const int32_t *)(d + o_order) + n_small;
       const dim3 grid((unsigned)std::min<int64_t>(n_big, cap * 4));
-      static const int mid_threads = std::getenv("SBGPU_BINS_MID_THREADS") ? std::atoi(std::getenv("SBGPU_BINS_MID_THREADS")) : 256;
+      static const int mid_threads = sb::exp_env("SBGPU_BINS_MID_THREADS") ? std::atoi(sb::exp_env("SBGPU_BINS_MID_THREADS")) : 256;
       if (single_pass && mid_threads != 1024 && n_heavy < n_big) {
          // the heavy loci on 1024 threads, the others on fewer (more workgroups per CU, cheaper barriers)
          if (n_heavy) {
@@ -545,7 +545,7 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
          const dim3 gm((unsigned)std::min<int64_t>(a.n_loci, cap * 8));
          // ... and on a table of 1024 slots / 512 bins (24 KB of LDS: six workgroups per CU instead of three; a locus of
          // more bins is redone with the big table like any other overflow): 1.83 -> 1.41 ms (SBGPU_BINS_MID_SLOTS=2048 for A/B)
-         static const int mid_slots = std::getenv("SBGPU_BINS_MID_SLOTS") ? std::atoi(std::getenv("SBGPU_BINS_MID_SLOTS")) : 1024;
+         static const int mid_slots = sb::exp_env("SBGPU_BINS_MID_SLOTS") ? std::atoi(sb::exp_env("SBGPU_BINS_MID_SLOTS")) : 1024;
          if (mid_threads == 256 && mid_slots == 1024 && compat_words == 1) hipLaunchKernelGGL((sb::bins_accum_kernel<1024, 512, 256, 1, true>), gm, dim3(256), 0, s, a);
          else if (mid_threads == 256 && mid_slots == 1024) hipLaunchKernelGGL((sb::bins_accum_kernel<1024, 512, 256, 2, true>), gm, dim3(256), 0, s, a);
          else if (mid_threads == 256 && compat_words == 1) hipLaunchKernelGGL((sb::bins_accum_kernel<sb::kBinsSlotsMid, sb::kBinsMaxMid, 256, 1, true>), gm, dim3(256), 0, s, a);
@@ -637,7 +637,7 @@ int bins_create_device_impl(sbgpu_ctx_t *c, const sbgpu_annotation_t *an, const 
    pa.flags = a.flags + 1;
    // one wave per locus (bins_pairs_locus_kernel) for loci of up to 64 isoforms, the thread-per-isoform kernel for the
    // others; SBGPU_PAIRS_BY_ISOFORM=1: the latter everywhere (A/B)
-   static const bool pairs_by_iso = std::getenv("SBGPU_PAIRS_BY_ISOFORM") && std::atoi(std::getenv("SBGPU_PAIRS_BY_ISOFORM")) != 0;
+   static const bool pairs_by_iso = sb::exp_env("SBGPU_PAIRS_BY_ISOFORM") && std::atoi(sb::exp_env("SBGPU_PAIRS_BY_ISOFORM")) != 0;
    bool any_wide_locus = false;
    for (int64_t l = 0; l < nl && !any_wide_locus; ++l) any_wide_locus = an->iso_off[l + 1] - an->iso_off[l] > 64;
    pa.only_wide_loci = pairs_by_iso ? 0 : 1;

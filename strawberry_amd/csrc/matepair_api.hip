@@ -382,208 +382,16 @@ int sbgpu_pair_mates_device(sbgpu_ctx_t *c, int64_t n_loci, const sbgpu_reads_t 
    M->device = sb::ctx_device(c);
    M->n_loci = n_loci;
    M->locus_pair_off.assign((size_t)n_loci + 1, 0);
-   char *w = nullptr;
-   auto bail = [&](int code, const std::string &msg) {
-      (void)hipFree(w);
-      sbgpu_matepairs_destroy(M);
-      return api_fail(code, msg);
-   };
-#define SB_TRY(expr)                                                                                     \
-   do {                                                                                                  \
-      hipError_t e_ = (expr);                                                                            \
-      if (e_ != hipSuccess) return bail(e_ == hipErrorOutOfMemory ? SBGPU_ENOMEM : SBGPU_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
-   } while (0)
    if (nr == 0 || n_loci == 0) {
       *out = M;
       return SBGPU_OK;
    }
-   // The flat form (matepair_flat.h: one device-wide sort brings the records of a read id together, another orders the pairs)
-   // serves every call; SBGPU_PAIR_PER_LOCUS=1 selects round 3's one-workgroup-per-cluster kernels (A/B runs, tests).
-   static const bool per_locus = std::getenv("SBGPU_PAIR_PER_LOCUS") && std::atoi(std::getenv("SBGPU_PAIR_PER_LOCUS")) != 0;
-   if (!per_locus) {
-      const int rc = pair_mates_flat(c, n_loci, dr, locus_read_off, s, M);
-      if (rc != SBGPU_OK) {
-         sbgpu_matepairs_destroy(M);
-         return rc;
-      }
-      *out = M;
-      return SBGPU_OK;
+   // every cluster of the call at once (matepair_flat.h)
+   const int rc = pair_mates_flat(c, n_loci, dr, locus_read_off, s, M);
+   if (rc != SBGPU_OK) {
+      sbgpu_matepairs_destroy(M);
+      return rc;
    }
-   // ---- round 3's per-cluster form (the flat form above has no limit per cluster)
-   // clusters the LDS sort does not hold (more than 8192 records) get a workgroup of their own with the sort's arrays in
-   // global scratch (matepair_big_kernel), the biggest first
-   std::vector<int32_t> big_loci;
-   std::vector<int64_t> big_off(1, 0);
-   for (int64_t l = 0; l < n_loci; ++l) {
-      const int64_t n = locus_read_off[l + 1] - locus_read_off[l];
-      if (n <= sb::kMateMaxReads) continue;
-      if (n > (int64_t)1 << 24)
-         return bail(SBGPU_EUNSUPPORTED, "sbgpu_pair_mates_device: not covered by the per-cluster form (SBGPU_PAIR_PER_LOCUS): a cluster has more than 2^24 records");
-      big_loci.push_back((int32_t)l);
-   }
-   std::sort(big_loci.begin(), big_loci.end(), [&](int32_t x, int32_t y) {
-      const int64_t nx = locus_read_off[x + 1] - locus_read_off[x], ny = locus_read_off[y + 1] - locus_read_off[y];
-      return nx != ny ? nx > ny : x < y;
-   });
-   for (int32_t l : big_loci) {
-      int64_t n2 = 1;
-      while (n2 < locus_read_off[l + 1] - locus_read_off[l]) n2 <<= 1;
-      big_off.push_back(big_off.back() + n2);
-   }
-   const size_t n_big = big_loci.size(), big_elems = (size_t)big_off.back();
-   SB_TRY(hipSetDevice(M->device));
-   const size_t nr1 = (size_t)nr, nl1 = (size_t)n_loci + 1;
-   size_t off = 0;
-   const size_t o_roff = off; off += up256(nl1 * 8);
-   const size_t o_fate = off; off += up256(nr1);
-   const size_t o_partner = off; off += up256(nr1 * 4);
-   const size_t o_rank = off; off += up256(nr1 * 4);
-   size_t o_cnt[7];
-   for (size_t &o : o_cnt) {
-      o = off;
-      off += up256(nl1 * 4);
-   }
-   const size_t o_flag = off; off += 256;
-   const size_t o_poff = off; off += up256(nl1 * 8);
-   const size_t o_lbase = off; off += up256(nl1 * 8);
-   const size_t o_rbase = off; off += up256(nl1 * 8);
-   const size_t o_bloci = off; off += up256((n_big + 1) * 4);
-   const size_t o_boff = off; off += up256((n_big + 1) * 8);
-   const size_t o_bkey = off; off += up256((big_elems + 1) * 8);
-   const size_t o_bidx = off; off += up256((big_elems + 1) * 4);
-   const size_t o_bcl = off; off += up256((big_elems + 1) * 4);
-   const size_t o_bcr = off; off += up256((big_elems + 1) * 4);
-   SB_TRY(hipMalloc(&w, off));
-   SB_TRY(hipMemsetAsync(w + o_flag, 0, 256, s));
-   SB_TRY(hipMemcpyAsync(w + o_roff, locus_read_off, nl1 * 8, hipMemcpyHostToDevice, s));
-   sb::MateArgs a = {};
-   a.n_loci = n_loci;
-   a.locus_read_off = (const int64_t *)(w + o_roff);
-   a.read_id = dr->read_id;
-   a.block_off = dr->block_off;
-   a.block_left = dr->block_left, a.block_right = dr->block_right;
-   a.partner_pos = dr->partner_pos;
-   a.flags = dr->flags;
-   a.nh = dr->nh;
-   a.fate = (int8_t *)(w + o_fate);
-   a.partner = (int32_t *)(w + o_partner);
-   a.rank = (int32_t *)(w + o_rank);
-   a.n_pairs = (int32_t *)(w + o_cnt[0]), a.n_complete = (int32_t *)(w + o_cnt[1]), a.n_single = (int32_t *)(w + o_cnt[2]);
-   a.n_refused = (int32_t *)(w + o_cnt[3]), a.n_orphan = (int32_t *)(w + o_cnt[4]);
-   a.n_lfeat = (int32_t *)(w + o_cnt[5]), a.n_rfeat = (int32_t *)(w + o_cnt[6]);
-   a.flags_out = (int32_t *)(w + o_flag);
-   const unsigned grid = (unsigned)std::min<int64_t>(n_loci, (int64_t)sb::ctx_cu_count(c) * 4);
-   const unsigned grid_small = (unsigned)std::min<int64_t>(n_loci, (int64_t)sb::ctx_cu_count(c) * 32);
-   const unsigned grid_mid = (unsigned)std::min<int64_t>(n_loci, (int64_t)sb::ctx_cu_count(c) * 12);
-   sb::MateBigArgs b = {};
-   hipStream_t side = sb::ctx_aux_stream(c, 3);
-   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-   if (n_big) { // first: they are the long ones
-      SB_TRY(hipMemcpyAsync(w + o_bloci, big_loci.data(), n_big * 4, hipMemcpyHostToDevice, s));
-      SB_TRY(hipMemcpyAsync(w + o_boff, big_off.data(), (n_big + 1) * 8, hipMemcpyHostToDevice, s));
-      b.n_big = (int32_t)n_big;
-      b.loci = (const int32_t *)(w + o_bloci);
-      b.big_off = (const int64_t *)(w + o_boff);
-      b.key = (unsigned long long *)(w + o_bkey);
-      b.idx = (int *)(w + o_bidx);
-      b.cl = (int *)(w + o_bcl);
-      b.cr = (int *)(w + o_bcr);
-      // on a side stream of the context, beside the LDS kernels below; joined before the counts are read
-      SB_TRY(sb::ctx_event(c, 0, &ev_fork));
-      SB_TRY(sb::ctx_event(c, 1, &ev_join));
-      SB_TRY(hipEventRecord(ev_fork, s));
-      SB_TRY(hipStreamWaitEvent(side, ev_fork, 0));
-      hipLaunchKernelGGL(sb::matepair_big_kernel, dim3((unsigned)std::min<size_t>(n_big, (size_t)sb::ctx_cu_count(c) * 2)), dim3(sb::kMateBigThreads), 0, side, a, b);
-      SB_TRY(hipGetLastError());
-      SB_TRY(hipEventRecord(ev_join, side));
-   }
-   static const bool one_class = std::getenv("SBGPU_FRONT_ONE_CLASS") && std::atoi(std::getenv("SBGPU_FRONT_ONE_CLASS")) != 0; // (A/B)
-   if (one_class) {
-      hipLaunchKernelGGL((sb::matepair_locus_kernel<sb::kMateMaxReads, -1>), dim3(grid), dim3(sb::kMateThreads), 0, s, a);
-   } else {
-      hipLaunchKernelGGL((sb::matepair_locus_kernel<sb::kMateMaxReads, sb::kMateMidReads>), dim3(grid), dim3(sb::kMateThreads), 0, s, a);
-      hipLaunchKernelGGL((sb::matepair_locus_kernel<sb::kMateMidReads, sb::kMateSmallReads>), dim3(grid_mid), dim3(sb::kMateThreads), 0, s, a);
-      hipLaunchKernelGGL((sb::matepair_locus_kernel<sb::kMateSmallReads, -1>), dim3(grid_small), dim3(sb::kMateThreads), 0, s, a);
-   }
-   SB_TRY(hipGetLastError());
-   if (n_big) SB_TRY(hipStreamWaitEvent(s, ev_join, 0));
-   std::vector<int32_t> cnt[7];
-   for (int k = 0; k < 7; ++k) {
-      cnt[k].resize((size_t)n_loci);
-      SB_TRY(hipMemcpyAsync(cnt[k].data(), w + o_cnt[k], (size_t)n_loci * 4, hipMemcpyDeviceToHost, s));
-   }
-   int32_t flags = 0;
-   SB_TRY(hipMemcpyAsync(&flags, w + o_flag, 4, hipMemcpyDeviceToHost, s));
-   SB_TRY(hipStreamSynchronize(s));
-   if (flags) {
-      std::string why = "sbgpu_pair_mates_device: not covered by the device form:";
-      if (flags & sb::kMateOpenOverflow) why += " more than 8 mates of one read id wait at a time;";
-      return bail(SBGPU_EUNSUPPORTED, why + " use sbgpu_pair_mates_host");
-   }
-   std::vector<int64_t> lbase((size_t)n_loci + 1, 0), rbase((size_t)n_loci + 1, 0);
-   for (int64_t l = 0; l < n_loci; ++l) {
-      M->locus_pair_off[(size_t)l + 1] = M->locus_pair_off[(size_t)l] + cnt[0][(size_t)l];
-      lbase[(size_t)l + 1] = lbase[(size_t)l] + cnt[5][(size_t)l];
-      rbase[(size_t)l + 1] = rbase[(size_t)l] + cnt[6][(size_t)l];
-      M->n_complete += cnt[1][(size_t)l];
-      M->n_single += cnt[2][(size_t)l];
-      M->n_refused += cnt[3][(size_t)l];
-      M->n_orphan += cnt[4][(size_t)l];
-   }
-   M->n_pairs = M->locus_pair_off[(size_t)n_loci];
-   M->n_lfeat = lbase[(size_t)n_loci];
-   M->n_rfeat = rbase[(size_t)n_loci];
-   // ---- the pairs' own arena
-   const size_t np1 = (size_t)M->n_pairs + 1, nlf = (size_t)M->n_lfeat + 1, nrf = (size_t)M->n_rfeat + 1;
-   size_t t = 0;
-   const size_t u_mass = t; t += up256(np1 * 8);
-   const size_t u_loff = t; t += up256(np1 * 8);
-   const size_t u_roff = t; t += up256(np1 * 8);
-   const size_t u_ll = t; t += up256(nlf * 4);
-   const size_t u_lr = t; t += up256(nlf * 4);
-   const size_t u_rl = t; t += up256(nrf * 4);
-   const size_t u_rr = t; t += up256(nrf * 4);
-   const size_t u_lc = t; t += up256(nlf);
-   const size_t u_rc = t; t += up256(nrf);
-   SB_TRY(sb::dev_take(t, &M->arena, &M->arena_cap));
-   M->d_mass = (double *)(M->arena + u_mass);
-   M->d_left_off = (int64_t *)(M->arena + u_loff);
-   M->d_right_off = (int64_t *)(M->arena + u_roff);
-   M->d_left_left = (uint32_t *)(M->arena + u_ll), M->d_left_right = (uint32_t *)(M->arena + u_lr);
-   M->d_right_left = (uint32_t *)(M->arena + u_rl), M->d_right_right = (uint32_t *)(M->arena + u_rr);
-   M->d_left_code = (uint8_t *)(M->arena + u_lc), M->d_right_code = (uint8_t *)(M->arena + u_rc);
-   SB_TRY(hipMemcpyAsync(w + o_poff, M->locus_pair_off.data(), nl1 * 8, hipMemcpyHostToDevice, s));
-   SB_TRY(hipMemcpyAsync(w + o_lbase, lbase.data(), nl1 * 8, hipMemcpyHostToDevice, s));
-   SB_TRY(hipMemcpyAsync(w + o_rbase, rbase.data(), nl1 * 8, hipMemcpyHostToDevice, s));
-   SB_TRY(hipMemcpyAsync(M->d_left_off + M->n_pairs, &M->n_lfeat, 8, hipMemcpyHostToDevice, s));
-   SB_TRY(hipMemcpyAsync(M->d_right_off + M->n_pairs, &M->n_rfeat, 8, hipMemcpyHostToDevice, s));
-   a.pair_off = (const int64_t *)(w + o_poff);
-   a.lfeat_base = (const int64_t *)(w + o_lbase);
-   a.rfeat_base = (const int64_t *)(w + o_rbase);
-   a.pair_mass = M->d_mass;
-   a.left_off = M->d_left_off, a.right_off = M->d_right_off;
-   a.left_code = M->d_left_code, a.right_code = M->d_right_code;
-   a.left_left = M->d_left_left, a.left_right = M->d_left_right;
-   a.right_left = M->d_right_left, a.right_right = M->d_right_right;
-   if (n_big) {
-      SB_TRY(hipEventRecord(ev_fork, s)); // (behind the uploads above)
-      SB_TRY(hipStreamWaitEvent(side, ev_fork, 0));
-      hipLaunchKernelGGL(sb::matepair_big_fill_kernel, dim3((unsigned)std::min<size_t>(n_big, (size_t)sb::ctx_cu_count(c) * 2)), dim3(sb::kMateBigThreads), 0, side, a, b);
-      SB_TRY(hipGetLastError());
-      SB_TRY(hipEventRecord(ev_join, side));
-   }
-   if (one_class) {
-      hipLaunchKernelGGL((sb::matepair_fill_kernel<sb::kMateMaxReads, -1>), dim3(grid), dim3(sb::kMateThreads), 0, s, a);
-   } else {
-      hipLaunchKernelGGL((sb::matepair_fill_kernel<sb::kMateMaxReads, sb::kMateMidReads>), dim3(grid), dim3(sb::kMateThreads), 0, s, a);
-      hipLaunchKernelGGL((sb::matepair_fill_kernel<sb::kMateMidReads, sb::kMateSmallReads>), dim3(grid_mid), dim3(sb::kMateThreads), 0, s, a);
-      hipLaunchKernelGGL((sb::matepair_fill_kernel<sb::kMateSmallReads, -1>), dim3(grid_small), dim3(sb::kMateThreads), 0, s, a);
-   }
-   SB_TRY(hipGetLastError());
-   if (n_big) SB_TRY(hipStreamWaitEvent(s, ev_join, 0));
-   SB_TRY(hipStreamSynchronize(s)); // the scratch goes away
-#undef SB_TRY
-   (void)hipFree(w);
    *out = M;
    return SBGPU_OK;
 }

@@ -572,7 +572,7 @@ int sbgpu_init(int device, sbgpu_ctx_t **ctx_out)
    // (SBGPU_STREAM_PRIORITY=0 turns that off; A/B measurements).
    int prio_least = 0, prio_greatest = 0;
    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-   const bool use_prio = !(std::getenv("SBGPU_STREAM_PRIORITY") && std::atoi(std::getenv("SBGPU_STREAM_PRIORITY")) == 0);
+   const bool use_prio = !(sb::exp_env("SBGPU_STREAM_PRIORITY") && std::atoi(sb::exp_env("SBGPU_STREAM_PRIORITY")) == 0);
    for (int i = 0; e == hipSuccess && i < kAuxStreams; ++i) {
       const bool long_kind = i == kKindStream[sb::kNumKinds - 1] || i == kKindStream[sb::kNumKinds - 2] || i == kKindStream[sb::kNumKinds - 3];
       e = hipStreamCreateWithPriority(&c->aux[i], hipStreamNonBlocking, (use_prio && long_kind) ? prio_greatest : 0);
@@ -675,11 +675,11 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
    p->ctx = c;
    const char *err = "";
    sb::PlanTuning tune;
-   if (const char *e = std::getenv("SBGPU_WAVE_RMULT")) tune.wave_rmult = std::atoi(e);
-   if (const char *e = std::getenv("SBGPU_MAX_WAVES")) tune.max_waves = std::atoll(e);
-   if (const char *e = std::getenv("SBGPU_LIGHT_BLOCK")) tune.light_block = std::atoi(e) != 0;
-   if (const char *e = std::getenv("SBGPU_ORDER")) tune.order_by_work = std::string(e) == "work";
-   if (const char *e = std::getenv("SBGPU_CLASS_ORDER")) tune.classes_by_prediction = std::string(e) != "cost";
+   if (const char *e = sb::exp_env("SBGPU_WAVE_RMULT")) tune.wave_rmult = std::atoi(e);
+   if (const char *e = sb::exp_env("SBGPU_MAX_WAVES")) tune.max_waves = std::atoll(e);
+   if (const char *e = sb::exp_env("SBGPU_LIGHT_BLOCK")) tune.light_block = std::atoi(e) != 0;
+   if (const char *e = sb::exp_env("SBGPU_ORDER")) tune.order_by_work = std::string(e) == "work";
+   if (const char *e = sb::exp_env("SBGPU_CLASS_ORDER")) tune.classes_by_prediction = std::string(e) != "cost";
    // SBGPU_PHASES="32,128,512": iteration limits at which the wave kind's loci are suspended and continue in
    // lane-rich layouts ("0" or "": one phase); SBGPU_PHASE_LAMBDA="8,2,0.25": the later phases' lane weights
    auto parse_list = [](const char *ev, auto conv, auto *out) {
@@ -692,12 +692,12 @@ int sbgpu_plan_create(sbgpu_ctx_t *c, int64_t n_loci, const int64_t *row_off, co
          pos = q + 1;
       }
    };
-   if (const char *e = std::getenv("SBGPU_PHASES")) {
+   if (const char *e = sb::exp_env("SBGPU_PHASES")) {
       tune.phases_auto = false;
       parse_list(e, [](const std::string &t) { return std::atoi(t.c_str()); }, &tune.phase_limits);
    }
    // a lane weight "t" makes the phase re-pack its survivors into their phase-0 layouts instead ("tile" phases)
-   if (const char *e = std::getenv("SBGPU_PHASE_LAMBDA"))
+   if (const char *e = sb::exp_env("SBGPU_PHASE_LAMBDA"))
       parse_list(e, [](const std::string &t) { return (!t.empty() && (t[0] == 't' || t[0] == 'T')) ? -1.0 : std::atof(t.c_str()); }, &tune.phase_lambda);
    const bool timing = std::getenv("SBGPU_HOST_TIMING") != nullptr; // diagnostic: stage times on stderr
    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1013,7 +1013,7 @@ static int em_run_impl(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_c
    // SBGPU_WAVE_ON_MAIN=1: the wave kinds (stream slot 0: the kinds that end last) run on the caller's stream itself, so
    // that neither their start nor the epilogue behind them waits for an event to cross hardware queues; the other
    // kinds fork off and join as before
-   static const bool wave_on_main = std::getenv("SBGPU_WAVE_ON_MAIN") && std::atoi(std::getenv("SBGPU_WAVE_ON_MAIN")) != 0;
+   static const bool wave_on_main = sb::exp_env("SBGPU_WAVE_ON_MAIN") && std::atoi(sb::exp_env("SBGPU_WAVE_ON_MAIN")) != 0;
    auto stream_of = [&](int k) -> hipStream_t { return (!fork || (wave_on_main && kKindStream[k] == 0)) ? main : c->aux[kKindStream[k]]; };
    if (fork) {
       HIP_TRY(hipEventRecord(c->fork, main));
@@ -1047,8 +1047,8 @@ static int em_run_impl(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_c
       // few microseconds of the block kind, in either order).  So every kind is held back a few microseconds behind
       // the next heavier one: tall, block (+SBGPU_BLOCK_DELAY_US), wave (+SBGPU_WAVE_DELAY_US more); 0 = off.
       // C3: 1.49 -> 1.45 ms per step with the wave delay at 5 (no better at 10-40).
-      static const int wave_delay_us = std::getenv("SBGPU_WAVE_DELAY_US") ? std::atoi(std::getenv("SBGPU_WAVE_DELAY_US")) : 5;
-      static const int block_delay_us = std::getenv("SBGPU_BLOCK_DELAY_US") ? std::atoi(std::getenv("SBGPU_BLOCK_DELAY_US")) : 5;
+      static const int wave_delay_us = sb::exp_env("SBGPU_WAVE_DELAY_US") ? std::atoi(sb::exp_env("SBGPU_WAVE_DELAY_US")) : 5;
+      static const int block_delay_us = sb::exp_env("SBGPU_BLOCK_DELAY_US") ? std::atoi(sb::exp_env("SBGPU_BLOCK_DELAY_US")) : 5;
       const bool tall_runs = p->launches[sb::kBlockTall].n_classes > 0;
       int hold_us = 0;
       if (fork && k == sb::kBlock && tall_runs) hold_us = block_delay_us;
@@ -1169,7 +1169,7 @@ extern "C" {
 int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_count, const double *d_F,
                         double *d_theta, int32_t *d_status, int32_t *d_iters, void *stream)
 {
-   static const bool use_graph = std::getenv("SBGPU_GRAPH") && std::atoi(std::getenv("SBGPU_GRAPH")) != 0;
+   static const bool use_graph = sb::exp_env("SBGPU_GRAPH") && std::atoi(sb::exp_env("SBGPU_GRAPH")) != 0;
    if (!use_graph || !c || !p || c->timing || p->n_wide_desc) // (cooperative launches and timing events stay outside)
       return em_run_impl(c, p, d_count, d_F, d_theta, d_status, d_iters, stream, false);
    const void *key[6] = {d_count, d_F, d_theta, d_status, d_iters, stream};

@@ -248,6 +248,19 @@ def test_wide_kernel_tiny_denominators_are_not_zero_denominators(ctx, oracle):
     assert theta_err(r["theta"], o_theta).max() < THETA_RTOL
 
 
+def _experiments_build():
+    from strawberry_amd import _lib
+    return _lib.load().sbgpu_build_id().decode().endswith("-exp")
+
+
+# The schedule / phase switches are experiment switches (csrc/api_internal.h: sb::exp_env): the shipped library does not read
+# them.  These tests run against the experiments build: `make -C strawberry_amd/csrc experiments`, then
+# SBGPU_LIB=strawberry_amd/lib/libsbgpu_exp.so python -m pytest tests/test_em_gpu.py -m gpu -k "phased or lane_rich or every_schedule"
+# (profiles/r06_pytest_gpu_experiments.txt).
+needs_experiments = pytest.mark.skipif("not _experiments_build()", reason="experiment switches: SBGPU_LIB=.../libsbgpu_exp.so (make experiments)")
+
+
+@needs_experiments
 def test_gpu_phased_execution_matches_oracle(ctx, oracle, monkeypatch):
     """Phases of the wave kind: loci still running at an iteration limit are suspended (theta and the iteration
     count are their whole state) and continue in a later launch with MORE lanes per locus (lane-rich layouts,
@@ -275,6 +288,7 @@ def test_gpu_phased_execution_matches_oracle(ctx, oracle, monkeypatch):
         np.testing.assert_array_equal(r1["iters"], r2["iters"])
 
 
+@needs_experiments
 def test_gpu_lane_rich_layouts_every_shape(ctx, oracle, monkeypatch):
     """Every lane-rich layout (1-4 columns per lane x 1-16 column lanes x 1-8 rows per lane, 1-64 lanes per
     locus) on shapes of its own: a first phase of 2 iterations hands every locus that is still running to the
@@ -301,6 +315,7 @@ def test_gpu_lane_rich_layouts_every_shape(ctx, oracle, monkeypatch):
         assert theta_err(r["theta"], o_theta).max() < THETA_RTOL, lam
 
 
+@needs_experiments
 @pytest.mark.parametrize("env", [{"SBGPU_WAVE_RMULT": "1"}, {"SBGPU_WAVE_RMULT": "2"}, {"SBGPU_WAVE_RMULT": "4"},
                                  {"SBGPU_LIGHT_BLOCK": "1"}, {"SBGPU_MAX_WAVES": "64"}])
 def test_gpu_every_schedule_gives_the_same_answer(ctx, oracle, monkeypatch, env):

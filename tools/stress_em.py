@@ -24,7 +24,9 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 8):
     r = s.results()
     th, st, it = o.em_batch(b.row_off, b.iso_off, b.f_off, b.count, b.F, threads=64)
     ok_st = (r["status"] == st)
-    ok_it = (r["iters"] == it)
+    # (the iteration count of a FAILED solve -- status 2, a denominator flushed to zero -- is unspecified within one iteration:
+    # include/sbgpu.h at sbgpu_em_run_device; theta and status are compared for every locus)
+    ok_it = (r["iters"] == it) | ((st == 2) & (r["status"] == 2) & (np.abs(r["iters"] - it) <= 1))
     err = np.abs(r["theta"] - th) / np.maximum(np.abs(th), 1e-9)
     kinds = np.bincount(s.plan.locus_kinds(), minlength=6)
     nbad = int((~ok_st).sum() + (~ok_it).sum())
