@@ -515,6 +515,11 @@ def front_main(args, ctx, dev, rank, world, sdist, torch, launch, comm=None):
         probe.append(dict(q.stage_wall_ms))
     stage = {k: float(np.median([p[k] for p in probe])) for k in front.FrontQuantifier.STAGES}
     chain_stage = q.stage_ms()    # the chain's kernels inside the last stage (HIP events)
+    filtered = None
+    if not args.no_cpu_baseline:
+        # the loci the reference's span filter touched, at full size, against the oracle's collapse (and the chain on its hits)
+        from oracle import OracleLib
+        filtered = q.check_filtered_loci(OracleLib())
     with_chain = q.compare_with_chain()
     c = q.counts
     n_rec, acc, feats = c["records"], c["accepted_records"], c["features"]
@@ -568,6 +573,9 @@ def front_main(args, ctx, dev, rank, world, sdist, torch, launch, comm=None):
                       "denom_zero": int((q.status[:q.n_loci] == 2).sum()), "maxiter": int((q.status[:q.n_loci] == 3).sum()),
                       "mean_iters": float(q.iters[:q.n_loci].mean())},
         "roofline": roof,
+        "parity_of_the_span_filtered_loci": dict(filtered or {}, what="the clusters in which the reference's span filter (alignments.cpp:666-682) dropped pairs: "
+                                                 "the sample's pairs through oracle/collapse_oracle.c, then sbgpu_quantify_resident on the oracle's unique hits of those loci alone under "
+                                                 "the pass' law and total: hit counts and theta / status / iterations / FPKM / Frac / keep of the records -> TPM pass, bit for bit"),
         "parity_with_chain": dict(with_chain, what="theta / status / iterations of the records -> theta pass against sbgpu_quantify_device on the "
                                   "sample's own unique hits (c3-chain), locus by locus: bit for bit wherever the reference's span filter "
                                   "(alignments.cpp:666-682) dropped no pair", unique_hits_front=c["unique_hits"], unique_hits_sample=q.n_hits),
@@ -577,6 +585,8 @@ def front_main(args, ctx, dev, rank, world, sdist, torch, launch, comm=None):
     print(json.dumps(out))
     if not with_chain["ok"]:
         raise SystemExit("bench.py: the records -> theta pass does not reproduce the chain's theta on the same sample")
+    if filtered is not None and not filtered["ok"]:
+        raise SystemExit("bench.py: the span-filtered loci do not match the oracle: %r" % (filtered,))
     if out.get("parity") and not out["parity"]["ok"]:
         raise SystemExit("bench.py: theta does not match the reference program's: %r" % out["parity"])
 

@@ -304,6 +304,76 @@ class FrontQuantifier(ChainQuantifier):
                            unique_hits=self.stream_info["unique_hits"])
         return self.stream_info
 
+    def check_filtered_loci(self, oracle, max_pairs=3_000_000):
+        """After a resident step(): the loci whose unique hits differ from the sample's -- the reference's span filter
+        (HitCluster::collapseAndFilterHits, alignments.cpp:666-682) dropped pairs there, which compare_with_chain can only count --
+        against the ORACLE: the sample's read pairs of each such cluster go through oracle/collapse_oracle.c (pinned on the
+        reference's own HitCluster), its unique hits must be as many as the front's, and the chain on exactly those hits -- the
+        affected loci alone, under the law and the mapped-read total the pass ended with -- must give the front's theta, status,
+        iterations, FPKM, Frac and keep bit for bit.  Test infrastructure: `oracle` is oracle.OracleLib (bench.py's parity leg,
+        tests).  -> dict."""
+        from .binweight import InsertSize
+        from .quantify import quantify_resident
+        a, smp = self.annot, self.sample
+        loci = np.nonzero(np.diff(self.front_hit_off) != np.diff(smp.locus_hit_off))[0]
+        out = {"loci": int(len(loci)), "pairs_through_the_oracle": 0, "pairs_the_oracle_dropped": 0, "ok": True}
+        if not len(loci):
+            return out
+        sub_loci, hit_locus, feats, masses, taken = [], [], [], [], []
+        for l in loci.tolist():
+            h0, h1 = int(smp.locus_hit_off[l]), int(smp.locus_hit_off[l + 1])
+            foff = smp.feat_off[h0:h1 + 1].cpu().numpy()
+            f0, f1 = int(foff[0]), int(foff[-1])
+            code = smp.feat_code[f0:f1].cpu().numpy()
+            fl, fr = smp.feat_left[f0:f1].cpu().numpy().view(np.uint32), smp.feat_right[f0:f1].cpu().numpy().view(np.uint32)
+            mass = smp.mass[h0:h1].cpu().numpy().astype(np.int64)
+            if out["pairs_through_the_oracle"] + int(mass.sum()) > max_pairs:
+                out["skipped_for_size"] = out.get("skipped_for_size", 0) + 1
+                continue
+            lb, rb, owner = [], [], []
+            for h in range(h1 - h0):
+                s0, s1 = int(foff[h] - f0), int(foff[h + 1] - f0)
+                gap = s0 + int(np.nonzero(code[s0:s1] == eb.GAP)[0][0])
+                lm = [(int(fl[i]), int(fr[i])) for i in range(s0, gap) if code[i] == eb.MATCH]
+                rm = [(int(fl[i]), int(fr[i])) for i in range(gap + 1, s1) if code[i] == eb.MATCH]
+                m = int(mass[h])
+                lb += [lm] * m
+                rb += [rm] * m
+                owner += [h] * m
+            uniq_pair, uniq_mass, _, n_filtered = oracle.collapse_cluster(lb, rb, [1] * len(lb))
+            out["pairs_through_the_oracle"] += len(lb)
+            out["pairs_the_oracle_dropped"] += int(n_filtered)
+            kept = [owner[int(p)] for p in uniq_pair]
+            if len(kept) != int(self.front_hit_off[l + 1] - self.front_hit_off[l]):
+                out["ok"] = False
+                out.setdefault("hit_count_mismatch", []).append(int(l))
+            j0 = int(a.iso_off[l])
+            taken.append(int(l))
+            sub_loci.append([[(int(a.exon_left[e]), int(a.exon_right[e])) for e in range(int(a.exon_off[j]), int(a.exon_off[j + 1]))]
+                             for j in range(j0, int(a.iso_off[l + 1]))])
+            for h, um in zip(kept, uniq_mass):
+                s0, s1 = int(foff[h] - f0), int(foff[h + 1] - f0)
+                hit_locus.append(len(sub_loci) - 1)
+                feats.append((code[s0:s1].tolist(), fl[s0:s1].tolist(), fr[s0:s1].tolist()))
+                masses.append(float(um))
+        if not sub_loci:
+            return out
+        sub = eb.Annotation(sub_loci)
+        hits = eb.Hits(hit_locus, feats, masses)
+        law = InsertSize.from_hist(self.law["start_offset"], self.law["emp_hist"]) if self.law["use_emp"] else self.insert
+        r = quantify_resident(sub, hits, law, self.read_len, self.total_mapped_reads, ctx=self.ctx)
+        j = 0
+        for used, l in enumerate(taken):
+            n, g0 = int(a.iso_off[l + 1] - a.iso_off[l]), int(a.iso_off[l])
+            same = all(np.array_equal(getattr(self, k)[g0:g0 + n], r[k][j:j + n]) for k in ("theta", "fpkm", "frac", "keep"))
+            same = same and int(self.status[l]) == int(r["status"][used]) and int(self.iters[l]) == int(r["iters"][used])
+            if not same:
+                out["ok"] = False
+                out.setdefault("theta_mismatch", []).append(int(l))
+            j += n
+        out["loci_checked"] = len(taken)
+        return out
+
     @staticmethod
     def stream_parts(parts, empirical=True, comm=None, min_isoform_frac=0.0):
         """Several samples (FrontQuantifiers brought to_host with ref_id 0, 1, ...) pushed one after the other as ONE stream: a

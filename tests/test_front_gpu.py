@@ -103,3 +103,18 @@ def test_records_from_host_in_chunks_equal_the_resident_pass():
         with pytest.raises(_lib.SbgpuError, match="exceed a chunk"):
             q.stream_step()
         q.close()
+
+
+def test_span_filtered_loci_against_the_oracle():
+    """Where the reference's span filter dropped pairs the front's unique hits differ from the sample's, and compare_with_chain can
+    only count them: those clusters' pairs go through the oracle's collapse instead, and the chain on the oracle's hits must be the
+    front's theta / FPKM on those loci, bit for bit (FrontQuantifier.check_filtered_loci; at full size inside bench.py --workload c3-front)."""
+    from oracle import OracleLib
+    from strawberry_amd import em, front
+    ctx = em.default_context(0)
+    q = front.FrontQuantifier(ctx, n_loci=2500, n_frags=2.5e6, seed=44, resident=True, empirical=True)
+    q.step()
+    r = q.check_filtered_loci(OracleLib())
+    assert r["ok"] and r["loci"] >= 1 and r["loci_checked"] == r["loci"], r
+    assert r["pairs_the_oracle_dropped"] == q.counts["pairs_dropped_by_the_span_filter"] > 0, (r, q.counts)
+    q.close()
