@@ -306,10 +306,11 @@ def chain_leg(args, ctx, dev, rank, world, sdist, torch, strong=False, with_cpu=
     per_rank = None
     if world > 1:   # every rank's own K steps (before it waits for the others), its loci and unique hits
         per_rank = sdist.gather_values([timed_steps.own_wall / args.steps * 1e3, q.n_loci, q.n_hits], rank, world, device=dev)
+    stage = q.stage_ms()      # (one more step, EVERY rank: the step's collectives are inside sbgpu_quantify_resident)
     if rank != 0:
+        q.close()
         return None
     ms = wall / args.steps * 1e3
-    stage = q.stage_ms()
     feats = q.hits.n_features / max(q.n_hits, 1)
     cw, kw = q.annot.compat_words, q.annot.key_words
     info = q.info or {}

@@ -20,22 +20,40 @@ def env_world():
 
 def init_process_group(backend=None):
     """Initialise torch.distributed from the environment when WORLD_SIZE > 1."""
+    import datetime
     import torch
     import torch.distributed as dist
     rank, world, local_rank = env_world()
+    # a rank that leaves the others in a collective must fail the job in minutes, not in the half hour of the default
+    tmo = datetime.timedelta(seconds=float(os.environ.get("SB_DIST_TIMEOUT_S", "600")))
     if world > 1 and not dist.is_initialized():
-        if backend is None:
-            backend = os.environ.get("SB_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        if backend == "nccl":
-            local_rank = local_rank % max(1, torch.cuda.device_count())
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend, rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        # (the rendezvous may print banners -- gloo's "Rank 1 is connected to 1 peer ranks" -- on STDOUT, which belongs to the one
+        # JSON line of bench.py: file descriptor 1 points at stderr while the group is made)
+        import sys
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            local_rank = _init_group(dist, torch, backend, rank, world, local_rank, tmo)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     return rank, world, local_rank
+
+
+def _init_group(dist, torch, backend, rank, world, local_rank, tmo):
+    if backend is None:
+        backend = os.environ.get("SB_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if backend == "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo, device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
+    return local_rank
 
 
 def predicted_iterations(nrow, niso):
