@@ -10,6 +10,10 @@
 //   sbgpu_pair_mates_device        HitCluster::addOpenHit / addHit                           (alignments.cpp:423-655)
 //   sbgpu_collapse_pairs_device    HitCluster::collapseAndFilterHits + Contig(PairedHit)     (alignments.cpp:656-703)
 //   sbgpu_quantify_host            LocusContext's constructor + estimate_abundances          (estimate.hpp:60-109, estimate.cpp:135-355)
+//                                  -- with -f (the table needs every hit's bin and the weights on the host); WITHOUT -f the
+//                                  program stays RESIDENT (round 6): the unique hits never leave the device, preProcess ends in
+//   sbgpu_quantify_resident        pass 1 on the device (the empirical insert-size law when no -i was given), bins, weights, EM,
+//                                  FPKM / Frac / keep / TPM; procSample only prints
 // The clusters (which transcripts form a locus, in which order) come from the reference's own Sample::addRef2Cluster; the GTF
 // is written by the reference's own Contig::print2gtf, the -f table by sbgpu_format_context_row.
 //
@@ -66,6 +70,10 @@ struct Front {
    std::vector<Locus> loci;
    sbgpu::LocusBatch batch; // annotation + unique hits (host copies)
    double t_inflate = 0, t_decode = 0, t_front = 0;
+   // resident mode (no -f): what sbgpu_quantify_resident left on the host
+   bool resident = false;
+   std::vector<double> r_theta, r_fpkm, r_frac, r_tpm;
+   std::vector<int32_t> r_keep, r_status;
 };
 Front &front()
 {
@@ -265,6 +273,71 @@ void Sample::preProcess(FILE *log)
       }
       B.add_locus(tx);
    }
+   // ---- without -f nothing but the abundances is wanted: the unique hits stay where they are (round 6)
+   if (!print_frag_context && ui[0] > 0) {
+      const int64_t nl = n_loci;
+      B.seg_off.assign((size_t)nl + 1, 0);
+      int64_t ns = sbgpu_segments_host(nl, B.iso_off.data(), B.exon_off.data(), B.exon_left.data(), B.exon_right.data(), B.seg_off.data(), nullptr,
+                                       nullptr, 0);
+      sbgpu::check((int)(ns < 0 ? ns : 0), "sbgpu_segments_host");
+      B.seg_left.assign((size_t)ns + 1, 0);
+      B.seg_right.assign((size_t)ns + 1, 0);
+      sbgpu_segments_host(nl, B.iso_off.data(), B.exon_off.data(), B.exon_left.data(), B.exon_right.data(), B.seg_off.data(), B.seg_left.data(),
+                          B.seg_right.data(), ns);
+      sbgpu_annotation_t an = B.annotation();
+      sbgpu_hits_t dh;
+      const float *d_mass = nullptr;
+      const int64_t *hoff = nullptr;
+      sbgpu::check(sbgpu_uniq_dev_hits(uq, &dh, &d_mass, &hoff), "sbgpu_uniq_dev_hits");
+      // the law main will make AFTER this function (Strawberry.cpp:329-356): N(200, 80) for a single-end library, -i's, or --
+      // the default -- the empirical one of pass 1, which the device builds (insert == NULL)
+      sbgpu_insert_t given = {};
+      const sbgpu_insert_t *ins = nullptr;
+      if (long_read_sample || SINGLE_END_EXP) given.mean = 200.0, given.sd = 80.0, ins = &given;
+      else if (kInsertSizeMean != 0 && kInsertSizeSD != 0) given.mean = kInsertSizeMean, given.sd = kInsertSizeSD, ins = &given;
+      sbgpu_abundance_params_t par = {};
+      par.filter_by_expression = filter_by_expression ? 1 : 0;
+      par.min_isoform_frac = kMinIsoformFrac;
+      par.effective_len_norm = effective_len_norm ? 1 : 0;
+      const size_t n_iso = (size_t)B.iso_off.back();
+      F.r_theta.assign(n_iso + 1, 0.0), F.r_fpkm.assign(n_iso + 1, 0.0), F.r_frac.assign(n_iso + 1, 0.0), F.r_tpm.assign(n_iso + 1, 0.0);
+      F.r_keep.assign(n_iso + 1, 0), F.r_status.assign((size_t)nl + 1, 0);
+      sbgpu_abundances_t res = {};
+      res.theta = F.r_theta.data(), res.fpkm = F.r_fpkm.data(), res.frac = F.r_frac.data(), res.tpm = F.r_tpm.data();
+      res.keep = F.r_keep.data(), res.status = F.r_status.data();
+      sbgpu_insert_t used;
+      sbgpu_bins_t *bins = nullptr;
+      const int rc = sbgpu_quantify_resident(ctx.get(), &an, &dh, d_mass, hoff, ins, _hit_factory->_reads_table.read_len_mode(), long_read_sample ? 1 : 0,
+                                             ui[4], &par, nullptr, &used, &res, &bins);
+      if (rc == SBGPU_OK) {
+         F.resident = true;
+         _total_mapped_reads = (int)ui[4]; // fragLenDist's total (alignments.cpp:1372): the sum over the clusters of (int) weighted_mass()
+         if (!ins) // main makes InsertSize(_frag_dist) next: the same sample, length by length (the law's own histogram)
+            for (int32_t l = used.start_offset; l <= used.end_offset; ++l)
+               for (int64_t k = 0; k < (int64_t)used.emp_hist[l - used.start_offset]; ++k) _hit_factory->_reads_table._frag_dist.push_back(l);
+         sbgpu_bins_destroy(bins);
+      } else if (rc != SBGPU_EUNSUPPORTED) { // (declined -- fractional masses, ... --: the host route below serves)
+         sbgpu::check(rc, "sbgpu_quantify_resident");
+      }
+   }
+   if (F.resident) {
+      sbgpu_uniq_dev_destroy(uq);
+      sbgpu_matepairs_destroy(mp);
+      sbgpu_bamreads_destroy(F.reads);
+      F.reads = nullptr;
+      hip_check(hipFree(d_cluster), "hipFree");
+      hip_check(hipFree(F.d_bytes), "hipFree");
+      hip_check(hipFree(F.d_rec_off), "hipFree");
+      F.d_bytes = F.d_rec_off = nullptr;
+      std::vector<uint8_t>().swap(F.raw);
+      for (int64_t l = 0; l < n_loci; ++l) {
+         const Locus &lc = F.loci[(size_t)l];
+         std::fprintf(log, "Finish inspecting locus: %s:%d-%d\n", _hit_factory->_ref_table.ref_real_name(lc.ref_id).c_str(), lc.left, lc.right);
+         std::fprintf(log, "Found %d of ref mRNAs from the reference gtf file.\n", (int)lc.transcripts.size());
+      }
+      F.t_front = secs(t0, clk::now());
+      return;
+   }
    B.hit_locus.assign((size_t)ui[0], 0);
    B.feat_off.assign((size_t)ui[0] + 1, 0);
    B.feat_code.assign((size_t)ui[1], 0);
@@ -337,6 +410,37 @@ void Sample::procSample(FILE *pfile, FILE *plogfile, FILE *fragfile)
    }
    sbgpu::LocusBatch &batch = F.batch;
    const std::vector<Locus> &loci = F.loci;
+   if (F.resident) {
+      // everything was computed in preProcess, on the device: the theta log (estimate.cpp:310-313), quantifyCluster's notice
+      // (alignments.cpp:1531-1532), the isoforms that survive the filter (estimate.cpp:346-355) with the reference's own print2gtf
+      for (int64_t l = 0; l < batch.n_loci(); ++l) {
+         if (F.r_status[(size_t)l] == SBGPU_EM_INIT_EMPTY) continue; // estimate_abundances() false: the locus is omitted
+         const Locus &lc = loci[(size_t)l];
+         const int64_t j0 = batch.iso_off[(size_t)l], niso = batch.iso_off[(size_t)l + 1] - j0;
+         for (int64_t j = 0; j < niso; ++j)
+            std::fprintf(plogfile, "isoform %d has %f raw read count.\n", (int)j + 1, F.r_theta[(size_t)(j0 + j)]);
+         std::cerr << ref_t.ref_real_name(lc.ref_id) << "\t" << lc.left << "\t" << lc.right << " finishes abundances estimation" << std::endl;
+      }
+      for (int64_t l = 0; l < batch.n_loci(); ++l) {
+         if (F.r_status[(size_t)l] == SBGPU_EM_INIT_EMPTY) continue;
+         const Locus &lc = loci[(size_t)l];
+         const int64_t j0 = batch.iso_off[(size_t)l], niso = batch.iso_off[(size_t)l + 1] - j0;
+         for (int64_t j = 0; j < niso; ++j) {
+            const size_t g = (size_t)(j0 + j);
+            if (!F.r_keep[g]) continue;
+            const bool na = F.r_keep[g] == 2; // effective length below zero: "NA" (estimate.cpp:319-322, :338-341)
+            const Contig &t = lc.transcripts[(size_t)j];
+            t.print2gtf(pfile, _hit_factory->_ref_table, na ? std::string("NA") : std::to_string(F.r_fpkm[g]), na ? std::string("NA") : std::to_string(F.r_frac[g]),
+                        std::to_string(F.r_tpm[g]), t.parent_id(), t.annotated_trans_id(), t.ref_gene_id(), t.ref_gene_name());
+         }
+      }
+      const char *timing = std::getenv("SBGPU_DROPIN_TIMING");
+      if (timing && timing[0] == '1')
+         std::fprintf(stderr, "sbgpu_front (resident): inflate + index %.3f s (%lld records) | upload + sbgpu_bam_decode_device + read lengths %.3f s | clusters, "
+                              "stream, pairs, unique hits, pass 1, bins, weights, EM, FPKM, TPM (device) %.3f s | output %.3f s\n",
+                      F.t_inflate, (long long)F.n_records, F.t_decode, F.t_front, secs(t_begin, clk::now()));
+      return;
+   }
    // ---- solve: bins, weights and the EM of all loci in ONE call; the reference's epilogue arithmetic (LocusBatch::quantify)
    sbgpu::InsertSize ins;
    // (a long-read sample has no insert-size law -- main never makes one, Strawberry.cpp:338-353 -- and needs none: its

@@ -3,6 +3,8 @@ reference goldens.  Tolerances: theta within 1e-9 relative (floor 1e-9 fragments
 of the reference -- five orders tighter than the 1e-4 the north star asks of
 FPKM/TPM; status and iteration counts exact."""
 import numpy as np
+import os
+
 import pytest
 
 from conftest import ref_flags_to_status
@@ -253,11 +255,28 @@ def _experiments_build():
     return _lib.load().sbgpu_build_id().decode().endswith("-exp")
 
 
-# The schedule / phase switches are experiment switches (csrc/api_internal.h: sb::exp_env): the shipped library does not read
-# them.  These tests run against the experiments build: `make -C strawberry_amd/csrc experiments`, then
-# SBGPU_LIB=strawberry_amd/lib/libsbgpu_exp.so python -m pytest tests/test_em_gpu.py -m gpu -k "phased or lane_rich or every_schedule"
-# (profiles/r06_pytest_gpu_experiments.txt).
-needs_experiments = pytest.mark.skipif("not _experiments_build()", reason="experiment switches: SBGPU_LIB=.../libsbgpu_exp.so (make experiments)")
+def needs_experiments(test):
+    """The schedule / phase switches are experiment switches (csrc/api_internal.h: sb::exp_env): the shipped library does not read
+    them.  A test that sets them runs its body in a process that loads the EXPERIMENTS build (libsbgpu_exp.so: `make -C
+    strawberry_amd/csrc experiments`, part of __graft_entry__.build()): from a process on the shipped library it starts such a
+    process on itself and passes with it."""
+    import functools
+    import subprocess
+    import sys
+
+    @functools.wraps(test)
+    def wrapper(*args, **kw):
+        if _experiments_build():
+            return test(*args, **kw)
+        lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "strawberry_amd", "lib", "libsbgpu_exp.so")
+        if not os.path.exists(lib):
+            pytest.fail("the experiments build is missing: make -C strawberry_amd/csrc experiments")
+        node = os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0]
+        r = subprocess.run([sys.executable, "-m", "pytest", node, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"],
+                           env=dict(os.environ, SBGPU_LIB=lib), capture_output=True, text=True, timeout=1800,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+    return wrapper
 
 
 @needs_experiments

@@ -116,7 +116,7 @@ def write_sam(directory, path):
     return len(recs)
 
 
-def run_driver(which, tmp_path, driver=DRIVER):
+def run_driver(which, tmp_path, driver=DRIVER, with_f=True):
     directory, extra, insert = RUNS[which]
     sam, bam = str(tmp_path / "toy.sam"), str(tmp_path / "toy.bam")
     n = write_sam(directory, sam)
@@ -132,7 +132,7 @@ def run_driver(which, tmp_path, driver=DRIVER):
         open(str(tmp_path / "genome.fa.fai"), "w").write("%s\t%d\t%d\t60\t61\n" % (lines[0][1:], sum(len(l) for l in lines[1:]), len(lines[0]) + 1))
     annot = [] if which in ASSEMBLY_MODE else ["-g", os.path.join(directory, "toy.gtf"), "-r"]
     cmd = [driver, bam] + annot + (["-i", "250/30"] if insert else []) + [
-        "-o", str(tmp_path / "out.gtf"), "-T", str(tmp_path / "log.txt"), "-f", str(tmp_path / "ctx.tsv")] + extra
+        "-o", str(tmp_path / "out.gtf"), "-T", str(tmp_path / "log.txt")] + (["-f", str(tmp_path / "ctx.tsv")] if with_f else []) + extra
     return subprocess.run(cmd, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
 
 
@@ -147,10 +147,10 @@ def test_reference_driver_over_libsbgpu_has_no_cpu_path(tmp_path):
     assert r.returncode != 0 and "sbgpu_init" in (r.stderr + r.stdout)
 
 
-def check_files(which, tmp_path, r, log_in_locus_order=True):
+def check_files(which, tmp_path, r, log_in_locus_order=True, names=("out.gtf", "ctx.tsv")):
     directory = RUNS[which][0]
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
-    for name in ("out.gtf", "ctx.tsv"):
+    for name in names:
         # (the GTF's first line is a comment holding the program's own command line, temporary paths included)
         got = [l for l in open(str(tmp_path / name), "rb").read().split(b"\n") if not l.startswith(b"#/")]
         want = [l for l in open(os.path.join(directory, name), "rb").read().split(b"\n") if not l.startswith(b"#/")]
@@ -202,6 +202,30 @@ def test_front_level_reference_driver_reproduces_reference_files(which, tmp_path
     from sbgpu_frag_lens_host), both strands, two chromosomes."""
     need_driver(FRONT)
     check_files(which, tmp_path, run_driver(which, tmp_path, FRONT), log_in_locus_order=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", sorted(set(RUNS) - FRONT_NOT_COVERED))
+def test_front_level_reference_driver_resident_without_f(which, tmp_path):
+    """The same program WITHOUT -f (round 6): nothing but the abundances is wanted, so the unique hits never leave the device --
+    the shim's preProcess ends in ONE sbgpu_quantify_resident (pass 1 on the device: the empirical insert-size law of the default
+    mode, E2E_EMP; bins, weights, EM, FPKM / Frac / keep / TPM), main builds its own law from the fragment lengths the law's
+    histogram gives back, procSample only prints.  The GTF and the theta log: the reference binary's, byte for byte (E2E_MASS'
+    fractional masses are declined by the device grouping: that run takes the host route, and says nothing about it)."""
+    need_driver(FRONT)
+    r = run_driver(which, tmp_path, FRONT, with_f=False)
+    check_files(which, tmp_path, r, log_in_locus_order=False, names=("out.gtf",))
+    assert not os.path.exists(str(tmp_path / "ctx.tsv"))
+    if which != "E2E_MASS":
+        env = dict(os.environ, SBGPU_DROPIN_TIMING="1")
+        sam, bam = str(tmp_path / "toy.sam"), str(tmp_path / "toy.bam")
+        directory, extra, insert = RUNS[which]
+        os.remove(str(tmp_path / "out.gtf"))
+        cmd = [FRONT, bam, "-g", os.path.join(directory, "toy.gtf"), "-r"] + (["-i", "250/30"] if insert else []) + [
+            "-o", str(tmp_path / "out.gtf"), "-T", str(tmp_path / "log2.txt")] + extra
+        r2 = subprocess.run(cmd, cwd=str(tmp_path), capture_output=True, text=True, timeout=600, env=env)
+        assert r2.returncode == 0 and "sbgpu_front (resident)" in r2.stderr, r2.stderr[-1500:]
+        del sam
 
 
 @pytest.mark.parametrize("which", sorted(RUNS))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: the round's evidence.  Usage (repo root): bash tools/profile_round.sh r01
 # Everything judged is collected under gpurun_out/$R/summary/ -- copy that directory's files into profiles/.
-R=${1:-r05}
+R=${1:-r06}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/$R
 SUM=$OUT/summary
@@ -80,7 +80,7 @@ cp $SUM/${R}_c3_pmc_summary.json $SUM/${R}_c2_pmc_summary.json $SUM/${R}_c3chain
 (timeout 900 python bench.py --workload c5 --no-cpu-baseline 2>/dev/null) > $SUM/${R}_bench_c5.json
 (timeout 900 python bench.py --workload c3t --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null) > $SUM/${R}_bench_c3t.json
 (timeout 900 python bench.py --workload c3-chain --steps 10 --warmup 3 2>/dev/null) > $SUM/${R}_bench_c3chain.json
-(timeout 900 python bench.py --gpus 2 --steps 10 --warmup 3 --no-chain --no-front 2>/dev/null | tail -1) > $SUM/${R}_bench_c3_2ranks_one_gpu.json
+(SB_DIST_TIMEOUT_S=120 timeout 900 python bench.py --gpus 2 --steps 10 --warmup 3 2>/dev/null | tail -1) > $SUM/${R}_bench_c3_2ranks_one_gpu.json
 bash tools/profile_exonbin.sh $R > /dev/null 2>&1
 cp $OUT/exonbin/summary.json $SUM/${R}_exonbin_summary.json
 cp $OUT/exonbin/stats/eb_kernel_stats.csv $SUM/${R}_exonbin_kernel_stats.csv
@@ -102,15 +102,15 @@ for f in $(find $OUT/stats_frontend -name "*kernel_stats.csv"); do cp $f $SUM/${
 (timeout 600 python tools/bench_host_entry.py 60000 2e8 3 2>/dev/null | tail -1) > $SUM/${R}_host_entry.json
 (timeout 1200 python tools/dropin_timing.py 2>/dev/null) > $SUM/${R}_dropin.txt
 # loci of 65-128 segments: the 128-bit segment basis against the exon walk (kernel rows of two profiled runs)
-(cd /tmp; for z in 1 0; do SBGPU_EXONBIN_SEGBASIS=$z timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_ebbig_$z -o eb -- python3 $REPO/tools/bench_exonbin_big.py > $OUT/stats_ebbig_$z.log 2>&1; done)
-(echo "# 1500 loci of ~98 segments, 4.5 M hits (tools/bench_exonbin_big.py under rocprofv3 --kernel-trace --stats): kernel rows"; echo "## 128-bit segment basis (default)"; python3 tools/kernel_stats.py $OUT/stats_ebbig_1 6 | grep sb::; echo "## exon walk everywhere (SBGPU_EXONBIN_SEGBASIS=0)"; python3 tools/kernel_stats.py $OUT/stats_ebbig_0 4 | grep sb::) > $SUM/${R}_exonbin_big_loci.txt
+(cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_ebbig_1 -o eb -- python3 $REPO/tools/bench_exonbin_big.py > $OUT/stats_ebbig_1.log 2>&1)
+(echo "# 1500 loci of ~98 segments, 4.5 M hits (tools/bench_exonbin_big.py under rocprofv3 --kernel-trace --stats): kernel rows, 128-bit segment basis"; python3 tools/kernel_stats.py $OUT/stats_ebbig_1 6 | grep sb::) > $SUM/${R}_exonbin_big_loci.txt
 # BAM records -> the read stream: the bench line and its kernel rows
 (timeout 300 python tools/bench_bamdecode.py 4e6 2>/dev/null | tail -1) > $SUM/${R}_bamdecode.json
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bamdecode -o bd -- python3 $REPO/tools/bench_bamdecode.py 4e6 --no-cpu-baseline > $OUT/stats_bamdecode.log 2>&1)
 for f in $(find $OUT/stats_bamdecode -name "*kernel_stats.csv"); do cp $f $SUM/${R}_bamdecode_kernel_stats.csv; done
 # round 5: strong-scaling shards a rank at a time (EM kinds, plan settings of a small shard, the chain's shards); records -> theta
 # (c3-front) with its kernel rows; instructions per algorithmic FMA of the tile kernels by layout; a full wide-locus tile's counters
-((timeout 600 python tools/probe_strong_kinds.py; echo; echo "# the world-8 shards under plan settings that trade lanes for iteration latency (tools/probe_strong_small.py)"; timeout 600 python tools/probe_strong_small.py 8; echo; echo "# the CHAIN's shards (tools/probe_strong_chain.py)"; timeout 900 python tools/probe_strong_chain.py) 2>/dev/null | grep -v amdgpu.ids) > $SUM/${R}_strong_shards.txt
+((timeout 600 python tools/probe_strong_kinds.py; echo; echo "# the CHAIN's shards (tools/probe_strong_chain.py)"; timeout 900 python tools/probe_strong_chain.py) 2>/dev/null | grep -v amdgpu.ids) > $SUM/${R}_strong_shards.txt
 ((echo "# records -> theta (bench.py --workload c3-front --gpus N), a rank at a time (tools/probe_strong_front.py)"; timeout 1200 python tools/probe_strong_front.py 2>/dev/null | grep world) > $SUM/${R}_strong_shards_front.txt)
 (cd /tmp && timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/stats_front_$R -o fr -- python3 $REPO/bench.py --workload c3-front --steps 2 --warmup 1 --no-cpu-baseline > /tmp/stats_front_$R.log 2>&1)
 for f in $(find /tmp/stats_front_$R -name "*kernel_stats.csv"); do cp $f $SUM/${R}_c3front_kernel_stats.csv; done
@@ -134,6 +134,9 @@ json.dump(summary, open("%s/%s_c3front_pmc_summary.json" % (summ, r), "w"), inde
 PY
 cp $SUM/${R}_c3front_pmc_summary.json $REPO/profiles/ 2>/dev/null
 (timeout 1500 python bench.py --workload c3-front --steps 5 --warmup 2 2>/dev/null | tail -1) > $SUM/${R}_bench_c3front.json
+# round 6: the records start in HOST memory (sbgpu_front_stream_*): C3's sample, and config 5's size (4e8 read pairs, two parts)
+(timeout 900 python bench.py --workload c3-front --from-host --steps 3 2>/dev/null | tail -1) > $SUM/${R}_bench_c3front_fromhost.json
+(SB_FRONT_FRAGS=4e8 timeout 1200 python bench.py --workload c3-front --from-host --steps 2 2>/dev/null | tail -1) > $SUM/${R}_bench_c5size_fromhost.json
 bash tools/pmc_em_layouts.sh > $SUM/${R}_em_layout_instr.txt 2>&1
 (bash tools/pmc_wide_one.sh 2>&1 | grep "^gpurun_out/pmcw") > $SUM/${R}_wide_tile_pmc.txt
 # random stress on this build (tails; the library's build id on top)
