@@ -227,3 +227,59 @@ def test_records_to_tpm_sharded_over_two_ranks(tmp_path, ctx):
         tpm_sum += z["tpm"].sum()
         q.close()
     assert abs(tpm_sum - 1e6) < 1e-3
+
+
+def test_pass_one_on_loci_of_many_isoforms(ctx):
+    """The device's pass 1 reads the compat words of a hit as its locus' isoform count says: loci of 33-70 isoforms have two and
+    three words per hit (bits beyond the locus' last isoform are not isoforms), waves whose 64 hits straddle loci gather instead
+    of walking one locus' table, and a locus of more than 63 isoforms or 64 exons takes the scalar walk: the law must be the host
+    form's, bitwise, on an annotation that mixes them with small loci."""
+    from strawberry_amd import exonbin as eb
+    from strawberry_amd.quantify import quantify_resident
+    rng = np.random.default_rng(314)
+    loci, base = [], 10000
+    for l in range(60):
+        niso = int(rng.choice([1, 2, 3, 33, 40, 64, 65, 70])) if l % 3 == 0 else int(rng.integers(1, 6))
+        n_ex = int(rng.integers(3, 9))
+        starts = base + np.sort(rng.choice(np.arange(0, 6000, 150), n_ex, replace=False))
+        exons = [(int(s), int(s) + int(rng.integers(80, 140))) for s in starts]
+        isos = []
+        for j in range(niso):
+            keep = [e for k, e in enumerate(exons) if k in (0, n_ex - 1) or rng.random() < 0.7]
+            if j % 2:            # a shortened first exon: another isoform with the same inner structure
+                keep = [(keep[0][0] + 10 + j % 30, keep[0][1])] + keep[1:]
+            isos.append(keep)
+        # distinct isoforms only
+        uniq = []
+        for i in isos:
+            if i not in uniq:
+                uniq.append(i)
+        loci.append(uniq)
+        base += 20000
+    annot = eb.Annotation(loci)
+    assert annot.compat_words >= 2
+    hl, feats = [], []
+    for l, isos in enumerate(loci):
+        for _ in range(int(rng.integers(5, 120))):
+            iso = isos[int(rng.integers(0, len(isos)))]
+            k = int(rng.integers(0, len(iso) - 1))
+            a, b = iso[k], iso[k + 1]
+            lb = [(a[1] - 40, a[1]), (b[0], b[0] + 33)]          # a read spliced over the junction k | k + 1
+            kk = min(k + 1 + int(rng.integers(0, 2)), len(iso) - 1)
+            c = iso[kk]
+            rb = [(c[1] - 60, c[1] - 10)] if kk > k + 1 else [(b[0] + 40, min(b[0] + 90, b[1]))]
+            f = eb.hit_features(lb, rb)
+            if f is not None:
+                hl.append(l)
+                feats.append(f)
+    # HitCluster's order inside a locus: (left end, right end); equal fragments once
+    keyed = sorted(set((hl[i], feats[i][1][0], feats[i][2][-1], tuple(map(tuple, feats[i]))) for i in range(len(hl))))
+    hits = eb.Hits([k[0] for k in keyed], [tuple(list(x) for x in k[3]) for k in keyed])
+    want = byhand_law(annot, hits, ctx)
+    assert want.total_reads > 50
+    r = quantify_resident(annot, hits, None, 75, hits.n_hits, ctx=ctx)
+    assert_same_law(r["insert"], want)
+    from strawberry_amd.quantify import quantify_host
+    h = quantify_host(annot, hits, None, 75, ctx=ctx)
+    assert_same_law(h["insert"], want)
+    np.testing.assert_array_equal(r["theta"], h["theta"])
