@@ -845,7 +845,8 @@ def main():
         tot = torch.tensor([b.n_frags], dtype=torch.int64, device=dev)
         (comm.allreduce_sum_(tot) if comm is not None else sdist.allreduce_sum_(tot))
         total_mapped = int(min(int(tot.item()), 2**31 - 1))   # the reference holds it in an int
-        return solver, sdist.ShardQuantifier(solver, total_mapped, min_isoform_frac=0.0, comm=comm, f32=f32)  # quant-only (-r): keep all
+        return solver, sdist.ShardQuantifier(solver, total_mapped, min_isoform_frac=0.0, comm=comm, f32=f32,
+                                             pipelined=os.environ.get("SB_PIPELINE", "1") != "0")  # quant-only (-r): keep all
 
     # ---- weak scaling: every rank holds its OWN full-size batch
     batch = make_batch(args.workload, rank)
@@ -863,6 +864,14 @@ def main():
     n_loci_all, n_frags_all = int(counts[0].item()), int(counts[1].item())
     weak = {"value": n_loci_all * args.steps / wall, "ms_per_step": wall / args.steps * 1e3,
             "mfrags_per_s": n_frags_all * args.steps / wall / 1e6, "loci": n_loci_all}
+    # the same K steps strictly one after the other (no step starts before the one before it has written its TPM): the latency
+    # of ONE batch beside the rate of a run of batches above -- reported, never `value`
+    serial_ms = None
+    if quant.pipelined:
+        quant.pipelined = False
+        serial_wall, _ = timed_steps(quant, args.steps, min(args.warmup, 2), dev, sdist, torch)
+        serial_ms = serial_wall / args.steps * 1e3
+        quant.pipelined = True
 
     # ---- strong scaling (BASELINE config 3: "loci sharded 1 -> 2 -> 4 -> 8"): ONE batch, LPT shards, one all-reduce
     if world > 1:
@@ -994,7 +1003,14 @@ def main():
         "config": {"workload": WORKLOADS[args.workload], "loci_per_gpu": batch.n_loci if args.scaling == "weak" else strong["loci_this_rank"],
                    "fragments_per_gpu": batch.n_frags,
                    "sharding": "independent loci per rank (own batch each), 1 all-reduce (8 B) per step" if args.scaling == "weak" else strong["sharding"],
-                   "collective": collective, "size_classes": solver.plan.info()["n_classes"]},
+                   "collective": collective, "size_classes": solver.plan.info()["n_classes"],
+                   "steps_pipelined": bool(getattr(quant, "pipelined", False)),
+                   "ms_per_step_one_after_the_other": serial_ms,
+                   "steps_pipelined_note": "a step's epilogue (abundance_kernel, the all-reduce, tpm_kernel) runs on a stream of its own beside the NEXT step's "
+                                           "EM kernels (sbgpu_em_run_device_split joins the kernels into that stream), theta / status / iterations double-"
+                                           "buffered; every step produces all of its outputs, all K are complete when the clock stops.  "
+                                           "ms_per_step_one_after_the_other: the same K steps with no overlap between two steps (SB_PIPELINE=0 makes that the "
+                                           "timed region)"},
         "launch": launch,
         "em_status": {"ok": int((res["status"] == 0).sum()), "init_empty": int((res["status"] == 1).sum()),
                       "denom_zero": int((res["status"] == 2).sum()), "maxiter": int((res["status"] == 3).sum()),

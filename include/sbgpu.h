@@ -169,6 +169,16 @@ int sbgpu_em_run_device(sbgpu_ctx_t *ctx, const sbgpu_plan_t *plan,
                         double *d_theta, int32_t *d_status, int32_t *d_iters,
                         void *stream);
 
+/* The same for a caller that runs batch after batch: the kernels start behind `fork_stream`'s work (the inputs) and their
+ * completion is joined into `join_stream` -- the stream the caller's epilogue for THIS batch runs on -- instead of into the
+ * stream they started from.  `fork_stream` is then free at once: the next call's kernels queue behind this call's on the
+ * library's own streams, kind by kind, without a cross-stream hand-off between two batches (the hand-offs are ~70 us of a
+ * 0.84 ms C3 step).  The caller keeps the batches' outputs apart (theta / status / iterations of the next batch in other
+ * buffers while this one's epilogue still reads them).                                                                  */
+int sbgpu_em_run_device_split(sbgpu_ctx_t *ctx, const sbgpu_plan_t *plan, const int32_t *d_count, const double *d_F,
+                              double *d_theta, int32_t *d_status, int32_t *d_iters, void *fork_stream,
+                              void *join_stream);
+
 /* The fp32 variant (BASELINE config 5, "fp32 vs fp64 tolerance sweep"): the same kernels with F, theta and all
  * arithmetic in fp32 (d_F, d_theta are float arrays; fp32 denormals flush too).  It exists to measure what
  * fp32 costs in accuracy and buys in speed; it is NOT a parity path: results differ from the reference's fp64

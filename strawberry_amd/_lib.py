@@ -38,7 +38,7 @@ SYMBOLS = [
     "sbgpu_binseq_device", "sbgpu_binseq_host", "sbgpu_em_batch", "sbgpu_abundance_device", "sbgpu_tpm_device",
     "sbgpu_quantify_resident", "sbgpu_allreduce_max_i64", "sbgpu_allreduce_max_i64_host", "sbgpu_comm_init_host",
     "sbgpu_front_stream_begin", "sbgpu_front_stream_push", "sbgpu_front_stream_end", "sbgpu_front_stream_info", "sbgpu_front_stream_hits",
-    "sbgpu_front_stream_destroy",
+    "sbgpu_front_stream_destroy", "sbgpu_em_run_device_split",
 ]
 
 
@@ -194,6 +194,7 @@ def load():
     L.sbgpu_em_last_phase_ms.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
     L.sbgpu_em_run_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.sbgpu_em_run_device_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.sbgpu_em_run_device_split.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.sbgpu_em_run_device_bias.argtypes = [vp] * 10
     L.sbgpu_em_run_device_bias_f32.argtypes = [vp] * 10
     L.sbgpu_em_batch.argtypes = [vp, C.POINTER(sbgpu_batch_t), vp, vp, vp]

@@ -966,7 +966,7 @@ int sbgpu_plan_classes(const sbgpu_plan_t *p, int64_t *out, int cap)
 // fp64 (the product path) and fp32 (BASELINE config 5's tolerance sweep) share the launch structure
 static int em_run_impl(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_count, const void *d_F_any, void *d_theta_any,
                        int32_t *d_status, int32_t *d_iters, void *stream, const bool f32, const void *d_row_bias = nullptr,
-                       const void *d_iso_bias = nullptr)
+                       const void *d_iso_bias = nullptr, void *join_stream = nullptr)
 {
    if (!c || !p) return fail(SBGPU_EINVAL, "sbgpu_em_run_device: null ctx/plan");
    if (p->host.n_loci == 0) return SBGPU_OK;
@@ -1001,6 +1001,11 @@ static int em_run_impl(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_c
    a32.row_bias = f32 ? (const float *)d_row_bias : nullptr, a32.iso_bias = f32 ? (const float *)d_iso_bias : nullptr;
    // Batches are dealt to the workgroups statically: nothing to reset between runs but the later phases' survivor
    // counts (only when the plan has phases)
+   // (split runs: a plan with per-run state of its own -- the phases' survivor counts, the wide loci's barrier words -- must
+   // not start while the previous run's kernels still use it: such a plan's runs wait for each other as the unsplit ones do)
+   if (join_stream && (p->zero_bytes || p->n_wide_desc))
+      for (int k = 0; k < sb::kNumKinds; ++k)
+         if (p->launches[k].n_classes > 0) HIP_TRY(hipStreamWaitEvent(main, c->join[k], 0));
    if (p->zero_bytes) HIP_TRY(hipMemsetAsync(p->d_zero, 0, p->zero_bytes, main));
    // a locus the kernels never reach (a wide-locus barrier that timed out) must not look solved: with wide loci in
    // the plan, status starts at -1 = SBGPU_EM_UNSOLVED (0xFF bytes); every other kernel writes all its loci
@@ -1153,13 +1158,19 @@ static int em_run_impl(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_c
          c->timed[k] = true;
       }
    }
+   // the kinds' streams join the caller's -- or, sbgpu_em_run_device_split, ANOTHER stream of the caller's (the one its epilogue
+   // runs on), so that the stream the next run forks from does not wait for this one's kernels
+   hipStream_t join_to = join_stream ? (hipStream_t)join_stream : main;
    if (fork) {
       for (int k = 0; k < sb::kNumKinds; ++k) {
          if (p->launches[k].n_classes == 0) continue;
-         if (stream_of(k) == main) continue;
+         if (stream_of(k) == join_to) continue;
          HIP_TRY(hipEventRecord(c->join[k], stream_of(k)));
-         HIP_TRY(hipStreamWaitEvent(main, c->join[k], 0));
+         HIP_TRY(hipStreamWaitEvent(join_to, c->join[k], 0));
       }
+   } else if (join_to != main) {
+      HIP_TRY(hipEventRecord(c->fork, main));
+      HIP_TRY(hipStreamWaitEvent(join_to, c->fork, 0));
    }
    return SBGPU_OK;
 }
@@ -1194,6 +1205,13 @@ int sbgpu_em_run_device(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_
    }
    HIP_TRY(hipGraphLaunch(p->graph_exec, (hipStream_t)stream));
    return SBGPU_OK;
+}
+
+int sbgpu_em_run_device_split(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_count, const double *d_F, double *d_theta,
+                              int32_t *d_status, int32_t *d_iters, void *fork_stream, void *join_stream)
+{
+   if (!join_stream) return fail(SBGPU_EINVAL, "sbgpu_em_run_device_split: null join stream");
+   return em_run_impl(c, p, d_count, d_F, d_theta, d_status, d_iters, fork_stream, false, nullptr, nullptr, join_stream);
 }
 
 int sbgpu_em_run_device_f32(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_count, const float *d_F,

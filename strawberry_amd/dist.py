@@ -256,10 +256,18 @@ class ShardQuantifier:
 
     `solver` is an em.EmBatchSolver over this rank's loci.  `total_mapped_reads`
     is the GLOBAL pass-1 count (alignments.cpp:1372), already all-reduced by the
-    caller (it precedes the EM: src/estimate.cpp:328)."""
+    caller (it precedes the EM: src/estimate.cpp:328).
+
+    Consecutive steps are PIPELINED (round 6): a step's epilogue -- abundance_kernel, the all-reduce, tpm_kernel: a chain of
+    three short launches and, at N > 1, a collective's latency -- runs on a stream of its own beside the NEXT step's EM
+    kernels, theta / status / iterations double-buffered so that the next EM does not overwrite what the epilogue still
+    reads; and the EM kernels' completion is joined into THAT stream (sbgpu_em_run_device_split), so that the next step's
+    kernels queue behind this step's on the library's own streams, kind by kind, without a hand-off across streams between
+    two steps.  Every step still produces all of its outputs; what overlaps is the tail of one batch with the head of the next,
+    as in a run over many batches.  pipelined=False: one stream, one buffer set (the steps strictly one after the other)."""
 
     def __init__(self, solver, total_mapped_reads, min_isoform_frac=0.01, effective_len_norm=False,
-                 insert_mean=0.0, filter_by_expression=True, comm=None, f32=False):
+                 insert_mean=0.0, filter_by_expression=True, comm=None, f32=False, pipelined=True):
         """comm: an AbiComm (the C-ABI collective); None: torch.distributed's default group.
         f32: run the EM's fp32 variant (BASELINE config 5; not a parity path), the epilogue stays fp64."""
         self.s = solver
@@ -268,14 +276,17 @@ class ShardQuantifier:
         self.kw = dict(total_mapped_reads=int(total_mapped_reads), min_isoform_frac=min_isoform_frac,
                        effective_len_norm=effective_len_norm, insert_mean=insert_mean,
                        filter_by_expression=filter_by_expression)
+        self.pipelined = bool(pipelined) and not f32
+        if self.pipelined:
+            torch = solver.torch
+            self._epi = torch.cuda.Stream(device=solver.dev)
+            self._sets = [(solver.d_theta, solver.d_status, solver.d_iters),
+                          (torch.zeros_like(solver.d_theta), torch.full_like(solver.d_status, -1), torch.zeros_like(solver.d_iters))]
+            self._read_done = [None, None]     # per buffer set: the event behind the epilogue that last read it
+            self._k = 0
 
-    def step(self):
+    def _epilogue(self):
         s = self.s
-        if self.f32:
-            s.run_em_f32()
-            s.theta32_as_f64()
-        else:
-            s.run_em()
         s.run_abundance(**self.kw)          # leaves this rank's sum of kept FPKM in d_sum_fpkm
         # the one collective: 8 bytes over xGMI
         if self.comm is not None:
@@ -284,6 +295,38 @@ class ShardQuantifier:
             allreduce_sum_(s.d_sum_fpkm)
         s.run_tpm(s.d_sum_fpkm)
 
+    def step(self):
+        s = self.s
+        if not self.pipelined:
+            if self.f32:
+                s.run_em_f32()
+                s.theta32_as_f64()
+            else:
+                s.run_em()
+            self._epilogue()
+            return
+        torch = s.torch
+        main = torch.cuda.current_stream(s.dev)
+        k = self._k
+        self._k ^= 1
+        s.d_theta, s.d_status, s.d_iters = self._sets[k]
+        if self._read_done[k] is not None:
+            main.wait_event(self._read_done[k])     # the epilogue of two steps ago has read this set
+        if getattr(s, "d_row_bias", None) is None:
+            s.run_em(join_stream=self._epi)      # (the kernels' completion is joined into the epilogue's stream, not into `main`)
+        else:
+            s.run_em()
+            solved = torch.cuda.Event()
+            solved.record(main)
+            self._epi.wait_event(solved)
+        with torch.cuda.stream(self._epi):
+            self._epilogue()
+            done = torch.cuda.Event()
+            done.record(self._epi)
+        self._read_done[k] = done
+
     def finish(self):
         """Wait for the step(s) issued so far; raises if a run failed on the device (SbgpuError)."""
+        if self.pipelined:
+            self._epi.synchronize()
         self.s.synchronize()

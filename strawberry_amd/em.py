@@ -146,9 +146,15 @@ class EmBatchSolver:
         self.d_row_bias32 = None if d_row_bias is None else d_row_bias.to(self.torch.float32)
         self.d_iso_bias32 = None if d_iso_bias is None else d_iso_bias.to(self.torch.float32)
 
-    def run_em(self):
-        """EmSolver::init + run for every locus; asynchronous on torch's current stream."""
+    def run_em(self, join_stream=None):
+        """EmSolver::init + run for every locus; asynchronous on torch's current stream.  join_stream (a torch stream): the
+        kernels' completion is joined into IT instead of the current stream (sbgpu_em_run_device_split: batch after batch)."""
         L = self.ctx.L
+        if join_stream is not None and getattr(self, "d_row_bias", None) is None:
+            _lib.check(L.sbgpu_em_run_device_split(self.ctx.h, self.plan.h, self.d_count.data_ptr(), self.d_F.data_ptr(),
+                                                   self.d_theta.data_ptr(), self.d_status.data_ptr(), self.d_iters.data_ptr(),
+                                                   self._stream(), C.c_void_p(join_stream.cuda_stream)), "sbgpu_em_run_device_split")
+            return
         if getattr(self, "d_row_bias", None) is not None:
             _lib.check(L.sbgpu_em_run_device_bias(self.ctx.h, self.plan.h, self.d_count.data_ptr(), self.d_F.data_ptr(),
                                                   self.d_row_bias.data_ptr(), self.d_iso_bias.data_ptr(), self.d_theta.data_ptr(),

@@ -126,6 +126,26 @@ def test_rccl_runs_at_world_one_when_forced(tmp_path):
         _lib.check(L.sbgpu_allreduce_sum_f64_host(comm.h, hf, 2), "f64_host")
         _lib.check(L.sbgpu_allreduce_sum_i64_host(comm.h, hi, 2), "i64_host")
         assert list(hf) == [1.25, -2.5] and list(hi) == [5, 1 << 50]
+        # round 6: the collectives INSIDE sbgpu_quantify_resident through the same communicator -- ncclAllReduce(max) of the
+        # histogram's length (host form), ncclAllReduce(sum) of the int64 histogram on the context's stream, ncclAllReduce(sum)
+        # of the FPKM total between the two epilogue kernels: the results of the call without a communicator, bit for bit
+        hm = (C.c_int64 * 2)(9, -4)
+        _lib.check(L.sbgpu_allreduce_max_i64_host(comm.h, hm, 2), "max_i64_host")
+        assert list(hm) == [9, -4]
+        import numpy as np
+        from strawberry_amd import exonbin as eb, synth
+        from strawberry_amd.quantify import quantify_resident
+        loci = synth.make_gene_models(50, seed=81)
+        hl, pairs = synth.make_fragments(loci, 100, seed=82, noise=0.2)
+        rows = [(l, eb.hit_features(lb, rb)) for l, (lb, rb) in zip(hl, pairs)]
+        rows = [(l, f) for l, f in rows if f is not None]
+        annot, hits = eb.Annotation(loci), eb.Hits([l for l, _ in rows], [f for _, f in rows])
+        a = quantify_resident(annot, hits, None, 75, hits.n_hits, ctx=ctx, comm=comm)
+        b = quantify_resident(annot, hits, None, 75, hits.n_hits, ctx=ctx, comm=None)
+        for k in ("theta", "fpkm", "frac", "tpm", "keep", "status", "iters"):
+            assert np.array_equal(a[k], b[k]), k
+        assert a["insert"]["mean"] == b["insert"]["mean"] and np.array_equal(a["insert"]["emp_hist"], b["insert"]["emp_hist"])
+        assert a["total_fpkm"] == b["total_fpkm"] and a["total_mapped_reads"] == b["total_mapped_reads"] == hits.n_hits
         comm.close()
         print("rccl world-1 ok")
     """ % ROOT)
@@ -137,3 +157,35 @@ def test_rccl_runs_at_world_one_when_forced(tmp_path):
     comm = dist.AbiComm(em.default_context(0), rank=0, world=1)
     assert comm.rccl_ranks() == 0
     comm.close()
+
+
+@pytest.mark.gpu
+def test_pipelined_steps_equal_the_steps_one_after_the_other():
+    """ShardQuantifier's pipelined steps (round 6: the epilogue on a stream of its own beside the next step's EM kernels,
+    the kernels' completion joined into THAT stream -- sbgpu_em_run_device_split -- and theta / status / iterations double-
+    buffered) leave, after 1, 2, 3 and 8 steps, the bytes of the steps run strictly one after the other; on a plan with
+    wide loci too (their runs wait for each other: per-run barrier words), and the split entry refuses a null join stream."""
+    import ctypes as C
+    import torch
+    from strawberry_amd import _lib, dist, em, synth
+    ctx = em.default_context(0)
+    for make in (lambda: synth.make_c3(n_loci=6000, total_frags=2e7, seed=91),
+                 lambda: synth.make_c3t(n_loci=3000, total_frags=1e7, seed=92, n_tail=12)):
+        b = make()
+        ref = em.EmBatchSolver(b, ctx)
+        q0 = dist.ShardQuantifier(ref, 10 ** 7, min_isoform_frac=0.01, pipelined=False, comm=dist.AbiComm(ctx, 0, 1))
+        q0.step()
+        q0.finish()
+        want = {k: getattr(ref, "d_" + k).cpu().numpy().copy() for k in ("theta", "status", "iters", "fpkm", "tpm")}
+        for n_steps in (1, 2, 3, 8):
+            s = em.EmBatchSolver(b, ctx)
+            q = dist.ShardQuantifier(s, 10 ** 7, min_isoform_frac=0.01, pipelined=True, comm=dist.AbiComm(ctx, 0, 1))
+            assert q.pipelined
+            for _ in range(n_steps):
+                q.step()
+            q.finish()
+            for k, w in want.items():
+                assert np.array_equal(getattr(s, "d_" + k).cpu().numpy(), w), (k, n_steps)
+    L = ctx.L
+    assert L.sbgpu_em_run_device_split(ctx.h, ref.plan.h, ref.d_count.data_ptr(), ref.d_F.data_ptr(), ref.d_theta.data_ptr(),
+                                       ref.d_status.data_ptr(), ref.d_iters.data_ptr(), None, None) == _lib.SBGPU_EINVAL

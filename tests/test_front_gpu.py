@@ -76,14 +76,14 @@ def test_records_from_host_in_chunks_equal_the_resident_pass():
     and with a given one; a chunk smaller than a cluster's records is refused (SBGPU_ESHAPE), not mis-served."""
     from strawberry_amd import _lib, em, front
     ctx = em.default_context(0)
-    for empirical in (True, False):
+    for empirical, pinned in ((True, True), (False, False)):    # (page-locked memory: the upload overlaps; pageable: staged by the runtime)
         q = front.FrontQuantifier(ctx, n_loci=2500, n_frags=2.5e6, seed=44, resident=True, empirical=empirical)
         q.step()
         size = {"theta": q.n_iso, "fpkm": q.n_iso, "frac": q.n_iso, "tpm": q.n_iso, "keep": q.n_iso, "status": q.n_loci, "iters": q.n_loci}
         want = {k: getattr(q, k)[:n].copy() for k, n in size.items()}
         want_law, want_off, want_tot = dict(q.law), q.front_hit_off.copy(), (q.total_fpkm, q.total_mapped_reads)
         n_bytes = q.n_bytes
-        q.to_host(n_bytes // 40 + 4096, pinned=True)
+        assert q.to_host(n_bytes // 40 + 4096, pinned=pinned)["pinned"] == pinned
         for chunk in (n_bytes // 40 + 4096, n_bytes // 7 + 4096):
             q.cut(chunk)
             for k in want:
