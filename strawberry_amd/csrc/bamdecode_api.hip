@@ -229,6 +229,54 @@ int sbgpu_bam_decode_device(sbgpu_ctx_t *c, const uint8_t *d_bytes, int64_t n_by
       *out = B;
       return SBGPU_OK;
    }
+   // what a workgroup may ask for on this device
+   int lds_max = 0;
+   if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, sb::ctx_device(c)) != hipSuccess || lds_max <= 0) lds_max = 64 * 1024;
+   // ---- one pass (bam_onepass_kernel): the handle's arrays get room for EVERY record and two blocks per record; a sample
+   // whose accepted records hold more blocks than that (or more than 2^30 records, or a look-back that ran out) is decoded
+   // by the two kernels below instead
+   const bool two_pass_only = std::getenv("SBGPU_BAM_TWO_PASS") && std::atoi(std::getenv("SBGPU_BAM_TWO_PASS")) != 0; // (the tests' hook for the fallback)
+   if (!two_pass_only && n <= sb::kOneMaxRecords) {
+      const int64_t block_cap = 2 * n + 1024;
+      B->n_reads = n, B->n_blocks = block_cap;
+      SB_TRY(sb::dev_take(lay_out(B, nullptr), &B->arena, &B->arena_cap));
+      lay_out(B, B->arena);
+      const size_t tiles = ((size_t)n + sb::kOneTile - 1) / sb::kOneTile;
+      const size_t o_state = 0, o_cnt1 = up256(tiles * 8), o_ticket = o_cnt1 + up256(16 * 8), w_bytes = o_ticket + 256;
+      SB_TRY(sb::dev_take(w_bytes, &w, &w_cap));
+      SB_TRY(hipMemsetAsync(w, 0, w_bytes, s));
+      sb::BamOneArgs a = {};
+      a.bytes = d_bytes, a.n_bytes = n_bytes, a.rec_off = d_rec_off, a.n = n, a.opts = *opts;
+      a.status = B->status;
+      a.o_record = B->record, a.o_read_id = B->read_id, a.o_ref = B->ref, a.o_nh = B->nh, a.o_nm = B->nm, a.o_read_len = B->read_len;
+      a.o_left = B->left, a.o_right = B->right, a.o_partner_pos = B->partner_pos, a.o_sam_flag = B->sam_flag, a.o_flags = B->flags;
+      a.o_block_off = B->block_off, a.o_block_left = B->block_left, a.o_block_right = B->block_right, a.block_cap = block_cap;
+      a.counts = (unsigned long long *)(w + o_cnt1), a.tile_state = (unsigned long long *)(w + o_state), a.ticket = (unsigned int *)(w + o_ticket);
+      // a wave's part of the staging buffer: 64 average records + 4 % + 512 bytes, in steps of 256 (a pass whose records do
+      // not fit walks them in global memory: slower, same results) -- three workgroups of four waves then fit a CU's 160 KB
+      // up to ~195 bytes per record
+      int stage_bytes = (int)std::min<int64_t>(std::max<int64_t>(4096, ((64 * (n_bytes / n + 1)) * 26 / 25 + 512 + 255) & ~(int64_t)255), 32 * 1024);
+      stage_bytes = std::max(0, std::min(stage_bytes, (lds_max - 512) / sb::kOneWaves)) & ~255;
+      const int resident = std::max(1, std::min(8, (int)(160 * 1024 / ((size_t)stage_bytes * sb::kOneWaves + 512))));
+      const int64_t grid = std::min<int64_t>((int64_t)tiles, (int64_t)sb::ctx_cu_count(c) * resident);
+      hipLaunchKernelGGL(sb::bam_onepass_kernel, dim3((unsigned)grid), dim3(64 * sb::kOneWaves), (size_t)stage_bytes * sb::kOneWaves, s, a, stage_bytes);
+      SB_TRY(hipGetLastError());
+      unsigned long long counts[16];
+      SB_TRY(hipMemcpyAsync(counts, w + o_cnt1, sizeof(counts), hipMemcpyDeviceToHost, s));
+      SB_TRY(hipStreamSynchronize(s));
+      sb::dev_give(w, w_cap);
+      w = nullptr, w_cap = 0;
+      if (counts[12] == 0) {
+         B->n_reads = (int64_t)counts[13], B->n_blocks = (int64_t)counts[14];
+         for (int k = 0; k <= SBGPU_BAM_TRUNCATED; ++k) B->by_status[k] = (int64_t)counts[k];
+         B->any_paired = counts[11] ? 1 : 0;
+         *out = B;
+         return SBGPU_OK;
+      }
+      sb::dev_give(B->arena, B->arena_cap);
+      B->arena = nullptr, B->arena_cap = 0;
+   }
+   // ---- two passes: decide and count (bam_scan_kernel), scans over the waves' totals, compact (bam_fill_kernel)
    const size_t nn = (size_t)n, n1 = nn + 1, nt = (nn + 63) / 64, nt1 = nt + 1; // (tiles of 64 records: a wave's pass)
    auto as_i64_i32 = [] __device__(int32_t v) { return (int64_t)v; };
    size_t tmp_bytes = 0;
@@ -266,10 +314,8 @@ int sbgpu_bam_decode_device(sbgpu_ctx_t *c, const uint8_t *d_bytes, int64_t n_by
    int stage_bytes = 8 * 1024;
    while (stage_bytes < 64 * 1024 && (int64_t)stage_bytes < 70 * (n_bytes / n + 1)) stage_bytes += 2 * 1024;
    if (stage_kb_env > 0) stage_bytes = std::min(64, std::max(1, stage_kb_env)) * 1024;
-   // what a workgroup may ask for on this device, less the kernel's static words; a launch that is refused all the same
-   // is repeated without the buffer (the kernel then walks every record in global memory: slower, same results)
-   int lds_max = 0;
-   if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, sb::ctx_device(c)) != hipSuccess || lds_max <= 0) lds_max = 64 * 1024;
+   // (what a workgroup may ask for, less the kernel's static words; a launch that is refused all the same is repeated
+   // without the buffer: the kernel then walks every record in global memory: slower, same results)
    stage_bytes = std::max(0, std::min(stage_bytes, lds_max - 256));
    const int resident = std::max(1, std::min(16, (int)(160 * 1024 / (stage_bytes + 256))));
    const int64_t scan_blocks = std::min<int64_t>((n + 63) / 64, (int64_t)sb::ctx_cu_count(c) * resident * 4);

@@ -66,6 +66,40 @@ def test_device_decode_large_stream_and_edges(ctx, oracle):
     assert e.n_records == 0 and e.n_reads == 0
 
 
+def test_device_decode_fallback_routes(ctx, oracle, monkeypatch):
+    """sbgpu_bam_decode_device decodes in ONE pass (bam_onepass_kernel: tiles of 1 024 records, a decoupled look-back for a
+    tile's place) and keeps the two-kernel form for what the one pass declines: here a stream whose accepted records hold MORE
+    than two blocks each on average (the one pass' arrays have room for 2 n + 1 024 blocks), and the hook that forces the
+    two kernels (SBGPU_BAM_TWO_PASS=1) on an ordinary stream -- all equal to the oracle, and the two forms equal to each
+    other array by array."""
+    from strawberry_amd import bam
+    rng = np.random.default_rng(41)
+    many = [B.record(0, 10 + 7 * i, 0, "r%d" % i, [("M", 10), ("N", 100), ("M", 10), ("N", 120), ("M", 10), ("N", 90), ("M", 12)])
+            for i in range(5000)]
+    raw = np.frombuffer(b"".join(many), np.uint8)
+    o = oracle.bam_decode(raw, n_ref=3)
+    d = bam.decode(raw, None, bam.BamOptions(n_ref=3), device=ctx)
+    assert d.n_reads == 5000 and d.n_blocks == 20000          # 4 blocks per record > the one pass' room: the two kernels ran
+    check_library_against_oracle(d, o)
+    d.close()
+    recs = B.random_records(rng, 30000)
+    raw = np.frombuffer(b"".join(recs), np.uint8)
+    off = bam.index(raw)
+    o = oracle.bam_decode(raw, off, n_ref=3)
+    one = bam.decode(raw, off, bam.BamOptions(n_ref=3), device=ctx)
+    monkeypatch.setenv("SBGPU_BAM_TWO_PASS", "1")
+    two = bam.decode(raw, off, bam.BamOptions(n_ref=3), device=ctx)
+    monkeypatch.delenv("SBGPU_BAM_TWO_PASS")
+    check_library_against_oracle(one, o)
+    check_library_against_oracle(two, o)
+    for k in ("status", "record", "read_id", "ref", "left", "right", "partner_pos", "flags", "nh", "nm", "read_len", "sam_flag",
+              "block_off", "block_left", "block_right"):
+        assert np.array_equal(getattr(one, k), getattr(two, k)), k
+    assert one.by_status == two.by_status and one.any_paired == two.any_paired
+    one.close()
+    two.close()
+
+
 def test_device_decode_on_garbage_records(ctx, oracle):
     """Noise behind valid size words (tests/test_bamdecode.py has the host form under AddressSanitizer): the device must take
     the oracle's way through it -- staged in LDS or walked in global memory (SBGPU_BAM_STAGE_KB is read once per process, so the
