@@ -147,7 +147,7 @@ int api_fail(int code, const std::string &msg); // records sbgpu_last_error(), r
 // with -DSB_EXPERIMENTS (`make experiments` -> libsbgpu_exp.so, never shipped, never timed by bench.py); the shipped library does
 // not read them.  What stays a plain getenv: resources (SBGPU_POOL_GB, SBGPU_HOST_THREADS), diagnostics (SBGPU_HOST_TIMING) and the
 // tests' hooks that force a fallback route the default inputs do not take (SBGPU_PAIR_FORCE_SORT, SBGPU_COLLAPSE_FORCE_SEQ,
-// SBGPU_COLLAPSE_TWO_SORTS, SBGPU_BAM_STAGE_KB, SBGPU_NO_WIDE, SBGPU_COMM_FORCE_RCCL).
+// SBGPU_COLLAPSE_TWO_SORTS, SBGPU_BAM_TWO_PASS, SBGPU_NO_WIDE, SBGPU_COMM_FORCE_RCCL).
 inline const char *exp_env(const char *name)
 {
 #ifdef SB_EXPERIMENTS

@@ -260,10 +260,13 @@ int sbgpu_bam_decode_device(sbgpu_ctx_t *c, const uint8_t *d_bytes, int64_t n_by
       const int resident = std::max(1, std::min(8, (int)(160 * 1024 / ((size_t)stage_bytes * sb::kOneWaves + 512))));
       const int64_t grid = std::min<int64_t>((int64_t)tiles, (int64_t)sb::ctx_cu_count(c) * resident);
       hipLaunchKernelGGL(sb::bam_onepass_kernel, dim3((unsigned)grid), dim3(64 * sb::kOneWaves), (size_t)stage_bytes * sb::kOneWaves, s, a, stage_bytes);
-      SB_TRY(hipGetLastError());
-      unsigned long long counts[16];
-      SB_TRY(hipMemcpyAsync(counts, w + o_cnt1, sizeof(counts), hipMemcpyDeviceToHost, s));
-      SB_TRY(hipStreamSynchronize(s));
+      // (a launch that is refused -- the staging buffer on a device with less LDS than it was told -- counts as a failure too)
+      unsigned long long counts[16] = {};
+      counts[12] = 1;
+      if (hipGetLastError() == hipSuccess) {
+         SB_TRY(hipMemcpyAsync(counts, w + o_cnt1, sizeof(counts), hipMemcpyDeviceToHost, s));
+         SB_TRY(hipStreamSynchronize(s));
+      }
       sb::dev_give(w, w_cap);
       w = nullptr, w_cap = 0;
       if (counts[12] == 0) {
@@ -309,11 +312,9 @@ int sbgpu_bam_decode_device(sbgpu_ctx_t *c, const uint8_t *d_bytes, int64_t n_by
    a.counts = (unsigned long long *)(w + o_cnt);
    a.tile_reads = (int32_t *)(w + o_tr), a.tile_blocks = (int32_t *)(w + o_tb);
    const int64_t cap = (int64_t)sb::ctx_cu_count(c) * 32, blocks = std::min<int64_t>((n + 255) / 256, cap);
-   // the staging buffer of a workgroup (one wave, 64 records): 1.1 x 64 average records, 8-64 KB (SBGPU_BAM_STAGE_KB overrides)
-   static const int stage_kb_env = std::getenv("SBGPU_BAM_STAGE_KB") ? std::atoi(std::getenv("SBGPU_BAM_STAGE_KB")) : 0;
+   // the staging buffer of a workgroup (one wave, 64 records): 1.1 x 64 average records, 8-64 KB
    int stage_bytes = 8 * 1024;
    while (stage_bytes < 64 * 1024 && (int64_t)stage_bytes < 70 * (n_bytes / n + 1)) stage_bytes += 2 * 1024;
-   if (stage_kb_env > 0) stage_bytes = std::min(64, std::max(1, stage_kb_env)) * 1024;
    // (what a workgroup may ask for, less the kernel's static words; a launch that is refused all the same is repeated
    // without the buffer: the kernel then walks every record in global memory: slower, same results)
    stage_bytes = std::max(0, std::min(stage_bytes, lds_max - 256));

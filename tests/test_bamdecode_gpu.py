@@ -102,8 +102,8 @@ def test_device_decode_fallback_routes(ctx, oracle, monkeypatch):
 
 def test_device_decode_on_garbage_records(ctx, oracle):
     """Noise behind valid size words (tests/test_bamdecode.py has the host form under AddressSanitizer): the device must take
-    the oracle's way through it -- staged in LDS or walked in global memory (SBGPU_BAM_STAGE_KB is read once per process, so the
-    second form is reached through records too long for the buffer)."""
+    the oracle's way through it -- staged in LDS or walked in global memory (the second form is reached through records too long
+    for the buffer)."""
     from strawberry_amd import bam
     recs = B.garbage_records(np.random.default_rng(32), 20000)
     long_tail = [B.record(1, 50, 0, "long%d" % k, [("M", 30000)], tags=[("NH", "C", 1), ("XS", "A", "-")]) for k in range(70)]   # 45 KB each
