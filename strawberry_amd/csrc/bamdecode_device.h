@@ -77,7 +77,13 @@ struct ByteWindow {
    SB_HD uint64_t peek8(const uint8_t *p, const uint8_t *) const
    {
       const uintptr_t q = (uintptr_t)p;
+#if defined(__HIP_DEVICE_COMPILE__)
+      // (the buffer is LDS and the pointer says so: ds_read2_b64 -- through the generic pointer the decoder's loads were
+      // flat_load_dwordx2, which look the address space up per lane and count against both wait counters)
+      const __attribute__((address_space(3))) uint64_t *b = (const __attribute__((address_space(3))) uint64_t *)(uint32_t)(q & ~(uintptr_t)7);
+#else
       const uint64_t *b = (const uint64_t *)(q & ~(uintptr_t)7);
+#endif
       const uint64_t lo = b[0], hi = b[1];
       const unsigned sh = 8u * (unsigned)(q & 7u);
       return sh ? (lo >> sh) | (hi << (64u - sh)) : lo;
