@@ -1058,6 +1058,9 @@ static int em_run_impl(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_c
       int hold_us = 0;
       if (fork && k == sb::kBlock && tall_runs) hold_us = block_delay_us;
       if (fork && kKindStream[k] == 0) hold_us = wave_delay_us + ((tall_runs && p->launches[sb::kBlock].n_classes > 0) ? block_delay_us : 0);
+      // (split runs: a kind's kernels follow each other on its stream, run after run, and the kinds drift apart by themselves --
+      // the hold would only sit on the path of the kind that ends last)
+      if (join_stream && !(p->zero_bytes || p->n_wide_desc)) hold_us = 0;
       if (hold_us > 0) {
          hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, s, (unsigned long long)hold_us * 100ull);
          HIP_TRY(hipGetLastError());
