@@ -173,8 +173,10 @@ int sbgpu_em_run_device(sbgpu_ctx_t *ctx, const sbgpu_plan_t *plan,
  * completion is joined into `join_stream` -- the stream the caller's epilogue for THIS batch runs on -- instead of into the
  * stream they started from.  `fork_stream` is then free at once: the next call's kernels queue behind this call's on the
  * library's own streams, kind by kind, without a cross-stream hand-off between two batches (the hand-offs are ~70 us of a
- * 0.84 ms C3 step).  The caller keeps the batches' outputs apart (theta / status / iterations of the next batch in other
- * buffers while this one's epilogue still reads them).                                                                  */
+ * 0.84 ms C3 step).  Two consecutive calls' kernels may run side by side (the kinds that end last alternate between two of
+ * the library's streams), call i + 2's run behind call i's: the caller keeps consecutive batches' outputs apart -- theta /
+ * status / iterations of call i + 1 in other buffers than call i's -- and lets `fork_stream` wait for the epilogue that
+ * last read a buffer set before it hands the set to a new call.                                                          */
 int sbgpu_em_run_device_split(sbgpu_ctx_t *ctx, const sbgpu_plan_t *plan, const int32_t *d_count, const double *d_F,
                               double *d_theta, int32_t *d_status, int32_t *d_iters, void *fork_stream,
                               void *join_stream);
