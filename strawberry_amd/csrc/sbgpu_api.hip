@@ -48,7 +48,6 @@ constexpr int kMaxPhaseEvents = 6; // later phases of the wave kind that get tim
 // side by side (one wave kind, block, tall block) get streams 0, 2 and 6: three distinct queues
 // that also avoid the caller's.
 constexpr int kKindStream[sb::kNumKinds] = {0, 0, 0, 2, 6, 1};
-constexpr int kWaveStreamAlt = 1; // the wave kinds' second stream (sbgpu_em_run_device_split): queue 3, beside 2 / 4 / 1 of the others
 
 } // namespace
 
@@ -61,6 +60,7 @@ struct sbgpu_ctx {
    hipEvent_t fork = nullptr;
    hipEvent_t join[kAuxStreams] = {};
    unsigned split_runs = 0; // sbgpu_em_run_device_split calls so far (their wave kinds alternate between two streams)
+   int wave_alt = -1;       // the wave kinds' second stream: -1 not looked for yet, 0 none (no alternation), else its index
    hipEvent_t t0[sb::kNumKinds] = {}, t1[sb::kNumKinds] = {}; // per-kind kernel timing (sbgpu_set_timing)
    hipEvent_t tp[kMaxPhaseEvents + 1] = {};                   // ends of the wave kind's phases
    bool timed[sb::kNumKinds] = {};
@@ -966,6 +966,26 @@ int sbgpu_plan_classes(const sbgpu_plan_t *p, int64_t *out, int cap)
 } // extern "C"
 
 // fp64 (the product path) and fp32 (BASELINE config 5's tolerance sweep) share the launch structure
+// A side stream whose kernels run BESIDE those of the three streams the kinds use (0, 2, 6): four 200 us holds, one per stream,
+// take ~200 us together when the candidate has a hardware queue of its own and ~400 when it shares one (HIP folds a process'
+// streams onto 4 queues by creation order; which one a stream got cannot be asked).  0: none found.
+static int find_wave_alt(sbgpu_ctx_t *c)
+{
+   const int used[3] = {kKindStream[sb::kWaveH], kKindStream[sb::kBlock], kKindStream[sb::kBlockTall]};
+   const int cand[5] = {1, 3, 4, 5, 7};
+   if (hipDeviceSynchronize() != hipSuccess) return 0;
+   for (int pass = 0; pass < 2; ++pass) // (the first pass also loads the kernel: its times are not looked at)
+      for (int ci = 0; ci < 5; ++ci) {
+         const auto t0 = std::chrono::steady_clock::now();
+         for (int u = 0; u < 3; ++u) hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, c->aux[used[u]], 200ull * 100ull);
+         hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, c->aux[cand[ci]], 200ull * 100ull);
+         if (hipDeviceSynchronize() != hipSuccess) return 0;
+         const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+         if (pass == 1 && us < 330.0) return cand[ci];
+      }
+   return 0;
+}
+
 static int em_run_impl(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_count, const void *d_F_any, void *d_theta_any,
                        int32_t *d_status, int32_t *d_iters, void *stream, const bool f32, const void *d_row_bias = nullptr,
                        const void *d_iso_bias = nullptr, void *join_stream = nullptr)
@@ -1023,8 +1043,14 @@ static int em_run_impl(sbgpu_ctx_t *c, const sbgpu_plan_t *p, const int32_t *d_c
    static const bool wave_on_main = sb::exp_env("SBGPU_WAVE_ON_MAIN") && std::atoi(sb::exp_env("SBGPU_WAVE_ON_MAIN")) != 0;
    // Split runs alternate the wave kinds (the kinds that end last) between two streams on two hardware queues: the next run's
    // wave kernel -- its longest loci first -- starts while this run's last workgroups still work through theirs, instead of
-   // behind them (C3: 0.76 -> 0.72 ms per step; a second stream that shares the first one's hardware queue: 0.79).
-   const int wave_slot = (join_stream && fork && !p->zero_bytes && !p->n_wide_desc && (c->split_runs++ & 1)) ? kWaveStreamAlt : 0;
+   // behind them (C3: 0.76 -> 0.72 ms per step; a second stream that shares a hardware queue with the first one or with the
+   // block kinds': 0.79).  Which stream that is depends on how the runtime folded the process' streams onto its hardware queues:
+   // it is looked for once (find_wave_alt), and without one the runs do not alternate.
+   if (join_stream && fork && c->wave_alt < 0) {
+      c->wave_alt = find_wave_alt(c);
+      if (std::getenv("SBGPU_HOST_TIMING")) std::fprintf(stderr, "[sbgpu] split runs: the wave kinds' second stream = %d (0: none)\n", c->wave_alt);
+   }
+   const int wave_slot = (join_stream && fork && c->wave_alt > 0 && !p->zero_bytes && !p->n_wide_desc && (c->split_runs++ & 1)) ? c->wave_alt : 0;
    auto stream_of = [&](int k) -> hipStream_t {
       if (!fork || (wave_on_main && kKindStream[k] == 0)) return main;
       return c->aux[kKindStream[k] == 0 ? wave_slot : kKindStream[k]];
