@@ -141,4 +141,8 @@ bash tools/pmc_em_layouts.sh > $SUM/${R}_em_layout_instr.txt 2>&1
 (bash tools/pmc_wide_one.sh 2>&1 | grep "^gpurun_out/pmcw") > $SUM/${R}_wide_tile_pmc.txt
 # random stress on this build (tails; the library's build id on top)
 (python -c "import sys; sys.path.insert(0, '.'); from strawberry_amd import _lib; print('libsbgpu build', _lib.load().sbgpu_build_id().decode())"; timeout 900 python tools/stress_em.py 48 2>&1 | tail -3; timeout 600 python tools/stress_exonbin.py 48 2>&1 | tail -2; timeout 600 python tools/stress_binseq.py 2>&1 | tail -2; timeout 600 python tools/stress_bamdecode.py 48 2>/dev/null | tail -2) > $SUM/${R}_stress.txt 2>&1
+# what travels back is the summary (gpurun merges at most 64 MiB of gpurun_out/): the raw traces and counter files stay on the box
+find $OUT -mindepth 1 -maxdepth 1 ! -name summary -exec rm -rf {} + 2>/dev/null
+find $REPO/gpurun_out -mindepth 1 -maxdepth 1 ! -name $R ! -name "profile_round_*.log" -exec rm -rf {} + 2>/dev/null
+du -sh $REPO/gpurun_out
 cat $SUM/${R}_pytest_gpu.txt; cat $SUM/${R}_bench_c3.json; echo; cat $SUM/${R}_bench_c2.json; echo; ls -la $SUM
