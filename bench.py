@@ -765,8 +765,8 @@ def dry_run(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps K (default: 200 for the EM workloads c3 / c2 / c5 -- a step is under a millisecond, and a run of batches needs ~20 steps to reach its steady rate --, 20 for the others)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps W before them (default: 20 for c3 / c2 / c5, 3 for the others)")
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
                     help="strong (default): ONE batch / ONE chain sample, its loci sharded over the ranks -- BASELINE config 3, "
@@ -778,6 +778,11 @@ def main():
     ap.add_argument("--from-host", action="store_true", help="c3-front: the records start in host memory and are pushed in chunks (sbgpu_front_stream_*)")
     ap.add_argument("--no-front", action="store_true", help="default workload: leave the records -> theta leg out of the line (also SB_BENCH_NO_FRONT=1)")
     args = ap.parse_args()
+    em_workload = args.workload in ("c3", "c2", "c5")
+    if args.steps is None:
+        args.steps = 200 if em_workload else 20
+    if args.warmup is None:
+        args.warmup = 20 if em_workload else 3
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -910,10 +915,14 @@ def main():
 
     # per-kind EM kernel time: HIP events on the streams the kernels run on, averaged over a few
     # extra (untimed) steps -- reading them synchronises, so it stays out of the timed region
+    # (pipelined steps: the events of the LAST step of a short burst -- a kernel that ran, as in the timed region, beside the
+    # tail of the step before it; a step by itself would time the kernels alone on the chip)
     probe, phase_probe = [], []
     solver.set_timing(True)
     for _ in range(5):
-        quant.step()
+        for _ in range(4 if getattr(quant, "pipelined", False) else 1):
+            quant.step()
+        quant.finish()
         probe.append(solver.last_kernel_ms())
         phase_probe.append(solver.last_phase_ms())
     solver.set_timing(False)
