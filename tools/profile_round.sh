@@ -9,9 +9,9 @@ mkdir -p $SUM
 cd $REPO
 (timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -4) > $SUM/${R}_pytest_gpu.txt
 cd /tmp && export TMPDIR=/tmp
-# kernel trace + stats in their own runs; every PMC group in its own run, never with a trace domain
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3 -o em -- python3 $REPO/bench.py --no-chain --no-front --no-cpu-baseline --steps 10 > $OUT/stats_c3.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c2 -o em -- python3 $REPO/bench.py --workload c2 --no-cpu-baseline --steps 10 > $OUT/stats_c2.log 2>&1
+# kernel trace + stats in their own runs (the bench's own default command: 200 steps as a run of batches); every PMC group in its own run, never with a trace domain
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3 -o em -- python3 $REPO/bench.py --no-chain --no-front --no-cpu-baseline > $OUT/stats_c3.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c2 -o em -- python3 $REPO/bench.py --workload c2 --no-cpu-baseline > $OUT/stats_c2.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_c3 -o em -- python3 $REPO/bench.py --no-chain --no-front --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_c3 -o em -- python3 $REPO/bench.py --no-chain --no-front --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_write.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_sq_c3 -o em -- python3 $REPO/bench.py --no-chain --no-front --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_sq.log 2>&1
