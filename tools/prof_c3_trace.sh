@@ -16,8 +16,10 @@ em = [r for r in rows if "em_" in r["Kernel_Name"] or "abundance" in r["Kernel_N
 # the last 4 steps' launches: name, queue, start and end relative to the first of them
 names = [r["Kernel_Name"] for r in em]
 last = [i for i, n in enumerate(names) if "tpm" in n]
-if len(last) >= 6:
-    lo = last[-6] + 1
+import os
+back = int(os.environ.get("SB_TRACE_STEPS", "6"))
+if len(last) >= back:
+    lo = last[-back] + 1
     t0 = int(em[lo]["Start_Timestamp"])
     for r in em[lo:]:
         print("%-60s q%-3s %9.1f %9.1f  %7.1f us" % (r["Kernel_Name"][:60], r.get("Queue_Id", "?"), (int(r["Start_Timestamp"]) - t0) / 1e3,
