@@ -47,3 +47,21 @@ def test_child_failure_is_the_parents_return_code():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--workload", "nonsense"], env=_env(),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
+
+
+def test_default_step_counts_by_workload():
+    """No --steps / --warmup: the EM workloads (a step is under a millisecond, a run of batches reaches its steady rate after ~20
+    of them) time 200 steps after 20, the others 20 after 3; explicit flags -- the driver's `--steps 20 --warmup 5` -- are taken as
+    they are, and the children of `--gpus 2` get the parent's resolved numbers."""
+    def line(*args):
+        r = subprocess.run([sys.executable, BENCH, *args], env=_env(), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    out = line()
+    assert (out["steps"], out["warmup"], out["workload"]) == (200, 20, "c3")
+    out = line("--workload", "c3-chain")
+    assert (out["steps"], out["warmup"]) == (20, 3)
+    out = line("--gpus", "1", "--steps", "20", "--warmup", "5")
+    assert (out["steps"], out["warmup"]) == (20, 5)
+    out = line("--gpus", "2", "--workload", "c2")
+    assert (out["steps"], out["warmup"], out["n_gpus"]) == (200, 20, 2)
